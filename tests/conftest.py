@@ -1,0 +1,29 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    if os.environ.get("TAPER_FORCE_NO_GPU"):
+        return False
+    return os.path.exists("/dev/kfd") and any(
+        p.name.startswith("renderD") for p in Path("/dev/dri").glob("renderD*")) if os.path.exists("/dev/dri") else False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
