@@ -1,0 +1,236 @@
+/*
+ * taper_hip.h -- the drop-in boundary: C ABI of the MI355X (gfx950) backend
+ * for taper's training hot path.
+ *
+ * The reference (vaibhawvipul/taper, Rust) defines no FFI for this path; its
+ * only foreign seam is cblas_sgemm behind src/gemm.rs:32-47.  This header is
+ * the interface a Rust `extern "C"` block in the taper crate would bind (see
+ * INTEGRATION.md): the host keeps Tensor / Tape / nn::Module, every Tensor
+ * method body that today loops over Vec<f32> becomes one call below.  Each
+ * entry point cites the reference code it replaces (file:line under the
+ * reference checkout).
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; the message is
+ *    in th_last_error() (thread-local).  Nothing panics or aborts: the
+ *    reference's assert!/panic! paths map to error returns.
+ *  - pointers named d_* are DEVICE pointers (fp32 unless noted) obtained from
+ *    th_malloc (or any hipMalloc'd memory); h_* are host pointers.
+ *  - every op is enqueued on the context's HIP stream and never synchronises;
+ *    only th_ctx_sync, th_memcpy_d2h and th_event_elapsed_ms wait.
+ *  - "accumulate" (+=) outputs mirror the reference's lazily-zeroed grad
+ *    slots (src/ops.rs:124-137): the caller zero-fills on first touch.
+ *  - one th_ctx per host thread / GPU (mirrors the thread-local tape,
+ *    src/tape.rs:6-9); a ctx must not be shared between threads.
+ */
+#ifndef TAPER_HIP_H
+#define TAPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct th_ctx th_ctx;
+typedef struct th_graph th_graph;
+typedef struct th_event th_event;
+typedef struct th_comm th_comm;
+
+/* ---- runtime --------------------------------------------------------- */
+const char *th_last_error(void);
+int th_device_count(int *out);
+int th_ctx_create(int device_id, th_ctx **out);
+int th_ctx_destroy(th_ctx *ctx);
+int th_ctx_sync(th_ctx *ctx);
+/* the ctx's hipStream_t, for interop (e.g. torch.cuda.ExternalStream) */
+void *th_ctx_stream(th_ctx *ctx);
+int th_ctx_device(th_ctx *ctx);
+
+/* Stream-ordered pooled allocator: replaces the Vec<f32> every reference op
+ * allocates for its output (e.g. src/ops.rs:22, 212).  th_free returns the
+ * block to the pool; it is safe to reuse because all work is on one stream. */
+int th_malloc(th_ctx *ctx, size_t bytes, void **d_out);
+int th_free(th_ctx *ctx, void *d_ptr);
+int th_pool_stats(th_ctx *ctx, size_t *bytes_reserved, size_t *bytes_in_use);
+int th_memcpy_h2d(th_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int th_memcpy_d2h(th_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* waits */
+int th_memcpy_d2d(th_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+int th_fill_f32(th_ctx *ctx, float *d_p, float v, size_t n);
+
+/* events (hipEvent on the ctx stream) -- used by bench.py for the live
+ * kernel timing the roofline line needs */
+int th_event_create(th_event **out);
+int th_event_destroy(th_event *ev);
+int th_event_record(th_ctx *ctx, th_event *ev);
+int th_event_elapsed_ms(th_event *start, th_event *stop, float *ms_out); /* waits for stop */
+
+/* hipGraph capture of everything enqueued between begin/end on this ctx; the
+ * host tape's op list for one training step is replayed with one launch. */
+int th_graph_begin(th_ctx *ctx);
+int th_graph_end(th_ctx *ctx, th_graph **out);
+int th_graph_launch(th_ctx *ctx, th_graph *g);
+int th_graph_destroy(th_graph *g);
+
+/* ---- gemm: src/gemm.rs:8-49 / 72-119 `sgemm_rowmajor` ----------------- */
+/* C[m,n] = alpha * op(A)[m,k] * op(B)[k,n] + beta * C, row-major;
+ * lda = transA ? m : k, ldb = transB ? k : n, ldc = n (gemm.rs:21-29).
+ * beta == 0 overwrites C (never reads it).  fp32 MFMA accumulate. */
+int th_sgemm(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, float alpha,
+             const float *d_a, const float *d_b, float beta, float *d_c);
+
+/* ---- fused Linear: src/nn.rs:54-60 (transpose + matmul + add_broadcast) */
+/* Y[B,out] = X[B,in] . W[out,in]^T + b[out]  (b nullable); relu != 0 fuses
+ * activation.rs:10-12 / ops.rs:312-349 into the epilogue. */
+int th_linear_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_b, float *d_y,
+                  int batch, int in_features, int out_features, int relu);
+/* backward of the three reference nodes at once (ops.rs:238-294,
+ * tensor.rs:574-587, 674-694); any of d_dx, d_dw, d_db may be NULL (input
+ * without requires_grad: ops.rs:243).  accumulate_mask bit0/1/2 = dx/dw/db:
+ * set -> += into an existing grad; clear -> the grad slot was None, the
+ * kernel overwrites (0 + x, saving the zero-fill of ops.rs:247-249). */
+int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy,
+                  float *d_dx, float *d_dw, float *d_db, int batch, int in_features, int out_features,
+                  int accumulate_mask);
+
+/* ---- element-wise: src/ops.rs:8-120,377-496; src/tensor.rs:36-161 ----- */
+int th_add(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
+int th_sub(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
+int th_mul(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
+int th_div(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
+/* y += alpha * x : accumulate_grad (alpha=1) / accumulate_grad_scaled, ops.rs:124-151 */
+int th_axpy(th_ctx *ctx, float alpha, const float *d_x, float *d_y, size_t n);
+/* g += gout * other : Mul backward, ops.rs:81-116 */
+int th_mul_bwd(th_ctx *ctx, const float *d_gout, const float *d_other, float *d_g, size_t n);
+/* Div backward, ops.rs:466-492: ga += gout / b ; gb -= gout * a / b^2 (either NULL to skip) */
+int th_div_bwd(th_ctx *ctx, const float *d_gout, const float *d_a, const float *d_b, float *d_ga, float *d_gb, size_t n);
+/* g += d_scalar[0] / divisor (scalar broadcast): sum(None) backward (divisor 1,
+ * tensor.rs:1006-1013) and mean backward (divisor n, tensor.rs:785-796) */
+int th_add_scalar_dev(th_ctx *ctx, const float *d_scalar, float divisor, float *d_g, size_t n);
+
+int th_relu_fwd(th_ctx *ctx, const float *d_x, float *d_y, size_t n);                 /* ops.rs:312-349 */
+/* ops.rs:358-369: gin (+)= x>0 ? g : 0; accumulate=0 overwrites (grad slot was None) */
+int th_relu_bwd(th_ctx *ctx, const float *d_x, const float *d_gout, float *d_gin, size_t n, int accumulate);
+int th_sigmoid_fwd(th_ctx *ctx, const float *d_x, float *d_y, size_t n);              /* tensor.rs:594-608 */
+int th_sigmoid_bwd(th_ctx *ctx, const float *d_y, const float *d_gout, float *d_gin, size_t n); /* tensor.rs:618-629 */
+int th_exp_fwd(th_ctx *ctx, const float *d_x, float *d_y, size_t n);                  /* tensor.rs:1091-1099 */
+int th_log_fwd(th_ctx *ctx, const float *d_x, float *d_y, size_t n);                  /* tensor.rs:1136-1142 */
+int th_log_bwd(th_ctx *ctx, const float *d_x, const float *d_gout, float *d_gin, size_t n); /* tensor.rs:1151-1165 */
+int th_pow_fwd(th_ctx *ctx, const float *d_x, float e, float *d_y, size_t n);         /* tensor.rs:1172-1178 */
+int th_pow_bwd(th_ctx *ctx, const float *d_x, float e, const float *d_gout, float *d_gin, size_t n); /* tensor.rs:1188-1202 */
+
+/* ---- broadcast / reduce / layout: src/tensor.rs ---------------------- */
+int th_transpose2d(th_ctx *ctx, const float *d_in, float *d_out, int rows, int cols);      /* tensor.rs:544-566 */
+int th_transpose2d_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int rows, int cols); /* tensor.rs:574-587: gin[i,j] += gout[j,i] */
+int th_bias_add_rows(th_ctx *ctx, const float *d_x, const float *d_bias, float *d_y, int rows, int cols, int relu); /* tensor.rs:658-663 */
+int th_colsum_accum(th_ctx *ctx, const float *d_g, float *d_gb, int rows, int cols);       /* tensor.rs:686-691: gb[f] += sum_b g[b,f] */
+int th_sub_rows(th_ctx *ctx, const float *d_x, const float *d_r, float *d_y, int rows, int cols); /* tensor.rs:730-736 */
+int th_rowsum_neg_accum(th_ctx *ctx, const float *d_g, float *d_gr, int rows, int cols);   /* tensor.rs:752-764: gr[row] -= sum_c g[row,c] */
+int th_rowsum(th_ctx *ctx, const float *d_x, float *d_y, int rows, int cols);              /* tensor.rs:890-939 (2-D, dim=1) */
+int th_colsum(th_ctx *ctx, const float *d_x, float *d_y, int rows, int cols);              /* tensor.rs:890-939 (2-D, dim=0) */
+int th_rowsum_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int rows, int cols);     /* tensor.rs:949-991 (dim=1): gin[r,c] += gout[r] */
+int th_colsum_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int rows, int cols);     /* tensor.rs:949-991 (dim=0): gin[r,c] += gout[c] */
+int th_sum_all(th_ctx *ctx, const float *d_x, float *d_out1, size_t n, float divisor);     /* out = sum / divisor: tensor.rs:996-998 (1), 772-775 mean (n) */
+/* row max + first-max index (strict >, NaN never wins; index stored as f32
+ * like the reference): tensor.rs:1021-1071, 1086-1088 */
+int th_rowmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols);
+int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols);
+
+/* ---- fused softmax cross-entropy: src/loss.rs:101-195, 271-290 -------- */
+/* logits [B,C], targets [B] fp32 class ids (cast `as usize`).  Writes
+ * logp[B,C] (nullable), loss[1] = -(1/B) sum_i logp[i,t_i], argmax[B] as f32
+ * (nullable), n_correct[1] as f32 (nullable; accuracy()*B).  Out-of-range
+ * target -> the row contributes NaN to loss (the reference panics,
+ * loss.rs:161). */
+int th_softmax_xent_fwd(th_ctx *ctx, const float *d_logits, const float *d_targets, int batch, int classes,
+                        float *d_logp, float *d_loss, float *d_argmax, float *d_ncorrect);
+/* dlogits (+)= (exp(logp) - onehot) * (g0 / B), g0 read from device (the
+ * upstream scalar grad, loss.rs:174-191); accumulate=0 overwrites */
+int th_softmax_xent_bwd(th_ctx *ctx, const float *d_logp, const float *d_targets, const float *d_g0,
+                        int batch, int classes, float *d_dlogits, int accumulate);
+int th_log_softmax_fwd(th_ctx *ctx, const float *d_x, float *d_logp, int rows, int cols); /* loss.rs:101-126 */
+int th_accuracy_count(th_ctx *ctx, const float *d_argmax, const float *d_targets, int n, float *d_ncorrect); /* loss.rs:281-287 */
+
+/* ---- conv / pool: src/tensor.rs:1221-2081 ----------------------------- */
+/* Direct 3x3 stride-1 convolution, NCHW, fused bias (nullable) and ReLU.
+ * weight_layout 0 = taper's reinterpretation (tensor.rs:1262, quirk Q3):
+ *   w_eff[co][k] = w_flat[k*C_out + co], k = ci*9 + kh*3 + kw;
+ * weight_layout 1 = standard [co][ci][3][3] (tensor.rs:1329,1348).
+ * Replaces im2col (1728-1780) + matmul + reshape + transpose_4d (2034-2076)
+ * + add_bias_4d (1983-1992) (+ relu). */
+int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,
+                   int n, int c_in, int h, int w, int c_out, int pad, int weight_layout, int relu);
+/* 1x1 stride-1 pad-0 convolution as GEMM.  layout 0 = taper (raw NCHW buffer
+ * reinterpreted as [N*H*W, C], tensor.rs:1799-1801, Q4 + Q3); 1 = standard. */
+int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,
+                   int n, int c_in, int h, int w, int c_out, int weight_layout, int relu);
+/* add_bias_4d fwd/bwd: tensor.rs:1983-1992, 2017-2024 (gb[c] += sum_{n,h,w}) */
+int th_bias_add_nchw(th_ctx *ctx, const float *d_x, const float *d_bias, float *d_y, int n, int c, int hw, int relu);
+int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int c, int hw);
+/* full_backward extension (not in the reference: Q2 cuts these gradients) */
+int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx,
+                         int n, int c_in, int h, int w, int c_out, int pad, int weight_layout); /* gx += */
+int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, float *d_gw,
+                          int n, int c_in, int h, int w, int c_out, int pad, int weight_layout); /* gw += */
+
+/* max-pool: tensor.rs:1391-1521.  s_h == 0 -> stride = kernel (1403).
+ * d_argmax: int64 absolute flat input index per output (1449-1461). */
+int th_maxpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int64_t *d_argmax, int n, int c, int h, int w,
+                     int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w);
+/* zero_first=1: zero each (b,c) plane of gin before scatter-add (1496-1500, Q5) */
+int th_maxpool2d_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, float *d_gin,
+                     int n, int c, int h, int w, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w,
+                     int zero_first);
+/* avg-pool: tensor.rs:1524-1660 (divisor k_h*k_w incl. padding, Q6) */
+int th_avgpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int n, int c, int h, int w,
+                     int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w);
+int th_avgpool2d_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int n, int c, int h, int w,
+                     int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w); /* gin += */
+
+/* ---- optimizers: src/optim.rs ----------------------------------------- */
+/* Fused multi-tensor Adam over flat arenas (optim.rs:83-113).
+ * d_offsets[n_tensors+1]: element offsets of each parameter tensor (int64);
+ * d_has_grad[n_tensors]: 0 -> the tensor is skipped entirely (grad None, Q8).
+ * d_t: int32[2] ON DEVICE: [0] = step counter t, incremented by this call
+ * first (optim.rs:84) so a captured graph advances it on every replay;
+ * [1] = scratch (bits of the step size).  The bias corrections use powi
+ * (square-and-multiply) like f32::powi.
+ * d_lr[1]: learning rate on device (set_lr, optim.rs:125-127). */
+int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v,
+                 const int64_t *d_offsets, const int32_t *d_has_grad, int n_tensors, int64_t total,
+                 int32_t *d_t, const float *d_lr, float beta1, float beta2, float eps, float weight_decay);
+int th_sgd_step(th_ctx *ctx, float *d_params, const float *d_grads, const int64_t *d_offsets,
+                const int32_t *d_has_grad, int n_tensors, int64_t total, const float *d_lr); /* optim.rs:21-33 */
+
+/* ---- data: src/data/mnist.rs:277-310 get_batch ------------------------ */
+/* out_images[i,:] = images[idx[i],:], out_labels[i] = labels[idx[i]], with
+ * idx = d_indices[(*d_cursor + i) % n_indices] (int32); d_cursor (int64, on
+ * device, advanced by th_log_step) lets a captured graph walk the epoch. */
+int th_gather_batch(th_ctx *ctx, const float *d_images, const float *d_labels, const int32_t *d_indices,
+                    int64_t n_indices, const int64_t *d_cursor, int batch, int row_len,
+                    float *d_out_images, float *d_out_labels);
+/* u8 -> f32 / 255 (data/mnist.rs:224-229) */
+int th_u8_to_unit_f32(th_ctx *ctx, const uint8_t *d_in, float *d_out, size_t n);
+/* End-of-step bookkeeping kept on device so a step never synchronises
+ * (examples/train_mnist.rs:110-111,121 read loss / accuracy on the host every
+ * step): metrics[2*s] = loss[0], metrics[2*s+1] = ncorrect[0] with
+ * s = d_state[0] % capacity; then d_state[0] += 1 (step) and
+ * d_state[1] += advance (sample cursor used by th_gather_batch). */
+int th_log_step(th_ctx *ctx, const float *d_loss, const float *d_ncorrect, float *d_metrics, int64_t capacity,
+                int64_t *d_state, int64_t advance);
+
+/* ---- data parallel (new; the reference has no collective) ------------- */
+/* One process per GPU.  Rank 0 calls th_comm_unique_id and ships the 128
+ * bytes to the other ranks out of band (torch.distributed / a file / MPI). */
+int th_comm_unique_id(uint8_t out_id[128]);
+int th_comm_init_rank(th_ctx *ctx, int n_ranks, int rank, const uint8_t id[128], th_comm **out);
+int th_comm_destroy(th_comm *comm);
+/* in-place sum over ranks of d_buf[n] then * scale (1/W): grads of the flat
+ * arena between loss.backward() and optim.step() */
+int th_allreduce_sum_scale(th_comm *comm, th_ctx *ctx, float *d_buf, size_t n, float scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAPER_HIP_H */

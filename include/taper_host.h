@@ -1,0 +1,162 @@
+/*
+ * taper_host.h -- C ABI over the C++ host mirror (taper_amd/csrc/host): the
+ * Tensor / Tape / nn::Module / loss / optim / data / train surface of the
+ * reference (src/lib.rs:1-17 re-exports) as opaque handles, so that tests and
+ * bench.py (Python, ctypes) -- or any other language -- can drive exactly the
+ * code path a Rust host would.  Device work happens only through
+ * include/taper_hip.h; this layer adds no arithmetic.
+ *
+ * Every function returns 0 on success; on failure the message is in
+ * tp_last_error() (the reference panics instead: src/ops.rs:201-208 etc.).
+ * Handles are owned by the caller and released with the matching *_free.
+ */
+#ifndef TAPER_HOST_H
+#define TAPER_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tp_tensor tp_tensor;
+typedef struct tp_module tp_module;
+typedef struct tp_optim tp_optim;
+typedef struct tp_dataset tp_dataset;
+typedef struct tp_loader tp_loader;
+typedef struct tp_trainer tp_trainer;
+typedef struct tp_comm tp_comm;
+
+const char *tp_last_error(void);
+
+/* ---- device / tape (src/tape.rs) ---- */
+int tp_device_set(int device_id);
+int tp_device_sync(void);
+int tp_device_shutdown(void);
+void *tp_device_ctx(void);                 /* the th_ctx* of this thread (for mixing with taper_hip.h calls) */
+int tp_tape_reset(void);                   /* tape.rs:43-49 */
+int tp_tape_len(size_t *out);
+int tp_tape_set_compat_zero_sentinel(int on);   /* quirk Q1 */
+int tp_set_full_backward(int on);               /* quirk Q2: 0 = faithful (default) */
+
+/* ---- Tensor (src/tensor.rs:470-541) ---- */
+int tp_tensor_new(const float *h_data, const size_t *shape, int ndim, tp_tensor **out);
+int tp_tensor_randn(const size_t *shape, int ndim, uint64_t seed, tp_tensor **out);
+int tp_tensor_clone(const tp_tensor *t, tp_tensor **out);     /* Arc clone */
+int tp_tensor_free(tp_tensor *t);
+int tp_tensor_set_requires_grad(tp_tensor *t, int on);
+int tp_tensor_requires_grad(const tp_tensor *t, int *out);
+int tp_tensor_ndim(const tp_tensor *t, int *out);
+int tp_tensor_shape(const tp_tensor *t, size_t *out4);
+int tp_tensor_len(const tp_tensor *t, size_t *out);
+int tp_tensor_data(const tp_tensor *t, float *h_out);          /* D2H copy of len floats */
+int tp_tensor_set_data(tp_tensor *t, const float *h_in);
+int tp_tensor_has_grad(const tp_tensor *t, int *out);
+int tp_tensor_grad(const tp_tensor *t, float *h_out);          /* error if grad is None */
+int tp_tensor_set_grad(tp_tensor *t, const float *h_in /* NULL -> None */);
+int tp_tensor_tape_node(const tp_tensor *t, size_t *out);
+int tp_tensor_dptr(const tp_tensor *t, void **d_out);          /* device pointer of the storage */
+int tp_tensor_backward(tp_tensor *t);                          /* tensor.rs:520-529 */
+int tp_tensor_zero_grad(tp_tensor *t);                         /* tensor.rs:531-533 */
+
+/* ---- ops (src/ops.rs, src/tensor.rs); each returns a new handle ---- */
+int tp_add(const tp_tensor *a, const tp_tensor *b, tp_tensor **out);
+int tp_sub(const tp_tensor *a, const tp_tensor *b, tp_tensor **out);
+int tp_mul(const tp_tensor *a, const tp_tensor *b, tp_tensor **out);
+int tp_div(const tp_tensor *a, const tp_tensor *b, tp_tensor **out);
+int tp_matmul(const tp_tensor *a, const tp_tensor *b, tp_tensor **out);
+int tp_add_broadcast(const tp_tensor *a, const tp_tensor *b, tp_tensor **out);
+int tp_sub_broadcast_rows(const tp_tensor *a, const tp_tensor *b, tp_tensor **out);
+int tp_relu(const tp_tensor *x, tp_tensor **out);
+int tp_sigmoid(const tp_tensor *x, tp_tensor **out);
+int tp_transpose(const tp_tensor *x, tp_tensor **out);
+int tp_exp(const tp_tensor *x, tp_tensor **out);
+int tp_log(const tp_tensor *x, tp_tensor **out);
+int tp_pow(const tp_tensor *x, float e, tp_tensor **out);
+int tp_mean(const tp_tensor *x, tp_tensor **out);
+int tp_sum(const tp_tensor *x, int dim /* -1 = all */, int keepdim, tp_tensor **out);
+int tp_max(const tp_tensor *x, int dim /* -1 = all */, tp_tensor **values, tp_tensor **indices);
+int tp_reshape(const tp_tensor *x, const size_t *shape, int ndim, tp_tensor **out);
+int tp_flatten(const tp_tensor *x, int start_dim, tp_tensor **out);
+int tp_squeeze(const tp_tensor *x, int dim /* -1 = all */, tp_tensor **out);
+int tp_unsqueeze(const tp_tensor *x, int dim, tp_tensor **out);
+int tp_linear(const tp_tensor *x, const tp_tensor *w, const tp_tensor *b /* nullable */, int relu, tp_tensor **out);
+int tp_conv2d(const tp_tensor *x, const tp_tensor *w, const tp_tensor *b /* nullable */, int stride_h, int stride_w,
+              int pad_h, int pad_w, int dil_h, int dil_w, int relu, tp_tensor **out);
+int tp_max_pool2d(const tp_tensor *x, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, tp_tensor **out);
+int tp_avg_pool2d(const tp_tensor *x, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, tp_tensor **out);
+
+/* ---- loss (src/loss.rs) ---- */
+int tp_log_softmax(const tp_tensor *x, tp_tensor **out);
+int tp_softmax(const tp_tensor *x, tp_tensor **out);
+int tp_cross_entropy_loss(const tp_tensor *logits, const tp_tensor *targets, tp_tensor **out);
+int tp_accuracy(const tp_tensor *pred, const tp_tensor *targets, float *out);
+int tp_one_hot(const tp_tensor *idx, int num_classes, tp_tensor **out);
+int tp_mse_loss(const tp_tensor *pred, const tp_tensor *targets, tp_tensor **out);
+
+/* ---- nn (src/nn.rs, src/activation.rs) ---- */
+int tp_linear_new(int in_features, int out_features, int with_bias, uint64_t seed, tp_module **out);
+int tp_relu_new(tp_module **out);
+int tp_sigmoid_new(tp_module **out);
+int tp_conv2d_new(int in_ch, int out_ch, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, int with_bias,
+                  int fuse_relu, uint64_t seed, tp_module **out);
+int tp_maxpool2d_new(int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, tp_module **out);
+int tp_avgpool2d_new(int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, tp_module **out);
+int tp_adaptive_avgpool2d_new(int out_h, int out_w, tp_module **out);
+int tp_flatten_new(int start_dim, tp_module **out);
+int tp_sequential_new(tp_module *const *layers, int n, int fuse_linear_relu, tp_module **out);
+int tp_module_free(tp_module *m);
+int tp_module_forward(const tp_module *m, const tp_tensor *x, tp_tensor **out);
+int tp_module_num_parameters(const tp_module *m, int *out);
+int tp_module_parameter(const tp_module *m, int i, tp_tensor **out);   /* shares storage with the model */
+
+/* ---- optim (src/optim.rs) ---- */
+int tp_adam_new(tp_tensor *const *params, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                tp_optim **out);
+int tp_sgd_new(tp_tensor *const *params, int n, float lr, tp_optim **out);
+int tp_optim_free(tp_optim *o);
+int tp_optim_step(tp_optim *o);
+int tp_optim_zero_grad(tp_optim *o);
+int tp_adam_set_lr(tp_optim *o, float lr);
+int tp_adam_get_lr(const tp_optim *o, float *out);
+int tp_adam_t(const tp_optim *o, int *out);
+int tp_adam_moments(const tp_optim *o, float *h_m, float *h_v);  /* concatenated in parameter order */
+int tp_optim_total(const tp_optim *o, int64_t *out);             /* padded arena length (all-reduce size) */
+
+/* ---- data (src/data/mnist.rs) ---- */
+int tp_dataset_from_host(const float *h_images, const float *h_labels, size_t n, int train, tp_dataset **out);
+int tp_dataset_from_idx(const char *images_path, const char *labels_path, int train, tp_dataset **out);
+int tp_dataset_synthetic(size_t n, uint64_t seed, int train, tp_dataset **out);
+int tp_dataset_len(const tp_dataset *d, size_t *out);
+int tp_dataset_tensors(const tp_dataset *d, tp_tensor **images, tp_tensor **labels);
+int tp_dataset_free(tp_dataset *d);
+int tp_loader_new(const tp_dataset *d, size_t batch_size, int shuffle, uint64_t seed, tp_loader **out);
+int tp_loader_reset(tp_loader *l);
+int tp_loader_num_batches(const tp_loader *l, size_t *out);
+int tp_loader_next(tp_loader *l, tp_tensor **images, tp_tensor **labels, int *has_batch);
+int tp_loader_free(tp_loader *l);
+
+/* ---- data parallel (new) ---- */
+int tp_comm_unique_id(uint8_t out_id[128]);
+int tp_comm_new(int n_ranks, int rank, const uint8_t id[128], tp_comm **out);
+int tp_comm_free(tp_comm *c);
+int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n);
+
+/* ---- train (src/train.rs, examples/train_mnist*.rs) ---- */
+int tp_trainer_new(tp_module *model, tp_optim *adam, tp_trainer **out);
+int tp_trainer_set_sample_shape(tp_trainer *t, const size_t *shape, int ndim);  /* e.g. {1,28,28} for the CNN */
+int tp_trainer_set_comm(tp_trainer *t, tp_comm *c /* nullable */);
+int tp_trainer_free(tp_trainer *t);
+/* one reference-literal step (examples/train_mnist.rs:89-121); reads loss / accuracy back */
+int tp_trainer_train_step(tp_trainer *t, const tp_tensor *images, const tp_tensor *labels, float *loss, float *acc);
+/* mode 0 = eager train_epoch (train.rs:98-144), 1 = hipGraph replay, 2 = evaluate (train.rs:147-172).
+ * per_step (nullable) receives 2*num_batches floats {loss, n_correct}; max_steps 0 = whole epoch. */
+int tp_trainer_run_epoch(tp_trainer *t, tp_loader *l, int mode, size_t max_steps, float *avg_loss, float *accuracy,
+                         size_t *total_correct, size_t *total_samples, size_t *num_batches, float *per_step,
+                         size_t per_step_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAPER_HOST_H */

@@ -1,0 +1,522 @@
+"""Python face of the host mirror (include/taper_host.h): the reference's
+public surface -- src/lib.rs:1-17: Tensor, Tape, nn, loss, optim, data, train
+-- with the reference's names and argument meaning.  Every call crosses the
+C ABI into libtaper_host.so (C++), which reaches the GPU only through
+libtaper_hip.so (hand-written HIP for gfx950).  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import TaperError, host, tp_check
+
+_p = C.c_void_p
+
+
+def _shape_arr(shape):
+    return (C.c_size_t * len(shape))(*[int(s) for s in shape])
+
+
+def _new_handle():
+    return _p()
+
+
+class Device:
+    @staticmethod
+    def set_device(i: int):
+        tp_check(host.tp_device_set(int(i)), "tp_device_set")
+
+    @staticmethod
+    def sync():
+        tp_check(host.tp_device_sync(), "tp_device_sync")
+
+    @staticmethod
+    def ctx_handle() -> int:
+        h = host.tp_device_ctx()
+        if not h:
+            raise TaperError(host.tp_last_error().decode())
+        return h
+
+
+class Tape:
+    """src/tape.rs"""
+
+    @staticmethod
+    def reset():
+        tp_check(host.tp_tape_reset(), "tp_tape_reset")
+
+    @staticmethod
+    def len() -> int:
+        n = C.c_size_t()
+        tp_check(host.tp_tape_len(C.byref(n)), "tp_tape_len")
+        return n.value
+
+    @staticmethod
+    def set_compat_zero_sentinel(on: bool):
+        tp_check(host.tp_tape_set_compat_zero_sentinel(1 if on else 0), "tp_tape_set_compat_zero_sentinel")
+
+
+def set_full_backward(on: bool):
+    """False (default) = faithful to the reference (conv weights never get gradients, quirk Q2)."""
+    tp_check(host.tp_set_full_backward(1 if on else 0), "tp_set_full_backward")
+
+
+class Tensor:
+    """src/tensor.rs Tensor: a shared handle to device storage + grad slot + tape node."""
+
+    def __init__(self, data=None, shape=None, _h=None):
+        if _h is not None:
+            self._h = _h
+            return
+        a = np.ascontiguousarray(np.asarray(data, dtype=np.float32))
+        if shape is None:
+            shape = a.shape if a.ndim else (1,)
+        a = a.reshape(-1)
+        if a.size != int(np.prod(shape)):
+            raise TaperError("Tensor::new: data length does not match shape")
+        h = _p()
+        tp_check(host.tp_tensor_new(a.ctypes.data, _shape_arr(shape), len(shape), C.byref(h)), "tp_tensor_new")
+        self._h = h.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                host.tp_tensor_free(h)
+            except Exception:
+                pass
+
+    @staticmethod
+    def scalar(v):
+        return Tensor([float(v)], (1,))
+
+    @staticmethod
+    def randn(shape, seed=0):
+        h = _p()
+        tp_check(host.tp_tensor_randn(_shape_arr(shape), len(shape), int(seed), C.byref(h)), "tp_tensor_randn")
+        return Tensor(_h=h.value)
+
+    def requires_grad(self):
+        tp_check(host.tp_tensor_set_requires_grad(self._h, 1), "set_requires_grad")
+        return self
+
+    def clone(self):
+        h = _p()
+        tp_check(host.tp_tensor_clone(self._h, C.byref(h)), "tp_tensor_clone")
+        return Tensor(_h=h.value)
+
+    def shape(self):
+        nd = C.c_int()
+        tp_check(host.tp_tensor_ndim(self._h, C.byref(nd)), "tp_tensor_ndim")
+        s = (C.c_size_t * 4)()
+        tp_check(host.tp_tensor_shape(self._h, s), "tp_tensor_shape")
+        return tuple(int(s[i]) for i in range(nd.value))
+
+    def numel(self):
+        n = C.c_size_t()
+        tp_check(host.tp_tensor_len(self._h, C.byref(n)), "tp_tensor_len")
+        return n.value
+
+    def data(self) -> np.ndarray:
+        out = np.empty(self.numel(), dtype=np.float32)
+        tp_check(host.tp_tensor_data(self._h, out.ctypes.data), "tp_tensor_data")
+        return out.reshape(self.shape())
+
+    def set_data(self, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(-1)
+        assert a.size == self.numel()
+        tp_check(host.tp_tensor_set_data(self._h, a.ctypes.data), "tp_tensor_set_data")
+
+    def grad(self):
+        has = C.c_int()
+        tp_check(host.tp_tensor_has_grad(self._h, C.byref(has)), "tp_tensor_has_grad")
+        if not has.value:
+            return None
+        out = np.empty(self.numel(), dtype=np.float32)
+        tp_check(host.tp_tensor_grad(self._h, out.ctypes.data), "tp_tensor_grad")
+        return out.reshape(self.shape())
+
+    grad_ref = grad
+
+    def set_grad(self, g):
+        if g is None:
+            tp_check(host.tp_tensor_set_grad(self._h, None), "tp_tensor_set_grad")
+        else:
+            a = np.ascontiguousarray(np.asarray(g, dtype=np.float32)).reshape(-1)
+            assert a.size == self.numel()
+            tp_check(host.tp_tensor_set_grad(self._h, a.ctypes.data), "tp_tensor_set_grad")
+
+    def tape_node(self):
+        n = C.c_size_t()
+        tp_check(host.tp_tensor_tape_node(self._h, C.byref(n)), "tp_tensor_tape_node")
+        return n.value
+
+    def dptr(self) -> int:
+        p = _p()
+        tp_check(host.tp_tensor_dptr(self._h, C.byref(p)), "tp_tensor_dptr")
+        return p.value
+
+    def backward(self):
+        tp_check(host.tp_tensor_backward(self._h), "tp_tensor_backward")
+
+    def zero_grad(self):
+        tp_check(host.tp_tensor_zero_grad(self._h), "tp_tensor_zero_grad")
+
+    # -- ops ---------------------------------------------------------------
+    def _bin(self, fn, o, name):
+        h = _p()
+        tp_check(fn(self._h, o._h, C.byref(h)), name)
+        return Tensor(_h=h.value)
+
+    def _un(self, fn, name, *args):
+        h = _p()
+        tp_check(fn(self._h, *args, C.byref(h)), name)
+        return Tensor(_h=h.value)
+
+    def __add__(self, o): return self._bin(host.tp_add, o, "add")
+    def __sub__(self, o): return self._bin(host.tp_sub, o, "sub")
+    def __mul__(self, o): return self._bin(host.tp_mul, o, "mul")
+    def __truediv__(self, o): return self._bin(host.tp_div, o, "div")
+    def matmul(self, o): return self._bin(host.tp_matmul, o, "matmul")
+    def add_broadcast(self, o): return self._bin(host.tp_add_broadcast, o, "add_broadcast")
+    def sub_broadcast_rows(self, o): return self._bin(host.tp_sub_broadcast_rows, o, "sub_broadcast_rows")
+    def relu(self): return self._un(host.tp_relu, "relu")
+    def sigmoid(self): return self._un(host.tp_sigmoid, "sigmoid")
+    def transpose(self): return self._un(host.tp_transpose, "transpose")
+    def exp(self): return self._un(host.tp_exp, "exp")
+    def log(self): return self._un(host.tp_log, "log")
+    def mean(self): return self._un(host.tp_mean, "mean")
+    def pow(self, e): return self._un(host.tp_pow, "pow", float(e))
+    def sqrt(self): return self.pow(0.5)
+    def sum(self, dim=None, keepdim=False): return self._un(host.tp_sum, "sum", -1 if dim is None else int(dim), 1 if keepdim else 0)
+    def reshape(self, shape): return self._un(host.tp_reshape, "reshape", _shape_arr(shape), len(shape))
+    view = reshape
+    def flatten(self, start_dim): return self._un(host.tp_flatten, "flatten", int(start_dim))
+    def squeeze(self, dim=None): return self._un(host.tp_squeeze, "squeeze", -1 if dim is None else int(dim))
+    def unsqueeze(self, dim): return self._un(host.tp_unsqueeze, "unsqueeze", int(dim))
+
+    def max(self, dim=None):
+        v, i = _p(), _p()
+        tp_check(host.tp_max(self._h, -1 if dim is None else int(dim), C.byref(v), C.byref(i)), "max")
+        return Tensor(_h=v.value), Tensor(_h=i.value)
+
+    def argmax(self, dim=None):
+        return self.max(dim)[1]
+
+    def linear(self, weight, bias=None, relu=False):
+        return self._un(host.tp_linear, "linear", weight._h, bias._h if bias is not None else None, 1 if relu else 0)
+
+    def conv2d(self, weight, bias, stride=(1, 1), padding=(0, 0), dilation=(1, 1), relu=False):
+        return self._un(host.tp_conv2d, "conv2d", weight._h, bias._h if bias is not None else None, stride[0], stride[1],
+                        padding[0], padding[1], dilation[0], dilation[1], 1 if relu else 0)
+
+    def conv2d_relu(self, weight, bias, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
+        return self.conv2d(weight, bias, stride, padding, dilation, relu=True)
+
+    def max_pool2d(self, kernel_size, stride=None, padding=(0, 0)):
+        s = stride or (0, 0)
+        return self._un(host.tp_max_pool2d, "max_pool2d", kernel_size[0], kernel_size[1], s[0], s[1], padding[0], padding[1])
+
+    def avg_pool2d(self, kernel_size, stride=None, padding=(0, 0)):
+        s = stride or (0, 0)
+        return self._un(host.tp_avg_pool2d, "avg_pool2d", kernel_size[0], kernel_size[1], s[0], s[1], padding[0], padding[1])
+
+
+# -- src/loss.rs ------------------------------------------------------------
+def _t1(fn, name, x, *args):
+    h = _p()
+    tp_check(fn(x._h, *args, C.byref(h)), name)
+    return Tensor(_h=h.value)
+
+
+def log_softmax(x, dim=-1): return _t1(host.tp_log_softmax, "log_softmax", x)
+def softmax(x, dim=-1): return _t1(host.tp_softmax, "softmax", x)
+def cross_entropy_loss(logits, targets): return _t1(host.tp_cross_entropy_loss, "cross_entropy_loss", logits, targets._h)
+def one_hot(idx, num_classes): return _t1(host.tp_one_hot, "one_hot", idx, int(num_classes))
+def mse_loss(pred, targets): return _t1(host.tp_mse_loss, "mse_loss", pred, targets._h)
+
+
+def accuracy(pred, targets) -> float:
+    out = C.c_float()
+    tp_check(host.tp_accuracy(pred._h, targets._h, C.byref(out)), "accuracy")
+    return float(out.value)
+
+
+# -- src/nn.rs, src/activation.rs ------------------------------------------------
+class Module:
+    def __init__(self, h):
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            host.tp_module_free(h)
+
+    def forward(self, x: Tensor) -> Tensor:
+        h = _p()
+        tp_check(host.tp_module_forward(self._h, x._h, C.byref(h)), "forward")
+        return Tensor(_h=h.value)
+
+    def parameters(self):
+        n = C.c_int()
+        tp_check(host.tp_module_num_parameters(self._h, C.byref(n)), "num_parameters")
+        out = []
+        for i in range(n.value):
+            h = _p()
+            tp_check(host.tp_module_parameter(self._h, i, C.byref(h)), "parameter")
+            out.append(Tensor(_h=h.value))
+        return out
+
+
+def _mk(fn, name, *args):
+    h = _p()
+    tp_check(fn(*args, C.byref(h)), name)
+    return h.value
+
+
+class Linear(Module):
+    def __init__(self, in_features, out_features, with_bias=True, seed=1):
+        super().__init__(_mk(host.tp_linear_new, "Linear::new", int(in_features), int(out_features), 1 if with_bias else 0, int(seed)))
+
+    @property
+    def weight(self): return self.parameters()[0]
+
+    @property
+    def bias(self):
+        p = self.parameters()
+        return p[1] if len(p) > 1 else None
+
+
+class ReLU(Module):
+    def __init__(self): super().__init__(_mk(host.tp_relu_new, "ReLU"))
+
+
+class Sigmoid(Module):
+    def __init__(self): super().__init__(_mk(host.tp_sigmoid_new, "Sigmoid"))
+
+
+class Conv2d(Module):
+    def __init__(self, in_ch, out_ch, kernel_size, stride=None, padding=None, dilation=None, groups=None, bias=True,
+                 seed=1, _relu=False):
+        if dilation not in (None, (1, 1)) or groups not in (None, 1):
+            raise TaperError("Conv2d: dilation/groups are out of scope (SURVEY.md section 2 row 8)")
+        s, p = stride or (1, 1), padding or (0, 0)
+        super().__init__(_mk(host.tp_conv2d_new, "Conv2d::new", int(in_ch), int(out_ch), kernel_size[0], kernel_size[1],
+                             s[0], s[1], p[0], p[1], 1 if bias else 0, 1 if _relu else 0, int(seed)))
+
+
+class Conv2dReLU(Conv2d):
+    def __init__(self, in_ch, out_ch, kernel_size, stride=None, padding=None, dilation=None, groups=None, bias=True, seed=1):
+        super().__init__(in_ch, out_ch, kernel_size, stride, padding, dilation, groups, bias, seed, _relu=True)
+
+
+class MaxPool2d(Module):
+    def __init__(self, kernel_size, stride=None, padding=None):
+        s, p = stride or (0, 0), padding or (0, 0)
+        super().__init__(_mk(host.tp_maxpool2d_new, "MaxPool2d::new", kernel_size[0], kernel_size[1], s[0], s[1], p[0], p[1]))
+
+
+class AvgPool2d(Module):
+    def __init__(self, kernel_size, stride=None, padding=None):
+        s, p = stride or (0, 0), padding or (0, 0)
+        super().__init__(_mk(host.tp_avgpool2d_new, "AvgPool2d::new", kernel_size[0], kernel_size[1], s[0], s[1], p[0], p[1]))
+
+
+class AdaptiveAvgPool2d(Module):
+    def __init__(self, output_size):
+        super().__init__(_mk(host.tp_adaptive_avgpool2d_new, "AdaptiveAvgPool2d::new", output_size[0], output_size[1]))
+
+    @staticmethod
+    def global_():
+        return AdaptiveAvgPool2d((1, 1))
+
+
+class Flatten(Module):
+    def __init__(self, start_dim=1):
+        super().__init__(_mk(host.tp_flatten_new, "Flatten::new", int(start_dim)))
+
+
+class Sequential(Module):
+    def __init__(self, layers, fuse=True):
+        self.layers = list(layers)  # keep the children alive
+        arr = (_p * len(self.layers))(*[l._h for l in self.layers])
+        super().__init__(_mk(host.tp_sequential_new, "Sequential::new", arr, len(self.layers), 1 if fuse else 0))
+
+
+# -- src/optim.rs -----------------------------------------------------------------
+class _Optim:
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            host.tp_optim_free(h)
+
+    def step(self): tp_check(host.tp_optim_step(self._h), "Optimizer::step")
+    def zero_grad(self): tp_check(host.tp_optim_zero_grad(self._h), "Optimizer::zero_grad")
+
+    def total(self) -> int:
+        n = C.c_int64()
+        tp_check(host.tp_optim_total(self._h, C.byref(n)), "tp_optim_total")
+        return n.value
+
+
+class Adam(_Optim):
+    def __init__(self, params, lr, betas=None, eps=None, weight_decay=None):
+        betas = betas or (0.9, 0.999)
+        self.params = list(params)
+        arr = (_p * len(self.params))(*[p._h for p in self.params])
+        self._h = _mk(host.tp_adam_new, "Adam::new", arr, len(self.params), float(lr), float(betas[0]), float(betas[1]),
+                      float(1e-8 if eps is None else eps), float(0.0 if weight_decay is None else weight_decay))
+
+    def set_lr(self, lr): tp_check(host.tp_adam_set_lr(self._h, float(lr)), "Adam::set_lr")
+
+    def get_lr(self):
+        v = C.c_float()
+        tp_check(host.tp_adam_get_lr(self._h, C.byref(v)), "Adam::get_lr")
+        return float(v.value)
+
+    def t(self):
+        v = C.c_int()
+        tp_check(host.tp_adam_t(self._h, C.byref(v)), "Adam::t")
+        return v.value
+
+    def moments(self):
+        n = sum(p.numel() for p in self.params)
+        m, v = np.empty(n, np.float32), np.empty(n, np.float32)
+        tp_check(host.tp_adam_moments(self._h, m.ctypes.data, v.ctypes.data), "Adam::moments")
+        return m, v
+
+
+class SGD(_Optim):
+    def __init__(self, params, lr, momentum=None):
+        self.params = list(params)
+        arr = (_p * len(self.params))(*[p._h for p in self.params])
+        self._h = _mk(host.tp_sgd_new, "SGD::new", arr, len(self.params), float(lr))
+
+
+# -- src/data/mnist.rs --------------------------------------------------------------
+class MNISTDataset:
+    def __init__(self, h):
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            host.tp_dataset_free(h)
+
+    @staticmethod
+    def from_host(images, labels, train=True):
+        im = np.ascontiguousarray(images, dtype=np.float32).reshape(-1, 784)
+        lb = np.ascontiguousarray(labels, dtype=np.float32).reshape(-1)
+        return MNISTDataset(_mk(host.tp_dataset_from_host, "MNISTDataset::from_host", im.ctypes.data, lb.ctypes.data, lb.size, 1 if train else 0))
+
+    @staticmethod
+    def from_idx(images_path, labels_path, train=True):
+        return MNISTDataset(_mk(host.tp_dataset_from_idx, "MNISTDataset::from_idx", str(images_path).encode(), str(labels_path).encode(), 1 if train else 0))
+
+    @staticmethod
+    def synthetic(n, seed=0x7461706572, train=True):
+        return MNISTDataset(_mk(host.tp_dataset_synthetic, "MNISTDataset::synthetic", int(n), int(seed), 1 if train else 0))
+
+    def len(self):
+        n = C.c_size_t()
+        tp_check(host.tp_dataset_len(self._h, C.byref(n)), "len")
+        return n.value
+
+    def tensors(self):
+        a, b = _p(), _p()
+        tp_check(host.tp_dataset_tensors(self._h, C.byref(a), C.byref(b)), "tensors")
+        return Tensor(_h=a.value), Tensor(_h=b.value)
+
+
+class DataLoader:
+    def __init__(self, dataset, batch_size, shuffle, seed=0x7461706572):
+        self.dataset = dataset
+        self._h = _mk(host.tp_loader_new, "DataLoader::new", dataset._h, int(batch_size), 1 if shuffle else 0, int(seed))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            host.tp_loader_free(h)
+
+    def reset(self): tp_check(host.tp_loader_reset(self._h), "DataLoader::reset")
+
+    def num_batches(self):
+        n = C.c_size_t()
+        tp_check(host.tp_loader_num_batches(self._h, C.byref(n)), "num_batches")
+        return n.value
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        a, b, has = _p(), _p(), C.c_int()
+        tp_check(host.tp_loader_next(self._h, C.byref(a), C.byref(b), C.byref(has)), "DataLoader::next")
+        if not has.value:
+            raise StopIteration
+        return Tensor(_h=a.value), Tensor(_h=b.value)
+
+
+# -- data parallel --------------------------------------------------------------------
+class Communicator:
+    """RCCL communicator, one process per GPU; the 128-byte id travels out of band."""
+
+    def __init__(self, n_ranks, rank, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self.n_ranks, self.rank = n_ranks, rank
+        self._h = _mk(host.tp_comm_new, "Communicator::new", int(n_ranks), int(rank), buf)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            host.tp_comm_free(h)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        tp_check(host.tp_comm_unique_id(buf), "Communicator::unique_id")
+        return bytes(buf)
+
+    def allreduce_mean(self, d_ptr: int, n: int):
+        tp_check(host.tp_comm_allreduce_mean(self._h, d_ptr, int(n)), "allreduce_mean")
+
+
+# -- src/train.rs ---------------------------------------------------------------------
+class Trainer:
+    """train.rs:74-172 + the captured-graph epoch driver."""
+
+    EAGER, GRAPH, EVAL = 0, 1, 2
+
+    def __init__(self, model: Module, optimizer: Adam, sample_shape=None, comm: Communicator | None = None):
+        self.model, self.optimizer, self.comm = model, optimizer, comm
+        self._h = _mk(host.tp_trainer_new, "Trainer::new", model._h, optimizer._h)
+        if sample_shape:
+            tp_check(host.tp_trainer_set_sample_shape(self._h, _shape_arr(sample_shape), len(sample_shape)), "set_sample_shape")
+        if comm is not None:
+            tp_check(host.tp_trainer_set_comm(self._h, comm._h), "set_comm")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            host.tp_trainer_free(h)
+
+    def train_step(self, images: Tensor, labels: Tensor):
+        loss, acc = C.c_float(), C.c_float()
+        tp_check(host.tp_trainer_train_step(self._h, images._h, labels._h, C.byref(loss), C.byref(acc)), "train_step")
+        return float(loss.value), float(acc.value)
+
+    def run_epoch(self, loader: DataLoader, mode=GRAPH, max_steps=0):
+        nb_max = loader.num_batches()
+        per = np.zeros(2 * nb_max, dtype=np.float32)
+        avg, acc = C.c_float(), C.c_float()
+        tc, ts, nb = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        tp_check(host.tp_trainer_run_epoch(self._h, loader._h, int(mode), int(max_steps), C.byref(avg), C.byref(acc), C.byref(tc),
+                                           C.byref(ts), C.byref(nb), per.ctypes.data, per.size), "run_epoch")
+        per = per[: 2 * nb.value].reshape(-1, 2)
+        return dict(avg_loss=float(avg.value), accuracy=float(acc.value), total_correct=tc.value, total_samples=ts.value,
+                    num_batches=nb.value, losses=per[:, 0].copy(), ncorrect=per[:, 1].copy())
+
+    def train_epoch(self, loader): return self.run_epoch(loader, self.EAGER)
+    def train_epoch_graph(self, loader, max_steps=0): return self.run_epoch(loader, self.GRAPH, max_steps)
+    def evaluate(self, loader): return self.run_epoch(loader, self.EVAL)

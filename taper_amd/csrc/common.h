@@ -1,0 +1,80 @@
+// common.h -- shared internals of libtaper_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/taper_hip.h"
+
+namespace th {
+
+void set_error(const char *fmt, ...);
+
+#define TH_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            th::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+
+#define TH_REQUIRE(cond, ...)              \
+    do {                                   \
+        if (!(cond)) {                     \
+            th::set_error(__VA_ARGS__);    \
+            return 2;                      \
+        }                                  \
+    } while (0)
+
+// launch check: kernel launches are asynchronous; this catches bad configs.
+#define TH_LAUNCH_CHECK() TH_HIP(hipGetLastError())
+
+constexpr int kWave = 64;       // gfx950 wavefront
+constexpr int kNumCU = 256;     // MI355X
+constexpr int kNumXCD = 8;
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Memory-bound grid: cap at 8 blocks/CU and grid-stride the rest.
+static inline int ew_grid(size_t n_items, int block) {
+    long g = (long)((n_items + block - 1) / block);
+    long cap = (long)kNumCU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace th
+
+struct th_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // pooled allocator state
+    std::multimap<size_t, void *> free_blocks;        // size -> block
+    std::unordered_map<void *, size_t> block_size;    // every block we own
+    std::unordered_set<void *> graph_owned;           // blocks pinned by a live graph
+    std::unordered_set<void *> graph_owned_freed;     // ...that the host has already th_free'd
+    size_t bytes_reserved = 0, bytes_in_use = 0;
+    // capture state
+    bool capturing = false;
+    std::vector<void *> capture_blocks;               // allocated during the current capture
+    std::multimap<size_t, void *> capture_free;       // freed again during the capture
+};
+
+struct th_graph {
+    th_ctx *ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<void *> blocks;                       // memory the captured kernels reference
+};
+
+struct th_event {
+    hipEvent_t ev = nullptr;
+};

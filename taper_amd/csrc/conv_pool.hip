@@ -1,0 +1,540 @@
+// conv_pool.hip -- direct 3x3 convolution, 1x1 convolution, max/avg pooling
+// and the NCHW bias kernels (src/tensor.rs:1221-2081).
+//
+// conv3x3: VALU direct convolution (north_star: "conv2d direct-3x3 ... LDS-
+// staged tiles"; MFMA is reserved for the dense GEMMs).  One workgroup owns
+// IMG images x 16 output channels; the input planes (+1-pixel halo) of 8
+// input channels at a time are staged in LDS; each thread keeps PX pixels x
+// 16 channels of accumulators in registers; the weights are re-laid-out once
+// per call into [ci][kh][kw][co] so that every weight read in the inner loop
+// is wave-uniform and is served by scalar loads (s_load_dwordx*), leaving the
+// LDS pipe to the input taps only.  The im2col buffer of the reference (up to
+// 231 MB at batch 256) is never materialised.
+#include "common.h"
+
+namespace th {
+
+constexpr int CO_T = 16;  // output channels per thread
+constexpr int CI_T = 8;   // input channels staged per LDS pass
+
+// w_t[((ci*3 + kh)*3 + kw) * co_pad + co] = w_eff[co][ci][kh][kw]
+// layout 0 (taper, tensor.rs:1262): w_eff[co][k] = w[k * c_out + co], k = ci*9 + kh*3 + kw
+// layout 1 (standard, tensor.rs:1329): w_eff[co][k] = w[co * c_in*9 + k]
+// flip != 0 builds the bwd-input filter: roles of ci/co swapped, taps mirrored.
+__global__ __launch_bounds__(256) void conv3x3_prep_weights(const float *__restrict__ w, float *__restrict__ w_t, int c_in,
+                                                            int c_out, int layout, int flip, int out_ch, int out_ch_pad,
+                                                            int in_ch) {
+    // output filter has `in_ch` input channels and `out_ch` output channels
+    const int total = in_ch * 9 * out_ch_pad;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int oc = i % out_ch_pad, tap = (i / out_ch_pad) % 9, ic = i / (out_ch_pad * 9);
+        float v = 0.f;
+        if (oc < out_ch) {
+            int co, ci, kh = tap / 3, kw = tap % 3;
+            if (!flip) {
+                co = oc; ci = ic;
+            } else {  // gx[ci] = sum_co gy[co] * w_eff[co][ci][2-kh][2-kw]
+                co = ic; ci = oc; kh = 2 - kh; kw = 2 - kw;
+            }
+            const int k = ci * 9 + kh * 3 + kw;
+            v = layout == 0 ? w[(long)k * c_out + co] : w[(long)co * c_in * 9 + k];
+        }
+        w_t[i] = v;
+    }
+}
+
+// grid = (ceil(n / IMG), out_ch_pad / 16); block = 256.
+// Thread item -> (image in group, output row, column group of PX pixels).
+template <int PX, bool ACCUM>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const float *__restrict__ x, const float *__restrict__ w_t,
+                                                      const float *__restrict__ bias, float *__restrict__ y, int n, int c_in,
+                                                      int h, int w, int c_out, int co_pad, int pad, int h_out, int w_out,
+                                                      int img_per_wg, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [img][CI_T][h+2][w+2 (+pad to even)]
+    const int hp = h + 2, wp = w + 2;     // LDS plane always carries a 1-px halo; pad==0 just shifts the window
+    const int plane = hp * wp;
+    const int groups_per_row = (w_out + PX - 1) / PX;
+    const int items_per_img = h_out * groups_per_row;
+    const int items = img_per_wg * items_per_img;
+    const int img0 = blockIdx.x * img_per_wg;
+    const int co0 = blockIdx.y * CO_T;
+    const int shift = 1 - pad;            // pad=1: window starts at halo; pad=0: starts one pixel in
+
+    for (int item0 = 0; item0 < items; item0 += 256) {
+        const int item = item0 + threadIdx.x;
+        const bool active = item < items;
+        const int li = active ? item / items_per_img : 0;
+        const int rem = active ? item % items_per_img : 0;
+        const int oh = rem / groups_per_row, ow0 = (rem % groups_per_row) * PX;
+        const int img = img0 + li;
+        const bool img_ok = active && img < n;
+
+        float acc[PX][CO_T];
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j) acc[p][j] = 0.f;
+
+        for (int cb = 0; cb < c_in; cb += CI_T) {
+            const int nci = min(CI_T, c_in - cb);
+            __syncthreads();  // previous pass done with xs
+            // stage: zero halo + interior copy, coalesced over the padded plane
+            const int stage_total = img_per_wg * nci * plane;
+            for (int s = threadIdx.x; s < stage_total; s += 256) {
+                const int si = s / (nci * plane), r1 = s % (nci * plane);
+                const int sc = r1 / plane, sp = r1 % plane;
+                const int sy = sp / wp - 1, sx = sp % wp - 1;
+                const int gi = img0 + si;
+                float v = 0.f;
+                if (gi < n && sy >= 0 && sy < h && sx >= 0 && sx < w)
+                    v = x[(((long)gi * c_in + cb + sc) * h + sy) * w + sx];
+                xs[(si * CI_T + sc) * plane + sp] = v;
+            }
+            __syncthreads();
+            if (active) {
+                for (int c = 0; c < nci; ++c) {
+                    const float *xp = xs + (li * CI_T + c) * plane;
+                    const float *wc = w_t + (long)(cb + c) * 9 * co_pad + co0;  // wave-uniform
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        float in[PX + 2];
+                        const float *row = xp + (oh + kh + shift) * wp + ow0 + shift;
+#pragma unroll
+                        for (int q = 0; q < PX + 2; ++q) in[q] = (ow0 + q < w_out + 2) ? row[q] : 0.f;
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float *wk = wc + (kh * 3 + kw) * co_pad;
+#pragma unroll
+                            for (int j = 0; j < CO_T; ++j) {
+                                const float wv = wk[j];
+#pragma unroll
+                                for (int p = 0; p < PX; ++p) acc[p][j] = fmaf(in[p + kw], wv, acc[p][j]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        if (img_ok) {
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j) {
+                const int co = co0 + j;
+                if (co >= c_out) break;
+                const float bv = bias ? bias[co] : 0.f;
+                float *yp = y + (((long)img * c_out + co) * h_out + oh) * w_out + ow0;
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    if (ow0 + p < w_out) {
+                        float v = acc[p][j] + bv;
+                        if (relu) v = v > 0.f ? v : 0.f;
+                        if (ACCUM) yp[p] += v;
+                        else yp[p] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// gw_eff[co][ci][kh][kw] += sum_{n,h,w} x[n,ci,h+kh-pad,w+kw-pad] * gy[n,co,h,w]
+// One workgroup per (co, ci) pair; 256 threads stride over n*h_out*w_out;
+// 9 block reductions.  Written back through the weight layout map.
+__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                 float *__restrict__ gw, int n, int c_in, int h, int w,
+                                                                 int c_out, int pad, int h_out, int w_out, int layout) {
+    __shared__ float sh[9][4];
+    const int co = blockIdx.x, ci = blockIdx.y;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    const int osp = h_out * w_out;
+    const long total = (long)n * osp;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int img = (int)(i / osp), p = (int)(i % osp);
+        const int oh = p / w_out, ow = p % w_out;
+        const float g = gy[((long)img * c_out + co) * osp + p];
+        const float *xp = x + ((long)img * c_in + ci) * h * w;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh + kh - pad;
+            if (ih < 0 || ih >= h) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow + kw - pad;
+                if (iw < 0 || iw >= w) continue;
+                acc[kh * 3 + kw] = fmaf(xp[ih * w + iw], g, acc[kh * 3 + kw]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) sh[t][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int t = threadIdx.x;
+        const float tot = ((sh[t][0] + sh[t][1]) + sh[t][2]) + sh[t][3];
+        const int k = ci * 9 + t;
+        const long idx = layout == 0 ? (long)k * c_out + co : (long)co * c_in * 9 + k;
+        gw[idx] += tot;
+    }
+}
+
+// ---- NCHW bias (tensor.rs:1983-1992, 2017-2024) ---------------------------
+__global__ __launch_bounds__(256) void bias_add_nchw_kernel(const float *__restrict__ x, const float *__restrict__ bias,
+                                                            float *__restrict__ y, long total, int c, int hw, int relu) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float v = x[i] + bias[(i / hw) % c];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__restrict__ g, float *__restrict__ gb, int n, int c,
+                                                             int hw) {
+    __shared__ float sh[4];
+    const int ch = blockIdx.x;
+    float s = 0.f;
+    const long total = (long)n * hw;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const long b = i / hw, sp = i % hw;
+        s += g[(b * c + ch) * hw + sp];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) gb[ch] += ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// tmp[n][p][co] -> y[n][co][p] + bias[co] (+relu): the reshape + transpose_4d
+// (tensor.rs:1275-1276, 2034-2076) + add_bias_4d of the 1x1 path
+__global__ __launch_bounds__(256) void nhwc_to_nchw_bias_kernel(const float *__restrict__ t, const float *__restrict__ bias,
+                                                                float *__restrict__ y, int hw, int c, int relu) {
+    __shared__ float tile[64][65];
+    const int img = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int p0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const float *tin = t + (long)img * hw * c;
+    float *yout = y + (long)img * hw * c;
+    for (int r = ty; r < 64; r += 4) {
+        const int p = p0 + r, cc = c0 + tx;
+        tile[r][tx] = (p < hw && cc < c) ? tin[(long)p * c + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int cc = c0 + r, p = p0 + tx;
+        if (cc < c && p < hw) {
+            float v = tile[tx][r] + (bias ? bias[cc] : 0.f);
+            if (relu) v = v > 0.f ? v : 0.f;
+            yout[(long)cc * hw + p] = v;
+        }
+    }
+}
+
+// ---- pooling --------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                          int64_t *__restrict__ argmax, long total, int h, int w, int h_out,
+                                                          int w_out, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w) {
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int ow = (int)(o % w_out), oh = (int)((o / w_out) % h_out);
+        const long bc = o / ((long)w_out * h_out);
+        const long in_base = bc * h * w;
+        float best = -INFINITY;      // tensor.rs:1431
+        long best_idx = in_base;     // tensor.rs:1432 "any valid default"
+        for (int kh = 0; kh < k_h; ++kh) {          // kh outer, kw inner (1435-1455)
+            const int ihp = oh * s_h + kh;
+            if (ihp < pad_h || ihp >= h + pad_h) continue;
+            for (int kw = 0; kw < k_w; ++kw) {
+                const int iwp = ow * s_w + kw;
+                if (iwp < pad_w || iwp >= w + pad_w) continue;
+                const long idx = in_base + (long)(ihp - pad_h) * w + (iwp - pad_w);
+                const float v = x[idx];
+                if (v > best) {  // strict: first max wins, NaN never wins
+                    best = v;
+                    best_idx = idx;
+                }
+            }
+        }
+        y[o] = best;
+        if (argmax) argmax[o] = best_idx;
+    }
+}
+
+// Gather form of the scatter-add of tensor.rs:1504-1514: every input pixel
+// walks the windows that can contain it in (oh, ow) ascending order -- the same
+// order the reference's sequential `for o in 0..out_spatial` adds them, so
+// the result is bit-identical, with no atomics.  (A pixel whose padded
+// coordinate lies outside a window can never be that window's argmax, except
+// the `best_idx = in_base` default of an all-NaN/-inf window, which points at
+// pixel (0,0): that window is the one covering (0,0) or contributes there.)
+__global__ __launch_bounds__(256) void maxpool_bwd_geo_kernel(const float *__restrict__ gout, const int64_t *__restrict__ argmax,
+                                                              float *__restrict__ gin, long total, int h, int w, int h_out,
+                                                              int w_out, int k_h, int k_w, int s_h, int s_w, int pad_h,
+                                                              int pad_w, int zero_first) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int iw = (int)(i % w), ih = (int)((i / w) % h);
+        const long bc = i / ((long)h * w);
+        const long obase = bc * h_out * w_out;
+        float v = zero_first ? 0.f : gin[i];
+        const int ihp = ih + pad_h, iwp = iw + pad_w;
+        const int oh_lo = ihp >= k_h ? (ihp - k_h) / s_h + 1 : 0, oh_hi = min(h_out - 1, ihp / s_h);
+        const int ow_lo = iwp >= k_w ? (iwp - k_w) / s_w + 1 : 0, ow_hi = min(w_out - 1, iwp / s_w);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const long o = obase + (long)oh * w_out + ow;
+                if (argmax[o] == i) v += gout[o];
+            }
+        gin[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long total, int h,
+                                                          int w, int h_out, int w_out, int k_h, int k_w, int s_h, int s_w,
+                                                          int pad_h, int pad_w) {
+    const float pool_size = (float)(k_h * k_w);  // tensor.rs:1548 (Q6)
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int ow = (int)(o % w_out), oh = (int)((o / w_out) % h_out);
+        const long in_base = (o / ((long)w_out * h_out)) * h * w;
+        float sum = 0.f;
+        for (int kh = 0; kh < k_h; ++kh) {
+            const int ihp = oh * s_h + kh;
+            if (ihp < pad_h || ihp >= h + pad_h) continue;
+            for (int kw = 0; kw < k_w; ++kw) {
+                const int iwp = ow * s_w + kw;
+                if (iwp < pad_w || iwp >= w + pad_w) continue;
+                sum += x[in_base + (long)(ihp - pad_h) * w + (iwp - pad_w)];
+            }
+        }
+        y[o] = sum / pool_size;
+    }
+}
+
+// one wave per (b,c) plane when the window is the whole plane (global pool)
+__global__ __launch_bounds__(256) void avgpool_global_kernel(const float *__restrict__ x, float *__restrict__ y, long planes,
+                                                             int hw, float pool_size) {
+    const int lane = threadIdx.x & 63;
+    const long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pl >= planes) return;
+    float s = 0.f;
+    for (int i = lane; i < hw; i += 64) s += x[pl * hw + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) y[pl] = s / pool_size;
+}
+
+// gather form of tensor.rs:1624-1653, (oh, ow) ascending like the reference
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float *__restrict__ gout, float *__restrict__ gin, long total,
+                                                          int h, int w, int h_out, int w_out, int k_h, int k_w, int s_h,
+                                                          int s_w, int pad_h, int pad_w) {
+    const float pool_size = (float)(k_h * k_w);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int iw = (int)(i % w), ih = (int)((i / w) % h);
+        const long obase = (i / ((long)h * w)) * h_out * w_out;
+        const int ihp = ih + pad_h, iwp = iw + pad_w;
+        const int oh_lo = ihp >= k_h ? (ihp - k_h) / s_h + 1 : 0, oh_hi = min(h_out - 1, ihp / s_h);
+        const int ow_lo = iwp >= k_w ? (iwp - k_w) / s_w + 1 : 0, ow_hi = min(w_out - 1, iwp / s_w);
+        float v = gin[i];
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) v += gout[obase + (long)oh * w_out + ow] / pool_size;
+        gin[i] = v;
+    }
+}
+
+static int conv3x3_launch(th_ctx *ctx, const float *x, const float *w_t, const float *bias, float *y, int n, int in_ch, int h,
+                          int w, int out_ch, int co_pad, int pad, int relu, bool accum) {
+    const int h_out = h + 2 * pad - 2, w_out = w + 2 * pad - 2;
+    const int px = (w_out % 4 == 0) ? 4 : ((w_out % 2 == 0) ? 2 : 1);
+    const int items_per_img = h_out * ((w_out + px - 1) / px);
+    int img_per_wg = 256 / items_per_img;
+    if (img_per_wg < 1) img_per_wg = 1;
+    if (img_per_wg > n) img_per_wg = n;
+    const int plane = (h + 2) * (w + 2);
+    // keep the LDS tile <= 64 KiB so two workgroups share a CU
+    while (img_per_wg > 1 && (size_t)img_per_wg * CI_T * plane * sizeof(float) > (64u << 10)) --img_per_wg;
+    const size_t lds = (size_t)img_per_wg * CI_T * plane * sizeof(float);
+    TH_REQUIRE(lds <= (160u << 10), "th_conv3x3: %dx%d plane does not fit the LDS tile", h, w);
+    dim3 grid(ceil_div(n, img_per_wg), co_pad / CO_T);
+#define TH_CONV_LAUNCH(PXV, ACC)                                                                                      \
+    {                                                                                                                 \
+        auto kern = conv3x3_kernel<PXV, ACC>;                                                                         \
+        if (lds > (64u << 10))                                                                                        \
+            TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, x, w_t, bias, y, n, in_ch, h, w, out_ch, co_pad,  \
+                           pad, h_out, w_out, img_per_wg, relu);                                                      \
+    }
+    if (!accum) {
+        if (px == 4) TH_CONV_LAUNCH(4, false) else if (px == 2) TH_CONV_LAUNCH(2, false) else TH_CONV_LAUNCH(1, false)
+    } else {
+        if (px == 4) TH_CONV_LAUNCH(4, true) else if (px == 2) TH_CONV_LAUNCH(2, true) else TH_CONV_LAUNCH(1, true)
+    }
+#undef TH_CONV_LAUNCH
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" {
+
+int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y, int n, int c_in, int h,
+                   int w, int c_out, int pad, int weight_layout, int relu) {
+    TH_REQUIRE(ctx && d_x && d_w && d_y, "th_conv3x3_fwd: null argument");
+    TH_REQUIRE(n > 0 && c_in > 0 && c_out > 0 && h + 2 * pad >= 3 && w + 2 * pad >= 3, "th_conv3x3_fwd: bad geometry");
+    TH_REQUIRE(pad == 0 || pad == 1, "th_conv3x3_fwd: pad must be 0 or 1 (got %d)", pad);
+    TH_REQUIRE(weight_layout == 0 || weight_layout == 1, "th_conv3x3_fwd: weight_layout must be 0 (taper) or 1 (standard)");
+    const int co_pad = (c_out + CO_T - 1) / CO_T * CO_T;
+    void *wt = nullptr;
+    if (th_malloc(ctx, (size_t)c_in * 9 * co_pad * sizeof(float), &wt)) return 1;
+    hipLaunchKernelGGL(conv3x3_prep_weights, dim3(ew_grid((size_t)c_in * 9 * co_pad, 256)), dim3(256), 0, ctx->stream, d_w,
+                       (float *)wt, c_in, c_out, weight_layout, 0, c_out, co_pad, c_in);
+    TH_LAUNCH_CHECK();
+    if (int rc = conv3x3_launch(ctx, d_x, (const float *)wt, d_bias, d_y, n, c_in, h, w, c_out, co_pad, pad, relu, false)) return rc;
+    return th_free(ctx, wt);
+}
+
+int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx, int n, int c_in, int h, int w,
+                         int c_out, int pad, int weight_layout) {
+    TH_REQUIRE(ctx && d_gy && d_w && d_gx, "th_conv3x3_bwd_input: null argument");
+    TH_REQUIRE(pad == 1, "th_conv3x3_bwd_input: only pad=1 (same-size) convolutions are supported");
+    // gx = conv3x3(gy, mirrored filter with ci/co swapped), pad 1, accumulated
+    const int ci_pad = (c_in + CO_T - 1) / CO_T * CO_T;
+    void *wt = nullptr;
+    if (th_malloc(ctx, (size_t)c_out * 9 * ci_pad * sizeof(float), &wt)) return 1;
+    hipLaunchKernelGGL(conv3x3_prep_weights, dim3(ew_grid((size_t)c_out * 9 * ci_pad, 256)), dim3(256), 0, ctx->stream, d_w,
+                       (float *)wt, c_in, c_out, weight_layout, 1, c_in, ci_pad, c_out);
+    TH_LAUNCH_CHECK();
+    if (int rc = conv3x3_launch(ctx, d_gy, (const float *)wt, nullptr, d_gx, n, c_out, h, w, c_in, ci_pad, 1, 0, true)) return rc;
+    return th_free(ctx, wt);
+}
+
+int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, float *d_gw, int n, int c_in, int h, int w,
+                          int c_out, int pad, int weight_layout) {
+    TH_REQUIRE(ctx && d_x && d_gy && d_gw, "th_conv3x3_bwd_weight: null argument");
+    TH_REQUIRE(pad == 0 || pad == 1, "th_conv3x3_bwd_weight: pad must be 0 or 1");
+    const int h_out = h + 2 * pad - 2, w_out = w + 2 * pad - 2;
+    hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(c_out, c_in), dim3(256), 0, ctx->stream, d_x, d_gy, d_gw, n, c_in, h, w,
+                       c_out, pad, h_out, w_out, weight_layout);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y, int n, int c_in, int h,
+                   int w, int c_out, int weight_layout, int relu) {
+    TH_REQUIRE(ctx && d_x && d_w && d_y, "th_conv1x1_fwd: null argument");
+    const int hw = h * w;
+    if (weight_layout == 0) {
+        // taper: col = raw NCHW buffer viewed [N*H*W, C_in] (tensor.rs:1799-1801, Q4);
+        // w viewed [C_in, C_out] (tensor.rs:1262, Q3); out2d = col . w2d -> NHWC -> NCHW (+bias)
+        void *tmp = nullptr;
+        if (th_malloc(ctx, (size_t)n * hw * c_out * sizeof(float), &tmp)) return 1;
+        if (int rc = th_sgemm(ctx, 0, 0, n * hw, c_out, c_in, 1.0f, d_x, d_w, 0.0f, (float *)tmp)) return rc;
+        hipLaunchKernelGGL(nhwc_to_nchw_bias_kernel, dim3(ceil_div(c_out, 64), ceil_div(hw, 64), n), dim3(256), 0, ctx->stream,
+                           (const float *)tmp, d_bias, d_y, hw, c_out, relu);
+        TH_LAUNCH_CHECK();
+        return th_free(ctx, tmp);
+    }
+    // standard: Y_n[C_out, HW] = W[C_out, C_in] . X_n[C_in, HW] per image
+    for (int i = 0; i < n; ++i) {
+        if (int rc = th_sgemm(ctx, 0, 0, c_out, hw, c_in, 1.0f, d_w, d_x + (size_t)i * c_in * hw, 0.0f,
+                              d_y + (size_t)i * c_out * hw))
+            return rc;
+    }
+    if (d_bias || relu) {
+        const long total = (long)n * c_out * hw;
+        if (d_bias) {
+            hipLaunchKernelGGL(bias_add_nchw_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, (const float *)d_y,
+                               d_bias, d_y, total, c_out, hw, relu);
+            TH_LAUNCH_CHECK();
+        } else {
+            return th_relu_fwd(ctx, d_y, d_y, (size_t)total);
+        }
+    }
+    return 0;
+}
+
+int th_bias_add_nchw(th_ctx *ctx, const float *d_x, const float *d_bias, float *d_y, int n, int c, int hw, int relu) {
+    TH_REQUIRE(ctx && d_x && d_bias && d_y, "th_bias_add_nchw: null argument");
+    const long total = (long)n * c * hw;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(bias_add_nchw_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_bias, d_y, total, c, hw, relu);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int c, int hw) {
+    TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
+    if (c == 0) return 0;
+    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_gb, n, c, hw);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_maxpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int64_t *d_argmax, int n, int c, int h, int w, int k_h, int k_w,
+                     int s_h, int s_w, int pad_h, int pad_w) {
+    TH_REQUIRE(ctx && d_x && d_y, "th_maxpool2d_fwd: null argument");
+    if (s_h == 0) { s_h = k_h; s_w = k_w; }
+    TH_REQUIRE(k_h > 0 && k_w > 0 && s_h > 0 && s_w > 0 && h + 2 * pad_h >= k_h && w + 2 * pad_w >= k_w, "th_maxpool2d_fwd: bad geometry");
+    const int h_out = (h + 2 * pad_h - k_h) / s_h + 1, w_out = (w + 2 * pad_w - k_w) / s_w + 1;
+    const long total = (long)n * c * h_out * w_out;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_y, d_argmax, total, h, w,
+                       h_out, w_out, k_h, k_w, s_h, s_w, pad_h, pad_w);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_maxpool2d_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, float *d_gin, int n, int c, int h, int w,
+                     int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, int zero_first) {
+    TH_REQUIRE(ctx && d_gout && d_argmax && d_gin, "th_maxpool2d_bwd: null argument");
+    if (s_h == 0) { s_h = k_h; s_w = k_w; }
+    TH_REQUIRE(k_h > 0 && k_w > 0 && s_h > 0 && s_w > 0, "th_maxpool2d_bwd: bad geometry");
+    const int h_out = (h + 2 * pad_h - k_h) / s_h + 1, w_out = (w + 2 * pad_w - k_w) / s_w + 1;
+    const long total = (long)n * c * h * w;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(maxpool_bwd_geo_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_gout, d_argmax, d_gin,
+                       total, h, w, h_out, w_out, k_h, k_w, s_h, s_w, pad_h, pad_w, zero_first);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_avgpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int n, int c, int h, int w, int k_h, int k_w, int s_h, int s_w,
+                     int pad_h, int pad_w) {
+    TH_REQUIRE(ctx && d_x && d_y, "th_avgpool2d_fwd: null argument");
+    if (s_h == 0) { s_h = k_h; s_w = k_w; }
+    TH_REQUIRE(k_h > 0 && k_w > 0 && s_h > 0 && s_w > 0 && h + 2 * pad_h >= k_h && w + 2 * pad_w >= k_w, "th_avgpool2d_fwd: bad geometry");
+    const int h_out = (h + 2 * pad_h - k_h) / s_h + 1, w_out = (w + 2 * pad_w - k_w) / s_w + 1;
+    const long total = (long)n * c * h_out * w_out;
+    if (total == 0) return 0;
+    if (k_h == h && k_w == w && pad_h == 0 && pad_w == 0) {  // global pool: one wave per plane
+        hipLaunchKernelGGL(avgpool_global_kernel, dim3(ceil_div((long)n * c, 4)), dim3(256), 0, ctx->stream, d_x, d_y, (long)n * c,
+                           h * w, (float)(k_h * k_w));
+    } else {
+        hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_y, total, h, w, h_out,
+                           w_out, k_h, k_w, s_h, s_w, pad_h, pad_w);
+    }
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_avgpool2d_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int n, int c, int h, int w, int k_h, int k_w, int s_h,
+                     int s_w, int pad_h, int pad_w) {
+    TH_REQUIRE(ctx && d_gout && d_gin, "th_avgpool2d_bwd: null argument");
+    if (s_h == 0) { s_h = k_h; s_w = k_w; }
+    const int h_out = (h + 2 * pad_h - k_h) / s_h + 1, w_out = (w + 2 * pad_w - k_w) / s_w + 1;
+    const long total = (long)n * c * h * w;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_gout, d_gin, total, h, w, h_out,
+                       w_out, k_h, k_w, s_h, s_w, pad_h, pad_w);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,413 @@
+// gemm.hip -- fp32 MFMA sgemm for gfx950: th_sgemm (src/gemm.rs semantics),
+// th_linear_fwd / th_linear_bwd (src/nn.rs:54-60 and its three tape nodes).
+//
+// Two kernels:
+//  * sgemm_tile128: 128x128x32 macro-tile, 4 waves x (2x2) v_mfma_f32_32x32x2_f32,
+//    LDS double-buffered with register prefetch, XCD-aware tile order.  Bound:
+//    MFMA fp32 peak (157.3 TF).  Used when the output has >= 64 macro-tiles.
+//  * sgemm_small16: 16x16 output tile per workgroup, 4 waves split K between
+//    them (v_mfma_f32_16x16x4_f32, operands straight from L2, no LDS staging),
+//    optional grid-level split-K with a deterministic second-pass reduce.
+//    For the latency-bound MNIST-MLP shapes (64x128x784, 128x784x64, ...).
+// Operands are described by (row stride, col stride) so NN / NT / TN / TT all
+// run the same code: "KC" = k-contiguous in memory, "MC" = m/n-contiguous.
+#include "common.h"
+
+namespace th {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct Epilogue {
+    float alpha, beta;
+    const float *bias;  // per output column (n), nullable
+    int relu;
+};
+
+__device__ __forceinline__ float epilogue_apply(float acc, float c_old, const Epilogue &ep, int col) {
+    float v = ep.alpha * acc;
+    if (ep.beta != 0.0f) v += ep.beta * c_old;
+    if (ep.bias) v += ep.bias[col];
+    if (ep.relu) v = v > 0.0f ? v : 0.0f;
+    return v;
+}
+
+// ------------------------------------------------------------------------
+// small / latency-bound kernel
+// ------------------------------------------------------------------------
+// grid = (tiles_n, tiles_m, kz); block = 256 (4 waves).  Wave w of slice z
+// covers k in [z*kslice + w*kwave, ...).  Lane l: r = l & 15 (row of A /
+// col of B), g = l >> 4 (which 4-wide k group).  In MFMA step s the lane
+// supplies k = kk + 4*g + s for BOTH operands, so every k is used once.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void sgemm_small16(const float *__restrict__ A, const float *__restrict__ B,
+                                                     float *__restrict__ C, float *__restrict__ partial,
+                                                     int m, int n, int k, long a_rs, long a_cs, long b_rs, long b_cs,
+                                                     int kslice, int a_vec, int b_vec, Epilogue ep) {
+    __shared__ float red[3][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
+    const int kbeg_slice = blockIdx.z * kslice;
+    const int kend_slice = min(k, kbeg_slice + kslice);
+    // split the slice between the 4 waves in multiples of 16
+    const int kwave = ((kend_slice - kbeg_slice + 63) / 64) * 16;
+    const int kbeg = kbeg_slice + wave * kwave;
+    const int kend = min(kend_slice, kbeg + kwave);
+
+    const int arow = row0 + r, bcol = col0 + r;
+    const bool a_ok = arow < m, b_ok = bcol < n;
+    const float *ap = A + (long)(a_ok ? arow : 0) * a_rs;
+    const float *bp = B + (long)(b_ok ? bcol : 0) * b_cs;
+
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = kbeg; kk < kend; kk += 16) {
+        const int kb = kk + g * 4;
+        float av[4], bv[4];
+        if (A_KC && a_vec && kb + 4 <= kend) {
+            float4 t = *reinterpret_cast<const float4 *>(ap + kb);
+            av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) av[s] = (kb + s < kend) ? ap[(long)(kb + s) * a_cs] : 0.f;
+        }
+        if (B_KC && b_vec && kb + 4 <= kend) {
+            float4 t = *reinterpret_cast<const float4 *>(bp + kb);
+            bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bv[s] = (kb + s < kend) ? bp[(long)(kb + s) * b_rs] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a = a_ok ? av[s] : 0.f;
+            const float b = b_ok ? bv[s] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+    }
+
+    // deterministic in-workgroup reduction: wave 0 adds waves 1,2,3 in order
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave - 1][lane][i] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += red[w][lane][i];
+        // C/D map of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + i
+        const int col = col0 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + (lane >> 4) * 4 + i;
+            if (row < m && col < n) {
+                const long idx = (long)row * n + col;
+                if (partial) {
+                    partial[(long)blockIdx.z * m * n + idx] = acc[i];
+                } else {
+                    const float c_old = ep.beta != 0.0f ? C[idx] : 0.0f;
+                    C[idx] = epilogue_apply(acc[i], c_old, ep, col);
+                }
+            }
+        }
+    }
+}
+
+// second pass of grid-level split-K: fixed slice order -> deterministic
+__global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ partial, float *__restrict__ C,
+                                                     long mn, int n, int kz, Epilogue ep) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mn) return;
+    float s = 0.f;
+    for (int z = 0; z < kz; ++z) s += partial[(long)z * mn + i];
+    const float c_old = ep.beta != 0.0f ? C[i] : 0.0f;
+    C[i] = epilogue_apply(s, c_old, ep, (int)(i % n));
+}
+
+// ------------------------------------------------------------------------
+// 128x128x32 MFMA kernel
+// ------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD_KC = BK + 1;   // [mn][k] image, odd stride: conflict-free ds_read_b32 / ds_write_b32
+constexpr int LD_MC = BM;       // [k][mn] image
+constexpr int TILE_KC = BM * LD_KC;
+constexpr int TILE_MC = BK * LD_MC;
+constexpr int TILE_MAX = TILE_KC > TILE_MC ? TILE_KC : TILE_MC;
+
+// Each thread stages 16 floats per operand per tile, as 4 float4.
+// KC source: the tile is [128 rows][32 k]; float4 along k: 8 per row ->
+//   thread t handles rows (t / 8) + 32*j, k quad (t % 8).
+// MC source: the tile is [32 k][128 mn]; float4 along mn: 32 per k row ->
+//   thread t handles k rows (t / 32) + 8*j, mn quad (t % 32).
+template <bool KC, bool GUARD>
+__device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_mn, long rs_k, int mn0, int k0,
+                                          int mn_lim, int k_lim, int t, float4 (&reg)[4]) {
+    // element (mn, k) lives at P[mn * rs_mn + k * rs_k]; exactly one stride is 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (KC) {
+            const int mn = mn0 + (t >> 3) + 32 * j, kq = k0 + (t & 7) * 4;
+            const float *p = P + (long)mn * rs_mn + kq;
+            if (!GUARD) {
+                reg[j] = *reinterpret_cast<const float4 *>(p);
+            } else {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (mn < mn_lim && kq + e < k_lim) ? p[e] : 0.f;
+                reg[j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            const int kr = k0 + (t >> 5) + 8 * j, mq = mn0 + (t & 31) * 4;
+            const float *p = P + (long)kr * rs_k + mq;
+            if (!GUARD) {
+                reg[j] = *reinterpret_cast<const float4 *>(p);
+            } else {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (kr < k_lim && mq + e < mn_lim) ? p[e] : 0.f;
+                reg[j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float *__restrict__ S, int t, const float4 (&reg)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (KC) {
+            float *s = S + ((t >> 3) + 32 * j) * LD_KC + (t & 7) * 4;
+            s[0] = reg[j].x; s[1] = reg[j].y; s[2] = reg[j].z; s[3] = reg[j].w;
+        } else {
+            float *s = S + ((t >> 5) + 8 * j) * LD_MC + (t & 31) * 4;
+            *reinterpret_cast<float4 *>(s) = reg[j];
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ float frag(const float *__restrict__ S, int mn, int kx) {
+    return KC ? S[mn * LD_KC + kx] : S[kx * LD_MC + mn];
+}
+
+template <bool A_KC, bool B_KC, bool GUARD>
+__global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict__ A, const float *__restrict__ B,
+                                                        float *__restrict__ C, int m, int n, int k,
+                                                        long a_rs, long a_cs, long b_rs, long b_cs,
+                                                        int tiles_m, int tiles_n, Epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS: As[2] then Bs[2], TILE_MAX floats each
+
+    // XCD-aware order: block b runs on XCD b % 8, so give each XCD a
+    // contiguous chunk of the tile list (neighbouring tiles share A/B panels
+    // in that XCD's L2).  Bijective for any grid size.
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid % kNumXCD, q = nwg / kNumXCD, rmd = nwg % kNumXCD;
+    const int tile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + bid / kNumXCD;
+    // within the chunk walk column-major in groups of 8 rows for panel reuse
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;  // wave's 64x64 sub-tile
+    const int li = lane & 31, lk = lane >> 5;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[4], rb[4];
+    const int nt = (k + BK - 1) / BK;
+    // element (i,k) of op(A) at A[i*a_rs + k*a_cs]; (k,j) of op(B) at B[k*b_rs + j*b_cs]
+    load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, 0, m, k, t, ra);
+    load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, 0, n, k, t, rb);
+    store_tile<A_KC>(smem, t, ra);
+    store_tile<B_KC>(smem + 2 * TILE_MAX, t, rb);
+    __syncthreads();
+
+    for (int it = 0; it < nt; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nt) {
+            load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, (it + 1) * BK, m, k, t, ra);
+            load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, (it + 1) * BK, n, k, t, rb);
+        }
+        const float *as = smem + cur * TILE_MAX, *bs = smem + (2 + cur) * TILE_MAX;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = frag<A_KC>(as, wm + li, kk + lk);
+            const float a1 = frag<A_KC>(as, wm + 32 + li, kk + lk);
+            const float b0 = frag<B_KC>(bs, wn + li, kk + lk);
+            const float b1 = frag<B_KC>(bs, wn + 32 + li, kk + lk);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (it + 1 < nt) {
+            store_tile<A_KC>(smem + (cur ^ 1) * TILE_MAX, t, ra);
+            store_tile<B_KC>(smem + (2 + (cur ^ 1)) * TILE_MAX, t, rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of 32x32x2: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wn + 32 * j + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (!GUARD || (row < m && col < n)) {
+                    const long idx = (long)row * n + col;
+                    const float c_old = ep.beta != 0.0f ? C[idx] : 0.0f;
+                    C[idx] = epilogue_apply(acc[i][j][e], c_old, ep, col);
+                }
+            }
+        }
+}
+
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+template <bool A_KC, bool B_KC>
+static int launch_small(th_ctx *ctx, const float *A, const float *B, float *C, int m, int n, int k, long a_rs, long a_cs,
+                        long b_rs, long b_cs, const Epilogue &ep) {
+    const int tiles_m = ceil_div(m, 16), tiles_n = ceil_div(n, 16);
+    const long tiles = (long)tiles_m * tiles_n;
+    // grid-level split-K only when the tile grid cannot fill the chip and K is deep
+    int kz = 1;
+    if (tiles < 256 && k >= 512) {
+        kz = (int)((512 + tiles - 1) / tiles);
+        const int kz_max = k / 128;  // >= 128 k per slice (32 per wave)
+        if (kz > kz_max) kz = kz_max;
+        if (kz < 1) kz = 1;
+    }
+    int kslice = ceil_div(k, kz);
+    kslice = (kslice + 15) / 16 * 16;
+    kz = ceil_div(k, kslice);
+    // float4 operand loads need 16-B aligned rows and slice starts
+    const int a_vec = A_KC && aligned16(A) && (a_rs % 4 == 0);
+    const int b_vec = B_KC && aligned16(B) && (b_cs % 4 == 0);
+    float *partial = nullptr;
+    if (kz > 1) {
+        void *p = nullptr;
+        if (th_malloc(ctx, (size_t)kz * m * n * sizeof(float), &p)) return 1;
+        partial = (float *)p;
+    }
+    hipLaunchKernelGGL((sgemm_small16<A_KC, B_KC>), dim3(tiles_n, tiles_m, kz), dim3(256), 0, ctx->stream, A, B, C,
+                       partial, m, n, k, a_rs, a_cs, b_rs, b_cs, kslice, a_vec, b_vec, ep);
+    TH_LAUNCH_CHECK();
+    if (kz > 1) {
+        const long mn = (long)m * n;
+        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, ctx->stream, partial, C, mn, n, kz, ep);
+        TH_LAUNCH_CHECK();
+        if (th_free(ctx, partial)) return 1;
+    }
+    return 0;
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C, int m, int n, int k, long a_rs,
+                          long a_cs, long b_rs, long b_cs, const Epilogue &ep) {
+    const int tiles_m = ceil_div(m, BM), tiles_n = ceil_div(n, BN);
+    const size_t lds = 4 * TILE_MAX * sizeof(float);
+    const long lda = A_KC ? a_rs : a_cs, ldb = B_KC ? b_cs : b_rs;
+    const bool exact = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && aligned16(A) && aligned16(B) &&
+                       (lda % 4 == 0) && (ldb % 4 == 0);
+    if (exact) {
+        auto kern = sgemm_tile128<A_KC, B_KC, false>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
+                           b_rs, b_cs, tiles_m, tiles_n, ep);
+    } else {
+        auto kern = sgemm_tile128<A_KC, B_KC, true>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
+                           b_rs, b_cs, tiles_m, tiles_n, ep);
+    }
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+// op(A)[i,k] = A[i*a_rs + k*a_cs], op(B)[k,j] = B[k*b_rs + j*b_cs]
+int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, const float *A, const float *B, float *C,
+                  const Epilogue &ep) {
+    if (m == 0 || n == 0) return 0;
+    const long a_rs = trans_a ? 1 : k, a_cs = trans_a ? m : 1;  // gemm.rs:88-92
+    const long b_rs = trans_b ? 1 : n, b_cs = trans_b ? k : 1;  // gemm.rs:93-97
+    const bool a_kc = !trans_a, b_kc = trans_b != 0;
+    const long tiles128 = (long)ceil_div(m, BM) * ceil_div(n, BN);
+    const bool big = m >= BM && n >= BN && k >= BK && tiles128 >= 64;
+#define TH_GEMM_CASE(AK, BKC)                                                                               \
+    if (a_kc == AK && b_kc == BKC)                                                                          \
+        return big ? launch_tile128<AK, BKC>(ctx, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, ep)             \
+                   : launch_small<AK, BKC>(ctx, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, ep);
+    TH_GEMM_CASE(true, true)
+    TH_GEMM_CASE(true, false)
+    TH_GEMM_CASE(false, true)
+    TH_GEMM_CASE(false, false)
+#undef TH_GEMM_CASE
+    return 3;
+}
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" {
+
+int th_sgemm(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, float alpha, const float *d_a,
+             const float *d_b, float beta, float *d_c) {
+    TH_REQUIRE(ctx, "th_sgemm: null ctx");
+    TH_REQUIRE(m >= 0 && n >= 0 && k >= 0, "th_sgemm: negative dimension");
+    TH_REQUIRE((m == 0 || n == 0) || (d_c && (k == 0 || (d_a && d_b))), "th_sgemm: null device pointer");
+    Epilogue ep{alpha, beta, nullptr, 0};
+    return gemm_dispatch(ctx, trans_a, trans_b, m, n, k, d_a, d_b, d_c, ep);
+}
+
+int th_linear_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_b, float *d_y, int batch,
+                  int in_features, int out_features, int relu) {
+    TH_REQUIRE(ctx && d_x && d_w && d_y, "th_linear_fwd: null argument");
+    // Y = X . W^T: op(B) = W^T with W stored [out, in]  ->  trans_b
+    Epilogue ep{1.0f, 0.0f, d_b, relu};
+    return gemm_dispatch(ctx, 0, 1, batch, out_features, in_features, d_x, d_w, d_y, ep);
+}
+
+int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, float *d_dx, float *d_dw,
+                  float *d_db, int batch, int in_features, int out_features, int accumulate_mask) {
+    TH_REQUIRE(ctx && d_dy, "th_linear_bwd: null argument");
+    if (d_dx) {  // dX[B,in] (+)= dY[B,out] . W[out,in]      (ops.rs:254-265 through the W^T node)
+        TH_REQUIRE(d_w, "th_linear_bwd: d_w required for d_dx");
+        Epilogue ep{1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f, nullptr, 0};
+        if (int rc = gemm_dispatch(ctx, 0, 0, batch, in_features, out_features, d_dy, d_w, d_dx, ep)) return rc;
+    }
+    if (d_dw) {  // dW[out,in] (+)= dY^T[out,B] . X[B,in]     (ops.rs:280-291 + tensor.rs:574-587)
+        TH_REQUIRE(d_x, "th_linear_bwd: d_x required for d_dw");
+        Epilogue ep{1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f, nullptr, 0};
+        if (int rc = gemm_dispatch(ctx, 1, 0, out_features, in_features, batch, d_dy, d_x, d_dw, ep)) return rc;
+    }
+    if (d_db) {  // db[out] (+)= sum_b dY[b,out]               (tensor.rs:686-691)
+        if (int rc = (accumulate_mask & 4) ? th_colsum_accum(ctx, d_dy, d_db, batch, out_features)
+                                           : th_colsum(ctx, d_dy, d_db, batch, out_features))
+            return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+// capi.cpp -- include/taper_host.h: opaque-handle C ABI over the C++ host.
+#include <cstring>
+
+#include "../../../include/taper_host.h"
+#include "taper.h"
+
+using namespace taper;
+
+struct tp_tensor { Tensor t; };
+struct tp_module { std::shared_ptr<Module> m; };
+struct tp_optim { std::shared_ptr<Optimizer> o; std::shared_ptr<Adam> adam; };
+struct tp_dataset { MNISTDataset d; };
+struct tp_loader { std::unique_ptr<DataLoader> l; };
+struct tp_trainer { std::unique_ptr<Trainer> t; };
+struct tp_comm { std::shared_ptr<Communicator> c; };
+
+static thread_local std::string g_err;
+
+#define TP_BEGIN try {
+#define TP_END                              \
+    return 0;                               \
+    }                                       \
+    catch (const std::exception &e) {       \
+        g_err = e.what();                   \
+        return 1;                           \
+    }                                       \
+    catch (...) {                           \
+        g_err = "unknown exception";        \
+        return 1;                           \
+    }
+
+static tp_tensor *wrap(const Tensor &t) { return new tp_tensor{t}; }
+static Shape mkshape(const size_t *s, int nd) { return Shape(s, s + nd); }
+static const Tensor &opt_t(const tp_tensor *t) {
+    static const Tensor none;
+    return t ? t->t : none;
+}
+
+extern "C" {
+
+const char *tp_last_error(void) { return g_err.c_str(); }
+
+int tp_device_set(int id) { TP_BEGIN Device::set_device(id); TP_END }
+int tp_device_sync(void) { TP_BEGIN Device::sync(); TP_END }
+int tp_device_shutdown(void) { TP_BEGIN Device::shutdown(); TP_END }
+void *tp_device_ctx(void) {
+    try { return Device::ctx(); } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+int tp_tape_reset(void) { TP_BEGIN Tape::reset(); TP_END }
+int tp_tape_len(size_t *out) { TP_BEGIN *out = Tape::len(); TP_END }
+int tp_tape_set_compat_zero_sentinel(int on) { TP_BEGIN Tape::set_compat_zero_sentinel(on != 0); TP_END }
+int tp_set_full_backward(int on) { TP_BEGIN set_full_backward(on != 0); TP_END }
+
+int tp_tensor_new(const float *h, const size_t *shape, int nd, tp_tensor **out) {
+    TP_BEGIN
+    Shape s = mkshape(shape, nd);
+    *out = wrap(Tensor(std::vector<float>(h, h + numel(s)), s));
+    TP_END
+}
+int tp_tensor_randn(const size_t *shape, int nd, uint64_t seed, tp_tensor **out) { TP_BEGIN *out = wrap(Tensor::randn(mkshape(shape, nd), seed)); TP_END }
+int tp_tensor_clone(const tp_tensor *t, tp_tensor **out) { TP_BEGIN *out = wrap(t->t); TP_END }
+int tp_tensor_free(tp_tensor *t) { TP_BEGIN delete t; TP_END }
+int tp_tensor_set_requires_grad(tp_tensor *t, int on) { TP_BEGIN t->t.set_requires_grad(on != 0); TP_END }
+int tp_tensor_requires_grad(const tp_tensor *t, int *out) { TP_BEGIN *out = t->t.get_requires_grad(); TP_END }
+int tp_tensor_ndim(const tp_tensor *t, int *out) { TP_BEGIN *out = (int)t->t.shape().size(); TP_END }
+int tp_tensor_shape(const tp_tensor *t, size_t *out4) {
+    TP_BEGIN
+    for (size_t i = 0; i < t->t.shape().size(); ++i) out4[i] = t->t.shape()[i];
+    TP_END
+}
+int tp_tensor_len(const tp_tensor *t, size_t *out) { TP_BEGIN *out = t->t.len(); TP_END }
+int tp_tensor_data(const tp_tensor *t, float *h_out) {
+    TP_BEGIN
+    auto v = t->t.data();
+    std::memcpy(h_out, v.data(), v.size() * sizeof(float));
+    TP_END
+}
+int tp_tensor_set_data(tp_tensor *t, const float *h_in) { TP_BEGIN t->t.set_data(std::vector<float>(h_in, h_in + t->t.len())); TP_END }
+int tp_tensor_has_grad(const tp_tensor *t, int *out) { TP_BEGIN *out = t->t.has_grad(); TP_END }
+int tp_tensor_grad(const tp_tensor *t, float *h_out) {
+    TP_BEGIN
+    TAPER_ASSERT(t->t.has_grad(), "grad is None");
+    auto v = t->t.grad();
+    std::memcpy(h_out, v.data(), v.size() * sizeof(float));
+    TP_END
+}
+int tp_tensor_set_grad(tp_tensor *t, const float *h_in) {
+    TP_BEGIN
+    if (!h_in) t->t.zero_grad();
+    else t->t.set_grad(std::vector<float>(h_in, h_in + t->t.len()));
+    TP_END
+}
+int tp_tensor_tape_node(const tp_tensor *t, size_t *out) { TP_BEGIN *out = t->t.tape_node(); TP_END }
+int tp_tensor_dptr(const tp_tensor *t, void **d_out) { TP_BEGIN *d_out = t->t.dptr(); TP_END }
+int tp_tensor_backward(tp_tensor *t) { TP_BEGIN t->t.backward(); TP_END }
+int tp_tensor_zero_grad(tp_tensor *t) { TP_BEGIN t->t.zero_grad(); TP_END }
+
+#define TP_BIN(name, expr) \
+    int name(const tp_tensor *a, const tp_tensor *b, tp_tensor **out) { TP_BEGIN *out = wrap(expr); TP_END }
+TP_BIN(tp_add, a->t + b->t)
+TP_BIN(tp_sub, a->t - b->t)
+TP_BIN(tp_mul, a->t * b->t)
+TP_BIN(tp_div, a->t / b->t)
+TP_BIN(tp_matmul, a->t.matmul(b->t))
+TP_BIN(tp_add_broadcast, a->t.add_broadcast(b->t))
+TP_BIN(tp_sub_broadcast_rows, a->t.sub_broadcast_rows(b->t))
+#define TP_UN(name, expr) \
+    int name(const tp_tensor *x, tp_tensor **out) { TP_BEGIN *out = wrap(expr); TP_END }
+TP_UN(tp_relu, x->t.relu())
+TP_UN(tp_sigmoid, x->t.sigmoid())
+TP_UN(tp_transpose, x->t.transpose())
+TP_UN(tp_exp, x->t.exp())
+TP_UN(tp_log, x->t.log())
+TP_UN(tp_mean, x->t.mean())
+TP_UN(tp_log_softmax, log_softmax(x->t))
+TP_UN(tp_softmax, softmax(x->t))
+int tp_pow(const tp_tensor *x, float e, tp_tensor **out) { TP_BEGIN *out = wrap(x->t.pow(e)); TP_END }
+int tp_sum(const tp_tensor *x, int dim, int keepdim, tp_tensor **out) { TP_BEGIN *out = wrap(x->t.sum(dim, keepdim != 0)); TP_END }
+int tp_max(const tp_tensor *x, int dim, tp_tensor **values, tp_tensor **indices) {
+    TP_BEGIN
+    auto r = x->t.max(dim);
+    if (values) *values = wrap(r.first);
+    if (indices) *indices = wrap(r.second);
+    TP_END
+}
+int tp_reshape(const tp_tensor *x, const size_t *shape, int nd, tp_tensor **out) { TP_BEGIN *out = wrap(x->t.reshape(mkshape(shape, nd))); TP_END }
+int tp_flatten(const tp_tensor *x, int sd, tp_tensor **out) { TP_BEGIN *out = wrap(x->t.flatten((size_t)sd)); TP_END }
+int tp_squeeze(const tp_tensor *x, int dim, tp_tensor **out) { TP_BEGIN *out = wrap(x->t.squeeze(dim)); TP_END }
+int tp_unsqueeze(const tp_tensor *x, int dim, tp_tensor **out) { TP_BEGIN *out = wrap(x->t.unsqueeze((size_t)dim)); TP_END }
+int tp_linear(const tp_tensor *x, const tp_tensor *w, const tp_tensor *b, int relu, tp_tensor **out) {
+    TP_BEGIN *out = wrap(x->t.linear(w->t, opt_t(b), relu != 0)); TP_END
+}
+int tp_conv2d(const tp_tensor *x, const tp_tensor *w, const tp_tensor *b, int sh, int sw, int ph, int pw, int dh, int dw, int relu,
+              tp_tensor **out) {
+    TP_BEGIN *out = wrap(x->t.conv2d(w->t, opt_t(b), {sh, sw}, {ph, pw}, {dh, dw}, relu != 0)); TP_END
+}
+int tp_max_pool2d(const tp_tensor *x, int kh, int kw, int sh, int sw, int ph, int pw, tp_tensor **out) {
+    TP_BEGIN *out = wrap(x->t.max_pool2d({kh, kw}, {sh, sw}, {ph, pw})); TP_END
+}
+int tp_avg_pool2d(const tp_tensor *x, int kh, int kw, int sh, int sw, int ph, int pw, tp_tensor **out) {
+    TP_BEGIN *out = wrap(x->t.avg_pool2d({kh, kw}, {sh, sw}, {ph, pw})); TP_END
+}
+
+int tp_cross_entropy_loss(const tp_tensor *lg, const tp_tensor *tg, tp_tensor **out) { TP_BEGIN *out = wrap(cross_entropy_loss(lg->t, tg->t)); TP_END }
+int tp_accuracy(const tp_tensor *p, const tp_tensor *tg, float *out) { TP_BEGIN *out = accuracy(p->t, tg->t); TP_END }
+int tp_one_hot(const tp_tensor *idx, int nc, tp_tensor **out) { TP_BEGIN *out = wrap(one_hot(idx->t, (size_t)nc)); TP_END }
+int tp_mse_loss(const tp_tensor *p, const tp_tensor *tg, tp_tensor **out) { TP_BEGIN *out = wrap(mse_loss(p->t, tg->t)); TP_END }
+
+int tp_linear_new(int in_f, int out_f, int bias, uint64_t seed, tp_module **out) {
+    TP_BEGIN *out = new tp_module{std::make_shared<Linear>((size_t)in_f, (size_t)out_f, bias != 0, seed)}; TP_END
+}
+int tp_relu_new(tp_module **out) { TP_BEGIN *out = new tp_module{std::make_shared<ReLU>()}; TP_END }
+int tp_sigmoid_new(tp_module **out) { TP_BEGIN *out = new tp_module{std::make_shared<Sigmoid>()}; TP_END }
+int tp_conv2d_new(int ic, int oc, int kh, int kw, int sh, int sw, int ph, int pw, int bias, int relu, uint64_t seed, tp_module **out) {
+    TP_BEGIN
+    auto c = std::make_shared<Conv2d>((size_t)ic, (size_t)oc, std::make_pair(kh, kw), std::make_pair(sh, sw), std::make_pair(ph, pw),
+                                      bias != 0, seed);
+    c->fuse_relu = relu != 0;
+    *out = new tp_module{c};
+    TP_END
+}
+int tp_maxpool2d_new(int kh, int kw, int sh, int sw, int ph, int pw, tp_module **out) {
+    TP_BEGIN *out = new tp_module{std::make_shared<MaxPool2d>(std::make_pair(kh, kw), std::make_pair(sh, sw), std::make_pair(ph, pw))}; TP_END
+}
+int tp_avgpool2d_new(int kh, int kw, int sh, int sw, int ph, int pw, tp_module **out) {
+    TP_BEGIN *out = new tp_module{std::make_shared<AvgPool2d>(std::make_pair(kh, kw), std::make_pair(sh, sw), std::make_pair(ph, pw))}; TP_END
+}
+int tp_adaptive_avgpool2d_new(int oh, int ow, tp_module **out) { TP_BEGIN *out = new tp_module{std::make_shared<AdaptiveAvgPool2d>(std::make_pair(oh, ow))}; TP_END }
+int tp_flatten_new(int sd, tp_module **out) { TP_BEGIN *out = new tp_module{std::make_shared<Flatten>((size_t)sd)}; TP_END }
+int tp_sequential_new(tp_module *const *layers, int n, int fuse, tp_module **out) {
+    TP_BEGIN
+    std::vector<std::shared_ptr<Module>> ls;
+    for (int i = 0; i < n; ++i) ls.push_back(layers[i]->m);
+    auto s = std::make_shared<Sequential>(ls);
+    s->fuse = fuse != 0;
+    *out = new tp_module{s};
+    TP_END
+}
+int tp_module_free(tp_module *m) { TP_BEGIN delete m; TP_END }
+int tp_module_forward(const tp_module *m, const tp_tensor *x, tp_tensor **out) { TP_BEGIN *out = wrap(m->m->forward(x->t)); TP_END }
+int tp_module_num_parameters(const tp_module *m, int *out) { TP_BEGIN *out = (int)m->m->parameters().size(); TP_END }
+int tp_module_parameter(const tp_module *m, int i, tp_tensor **out) {
+    TP_BEGIN
+    auto p = m->m->parameters();
+    TAPER_ASSERT(i >= 0 && (size_t)i < p.size(), "parameter index out of range");
+    *out = wrap(p[i]);
+    TP_END
+}
+
+static std::vector<Tensor> collect(tp_tensor *const *ps, int n) {
+    std::vector<Tensor> v;
+    for (int i = 0; i < n; ++i) v.push_back(ps[i]->t);
+    return v;
+}
+int tp_adam_new(tp_tensor *const *ps, int n, float lr, float b1, float b2, float eps, float wd, tp_optim **out) {
+    TP_BEGIN
+    auto a = std::make_shared<Adam>(collect(ps, n), lr, b1, b2, eps, wd);
+    *out = new tp_optim{a, a};
+    TP_END
+}
+int tp_sgd_new(tp_tensor *const *ps, int n, float lr, tp_optim **out) {
+    TP_BEGIN *out = new tp_optim{std::make_shared<SGD>(collect(ps, n), lr), nullptr}; TP_END
+}
+int tp_optim_free(tp_optim *o) { TP_BEGIN delete o; TP_END }
+int tp_optim_step(tp_optim *o) { TP_BEGIN o->o->step(); TP_END }
+int tp_optim_zero_grad(tp_optim *o) { TP_BEGIN o->o->zero_grad(); TP_END }
+int tp_adam_set_lr(tp_optim *o, float lr) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); o->adam->set_lr(lr); TP_END }
+int tp_adam_get_lr(const tp_optim *o, float *out) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); *out = o->adam->get_lr(); TP_END }
+int tp_adam_t(const tp_optim *o, int *out) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); *out = o->adam->t(); TP_END }
+int tp_adam_moments(const tp_optim *o, float *h_m, float *h_v) {
+    TP_BEGIN
+    TAPER_ASSERT(o->adam, "not an Adam optimizer");
+    auto m = o->adam->m(), v = o->adam->v();
+    if (h_m) std::memcpy(h_m, m.data(), m.size() * sizeof(float));
+    if (h_v) std::memcpy(h_v, v.data(), v.size() * sizeof(float));
+    TP_END
+}
+int tp_optim_total(const tp_optim *o, int64_t *out) { TP_BEGIN *out = o->o->flat().total; TP_END }
+
+int tp_dataset_from_host(const float *im, const float *lb, size_t n, int train, tp_dataset **out) {
+    TP_BEGIN
+    *out = new tp_dataset{MNISTDataset::from_host(std::vector<float>(im, im + n * 784), std::vector<float>(lb, lb + n), train != 0)};
+    TP_END
+}
+int tp_dataset_from_idx(const char *ip, const char *lp, int train, tp_dataset **out) {
+    TP_BEGIN *out = new tp_dataset{MNISTDataset::from_idx_files(ip, lp, train != 0)}; TP_END
+}
+int tp_dataset_synthetic(size_t n, uint64_t seed, int train, tp_dataset **out) {
+    TP_BEGIN *out = new tp_dataset{MNISTDataset::synthetic(n, seed, train != 0)}; TP_END
+}
+int tp_dataset_len(const tp_dataset *d, size_t *out) { TP_BEGIN *out = d->d.len(); TP_END }
+int tp_dataset_tensors(const tp_dataset *d, tp_tensor **im, tp_tensor **lb) {
+    TP_BEGIN
+    if (im) *im = wrap(d->d.images);
+    if (lb) *lb = wrap(d->d.labels);
+    TP_END
+}
+int tp_dataset_free(tp_dataset *d) { TP_BEGIN delete d; TP_END }
+int tp_loader_new(const tp_dataset *d, size_t bs, int shuffle, uint64_t seed, tp_loader **out) {
+    TP_BEGIN *out = new tp_loader{std::make_unique<DataLoader>(d->d, bs, shuffle != 0, seed)}; TP_END
+}
+int tp_loader_reset(tp_loader *l) { TP_BEGIN l->l->reset(); TP_END }
+int tp_loader_num_batches(const tp_loader *l, size_t *out) { TP_BEGIN *out = l->l->num_batches(); TP_END }
+int tp_loader_next(tp_loader *l, tp_tensor **im, tp_tensor **lb, int *has) {
+    TP_BEGIN
+    Tensor a, b;
+    *has = l->l->next(&a, &b) ? 1 : 0;
+    if (*has) {
+        *im = wrap(a);
+        *lb = wrap(b);
+    }
+    TP_END
+}
+int tp_loader_free(tp_loader *l) { TP_BEGIN delete l; TP_END }
+
+int tp_comm_unique_id(uint8_t out_id[128]) {
+    TP_BEGIN
+    auto id = Communicator::unique_id();
+    std::memcpy(out_id, id.data(), 128);
+    TP_END
+}
+int tp_comm_new(int n, int r, const uint8_t id[128], tp_comm **out) {
+    TP_BEGIN *out = new tp_comm{std::make_shared<Communicator>(n, r, std::vector<uint8_t>(id, id + 128))}; TP_END
+}
+int tp_comm_free(tp_comm *c) { TP_BEGIN delete c; TP_END }
+int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n) { TP_BEGIN c->c->allreduce_mean((float *)d_buf, n); TP_END }
+
+int tp_trainer_new(tp_module *m, tp_optim *o, tp_trainer **out) {
+    TP_BEGIN
+    TAPER_ASSERT(o->adam, "Trainer takes an Adam optimizer (src/train.rs:76)");
+    *out = new tp_trainer{std::make_unique<Trainer>(m->m, o->adam)};
+    TP_END
+}
+int tp_trainer_set_sample_shape(tp_trainer *t, const size_t *shape, int nd) { TP_BEGIN t->t->sample_shape = mkshape(shape, nd); TP_END }
+int tp_trainer_set_comm(tp_trainer *t, tp_comm *c) { TP_BEGIN t->t->comm = c ? c->c : nullptr; TP_END }
+int tp_trainer_free(tp_trainer *t) { TP_BEGIN delete t; TP_END }
+int tp_trainer_train_step(tp_trainer *t, const tp_tensor *im, const tp_tensor *lb, float *loss, float *acc) {
+    TP_BEGIN t->t->train_step(im->t, lb->t, loss, acc); TP_END
+}
+int tp_trainer_run_epoch(tp_trainer *t, tp_loader *l, int mode, size_t max_steps, float *avg_loss, float *accuracy_out,
+                         size_t *total_correct, size_t *total_samples, size_t *num_batches, float *per_step, size_t cap) {
+    TP_BEGIN
+    EpochResult r;
+    if (mode == 0) r = t->t->train_epoch(*l->l);
+    else if (mode == 1) r = t->t->train_epoch_graph(*l->l, max_steps);
+    else r = t->t->evaluate(*l->l);
+    if (avg_loss) *avg_loss = r.avg_loss;
+    if (accuracy_out) *accuracy_out = r.accuracy;
+    if (total_correct) *total_correct = r.total_correct;
+    if (total_samples) *total_samples = r.total_samples;
+    if (num_batches) *num_batches = r.num_batches;
+    if (per_step)
+        for (size_t i = 0; i < r.losses.size() && 2 * i + 1 < cap; ++i) {
+            per_step[2 * i] = r.losses[i];
+            per_step[2 * i + 1] = r.ncorrect[i];
+        }
+    TP_END
+}
+
+}  // extern "C"

@@ -1,0 +1,578 @@
+// nn.cpp -- loss, layers, optimizers, data loader, communicator and trainer of
+// the host mirror (src/loss.rs, src/nn.rs, src/optim.rs, src/data/mnist.rs,
+// src/train.rs, examples/train_mnist*.rs).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "taper.h"
+
+namespace taper {
+
+#define TH(call) th_check((call), #call)
+
+// ---------------------------------------------------------------- loss
+Tensor log_softmax(const Tensor &x, int dim) {  // loss.rs:101-126
+    const int nd = (int)x.shape().size();
+    if (dim < 0) dim += nd;
+    TAPER_ASSERT(dim == nd - 1, "Only last-dim log_softmax is supported");
+    TAPER_ASSERT(nd == 2, "log_softmax: 2-D input expected");
+    if (!x.get_requires_grad()) {  // one fused kernel when no tape is needed
+        Tensor out = Tensor::empty(x.shape());
+        TH(th_log_softmax_fwd(Device::ctx(), x.dptr(), out.dptr(), (int)x.shape()[0], (int)x.shape()[1]));
+        return out;
+    }
+    // with autograd: the reference's own chain of differentiable primitives
+    Tensor mx = x.max(dim).first;
+    Tensor shifted = x.sub_broadcast_rows(mx);
+    Tensor log_sum = shifted.exp().sum(dim, true).log();
+    return shifted.sub_broadcast_rows(log_sum);
+}
+
+Tensor softmax(const Tensor &x, int dim) { return log_softmax(x, dim).exp(); }  // Q12
+
+Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out) {  // loss.rs:136-195
+    const Shape &ts = targets.shape();
+    TAPER_ASSERT(ts.size() == 1 || (ts.size() == 2 && ts[1] == 1), "Targets must be [B] or [B,1]");
+    TAPER_ASSERT(logits.shape().size() == 2, "Logits must be [B,C]");
+    TAPER_ASSERT(logits.shape()[0] == ts[0], "Batch sizes must match");
+    const int b = (int)logits.shape()[0], c = (int)logits.shape()[1];
+    th_ctx *ctx = Device::ctx();
+    Tensor logp = Tensor::empty(logits.shape());
+    Tensor loss = Tensor::empty({1});
+    float *nc = nullptr;
+    if (n_correct_out) {
+        *n_correct_out = Tensor::empty({1});
+        nc = n_correct_out->dptr();
+    }
+    TH(th_softmax_xent_fwd(ctx, logits.dptr(), targets.dptr(), b, c, logp.dptr(), loss.dptr(), nullptr, nc));
+    if (logits.get_requires_grad()) {
+        loss.set_requires_grad(true);
+        Tensor lg = logits, lp = logp, t = targets, out = loss;
+        Tape::push(loss, true, [lg, lp, t, out, b, c]() {
+            if (!out.has_grad()) return;
+            bool none;
+            float *g = lg.grad_for_write(&none);
+            TH(th_softmax_xent_bwd(Device::ctx(), lp.dptr(), t.dptr(), out.grad_dptr(), b, c, g, none ? 0 : 1));
+        });
+    }
+    return loss;
+}
+
+float accuracy(const Tensor &pred, const Tensor &targets) {  // loss.rs:271-290
+    TAPER_ASSERT(pred.shape()[0] == targets.shape()[0], "Batch sizes must match");
+    TAPER_ASSERT(pred.shape().size() == 2, "accuracy: predictions must be [B,C]");
+    th_ctx *ctx = Device::ctx();
+    const int b = (int)pred.shape()[0], c = (int)pred.shape()[1];
+    Tensor am = Tensor::empty({(size_t)b}), cnt = Tensor::empty({1});
+    TH(th_rowmax(ctx, pred.dptr(), nullptr, am.dptr(), b, c));
+    TH(th_accuracy_count(ctx, am.dptr(), targets.dptr(), b, cnt.dptr()));
+    return cnt.data()[0] / (float)targets.len();
+}
+
+Tensor one_hot(const Tensor &indices, size_t num_classes) {  // loss.rs:248-268 (host-side, off the hot path)
+    TAPER_ASSERT(indices.shape().size() == 1, "Indices must be 1D");
+    std::vector<float> idx = indices.data(), oh(idx.size() * num_classes, 0.f);
+    for (size_t i = 0; i < idx.size(); ++i) {
+        size_t cls = (size_t)idx[i];
+        TAPER_ASSERT(cls < num_classes, "Index out of bounds for one_hot");
+        oh[i * num_classes + cls] = 1.0f;
+    }
+    return Tensor(oh, {idx.size(), num_classes});
+}
+
+Tensor mse_loss(const Tensor &pred, const Tensor &targets) {  // loss.rs:76-80
+    Tensor diff = pred - targets;
+    return (diff * diff).mean();
+}
+
+// ---------------------------------------------------------------- layers
+static std::vector<float> uniform_init(size_t n, float bound, uint64_t seed) {
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<float> d(-bound, bound);
+    std::vector<float> v(n);
+    for (auto &x : v) x = d(rng);
+    return v;
+}
+
+Linear::Linear(size_t in_f, size_t out_f, bool with_bias, uint64_t seed) {  // nn.rs:35-50
+    const float scale = std::sqrt(2.0f / (float)in_f);
+    weight = Tensor(uniform_init(in_f * out_f, scale, seed), {out_f, in_f}).requires_grad();
+    if (with_bias) bias = Tensor(std::vector<float>(out_f, 0.f), {out_f}).requires_grad();
+}
+
+Tensor Linear::forward(const Tensor &x) const { return x.linear(weight, bias, false); }          // nn.rs:54-60
+Tensor Linear::forward_fused_relu(const Tensor &x) const { return x.linear(weight, bias, true); }
+
+std::vector<Tensor> Linear::parameters() const {  // nn.rs:71-77
+    std::vector<Tensor> p{weight};
+    if (bias.defined()) p.push_back(bias);
+    return p;
+}
+
+Conv2d::Conv2d(size_t in_ch, size_t out_ch, std::pair<int, int> kernel, std::pair<int, int> s, std::pair<int, int> p,
+               bool with_bias, uint64_t seed)
+    : stride(s), padding(p) {  // nn.rs:190-244
+    const size_t fan_in = in_ch * kernel.first * kernel.second;
+    const float bound = std::sqrt(2.0f / (float)fan_in) * std::sqrt(3.0f);
+    weight = Tensor(uniform_init(out_ch * fan_in, bound, seed), {out_ch, in_ch, (size_t)kernel.first, (size_t)kernel.second})
+                 .requires_grad();
+    if (with_bias) bias = Tensor(std::vector<float>(out_ch, 0.f), {out_ch}).requires_grad();
+}
+
+Tensor Conv2d::forward(const Tensor &x) const { return x.conv2d(weight, bias, stride, padding, dilation, fuse_relu); }
+
+std::vector<Tensor> Conv2d::parameters() const {
+    std::vector<Tensor> p{weight};
+    if (bias.defined()) p.push_back(bias);
+    return p;
+}
+
+Tensor AvgPool2d::forward(const Tensor &x) const {  // nn.rs:593-608
+    if (kernel == std::make_pair(0, 0)) return x.avg_pool2d({(int)x.shape()[2], (int)x.shape()[3]}, {1, 1}, {0, 0});
+    return x.avg_pool2d(kernel, stride, padding);
+}
+
+Tensor AdaptiveAvgPool2d::forward(const Tensor &x) const {  // nn.rs:670-686
+    const int kh = (int)x.shape()[2] / output_size.first, kw = (int)x.shape()[3] / output_size.second;
+    return x.avg_pool2d({kh, kw}, {kh, kw}, {0, 0});
+}
+
+Tensor Sequential::forward(const Tensor &input) const {  // nn.rs:149-151
+    Tensor x = input;
+    for (size_t i = 0; i < layers.size(); ++i) {
+        if (fuse && i + 1 < layers.size()) {
+            auto *lin = dynamic_cast<Linear *>(layers[i].get());
+            if (lin && dynamic_cast<ReLU *>(layers[i + 1].get())) {
+                x = lin->forward_fused_relu(x);  // Linear + ReLU: one kernel, one tape node
+                ++i;
+                continue;
+            }
+        }
+        x = layers[i]->forward(x);
+    }
+    return x;
+}
+
+std::vector<Tensor> Sequential::parameters() const {  // nn.rs:159-161
+    std::vector<Tensor> p;
+    for (auto &l : layers)
+        for (auto &t : l->parameters()) p.push_back(t);
+    return p;
+}
+
+// ---------------------------------------------------------------- flat arenas + optimizers
+FlatParams::FlatParams(const std::vector<Tensor> &ps) : params(ps) {
+    th_ctx *ctx = Device::ctx();
+    offsets.resize(ps.size() + 1, 0);
+    for (size_t i = 0; i < ps.size(); ++i) {
+        // keep every slice 16-byte aligned for the dwordx4 kernels
+        offsets[i + 1] = offsets[i] + (int64_t)((ps[i].len() + 3) / 4 * 4);
+    }
+    total = offsets.back();
+    p_arena = Buffer::alloc((size_t)total);
+    g_arena = Buffer::alloc((size_t)total);
+    TH(th_fill_f32(ctx, p_arena->d, 0.f, (size_t)total));
+    TH(th_fill_f32(ctx, g_arena->d, 0.f, (size_t)total));
+    for (size_t i = 0; i < ps.size(); ++i) {
+        Buffer &b = *ps[i].data_;
+        float *dst = p_arena->d + offsets[i];
+        TH(th_memcpy_d2d(ctx, dst, b.d, b.n * sizeof(float)));
+        // re-home the storage IN PLACE so every handle (model layers, user clones) follows
+        if (b.owned && b.d) TH(th_free(ctx, b.d));
+        b.d = dst;
+        b.owned = false;
+        b.parent = p_arena;
+        GradSlot &g = *ps[i].grad_;
+        const bool had = g.has;
+        auto view = Buffer::view(g_arena, (size_t)offsets[i], ps[i].len());
+        if (had && g.buf) TH(th_memcpy_d2d(ctx, view->d, g.buf->d, ps[i].len() * sizeof(float)));
+        g.buf = view;
+        g.known_zero = !had;
+    }
+    d_offsets_buf = Buffer::alloc((ps.size() + 1) * 2);
+    d_has_grad_buf = Buffer::alloc(ps.size());
+    TH(th_memcpy_h2d(ctx, d_offsets_buf->d, offsets.data(), offsets.size() * sizeof(int64_t)));
+    uploaded_mask.assign(ps.size(), -1);
+    sync_mask();
+}
+
+void FlatParams::sync_mask() {
+    std::vector<int32_t> mask(params.size());
+    for (size_t i = 0; i < params.size(); ++i) mask[i] = params[i].has_grad() ? 1 : 0;
+    if (mask == uploaded_mask) return;
+    // h2d synchronises: illegal inside a graph capture; callers run one eager
+    // step first so the (static) mask is already resident
+    TH(th_memcpy_h2d(Device::ctx(), d_has_grad_buf->d, mask.data(), mask.size() * sizeof(int32_t)));
+    uploaded_mask = mask;
+}
+
+void FlatParams::zero_missing() {
+    for (size_t i = 0; i < params.size(); ++i) {
+        GradSlot &g = *params[i].grad_;
+        if (!g.has && !g.known_zero) {
+            TH(th_fill_f32(Device::ctx(), g.buf->d, 0.f, params[i].len()));
+            g.known_zero = true;
+        }
+    }
+}
+
+void FlatParams::zero_grad() {
+    for (auto &p : params) p.zero_grad();
+}
+
+SGD::SGD(const std::vector<Tensor> &params, float lr) : fp_(params) {
+    lr_buf_ = Buffer::alloc(4);
+    TH(th_memcpy_h2d(Device::ctx(), lr_buf_->d, &lr, sizeof(float)));
+}
+
+void SGD::step() {  // optim.rs:21-33
+    fp_.sync_mask();
+    TH(th_sgd_step(Device::ctx(), fp_.p_arena->d, fp_.g_arena->d, fp_.d_offsets(), fp_.d_has_grad(), (int)fp_.params.size(),
+                   fp_.total, lr_buf_->d));
+}
+
+Adam::Adam(const std::vector<Tensor> &params, float lr, float beta1, float beta2, float eps, float wd)
+    : fp_(params), lr_(lr), beta1_(beta1), beta2_(beta2), eps_(eps), wd_(wd) {  // optim.rs:54-81
+    th_ctx *ctx = Device::ctx();
+    m_ = Buffer::alloc((size_t)fp_.total);
+    v_ = Buffer::alloc((size_t)fp_.total);
+    TH(th_fill_f32(ctx, m_->d, 0.f, (size_t)fp_.total));
+    TH(th_fill_f32(ctx, v_->d, 0.f, (size_t)fp_.total));
+    state_ = Buffer::alloc(4);
+    TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // t = 0
+    set_lr(lr);
+}
+
+void Adam::set_lr(float lr) {  // optim.rs:125-127
+    lr_ = lr;
+    TH(th_memcpy_h2d(Device::ctx(), state_->d + 2, &lr, sizeof(float)));
+}
+
+void Adam::step() {  // optim.rs:83-113
+    fp_.sync_mask();
+    TH(th_adam_step(Device::ctx(), fp_.p_arena->d, fp_.g_arena->d, m_->d, v_->d, fp_.d_offsets(), fp_.d_has_grad(),
+                    (int)fp_.params.size(), fp_.total, reinterpret_cast<int32_t *>(state_->d), state_->d + 2, beta1_, beta2_,
+                    eps_, wd_));
+}
+
+int Adam::t() const {
+    int32_t t = 0;
+    TH(th_memcpy_d2h(Device::ctx(), &t, state_->d, sizeof(t)));
+    return t;
+}
+
+static std::vector<float> gather_unpadded(const FlatParams &fp, const float *arena) {
+    std::vector<float> all((size_t)fp.total), out;
+    TH(th_memcpy_d2h(Device::ctx(), all.data(), arena, all.size() * sizeof(float)));
+    for (size_t i = 0; i < fp.params.size(); ++i)
+        out.insert(out.end(), all.begin() + fp.offsets[i], all.begin() + fp.offsets[i] + fp.params[i].len());
+    return out;
+}
+std::vector<float> Adam::m() const { return gather_unpadded(fp_, m_->d); }
+std::vector<float> Adam::v() const { return gather_unpadded(fp_, v_->d); }
+
+// ---------------------------------------------------------------- data
+MNISTDataset MNISTDataset::from_host(const std::vector<float> &images, const std::vector<float> &labels, bool train) {
+    TAPER_ASSERT(images.size() == labels.size() * 784, "MNISTDataset: images must be [N,784]");
+    MNISTDataset d;
+    d.images = Tensor(images, {labels.size(), 784});
+    d.labels = Tensor(labels, {labels.size()});
+    d.train = train;
+    return d;
+}
+
+MNISTDataset MNISTDataset::from_u8(const std::vector<uint8_t> &pixels, const std::vector<uint8_t> &labels, bool train) {
+    TAPER_ASSERT(pixels.size() == labels.size() * 784, "MNISTDataset: pixels must be [N,784]");
+    th_ctx *ctx = Device::ctx();
+    MNISTDataset d;
+    d.images = Tensor::empty({labels.size(), 784});
+    auto staging = Buffer::alloc((pixels.size() + 3) / 4);
+    TH(th_memcpy_h2d(ctx, staging->d, pixels.data(), pixels.size()));
+    TH(th_u8_to_unit_f32(ctx, reinterpret_cast<const uint8_t *>(staging->d), d.images.dptr(), pixels.size()));  // mnist.rs:226
+    std::vector<float> lf(labels.begin(), labels.end());  // mnist.rs:268
+    d.labels = Tensor(lf, {labels.size()});
+    d.train = train;
+    Device::sync();
+    return d;
+}
+
+static uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+MNISTDataset MNISTDataset::from_idx_files(const std::string &images_path, const std::string &labels_path, bool train) {
+    auto slurp = [](const std::string &path) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw Error("Failed to open " + path);
+        return std::vector<unsigned char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    };
+    std::vector<unsigned char> ib = slurp(images_path), lb = slurp(labels_path);
+    // mnist.rs:185-233
+    TAPER_ASSERT(ib.size() >= 16, "File " + images_path + " is too small");
+    TAPER_ASSERT(be32(ib.data()) == 0x00000803, "Invalid magic number for images");
+    const size_t n = be32(ib.data() + 4), rows = be32(ib.data() + 8), cols = be32(ib.data() + 12);
+    TAPER_ASSERT(rows == 28 && cols == 28, "Unexpected image size");
+    TAPER_ASSERT(ib.size() == 16 + n * 784, "File size mismatch (images)");
+    // mnist.rs:236-274
+    TAPER_ASSERT(lb.size() >= 8, "File " + labels_path + " is too small");
+    TAPER_ASSERT(be32(lb.data()) == 0x00000801, "Invalid magic number for labels");
+    const size_t nl = be32(lb.data() + 4);
+    TAPER_ASSERT(lb.size() == 8 + nl, "File size mismatch (labels)");
+    TAPER_ASSERT(nl == n, "image / label count mismatch");
+    return from_u8(std::vector<uint8_t>(ib.begin() + 16, ib.end()), std::vector<uint8_t>(lb.begin() + 8, lb.end()), train);
+}
+
+static inline uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+MNISTDataset MNISTDataset::synthetic(size_t n, uint64_t seed, bool train) {
+    std::vector<uint8_t> px(n * 784), lb(n);
+    uint64_t s = seed;
+    for (size_t i = 0; i < px.size(); i += 8) {
+        uint64_t r = splitmix64(s);
+        for (size_t j = 0; j < 8 && i + j < px.size(); ++j) px[i + j] = (uint8_t)(r >> (8 * j));
+    }
+    for (size_t i = 0; i < n; ++i) lb[i] = (uint8_t)(splitmix64(s) % 10);
+    return from_u8(px, lb, train);
+}
+
+std::pair<Tensor, Tensor> MNISTDataset::get_batch(const std::vector<size_t> &indices) const {  // mnist.rs:277-310
+    std::vector<int32_t> idx(indices.begin(), indices.end());
+    th_ctx *ctx = Device::ctx();
+    auto d_idx = Buffer::alloc(idx.size());
+    TH(th_memcpy_h2d(ctx, d_idx->d, idx.data(), idx.size() * sizeof(int32_t)));
+    Tensor xb = Tensor::empty({idx.size(), 784}), yb = Tensor::empty({idx.size()});
+    TH(th_gather_batch(ctx, images.dptr(), labels.dptr(), reinterpret_cast<const int32_t *>(d_idx->d), (int64_t)idx.size(), nullptr,
+                       (int)idx.size(), 784, xb.dptr(), yb.dptr()));
+    return {xb, yb};
+}
+
+DataLoader::DataLoader(MNISTDataset dataset, size_t batch_size, bool shuffle, uint64_t seed)
+    : ds_(std::move(dataset)), bs_(batch_size), shuffle_(shuffle), rng_(seed) {  // mnist.rs:335-353
+    TAPER_ASSERT(batch_size > 0, "DataLoader: batch_size must be positive");
+    indices_.resize(ds_.len());
+    for (size_t i = 0; i < indices_.size(); ++i) indices_[i] = (int32_t)i;
+    if (shuffle_) std::shuffle(indices_.begin(), indices_.end(), rng_);
+    d_idx_ = Buffer::alloc(std::max<size_t>(indices_.size(), 1));
+    upload_indices();
+}
+
+void DataLoader::upload_indices() {
+    TH(th_memcpy_h2d(Device::ctx(), d_idx_->d, indices_.data(), indices_.size() * sizeof(int32_t)));
+}
+
+void DataLoader::reset() {  // mnist.rs:355-363
+    cur_ = 0;
+    if (shuffle_) {
+        std::shuffle(indices_.begin(), indices_.end(), rng_);
+        upload_indices();
+    }
+}
+
+size_t DataLoader::num_batches() const { return (ds_.len() + bs_ - 1) / bs_; }  // mnist.rs:365-367
+
+bool DataLoader::next(Tensor *images, Tensor *labels) {  // mnist.rs:373-385 (keeps the last partial batch)
+    if (cur_ >= ds_.len()) return false;
+    const size_t end = std::min(cur_ + bs_, ds_.len()), b = end - cur_;
+    *images = Tensor::empty({b, 784});
+    *labels = Tensor::empty({b});
+    TH(th_gather_batch(Device::ctx(), ds_.images.dptr(), ds_.labels.dptr(), d_indices() + cur_, (int64_t)b, nullptr, (int)b, 784,
+                       images->dptr(), labels->dptr()));
+    cur_ = end;
+    return true;
+}
+
+// ---------------------------------------------------------------- communicator
+std::vector<uint8_t> Communicator::unique_id() {
+    std::vector<uint8_t> id(128);
+    TH(th_comm_unique_id(id.data()));
+    return id;
+}
+
+Communicator::Communicator(int n, int r, const std::vector<uint8_t> &id) : n_ranks(n), rank(r) {
+    TAPER_ASSERT(id.size() == 128, "Communicator: unique id must be 128 bytes");
+    TH(th_comm_init_rank(Device::ctx(), n, r, id.data(), &comm_));
+}
+
+Communicator::~Communicator() { th_comm_destroy(comm_); }
+
+void Communicator::allreduce_mean(float *d_buf, size_t n) const {
+    TH(th_allreduce_sum_scale(comm_, Device::ctx(), d_buf, n, 1.0f / (float)n_ranks));
+}
+
+// ---------------------------------------------------------------- trainer
+static Tensor shape_input(const Tensor &images, const Shape &sample_shape) {
+    if (sample_shape.empty()) return images;
+    Shape s{images.shape()[0]};
+    s.insert(s.end(), sample_shape.begin(), sample_shape.end());
+    return images.reshape(s);  // train_mnist_cnn.rs:161-162
+}
+
+static void reduce_grads(Trainer &t) {
+    if (!t.comm) return;
+    FlatParams &fp = t.optimizer->flat();
+    fp.zero_missing();  // grad None contributes zeros; the has_grad mask is rank-invariant
+    t.comm->allreduce_mean(fp.g_arena->d, (size_t)fp.total);
+}
+
+void Trainer::train_step(const Tensor &images, const Tensor &labels, float *loss_out, float *acc_out) {
+    Tape::reset();                                              // train_mnist.rs:91
+    Tensor logits = model->forward(shape_input(images, sample_shape));  // :101
+    Tensor loss = cross_entropy_loss(logits, labels);           // :107
+    const float acc = accuracy(logits, labels);                 // :110
+    loss.backward();                                            // :115
+    reduce_grads(*this);
+    optimizer->step();                                          // :118
+    optimizer->zero_grad();                                     // :119
+    if (loss_out) *loss_out = loss.data()[0];                   // :121
+    if (acc_out) *acc_out = acc;
+}
+
+EpochResult Trainer::train_epoch(DataLoader &loader) {  // train.rs:98-144
+    EpochResult r;
+    float total_loss = 0.f;
+    loader.reset();
+    r.num_batches = loader.num_batches();
+    Tensor images, labels;
+    while (loader.next(&images, &labels)) {
+        float loss, acc;
+        train_step(images, labels, &loss, &acc);
+        const size_t b = images.shape()[0];
+        r.total_correct += (size_t)(acc * (float)b);  // train.rs:117 (truncating cast, Q13)
+        r.total_samples += b;
+        total_loss += loss;
+        r.losses.push_back(loss);
+        r.ncorrect.push_back(acc * (float)b);
+    }
+    r.avg_loss = total_loss / (float)r.num_batches;                    // train.rs:140
+    r.accuracy = (float)r.total_correct / (float)r.total_samples;      // train.rs:141
+    return r;
+}
+
+EpochResult Trainer::evaluate(DataLoader &loader) {  // train.rs:147-172
+    EpochResult r;
+    float total_loss = 0.f;
+    loader.reset();
+    r.num_batches = loader.num_batches();
+    Tensor images, labels;
+    while (loader.next(&images, &labels)) {
+        Tape::reset();
+        Tensor logits = model->forward(shape_input(images, sample_shape));
+        Tensor loss = cross_entropy_loss(logits, labels);
+        const float acc = accuracy(logits, labels);
+        const size_t b = images.shape()[0];
+        r.total_correct += (size_t)(acc * (float)b);
+        r.total_samples += b;
+        const float l = loss.data()[0];
+        total_loss += l;
+        r.losses.push_back(l);
+        r.ncorrect.push_back(acc * (float)b);
+    }
+    r.avg_loss = total_loss / (float)r.num_batches;
+    r.accuracy = (float)r.total_correct / (float)r.total_samples;
+    return r;
+}
+
+// The captured form of one step: identical op list, but nothing is read back;
+// the batch comes from the device-resident dataset through the device cursor.
+void Trainer::enqueue_step(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
+                           size_t batch, bool from_cursor) {
+    th_ctx *ctx = Device::ctx();
+    int64_t *state = reinterpret_cast<int64_t *>(state_->d);
+    TH(th_gather_batch(ctx, d_images, d_labels, d_indices, n_indices, from_cursor ? state + 1 : nullptr, (int)batch, 784, xb_->d,
+                       yb_->d));
+    Tape::reset();
+    Tensor x = Tensor::from_device(xb_->d, {batch, 784});
+    Tensor y = Tensor::from_device(yb_->d, {batch});
+    Tensor logits = model->forward(shape_input(x, sample_shape));
+    Tensor ncorrect;
+    Tensor loss = cross_entropy_loss(logits, y, &ncorrect);
+    loss.backward();
+    reduce_grads(*this);
+    optimizer->step();
+    optimizer->zero_grad();
+    TH(th_log_step(ctx, loss.dptr(), ncorrect.dptr(), metrics_->d, (int64_t)metrics_cap_, state, (int64_t)batch));
+}
+
+EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
+    th_ctx *ctx = Device::ctx();
+    loader.reset();
+    const MNISTDataset &ds = loader.dataset();
+    const size_t n = ds.len(), bs = loader.batch_size();
+    size_t nb = loader.num_batches();
+    if (max_steps && max_steps < nb) nb = max_steps;
+    const size_t n_full = std::min(nb, n / bs);
+    if (!xb_ || xb_->n < bs * 784) {
+        xb_ = Buffer::alloc(bs * 784);
+        yb_ = Buffer::alloc(bs);
+        if (graph_) { th_graph_destroy(graph_); graph_ = nullptr; }
+    }
+    if (!state_) state_ = Buffer::alloc(4);
+    if (metrics_cap_ < nb + 1) {
+        metrics_cap_ = nb + 1;
+        metrics_ = Buffer::alloc(2 * metrics_cap_);
+        if (graph_) { th_graph_destroy(graph_); graph_ = nullptr; }
+    }
+    TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // step = 0, cursor = 0
+    const float *d_img = ds.images.dptr(), *d_lab = ds.labels.dptr();
+    const int32_t *d_idx = loader.d_indices();
+    const void *key = d_img;
+    if (graph_ && (graph_batch_ != bs || graph_key_ != key)) { th_graph_destroy(graph_); graph_ = nullptr; }
+
+    size_t done = 0;
+    if (!graph_ && n_full > 0) {
+        // step 0 runs eagerly (pool warm-up, has_grad mask upload), then the SAME
+        // host code is replayed under stream capture to record the op list
+        enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
+        done = 1;
+        if (n_full > 1) {
+            TH(th_graph_begin(ctx));
+            try {
+                enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
+            } catch (...) {
+                th_graph *g = nullptr;
+                th_graph_end(ctx, &g);
+                th_graph_destroy(g);
+                throw;
+            }
+            TH(th_graph_end(ctx, &graph_));
+            graph_batch_ = bs;
+            graph_key_ = key;
+        }
+    }
+    for (; done < n_full; ++done) TH(th_graph_launch(ctx, graph_));
+    if (nb > n_full) {  // the last, partial batch (mnist.rs:373-385 keeps it)
+        const size_t rem = n - n_full * bs;
+        enqueue_step(d_img, d_lab, d_idx, (int64_t)n, rem, true);
+    }
+    loader.advance(std::min(n, nb * bs));
+
+    std::vector<float> mt(2 * nb);
+    TH(th_memcpy_d2h(ctx, mt.data(), metrics_->d, mt.size() * sizeof(float)));
+    EpochResult r;
+    r.num_batches = nb;
+    float total_loss = 0.f;
+    for (size_t s = 0; s < nb; ++s) {
+        const size_t b = (s < n_full) ? bs : n - n_full * bs;
+        const float acc = mt[2 * s + 1] / (float)b;       // loss.rs:289
+        r.total_correct += (size_t)(acc * (float)b);      // train.rs:117 (Q13)
+        r.total_samples += b;
+        total_loss += mt[2 * s];
+        r.losses.push_back(mt[2 * s]);
+        r.ncorrect.push_back(mt[2 * s + 1]);
+    }
+    r.avg_loss = total_loss / (float)nb;
+    r.accuracy = (float)r.total_correct / (float)r.total_samples;
+    return r;
+}
+
+Trainer::~Trainer() {
+    if (graph_) th_graph_destroy(graph_);
+}
+
+}  // namespace taper

@@ -1,0 +1,419 @@
+// taper.h -- host side of the MI355X backend: a C++ mirror of the reference's
+// Rust API surface (Tensor / Tape / nn::Module / loss / optim / data / train)
+// that owns the tape and the op-record list and reaches the GPU ONLY through
+// the C ABI of include/taper_hip.h -- exactly what a Rust `extern "C"` block
+// in the taper crate would bind.  No HIP headers here: this
+// library is built with plain g++.
+//
+// Names, argument meaning and error behaviour follow the reference:
+//   src/tensor.rs, src/ops.rs, src/tape.rs, src/nn.rs, src/activation.rs,
+//   src/loss.rs, src/optim.rs, src/data/mnist.rs, src/train.rs.
+// The reference panics (assert!/panic!) on misuse; here that is taper::Error.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/taper_hip.h"
+
+namespace taper {
+
+struct Error : std::runtime_error {
+    explicit Error(const std::string &m) : std::runtime_error(m) {}
+};
+void th_check(int rc, const char *what);  // throws Error(th_last_error())
+#define TAPER_ASSERT(cond, msg)                       \
+    do {                                              \
+        if (!(cond)) throw ::taper::Error(msg);       \
+    } while (0)
+
+using Shape = std::vector<size_t>;  // <= 4 dims (SmallVec<[usize;4]>, tensor.rs:240)
+size_t numel(const Shape &s);
+
+// One context (GPU + stream + pool) per host thread, like the thread-local
+// tape (tape.rs:6-9).  Device id: set_device() > $TAPER_DEVICE > $LOCAL_RANK > 0.
+class Device {
+   public:
+    static th_ctx *ctx();
+    static void set_device(int id);
+    static int device_id();
+    static void sync();
+    static void shutdown();
+};
+
+// Device storage.  `owned` buffers return to the ctx pool on destruction;
+// views (optimizer arenas, batch staging) do not.
+struct Buffer {
+    float *d = nullptr;
+    size_t n = 0;
+    bool owned = true;
+    std::shared_ptr<Buffer> parent;  // keeps an arena alive for views
+    Buffer() = default;
+    Buffer(const Buffer &) = delete;
+    ~Buffer();
+    static std::shared_ptr<Buffer> alloc(size_t n);
+    static std::shared_ptr<Buffer> view(const std::shared_ptr<Buffer> &parent, size_t offset, size_t n);
+    static std::shared_ptr<Buffer> borrow(float *d, size_t n);
+};
+
+// grad: Arc<RwLock<Option<Vec<f32>>>> (tensor.rs:241)
+struct GradSlot {
+    std::shared_ptr<Buffer> buf;  // storage; may be a view into an optimizer's flat arena
+    bool has = false;             // Some / None
+    bool known_zero = false;      // arena slice currently all-zero (DP all-reduce of grad-less params)
+};
+
+class Tensor {
+   public:
+    Tensor() = default;
+    Tensor(const std::vector<float> &data, const Shape &shape);  // tensor.rs:470 (uploads)
+    static Tensor scalar(float v);                                // tensor.rs:480
+    static Tensor empty(const Shape &shape);                      // uninitialised device storage
+    static Tensor zeros(const Shape &shape);
+    static Tensor from_device(float *d, const Shape &shape);      // non-owning view of device memory
+    static Tensor randn(const Shape &shape, uint64_t seed = 0);   // ops.rs:301-309 (seeded)
+
+    Tensor requires_grad() const;        // tensor.rs:484-487 (builder style)
+    bool get_requires_grad() const { return requires_grad_; }
+    void set_requires_grad(bool on) { requires_grad_ = on; }
+    bool defined() const { return (bool)data_; }
+    const Shape &shape() const { return shape_; }
+    size_t len() const { return data_ ? data_->n : 0; }
+    float *dptr() const { return data_->d; }
+    std::vector<float> data() const;     // tensor.rs:494 (D2H copy, synchronises)
+    void set_data(const std::vector<float> &v);
+    bool has_grad() const { return grad_ && grad_->has; }
+    std::vector<float> grad() const;     // tensor.rs:505-518; empty vector when None
+    float *grad_dptr() const { return has_grad() ? grad_->buf->d : nullptr; }
+    void set_grad(const std::vector<float> &g);  // `*w.grad.write().unwrap() = Some(..)` (optim.rs:372)
+    size_t tape_node() const { return tape_node_ ? *tape_node_ : 0; }
+
+    void backward() const;               // tensor.rs:520-529
+    void zero_grad() const;              // tensor.rs:531-533
+
+    // ops (src/ops.rs, src/tensor.rs)
+    Tensor operator+(const Tensor &o) const;   // ops.rs:8-51
+    Tensor operator-(const Tensor &o) const;   // ops.rs:377-416
+    Tensor operator*(const Tensor &o) const;   // ops.rs:53-120
+    Tensor operator/(const Tensor &o) const;   // ops.rs:440-496
+    Tensor matmul(const Tensor &o) const;      // ops.rs:200-298
+    Tensor relu() const;                       // ops.rs:312-374
+    Tensor transpose() const;                  // tensor.rs:544-591
+    Tensor sigmoid() const;                    // tensor.rs:594-634
+    Tensor add_broadcast(const Tensor &o) const;       // tensor.rs:636-704
+    Tensor sub_broadcast_rows(const Tensor &o) const;  // tensor.rs:707-770
+    Tensor mean() const;                       // tensor.rs:772-800
+    Tensor reshape(const Shape &s) const;      // tensor.rs:803-840
+    Tensor view(const Shape &s) const { return reshape(s); }
+    Tensor flatten(size_t start_dim) const;    // tensor.rs:843-858
+    Tensor squeeze(int dim = -1) const;        // tensor.rs:861-877
+    Tensor unsqueeze(size_t dim) const;        // tensor.rs:880-887
+    Tensor sum(int dim = -1, bool keepdim = false) const;  // tensor.rs:890-1018 (dim: 2-D only, Q14)
+    std::pair<Tensor, Tensor> max(int dim = -1) const;     // tensor.rs:1021-1083
+    Tensor argmax(int dim = -1) const;         // tensor.rs:1086-1088
+    Tensor exp() const;                        // tensor.rs:1091-1133
+    Tensor log() const;                        // tensor.rs:1136-1169
+    Tensor pow(float e) const;                 // tensor.rs:1172-1206
+    Tensor sqrt() const { return pow(0.5f); }  // tensor.rs:1209-1211
+    // conv / pool (tensor.rs:1221-1660).  bias may be undefined (None).
+    Tensor conv2d(const Tensor &weight, const Tensor &bias, std::pair<int, int> stride, std::pair<int, int> padding,
+                  std::pair<int, int> dilation, bool relu = false) const;
+    Tensor conv2d_relu(const Tensor &weight, const Tensor &bias, std::pair<int, int> stride, std::pair<int, int> padding,
+                       std::pair<int, int> dilation) const;
+    Tensor max_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride /* {0,0} = None */,
+                      std::pair<int, int> padding) const;
+    Tensor avg_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride, std::pair<int, int> padding) const;
+    // fused Linear (nn.rs:54-60): y = x . W^T + b, optional fused ReLU; ONE tape node
+    Tensor linear(const Tensor &weight, const Tensor &bias, bool relu = false) const;
+
+    // internals shared with nn/optim
+    float *grad_for_write(bool *was_none) const;  // storage of the grad slot; *was_none tells the caller to overwrite
+    float *grad_accum_ptr() const;                // lazily zero-filled slot (ops.rs:126-129)
+    std::shared_ptr<Buffer> data_;
+    Shape shape_;
+    std::shared_ptr<GradSlot> grad_;
+    bool requires_grad_ = false;
+    std::shared_ptr<size_t> tape_node_;
+};
+
+// ---- tape (src/tape.rs) ----------------------------------------------------
+class Tape {
+   public:
+    static void reset();                                   // tape.rs:43-49
+    static size_t len();
+    static void push(const Tensor &out, bool any_input_requires_grad, std::function<void()> backward_fn);  // tape.rs:51-101
+    static void backward(size_t final_node_id);            // tape.rs:106-127
+    // false (default): ids are 1-based so every recorded node can be a root
+    // (the reference tests' intent); true: the literal tensor.rs:524-528
+    // behaviour where node id 0 doubles as "no node" (quirk Q1).
+    static void set_compat_zero_sentinel(bool on);
+    static bool compat_zero_sentinel();
+};
+
+// conv gradient mode: false = faithful (the reference cuts the tape at
+// im2col / transpose_4d, quirk Q2: conv weights and conv inputs never get
+// gradients); true = full_backward extension.
+void set_full_backward(bool on);
+bool full_backward();
+
+// ---- loss (src/loss.rs) ------------------------------------------------------
+Tensor log_softmax(const Tensor &x, int dim = -1);                         // loss.rs:101-126
+Tensor softmax(const Tensor &x, int dim = -1);                             // exp(log_softmax), Q12
+// n_correct_out (optional): device scalar receiving accuracy()*B from the fused kernel
+Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out = nullptr);  // loss.rs:136-195
+float accuracy(const Tensor &predictions, const Tensor &targets);          // loss.rs:271-290 (synchronises)
+Tensor one_hot(const Tensor &indices, size_t num_classes);                 // loss.rs:248-268
+Tensor mse_loss(const Tensor &pred, const Tensor &targets);                // loss.rs:76-80
+
+// ---- nn (src/nn.rs, src/activation.rs) --------------------------------------
+class Module {
+   public:
+    virtual ~Module() = default;
+    virtual Tensor forward(const Tensor &input) const = 0;  // nn.rs:11
+    virtual std::vector<Tensor> parameters() const = 0;     // nn.rs:12
+    virtual const char *name() const = 0;
+};
+using Layer = Module;  // north_star calls the trait "nn::Layer"
+
+class Linear : public Module {  // nn.rs:28-78
+   public:
+    Tensor weight, bias;  // [out,in], [out] (bias undefined when with_bias=false)
+    Linear(size_t in_features, size_t out_features, bool with_bias, uint64_t seed);
+    Tensor forward(const Tensor &input) const override;
+    Tensor forward_fused_relu(const Tensor &input) const;
+    std::vector<Tensor> parameters() const override;
+    const char *name() const override { return "Linear"; }
+};
+
+class ReLU : public Module {  // activation.rs:7-21
+   public:
+    Tensor forward(const Tensor &x) const override { return x.relu(); }
+    std::vector<Tensor> parameters() const override { return {}; }
+    const char *name() const override { return "ReLU"; }
+};
+
+class Sigmoid : public Module {  // activation.rs:37-51
+   public:
+    Tensor forward(const Tensor &x) const override { return x.sigmoid(); }
+    std::vector<Tensor> parameters() const override { return {}; }
+    const char *name() const override { return "Sigmoid"; }
+};
+
+class Conv2d : public Module {  // nn.rs:180-354 (groups == 1)
+   public:
+    Tensor weight, bias;
+    std::pair<int, int> stride{1, 1}, padding{0, 0}, dilation{1, 1};
+    bool fuse_relu = false;
+    Conv2d(size_t in_ch, size_t out_ch, std::pair<int, int> kernel, std::pair<int, int> stride, std::pair<int, int> padding,
+           bool with_bias, uint64_t seed);
+    Tensor forward(const Tensor &x) const override;
+    std::vector<Tensor> parameters() const override;
+    const char *name() const override { return fuse_relu ? "Conv2dReLU" : "Conv2d"; }
+};
+
+class Conv2dReLU : public Conv2d {  // nn.rs:433-490
+   public:
+    Conv2dReLU(size_t in_ch, size_t out_ch, std::pair<int, int> kernel, std::pair<int, int> stride,
+               std::pair<int, int> padding, bool with_bias, uint64_t seed)
+        : Conv2d(in_ch, out_ch, kernel, stride, padding, with_bias, seed) {
+        fuse_relu = true;
+    }
+};
+
+class MaxPool2d : public Module {  // nn.rs:508-549
+   public:
+    std::pair<int, int> kernel, stride, padding;
+    MaxPool2d(std::pair<int, int> k, std::pair<int, int> s, std::pair<int, int> p) : kernel(k), stride(s), padding(p) {}
+    Tensor forward(const Tensor &x) const override { return x.max_pool2d(kernel, stride, padding); }
+    std::vector<Tensor> parameters() const override { return {}; }
+    const char *name() const override { return "MaxPool2d"; }
+};
+
+class AvgPool2d : public Module {  // nn.rs:570-623; kernel {0,0} = global
+   public:
+    std::pair<int, int> kernel, stride, padding;
+    AvgPool2d(std::pair<int, int> k, std::pair<int, int> s, std::pair<int, int> p) : kernel(k), stride(s), padding(p) {}
+    Tensor forward(const Tensor &x) const override;
+    std::vector<Tensor> parameters() const override { return {}; }
+    const char *name() const override { return "AvgPool2d"; }
+};
+
+class AdaptiveAvgPool2d : public Module {  // nn.rs:655-697
+   public:
+    std::pair<int, int> output_size;
+    explicit AdaptiveAvgPool2d(std::pair<int, int> o) : output_size(o) {}
+    Tensor forward(const Tensor &x) const override;
+    std::vector<Tensor> parameters() const override { return {}; }
+    const char *name() const override { return "AdaptiveAvgPool2d"; }
+};
+
+class Flatten : public Module {  // nn.rs:730-756
+   public:
+    size_t start_dim;
+    explicit Flatten(size_t s = 1) : start_dim(s) {}
+    Tensor forward(const Tensor &x) const override { return x.flatten(start_dim); }
+    std::vector<Tensor> parameters() const override { return {}; }
+    const char *name() const override { return "Flatten"; }
+};
+
+class Sequential : public Module {  // nn.rs:130-162
+   public:
+    std::vector<std::shared_ptr<Module>> layers;
+    bool fuse = true;  // Linear followed by ReLU runs as one fused kernel + one tape node
+    explicit Sequential(std::vector<std::shared_ptr<Module>> l) : layers(std::move(l)) {}
+    Tensor forward(const Tensor &input) const override;
+    std::vector<Tensor> parameters() const override;
+    const char *name() const override { return "Sequential"; }
+};
+
+// ---- optim (src/optim.rs) ------------------------------------------------------
+// Parameters, their grads and the moments live in flat device arenas so that
+// (a) Adam is ONE kernel launch and (b) data-parallel training all-reduces ONE
+// buffer.  Constructing an optimizer re-homes each parameter's storage and
+// grad slot into the arenas (values preserved).
+class FlatParams {
+   public:
+    std::vector<Tensor> params;
+    std::shared_ptr<Buffer> p_arena, g_arena;
+    std::shared_ptr<Buffer> d_offsets_buf, d_has_grad_buf;  // int64[n+1], int32[n] (stored in float buffers)
+    std::vector<int64_t> offsets;
+    std::vector<int32_t> uploaded_mask;
+    int64_t total = 0;
+    explicit FlatParams(const std::vector<Tensor> &ps);
+    const int64_t *d_offsets() const { return reinterpret_cast<const int64_t *>(d_offsets_buf->d); }
+    const int32_t *d_has_grad() const { return reinterpret_cast<const int32_t *>(d_has_grad_buf->d); }
+    void sync_mask();        // upload has_grad mask iff it changed (not allowed while capturing)
+    void zero_missing();     // zero-fill arena slices of grad-less params (before an all-reduce)
+    void zero_grad();        // optim.rs:115-119
+};
+
+class Optimizer {
+   public:
+    virtual ~Optimizer() = default;
+    virtual void step() = 0;
+    virtual void zero_grad() = 0;
+    virtual FlatParams &flat() = 0;
+};
+
+class SGD : public Optimizer {  // optim.rs:8-40 (momentum ignored, 14-17)
+   public:
+    SGD(const std::vector<Tensor> &params, float lr);
+    void step() override;
+    void zero_grad() override { fp_.zero_grad(); }
+    FlatParams &flat() override { return fp_; }
+
+   private:
+    FlatParams fp_;
+    std::shared_ptr<Buffer> lr_buf_;
+};
+
+class Adam : public Optimizer {  // optim.rs:43-128
+   public:
+    Adam(const std::vector<Tensor> &params, float lr, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f,
+         float weight_decay = 0.0f);
+    void step() override;                          // optim.rs:83-113
+    void zero_grad() override { fp_.zero_grad(); } // optim.rs:115-119
+    float get_lr() const { return lr_; }
+    void set_lr(float lr);                         // optim.rs:125-127
+    int t() const;                                 // reads the device counter (synchronises)
+    std::vector<float> m() const;
+    std::vector<float> v() const;
+    FlatParams &flat() override { return fp_; }
+
+   private:
+    FlatParams fp_;
+    std::shared_ptr<Buffer> m_, v_, state_;  // state_: int32 t, int32 scratch, float lr
+    float lr_, beta1_, beta2_, eps_, wd_;
+};
+
+// ---- data (src/data/mnist.rs) -----------------------------------------------------
+class MNISTDataset {
+   public:
+    Tensor images, labels;  // [N,784] in [0,1], [N] class ids as f32; device resident
+    bool train = true;
+    size_t len() const { return labels.len(); }
+    static MNISTDataset from_host(const std::vector<float> &images, const std::vector<float> &labels, bool train);
+    static MNISTDataset from_u8(const std::vector<uint8_t> &pixels, const std::vector<uint8_t> &labels, bool train);
+    static MNISTDataset from_idx_files(const std::string &images_path, const std::string &labels_path, bool train);  // mnist.rs:185-274
+    static MNISTDataset synthetic(size_t n, uint64_t seed, bool train);  // u8 ~ U{0..255}/255, labels U{0..9}
+    std::pair<Tensor, Tensor> get_batch(const std::vector<size_t> &indices) const;  // mnist.rs:277-310
+};
+
+class DataLoader {  // mnist.rs:327-386
+   public:
+    DataLoader(MNISTDataset dataset, size_t batch_size, bool shuffle, uint64_t seed = 0x7461706572ull);
+    void reset();                 // mnist.rs:355-363 (reshuffles)
+    size_t num_batches() const;   // mnist.rs:365-367
+    bool next(Tensor *images, Tensor *labels);  // mnist.rs:373-385; false at end
+    const MNISTDataset &dataset() const { return ds_; }
+    size_t batch_size() const { return bs_; }
+    const int32_t *d_indices() const { return reinterpret_cast<const int32_t *>(d_idx_->d); }
+    size_t current() const { return cur_; }
+    void advance(size_t n) { cur_ += n; }
+
+   private:
+    void upload_indices();
+    MNISTDataset ds_;
+    size_t bs_;
+    bool shuffle_;
+    std::vector<int32_t> indices_;
+    std::shared_ptr<Buffer> d_idx_;
+    size_t cur_ = 0;
+    std::mt19937_64 rng_;
+};
+
+// ---- data parallel (new) ---------------------------------------------------------------
+class Communicator {
+   public:
+    static std::vector<uint8_t> unique_id();
+    Communicator(int n_ranks, int rank, const std::vector<uint8_t> &id);
+    ~Communicator();
+    void allreduce_mean(float *d_buf, size_t n) const;  // sum over ranks * 1/W on the ctx stream
+    int n_ranks, rank;
+
+   private:
+    th_comm *comm_ = nullptr;
+};
+
+// ---- train (src/train.rs, examples/train_mnist*.rs) ------------------------------------
+struct EpochResult {
+    float avg_loss = 0.f;     // sum(loss) / num_batches   (train.rs:140)
+    float accuracy = 0.f;     // total_correct / total_samples with the per-batch truncation of train.rs:117 (Q13)
+    size_t total_correct = 0, total_samples = 0, num_batches = 0;
+    std::vector<float> losses, ncorrect;  // per step
+};
+
+class Trainer {  // train.rs:74-172
+   public:
+    std::shared_ptr<Module> model;
+    std::shared_ptr<Adam> optimizer;
+    std::shared_ptr<Communicator> comm;   // optional: data-parallel grad all-reduce before step()
+    Shape sample_shape;                   // {} -> feed [B,784]; {1,28,28} -> reshape like train_mnist_cnn.rs:161-162
+    std::string device = "hip:gfx950";    // train.rs:79 "For future GPU support"
+    Trainer(std::shared_ptr<Module> m, std::shared_ptr<Adam> o) : model(std::move(m)), optimizer(std::move(o)) {}
+
+    // one step exactly as examples/train_mnist.rs:89-121 (reads loss + accuracy back every step)
+    void train_step(const Tensor &images, const Tensor &labels, float *loss_out, float *acc_out);
+    EpochResult train_epoch(DataLoader &loader);              // train.rs:98-144 (eager, synchronising)
+    EpochResult evaluate(DataLoader &loader);                 // train.rs:147-172
+    // same arithmetic, but the step's op list is captured once into a hipGraph
+    // and replayed; loss / n_correct stay on device until the epoch ends.
+    EpochResult train_epoch_graph(DataLoader &loader, size_t max_steps = 0);
+    ~Trainer();
+
+   private:
+    void enqueue_step(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
+                      size_t batch, bool from_cursor);
+    th_graph *graph_ = nullptr;
+    size_t graph_batch_ = 0;
+    const void *graph_key_ = nullptr;
+    std::shared_ptr<Buffer> xb_, yb_, state_, metrics_, step_loss_, step_ncorrect_;
+    size_t metrics_cap_ = 0;
+};
+
+}  // namespace taper

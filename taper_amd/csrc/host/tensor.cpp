@@ -1,0 +1,730 @@
+// tensor.cpp -- Device, Buffer, Tensor, Tape: host owner of the op-record list
+// (mirrors src/tensor.rs, src/ops.rs, src/tape.rs).  Every op = shape checks
+// on the host + one call through the C ABI + (optionally) one recorded
+// closure.  Nothing here touches the device except via th_*.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "taper.h"
+
+namespace taper {
+
+void th_check(int rc, const char *what) {
+    if (rc != 0) throw Error(std::string(what) + ": " + th_last_error());
+}
+#define TH(call) th_check((call), #call)
+
+size_t numel(const Shape &s) {
+    size_t n = 1;
+    for (size_t d : s) n *= d;
+    return n;
+}
+
+// ---------------------------------------------------------------- Device
+namespace {
+thread_local th_ctx *t_ctx = nullptr;
+thread_local int t_device = -1;
+
+int default_device() {
+    if (t_device >= 0) return t_device;
+    if (const char *e = std::getenv("TAPER_DEVICE")) return std::atoi(e);
+    if (const char *e = std::getenv("LOCAL_RANK")) return std::atoi(e);
+    return 0;
+}
+}  // namespace
+
+th_ctx *Device::ctx() {
+    if (!t_ctx) {
+        int n = 0;
+        TH(th_device_count(&n));
+        TAPER_ASSERT(n > 0, "taper: no MI355X visible -- the HIP backend has no CPU fallback");
+        int id = default_device();
+        if (id >= n) id = id % n;
+        TH(th_ctx_create(id, &t_ctx));
+        t_device = id;
+    }
+    return t_ctx;
+}
+
+void Device::set_device(int id) {
+    TAPER_ASSERT(!t_ctx || id == t_device, "Device::set_device after the context was created");
+    t_device = id;
+}
+int Device::device_id() { return t_ctx ? t_device : default_device(); }
+void Device::sync() { TH(th_ctx_sync(ctx())); }
+void Device::shutdown() {
+    if (t_ctx) {
+        Tape::reset();
+        th_ctx_destroy(t_ctx);
+        t_ctx = nullptr;
+    }
+}
+
+// ---------------------------------------------------------------- Buffer
+Buffer::~Buffer() {
+    if (owned && d && t_ctx) th_free(t_ctx, d);
+}
+
+std::shared_ptr<Buffer> Buffer::alloc(size_t n) {
+    auto b = std::make_shared<Buffer>();
+    void *p = nullptr;
+    TH(th_malloc(Device::ctx(), std::max<size_t>(n, 1) * sizeof(float), &p));
+    b->d = (float *)p;
+    b->n = n;
+    return b;
+}
+
+std::shared_ptr<Buffer> Buffer::view(const std::shared_ptr<Buffer> &parent, size_t offset, size_t n) {
+    auto b = std::make_shared<Buffer>();
+    b->d = parent->d + offset;
+    b->n = n;
+    b->owned = false;
+    b->parent = parent;
+    return b;
+}
+
+std::shared_ptr<Buffer> Buffer::borrow(float *d, size_t n) {
+    auto b = std::make_shared<Buffer>();
+    b->d = d;
+    b->n = n;
+    b->owned = false;
+    return b;
+}
+
+// ---------------------------------------------------------------- Tape
+namespace {
+struct TapeState {
+    std::vector<std::function<void()>> nodes;
+    bool zero_sentinel = false;
+};
+thread_local TapeState t_tape;
+thread_local bool t_full_backward = false;
+}  // namespace
+
+void Tape::reset() { t_tape.nodes.clear(); }
+size_t Tape::len() { return t_tape.nodes.size(); }
+void Tape::set_compat_zero_sentinel(bool on) { t_tape.zero_sentinel = on; }
+bool Tape::compat_zero_sentinel() { return t_tape.zero_sentinel; }
+
+void Tape::push(const Tensor &out, bool any_input_requires_grad, std::function<void()> fn) {
+    if (!any_input_requires_grad) return;  // tape.rs:55-57, 82-84
+    const size_t index = t_tape.nodes.size();
+    t_tape.nodes.push_back(std::move(fn));
+    *out.tape_node_ = t_tape.zero_sentinel ? index : index + 1;  // tape.rs:65-75 vs Q1
+}
+
+void Tape::backward(size_t final_node_id) {  // tape.rs:106-127
+    if (t_tape.nodes.empty()) return;
+    size_t last;
+    if (t_tape.zero_sentinel) {
+        last = std::min(final_node_id, t_tape.nodes.size() - 1);
+    } else {
+        if (final_node_id == 0) return;
+        last = std::min(final_node_id - 1, t_tape.nodes.size() - 1);
+    }
+    for (size_t i = last + 1; i-- > 0;) {
+        std::function<void()> fn = t_tape.nodes[i];  // clone: closures may record nodes (Q7)
+        fn();
+    }
+}
+
+void set_full_backward(bool on) { t_full_backward = on; }
+bool full_backward() { return t_full_backward; }
+
+// ---------------------------------------------------------------- Tensor basics
+static Tensor make(const std::shared_ptr<Buffer> &buf, const Shape &shape) {
+    TAPER_ASSERT(shape.size() >= 1 && shape.size() <= 4, "Tensor: 1..4 dimensions supported");
+    Tensor t;
+    t.data_ = buf;
+    t.shape_ = shape;
+    t.grad_ = std::make_shared<GradSlot>();
+    t.tape_node_ = std::make_shared<size_t>(0);
+    return t;
+}
+
+Tensor Tensor::empty(const Shape &shape) { return make(Buffer::alloc(numel(shape)), shape); }
+
+Tensor Tensor::zeros(const Shape &shape) {
+    Tensor t = empty(shape);
+    TH(th_fill_f32(Device::ctx(), t.dptr(), 0.0f, t.len()));
+    return t;
+}
+
+Tensor::Tensor(const std::vector<float> &data, const Shape &shape) {
+    TAPER_ASSERT(data.size() == numel(shape), "Tensor::new: data length does not match shape");
+    *this = empty(shape);
+    TH(th_memcpy_h2d(Device::ctx(), dptr(), data.data(), data.size() * sizeof(float)));
+}
+
+Tensor Tensor::scalar(float v) { return Tensor(std::vector<float>{v}, Shape{1}); }
+Tensor Tensor::from_device(float *d, const Shape &shape) { return make(Buffer::borrow(d, numel(shape)), shape); }
+
+Tensor Tensor::randn(const Shape &shape, uint64_t seed) {
+    std::mt19937_64 rng(seed);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> v(numel(shape));
+    for (auto &x : v) x = nd(rng);
+    return Tensor(v, shape);
+}
+
+Tensor Tensor::requires_grad() const {
+    Tensor t = *this;
+    t.requires_grad_ = true;
+    return t;
+}
+
+std::vector<float> Tensor::data() const {
+    std::vector<float> v(len());
+    TH(th_memcpy_d2h(Device::ctx(), v.data(), dptr(), v.size() * sizeof(float)));
+    return v;
+}
+
+void Tensor::set_data(const std::vector<float> &v) {
+    TAPER_ASSERT(v.size() == len(), "set_data: length mismatch");
+    TH(th_memcpy_h2d(Device::ctx(), dptr(), v.data(), v.size() * sizeof(float)));
+}
+
+std::vector<float> Tensor::grad() const {
+    if (!has_grad()) return {};
+    std::vector<float> v(len());
+    TH(th_memcpy_d2h(Device::ctx(), v.data(), grad_->buf->d, v.size() * sizeof(float)));
+    return v;
+}
+
+void Tensor::set_grad(const std::vector<float> &g) {
+    if (g.empty()) {
+        zero_grad();
+        return;
+    }
+    TAPER_ASSERT(g.size() == len(), "set_grad: length mismatch");
+    bool none;
+    float *p = grad_for_write(&none);
+    TH(th_memcpy_h2d(Device::ctx(), p, g.data(), g.size() * sizeof(float)));
+}
+
+float *Tensor::grad_for_write(bool *was_none) const {
+    if (!grad_->buf) grad_->buf = Buffer::alloc(len());
+    if (was_none) *was_none = !grad_->has;
+    grad_->has = true;
+    grad_->known_zero = false;
+    return grad_->buf->d;
+}
+
+float *Tensor::grad_accum_ptr() const {  // `if slot.is_none() { zeros }` (ops.rs:126-129)
+    bool none;
+    float *p = grad_for_write(&none);
+    if (none) TH(th_fill_f32(Device::ctx(), p, 0.0f, len()));
+    return p;
+}
+
+void Tensor::backward() const {  // tensor.rs:520-529
+    bool none;
+    float *g = grad_for_write(&none);
+    TH(th_fill_f32(Device::ctx(), g, 1.0f, len()));
+    Tape::backward(*tape_node_);  // id 0 = "no node" in both id schemes
+}
+
+void Tensor::zero_grad() const { grad_->has = false; }  // tensor.rs:531-533
+
+// t.grad (+)= alpha * src  -- accumulate_grad / accumulate_grad_scaled (ops.rs:124-151)
+static void accumulate_into(const Tensor &t, const float *src, float alpha = 1.0f) {
+    th_ctx *c = Device::ctx();
+    bool none;
+    float *g = t.grad_for_write(&none);
+    if (none && alpha == 1.0f) {
+        TH(th_memcpy_d2d(c, g, src, t.len() * sizeof(float)));  // 0 + x
+        return;
+    }
+    if (none) TH(th_fill_f32(c, g, 0.0f, t.len()));
+    TH(th_axpy(c, alpha, src, g, t.len()));
+}
+
+static void check_same_len(const Tensor &a, const Tensor &b) {
+    TAPER_ASSERT(a.len() == b.len(), "Tensor dimensions must match");  // ops.rs:11-15 (count only, Q12)
+}
+
+// ---------------------------------------------------------------- element-wise
+Tensor Tensor::operator+(const Tensor &o) const {
+    check_same_len(*this, o);
+    Tensor out = empty(shape_);
+    TH(th_add(Device::ctx(), dptr(), o.dptr(), out.dptr(), len()));
+    if (requires_grad_ || o.requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor a = *this, b = o, r = out;
+        Tape::push(out, true, [a, b, r]() {
+            if (!r.has_grad()) return;
+            if (a.get_requires_grad()) accumulate_into(a, r.grad_dptr());
+            if (b.get_requires_grad()) accumulate_into(b, r.grad_dptr());
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::operator-(const Tensor &o) const {
+    check_same_len(*this, o);
+    Tensor out = empty(shape_);
+    TH(th_sub(Device::ctx(), dptr(), o.dptr(), out.dptr(), len()));
+    if (requires_grad_ || o.requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor a = *this, b = o, r = out;
+        Tape::push(out, true, [a, b, r]() {
+            if (!r.has_grad()) return;
+            if (a.get_requires_grad()) accumulate_into(a, r.grad_dptr());
+            if (b.get_requires_grad()) accumulate_into(b, r.grad_dptr(), -1.0f);
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::operator*(const Tensor &o) const {
+    check_same_len(*this, o);
+    Tensor out = empty(shape_);
+    TH(th_mul(Device::ctx(), dptr(), o.dptr(), out.dptr(), len()));
+    if (requires_grad_ || o.requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor a = *this, b = o, r = out;
+        Tape::push(out, true, [a, b, r]() {
+            if (!r.has_grad()) return;
+            th_ctx *c = Device::ctx();
+            if (a.get_requires_grad()) TH(th_mul_bwd(c, r.grad_dptr(), b.dptr(), a.grad_accum_ptr(), a.len()));
+            if (b.get_requires_grad()) TH(th_mul_bwd(c, r.grad_dptr(), a.dptr(), b.grad_accum_ptr(), b.len()));
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::operator/(const Tensor &o) const {
+    check_same_len(*this, o);
+    Tensor out = empty(shape_);
+    TH(th_div(Device::ctx(), dptr(), o.dptr(), out.dptr(), len()));
+    if (requires_grad_ || o.requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor a = *this, b = o, r = out;
+        Tape::push(out, true, [a, b, r]() {
+            if (!r.has_grad()) return;
+            float *ga = a.get_requires_grad() ? a.grad_accum_ptr() : nullptr;
+            float *gb = b.get_requires_grad() ? b.grad_accum_ptr() : nullptr;
+            TH(th_div_bwd(Device::ctx(), r.grad_dptr(), a.dptr(), b.dptr(), ga, gb, a.len()));
+        });
+    }
+    return out;
+}
+
+template <typename Fwd, typename Bwd>
+static Tensor unary_op(const Tensor &x, Fwd fwd, Bwd bwd) {
+    Tensor out = Tensor::empty(x.shape());
+    fwd(x, out);
+    if (x.get_requires_grad()) {
+        out.set_requires_grad(true);
+        Tensor in = x, r = out;
+        Tape::push(out, true, [in, r, bwd]() {
+            if (!r.has_grad()) return;
+            bwd(in, r);
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::relu() const {
+    return unary_op(
+        *this, [](const Tensor &x, Tensor &y) { TH(th_relu_fwd(Device::ctx(), x.dptr(), y.dptr(), x.len())); },
+        [](const Tensor &x, const Tensor &y) {
+            bool none;
+            float *gin = x.grad_for_write(&none);
+            TH(th_relu_bwd(Device::ctx(), x.dptr(), y.grad_dptr(), gin, x.len(), none ? 0 : 1));  // mask on the INPUT (Q15)
+        });
+}
+
+Tensor Tensor::sigmoid() const {
+    return unary_op(
+        *this, [](const Tensor &x, Tensor &y) { TH(th_sigmoid_fwd(Device::ctx(), x.dptr(), y.dptr(), x.len())); },
+        [](const Tensor &x, const Tensor &y) {
+            TH(th_sigmoid_bwd(Device::ctx(), y.dptr(), y.grad_dptr(), x.grad_accum_ptr(), x.len()));  // saved output
+        });
+}
+
+Tensor Tensor::exp() const {
+    return unary_op(
+        *this, [](const Tensor &x, Tensor &y) { TH(th_exp_fwd(Device::ctx(), x.dptr(), y.dptr(), x.len())); },
+        [](const Tensor &x, const Tensor &y) {
+            TH(th_mul_bwd(Device::ctx(), y.grad_dptr(), y.dptr(), x.grad_accum_ptr(), x.len()));  // gout * e^x
+        });
+}
+
+Tensor Tensor::log() const {
+    return unary_op(
+        *this, [](const Tensor &x, Tensor &y) { TH(th_log_fwd(Device::ctx(), x.dptr(), y.dptr(), x.len())); },
+        [](const Tensor &x, const Tensor &y) {
+            TH(th_log_bwd(Device::ctx(), x.dptr(), y.grad_dptr(), x.grad_accum_ptr(), x.len()));
+        });
+}
+
+Tensor Tensor::pow(float e) const {
+    return unary_op(
+        *this, [e](const Tensor &x, Tensor &y) { TH(th_pow_fwd(Device::ctx(), x.dptr(), e, y.dptr(), x.len())); },
+        [e](const Tensor &x, const Tensor &y) {
+            TH(th_pow_bwd(Device::ctx(), x.dptr(), e, y.grad_dptr(), x.grad_accum_ptr(), x.len()));
+        });
+}
+
+// ---------------------------------------------------------------- matmul / transpose / linear
+Tensor Tensor::matmul(const Tensor &o) const {  // ops.rs:200-298
+    TAPER_ASSERT(shape_.size() == 2, "First tensor must be 2D");
+    TAPER_ASSERT(o.shape_.size() == 2, "Second tensor must be 2D");
+    const int m = (int)shape_[0], k = (int)shape_[1], k2 = (int)o.shape_[0], n = (int)o.shape_[1];
+    TAPER_ASSERT(k == k2, "Inner dimensions must match: " + std::to_string(k) + " vs " + std::to_string(k2));
+    Tensor out = empty({(size_t)m, (size_t)n});
+    TH(th_sgemm(Device::ctx(), 0, 0, m, n, k, 1.0f, dptr(), o.dptr(), 0.0f, out.dptr()));
+    if (requires_grad_ || o.requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor a = *this, b = o, r = out;
+        Tape::push(out, true, [a, b, r, m, n, k]() {
+            if (!r.has_grad()) return;
+            th_ctx *c = Device::ctx();
+            bool none;
+            if (a.get_requires_grad()) {  // dA += dC * B^T  (ops.rs:254-265)
+                float *ga = a.grad_for_write(&none);
+                TH(th_sgemm(c, 0, 1, m, k, n, 1.0f, r.grad_dptr(), b.dptr(), none ? 0.0f : 1.0f, ga));
+            }
+            if (b.get_requires_grad()) {  // dB += A^T * dC  (ops.rs:280-291)
+                float *gb = b.grad_for_write(&none);
+                TH(th_sgemm(c, 1, 0, k, n, m, 1.0f, a.dptr(), r.grad_dptr(), none ? 0.0f : 1.0f, gb));
+            }
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::transpose() const {  // tensor.rs:544-591
+    TAPER_ASSERT(shape_.size() == 2, "Can only transpose 2D tensors");
+    const int rows = (int)shape_[0], cols = (int)shape_[1];
+    Tensor out = empty({(size_t)cols, (size_t)rows});
+    TH(th_transpose2d(Device::ctx(), dptr(), out.dptr(), rows, cols));
+    if (requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor in = *this, r = out;
+        Tape::push(out, true, [in, r, rows, cols]() {
+            if (!r.has_grad()) return;
+            bool none;
+            float *gin = in.grad_for_write(&none);
+            if (none) TH(th_transpose2d(Device::ctx(), r.grad_dptr(), gin, cols, rows));
+            else TH(th_transpose2d_bwd(Device::ctx(), r.grad_dptr(), gin, rows, cols));
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  // nn.rs:54-60 fused
+    TAPER_ASSERT(shape_.size() == 2, "First tensor must be 2D");
+    TAPER_ASSERT(w.shape_.size() == 2, "Second tensor must be 2D");
+    const int batch = (int)shape_[0], in_f = (int)shape_[1], out_f = (int)w.shape_[0];
+    TAPER_ASSERT((size_t)in_f == w.shape_[1],
+                 "Inner dimensions must match: " + std::to_string(in_f) + " vs " + std::to_string(w.shape_[1]));
+    if (bias.defined()) TAPER_ASSERT(bias.shape_.size() == 1 && bias.shape_[0] == (size_t)out_f, "Last dimension must match for broadcasting");
+    Tensor out = empty({(size_t)batch, (size_t)out_f});
+    TH(th_linear_fwd(Device::ctx(), dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, out.dptr(), batch, in_f, out_f, relu ? 1 : 0));
+    const bool need = requires_grad_ || w.requires_grad_ || (bias.defined() && bias.requires_grad_);
+    if (need) {
+        out.requires_grad_ = true;
+        Tensor x = *this, wt = w, b = bias, r = out;
+        Tape::push(out, true, [x, wt, b, r, batch, in_f, out_f, relu]() {
+            if (!r.has_grad()) return;
+            th_ctx *c = Device::ctx();
+            const float *dy = r.grad_dptr();
+            std::shared_ptr<Buffer> dz;
+            if (relu) {  // relu backward through the post-activation mask (y > 0 <=> pre-activation > 0, Q15)
+                dz = Buffer::alloc(r.len());
+                TH(th_relu_bwd(c, r.dptr(), dy, dz->d, r.len(), 0));
+                dy = dz->d;
+            }
+            int mask = 0;
+            bool none;
+            float *dx = nullptr, *dw = nullptr, *db = nullptr;
+            if (x.get_requires_grad()) { dx = x.grad_for_write(&none); if (!none) mask |= 1; }
+            if (wt.get_requires_grad()) { dw = wt.grad_for_write(&none); if (!none) mask |= 2; }
+            if (b.defined() && b.get_requires_grad()) { db = b.grad_for_write(&none); if (!none) mask |= 4; }
+            TH(th_linear_bwd(c, x.dptr(), wt.dptr(), dy, dx, dw, db, batch, in_f, out_f, mask));
+        });
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------- broadcast / reduce
+Tensor Tensor::add_broadcast(const Tensor &o) const {  // tensor.rs:636-704
+    if (shape_ == o.shape_) return *this + o;
+    TAPER_ASSERT(shape_.size() == 2 && o.shape_.size() == 1, "Unsupported broadcasting shapes");
+    TAPER_ASSERT(shape_[1] == o.shape_[0], "Last dimension must match for broadcasting");
+    const int rows = (int)shape_[0], cols = (int)shape_[1];
+    Tensor out = empty(shape_);
+    TH(th_bias_add_rows(Device::ctx(), dptr(), o.dptr(), out.dptr(), rows, cols, 0));
+    if (requires_grad_ || o.requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor a = *this, b = o, r = out;
+        Tape::push(out, true, [a, b, r, rows, cols]() {
+            if (!r.has_grad()) return;
+            if (a.get_requires_grad()) accumulate_into(a, r.grad_dptr());
+            if (b.get_requires_grad()) {
+                bool none;
+                float *gb = b.grad_for_write(&none);
+                if (none) TH(th_colsum(Device::ctx(), r.grad_dptr(), gb, rows, cols));
+                else TH(th_colsum_accum(Device::ctx(), r.grad_dptr(), gb, rows, cols));
+            }
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::sub_broadcast_rows(const Tensor &o) const {  // tensor.rs:707-770
+    if (shape_ == o.shape_) return *this - o;
+    TAPER_ASSERT(shape_.size() == 2 && o.shape_.size() == 2 && shape_[0] == o.shape_[0] && o.shape_[1] == 1,
+                 "Unsupported broadcasting shapes for sub_broadcast_rows");
+    const int rows = (int)shape_[0], cols = (int)shape_[1];
+    Tensor out = empty(shape_);
+    TH(th_sub_rows(Device::ctx(), dptr(), o.dptr(), out.dptr(), rows, cols));
+    if (requires_grad_ || o.requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor a = *this, b = o, r = out;
+        Tape::push(out, true, [a, b, r, rows, cols]() {
+            if (!r.has_grad()) return;
+            if (a.get_requires_grad()) accumulate_into(a, r.grad_dptr());
+            if (b.get_requires_grad()) TH(th_rowsum_neg_accum(Device::ctx(), r.grad_dptr(), b.grad_accum_ptr(), rows, cols));
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::mean() const {  // tensor.rs:772-800
+    Tensor out = empty({1});
+    const float n = (float)len();
+    TH(th_sum_all(Device::ctx(), dptr(), out.dptr(), len(), n));
+    if (requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor in = *this, r = out;
+        Tape::push(out, true, [in, r, n]() {
+            if (!r.has_grad()) return;
+            TH(th_add_scalar_dev(Device::ctx(), r.grad_dptr(), n, in.grad_accum_ptr(), in.len()));
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::reshape(const Shape &s) const {  // tensor.rs:803-840
+    TAPER_ASSERT(numel(s) == len(), "Cannot reshape tensor of size " + std::to_string(len()));
+    // The reference clones the Vec (814); tensors are immutable once produced,
+    // so the device build shares the storage and only gives the view its own
+    // grad slot / tape node.
+    Tensor out = make(data_, s);
+    if (requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor in = *this, r = out;
+        Tape::push(out, true, [in, r]() {
+            if (!r.has_grad()) return;
+            accumulate_into(in, r.grad_dptr());
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::flatten(size_t start_dim) const {  // tensor.rs:843-858
+    TAPER_ASSERT(start_dim < shape_.size(), "start_dim out of bounds");
+    Shape ns(shape_.begin(), shape_.begin() + start_dim);
+    size_t rest = 1;
+    for (size_t i = start_dim; i < shape_.size(); ++i) rest *= shape_[i];
+    ns.push_back(rest);
+    return reshape(ns);
+}
+
+Tensor Tensor::squeeze(int dim) const {  // tensor.rs:861-877
+    Shape ns;
+    if (dim >= 0) {
+        TAPER_ASSERT((size_t)dim < shape_.size(), "Dimension out of bounds");
+        TAPER_ASSERT(shape_[dim] == 1, "Can only squeeze dimensions of size 1");
+        for (size_t i = 0; i < shape_.size(); ++i)
+            if ((int)i != dim) ns.push_back(shape_[i]);
+    } else {
+        for (size_t d : shape_)
+            if (d != 1) ns.push_back(d);
+    }
+    if (ns.empty()) ns.push_back(1);
+    return reshape(ns);
+}
+
+Tensor Tensor::unsqueeze(size_t dim) const {  // tensor.rs:880-887
+    TAPER_ASSERT(dim <= shape_.size() && shape_.size() < 4, "Dimension out of bounds");
+    Shape ns = shape_;
+    ns.insert(ns.begin() + dim, 1);
+    return reshape(ns);
+}
+
+Tensor Tensor::sum(int dim, bool keepdim) const {  // tensor.rs:890-1018
+    th_ctx *c = Device::ctx();
+    if (dim < 0) {
+        Tensor out = empty({1});
+        TH(th_sum_all(c, dptr(), out.dptr(), len(), 1.0f));
+        if (requires_grad_) {
+            out.requires_grad_ = true;
+            Tensor in = *this, r = out;
+            Tape::push(out, true, [in, r]() {
+                if (!r.has_grad()) return;
+                TH(th_add_scalar_dev(Device::ctx(), r.grad_dptr(), 1.0f, in.grad_accum_ptr(), in.len()));
+            });
+        }
+        return out;
+    }
+    TAPER_ASSERT((size_t)dim < shape_.size(), "Dimension " + std::to_string(dim) + " out of bounds");
+    size_t outer = 1, inner = 1;
+    for (int i = 0; i < dim; ++i) outer *= shape_[i];
+    for (size_t i = dim + 1; i < shape_.size(); ++i) inner *= shape_[i];
+    const size_t d = shape_[dim];
+    // the reference's index math is only exercised for 2-D inputs (Q14)
+    TAPER_ASSERT(inner == 1 || outer == 1, "sum(dim): only the first or last dimension can be reduced");
+    Shape os;
+    for (size_t i = 0; i < shape_.size(); ++i) {
+        if ((int)i == dim) { if (keepdim) os.push_back(1); }
+        else os.push_back(shape_[i]);
+    }
+    if (os.empty()) os.push_back(1);
+    Tensor out = empty(os);
+    const bool by_row = inner == 1;  // [outer, d] -> [outer]
+    const int rows = by_row ? (int)outer : (int)d, cols = by_row ? (int)d : (int)inner;
+    if (by_row) TH(th_rowsum(c, dptr(), out.dptr(), rows, cols));
+    else TH(th_colsum(c, dptr(), out.dptr(), rows, cols));
+    if (requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor in = *this, r = out;
+        Tape::push(out, true, [in, r, by_row, rows, cols]() {
+            if (!r.has_grad()) return;
+            if (by_row) TH(th_rowsum_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), rows, cols));
+            else TH(th_colsum_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), rows, cols));
+        });
+    }
+    return out;
+}
+
+std::pair<Tensor, Tensor> Tensor::max(int dim) const {  // tensor.rs:1021-1083 (no tape node)
+    th_ctx *c = Device::ctx();
+    if (dim < 0) {
+        // global max; NOTE the reference's max_by keeps the LAST of equal maxima,
+        // this kernel keeps the first (off the hot path; documented in DESIGN.md)
+        Tensor v = empty({1}), i = empty({1});
+        TH(th_rowmax(c, dptr(), v.dptr(), i.dptr(), 1, (int)len()));
+        return {v, i};
+    }
+    TAPER_ASSERT((size_t)dim < shape_.size(), "Dimension " + std::to_string(dim) + " out of bounds");
+    TAPER_ASSERT(shape_.size() == 2, "max(dim): 2-D tensors only (Q14)");
+    const int rows = (int)shape_[0], cols = (int)shape_[1];
+    Shape os = shape_;
+    os[dim] = 1;
+    Tensor v = empty(os), i = empty(os);
+    if (dim == 1) TH(th_rowmax(c, dptr(), v.dptr(), i.dptr(), rows, cols));
+    else TH(th_colmax(c, dptr(), v.dptr(), i.dptr(), rows, cols));
+    return {v, i};
+}
+
+Tensor Tensor::argmax(int dim) const { return max(dim).second; }
+
+// ---------------------------------------------------------------- conv / pool
+Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> stride, std::pair<int, int> padding,
+                      std::pair<int, int> dilation, bool relu) const {  // tensor.rs:1221-1285 (+1379-1389)
+    TAPER_ASSERT(shape_.size() == 4, "Input must be 4D: [N, C_in, H, W]");
+    TAPER_ASSERT(w.shape_.size() == 4, "Weight must be 4D: [C_out, C_in, K_h, K_w]");
+    const int n = (int)shape_[0], c_in = (int)shape_[1], h = (int)shape_[2], wd = (int)shape_[3];
+    const int c_out = (int)w.shape_[0], k_h = (int)w.shape_[2], k_w = (int)w.shape_[3];
+    TAPER_ASSERT((size_t)c_in == w.shape_[1], "Input and weight channel dimensions must match");
+    if (bias.defined()) TAPER_ASSERT(bias.shape_ == Shape{(size_t)c_out}, "Bias must be 1D with C_out elements");
+    const int h_out = (h + 2 * padding.first - dilation.first * (k_h - 1) - 1) / stride.first + 1;
+    const int w_out = (wd + 2 * padding.second - dilation.second * (k_w - 1) - 1) / stride.second + 1;
+    th_ctx *c = Device::ctx();
+    const bool is3 = k_h == 3 && k_w == 3 && stride == std::make_pair(1, 1) && dilation == std::make_pair(1, 1);
+    const bool is1 = k_h == 1 && k_w == 1;
+    const float *bp = bias.defined() ? bias.dptr() : nullptr;
+    Tensor out = empty({(size_t)n, (size_t)c_out, (size_t)h_out, (size_t)w_out});
+    const int pad = padding.first;
+    if (is3) {
+        TAPER_ASSERT(padding.first == padding.second && (pad == 0 || pad == 1), "conv2d 3x3: padding must be (0,0) or (1,1)");
+        TH(th_conv3x3_fwd(c, dptr(), w.dptr(), bp, out.dptr(), n, c_in, h, wd, c_out, pad, /*taper layout*/ 0, relu ? 1 : 0));
+    } else if (is1) {
+        TAPER_ASSERT(h == h_out && wd == w_out, "im2col_1x1 requires h_in == h_out (tensor.rs:1796-1797)");
+        TH(th_conv1x1_fwd(c, dptr(), w.dptr(), bp, out.dptr(), n, c_in, h, wd, c_out, 0, relu ? 1 : 0));
+    } else {
+        throw Error("conv2d: only 3x3 stride-1 and 1x1 kernels are supported (the reference's general im2col is out of scope, Q9)");
+    }
+    // Tape.  Faithful mode (Q2): the chain is cut at transpose_4d / im2col, so only
+    // the bias (through add_bias_4d, tensor.rs:2003-2027) ever receives a gradient.
+    const bool fb = full_backward();
+    const bool bias_grad = bias.defined() && bias.requires_grad_;
+    const bool w_grad = fb && w.requires_grad_;
+    const bool x_grad = fb && requires_grad_ && is3 && pad == 1;
+    if (bias_grad || w_grad || x_grad) {
+        out.requires_grad_ = true;
+        Tensor x = *this, wt = w, b = bias, r = out;
+        Tape::push(out, true, [x, wt, b, r, n, c_in, h, wd, c_out, h_out, w_out, pad, relu, bias_grad, w_grad, x_grad, is3]() {
+            if (!r.has_grad()) return;
+            th_ctx *c = Device::ctx();
+            const float *gy = r.grad_dptr();
+            std::shared_ptr<Buffer> dz;
+            if (relu) {
+                dz = Buffer::alloc(r.len());
+                TH(th_relu_bwd(c, r.dptr(), gy, dz->d, r.len(), 0));
+                gy = dz->d;
+            }
+            if (bias_grad) TH(th_bias_grad_nchw(c, gy, b.grad_accum_ptr(), n, c_out, h_out * w_out));
+            if (w_grad && is3) TH(th_conv3x3_bwd_weight(c, x.dptr(), gy, wt.grad_accum_ptr(), n, c_in, h, wd, c_out, pad, 0));
+            if (x_grad) TH(th_conv3x3_bwd_input(c, gy, wt.dptr(), x.grad_accum_ptr(), n, c_in, h, wd, c_out, pad, 0));
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::conv2d_relu(const Tensor &w, const Tensor &bias, std::pair<int, int> stride, std::pair<int, int> padding,
+                           std::pair<int, int> dilation) const {
+    return conv2d(w, bias, stride, padding, dilation, true);
+}
+
+Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pair<int, int> p) const {  // tensor.rs:1391-1521
+    TAPER_ASSERT(shape_.size() == 4, "Input must be 4D: [N, C, H, W]");
+    if (s.first == 0) s = k;  // stride.unwrap_or(kernel_size)
+    const int n = (int)shape_[0], ch = (int)shape_[1], h = (int)shape_[2], w = (int)shape_[3];
+    TAPER_ASSERT(k.first > 0 && k.second > 0 && h + 2 * p.first >= k.first && w + 2 * p.second >= k.second, "max_pool2d: bad geometry");
+    const int h_out = (h + 2 * p.first - k.first) / s.first + 1, w_out = (w + 2 * p.second - k.second) / s.second + 1;
+    Tensor out = empty({(size_t)n, (size_t)ch, (size_t)h_out, (size_t)w_out});
+    auto arg = Buffer::alloc(out.len() * 2);  // int64 per output
+    TH(th_maxpool2d_fwd(Device::ctx(), dptr(), out.dptr(), reinterpret_cast<int64_t *>(arg->d), n, ch, h, w, k.first, k.second,
+                        s.first, s.second, p.first, p.second));
+    if (requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor in = *this, r = out;
+        Tape::push(out, true, [in, r, arg, n, ch, h, w, k, s, p]() {
+            if (!r.has_grad()) return;
+            bool none;
+            float *gin = in.grad_for_write(&none);  // zero_first (Q5) overwrites whatever was there
+            TH(th_maxpool2d_bwd(Device::ctx(), r.grad_dptr(), reinterpret_cast<const int64_t *>(arg->d), gin, n, ch, h, w, k.first,
+                                k.second, s.first, s.second, p.first, p.second, /*zero_first*/ 1));
+        });
+    }
+    return out;
+}
+
+Tensor Tensor::avg_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pair<int, int> p) const {  // tensor.rs:1524-1660
+    TAPER_ASSERT(shape_.size() == 4, "Input must be 4D: [N, C, H, W]");
+    if (s.first == 0) s = k;
+    const int n = (int)shape_[0], ch = (int)shape_[1], h = (int)shape_[2], w = (int)shape_[3];
+    TAPER_ASSERT(k.first > 0 && k.second > 0 && h + 2 * p.first >= k.first && w + 2 * p.second >= k.second, "avg_pool2d: bad geometry");
+    const int h_out = (h + 2 * p.first - k.first) / s.first + 1, w_out = (w + 2 * p.second - k.second) / s.second + 1;
+    Tensor out = empty({(size_t)n, (size_t)ch, (size_t)h_out, (size_t)w_out});
+    TH(th_avgpool2d_fwd(Device::ctx(), dptr(), out.dptr(), n, ch, h, w, k.first, k.second, s.first, s.second, p.first, p.second));
+    if (requires_grad_) {
+        out.requires_grad_ = true;
+        Tensor in = *this, r = out;
+        Tape::push(out, true, [in, r, n, ch, h, w, k, s, p]() {
+            if (!r.has_grad()) return;
+            TH(th_avgpool2d_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), n, ch, h, w, k.first, k.second, s.first, s.second,
+                                p.first, p.second));
+        });
+    }
+    return out;
+}
+
+}  // namespace taper

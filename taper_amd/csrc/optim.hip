@@ -1,0 +1,179 @@
+// optim.hip -- fused multi-tensor Adam / SGD over the flat parameter arenas
+// (src/optim.rs:8-128), the batch gather of the data loader
+// (src/data/mnist.rs:277-310) and the device-side step bookkeeping.
+// All HBM-bound: Adam touches 28 B per parameter (p r/w, g r, m r/w, v r/w).
+#include "common.h"
+
+namespace th {
+
+// llvm.powi.f32 as lowered by compiler-rt __powisf2 (f32::powi, optim.rs:87-88)
+__device__ __forceinline__ float powi_f32(float a, int b) {
+    const bool recip = b < 0;
+    float r = 1.0f;
+    while (true) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0f / r : r;
+}
+
+// t += 1; step_size = lr * sqrt(1 - b2^t) / (1 - b1^t)   (optim.rs:84-90)
+__global__ void adam_tick_kernel(int32_t *__restrict__ t_state, const float *__restrict__ lr, float beta1, float beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int t = t_state[0] + 1;
+        t_state[0] = t;
+        const float bc1 = 1.0f - powi_f32(beta1, t);
+        const float bc2 = 1.0f - powi_f32(beta2, t);
+        const float step = lr[0] * (sqrtf(bc2) / bc1);
+        t_state[1] = __float_as_int(step);
+    }
+}
+
+__device__ __forceinline__ int find_tensor(const int64_t *__restrict__ offsets, int n_tensors, int64_t i) {
+    int lo = 0, hi = n_tensors;  // offsets[lo] <= i < offsets[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, const int64_t *__restrict__ offsets,
+                                                   const int32_t *__restrict__ has_grad, int n_tensors, int64_t total,
+                                                   const int32_t *__restrict__ t_state, float beta1, float beta2, float eps,
+                                                   float wd) {
+    const float step = __int_as_float(t_state[1]);
+    const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ti = find_tensor(offsets, n_tensors, i);
+        if (!has_grad[ti]) continue;                       // grad None: skipped entirely (Q8)
+        const float pv = p[i];
+        const float gv = g[i] + wd * pv;                   // optim.rs:101
+        const float mv = beta1 * m[i] + omb1 * gv;         // optim.rs:104
+        const float vv = beta2 * v[i] + omb2 * gv * gv;    // optim.rs:107
+        m[i] = mv;
+        v[i] = vv;
+        p[i] = pv - step * mv / (sqrtf(vv) + eps);         // optim.rs:110 (Q10)
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                  const int64_t *__restrict__ offsets, const int32_t *__restrict__ has_grad,
+                                                  int n_tensors, int64_t total, const float *__restrict__ lr) {
+    const float l = lr[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ti = find_tensor(offsets, n_tensors, i);
+        if (!has_grad[ti]) continue;
+        p[i] -= l * g[i];                                  // optim.rs:28-30
+    }
+}
+
+// one workgroup per batch row; row_len floats copied as float4 when aligned
+__global__ __launch_bounds__(256) void gather_batch_kernel(const float *__restrict__ images, const float *__restrict__ labels,
+                                                           const int32_t *__restrict__ indices, int64_t n_indices,
+                                                           const int64_t *__restrict__ cursor, int row_len,
+                                                           float *__restrict__ out_images, float *__restrict__ out_labels) {
+    const int64_t pos = ((cursor ? cursor[0] : 0) + blockIdx.x) % n_indices;
+    const int64_t src = indices ? (int64_t)indices[pos] : pos;
+    const float *s = images + src * row_len;
+    float *d = out_images + (int64_t)blockIdx.x * row_len;
+    if ((row_len & 3) == 0) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(s);
+        float4 *d4 = reinterpret_cast<float4 *>(d);
+        for (int i = threadIdx.x; i < row_len / 4; i += 256) d4[i] = s4[i];
+    } else {
+        for (int i = threadIdx.x; i < row_len; i += 256) d[i] = s[i];
+    }
+    if (threadIdx.x == 0) out_labels[blockIdx.x] = labels[src];
+}
+
+__global__ __launch_bounds__(256) void u8_to_unit_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (float)in[i] / 255.0f;  // data/mnist.rs:226
+}
+
+__global__ void log_step_kernel(const float *__restrict__ loss, const float *__restrict__ ncorrect, float *__restrict__ metrics,
+                                int64_t capacity, int64_t *__restrict__ state, int64_t advance) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int64_t s = state[0] % capacity;
+        metrics[2 * s] = loss ? loss[0] : 0.f;
+        metrics[2 * s + 1] = ncorrect ? ncorrect[0] : 0.f;
+        state[0] += 1;
+        state[1] += advance;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ x, size_t n, float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= scale;
+}
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" {
+
+int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v, const int64_t *d_offsets,
+                 const int32_t *d_has_grad, int n_tensors, int64_t total, int32_t *d_t, const float *d_lr, float beta1,
+                 float beta2, float eps, float weight_decay) {
+    TH_REQUIRE(ctx && d_params && d_grads && d_m && d_v && d_offsets && d_has_grad && d_t && d_lr, "th_adam_step: null argument");
+    TH_REQUIRE(n_tensors > 0 && total >= 0, "th_adam_step: bad sizes");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, ctx->stream, d_t, d_lr, beta1, beta2);
+    TH_LAUNCH_CHECK();
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((size_t)total, 256)), dim3(256), 0, ctx->stream, d_params, d_grads, d_m, d_v,
+                       d_offsets, d_has_grad, n_tensors, total, (const int32_t *)d_t, beta1, beta2, eps, weight_decay);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_sgd_step(th_ctx *ctx, float *d_params, const float *d_grads, const int64_t *d_offsets, const int32_t *d_has_grad,
+                int n_tensors, int64_t total, const float *d_lr) {
+    TH_REQUIRE(ctx && d_params && d_grads && d_offsets && d_has_grad && d_lr, "th_sgd_step: null argument");
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid((size_t)total, 256)), dim3(256), 0, ctx->stream, d_params, d_grads, d_offsets,
+                       d_has_grad, n_tensors, total, d_lr);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_gather_batch(th_ctx *ctx, const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
+                    const int64_t *d_cursor, int batch, int row_len, float *d_out_images, float *d_out_labels) {
+    TH_REQUIRE(ctx && d_images && d_labels && d_out_images && d_out_labels, "th_gather_batch: null argument");
+    TH_REQUIRE(batch >= 0 && row_len > 0 && n_indices > 0, "th_gather_batch: bad sizes");
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(batch), dim3(256), 0, ctx->stream, d_images, d_labels, d_indices, n_indices,
+                       d_cursor, row_len, d_out_images, d_out_labels);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_u8_to_unit_f32(th_ctx *ctx, const uint8_t *d_in, float *d_out, size_t n) {
+    TH_REQUIRE(ctx && (n == 0 || (d_in && d_out)), "th_u8_to_unit_f32: null argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(u8_to_unit_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ctx->stream, d_in, d_out, n);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_log_step(th_ctx *ctx, const float *d_loss, const float *d_ncorrect, float *d_metrics, int64_t capacity, int64_t *d_state,
+                int64_t advance) {
+    TH_REQUIRE(ctx && d_metrics && d_state && capacity > 0, "th_log_step: bad argument");
+    hipLaunchKernelGGL(log_step_kernel, dim3(1), dim3(64), 0, ctx->stream, d_loss, d_ncorrect, d_metrics, capacity, d_state, advance);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
+namespace th {
+int scale_inplace(th_ctx *ctx, float *d_x, size_t n, float scale) {
+    if (n == 0 || scale == 1.0f) return 0;
+    hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ctx->stream, d_x, n, scale);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace th

@@ -1,0 +1,453 @@
+// reduce.hip -- broadcast / reduction / layout kernels and the fused softmax
+// cross-entropy (src/tensor.rs:544-591,636-770,890-1088; src/loss.rs:101-195,
+// 271-290).  All HBM-bound; reductions use wave64 shuffles + a fixed-order LDS
+// combine (no atomics -> deterministic).
+#include "common.h"
+
+namespace th {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide sum for 256 threads; result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float *sh /* >= 4 floats */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __syncthreads();
+    return r;
+}
+
+// ---- 2-D transpose through a padded LDS tile (tensor.rs:544-566) ---------
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows,
+                                                        int cols) {
+    // out[j*rows + i] (=|+=) in[i*cols + j]; 64x64 tile, 65-float pitch
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+#pragma unroll
+    for (int r = ty; r < 64; r += 4) {
+        const int i = i0 + r, j = j0 + tx;
+        tile[r][tx] = (i < rows && j < cols) ? in[(long)i * cols + j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 64; r += 4) {
+        const int j = j0 + r, i = i0 + tx;
+        if (i < rows && j < cols) {
+            const long o = (long)j * rows + i;
+            if (ACCUM) out[o] += tile[tx][r];
+            else out[o] = tile[tx][r];
+        }
+    }
+}
+
+// ---- y[r,c] = x[r,c] + bias[c] (+relu)  (tensor.rs:658-663) -------------
+__global__ __launch_bounds__(256) void bias_add_rows_kernel(const float *__restrict__ x, const float *__restrict__ bias,
+                                                            float *__restrict__ y, long total, int cols, int relu) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = tid; i < total; i += stride) {
+        float v = x[i] + bias[i % cols];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[i] = v;
+    }
+}
+
+// ---- column sums of a [rows, cols] matrix --------------------------------
+// grid.x covers columns in chunks of 64; each block has 4 waves striding the
+// rows; lanes are consecutive columns (coalesced); fixed-order LDS combine.
+template <bool ACCUM, bool NEGATE>
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g, float *__restrict__ out, int rows,
+                                                     int cols) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = wave; r < rows; r += 4) s += g[(long)r * cols + c];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (NEGATE) tot = -tot;
+        if (ACCUM) out[c] += tot;
+        else out[c] = tot;
+    }
+}
+
+// ---- row-wise ops on [rows, cols]: one wave per row ----------------------
+enum RowOp { ROW_SUM = 0, ROW_SUM_NEG_ACCUM = 1 };
+
+template <int OP>
+__global__ __launch_bounds__(256) void rowsum_kernel(const float *__restrict__ x, float *__restrict__ out, int rows,
+                                                     int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += x[(long)row * cols + c];
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (OP == ROW_SUM) out[row] = s;
+        else out[row] -= s;  // tensor.rs:752-764: grad_r[row] -= sum
+    }
+}
+
+__global__ __launch_bounds__(256) void sub_rows_kernel(const float *__restrict__ x, const float *__restrict__ r,
+                                                       float *__restrict__ y, long total, int cols) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = tid; i < total; i += stride) y[i] = x[i] - r[i / cols];
+}
+
+// gin[r,c] += gout[r]  (BY_ROW) or gout[c]
+template <bool BY_ROW>
+__global__ __launch_bounds__(256) void bcast_accum_kernel(const float *__restrict__ gout, float *__restrict__ gin,
+                                                          long total, int cols) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = tid; i < total; i += stride) gin[i] += BY_ROW ? gout[i / cols] : gout[i % cols];
+}
+
+// ---- full reduction: two deterministic passes ---------------------------
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float *__restrict__ x, float *__restrict__ part, size_t n) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_final_kernel(const float *__restrict__ part, int nparts, float *__restrict__ out,
+                                                        float divisor) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) out[0] = s / divisor;
+}
+
+// ---- max / first-argmax along rows or columns (tensor.rs:1042-1066) ------
+// strict '>' starting from -inf: first maximum wins, NaN never wins, an
+// all-NaN (or all -inf) slice reports value -inf / index 0.
+__device__ __forceinline__ void argmax_combine(float &v, int &i, float ov, int oi) {
+    // keep the larger value; on ties keep the smaller index (first max)
+    if (ov > v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+    }
+}
+
+__global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ x, float *__restrict__ vmax,
+                                                     float *__restrict__ imax, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = x[(long)row * cols + c];
+        if (v > best) {
+            best = v;
+            bi = c;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        argmax_combine(best, bi, ov, oi);
+    }
+    if (lane == 0) {
+        if (vmax) vmax[row] = best;
+        if (imax) imax[row] = (bi == 0x7fffffff) ? 0.f : (float)bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x, float *__restrict__ vmax,
+                                                     float *__restrict__ imax, int rows, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int r = 0; r < rows; ++r) {
+        const float v = x[(long)r * cols + c];
+        if (v > best) {
+            best = v;
+            bi = r;
+        }
+    }
+    if (vmax) vmax[c] = best;
+    if (imax) imax[c] = (float)bi;
+}
+
+// ---- fused log-softmax + NLL + argmax (loss.rs:101-195, 271-290) ---------
+// One wave per row (classes strided over lanes), 4 rows per block.  The
+// per-row NLL terms go to `row_nll`; a second single-block kernel adds them
+// in a fixed tree order and scales by 1/B.
+__global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float *__restrict__ logits,
+                                                                const float *__restrict__ targets, int batch, int classes,
+                                                                float *__restrict__ logp, float *__restrict__ row_nll,
+                                                                float *__restrict__ argmax_out, float *__restrict__ row_hit) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= batch) return;
+    const float *x = logits + (long)row * classes;
+    // row max + first argmax (tensor.rs:1062)
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < classes; c += 64) {
+        const float v = x[c];
+        if (v > best) {
+            best = v;
+            bi = c;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        argmax_combine(best, bi, ov, oi);
+    }
+    if (bi == 0x7fffffff) bi = 0;
+    // sum exp(x - max)
+    float s = 0.f;
+    for (int c = lane; c < classes; c += 64) s += expf(x[c] - best);
+    s = wave_sum_all(s);
+    const float log_sum = logf(s);
+    const float tf = targets ? targets[row] : 0.f;
+    // Rust `as usize`: saturating, NaN -> 0
+    const long cls = (tf >= 0.f) ? (long)fminf(tf, 2147483520.f) : 0;
+    for (int c = lane; c < classes; c += 64) {
+        const float lp = (x[c] - best) - log_sum;  // loss.rs:117-125
+        if (logp) logp[(long)row * classes + c] = lp;
+        if (row_nll && c == cls) row_nll[row] = -lp;
+    }
+    if (lane == 0) {
+        if (row_nll && cls >= classes) row_nll[row] = NAN;  // the reference panics (loss.rs:161)
+        if (argmax_out) argmax_out[row] = (float)bi;
+        if (row_hit) row_hit[row] = (fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;  // loss.rs:283
+    }
+}
+
+__global__ __launch_bounds__(256) void xent_finish_kernel(const float *__restrict__ row_nll, const float *__restrict__ row_hit,
+                                                          int batch, float *__restrict__ loss, float *__restrict__ ncorrect) {
+    __shared__ float sh[4];
+    float s = 0.f, h = 0.f;
+    for (int i = threadIdx.x; i < batch; i += 256) {
+        s += row_nll[i];
+        if (row_hit) h += row_hit[i];
+    }
+    s = block_sum_256(s, sh);
+    h = block_sum_256(h, sh);
+    if (threadIdx.x == 0) {
+        loss[0] = s / (float)batch;  // loss.rs:164
+        if (ncorrect) ncorrect[0] = h;
+    }
+}
+
+// dlogits[i,c] += (exp(logp[i,c]) - [c == t_i]) * (g0 / B)   (loss.rs:174-191)
+__global__ __launch_bounds__(256) void softmax_xent_bwd_kernel(const float *__restrict__ logp, const float *__restrict__ targets,
+                                                               const float *__restrict__ g0, int batch, int classes,
+                                                               float *__restrict__ dlogits, int accumulate) {
+    const long total = (long)batch * classes;
+    const float scale = g0[0] / (float)batch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int row = (int)(i / classes), c = (int)(i % classes);
+        const float tf = targets[row];
+        const long cls = (tf >= 0.f) ? (long)fminf(tf, 2147483520.f) : 0;
+        float gval = expf(logp[i]);
+        if (c == cls) gval -= 1.0f;
+        dlogits[i] = accumulate ? dlogits[i] + gval * scale : gval * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void accuracy_count_kernel(const float *__restrict__ am, const float *__restrict__ t, int n,
+                                                             float *__restrict__ out) {
+    __shared__ float sh[4];
+    float h = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) h += (fabsf(am[i] - t[i]) < 1e-6f) ? 1.f : 0.f;
+    h = block_sum_256(h, sh);
+    if (threadIdx.x == 0) out[0] = h;
+}
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" {
+
+int th_transpose2d(th_ctx *ctx, const float *d_in, float *d_out, int rows, int cols) {
+    TH_REQUIRE(ctx && d_in && d_out && rows >= 0 && cols >= 0, "th_transpose2d: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    hipLaunchKernelGGL(transpose_kernel<false>, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, ctx->stream,
+                       d_in, d_out, rows, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_transpose2d_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int rows, int cols) {
+    // gin[i*cols + j] += gout[j*rows + i]: the transpose of a [cols, rows] matrix, accumulated
+    TH_REQUIRE(ctx && d_gout && d_gin && rows >= 0 && cols >= 0, "th_transpose2d_bwd: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    hipLaunchKernelGGL(transpose_kernel<true>, dim3(ceil_div(rows, 64), ceil_div(cols, 64)), dim3(256), 0, ctx->stream,
+                       d_gout, d_gin, cols, rows);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_bias_add_rows(th_ctx *ctx, const float *d_x, const float *d_bias, float *d_y, int rows, int cols, int relu) {
+    TH_REQUIRE(ctx && d_x && d_bias && d_y && rows >= 0 && cols >= 0, "th_bias_add_rows: bad argument");
+    const long total = (long)rows * cols;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(bias_add_rows_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_bias, d_y, total,
+                       cols, relu);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_colsum_accum(th_ctx *ctx, const float *d_g, float *d_gb, int rows, int cols) {
+    TH_REQUIRE(ctx && d_g && d_gb && rows >= 0 && cols >= 0, "th_colsum_accum: bad argument");
+    if (cols == 0) return 0;
+    hipLaunchKernelGGL((colsum_kernel<true, false>), dim3(ceil_div(cols, 64)), dim3(256), 0, ctx->stream, d_g, d_gb, rows, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_colsum(th_ctx *ctx, const float *d_x, float *d_y, int rows, int cols) {
+    TH_REQUIRE(ctx && d_x && d_y && rows >= 0 && cols >= 0, "th_colsum: bad argument");
+    if (cols == 0) return 0;
+    hipLaunchKernelGGL((colsum_kernel<false, false>), dim3(ceil_div(cols, 64)), dim3(256), 0, ctx->stream, d_x, d_y, rows, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_sub_rows(th_ctx *ctx, const float *d_x, const float *d_r, float *d_y, int rows, int cols) {
+    TH_REQUIRE(ctx && d_x && d_r && d_y && rows >= 0 && cols >= 0, "th_sub_rows: bad argument");
+    const long total = (long)rows * cols;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(sub_rows_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_r, d_y, total, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_rowsum_neg_accum(th_ctx *ctx, const float *d_g, float *d_gr, int rows, int cols) {
+    TH_REQUIRE(ctx && d_g && d_gr && rows >= 0 && cols >= 0, "th_rowsum_neg_accum: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rowsum_kernel<ROW_SUM_NEG_ACCUM>, dim3(ceil_div(rows, 4)), dim3(256), 0, ctx->stream, d_g, d_gr, rows, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_rowsum(th_ctx *ctx, const float *d_x, float *d_y, int rows, int cols) {
+    TH_REQUIRE(ctx && d_x && d_y && rows >= 0 && cols >= 0, "th_rowsum: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rowsum_kernel<ROW_SUM>, dim3(ceil_div(rows, 4)), dim3(256), 0, ctx->stream, d_x, d_y, rows, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_rowsum_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int rows, int cols) {
+    TH_REQUIRE(ctx && d_gout && d_gin && rows >= 0 && cols >= 0, "th_rowsum_bwd: bad argument");
+    const long total = (long)rows * cols;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(bcast_accum_kernel<true>, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_gout, d_gin, total, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_colsum_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int rows, int cols) {
+    TH_REQUIRE(ctx && d_gout && d_gin && rows >= 0 && cols >= 0, "th_colsum_bwd: bad argument");
+    const long total = (long)rows * cols;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(bcast_accum_kernel<false>, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_gout, d_gin, total, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_sum_all(th_ctx *ctx, const float *d_x, float *d_out1, size_t n, float divisor) {
+    TH_REQUIRE(ctx && d_out1 && (n == 0 || d_x), "th_sum_all: bad argument");
+    int nparts = (int)((n + 256 * 16 - 1) / (256 * 16));
+    if (nparts < 1) nparts = 1;
+    if (nparts > 1024) nparts = 1024;
+    void *part = nullptr;
+    if (th_malloc(ctx, nparts * sizeof(float), &part)) return 1;
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(nparts), dim3(256), 0, ctx->stream, d_x, (float *)part, n);
+    TH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float *)part, nparts, d_out1, divisor);
+    TH_LAUNCH_CHECK();
+    return th_free(ctx, part);
+}
+
+int th_rowmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols) {
+    TH_REQUIRE(ctx && d_x && rows >= 0 && cols >= 0, "th_rowmax: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rowmax_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ctx->stream, d_x, d_max, d_argmax_f32, rows, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols) {
+    TH_REQUIRE(ctx && d_x && rows >= 0 && cols >= 0, "th_colmax: bad argument");
+    if (cols == 0) return 0;
+    hipLaunchKernelGGL(colmax_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, ctx->stream, d_x, d_max, d_argmax_f32, rows, cols);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_softmax_xent_fwd(th_ctx *ctx, const float *d_logits, const float *d_targets, int batch, int classes, float *d_logp,
+                        float *d_loss, float *d_argmax, float *d_ncorrect) {
+    TH_REQUIRE(ctx && d_logits && d_targets && d_loss && batch > 0 && classes > 0, "th_softmax_xent_fwd: bad argument");
+    void *tmp = nullptr;
+    if (th_malloc(ctx, 2 * (size_t)batch * sizeof(float), &tmp)) return 1;
+    float *row_nll = (float *)tmp, *row_hit = row_nll + batch;
+    hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3(ceil_div(batch, 4)), dim3(256), 0, ctx->stream, d_logits, d_targets, batch,
+                       classes, d_logp, row_nll, d_argmax, row_hit);
+    TH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(xent_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float *)row_nll,
+                       d_ncorrect ? (const float *)row_hit : (const float *)nullptr, batch, d_loss, d_ncorrect);
+    TH_LAUNCH_CHECK();
+    return th_free(ctx, tmp);
+}
+
+int th_softmax_xent_bwd(th_ctx *ctx, const float *d_logp, const float *d_targets, const float *d_g0, int batch, int classes,
+                        float *d_dlogits, int accumulate) {
+    TH_REQUIRE(ctx && d_logp && d_targets && d_g0 && d_dlogits && batch > 0 && classes > 0, "th_softmax_xent_bwd: bad argument");
+    const long total = (long)batch * classes;
+    hipLaunchKernelGGL(softmax_xent_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_logp, d_targets, d_g0,
+                       batch, classes, d_dlogits, accumulate);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_log_softmax_fwd(th_ctx *ctx, const float *d_x, float *d_logp, int rows, int cols) {
+    TH_REQUIRE(ctx && d_x && d_logp && rows >= 0 && cols > 0, "th_log_softmax_fwd: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ctx->stream, d_x,
+                       (const float *)nullptr, rows, cols, d_logp, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_accuracy_count(th_ctx *ctx, const float *d_argmax, const float *d_targets, int n, float *d_ncorrect) {
+    TH_REQUIRE(ctx && d_argmax && d_targets && d_ncorrect && n >= 0, "th_accuracy_count: bad argument");
+    hipLaunchKernelGGL(accuracy_count_kernel, dim3(1), dim3(256), 0, ctx->stream, d_argmax, d_targets, n, d_ncorrect);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,562 @@
+"""Per-kernel parity: every entry point of include/taper_hip.h on the hot path
+is called through the C ABI on the GPU and compared with the CPU oracle on the
+same seeded inputs.  Bar: bit-exact for index / argmax / pool-index work,
+fp32 within 1e-4 relative (north_star) for everything else."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from taper_amd import hip
+    c = hip.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def close(a, b, rtol=RTOL, atol=1e-6):
+    """relative + absolute criterion; the scale of the reference sets the floor near zero"""
+    b = np.asarray(b)
+    scale = float(np.abs(b).max()) if b.size else 0.0
+    np.testing.assert_allclose(np.asarray(a).reshape(b.shape), b, rtol=rtol, atol=atol + rtol * 1e-2 * scale)
+
+
+# ------------------------------------------------------------------ sgemm
+MLP_SHAPES = [  # (ta, tb, m, n, k): the hot-path GEMMs of BASELINE configs
+    (0, 0, 64, 128, 784), (0, 0, 64, 10, 128), (1, 0, 784, 128, 64), (1, 0, 128, 10, 64), (0, 1, 64, 128, 10),
+    (0, 1, 128, 784, 10), (0, 0, 256, 128, 128), (0, 0, 1024, 10, 64),
+]
+ODD_SHAPES = [(0, 0, 1, 1, 1), (0, 0, 2, 3, 2), (1, 1, 17, 5, 33), (0, 1, 33, 65, 129), (1, 0, 130, 70, 9),
+              (0, 0, 16, 16, 2000), (1, 0, 40, 24, 4100), (0, 0, 3, 200, 7)]
+BIG_SHAPES = [(0, 0, 1024, 1024, 256), (0, 1, 1024, 1152, 96), (1, 0, 1280, 1024, 64), (1, 1, 1024, 1024, 40),
+              (0, 0, 1100, 1030, 70)]
+
+
+@pytest.mark.parametrize("ta,tb,m,n,k", MLP_SHAPES + ODD_SHAPES + BIG_SHAPES)
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (1.0, 1.0), (0.5, -2.0)])
+def test_sgemm(ctx, O, ta, tb, m, n, k, alpha, beta):
+    if (m * n * k > 5e7) and (alpha, beta) == (0.5, -2.0):
+        pytest.skip("one big case per variant is enough")
+    rng = np.random.default_rng(m * 31 + n * 7 + k)
+    a = rng.uniform(-1, 1, (k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k) if tb else (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    ref = c0.copy()
+    O.sgemm_rowmajor(ta, tb, m, n, k, alpha, a, b, beta, ref)
+    da, db, dc = ctx.upload(a), ctx.upload(b), ctx.upload(c0)
+    ctx.call("th_sgemm", ta, tb, m, n, k, alpha, da, db, beta, dc)
+    got = ctx.download(dc, (m, n))
+    # fp32 accumulation-order tolerance scales with sqrt(k)
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=2e-6 * np.sqrt(k) * max(1.0, abs(alpha)) + 1e-6)
+
+
+def test_sgemm_beta0_ignores_nan_c(ctx):
+    """beta == 0 overwrites C without reading it (matrixmultiply / gemm.rs semantics)"""
+    a = np.ones((32, 8), np.float32)
+    b = np.ones((8, 32), np.float32)
+    c = np.full((32, 32), np.nan, np.float32)
+    dc = ctx.upload(c)
+    ctx.call("th_sgemm", 0, 0, 32, 32, 8, 1.0, ctx.upload(a), ctx.upload(b), 0.0, dc)
+    np.testing.assert_array_equal(ctx.download(dc, (32, 32)), np.full((32, 32), 8.0, np.float32))
+
+
+def test_sgemm_transpose_detecting(ctx):
+    """A = I with an ASYMMETRIC B catches a swapped C write (guide: always A=I-check)"""
+    n = 256
+    a = np.eye(n, dtype=np.float32)
+    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 97) + np.arange(n, dtype=np.float32)[:, None] * 0.5
+    dc = ctx.empty(n * n)
+    ctx.call("th_sgemm", 0, 0, n, n, n, 1.0, ctx.upload(a), ctx.upload(b), 0.0, dc)
+    np.testing.assert_array_equal(ctx.download(dc, (n, n)), b)
+    big = 1024  # through the 128x128 MFMA kernel
+    a = np.eye(big, dtype=np.float32)
+    b = ((np.arange(big * big, dtype=np.int64).reshape(big, big) * 7919) % 1013).astype(np.float32)
+    dc = ctx.empty(big * big)
+    ctx.call("th_sgemm", 0, 0, big, big, big, 1.0, ctx.upload(a), ctx.upload(b), 0.0, dc)
+    np.testing.assert_array_equal(ctx.download(dc, (big, big)), b)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0)])
+def test_sgemm_4096_sampled_rows(ctx, ta, tb):
+    """BASELINE configs[4] size; the oracle is too slow at 137 GFLOP, so 48 random
+    rows are checked against float64 numpy and the rest through linearity."""
+    n = 4096
+    rng = np.random.default_rng(4096 + ta * 2 + tb)
+    a = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    da, db, dc = ctx.upload(a), ctx.upload(b), ctx.empty(n * n)
+    ctx.call("th_sgemm", ta, tb, n, n, n, 1.0, da, db, 0.0, dc)
+    got = ctx.download(dc, (n, n))
+    rows = rng.choice(n, 48, replace=False)
+    opa = (a.T if ta else a)[rows].astype(np.float64)
+    opb = (b.T if tb else b).astype(np.float64)
+    np.testing.assert_allclose(got[rows], opa @ opb, rtol=RTOL, atol=2e-4)
+    # linearity: C(2A, B) with beta=-1 on top of the first result gives C again
+    da2 = ctx.upload(2 * a)
+    ctx.call("th_sgemm", ta, tb, n, n, n, 1.0, da2, db, -1.0, dc)
+    np.testing.assert_allclose(ctx.download(dc, (n, n)), got, rtol=RTOL, atol=2e-4)
+
+
+# ------------------------------------------------------------------ linear
+@pytest.mark.parametrize("batch,inf,outf", [(64, 784, 128), (64, 128, 10), (32, 784, 128), (1, 5, 3), (128, 128, 64), (256, 3136, 10)])
+@pytest.mark.parametrize("relu", [0, 1])
+def test_linear_fwd_bwd(ctx, O, batch, inf, outf, relu):
+    rng = np.random.default_rng(batch + inf + outf)
+    x = rng.uniform(0, 1, (batch, inf)).astype(np.float32)
+    w = rng.uniform(-0.1, 0.1, (outf, inf)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, outf).astype(np.float32)
+    dy = rng.uniform(-1, 1, (batch, outf)).astype(np.float32)
+    # oracle: the reference's three-node chain (nn.rs:54-60)
+    O.Tape.reset()
+    O.Tape.set_zero_sentinel(False)
+    xt, wt, bt = O.Tensor(x).requires_grad(), O.Tensor(w).requires_grad(), O.Tensor(b).requires_grad()
+    pre = xt.matmul(wt.transpose()).add_broadcast(bt)
+    out = pre.relu() if relu else pre
+    (out * O.Tensor(dy)).sum(None, False).backward()
+    O.Tape.set_zero_sentinel(True)
+    dx_, dw_, db_, dyd = ctx.upload(x), ctx.upload(w), ctx.upload(b), ctx.upload(dy)
+    y = ctx.empty(batch * outf)
+    ctx.call("th_linear_fwd", dx_, dw_, db_, y, batch, inf, outf, relu)
+    yv = ctx.download(y, (batch, outf))
+    close(yv, out.data())
+    dz = dy * (yv > 0) if relu else dy
+    dzd = ctx.upload(dz.astype(np.float32))
+    gx, gw, gb = ctx.empty(batch * inf), ctx.empty(outf * inf), ctx.empty(outf)
+    ctx.call("th_linear_bwd", dx_, dw_, dzd, gx, gw, gb, batch, inf, outf, 0)   # grads were None: overwrite
+    close(ctx.download(gx, (batch, inf)), xt.grad())
+    close(ctx.download(gw, (outf, inf)), wt.grad())
+    close(ctx.download(gb, (outf,)), bt.grad())
+    ctx.call("th_linear_bwd", dx_, dw_, dzd, gx, gw, gb, batch, inf, outf, 7)   # accumulate on top
+    close(ctx.download(gw, (outf, inf)), 2 * wt.grad())
+    close(ctx.download(gx, (batch, inf)), 2 * xt.grad())
+    close(ctx.download(gb, (outf,)), 2 * bt.grad())
+    O.Tape.reset()
+
+
+# ------------------------------------------------------------------ element-wise
+@pytest.mark.parametrize("n", [1, 3, 4, 1000, 100_003, 1 << 20])
+def test_elementwise(ctx, n):
+    rng = np.random.default_rng(n)
+    a = rng.uniform(-2, 2, n).astype(np.float32)
+    b = rng.uniform(0.5, 2, n).astype(np.float32)
+    g = rng.uniform(-1, 1, n).astype(np.float32)
+    da, db, dg, out = ctx.upload(a), ctx.upload(b), ctx.upload(g), ctx.empty(n)
+    for name, ref in [("th_add", a + b), ("th_sub", a - b), ("th_mul", a * b), ("th_div", a / b)]:
+        ctx.call(name, da, db, out, n)
+        np.testing.assert_array_equal(ctx.download(out, n), ref)  # IEEE basic ops: bit-exact
+    ctx.call("th_relu_fwd", da, out, n)
+    np.testing.assert_array_equal(ctx.download(out, n), np.maximum(a, 0))
+    acc0 = rng.uniform(-1, 1, n).astype(np.float32)
+    acc = ctx.upload(acc0)
+    ctx.call("th_relu_bwd", da, dg, acc, n, 1)
+    np.testing.assert_array_equal(ctx.download(acc, n), acc0 + np.where(a > 0, g, 0).astype(np.float32))
+    ctx.call("th_relu_bwd", da, dg, acc, n, 0)
+    np.testing.assert_array_equal(ctx.download(acc, n), np.where(a > 0, g, 0).astype(np.float32))
+    acc = ctx.upload(acc0)
+    ctx.call("th_axpy", 1.0, dg, acc, n)
+    np.testing.assert_array_equal(ctx.download(acc, n), acc0 + g)
+    ctx.call("th_axpy", -1.0, dg, acc, n)
+    np.testing.assert_array_equal(ctx.download(acc, n), (acc0 + g) + np.float32(-1.0) * g)
+    acc = ctx.upload(acc0)
+    ctx.call("th_mul_bwd", dg, db, acc, n)
+    np.testing.assert_array_equal(ctx.download(acc, n), acc0 + g * b)
+    # transcendental ops: device libm vs host libm within a few ulp
+    ctx.call("th_exp_fwd", da, out, n)
+    np.testing.assert_allclose(ctx.download(out, n), np.exp(a), rtol=1e-6)
+    ctx.call("th_log_fwd", db, out, n)
+    np.testing.assert_allclose(ctx.download(out, n), np.log(b), rtol=1e-6, atol=1e-7)
+    ctx.call("th_sigmoid_fwd", da, out, n)
+    sig = np.where(a > 0, 1 / (1 + np.exp(-a.astype(np.float64))), np.exp(a.astype(np.float64)) / (1 + np.exp(a.astype(np.float64))))
+    np.testing.assert_allclose(ctx.download(out, n), sig, rtol=1e-6)
+    s = ctx.download(out, n)
+    acc = ctx.upload(acc0)
+    ctx.call("th_sigmoid_bwd", out, dg, acc, n)
+    np.testing.assert_allclose(ctx.download(acc, n), acc0 + g * s * (1 - s), rtol=1e-6, atol=1e-7)
+    ctx.call("th_pow_fwd", db, 0.5, out, n)
+    np.testing.assert_allclose(ctx.download(out, n), np.sqrt(b), rtol=1e-6)
+    acc = ctx.upload(acc0)
+    ga, gb = ctx.upload(acc0), ctx.upload(acc0)
+    ctx.call("th_div_bwd", dg, da, db, ga, gb, n)
+    np.testing.assert_allclose(ctx.download(ga, n), acc0 + g / b, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ctx.download(gb, n), acc0 - g * a / (b * b), rtol=1e-5, atol=1e-6)
+
+
+def test_relu_nan_matches_maxps(ctx):
+    """_mm_max_ps(v, 0) returns 0 for NaN (ops.rs:328); -0.0 -> +0.0"""
+    a = np.array([np.nan, -0.0, 0.0, -1.0, 2.0, np.inf, -np.inf, 1e-45], np.float32)
+    out = ctx.empty(a.size)
+    ctx.call("th_relu_fwd", ctx.upload(a), out, a.size)
+    got = ctx.download(out, a.size)
+    np.testing.assert_array_equal(got, np.array([0, 0, 0, 0, 2, np.inf, 0, 1e-45], np.float32))
+    assert not np.signbit(got[1])
+
+
+# ------------------------------------------------------------------ layout / broadcast / reduce
+@pytest.mark.parametrize("rows,cols", [(128, 784), (10, 128), (1, 7), (65, 63), (4096, 512)])
+def test_transpose(ctx, rows, cols):
+    rng = np.random.default_rng(rows * cols)
+    x = rng.uniform(-1, 1, (rows, cols)).astype(np.float32)
+    out = ctx.empty(rows * cols)
+    ctx.call("th_transpose2d", ctx.upload(x), out, rows, cols)
+    np.testing.assert_array_equal(ctx.download(out, (cols, rows)), x.T)
+    gout = rng.uniform(-1, 1, (cols, rows)).astype(np.float32)
+    gin0 = rng.uniform(-1, 1, (rows, cols)).astype(np.float32)
+    gin = ctx.upload(gin0)
+    ctx.call("th_transpose2d_bwd", ctx.upload(gout), gin, rows, cols)
+    np.testing.assert_array_equal(ctx.download(gin, (rows, cols)), gin0 + gout.T)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 128), (64, 10), (1, 1), (1000, 10), (7, 300), (4096, 4096)])
+def test_bias_colsum_rowops(ctx, O, rows, cols):
+    rng = np.random.default_rng(rows + cols)
+    x = rng.uniform(-1, 1, (rows, cols)).astype(np.float32)
+    bias = rng.uniform(-1, 1, cols).astype(np.float32)
+    r = rng.uniform(-1, 1, rows).astype(np.float32)
+    dx, dbias, dr, out = ctx.upload(x), ctx.upload(bias), ctx.upload(r), ctx.empty(rows * cols)
+    ctx.call("th_bias_add_rows", dx, dbias, out, rows, cols, 0)
+    np.testing.assert_array_equal(ctx.download(out, (rows, cols)), x + bias)
+    ctx.call("th_bias_add_rows", dx, dbias, out, rows, cols, 1)
+    np.testing.assert_array_equal(ctx.download(out, (rows, cols)), np.maximum(x + bias, 0))
+    ctx.call("th_sub_rows", dx, dr, out, rows, cols)
+    np.testing.assert_array_equal(ctx.download(out, (rows, cols)), x - r[:, None])
+    # sums: order differs from the reference's sequential loop -> tolerance, float64 truth
+    x64 = x.astype(np.float64)
+    tol = dict(rtol=RTOL, atol=1e-6 * max(rows, cols))
+    gb0 = rng.uniform(-1, 1, cols).astype(np.float32)
+    gb = ctx.upload(gb0)
+    ctx.call("th_colsum_accum", dx, gb, rows, cols)
+    np.testing.assert_allclose(ctx.download(gb, cols), gb0 + x64.sum(0), **tol)
+    ctx.call("th_colsum", dx, gb, rows, cols)
+    np.testing.assert_allclose(ctx.download(gb, cols), x64.sum(0), **tol)
+    rs = ctx.empty(rows)
+    ctx.call("th_rowsum", dx, rs, rows, cols)
+    np.testing.assert_allclose(ctx.download(rs, rows), x64.sum(1), **tol)
+    gr = ctx.upload(r)
+    ctx.call("th_rowsum_neg_accum", dx, gr, rows, cols)
+    np.testing.assert_allclose(ctx.download(gr, rows), r - x64.sum(1), **tol)
+    s = ctx.empty(1)
+    ctx.call("th_sum_all", dx, s, rows * cols, 1.0)
+    np.testing.assert_allclose(ctx.download(s, 1)[0], x64.sum(), rtol=RTOL, atol=1e-6 * rows * cols ** 0.5)
+    ctx.call("th_sum_all", dx, s, rows * cols, float(rows * cols))
+    np.testing.assert_allclose(ctx.download(s, 1)[0], x64.mean(), rtol=RTOL, atol=1e-6)
+    g0 = rng.uniform(-1, 1, (rows, cols)).astype(np.float32)
+    gin = ctx.upload(g0)
+    ctx.call("th_rowsum_bwd", dr, gin, rows, cols)
+    np.testing.assert_array_equal(ctx.download(gin, (rows, cols)), g0 + r[:, None])
+    gin = ctx.upload(g0)
+    ctx.call("th_colsum_bwd", dbias, gin, rows, cols)
+    np.testing.assert_array_equal(ctx.download(gin, (rows, cols)), g0 + bias)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 10), (3, 4), (1, 1), (1024, 10), (5, 1000), (2, 64), (2, 65)])
+def test_rowmax_colmax_bit_exact(ctx, O, rows, cols):
+    rng = np.random.default_rng(rows * 1000 + cols)
+    # few distinct values -> many ties: the first maximum must win (tensor.rs:1062)
+    x = rng.integers(0, 4, (rows, cols)).astype(np.float32)
+    if rows > 2 and cols > 2:
+        x[1, :] = np.nan      # all-NaN row -> value -inf, index 0
+        x[2, 0] = np.nan      # NaN never wins
+    xt = O.Tensor(x)
+    v, i = xt.max(1)
+    dv, di = ctx.empty(rows), ctx.empty(rows)
+    ctx.call("th_rowmax", ctx.upload(x), dv, di, rows, cols)
+    np.testing.assert_array_equal(ctx.download(di, rows), i.data().reshape(-1))
+    np.testing.assert_array_equal(ctx.download(dv, rows), v.data().reshape(-1))
+    v, i = xt.max(0)
+    dv, di = ctx.empty(cols), ctx.empty(cols)
+    ctx.call("th_colmax", ctx.upload(x), dv, di, rows, cols)
+    np.testing.assert_array_equal(ctx.download(di, cols), i.data().reshape(-1))
+    np.testing.assert_array_equal(ctx.download(dv, cols), v.data().reshape(-1))
+
+
+# ------------------------------------------------------------------ softmax cross-entropy
+@pytest.mark.parametrize("batch,classes", [(64, 10), (128, 10), (256, 10), (1024, 10), (1, 2), (7, 3), (32, 100), (5, 1)])
+def test_softmax_xent(ctx, O, batch, classes):
+    rng = np.random.default_rng(batch * 17 + classes)
+    logits = (rng.standard_normal((batch, classes)) * 3).astype(np.float32)
+    if batch > 4:
+        logits[3] = 1000.0 + np.arange(classes)        # tests/smoke.rs:504-523 stability case
+        logits[4] = np.round(logits[4])                # ties for the argmax
+    targets = rng.integers(0, classes, batch).astype(np.float32)
+    O.Tape.reset()
+    lt = O.Tensor(logits).requires_grad()
+    tt = O.Tensor(targets)
+    loss = O.cross_entropy_loss(lt, tt)
+    O.Tape.set_zero_sentinel(False)
+    loss.backward()
+    O.Tape.set_zero_sentinel(True)
+    ref_logp = O.log_softmax(O.Tensor(logits)).data()
+    ref_am = O.Tensor(logits).argmax(1).data().reshape(-1)
+    ref_acc = O.accuracy(O.Tensor(logits), tt)
+    dl, dt = ctx.upload(logits), ctx.upload(targets)
+    logp, dloss, am, nc = ctx.empty(batch * classes), ctx.empty(1), ctx.empty(batch), ctx.empty(1)
+    ctx.call("th_softmax_xent_fwd", dl, dt, batch, classes, logp, dloss, am, nc)
+    close(ctx.download(logp, (batch, classes)), ref_logp, atol=1e-5)
+    np.testing.assert_allclose(ctx.download(dloss, 1)[0], loss.data()[0], rtol=RTOL, atol=1e-6)
+    np.testing.assert_array_equal(ctx.download(am, batch), ref_am)                 # index work: bit-exact
+    assert ctx.download(nc, 1)[0] == round(ref_acc * batch)
+    g0 = ctx.upload(np.ones(1, np.float32))
+    dlog = ctx.empty(batch * classes)
+    ctx.call("th_softmax_xent_bwd", logp, dt, g0, batch, classes, dlog, 0)
+    close(ctx.download(dlog, (batch, classes)), lt.grad(), atol=1e-7)
+    ctx.call("th_softmax_xent_bwd", logp, dt, g0, batch, classes, dlog, 1)
+    close(ctx.download(dlog, (batch, classes)), 2 * lt.grad(), atol=1e-7)
+    lp2 = ctx.empty(batch * classes)
+    ctx.call("th_log_softmax_fwd", dl, lp2, batch, classes)
+    close(ctx.download(lp2, (batch, classes)), ref_logp, atol=1e-5)
+    cnt = ctx.empty(1)
+    ctx.call("th_accuracy_count", am, dt, batch, cnt)
+    assert ctx.download(cnt, 1)[0] == round(ref_acc * batch)
+    O.Tape.reset()
+
+
+# ------------------------------------------------------------------ conv / pool
+CONV_CASES = [  # n, c_in, h, w, c_out, pad  (reference CNN layers at a small batch + edge cases)
+    (4, 1, 28, 28, 32, 1), (3, 32, 28, 28, 32, 1), (3, 32, 14, 14, 64, 1), (2, 64, 14, 14, 64, 1), (6, 64, 7, 7, 128, 1),
+    (1, 3, 5, 5, 2, 1), (2, 5, 9, 6, 7, 1), (2, 4, 8, 8, 20, 0), (1, 1, 3, 3, 1, 0), (7, 9, 7, 7, 17, 1),
+]
+
+
+@pytest.mark.parametrize("n,c_in,h,w,c_out,pad", CONV_CASES)
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("relu", [0, 1])
+def test_conv3x3_fwd(ctx, O, n, c_in, h, w, c_out, pad, layout, relu):
+    rng = np.random.default_rng(n + c_in * 3 + h * 5 + c_out * 7 + pad)
+    x = rng.uniform(-1, 1, (n, c_in, h, w)).astype(np.float32)
+    wt = rng.uniform(-0.5, 0.5, (c_out, c_in, 3, 3)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, c_out).astype(np.float32)
+    xt, wtt, bt = O.Tensor(x), O.Tensor(wt), O.Tensor(b)
+    if layout == 0:   # the live reference path: im2col + reinterpreted weight (tensor.rs:1221-1285, Q3)
+        ref = (xt.conv2d_relu if relu else xt.conv2d)(wtt, bt, (1, 1), (pad, pad), (1, 1))
+    else:             # the reference's direct kernel with standard weights (tensor.rs:1287-1376)
+        ref = xt.conv2d_direct_3x3(wtt, bt, (1, 1), (pad, pad))
+        ref = ref.relu() if relu else ref
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    assert ref.shape() == (n, c_out, ho, wo)
+    y = ctx.empty(n * c_out * ho * wo)
+    ctx.call("th_conv3x3_fwd", ctx.upload(x), ctx.upload(wt), ctx.upload(b), y, n, c_in, h, w, c_out, pad, layout, relu)
+    close(ctx.download(y, ref.shape()), ref.data(), atol=1e-5)
+    # no bias
+    y2 = ctx.empty(n * c_out * ho * wo)
+    ctx.call("th_conv3x3_fwd", ctx.upload(x), ctx.upload(wt), None, y2, n, c_in, h, w, c_out, pad, layout, 0)
+    ref2 = xt.conv2d(wtt, None, (1, 1), (pad, pad), (1, 1)) if layout == 0 else xt.conv2d_direct_3x3(wtt, None, (1, 1), (pad, pad))
+    close(ctx.download(y2, ref2.shape()), ref2.data(), atol=1e-5)
+
+
+@pytest.mark.parametrize("n,c_in,h,w,c_out", [(2, 1, 6, 6, 4), (3, 8, 7, 7, 16), (2, 5, 4, 9, 3)])
+def test_conv1x1_taper_layout(ctx, O, n, c_in, h, w, c_out):
+    """Q4: the reference's 1x1 path reinterprets the NCHW buffer as [N*H*W, C]"""
+    rng = np.random.default_rng(n + c_in + c_out)
+    x = rng.uniform(-1, 1, (n, c_in, h, w)).astype(np.float32)
+    wt = rng.uniform(-0.5, 0.5, (c_out, c_in, 1, 1)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, c_out).astype(np.float32)
+    ref = O.Tensor(x).conv2d(O.Tensor(wt), O.Tensor(b), (1, 1), (0, 0), (1, 1))
+    y = ctx.empty(n * c_out * h * w)
+    ctx.call("th_conv1x1_fwd", ctx.upload(x), ctx.upload(wt), ctx.upload(b), y, n, c_in, h, w, c_out, 0, 0)
+    close(ctx.download(y, ref.shape()), ref.data(), atol=1e-5)
+    # standard layout = a true per-pixel channel mix
+    ctx.call("th_conv1x1_fwd", ctx.upload(x), ctx.upload(wt), ctx.upload(b), y, n, c_in, h, w, c_out, 1, 0)
+    std = np.einsum("oc,nchw->nohw", wt[:, :, 0, 0].astype(np.float64), x.astype(np.float64)) + b[None, :, None, None]
+    close(ctx.download(y, std.shape), std, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,c_in,h,w,c_out", [(3, 4, 8, 8, 5), (2, 32, 14, 14, 32), (4, 1, 28, 28, 8), (2, 16, 7, 7, 24)])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_conv3x3_bwd_full_mode(ctx, O, n, c_in, h, w, c_out, layout):
+    """full_backward extension (not in the reference, Q2): checked against the oracle's
+    differentiable im2col chain (layout 0) / the same chain on re-laid-out weights."""
+    rng = np.random.default_rng(n * 3 + c_in + c_out)
+    x = rng.uniform(-1, 1, (n, c_in, h, w)).astype(np.float32)
+    wt = rng.uniform(-0.5, 0.5, (c_out, c_in, 3, 3)).astype(np.float32)
+    gy = rng.uniform(-1, 1, (n, c_out, h, w)).astype(np.float32)
+    k = c_in * 9
+    # express a standard-layout filter in taper's layout so the oracle chain can differentiate it
+    w_taper = wt if layout == 0 else np.ascontiguousarray(wt.reshape(c_out, k).T).reshape(c_out, c_in, 3, 3)
+    O.Tape.reset()
+    O.Tape.set_zero_sentinel(False)
+    xt, wtt = O.Tensor(x).requires_grad(), O.Tensor(w_taper).requires_grad()
+    out = xt.conv2d(wtt, None, (1, 1), (1, 1), (1, 1), mode=1)
+    (out * O.Tensor(gy)).sum(None, False).backward()
+    O.Tape.set_zero_sentinel(True)
+    gx_ref = xt.grad()
+    gw_ref = wtt.grad() if layout == 0 else np.ascontiguousarray(wtt.grad().reshape(k, c_out).T).reshape(c_out, c_in, 3, 3)
+    gx, gw = ctx.zeros(x.size), ctx.zeros(wt.size)
+    ctx.call("th_conv3x3_bwd_input", ctx.upload(gy), ctx.upload(wt), gx, n, c_in, h, w, c_out, 1, layout)
+    ctx.call("th_conv3x3_bwd_weight", ctx.upload(x), ctx.upload(gy), gw, n, c_in, h, w, c_out, 1, layout)
+    close(ctx.download(gx, x.shape), gx_ref, atol=1e-4)
+    close(ctx.download(gw, wt.shape), gw_ref, atol=1e-4)
+    O.Tape.reset()
+
+
+POOL_CASES = [  # n, c, h, w, k, s, pad
+    (4, 32, 28, 28, (2, 2), (2, 2), (0, 0)), (3, 64, 14, 14, (2, 2), (2, 2), (0, 0)), (2, 3, 7, 7, (2, 2), None, (0, 0)),
+    (2, 3, 9, 8, (3, 3), (2, 2), (1, 1)), (1, 2, 5, 5, (3, 3), (1, 1), (1, 1)), (2, 2, 6, 6, (2, 3), (1, 2), (0, 1)),
+]
+
+
+@pytest.mark.parametrize("n,c,h,w,k,s,pad", POOL_CASES)
+def test_maxpool_bit_exact(ctx, O, n, c, h, w, k, s, pad):
+    rng = np.random.default_rng(n + c + h + w)
+    x = rng.integers(-3, 4, (n, c, h, w)).astype(np.float32)   # many ties: first max (kh outer, kw inner) must win
+    x[0, 0, :2, :2] = np.nan                                   # NaN never wins (tensor.rs:1451)
+    O.Tape.reset()
+    O.Tape.set_zero_sentinel(False)
+    xt = O.Tensor(x).requires_grad()
+    ref, ref_idx = xt.max_pool2d(k, s, pad, zero_first=True, return_indices=True)
+    _, _, ho, wo = ref.shape()
+    gout = rng.uniform(-1, 1, (n, c, ho, wo)).astype(np.float32)
+    xt.set_grad(np.full(x.shape, 5.0, np.float32))   # pre-existing grad is ZEROED by the reference backward (Q5)
+    (ref * O.Tensor(gout)).sum(None, False).backward()
+    O.Tape.set_zero_sentinel(True)
+    sh, sw = s or (0, 0)
+    y, am = ctx.empty(n * c * ho * wo), ctx.empty(n * c * ho * wo, np.int64)
+    ctx.call("th_maxpool2d_fwd", ctx.upload(x), y, am, n, c, h, w, k[0], k[1], sh, sw, pad[0], pad[1])
+    np.testing.assert_array_equal(ctx.download(am, (n, c, ho, wo), np.int64), ref_idx)   # absolute flat index, bit-exact
+    np.testing.assert_array_equal(ctx.download(y, (n, c, ho, wo)), ref.data())
+    gin = ctx.upload(np.full(x.shape, 5.0, np.float32))
+    ctx.call("th_maxpool2d_bwd", ctx.upload(gout), am, gin, n, c, h, w, k[0], k[1], sh, sw, pad[0], pad[1], 1)
+    np.testing.assert_array_equal(ctx.download(gin, x.shape), xt.grad())                 # same add order: bit-exact
+    O.Tape.reset()
+
+
+@pytest.mark.parametrize("n,c,h,w,k,s,pad", POOL_CASES + [(5, 128, 7, 7, (7, 7), (7, 7), (0, 0)), (2, 4, 7, 7, (7, 7), (1, 1), (0, 0))])
+def test_avgpool(ctx, O, n, c, h, w, k, s, pad):
+    rng = np.random.default_rng(n * c + h)
+    x = rng.uniform(-1, 1, (n, c, h, w)).astype(np.float32)
+    O.Tape.reset()
+    O.Tape.set_zero_sentinel(False)
+    xt = O.Tensor(x).requires_grad()
+    ref = xt.avg_pool2d(k, s, pad)
+    _, _, ho, wo = ref.shape()
+    gout = rng.uniform(-1, 1, (n, c, ho, wo)).astype(np.float32)
+    (ref * O.Tensor(gout)).sum(None, False).backward()
+    O.Tape.set_zero_sentinel(True)
+    sh, sw = s or (0, 0)
+    y = ctx.empty(n * c * ho * wo)
+    ctx.call("th_avgpool2d_fwd", ctx.upload(x), y, n, c, h, w, k[0], k[1], sh, sw, pad[0], pad[1])
+    close(ctx.download(y, (n, c, ho, wo)), ref.data(), atol=1e-6)
+    gin = ctx.zeros(x.size)
+    ctx.call("th_avgpool2d_bwd", ctx.upload(gout), gin, n, c, h, w, k[0], k[1], sh, sw, pad[0], pad[1])
+    close(ctx.download(gin, x.shape), xt.grad(), atol=1e-7)
+    O.Tape.reset()
+
+
+def test_bias_nchw(ctx):
+    rng = np.random.default_rng(5)
+    n, c, hw = 6, 20, 49
+    x = rng.uniform(-1, 1, (n, c, hw)).astype(np.float32)
+    b = rng.uniform(-1, 1, c).astype(np.float32)
+    y = ctx.empty(x.size)
+    ctx.call("th_bias_add_nchw", ctx.upload(x), ctx.upload(b), y, n, c, hw, 1)
+    np.testing.assert_array_equal(ctx.download(y, x.shape), np.maximum(x + b[None, :, None], 0))
+    gb0 = rng.uniform(-1, 1, c).astype(np.float32)
+    gb = ctx.upload(gb0)
+    ctx.call("th_bias_grad_nchw", ctx.upload(x), gb, n, c, hw)
+    np.testing.assert_allclose(ctx.download(gb, c), gb0 + x.astype(np.float64).sum((0, 2)), rtol=RTOL, atol=1e-5)
+
+
+# ------------------------------------------------------------------ optimizers / data
+def test_adam_matches_oracle_over_steps(ctx, O):
+    rng = np.random.default_rng(9)
+    sizes = [128 * 784, 128, 1280, 10, 7]          # 4 with grads + 1 without (Q8)
+    has = [1, 1, 1, 1, 0]
+    offs = np.zeros(len(sizes) + 1, np.int64)
+    for i, s in enumerate(sizes):
+        offs[i + 1] = offs[i] + (s + 3) // 4 * 4
+    total = int(offs[-1])
+    p0 = rng.uniform(-0.1, 0.1, total).astype(np.float32)
+    params = [O.Tensor(p0[offs[i]:offs[i] + s]).requires_grad() for i, s in enumerate(sizes)]
+    oopt = O.Adam(params, 1e-3, None, None, 1e-4)
+    dp, dm, dv = ctx.upload(p0), ctx.zeros(total), ctx.zeros(total)
+    doffs, dhas = ctx.upload(offs), ctx.upload(np.array(has, np.int32))
+    state = ctx.upload(np.zeros(2, np.int32))
+    lr = ctx.upload(np.array([1e-3], np.float32))
+    for step in range(25):
+        g = (rng.standard_normal(total) * 0.01).astype(np.float32)
+        for i, s in enumerate(sizes):
+            params[i].set_grad(g[offs[i]:offs[i] + s] if has[i] else None)
+        oopt.step()
+        dg = ctx.upload(g)
+        ctx.call("th_adam_step", dp, dg, dm, dv, doffs, dhas, len(sizes), total, state, lr, 0.9, 0.999, 1e-8, 1e-4)
+    got = ctx.download(dp, total)
+    assert ctx.download(state, 2, np.int32)[0] == 25 == oopt.t()
+    for i, s in enumerate(sizes):
+        np.testing.assert_allclose(got[offs[i]:offs[i] + s], params[i].data(), rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(ctx.download(dm, total)[offs[i]:offs[i] + s], oopt.m(i), rtol=RTOL, atol=1e-9)
+    np.testing.assert_array_equal(got[offs[4]:offs[4] + 7], p0[offs[4]:offs[4] + 7])   # grad-less: untouched
+
+
+def test_powi_matches(O):
+    for b, t in [(0.9, 1), (0.9, 7), (0.999, 1000), (0.999, 12345), (0.5, 31)]:
+        assert O.powi(b, t) == pytest.approx(np.float32(b) ** t, rel=1e-5)
+
+
+def test_sgd(ctx):
+    p0 = np.linspace(-1, 1, 16).astype(np.float32)
+    g = np.linspace(1, 2, 16).astype(np.float32)
+    dp = ctx.upload(p0)
+    ctx.call("th_sgd_step", dp, ctx.upload(g), ctx.upload(np.array([0, 8, 16], np.int64)), ctx.upload(np.array([1, 0], np.int32)), 2, 16,
+             ctx.upload(np.array([0.1], np.float32)))
+    ref = p0.copy()
+    ref[:8] -= np.float32(0.1) * g[:8]
+    np.testing.assert_array_equal(ctx.download(dp, 16), ref)
+
+
+def test_gather_batch_and_u8(ctx, O):
+    rng = np.random.default_rng(11)
+    n = 300
+    px = rng.integers(0, 256, (n, 784)).astype(np.uint8)
+    labels = rng.integers(0, 10, n).astype(np.float32)
+    imgs = ctx.empty(n * 784)
+    ctx.call("th_u8_to_unit_f32", ctx.upload(px), imgs, n * 784)
+    ref_imgs = px.astype(np.float32) / np.float32(255.0)          # data/mnist.rs:226
+    np.testing.assert_array_equal(ctx.download(imgs, (n, 784)), ref_imgs)
+    idx = rng.permutation(n).astype(np.int32)
+    xb, yb = ctx.empty(64 * 784), ctx.empty(64)
+    cursor = ctx.upload(np.array([100], np.int64))
+    ctx.call("th_gather_batch", imgs, ctx.upload(labels), ctx.upload(idx), n, cursor, 64, 784, xb, yb)
+    rx, ry = O.get_batch(ref_imgs, labels, idx[100:164])
+    np.testing.assert_array_equal(ctx.download(xb, (64, 784)), rx)
+    np.testing.assert_array_equal(ctx.download(yb, 64), ry)
+
+
+def test_log_step_and_graph_replay(ctx):
+    """device-side step log + cursor under hipGraph replay"""
+    state = ctx.upload(np.zeros(2, np.int64))
+    metrics = ctx.zeros(2 * 8)
+    loss, nc = ctx.upload(np.array([1.5], np.float32)), ctx.upload(np.array([3.0], np.float32))
+    ctx.graph_begin()
+    ctx.call("th_axpy", 1.0, nc, loss, 1)                       # loss += 3 every replay
+    ctx.call("th_log_step", loss, nc, metrics, 8, state, 64)
+    g = ctx.graph_end()
+    for _ in range(5):
+        ctx.graph_launch(g)
+    ctx.sync()
+    ctx.graph_destroy(g)
+    np.testing.assert_array_equal(ctx.download(state, 2, np.int64), [5, 320])
+    m = ctx.download(metrics, (8, 2))
+    np.testing.assert_array_equal(m[:5, 0], [4.5, 7.5, 10.5, 13.5, 16.5])
+
+
+def test_error_paths(ctx):
+    """the reference panics; the C ABI returns an error code + message"""
+    from taper_amd._lib import TaperError
+    with pytest.raises(TaperError):
+        ctx.call("th_sgemm", 0, 0, -1, 2, 2, 1.0, None, None, 0.0, None)
+    with pytest.raises(TaperError):
+        ctx.call("th_conv3x3_fwd", None, None, None, None, 1, 1, 4, 4, 1, 1, 0, 0)
+    with pytest.raises(TaperError):
+        x = ctx.zeros(16)
+        ctx.call("th_conv3x3_fwd", x, x, None, x, 1, 1, 4, 4, 1, 2, 0, 0)   # pad 2 unsupported

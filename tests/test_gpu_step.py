@@ -1,0 +1,219 @@
+"""Whole-step parity: identical weights + batch ->
+loss, logits, every parameter gradient (incl. which ones are None, quirk Q2)
+and the post-Adam weights must match the CPU oracle; the hipGraph-replayed
+epoch must match the eager epoch; size-independent properties at full size."""
+import numpy as np
+import pytest
+
+from tests import backends
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _compare_grads(h_grads, o_grads, names=None):
+    assert len(h_grads) == len(o_grads)
+    for i, (hg, og) in enumerate(zip(h_grads, o_grads)):
+        assert (hg is None) == (og is None), f"param {i}: grad None-ness differs (hip {hg is None}, oracle {og is None})"
+        if og is not None:
+            scale = float(np.abs(og).max())
+            np.testing.assert_allclose(hg, og, rtol=RTOL, atol=RTOL * 1e-1 * scale + 1e-8, err_msg=f"param {i}")
+
+
+MODELS = {
+    "mlp_baseline": (backends.mlp_baseline, None),       # BASELINE configs[0/1]
+    "mlp_example": (backends.mlp_example, None),         # examples/train_mnist.rs
+    "cnn_simple": (backends.cnn_simple, (1, 28, 28)),    # BASELINE configs[2]
+    "cnn_reference": (backends.cnn_reference, (1, 28, 28)),  # examples/train_mnist_cnn.rs
+}
+
+
+@pytest.mark.parametrize("name,batch", [("mlp_baseline", 64), ("mlp_baseline", 32), ("mlp_baseline", 1), ("mlp_example", 256),
+                                        ("mlp_example", 96), ("cnn_simple", 16), ("cnn_reference", 8), ("cnn_reference", 3)])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_forward_backward_parity(name, batch, fuse):
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(hash(name) % 1000 + batch)
+    builder, sample = MODELS[name]
+    spec = backends.nonzero_biases(builder(rng), rng)
+    x, y = backends.mnist_like(rng, batch)
+    x_shape = (batch, 784) if sample is None else (batch,) + sample
+    hm, om = H.sequential(spec, fuse=fuse), Orc.sequential(spec)
+    h_loss, h_acc, h_logits, h_grads = H.forward_backward(hm, x, y, x_shape)
+    o_loss, o_acc, o_logits, o_grads = Orc.forward_backward(om, x, y, x_shape)
+    np.testing.assert_allclose(h_logits, o_logits, rtol=RTOL, atol=RTOL * float(np.abs(o_logits).max()))
+    assert abs(h_loss - o_loss) <= RTOL * max(1.0, abs(o_loss))
+    assert h_acc == pytest.approx(o_acc, abs=1e-6)
+    _compare_grads(h_grads, o_grads)
+    if name.startswith("cnn"):
+        # Q2: faithful mode -- conv weights never get gradients; only the LAST conv's bias does
+        assert h_grads[0] is None and o_grads[0] is None
+
+
+@pytest.mark.parametrize("name,batch", [("cnn_simple", 6), ("cnn_reference", 4)])
+def test_full_backward_extension(name, batch):
+    """full_backward mode (extension, not reference behaviour): every parameter gets a
+    gradient and it matches the oracle's differentiable im2col chain."""
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(77 + batch)
+    builder, sample = MODELS[name]
+    spec = backends.nonzero_biases(builder(rng), rng)
+    x, y = backends.mnist_like(rng, batch)
+    x_shape = (batch,) + sample
+    hm, om = H.sequential(spec, full_backward=True), Orc.sequential(spec, full_backward=True)
+    try:
+        h_loss, _, h_logits, h_grads = H.forward_backward(hm, x, y, x_shape)
+    finally:
+        H.m.set_full_backward(False)
+    o_loss, _, o_logits, o_grads = Orc.forward_backward(om, x, y, x_shape)
+    assert all(g is not None for g in o_grads)
+    assert abs(h_loss - o_loss) <= RTOL * max(1.0, abs(o_loss))
+    for i, (hg, og) in enumerate(zip(h_grads, o_grads)):
+        assert hg is not None, f"param {i} has no grad in full_backward mode"
+        np.testing.assert_allclose(hg, og, rtol=5e-4, atol=5e-4 * float(np.abs(og).max()) + 1e-8, err_msg=f"param {i}")
+
+
+@pytest.mark.parametrize("name,batch,lr", [("mlp_baseline", 64, 1e-3), ("mlp_example", 256, 1e-3), ("cnn_reference", 8, 1e-2)])
+def test_training_steps_parity(name, batch, lr):
+    """5 consecutive steps of examples/train_mnist.rs:89-121 (Adam, wd 1e-4): per-step
+    loss / accuracy and the weights after every step."""
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(5 + batch)
+    builder, sample = MODELS[name]
+    spec = backends.nonzero_biases(builder(rng), rng)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    hopt = T.Adam(hm.parameters(), lr, None, None, 1e-4)
+    oopt = Orc.m.Adam(om.parameters(), lr, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt, sample_shape=sample)
+    x_all, y_all = backends.mnist_like(rng, 5 * batch)
+    for s in range(5):
+        x, y = x_all[s * batch:(s + 1) * batch], y_all[s * batch:(s + 1) * batch]
+        loss, acc = tr.train_step(T.Tensor(x), T.Tensor(y))
+        r = om.train_step(oopt, x, y, (batch, 784) if sample is None else (batch,) + sample)
+        assert abs(loss - r["loss"]) <= 2 * RTOL * max(1.0, abs(r["loss"])), f"step {s}"
+        assert acc == pytest.approx(r["acc"], abs=1.5 / batch), f"step {s}"
+        for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+            od = op.data()
+            # Adam normalises the step to ~lr per element, so |dw| ~ lr: compare on that scale
+            np.testing.assert_allclose(hp.data(), od, rtol=RTOL, atol=lr * 2e-2, err_msg=f"step {s} param {i}")
+    assert hopt.t() == 5
+
+
+def test_adam_state_parity_after_steps():
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    rng = np.random.default_rng(21)
+    spec = backends.mlp_baseline(rng)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    hopt, oopt = T.Adam(hm.parameters(), 1e-3, None, None, 1e-4), Orc.m.Adam(om.parameters(), 1e-3, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt)
+    for s in range(3):
+        x, y = backends.mnist_like(rng, 64)
+        tr.train_step(T.Tensor(x), T.Tensor(y))
+        om.train_step(oopt, x, y, (64, 784))
+    m, v = hopt.moments()
+    om_ = np.concatenate([oopt.m(i) for i in range(4)])
+    ov_ = np.concatenate([oopt.v(i) for i in range(4)])
+    np.testing.assert_allclose(m, om_, rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(v, ov_, rtol=1e-3, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,batch", [(640, 64), (1000, 64), (300, 128)])
+def test_graph_epoch_equals_eager_epoch(n, batch):
+    """The hipGraph-replayed epoch (train_epoch_graph) must produce the same per-step
+    losses, counts and final weights as the reference-literal eager loop, including
+    the last partial batch (data/mnist.rs:373-385)."""
+    import taper_amd as T
+    H = backends.get("hip")
+    rng = np.random.default_rng(n + batch)
+    spec = backends.mlp_baseline(rng)
+    x, y = backends.mnist_like(rng, n)
+    results, finals = [], []
+    for mode in (T.Trainer.EAGER, T.Trainer.GRAPH):
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        tr = T.Trainer(model, opt)
+        ds = T.MNISTDataset.from_host(x, y)
+        loader = T.DataLoader(ds, batch, True, seed=123)
+        ep = [tr.run_epoch(loader, mode) for _ in range(2)]      # two epochs: the graph is reused, data reshuffled
+        results.append(ep)
+        finals.append([p.data() for p in model.parameters()])
+        assert opt.t() == 2 * ((n + batch - 1) // batch)
+    for e in range(2):
+        a, b = results[0][e], results[1][e]
+        assert a["num_batches"] == b["num_batches"] == (n + batch - 1) // batch
+        assert a["total_samples"] == b["total_samples"] == n
+        np.testing.assert_allclose(b["losses"], a["losses"], rtol=1e-6, atol=1e-7)   # same kernels, same order
+        np.testing.assert_array_equal(b["ncorrect"], a["ncorrect"])
+        assert a["total_correct"] == b["total_correct"]
+    for pa, pb in zip(*finals):
+        np.testing.assert_allclose(pb, pa, rtol=1e-6, atol=1e-8)
+
+
+def test_epoch_against_oracle_with_loader_semantics():
+    """DataLoader order (index order, last partial batch kept) + Trainer metrics formulas
+    (train.rs:117,140-141, Q13) against the oracle driven with the same batches."""
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(3)
+    n, batch = 200, 64
+    spec = backends.mlp_baseline(rng)
+    x, y = backends.mnist_like(rng, n)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    hopt, oopt = T.Adam(hm.parameters(), 1e-3, None, None, 1e-4), Orc.m.Adam(om.parameters(), 1e-3, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt)
+    loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False)
+    assert loader.num_batches() == 4
+    ep = tr.run_epoch(loader, T.Trainer.GRAPH)
+    tot_loss, tot_correct = np.float32(0), 0
+    for s in range(0, n, batch):
+        xb, yb = x[s:s + batch], y[s:s + batch]
+        r = om.train_step(oopt, xb, yb, (len(xb), 784))
+        tot_loss += np.float32(r["loss"])
+        tot_correct += int(np.float32(r["acc"]) * np.float32(len(xb)))
+    assert ep["total_samples"] == n
+    assert abs(ep["avg_loss"] - tot_loss / 4) <= 2 * RTOL * max(1.0, abs(tot_loss / 4))
+    assert abs(ep["total_correct"] - tot_correct) <= 2
+
+
+def test_full_size_properties_config1():
+    """BASELINE configs[1] at full size (60 000 samples, batch 64): size-independent
+    properties -- every step logged, counts bounded, loss finite and decreasing on a
+    learnable synthetic task, identical reruns are bit-identical (determinism)."""
+    import taper_amd as T
+    H = backends.get("hip")
+    rng = np.random.default_rng(60000)
+    n = 60000
+    y = rng.integers(0, 10, n).astype(np.float32)
+    x = rng.integers(0, 256, (n, 784)).astype(np.float32) / np.float32(255.0)
+    x[np.arange(n), (y.astype(int) * 78)] = 1.0        # a learnable signal: one bright pixel per class
+    spec = backends.mlp_baseline(np.random.default_rng(1))
+    runs = []
+    for _ in range(2):
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        tr = T.Trainer(model, opt)
+        loader = T.DataLoader(T.MNISTDataset.from_host(x, y), 64, False)
+        ep = tr.run_epoch(loader, T.Trainer.GRAPH)
+        runs.append((ep, [p.data() for p in model.parameters()]))
+    ep = runs[0][0]
+    assert ep["num_batches"] == 938 and ep["total_samples"] == n     # 60000/64 -> 938, last batch 32
+    assert np.isfinite(ep["losses"]).all()
+    assert (ep["ncorrect"] >= 0).all() and (ep["ncorrect"][:-1] <= 64).all() and ep["ncorrect"][-1] <= 32
+    assert ep["ncorrect"].sum() == pytest.approx(ep["total_correct"], abs=938)
+    assert ep["losses"][-50:].mean() < 0.5 * ep["losses"][:10].mean()
+    assert ep["accuracy"] > 0.5
+    np.testing.assert_array_equal(runs[0][0]["losses"], runs[1][0]["losses"])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
