@@ -71,38 +71,31 @@ def algorithmic_step(key, batch):
 
 
 # ---------------------------------------------------------------------------- distributed plumbing
+# One process per GPU (launched by torch.distributed.run, which only sets RANK /
+# LOCAL_RANK / WORLD_SIZE / MASTER_*).  The data path is RCCL on our own HIP
+# stream; the control plane (unique-id broadcast, barriers, max over ranks) is
+# taper_amd.dist.FileRendezvous.  torch is deliberately NOT imported here: it
+# bundles a second HIP runtime + RCCL, and two runtimes in one process corrupt
+# each other (observed: "double free or corruption" at exit).
 def init_dist(n_gpus):
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    from taper_amd.dist import FileRendezvous, env_rank_world
+    rank, world, _ = env_rank_world()
     if world == 1:
         return None, 0, 1
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # bootstrap / barrier / max-reduce only
     assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
-    return dist, rank, world
+    return FileRendezvous(rank, world), rank, world
 
 
-def barrier_sync(dist, T):
-    T.Device.sync()
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-    except Exception:
-        pass
-    if dist is not None:
-        dist.barrier()
+def barrier_sync(rdzv, T):
+    T.Device.sync()      # hipStreamSynchronize on the stream every kernel / collective is enqueued on
+    if rdzv is not None:
+        rdzv.barrier()
 
 
-def make_comm(dist, T, rank, world):
-    if dist is None:
-        return None, "none"
-    import torch
-    uid = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        uid = torch.frombuffer(bytearray(T.Communicator.unique_id()), dtype=torch.uint8).clone()
-    dist.broadcast(uid, src=0)
-    return T.Communicator(world, rank, bytes(uid.numpy().tobytes())), "rccl"
+def make_comm(rdzv, T):
+    from taper_amd.dist import init_data_parallel
+    comm = init_data_parallel(T, rdzv)
+    return comm, ("rccl" if comm is not None else "none")
 
 
 # ---------------------------------------------------------------------------- the timed loop
@@ -182,15 +175,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    dist, rank, world = init_dist(args.gpus)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import taper_amd as T
+    dist, rank, world = init_dist(args.gpus)
     T.Device.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 
     key, batch, sample_shape, lr = WORKLOADS[args.workload]
     model = build_model(T, key)
     opt = T.Adam(model.parameters(), lr, None, None, 1e-4)          # examples/train_mnist.rs:50-51
-    comm, comm_kind = make_comm(dist, T, rank, world)
+    comm, comm_kind = make_comm(dist, T)
     trainer = T.Trainer(model, opt, sample_shape=sample_shape, comm=comm)
     # every rank owns its shard of the synthetic epoch (rows are independent: SURVEY.md 8e)
     ds = T.MNISTDataset.synthetic(args.dataset_size, seed=0x7461706572 + rank)
@@ -204,13 +197,8 @@ def main():
     dt = time.perf_counter() - t0
 
     if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ss = torch.tensor([samples], dtype=torch.float64)
-        dist.all_reduce(ss, op=dist.ReduceOp.SUM)
-        samples = int(ss.item())
+        dt = dist.all_reduce_max(dt)                 # MAX over ranks
+        samples = int(dist.all_reduce_sum(samples))  # whole-job aggregate
 
     if rank == 0:
         flops, nbytes = algorithmic_step(key, batch)
@@ -244,8 +232,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
 
 
 if __name__ == "__main__":

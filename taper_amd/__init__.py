@@ -10,6 +10,7 @@ missing: there is no CPU or PyTorch fallback.
 """
 from . import hip  # noqa: F401
 from ._lib import TaperError, build_native  # noqa: F401
+from . import dist  # noqa: F401
 from .api import (  # noqa: F401
     SGD, Adam, AdaptiveAvgPool2d, AvgPool2d, Communicator, Conv2d, Conv2dReLU, DataLoader, Device, Flatten, Linear,
     MaxPool2d, MNISTDataset, Module, ReLU, Sequential, Sigmoid, Tape, Tensor, Trainer, accuracy, cross_entropy_loss,

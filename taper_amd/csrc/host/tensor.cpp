@@ -223,7 +223,7 @@ void Tensor::backward() const {  // tensor.rs:520-529
     bool none;
     float *g = grad_for_write(&none);
     TH(th_fill_f32(Device::ctx(), g, 1.0f, len()));
-    Tape::backward(*tape_node_);  // id 0 = "no node" in both id schemes
+    if (*tape_node_ != 0) Tape::backward(*tape_node_);  // tensor.rs:526: id 0 = "no node" (in both id schemes)
 }
 
 void Tensor::zero_grad() const { grad_->has = false; }  // tensor.rs:531-533

@@ -1,0 +1,109 @@
+"""Single-node rendezvous for one-process-per-GPU data parallelism.
+
+The data path of DP training is native: RCCL all-reduce on the th_ctx stream
+(include/taper_hip.h: th_comm_*).  What is left for the host is control
+plane only -- shipping RCCL's 128-byte unique id from rank 0, barriers around
+the timed region and a max/sum of a few floats.  This module does that through
+a directory in /dev/shm (or /tmp), keyed by the launcher's PID + MASTER_PORT,
+so the bench process never has to import torch: PyTorch bundles its own copy
+of the HIP runtime and RCCL, and two HIP runtimes in one process corrupt each
+other's state at exit.
+
+Launch contract (same as torch.distributed.run provides): RANK, WORLD_SIZE,
+LOCAL_RANK, MASTER_PORT in the environment, all ranks on ONE node.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import time
+from pathlib import Path
+
+
+class FileRendezvous:
+    def __init__(self, rank: int, world: int, key: str | None = None, root: str | None = None, timeout_s: float = 600.0):
+        self.rank, self.world, self.timeout_s = int(rank), int(world), timeout_s
+        if key is None:
+            # all workers of one torchrun share the agent as parent and the master port
+            key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+        base = Path(root or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
+        self.dir = base / f"taper_rdzv_{key}"
+        self.dir.mkdir(parents=True, exist_ok=True)
+        self._seq = 0
+
+    # -- primitives ---------------------------------------------------------
+    def _path(self, name: str, rank: int | None = None) -> Path:
+        return self.dir / (f"{name}.{rank}" if rank is not None else name)
+
+    def _publish(self, path: Path, payload: bytes) -> None:
+        tmp = path.with_suffix(path.suffix + f".tmp{os.getpid()}")
+        tmp.write_bytes(payload)
+        os.replace(tmp, path)  # atomic: readers never see a partial file
+
+    def _wait_for(self, path: Path) -> bytes:
+        deadline = time.monotonic() + self.timeout_s
+        spins = 0
+        while True:
+            try:
+                return path.read_bytes()
+            except FileNotFoundError:
+                pass
+            spins += 1
+            if spins > 2000:
+                time.sleep(0.0002)
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rendezvous: rank {self.rank} timed out waiting for {path}")
+
+    def _next(self, tag: str) -> str:
+        self._seq += 1
+        return f"{tag}{self._seq:06d}"
+
+    # -- collectives on tiny host values ----------------------------------------
+    def broadcast_bytes(self, payload: bytes | None, src: int = 0) -> bytes:
+        name = self._next("bcast")
+        if self.rank == src:
+            assert payload is not None
+            self._publish(self._path(name), payload)
+            return payload
+        return self._wait_for(self._path(name))
+
+    def all_gather_bytes(self, payload: bytes) -> list[bytes]:
+        name = self._next("gather")
+        self._publish(self._path(name, self.rank), payload)
+        return [self._wait_for(self._path(name, r)) for r in range(self.world)]
+
+    def barrier(self) -> None:
+        self.all_gather_bytes(b"1")
+
+    def all_reduce_max(self, v: float) -> float:
+        return max(struct.unpack("d", b)[0] for b in self.all_gather_bytes(struct.pack("d", float(v))))
+
+    def all_reduce_sum(self, v: float) -> float:
+        return sum(struct.unpack("d", b)[0] for b in self.all_gather_bytes(struct.pack("d", float(v))))
+
+    def close(self) -> None:
+        """last one out removes the directory"""
+        try:
+            self.barrier()
+            if self.rank == 0:
+                time.sleep(0.05)
+                for p in self.dir.iterdir():
+                    try:
+                        p.unlink()
+                    except OSError:
+                        pass
+                self.dir.rmdir()
+        except Exception:
+            pass
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_data_parallel(T, rdzv: FileRendezvous | None):
+    """-> taper_amd.Communicator over RCCL (or None for a single rank)."""
+    if rdzv is None or rdzv.world == 1:
+        return None
+    uid = rdzv.broadcast_bytes(T.Communicator.unique_id() if rdzv.rank == 0 else None, src=0)
+    return T.Communicator(rdzv.world, rdzv.rank, uid)

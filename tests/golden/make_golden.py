@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz: small input/output vectors from an INDEPENDENT
+implementation (PyTorch-CPU 2.10 in the authoring container, float64 numpy for
+Adam) for the parts of the hot path the reference's own tests do not pin
+(SURVEY.md section 4 "Not pinned by any reference test": conv2d, pools,
+transpose, add_broadcast, sigmoid, Adam).  Mappings:
+  reference conv  == F.conv2d(x, w.flatten().reshape(9*C_in, C_out).T.reshape(C_out, C_in, 3, 3), b, padding=1)   (Q3)
+  max_pool2d      == F.max_pool2d(return_indices=True); reference index = plane base + torch's per-plane index
+  avg_pool2d      == F.avg_pool2d(count_include_pad=True)                                                       (Q6)
+  cross_entropy   == F.cross_entropy(reduction="mean")
+Run:  python tests/golden/make_golden.py      (needs torch; the fixtures are committed, torch never travels)
+"""
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+OUT = Path(__file__).resolve().parent
+rng = np.random.default_rng(20250928)
+torch.manual_seed(0)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def conv_case(n, ci, h, w, co, name):
+    x = f32(rng.uniform(-1, 1, (n, ci, h, w)))
+    wt = f32(rng.uniform(-0.5, 0.5, (co, ci, 3, 3)))
+    b = f32(rng.uniform(-0.5, 0.5, co))
+    w_eff = torch.from_numpy(wt).double().flatten().reshape(9 * ci, co).T.reshape(co, ci, 3, 3)   # Q3 reinterpretation
+    y_taper = F.conv2d(torch.from_numpy(x).double(), w_eff, torch.from_numpy(b).double(), padding=1)
+    y_std = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1)
+    np.savez_compressed(OUT / f"{name}.npz", x=x, w=wt, b=b, y_taper=f32(y_taper.numpy()), y_standard=f32(y_std.numpy()))
+
+
+def pool_case(n, c, h, w, k, s, p, name):
+    x = f32(rng.integers(-4, 5, (n, c, h, w)))          # ties on purpose: first max must win
+    xt = torch.from_numpy(x).double()
+    y, idx = F.max_pool2d(xt, k, s, p, return_indices=True)
+    base = (np.arange(n * c) * h * w).reshape(n, c, 1, 1)
+    avg = F.avg_pool2d(torch.from_numpy(f32(rng.uniform(-1, 1, (n, c, h, w)))).double(), k, s, p, count_include_pad=True)
+    xa = f32(rng.uniform(-1, 1, (n, c, h, w)))
+    avg = F.avg_pool2d(torch.from_numpy(xa).double(), k, s, p, count_include_pad=True)
+    np.savez_compressed(OUT / f"{name}.npz", x=x, k=np.array(k), s=np.array(s), p=np.array(p), y=f32(y.numpy()),
+                        argmax=(idx.numpy() + base).astype(np.int64), xa=xa, avg=f32(avg.numpy()))
+
+
+def xent_case(b, c, name):
+    logits = f32(rng.standard_normal((b, c)) * 3)
+    t = rng.integers(0, c, b)
+    lt = torch.from_numpy(logits).double().requires_grad_()
+    loss = F.cross_entropy(lt, torch.from_numpy(t), reduction="mean")
+    loss.backward()
+    np.savez_compressed(OUT / f"{name}.npz", logits=logits, targets=f32(t), loss=f32(loss.item()), dlogits=f32(lt.grad.numpy()),
+                        logp=f32(F.log_softmax(lt, 1).detach().numpy()), argmax=f32(logits.argmax(1)))
+
+
+def adam_case(name, steps=6):
+    """SURVEY.md A.3 (src/optim.rs:83-113) in float64: eps added to sqrt(v) BEFORE the bias fold (Q10)"""
+    n = 257
+    p = rng.uniform(-1, 1, n)
+    grads = rng.standard_normal((steps, n)) * 0.1
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-8, 1e-4
+    p0 = f32(p)
+    p = p0.astype(np.float64)
+    m, v = np.zeros(n), np.zeros(n)
+    traj = []
+    for t in range(1, steps + 1):
+        g = f32(grads[t - 1]).astype(np.float64) + wd * p
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        step = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        p = p - step * m / (np.sqrt(v) + eps)
+        traj.append(p.copy())
+    np.savez_compressed(OUT / f"{name}.npz", p0=p0, grads=f32(grads), traj=f32(np.array(traj)), m=f32(m), v=f32(v),
+                        hyper=np.array([lr, b1, b2, eps, wd]))
+
+
+def misc_case(name):
+    x = f32(rng.uniform(-3, 3, (37, 53)))
+    bias = f32(rng.uniform(-1, 1, 53))
+    np.savez_compressed(OUT / f"{name}.npz", x=x, bias=bias, transpose=x.T.copy(), add_broadcast=x + bias,
+                        sigmoid=f32(torch.sigmoid(torch.from_numpy(x).double()).numpy()), relu=np.maximum(x, 0),
+                        colsum=f32(x.astype(np.float64).sum(0)), rowmax=x.max(1), rowargmax=f32(x.argmax(1)))
+
+
+if __name__ == "__main__":
+    conv_case(2, 1, 28, 28, 8, "conv_c1")
+    conv_case(2, 16, 14, 14, 24, "conv_c16")
+    conv_case(3, 5, 7, 7, 3, "conv_odd")
+    pool_case(2, 3, 28, 28, (2, 2), (2, 2), (0, 0), "pool_2x2")
+    pool_case(2, 2, 9, 8, (3, 3), (2, 2), (1, 1), "pool_3x3_pad")
+    pool_case(3, 4, 7, 7, (7, 7), (7, 7), (0, 0), "pool_global")
+    xent_case(64, 10, "xent_64x10")
+    xent_case(7, 3, "xent_7x3")
+    adam_case("adam_traj")
+    misc_case("misc_2d")
+    print("wrote", sorted(p.name for p in OUT.glob("*.npz")))

@@ -344,15 +344,20 @@ def test_conv3x3_fwd(ctx, O, n, c_in, h, w, c_out, pad, layout, relu):
         ref = xt.conv2d_direct_3x3(wtt, bt, (1, 1), (pad, pad))
         ref = ref.relu() if relu else ref
     ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
-    assert ref.shape() == (n, c_out, ho, wo)
+    # The dead-code direct kernel sizes its output (h + 2p - 2)/s + 1 (tensor.rs:1307-1308), one
+    # row/column larger than a 3x3 convolution produces; the extra border holds partial sums.
+    # The live path and th_conv3x3_fwd use the conv2d geometry (tensor.rs:1254-1255): compare there.
+    assert ref.shape() == ((n, c_out, ho, wo) if layout == 0 else (n, c_out, ho + 1, wo + 1))
+    ref_d = ref.data()[:, :, :ho, :wo]
     y = ctx.empty(n * c_out * ho * wo)
     ctx.call("th_conv3x3_fwd", ctx.upload(x), ctx.upload(wt), ctx.upload(b), y, n, c_in, h, w, c_out, pad, layout, relu)
-    close(ctx.download(y, ref.shape()), ref.data(), atol=1e-5)
+    close(ctx.download(y, ref_d.shape), ref_d, atol=1e-5)
     # no bias
     y2 = ctx.empty(n * c_out * ho * wo)
     ctx.call("th_conv3x3_fwd", ctx.upload(x), ctx.upload(wt), None, y2, n, c_in, h, w, c_out, pad, layout, 0)
     ref2 = xt.conv2d(wtt, None, (1, 1), (pad, pad), (1, 1)) if layout == 0 else xt.conv2d_direct_3x3(wtt, None, (1, 1), (pad, pad))
-    close(ctx.download(y2, ref2.shape()), ref2.data(), atol=1e-5)
+    ref2_d = ref2.data()[:, :, :ho, :wo]
+    close(ctx.download(y2, ref2_d.shape), ref2_d, atol=1e-5)
 
 
 @pytest.mark.parametrize("n,c_in,h,w,c_out", [(2, 1, 6, 6, 4), (3, 8, 7, 7, 16), (2, 5, 4, 9, 3)])
@@ -499,8 +504,18 @@ def test_adam_matches_oracle_over_steps(ctx, O):
 
 
 def test_powi_matches(O):
+    def powisf2(a, b):  # compiler-rt __powisf2 in float32, what f32::powi lowers to (optim.rs:87-88)
+        a, r = np.float32(a), np.float32(1)
+        while True:
+            if b & 1:
+                r = np.float32(r * a)
+            b //= 2
+            if b == 0:
+                return r
+            a = np.float32(a * a)
     for b, t in [(0.9, 1), (0.9, 7), (0.999, 1000), (0.999, 12345), (0.5, 31)]:
-        assert O.powi(b, t) == pytest.approx(np.float32(b) ** t, rel=1e-5)
+        assert O.powi(b, t) == powisf2(b, t)
+        assert O.powi(b, t) == pytest.approx(float(np.float32(b)) ** t, rel=2e-3)
 
 
 def test_sgd(ctx):

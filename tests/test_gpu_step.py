@@ -192,7 +192,8 @@ def test_full_size_properties_config1():
     n = 60000
     y = rng.integers(0, 10, n).astype(np.float32)
     x = rng.integers(0, 256, (n, 784)).astype(np.float32) / np.float32(255.0)
-    x[np.arange(n), (y.astype(int) * 78)] = 1.0        # a learnable signal: one bright pixel per class
+    for c in range(10):                                 # a learnable signal: a bright 40-pixel band per class
+        x[y == c, c * 78:c * 78 + 40] = 1.0
     spec = backends.mlp_baseline(np.random.default_rng(1))
     runs = []
     for _ in range(2):
