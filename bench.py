@@ -121,15 +121,15 @@ def time_dominant_kernel(T, key, batch, reps=400):
     dz = ctx.upload(rng.uniform(-1, 1, (batch, out_f)).astype(np.float32))
     dw = ctx.zeros(out_f * in_f)
     for _ in range(20):
-        ctx.call("th_linear_bwd", x, None, dz, None, dw, None, batch, in_f, out_f, 0)
+        ctx.call("th_linear_bwd", x, None, dz, None, None, dw, None, batch, in_f, out_f, 0)
     e0, e1 = hip.Event(), hip.Event()
     ctx.record(e0)
     for _ in range(reps):
-        ctx.call("th_linear_bwd", x, None, dz, None, dw, None, batch, in_f, out_f, 0)
+        ctx.call("th_linear_bwd", x, None, dz, None, None, dw, None, batch, in_f, out_f, 0)
     ctx.record(e1)
     us = hip.Ctx.elapsed_ms(e0, e1) * 1e3 / reps
     alg_bytes = 4 * (batch * out_f + batch * in_f + out_f * in_f)
-    return dict(kernel="sgemm_small16<TN> (dW1 = dZ1^T.X, 128x784x%d)" % batch, us_per_launch=us, alg_bytes=alg_bytes,
+    return dict(kernel="linear_bwd_small (dW1 = dZ1^T.X, 128x784x%d)" % batch, us_per_launch=us, alg_bytes=alg_bytes,
                 alg_flops=2 * out_f * in_f * batch)
 
 

@@ -87,10 +87,13 @@ int th_linear_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
                   int batch, int in_features, int out_features, int relu);
 /* backward of the three reference nodes at once (ops.rs:238-294,
  * tensor.rs:574-587, 674-694); any of d_dx, d_dw, d_db may be NULL (input
- * without requires_grad: ops.rs:243).  accumulate_mask bit0/1/2 = dx/dw/db:
- * set -> += into an existing grad; clear -> the grad slot was None, the
- * kernel overwrites (0 + x, saving the zero-fill of ops.rs:247-249). */
-int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy,
+ * without requires_grad: ops.rs:243).  d_relu_y (nullable): the layer's
+ * POST-activation output; when given, the ReLU backward (ops.rs:358-369) is
+ * folded in: dZ = dY * (Y > 0) (Y > 0 <=> pre-activation > 0, quirk Q15).
+ * accumulate_mask bit0/1/2 = dx/dw/db: set -> += into an existing grad;
+ * clear -> the grad slot was None, the kernel overwrites (0 + x, saving the
+ * zero-fill of ops.rs:247-249).  Latency-bound shapes run as ONE launch. */
+int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y,
                   float *d_dx, float *d_dw, float *d_db, int batch, int in_features, int out_features,
                   int accumulate_mask);
 
@@ -141,10 +144,14 @@ int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, 
 /* logits [B,C], targets [B] fp32 class ids (cast `as usize`).  Writes
  * logp[B,C] (nullable), loss[1] = -(1/B) sum_i logp[i,t_i], argmax[B] as f32
  * (nullable), n_correct[1] as f32 (nullable; accuracy()*B).  Out-of-range
- * target -> the row contributes NaN to loss (the reference panics,
- * loss.rs:161). */
+ * target -> NaN loss (the reference panics, loss.rs:161).
+ * d_dlogits_unit (nullable) receives (softmax - onehot) * (1/B): the gradient
+ * of loss.rs:174-191 for an upstream grad of exactly 1, so that
+ * loss.backward() needs no further launch.
+ * d_metrics / d_state (nullable): th_log_step folded into this kernel. */
 int th_softmax_xent_fwd(th_ctx *ctx, const float *d_logits, const float *d_targets, int batch, int classes,
-                        float *d_logp, float *d_loss, float *d_argmax, float *d_ncorrect);
+                        float *d_logp, float *d_loss, float *d_argmax, float *d_ncorrect, float *d_dlogits_unit,
+                        float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance);
 /* dlogits (+)= (exp(logp) - onehot) * (g0 / B), g0 read from device (the
  * upstream scalar grad, loss.rs:174-191); accumulate=0 overwrites */
 int th_softmax_xent_bwd(th_ctx *ctx, const float *d_logp, const float *d_targets, const float *d_g0,
@@ -192,10 +199,10 @@ int th_avgpool2d_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int n, int 
 /* Fused multi-tensor Adam over flat arenas (optim.rs:83-113).
  * d_offsets[n_tensors+1]: element offsets of each parameter tensor (int64);
  * d_has_grad[n_tensors]: 0 -> the tensor is skipped entirely (grad None, Q8).
- * d_t: int32[2] ON DEVICE: [0] = step counter t, incremented by this call
- * first (optim.rs:84) so a captured graph advances it on every replay;
- * [1] = scratch (bits of the step size).  The bias corrections use powi
- * (square-and-multiply) like f32::powi.
+ * d_t: int32[2] ON DEVICE: [0] = step counter t, advanced by this call
+ * (optim.rs:84) so a captured graph advances it on every replay; [1] = the
+ * kernel's arrival counter (must be 0 between calls).  The bias corrections
+ * use powi (square-and-multiply) like f32::powi.
  * d_lr[1]: learning rate on device (set_lr, optim.rs:125-127). */
 int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v,
                  const int64_t *d_offsets, const int32_t *d_has_grad, int n_tensors, int64_t total,

@@ -35,66 +35,96 @@ __device__ __forceinline__ float epilogue_apply(float acc, float c_old, const Ep
 // ------------------------------------------------------------------------
 // small / latency-bound kernel
 // ------------------------------------------------------------------------
-// grid = (tiles_n, tiles_m, kz); block = 256 (4 waves).  Wave w of slice z
-// covers k in [z*kslice + w*kwave, ...).  Lane l: r = l & 15 (row of A /
-// col of B), g = l >> 4 (which 4-wide k group).  In MFMA step s the lane
-// supplies k = kk + 4*g + s for BOTH operands, so every k is used once.
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void sgemm_small16(const float *__restrict__ A, const float *__restrict__ B,
-                                                     float *__restrict__ C, float *__restrict__ partial,
-                                                     int m, int n, int k, long a_rs, long a_cs, long b_rs, long b_cs,
-                                                     int kslice, int a_vec, int b_vec, Epilogue ep) {
-    __shared__ float red[3][64][4];
+// One workgroup (NW waves) per 16x16 output tile; wave w covers its share of
+// [kbeg_slice, kend_slice).  Lane l: r = l & 15 (row of A / col of B),
+// g = l >> 4 (which 4-wide k group).  In MFMA step s the lane supplies
+// k = kk + 4*g + s for BOTH operands, so every k is used exactly once.
+// MASKED: A values are multiplied by (Amask[same index] > 0) on the fly -- the
+// ReLU backward (ops.rs:358-369) folded into the operand load of the two
+// backward GEMMs of a Linear layer.
+struct SmallArgs {
+    const float *A, *Amask, *B;
+    float *C, *partial;
+    int m, n, k;
+    long a_rs, a_cs, b_rs, b_cs;
+    int kslice, a_vec, b_vec;
+    Epilogue ep;
+};
+
+template <bool A_KC, bool B_KC, int NW, bool MASKED>
+__device__ __forceinline__ void small16_body(const SmallArgs &p, int tile_row, int tile_col, int zslice, float (*red)[64][4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
-    const int kbeg_slice = blockIdx.z * kslice;
-    const int kend_slice = min(k, kbeg_slice + kslice);
-    // split the slice between the 4 waves in multiples of 16
-    const int kwave = ((kend_slice - kbeg_slice + 63) / 64) * 16;
+    const int row0 = tile_row * 16, col0 = tile_col * 16;
+    const int kbeg_slice = zslice * p.kslice;
+    const int kend_slice = min(p.k, kbeg_slice + p.kslice);
+    // split the slice between the NW waves in multiples of 16
+    const int kwave = ((kend_slice - kbeg_slice + 16 * NW - 1) / (16 * NW)) * 16;
     const int kbeg = kbeg_slice + wave * kwave;
     const int kend = min(kend_slice, kbeg + kwave);
 
     const int arow = row0 + r, bcol = col0 + r;
-    const bool a_ok = arow < m, b_ok = bcol < n;
-    const float *ap = A + (long)(a_ok ? arow : 0) * a_rs;
-    const float *bp = B + (long)(b_ok ? bcol : 0) * b_cs;
+    const bool a_ok = arow < p.m, b_ok = bcol < p.n;
+    const long a_off = (long)(a_ok ? arow : 0) * p.a_rs;
+    const float *ap = p.A + a_off;
+    const float *mp = MASKED ? p.Amask + a_off : nullptr;
+    const float *bp = p.B + (long)(b_ok ? bcol : 0) * p.b_cs;
 
+    // These shapes are latency-bound: after a kernel boundary every dependent
+    // global round trip costs ~0.5-1 us, so the operand loads of CH k-steps
+    // (64 k per wave) are all issued before the first MFMA consumes any.
+    constexpr int CH = 4;
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kk = kbeg; kk < kend; kk += 16) {
-        const int kb = kk + g * 4;
-        float av[4], bv[4];
-        if (A_KC && a_vec && kb + 4 <= kend) {
-            float4 t = *reinterpret_cast<const float4 *>(ap + kb);
-            av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-        } else {
+    for (int kk0 = kbeg; kk0 < kend; kk0 += 16 * CH) {
+        float av[CH][4], bv[CH][4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) av[s] = (kb + s < kend) ? ap[(long)(kb + s) * a_cs] : 0.f;
+        for (int c = 0; c < CH; ++c) {
+            const int kb = kk0 + 16 * c + g * 4;
+            if (A_KC && p.a_vec && kb + 4 <= kend) {
+                float4 t = *reinterpret_cast<const float4 *>(ap + kb);
+                av[c][0] = t.x; av[c][1] = t.y; av[c][2] = t.z; av[c][3] = t.w;
+                if (MASKED) {
+                    float4 q = *reinterpret_cast<const float4 *>(mp + kb);
+                    av[c][0] = q.x > 0.f ? av[c][0] : 0.f; av[c][1] = q.y > 0.f ? av[c][1] : 0.f;
+                    av[c][2] = q.z > 0.f ? av[c][2] : 0.f; av[c][3] = q.w > 0.f ? av[c][3] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bool in = kb + s < kend;
+                    float v = in ? ap[(long)(kb + s) * p.a_cs] : 0.f;
+                    if (MASKED) v = (in && mp[(long)(kb + s) * p.a_cs] > 0.f) ? v : 0.f;
+                    av[c][s] = v;
+                }
+            }
+            if (B_KC && p.b_vec && kb + 4 <= kend) {
+                float4 t = *reinterpret_cast<const float4 *>(bp + kb);
+                bv[c][0] = t.x; bv[c][1] = t.y; bv[c][2] = t.z; bv[c][3] = t.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bv[c][s] = (kb + s < kend) ? bp[(long)(kb + s) * p.b_rs] : 0.f;
+            }
         }
-        if (B_KC && b_vec && kb + 4 <= kend) {
-            float4 t = *reinterpret_cast<const float4 *>(bp + kb);
-            bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-        } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bv[s] = (kb + s < kend) ? bp[(long)(kb + s) * b_rs] : 0.f;
-        }
+        for (int c = 0; c < CH; ++c) {
+            if (kk0 + 16 * c >= kend) break;  // wave-uniform
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float a = a_ok ? av[s] : 0.f;
-            const float b = b_ok ? bv[s] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                const float a = a_ok ? av[c][s] : 0.f;
+                const float b = b_ok ? bv[c][s] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
         }
     }
 
-    // deterministic in-workgroup reduction: wave 0 adds waves 1,2,3 in order
+    // deterministic in-workgroup reduction: wave 0 adds waves 1..NW-1 in order
     if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[wave - 1][lane][i] = acc[i];
     }
     __syncthreads();
     if (wave == 0) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w)
+        for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] += red[w][lane][i];
         // C/D map of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + i
@@ -102,17 +132,24 @@ __global__ __launch_bounds__(256) void sgemm_small16(const float *__restrict__ A
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + (lane >> 4) * 4 + i;
-            if (row < m && col < n) {
-                const long idx = (long)row * n + col;
-                if (partial) {
-                    partial[(long)blockIdx.z * m * n + idx] = acc[i];
+            if (row < p.m && col < p.n) {
+                const long idx = (long)row * p.n + col;
+                if (p.partial) {
+                    p.partial[(long)zslice * p.m * p.n + idx] = acc[i];
                 } else {
-                    const float c_old = ep.beta != 0.0f ? C[idx] : 0.0f;
-                    C[idx] = epilogue_apply(acc[i], c_old, ep, col);
+                    const float c_old = p.ep.beta != 0.0f ? p.C[idx] : 0.0f;
+                    p.C[idx] = epilogue_apply(acc[i], c_old, p.ep, col);
                 }
             }
         }
     }
+}
+
+// grid = (tiles_n, tiles_m, kz); block = 64 * NW
+template <bool A_KC, bool B_KC, int NW>
+__global__ __launch_bounds__(64 * NW) void sgemm_small16(SmallArgs p) {
+    __shared__ float red[NW - 1][64][4];
+    small16_body<A_KC, B_KC, NW, false>(p, blockIdx.y, blockIdx.x, blockIdx.z, red);
 }
 
 // second pass of grid-level split-K: fixed slice order -> deterministic
@@ -124,6 +161,52 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ p
     for (int z = 0; z < kz; ++z) s += partial[(long)z * mn + i];
     const float c_old = ep.beta != 0.0f ? C[i] : 0.0f;
     C[i] = epilogue_apply(s, c_old, ep, (int)(i % n));
+}
+
+// Whole backward of one (small) Linear layer in ONE launch (the reference runs
+// three tape nodes: ops.rs:238-294, tensor.rs:574-587, 674-694, plus the ReLU
+// node ops.rs:358-369 when MASKED).  Workgroup roles by block index:
+//   [0, n_dw)            dW[out,in] (+)= dZ^T . X      (TN: A = dZ^T is MC, B = X is MC)
+//   [n_dw, n_dw + n_dx)  dX[B,in]   (+)= dZ . W        (NN: A = dZ is KC,  B = W is MC)
+//   the rest             db[out]    (+)= sum_b dZ[b,:] (64 columns per workgroup)
+// with dZ = dY (* (Y > 0) when MASKED).
+struct LinearBwdArgs {
+    SmallArgs dw, dx;
+    int n_dw, n_dx, dw_tiles_n, dx_tiles_n;
+    const float *dy, *ymask;
+    float *db;
+    int batch, out_f, db_accum;
+};
+
+template <bool MASKED>
+__global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
+    __shared__ float red[3][64][4];
+    const int bid = blockIdx.x;
+    if (bid < q.n_dw) {
+        small16_body<false, false, 4, MASKED>(q.dw, bid / q.dw_tiles_n, bid % q.dw_tiles_n, 0, red);
+    } else if (bid < q.n_dw + q.n_dx) {
+        const int t = bid - q.n_dw;
+        small16_body<true, false, 4, MASKED>(q.dx, t / q.dx_tiles_n, t % q.dx_tiles_n, 0, red);
+    } else {
+        // bias gradient: 4 waves stride the batch rows, lanes are consecutive columns
+        float(*part)[64] = reinterpret_cast<float(*)[64]>(&red[0][0][0]);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int c = (bid - q.n_dw - q.n_dx) * 64 + lane;
+        float s = 0.f;
+        if (c < q.out_f)
+            for (int r = wave; r < q.batch; r += 4) {
+                const long idx = (long)r * q.out_f + c;
+                float v = q.dy[idx];
+                if (MASKED) v = q.ymask[idx] > 0.f ? v : 0.f;
+                s += v;
+            }
+        part[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && c < q.out_f) {
+            const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+            q.db[c] = q.db_accum ? q.db[c] + tot : tot;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -282,34 +365,41 @@ static int launch_small(th_ctx *ctx, const float *A, const float *B, float *C, i
                         long b_rs, long b_cs, const Epilogue &ep) {
     const int tiles_m = ceil_div(m, 16), tiles_n = ceil_div(n, 16);
     const long tiles = (long)tiles_m * tiles_n;
-    // grid-level split-K only when the tile grid cannot fill the chip and K is deep
+    SmallArgs p{A, nullptr, B, C, nullptr, m, n, k, a_rs, a_cs, b_rs, b_cs, 0, 0, 0, ep};
+    // float4 operand loads need 16-B aligned rows and slice starts
+    p.a_vec = A_KC && aligned16(A) && (a_rs % 4 == 0);
+    p.b_vec = B_KC && aligned16(B) && (b_cs % 4 == 0);
+    // Deep K on a grid that cannot fill the chip: first widen the workgroup to
+    // 16 waves (in-LDS reduction, still one launch); only very deep K goes to a
+    // grid-level split with a second reduce pass.
     int kz = 1;
-    if (tiles < 256 && k >= 512) {
-        kz = (int)((512 + tiles - 1) / tiles);
-        const int kz_max = k / 128;  // >= 128 k per slice (32 per wave)
+    const bool wide = tiles < 256 && k >= 256;
+    if (tiles < 64 && k >= 8192) {
+        kz = (int)((256 + tiles - 1) / tiles);
+        const int kz_max = k / 1024;
         if (kz > kz_max) kz = kz_max;
         if (kz < 1) kz = 1;
     }
     int kslice = ceil_div(k, kz);
     kslice = (kslice + 15) / 16 * 16;
     kz = ceil_div(k, kslice);
-    // float4 operand loads need 16-B aligned rows and slice starts
-    const int a_vec = A_KC && aligned16(A) && (a_rs % 4 == 0);
-    const int b_vec = B_KC && aligned16(B) && (b_cs % 4 == 0);
-    float *partial = nullptr;
+    p.kslice = kslice;
     if (kz > 1) {
-        void *p = nullptr;
-        if (th_malloc(ctx, (size_t)kz * m * n * sizeof(float), &p)) return 1;
-        partial = (float *)p;
+        void *ws = nullptr;
+        if (th_malloc(ctx, (size_t)kz * m * n * sizeof(float), &ws)) return 1;
+        p.partial = (float *)ws;
     }
-    hipLaunchKernelGGL((sgemm_small16<A_KC, B_KC>), dim3(tiles_n, tiles_m, kz), dim3(256), 0, ctx->stream, A, B, C,
-                       partial, m, n, k, a_rs, a_cs, b_rs, b_cs, kslice, a_vec, b_vec, ep);
+    if (wide)
+        hipLaunchKernelGGL((sgemm_small16<A_KC, B_KC, 16>), dim3(tiles_n, tiles_m, kz), dim3(1024), 0, ctx->stream, p);
+    else
+        hipLaunchKernelGGL((sgemm_small16<A_KC, B_KC, 4>), dim3(tiles_n, tiles_m, kz), dim3(256), 0, ctx->stream, p);
     TH_LAUNCH_CHECK();
     if (kz > 1) {
         const long mn = (long)m * n;
-        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, ctx->stream, partial, C, mn, n, kz, ep);
+        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, ctx->stream, (const float *)p.partial, C, mn, n,
+                           kz, ep);
         TH_LAUNCH_CHECK();
-        if (th_free(ctx, partial)) return 1;
+        if (th_free(ctx, p.partial)) return 1;
     }
     return 0;
 }
@@ -345,6 +435,11 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
     return 0;
 }
 
+static inline bool gemm_is_big(int m, int n, int k) {
+    const long tiles128 = (long)ceil_div(m, BM) * ceil_div(n, BN);
+    return m >= BM && n >= BN && k >= BK && tiles128 >= 64;
+}
+
 // op(A)[i,k] = A[i*a_rs + k*a_cs], op(B)[k,j] = B[k*b_rs + j*b_cs]
 int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, const float *A, const float *B, float *C,
                   const Epilogue &ep) {
@@ -352,8 +447,7 @@ int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, co
     const long a_rs = trans_a ? 1 : k, a_cs = trans_a ? m : 1;  // gemm.rs:88-92
     const long b_rs = trans_b ? 1 : n, b_cs = trans_b ? k : 1;  // gemm.rs:93-97
     const bool a_kc = !trans_a, b_kc = trans_b != 0;
-    const long tiles128 = (long)ceil_div(m, BM) * ceil_div(n, BN);
-    const bool big = m >= BM && n >= BN && k >= BK && tiles128 >= 64;
+    const bool big = gemm_is_big(m, n, k);
 #define TH_GEMM_CASE(AK, BKC)                                                                               \
     if (a_kc == AK && b_kc == BKC)                                                                          \
         return big ? launch_tile128<AK, BKC>(ctx, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, ep)             \
@@ -389,25 +483,67 @@ int th_linear_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
     return gemm_dispatch(ctx, 0, 1, batch, out_features, in_features, d_x, d_w, d_y, ep);
 }
 
-int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, float *d_dx, float *d_dw,
-                  float *d_db, int batch, int in_features, int out_features, int accumulate_mask) {
+int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
+                  float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask) {
     TH_REQUIRE(ctx && d_dy, "th_linear_bwd: null argument");
-    if (d_dx) {  // dX[B,in] (+)= dY[B,out] . W[out,in]      (ops.rs:254-265 through the W^T node)
-        TH_REQUIRE(d_w, "th_linear_bwd: d_w required for d_dx");
+    TH_REQUIRE(!d_dx || d_w, "th_linear_bwd: d_w required for d_dx");
+    TH_REQUIRE(!d_dw || d_x, "th_linear_bwd: d_x required for d_dw");
+    if (batch == 0 || out_features == 0 || in_features == 0) return 0;
+    const bool dw_big = d_dw && gemm_is_big(out_features, in_features, batch);
+    const bool dx_big = d_dx && gemm_is_big(batch, in_features, out_features);
+    // latency-bound shapes (the MNIST MLP / classifier heads): the whole layer backward is ONE launch
+    if (!dw_big && !dx_big && batch <= 4096 && out_features <= 4096) {
+        LinearBwdArgs q{};
+        const int dw_tm = ceil_div(out_features, 16), dw_tn = ceil_div(in_features, 16);
+        const int dx_tm = ceil_div(batch, 16), dx_tn = ceil_div(in_features, 16);
+        q.n_dw = d_dw ? dw_tm * dw_tn : 0;
+        q.n_dx = d_dx ? dx_tm * dx_tn : 0;
+        q.dw_tiles_n = dw_tn;
+        q.dx_tiles_n = dx_tn;
+        // dW = dZ^T . X : op(A)[i=o,k=b] = dY[b*out + o] (rs 1, cs out); op(B)[k=b,j] = X[b*in + j]
+        q.dw = SmallArgs{d_dy, d_relu_y, d_x, d_dw, nullptr, out_features, in_features, batch, 1, out_features, in_features, 1,
+                         (batch + 15) / 16 * 16, 0, 0, Epilogue{1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f, nullptr, 0}};
+        // dX = dZ . W : op(A)[i=b,k=o] = dY[b*out + o] (rs out, cs 1); op(B)[k=o,j] = W[o*in + j]
+        q.dx = SmallArgs{d_dy, d_relu_y, d_w, d_dx, nullptr, batch, in_features, out_features, out_features, 1, in_features, 1,
+                         (out_features + 15) / 16 * 16, 0, 0, Epilogue{1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f, nullptr, 0}};
+        q.dx.a_vec = aligned16(d_dy) && (!d_relu_y || aligned16(d_relu_y)) && (out_features % 4 == 0);
+        q.dy = d_dy;
+        q.ymask = d_relu_y;
+        q.db = d_db;
+        q.batch = batch;
+        q.out_f = out_features;
+        q.db_accum = (accumulate_mask & 4) ? 1 : 0;
+        const int n_db = d_db ? ceil_div(out_features, 64) : 0;
+        const int grid = q.n_dw + q.n_dx + n_db;
+        if (grid == 0) return 0;
+        if (d_relu_y) hipLaunchKernelGGL(linear_bwd_small<true>, dim3(grid), dim3(256), 0, ctx->stream, q);
+        else hipLaunchKernelGGL(linear_bwd_small<false>, dim3(grid), dim3(256), 0, ctx->stream, q);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
+    // large shapes: MFMA tile kernels; the ReLU mask is materialised once
+    const float *dz = d_dy;
+    void *tmp = nullptr;
+    if (d_relu_y) {
+        const size_t n = (size_t)batch * out_features;
+        if (th_malloc(ctx, n * sizeof(float), &tmp)) return 1;
+        if (int rc = th_relu_bwd(ctx, d_relu_y, d_dy, (float *)tmp, n, 0)) return rc;
+        dz = (const float *)tmp;
+    }
+    if (d_dx) {  // dX[B,in] (+)= dZ[B,out] . W[out,in]      (ops.rs:254-265 through the W^T node)
         Epilogue ep{1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f, nullptr, 0};
-        if (int rc = gemm_dispatch(ctx, 0, 0, batch, in_features, out_features, d_dy, d_w, d_dx, ep)) return rc;
+        if (int rc = gemm_dispatch(ctx, 0, 0, batch, in_features, out_features, dz, d_w, d_dx, ep)) return rc;
     }
-    if (d_dw) {  // dW[out,in] (+)= dY^T[out,B] . X[B,in]     (ops.rs:280-291 + tensor.rs:574-587)
-        TH_REQUIRE(d_x, "th_linear_bwd: d_x required for d_dw");
+    if (d_dw) {  // dW[out,in] (+)= dZ^T[out,B] . X[B,in]     (ops.rs:280-291 + tensor.rs:574-587)
         Epilogue ep{1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f, nullptr, 0};
-        if (int rc = gemm_dispatch(ctx, 1, 0, out_features, in_features, batch, d_dy, d_x, d_dw, ep)) return rc;
+        if (int rc = gemm_dispatch(ctx, 1, 0, out_features, in_features, batch, dz, d_x, d_dw, ep)) return rc;
     }
-    if (d_db) {  // db[out] (+)= sum_b dY[b,out]               (tensor.rs:686-691)
-        if (int rc = (accumulate_mask & 4) ? th_colsum_accum(ctx, d_dy, d_db, batch, out_features)
-                                           : th_colsum(ctx, d_dy, d_db, batch, out_features))
+    if (d_db) {  // db[out] (+)= sum_b dZ[b,out]               (tensor.rs:686-691)
+        if (int rc = (accumulate_mask & 4) ? th_colsum_accum(ctx, dz, d_db, batch, out_features)
+                                           : th_colsum(ctx, dz, d_db, batch, out_features))
             return rc;
     }
-    return 0;
+    return tmp ? th_free(ctx, tmp) : 0;
 }
 
 }  // extern "C"

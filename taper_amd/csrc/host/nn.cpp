@@ -33,26 +33,40 @@ Tensor log_softmax(const Tensor &x, int dim) {  // loss.rs:101-126
 
 Tensor softmax(const Tensor &x, int dim) { return log_softmax(x, dim).exp(); }  // Q12
 
-Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out) {  // loss.rs:136-195
+Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log) {  // loss.rs:136-195
     const Shape &ts = targets.shape();
     TAPER_ASSERT(ts.size() == 1 || (ts.size() == 2 && ts[1] == 1), "Targets must be [B] or [B,1]");
     TAPER_ASSERT(logits.shape().size() == 2, "Logits must be [B,C]");
     TAPER_ASSERT(logits.shape()[0] == ts[0], "Batch sizes must match");
     const int b = (int)logits.shape()[0], c = (int)logits.shape()[1];
     th_ctx *ctx = Device::ctx();
+    const bool need_grad = logits.get_requires_grad();
     Tensor logp = Tensor::empty(logits.shape());
     Tensor loss = Tensor::empty({1});
+    // the gradient for an upstream grad of exactly 1 comes out of the forward kernel
+    std::shared_ptr<Buffer> dunit = need_grad ? Buffer::alloc(logits.len()) : nullptr;
     float *nc = nullptr;
     if (n_correct_out) {
         *n_correct_out = Tensor::empty({1});
         nc = n_correct_out->dptr();
     }
-    TH(th_softmax_xent_fwd(ctx, logits.dptr(), targets.dptr(), b, c, logp.dptr(), loss.dptr(), nullptr, nc));
-    if (logits.get_requires_grad()) {
+    TH(th_softmax_xent_fwd(ctx, logits.dptr(), targets.dptr(), b, c, logp.dptr(), loss.dptr(), nullptr, nc,
+                           dunit ? dunit->d : nullptr, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                           log ? log->d_state : nullptr, log ? log->advance : 0));
+    if (need_grad) {
         loss.set_requires_grad(true);
         Tensor lg = logits, lp = logp, t = targets, out = loss;
-        Tape::push(loss, true, [lg, lp, t, out, b, c]() {
+        Tape::push(loss, true, [lg, lp, t, out, dunit, b, c]() {
             if (!out.has_grad()) return;
+            if (out.grad_->shared_const && !lg.has_grad() && !lg.grad_->buf_is_arena) {
+                // loss.backward() on the root: upstream grad is the constant 1 and logits.grad is
+                // None -> (softmax - onehot)/B from the forward kernel IS the gradient: adopt it
+                lg.grad_->buf = dunit;
+                lg.grad_->has = true;
+                lg.grad_->known_zero = false;
+                lg.grad_->shared_const = false;
+                return;
+            }
             bool none;
             float *g = lg.grad_for_write(&none);
             TH(th_softmax_xent_bwd(Device::ctx(), lp.dptr(), t.dptr(), out.grad_dptr(), b, c, g, none ? 0 : 1));
@@ -190,6 +204,8 @@ FlatParams::FlatParams(const std::vector<Tensor> &ps) : params(ps) {
         auto view = Buffer::view(g_arena, (size_t)offsets[i], ps[i].len());
         if (had && g.buf) TH(th_memcpy_d2d(ctx, view->d, g.buf->d, ps[i].len() * sizeof(float)));
         g.buf = view;
+        g.buf_is_arena = true;
+        g.shared_const = false;
         g.known_zero = !had;
     }
     d_offsets_buf = Buffer::alloc((ps.size() + 1) * 2);
@@ -479,7 +495,9 @@ EpochResult Trainer::evaluate(DataLoader &loader) {  // train.rs:147-172
 }
 
 // The captured form of one step: identical op list, but nothing is read back;
-// the batch comes from the device-resident dataset through the device cursor.
+// the batch comes from the device-resident dataset through the device cursor and
+// the loss kernel itself appends {loss, n_correct} to the device log and advances
+// the step / cursor state.
 void Trainer::enqueue_step(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
                            size_t batch, bool from_cursor) {
     th_ctx *ctx = Device::ctx();
@@ -491,12 +509,17 @@ void Trainer::enqueue_step(const float *d_images, const float *d_labels, const i
     Tensor y = Tensor::from_device(yb_->d, {batch});
     Tensor logits = model->forward(shape_input(x, sample_shape));
     Tensor ncorrect;
-    Tensor loss = cross_entropy_loss(logits, y, &ncorrect);
+    StepLogSink sink{metrics_->d, (int64_t)metrics_cap_, state, (int64_t)batch};
+    Tensor loss = cross_entropy_loss(logits, y, &ncorrect, &sink);
     loss.backward();
     reduce_grads(*this);
     optimizer->step();
     optimizer->zero_grad();
-    TH(th_log_step(ctx, loss.dptr(), ncorrect.dptr(), metrics_->d, (int64_t)metrics_cap_, state, (int64_t)batch));
+}
+
+void Trainer::drop_graphs() {
+    for (auto &g : graphs_) th_graph_destroy(g.second);
+    graphs_.clear();
 }
 
 EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
@@ -508,44 +531,63 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     if (max_steps && max_steps < nb) nb = max_steps;
     const size_t n_full = std::min(nb, n / bs);
     if (!xb_ || xb_->n < bs * 784) {
+        drop_graphs();
         xb_ = Buffer::alloc(bs * 784);
         yb_ = Buffer::alloc(bs);
-        if (graph_) { th_graph_destroy(graph_); graph_ = nullptr; }
     }
     if (!state_) state_ = Buffer::alloc(4);
     if (metrics_cap_ < nb + 1) {
+        drop_graphs();
         metrics_cap_ = nb + 1;
         metrics_ = Buffer::alloc(2 * metrics_cap_);
-        if (graph_) { th_graph_destroy(graph_); graph_ = nullptr; }
     }
     TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // step = 0, cursor = 0
     const float *d_img = ds.images.dptr(), *d_lab = ds.labels.dptr();
     const int32_t *d_idx = loader.d_indices();
     const void *key = d_img;
-    if (graph_ && (graph_batch_ != bs || graph_key_ != key)) { th_graph_destroy(graph_); graph_ = nullptr; }
+    if (!graphs_.empty() && (graph_batch_ != bs || graph_key_ != key)) drop_graphs();
 
     size_t done = 0;
-    if (!graph_ && n_full > 0) {
-        // step 0 runs eagerly (pool warm-up, has_grad mask upload), then the SAME
-        // host code is replayed under stream capture to record the op list
+    if (graphs_.empty() && n_full > 0) {
+        // step 0 runs eagerly (pool warm-up, has_grad mask upload); then the SAME host code
+        // is run under stream capture to record the op list of 1 step and of a chunk of
+        // steps (one hipGraphLaunch per chunk amortises the ~10 us host cost of a replay)
         enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
         done = 1;
-        if (n_full > 1) {
+        const size_t chunk = graph_chunk;
+        for (size_t steps : {chunk, (size_t)1}) {
+            if (steps == 0 || (steps > 1 && n_full < 2 * steps)) continue;
+            if (!graphs_.empty() && graphs_.back().first == steps) continue;
             TH(th_graph_begin(ctx));
+            th_graph *g = nullptr;
             try {
-                enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
+                for (size_t s = 0; s < steps; ++s) enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
             } catch (...) {
-                th_graph *g = nullptr;
                 th_graph_end(ctx, &g);
                 th_graph_destroy(g);
                 throw;
             }
-            TH(th_graph_end(ctx, &graph_));
-            graph_batch_ = bs;
-            graph_key_ = key;
+            TH(th_graph_end(ctx, &g));
+            graphs_.emplace_back(steps, g);
+        }
+        graph_batch_ = bs;
+        graph_key_ = key;
+    }
+    while (done < n_full) {
+        bool launched = false;
+        for (auto &g : graphs_) {
+            if (done + g.first <= n_full) {
+                TH(th_graph_launch(ctx, g.second));
+                done += g.first;
+                launched = true;
+                break;
+            }
+        }
+        if (!launched) {  // no graph fits (e.g. n_full == 1 on a later call): run the step eagerly
+            enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
+            ++done;
         }
     }
-    for (; done < n_full; ++done) TH(th_graph_launch(ctx, graph_));
     if (nb > n_full) {  // the last, partial batch (mnist.rs:373-385 keeps it)
         const size_t rem = n - n_full * bs;
         enqueue_step(d_img, d_lab, d_idx, (int64_t)n, rem, true);
@@ -571,8 +613,6 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     return r;
 }
 
-Trainer::~Trainer() {
-    if (graph_) th_graph_destroy(graph_);
-}
+Trainer::~Trainer() { drop_graphs(); }
 
 }  // namespace taper

@@ -44,6 +44,7 @@ class Device {
     static int device_id();
     static void sync();
     static void shutdown();
+    static float *ones1();  // persistent device constant [1.0f]: the implicit upstream grad of a scalar root
 };
 
 // Device storage.  `owned` buffers return to the ctx pool on destruction;
@@ -66,6 +67,8 @@ struct GradSlot {
     std::shared_ptr<Buffer> buf;  // storage; may be a view into an optimizer's flat arena
     bool has = false;             // Some / None
     bool known_zero = false;      // arena slice currently all-zero (DP all-reduce of grad-less params)
+    bool shared_const = false;    // buf is the ctx-wide read-only [1.0] (set by backward() on a scalar root)
+    bool buf_is_arena = false;    // buf is a view into an optimizer's flat grad arena (never re-pointed)
 };
 
 class Tensor {
@@ -164,8 +167,16 @@ bool full_backward();
 // ---- loss (src/loss.rs) ------------------------------------------------------
 Tensor log_softmax(const Tensor &x, int dim = -1);                         // loss.rs:101-126
 Tensor softmax(const Tensor &x, int dim = -1);                             // exp(log_softmax), Q12
+// Device-side step log folded into the loss kernel (th_softmax_xent_fwd): see Trainer.
+struct StepLogSink {
+    float *d_metrics = nullptr;
+    int64_t capacity = 0;
+    int64_t *d_state = nullptr;
+    int64_t advance = 0;
+};
 // n_correct_out (optional): device scalar receiving accuracy()*B from the fused kernel
-Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out = nullptr);  // loss.rs:136-195
+Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out = nullptr,
+                          const StepLogSink *log = nullptr);  // loss.rs:136-195
 float accuracy(const Tensor &predictions, const Tensor &targets);          // loss.rs:271-290 (synchronises)
 Tensor one_hot(const Tensor &indices, size_t num_classes);                 // loss.rs:248-268
 Tensor mse_loss(const Tensor &pred, const Tensor &targets);                // loss.rs:76-80
@@ -395,6 +406,7 @@ class Trainer {  // train.rs:74-172
     std::shared_ptr<Communicator> comm;   // optional: data-parallel grad all-reduce before step()
     Shape sample_shape;                   // {} -> feed [B,784]; {1,28,28} -> reshape like train_mnist_cnn.rs:161-162
     std::string device = "hip:gfx950";    // train.rs:79 "For future GPU support"
+    size_t graph_chunk = 32;              // steps captured per hipGraph replay (plus a 1-step graph for the tail)
     Trainer(std::shared_ptr<Module> m, std::shared_ptr<Adam> o) : model(std::move(m)), optimizer(std::move(o)) {}
 
     // one step exactly as examples/train_mnist.rs:89-121 (reads loss + accuracy back every step)
@@ -409,7 +421,8 @@ class Trainer {  // train.rs:74-172
    private:
     void enqueue_step(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
                       size_t batch, bool from_cursor);
-    th_graph *graph_ = nullptr;
+    void drop_graphs();
+    std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
     size_t graph_batch_ = 0;
     const void *graph_key_ = nullptr;
     std::shared_ptr<Buffer> xb_, yb_, state_, metrics_, step_loss_, step_ncorrect_;

@@ -26,6 +26,7 @@ size_t numel(const Shape &s) {
 namespace {
 thread_local th_ctx *t_ctx = nullptr;
 thread_local int t_device = -1;
+thread_local float *t_ones = nullptr;
 
 int default_device() {
     if (t_device >= 0) return t_device;
@@ -54,9 +55,20 @@ void Device::set_device(int id) {
 }
 int Device::device_id() { return t_ctx ? t_device : default_device(); }
 void Device::sync() { TH(th_ctx_sync(ctx())); }
+float *Device::ones1() {
+    if (!t_ones) {
+        void *p = nullptr;
+        TH(th_malloc(ctx(), 256, &p));
+        t_ones = (float *)p;
+        TH(th_fill_f32(ctx(), t_ones, 1.0f, 4));
+    }
+    return t_ones;
+}
+
 void Device::shutdown() {
     if (t_ctx) {
         Tape::reset();
+        t_ones = nullptr;
         th_ctx_destroy(t_ctx);
         t_ctx = nullptr;
     }
@@ -205,6 +217,12 @@ void Tensor::set_grad(const std::vector<float> &g) {
 }
 
 float *Tensor::grad_for_write(bool *was_none) const {
+    if (grad_->shared_const) {  // never write through the shared [1.0]: give the slot private storage first
+        auto priv = Buffer::alloc(len());
+        if (grad_->has) TH(th_memcpy_d2d(Device::ctx(), priv->d, grad_->buf->d, len() * sizeof(float)));
+        grad_->buf = priv;
+        grad_->shared_const = false;
+    }
     if (!grad_->buf) grad_->buf = Buffer::alloc(len());
     if (was_none) *was_none = !grad_->has;
     grad_->has = true;
@@ -220,13 +238,27 @@ float *Tensor::grad_accum_ptr() const {  // `if slot.is_none() { zeros }` (ops.r
 }
 
 void Tensor::backward() const {  // tensor.rs:520-529
-    bool none;
-    float *g = grad_for_write(&none);
-    TH(th_fill_f32(Device::ctx(), g, 1.0f, len()));
+    if (len() == 1 && !grad_->buf_is_arena) {
+        // scalar root (a loss): grad = [1.0] is the ctx-wide constant, no fill launch
+        grad_->buf = Buffer::borrow(Device::ones1(), 1);
+        grad_->has = true;
+        grad_->known_zero = false;
+        grad_->shared_const = true;
+    } else {
+        bool none;
+        float *g = grad_for_write(&none);
+        TH(th_fill_f32(Device::ctx(), g, 1.0f, len()));
+    }
     if (*tape_node_ != 0) Tape::backward(*tape_node_);  // tensor.rs:526: id 0 = "no node" (in both id schemes)
 }
 
-void Tensor::zero_grad() const { grad_->has = false; }  // tensor.rs:531-533
+void Tensor::zero_grad() const {  // tensor.rs:531-533
+    grad_->has = false;
+    if (grad_->shared_const) {
+        grad_->buf.reset();
+        grad_->shared_const = false;
+    }
+}
 
 // t.grad (+)= alpha * src  -- accumulate_grad / accumulate_grad_scaled (ops.rs:124-151)
 static void accumulate_into(const Tensor &t, const float *src, float alpha = 1.0f) {
@@ -433,19 +465,16 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
             if (!r.has_grad()) return;
             th_ctx *c = Device::ctx();
             const float *dy = r.grad_dptr();
-            std::shared_ptr<Buffer> dz;
-            if (relu) {  // relu backward through the post-activation mask (y > 0 <=> pre-activation > 0, Q15)
-                dz = Buffer::alloc(r.len());
-                TH(th_relu_bwd(c, r.dptr(), dy, dz->d, r.len(), 0));
-                dy = dz->d;
-            }
+            // relu backward through the post-activation mask (y > 0 <=> pre-activation > 0, Q15),
+            // folded into the operand loads of the backward GEMMs
+            const float *relu_y = relu ? r.dptr() : nullptr;
             int mask = 0;
             bool none;
             float *dx = nullptr, *dw = nullptr, *db = nullptr;
             if (x.get_requires_grad()) { dx = x.grad_for_write(&none); if (!none) mask |= 1; }
             if (wt.get_requires_grad()) { dw = wt.grad_for_write(&none); if (!none) mask |= 2; }
             if (b.defined() && b.get_requires_grad()) { db = b.grad_for_write(&none); if (!none) mask |= 4; }
-            TH(th_linear_bwd(c, x.dptr(), wt.dptr(), dy, dx, dw, db, batch, in_f, out_f, mask));
+            TH(th_linear_bwd(c, x.dptr(), wt.dptr(), dy, relu_y, dx, dw, db, batch, in_f, out_f, mask));
         });
     }
     return out;

@@ -19,18 +19,6 @@ __device__ __forceinline__ float powi_f32(float a, int b) {
     return recip ? 1.0f / r : r;
 }
 
-// t += 1; step_size = lr * sqrt(1 - b2^t) / (1 - b1^t)   (optim.rs:84-90)
-__global__ void adam_tick_kernel(int32_t *__restrict__ t_state, const float *__restrict__ lr, float beta1, float beta2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int t = t_state[0] + 1;
-        t_state[0] = t;
-        const float bc1 = 1.0f - powi_f32(beta1, t);
-        const float bc2 = 1.0f - powi_f32(beta2, t);
-        const float step = lr[0] * (sqrtf(bc2) / bc1);
-        t_state[1] = __float_as_int(step);
-    }
-}
-
 __device__ __forceinline__ int find_tensor(const int64_t *__restrict__ offsets, int n_tensors, int64_t i) {
     int lo = 0, hi = n_tensors;  // offsets[lo] <= i < offsets[hi]
     while (hi - lo > 1) {
@@ -40,12 +28,20 @@ __device__ __forceinline__ int find_tensor(const int64_t *__restrict__ offsets, 
     return lo;
 }
 
+// One launch per step.  Every workgroup reads the OLD step counter t, forms
+// t+1 and step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) (optim.rs:84-90) itself;
+// the LAST workgroup to finish (agent-scope arrival counter in t_state[1])
+// publishes t+1 -- by then every other workgroup has long read the old value,
+// so a captured graph advances t on every replay without a separate tick kernel.
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, const int64_t *__restrict__ offsets,
                                                    const int32_t *__restrict__ has_grad, int n_tensors, int64_t total,
-                                                   const int32_t *__restrict__ t_state, float beta1, float beta2, float eps,
-                                                   float wd) {
-    const float step = __int_as_float(t_state[1]);
+                                                   int32_t *t_state, const float *__restrict__ lr, float beta1, float beta2,
+                                                   float eps, float wd) {
+    const int t = __hip_atomic_load(&t_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;  // optim.rs:84
+    const float bc1 = 1.0f - powi_f32(beta1, t);
+    const float bc2 = 1.0f - powi_f32(beta2, t);
+    const float step = lr[0] * (sqrtf(bc2) / bc1);
     const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ti = find_tensor(offsets, n_tensors, i);
@@ -57,6 +53,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         m[i] = mv;
         v[i] = vv;
         p[i] = pv - step * mv / (sqrtf(vv) + eps);         // optim.rs:110 (Q10)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int arrived = __hip_atomic_fetch_add(&t_state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == (int)gridDim.x - 1) {
+            __hip_atomic_store(&t_state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&t_state[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -121,11 +125,10 @@ int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m,
                  float beta2, float eps, float weight_decay) {
     TH_REQUIRE(ctx && d_params && d_grads && d_m && d_v && d_offsets && d_has_grad && d_t && d_lr, "th_adam_step: null argument");
     TH_REQUIRE(n_tensors > 0 && total >= 0, "th_adam_step: bad sizes");
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, ctx->stream, d_t, d_lr, beta1, beta2);
-    TH_LAUNCH_CHECK();
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((size_t)total, 256)), dim3(256), 0, ctx->stream, d_params, d_grads, d_m, d_v,
-                       d_offsets, d_has_grad, n_tensors, total, (const int32_t *)d_t, beta1, beta2, eps, weight_decay);
+    // the grid is never empty so that t always advances (optim.rs:84 increments even with no grads)
+    const int grid = ew_grid((size_t)(total > 0 ? total : 1), 256);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_params, d_grads, d_m, d_v, d_offsets, d_has_grad,
+                       n_tensors, total, d_t, d_lr, beta1, beta2, eps, weight_decay);
     TH_LAUNCH_CHECK();
     return 0;
 }

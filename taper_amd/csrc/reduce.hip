@@ -196,21 +196,28 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x
 }
 
 // ---- fused log-softmax + NLL + argmax (loss.rs:101-195, 271-290) ---------
-// One wave per row (classes strided over lanes), 4 rows per block.  The
-// per-row NLL terms go to `row_nll`; a second single-block kernel adds them
-// in a fixed tree order and scales by 1/B.
-__global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float *__restrict__ logits,
-                                                                const float *__restrict__ targets, int batch, int classes,
-                                                                float *__restrict__ logp, float *__restrict__ row_nll,
-                                                                float *__restrict__ argmax_out, float *__restrict__ row_hit) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= batch) return;
-    const float *x = logits + (long)row * classes;
-    // row max + first argmax (tensor.rs:1062)
+// A row is owned by LPR lanes (16 when classes <= 16 -- four rows per wave for
+// the 10-class MNIST head -- else a whole wave); reductions are xor-shuffles
+// inside the lane group.  Per row: first-max argmax (tensor.rs:1062), logp,
+// the NLL term, the accuracy hit, and optionally the unit-upstream gradient
+// (softmax - onehot) * (1/B) so that backward() from the loss needs no launch.
+struct XentArgs {
+    const float *logits, *targets;
+    int batch, classes;
+    float *logp, *argmax_out, *dunit;   // nullable
+};
+
+__device__ __forceinline__ long target_class(float tf) {  // Rust `as usize`: saturating, NaN -> 0
+    return (tf >= 0.f) ? (long)fminf(tf, 2147483520.f) : 0;
+}
+
+// returns (nll, hit) of `row`, valid in the group's first lane
+template <int LPR>
+__device__ __forceinline__ void xent_row(const XentArgs &a, int row, int sub, float &nll, float &hit) {
+    const float *x = a.logits + (long)row * a.classes;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = lane; c < classes; c += 64) {
+    for (int c = sub; c < a.classes; c += LPR) {
         const float v = x[c];
         if (v > best) {
             best = v;
@@ -218,45 +225,120 @@ __global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float *__r
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = LPR / 2; off > 0; off >>= 1) {
         const float ov = __shfl_xor(best, off, 64);
         const int oi = __shfl_xor(bi, off, 64);
         argmax_combine(best, bi, ov, oi);
     }
     if (bi == 0x7fffffff) bi = 0;
-    // sum exp(x - max)
     float s = 0.f;
-    for (int c = lane; c < classes; c += 64) s += expf(x[c] - best);
-    s = wave_sum_all(s);
+    for (int c = sub; c < a.classes; c += LPR) s += expf(x[c] - best);
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float log_sum = logf(s);
-    const float tf = targets ? targets[row] : 0.f;
-    // Rust `as usize`: saturating, NaN -> 0
-    const long cls = (tf >= 0.f) ? (long)fminf(tf, 2147483520.f) : 0;
-    for (int c = lane; c < classes; c += 64) {
+    const float tf = a.targets ? a.targets[row] : 0.f;
+    const long cls = target_class(tf);
+    const float inv_b = 1.0f / (float)a.batch;
+    float my_nll = 0.f;
+    for (int c = sub; c < a.classes; c += LPR) {
         const float lp = (x[c] - best) - log_sum;  // loss.rs:117-125
-        if (logp) logp[(long)row * classes + c] = lp;
-        if (row_nll && c == cls) row_nll[row] = -lp;
+        if (a.logp) a.logp[(long)row * a.classes + c] = lp;
+        if (c == cls) my_nll = -lp;
+        if (a.dunit) {  // loss.rs:174-191 with g0 = 1: (exp(logp) - onehot) * (1 / B)
+            float gv = expf(lp);
+            if (c == cls) gv -= 1.0f;
+            a.dunit[(long)row * a.classes + c] = gv * inv_b;
+        }
     }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) my_nll += __shfl_xor(my_nll, off, 64);  // exactly one lane holds it
+    nll = (cls >= a.classes) ? NAN : my_nll;  // the reference panics (loss.rs:161)
+    hit = (fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;  // loss.rs:283
+    if (sub == 0 && a.argmax_out) a.argmax_out[row] = (float)bi;
+}
+
+struct StepLog {  // th_log_step folded into the loss kernel (nullable metrics)
+    float *metrics;
+    int64_t capacity;
+    int64_t *state;
+    int64_t advance;
+};
+
+__device__ __forceinline__ void step_log(const StepLog &lg, float loss, float ncorrect) {
+    if (!lg.metrics) return;
+    const int64_t s = lg.state[0] % lg.capacity;
+    lg.metrics[2 * s] = loss;
+    lg.metrics[2 * s + 1] = ncorrect;
+    lg.state[0] += 1;
+    lg.state[1] += lg.advance;
+}
+
+// whole batch in ONE workgroup (batch <= 1024): rows -> block reduce -> loss, count, log
+template <int LPR>
+__global__ __launch_bounds__(1024) void softmax_xent_fused_kernel(XentArgs a, float *__restrict__ loss, float *__restrict__ ncorrect,
+                                                                  StepLog lg) {
+    __shared__ float sh_n[16], sh_h[16];
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
+    float acc_n = 0.f, acc_h = 0.f;
+    for (int row = grp; row < a.batch; row += ngrp) {  // whole lane groups iterate together
+        float nll, hit;
+        xent_row<LPR>(a, row, sub, nll, hit);
+        if (sub == 0) {
+            acc_n += nll;
+            acc_h += hit;
+        }
+    }
+    acc_n = wave_sum(acc_n);
+    acc_h = wave_sum(acc_h);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (lane == 0) {
-        if (row_nll && cls >= classes) row_nll[row] = NAN;  // the reference panics (loss.rs:161)
-        if (argmax_out) argmax_out[row] = (float)bi;
-        if (row_hit) row_hit[row] = (fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;  // loss.rs:283
+        sh_n[wave] = acc_n;
+        sh_h[wave] = acc_h;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float n = 0.f, h = 0.f;
+        for (int w = 0; w < nw; ++w) {
+            n += sh_n[w];
+            h += sh_h[w];
+        }
+        const float l = n / (float)a.batch;  // loss.rs:164
+        loss[0] = l;
+        if (ncorrect) ncorrect[0] = h;
+        step_log(lg, l, h);
+    }
+}
+
+// large batches: rows spread over the chip, per-row terms to scratch, then a finish kernel
+template <int LPR>
+__global__ __launch_bounds__(256) void softmax_xent_rows_kernel(XentArgs a, float *__restrict__ row_nll, float *__restrict__ row_hit) {
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = 256 / LPR;
+    const int row = blockIdx.x * ngrp + grp;
+    if (row >= a.batch) return;  // whole lane groups exit together; shuffles stay inside a group
+    float nll, hit;
+    xent_row<LPR>(a, row, sub, nll, hit);
+    if (sub == 0) {
+        if (row_nll) row_nll[row] = nll;
+        if (row_hit) row_hit[row] = hit;
     }
 }
 
 __global__ __launch_bounds__(256) void xent_finish_kernel(const float *__restrict__ row_nll, const float *__restrict__ row_hit,
-                                                          int batch, float *__restrict__ loss, float *__restrict__ ncorrect) {
+                                                          int batch, float *__restrict__ loss, float *__restrict__ ncorrect,
+                                                          StepLog lg) {
     __shared__ float sh[4];
     float s = 0.f, h = 0.f;
     for (int i = threadIdx.x; i < batch; i += 256) {
         s += row_nll[i];
-        if (row_hit) h += row_hit[i];
+        h += row_hit[i];
     }
     s = block_sum_256(s, sh);
     h = block_sum_256(h, sh);
     if (threadIdx.x == 0) {
-        loss[0] = s / (float)batch;  // loss.rs:164
+        const float l = s / (float)batch;  // loss.rs:164
+        loss[0] = l;
         if (ncorrect) ncorrect[0] = h;
+        step_log(lg, l, h);
     }
 }
 
@@ -269,7 +351,7 @@ __global__ __launch_bounds__(256) void softmax_xent_bwd_kernel(const float *__re
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int row = (int)(i / classes), c = (int)(i % classes);
         const float tf = targets[row];
-        const long cls = (tf >= 0.f) ? (long)fminf(tf, 2147483520.f) : 0;
+        const long cls = target_class(tf);
         float gval = expf(logp[i]);
         if (c == cls) gval -= 1.0f;
         dlogits[i] = accumulate ? dlogits[i] + gval * scale : gval * scale;
@@ -410,16 +492,30 @@ int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, 
 }
 
 int th_softmax_xent_fwd(th_ctx *ctx, const float *d_logits, const float *d_targets, int batch, int classes, float *d_logp,
-                        float *d_loss, float *d_argmax, float *d_ncorrect) {
+                        float *d_loss, float *d_argmax, float *d_ncorrect, float *d_dlogits_unit, float *d_metrics,
+                        int64_t metrics_capacity, int64_t *d_state, int64_t advance) {
     TH_REQUIRE(ctx && d_logits && d_targets && d_loss && batch > 0 && classes > 0, "th_softmax_xent_fwd: bad argument");
+    TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_softmax_xent_fwd: metrics need d_state and a capacity");
+    XentArgs a{d_logits, d_targets, batch, classes, d_logp, d_argmax, d_dlogits_unit};
+    StepLog lg{d_metrics, metrics_capacity, d_state, advance};
+    const bool narrow = classes <= 16;
+    if (batch <= 1024) {  // one launch: rows, reduction, loss, count and the step log
+        const int lpr = narrow ? 16 : 64;
+        int threads = ((batch * lpr + 63) / 64) * 64;
+        threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : threads);
+        if (narrow) hipLaunchKernelGGL(softmax_xent_fused_kernel<16>, dim3(1), dim3(threads), 0, ctx->stream, a, d_loss, d_ncorrect, lg);
+        else hipLaunchKernelGGL(softmax_xent_fused_kernel<64>, dim3(1), dim3(threads), 0, ctx->stream, a, d_loss, d_ncorrect, lg);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
     void *tmp = nullptr;
     if (th_malloc(ctx, 2 * (size_t)batch * sizeof(float), &tmp)) return 1;
     float *row_nll = (float *)tmp, *row_hit = row_nll + batch;
-    hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3(ceil_div(batch, 4)), dim3(256), 0, ctx->stream, d_logits, d_targets, batch,
-                       classes, d_logp, row_nll, d_argmax, row_hit);
+    if (narrow) hipLaunchKernelGGL(softmax_xent_rows_kernel<16>, dim3(ceil_div(batch, 16)), dim3(256), 0, ctx->stream, a, row_nll, row_hit);
+    else hipLaunchKernelGGL(softmax_xent_rows_kernel<64>, dim3(ceil_div(batch, 4)), dim3(256), 0, ctx->stream, a, row_nll, row_hit);
     TH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(xent_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float *)row_nll,
-                       d_ncorrect ? (const float *)row_hit : (const float *)nullptr, batch, d_loss, d_ncorrect);
+    hipLaunchKernelGGL(xent_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float *)row_nll, (const float *)row_hit, batch,
+                       d_loss, d_ncorrect, lg);
     TH_LAUNCH_CHECK();
     return th_free(ctx, tmp);
 }
@@ -437,8 +533,11 @@ int th_softmax_xent_bwd(th_ctx *ctx, const float *d_logp, const float *d_targets
 int th_log_softmax_fwd(th_ctx *ctx, const float *d_x, float *d_logp, int rows, int cols) {
     TH_REQUIRE(ctx && d_x && d_logp && rows >= 0 && cols > 0, "th_log_softmax_fwd: bad argument");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ctx->stream, d_x,
-                       (const float *)nullptr, rows, cols, d_logp, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    XentArgs a{d_x, nullptr, rows, cols, d_logp, nullptr, nullptr};
+    if (cols <= 16)
+        hipLaunchKernelGGL(softmax_xent_rows_kernel<16>, dim3(ceil_div(rows, 16)), dim3(256), 0, ctx->stream, a, (float *)nullptr, (float *)nullptr);
+    else
+        hipLaunchKernelGGL(softmax_xent_rows_kernel<64>, dim3(ceil_div(rows, 4)), dim3(256), 0, ctx->stream, a, (float *)nullptr, (float *)nullptr);
     TH_LAUNCH_CHECK();
     return 0;
 }

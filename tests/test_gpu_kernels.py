@@ -131,17 +131,20 @@ def test_linear_fwd_bwd(ctx, O, batch, inf, outf, relu):
     ctx.call("th_linear_fwd", dx_, dw_, db_, y, batch, inf, outf, relu)
     yv = ctx.download(y, (batch, outf))
     close(yv, out.data())
-    dz = dy * (yv > 0) if relu else dy
-    dzd = ctx.upload(dz.astype(np.float32))
     gx, gw, gb = ctx.empty(batch * inf), ctx.empty(outf * inf), ctx.empty(outf)
-    ctx.call("th_linear_bwd", dx_, dw_, dzd, gx, gw, gb, batch, inf, outf, 0)   # grads were None: overwrite
+    # the ReLU backward is folded into the kernel through the post-activation output (Q15)
+    ctx.call("th_linear_bwd", dx_, dw_, dyd, y if relu else None, gx, gw, gb, batch, inf, outf, 0)   # grads were None: overwrite
     close(ctx.download(gx, (batch, inf)), xt.grad())
     close(ctx.download(gw, (outf, inf)), wt.grad())
     close(ctx.download(gb, (outf,)), bt.grad())
-    ctx.call("th_linear_bwd", dx_, dw_, dzd, gx, gw, gb, batch, inf, outf, 7)   # accumulate on top
+    ctx.call("th_linear_bwd", dx_, dw_, dyd, y if relu else None, gx, gw, gb, batch, inf, outf, 7)   # accumulate on top
     close(ctx.download(gw, (outf, inf)), 2 * wt.grad())
     close(ctx.download(gx, (batch, inf)), 2 * xt.grad())
     close(ctx.download(gb, (outf,)), 2 * bt.grad())
+    # partial outputs: dW only (layer 1 of the MLP: the input has no grad, ops.rs:243)
+    gw2 = ctx.empty(outf * inf)
+    ctx.call("th_linear_bwd", dx_, None, dyd, y if relu else None, None, gw2, None, batch, inf, outf, 0)
+    close(ctx.download(gw2, (outf, inf)), wt.grad())
     O.Tape.reset()
 
 
@@ -282,7 +285,8 @@ def test_rowmax_colmax_bit_exact(ctx, O, rows, cols):
 
 
 # ------------------------------------------------------------------ softmax cross-entropy
-@pytest.mark.parametrize("batch,classes", [(64, 10), (128, 10), (256, 10), (1024, 10), (1, 2), (7, 3), (32, 100), (5, 1)])
+@pytest.mark.parametrize("batch,classes", [(64, 10), (128, 10), (256, 10), (1024, 10), (1, 2), (7, 3), (32, 100), (5, 1),
+                                           (2048, 10), (1500, 37), (63, 16), (65, 17)])
 def test_softmax_xent(ctx, O, batch, classes):
     rng = np.random.default_rng(batch * 17 + classes)
     logits = (rng.standard_normal((batch, classes)) * 3).astype(np.float32)
@@ -302,7 +306,15 @@ def test_softmax_xent(ctx, O, batch, classes):
     ref_acc = O.accuracy(O.Tensor(logits), tt)
     dl, dt = ctx.upload(logits), ctx.upload(targets)
     logp, dloss, am, nc = ctx.empty(batch * classes), ctx.empty(1), ctx.empty(batch), ctx.empty(1)
-    ctx.call("th_softmax_xent_fwd", dl, dt, batch, classes, logp, dloss, am, nc)
+    dunit = ctx.empty(batch * classes)
+    state, metrics = ctx.upload(np.array([2, 100], np.int64)), ctx.zeros(2 * 8)
+    ctx.call("th_softmax_xent_fwd", dl, dt, batch, classes, logp, dloss, am, nc, dunit, metrics, 8, state, batch)
+    close(ctx.download(dunit, (batch, classes)), lt.grad(), atol=1e-7)      # unit-upstream gradient from the forward kernel
+    np.testing.assert_array_equal(ctx.download(state, 2, np.int64), [3, 100 + batch])   # fused th_log_step
+    mrow = ctx.download(metrics, (8, 2))[2]
+    assert mrow[0] == ctx.download(dloss, 1)[0] and mrow[1] == ctx.download(nc, 1)[0]
+    ctx.call("th_softmax_xent_fwd", dl, dt, batch, classes, None, dloss, None, None, None, None, 0, None, 0)   # all optionals off
+    np.testing.assert_allclose(ctx.download(dloss, 1)[0], loss.data()[0], rtol=RTOL, atol=1e-6)
     close(ctx.download(logp, (batch, classes)), ref_logp, atol=1e-5)
     np.testing.assert_allclose(ctx.download(dloss, 1)[0], loss.data()[0], rtol=RTOL, atol=1e-6)
     np.testing.assert_array_equal(ctx.download(am, batch), ref_am)                 # index work: bit-exact
@@ -575,3 +587,18 @@ def test_error_paths(ctx):
     with pytest.raises(TaperError):
         x = ctx.zeros(16)
         ctx.call("th_conv3x3_fwd", x, x, None, x, 1, 1, 4, 4, 1, 2, 0, 0)   # pad 2 unsupported
+
+
+def test_rccl_single_rank_allreduce(ctx):
+    """th_comm_* over RCCL with one rank: sum over ranks is the identity, then the 1/W scale"""
+    import ctypes
+    from taper_amd._lib import hip as lib, th_check
+    uid = (ctypes.c_uint8 * 128)()
+    th_check(lib.th_comm_unique_id(uid), "th_comm_unique_id")
+    comm = ctypes.c_void_p()
+    th_check(lib.th_comm_init_rank(ctx.h, 1, 0, uid, ctypes.byref(comm)), "th_comm_init_rank")
+    x = np.arange(101_772, dtype=np.float32)
+    d = ctx.upload(x)
+    th_check(lib.th_allreduce_sum_scale(comm, ctx.h, int(d), x.size, 0.5), "th_allreduce_sum_scale")
+    np.testing.assert_array_equal(ctx.download(d, x.size), x * np.float32(0.5))
+    lib.th_comm_destroy(comm)
