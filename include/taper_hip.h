@@ -38,6 +38,18 @@ typedef struct th_graph th_graph;
 typedef struct th_event th_event;
 typedef struct th_comm th_comm;
 
+/* Adam update applied in the epilogue of the kernel that produces a parameter's
+ * gradient (src/optim.rs:99-110 for that tensor, same arithmetic as
+ * th_adam_step).  Slices of the flat p / m / v arenas at the parameter's offset;
+ * d_t is the step counter ALREADY advanced for this step (th_adam_tick or the
+ * tick folded into th_softmax_xent_fwd / th_linear_xent_head). */
+typedef struct th_adam_fuse {
+    float *d_p, *d_m, *d_v;
+    const int32_t *d_t;
+    const float *d_lr;
+    float beta1, beta2, eps, weight_decay;
+} th_adam_fuse;
+
 /* ---- runtime --------------------------------------------------------- */
 const char *th_last_error(void);
 int th_device_count(int *out);
@@ -96,6 +108,29 @@ int th_linear_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
 int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y,
                   float *d_dx, float *d_dw, float *d_db, int batch, int in_features, int out_features,
                   int accumulate_mask);
+/* same, and additionally applies the Adam update of W / b in the epilogue
+ * (w_fuse / b_fuse nullable).  A fused tensor's gradient must be complete in
+ * this call: its accumulate_mask bit must be clear (grad slot was None). */
+int th_linear_bwd_adam(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y,
+                       float *d_dx, float *d_dw, float *d_db, int batch, int in_features, int out_features,
+                       int accumulate_mask, const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse);
+
+/* ---- fused classifier head: last Linear + softmax cross-entropy --------- */
+/* One workgroup computes logits = H[B,in] . W[C,in]^T + b (nn.rs:54-60), the
+ * loss / accuracy count / step log of th_softmax_xent_fwd (loss.rs:101-195,
+ * 271-290) AND the backward products for an upstream gradient of exactly 1:
+ *   dlogits = (softmax - onehot)/B,  d_dw[C,in] = dlogits^T . H,  d_db[C] = colsum(dlogits),
+ *   d_dh[B,in] = dlogits . W   (the ReLU mask of the previous layer is applied by ITS backward).
+ * Requires classes <= 16, in_features <= 256, batch <= 4096.  Nullable:
+ * d_bias, d_logits, d_ncorrect, d_dh, d_dw, d_db, metrics/state, d_adam_tick,
+ * w_fuse, b_fuse.  d_adam_tick (int32[2], th_adam_step's d_t): t += 1 is done
+ * here (optim.rs:84) so that the fused updates of this step see the new t.
+ * W / b are updated (fuse) only after every read of W in this launch. */
+int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d_w, const float *d_bias, const float *d_targets,
+                        int batch, int in_features, int classes, float *d_logits, float *d_loss, float *d_ncorrect,
+                        float *d_dh, float *d_dw, float *d_db, float *d_metrics, int64_t metrics_capacity,
+                        int64_t *d_state, int64_t advance, int32_t *d_adam_tick, const th_adam_fuse *w_fuse,
+                        const th_adam_fuse *b_fuse);
 
 /* ---- element-wise: src/ops.rs:8-120,377-496; src/tensor.rs:36-161 ----- */
 int th_add(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
@@ -151,7 +186,8 @@ int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, 
  * d_metrics / d_state (nullable): th_log_step folded into this kernel. */
 int th_softmax_xent_fwd(th_ctx *ctx, const float *d_logits, const float *d_targets, int batch, int classes,
                         float *d_logp, float *d_loss, float *d_argmax, float *d_ncorrect, float *d_dlogits_unit,
-                        float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance);
+                        float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                        int32_t *d_adam_tick /* nullable: t += 1 here, see th_adam_step pre_ticked */);
 /* dlogits (+)= (exp(logp) - onehot) * (g0 / B), g0 read from device (the
  * upstream scalar grad, loss.rs:174-191); accumulate=0 overwrites */
 int th_softmax_xent_bwd(th_ctx *ctx, const float *d_logp, const float *d_targets, const float *d_g0,
@@ -206,7 +242,10 @@ int th_avgpool2d_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int n, int 
  * d_lr[1]: learning rate on device (set_lr, optim.rs:125-127). */
 int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v,
                  const int64_t *d_offsets, const int32_t *d_has_grad, int n_tensors, int64_t total,
-                 int32_t *d_t, const float *d_lr, float beta1, float beta2, float eps, float weight_decay);
+                 int32_t *d_t, const float *d_lr, float beta1, float beta2, float eps, float weight_decay,
+                 int pre_ticked /* 1: d_t[0] was already advanced for this step; use it as is */);
+/* t += 1 alone (optim.rs:84), for steps whose updates all ran fused */
+int th_adam_tick(th_ctx *ctx, int32_t *d_t);
 int th_sgd_step(th_ctx *ctx, float *d_params, const float *d_grads, const int64_t *d_offsets,
                 const int32_t *d_has_grad, int n_tensors, int64_t total, const float *d_lr); /* optim.rs:21-33 */
 

@@ -488,9 +488,11 @@ class Trainer:
 
     EAGER, GRAPH, EVAL = 0, 1, 2
 
-    def __init__(self, model: Module, optimizer: Adam, sample_shape=None, comm: Communicator | None = None):
+    def __init__(self, model: Module, optimizer: Adam, sample_shape=None, comm: Communicator | None = None,
+                 graph_chunk: int = 32, fuse_head: bool = True, fuse_adam: bool = True):
         self.model, self.optimizer, self.comm = model, optimizer, comm
         self._h = _mk(host.tp_trainer_new, "Trainer::new", model._h, optimizer._h)
+        tp_check(host.tp_trainer_set_options(self._h, int(graph_chunk), 1 if fuse_head else 0, 1 if fuse_adam else 0), "set_options")
         if sample_shape:
             tp_check(host.tp_trainer_set_sample_shape(self._h, _shape_arr(sample_shape), len(sample_shape)), "set_sample_shape")
         if comm is not None:

@@ -11,7 +11,7 @@
 //    For the latency-bound MNIST-MLP shapes (64x128x784, 128x784x64, ...).
 // Operands are described by (row stride, col stride) so NN / NT / TN / TT all
 // run the same code: "KC" = k-contiguous in memory, "MC" = m/n-contiguous.
-#include "common.h"
+#include "adam_dev.h"
 
 namespace th {
 
@@ -22,7 +22,13 @@ struct Epilogue {
     float alpha, beta;
     const float *bias;  // per output column (n), nullable
     int relu;
+    AdamDev adam;       // adam.p != nullptr: C is a complete gradient and the Adam update of the
+                        // parameter at the same index runs right here (th_linear_bwd_adam)
 };
+
+static inline Epilogue make_ep(float alpha, float beta, const float *bias = nullptr, int relu = 0) {
+    return Epilogue{alpha, beta, bias, relu, AdamDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f}};
+}
 
 __device__ __forceinline__ float epilogue_apply(float acc, float c_old, const Epilogue &ep, int col) {
     float v = ep.alpha * acc;
@@ -71,8 +77,32 @@ __device__ __forceinline__ void small16_body(const SmallArgs &p, int tile_row, i
     const float *bp = p.B + (long)(b_ok ? bcol : 0) * p.b_cs;
 
     // These shapes are latency-bound: after a kernel boundary every dependent
-    // global round trip costs ~0.5-1 us, so the operand loads of CH k-steps
-    // (64 k per wave) are all issued before the first MFMA consumes any.
+    // global round trip costs ~0.5-1 us.  So (a) everything the epilogue will
+    // need from memory -- bias, the old C for beta != 0, the Adam state of a fused
+    // update -- is requested by wave 0 NOW, under the operand loads; (b) the
+    // operand loads of CH k-steps (64 k per wave) are all issued before the
+    // first MFMA consumes any.
+    const int ecol = col0 + (lane & 15);
+    const bool fuse_adam = p.ep.adam.p != nullptr && p.partial == nullptr;
+    float e_bias = 0.f, e_cold[4] = {0.f, 0.f, 0.f, 0.f}, e_p[4], e_m[4], e_v[4], e_step = 0.f;
+    long e_ix[4];
+    bool e_ok[4];
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + (lane >> 4) * 4 + i;
+            e_ok[i] = row < p.m && ecol < p.n;
+            e_ix[i] = e_ok[i] ? (long)row * p.n + ecol : 0;
+            if (p.ep.beta != 0.0f && !p.partial) e_cold[i] = p.C[e_ix[i]];
+            if (fuse_adam) {
+                e_p[i] = p.ep.adam.p[e_ix[i]];
+                e_m[i] = p.ep.adam.m[e_ix[i]];
+                e_v[i] = p.ep.adam.v[e_ix[i]];
+            }
+        }
+        if (p.ep.bias && ecol < p.n) e_bias = p.ep.bias[ecol];
+        if (fuse_adam) e_step = adam_dev_step(p.ep.adam);
+    }
     constexpr int CH = 4;
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int kk0 = kbeg; kk0 < kend; kk0 += 16 * CH) {
@@ -128,18 +158,26 @@ __device__ __forceinline__ void small16_body(const SmallArgs &p, int tile_row, i
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] += red[w][lane][i];
         // C/D map of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + i
-        const int col = col0 + (lane & 15);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = row0 + (lane >> 4) * 4 + i;
-            if (row < p.m && col < p.n) {
-                const long idx = (long)row * p.n + col;
-                if (p.partial) {
-                    p.partial[(long)zslice * p.m * p.n + idx] = acc[i];
-                } else {
-                    const float c_old = p.ep.beta != 0.0f ? p.C[idx] : 0.0f;
-                    p.C[idx] = epilogue_apply(acc[i], c_old, p.ep, col);
-                }
+            if (!e_ok[i]) continue;
+            if (p.partial) {
+                p.partial[(long)zslice * p.m * p.n + e_ix[i]] = acc[i];
+                continue;
+            }
+            float out = p.ep.alpha * acc[i];
+            if (p.ep.beta != 0.0f) out += p.ep.beta * e_cold[i];
+            if (p.ep.bias) out += e_bias;
+            if (p.ep.relu) out = out > 0.0f ? out : 0.0f;
+            p.C[e_ix[i]] = out;
+            if (fuse_adam) {  // th_linear_bwd_adam: C is a complete gradient (optim.rs:99-110)
+                const AdamDev &ad = p.ep.adam;
+                const float gv = out + ad.wd * e_p[i];
+                const float mn = ad.beta1 * e_m[i] + (1.0f - ad.beta1) * gv;
+                const float vn = ad.beta2 * e_v[i] + (1.0f - ad.beta2) * gv * gv;
+                ad.m[e_ix[i]] = mn;
+                ad.v[e_ix[i]] = vn;
+                ad.p[e_ix[i]] = e_p[i] - e_step * mn / (sqrtf(vn) + ad.eps);
             }
         }
     }
@@ -176,6 +214,7 @@ struct LinearBwdArgs {
     const float *dy, *ymask;
     float *db;
     int batch, out_f, db_accum;
+    AdamDev db_adam;
 };
 
 template <bool MASKED>
@@ -204,7 +243,11 @@ __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
         __syncthreads();
         if (wave == 0 && c < q.out_f) {
             const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-            q.db[c] = q.db_accum ? q.db[c] + tot : tot;
+            const float out = q.db_accum ? q.db[c] + tot : tot;
+            q.db[c] = out;
+            if (q.db_adam.p)
+                adam_update(q.db_adam.p, q.db_adam.m, q.db_adam.v, c, out, adam_dev_step(q.db_adam), q.db_adam.beta1,
+                            q.db_adam.beta2, q.db_adam.eps, q.db_adam.wd);
         }
     }
 }
@@ -435,6 +478,8 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
     return 0;
 }
 
+int adam_slice(th_ctx *ctx, const AdamDev &a, const float *d_g, int64_t n);  // optim.hip
+
 static inline bool gemm_is_big(int m, int n, int k) {
     const long tiles128 = (long)ceil_div(m, BM) * ceil_div(n, BN);
     return m >= BM && n >= BN && k >= BK && tiles128 >= 64;
@@ -471,7 +516,7 @@ int th_sgemm(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, float a
     TH_REQUIRE(ctx, "th_sgemm: null ctx");
     TH_REQUIRE(m >= 0 && n >= 0 && k >= 0, "th_sgemm: negative dimension");
     TH_REQUIRE((m == 0 || n == 0) || (d_c && (k == 0 || (d_a && d_b))), "th_sgemm: null device pointer");
-    Epilogue ep{alpha, beta, nullptr, 0};
+    Epilogue ep = make_ep(alpha, beta);
     return gemm_dispatch(ctx, trans_a, trans_b, m, n, k, d_a, d_b, d_c, ep);
 }
 
@@ -479,13 +524,23 @@ int th_linear_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
                   int in_features, int out_features, int relu) {
     TH_REQUIRE(ctx && d_x && d_w && d_y, "th_linear_fwd: null argument");
     // Y = X . W^T: op(B) = W^T with W stored [out, in]  ->  trans_b
-    Epilogue ep{1.0f, 0.0f, d_b, relu};
+    Epilogue ep = make_ep(1.0f, 0.0f, d_b, relu);
     return gemm_dispatch(ctx, 0, 1, batch, out_features, in_features, d_x, d_w, d_y, ep);
 }
 
 int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
                   float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask) {
+    return th_linear_bwd_adam(ctx, d_x, d_w, d_dy, d_relu_y, d_dx, d_dw, d_db, batch, in_features, out_features, accumulate_mask,
+                              nullptr, nullptr);
+}
+
+int th_linear_bwd_adam(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
+                       float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask,
+                       const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse) {
     TH_REQUIRE(ctx && d_dy, "th_linear_bwd: null argument");
+    const AdamDev w_adam = make_adam_dev(d_dw ? w_fuse : nullptr), b_adam = make_adam_dev(d_db ? b_fuse : nullptr);
+    TH_REQUIRE(!w_adam.p || !(accumulate_mask & 2), "th_linear_bwd_adam: a fused dW must not accumulate (grad slot must be None)");
+    TH_REQUIRE(!b_adam.p || !(accumulate_mask & 4), "th_linear_bwd_adam: a fused db must not accumulate (grad slot must be None)");
     TH_REQUIRE(!d_dx || d_w, "th_linear_bwd: d_w required for d_dx");
     TH_REQUIRE(!d_dw || d_x, "th_linear_bwd: d_x required for d_dw");
     if (batch == 0 || out_features == 0 || in_features == 0) return 0;
@@ -502,11 +557,16 @@ int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
         q.dx_tiles_n = dx_tn;
         // dW = dZ^T . X : op(A)[i=o,k=b] = dY[b*out + o] (rs 1, cs out); op(B)[k=b,j] = X[b*in + j]
         q.dw = SmallArgs{d_dy, d_relu_y, d_x, d_dw, nullptr, out_features, in_features, batch, 1, out_features, in_features, 1,
-                         (batch + 15) / 16 * 16, 0, 0, Epilogue{1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f, nullptr, 0}};
+                         (batch + 15) / 16 * 16, 0, 0, make_ep(1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f)};
         // dX = dZ . W : op(A)[i=b,k=o] = dY[b*out + o] (rs out, cs 1); op(B)[k=o,j] = W[o*in + j]
         q.dx = SmallArgs{d_dy, d_relu_y, d_w, d_dx, nullptr, batch, in_features, out_features, out_features, 1, in_features, 1,
-                         (out_features + 15) / 16 * 16, 0, 0, Epilogue{1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f, nullptr, 0}};
+                         (out_features + 15) / 16 * 16, 0, 0, make_ep(1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f)};
         q.dx.a_vec = aligned16(d_dy) && (!d_relu_y || aligned16(d_relu_y)) && (out_features % 4 == 0);
+        // The dX workgroups of this launch read W: updating W in the dW epilogue would race with
+        // them, so with a dX output the W update runs as a slice kernel behind the launch.
+        const bool w_in_kernel = w_adam.p && !d_dx;
+        if (w_in_kernel) q.dw.ep.adam = w_adam;
+        q.db_adam = b_adam;
         q.dy = d_dy;
         q.ymask = d_relu_y;
         q.db = d_db;
@@ -519,6 +579,7 @@ int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
         if (d_relu_y) hipLaunchKernelGGL(linear_bwd_small<true>, dim3(grid), dim3(256), 0, ctx->stream, q);
         else hipLaunchKernelGGL(linear_bwd_small<false>, dim3(grid), dim3(256), 0, ctx->stream, q);
         TH_LAUNCH_CHECK();
+        if (w_adam.p && !w_in_kernel) return adam_slice(ctx, w_adam, d_dw, (int64_t)out_features * in_features);
         return 0;
     }
     // large shapes: MFMA tile kernels; the ReLU mask is materialised once
@@ -531,11 +592,11 @@ int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
         dz = (const float *)tmp;
     }
     if (d_dx) {  // dX[B,in] (+)= dZ[B,out] . W[out,in]      (ops.rs:254-265 through the W^T node)
-        Epilogue ep{1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f, nullptr, 0};
+        Epilogue ep = make_ep(1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f);
         if (int rc = gemm_dispatch(ctx, 0, 0, batch, in_features, out_features, dz, d_w, d_dx, ep)) return rc;
     }
     if (d_dw) {  // dW[out,in] (+)= dZ^T[out,B] . X[B,in]     (ops.rs:280-291 + tensor.rs:574-587)
-        Epilogue ep{1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f, nullptr, 0};
+        Epilogue ep = make_ep(1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f);
         if (int rc = gemm_dispatch(ctx, 1, 0, out_features, in_features, batch, dz, d_x, d_dw, ep)) return rc;
     }
     if (d_db) {  // db[out] (+)= sum_b dZ[b,out]               (tensor.rs:686-691)
@@ -543,6 +604,9 @@ int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
                                            : th_colsum(ctx, dz, d_db, batch, out_features))
             return rc;
     }
+    // large shapes: the fused updates run as slice kernels behind the GEMMs
+    if (int rc = adam_slice(ctx, w_adam, d_dw, (int64_t)out_features * in_features)) return rc;
+    if (int rc = adam_slice(ctx, b_adam, d_db, out_features)) return rc;
     return tmp ? th_free(ctx, tmp) : 0;
 }
 

@@ -273,6 +273,14 @@ int tp_trainer_new(tp_module *m, tp_optim *o, tp_trainer **out) {
 }
 int tp_trainer_set_sample_shape(tp_trainer *t, const size_t *shape, int nd) { TP_BEGIN t->t->sample_shape = mkshape(shape, nd); TP_END }
 int tp_trainer_set_comm(tp_trainer *t, tp_comm *c) { TP_BEGIN t->t->comm = c ? c->c : nullptr; TP_END }
+int tp_trainer_set_options(tp_trainer *t, int graph_chunk, int fuse_head, int fuse_adam) {
+    TP_BEGIN
+    TAPER_ASSERT(graph_chunk >= 1, "graph_chunk must be >= 1");
+    t->t->graph_chunk = (size_t)graph_chunk;
+    t->t->fuse_head = fuse_head != 0;
+    t->t->fuse_adam = fuse_adam != 0;
+    TP_END
+}
 int tp_trainer_free(tp_trainer *t) { TP_BEGIN delete t; TP_END }
 int tp_trainer_train_step(tp_trainer *t, const tp_tensor *im, const tp_tensor *lb, float *loss, float *acc) {
     TP_BEGIN t->t->train_step(im->t, lb->t, loss, acc); TP_END

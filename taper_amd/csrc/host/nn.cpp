@@ -52,7 +52,7 @@ Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n
     }
     TH(th_softmax_xent_fwd(ctx, logits.dptr(), targets.dptr(), b, c, logp.dptr(), loss.dptr(), nullptr, nc,
                            dunit ? dunit->d : nullptr, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
-                           log ? log->d_state : nullptr, log ? log->advance : 0));
+                           log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr));
     if (need_grad) {
         loss.set_requires_grad(true);
         Tensor lg = logits, lp = logp, t = targets, out = loss;
@@ -70,6 +70,71 @@ Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n
             bool none;
             float *g = lg.grad_for_write(&none);
             TH(th_softmax_xent_bwd(Device::ctx(), lp.dptr(), t.dptr(), out.grad_dptr(), b, c, g, none ? 0 : 1));
+        });
+    }
+    return loss;
+}
+
+bool linear_cross_entropy_supported(const Tensor &h, const Tensor &weight) {
+    return h.shape().size() == 2 && weight.shape().size() == 2 && h.shape()[1] == weight.shape()[1] && weight.shape()[0] <= 16 &&
+           weight.shape()[1] <= 256 && h.shape()[0] >= 1 &&
+           h.shape()[0] <= 256;  // one workgroup walks 64-row chunks: beyond this the multi-workgroup kernels win
+}
+
+Tensor linear_cross_entropy(const Tensor &h, const Tensor &w, const Tensor &bias, const Tensor &targets, Tensor *n_correct_out,
+                            const StepLogSink *log) {  // nn.rs:54-60 + loss.rs:136-195 in one launch
+    TAPER_ASSERT(linear_cross_entropy_supported(h, w), "linear_cross_entropy: unsupported shapes");
+    TAPER_ASSERT(targets.shape()[0] == h.shape()[0], "Batch sizes must match");
+    const int b = (int)h.shape()[0], k = (int)h.shape()[1], c = (int)w.shape()[0];
+    th_ctx *ctx = Device::ctx();
+    Tensor loss = Tensor::empty({1});
+    float *nc = nullptr;
+    if (n_correct_out) {
+        *n_correct_out = Tensor::empty({1});
+        nc = n_correct_out->dptr();
+    }
+    const bool h_grad = h.get_requires_grad();
+    const bool w_grad = w.get_requires_grad() && !w.has_grad();
+    const bool b_grad = bias.defined() && bias.get_requires_grad() && !bias.has_grad();
+    TAPER_ASSERT(!w.get_requires_grad() || w_grad, "linear_cross_entropy: weight already has a gradient (accumulation unsupported)");
+    TAPER_ASSERT(!(bias.defined() && bias.get_requires_grad()) || b_grad, "linear_cross_entropy: bias already has a gradient");
+    // gradient destinations: parameter grads go straight into their (currently None) slots
+    std::shared_ptr<Buffer> dh = h_grad ? Buffer::alloc(h.len()) : nullptr;
+    float *dw = nullptr, *db = nullptr;
+    if (w_grad) {
+        if (!w.grad_->buf) w.grad_->buf = Buffer::alloc(w.len());
+        dw = w.grad_->buf->d;
+        w.grad_->known_zero = false;
+    }
+    if (b_grad) {
+        if (!bias.grad_->buf) bias.grad_->buf = Buffer::alloc(bias.len());
+        db = bias.grad_->buf->d;
+        bias.grad_->known_zero = false;
+    }
+    th_adam_fuse wf{}, bf{};
+    const th_adam_fuse *pw = nullptr, *pb = nullptr;
+    if (Adam *fa = FusedAdamScope::active()) {
+        if (w_grad && fa->fuse_for(w, &wf)) pw = &wf;
+        if (b_grad && fa->fuse_for(bias, &bf)) pb = &bf;
+    }
+    TH(th_linear_xent_head(ctx, h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, nullptr,
+                           loss.dptr(), nc, dh ? dh->d : nullptr, dw, db, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                           log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr, pw, pb));
+    if (h_grad || w_grad || b_grad) {
+        loss.set_requires_grad(true);
+        Tensor hh = h, ww = w, bb = bias, out = loss;
+        Tape::push(loss, true, [hh, ww, bb, out, dh, w_grad, b_grad]() {
+            if (!out.has_grad()) return;
+            // the gradients were produced by the forward launch for an upstream grad of exactly 1
+            TAPER_ASSERT(out.grad_->shared_const, "linear_cross_entropy: only loss.backward() from the root is supported");
+            if (dh) {
+                TAPER_ASSERT(!hh.has_grad() && !hh.grad_->buf_is_arena, "linear_cross_entropy: input already has a gradient");
+                hh.grad_->buf = dh;
+                hh.grad_->has = true;
+                hh.grad_->shared_const = false;
+            }
+            if (w_grad) ww.grad_->has = true;
+            if (b_grad) bb.grad_->has = true;
         });
     }
     return loss;
@@ -154,10 +219,12 @@ Tensor AdaptiveAvgPool2d::forward(const Tensor &x) const {  // nn.rs:670-686
     return x.avg_pool2d({kh, kw}, {kh, kw}, {0, 0});
 }
 
-Tensor Sequential::forward(const Tensor &input) const {  // nn.rs:149-151
+Tensor Sequential::forward(const Tensor &input) const { return forward_prefix(input, layers.size()); }  // nn.rs:149-151
+
+Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
     Tensor x = input;
-    for (size_t i = 0; i < layers.size(); ++i) {
-        if (fuse && i + 1 < layers.size()) {
+    for (size_t i = 0; i < n_layers; ++i) {
+        if (fuse && i + 1 < n_layers) {
             auto *lin = dynamic_cast<Linear *>(layers[i].get());
             if (lin && dynamic_cast<ReLU *>(layers[i + 1].get())) {
                 x = lin->forward_fused_relu(x);  // Linear + ReLU: one kernel, one tape node
@@ -215,14 +282,19 @@ FlatParams::FlatParams(const std::vector<Tensor> &ps) : params(ps) {
     sync_mask();
 }
 
-void FlatParams::sync_mask() {
+size_t FlatParams::sync_mask(const std::vector<char> *excluded) {
     std::vector<int32_t> mask(params.size());
-    for (size_t i = 0; i < params.size(); ++i) mask[i] = params[i].has_grad() ? 1 : 0;
-    if (mask == uploaded_mask) return;
+    size_t selected = 0;
+    for (size_t i = 0; i < params.size(); ++i) {
+        mask[i] = (params[i].has_grad() && !(excluded && (*excluded)[i])) ? 1 : 0;
+        selected += (size_t)mask[i];
+    }
+    if (mask == uploaded_mask) return selected;
     // h2d synchronises: illegal inside a graph capture; callers run one eager
     // step first so the (static) mask is already resident
     TH(th_memcpy_h2d(Device::ctx(), d_has_grad_buf->d, mask.data(), mask.size() * sizeof(int32_t)));
     uploaded_mask = mask;
+    return selected;
 }
 
 void FlatParams::zero_missing() {
@@ -259,8 +331,33 @@ Adam::Adam(const std::vector<Tensor> &params, float lr, float beta1, float beta2
     TH(th_fill_f32(ctx, v_->d, 0.f, (size_t)fp_.total));
     state_ = Buffer::alloc(4);
     TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // t = 0
+    fused_.assign(fp_.params.size(), 0);
     set_lr(lr);
 }
+
+bool Adam::fuse_for(const Tensor &param, th_adam_fuse *out) {
+    for (size_t i = 0; i < fp_.params.size(); ++i) {
+        if (fp_.params[i].grad_ != param.grad_) continue;
+        const int64_t off = fp_.offsets[i];
+        *out = th_adam_fuse{fp_.p_arena->d + off, m_->d + off, v_->d + off, d_tick(), state_->d + 2, beta1_, beta2_, eps_, wd_};
+        fused_[i] = 1;
+        return true;
+    }
+    return false;
+}
+
+namespace {
+thread_local Adam *t_fused_adam = nullptr;
+}
+FusedAdamScope::FusedAdamScope(Adam *adam) : prev_(t_fused_adam) {
+    t_fused_adam = adam;
+    if (adam) adam->set_external_tick(true);
+}
+FusedAdamScope::~FusedAdamScope() {
+    if (t_fused_adam) t_fused_adam->set_external_tick(false);
+    t_fused_adam = prev_;
+}
+Adam *FusedAdamScope::active() { return t_fused_adam; }
 
 void Adam::set_lr(float lr) {  // optim.rs:125-127
     lr_ = lr;
@@ -268,10 +365,13 @@ void Adam::set_lr(float lr) {  // optim.rs:125-127
 }
 
 void Adam::step() {  // optim.rs:83-113
-    fp_.sync_mask();
+    // parameters whose update already ran in a fused epilogue this step are masked out
+    const size_t left = fp_.sync_mask(&fused_);
+    std::fill(fused_.begin(), fused_.end(), 0);
+    if (external_tick_ && left == 0) return;  // t was ticked by the loss kernel and nothing is left to update
     TH(th_adam_step(Device::ctx(), fp_.p_arena->d, fp_.g_arena->d, m_->d, v_->d, fp_.d_offsets(), fp_.d_has_grad(),
-                    (int)fp_.params.size(), fp_.total, reinterpret_cast<int32_t *>(state_->d), state_->d + 2, beta1_, beta2_,
-                    eps_, wd_));
+                    (int)fp_.params.size(), fp_.total, d_tick(), state_->d + 2, beta1_, beta2_, eps_, wd_,
+                    external_tick_ ? 1 : 0));
 }
 
 int Adam::t() const {
@@ -494,27 +594,49 @@ EpochResult Trainer::evaluate(DataLoader &loader) {  // train.rs:147-172
     return r;
 }
 
-// The captured form of one step: identical op list, but nothing is read back;
-// the batch comes from the device-resident dataset through the device cursor and
-// the loss kernel itself appends {loss, n_correct} to the device log and advances
-// the step / cursor state.
-void Trainer::enqueue_step(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
-                           size_t batch, bool from_cursor) {
-    th_ctx *ctx = Device::ctx();
+// The captured form of a step: identical arithmetic, but nothing is read back.  The batches
+// come from the device-resident dataset through the device cursor (ONE gather launch for a
+// whole chunk of steps), and the loss kernel itself appends {loss, n_correct} to the device
+// log and advances the step / cursor state.
+void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
     int64_t *state = reinterpret_cast<int64_t *>(state_->d);
-    TH(th_gather_batch(ctx, d_images, d_labels, d_indices, n_indices, from_cursor ? state + 1 : nullptr, (int)batch, 784, xb_->d,
-                       yb_->d));
+    // Adam updates ride in the epilogues of the kernels that produce the gradients -- unless the
+    // gradients still have to be all-reduced across ranks first
+    FusedAdamScope scope((fuse_adam && !comm) ? optimizer.get() : nullptr);
     Tape::reset();
-    Tensor x = Tensor::from_device(xb_->d, {batch, 784});
-    Tensor y = Tensor::from_device(yb_->d, {batch});
-    Tensor logits = model->forward(shape_input(x, sample_shape));
-    Tensor ncorrect;
-    StepLogSink sink{metrics_->d, (int64_t)metrics_cap_, state, (int64_t)batch};
-    Tensor loss = cross_entropy_loss(logits, y, &ncorrect, &sink);
+    Tensor x = Tensor::from_device(d_xb, {batch, 784});
+    Tensor y = Tensor::from_device(d_yb, {batch});
+    Tensor xin = shape_input(x, sample_shape);
+    StepLogSink sink{metrics_->d, (int64_t)metrics_cap_, state, (int64_t)batch,
+                     FusedAdamScope::active() ? optimizer->d_tick() : nullptr};
+    Tensor ncorrect, loss;
+    auto *seq = dynamic_cast<Sequential *>(model.get());
+    Linear *last = (fuse_head && seq && !seq->layers.empty()) ? dynamic_cast<Linear *>(seq->layers.back().get()) : nullptr;
+    bool used_head = false;
+    if (last) {
+        Tensor h = seq->forward_prefix(xin, seq->layers.size() - 1);
+        if (linear_cross_entropy_supported(h, last->weight) && !last->weight.has_grad() &&
+            !(last->bias.defined() && last->bias.has_grad())) {
+            loss = linear_cross_entropy(h, last->weight, last->bias, y, &ncorrect, &sink);
+            used_head = true;
+        } else {
+            loss = cross_entropy_loss(last->forward(h), y, &ncorrect, &sink);
+            used_head = true;
+        }
+    }
+    if (!used_head) loss = cross_entropy_loss(model->forward(xin), y, &ncorrect, &sink);
     loss.backward();
     reduce_grads(*this);
     optimizer->step();
     optimizer->zero_grad();
+}
+
+void Trainer::enqueue_steps(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
+                            size_t batch, size_t steps) {
+    int64_t *state = reinterpret_cast<int64_t *>(state_->d);
+    TH(th_gather_batch(Device::ctx(), d_images, d_labels, d_indices, n_indices, state + 1, (int)(batch * steps), 784, xb_->d,
+                       yb_->d));
+    for (size_t s = 0; s < steps; ++s) enqueue_compute(xb_->d + s * batch * 784, yb_->d + s * batch, batch);
 }
 
 void Trainer::drop_graphs() {
@@ -530,10 +652,11 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     size_t nb = loader.num_batches();
     if (max_steps && max_steps < nb) nb = max_steps;
     const size_t n_full = std::min(nb, n / bs);
-    if (!xb_ || xb_->n < bs * 784) {
+    const size_t chunk = std::max<size_t>(graph_chunk, 1);
+    if (!xb_ || xb_->n < chunk * bs * 784) {
         drop_graphs();
-        xb_ = Buffer::alloc(bs * 784);
-        yb_ = Buffer::alloc(bs);
+        xb_ = Buffer::alloc(chunk * bs * 784);
+        yb_ = Buffer::alloc(chunk * bs);
     }
     if (!state_) state_ = Buffer::alloc(4);
     if (metrics_cap_ < nb + 1) {
@@ -552,16 +675,15 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
         // step 0 runs eagerly (pool warm-up, has_grad mask upload); then the SAME host code
         // is run under stream capture to record the op list of 1 step and of a chunk of
         // steps (one hipGraphLaunch per chunk amortises the ~10 us host cost of a replay)
-        enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
+        enqueue_steps(d_img, d_lab, d_idx, (int64_t)n, bs, 1);
         done = 1;
-        const size_t chunk = graph_chunk;
         for (size_t steps : {chunk, (size_t)1}) {
             if (steps == 0 || (steps > 1 && n_full < 2 * steps)) continue;
             if (!graphs_.empty() && graphs_.back().first == steps) continue;
             TH(th_graph_begin(ctx));
             th_graph *g = nullptr;
             try {
-                for (size_t s = 0; s < steps; ++s) enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
+                enqueue_steps(d_img, d_lab, d_idx, (int64_t)n, bs, steps);
             } catch (...) {
                 th_graph_end(ctx, &g);
                 th_graph_destroy(g);
@@ -584,13 +706,13 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             }
         }
         if (!launched) {  // no graph fits (e.g. n_full == 1 on a later call): run the step eagerly
-            enqueue_step(d_img, d_lab, d_idx, (int64_t)n, bs, true);
+            enqueue_steps(d_img, d_lab, d_idx, (int64_t)n, bs, 1);
             ++done;
         }
     }
     if (nb > n_full) {  // the last, partial batch (mnist.rs:373-385 keeps it)
         const size_t rem = n - n_full * bs;
-        enqueue_step(d_img, d_lab, d_idx, (int64_t)n, rem, true);
+        enqueue_steps(d_img, d_lab, d_idx, (int64_t)n, rem, 1);
     }
     loader.advance(std::min(n, nb * bs));
 

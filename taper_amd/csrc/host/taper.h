@@ -173,7 +173,14 @@ struct StepLogSink {
     int64_t capacity = 0;
     int64_t *d_state = nullptr;
     int64_t advance = 0;
+    int32_t *d_adam_tick = nullptr;  // Adam's t += 1 folded into the loss kernel (fused-update steps)
 };
+// Classifier head = last Linear + cross-entropy as ONE launch (th_linear_xent_head), with the
+// backward products for loss.backward() from the root computed in the same launch.  Trainer-internal:
+// the recorded node only supports that backward (unit upstream grad, grad slots None).
+bool linear_cross_entropy_supported(const Tensor &h, const Tensor &weight);
+Tensor linear_cross_entropy(const Tensor &h, const Tensor &weight, const Tensor &bias, const Tensor &targets,
+                            Tensor *n_correct_out, const StepLogSink *log);
 // n_correct_out (optional): device scalar receiving accuracy()*B from the fused kernel
 Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out = nullptr,
                           const StepLogSink *log = nullptr);  // loss.rs:136-195
@@ -278,6 +285,7 @@ class Sequential : public Module {  // nn.rs:130-162
     bool fuse = true;  // Linear followed by ReLU runs as one fused kernel + one tape node
     explicit Sequential(std::vector<std::shared_ptr<Module>> l) : layers(std::move(l)) {}
     Tensor forward(const Tensor &input) const override;
+    Tensor forward_prefix(const Tensor &input, size_t n_layers) const;  // layers [0, n_layers)
     std::vector<Tensor> parameters() const override;
     const char *name() const override { return "Sequential"; }
 };
@@ -298,7 +306,9 @@ class FlatParams {
     explicit FlatParams(const std::vector<Tensor> &ps);
     const int64_t *d_offsets() const { return reinterpret_cast<const int64_t *>(d_offsets_buf->d); }
     const int32_t *d_has_grad() const { return reinterpret_cast<const int32_t *>(d_has_grad_buf->d); }
-    void sync_mask();        // upload has_grad mask iff it changed (not allowed while capturing)
+    // upload the (has_grad && !excluded) mask iff it changed (not allowed while capturing);
+    // returns how many tensors the mask selects
+    size_t sync_mask(const std::vector<char> *excluded = nullptr);
     void zero_missing();     // zero-fill arena slices of grad-less params (before an all-reduce)
     void zero_grad();        // optim.rs:115-119
 };
@@ -336,10 +346,31 @@ class Adam : public Optimizer {  // optim.rs:43-128
     std::vector<float> v() const;
     FlatParams &flat() override { return fp_; }
 
+    // ---- fused-update steps (Trainer-internal) ----
+    // While a FusedAdamScope is active on this thread, the kernels that produce a parameter's
+    // gradient apply that parameter's Adam update in their epilogue (same arithmetic, same t);
+    // step() then only covers the parameters nobody fused, with the counter already ticked.
+    int32_t *d_tick() const { return reinterpret_cast<int32_t *>(state_->d); }
+    bool fuse_for(const Tensor &param, th_adam_fuse *out);  // false: not ours / has a grad already
+    void set_external_tick(bool on) { external_tick_ = on; }
+
    private:
     FlatParams fp_;
-    std::shared_ptr<Buffer> m_, v_, state_;  // state_: int32 t, int32 scratch, float lr
+    std::shared_ptr<Buffer> m_, v_, state_;  // state_: int32 t, int32 arrival counter, float lr
     float lr_, beta1_, beta2_, eps_, wd_;
+    bool external_tick_ = false;
+    std::vector<char> fused_;                // per parameter: updated by a fused epilogue this step
+};
+
+// RAII: marks `adam` as the optimizer whose updates may be fused on this thread.
+class FusedAdamScope {
+   public:
+    explicit FusedAdamScope(Adam *adam);
+    ~FusedAdamScope();
+    static Adam *active();
+
+   private:
+    Adam *prev_;
 };
 
 // ---- data (src/data/mnist.rs) -----------------------------------------------------
@@ -407,6 +438,8 @@ class Trainer {  // train.rs:74-172
     Shape sample_shape;                   // {} -> feed [B,784]; {1,28,28} -> reshape like train_mnist_cnn.rs:161-162
     std::string device = "hip:gfx950";    // train.rs:79 "For future GPU support"
     size_t graph_chunk = 32;              // steps captured per hipGraph replay (plus a 1-step graph for the tail)
+    bool fuse_head = true;                // last Linear + cross-entropy as one launch (graph path)
+    bool fuse_adam = true;                // Adam updates in the epilogue of the grad-producing kernels (graph path, no DP)
     Trainer(std::shared_ptr<Module> m, std::shared_ptr<Adam> o) : model(std::move(m)), optimizer(std::move(o)) {}
 
     // one step exactly as examples/train_mnist.rs:89-121 (reads loss + accuracy back every step)
@@ -419,8 +452,10 @@ class Trainer {  // train.rs:74-172
     ~Trainer();
 
    private:
-    void enqueue_step(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
-                      size_t batch, bool from_cursor);
+    // gathers `steps` batches with one launch, then enqueues the compute of each step
+    void enqueue_steps(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
+                       size_t batch, size_t steps);
+    void enqueue_compute(float *d_xb, float *d_yb, size_t batch);
     void drop_graphs();
     std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
     size_t graph_batch_ = 0;

@@ -471,10 +471,21 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
             int mask = 0;
             bool none;
             float *dx = nullptr, *dw = nullptr, *db = nullptr;
+            th_adam_fuse wf{}, bf{};
+            const th_adam_fuse *pw = nullptr, *pb = nullptr;
+            Adam *fa = FusedAdamScope::active();  // Trainer: apply this layer's Adam update in the epilogue
             if (x.get_requires_grad()) { dx = x.grad_for_write(&none); if (!none) mask |= 1; }
-            if (wt.get_requires_grad()) { dw = wt.grad_for_write(&none); if (!none) mask |= 2; }
-            if (b.defined() && b.get_requires_grad()) { db = b.grad_for_write(&none); if (!none) mask |= 4; }
-            TH(th_linear_bwd(c, x.dptr(), wt.dptr(), dy, relu_y, dx, dw, db, batch, in_f, out_f, mask));
+            if (wt.get_requires_grad()) {
+                dw = wt.grad_for_write(&none);
+                if (!none) mask |= 2;
+                else if (fa && fa->fuse_for(wt, &wf)) pw = &wf;
+            }
+            if (b.defined() && b.get_requires_grad()) {
+                db = b.grad_for_write(&none);
+                if (!none) mask |= 4;
+                else if (fa && fa->fuse_for(b, &bf)) pb = &bf;
+            }
+            TH(th_linear_bwd_adam(c, x.dptr(), wt.dptr(), dy, relu_y, dx, dw, db, batch, in_f, out_f, mask, pw, pb));
         });
     }
     return out;

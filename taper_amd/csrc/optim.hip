@@ -2,22 +2,9 @@
 // (src/optim.rs:8-128), the batch gather of the data loader
 // (src/data/mnist.rs:277-310) and the device-side step bookkeeping.
 // All HBM-bound: Adam touches 28 B per parameter (p r/w, g r, m r/w, v r/w).
-#include "common.h"
+#include "adam_dev.h"
 
 namespace th {
-
-// llvm.powi.f32 as lowered by compiler-rt __powisf2 (f32::powi, optim.rs:87-88)
-__device__ __forceinline__ float powi_f32(float a, int b) {
-    const bool recip = b < 0;
-    float r = 1.0f;
-    while (true) {
-        if (b & 1) r *= a;
-        b /= 2;
-        if (b == 0) break;
-        a *= a;
-    }
-    return recip ? 1.0f / r : r;
-}
 
 __device__ __forceinline__ int find_tensor(const int64_t *__restrict__ offsets, int n_tensors, int64_t i) {
     int lo = 0, hi = n_tensors;  // offsets[lo] <= i < offsets[hi]
@@ -28,32 +15,26 @@ __device__ __forceinline__ int find_tensor(const int64_t *__restrict__ offsets, 
     return lo;
 }
 
-// One launch per step.  Every workgroup reads the OLD step counter t, forms
-// t+1 and step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) (optim.rs:84-90) itself;
-// the LAST workgroup to finish (agent-scope arrival counter in t_state[1])
-// publishes t+1 -- by then every other workgroup has long read the old value,
-// so a captured graph advances t on every replay without a separate tick kernel.
+// One launch per step.  Every workgroup reads the step counter, forms this
+// step's t and step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) (optim.rs:84-90)
+// itself.  pre_ticked == 0: t = old + 1 and the LAST workgroup to finish
+// (agent-scope arrival counter in t_state[1]) publishes it -- by then every
+// other workgroup has long read the old value, so a captured graph advances t
+// on every replay without a separate tick kernel.  pre_ticked == 1: an earlier
+// kernel of this step already advanced t_state[0] (fused-update steps).
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, const int64_t *__restrict__ offsets,
                                                    const int32_t *__restrict__ has_grad, int n_tensors, int64_t total,
                                                    int32_t *t_state, const float *__restrict__ lr, float beta1, float beta2,
-                                                   float eps, float wd) {
-    const int t = __hip_atomic_load(&t_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;  // optim.rs:84
-    const float bc1 = 1.0f - powi_f32(beta1, t);
-    const float bc2 = 1.0f - powi_f32(beta2, t);
-    const float step = lr[0] * (sqrtf(bc2) / bc1);
-    const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+                                                   float eps, float wd, int pre_ticked) {
+    const int t = __hip_atomic_load(&t_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (pre_ticked ? 0 : 1);  // optim.rs:84
+    const float step = adam_step_size(lr[0], beta1, beta2, t);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ti = find_tensor(offsets, n_tensors, i);
-        if (!has_grad[ti]) continue;                       // grad None: skipped entirely (Q8)
-        const float pv = p[i];
-        const float gv = g[i] + wd * pv;                   // optim.rs:101
-        const float mv = beta1 * m[i] + omb1 * gv;         // optim.rs:104
-        const float vv = beta2 * v[i] + omb2 * gv * gv;    // optim.rs:107
-        m[i] = mv;
-        v[i] = vv;
-        p[i] = pv - step * mv / (sqrtf(vv) + eps);         // optim.rs:110 (Q10)
+        if (!has_grad[ti]) continue;  // grad None: skipped entirely (Q8)
+        adam_update(p, m, v, i, g[i], step, beta1, beta2, eps, wd);
     }
+    if (pre_ticked) return;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int arrived = __hip_atomic_fetch_add(&t_state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -62,6 +43,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
             __hip_atomic_store(&t_state[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+__global__ void adam_tick_kernel(int32_t *t_state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) t_state[0] += 1;
+}
+
+// Adam on one contiguous slice with an already-ticked t (fallback of the fused
+// entry points when the gradient came from the large-shape kernels)
+__global__ __launch_bounds__(256) void adam_slice_kernel(AdamDev a, const float *__restrict__ g, int64_t n) {
+    const float step = adam_dev_step(a);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        adam_update(a.p, a.m, a.v, i, g[i], step, a.beta1, a.beta2, a.eps, a.wd);
 }
 
 __global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g,
@@ -122,13 +115,20 @@ extern "C" {
 
 int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v, const int64_t *d_offsets,
                  const int32_t *d_has_grad, int n_tensors, int64_t total, int32_t *d_t, const float *d_lr, float beta1,
-                 float beta2, float eps, float weight_decay) {
+                 float beta2, float eps, float weight_decay, int pre_ticked) {
     TH_REQUIRE(ctx && d_params && d_grads && d_m && d_v && d_offsets && d_has_grad && d_t && d_lr, "th_adam_step: null argument");
     TH_REQUIRE(n_tensors > 0 && total >= 0, "th_adam_step: bad sizes");
     // the grid is never empty so that t always advances (optim.rs:84 increments even with no grads)
     const int grid = ew_grid((size_t)(total > 0 ? total : 1), 256);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_params, d_grads, d_m, d_v, d_offsets, d_has_grad,
-                       n_tensors, total, d_t, d_lr, beta1, beta2, eps, weight_decay);
+                       n_tensors, total, d_t, d_lr, beta1, beta2, eps, weight_decay, pre_ticked);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_adam_tick(th_ctx *ctx, int32_t *d_t) {
+    TH_REQUIRE(ctx && d_t, "th_adam_tick: null argument");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, ctx->stream, d_t);
     TH_LAUNCH_CHECK();
     return 0;
 }
@@ -173,6 +173,13 @@ int th_log_step(th_ctx *ctx, const float *d_loss, const float *d_ncorrect, float
 }  // extern "C"
 
 namespace th {
+int adam_slice(th_ctx *ctx, const AdamDev &a, const float *d_g, int64_t n) {
+    if (n == 0 || !a.p) return 0;
+    hipLaunchKernelGGL(adam_slice_kernel, dim3(ew_grid((size_t)n, 256)), dim3(256), 0, ctx->stream, a, d_g, n);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
 int scale_inplace(th_ctx *ctx, float *d_x, size_t n, float scale) {
     if (n == 0 || scale == 1.0f) return 0;
     hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ctx->stream, d_x, n, scale);

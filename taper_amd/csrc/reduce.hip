@@ -215,6 +215,7 @@ __device__ __forceinline__ long target_class(float tf) {  // Rust `as usize`: sa
 template <int LPR>
 __device__ __forceinline__ void xent_row(const XentArgs &a, int row, int sub, float &nll, float &hit) {
     const float *x = a.logits + (long)row * a.classes;
+    const float tf = a.targets ? a.targets[row] : 0.f;   // requested together with the logits
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int c = sub; c < a.classes; c += LPR) {
@@ -236,7 +237,6 @@ __device__ __forceinline__ void xent_row(const XentArgs &a, int row, int sub, fl
 #pragma unroll
     for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float log_sum = logf(s);
-    const float tf = a.targets ? a.targets[row] : 0.f;
     const long cls = target_class(tf);
     const float inv_b = 1.0f / (float)a.batch;
     float my_nll = 0.f;
@@ -262,9 +262,11 @@ struct StepLog {  // th_log_step folded into the loss kernel (nullable metrics)
     int64_t capacity;
     int64_t *state;
     int64_t advance;
+    int32_t *adam_tick;  // nullable: Adam's t += 1 (optim.rs:84) for a step whose updates run fused
 };
 
 __device__ __forceinline__ void step_log(const StepLog &lg, float loss, float ncorrect) {
+    if (lg.adam_tick) lg.adam_tick[0] += 1;
     if (!lg.metrics) return;
     const int64_t s = lg.state[0] % lg.capacity;
     lg.metrics[2 * s] = loss;
@@ -493,11 +495,11 @@ int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, 
 
 int th_softmax_xent_fwd(th_ctx *ctx, const float *d_logits, const float *d_targets, int batch, int classes, float *d_logp,
                         float *d_loss, float *d_argmax, float *d_ncorrect, float *d_dlogits_unit, float *d_metrics,
-                        int64_t metrics_capacity, int64_t *d_state, int64_t advance) {
+                        int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick) {
     TH_REQUIRE(ctx && d_logits && d_targets && d_loss && batch > 0 && classes > 0, "th_softmax_xent_fwd: bad argument");
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_softmax_xent_fwd: metrics need d_state and a capacity");
     XentArgs a{d_logits, d_targets, batch, classes, d_logp, d_argmax, d_dlogits_unit};
-    StepLog lg{d_metrics, metrics_capacity, d_state, advance};
+    StepLog lg{d_metrics, metrics_capacity, d_state, advance, d_adam_tick};
     const bool narrow = classes <= 16;
     if (batch <= 1024) {  // one launch: rows, reduction, loss, count and the step log
         const int lpr = narrow ? 16 : 64;

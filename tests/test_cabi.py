@@ -34,7 +34,7 @@ def test_header_parser_matches_declarations():
     r, a = _lib.HIP_PROTOS["th_sgemm"]
     assert r is ctypes.c_int and len(a) == 11 and a[1] is ctypes.c_int and a[6] is ctypes.c_float and a[7] is ctypes.c_void_p
     r, a = _lib.HIP_PROTOS["th_adam_step"]
-    assert len(a) == 15 and a[8] is ctypes.c_int64 and a[11] is ctypes.c_float
+    assert len(a) == 16 and a[8] is ctypes.c_int64 and a[11] is ctypes.c_float
     assert _lib.HIP_PROTOS["th_last_error"][0] is ctypes.c_char_p
 
 

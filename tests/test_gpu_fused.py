@@ -1,0 +1,203 @@
+"""Fused launches of the graph-replayed step, each checked against the oracle's
+unfused chain: the classifier head (last Linear + cross-entropy + its backward
+products in one workgroup launch), the Linear backward with the Adam update in
+its epilogue, and the Trainer configurations that combine them."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import backends
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+class AdamFuse(C.Structure):  # include/taper_hip.h: th_adam_fuse
+    _fields_ = [("d_p", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_t", C.c_void_p), ("d_lr", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from taper_amd import hip
+    c = hip.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def close(a, b, rtol=RTOL, atol=1e-7):
+    b = np.asarray(b)
+    scale = float(np.abs(b).max()) if b.size else 0.0
+    np.testing.assert_allclose(np.asarray(a).reshape(b.shape), b, rtol=rtol, atol=atol + rtol * 1e-2 * scale)
+
+
+def oracle_head(O, h, w, b, y):
+    """reference chain: Linear (3 nodes) + cross_entropy_loss (6 nodes), backward from the loss"""
+    O.Tape.reset()
+    O.Tape.set_zero_sentinel(True)   # the loss is never node 0 here
+    ht, wt, bt = O.Tensor(h).requires_grad(), O.Tensor(w).requires_grad(), O.Tensor(b).requires_grad()
+    logits = ht.matmul(wt.transpose()).add_broadcast(bt)
+    yt = O.Tensor(y)
+    loss = O.cross_entropy_loss(logits, yt)
+    acc = O.accuracy(logits, yt)
+    loss.backward()
+    out = dict(logits=logits.data(), loss=float(loss.data()[0]), ncorrect=round(acc * len(y)), dh=ht.grad(), dw=wt.grad(), db=bt.grad())
+    O.Tape.reset()
+    return out
+
+
+@pytest.mark.parametrize("batch,k,c", [(64, 128, 10), (128, 128, 10), (32, 128, 10), (1, 3, 2), (200, 64, 10), (256, 256, 16), (70, 37, 5), (1024, 64, 10)])
+def test_linear_xent_head(ctx, O, batch, k, c):
+    rng = np.random.default_rng(batch * 7 + k + c)
+    h = np.maximum(rng.standard_normal((batch, k)), 0).astype(np.float32)        # post-ReLU activations
+    w = rng.uniform(-0.3, 0.3, (c, k)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    ref = oracle_head(O, h, w, b, y)
+    dh_, dw_, db_ = ctx.empty(batch * k), ctx.empty(c * k), ctx.empty(c)
+    logits, loss, nc = ctx.empty(batch * c), ctx.empty(1), ctx.empty(1)
+    state, metrics = ctx.upload(np.array([5, 640], np.int64)), ctx.zeros(2 * 16)
+    tick = ctx.upload(np.array([41, 0], np.int32))
+    ctx.call("th_linear_xent_head", ctx.upload(h), ctx.upload(w), ctx.upload(b), ctx.upload(y), batch, k, c, logits, loss, nc,
+             dh_, dw_, db_, metrics, 16, state, batch, tick, None, None)
+    close(ctx.download(logits, (batch, c)), ref["logits"], atol=1e-6)
+    assert ctx.download(loss, 1)[0] == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
+    assert ctx.download(nc, 1)[0] == ref["ncorrect"]
+    close(ctx.download(dh_, (batch, k)), ref["dh"])
+    close(ctx.download(dw_, (c, k)), ref["dw"])
+    close(ctx.download(db_, c), ref["db"])
+    np.testing.assert_array_equal(ctx.download(state, 2, np.int64), [6, 640 + batch])
+    assert ctx.download(metrics, (16, 2))[5, 0] == ctx.download(loss, 1)[0]
+    assert ctx.download(tick, 2, np.int32)[0] == 42                                      # optim.rs:84 folded in
+    # every optional output off
+    ctx.call("th_linear_xent_head", ctx.upload(h), ctx.upload(w), None, ctx.upload(y), batch, k, c, None, loss, None,
+             None, None, None, None, 0, None, 0, None, None, None)
+    assert np.isfinite(ctx.download(loss, 1)[0])
+
+
+def test_head_limits_are_errors(ctx):
+    from taper_amd._lib import TaperError
+    x = ctx.zeros(64 * 300)
+    with pytest.raises(TaperError, match="classes <= 16"):
+        ctx.call("th_linear_xent_head", x, x, None, x, 4, 300, 10, None, x, None, None, None, None, None, 0, None, 0, None, None, None)
+    with pytest.raises(TaperError, match="classes <= 16"):
+        ctx.call("th_linear_xent_head", x, x, None, x, 4, 64, 17, None, x, None, None, None, None, None, 0, None, 0, None, None, None)
+
+
+def _adam_ref(O, p0, g, lr, t, wd=1e-4):
+    """one oracle Adam step at step counter t (m = v = 0 before)"""
+    pt = O.Tensor(p0).requires_grad()
+    opt = O.Adam([pt], lr, None, None, wd)
+    for _ in range(t - 1):      # advance the counter with zero-effect steps (grad None: skipped, t still ticks)
+        opt.step()
+    pt.set_grad(g)
+    opt.step()
+    return pt.data(), opt.m(0), opt.v(0)
+
+
+@pytest.mark.parametrize("batch,inf,outf,with_dx", [(64, 784, 128, False), (64, 128, 64, True), (16, 40, 24, False)])
+def test_linear_bwd_adam_epilogue(ctx, O, batch, inf, outf, with_dx):
+    """dW/db from the fused kernel + Adam applied in the epilogue == oracle grads followed by oracle Adam"""
+    rng = np.random.default_rng(batch + inf + outf)
+    x = rng.uniform(0, 1, (batch, inf)).astype(np.float32)
+    w = rng.uniform(-0.1, 0.1, (outf, inf)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, outf).astype(np.float32)
+    dy = (rng.standard_normal((batch, outf)) * 0.01).astype(np.float32)
+    yact = np.maximum(rng.standard_normal((batch, outf)), 0).astype(np.float32)          # post-ReLU output -> mask
+    dz = dy * (yact > 0)
+    gw, gb, gx = dz.T @ x, dz.sum(0), dz @ w
+    lr, t = 1e-3, 3
+    w_ref, wm_ref, wv_ref = _adam_ref(O, w, gw.astype(np.float32), lr, t)
+    b_ref, _, _ = _adam_ref(O, b, gb.astype(np.float32), lr, t)
+    dw_, db_, dx_ = ctx.empty(w.size), ctx.empty(b.size), (ctx.empty(x.size) if with_dx else None)
+    pw, pb = ctx.upload(w), ctx.upload(b)
+    mw, vw, mb, vb = ctx.zeros(w.size), ctx.zeros(w.size), ctx.zeros(b.size), ctx.zeros(b.size)
+    tick, dlr = ctx.upload(np.array([t, 0], np.int32)), ctx.upload(np.array([lr], np.float32))   # pre-ticked
+    wf = AdamFuse(int(pw), int(mw), int(vw), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4)
+    bf = AdamFuse(int(pb), int(mb), int(vb), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4)
+    w_in = ctx.upload(w)   # the kernel reads W for dX; keep an untouched copy as its operand when W itself is updated
+    ctx.call("th_linear_bwd_adam", ctx.upload(x), pw if with_dx else w_in, ctx.upload(dy), ctx.upload(yact), dx_, dw_, db_, batch, inf,
+             outf, 0, C.byref(wf), C.byref(bf))
+    close(ctx.download(dw_, w.shape), gw, atol=1e-6)
+    close(ctx.download(db_, b.shape), gb, atol=1e-6)
+    if with_dx:
+        close(ctx.download(dx_, x.shape), gx, atol=1e-6)      # dX used the PRE-update W (no race with the fused update)
+    np.testing.assert_allclose(ctx.download(pw, w.shape), w_ref, rtol=RTOL, atol=lr * 2e-2)
+    np.testing.assert_allclose(ctx.download(pb, b.shape), b_ref, rtol=RTOL, atol=lr * 2e-2)
+    np.testing.assert_allclose(ctx.download(mw, w.shape), wm_ref.reshape(w.shape), rtol=1e-3, atol=1e-8)
+    assert ctx.download(tick, 2, np.int32)[0] == t            # fused epilogues never tick
+
+
+def test_fused_bwd_rejects_accumulating_into_fused_grad(ctx):
+    from taper_amd._lib import TaperError
+    z = ctx.zeros(64 * 64)
+    f = AdamFuse(int(z), int(z), int(z), int(z), int(z), 0.9, 0.999, 1e-8, 0.0)
+    with pytest.raises(TaperError, match="must not accumulate"):
+        ctx.call("th_linear_bwd_adam", z, z, z, None, None, z, None, 8, 8, 8, 2, C.byref(f), None)
+
+
+CONFIGS = [dict(graph_chunk=1, fuse_head=False, fuse_adam=False), dict(graph_chunk=8, fuse_head=True, fuse_adam=False),
+           dict(graph_chunk=8, fuse_head=False, fuse_adam=True), dict(graph_chunk=32, fuse_head=True, fuse_adam=True)]
+
+
+@pytest.mark.parametrize("model_name,batch", [("mlp_baseline", 64), ("mlp_example", 96)])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"chunk{c['graph_chunk']}-head{int(c['fuse_head'])}-adam{int(c['fuse_adam'])}")
+def test_fused_epoch_matches_oracle(model_name, batch, cfg):
+    """every fusion configuration of the graph path against the oracle driven with the same batches
+    (3 epochs of 5 steps incl. a partial batch; Adam's t must tick once per step in every config)"""
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(11)
+    n = 4 * batch + batch // 2
+    spec = backends.nonzero_biases(getattr(backends, model_name)(rng), rng)
+    x, y = backends.mnist_like(rng, n)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    hopt, oopt = T.Adam(hm.parameters(), 1e-3, None, None, 1e-4), Orc.m.Adam(om.parameters(), 1e-3, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt, **cfg)
+    loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False)
+    for epoch in range(3):
+        ep = tr.run_epoch(loader, T.Trainer.GRAPH)
+        ref_losses, ref_nc = [], []
+        for s in range(0, n, batch):
+            xb, yb = x[s:s + batch], y[s:s + batch]
+            r = om.train_step(oopt, xb, yb, (len(xb), 784))
+            ref_losses.append(r["loss"])
+            ref_nc.append(round(r["acc"] * len(xb)))
+        np.testing.assert_allclose(ep["losses"], ref_losses, rtol=3e-4, atol=1e-5, err_msg=f"epoch {epoch}")
+        assert np.abs(ep["ncorrect"] - np.array(ref_nc)).max() <= 1
+    assert hopt.t() == oopt.t() == 15
+    for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+        np.testing.assert_allclose(hp.data(), op.data(), rtol=RTOL, atol=1e-3 * 5e-2, err_msg=f"param {i}")
+    m, v = hopt.moments()
+    np.testing.assert_allclose(m, np.concatenate([oopt.m(i) for i in range(len(om.parameters()))]), rtol=2e-3, atol=1e-7)
+
+
+def test_cnn_epoch_graph_matches_oracle():
+    """reference CNN (faithful mode) through the graph path: conv stack generic, classifier head fused"""
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(13)
+    batch, n = 8, 28
+    spec = backends.nonzero_biases(backends.cnn_reference(rng), rng)
+    x, y = backends.mnist_like(rng, n)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    hopt, oopt = T.Adam(hm.parameters(), 1e-2, None, None, 1e-4), Orc.m.Adam(om.parameters(), 1e-2, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt, sample_shape=(1, 28, 28), graph_chunk=2)
+    loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False)
+    ep = tr.run_epoch(loader, T.Trainer.GRAPH)
+    ref = [om.train_step(oopt, x[s:s + batch], y[s:s + batch], (len(x[s:s + batch]), 1, 28, 28))["loss"] for s in range(0, n, batch)]
+    np.testing.assert_allclose(ep["losses"], ref, rtol=5e-4, atol=1e-5)
+    assert hopt.t() == 4
+    for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+        np.testing.assert_allclose(hp.data(), op.data(), rtol=RTOL, atol=1e-2 * 5e-2, err_msg=f"param {i}")
+    # quirk Q2 survives the fused path: conv weights untouched by the optimizer
+    np.testing.assert_array_equal(hm.parameters()[0].data(), spec[0]["w"])

@@ -308,12 +308,12 @@ def test_softmax_xent(ctx, O, batch, classes):
     logp, dloss, am, nc = ctx.empty(batch * classes), ctx.empty(1), ctx.empty(batch), ctx.empty(1)
     dunit = ctx.empty(batch * classes)
     state, metrics = ctx.upload(np.array([2, 100], np.int64)), ctx.zeros(2 * 8)
-    ctx.call("th_softmax_xent_fwd", dl, dt, batch, classes, logp, dloss, am, nc, dunit, metrics, 8, state, batch)
+    ctx.call("th_softmax_xent_fwd", dl, dt, batch, classes, logp, dloss, am, nc, dunit, metrics, 8, state, batch, None)
     close(ctx.download(dunit, (batch, classes)), lt.grad(), atol=1e-7)      # unit-upstream gradient from the forward kernel
     np.testing.assert_array_equal(ctx.download(state, 2, np.int64), [3, 100 + batch])   # fused th_log_step
     mrow = ctx.download(metrics, (8, 2))[2]
     assert mrow[0] == ctx.download(dloss, 1)[0] and mrow[1] == ctx.download(nc, 1)[0]
-    ctx.call("th_softmax_xent_fwd", dl, dt, batch, classes, None, dloss, None, None, None, None, 0, None, 0)   # all optionals off
+    ctx.call("th_softmax_xent_fwd", dl, dt, batch, classes, None, dloss, None, None, None, None, 0, None, 0, None)   # all optionals off
     np.testing.assert_allclose(ctx.download(dloss, 1)[0], loss.data()[0], rtol=RTOL, atol=1e-6)
     close(ctx.download(logp, (batch, classes)), ref_logp, atol=1e-5)
     np.testing.assert_allclose(ctx.download(dloss, 1)[0], loss.data()[0], rtol=RTOL, atol=1e-6)
@@ -506,7 +506,7 @@ def test_adam_matches_oracle_over_steps(ctx, O):
             params[i].set_grad(g[offs[i]:offs[i] + s] if has[i] else None)
         oopt.step()
         dg = ctx.upload(g)
-        ctx.call("th_adam_step", dp, dg, dm, dv, doffs, dhas, len(sizes), total, state, lr, 0.9, 0.999, 1e-8, 1e-4)
+        ctx.call("th_adam_step", dp, dg, dm, dv, doffs, dhas, len(sizes), total, state, lr, 0.9, 0.999, 1e-8, 1e-4, 0)
     got = ctx.download(dp, total)
     assert ctx.download(state, 2, np.int32)[0] == 25 == oopt.t()
     for i, s in enumerate(sizes):

@@ -148,11 +148,13 @@ def test_graph_epoch_equals_eager_epoch(n, batch):
         a, b = results[0][e], results[1][e]
         assert a["num_batches"] == b["num_batches"] == (n + batch - 1) // batch
         assert a["total_samples"] == b["total_samples"] == n
-        np.testing.assert_allclose(b["losses"], a["losses"], rtol=1e-6, atol=1e-7)   # same kernels, same order
-        np.testing.assert_array_equal(b["ncorrect"], a["ncorrect"])
-        assert a["total_correct"] == b["total_correct"]
+        # the graph path runs fused launches (classifier head, Adam in the epilogues): same arithmetic,
+        # different summation order than the per-op eager path
+        np.testing.assert_allclose(b["losses"], a["losses"], rtol=3e-4, atol=1e-5)
+        assert np.abs(b["ncorrect"] - a["ncorrect"]).max() <= 1
+        assert abs(int(a["total_correct"]) - int(b["total_correct"])) <= 3
     for pa, pb in zip(*finals):
-        np.testing.assert_allclose(pb, pa, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(pb, pa, rtol=1e-4, atol=1e-3 * 5e-2)
 
 
 def test_epoch_against_oracle_with_loader_semantics():
