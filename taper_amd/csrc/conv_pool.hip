@@ -4,8 +4,8 @@
 // conv3x3: VALU direct convolution (north_star: "conv2d direct-3x3 ... LDS-
 // staged tiles"; MFMA is reserved for the dense GEMMs).  One workgroup owns
 // IMG images x 16 output channels; the input planes (+1-pixel halo) of 8
-// input channels at a time are staged in LDS; each thread keeps PX pixels x
-// 16 channels of accumulators in registers; the weights are re-laid-out once
+// input channels at a time are staged in LDS; each thread keeps a 2x4 pixel
+// tile x 8 channels of accumulators in registers; the weights are re-laid-out once
 // per call into [ci][kh][kw][co] so that every weight read in the inner loop
 // is wave-uniform and is served by scalar loads (s_load_dwordx*), leaving the
 // LDS pipe to the input taps only.  The im2col buffer of the reference (up to
@@ -14,7 +14,7 @@
 
 namespace th {
 
-constexpr int CO_T = 16;  // output channels per thread
+constexpr int CO_T = 8;   // output channels per thread (9 x 8 = 72 weight SGPRs per input channel: no spills)
 constexpr int CI_T = 8;   // input channels staged per LDS pass
 
 // w_t[((ci*3 + kh)*3 + kw) * co_pad + co] = w_eff[co][ci][kh][kw]
@@ -43,10 +43,130 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float *__restr
     }
 }
 
-// grid = (ceil(n / IMG), out_ch_pad / 16); block = 256.
-// Thread item -> (image in group, output row, column group of PX pixels).
-template <int PX, bool ACCUM>
+// grid = (ceil(n / IMG), out_ch_pad / CO_T); block = 256.
+// Thread item -> (image in group, 2x4 output pixel tile); CO_T = 8 output channels.
+// Per input channel a thread reads its 4x6 input window from LDS once (24 reads)
+// and issues 9 taps x 8 pixels x 8 channels = 576 FMAs against 72 wave-uniform
+// weights held in SGPRs (scalar loads): 24 FMAs per LDS read, 8 per weight dword.
+constexpr int TPH = 2, TPW = 4;   // pixel tile
+
+template <bool ACCUM>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float *__restrict__ x, const float *__restrict__ w_t,
+                                                      const float *__restrict__ bias, float *__restrict__ y, int n, int c_in,
+                                                      int h, int w, int c_out, int co_pad, int pad, int h_out, int w_out,
+                                                      int img_per_wg, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [img][CI_T][hp][wp]
+    const int tiles_w = (w_out + TPW - 1) / TPW, tiles_h = (h_out + TPH - 1) / TPH;
+    // the LDS plane carries a zero halo and is padded so that edge tiles read in bounds
+    const int hp = tiles_h * TPH + 2 + (1 - pad);
+    const int wp = (tiles_w * TPW + 2 + (1 - pad)) | 1;   // odd pitch: window rows fall on different banks
+    const int plane = hp * wp;
+    const int tiles_per_img = tiles_w * tiles_h;
+    const int items = img_per_wg * tiles_per_img;
+    const int img0 = blockIdx.x * img_per_wg;
+    const int co0 = blockIdx.y * CO_T;
+    const int shift = 1 - pad;            // pad=1: window starts on the halo; pad=0: one pixel in
+    const int tid = threadIdx.x;
+
+    // the halo (and everything else) is zeroed once; the staging passes only rewrite interiors
+    for (int i = tid; i < img_per_wg * CI_T * plane; i += 256) xs[i] = 0.f;
+
+    for (int item0 = 0; item0 < items; item0 += 256) {
+        const int item = item0 + tid;
+        const bool active = item < items;
+        const int li = active ? item / tiles_per_img : 0;
+        const int rem = active ? item % tiles_per_img : 0;
+        const int oh0 = (rem / tiles_w) * TPH, ow0 = (rem % tiles_w) * TPW;
+        const int img = img0 + li;
+        const bool img_ok = active && img < n;
+
+        float acc[TPH * TPW][CO_T];   // pixel p = (dy, dx) = (p / TPW, p % TPW)
+#pragma unroll
+        for (int p = 0; p < TPH * TPW; ++p)
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j) acc[p][j] = 0.f;
+
+        for (int cb = 0; cb < c_in; cb += CI_T) {
+            const int nci = min(CI_T, c_in - cb);
+            __syncthreads();  // previous pass (and the zero fill) done with xs
+            // stage interiors.  Per image the nci planes are ONE contiguous run of nci*h*w floats:
+            // consecutive threads take consecutive floats (fully coalesced) and track their
+            // (channel, row, col) incrementally -- no integer division in the loop.
+            const int run = nci * h * w;
+            const int step_y = 256 / w, step_x = 256 % w;
+            for (int si = 0; si < img_per_wg; ++si) {
+                const int gi = img0 + si;
+                if (gi >= n) break;
+                const float *src = x + ((long)gi * c_in + cb) * h * w;
+                float *dst = xs + (si * CI_T) * plane + wp + 1;
+                int sy = tid / w, sx = tid % w, sc = 0;
+                while (sy >= h) { sy -= h; ++sc; }
+                for (int e = tid; e < run; e += 256) {
+                    dst[sc * plane + sy * wp + sx] = src[e];
+                    sx += step_x;
+                    sy += step_y;
+                    if (sx >= w) { sx -= w; ++sy; }
+                    while (sy >= h) { sy -= h; ++sc; }
+                }
+            }
+            __syncthreads();
+            if (active) {
+                const float *xbase = xs + (li * CI_T) * plane + (oh0 + shift) * wp + ow0 + shift;
+                for (int c = 0; c < nci; ++c) {
+                    const float *xp = xbase + c * plane;
+                    float in[TPH + 2][TPW + 2];
+#pragma unroll
+                    for (int yy = 0; yy < TPH + 2; ++yy)
+#pragma unroll
+                        for (int xx = 0; xx < TPW + 2; ++xx) in[yy][xx] = xp[yy * wp + xx];
+                    const float *wc = w_t + (long)(cb + c) * 9 * co_pad + co0;  // wave-uniform -> scalar loads
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float *wk = wc + (kh * 3 + kw) * co_pad;
+#pragma unroll
+                            for (int j = 0; j < CO_T; ++j) {
+                                const float wv = wk[j];
+#pragma unroll
+                                for (int p = 0; p < TPH * TPW; ++p)
+                                    acc[p][j] = fmaf(in[p / TPW + kh][p % TPW + kw], wv, acc[p][j]);
+                            }
+                        }
+                }
+            }
+        }
+
+        if (img_ok) {
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j) {
+                const int co = co0 + j;
+                if (co >= c_out) break;
+                const float bv = bias ? bias[co] : 0.f;
+                float *yp = y + ((long)img * c_out + co) * h_out * w_out;
+#pragma unroll
+                for (int p = 0; p < TPH * TPW; ++p) {
+                    const int oh = oh0 + p / TPW, ow = ow0 + p % TPW;
+                    if (oh < h_out && ow < w_out) {
+                        float v = acc[p][j] + bv;
+                        if (relu) v = v > 0.f ? v : 0.f;
+                        float *q = yp + oh * w_out + ow;
+                        if (ACCUM) *q += v;
+                        else *q = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Row-tile variant for small / odd planes (14x14, 7x7, ...): thread item -> (image, output row,
+// column group of PX pixels) x CO_R = 16 output channels.  More, finer work items than the 2x4
+// tile kernel, which matters when an image only has 49 or 196 pixels.
+constexpr int CO_R = 16;
+
+template <int PX, bool ACCUM>
+__global__ __launch_bounds__(256) void conv3x3_rows_kernel(const float *__restrict__ x, const float *__restrict__ w_t,
                                                       const float *__restrict__ bias, float *__restrict__ y, int n, int c_in,
                                                       int h, int w, int c_out, int co_pad, int pad, int h_out, int w_out,
                                                       int img_per_wg, int relu) {
@@ -57,8 +177,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float *__restrict__ 
     const int items_per_img = h_out * groups_per_row;
     const int items = img_per_wg * items_per_img;
     const int img0 = blockIdx.x * img_per_wg;
-    const int co0 = blockIdx.y * CO_T;
+    const int co0 = blockIdx.y * CO_R;
     const int shift = 1 - pad;            // pad=1: window starts at halo; pad=0: starts one pixel in
+
+    for (int i = threadIdx.x; i < img_per_wg * CI_T * plane; i += 256) xs[i] = 0.f;   // halo zeroed once
 
     for (int item0 = 0; item0 < items; item0 += 256) {
         const int item = item0 + threadIdx.x;
@@ -69,26 +191,33 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float *__restrict__ 
         const int img = img0 + li;
         const bool img_ok = active && img < n;
 
-        float acc[PX][CO_T];
+        float acc[PX][CO_R];
 #pragma unroll
         for (int p = 0; p < PX; ++p)
 #pragma unroll
-            for (int j = 0; j < CO_T; ++j) acc[p][j] = 0.f;
+            for (int j = 0; j < CO_R; ++j) acc[p][j] = 0.f;
 
         for (int cb = 0; cb < c_in; cb += CI_T) {
             const int nci = min(CI_T, c_in - cb);
             __syncthreads();  // previous pass done with xs
-            // stage: zero halo + interior copy, coalesced over the padded plane
-            const int stage_total = img_per_wg * nci * plane;
-            for (int s = threadIdx.x; s < stage_total; s += 256) {
-                const int si = s / (nci * plane), r1 = s % (nci * plane);
-                const int sc = r1 / plane, sp = r1 % plane;
-                const int sy = sp / wp - 1, sx = sp % wp - 1;
+            // stage interiors (the halo was zeroed once): per image the nci planes are ONE contiguous run;
+            // threads take consecutive floats and track (channel, row, col) incrementally
+            const int run = nci * h * w;
+            const int step_y = 256 / w, step_x = 256 % w;
+            for (int si = 0; si < img_per_wg; ++si) {
                 const int gi = img0 + si;
-                float v = 0.f;
-                if (gi < n && sy >= 0 && sy < h && sx >= 0 && sx < w)
-                    v = x[(((long)gi * c_in + cb + sc) * h + sy) * w + sx];
-                xs[(si * CI_T + sc) * plane + sp] = v;
+                if (gi >= n) break;
+                const float *src = x + ((long)gi * c_in + cb) * h * w;
+                float *dst = xs + (si * CI_T) * plane + wp + 1;
+                int sy = threadIdx.x / w, sx = threadIdx.x % w, sc = 0;
+                while (sy >= h) { sy -= h; ++sc; }
+                for (int e = threadIdx.x; e < run; e += 256) {
+                    dst[sc * plane + sy * wp + sx] = src[e];
+                    sx += step_x;
+                    sy += step_y;
+                    if (sx >= w) { sx -= w; ++sy; }
+                    while (sy >= h) { sy -= h; ++sc; }
+                }
             }
             __syncthreads();
             if (active) {
@@ -105,7 +234,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float *__restrict__ 
                         for (int kw = 0; kw < 3; ++kw) {
                             const float *wk = wc + (kh * 3 + kw) * co_pad;
 #pragma unroll
-                            for (int j = 0; j < CO_T; ++j) {
+                            for (int j = 0; j < CO_R; ++j) {
                                 const float wv = wk[j];
 #pragma unroll
                                 for (int p = 0; p < PX; ++p) acc[p][j] = fmaf(in[p + kw], wv, acc[p][j]);
@@ -118,7 +247,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float *__restrict__ 
 
         if (img_ok) {
 #pragma unroll
-            for (int j = 0; j < CO_T; ++j) {
+            for (int j = 0; j < CO_R; ++j) {
                 const int co = co0 + j;
                 if (co >= c_out) break;
                 const float bv = bias ? bias[co] : 0.f;
@@ -201,9 +330,14 @@ __global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__rest
     const int ch = blockIdx.x;
     float s = 0.f;
     const long total = (long)n * hw;
+    // (image, pixel) tracked incrementally: no integer division per element
+    const int step_b = 256 / hw, step_sp = 256 % hw;
+    int b = threadIdx.x / hw, sp = threadIdx.x % hw;
     for (long i = threadIdx.x; i < total; i += 256) {
-        const long b = i / hw, sp = i % hw;
-        s += g[(b * c + ch) * hw + sp];
+        s += g[((long)b * c + ch) * hw + sp];
+        sp += step_sp;
+        b += step_b;
+        if (sp >= hw) { sp -= hw; ++b; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -349,31 +483,54 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float *__restric
 static int conv3x3_launch(th_ctx *ctx, const float *x, const float *w_t, const float *bias, float *y, int n, int in_ch, int h,
                           int w, int out_ch, int co_pad, int pad, int relu, bool accum) {
     const int h_out = h + 2 * pad - 2, w_out = w + 2 * pad - 2;
+    if (w_out >= 16 && w_out % TPW == 0 && h_out % TPH == 0) {
+        // large planes: 2x4 pixel tiles x 8 channels, packed-FMA inner loop
+        const int tiles_h = h_out / TPH, tiles_w = w_out / TPW;
+        const int tiles_per_img = tiles_h * tiles_w;
+        int img_per_wg = 256 / tiles_per_img;
+        if (img_per_wg < 1) img_per_wg = 1;
+        if (img_per_wg > n) img_per_wg = n;
+        const int plane = (tiles_h * TPH + 2 + (1 - pad)) * ((tiles_w * TPW + 2 + (1 - pad)) | 1);
+        while (img_per_wg > 1 && (size_t)img_per_wg * CI_T * plane * sizeof(float) > (64u << 10)) --img_per_wg;  // 2 workgroups per CU
+        const size_t lds = (size_t)img_per_wg * CI_T * plane * sizeof(float);
+        TH_REQUIRE(lds <= (160u << 10), "th_conv3x3: %dx%d plane does not fit the LDS tile", h, w);
+        dim3 grid(ceil_div(n, img_per_wg), co_pad / CO_T);
+#define TH_CONV_TILE(ACC)                                                                                                       \
+    {                                                                                                                           \
+        auto kern = conv3x3_kernel<ACC>;                                                                                        \
+        if (lds > (64u << 10)) TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, x, w_t, bias, y, n, in_ch, h, w, out_ch, co_pad, pad, h_out, \
+                           w_out, img_per_wg, relu);                                                                            \
+    }
+        if (accum) TH_CONV_TILE(true) else TH_CONV_TILE(false)
+#undef TH_CONV_TILE
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
+    // small / odd planes: row tiles of PX pixels x 16 channels
     const int px = (w_out % 4 == 0) ? 4 : ((w_out % 2 == 0) ? 2 : 1);
     const int items_per_img = h_out * ((w_out + px - 1) / px);
     int img_per_wg = 256 / items_per_img;
     if (img_per_wg < 1) img_per_wg = 1;
     if (img_per_wg > n) img_per_wg = n;
     const int plane = (h + 2) * (w + 2);
-    // keep the LDS tile <= 64 KiB so two workgroups share a CU
     while (img_per_wg > 1 && (size_t)img_per_wg * CI_T * plane * sizeof(float) > (64u << 10)) --img_per_wg;
     const size_t lds = (size_t)img_per_wg * CI_T * plane * sizeof(float);
     TH_REQUIRE(lds <= (160u << 10), "th_conv3x3: %dx%d plane does not fit the LDS tile", h, w);
-    dim3 grid(ceil_div(n, img_per_wg), co_pad / CO_T);
-#define TH_CONV_LAUNCH(PXV, ACC)                                                                                      \
-    {                                                                                                                 \
-        auto kern = conv3x3_kernel<PXV, ACC>;                                                                         \
-        if (lds > (64u << 10))                                                                                        \
-            TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, x, w_t, bias, y, n, in_ch, h, w, out_ch, co_pad,  \
-                           pad, h_out, w_out, img_per_wg, relu);                                                      \
+    dim3 grid(ceil_div(n, img_per_wg), co_pad / CO_R);
+#define TH_CONV_ROWS(PXV, ACC)                                                                                                  \
+    {                                                                                                                           \
+        auto kern = conv3x3_rows_kernel<PXV, ACC>;                                                                              \
+        if (lds > (64u << 10)) TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, x, w_t, bias, y, n, in_ch, h, w, out_ch, co_pad, pad, h_out, \
+                           w_out, img_per_wg, relu);                                                                            \
     }
     if (!accum) {
-        if (px == 4) TH_CONV_LAUNCH(4, false) else if (px == 2) TH_CONV_LAUNCH(2, false) else TH_CONV_LAUNCH(1, false)
+        if (px == 4) TH_CONV_ROWS(4, false) else if (px == 2) TH_CONV_ROWS(2, false) else TH_CONV_ROWS(1, false)
     } else {
-        if (px == 4) TH_CONV_LAUNCH(4, true) else if (px == 2) TH_CONV_LAUNCH(2, true) else TH_CONV_LAUNCH(1, true)
+        if (px == 4) TH_CONV_ROWS(4, true) else if (px == 2) TH_CONV_ROWS(2, true) else TH_CONV_ROWS(1, true)
     }
-#undef TH_CONV_LAUNCH
+#undef TH_CONV_ROWS
     TH_LAUNCH_CHECK();
     return 0;
 }
@@ -390,7 +547,7 @@ int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float 
     TH_REQUIRE(n > 0 && c_in > 0 && c_out > 0 && h + 2 * pad >= 3 && w + 2 * pad >= 3, "th_conv3x3_fwd: bad geometry");
     TH_REQUIRE(pad == 0 || pad == 1, "th_conv3x3_fwd: pad must be 0 or 1 (got %d)", pad);
     TH_REQUIRE(weight_layout == 0 || weight_layout == 1, "th_conv3x3_fwd: weight_layout must be 0 (taper) or 1 (standard)");
-    const int co_pad = (c_out + CO_T - 1) / CO_T * CO_T;
+    const int co_pad = (c_out + CO_R - 1) / CO_R * CO_R;   // multiple of both kernels' channel blocks
     void *wt = nullptr;
     if (th_malloc(ctx, (size_t)c_in * 9 * co_pad * sizeof(float), &wt)) return 1;
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3(ew_grid((size_t)c_in * 9 * co_pad, 256)), dim3(256), 0, ctx->stream, d_w,
@@ -405,7 +562,7 @@ int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float
     TH_REQUIRE(ctx && d_gy && d_w && d_gx, "th_conv3x3_bwd_input: null argument");
     TH_REQUIRE(pad == 1, "th_conv3x3_bwd_input: only pad=1 (same-size) convolutions are supported");
     // gx = conv3x3(gy, mirrored filter with ci/co swapped), pad 1, accumulated
-    const int ci_pad = (c_in + CO_T - 1) / CO_T * CO_T;
+    const int ci_pad = (c_in + CO_R - 1) / CO_R * CO_R;
     void *wt = nullptr;
     if (th_malloc(ctx, (size_t)c_out * 9 * ci_pad * sizeof(float), &wt)) return 1;
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3(ew_grid((size_t)c_out * 9 * ci_pad, 256)), dim3(256), 0, ctx->stream, d_w,

@@ -41,7 +41,7 @@ def main():
     for s in args.sizes.split(","):
         dims = [int(v) for v in s.split("x")]
         m, n, k = dims * 3 if len(dims) == 1 else dims
-        for name, ta, tb, beta in [("NN", 0, 0, 0.0), ("NT", 0, 1, 0.0), ("TN", 1, 0, 1.0)]:
+        for name, ta, tb, beta in [("NN", 0, 0, 0.0), ("NT", 0, 1, 0.0), ("TN", 1, 0, 1.0), ("TN(beta=0)", 1, 0, 0.0), ("NN(beta=1)", 0, 0, 1.0), ("TT", 1, 1, 0.0)]:
             ms, tf = bench(ctx, ta, tb, m, n, k, args.reps, beta)
             rows.append(dict(variant=name, m=m, n=n, k=k, beta=beta, ms=round(ms, 4), tflops=round(tf, 2), frac_of_peak=round(tf / PEAK, 4)))
             print(json.dumps(rows[-1]), flush=True)
