@@ -65,6 +65,8 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
     float *lg = Ws + HEAD_CMAX * LD;         // [64][16]   logits, then dlogits
     float *part = lg + HEAD_RC * HEAD_CMAX;  // [4 tiles][3][64 lanes][4]  k-split partials of the logits
     float *red = part + 4 * 3 * 64 * 4;      // [32] block reduction scratch
+    float *dbp = red + 32;                   // [16 waves][16 classes] per-wave column sums of dlogits
+    float *dl = dbp + 16 * HEAD_CMAX;        // [64][16]   dlogits (separate from lg: no barrier between read and write)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, g4 = lane >> 4;
 
@@ -97,8 +99,31 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
     }
     const bool vec4 = (K & 3) == 0 && (((uintptr_t)a.h | (uintptr_t)a.w) & 15) == 0;
 
-    // ---- stage W (zero-padded to [16][KP]) ----
-    if (vec4) {
+    // ---- stage W (zero-padded to [16][KP]) and, when KP is a power of two (the 128-wide MNIST head),
+    //      the first H chunk in the SAME round trip: all loads are issued before any LDS store waits ----
+    const int kq = KP / 4;
+    const bool pow2 = vec4 && (kq & (kq - 1)) == 0;
+    bool h0_staged = false;
+    if (pow2) {
+        const int lg2 = __ffs(kq) - 1, rstep = HEAD_T >> lg2;     // rows advanced per 1024 threads
+        const int kk = (t & (kq - 1)) * 4, rr0 = t >> lg2;
+        const int rows0 = min(HEAD_RC, a.batch);
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f), hv[4];
+        if (rr0 < C && rr0 < HEAD_CMAX && kk < K) wv = *reinterpret_cast<const float4 *>(a.w + rr0 * K + kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = rr0 + j * rstep;
+            hv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < rows0 && kk < K) hv[j] = *reinterpret_cast<const float4 *>(a.h + (long)rr * K + kk);
+        }
+        if (rr0 < HEAD_CMAX) *reinterpret_cast<float4 *>(Ws + rr0 * LD + kk) = wv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = rr0 + j * rstep;
+            if (rr < HEAD_RC) *reinterpret_cast<float4 *>(Hs + rr * LD + kk) = hv[j];
+        }
+        h0_staged = true;
+    } else if (vec4) {
         for (int i = t; i < HEAD_CMAX * (KP / 4); i += HEAD_T) {
             const int cc = i / (KP / 4), kk = (i % (KP / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -125,7 +150,9 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
         const int rows = min(HEAD_RC, a.batch - r0);
         if (r0 > 0) __syncthreads();  // previous chunk's readers are done with Hs / lg
         const float tf = (row_l < rows) ? a.targets[r0 + row_l] : 0.f;   // requested with the H loads
-        if (vec4) {
+        if (r0 == 0 && h0_staged) {
+            // chunk 0 is already in LDS
+        } else if (vec4) {
             for (int i = t; i < HEAD_RC * (KP / 4); i += HEAD_T) {
                 const int rr = i / (KP / 4), kk = (i % (KP / 4)) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -215,8 +242,12 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
                 nll_acc += (cls >= C) ? NAN : my_nll;         // the reference panics (loss.rs:161)
                 hit_acc += (fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;  // loss.rs:283
             }
-            __syncthreads();                                  // every lane has read its logit
-            lg[row_l * HEAD_CMAX + sub] = dlv;                // rows >= `rows`, classes >= C hold 0
+            dl[row_l * HEAD_CMAX + sub] = dlv;                // rows >= `rows`, classes >= C hold 0
+            // db: column sums of dlogits (tensor.rs:686-691) -- the wave's 4 rows by shuffles, waves via LDS
+            float cs = dlv;
+            cs += __shfl_xor(cs, 16, 64);
+            cs += __shfl_xor(cs, 32, 64);
+            if (lane < HEAD_CMAX) dbp[wave * HEAD_CMAX + lane] = cs;
         }
         __syncthreads();
         HEAD_STAMP(4);
@@ -226,7 +257,7 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
             const int ntiles = 4 * dw_tiles;                  // 4 row tiles x K/16 column tiles
             for (int tl = wave; tl < ntiles; tl += 16) {
                 const int rt = tl / dw_tiles, ct = tl % dw_tiles;
-                const float4 av = *reinterpret_cast<const float4 *>(lg + (rt * 16 + r16) * HEAD_CMAX + g4 * 4);  // A[row][class]
+                const float4 av = *reinterpret_cast<const float4 *>(dl + (rt * 16 + r16) * HEAD_CMAX + g4 * 4);  // A[row][class]
                 floatx4 acc = {0.f, 0.f, 0.f, 0.f};
                 const float *bp = Ws + ct * 16 + r16;         // B[k = class][j = col] = W[class][col]
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[(g4 * 4 + 0) * LD], acc, 0, 0, 0);
@@ -245,18 +276,26 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
         // ---- dW[class][k] += sum_row dl[row][class] * H[row][k]   (ops.rs:280-291): K_mfma = 64 rows ----
         if (own_dw) {
             const float *bp = Hs + wave * 16 + r16;           // B[k = row][j = col] = H[row][col]
+            floatx4 acc2 = {0.f, 0.f, 0.f, 0.f};              // second chain: halves the dependent-MFMA latency
 #pragma unroll
-            for (int ks = 0; ks < HEAD_RC / 16; ++ks) {
+            for (int ks = 0; ks < HEAD_RC / 16; ks += 2) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const int rr = ks * 16 + g4 * 4 + s;
-                    dw_acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lg[rr * HEAD_CMAX + r16], bp[rr * LD], dw_acc, 0, 0, 0);  // A[class][row]
+                    const int r1 = ks * 16 + g4 * 4 + s, r2 = r1 + 16;
+                    dw_acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[r1 * HEAD_CMAX + r16], bp[r1 * LD], dw_acc, 0, 0, 0);  // A[class][row]
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[r2 * HEAD_CMAX + r16], bp[r2 * LD], acc2, 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dw_acc[i] += acc2[i];
         }
-        // ---- db[class] += sum_row dl[row][class]   (tensor.rs:686-691) ----
-        if (a.db && t < HEAD_CMAX)
-            for (int rr = 0; rr < rows; ++rr) db_acc += lg[rr * HEAD_CMAX + t];
+        // ---- db[class] += sum over the 16 waves' partial column sums, fixed order ----
+        if (a.db && t < HEAD_CMAX) {
+            float sdb = 0.f;
+#pragma unroll
+            for (int w = 0; w < HEAD_T / 64; ++w) sdb += dbp[w * HEAD_CMAX + t];
+            db_acc += sdb;
+        }
     }
 
     HEAD_STAMP(6);
@@ -332,7 +371,7 @@ __global__ void head_prof_end_kernel() { g_head_prof[15] = wall_clock64(); }
 
 static size_t head_lds_bytes(int k) {
     const int kp = (k + 15) & ~15, ld = kp + 4;
-    return ((size_t)(HEAD_RC + HEAD_CMAX) * ld + HEAD_RC * HEAD_CMAX + 4 * 3 * 64 * 4 + 32) * sizeof(float);
+    return ((size_t)(HEAD_RC + HEAD_CMAX) * ld + 2 * HEAD_RC * HEAD_CMAX + 4 * 3 * 64 * 4 + 32 + 16 * HEAD_CMAX) * sizeof(float);
 }
 
 }  // namespace th
