@@ -50,6 +50,17 @@ typedef struct th_adam_fuse {
     float beta1, beta2, eps, weight_decay;
 } th_adam_fuse;
 
+/* Adam update of a gradient slice that an EARLIER launch of this step already
+ * completed; a later launch carries it in spare workgroups instead of paying
+ * a kernel boundary for it (th_linear_bwd_adam_ex) -- or th_adam_slices runs
+ * the leftovers.  The carrying launch must not read f.d_p. */
+typedef struct th_adam_slice {
+    const float *d_g;
+    int64_t n;
+    th_adam_fuse f;
+} th_adam_slice;
+#define TH_MAX_ADAM_SLICES 4
+
 /* ---- runtime --------------------------------------------------------- */
 const char *th_last_error(void);
 int th_device_count(int *out);
@@ -114,6 +125,13 @@ int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
 int th_linear_bwd_adam(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y,
                        float *d_dx, float *d_dw, float *d_db, int batch, int in_features, int out_features,
                        int accumulate_mask, const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse);
+/* same, plus up to TH_MAX_ADAM_SLICES deferred updates (extra nullable) of
+ * OTHER parameters whose gradients are already complete (e.g. the classifier
+ * head's W / b, produced by th_linear_xent_head one launch earlier). */
+int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y,
+                          float *d_dx, float *d_dw, float *d_db, int batch, int in_features, int out_features,
+                          int accumulate_mask, const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse,
+                          const th_adam_slice *extra, int n_extra);
 
 /* ---- fused classifier head: last Linear + softmax cross-entropy --------- */
 /* One workgroup computes logits = H[B,in] . W[C,in]^T + b (nn.rs:54-60), the
@@ -246,6 +264,8 @@ int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m,
                  int pre_ticked /* 1: d_t[0] was already advanced for this step; use it as is */);
 /* t += 1 alone (optim.rs:84), for steps whose updates all ran fused */
 int th_adam_tick(th_ctx *ctx, int32_t *d_t);
+/* the deferred updates nobody carried (one launch for all n <= TH_MAX_ADAM_SLICES slices) */
+int th_adam_slices(th_ctx *ctx, const th_adam_slice *slices, int n);
 int th_sgd_step(th_ctx *ctx, float *d_params, const float *d_grads, const int64_t *d_offsets,
                 const int32_t *d_has_grad, int n_tensors, int64_t total, const float *d_lr); /* optim.rs:21-33 */
 

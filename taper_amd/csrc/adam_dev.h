@@ -57,4 +57,77 @@ static inline AdamDev make_adam_dev(const th_adam_fuse *f) {
     return AdamDev{f->d_p, f->d_m, f->d_v, f->d_t, f->d_lr, f->beta1, f->beta2, f->eps, f->weight_decay};
 }
 
+// Deferred updates carried by another launch (th_adam_slice): block b of the role handles 1024
+// consecutive elements of one slice.
+struct AdamSlices {
+    AdamDev a[TH_MAX_ADAM_SLICES];
+    const float *g[TH_MAX_ADAM_SLICES];
+    int64_t n[TH_MAX_ADAM_SLICES];
+    int first_block[TH_MAX_ADAM_SLICES + 1];   // prefix of blocks per slice
+    int count;
+    int blocks() const { return first_block[count]; }
+};
+
+static inline AdamSlices make_adam_slices(const th_adam_slice *s, int n) {
+    AdamSlices r{};
+    r.count = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!s[i].f.d_p || s[i].n <= 0) continue;
+        r.a[r.count] = make_adam_dev(&s[i].f);
+        r.g[r.count] = s[i].d_g;
+        r.n[r.count] = s[i].n;
+        r.first_block[r.count + 1] = r.first_block[r.count] + (int)((s[i].n + 1023) / 1024);
+        ++r.count;
+    }
+    for (int i = r.count; i < TH_MAX_ADAM_SLICES; ++i) r.first_block[i + 1] = r.first_block[r.count];
+    return r;
+}
+
+// 256 threads; optim.rs:99-110 on elements [1024 b', 1024 b' + 1024) of the slice owning block b
+__device__ __forceinline__ void adam_slices_block(const AdamSlices &x, int b) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < TH_MAX_ADAM_SLICES; ++i)
+        if (i < x.count && b >= x.first_block[i]) s = i;
+    const AdamDev &a = x.a[s];
+    const float *__restrict__ g = x.g[s];
+    const int64_t n = x.n[s];
+    const int64_t i0 = (int64_t)(b - x.first_block[s]) * 1024 + threadIdx.x * 4;
+    if (i0 >= n) return;
+    const bool vec = i0 + 4 <= n && ((((uintptr_t)a.p | (uintptr_t)a.m | (uintptr_t)a.v | (uintptr_t)g) & 15) == 0);
+    float gv[4], pv[4], mv[4], vv[4];
+    const int cnt = (int)(n - i0 < 4 ? n - i0 : 4);
+    if (vec) {
+        const float4 g4 = *reinterpret_cast<const float4 *>(g + i0), p4 = *reinterpret_cast<const float4 *>(a.p + i0);
+        const float4 m4 = *reinterpret_cast<const float4 *>(a.m + i0), v4 = *reinterpret_cast<const float4 *>(a.v + i0);
+        gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+        pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
+        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+        vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = i0 + (j < cnt ? j : 0);
+            gv[j] = g[i]; pv[j] = a.p[i]; mv[j] = a.m[i]; vv[j] = a.v[i];
+        }
+    }
+    const float step = adam_dev_step(a);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float gj = gv[j] + a.wd * pv[j];
+        mv[j] = a.beta1 * mv[j] + (1.0f - a.beta1) * gj;
+        vv[j] = a.beta2 * vv[j] + (1.0f - a.beta2) * gj * gj;
+        pv[j] = pv[j] - step * mv[j] / (sqrtf(vv[j]) + a.eps);
+    }
+    if (vec) {
+        *reinterpret_cast<float4 *>(a.p + i0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        *reinterpret_cast<float4 *>(a.m + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+        *reinterpret_cast<float4 *>(a.v + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+        for (int j = 0; j < cnt; ++j) {
+            a.p[i0 + j] = pv[j]; a.m[i0 + j] = mv[j]; a.v[i0 + j] = vv[j];
+        }
+    }
+}
+
 }  // namespace th

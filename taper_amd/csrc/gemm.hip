@@ -206,15 +206,17 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ p
 // node ops.rs:358-369 when MASKED).  Workgroup roles by block index:
 //   [0, n_dw)            dW[out,in] (+)= dZ^T . X      (TN: A = dZ^T is MC, B = X is MC)
 //   [n_dw, n_dw + n_dx)  dX[B,in]   (+)= dZ . W        (NN: A = dZ is KC,  B = W is MC)
-//   the rest             db[out]    (+)= sum_b dZ[b,:] (64 columns per workgroup)
+//   next n_db            db[out]    (+)= sum_b dZ[b,:] (64 columns per workgroup)
+//   the rest             deferred Adam updates of OTHER parameters (th_adam_slice), 1024 elements each
 // with dZ = dY (* (Y > 0) when MASKED).
 struct LinearBwdArgs {
     SmallArgs dw, dx;
-    int n_dw, n_dx, dw_tiles_n, dx_tiles_n;
+    int n_dw, n_dx, n_db, dw_tiles_n, dx_tiles_n;
     const float *dy, *ymask;
     float *db;
     int batch, out_f, db_accum;
     AdamDev db_adam;
+    AdamSlices extra;
 };
 
 template <bool MASKED>
@@ -226,28 +228,47 @@ __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
     } else if (bid < q.n_dw + q.n_dx) {
         const int t = bid - q.n_dw;
         small16_body<true, false, 4, MASKED>(q.dx, t / q.dx_tiles_n, t % q.dx_tiles_n, 0, red);
+    } else if (bid >= q.n_dw + q.n_dx + q.n_db) {
+        adam_slices_block(q.extra, bid - q.n_dw - q.n_dx - q.n_db);
     } else {
         // bias gradient: 4 waves stride the batch rows, lanes are consecutive columns
         float(*part)[64] = reinterpret_cast<float(*)[64]>(&red[0][0][0]);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int c = (bid - q.n_dw - q.n_dx) * 64 + lane;
+        // epilogue operands are requested before the column sum, not after it (one round trip, not two)
+        const bool own = wave == 0 && c < q.out_f, fuse = own && q.db_adam.p;
+        float pv = 0.f, mv = 0.f, vv = 0.f, step = 0.f, old = 0.f;
+        if (fuse) {
+            pv = q.db_adam.p[c];
+            mv = q.db_adam.m[c];
+            vv = q.db_adam.v[c];
+            step = adam_dev_step(q.db_adam);
+        }
+        if (own && q.db_accum) old = q.db[c];
         float s = 0.f;
-        if (c < q.out_f)
+        if (c < q.out_f) {
+#pragma unroll 4
             for (int r = wave; r < q.batch; r += 4) {
                 const long idx = (long)r * q.out_f + c;
                 float v = q.dy[idx];
                 if (MASKED) v = q.ymask[idx] > 0.f ? v : 0.f;
                 s += v;
             }
+        }
         part[wave][lane] = s;
         __syncthreads();
-        if (wave == 0 && c < q.out_f) {
+        if (own) {
             const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-            const float out = q.db_accum ? q.db[c] + tot : tot;
+            const float out = q.db_accum ? old + tot : tot;
             q.db[c] = out;
-            if (q.db_adam.p)
-                adam_update(q.db_adam.p, q.db_adam.m, q.db_adam.v, c, out, adam_dev_step(q.db_adam), q.db_adam.beta1,
-                            q.db_adam.beta2, q.db_adam.eps, q.db_adam.wd);
+            if (fuse) {   // optim.rs:99-110
+                const float gv = out + q.db_adam.wd * pv;
+                const float mn = q.db_adam.beta1 * mv + (1.0f - q.db_adam.beta1) * gv;
+                const float vn = q.db_adam.beta2 * vv + (1.0f - q.db_adam.beta2) * gv * gv;
+                q.db_adam.m[c] = mn;
+                q.db_adam.v[c] = vn;
+                q.db_adam.p[c] = pv - step * mn / (sqrtf(vn) + q.db_adam.eps);
+            }
         }
     }
 }
@@ -560,13 +581,23 @@ int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
 int th_linear_bwd_adam(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
                        float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask,
                        const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse) {
+    return th_linear_bwd_adam_ex(ctx, d_x, d_w, d_dy, d_relu_y, d_dx, d_dw, d_db, batch, in_features, out_features, accumulate_mask,
+                                 w_fuse, b_fuse, nullptr, 0);
+}
+
+int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
+                          float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask,
+                          const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra) {
     TH_REQUIRE(ctx && d_dy, "th_linear_bwd: null argument");
+    TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_linear_bwd_adam_ex: bad extra slices");
+    for (int i = 0; i < n_extra; ++i)
+        TH_REQUIRE(extra[i].f.d_p != d_w || !d_dx, "th_linear_bwd_adam_ex: a carried slice must not alias the weight this launch reads");
     const AdamDev w_adam = make_adam_dev(d_dw ? w_fuse : nullptr), b_adam = make_adam_dev(d_db ? b_fuse : nullptr);
     TH_REQUIRE(!w_adam.p || !(accumulate_mask & 2), "th_linear_bwd_adam: a fused dW must not accumulate (grad slot must be None)");
     TH_REQUIRE(!b_adam.p || !(accumulate_mask & 4), "th_linear_bwd_adam: a fused db must not accumulate (grad slot must be None)");
     TH_REQUIRE(!d_dx || d_w, "th_linear_bwd: d_w required for d_dx");
     TH_REQUIRE(!d_dw || d_x, "th_linear_bwd: d_x required for d_dw");
-    if (batch == 0 || out_features == 0 || in_features == 0) return 0;
+    if (batch == 0 || out_features == 0 || in_features == 0) return th_adam_slices(ctx, extra, n_extra);
     const bool dw_big = d_dw && gemm_is_big(out_features, in_features, batch);
     const bool dx_big = d_dx && gemm_is_big(batch, in_features, out_features);
     // latency-bound shapes (the MNIST MLP / classifier heads): the whole layer backward is ONE launch
@@ -596,8 +627,9 @@ int th_linear_bwd_adam(th_ctx *ctx, const float *d_x, const float *d_w, const fl
         q.batch = batch;
         q.out_f = out_features;
         q.db_accum = (accumulate_mask & 4) ? 1 : 0;
-        const int n_db = d_db ? ceil_div(out_features, 64) : 0;
-        const int grid = q.n_dw + q.n_dx + n_db;
+        q.n_db = d_db ? ceil_div(out_features, 64) : 0;
+        q.extra = make_adam_slices(extra, n_extra);
+        const int grid = q.n_dw + q.n_dx + q.n_db + q.extra.blocks();
         if (grid == 0) return 0;
         if (d_relu_y) hipLaunchKernelGGL(linear_bwd_small<true>, dim3(grid), dim3(256), 0, ctx->stream, q);
         else hipLaunchKernelGGL(linear_bwd_small<false>, dim3(grid), dim3(256), 0, ctx->stream, q);
@@ -630,6 +662,7 @@ int th_linear_bwd_adam(th_ctx *ctx, const float *d_x, const float *d_w, const fl
     // large shapes: the fused updates run as slice kernels behind the GEMMs
     if (int rc = adam_slice(ctx, w_adam, d_dw, (int64_t)out_features * in_features)) return rc;
     if (int rc = adam_slice(ctx, b_adam, d_db, out_features)) return rc;
+    if (int rc = th_adam_slices(ctx, extra, n_extra)) return rc;
     return tmp ? th_free(ctx, tmp) : 0;
 }
 

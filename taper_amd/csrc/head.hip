@@ -72,8 +72,11 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
 
     // the tick comes first: every fused update of this step (here and in the
     // following backward launches) must see t+1 (optim.rs:84)
-    if (t == 0 && a.adam_tick)
-        __hip_atomic_store(&a.adam_tick[0], a.adam_tick[0] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (it is PUBLISHED by thread 0 at the end of this launch; in here t+1 is formed in registers,
+    // so that no thread waits for a second global round trip before its Adam epilogue)
+    // Plain accesses: nothing else touches the counter while this launch runs, and an sc1 store would
+    // drop the line from L2, turning the next launch's first load into a fabric round trip.
+    const int32_t tick_old = a.adam_tick ? a.adam_tick[0] : 0;
 
     // ---- everything this launch needs from global memory is requested up front: after a kernel
     //      boundary each dependent round trip costs ~1 us, so none may hide behind a barrier ----
@@ -96,6 +99,17 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
         bp_ = a.b_adam.p[t];
         bm_ = a.b_adam.m[t];
         bv_ = a.b_adam.v[t];
+    }
+    // step counters / learning rates of the fused updates: loaded now, bias correction formed after staging
+    int32_t w_t = 0, b_t = 0;
+    float w_lr = 0.f, b_lr = 0.f;
+    if (a.w_adam.p) {
+        w_t = (a.w_adam.t == a.adam_tick) ? tick_old + 1 : a.w_adam.t[0];
+        w_lr = a.w_adam.lr[0];
+    }
+    if (a.b_adam.p) {
+        b_t = (a.b_adam.t == a.adam_tick) ? tick_old + 1 : a.b_adam.t[0];
+        b_lr = a.b_adam.lr[0];
     }
     const bool vec4 = (K & 3) == 0 && (((uintptr_t)a.h | (uintptr_t)a.w) & 15) == 0;
 
@@ -137,6 +151,8 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
         }
     }
 
+    if (a.w_adam.p) w_step = adam_step_size(w_lr, a.w_adam.beta1, a.w_adam.beta2, w_t);   // optim.rs:87-90
+    if (a.b_adam.p) b_step = adam_step_size(b_lr, a.b_adam.beta1, a.b_adam.beta2, b_t);
     HEAD_STAMP(1);
     // dW tiles: wave `wave` owns column tile `wave` (K <= 256 -> at most 16 tiles)
     floatx4 dw_acc = {0.f, 0.f, 0.f, 0.f};
@@ -319,6 +335,7 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
         const float l = n / (float)a.batch;  // loss.rs:164
         a.loss[0] = l;
         if (a.ncorrect) a.ncorrect[0] = hsum;
+        if (a.adam_tick) a.adam_tick[0] = tick_old + 1;  // optim.rs:84
         if (a.metrics) {  // the step log of th_log_step
             a.metrics[2 * log_slot] = l;
             a.metrics[2 * log_slot + 1] = hsum;
@@ -330,8 +347,6 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
     HEAD_STAMP(7);
     // ---- gradients out (+ fused Adam, optim.rs:99-110: every read of W above came from the LDS
     //      copy and the p / m / v values were requested at kernel entry) ----
-    if (fuse_w) w_step = adam_dev_step(a.w_adam);
-    if (fuse_b) b_step = adam_dev_step(a.b_adam);
     if (own_dw) {
         const int col = wave * 16 + r16;
 #pragma unroll

@@ -352,6 +352,12 @@ class Adam : public Optimizer {  // optim.rs:43-128
     // step() then only covers the parameters nobody fused, with the counter already ticked.
     int32_t *d_tick() const { return reinterpret_cast<int32_t *>(state_->d); }
     bool fuse_for(const Tensor &param, th_adam_fuse *out);  // false: not ours / has a grad already
+    // The gradient of `param` is (or is being) completed by the launch just enqueued, which could not
+    // update it in place (the head kernel; a backward whose dX workgroups still read W): a LATER
+    // launch of this step carries the update in spare workgroups (th_adam_slice), step() the leftovers.
+    bool defer_for(const Tensor &param);
+    int take_deferred(const float *launch_reads, th_adam_slice *out);  // <= TH_MAX_ADAM_SLICES, skipping aliases
+    void flush_deferred();
     void set_external_tick(bool on) { external_tick_ = on; }
 
    private:
@@ -360,6 +366,7 @@ class Adam : public Optimizer {  // optim.rs:43-128
     float lr_, beta1_, beta2_, eps_, wd_;
     bool external_tick_ = false;
     std::vector<char> fused_;                // per parameter: updated by a fused epilogue this step
+    std::vector<th_adam_slice> deferred_;    // updates waiting for a carrier launch
 };
 
 // RAII: marks `adam` as the optimizer whose updates may be fused on this thread.

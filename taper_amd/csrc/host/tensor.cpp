@@ -475,9 +475,14 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
             const th_adam_fuse *pw = nullptr, *pb = nullptr;
             Adam *fa = FusedAdamScope::active();  // Trainer: apply this layer's Adam update in the epilogue
             if (x.get_requires_grad()) { dx = x.grad_for_write(&none); if (!none) mask |= 1; }
+            // updates of downstream parameters whose gradients are already complete ride along
+            th_adam_slice carried[TH_MAX_ADAM_SLICES];
+            const int n_carried = fa ? fa->take_deferred(dx ? wt.dptr() : nullptr, carried) : 0;
+            bool defer_w = false;
             if (wt.get_requires_grad()) {
                 dw = wt.grad_for_write(&none);
                 if (!none) mask |= 2;
+                else if (fa && dx) defer_w = true;   // the dX workgroups read W: the next launch updates it
                 else if (fa && fa->fuse_for(wt, &wf)) pw = &wf;
             }
             if (b.defined() && b.get_requires_grad()) {
@@ -485,7 +490,9 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
                 if (!none) mask |= 4;
                 else if (fa && fa->fuse_for(b, &bf)) pb = &bf;
             }
-            TH(th_linear_bwd_adam(c, x.dptr(), wt.dptr(), dy, relu_y, dx, dw, db, batch, in_f, out_f, mask, pw, pb));
+            TH(th_linear_bwd_adam_ex(c, x.dptr(), wt.dptr(), dy, relu_y, dx, dw, db, batch, in_f, out_f, mask, pw, pb, carried,
+                                     n_carried));
+            if (defer_w) fa->defer_for(wt);
         });
     }
     return out;

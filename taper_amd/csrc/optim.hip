@@ -57,6 +57,8 @@ __global__ __launch_bounds__(256) void adam_slice_kernel(AdamDev a, const float 
         adam_update(a.p, a.m, a.v, i, g[i], step, a.beta1, a.beta2, a.eps, a.wd);
 }
 
+__global__ __launch_bounds__(256) void adam_slices_kernel(AdamSlices x) { adam_slices_block(x, blockIdx.x); }
+
 __global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                   const int64_t *__restrict__ offsets, const int32_t *__restrict__ has_grad,
                                                   int n_tensors, int64_t total, const float *__restrict__ lr) {
@@ -129,6 +131,15 @@ int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m,
 int th_adam_tick(th_ctx *ctx, int32_t *d_t) {
     TH_REQUIRE(ctx && d_t, "th_adam_tick: null argument");
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, ctx->stream, d_t);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_adam_slices(th_ctx *ctx, const th_adam_slice *slices, int n) {
+    TH_REQUIRE(ctx && n >= 0 && n <= TH_MAX_ADAM_SLICES && (n == 0 || slices), "th_adam_slices: bad argument");
+    const AdamSlices x = make_adam_slices(slices, n);
+    if (x.blocks() == 0) return 0;
+    hipLaunchKernelGGL(adam_slices_kernel, dim3(x.blocks()), dim3(256), 0, ctx->stream, x);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -143,6 +143,52 @@ def test_fused_bwd_rejects_accumulating_into_fused_grad(ctx):
         ctx.call("th_linear_bwd_adam", z, z, z, None, None, z, None, 8, 8, 8, 2, C.byref(f), None)
 
 
+class AdamSlice(C.Structure):  # include/taper_hip.h: th_adam_slice
+    _fields_ = [("d_g", C.c_void_p), ("n", C.c_int64), ("f", AdamFuse)]
+
+
+@pytest.mark.parametrize("carrier", ["linear_bwd", "standalone"])
+@pytest.mark.parametrize("sizes", [(1280, 10), (1, 1023, 1025, 4099)])
+def test_deferred_adam_slices(ctx, O, carrier, sizes):
+    """updates of already-complete gradients carried by another launch (or by th_adam_slices) == oracle Adam;
+    ragged lengths cover the float4 body, the scalar tail and slices spanning several workgroups"""
+    rng = np.random.default_rng(sum(sizes))
+    lr, t = 1e-3, 5
+    tick, dlr = ctx.upload(np.array([t, 0], np.int32)), ctx.upload(np.array([lr], np.float32))
+    slices, refs, keep = (AdamSlice * len(sizes))(), [], []
+    for i, n in enumerate(sizes):
+        p0 = rng.uniform(-0.1, 0.1, n).astype(np.float32)
+        g = (rng.standard_normal(n) * 0.01).astype(np.float32)
+        refs.append(_adam_ref(O, p0, g, lr, t))
+        bufs = [ctx.upload(p0), ctx.zeros(n), ctx.zeros(n), ctx.upload(g)]
+        keep.append(bufs)
+        slices[i] = AdamSlice(int(bufs[3]), n, AdamFuse(int(bufs[0]), int(bufs[1]), int(bufs[2]), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4))
+    if carrier == "standalone":
+        ctx.call("th_adam_slices", slices, len(sizes))
+    else:
+        batch, inf, outf = 32, 48, 24
+        x = rng.uniform(0, 1, (batch, inf)).astype(np.float32)
+        dy = (rng.standard_normal((batch, outf)) * 0.01).astype(np.float32)
+        dw_, db_ = ctx.empty(outf * inf), ctx.empty(outf)
+        ctx.call("th_linear_bwd_adam_ex", ctx.upload(x), None, ctx.upload(dy), None, None, dw_, db_, batch, inf, outf, 0, None, None,
+                 slices, len(sizes))
+        close(ctx.download(dw_, (outf, inf)), dy.T @ x, atol=1e-6)       # the carrier's own products are untouched
+        close(ctx.download(db_, (outf,)), dy.sum(0), atol=1e-6)
+    for bufs, (p_ref, m_ref, v_ref), n in zip(keep, refs, sizes):
+        np.testing.assert_allclose(ctx.download(bufs[0], (n,)), p_ref, rtol=RTOL, atol=lr * 2e-2)
+        np.testing.assert_allclose(ctx.download(bufs[1], (n,)), m_ref.reshape(n), rtol=1e-3, atol=1e-8)
+        np.testing.assert_allclose(ctx.download(bufs[2], (n,)), v_ref.reshape(n), rtol=1e-3, atol=1e-12)
+    assert ctx.download(tick, 2, np.int32)[0] == t
+
+
+def test_carried_slice_must_not_alias_the_weight_read_for_dx(ctx):
+    from taper_amd._lib import TaperError
+    z = ctx.zeros(64 * 64)
+    sl = (AdamSlice * 1)(AdamSlice(int(z), 64, AdamFuse(int(z), int(z), int(z), int(z), int(z), 0.9, 0.999, 1e-8, 0.0)))
+    with pytest.raises(TaperError, match="must not alias"):
+        ctx.call("th_linear_bwd_adam_ex", z, z, z, None, z, None, None, 8, 8, 8, 0, None, None, sl, 1)
+
+
 CONFIGS = [dict(graph_chunk=1, fuse_head=False, fuse_adam=False), dict(graph_chunk=8, fuse_head=True, fuse_adam=False),
            dict(graph_chunk=8, fuse_head=False, fuse_adam=True), dict(graph_chunk=32, fuse_head=True, fuse_adam=True)]
 

@@ -76,6 +76,24 @@ def main():
         "adam_step (100 480 params)": lambda: ctx.call("th_adam_step", pflat, gflat, mflat, vflat, offs, has, 2, HID * IN + HID, tick, lr,
                                                         0.9, 0.999, 1e-8, 1e-4, 1),
     }
+    metrics, state = ctx.zeros(2 * 4096), ctx.upload(np.array([0, 0], np.int64))
+    m2, v2, mb2, vb2 = ctx.zeros(OUT * HID), ctx.zeros(OUT * HID), ctx.zeros(OUT), ctx.zeros(OUT)
+    wf2 = AdamFuse(int(w2), int(m2), int(v2), int(tick), int(lr), 0.9, 0.999, 1e-8, 1e-4)
+    bf2 = AdamFuse(int(b2), int(mb2), int(vb2), int(tick), int(lr), 0.9, 0.999, 1e-8, 1e-4)
+    cases["head + step log"] = lambda: ctx.call("th_linear_xent_head", h, w2, b2, y, B, HID, OUT, None, loss, nc, dh, dw2, db2,
+                                                metrics, 4096, state, 1, None, None, None)
+    cases["head + step log + tick"] = lambda: ctx.call("th_linear_xent_head", h, w2, b2, y, B, HID, OUT, None, loss, nc, dh, dw2, db2,
+                                                       metrics, 4096, state, 1, tick, None, None)
+    cases["head + step log + tick + fused Adam"] = lambda: ctx.call("th_linear_xent_head", h, w2, b2, y, B, HID, OUT, None, loss, nc, dh,
+                                                                    dw2, db2, metrics, 4096, state, 1, tick, C.byref(wf2), C.byref(bf2))
+    cases["head + fused Adam only"] = lambda: ctx.call("th_linear_xent_head", h, w2, b2, y, B, HID, OUT, None, loss, nc, dh,
+                                                       dw2, db2, None, 0, None, 0, None, C.byref(wf2), C.byref(bf2))
+
+    def step_like():
+        cases["linear_fwd L1 (B x784->128, relu)"]()
+        cases["linear_xent_head (L2+xent+bwd)"]()
+        cases["linear_bwd_adam L1 (+Adam epilogue)"]()
+    cases["step-like chain (L1 fwd, head, L1 bwd+Adam) /3 launches"] = step_like
     out = {}
     for name, fn in cases.items():
         out[name] = round(chain_us(ctx, fn), 3)
