@@ -204,14 +204,17 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ p
 // Whole backward of one (small) Linear layer in ONE launch (the reference runs
 // three tape nodes: ops.rs:238-294, tensor.rs:574-587, 674-694, plus the ReLU
 // node ops.rs:358-369 when MASKED).  Workgroup roles by block index:
-//   [0, n_dw)            dW[out,in] (+)= dZ^T . X      (TN: A = dZ^T is MC, B = X is MC)
+//   [0, n_dw)            dW[out,in] (+)= dZ^T . X      (TN: A = dZ^T is MC, B = X is MC); n_dw = the tile
+//                        count rounded up to 8: block b runs on XCD b % 8, and XCD x takes the x-th
+//                        eighth of the tiles in column-major order, so each XCD's L2 fetches only its
+//                        own X columns / Adam state lines instead of every XCD fetching all of X
 //   [n_dw, n_dw + n_dx)  dX[B,in]   (+)= dZ . W        (NN: A = dZ is KC,  B = W is MC)
 //   next n_db            db[out]    (+)= sum_b dZ[b,:] (64 columns per workgroup)
 //   the rest             deferred Adam updates of OTHER parameters (th_adam_slice), 1024 elements each
 // with dZ = dY (* (Y > 0) when MASKED).
 struct LinearBwdArgs {
     SmallArgs dw, dx;
-    int n_dw, n_dx, n_db, dw_tiles_n, dx_tiles_n;
+    int n_dw, n_dx, n_db, dw_tiles, dw_tiles_m, dx_tiles_n;
     const float *dy, *ymask;
     float *db;
     int batch, out_f, db_accum;
@@ -224,7 +227,8 @@ __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
     __shared__ float red[3][64][4];
     const int bid = blockIdx.x;
     if (bid < q.n_dw) {
-        small16_body<false, false, 4, MASKED>(q.dw, bid / q.dw_tiles_n, bid % q.dw_tiles_n, 0, red);
+        const int t = (bid & 7) * (q.n_dw >> 3) + (bid >> 3);
+        if (t < q.dw_tiles) small16_body<false, false, 4, MASKED>(q.dw, t % q.dw_tiles_m, t / q.dw_tiles_m, 0, red);
     } else if (bid < q.n_dw + q.n_dx) {
         const int t = bid - q.n_dw;
         small16_body<true, false, 4, MASKED>(q.dx, t / q.dx_tiles_n, t % q.dx_tiles_n, 0, red);
@@ -605,9 +609,10 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
         LinearBwdArgs q{};
         const int dw_tm = ceil_div(out_features, 16), dw_tn = ceil_div(in_features, 16);
         const int dx_tm = ceil_div(batch, 16), dx_tn = ceil_div(in_features, 16);
-        q.n_dw = d_dw ? dw_tm * dw_tn : 0;
+        q.dw_tiles = d_dw ? dw_tm * dw_tn : 0;
+        q.n_dw = (q.dw_tiles + 7) & ~7;
+        q.dw_tiles_m = dw_tm;
         q.n_dx = d_dx ? dx_tm * dx_tn : 0;
-        q.dw_tiles_n = dw_tn;
         q.dx_tiles_n = dx_tn;
         // dW = dZ^T . X : op(A)[i=o,k=b] = dY[b*out + o] (rs 1, cs out); op(B)[k=b,j] = X[b*in + j]
         q.dw = SmallArgs{d_dy, d_relu_y, d_x, d_dw, nullptr, out_features, in_features, batch, 1, out_features, in_features, 1,
