@@ -213,6 +213,18 @@ int th_softmax_xent_bwd(th_ctx *ctx, const float *d_logp, const float *d_targets
 int th_log_softmax_fwd(th_ctx *ctx, const float *d_x, float *d_logp, int rows, int cols); /* loss.rs:101-126 */
 int th_accuracy_count(th_ctx *ctx, const float *d_argmax, const float *d_targets, int n, float *d_ncorrect); /* loss.rs:281-287 */
 
+/* ---- other losses / layers: src/loss.rs:6-73, 201-245; src/nn.rs:798-822 */
+/* loss[0] = -mean(y ln(p') + (1-y) ln(1-p')), p' = clamp(p, 1e-7, 1-1e-7)  (loss.rs:16-23) */
+int th_bce_fwd(th_ctx *ctx, const float *d_pred, const float *d_targets, size_t n, float *d_loss1);
+/* loss.rs:41-66; d_gpred / d_gtargets nullable; accumulate_mask bit0 / bit1: += into that grad */
+int th_bce_bwd(th_ctx *ctx, const float *d_pred, const float *d_targets, const float *d_g0, size_t n, float *d_gpred,
+               float *d_gtargets, int accumulate_mask);
+/* cross_entropy_loss_onehot backward, loss.rs:226-240: dlogits (+)= (exp(logp) - targets) * g0 / batch */
+int th_xent_onehot_bwd(th_ctx *ctx, const float *d_logp, const float *d_targets, const float *d_g0, int batch, int classes,
+                       float *d_dlogits, int accumulate);
+/* Dropout mask, nn.rs:808-818: mask[i] = u_i > p ? 1/(1-p) : 0 with u_i = splitmix64(seed, i) in [0,1) */
+int th_dropout_mask(th_ctx *ctx, float *d_mask, size_t n, float p, uint64_t seed);
+
 /* ---- conv / pool: src/tensor.rs:1221-2081 ----------------------------- */
 /* Direct 3x3 stride-1 convolution, NCHW, fused bias (nullable) and ReLU.
  * weight_layout 0 = taper's reinterpretation (tensor.rs:1262, quirk Q3):
@@ -266,6 +278,8 @@ int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m,
 int th_adam_tick(th_ctx *ctx, int32_t *d_t);
 /* the deferred updates nobody carried (one launch for all n <= TH_MAX_ADAM_SLICES slices) */
 int th_adam_slices(th_ctx *ctx, const th_adam_slice *slices, int n);
+/* x *= scale in place: AdamW's decoupled decay `w *= 1 - lr*wd` (optim.rs:150-159) */
+int th_scale(th_ctx *ctx, float *d_x, size_t n, float scale);
 int th_sgd_step(th_ctx *ctx, float *d_params, const float *d_grads, const int64_t *d_offsets,
                 const int32_t *d_has_grad, int n_tensors, int64_t total, const float *d_lr); /* optim.rs:21-33 */
 

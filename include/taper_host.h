@@ -26,6 +26,7 @@ typedef struct tp_optim tp_optim;
 typedef struct tp_dataset tp_dataset;
 typedef struct tp_loader tp_loader;
 typedef struct tp_trainer tp_trainer;
+typedef struct tp_sched tp_sched;
 typedef struct tp_comm tp_comm;
 
 const char *tp_last_error(void);
@@ -94,6 +95,8 @@ int tp_cross_entropy_loss(const tp_tensor *logits, const tp_tensor *targets, tp_
 int tp_accuracy(const tp_tensor *pred, const tp_tensor *targets, float *out);
 int tp_one_hot(const tp_tensor *idx, int num_classes, tp_tensor **out);
 int tp_mse_loss(const tp_tensor *pred, const tp_tensor *targets, tp_tensor **out);
+int tp_bce_loss(const tp_tensor *pred, const tp_tensor *targets, tp_tensor **out);                    /* loss.rs:6-73 */
+int tp_cross_entropy_loss_onehot(const tp_tensor *logits, const tp_tensor *targets, tp_tensor **out); /* loss.rs:201-245 */
 
 /* ---- nn (src/nn.rs, src/activation.rs) ---- */
 int tp_linear_new(int in_features, int out_features, int with_bias, uint64_t seed, tp_module **out);
@@ -105,6 +108,9 @@ int tp_maxpool2d_new(int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, t
 int tp_avgpool2d_new(int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, tp_module **out);
 int tp_adaptive_avgpool2d_new(int out_h, int out_w, tp_module **out);
 int tp_flatten_new(int start_dim, tp_module **out);
+int tp_dropout_new(float p, uint64_t seed, tp_module **out);                 /* nn.rs:773-827 */
+int tp_dropout_set_training(tp_module *m, int training);                     /* train() / eval() */
+int tp_dropout_last_mask(const tp_module *m, tp_tensor **out);               /* mask of the latest training forward */
 int tp_sequential_new(tp_module *const *layers, int n, int fuse_linear_relu, tp_module **out);
 int tp_module_free(tp_module *m);
 int tp_module_forward(const tp_module *m, const tp_tensor *x, tp_tensor **out);
@@ -115,6 +121,8 @@ int tp_module_parameter(const tp_module *m, int i, tp_tensor **out);   /* shares
 int tp_adam_new(tp_tensor *const *params, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
                 tp_optim **out);
 int tp_sgd_new(tp_tensor *const *params, int n, float lr, tp_optim **out);
+int tp_adamw_new(tp_tensor *const *params, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 tp_optim **out);                                            /* optim.rs:130-180 */
 int tp_optim_free(tp_optim *o);
 int tp_optim_step(tp_optim *o);
 int tp_optim_zero_grad(tp_optim *o);
@@ -123,6 +131,16 @@ int tp_adam_get_lr(const tp_optim *o, float *out);
 int tp_adam_t(const tp_optim *o, int *out);
 int tp_adam_moments(const tp_optim *o, float *h_m, float *h_v);  /* concatenated in parameter order */
 int tp_optim_total(const tp_optim *o, int64_t *out);             /* padded arena length (all-reduce size) */
+int tp_adam_load_state(tp_optim *o, int t, const float *h_m, const float *h_v);  /* inverse of tp_adam_t / tp_adam_moments */
+
+/* ---- LR schedulers (src/optim.rs:183-352) ---- */
+int tp_sched_step_lr(float base_lr, size_t step_size, float gamma, tp_sched **out);
+int tp_sched_exponential(float base_lr, float gamma, tp_sched **out);
+int tp_sched_cosine(float base_lr, size_t t_max, float min_lr, tp_sched **out);
+int tp_sched_plateau(float initial_lr, float factor, size_t patience, float min_lr, int mode_max, tp_sched **out);
+int tp_sched_step(tp_sched *s, const float *metric /* NULL = None */);
+int tp_sched_get_lr(const tp_sched *s, float *out);
+int tp_sched_free(tp_sched *s);
 
 /* ---- data (src/data/mnist.rs) ---- */
 int tp_dataset_from_host(const float *h_images, const float *h_labels, size_t n, int train, tp_dataset **out);
@@ -158,6 +176,22 @@ int tp_trainer_train_step(tp_trainer *t, const tp_tensor *images, const tp_tenso
 int tp_trainer_run_epoch(tp_trainer *t, tp_loader *l, int mode, size_t max_steps, float *avg_loss, float *accuracy,
                          size_t *total_correct, size_t *total_samples, size_t *num_batches, float *per_step,
                          size_t per_step_cap);
+
+/* train.rs:175-261: fit = epochs of train + evaluate + scheduler.step(Some(val_loss)) + metrics + early
+ * stop at val_acc > 0.99; graph != 0 trains through the captured step */
+int tp_trainer_set_scheduler(tp_trainer *t, tp_sched *s /* nullable; shared with the caller's handle */);
+int tp_trainer_fit(tp_trainer *t, tp_loader *train, tp_loader *val, size_t epochs, int verbose, int graph);
+/* Metrics (train.rs:9-71): which = 0 train_loss, 1 train_acc, 2 val_loss, 3 val_acc, 4 epoch_times */
+int tp_trainer_metrics(const tp_trainer *t, int which, float *h_out, size_t cap, size_t *n_out);
+/* which = 0: the print_last line, 1: the plot_summary text (NUL-terminated, truncated to cap) */
+int tp_trainer_metrics_text(const tp_trainer *t, int which, char *buf, size_t cap);
+/* train.rs:264-292 text checkpoint and its inverse; the optimizer-state pair is an extension */
+int tp_trainer_save_checkpoint(const tp_trainer *t, const char *path);
+int tp_trainer_load_checkpoint(tp_trainer *t, const char *path);
+int tp_trainer_save_optimizer_state(const tp_trainer *t, const char *path);
+int tp_trainer_load_optimizer_state(tp_trainer *t, const char *path);
+/* an f32 as Rust's `{}` prints it (the checkpoint's number format) */
+int tp_format_f32(float v, char *buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (numpy float32 / plain Python) of the reference code
+around the training step that SURVEY.md 8(f) ranks "next": LR schedulers and AdamW (src/optim.rs),
+cross_entropy_loss_onehot and Dropout (src/loss.rs, src/nn.rs), Metrics text and the text checkpoint
+(src/train.rs).  Each function cites the reference lines it follows.  Only tests/ may import this.
+
+Pinning: the schedulers against the reference's own unit-test expectations where it has them
+(src/optim.rs tests: none for schedulers -> closed forms checked in tests/test_train_extra.py);
+the number format against Rust's documented `Display for f32` outputs (shortest round-trip digits,
+never an exponent: 1 -> "1", f32::MAX -> "340282350000000000000000000000000000000",
+f32::MIN_POSITIVE -> "0.000000000000000000000000000000000000011754944")."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+f32 = np.float32
+PI_F32 = f32(3.14159274101257324)   # std::f32::consts::PI
+
+
+# ---- src/optim.rs:183-352 ---------------------------------------------------------------------
+class StepLR:  # optim.rs:190-221
+    def __init__(self, base_lr, step_size, gamma):
+        self.current_lr, self.step_size, self.gamma, self.current_epoch = f32(base_lr), int(step_size), f32(gamma), 0
+
+    def step(self, metrics=None):
+        self.current_epoch += 1
+        if self.current_epoch % self.step_size == 0:
+            self.current_lr = f32(self.current_lr * self.gamma)
+
+    def get_lr(self):
+        return float(self.current_lr)
+
+
+class ExponentialLR:  # optim.rs:223-249
+    def __init__(self, base_lr, gamma):
+        self.current_lr, self.gamma = f32(base_lr), f32(gamma)
+
+    def step(self, metrics=None):
+        self.current_lr = f32(self.current_lr * self.gamma)
+
+    def get_lr(self):
+        return float(self.current_lr)
+
+
+class CosineAnnealingLR:  # optim.rs:251-288
+    def __init__(self, base_lr, t_max, min_lr=None):
+        self.base_lr, self.min_lr = f32(base_lr), f32(0.0 if min_lr is None else min_lr)
+        self.current_lr, self.t_max, self.current_epoch = f32(base_lr), int(t_max), 0
+
+    def step(self, metrics=None):
+        self.current_epoch += 1
+        progress = f32(f32(self.current_epoch) / f32(self.t_max))
+        cos_val = f32(f32(f32(1.0) + np.cos(f32(progress * PI_F32), dtype=f32)) / f32(2.0))
+        self.current_lr = f32(self.min_lr + f32(f32(self.base_lr - self.min_lr) * cos_val))
+
+    def get_lr(self):
+        return float(self.current_lr)
+
+
+class ReduceLROnPlateau:  # optim.rs:290-352
+    def __init__(self, initial_lr, factor, patience, min_lr=None, mode=None):
+        self.mode = mode or "min"
+        self.current_lr, self.factor, self.patience = f32(initial_lr), f32(factor), int(patience)
+        self.min_lr = f32(1e-6 if min_lr is None else min_lr)
+        self.best_metric = f32(np.inf if self.mode == "min" else -np.inf)
+        self.patience_counter = 0
+
+    def step(self, metrics=None):
+        if metrics is None:
+            return
+        metric = f32(metrics)
+        improved = metric < self.best_metric if self.mode == "min" else metric > self.best_metric
+        if improved:
+            self.best_metric, self.patience_counter = metric, 0
+        else:
+            self.patience_counter += 1
+            if self.patience_counter >= self.patience:
+                self.current_lr = max(f32(self.current_lr * self.factor), self.min_lr)
+                self.patience_counter = 0
+
+    def get_lr(self):
+        return float(self.current_lr)
+
+
+def adamw_step(oracle_adam, params):
+    """optim.rs:147-168 on top of the C oracle's Adam: every weight decays by (1 - lr*wd) in f32 (grad or
+    not), then a standard Adam step with weight_decay = 0.  `oracle_adam` must have been built with
+    weight_decay=None; returns nothing (params are updated in place)."""
+    lr, wd = f32(oracle_adam.get_lr()), f32(oracle_adam.decoupled_wd)
+    if wd > 0:
+        factor = f32(f32(1.0) - f32(lr * wd))
+        for p in params:
+            p.set_data((p.data() * factor).astype(f32))
+    oracle_adam.step()
+
+
+# ---- src/loss.rs:201-245 ------------------------------------------------------------------------
+def log_softmax_rows(x):
+    """loss.rs:101-126 on a [B,C] float32 array"""
+    x = np.asarray(x, f32)
+    shifted = (x - x.max(axis=1, keepdims=True)).astype(f32)
+    lse = np.log(np.exp(shifted, dtype=f32).sum(axis=1, keepdims=True, dtype=f32), dtype=f32)
+    return (shifted - lse).astype(f32)
+
+
+def cross_entropy_loss_onehot(logits, targets, gloss=1.0):
+    """-> (loss, dlogits): loss = -sum(t * log_softmax(x)) / B (loss.rs:214-222); the recorded node's
+    gradient is (softmax - t) * gloss / B whatever the rows of t sum to (loss.rs:226-240)"""
+    logits, targets = np.asarray(logits, f32), np.asarray(targets, f32)
+    b = logits.shape[0]
+    logp = log_softmax_rows(logits)
+    loss = f32(-f32((targets * logp).astype(f32).sum(dtype=f32)) / f32(b))
+    grad = ((np.exp(logp, dtype=f32) - targets) * f32(gloss) / f32(b)).astype(f32)
+    return float(loss), grad
+
+
+# ---- src/nn.rs:798-822 ---------------------------------------------------------------------------
+def dropout_forward(x, mask=None, p=0.5, training=True):
+    """mask: the {0, 1/(1-p)} tensor the layer drew (the reference's RNG is unseeded, so parity is
+    'output == input * mask' plus the statistics of the mask)"""
+    x = np.asarray(x, f32)
+    if not training or p == 0.0:
+        return x
+    if p == 1.0:
+        return np.zeros_like(x)
+    return (x * np.asarray(mask, f32)).astype(f32)
+
+
+# ---- src/train.rs -----------------------------------------------------------------------------------
+def format_f32_display(v) -> str:
+    """Rust `{}` for f32 (train.rs:283-285 `writeln!(file, "{}", value)`): shortest digits that
+    round-trip, positional, no trailing ".0" """
+    v = f32(v)
+    if np.isnan(v):
+        return "NaN"
+    if np.isinf(v):
+        return "-inf" if v < 0 else "inf"
+    s = np.format_float_positional(v, unique=True, trim="-")
+    return s
+
+
+def checkpoint_text(params) -> str:
+    """train.rs:264-292: params = [(shape tuple, flat float32 array), ...]"""
+    lines = [str(len(params))]
+    for shape, data in params:
+        lines.append(" ".join([str(len(shape))] + [str(d) for d in shape]))
+        lines.extend(format_f32_display(x) for x in np.asarray(data, f32).reshape(-1))
+    return "\n".join(lines) + "\n"
+
+
+def metrics_last_line(m) -> str:
+    """train.rs:29-45 (m: dict of lists)"""
+    if not (m["train_loss"] and m["train_acc"] and m["val_loss"] and m["val_acc"]):
+        return ""
+    return "Train Loss: %.4f | Train Acc: %.2f%% | Val Loss: %.4f | Val Acc: %.2f%%" % (
+        m["train_loss"][-1], float(f32(m["train_acc"][-1]) * f32(100.0)), m["val_loss"][-1], float(f32(m["val_acc"][-1]) * f32(100.0)))
+
+
+def metrics_summary(m) -> str:
+    """train.rs:47-70"""
+    bar = "=" * 50
+    s = "\nTraining Summary:\n" + bar + "\n"
+    if m["train_acc"]:
+        pct = lambda a: float(f32(a) * f32(100.0))
+        best_t = max([0.0] + [float(a) for a in m["train_acc"]])
+        best_v = max([0.0] + [float(a) for a in m["val_acc"]])
+        s += "Best Train Accuracy: %.2f%%\nBest Val Accuracy: %.2f%%\nFinal Train Accuracy: %.2f%%\nFinal Val Accuracy: %.2f%%\n" % (
+            pct(best_t), pct(best_v), pct(m["train_acc"][-1]), pct(m["val_acc"][-1]))
+        if m["epoch_times"]:
+            total = f32(0.0)
+            for t in m["epoch_times"]:
+                total = f32(total + f32(t))
+            s += "Total Training Time: %.2fs\nAverage Epoch Time: %.2fs\n" % (float(total), float(f32(total / f32(len(m["epoch_times"])))))
+    return s + bar + "\n"
+
+
+def fit_schedule(val_losses, scheduler, lr0):
+    """the learning rate each epoch of Trainer::fit trains with (train.rs:209-213: after epoch e the
+    scheduler steps on Some(val_loss) and its lr is handed to the optimizer)"""
+    lrs, lr = [], float(f32(lr0))
+    for vl in val_losses:
+        lrs.append(lr)
+        scheduler.step(vl)
+        lr = scheduler.get_lr()
+    return lrs

@@ -12,9 +12,10 @@ from . import hip  # noqa: F401
 from ._lib import TaperError, build_native  # noqa: F401
 from . import dist  # noqa: F401
 from .api import (  # noqa: F401
-    SGD, Adam, AdaptiveAvgPool2d, AvgPool2d, Communicator, Conv2d, Conv2dReLU, DataLoader, Device, Flatten, Linear,
-    MaxPool2d, MNISTDataset, Module, ReLU, Sequential, Sigmoid, Tape, Tensor, Trainer, accuracy, cross_entropy_loss,
-    log_softmax, mse_loss, one_hot, set_full_backward, softmax,
+    SGD, Adam, AdamW, AdaptiveAvgPool2d, AvgPool2d, Communicator, Conv2d, Conv2dReLU, CosineAnnealingLR, DataLoader, Device,
+    Dropout, ExponentialLR, Flatten, Linear, MaxPool2d, MNISTDataset, Module, ReduceLROnPlateau, ReLU, Sequential, Sigmoid,
+    StepLR, Tape, Tensor, Trainer, accuracy, bce_loss, cross_entropy_loss, cross_entropy_loss_onehot, format_f32, log_softmax,
+    mse_loss, one_hot, set_full_backward, softmax,
 )
 
 Layer = Module  # the north_star calls the trait nn::Layer

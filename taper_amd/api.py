@@ -236,6 +236,8 @@ def softmax(x, dim=-1): return _t1(host.tp_softmax, "softmax", x)
 def cross_entropy_loss(logits, targets): return _t1(host.tp_cross_entropy_loss, "cross_entropy_loss", logits, targets._h)
 def one_hot(idx, num_classes): return _t1(host.tp_one_hot, "one_hot", idx, int(num_classes))
 def mse_loss(pred, targets): return _t1(host.tp_mse_loss, "mse_loss", pred, targets._h)
+def bce_loss(pred, targets): return _t1(host.tp_bce_loss, "bce_loss", pred, targets._h)
+def cross_entropy_loss_onehot(logits, targets): return _t1(host.tp_cross_entropy_loss_onehot, "cross_entropy_loss_onehot", logits, targets._h)
 
 
 def accuracy(pred, targets) -> float:
@@ -338,6 +340,21 @@ class Flatten(Module):
         super().__init__(_mk(host.tp_flatten_new, "Flatten::new", int(start_dim)))
 
 
+class Dropout(Module):
+    """nn.rs:773-827; the mask comes from a counter-based generator (the reference's RNG is unseeded)"""
+
+    def __init__(self, p, seed=0x64726F70):
+        super().__init__(_mk(host.tp_dropout_new, "Dropout::new", float(p), int(seed)))
+
+    def eval(self): tp_check(host.tp_dropout_set_training(self._h, 0), "Dropout::eval")
+    def train(self): tp_check(host.tp_dropout_set_training(self._h, 1), "Dropout::train")
+
+    def last_mask(self) -> Tensor:
+        h = _p()
+        tp_check(host.tp_dropout_last_mask(self._h, C.byref(h)), "Dropout::last_mask")
+        return Tensor(_h=h.value)
+
+
 class Sequential(Module):
     def __init__(self, layers, fuse=True):
         self.layers = list(layers)  # keep the children alive
@@ -386,6 +403,68 @@ class Adam(_Optim):
         m, v = np.empty(n, np.float32), np.empty(n, np.float32)
         tp_check(host.tp_adam_moments(self._h, m.ctypes.data, v.ctypes.data), "Adam::moments")
         return m, v
+
+
+    def load_state(self, t, m, v):
+        m, v = np.ascontiguousarray(m, np.float32), np.ascontiguousarray(v, np.float32)
+        tp_check(host.tp_adam_load_state(self._h, int(t), m.ctypes.data, v.ctypes.data), "Adam::load_state")
+
+
+class AdamW(Adam):
+    """optim.rs:130-180: decoupled decay on every weight, then Adam with weight_decay = 0"""
+
+    def __init__(self, params, lr, betas=None, eps=None, weight_decay=None):
+        betas = betas or (0.9, 0.999)
+        self.params = list(params)
+        arr = (_p * len(self.params))(*[p._h for p in self.params])
+        self._h = _mk(host.tp_adamw_new, "AdamW::new", arr, len(self.params), float(lr), float(betas[0]), float(betas[1]),
+                      float(1e-8 if eps is None else eps), float(0.0 if weight_decay is None else weight_decay))
+
+
+class _Scheduler:
+    """optim.rs:183-188 LRScheduler: step(metrics: Option<f32>), get_lr()"""
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            host.tp_sched_free(h)
+
+    def step(self, metrics=None):
+        m = None if metrics is None else C.byref(C.c_float(float(metrics)))
+        tp_check(host.tp_sched_step(self._h, m), "LRScheduler::step")
+
+    def get_lr(self) -> float:
+        v = C.c_float()
+        tp_check(host.tp_sched_get_lr(self._h, C.byref(v)), "LRScheduler::get_lr")
+        return float(v.value)
+
+
+class StepLR(_Scheduler):
+    def __init__(self, base_lr, step_size, gamma):
+        self._h = _mk(host.tp_sched_step_lr, "StepLR::new", float(base_lr), int(step_size), float(gamma))
+
+
+class ExponentialLR(_Scheduler):
+    def __init__(self, base_lr, gamma):
+        self._h = _mk(host.tp_sched_exponential, "ExponentialLR::new", float(base_lr), float(gamma))
+
+
+class CosineAnnealingLR(_Scheduler):
+    def __init__(self, base_lr, t_max, min_lr=None):
+        self._h = _mk(host.tp_sched_cosine, "CosineAnnealingLR::new", float(base_lr), int(t_max), float(min_lr or 0.0))
+
+
+class ReduceLROnPlateau(_Scheduler):
+    def __init__(self, initial_lr, factor, patience, min_lr=None, mode=None):
+        self._h = _mk(host.tp_sched_plateau, "ReduceLROnPlateau::new", float(initial_lr), float(factor), int(patience),
+                      float(1e-6 if min_lr is None else min_lr), 1 if (mode or "min") == "max" else 0)
+
+
+def format_f32(v) -> str:
+    """an f32 as Rust's `{}` prints it (the checkpoint's number format, train.rs:283-285)"""
+    buf = C.create_string_buffer(160)
+    tp_check(host.tp_format_f32(float(v), buf, len(buf)), "format_f32")
+    return buf.value.decode()
 
 
 class SGD(_Optim):
@@ -489,14 +568,16 @@ class Trainer:
     EAGER, GRAPH, EVAL = 0, 1, 2
 
     def __init__(self, model: Module, optimizer: Adam, sample_shape=None, comm: Communicator | None = None,
-                 graph_chunk: int = 32, fuse_head: bool = True, fuse_adam: bool = True):
-        self.model, self.optimizer, self.comm = model, optimizer, comm
+                 graph_chunk: int = 32, fuse_head: bool = True, fuse_adam: bool = True, scheduler=None):
+        self.model, self.optimizer, self.comm, self.scheduler = model, optimizer, comm, scheduler
         self._h = _mk(host.tp_trainer_new, "Trainer::new", model._h, optimizer._h)
         tp_check(host.tp_trainer_set_options(self._h, int(graph_chunk), 1 if fuse_head else 0, 1 if fuse_adam else 0), "set_options")
         if sample_shape:
             tp_check(host.tp_trainer_set_sample_shape(self._h, _shape_arr(sample_shape), len(sample_shape)), "set_sample_shape")
         if comm is not None:
             tp_check(host.tp_trainer_set_comm(self._h, comm._h), "set_comm")
+        if scheduler is not None:
+            tp_check(host.tp_trainer_set_scheduler(self._h, scheduler._h), "set_scheduler")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -522,3 +603,28 @@ class Trainer:
     def train_epoch(self, loader): return self.run_epoch(loader, self.EAGER)
     def train_epoch_graph(self, loader, max_steps=0): return self.run_epoch(loader, self.GRAPH, max_steps)
     def evaluate(self, loader): return self.run_epoch(loader, self.EVAL)
+
+    # -- train.rs:175-292 ---------------------------------------------------------
+    def fit(self, train_loader: DataLoader, val_loader: DataLoader, epochs: int, verbose: bool = False, graph: bool = True):
+        tp_check(host.tp_trainer_fit(self._h, train_loader._h, val_loader._h, int(epochs), 1 if verbose else 0, 1 if graph else 0), "fit")
+        return self.metrics()
+
+    def metrics(self):
+        out = {}
+        for which, name in enumerate(("train_loss", "train_acc", "val_loss", "val_acc", "epoch_times")):
+            n = C.c_size_t()
+            tp_check(host.tp_trainer_metrics(self._h, which, None, 0, C.byref(n)), "metrics")
+            buf = np.zeros(n.value, np.float32)
+            tp_check(host.tp_trainer_metrics(self._h, which, buf.ctypes.data, buf.size, None), "metrics")
+            out[name] = buf
+        return out
+
+    def metrics_text(self, summary=False) -> str:
+        buf = C.create_string_buffer(2048)
+        tp_check(host.tp_trainer_metrics_text(self._h, 1 if summary else 0, buf, len(buf)), "metrics_text")
+        return buf.value.decode()
+
+    def save_checkpoint(self, path): tp_check(host.tp_trainer_save_checkpoint(self._h, str(path).encode()), "save_checkpoint")
+    def load_checkpoint(self, path): tp_check(host.tp_trainer_load_checkpoint(self._h, str(path).encode()), "load_checkpoint")
+    def save_optimizer_state(self, path): tp_check(host.tp_trainer_save_optimizer_state(self._h, str(path).encode()), "save_optimizer_state")
+    def load_optimizer_state(self, path): tp_check(host.tp_trainer_load_optimizer_state(self._h, str(path).encode()), "load_optimizer_state")

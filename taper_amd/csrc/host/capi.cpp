@@ -1,4 +1,5 @@
 // capi.cpp -- include/taper_host.h: opaque-handle C ABI over the C++ host.
+#include <algorithm>
 #include <cstring>
 
 #include "../../../include/taper_host.h"
@@ -13,6 +14,7 @@ struct tp_dataset { MNISTDataset d; };
 struct tp_loader { std::unique_ptr<DataLoader> l; };
 struct tp_trainer { std::unique_ptr<Trainer> t; };
 struct tp_comm { std::shared_ptr<Communicator> c; };
+struct tp_sched { std::shared_ptr<LRScheduler> s; };
 
 static thread_local std::string g_err;
 
@@ -146,6 +148,25 @@ int tp_accuracy(const tp_tensor *p, const tp_tensor *tg, float *out) { TP_BEGIN 
 int tp_one_hot(const tp_tensor *idx, int nc, tp_tensor **out) { TP_BEGIN *out = wrap(one_hot(idx->t, (size_t)nc)); TP_END }
 int tp_mse_loss(const tp_tensor *p, const tp_tensor *tg, tp_tensor **out) { TP_BEGIN *out = wrap(mse_loss(p->t, tg->t)); TP_END }
 
+int tp_bce_loss(const tp_tensor *p, const tp_tensor *tg, tp_tensor **out) { TP_BEGIN *out = wrap(bce_loss(p->t, tg->t)); TP_END }
+int tp_cross_entropy_loss_onehot(const tp_tensor *l, const tp_tensor *tg, tp_tensor **out) {
+    TP_BEGIN *out = wrap(cross_entropy_loss_onehot(l->t, tg->t)); TP_END
+}
+
+static Dropout *as_dropout(const tp_module *m) {
+    auto *d = dynamic_cast<Dropout *>(m->m.get());
+    TAPER_ASSERT(d, "not a Dropout module");
+    return d;
+}
+int tp_dropout_new(float p, uint64_t seed, tp_module **out) { TP_BEGIN *out = new tp_module{std::make_shared<Dropout>(p, seed)}; TP_END }
+int tp_dropout_set_training(tp_module *m, int training) {
+    TP_BEGIN
+    if (training) as_dropout(m)->train();
+    else as_dropout(m)->eval();
+    TP_END
+}
+int tp_dropout_last_mask(const tp_module *m, tp_tensor **out) { TP_BEGIN *out = wrap(as_dropout(m)->last_mask()); TP_END }
+
 int tp_linear_new(int in_f, int out_f, int bias, uint64_t seed, tp_module **out) {
     TP_BEGIN *out = new tp_module{std::make_shared<Linear>((size_t)in_f, (size_t)out_f, bias != 0, seed)}; TP_END
 }
@@ -201,6 +222,36 @@ int tp_adam_new(tp_tensor *const *ps, int n, float lr, float b1, float b2, float
 int tp_sgd_new(tp_tensor *const *ps, int n, float lr, tp_optim **out) {
     TP_BEGIN *out = new tp_optim{std::make_shared<SGD>(collect(ps, n), lr), nullptr}; TP_END
 }
+int tp_adamw_new(tp_tensor *const *ps, int n, float lr, float b1, float b2, float eps, float wd, tp_optim **out) {
+    TP_BEGIN
+    auto w = std::make_shared<AdamW>(collect(ps, n), lr, b1, b2, eps, wd);
+    *out = new tp_optim{w, std::shared_ptr<Adam>(w, &w->adam)};
+    TP_END
+}
+int tp_adam_load_state(tp_optim *o, int t, const float *h_m, const float *h_v) {
+    TP_BEGIN
+    TAPER_ASSERT(o->adam, "not an Adam optimizer");
+    size_t n = 0;
+    for (const Tensor &p : o->adam->flat().params) n += p.len();
+    o->adam->load_state(t, std::vector<float>(h_m, h_m + n), std::vector<float>(h_v, h_v + n));
+    TP_END
+}
+int tp_sched_step_lr(float lr, size_t step, float gamma, tp_sched **out) { TP_BEGIN *out = new tp_sched{std::make_shared<StepLR>(lr, step, gamma)}; TP_END }
+int tp_sched_exponential(float lr, float gamma, tp_sched **out) { TP_BEGIN *out = new tp_sched{std::make_shared<ExponentialLR>(lr, gamma)}; TP_END }
+int tp_sched_cosine(float lr, size_t t_max, float min_lr, tp_sched **out) {
+    TP_BEGIN *out = new tp_sched{std::make_shared<CosineAnnealingLR>(lr, t_max, min_lr)}; TP_END
+}
+int tp_sched_plateau(float lr, float factor, size_t patience, float min_lr, int mode_max, tp_sched **out) {
+    TP_BEGIN
+    auto s = std::make_shared<ReduceLROnPlateau>(lr, factor, patience, min_lr, mode_max ? "max" : "min");
+    s->verbose = false;
+    *out = new tp_sched{s};
+    TP_END
+}
+int tp_sched_step(tp_sched *s, const float *metric) { TP_BEGIN s->s->step(metric); TP_END }
+int tp_sched_get_lr(const tp_sched *s, float *out) { TP_BEGIN *out = s->s->get_lr(); TP_END }
+int tp_sched_free(tp_sched *s) { TP_BEGIN delete s; TP_END }
+
 int tp_optim_free(tp_optim *o) { TP_BEGIN delete o; TP_END }
 int tp_optim_step(tp_optim *o) { TP_BEGIN o->o->step(); TP_END }
 int tp_optim_zero_grad(tp_optim *o) { TP_BEGIN o->o->zero_grad(); TP_END }
@@ -304,5 +355,35 @@ int tp_trainer_run_epoch(tp_trainer *t, tp_loader *l, int mode, size_t max_steps
         }
     TP_END
 }
+
+
+static int copy_text(const std::string &s, char *buf, size_t cap) {
+    if (!buf || cap == 0) return 0;
+    const size_t n = std::min(s.size(), cap - 1);
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+    return 0;
+}
+int tp_trainer_set_scheduler(tp_trainer *t, tp_sched *s) { TP_BEGIN t->t->scheduler = s ? s->s : nullptr; TP_END }
+int tp_trainer_fit(tp_trainer *t, tp_loader *train, tp_loader *val, size_t epochs, int verbose, int graph) {
+    TP_BEGIN t->t->fit(*train->l, *val->l, epochs, verbose != 0, graph != 0); TP_END
+}
+int tp_trainer_metrics(const tp_trainer *t, int which, float *h_out, size_t cap, size_t *n_out) {
+    TP_BEGIN
+    const Metrics &m = t->t->metrics;
+    const std::vector<float> *v[5] = {&m.train_loss, &m.train_acc, &m.val_loss, &m.val_acc, &m.epoch_times};
+    TAPER_ASSERT(which >= 0 && which < 5, "tp_trainer_metrics: which must be 0..4");
+    if (n_out) *n_out = v[which]->size();
+    if (h_out) std::memcpy(h_out, v[which]->data(), std::min(cap, v[which]->size()) * sizeof(float));
+    TP_END
+}
+int tp_trainer_metrics_text(const tp_trainer *t, int which, char *buf, size_t cap) {
+    TP_BEGIN copy_text(which == 0 ? t->t->metrics.last_line() : t->t->metrics.summary(), buf, cap); TP_END
+}
+int tp_trainer_save_checkpoint(const tp_trainer *t, const char *path) { TP_BEGIN t->t->save_checkpoint(path); TP_END }
+int tp_trainer_load_checkpoint(tp_trainer *t, const char *path) { TP_BEGIN t->t->load_checkpoint(path); TP_END }
+int tp_trainer_save_optimizer_state(const tp_trainer *t, const char *path) { TP_BEGIN t->t->save_optimizer_state(path); TP_END }
+int tp_trainer_load_optimizer_state(tp_trainer *t, const char *path) { TP_BEGIN t->t->load_optimizer_state(path); TP_END }
+int tp_format_f32(float v, char *buf, size_t cap) { TP_BEGIN copy_text(format_f32_display(v), buf, cap); TP_END }
 
 }  // extern "C"

@@ -412,6 +412,24 @@ static std::vector<float> gather_unpadded(const FlatParams &fp, const float *are
         out.insert(out.end(), all.begin() + fp.offsets[i], all.begin() + fp.offsets[i] + fp.params[i].len());
     return out;
 }
+static void scatter_padded(const FlatParams &fp, const std::vector<float> &src, float *arena) {
+    std::vector<float> all((size_t)fp.total, 0.f);
+    size_t off = 0;
+    for (size_t i = 0; i < fp.params.size(); ++i) {
+        std::copy(src.begin() + (long)off, src.begin() + (long)(off + fp.params[i].len()), all.begin() + fp.offsets[i]);
+        off += fp.params[i].len();
+    }
+    TH(th_memcpy_h2d(Device::ctx(), arena, all.data(), all.size() * sizeof(float)));
+}
+void Adam::load_state(int t, const std::vector<float> &m, const std::vector<float> &v) {
+    size_t n = 0;
+    for (const Tensor &p : fp_.params) n += p.len();
+    TAPER_ASSERT(m.size() == n && v.size() == n, "Adam::load_state: moment vectors must cover every parameter");
+    scatter_padded(fp_, m, m_->d);
+    scatter_padded(fp_, v, v_->d);
+    const int32_t st[2] = {t, 0};
+    TH(th_memcpy_h2d(Device::ctx(), state_->d, st, sizeof st));
+}
 std::vector<float> Adam::m() const { return gather_unpadded(fp_, m_->d); }
 std::vector<float> Adam::v() const { return gather_unpadded(fp_, v_->d); }
 

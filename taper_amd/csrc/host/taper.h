@@ -187,6 +187,8 @@ Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n
 float accuracy(const Tensor &predictions, const Tensor &targets);          // loss.rs:271-290 (synchronises)
 Tensor one_hot(const Tensor &indices, size_t num_classes);                 // loss.rs:248-268
 Tensor mse_loss(const Tensor &pred, const Tensor &targets);                // loss.rs:76-80
+Tensor bce_loss(const Tensor &pred, const Tensor &targets);                // loss.rs:6-73
+Tensor cross_entropy_loss_onehot(const Tensor &logits, const Tensor &targets);  // loss.rs:201-245
 
 // ---- nn (src/nn.rs, src/activation.rs) --------------------------------------
 class Module {
@@ -279,6 +281,24 @@ class Flatten : public Module {  // nn.rs:730-756
     const char *name() const override { return "Flatten"; }
 };
 
+class Dropout : public Module {  // nn.rs:773-827
+   public:
+    explicit Dropout(float p, uint64_t seed = 0x64726f70ull);
+    void eval() { training_ = false; }    // nn.rs:789-791
+    void train() { training_ = true; }    // nn.rs:793-795
+    Tensor forward(const Tensor &x) const override;
+    std::vector<Tensor> parameters() const override { return {}; }
+    const char *name() const override { return "Dropout"; }
+    Tensor last_mask() const { return last_mask_; }   // the mask of the latest training-mode forward (tests)
+
+   private:
+    float p_;
+    bool training_ = true;
+    uint64_t seed_;
+    mutable uint64_t calls_ = 0;
+    mutable Tensor last_mask_;
+};
+
 class Sequential : public Module {  // nn.rs:130-162
    public:
     std::vector<std::shared_ptr<Module>> layers;
@@ -341,6 +361,13 @@ class Adam : public Optimizer {  // optim.rs:43-128
     void zero_grad() override { fp_.zero_grad(); } // optim.rs:115-119
     float get_lr() const { return lr_; }
     void set_lr(float lr);                         // optim.rs:125-127
+    float weight_decay() const { return wd_; }
+    float beta1() const { return beta1_; }
+    float beta2() const { return beta2_; }
+    float eps() const { return eps_; }
+    void set_weight_decay(float wd) { wd_ = wd; }
+    // optimizer state as host vectors (checkpointing): t, and m / v in parameter order without padding
+    void load_state(int t, const std::vector<float> &m, const std::vector<float> &v);
     int t() const;                                 // reads the device counter (synchronises)
     std::vector<float> m() const;
     std::vector<float> v() const;
@@ -367,6 +394,73 @@ class Adam : public Optimizer {  // optim.rs:43-128
     bool external_tick_ = false;
     std::vector<char> fused_;                // per parameter: updated by a fused epilogue this step
     std::vector<th_adam_slice> deferred_;    // updates waiting for a carrier launch
+};
+
+class AdamW : public Optimizer {  // optim.rs:130-180: decay applied to the weights, then Adam with wd = 0
+   public:
+    AdamW(const std::vector<Tensor> &params, float lr, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f,
+          float weight_decay = 0.0f)
+        : adam(params, lr, beta1, beta2, eps, weight_decay) {}
+    void step() override;
+    void zero_grad() override { adam.zero_grad(); }
+    FlatParams &flat() override { return adam.flat(); }
+    float get_lr() const { return adam.get_lr(); }
+    void set_lr(float lr) { adam.set_lr(lr); }
+    Adam adam;
+};
+
+// ---- learning-rate schedulers (optim.rs:183-352); all arithmetic in f32 like the reference ----
+class LRScheduler {
+   public:
+    virtual ~LRScheduler() = default;
+    virtual void step(const float *metric /* nullptr = None */) = 0;
+    virtual float get_lr() const = 0;
+};
+class StepLR : public LRScheduler {  // optim.rs:190-221
+   public:
+    StepLR(float base_lr, size_t step_size, float gamma) : lr_(base_lr), step_size_(step_size), gamma_(gamma) {}
+    void step(const float *) override;
+    float get_lr() const override { return lr_; }
+
+   private:
+    float lr_;
+    size_t step_size_;
+    float gamma_;
+    size_t epoch_ = 0;
+};
+class ExponentialLR : public LRScheduler {  // optim.rs:223-249
+   public:
+    ExponentialLR(float base_lr, float gamma) : lr_(base_lr), gamma_(gamma) {}
+    void step(const float *) override { lr_ *= gamma_; }
+    float get_lr() const override { return lr_; }
+
+   private:
+    float lr_, gamma_;
+};
+class CosineAnnealingLR : public LRScheduler {  // optim.rs:251-288
+   public:
+    CosineAnnealingLR(float base_lr, size_t t_max, float min_lr = 0.0f) : base_(base_lr), min_(min_lr), lr_(base_lr), t_max_(t_max) {}
+    void step(const float *) override;
+    float get_lr() const override { return lr_; }
+
+   private:
+    float base_, min_, lr_;
+    size_t t_max_, epoch_ = 0;
+};
+class ReduceLROnPlateau : public LRScheduler {  // optim.rs:290-352
+   public:
+    ReduceLROnPlateau(float initial_lr, float factor, size_t patience, float min_lr = 1e-6f, const std::string &mode = "min");
+    void step(const float *metric) override;
+    float get_lr() const override { return lr_; }
+    bool verbose = true;   // the reference prints "Reducing learning rate to ..." (optim.rs:342)
+
+   private:
+    float lr_, factor_;
+    size_t patience_;
+    float min_lr_;
+    bool mode_min_;
+    float best_;
+    size_t counter_ = 0;
 };
 
 // RAII: marks `adam` as the optimizer whose updates may be fused on this thread.
@@ -437,6 +531,18 @@ struct EpochResult {
     std::vector<float> losses, ncorrect;  // per step
 };
 
+struct Metrics {  // train.rs:9-71
+    std::vector<float> train_loss, train_acc, val_loss, val_acc, epoch_times;
+    std::string last_line() const;     // text of print_last (train.rs:29-45); empty before the first epoch
+    std::string summary() const;       // text of plot_summary (train.rs:47-70)
+    void print_last() const;
+    void plot_summary() const;
+};
+
+// f32 as Rust's `{}` prints it (shortest digits that round-trip, never an exponent): the number
+// format of the checkpoint file (train.rs:283-285)
+std::string format_f32_display(float v);
+
 class Trainer {  // train.rs:74-172
    public:
     std::shared_ptr<Module> model;
@@ -456,6 +562,18 @@ class Trainer {  // train.rs:74-172
     // same arithmetic, but the step's op list is captured once into a hipGraph
     // and replayed; loss / n_correct stay on device until the epoch ends.
     EpochResult train_epoch_graph(DataLoader &loader, size_t max_steps = 0);
+    // train.rs:175-261: epochs of train + evaluate, scheduler.step(Some(val_loss)) -> optimizer.set_lr,
+    // metrics, early stop at val_acc > 0.99.  graph = true trains through the captured step.
+    std::shared_ptr<LRScheduler> scheduler;
+    Metrics metrics;
+    void fit(DataLoader &train_loader, DataLoader &val_loader, size_t epochs, bool verbose, bool graph = true);
+    // train.rs:264-292 text checkpoint (parameter count; per parameter "ndim d0 d1 ..." then one value per
+    // line); load_checkpoint is its inverse (shapes must match the model).  The optimizer-state pair
+    // is an extension in the same number format: "adam t lr beta1 beta2 eps wd", then m and v per parameter.
+    void save_checkpoint(const std::string &path) const;
+    void load_checkpoint(const std::string &path);
+    void save_optimizer_state(const std::string &path) const;
+    void load_optimizer_state(const std::string &path);
     ~Trainer();
 
    private:

@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ x, size_
 
 }  // namespace th
 
+namespace th {
+int scale_inplace(th_ctx *ctx, float *d_x, size_t n, float scale);
+}
 using namespace th;
 
 extern "C" {
@@ -142,6 +145,11 @@ int th_adam_slices(th_ctx *ctx, const th_adam_slice *slices, int n) {
     hipLaunchKernelGGL(adam_slices_kernel, dim3(x.blocks()), dim3(256), 0, ctx->stream, x);
     TH_LAUNCH_CHECK();
     return 0;
+}
+
+int th_scale(th_ctx *ctx, float *d_x, size_t n, float scale) {
+    TH_REQUIRE(ctx && (n == 0 || d_x), "th_scale: null argument");
+    return th::scale_inplace(ctx, d_x, n, scale);
 }
 
 int th_sgd_step(th_ctx *ctx, float *d_params, const float *d_grads, const int64_t *d_offsets, const int32_t *d_has_grad,

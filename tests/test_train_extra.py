@@ -1,0 +1,383 @@
+"""LR schedulers, AdamW, Trainer::fit / Metrics, the text checkpoint,
+bce_loss / cross_entropy_loss_onehot / Dropout and the XOR demo -- the host library (and its kernels)
+against the oracle's restatement (oracle/train_extra.py, oracle's C bce_loss / Adam / SGD)."""
+import math
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import train_extra as OX
+from tests import backends
+
+ROOT = Path(__file__).resolve().parent.parent
+RTOL = 1e-4
+
+
+# ------------------------------------------------------------------ host logic (no GPU needed)
+RUST_DISPLAY_KATS = [  # `println!("{}", x)` for f32, Rust's documented shortest-round-trip positional form
+    (1.0, "1"), (0.1, "0.1"), (-2.5, "-2.5"), (1e-7, "0.0000001"), (16777216.0, "16777216"), (0.3, "0.3"),
+    (3.4028235e38, "340282350000000000000000000000000000000"), (1.17549435e-38, "0.000000000000000000000000000000000000011754944"),
+    (1e-45, "0.000000000000000000000000000000000000000000001"), (-0.0, "-0"), (0.0, "0"), (123456.79, "123456.79"),
+    (float("inf"), "inf"), (float("-inf"), "-inf"), (float("nan"), "NaN"), (1e10, "10000000000"), (0.001, "0.001"),
+]
+
+
+@pytest.mark.parametrize("value,text", RUST_DISPLAY_KATS)
+def test_f32_display_known_answers(value, text):
+    """pins the oracle's number format (and the host's) on Rust's own outputs"""
+    import taper_amd as T
+    assert OX.format_f32_display(value) == text
+    assert T.format_f32(value) == text
+
+
+def test_f32_display_host_equals_oracle_and_round_trips():
+    import taper_amd as T
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2**32, 4000, dtype=np.uint64).astype(np.uint32)
+    vals = bits.view(np.float32)
+    vals = np.concatenate([vals[np.isfinite(vals)], np.float32([1e-30, 7e22, 0.5, 65504.0, 9.999999e-5])])
+    for v in vals:
+        s = T.format_f32(v)
+        assert s == OX.format_f32_display(v), repr(v)
+        assert "e" not in s and np.float32(s) == v
+
+
+SCHEDULERS = [
+    ("StepLR", (0.1, 3, 0.5)), ("StepLR", (0.01, 1, 0.9)), ("ExponentialLR", (0.05, 0.95)),
+    ("CosineAnnealingLR", (0.1, 10, None)), ("CosineAnnealingLR", (0.01, 7, 1e-4)),
+    ("ReduceLROnPlateau", (0.1, 0.5, 2, None, None)), ("ReduceLROnPlateau", (0.1, 0.1, 1, 1e-3, "max")),
+]
+
+
+@pytest.mark.parametrize("name,args", SCHEDULERS, ids=[f"{n}{i}" for i, (n, _) in enumerate(SCHEDULERS)])
+def test_schedulers_match_oracle(name, args):
+    """optim.rs:183-352: same f32 sequence as the restatement over 25 epochs of a wobbling metric"""
+    import taper_amd as T
+    h, o = getattr(T, name)(*args), getattr(OX, name)(*args)
+    rng = np.random.default_rng(3)
+    metric = 1.0
+    assert h.get_lr() == o.get_lr()
+    for epoch in range(25):
+        metric = metric * 0.9 if epoch % 4 else metric * 1.05 + rng.uniform(0, 0.01)   # improves, stalls, regresses
+        h.step(metric)
+        o.step(metric)
+        # exact for the multiplicative schedules; cosf (libm) vs numpy's float32 cos may differ by an ulp
+        assert h.get_lr() == pytest.approx(o.get_lr(), rel=2e-6 if name.startswith("Cosine") else 2e-7, abs=0), f"epoch {epoch}"
+
+
+def test_scheduler_closed_forms():
+    """what the reference's formulas amount to (optim.rs:209-214, 275-283, 325-347)"""
+    import taper_amd as T
+    s = T.StepLR(0.1, 2, 0.5)
+    lrs = []
+    for _ in range(6):
+        s.step()
+        lrs.append(s.get_lr())
+    np.testing.assert_allclose(lrs, [0.1, 0.05, 0.05, 0.025, 0.025, 0.0125], rtol=1e-6)
+    c = T.CosineAnnealingLR(0.2, 4, 0.0)
+    got = []
+    for _ in range(4):
+        c.step()
+        got.append(c.get_lr())
+    np.testing.assert_allclose(got, [0.2 * (1 + math.cos(math.pi * e / 4)) / 2 for e in (1, 2, 3, 4)], rtol=1e-5, atol=1e-8)
+    p = T.ReduceLROnPlateau(0.1, 0.5, 2, 0.03)
+    p.step(None)                       # None: nothing happens (optim.rs:326)
+    for m in (1.0, 1.0, 1.0):          # first improves on inf, then two stalls -> one reduction
+        p.step(m)
+    assert p.get_lr() == pytest.approx(0.05)
+    for m in (2.0, 2.0):
+        p.step(m)
+    assert p.get_lr() == pytest.approx(0.03)   # clamped at min_lr (optim.rs:340)
+
+
+# ------------------------------------------------------------------ device paths
+gpu = pytest.mark.gpu
+
+
+def _close(a, b, rtol=RTOL, atol=1e-7):
+    b = np.asarray(b)
+    scale = float(np.abs(b).max()) if b.size else 0.0
+    np.testing.assert_allclose(np.asarray(a).reshape(b.shape), b, rtol=rtol, atol=atol + rtol * 1e-2 * scale)
+
+
+@gpu
+@pytest.mark.parametrize("n,targets_grad", [(4, False), (1000, False), (257, True), (70000, False)])
+def test_bce_loss_matches_oracle(n, targets_grad):
+    """loss.rs:6-73 incl. the clamp at both ends and (optionally) the gradient towards the targets"""
+    import taper_amd as T
+    from oracle import oracle as O
+    rng = np.random.default_rng(n)
+    p = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    p[:4] = [0.0, 1.0, 1e-9, 1.0 - 1e-9][: min(4, n)]          # hit the clamp
+    y = (rng.uniform(0, 1, n) > 0.5).astype(np.float32)
+    if targets_grad:
+        y = rng.uniform(0.05, 0.95, n).astype(np.float32)
+    res = []
+    for M in (O, T):
+        M.Tape.reset()
+        pt = M.Tensor(p, (n, 1)).requires_grad()
+        yt = M.Tensor(y, (n, 1))
+        if targets_grad:
+            yt = yt.requires_grad()
+        loss = M.bce_loss(pt, yt)
+        (loss * M.Tensor(np.float32([1.7]), (1,))).backward()       # a non-unit upstream gradient
+        res.append((loss.data()[0], pt.grad(), yt.grad() if targets_grad else None))
+    (lo, gpo, gyo), (lh, gph, gyh) = res
+    assert lh == pytest.approx(lo, rel=RTOL)
+    _close(gph, gpo, rtol=2e-4)
+    if targets_grad:
+        _close(gyh, gyo, rtol=2e-4)
+
+
+@gpu
+def test_bce_loss_accumulates_into_existing_grad():
+    import taper_amd as T
+    rng = np.random.default_rng(0)
+    p, y = rng.uniform(0.1, 0.9, 64).astype(np.float32), (rng.uniform(0, 1, 64) > 0.5).astype(np.float32)
+    T.Tape.reset()
+    pt, yt = T.Tensor(p, (64,)).requires_grad(), T.Tensor(y, (64,))
+    l1 = T.bce_loss(pt, yt)
+    l2 = T.bce_loss(pt, yt)
+    (l1 + l2).backward()
+    g2 = pt.grad().copy()
+    pt.zero_grad()
+    T.Tape.reset()
+    T.bce_loss(pt, yt).backward()
+    _close(g2, 2 * pt.grad())
+
+
+@gpu
+@pytest.mark.parametrize("b,c,normalised", [(8, 10, True), (33, 7, False), (256, 10, True)])
+def test_cross_entropy_loss_onehot_matches_oracle(b, c, normalised):
+    """loss.rs:201-245; with un-normalised targets the recorded gradient is still (softmax - t)/B"""
+    import taper_amd as T
+    rng = np.random.default_rng(b * c)
+    x = (rng.standard_normal((b, c)) * 3).astype(np.float32)
+    t = np.eye(c, dtype=np.float32)[rng.integers(0, c, b)] if normalised else rng.uniform(0, 1, (b, c)).astype(np.float32)
+    T.Tape.reset()
+    xt = T.Tensor(x, (b, c)).requires_grad()
+    loss = T.cross_entropy_loss_onehot(xt, T.Tensor(t, (b, c)))
+    (loss * T.Tensor(np.float32([0.5]), (1,))).backward()
+    lo, go = OX.cross_entropy_loss_onehot(x, t, gloss=0.5)
+    assert loss.data()[0] == pytest.approx(lo, rel=RTOL, abs=1e-6)
+    _close(xt.grad(), go, rtol=2e-4)
+    if normalised:   # same value as the index form (loss.rs:136-195)
+        T.Tape.reset()
+        li = T.cross_entropy_loss(T.Tensor(x, (b, c)), T.Tensor(t.argmax(1).astype(np.float32), (b,)))
+        assert li.data()[0] == pytest.approx(lo, rel=RTOL, abs=1e-6)
+
+
+@gpu
+def test_onehot_shape_checks_are_errors():
+    import taper_amd as T
+    with pytest.raises(T.TaperError, match="shapes must match"):
+        T.cross_entropy_loss_onehot(T.Tensor(np.zeros((2, 3), np.float32), (2, 3)), T.Tensor(np.zeros((2, 4), np.float32), (2, 4)))
+    with pytest.raises(T.TaperError, match="must match in length"):
+        T.bce_loss(T.Tensor(np.zeros(3, np.float32), (3,)), T.Tensor(np.zeros(4, np.float32), (4,)))
+
+
+@gpu
+def test_dropout_semantics():
+    """nn.rs:798-822: identity in eval / p = 0, zeros at p = 1, otherwise input * mask with mask in
+    {0, 1/(1-p)}, keep rate ~ 1-p, a fresh mask per call, gradient = upstream * mask"""
+    import taper_amd as T
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((64, 512)).astype(np.float32)
+    xt = T.Tensor(x, x.shape)
+    for p in (0.0, 0.3, 0.5, 0.9, 1.0):
+        d = T.Dropout(p)
+        y = d.forward(xt).data()
+        if p == 0.0:
+            np.testing.assert_array_equal(y, x)
+        elif p == 1.0:
+            np.testing.assert_array_equal(y, np.zeros_like(x))
+        else:
+            m = d.last_mask().data()
+            scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+            assert set(np.unique(m)) <= {np.float32(0.0), scale}
+            keep = float((m > 0).mean())
+            assert abs(keep - (1 - p)) < 4 * math.sqrt(p * (1 - p) / m.size) + 1e-3
+            np.testing.assert_array_equal(y, OX.dropout_forward(x, m, p))
+            m2 = (d.forward(xt), d.last_mask().data())[1]
+            assert (m2 != m).mean() > 0.05                         # successive draws differ
+        d.eval()
+        np.testing.assert_array_equal(d.forward(xt).data(), x)   # eval(): identity (nn.rs:800-802)
+    with pytest.raises(T.TaperError, match="between 0 and 1"):
+        T.Dropout(1.5)
+    T.Tape.reset()
+    d = T.Dropout(0.4)
+    xg = T.Tensor(x, x.shape).requires_grad()
+    d.forward(xg).mean().backward()
+    _close(xg.grad(), d.last_mask().data() / np.float32(x.size))
+
+
+@gpu
+def test_adamw_matches_oracle():
+    """optim.rs:130-180: decay hits every weight (also one without a gradient), Adam runs with wd = 0"""
+    import taper_amd as T
+    from oracle import oracle as O
+    rng = np.random.default_rng(9)
+    shapes = [(16, 8), (16,), (5, 5)]
+    init = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    hp = [T.Tensor(a, a.shape).requires_grad() for a in init]
+    op = [O.Tensor(a, a.shape).requires_grad() for a in init]
+    hopt = T.AdamW(hp, 1e-2, None, None, 0.05)
+    oopt = O.Adam(op, 1e-2, None, None, None)
+    oopt.decoupled_wd = 0.05
+    for step in range(6):
+        for i, (h, o) in enumerate(zip(hp, op)):
+            if i == 2 and step % 2 == 0:
+                continue                                            # grad None on some steps (Q8)
+            g = rng.standard_normal(shapes[i]).astype(np.float32)
+            h.set_grad(g)
+            o.set_grad(g)
+        hopt.step()
+        OX.adamw_step(oopt, op)
+        hopt.zero_grad()
+        oopt.zero_grad()
+        for h, o in zip(hp, op):
+            np.testing.assert_allclose(h.data(), o.data(), rtol=RTOL, atol=1e-6, err_msg=f"step {step}")
+    assert hopt.t() == oopt.t() == 6
+
+
+def _small_problem(rng, n_train=1024, n_val=512):
+    """a learnable 10-class problem in MNIST's shape: class = argmax of 10 fixed random projections"""
+    proj = rng.standard_normal((784, 10)).astype(np.float32)
+
+    def make(n):
+        x = rng.uniform(0, 1, (n, 784)).astype(np.float32)
+        return x, (x - 0.5).dot(proj).argmax(1).astype(np.float32)
+    return make(n_train), make(n_val)
+
+
+@gpu
+@pytest.mark.parametrize("graph", [True, False], ids=["graph", "eager"])
+def test_fit_with_scheduler_and_metrics(graph, capfd):
+    """train.rs:175-261: per-epoch train + evaluate, scheduler.step(Some(val_loss)) -> optimizer lr,
+    Metrics vectors and their printed forms"""
+    import taper_amd as T
+    rng = np.random.default_rng(21)
+    (xtr, ytr), (xva, yva) = _small_problem(rng)
+    H = backends.get("hip")
+    model = H.sequential(backends.mlp_baseline(rng))
+    opt = T.Adam(model.parameters(), 2e-3, None, None, 1e-4)
+    sched = T.StepLR(2e-3, 2, 0.5)
+    tr = T.Trainer(model, opt, scheduler=sched)
+    train, val = T.DataLoader(T.MNISTDataset.from_host(xtr, ytr), 128, True), T.DataLoader(T.MNISTDataset.from_host(xva, yva, False), 128, False)
+    m = tr.fit(train, val, 5, verbose=True, graph=graph)
+    out = capfd.readouterr().out
+    assert all(len(m[k]) == 5 for k in m)
+    assert m["train_loss"][-1] < m["train_loss"][0] and m["val_acc"][-1] > 0.3          # it learns
+    ref = OX.StepLR(2e-3, 2, 0.5)
+    OX.fit_schedule(list(m["val_loss"]), ref, 2e-3)
+    assert opt.get_lr() == pytest.approx(ref.get_lr(), rel=1e-6) == pytest.approx(2e-3 * 0.25, rel=1e-6)
+    md = {k: [float(v) for v in m[k]] for k in m}
+    assert tr.metrics_text() == OX.metrics_last_line(md)
+    assert tr.metrics_text(summary=True) == OX.metrics_summary(md)
+    assert "Starting training for 5 epochs" in out and "Epoch 5 - Train Loss:" in out and "Learning Rate: 0.000500" in out
+    assert "Training Summary:" in out
+    # evaluate() agrees with the metrics fit recorded for the last epoch
+    ev = tr.run_epoch(val, T.Trainer.EVAL)
+    assert ev["avg_loss"] == pytest.approx(m["val_loss"][-1], rel=1e-6)
+
+
+@gpu
+def test_fit_stops_early_at_99_percent(capfd):
+    """train.rs:247-250"""
+    import taper_amd as T
+    rng = np.random.default_rng(4)
+    x = np.zeros((256, 784), np.float32)
+    y = rng.integers(0, 10, 256).astype(np.float32)
+    x[np.arange(256), (y * 70).astype(int)] = 1.0                                   # one hot pixel per class: trivially separable
+    H = backends.get("hip")
+    model = H.sequential(backends.mlp_baseline(rng))
+    tr = T.Trainer(model, T.Adam(model.parameters(), 1e-2, None, None, None))
+    ds = T.MNISTDataset.from_host(x, y)
+    m = tr.fit(T.DataLoader(ds, 64, True), T.DataLoader(ds, 64, False), 40, verbose=False)
+    assert 1 <= len(m["val_acc"]) < 40 and m["val_acc"][-1] > 0.99
+    assert "Reached 99% validation accuracy! Stopping early." in capfd.readouterr().out
+
+
+@gpu
+def test_checkpoint_text_format_and_round_trip(tmp_path):
+    """train.rs:264-292 byte for byte (vs the restated writer), then load -> identical parameters;
+    with the optimizer state restored, training continues exactly as if it had never stopped"""
+    import taper_amd as T
+    rng = np.random.default_rng(8)
+    H = backends.get("hip")
+    spec = backends.nonzero_biases(backends.mlp_example(rng), rng)
+    (xtr, ytr), _ = _small_problem(rng, 512, 8)
+
+    def make():
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        return model, opt, T.Trainer(model, opt), T.DataLoader(T.MNISTDataset.from_host(xtr, ytr), 64, False)
+
+    model, opt, tr, loader = make()
+    tr.run_epoch(loader, T.Trainer.GRAPH)
+    ck, st = tmp_path / "model.ckpt", tmp_path / "adam.ckpt"
+    tr.save_checkpoint(ck)
+    tr.save_optimizer_state(st)
+    params = [(tuple(p.shape()), p.data()) for p in model.parameters()]
+    assert ck.read_text() == OX.checkpoint_text(params)
+    head = st.read_text().split("\n", 1)[0].split()
+    assert head[:2] == ["adam", "8"] and head[2:] == [OX.format_f32_display(v) for v in (1e-3, 0.9, 0.999, 1e-8, 1e-4)]
+    ref = tr.run_epoch(loader, T.Trainer.GRAPH)                      # the uninterrupted run: one more epoch
+
+    model2, opt2, tr2, loader2 = make()                              # fresh process-equivalent: same init, no training
+    tr2.load_checkpoint(ck)
+    tr2.load_optimizer_state(st)
+    for (shape, data), p in zip(params, model2.parameters()):
+        np.testing.assert_array_equal(p.data(), data)               # text round trip is exact
+    assert opt2.t() == 8
+    res = tr2.run_epoch(loader2, T.Trainer.GRAPH)
+    np.testing.assert_array_equal(res["losses"], ref["losses"])      # bit-identical continuation
+    for a, b in zip(model.parameters(), model2.parameters()):
+        np.testing.assert_array_equal(a.data(), b.data())
+    with pytest.raises(T.TaperError, match="shape mismatch|count mismatch"):
+        other = H.sequential(backends.mlp_baseline(rng))
+        T.Trainer(other, T.Adam(other.parameters(), 1e-3)).load_checkpoint(ck)
+
+
+@gpu
+def test_xor_training_trajectory_matches_oracle():
+    """src/main.rs: Linear(2,4) - Sigmoid - Linear(4,1) - Sigmoid, bce_loss, SGD(0.1): same losses as the
+    oracle step by step from the same initial weights"""
+    import taper_amd as T
+    from oracle import oracle as O
+    rng = np.random.default_rng(1)
+    x = np.float32([[0, 0], [0, 1], [1, 0], [1, 1]])
+    y = np.float32([[0], [1], [1], [0]])
+    w1, b1 = rng.uniform(-1, 1, (4, 2)).astype(np.float32), np.zeros(4, np.float32)
+    w2, b2 = rng.uniform(-0.7, 0.7, (1, 4)).astype(np.float32), np.zeros(1, np.float32)
+    losses = []
+    for M in (O, T):
+        ps = [M.Tensor(a, a.shape).requires_grad() for a in (w1, b1, w2, b2)]
+        opt = M.SGD(ps, 0.10, None)
+        ls = []
+        for it in range(300):
+            M.Tape.reset()
+            xt, yt = M.Tensor(x, (4, 2)), M.Tensor(y, (4, 1))
+            h = xt.matmul(ps[0].transpose()).add_broadcast(ps[1]).sigmoid()       # Linear::forward (nn.rs:54-60) + Sigmoid
+            yhat = h.matmul(ps[2].transpose()).add_broadcast(ps[3]).sigmoid()
+            loss = M.bce_loss(yhat, yt)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            ls.append(float(loss.data()[0]))
+        losses.append(ls)
+    np.testing.assert_allclose(losses[1], losses[0], rtol=2e-4)
+    assert losses[1][-1] < losses[1][0]
+
+
+@gpu
+def test_xor_example_learns_xor():
+    """the C++ counterpart of src/main.rs, all 50 000 iterations"""
+    exe = ROOT / "examples" / "_build" / "xor"
+    if not exe.exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "examples")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "iteration    0: Loss = " in out.stdout and "learned XOR" in out.stdout
