@@ -12,7 +12,7 @@ namespace ex {
 
 struct Args {
     std::string data_dir = "data/mnist";  // data/mnist.rs:13 default
-    size_t epochs = 3, batch_size = 256, train_n = 60000, test_n = 10000;
+    size_t epochs = 0 /* 0 = the example's own default */, batch_size = 256, train_n = 60000, test_n = 10000;
     bool eager = false;                   // --eager: the literal per-step loop of the reference example
 };
 

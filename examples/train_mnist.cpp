@@ -11,7 +11,7 @@ using namespace taper;
 
 int main(int argc, char **argv) {
     ex::Args args = ex::parse(argc, argv);
-    if (args.epochs == 3) args.epochs = 10;  // train_mnist.rs:62
+    if (args.epochs == 0) args.epochs = 10;  // train_mnist.rs:62
     try {
         printf("MNIST Neural Network Training\n\nLoading MNIST dataset...\n");
         MNISTDataset train_ds = ex::load(args, true), test_ds = ex::load(args, false);

@@ -16,6 +16,7 @@ int main(int argc, char **argv) {
         else argv[kept++] = argv[i];
     }
     ex::Args args = ex::parse(kept, argv);
+    if (args.epochs == 0) args.epochs = 50;  // train_mnist_cnn.rs:115
     try {
         printf("MNIST CNN Training\n\nLoading MNIST dataset...\n");
         MNISTDataset train_ds = ex::load(args, true), test_ds = ex::load(args, false);
@@ -38,7 +39,7 @@ int main(int argc, char **argv) {
         size_t n_params = 0;
         for (const Tensor &p : model->parameters()) n_params += p.len();
         printf("Total parameters: %zu\n", n_params);
-        const float lr = 0.01f;
+        float lr = 0.01f;
         auto optimizer = std::make_shared<Adam>(model->parameters(), lr, 0.9f, 0.999f, 1e-8f, 0.0001f);  // train_mnist_cnn.rs:108-109
         Trainer trainer(model, optimizer);
         trainer.sample_shape = {1, 28, 28};                                                              // train_mnist_cnn.rs:161-162
@@ -47,11 +48,20 @@ int main(int argc, char **argv) {
 
         for (size_t epoch = 1; epoch <= args.epochs; ++epoch) {
             const auto t0 = std::chrono::steady_clock::now();
+            if (epoch % 5 == 0 && epoch >= 5) {  // train_mnist_cnn.rs:132-137; lr lives on the device, the captured graph reads it
+                lr *= 0.8f;
+                printf("   Reducing learning rate to %.6f\n", lr);
+                optimizer->set_lr(lr);
+            }
             const EpochResult tr = args.eager ? trainer.train_epoch(train_loader) : trainer.train_epoch_graph(train_loader);
             const EpochResult va = trainer.evaluate(test_loader);
             const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             printf("Epoch %zu/%zu:\n   Train Loss: %.4f | Train Acc: %.2f%%\n   Val Loss: %.4f   | Val Acc: %.2f%%\n   Time: %.2fs (%.0f samples/s)\n\n",
                    epoch, args.epochs, tr.avg_loss, tr.accuracy * 100.f, va.avg_loss, va.accuracy * 100.f, secs, tr.total_samples / secs);
+            if (va.accuracy > 0.995f) {  // train_mnist_cnn.rs:261-267
+                printf("Reached %.2f%% validation accuracy! Stopping early.\n", va.accuracy * 100.f);
+                break;
+            }
         }
         printf("Training Complete!\n");
     } catch (const std::exception &e) {

@@ -189,6 +189,7 @@ void Trainer::fit(DataLoader &train_loader, DataLoader &val_loader, size_t epoch
         }
     }
     metrics.plot_summary();
+    fflush(stdout);
 }
 
 // ---------------------------------------------------------------- checkpoint

@@ -243,12 +243,15 @@ def test_adamw_matches_oracle():
 
 
 def _small_problem(rng, n_train=1024, n_val=512):
-    """a learnable 10-class problem in MNIST's shape: class = argmax of 10 fixed random projections"""
-    proj = rng.standard_normal((784, 10)).astype(np.float32)
+    """a learnable 10-class problem in MNIST's shape: a fixed random template per class plus noise"""
+    templates = (rng.uniform(0, 1, (10, 784)) > 0.7).astype(np.float32)
 
     def make(n):
-        x = rng.uniform(0, 1, (n, 784)).astype(np.float32)
-        return x, (x - 0.5).dot(proj).argmax(1).astype(np.float32)
+        y = rng.integers(0, 10, n)
+        x = np.clip(0.6 * templates[y] + rng.uniform(0, 0.4, (n, 784)), 0, 1).astype(np.float32)
+        flip = rng.uniform(0, 1, n) < 0.1                      # 10 % label noise: accuracy tops out near 0.9,
+        y = np.where(flip, rng.integers(0, 10, n), y)          # so fit()'s 99 % early stop stays out of the way
+        return x, y.astype(np.float32)
     return make(n_train), make(n_val)
 
 
