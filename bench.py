@@ -281,6 +281,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="mlp_784-128-10_b64", choices=sorted(WORKLOADS))
     ap.add_argument("--dataset-size", type=int, default=60000)
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's per-GPU batch (SURVEY 8d batch sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel timing after the timed region")
     args = ap.parse_args()
@@ -291,6 +292,9 @@ def main():
     T.Device.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 
     key, batch, sample_shape, lr = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+        args.workload = args.workload.rsplit("_b", 1)[0] + f"_b{batch}"
     model = build_model(T, key)
     opt = T.Adam(model.parameters(), lr, None, None, 1e-4)          # examples/train_mnist.rs:50-51
     comm, comm_kind = make_comm(dist, T)

@@ -190,15 +190,34 @@ __global__ __launch_bounds__(64 * NW) void sgemm_small16(SmallArgs p) {
     small16_body<A_KC, B_KC, NW, false>(p, blockIdx.y, blockIdx.x, blockIdx.z, red);
 }
 
-// second pass of grid-level split-K: fixed slice order -> deterministic
+// second pass of grid-level split-K: fixed slice order -> deterministic.  With ep.adam set, C is a
+// complete gradient and the parameter's Adam update (optim.rs:99-110) runs on the same element.
 __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ partial, float *__restrict__ C,
                                                      long mn, int n, int kz, Epilogue ep) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= mn) return;
+    const bool fuse = ep.adam.p != nullptr;
+    float pv = 0.f, mv = 0.f, vv = 0.f, step = 0.f;
+    if (fuse) {
+        pv = ep.adam.p[i];
+        mv = ep.adam.m[i];
+        vv = ep.adam.v[i];
+        step = adam_dev_step(ep.adam);
+    }
+    const float c_old = ep.beta != 0.0f ? C[i] : 0.0f;
     float s = 0.f;
     for (int z = 0; z < kz; ++z) s += partial[(long)z * mn + i];
-    const float c_old = ep.beta != 0.0f ? C[i] : 0.0f;
-    C[i] = epilogue_apply(s, c_old, ep, (int)(i % n));
+    const float out = epilogue_apply(s, c_old, ep, (int)(i % n));
+    C[i] = out;
+    if (fuse) {
+        const AdamDev &ad = ep.adam;
+        const float gv = out + ad.wd * pv;
+        const float mn_ = ad.beta1 * mv + (1.0f - ad.beta1) * gv;
+        const float vn = ad.beta2 * vv + (1.0f - ad.beta2) * gv * gv;
+        ad.m[i] = mn_;
+        ad.v[i] = vn;
+        ad.p[i] = pv - step * mn_ / (sqrtf(vn) + ad.eps);
+    }
 }
 
 // Whole backward of one (small) Linear layer in ONE launch (the reference runs
@@ -294,14 +313,14 @@ constexpr int TILE_MAX = TILE_KC > TILE_MC ? TILE_KC : TILE_MC;
 //   thread t handles k rows (t / 32) + 8*j, mn quad (t % 32).
 template <bool KC, bool GUARD>
 __device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_mn, long rs_k, int mn0, int k0,
-                                          int mn_lim, int k_lim, int t, float4 (&reg)[4]) {
+                                          int mn_lim, int k_lim, int t, float4 (&reg)[4], bool vec = false) {
     // element (mn, k) lives at P[mn * rs_mn + k * rs_k]; exactly one stride is 1
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (KC) {
             const int mn = mn0 + (t >> 3) + 32 * j, kq = k0 + (t & 7) * 4;
             const float *p = P + (long)mn * rs_mn + kq;
-            if (!GUARD) {
+            if (!GUARD || (vec && mn < mn_lim && kq + 3 < k_lim)) {   // interior of a ragged problem: still one dwordx4
                 reg[j] = *reinterpret_cast<const float4 *>(p);
             } else {
                 float v[4];
@@ -312,7 +331,7 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_m
         } else {
             const int kr = k0 + (t >> 5) + 8 * j, mq = mn0 + (t & 31) * 4;
             const float *p = P + (long)kr * rs_k + mq;
-            if (!GUARD) {
+            if (!GUARD || (vec && kr < k_lim && mq + 3 < mn_lim)) {
                 reg[j] = *reinterpret_cast<const float4 *>(p);
             } else {
                 float v[4];
@@ -347,7 +366,10 @@ template <bool A_KC, bool B_KC, bool GUARD>
 __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict__ A, const float *__restrict__ B,
                                                         float *__restrict__ C, int m, int n, int k,
                                                         long a_rs, long a_cs, long b_rs, long b_cs,
-                                                        int tiles_m, int tiles_n, Epilogue ep) {
+                                                        int tiles_m, int tiles_n, Epilogue ep, int kslice,
+                                                        float *__restrict__ partial, int vec) {
+    // blockIdx.y = K slice [y*kslice, (y+1)*kslice): with `partial` set every slice writes its raw
+    // accumulators to partial[y][m*n] and splitk_reduce applies the epilogue in fixed slice order
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS: As[2] then Bs[2], TILE_MAX floats each
 
@@ -375,10 +397,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[4], rb[4];
-    const int nt = (k + BK - 1) / BK;
+    const int kbeg = blockIdx.y * kslice, kend = min(k, kbeg + kslice);
+    const int nt = (kend - kbeg + BK - 1) / BK;
     // element (i,k) of op(A) at A[i*a_rs + k*a_cs]; (k,j) of op(B) at B[k*b_rs + j*b_cs]
-    load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, 0, m, k, t, ra);
-    load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, 0, n, k, t, rb);
+    load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, kbeg, m, kend, t, ra, vec);
+    load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, kbeg, n, kend, t, rb, vec);
     store_tile<A_KC>(smem, t, ra);
     store_tile<B_KC>(smem + 2 * TILE_MAX, t, rb);
     __syncthreads();
@@ -386,8 +409,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
     for (int it = 0; it < nt; ++it) {
         const int cur = it & 1;
         if (it + 1 < nt) {
-            load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, (it + 1) * BK, m, k, t, ra);
-            load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, (it + 1) * BK, n, k, t, rb);
+            load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, kbeg + (it + 1) * BK, m, kend, t, ra, vec);
+            load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, kbeg + (it + 1) * BK, n, kend, t, rb, vec);
         }
         const float *as = smem + cur * TILE_MAX, *bs = smem + (2 + cur) * TILE_MAX;
 #pragma unroll
@@ -419,6 +442,10 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
                 const int row = row0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 if (!GUARD || (row < m && col < n)) {
                     const long idx = (long)row * n + col;
+                    if (partial) {
+                        partial[(long)blockIdx.y * m * n + idx] = acc[i][j][e];
+                        continue;
+                    }
                     const float c_old = ep.beta != 0.0f ? C[idx] : 0.0f;
                     C[idx] = epilogue_apply(acc[i][j][e], c_old, ep, col);
                 }
@@ -472,14 +499,39 @@ static int launch_small(th_ctx *ctx, const float *A, const float *B, float *C, i
     return 0;
 }
 
+int adam_slice(th_ctx *ctx, const AdamDev &a, const float *d_g, int64_t n);  // optim.hip
+
+// K slices for the 128x128 kernel: only when the tile grid cannot fill the chip and K is deep
+// enough that every slice still runs >= 8 k-iterations of 32
+static inline int tile128_kz(int m, int n, int k) {
+    const long tiles = (long)ceil_div(m, BM) * ceil_div(n, BN);
+    if (tiles >= 384 || k < 512) return 1;
+    int kz = (int)((512 + tiles - 1) / tiles);   // 2 workgroups per CU (__launch_bounds__(256, 2))
+    const int kz_max = k / 256;
+    if (kz > kz_max) kz = kz_max;
+    return kz < 1 ? 1 : kz;
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C, int m, int n, int k, long a_rs,
                           long a_cs, long b_rs, long b_cs, const Epilogue &ep) {
     const int tiles_m = ceil_div(m, BM), tiles_n = ceil_div(n, BN);
     const size_t lds = 4 * TILE_MAX * sizeof(float);
     const long lda = A_KC ? a_rs : a_cs, ldb = B_KC ? b_cs : b_rs;
-    const bool exact = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && aligned16(A) && aligned16(B) &&
-                       (lda % 4 == 0) && (ldb % 4 == 0);
+    int kz = tile128_kz(m, n, k);
+    int kslice = ceil_div(ceil_div(k, kz), BK) * BK;
+    kz = ceil_div(k, kslice);
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    const bool exact = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && vec;
+    float *partial = nullptr;
+    if (kz > 1) {
+        void *ws = nullptr;
+        if (th_malloc(ctx, (size_t)kz * m * n * sizeof(float), &ws)) return 1;
+        partial = (float *)ws;
+    }
+    // a fused Adam update belongs to the pass that completes the gradient
+    Epilogue kep = ep;
+    kep.adam.p = nullptr;
     if (exact) {
         auto kern = sgemm_tile128<A_KC, B_KC, false>;
         static bool attr_set = false;
@@ -487,8 +539,8 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
             TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
-                           b_rs, b_cs, tiles_m, tiles_n, ep);
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
+                           b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, 1);
     } else {
         auto kern = sgemm_tile128<A_KC, B_KC, true>;
         static bool attr_set = false;
@@ -496,18 +548,26 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
             TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
-                           b_rs, b_cs, tiles_m, tiles_n, ep);
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
+                           b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, vec ? 1 : 0);
     }
     TH_LAUNCH_CHECK();
+    if (kz > 1) {
+        const long mn = (long)m * n;
+        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, ctx->stream, (const float *)partial, C, mn, n, kz, ep);
+        TH_LAUNCH_CHECK();
+        if (th_free(ctx, partial)) return 1;
+    } else if (ep.adam.p) {
+        return adam_slice(ctx, ep.adam, C, (int64_t)m * n);   // no reduce pass to ride on
+    }
     return 0;
 }
 
-int adam_slice(th_ctx *ctx, const AdamDev &a, const float *d_g, int64_t n);  // optim.hip
 
 static inline bool gemm_is_big(int m, int n, int k) {
     const long tiles128 = (long)ceil_div(m, BM) * ceil_div(n, BN);
-    return m >= BM && n >= BN && k >= BK && tiles128 >= 64;
+    if (m < BM || n < BN || k < BK) return false;
+    return tiles128 >= 64 || tiles128 * tile128_kz(m, n, k) >= 48;   // deep K: split-K slices fill the chip
 }
 
 // op(A)[i,k] = A[i*a_rs + k*a_cs], op(B)[k,j] = B[k*b_rs + j*b_cs]
@@ -523,7 +583,8 @@ int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, co
     // (twice the L1->L2 read requests).  An O(n^2) LDS-tiled transpose of an m/n-contiguous
     // operand costs ~35 us per 64 MB -- 3 % of the O(n^3) product -- so deep, large GEMMs are
     // run as NT on transposed copies taken from the stream-ordered pool.
-    if (big && k >= 1024 && (!a_kc || !b_kc)) {
+    // (only when both m and n are wide: for a narrow output the copies cost as much as the product)
+    if (big && k >= 1024 && m >= 1024 && n >= 1024 && (!a_kc || !b_kc)) {
         void *at = nullptr, *bt = nullptr;
         const float *A2 = A, *B2 = B;
         if (!a_kc) {  // A stored [k][m] -> [m][k]
@@ -657,6 +718,7 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
     }
     if (d_dw) {  // dW[out,in] (+)= dZ^T[out,B] . X[B,in]     (ops.rs:280-291 + tensor.rs:574-587)
         Epilogue ep = make_ep(1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f);
+        ep.adam = w_adam;   // the dX product above has already consumed W (same stream): update it with the gradient
         if (int rc = gemm_dispatch(ctx, 1, 0, out_features, in_features, batch, dz, d_x, d_dw, ep)) return rc;
     }
     if (d_db) {  // db[out] (+)= sum_b dZ[b,out]               (tensor.rs:686-691)
@@ -664,8 +726,7 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
                                            : th_colsum(ctx, dz, d_db, batch, out_features))
             return rc;
     }
-    // large shapes: the fused updates run as slice kernels behind the GEMMs
-    if (int rc = adam_slice(ctx, w_adam, d_dw, (int64_t)out_features * in_features)) return rc;
+    // large shapes: W's update rode in the dW product; the bias update runs as a slice kernel
     if (int rc = adam_slice(ctx, b_adam, d_db, out_features)) return rc;
     if (int rc = th_adam_slices(ctx, extra, n_extra)) return rc;
     return tmp ? th_free(ctx, tmp) : 0;

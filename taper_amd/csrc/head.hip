@@ -24,6 +24,8 @@
 
 namespace th {
 
+int adam_slice(th_ctx *ctx, const AdamDev &a, const float *d_g, int64_t n);  // optim.hip
+
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int HEAD_RC = 64;     // rows per chunk
@@ -41,6 +43,11 @@ struct HeadArgs {
     int64_t advance;
     int32_t *adam_tick;
     AdamDev w_adam, b_adam;
+    // multi-workgroup mode (batch > 256): workgroup g owns rows [g*rows_per_wg, (g+1)*rows_per_wg) and
+    // writes its dW / db / {nll sum, hits} to slot g of the partial buffers; head_finish_kernel adds the
+    // slots in order.  rows_per_wg == 0: one workgroup, final results written directly.
+    int rows_per_wg;
+    float *part_scalar;
 };
 
 __device__ __forceinline__ long head_target_class(float tf) {  // Rust `as usize`: saturating, NaN -> 0
@@ -69,6 +76,13 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
     float *dl = dbp + 16 * HEAD_CMAX;        // [64][16]   dlogits (separate from lg: no barrier between read and write)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, g4 = lane >> 4;
+    const bool multi = a.rows_per_wg > 0;
+    const int row_beg = multi ? blockIdx.x * a.rows_per_wg : 0;
+    const int row_end = multi ? min(a.batch, row_beg + a.rows_per_wg) : a.batch;
+    if (multi) {   // this workgroup's slots
+        if (a.dw) a.dw += (long)blockIdx.x * a.c * a.k;
+        if (a.db) a.db += (long)blockIdx.x * a.c;
+    }
 
     // the tick comes first: every fused update of this step (here and in the
     // following backward launches) must see t+1 (optim.rs:84)
@@ -76,12 +90,12 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
     // so that no thread waits for a second global round trip before its Adam epilogue)
     // Plain accesses: nothing else touches the counter while this launch runs, and an sc1 store would
     // drop the line from L2, turning the next launch's first load into a fabric round trip.
-    const int32_t tick_old = a.adam_tick ? a.adam_tick[0] : 0;
+    const int32_t tick_old = (a.adam_tick && !multi) ? a.adam_tick[0] : 0;
 
     // ---- everything this launch needs from global memory is requested up front: after a kernel
     //      boundary each dependent round trip costs ~1 us, so none may hide behind a barrier ----
     const float bias_v = (a.bias && r16 < C) ? a.bias[r16] : 0.f;               // logits epilogue
-    const int64_t log_slot = (t == 0 && a.metrics) ? a.state[0] % a.capacity : 0;  // step log
+    const int64_t log_slot = (t == 0 && a.metrics && !multi) ? a.state[0] % a.capacity : 0;  // step log
     const bool own_dw = a.dw && wave < (KP / 16);
     const bool fuse_w = own_dw && a.w_adam.p, fuse_b = a.db && t < C && a.b_adam.p;
     float wp_[4], wm_[4], wv_[4], w_step = 0.f, bp_ = 0.f, bm_ = 0.f, bv_ = 0.f, b_step = 0.f;
@@ -121,14 +135,14 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
     if (pow2) {
         const int lg2 = __ffs(kq) - 1, rstep = HEAD_T >> lg2;     // rows advanced per 1024 threads
         const int kk = (t & (kq - 1)) * 4, rr0 = t >> lg2;
-        const int rows0 = min(HEAD_RC, a.batch);
+        const int rows0 = min(HEAD_RC, row_end - row_beg);
         float4 wv = make_float4(0.f, 0.f, 0.f, 0.f), hv[4];
         if (rr0 < C && rr0 < HEAD_CMAX && kk < K) wv = *reinterpret_cast<const float4 *>(a.w + rr0 * K + kk);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int rr = rr0 + j * rstep;
             hv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < rows0 && kk < K) hv[j] = *reinterpret_cast<const float4 *>(a.h + (long)rr * K + kk);
+            if (rr < rows0 && kk < K) hv[j] = *reinterpret_cast<const float4 *>(a.h + (long)(row_beg + rr) * K + kk);
         }
         if (rr0 < HEAD_CMAX) *reinterpret_cast<float4 *>(Ws + rr0 * LD + kk) = wv;
 #pragma unroll
@@ -162,11 +176,11 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
     const int row_l = t >> 4, sub = t & 15;
     const float inv_b = 1.0f / (float)a.batch;
 
-    for (int r0 = 0; r0 < a.batch; r0 += HEAD_RC) {
-        const int rows = min(HEAD_RC, a.batch - r0);
-        if (r0 > 0) __syncthreads();  // previous chunk's readers are done with Hs / lg
+    for (int r0 = row_beg; r0 < row_end; r0 += HEAD_RC) {
+        const int rows = min(HEAD_RC, row_end - r0);
+        if (r0 > row_beg) __syncthreads();  // previous chunk's readers are done with Hs / lg
         const float tf = (row_l < rows) ? a.targets[r0 + row_l] : 0.f;   // requested with the H loads
-        if (r0 == 0 && h0_staged) {
+        if (r0 == row_beg && h0_staged) {
             // chunk 0 is already in LDS
         } else if (vec4) {
             for (int i = t; i < HEAD_RC * (KP / 4); i += HEAD_T) {
@@ -332,11 +346,15 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
             n += red[w];
             hsum += red[16 + w];
         }
+        if (multi) {   // raw sums of this workgroup's rows; head_finish_kernel divides, logs and ticks
+            a.part_scalar[2 * blockIdx.x] = n;
+            a.part_scalar[2 * blockIdx.x + 1] = hsum;
+        }
         const float l = n / (float)a.batch;  // loss.rs:164
-        a.loss[0] = l;
-        if (a.ncorrect) a.ncorrect[0] = hsum;
-        if (a.adam_tick) a.adam_tick[0] = tick_old + 1;  // optim.rs:84
-        if (a.metrics) {  // the step log of th_log_step
+        if (!multi) a.loss[0] = l;
+        if (!multi && a.ncorrect) a.ncorrect[0] = hsum;
+        if (!multi && a.adam_tick) a.adam_tick[0] = tick_old + 1;  // optim.rs:84
+        if (!multi && a.metrics) {  // the step log of th_log_step
             a.metrics[2 * log_slot] = l;
             a.metrics[2 * log_slot + 1] = hsum;
             a.state[0] += 1;
@@ -380,6 +398,58 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
     HEAD_STAMP(8);
 }
 
+// Last pass of the multi-workgroup head (dW was summed over the slots by th_colsum): db = sum of
+// the workgroups' slots in slot order, then loss / n_correct, the step log and Adam's tick.
+__global__ __launch_bounds__(256) void head_finish_kernel(HeadArgs a, const float *__restrict__ part_db, int n_wg) {
+    __shared__ float sh[2][4];
+    __shared__ float dbs[16][HEAD_CMAX];
+    const int t = threadIdx.x;
+    if (a.db) {   // thread (part, cls) adds slots part, part+16, ...; thread cls then adds the 16 parts in order
+        const int cls = t & 15, part = t >> 4;
+        float s = 0.f;
+        if (cls < a.c)
+            for (int g = part; g < n_wg; g += 16) s += part_db[(long)g * a.c + cls];
+        dbs[part][cls] = s;
+        __syncthreads();
+        if (t < a.c) {
+            float tot = 0.f;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) tot += dbs[p][t];
+            a.db[t] = tot;
+        }
+    }
+    float n = 0.f, hsum = 0.f;
+    for (int g = t; g < n_wg; g += 256) {
+        n += a.part_scalar[2 * g];
+        hsum += a.part_scalar[2 * g + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_down(n, off, 64);
+        hsum += __shfl_down(hsum, off, 64);
+    }
+    if ((t & 63) == 0) {
+        sh[0][t >> 6] = n;
+        sh[1][t >> 6] = hsum;
+    }
+    __syncthreads();
+    if (t == 0) {
+        n = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+        hsum = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+        const float l = n / (float)a.batch;  // loss.rs:164
+        a.loss[0] = l;
+        if (a.ncorrect) a.ncorrect[0] = hsum;
+        if (a.adam_tick) a.adam_tick[0] += 1;  // optim.rs:84
+        if (a.metrics) {
+            const int64_t slot = a.state[0] % a.capacity;
+            a.metrics[2 * slot] = l;
+            a.metrics[2 * slot + 1] = hsum;
+            a.state[0] += 1;
+            a.state[1] += a.advance;
+        }
+    }
+}
+
 #ifdef TH_PROFILE
 __global__ void head_prof_end_kernel() { g_head_prof[15] = wall_clock64(); }
 #endif
@@ -399,14 +469,14 @@ extern "C" int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d
                                    int64_t *d_state, int64_t advance, int32_t *d_adam_tick, const th_adam_fuse *w_fuse,
                                    const th_adam_fuse *b_fuse) {
     TH_REQUIRE(ctx && d_h && d_w && d_targets && d_loss, "th_linear_xent_head: null argument");
-    TH_REQUIRE(batch > 0 && batch <= 4096 && classes > 0 && classes <= HEAD_CMAX && in_features > 0 && in_features <= HEAD_KMAX,
-               "th_linear_xent_head: needs batch <= 4096, classes <= 16, in_features <= 256 (got %d, %d, %d)", batch, classes,
+    TH_REQUIRE(batch > 0 && batch <= (1 << 22) && classes > 0 && classes <= HEAD_CMAX && in_features > 0 && in_features <= HEAD_KMAX,
+               "th_linear_xent_head: needs batch <= 4194304, classes <= 16, in_features <= 256 (got %d, %d, %d)", batch, classes,
                in_features);
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_linear_xent_head: metrics need d_state and a capacity");
     TH_REQUIRE(!(w_fuse && w_fuse->d_p) || d_dw, "th_linear_xent_head: fused W update needs d_dw");
     TH_REQUIRE(!(b_fuse && b_fuse->d_p) || d_db, "th_linear_xent_head: fused b update needs d_db");
     HeadArgs a{d_h, d_w, d_bias, d_targets, batch, in_features, classes, d_logits, d_loss, d_ncorrect, d_dh, d_dw, d_db,
-               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, make_adam_dev(w_fuse), make_adam_dev(b_fuse)};
+               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, make_adam_dev(w_fuse), make_adam_dev(b_fuse), 0, nullptr};
     const size_t lds = head_lds_bytes(in_features);
     static bool attr_set = false;
     if (!attr_set) {
@@ -414,9 +484,35 @@ extern "C" int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d
                                    (int)head_lds_bytes(HEAD_KMAX)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(linear_xent_head_kernel, dim3(1), dim3(HEAD_T), lds, ctx->stream, a);
+    if (batch <= 256) {   // latency-bound: one workgroup, one launch
+        hipLaunchKernelGGL(linear_xent_head_kernel, dim3(1), dim3(HEAD_T), lds, ctx->stream, a);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
+    // throughput-bound: up to 256 workgroups of 64-row chunks + a finish pass
+    int rows_per_wg = ceil_div(ceil_div(batch, 256), HEAD_RC) * HEAD_RC;
+    const int n_wg = ceil_div(batch, rows_per_wg);
+    const size_t n_dw = d_dw ? (size_t)classes * in_features : 0, n_db = d_db ? (size_t)classes : 0;
+    void *ws = nullptr;
+    if (th_malloc(ctx, (size_t)n_wg * (n_dw + n_db + 2) * sizeof(float), &ws)) return 1;
+    float *part_dw = (float *)ws, *part_db = part_dw + (size_t)n_wg * n_dw, *part_sc = part_db + (size_t)n_wg * n_db;
+    HeadArgs rows = a;
+    rows.rows_per_wg = rows_per_wg;
+    rows.dw = d_dw ? part_dw : nullptr;
+    rows.db = d_db ? part_db : nullptr;
+    rows.part_scalar = part_sc;
+    rows.w_adam.p = nullptr;      // fused updates need the complete gradient: they run behind the finish pass
+    rows.b_adam.p = nullptr;
+    hipLaunchKernelGGL(linear_xent_head_kernel, dim3(n_wg), dim3(HEAD_T), lds, ctx->stream, rows);
     TH_LAUNCH_CHECK();
-    return 0;
+    a.part_scalar = part_sc;
+    if (d_dw)   // dW[c][k] = sum over the workgroups' slots: a column sum of the [n_wg, c*k] slot matrix
+        if (int rc = th_colsum(ctx, part_dw, d_dw, n_wg, (int)n_dw)) return rc;
+    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, a, (const float *)part_db, n_wg);
+    TH_LAUNCH_CHECK();
+    if (th_free(ctx, ws)) return 1;
+    if (int rc = adam_slice(ctx, a.w_adam, d_dw, (int64_t)n_dw)) return rc;
+    return adam_slice(ctx, a.b_adam, d_db, (int64_t)n_db);
 }
 
 #ifdef TH_PROFILE

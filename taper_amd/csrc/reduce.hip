@@ -70,23 +70,58 @@ __global__ __launch_bounds__(256) void bias_add_rows_kernel(const float *__restr
 // ---- column sums of a [rows, cols] matrix --------------------------------
 // grid.x covers columns in chunks of 64; each block has 4 waves striding the
 // rows; lanes are consecutive columns (coalesced); fixed-order LDS combine.
+// Tall inputs are cut into row slabs (blockIdx.y) whose sums land in out[slab][cols]; a second
+// launch of the same kernel adds the slabs in order (deterministic, no atomics).
 template <bool ACCUM, bool NEGATE>
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g, float *__restrict__ out, int rows,
-                                                     int cols) {
+                                                     int cols, int rows_per_slab) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < cols)
-        for (int r = wave; r < rows; r += 4) s += g[(long)r * cols + c];
-    part[wave][lane] = s;
+    const int r_beg = blockIdx.y * rows_per_slab, r_end = min(rows, r_beg + rows_per_slab);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < cols) {
+        int r = r_beg + wave;
+        for (; r + 4 < r_end; r += 8) {   // two independent chains keep more loads in flight
+            s0 += g[(long)r * cols + c];
+            s1 += g[(long)(r + 4) * cols + c];
+        }
+        if (r < r_end) s0 += g[(long)r * cols + c];
+    }
+    part[wave][lane] = s0 + s1;
     __syncthreads();
     if (wave == 0 && c < cols) {
         float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
         if (NEGATE) tot = -tot;
-        if (ACCUM) out[c] += tot;
-        else out[c] = tot;
+        float *o = out + (long)blockIdx.y * cols + c;
+        if (ACCUM) *o += tot;
+        else *o = tot;
     }
+}
+
+template <bool ACCUM, bool NEGATE>
+static int colsum_launch(th_ctx *ctx, const float *g, float *out, int rows, int cols) {
+    const int gx = ceil_div(cols, 64);
+    int slabs = 1;
+    if (rows >= 256 && gx < 128) {   // too few column blocks to fill the chip: split the rows (>= 32 per slab)
+        slabs = ceil_div(rows, 32);
+        const int cap = ceil_div(512, gx);
+        if (slabs > cap) slabs = cap;
+    }
+    if (slabs <= 1) {
+        hipLaunchKernelGGL((colsum_kernel<ACCUM, NEGATE>), dim3(gx), dim3(256), 0, ctx->stream, g, out, rows, cols, rows);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
+    const int rps = ceil_div(rows, slabs);
+    slabs = ceil_div(rows, rps);
+    void *part = nullptr;
+    if (th_malloc(ctx, (size_t)slabs * cols * sizeof(float), &part)) return 1;
+    hipLaunchKernelGGL((colsum_kernel<false, false>), dim3(gx, slabs), dim3(256), 0, ctx->stream, g, (float *)part, rows, cols, rps);
+    TH_LAUNCH_CHECK();
+    hipLaunchKernelGGL((colsum_kernel<ACCUM, NEGATE>), dim3(gx), dim3(256), 0, ctx->stream, (const float *)part, out, slabs, cols, slabs);
+    TH_LAUNCH_CHECK();
+    return th_free(ctx, part);
 }
 
 // ---- row-wise ops on [rows, cols]: one wave per row ----------------------
@@ -407,17 +442,13 @@ int th_bias_add_rows(th_ctx *ctx, const float *d_x, const float *d_bias, float *
 int th_colsum_accum(th_ctx *ctx, const float *d_g, float *d_gb, int rows, int cols) {
     TH_REQUIRE(ctx && d_g && d_gb && rows >= 0 && cols >= 0, "th_colsum_accum: bad argument");
     if (cols == 0) return 0;
-    hipLaunchKernelGGL((colsum_kernel<true, false>), dim3(ceil_div(cols, 64)), dim3(256), 0, ctx->stream, d_g, d_gb, rows, cols);
-    TH_LAUNCH_CHECK();
-    return 0;
+    return colsum_launch<true, false>(ctx, d_g, d_gb, rows, cols);
 }
 
 int th_colsum(th_ctx *ctx, const float *d_x, float *d_y, int rows, int cols) {
     TH_REQUIRE(ctx && d_x && d_y && rows >= 0 && cols >= 0, "th_colsum: bad argument");
     if (cols == 0) return 0;
-    hipLaunchKernelGGL((colsum_kernel<false, false>), dim3(ceil_div(cols, 64)), dim3(256), 0, ctx->stream, d_x, d_y, rows, cols);
-    TH_LAUNCH_CHECK();
-    return 0;
+    return colsum_launch<false, false>(ctx, d_x, d_y, rows, cols);
 }
 
 int th_sub_rows(th_ctx *ctx, const float *d_x, const float *d_r, float *d_y, int rows, int cols) {

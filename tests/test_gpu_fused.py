@@ -53,7 +53,8 @@ def oracle_head(O, h, w, b, y):
     return out
 
 
-@pytest.mark.parametrize("batch,k,c", [(64, 128, 10), (128, 128, 10), (32, 128, 10), (1, 3, 2), (200, 64, 10), (256, 256, 16), (70, 37, 5), (1024, 64, 10)])
+@pytest.mark.parametrize("batch,k,c", [(64, 128, 10), (128, 128, 10), (32, 128, 10), (1, 3, 2), (200, 64, 10), (256, 256, 16), (70, 37, 5), (1024, 64, 10),
+                                       (257, 128, 10), (4096, 128, 10), (16500, 128, 10), (33000, 48, 7)])   # > 256: multi-workgroup + finish pass
 def test_linear_xent_head(ctx, O, batch, k, c):
     rng = np.random.default_rng(batch * 7 + k + c)
     h = np.maximum(rng.standard_normal((batch, k)), 0).astype(np.float32)        # post-ReLU activations
@@ -102,7 +103,8 @@ def _adam_ref(O, p0, g, lr, t, wd=1e-4):
     return pt.data(), opt.m(0), opt.v(0)
 
 
-@pytest.mark.parametrize("batch,inf,outf,with_dx", [(64, 784, 128, False), (64, 128, 64, True), (16, 40, 24, False)])
+@pytest.mark.parametrize("batch,inf,outf,with_dx", [(64, 784, 128, False), (64, 128, 64, True), (16, 40, 24, False),
+                                                    (4096, 784, 128, False), (3000, 256, 130, True)])   # large: Adam rides in the split-K reduce
 def test_linear_bwd_adam_epilogue(ctx, O, batch, inf, outf, with_dx):
     """dW/db from the fused kernel + Adam applied in the epilogue == oracle grads followed by oracle Adam"""
     rng = np.random.default_rng(batch + inf + outf)
@@ -131,7 +133,7 @@ def test_linear_bwd_adam_epilogue(ctx, O, batch, inf, outf, with_dx):
         close(ctx.download(dx_, x.shape), gx, atol=1e-6)      # dX used the PRE-update W (no race with the fused update)
     np.testing.assert_allclose(ctx.download(pw, w.shape), w_ref, rtol=RTOL, atol=lr * 2e-2)
     np.testing.assert_allclose(ctx.download(pb, b.shape), b_ref, rtol=RTOL, atol=lr * 2e-2)
-    np.testing.assert_allclose(ctx.download(mw, w.shape), wm_ref.reshape(w.shape), rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(ctx.download(mw, w.shape), wm_ref.reshape(w.shape), rtol=1e-3, atol=1e-8 + 1e-4 * float(np.abs(wm_ref).max()))
     assert ctx.download(tick, 2, np.int32)[0] == t            # fused epilogues never tick
 
 
