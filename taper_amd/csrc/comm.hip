@@ -67,6 +67,12 @@ int th_comm_destroy(th_comm *comm) {
 int th_allreduce_sum_scale(th_comm *comm, th_ctx *ctx, float *d_buf, size_t n, float scale) {
     TH_REQUIRE(comm && ctx && (n == 0 || d_buf), "th_allreduce_sum_scale: null argument");
     if (n == 0) return 0;
+    // the data-parallel mean (scale == 1/n_ranks) is RCCL's own ncclAvg: no scale launch behind the collective
+    const float mean = 1.0f / (float)comm->n_ranks;
+    if (scale == mean) {
+        TH_NCCL(ncclAllReduce(d_buf, d_buf, n, ncclFloat, ncclAvg, comm->comm, ctx->stream));
+        return 0;
+    }
     TH_NCCL(ncclAllReduce(d_buf, d_buf, n, ncclFloat, ncclSum, comm->comm, ctx->stream));
     return th::scale_inplace(ctx, d_buf, n, scale);
 }

@@ -400,8 +400,18 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
     const int kbeg = blockIdx.y * kslice, kend = min(k, kbeg + kslice);
     const int nt = (kend - kbeg + BK - 1) / BK;
     // element (i,k) of op(A) at A[i*a_rs + k*a_cs]; (k,j) of op(B) at B[k*b_rs + j*b_cs]
-    load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, kbeg, m, kend, t, ra, vec);
-    load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, kbeg, n, kend, t, rb, vec);
+    // ragged problems: a workgroup whose A rows (B columns) are all in range loads every full
+    // k-iteration through the unguarded dwordx4 path; only edge tiles and the K tail pay for bounds checks
+    const bool a_int = !GUARD || (vec && row0 + BM <= m), b_int = !GUARD || (vec && col0 + BN <= n);
+#define TH_LOAD_AB(K0)                                                                              \
+    {                                                                                               \
+        const bool kfull = (K0) + BK <= kend;                                                       \
+        if (a_int && kfull) load_tile<A_KC, false>(A, a_rs, a_cs, row0, (K0), m, kend, t, ra);      \
+        else load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, (K0), m, kend, t, ra, vec);                \
+        if (b_int && kfull) load_tile<B_KC, false>(B, b_cs, b_rs, col0, (K0), n, kend, t, rb);      \
+        else load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, (K0), n, kend, t, rb, vec);                \
+    }
+    TH_LOAD_AB(kbeg)
     store_tile<A_KC>(smem, t, ra);
     store_tile<B_KC>(smem + 2 * TILE_MAX, t, rb);
     __syncthreads();
@@ -409,8 +419,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
     for (int it = 0; it < nt; ++it) {
         const int cur = it & 1;
         if (it + 1 < nt) {
-            load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, kbeg + (it + 1) * BK, m, kend, t, ra, vec);
-            load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, kbeg + (it + 1) * BK, n, kend, t, rb, vec);
+            TH_LOAD_AB(kbeg + (it + 1) * BK)
         }
         const float *as = smem + cur * TILE_MAX, *bs = smem + (2 + cur) * TILE_MAX;
 #pragma unroll
@@ -431,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
         __syncthreads();
     }
 
+#undef TH_LOAD_AB
     // epilogue.  C/D map of 32x32x2: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -714,7 +714,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     if (!graphs_.empty() && (graph_batch_ != bs || graph_key_ != key)) drop_graphs();
 
     size_t done = 0;
-    if (graphs_.empty() && n_full > 0) {
+    if (graphs_.empty() && n_full > 0 && !graph_capture_failed_) {
         // step 0 runs eagerly (pool warm-up, has_grad mask upload); then the SAME host code
         // is run under stream capture to record the op list of 1 step and of a chunk of
         // steps (one hipGraphLaunch per chunk amortises the ~10 us host cost of a replay)
@@ -727,12 +727,17 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             th_graph *g = nullptr;
             try {
                 enqueue_steps(d_img, d_lab, d_idx, (int64_t)n, bs, steps);
-            } catch (...) {
-                th_graph_end(ctx, &g);
-                th_graph_destroy(g);
-                throw;
+                TH(th_graph_end(ctx, &g));
+            } catch (const std::exception &e) {
+                if (!g) th_graph_end(ctx, &g);
+                if (g) th_graph_destroy(g);
+                if (!comm) throw;
+                // a collective that cannot be captured must not take the run down: the same op list
+                // is enqueued eagerly from here on (identical results, one host launch per kernel)
+                fprintf(stderr, "taper: step capture with the communicator failed (%s); running data-parallel steps eagerly\n", e.what());
+                graph_capture_failed_ = true;
+                break;
             }
-            TH(th_graph_end(ctx, &g));
             graphs_.emplace_back(steps, g);
         }
         graph_batch_ = bs;

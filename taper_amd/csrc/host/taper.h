@@ -584,6 +584,7 @@ class Trainer {  // train.rs:74-172
     void drop_graphs();
     std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
     size_t graph_batch_ = 0;
+    bool graph_capture_failed_ = false;
     const void *graph_key_ = nullptr;
     std::shared_ptr<Buffer> xb_, yb_, state_, metrics_, step_loss_, step_ncorrect_;
     size_t metrics_cap_ = 0;

@@ -249,3 +249,26 @@ def test_cnn_epoch_graph_matches_oracle():
         np.testing.assert_allclose(hp.data(), op.data(), rtol=RTOL, atol=1e-2 * 5e-2, err_msg=f"param {i}")
     # quirk Q2 survives the fused path: conv weights untouched by the optimizer
     np.testing.assert_array_equal(hm.parameters()[0].data(), spec[0]["w"])
+
+
+def test_data_parallel_step_with_single_rank_communicator_matches_plain_step():
+    """the data-parallel op list (backward -> RCCL mean all-reduce of the flat grad arena -> unfused Adam),
+    captured into the step graph with a 1-rank communicator, gives the single-GPU results"""
+    import taper_amd as T
+    H = backends.get("hip")
+    rng = np.random.default_rng(13)
+    spec = backends.nonzero_biases(backends.mlp_baseline(rng), rng)
+    x, y = backends.mnist_like(rng, 64 * 40 + 17)
+    out = []
+    for with_comm in (False, True):
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        comm = T.Communicator(1, 0, T.Communicator.unique_id()) if with_comm else None
+        tr = T.Trainer(model, opt, comm=comm, fuse_adam=False)
+        ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), 64, False), T.Trainer.GRAPH)
+        out.append((ep["losses"], [p.data() for p in model.parameters()], opt.t()))
+        del tr, comm
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(a, b)
+    assert out[0][2] == out[1][2] == 41

@@ -606,4 +606,7 @@ def test_rccl_single_rank_allreduce(ctx):
     d = ctx.upload(x)
     th_check(lib.th_allreduce_sum_scale(comm, ctx.h, int(d), x.size, 0.5), "th_allreduce_sum_scale")
     np.testing.assert_array_equal(ctx.download(d, x.size), x * np.float32(0.5))
+    # scale == 1/n_ranks: the mean runs as ncclAvg inside the collective (no scale launch)
+    th_check(lib.th_allreduce_sum_scale(comm, ctx.h, int(d), x.size, 1.0), "th_allreduce_sum_scale")
+    np.testing.assert_array_equal(ctx.download(d, x.size), x * np.float32(0.5))
     lib.th_comm_destroy(comm)
