@@ -320,8 +320,14 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_m
         if (KC) {
             const int mn = mn0 + (t >> 3) + 32 * j, kq = k0 + (t & 7) * 4;
             const float *p = P + (long)mn * rs_mn + kq;
-            if (!GUARD || (vec && mn < mn_lim && kq + 3 < k_lim)) {   // interior of a ragged problem: still one dwordx4
+            if (!GUARD) {
                 reg[j] = *reinterpret_cast<const float4 *>(p);
+            } else if (vec) {
+                // ragged problem, rows 16-B aligned and k_lim % 4 == 0: a quad is entirely inside or outside.
+                // Branch-free: load from the clamped (always valid) address, then zero what lies outside.
+                const bool in = mn < mn_lim && kq < k_lim;
+                const float4 v = *reinterpret_cast<const float4 *>(P + (long)min(mn, mn_lim - 1) * rs_mn + min(kq, k_lim - 4));
+                reg[j] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 float v[4];
 #pragma unroll
@@ -331,8 +337,12 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_m
         } else {
             const int kr = k0 + (t >> 5) + 8 * j, mq = mn0 + (t & 31) * 4;
             const float *p = P + (long)kr * rs_k + mq;
-            if (!GUARD || (vec && kr < k_lim && mq + 3 < mn_lim)) {
+            if (!GUARD) {
                 reg[j] = *reinterpret_cast<const float4 *>(p);
+            } else if (vec) {   // mn_lim % 4 == 0
+                const bool in = kr < k_lim && mq < mn_lim;
+                const float4 v = *reinterpret_cast<const float4 *>(P + (long)min(kr, k_lim - 1) * rs_k + min(mq, mn_lim - 4));
+                reg[j] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 float v[4];
 #pragma unroll
@@ -400,18 +410,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
     const int kbeg = blockIdx.y * kslice, kend = min(k, kbeg + kslice);
     const int nt = (kend - kbeg + BK - 1) / BK;
     // element (i,k) of op(A) at A[i*a_rs + k*a_cs]; (k,j) of op(B) at B[k*b_rs + j*b_cs]
-    // ragged problems: a workgroup whose A rows (B columns) are all in range loads every full
-    // k-iteration through the unguarded dwordx4 path; only edge tiles and the K tail pay for bounds checks
-    const bool a_int = !GUARD || (vec && row0 + BM <= m), b_int = !GUARD || (vec && col0 + BN <= n);
-#define TH_LOAD_AB(K0)                                                                              \
-    {                                                                                               \
-        const bool kfull = (K0) + BK <= kend;                                                       \
-        if (a_int && kfull) load_tile<A_KC, false>(A, a_rs, a_cs, row0, (K0), m, kend, t, ra);      \
-        else load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, (K0), m, kend, t, ra, vec);                \
-        if (b_int && kfull) load_tile<B_KC, false>(B, b_cs, b_rs, col0, (K0), n, kend, t, rb);      \
-        else load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, (K0), n, kend, t, rb, vec);                \
-    }
-    TH_LOAD_AB(kbeg)
+    load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, kbeg, m, kend, t, ra, vec);
+    load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, kbeg, n, kend, t, rb, vec);
     store_tile<A_KC>(smem, t, ra);
     store_tile<B_KC>(smem + 2 * TILE_MAX, t, rb);
     __syncthreads();
@@ -419,7 +419,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
     for (int it = 0; it < nt; ++it) {
         const int cur = it & 1;
         if (it + 1 < nt) {
-            TH_LOAD_AB(kbeg + (it + 1) * BK)
+            load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, kbeg + (it + 1) * BK, m, kend, t, ra, vec);
+            load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, kbeg + (it + 1) * BK, n, kend, t, rb, vec);
         }
         const float *as = smem + cur * TILE_MAX, *bs = smem + (2 + cur) * TILE_MAX;
 #pragma unroll
@@ -440,7 +441,6 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
         __syncthreads();
     }
 
-#undef TH_LOAD_AB
     // epilogue.  C/D map of 32x32x2: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -531,7 +531,10 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
     int kz = tile128_kz(m, n, k);
     int kslice = ceil_div(ceil_div(k, kz), BK) * BK;
     kz = ceil_div(k, kslice);
-    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    // dwordx4 operand loads: 16-B aligned rows, and whole quads in or out of range along the vector axis
+    // (k for a k-contiguous operand, m / n for an m/n-contiguous one); slices start on multiples of 32
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((A_KC ? k : m) % 4 == 0) &&
+                     ((B_KC ? k : n) % 4 == 0) && m >= 4 && n >= 4 && k >= 4;
     const bool exact = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && vec;
     float *partial = nullptr;
     if (kz > 1) {

@@ -379,8 +379,7 @@ def test_xor_training_trajectory_matches_oracle():
 def test_xor_example_learns_xor():
     """the C++ counterpart of src/main.rs, all 50 000 iterations"""
     exe = ROOT / "examples" / "_build" / "xor"
-    if not exe.exists():
-        subprocess.check_call(["make", "-C", str(ROOT / "examples")])
+    subprocess.check_call(["make", "-s", "-C", str(ROOT / "examples")])   # no-op when current; never run a stale binary
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "iteration    0: Loss = " in out.stdout and "learned XOR" in out.stdout
