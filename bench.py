@@ -228,6 +228,30 @@ class StepKernels:
         return dict(step_us=round(full, 3), kernels=out)
 
 
+def batch_sweep(T, build_model, key, lr, dataset_size, batches=(256, 1024, 4096, 16384, 60000)):
+    """SURVEY.md 8(d) batch sweep of the same model / optimizer / step on one GPU (fresh model per point; the
+    headline `value` stays BASELINE configs[1], batch 64): where the path stops being launch-bound."""
+    out = []
+    for b in batches:
+        if b > dataset_size:
+            continue
+        model = build_model(T, key)
+        opt = T.Adam(model.parameters(), lr, None, None, 1e-4)
+        trainer = T.Trainer(model, opt)
+        loader = T.DataLoader(T.MNISTDataset.synthetic(dataset_size, seed=0x7461706572), b, False)
+        steps = max(40, min(400, 2_000_000 // b))
+        run_steps(T, trainer, loader, max(steps // 8, 3))
+        T.Device.sync()
+        t0 = time.perf_counter()
+        samples = run_steps(T, trainer, loader, steps)
+        T.Device.sync()
+        dt = time.perf_counter() - t0
+        out.append(dict(batch=b, steps=steps, ms_per_step=round(dt / steps * 1e3, 5), samples_per_s=round(samples / dt, 1),
+                        epochs_per_s=round(samples / dt / 60000.0, 2)))
+        del trainer, opt, model, loader
+    return out
+
+
 def pmc_traffic(workload, kernel):
     """bytes per launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE,
     collected separately: tools/profile_bench.sh); counters cannot be read from inside the process."""
@@ -284,6 +308,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the workload's per-GPU batch (SURVEY 8d batch sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel timing after the timed region")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch sweep (SURVEY 8d) reported beside the headline value")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -337,6 +362,9 @@ def main():
                         alg_bytes_per_launch=k["alg_bytes_per_launch"], mfma_tflops=k["mfma_tflops"],
                         dominant_by="algorithmic bytes; by time the leader is %s (%.1f us)" % (by_time["kernel"], by_time["us_per_launch"]),
                         step_us_three_launch_chain=sk["step_us"], kernels=sk["kernels"])
+        sweep = None
+        if key == "mlp_baseline" and world == 1 and not args.batch and not args.no_sweep:
+            sweep = batch_sweep(T, build_model, key, lr, args.dataset_size)
         cpu = None
         if not args.no_cpu_baseline:
             try:
@@ -355,7 +383,7 @@ def main():
                 "alg_flops_per_step": flops, "alg_bytes_per_step": nbytes,
                 "hbm_frac": round(nbytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                 "mfma_frac": round(flops / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TF, 6)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "batch_sweep": sweep, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
