@@ -1,0 +1,254 @@
+// conv_mfma.hip -- direct 3x3 convolution (stride 1, pad 0/1) on the fp32 matrix cores for layers
+// with C_in >= 8 (src/tensor.rs:1221-1285 conv2d, 1728-1780 im2col_3x3, 1972-2076 the layout
+// round trips -- none of which is materialised here).
+//
+// Why MFMA: with C_in >= 32 the layer is a dense contraction over K = 9*C_in = 288..576 at
+// 20-130 flop/B -- compute-bound, and v_mfma_f32_16x16x4_f32 is exact fp32 (a k-ordered fmaf
+// chain), so the parity bar is the same as for the VALU kernel (conv_pool.hip), which stays the
+// path for conv1 (C_in = 1: K = 9, HBM-bound).  It is still a DIRECT convolution: the im2col
+// matrix exists only as LDS addresses.
+//
+//   D[co][px] = sum_k Wc[k][co] * X[px, k],   k = (ci, kh, kw)
+//   A operand (16 x 4):  lane l -> Wc[4s + (l>>4)][co0 + (l&15)]          (weights, LDS [k][co])
+//   B operand (4 x 16):  lane l -> patch[(ci,kh,kw) of k = 4s + (l>>4)] at pixel px0 + (l&15)
+//   D tile (16 x 16):    lane l, i -> co = co0 + 4*(l>>4) + i, px = px0 + (l&15)
+//
+// A workgroup owns IMG images x R output rows x all W_out columns (<= 128 pixels = 8 pixel tiles,
+// two per wave) and CO_B <= 128 output channels; per pass CI_T = 8 input channels are staged:
+// the zero-haloed input patch [8][IMG][R+2][W_out+2] and the weight slab [72][CO_B].  The global
+// loads of pass p+1 are issued before the MFMAs of pass p and parked in registers (one round trip per
+// pass, hidden behind 18 k-steps), then written to the single LDS buffer between two barriers.
+#include "common.h"
+
+namespace th {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int MF_CI = 8;              // input channels per pass  -> 72 k = 18 MFMA k-steps
+constexpr int MF_KS = MF_CI * 9 / 4;  // 18
+constexpr int MF_PX_MAX = 128;        // pixels per workgroup (8 tiles of 16)
+constexpr int MF_CO_MAX = 64;         // output channels per workgroup (4 tiles of 16)
+
+constexpr int MF_PPT = 12;            // patch elements per thread per pass (patch <= 3072 floats)
+
+struct ConvMfmaArgs {
+    const float *x, *w, *bias;
+    float *y;
+    int n, c_in, h, w_in, c_out, pad, h_out, w_out;
+    int w_ld, w_cols;      // weights [K = 9*c_in][w_ld] floats, k = ci*9 + kh*3 + kw, columns [0, w_cols) readable;
+                           // 16-B aligned rows (w_ld % 4 == 0)
+    int img_t, rows_t;     // images / output rows per workgroup
+    int bands;             // row bands per image group = ceil(h_out / rows_t)
+    int co_b;              // output channels per workgroup (multiple of 16)
+    int relu;
+};
+
+template <int CT, bool ACCUM>   // CT = co_b / 16
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CO_B = 16 * CT;
+    constexpr int WQ = MF_CI * 9 * CO_B / 4;                   // float4 quads in the weight slab
+    constexpr int WPT = (WQ + 255) / 256;                      // quads per thread per pass
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const int wp = a.w_out + 2, rp = a.rows_t + 2;           // patch pitch / rows (input window of the band)
+    const int img_stride = rp * wp, ci_stride = a.img_t * img_stride;
+    const int patch_n = MF_CI * ci_stride;
+    float *patch = lds;                                        // [MF_CI][img_t][rp][wp]
+    float *wsl = lds + ((patch_n + 3) & ~3);                   // [72][CO_B], 16-B aligned
+    const int grp = blockIdx.x / a.bands, band = blockIdx.x % a.bands;
+    const int img0 = grp * a.img_t, oh0 = band * a.rows_t;
+    const int co0 = blockIdx.y * CO_B;
+    const int rows_here = min(a.rows_t, a.h_out - oh0);
+    const int px_per_img = a.rows_t * a.w_out;
+    const int m_wg = a.img_t * px_per_img;                     // <= 128 (rows past rows_here are discarded)
+
+    // this lane's B column in its two pixel tiles: LDS offset of the window's top-left corner
+    int pix_off[2];
+    bool pix_ok[2];
+    int pix_img[2], pix_r[2], pix_c[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = (wave + 4 * q) * 16 + l16;
+        const bool ok = p < m_wg;
+        const int il = ok ? p / px_per_img : 0, rem = ok ? p % px_per_img : 0;
+        const int r = rem / a.w_out, c = rem % a.w_out;
+        pix_img[q] = il; pix_r[q] = r; pix_c[q] = c;
+        pix_ok[q] = ok && r < rows_here && img0 + il < a.n;
+        pix_off[q] = il * img_stride + r * wp + c;
+    }
+    // LDS offset of tap k = 4s + g4 relative to the window corner, for the 18 k-steps of a pass
+    int koff[MF_KS];
+#pragma unroll
+    for (int s = 0; s < MF_KS; ++s) {
+        const int kk = 4 * s + g4, cl = kk / 9, tap = kk % 9;
+        koff[s] = cl * ci_stride + (tap / 3) * wp + (tap % 3);
+    }
+    // Staging plan, fixed for the whole kernel (only the channel base moves between passes): patch
+    // element e = t + 256 j -> global offset within channel block 0 (or -1: halo / tail -> zero) and
+    // its local channel; weight quad u = t + 256 j -> row kk and column quad.
+    const int shift = 1 - a.pad;                               // pad = 0: the window starts one pixel in
+    const long chan = (long)a.h * a.w_in;
+    int p_goff[MF_PPT];   // (offset << 3) | local channel, or -1
+#pragma unroll
+    for (int j = 0; j < MF_PPT; ++j) {
+        const int e = t + 256 * j;
+        p_goff[j] = -1;
+        if (e < patch_n) {
+            const int cl = e / ci_stride, r1 = e % ci_stride;
+            const int il = r1 / img_stride, r2 = r1 % img_stride;
+            const int rr = r2 / wp, cc = r2 % wp;
+            const int img = img0 + il, ih = oh0 + rr - 1 + shift, iw = cc - 1 + shift;
+            if (img < a.n && ih >= 0 && ih < a.h && iw >= 0 && iw < a.w_in)
+                p_goff[j] = (int)((((((long)il * a.c_in + cl) * a.h + ih) * a.w_in + iw) << 3) | cl);   // relative to image img0, channel cb
+        }
+    }
+    const float *xbase = a.x + (long)img0 * a.c_in * chan;
+
+    floatx4 acc[2][CT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[q][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    float pv[MF_PPT];
+    float4 wv[WPT];
+    // all global loads of a pass are issued back to back (one round trip), held in registers while the
+    // previous pass computes, then written to LDS
+#define TH_MF_LOAD(CB)                                                                                           \
+    {                                                                                                            \
+        const float *xc = xbase + (long)(CB) * chan;                                                             \
+        _Pragma("unroll") for (int j = 0; j < MF_PPT; ++j)                                                       \
+            pv[j] = (p_goff[j] >= 0 && (CB) + (p_goff[j] & 7) < a.c_in) ? xc[p_goff[j] >> 3] : 0.f;               \
+        _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                        \
+            const int u = t + 256 * j, kk = u / (CO_B / 4), cq = (u % (CO_B / 4)) * 4;                           \
+            const int k = (CB) * 9 + kk, co = co0 + cq;                                                          \
+            wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
+            if (u < WQ && k < a.c_in * 9 && co + 3 < a.w_cols)                                                   \
+                wv[j] = *reinterpret_cast<const float4 *>(a.w + (long)k * a.w_ld + co);                          \
+        }                                                                                                        \
+    }
+#define TH_MF_STORE()                                                                                            \
+    {                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < MF_PPT; ++j) {                                                     \
+            const int e = t + 256 * j;                                                                           \
+            if (e < patch_n) patch[e] = pv[j];                                                                   \
+        }                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                        \
+            const int u = t + 256 * j;                                                                           \
+            if (u < WQ) *reinterpret_cast<float4 *>(wsl + 4 * u) = wv[j];                                        \
+        }                                                                                                        \
+    }
+    TH_MF_LOAD(0)
+    TH_MF_STORE()
+    __syncthreads();
+    for (int cb = 0; cb < a.c_in; cb += MF_CI) {
+        const bool more = cb + MF_CI < a.c_in;
+        if (more) TH_MF_LOAD(cb + MF_CI)
+        // ---- 18 k-steps: per step 2 pixel fragments and CT weight fragments feed 2*CT MFMAs ----
+#pragma unroll
+        for (int s = 0; s < MF_KS; ++s) {
+            const float b0 = patch[pix_off[0] + koff[s]];
+            const float b1 = patch[pix_off[1] + koff[s]];
+            const float *wk = wsl + (4 * s + g4) * CO_B + l16;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const float av = wk[16 * j];
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1][j], 0, 0, 0);
+            }
+        }
+        if (more) {
+            __syncthreads();   // every wave is done reading this pass
+            TH_MF_STORE()
+            __syncthreads();
+        }
+    }
+#undef TH_MF_LOAD
+#undef TH_MF_STORE
+
+    // ---- epilogue: bias + ReLU (tensor.rs:2005-2025, nn.rs:433-490), NCHW store ----
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (!pix_ok[q]) continue;
+        const int img = img0 + pix_img[q], oh = oh0 + pix_r[q], ow = pix_c[q];
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 16 * j + 4 * g4 + i;
+                if (co >= a.c_out) continue;
+                float v = acc[q][j][i] + (a.bias ? a.bias[co] : 0.f);
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                float *dst = a.y + (((long)img * a.c_out + co) * a.h_out + oh) * a.w_out + ow;
+                if (ACCUM) *dst += v;
+                else *dst = v;
+            }
+    }
+}
+
+// images x rows per workgroup: the fullest tiling of <= 128 pixels by whole output rows of one or more images
+static void conv_mfma_plan(int h_out, int w_out, int n, int *img_t, int *rows_t) {
+    int best_fill = -1;
+    *img_t = 1;
+    *rows_t = 1;
+    for (int r = 1; r <= h_out; ++r) {
+        if (r * w_out > MF_PX_MAX) break;
+        int im = MF_PX_MAX / (r * w_out);
+        if (im > n) im = n;
+        const int patch_cap = MF_PPT * 256 / (MF_CI * (r + 2) * (w_out + 2));   // the staged patch is <= 12 floats per thread
+        if (im > patch_cap) im = patch_cap;
+        if (im < 1) continue;
+        const int bands = ceil_div(h_out, r);
+        // useful pixels per 128-pixel workgroup slot, counting the ragged last band; prefer fewer,
+        // taller bands on ties (less halo re-read)
+        const int fill = (int)((long)h_out * w_out * im * 1000 / ((long)bands * MF_PX_MAX));
+        if (fill >= best_fill) {
+            best_fill = fill;
+            *img_t = im;
+            *rows_t = r;
+        }
+    }
+}
+
+bool conv3x3_mfma_supported(int c_in, int h, int w, int pad) {
+    const int w_out = w + 2 * pad - 2, h_out = h + 2 * pad - 2;
+    return c_in >= MF_CI && w_out >= 1 && h_out >= 1 && MF_CI * 3 * (w_out + 2) <= MF_PPT * 256;
+}
+
+// y (+)= conv3x3(x, w) [+ bias, relu]; weights [9*c_in][w_ld] with columns [0, w_cols) readable, rows 16-B aligned
+int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
+                        int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum) {
+    TH_REQUIRE(w_ld % 4 == 0 && ((uintptr_t)w & 15) == 0, "conv3x3_mfma: weight rows must be 16-byte aligned");
+    ConvMfmaArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.n = n; a.c_in = c_in; a.h = h; a.w_in = w_in; a.c_out = c_out; a.pad = pad;
+    a.h_out = h + 2 * pad - 2;
+    a.w_out = w_in + 2 * pad - 2;
+    a.w_ld = w_ld; a.w_cols = w_cols;
+    conv_mfma_plan(a.h_out, a.w_out, n, &a.img_t, &a.rows_t);
+    a.bands = ceil_div(a.h_out, a.rows_t);
+    a.relu = relu;
+    const int co_tiles = ceil_div(c_out, 16);
+    // <= 64 output channels per workgroup: 32 accumulator + 18 prefetch VGPRs keep 3 workgroups per CU,
+    // and wide layers get twice the workgroups (conv5 of the reference CNN: 232 instead of 116)
+    const int ct = co_tiles >= 4 ? 4 : (co_tiles >= 2 ? 2 : 1);
+    a.co_b = ct * 16;
+    const size_t patch_n = (size_t)MF_CI * a.img_t * (a.rows_t + 2) * (a.w_out + 2);
+    const size_t lds = (((patch_n + 3) & ~(size_t)3) + (size_t)MF_CI * 9 * a.co_b) * sizeof(float);
+    dim3 grid(ceil_div(n, a.img_t) * a.bands, ceil_div(c_out, a.co_b));
+#define TH_MF(CTV, ACC) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC>), grid, dim3(256), lds, ctx->stream, a);
+#define TH_MF_CT(ACC)                                  \
+    switch (ct) {                                      \
+        case 4: TH_MF(4, ACC) break;                   \
+        case 2: TH_MF(2, ACC) break;                   \
+        default: TH_MF(1, ACC) break;                  \
+    }
+    if (accum) TH_MF_CT(true) else TH_MF_CT(false)
+#undef TH_MF_CT
+#undef TH_MF
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace th

@@ -535,6 +535,11 @@ static int conv3x3_launch(th_ctx *ctx, const float *x, const float *w_t, const f
     return 0;
 }
 
+// conv_mfma.hip: the matrix-core path for C_in >= 8
+bool conv3x3_mfma_supported(int c_in, int h, int w, int pad);
+int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
+                        int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum);
+
 }  // namespace th
 
 using namespace th;
@@ -547,13 +552,21 @@ int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float 
     TH_REQUIRE(n > 0 && c_in > 0 && c_out > 0 && h + 2 * pad >= 3 && w + 2 * pad >= 3, "th_conv3x3_fwd: bad geometry");
     TH_REQUIRE(pad == 0 || pad == 1, "th_conv3x3_fwd: pad must be 0 or 1 (got %d)", pad);
     TH_REQUIRE(weight_layout == 0 || weight_layout == 1, "th_conv3x3_fwd: weight_layout must be 0 (taper) or 1 (standard)");
+    const bool mfma = conv3x3_mfma_supported(c_in, h, w, pad);
+    // the taper layout IS the [k][co] slab the matrix-core kernel stages (tensor.rs:1262): read it in place
+    if (mfma && weight_layout == 0 && c_out % 4 == 0 && ((uintptr_t)d_w & 15) == 0)
+        return conv3x3_mfma_launch(ctx, d_x, d_w, c_out, c_out, d_bias, d_y, n, c_in, h, w, c_out, pad, relu, false);
     const int co_pad = (c_out + CO_R - 1) / CO_R * CO_R;   // multiple of both kernels' channel blocks
     void *wt = nullptr;
     if (th_malloc(ctx, (size_t)c_in * 9 * co_pad * sizeof(float), &wt)) return 1;
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3(ew_grid((size_t)c_in * 9 * co_pad, 256)), dim3(256), 0, ctx->stream, d_w,
                        (float *)wt, c_in, c_out, weight_layout, 0, c_out, co_pad, c_in);
     TH_LAUNCH_CHECK();
-    if (int rc = conv3x3_launch(ctx, d_x, (const float *)wt, d_bias, d_y, n, c_in, h, w, c_out, co_pad, pad, relu, false)) return rc;
+    if (mfma) {
+        if (int rc = conv3x3_mfma_launch(ctx, d_x, (const float *)wt, co_pad, co_pad, d_bias, d_y, n, c_in, h, w, c_out, pad, relu, false)) return rc;
+    } else if (int rc = conv3x3_launch(ctx, d_x, (const float *)wt, d_bias, d_y, n, c_in, h, w, c_out, co_pad, pad, relu, false)) {
+        return rc;
+    }
     return th_free(ctx, wt);
 }
 
@@ -568,7 +581,11 @@ int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3(ew_grid((size_t)c_out * 9 * ci_pad, 256)), dim3(256), 0, ctx->stream, d_w,
                        (float *)wt, c_in, c_out, weight_layout, 1, c_in, ci_pad, c_out);
     TH_LAUNCH_CHECK();
-    if (int rc = conv3x3_launch(ctx, d_gy, (const float *)wt, nullptr, d_gx, n, c_out, h, w, c_in, ci_pad, 1, 0, true)) return rc;
+    if (conv3x3_mfma_supported(c_out, h, w, 1)) {   // the mirrored filter [k = (co, kh, kw)][ci] feeds the matrix-core kernel as is
+        if (int rc = conv3x3_mfma_launch(ctx, d_gy, (const float *)wt, ci_pad, ci_pad, nullptr, d_gx, n, c_out, h, w, c_in, 1, 0, true)) return rc;
+    } else if (int rc = conv3x3_launch(ctx, d_gy, (const float *)wt, nullptr, d_gx, n, c_out, h, w, c_in, ci_pad, 1, 0, true)) {
+        return rc;
+    }
     return th_free(ctx, wt);
 }
 
