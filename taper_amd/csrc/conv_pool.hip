@@ -324,15 +324,18 @@ __global__ __launch_bounds__(256) void bias_add_nchw_kernel(const float *__restr
     }
 }
 
-__global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__restrict__ g, float *__restrict__ gb, int n, int c,
-                                                             int hw) {
+// grid = (c, slabs): block (ch, s) sums channel ch over its slab of images; with `part` set the slab sums land
+// in part[s][c] and th_colsum_accum adds them to gb in slab order (deterministic), else gb[ch] += the sum.
+__global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__restrict__ g, float *__restrict__ gb,
+                                                             float *__restrict__ part, int n, int c, int hw, int img_per_slab) {
     __shared__ float sh[4];
     const int ch = blockIdx.x;
+    const int b0 = blockIdx.y * img_per_slab, b1 = min(n, b0 + img_per_slab);
     float s = 0.f;
-    const long total = (long)n * hw;
+    const long total = (long)(b1 - b0) * hw;
     // (image, pixel) tracked incrementally: no integer division per element
     const int step_b = 256 / hw, step_sp = 256 % hw;
-    int b = threadIdx.x / hw, sp = threadIdx.x % hw;
+    int b = b0 + threadIdx.x / hw, sp = threadIdx.x % hw;
     for (long i = threadIdx.x; i < total; i += 256) {
         s += g[((long)b * c + ch) * hw + sp];
         sp += step_sp;
@@ -343,7 +346,11 @@ __global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__rest
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) gb[ch] += ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    if (threadIdx.x == 0) {
+        const float tot = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        if (part) part[(long)blockIdx.y * c + ch] = tot;
+        else gb[ch] += tot;
+    }
 }
 
 // tmp[n][p][co] -> y[n][co][p] + bias[co] (+relu): the reshape + transpose_4d
@@ -646,9 +653,24 @@ int th_bias_add_nchw(th_ctx *ctx, const float *d_x, const float *d_bias, float *
 int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int c, int hw) {
     TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
     if (c == 0) return 0;
-    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_gb, n, c, hw);
+    int slabs = 1;
+    if ((long)n * hw >= 16384 && c < 256) {   // one workgroup per channel cannot fill the chip: split the images
+        slabs = ceil_div(512, c);
+        if (slabs > n) slabs = n;
+    }
+    if (slabs <= 1) {
+        hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_gb, (float *)nullptr, n, c, hw, n);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
+    const int ips = ceil_div(n, slabs);
+    slabs = ceil_div(n, ips);
+    void *part = nullptr;
+    if (th_malloc(ctx, (size_t)slabs * c * sizeof(float), &part)) return 1;
+    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c, slabs), dim3(256), 0, ctx->stream, d_gout, d_gb, (float *)part, n, c, hw, ips);
     TH_LAUNCH_CHECK();
-    return 0;
+    if (int rc = th_colsum_accum(ctx, (const float *)part, d_gb, slabs, c)) return rc;
+    return th_free(ctx, part);
 }
 
 int th_maxpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int64_t *d_argmax, int n, int c, int h, int w, int k_h, int k_w,
