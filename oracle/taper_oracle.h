@@ -11,7 +11,7 @@
  *
  * Pinning status: pinned against every known-answer test the reference
  * holds for this path (tests/smoke.rs, src/loss.rs:292-374,
- * src/optim.rs:354-423, src/train.rs:387-417) -- see tests/test_oracle_kats.py.
+ * src/optim.rs:354-423, src/train.rs:387-417) -- see tests/test_kats.py (both backends) and tests/test_golden.py.
  * The reference holds NO vectors for conv2d / pools / transpose values /
  * Adam's exact numbers; those parts are "parity unpinned by reference
  * tests" and are cross-checked against torch-CPU fixtures generated in the

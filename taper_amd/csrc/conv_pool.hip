@@ -1,8 +1,11 @@
 // conv_pool.hip -- direct 3x3 convolution, 1x1 convolution, max/avg pooling
 // and the NCHW bias kernels (src/tensor.rs:1221-2081).
 //
-// conv3x3: VALU direct convolution (north_star: "conv2d direct-3x3 ... LDS-
-// staged tiles"; MFMA is reserved for the dense GEMMs).  One workgroup owns
+// conv3x3 (this file): VALU direct convolution, the path for C_in < 8 (conv1 of both CNNs: K = 9,
+// HBM-bound) and for planes the matrix-core kernel does not take; layers with C_in >= 8 run the
+// direct convolution of conv_mfma.hip (measured 1.8-3.7x faster on the reference CNN's conv2-5;
+// the north_star's "MFMA only for the dense GEMMs" plan was written before that measurement --
+// DESIGN.md section 3).  One workgroup owns
 // IMG images x 16 output channels; the input planes (+1-pixel halo) of 8
 // input channels at a time are staged in LDS; each thread keeps a 2x4 pixel
 // tile x 8 channels of accumulators in registers; the weights are re-laid-out once
@@ -654,7 +657,7 @@ int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int 
     TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
     if (c == 0) return 0;
     int slabs = 1;
-    if ((long)n * hw >= 16384 && c < 256) {   // one workgroup per channel cannot fill the chip: split the images
+    if ((long)n * hw >= 4096 && c < 256) {   // one workgroup per channel cannot fill the chip: split the images
         slabs = ceil_div(512, c);
         if (slabs > n) slabs = n;
     }
