@@ -1,7 +1,7 @@
 """Which combination crashes rocprofv3 --kernel-trace: graph replays with events / without / backlog depth."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from bench import StepKernels
 from taper_amd import hip
 
