@@ -484,7 +484,7 @@ extern "C" int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d
                                    (int)head_lds_bytes(HEAD_KMAX)));
         attr_set = true;
     }
-    if (batch <= 256) {   // latency-bound: one workgroup, one launch
+    if (batch <= 64) {   // latency-bound: one workgroup, one launch (a single 64-row chunk)
         hipLaunchKernelGGL(linear_xent_head_kernel, dim3(1), dim3(HEAD_T), lds, ctx->stream, a);
         TH_LAUNCH_CHECK();
         return 0;
