@@ -307,6 +307,8 @@ def main():
     ap.add_argument("--dataset-size", type=int, default=60000)
     ap.add_argument("--batch", type=int, default=0, help="override the workload's per-GPU batch (SURVEY 8d batch sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-backward", action="store_true",
+                    help="CNN workloads: train the conv weights too (extension; the reference cuts the tape there, quirk Q2)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel timing after the timed region")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch sweep (SURVEY 8d) reported beside the headline value")
     args = ap.parse_args()
@@ -317,6 +319,8 @@ def main():
     T.Device.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 
     key, batch, sample_shape, lr = WORKLOADS[args.workload]
+    if args.full_backward:
+        T.set_full_backward(True)
     if args.batch:
         batch = args.batch
         args.workload = args.workload.rsplit("_b", 1)[0] + f"_b{batch}"
@@ -377,7 +381,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "per_gpu_batch": batch, "global_batch": batch * world,
                        "optimizer": f"Adam(lr={lr}, wd=1e-4)", "parallelism": f"dp{world}" if world > 1 else "single",
-                       "comm": comm_kind, "step": "hipGraph replay of gather+fwd+xent+bwd+adam+log"},
+                       "comm": comm_kind, "step": "hipGraph replay of gather+fwd+xent+bwd+adam+log",
+                       **({"conv_gradients": "full_backward (extension)"} if args.full_backward else {})},
             "epochs_per_s": round(samples / dt / 60000.0, 3),
             "step_roofline": None if flops is None else {
                 "alg_flops_per_step": flops, "alg_bytes_per_step": nbytes,

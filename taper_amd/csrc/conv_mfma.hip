@@ -251,4 +251,219 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 convolution on the matrix cores (full_backward extension; the reference
+// cuts the tape before it, quirk Q2):
+//   gw_eff[k][co] += sum_px patch[px, k] * gy[px, co],   k = (ci, kh, kw),  px = (n, oh, ow)
+// The contraction runs over PIXELS.  A workgroup owns a slab of 16 input channels (K = 144 = 9 k-tiles)
+// x co_b <= 64 output channels and walks every G-th pixel block (<= 128 pixels: whole rows of 1..9
+// images, the forward kernel's tiling), keeping its 9*CT accumulator tiles in registers; it writes ONE
+// partial [144][co_b] slab, and wgrad_reduce_kernel adds the G partials in order into the weight
+// gradient through the layout map (deterministic, no atomics).
+//   A operand (16 k x 4 px): lane l -> patch[pix_off[px0 + (l>>4)] + koff(k0 + (l&15))]   (LDS gather)
+//   B operand (4 px x 16 co): lane l -> gyL[co0 + (l&15)][px0 + (l>>4)]
+constexpr int WG_CI = 16;                 // input channels per slab
+constexpr int WG_KT = WG_CI * 9 / 16;     // 9 k-tiles
+constexpr int WG_GP = MF_PX_MAX + 1;      // odd pitch of the gy tile: conflict-free column reads
+
+struct ConvWgradArgs {
+    const float *x, *gy;
+    float *part;           // [G][9*c_in][co_ld]
+    int n, c_in, h, w_in, c_out, pad, h_out, w_out;
+    int img_t, rows_t, bands, n_pb, G, co_ld;
+};
+
+template <int CT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CO_B = 16 * CT, NPAIR = WG_KT * CT, SLOTS = (NPAIR + 3) / 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const int wp = a.w_out + 2, rp = a.rows_t + 2;
+    const int img_stride = rp * wp, ci_stride = a.img_t * img_stride;       // <= 384
+    float *patch = lds;                                                        // [16][img_t][rp][wp]
+    float *gyl = lds + WG_CI * ci_stride;                                      // [CO_B][WG_GP]
+    int *pixoff = reinterpret_cast<int *>(gyl + CO_B * WG_GP);                 // [128]
+    const int cb = blockIdx.y * WG_CI, co0 = blockIdx.z * CO_B;
+    const int px_per_img = a.rows_t * a.w_out, m_wg = a.img_t * px_per_img;
+    const int shift = 1 - a.pad;
+    const long chan = (long)a.h * a.w_in, ochan = (long)a.h_out * a.w_out;
+
+    // ---- block-invariant plans ----
+    // pixel p of a block -> LDS offset of its window corner (same for every block)
+    if (t < MF_PX_MAX) {
+        const int il = t < m_wg ? t / px_per_img : 0, rem = t < m_wg ? t % px_per_img : 0;
+        pixoff[t] = il * img_stride + (rem / a.w_out) * wp + rem % a.w_out;
+    }
+    // patch element q (within one channel's [img_t][rp][wp] chunk), two per thread
+    int pq_rel[2], pq_meta[2];            // meta = il | rr << 8 | col_ok << 16 | present << 17
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = t + 256 * u;
+        pq_rel[u] = 0;
+        pq_meta[u] = 0;
+        if (q < ci_stride) {
+            const int il = q / img_stride, r2 = q % img_stride, rr = r2 / wp, cc = r2 % wp;
+            const int iw = cc - 1 + shift;
+            pq_rel[u] = (int)((long)il * a.c_in * chan + (long)(rr - 1 + shift) * a.w_in + iw);
+            pq_meta[u] = il | (rr << 8) | ((iw >= 0 && iw < a.w_in) ? 1 << 16 : 0) | (1 << 17);
+        }
+    }
+    // gy element: pixel t % 128, output-channel parity t / 128
+    const int gp = t & 127, gpar = t >> 7;
+    const int g_il = gp < m_wg ? gp / px_per_img : 0, g_rem = gp < m_wg ? gp % px_per_img : 0;
+    const int g_r = g_rem / a.w_out, g_c = g_rem % a.w_out;
+    // this wave's (k-tile, co-tile) pairs: p = wave*SLOTS + j, co-tile-major
+    int koffk[SLOTS];
+    bool slot_ok[SLOTS], slot_hi[SLOTS];
+    const int p_first = wave * SLOTS;
+    const int ct_lo = min(p_first / WG_KT, CT - 1), ct_hi = min((p_first + SLOTS - 1) / WG_KT, CT - 1);
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int p = p_first + j;
+        slot_ok[j] = p < NPAIR;
+        const int ct = slot_ok[j] ? p / WG_KT : ct_lo, kt = slot_ok[j] ? p % WG_KT : 0;
+        slot_hi[j] = ct != ct_lo;
+        const int k = kt * 16 + l16, cl = k / 9, tap = k % 9;
+        koffk[j] = cl * ci_stride + (tap / 3) * wp + tap % 3;
+    }
+    floatx4 acc[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int pb = blockIdx.x; pb < a.n_pb; pb += a.G) {
+        const int grp = pb / a.bands, band = pb % a.bands;
+        const int img0 = grp * a.img_t, oh0 = band * a.rows_t;
+        const int rows_here = min(a.rows_t, a.h_out - oh0);
+        __syncthreads();   // the previous block's MFMAs are done with patch / gyl (and pixoff is written)
+        // ---- stage the 16-channel input patch (zero halo / tails), 8 channels per batch of loads ----
+        const float *xb = a.x + ((long)img0 * a.c_in + cb) * chan + (long)oh0 * a.w_in;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float v[8][2];
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cl = half * 8 + c8, meta = pq_meta[u];
+                    const int il = meta & 255, rr = (meta >> 8) & 255, ih = oh0 + rr - 1 + shift;
+                    const bool ok = (meta >> 16 & 1) && ih >= 0 && ih < a.h && img0 + il < a.n && cb + cl < a.c_in;
+                    v[c8][u] = ok ? xb[(long)cl * chan + pq_rel[u]] : 0.f;
+                }
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (pq_meta[u] >> 17 & 1) patch[(half * 8 + c8) * ci_stride + t + 256 * u] = v[c8][u];
+        }
+        // ---- stage gy[co_b][128 px] (zero for pixels outside this block / image range) ----
+        {
+            const bool pok = gp < m_wg && g_r < rows_here && img0 + g_il < a.n;
+            const float *gb = a.gy + ((long)(img0 + g_il) * a.c_out + co0) * ochan + (long)(oh0 + g_r) * a.w_out + g_c;
+#pragma unroll
+            for (int b0 = 0; b0 < CO_B / 2; b0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int co = 2 * (b0 + i) + gpar;
+                    v[i] = (pok && co0 + co < a.c_out) ? gb[(long)co * ochan] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gyl[(2 * (b0 + i) + gpar) * WG_GP + gp] = v[i];
+            }
+        }
+        __syncthreads();
+        // ---- 32 reduction steps of 4 pixels ----
+#pragma unroll 4
+        for (int rs = 0; rs < MF_PX_MAX / 4; ++rs) {
+            const int px = 4 * rs + g4;
+            const int po = pixoff[px];
+            const float b_lo = gyl[(ct_lo * 16 + l16) * WG_GP + px];
+            const float b_hi = gyl[(ct_hi * 16 + l16) * WG_GP + px];
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) {
+                const float av = patch[po + koffk[j]];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, slot_hi[j] ? b_hi : b_lo, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- one partial slab per workgroup: part[g][k][co]  (D tile: row = k = 4*(l>>4)+i, col = co = l&15) ----
+    float *pp = a.part + (long)blockIdx.x * 9 * a.c_in * a.co_ld;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int p = p_first + j;
+        if (p >= NPAIR) continue;
+        const int ct = p / WG_KT, kt = p % WG_KT;
+        const int co = co0 + ct * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = cb * 9 + kt * 16 + 4 * g4 + i;
+            if (k < a.c_in * 9 && co < a.co_ld) pp[(long)k * a.co_ld + co] = acc[j][i];
+        }
+    }
+}
+
+// gw (+)= sum_g part[g][k][co], written through the weight layout map (0: [k][c_out], 1: [co][9 c_in])
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, int G, int kt,
+                                                           int c_out, int co_ld, int layout) {
+    const long total = (long)kt * c_out;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i / c_out), co = (int)(i % c_out);
+        const float *src = part + (long)k * co_ld + co;
+        const long stride = (long)kt * co_ld;
+        float s0 = 0.f, s1 = 0.f;
+        int g = 0;
+        for (; g + 1 < G; g += 2) {
+            s0 += src[g * stride];
+            s1 += src[(g + 1) * stride];
+        }
+        if (g < G) s0 += src[g * stride];
+        const long idx = layout == 0 ? (long)k * c_out + co : (long)co * kt + k;
+        gw[idx] += s0 + s1;
+    }
+}
+
+int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
+                              int pad, int layout) {
+    ConvWgradArgs a{};
+    a.x = x; a.gy = gy;
+    a.n = n; a.c_in = c_in; a.h = h; a.w_in = w_in; a.c_out = c_out; a.pad = pad;
+    a.h_out = h + 2 * pad - 2;
+    a.w_out = w_in + 2 * pad - 2;
+    conv_mfma_plan(a.h_out, a.w_out, n, &a.img_t, &a.rows_t);
+    a.bands = ceil_div(a.h_out, a.rows_t);
+    a.n_pb = ceil_div(n, a.img_t) * a.bands;
+    const int co_tiles = ceil_div(c_out, 16);
+    const int ct = co_tiles >= 4 ? 4 : (co_tiles >= 2 ? 2 : 1);
+    const int co_b = ct * 16;
+    const int slabs = ceil_div(c_in, WG_CI), co_blocks = ceil_div(c_out, co_b);
+    a.co_ld = co_blocks * co_b;
+    int G = ceil_div(768, slabs * co_blocks);           // ~3 workgroups per CU in total
+    if (G > a.n_pb) G = a.n_pb;
+    if (G > 512) G = 512;
+    a.G = G;
+    const int kt = 9 * c_in;
+    void *ws = nullptr;
+    if (th_malloc(ctx, (size_t)G * kt * a.co_ld * sizeof(float), &ws)) return 1;
+    a.part = (float *)ws;
+    const size_t ci_stride = (size_t)a.img_t * (a.rows_t + 2) * (a.w_out + 2);
+    TH_REQUIRE(ci_stride <= 512, "conv3x3_wgrad: patch chunk too large");
+    const size_t lds = (WG_CI * ci_stride + (size_t)co_b * WG_GP) * sizeof(float) + MF_PX_MAX * sizeof(int);
+    dim3 grid(G, slabs, co_blocks);
+    switch (ct) {
+        case 4: {
+            auto kern = conv3x3_wgrad_mfma_kernel<4>;
+            if (lds > (64u << 10)) TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);
+        } break;
+        case 2: hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<2>, grid, dim3(256), lds, ctx->stream, a); break;
+        default: hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<1>, grid, dim3(256), lds, ctx->stream, a); break;
+    }
+    TH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((size_t)kt * c_out, 256)), dim3(256), 0, ctx->stream, (const float *)a.part, gw, G,
+                       kt, c_out, a.co_ld, layout);
+    TH_LAUNCH_CHECK();
+    return th_free(ctx, ws);
+}
+
 }  // namespace th

@@ -549,6 +549,8 @@ static int conv3x3_launch(th_ctx *ctx, const float *x, const float *w_t, const f
 bool conv3x3_mfma_supported(int c_in, int h, int w, int pad);
 int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
                         int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum);
+int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
+                              int pad, int layout);
 
 }  // namespace th
 
@@ -604,6 +606,8 @@ int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, floa
     TH_REQUIRE(ctx && d_x && d_gy && d_gw, "th_conv3x3_bwd_weight: null argument");
     TH_REQUIRE(pad == 0 || pad == 1, "th_conv3x3_bwd_weight: pad must be 0 or 1");
     const int h_out = h + 2 * pad - 2, w_out = w + 2 * pad - 2;
+    if (conv3x3_mfma_supported(c_in, h, w, pad) && (long)n * h_out * w_out >= 2048)   // enough pixels to contract over
+        return conv3x3_wgrad_mfma_launch(ctx, d_x, d_gy, d_gw, n, c_in, h, w, c_out, pad, weight_layout);
     hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(c_out, c_in), dim3(256), 0, ctx->stream, d_x, d_gy, d_gw, n, c_in, h, w,
                        c_out, pad, h_out, w_out, weight_layout);
     TH_LAUNCH_CHECK();
