@@ -403,24 +403,28 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a
     }
 }
 
-// gw (+)= sum_g part[g][k][co], written through the weight layout map (0: [k][c_out], 1: [co][9 c_in])
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, int G, int kt,
-                                                           int c_out, int co_ld, int layout) {
+// gw (+)= tmp[k][co] through the weight layout map (0: [k][c_out], 1: [co][9 c_in]); tmp is the ordered
+// sum of the G partial slabs (th_colsum over the [G, kt*co_ld] matrix: deterministic, no atomics)
+__global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float *__restrict__ tmp, float *__restrict__ gw, int kt, int c_out,
+                                                            int co_ld, int layout) {
     const long total = (long)kt * c_out;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int k = (int)(i / c_out), co = (int)(i % c_out);
-        const float *src = part + (long)k * co_ld + co;
-        const long stride = (long)kt * co_ld;
-        float s0 = 0.f, s1 = 0.f;
-        int g = 0;
-        for (; g + 1 < G; g += 2) {
-            s0 += src[g * stride];
-            s1 += src[(g + 1) * stride];
-        }
-        if (g < G) s0 += src[g * stride];
         const long idx = layout == 0 ? (long)k * c_out + co : (long)co * kt + k;
-        gw[idx] += s0 + s1;
+        gw[idx] += tmp[(long)k * co_ld + co];
     }
+}
+
+// part: [G][kt][co_ld] partial slabs -> gw
+int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout) {
+    void *tmp = nullptr;
+    const int cols = kt * co_ld;
+    if (th_malloc(ctx, (size_t)cols * sizeof(float), &tmp)) return 1;
+    if (int rc = th_colsum(ctx, part, (float *)tmp, G, cols)) return rc;
+    hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(ew_grid((size_t)kt * c_out, 256)), dim3(256), 0, ctx->stream, (const float *)tmp, gw, kt,
+                       c_out, co_ld, layout);
+    TH_LAUNCH_CHECK();
+    return th_free(ctx, tmp);
 }
 
 int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
@@ -438,7 +442,7 @@ int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, floa
     const int co_b = ct * 16;
     const int slabs = ceil_div(c_in, WG_CI), co_blocks = ceil_div(c_out, co_b);
     a.co_ld = co_blocks * co_b;
-    int G = ceil_div(768, slabs * co_blocks);           // ~3 workgroups per CU in total
+    int G = ceil_div(512, slabs * co_blocks);           // 2 workgroups per CU in total (LDS: 58 KB each)
     if (G > a.n_pb) G = a.n_pb;
     if (G > 512) G = 512;
     a.G = G;
@@ -460,9 +464,7 @@ int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, floa
         default: hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<1>, grid, dim3(256), lds, ctx->stream, a); break;
     }
     TH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((size_t)kt * c_out, 256)), dim3(256), 0, ctx->stream, (const float *)a.part, gw, G,
-                       kt, c_out, a.co_ld, layout);
-    TH_LAUNCH_CHECK();
+    if (int rc = wgrad_reduce(ctx, a.part, gw, G, kt, c_out, a.co_ld, layout)) return rc;
     return th_free(ctx, ws);
 }
 

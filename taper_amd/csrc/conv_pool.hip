@@ -270,20 +270,23 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const float *__restri
 }
 
 // gw_eff[co][ci][kh][kw] += sum_{n,h,w} x[n,ci,h+kh-pad,w+kw-pad] * gy[n,co,h,w]
-// One workgroup per (co, ci) pair; 256 threads stride over n*h_out*w_out;
-// 9 block reductions.  Written back through the weight layout map.
+// One workgroup per (co, ci) pair and image slab (blockIdx.z); 256 threads stride over the slab's
+// n*h_out*w_out pixels; 9 block reductions.  Without slabs the result is added to gw through the weight
+// layout map; with `part` set, slab z writes part[z][k][c_out] and wgrad_reduce adds the slabs in order.
 __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ gy,
-                                                                 float *__restrict__ gw, int n, int c_in, int h, int w,
-                                                                 int c_out, int pad, int h_out, int w_out, int layout) {
+                                                                 float *__restrict__ gw, float *__restrict__ part, int n, int c_in,
+                                                                 int h, int w, int c_out, int pad, int h_out, int w_out, int layout,
+                                                                 int img_per_slab) {
     __shared__ float sh[9][4];
     const int co = blockIdx.x, ci = blockIdx.y;
+    const int b0 = blockIdx.z * img_per_slab, b1 = min(n, b0 + img_per_slab);
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.f;
     const int osp = h_out * w_out;
-    const long total = (long)n * osp;
+    const long total = (long)(b1 - b0) * osp;
     for (long i = threadIdx.x; i < total; i += 256) {
-        const int img = (int)(i / osp), p = (int)(i % osp);
+        const int img = b0 + (int)(i / osp), p = (int)(i % osp);
         const int oh = p / w_out, ow = p % w_out;
         const float g = gy[((long)img * c_out + co) * osp + p];
         const float *xp = x + ((long)img * c_in + ci) * h * w;
@@ -312,8 +315,12 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__
         const int t = threadIdx.x;
         const float tot = ((sh[t][0] + sh[t][1]) + sh[t][2]) + sh[t][3];
         const int k = ci * 9 + t;
-        const long idx = layout == 0 ? (long)k * c_out + co : (long)co * c_in * 9 + k;
-        gw[idx] += tot;
+        if (part) {
+            part[((long)blockIdx.z * c_in * 9 + k) * c_out + co] = tot;
+        } else {
+            const long idx = layout == 0 ? (long)k * c_out + co : (long)co * c_in * 9 + k;
+            gw[idx] += tot;
+        }
     }
 }
 
@@ -551,6 +558,7 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
                         int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum);
 int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
                               int pad, int layout);
+int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout);
 
 }  // namespace th
 
@@ -608,10 +616,26 @@ int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, floa
     const int h_out = h + 2 * pad - 2, w_out = w + 2 * pad - 2;
     if (conv3x3_mfma_supported(c_in, h, w, pad) && (long)n * h_out * w_out >= 2048)   // enough pixels to contract over
         return conv3x3_wgrad_mfma_launch(ctx, d_x, d_gy, d_gw, n, c_in, h, w, c_out, pad, weight_layout);
-    hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(c_out, c_in), dim3(256), 0, ctx->stream, d_x, d_gy, d_gw, n, c_in, h, w,
-                       c_out, pad, h_out, w_out, weight_layout);
+    int slabs = 1;
+    if ((long)c_out * c_in < 512 && (long)n * h_out * w_out >= 8192) {   // few (co, ci) pairs, many pixels (conv1): split the images
+        slabs = ceil_div(1024, c_out * c_in);
+        if (slabs > n) slabs = n;
+    }
+    if (slabs <= 1) {
+        hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(c_out, c_in), dim3(256), 0, ctx->stream, d_x, d_gy, d_gw, (float *)nullptr, n,
+                           c_in, h, w, c_out, pad, h_out, w_out, weight_layout, n);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
+    const int ips = ceil_div(n, slabs);
+    slabs = ceil_div(n, ips);
+    void *part = nullptr;
+    if (th_malloc(ctx, (size_t)slabs * c_in * 9 * c_out * sizeof(float), &part)) return 1;
+    hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(c_out, c_in, slabs), dim3(256), 0, ctx->stream, d_x, d_gy, d_gw, (float *)part, n,
+                       c_in, h, w, c_out, pad, h_out, w_out, weight_layout, ips);
     TH_LAUNCH_CHECK();
-    return 0;
+    if (int rc = wgrad_reduce(ctx, (const float *)part, d_gw, slabs, c_in * 9, c_out, c_out, weight_layout)) return rc;
+    return th_free(ctx, part);
 }
 
 int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y, int n, int c_in, int h,

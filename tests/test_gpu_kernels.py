@@ -399,7 +399,8 @@ def test_conv1x1_taper_layout(ctx, O, n, c_in, h, w, c_out):
 
 @pytest.mark.parametrize("n,c_in,h,w,c_out", [(3, 4, 8, 8, 5), (2, 32, 14, 14, 32), (4, 1, 28, 28, 8), (2, 16, 7, 7, 24),
                                               # >= 2048 output pixels and C_in >= 8: the matrix-core weight-gradient kernel
-                                              (12, 16, 14, 14, 24), (4, 40, 28, 28, 70), (50, 9, 7, 7, 16), (3, 32, 28, 28, 32)])
+                                              (12, 16, 14, 14, 24), (4, 40, 28, 28, 70), (50, 9, 7, 7, 16), (3, 32, 28, 28, 32),
+                                              (16, 1, 28, 28, 32), (11, 3, 30, 30, 5)])   # few channel pairs, many pixels: image slabs
 @pytest.mark.parametrize("layout", [0, 1])
 def test_conv3x3_bwd_full_mode(ctx, O, n, c_in, h, w, c_out, layout):
     """full_backward extension (not in the reference, Q2): checked against the oracle's
