@@ -351,7 +351,7 @@ def main():
             # rocprofv3 (ROCm 7.2) segfaults in hipGraphLaunch once a process replays more than one
             # instantiated graph back to back; the Trainer's replays above are what the trace is for.
             roof = dict(skipped="per-kernel timers are not run under rocprofv3; see profiles/ for the trace of this command")
-        elif key == "mlp_baseline" and not args.no_roofline:
+        elif key == "mlp_baseline" and not args.no_roofline and world == 1:
             # per-launch durations of the step's three kernels, measured live (HIP events on the ctx
             # stream, graph chains with / without each launch).  `roofline` is the kernel that carries
             # the step's HBM traffic (81% of its algorithmic bytes); the full list is in `kernels`.
@@ -370,7 +370,7 @@ def main():
         if key == "mlp_baseline" and world == 1 and not args.batch and not args.no_sweep:
             sweep = batch_sweep(T, build_model, key, lr, args.dataset_size)
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             try:
                 cpu = cpu_baseline(key, batch, sample_shape, lr)
             except Exception as e:  # the baseline is reported, never required
