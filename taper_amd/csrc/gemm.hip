@@ -82,26 +82,24 @@ __device__ __forceinline__ void small16_body(const SmallArgs &p, int tile_row, i
     // update -- is requested by wave 0 NOW, under the operand loads; (b) the
     // operand loads of CH k-steps (64 k per wave) are all issued before the
     // first MFMA consumes any.
+    // Epilogue work is spread over waves 0..3: wave e finishes output element e of every lane (row
+    // 4*(lane>>4) + e of the tile), so the p / m / v traffic of a fused Adam update and the final adds
+    // run on four SIMDs instead of one.
     const int ecol = col0 + (lane & 15);
     const bool fuse_adam = p.ep.adam.p != nullptr && p.partial == nullptr;
-    float e_bias = 0.f, e_cold[4] = {0.f, 0.f, 0.f, 0.f}, e_p[4], e_m[4], e_v[4], e_step = 0.f;
-    long e_ix[4];
-    bool e_ok[4];
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + (lane >> 4) * 4 + i;
-            e_ok[i] = row < p.m && ecol < p.n;
-            e_ix[i] = e_ok[i] ? (long)row * p.n + ecol : 0;
-            if (p.ep.beta != 0.0f && !p.partial) e_cold[i] = p.C[e_ix[i]];
-            if (fuse_adam) {
-                e_p[i] = p.ep.adam.p[e_ix[i]];
-                e_m[i] = p.ep.adam.m[e_ix[i]];
-                e_v[i] = p.ep.adam.v[e_ix[i]];
-            }
+    const int erow = row0 + (lane >> 4) * 4 + wave;     // meaningful for wave < 4
+    const bool e_ok = wave < 4 && erow < p.m && ecol < p.n;
+    const long e_ix = e_ok ? (long)erow * p.n + ecol : 0;
+    float e_bias = 0.f, e_cold = 0.f, e_p = 0.f, e_m = 0.f, e_v = 0.f, e_step = 0.f;
+    if (e_ok) {
+        if (p.ep.beta != 0.0f && !p.partial) e_cold = p.C[e_ix];
+        if (fuse_adam) {
+            e_p = p.ep.adam.p[e_ix];
+            e_m = p.ep.adam.m[e_ix];
+            e_v = p.ep.adam.v[e_ix];
+            e_step = adam_dev_step(p.ep.adam);
         }
-        if (p.ep.bias && ecol < p.n) e_bias = p.ep.bias[ecol];
-        if (fuse_adam) e_step = adam_dev_step(p.ep.adam);
+        if (p.ep.bias) e_bias = p.ep.bias[ecol];
     }
     constexpr int CH = 4;
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -147,37 +145,33 @@ __device__ __forceinline__ void small16_body(const SmallArgs &p, int tile_row, i
         }
     }
 
-    // deterministic in-workgroup reduction: wave 0 adds waves 1..NW-1 in order
-    if (wave > 0) {
+    // deterministic in-workgroup reduction: every wave parks its 4 partial sums; wave e adds element e
+    // of waves 0..NW-1 in wave order
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave - 1][lane][i] = acc[i];
-    }
+    for (int i = 0; i < 4; ++i) red[wave][lane][i] = acc[i];
     __syncthreads();
-    if (wave == 0) {
-        for (int w = 0; w < NW - 1; ++w)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] += red[w][lane][i];
-        // C/D map of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + i
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (!e_ok[i]) continue;
+    if (wave < 4) {
+        float sum = red[0][lane][wave];
+        for (int w = 1; w < NW; ++w) sum += red[w][lane][wave];
+        // C/D map of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + i  (here i = wave)
+        if (e_ok) {
             if (p.partial) {
-                p.partial[(long)zslice * p.m * p.n + e_ix[i]] = acc[i];
-                continue;
-            }
-            float out = p.ep.alpha * acc[i];
-            if (p.ep.beta != 0.0f) out += p.ep.beta * e_cold[i];
-            if (p.ep.bias) out += e_bias;
-            if (p.ep.relu) out = out > 0.0f ? out : 0.0f;
-            p.C[e_ix[i]] = out;
-            if (fuse_adam) {  // th_linear_bwd_adam: C is a complete gradient (optim.rs:99-110)
-                const AdamDev &ad = p.ep.adam;
-                const float gv = out + ad.wd * e_p[i];
-                const float mn = ad.beta1 * e_m[i] + (1.0f - ad.beta1) * gv;
-                const float vn = ad.beta2 * e_v[i] + (1.0f - ad.beta2) * gv * gv;
-                ad.m[e_ix[i]] = mn;
-                ad.v[e_ix[i]] = vn;
-                ad.p[e_ix[i]] = e_p[i] - e_step * mn / (sqrtf(vn) + ad.eps);
+                p.partial[(long)zslice * p.m * p.n + e_ix] = sum;
+            } else {
+                float out = p.ep.alpha * sum;
+                if (p.ep.beta != 0.0f) out += p.ep.beta * e_cold;
+                if (p.ep.bias) out += e_bias;
+                if (p.ep.relu) out = out > 0.0f ? out : 0.0f;
+                p.C[e_ix] = out;
+                if (fuse_adam) {  // th_linear_bwd_adam: C is a complete gradient (optim.rs:99-110)
+                    const AdamDev &ad = p.ep.adam;
+                    const float gv = out + ad.wd * e_p;
+                    const float mn = ad.beta1 * e_m + (1.0f - ad.beta1) * gv;
+                    const float vn = ad.beta2 * e_v + (1.0f - ad.beta2) * gv * gv;
+                    ad.m[e_ix] = mn;
+                    ad.v[e_ix] = vn;
+                    ad.p[e_ix] = e_p - e_step * mn / (sqrtf(vn) + ad.eps);
+                }
             }
         }
     }
@@ -186,7 +180,7 @@ __device__ __forceinline__ void small16_body(const SmallArgs &p, int tile_row, i
 // grid = (tiles_n, tiles_m, kz); block = 64 * NW
 template <bool A_KC, bool B_KC, int NW>
 __global__ __launch_bounds__(64 * NW) void sgemm_small16(SmallArgs p) {
-    __shared__ float red[NW - 1][64][4];
+    __shared__ float red[NW][64][4];
     small16_body<A_KC, B_KC, NW, false>(p, blockIdx.y, blockIdx.x, blockIdx.z, red);
 }
 
@@ -243,7 +237,7 @@ struct LinearBwdArgs {
 
 template <bool MASKED>
 __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
-    __shared__ float red[3][64][4];
+    __shared__ float red[4][64][4];
     const int bid = blockIdx.x;
     if (bid < q.n_dw) {
         const int t = (bid & 7) * (q.n_dw >> 3) + (bid >> 3);

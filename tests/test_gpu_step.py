@@ -2,6 +2,8 @@
 loss, logits, every parameter gradient (incl. which ones are None, quirk Q2)
 and the post-Adam weights must match the CPU oracle; the hipGraph-replayed
 epoch must match the eager epoch; size-independent properties at full size."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -35,7 +37,9 @@ MODELS = {
 def test_forward_backward_parity(name, batch, fuse):
     H, Orc = backends.get("hip"), backends.get("oracle")
     Orc.set_zero_sentinel(True)
-    rng = np.random.default_rng(hash(name) % 1000 + batch)
+    # a stable seed (str hashes change per process): the inputs must be the same on every run -- a pre-activation
+    # within rounding of 0 flips its ReLU mask between two summation orders, a discontinuity no tolerance covers
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + batch)
     builder, sample = MODELS[name]
     spec = backends.nonzero_biases(builder(rng), rng)
     x, y = backends.mnist_like(rng, batch)
