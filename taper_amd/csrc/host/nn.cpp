@@ -714,15 +714,25 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     if (!graphs_.empty() && (graph_batch_ != bs || graph_key_ != key)) drop_graphs();
 
     size_t done = 0;
-    if (graphs_.empty() && n_full > 0 && !graph_capture_failed_) {
+    // Graph sizes still missing for this epoch length (a short first call -- e.g. a 2-step warm-up -- only
+    // records the 1-step graph; the chunk graph is added by the first call long enough to use it).
+    auto have = [&](size_t steps) {
+        for (auto &g : graphs_)
+            if (g.first == steps) return true;
+        return false;
+    };
+    std::vector<size_t> want;
+    for (size_t steps : {chunk, (size_t)1}) {
+        if (steps == 0 || (steps > 1 && n_full < 2 * steps) || have(steps)) continue;
+        if (std::find(want.begin(), want.end(), steps) == want.end()) want.push_back(steps);
+    }
+    if (!want.empty() && n_full > 0 && !graph_capture_failed_) {
         // step 0 runs eagerly (pool warm-up, has_grad mask upload); then the SAME host code
         // is run under stream capture to record the op list of 1 step and of a chunk of
         // steps (one hipGraphLaunch per chunk amortises the ~10 us host cost of a replay)
         enqueue_steps(d_img, d_lab, d_idx, (int64_t)n, bs, 1);
         done = 1;
-        for (size_t steps : {chunk, (size_t)1}) {
-            if (steps == 0 || (steps > 1 && n_full < 2 * steps)) continue;
-            if (!graphs_.empty() && graphs_.back().first == steps) continue;
+        for (size_t steps : want) {
             TH(th_graph_begin(ctx));
             th_graph *g = nullptr;
             try {
@@ -740,6 +750,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             }
             graphs_.emplace_back(steps, g);
         }
+        std::sort(graphs_.begin(), graphs_.end(), [](const auto &x, const auto &y) { return x.first > y.first; });   // largest first
         graph_batch_ = bs;
         graph_key_ = key;
     }
