@@ -345,7 +345,7 @@ CONV_CASES = [  # n, c_in, h, w, c_out, pad  (reference CNN layers at a small ba
     (1, 3, 5, 5, 2, 1), (2, 5, 9, 6, 7, 1), (2, 4, 8, 8, 20, 0), (1, 1, 3, 3, 1, 0), (7, 9, 7, 7, 17, 1),
     # matrix-core path (C_in >= 8): ragged channel counts, pad 0, wide / tall / tiny planes, > 128 output channels
     (5, 8, 10, 12, 16, 1), (3, 13, 9, 11, 33, 0), (2, 16, 3, 40, 8, 1), (9, 24, 5, 5, 150, 1), (2, 40, 30, 30, 48, 0),
-    (3, 8, 3, 3, 4, 0), (1, 64, 1, 1, 10, 1),
+    (3, 8, 3, 3, 4, 0), (1, 64, 1, 1, 10, 1), (1, 8, 20, 120, 16, 1), (1, 8, 6, 130, 8, 1),   # widest matrix-core plane / VALU fallback
 ]
 
 
