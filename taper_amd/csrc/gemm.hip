@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ p
 // with dZ = dY (* (Y > 0) when MASKED).
 struct LinearBwdArgs {
     SmallArgs dw, dx;
-    int n_dw, n_dx, n_db, dw_tiles, dw_tiles_m, dx_tiles_n;
+    int n_dw, n_dx, n_db, dw_tiles, dw_tiles_m, dx_tiles_n, dw_kz;   // dw_tiles counts (tile, K slice) pairs
     const float *dy, *ymask;
     float *db;
     int batch, out_f, db_accum;
@@ -241,7 +241,10 @@ __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
     const int bid = blockIdx.x;
     if (bid < q.n_dw) {
         const int t = (bid & 7) * (q.n_dw >> 3) + (bid >> 3);
-        if (t < q.dw_tiles) small16_body<false, false, 4, MASKED>(q.dw, t % q.dw_tiles_m, t / q.dw_tiles_m, 0, red);
+        if (t < q.dw_tiles) {   // K slice innermost: the slices of one tile share its XCD (and its operand columns)
+            const int z = t % q.dw_kz, tile = t / q.dw_kz;
+            small16_body<false, false, 4, MASKED>(q.dw, tile % q.dw_tiles_m, tile / q.dw_tiles_m, z, red);
+        }
     } else if (bid < q.n_dw + q.n_dx) {
         const int t = bid - q.n_dw;
         small16_body<true, false, 4, MASKED>(q.dx, t / q.dx_tiles_n, t % q.dx_tiles_n, 0, red);
@@ -264,8 +267,21 @@ __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
         if (own && q.db_accum) old = q.db[c];
         float s = 0.f;
         if (c < q.out_f) {
-#pragma unroll 4
-            for (int r = wave; r < q.batch; r += 4) {
+            // 16 independent loads in flight per lane: at batch 1024 this role (256 rows per wave) was the
+            // kernel's long pole with 4
+            int r = wave;
+            for (; r + 60 < q.batch; r += 64) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const long idx = (long)(r + 4 * u) * q.out_f + c;
+                    v[u] = q.dy[idx];
+                    if (MASKED) v[u] = q.ymask[idx] > 0.f ? v[u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += v[u];
+            }
+            for (; r < q.batch; r += 4) {
                 const long idx = (long)r * q.out_f + c;
                 float v = q.dy[idx];
                 if (MASKED) v = q.ymask[idx] > 0.f ? v : 0.f;
@@ -574,7 +590,7 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
 static inline bool gemm_is_big(int m, int n, int k) {
     const long tiles128 = (long)ceil_div(m, BM) * ceil_div(n, BN);
     if (m < BM || n < BN || k < BK) return false;
-    return tiles128 >= 64 || tiles128 * tile128_kz(m, n, k) >= 48;   // deep K: split-K slices fill the chip
+    return tiles128 >= 64 || tiles128 * tile128_kz(m, n, k) >= 96;   // deep K: split-K slices fill the chip (below: 16x16 tiles with K slices)
 }
 
 // op(A)[i,k] = A[i*a_rs + k*a_cs], op(B)[k,j] = B[k*b_rs + j*b_cs]
@@ -677,7 +693,12 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
         LinearBwdArgs q{};
         const int dw_tm = ceil_div(out_features, 16), dw_tn = ceil_div(in_features, 16);
         const int dx_tm = ceil_div(batch, 16), dx_tn = ceil_div(in_features, 16);
-        q.dw_tiles = d_dw ? dw_tm * dw_tn : 0;
+        // deep batches: K slices of 256 rows per dW tile (a 16x16 tile over 1024 rows was the step's long pole at
+        // batch 1024), partial tiles summed in slice order by splitk_reduce, which also carries the fused Adam update
+        int dw_kz = 1;
+        if (d_dw && batch >= 512) dw_kz = batch / 256;
+        q.dw_kz = dw_kz;
+        q.dw_tiles = d_dw ? dw_tm * dw_tn * dw_kz : 0;
         q.n_dw = (q.dw_tiles + 7) & ~7;
         q.dw_tiles_m = dw_tm;
         q.n_dx = d_dx ? dx_tm * dx_tn : 0;
@@ -691,8 +712,14 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
         q.dx.a_vec = aligned16(d_dy) && (!d_relu_y || aligned16(d_relu_y)) && (out_features % 4 == 0);
         // The dX workgroups of this launch read W: updating W in the dW epilogue would race with
         // them, so with a dX output the W update runs as a slice kernel behind the launch.
-        const bool w_in_kernel = w_adam.p && !d_dx;
+        const bool w_in_kernel = w_adam.p && !d_dx && dw_kz == 1;
         if (w_in_kernel) q.dw.ep.adam = w_adam;
+        void *dw_part = nullptr;
+        if (dw_kz > 1) {
+            if (th_malloc(ctx, (size_t)dw_kz * out_features * in_features * sizeof(float), &dw_part)) return 1;
+            q.dw.partial = (float *)dw_part;
+            q.dw.kslice = ceil_div(ceil_div(batch, dw_kz), 16) * 16;
+        }
         q.db_adam = b_adam;
         q.dy = d_dy;
         q.ymask = d_relu_y;
@@ -707,6 +734,16 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
         if (d_relu_y) hipLaunchKernelGGL(linear_bwd_small<true>, dim3(grid), dim3(256), 0, ctx->stream, q);
         else hipLaunchKernelGGL(linear_bwd_small<false>, dim3(grid), dim3(256), 0, ctx->stream, q);
         TH_LAUNCH_CHECK();
+        if (dw_kz > 1) {
+            // this launch is behind the dX workgroups that read W (same stream), so the fused update may ride here
+            Epilogue ep = make_ep(1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f);
+            ep.adam = w_adam;
+            const long mn = (long)out_features * in_features;
+            hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, ctx->stream, (const float *)dw_part, d_dw, mn,
+                               in_features, dw_kz, ep);
+            TH_LAUNCH_CHECK();
+            return th_free(ctx, dw_part);
+        }
         if (w_adam.p && !w_in_kernel) return adam_slice(ctx, w_adam, d_dw, (int64_t)out_features * in_features);
         return 0;
     }

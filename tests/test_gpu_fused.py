@@ -104,7 +104,8 @@ def _adam_ref(O, p0, g, lr, t, wd=1e-4):
 
 
 @pytest.mark.parametrize("batch,inf,outf,with_dx", [(64, 784, 128, False), (64, 128, 64, True), (16, 40, 24, False),
-                                                    (4096, 784, 128, False), (3000, 256, 130, True)])   # large: Adam rides in the split-K reduce
+                                                    (4096, 784, 128, False), (3000, 256, 130, True),   # large: Adam rides in the split-K reduce
+                                                    (1024, 784, 128, False), (600, 64, 48, True)])      # mid: K slices + reduce carry the update
 def test_linear_bwd_adam_epilogue(ctx, O, batch, inf, outf, with_dx):
     """dW/db from the fused kernel + Adam applied in the epilogue == oracle grads followed by oracle Adam"""
     rng = np.random.default_rng(batch + inf + outf)

@@ -113,7 +113,8 @@ def test_sgemm_4096_sampled_rows(ctx, ta, tb):
 
 # ------------------------------------------------------------------ linear
 @pytest.mark.parametrize("batch,inf,outf", [(64, 784, 128), (64, 128, 10), (32, 784, 128), (1, 5, 3), (128, 128, 64), (256, 3136, 10),
-                                            (4096, 784, 128), (5000, 200, 130)])   # large batch: tile kernels, split-K dW
+                                            (4096, 784, 128), (5000, 200, 130),   # large batch: tile kernels, split-K dW
+                                            (1024, 784, 128), (700, 100, 30)])     # mid batch: K slices inside the one-launch backward
 @pytest.mark.parametrize("relu", [0, 1])
 def test_linear_fwd_bwd(ctx, O, batch, inf, outf, relu):
     rng = np.random.default_rng(batch + inf + outf)
