@@ -400,7 +400,18 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
 
 // Last pass of the multi-workgroup head (dW was summed over the slots by th_colsum): db = sum of
 // the workgroups' slots in slot order, then loss / n_correct, the step log and Adam's tick.
-__global__ __launch_bounds__(256) void head_finish_kernel(HeadArgs a, const float *__restrict__ part_db, int n_wg) {
+__global__ __launch_bounds__(256) void head_finish_kernel(HeadArgs a, const float *__restrict__ part_dw,
+                                                          const float *__restrict__ part_db, int n_wg) {
+    // part_dw != nullptr (few slots): every block also adds its share of dW over the slots, in slot order
+    if (part_dw) {
+        const int n_dw = a.c * a.k;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n_dw; i += gridDim.x * 256) {
+            float s = 0.f;
+            for (int g = 0; g < n_wg; ++g) s += part_dw[(long)g * n_dw + i];
+            a.dw[i] = s;
+        }
+    }
+    if (blockIdx.x != 0) return;
     __shared__ float sh[2][4];
     __shared__ float dbs[16][HEAD_CMAX];
     const int t = threadIdx.x;
@@ -506,9 +517,13 @@ extern "C" int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d
     hipLaunchKernelGGL(linear_xent_head_kernel, dim3(n_wg), dim3(HEAD_T), lds, ctx->stream, rows);
     TH_LAUNCH_CHECK();
     a.part_scalar = part_sc;
-    if (d_dw)   // dW[c][k] = sum over the workgroups' slots: a column sum of the [n_wg, c*k] slot matrix
+    if (d_dw && n_wg > 16) {   // dW[c][k] = sum over the workgroups' slots: a column sum of the [n_wg, c*k] slot matrix
         if (int rc = th_colsum(ctx, part_dw, d_dw, n_wg, (int)n_dw)) return rc;
-    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, a, (const float *)part_db, n_wg);
+        hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, a, (const float *)nullptr, (const float *)part_db, n_wg);
+    } else {                   // few slots: the finish launch adds them itself
+        hipLaunchKernelGGL(head_finish_kernel, dim3(d_dw ? ceil_div((long)n_dw, 256) : 1), dim3(256), 0, ctx->stream, a,
+                           d_dw ? (const float *)part_dw : (const float *)nullptr, (const float *)part_db, n_wg);
+    }
     TH_LAUNCH_CHECK();
     if (th_free(ctx, ws)) return 1;
     if (int rc = adam_slice(ctx, a.w_adam, d_dw, (int64_t)n_dw)) return rc;
