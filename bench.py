@@ -367,7 +367,8 @@ def main():
                         dominant_by="algorithmic bytes; by time the leader is %s (%.1f us)" % (by_time["kernel"], by_time["us_per_launch"]),
                         step_us_three_launch_chain=sk["step_us"], kernels=sk["kernels"])
         sweep = None
-        if key == "mlp_baseline" and world == 1 and not args.batch and not args.no_sweep:
+        # (not under rocprofv3: the trace of this command is for the headline workload's kernels only)
+        if key == "mlp_baseline" and world == 1 and not args.batch and not args.no_sweep and not under_profiler:
             sweep = batch_sweep(T, build_model, key, lr, args.dataset_size)
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
