@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 
@@ -721,6 +722,9 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             if (g.first == steps) return true;
         return false;
     };
+    // operator override: TAPER_DP_EAGER=1 keeps data-parallel steps out of hipGraphs (collectives launched eagerly)
+    if (comm && !graph_capture_failed_ && std::getenv("TAPER_DP_EAGER") && std::getenv("TAPER_DP_EAGER")[0] == '1')
+        graph_capture_failed_ = true;
     std::vector<size_t> want;
     for (size_t steps : {chunk, (size_t)1}) {
         if (steps == 0 || (steps > 1 && n_full < 2 * steps) || have(steps)) continue;
