@@ -221,6 +221,61 @@ def test_full_size_properties_config1():
         np.testing.assert_array_equal(a, b)
 
 
+def test_large_batch_step_matches_oracle():
+    """the throughput-bound path (split-K tile GEMMs, multi-workgroup head, slabbed column sums, Adam in the
+    split-K reduce) on one 16 384-row batch: loss, gradients and two Adam steps against the oracle"""
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(16384)
+    batch = 16384
+    spec = backends.nonzero_biases(backends.mlp_baseline(rng), rng)
+    x, y = backends.mnist_like(rng, batch)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    h_loss, h_acc, h_logits, h_grads = H.forward_backward(hm, x, y, (batch, 784))
+    o_loss, o_acc, o_logits, o_grads = Orc.forward_backward(om, x, y, (batch, 784))
+    np.testing.assert_allclose(h_logits, o_logits, rtol=RTOL, atol=RTOL * float(np.abs(o_logits).max()))
+    assert abs(h_loss - o_loss) <= RTOL * max(1.0, abs(o_loss))
+    assert abs(h_acc - o_acc) <= 2.0 / batch          # an argmax between two logits within rounding may flip
+    for i, (hg, og) in enumerate(zip(h_grads, o_grads)):
+        scale = float(np.abs(og).max())               # sums of 16 384 terms: absolute error scales with the largest entry
+        np.testing.assert_allclose(hg, og, rtol=RTOL, atol=2e-4 * scale, err_msg=f"param {i}")
+    import taper_amd as T
+    hopt, oopt = T.Adam(hm.parameters(), 1e-3, None, None, 1e-4), Orc.m.Adam(om.parameters(), 1e-3, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt)
+    loader = T.DataLoader(T.MNISTDataset.from_host(np.concatenate([x, x]), np.concatenate([y, y])), batch, False)
+    ep = tr.run_epoch(loader, T.Trainer.GRAPH)
+    ref = [om.train_step(oopt, x, y, (batch, 784))["loss"] for _ in range(2)]
+    np.testing.assert_allclose(ep["losses"], ref, rtol=3e-4)
+    for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+        np.testing.assert_allclose(hp.data(), op.data(), rtol=RTOL, atol=1e-3 * 5e-2, err_msg=f"param {i}")
+
+
+def test_full_batch_gradient_is_the_mean_of_shard_gradients():
+    """size-independent property at BASELINE's full size: the gradient of ONE 60 000-row step equals the
+    row-weighted mean of the gradients of four 15 000-row steps (what data parallelism relies on)"""
+    H = backends.get("hip")
+    rng = np.random.default_rng(3)
+    n = 60000
+    spec = backends.nonzero_biases(backends.mlp_baseline(rng), rng)
+    x, y = backends.mnist_like(rng, n)
+    model = H.sequential(spec)
+    full_loss, _, _, full = H.forward_backward(model, x, y, (n, 784))
+    acc = [np.zeros_like(g) for g in full]
+    loss_acc = 0.0
+    for s in range(4):
+        sl = slice(s * 15000, (s + 1) * 15000)
+        l, _, _, g = H.forward_backward(model, x[sl], y[sl], (15000, 784))
+        loss_acc += l / 4
+        for a, gi in zip(acc, g):
+            a += np.asarray(gi) / 4
+    assert abs(full_loss - loss_acc) <= 1e-5 * max(1.0, abs(full_loss))
+    for i, (f, a) in enumerate(zip(full, acc)):
+        # 1e-3 of the scale: among 7.7 M hidden activations a couple sit within rounding of 0, and the two GEMM paths
+        # (one 60 000-row problem vs four 15 000-row ones) round them to different sides -- each flipped ReLU mask moves
+        # one row of dW1 by ~1e-4 of its scale; a dropped tile or slice would be an O(1) error
+        np.testing.assert_allclose(f, a, rtol=RTOL, atol=1e-3 * float(np.abs(f).max()), err_msg=f"param {i}")
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
