@@ -239,7 +239,7 @@ def batch_sweep(T, build_model, key, lr, dataset_size, batches=(256, 1024, 4096,
         opt = T.Adam(model.parameters(), lr, None, None, 1e-4)
         trainer = T.Trainer(model, opt)
         loader = T.DataLoader(T.MNISTDataset.synthetic(dataset_size, seed=0x7461706572), b, False)
-        steps = max(40, min(400, 2_000_000 // b))
+        steps = min(80_000, max(200, 20_000_000 // b))   # >= 150 ms of work per point: short bursts run below the steady clocks
         run_steps(T, trainer, loader, max(steps // 8, 3))
         T.Device.sync()
         t0 = time.perf_counter()
