@@ -23,7 +23,7 @@ def _run(name, *flags):
 
 def test_examples_build_without_a_gpu():
     subprocess.check_call(["make", "-C", str(ROOT / "examples")])
-    assert (BIN / "train_mnist").exists() and (BIN / "train_mnist_cnn").exists()
+    assert (BIN / "train_mnist").exists() and (BIN / "train_mnist_cnn").exists() and (BIN / "cabi_step").exists()
 
 
 @pytest.mark.gpu
@@ -38,3 +38,19 @@ def test_train_mnist_example_runs(mode):
 def test_train_mnist_cnn_example_runs(mode):
     losses = _run("train_mnist_cnn", "--epochs", "2", "--train-n", "1024", "--test-n", "512", "--batch-size", "128", *mode)
     assert len(losses) == 2 and all(l == l and l < 5.0 for l in losses)
+
+
+def test_boundary_headers_are_plain_c11():
+    """include/*.h is the drop-in boundary: it must compile as C (extern "C", plain pointers and sizes)"""
+    for h in ("taper_hip.h", "taper_host.h"):
+        subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-x", "c", "-fsyntax-only", "-"],
+                       input=f'#include "{ROOT}/include/{h}"\n', text=True, check=True)
+
+
+@pytest.mark.gpu
+def test_plain_c_client_trains_through_the_abi():
+    """examples/cabi_step.c: the fused 3-launch MLP step driven from C through th_* alone"""
+    subprocess.check_call(["make", "-s", "-C", str(ROOT / "examples")])
+    out = subprocess.run([str(BIN / "cabi_step")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "loss decreased" in out.stdout and "adam t = 50" in out.stdout
