@@ -1,0 +1,55 @@
+"""Randomly drawn shapes (hypothesis, derandomised: the same examples on every run) through the kernel
+parity checks of tests/test_gpu_kernels.py -- ragged sizes, every padding / layout / fusion flag --
+so that the hand-picked cases there are not the only ones that ever ran."""
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from tests import test_gpu_kernels as K
+
+pytestmark = pytest.mark.gpu
+ctx, O = K.ctx, K.O          # the module-scoped fixtures
+CFG = dict(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@settings(**CFG)
+@given(batch=st.integers(1, 300), inf=st.integers(1, 260), outf=st.integers(1, 48), relu=st.integers(0, 1))
+def test_linear_random_shapes(ctx, O, batch, inf, outf, relu):
+    K.test_linear_fwd_bwd(ctx, O, batch, inf, outf, relu)
+
+
+@settings(**CFG)
+@given(ta=st.integers(0, 1), tb=st.integers(0, 1), m=st.integers(1, 200), n=st.integers(1, 200), k=st.integers(1, 700),
+       ab=st.sampled_from([(1.0, 0.0), (1.0, 1.0), (0.5, -2.0)]))
+def test_sgemm_random_shapes(ctx, O, ta, tb, m, n, k, ab):
+    K.test_sgemm(ctx, O, ta, tb, m, n, k, ab[0], ab[1])
+
+
+@settings(**CFG)
+@given(n=st.integers(1, 6), c_in=st.integers(1, 40), h=st.integers(3, 24), w=st.integers(3, 30), c_out=st.integers(1, 70),
+       pad=st.integers(0, 1), layout=st.integers(0, 1), relu=st.integers(0, 1))
+def test_conv3x3_random_shapes(ctx, O, n, c_in, h, w, c_out, pad, layout, relu):
+    K.test_conv3x3_fwd(ctx, O, n, c_in, h, w, c_out, pad, layout, relu)
+
+
+@settings(**{**CFG, "max_examples": 15})
+@given(n=st.integers(1, 40), c_in=st.integers(1, 24), hw=st.integers(3, 16), c_out=st.integers(1, 40), layout=st.integers(0, 1))
+def test_conv3x3_backward_random_shapes(ctx, O, n, c_in, hw, c_out, layout):
+    K.test_conv3x3_bwd_full_mode(ctx, O, n, c_in, hw, hw, c_out, layout)
+
+
+@settings(**CFG)
+@given(n=st.integers(1, 4), c=st.integers(1, 9), h=st.integers(3, 15), w=st.integers(3, 15), kh=st.integers(2, 3), kw=st.integers(2, 3),
+       sh=st.integers(1, 3), sw=st.integers(1, 3), ph=st.integers(0, 1), pw=st.integers(0, 1))
+def test_pools_random_geometry(ctx, O, n, c, h, w, kh, kw, sh, sw, ph, pw):
+    if ph > kh // 2 or pw > kw // 2 or h + 2 * ph < kh or w + 2 * pw < kw:
+        return                                   # not a valid pooling window (the reference asserts the same)
+    # (windows of at least 2x2: the checked-in case plants a 2x2 NaN block, and a window that is ALL NaN without
+    # containing element (0,0,0,0) is the one documented deviation of the gather-form backward)
+    K.test_maxpool_bit_exact(ctx, O, n, c, h, w, (kh, kw), (sh, sw), (ph, pw))
+    K.test_avgpool(ctx, O, n, c, h, w, (kh, kw), (sh, sw), (ph, pw))
+
+
+@settings(**CFG)
+@given(batch=st.integers(1, 400), classes=st.integers(1, 40))
+def test_softmax_xent_random_shapes(ctx, O, batch, classes):
+    K.test_softmax_xent(ctx, O, batch, classes)
