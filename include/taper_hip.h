@@ -139,7 +139,8 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
  * 271-290) AND the backward products for an upstream gradient of exactly 1:
  *   dlogits = (softmax - onehot)/B,  d_dw[C,in] = dlogits^T . H,  d_db[C] = colsum(dlogits),
  *   d_dh[B,in] = dlogits . W   (the ReLU mask of the previous layer is applied by ITS backward).
- * Requires classes <= 16, in_features <= 256, batch <= 4096.  Nullable:
+ * Requires classes <= 16, in_features <= 256.  Up to 64 rows: ONE workgroup, one launch; above: up to 256
+ * workgroups each own a row range and write dW / db / loss partials, a finish pass adds them in order.  Nullable:
  * d_bias, d_logits, d_ncorrect, d_dh, d_dw, d_db, metrics/state, d_adam_tick,
  * w_fuse, b_fuse.  d_adam_tick (int32[2], th_adam_step's d_t): t += 1 is done
  * here (optim.rs:84) so that the fused updates of this step see the new t.

@@ -20,6 +20,10 @@
 //   db       [16] += column sums of dl
 // Then: loss / count / step log / Adam tick by thread 0, dW / db out (+ fused
 // Adam update of W and b: every read of W in this launch came from the LDS copy).
+//
+// Above 64 rows the same kernel runs as up to 256 workgroups, each owning a row range (logits,
+// softmax, dlogits and dH are row-local); dW / db / {nll, hits} go to per-workgroup slots and
+// head_finish_kernel (+ th_colsum for many slots) adds them in slot order: deterministic, no atomics.
 #include "adam_dev.h"
 
 namespace th {
