@@ -489,9 +489,9 @@ static int launch_small(th_ctx *ctx, const float *A, const float *B, float *C, i
     // grid-level split with a second reduce pass.
     int kz = 1;
     const bool wide = tiles < 256 && k >= 256;
-    if (tiles < 64 && k >= 8192) {
+    if (tiles < 64 && k >= 2048) {   // e.g. the simple CNN's Linear(3136, 10) at batch 256: 16 tiles
         kz = (int)((256 + tiles - 1) / tiles);
-        const int kz_max = k / 1024;
+        const int kz_max = k / 512;
         if (kz > kz_max) kz = kz_max;
         if (kz < 1) kz = 1;
     }
