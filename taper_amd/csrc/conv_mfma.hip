@@ -43,19 +43,20 @@ struct ConvMfmaArgs {
     int relu;
 };
 
-template <int CT, bool ACCUM>   // CT = co_b / 16
+template <int CT, bool ACCUM, int CIT>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CO_B = 16 * CT;
-    constexpr int WQ = MF_CI * 9 * CO_B / 4;                   // float4 quads in the weight slab
+    constexpr int KS = (CIT * 9 + 3) / 4;                      // k-steps per pass: 18, or 3 (k = 9 padded to 12)
+    constexpr int WQ = KS * 4 * CO_B / 4;                      // float4 quads in the weight slab (rows past 9*CIT are zero)
     constexpr int WPT = (WQ + 255) / 256;                      // quads per thread per pass
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l16 = lane & 15, g4 = lane >> 4;
     const int wp = a.w_out + 2, rp = a.rows_t + 2;           // patch pitch / rows (input window of the band)
     const int img_stride = rp * wp, ci_stride = a.img_t * img_stride;
-    const int patch_n = MF_CI * ci_stride;
-    float *patch = lds;                                        // [MF_CI][img_t][rp][wp]
-    float *wsl = lds + ((patch_n + 3) & ~3);                   // [72][CO_B], 16-B aligned
+    const int patch_n = CIT * ci_stride;
+    float *patch = lds;                                        // [CIT][img_t][rp][wp], then one zero float
+    float *wsl = lds + ((patch_n + 4) & ~3);                   // [4 KS][CO_B], 16-B aligned
     const int grp = blockIdx.x / a.bands, band = blockIdx.x % a.bands;
     const int img0 = grp * a.img_t, oh0 = band * a.rows_t;
     const int co0 = blockIdx.y * CO_B;
@@ -78,12 +79,20 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
         pix_off[q] = il * img_stride + r * wp + c;
     }
     // LDS offset of tap k = 4s + g4 relative to the window corner, for the 18 k-steps of a pass
-    int koff[MF_KS];
+    int koff[KS];
 #pragma unroll
-    for (int s = 0; s < MF_KS; ++s) {
+    for (int s = 0; s < KS; ++s) {
         const int kk = 4 * s + g4, cl = kk / 9, tap = kk % 9;
         koff[s] = cl * ci_stride + (tap / 3) * wp + (tap % 3);
     }
+    // padded k (>= 9*CIT, only when CIT = 1): the weight rows are zero, and the pixel operand must be a finite
+    // number too (0 * NaN would poison the sum): point it at the zero float behind the patch
+    int pix_off_pad[2] = {pix_off[0], pix_off[1]};
+    if (CIT * 9 % 4 != 0 && 4 * (KS - 1) + g4 >= CIT * 9) {
+        koff[KS - 1] = 0;
+        pix_off_pad[0] = pix_off_pad[1] = patch_n;
+    }
+    if (threadIdx.x == 0) patch[patch_n] = 0.f;
     // Staging plan, fixed for the whole kernel (only the channel base moves between passes): patch
     // element e = t + 256 j -> global offset within channel block 0 (or -1: halo / tail -> zero) and
     // its local channel; weight quad u = t + 256 j -> row kk and column quad.
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
             const int u = t + 256 * j, kk = u / (CO_B / 4), cq = (u % (CO_B / 4)) * 4;                           \
             const int k = (CB) * 9 + kk, co = co0 + cq;                                                          \
             wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
-            if (u < WQ && k < a.c_in * 9 && co + 3 < a.w_cols)                                                   \
+            if (u < WQ && kk < CIT * 9 && k < a.c_in * 9 && co + 3 < a.w_cols)                                   \
                 wv[j] = *reinterpret_cast<const float4 *>(a.w + (long)k * a.w_ld + co);                          \
         }                                                                                                        \
     }
@@ -142,14 +151,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     TH_MF_LOAD(0)
     TH_MF_STORE()
     __syncthreads();
-    for (int cb = 0; cb < a.c_in; cb += MF_CI) {
-        const bool more = cb + MF_CI < a.c_in;
-        if (more) TH_MF_LOAD(cb + MF_CI)
+    for (int cb = 0; cb < a.c_in; cb += CIT) {
+        const bool more = cb + CIT < a.c_in;
+        if (more) TH_MF_LOAD(cb + CIT)
         // ---- 18 k-steps: per step 2 pixel fragments and CT weight fragments feed 2*CT MFMAs ----
 #pragma unroll
-        for (int s = 0; s < MF_KS; ++s) {
-            const float b0 = patch[pix_off[0] + koff[s]];
-            const float b1 = patch[pix_off[1] + koff[s]];
+        for (int s = 0; s < KS; ++s) {
+            const float b0 = patch[(s == KS - 1 ? pix_off_pad[0] : pix_off[0]) + koff[s]];
+            const float b1 = patch[(s == KS - 1 ? pix_off_pad[1] : pix_off[1]) + koff[s]];
             const float *wk = wsl + (4 * s + g4) * CO_B + l16;
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
 }
 
 // images x rows per workgroup: the fullest tiling of <= 128 pixels by whole output rows of one or more images
-static void conv_mfma_plan(int h_out, int w_out, int n, int *img_t, int *rows_t) {
+static void conv_mfma_plan(int h_out, int w_out, int n, int *img_t, int *rows_t, int cit = MF_CI) {
     int best_fill = -1;
     *img_t = 1;
     *rows_t = 1;
@@ -196,7 +205,7 @@ static void conv_mfma_plan(int h_out, int w_out, int n, int *img_t, int *rows_t)
         if (r * w_out > MF_PX_MAX) break;
         int im = MF_PX_MAX / (r * w_out);
         if (im > n) im = n;
-        const int patch_cap = MF_PPT * 256 / (MF_CI * (r + 2) * (w_out + 2));   // the staged patch is <= 12 floats per thread
+        const int patch_cap = MF_PPT * 256 / (cit * (r + 2) * (w_out + 2));   // the staged patch is <= 12 floats per thread
         if (im > patch_cap) im = patch_cap;
         if (im < 1) continue;
         const int bands = ceil_div(h_out, r);
@@ -213,7 +222,7 @@ static void conv_mfma_plan(int h_out, int w_out, int n, int *img_t, int *rows_t)
 
 bool conv3x3_mfma_supported(int c_in, int h, int w, int pad) {
     const int w_out = w + 2 * pad - 2, h_out = h + 2 * pad - 2;
-    return c_in >= MF_CI && w_out >= 1 && h_out >= 1 && MF_CI * 3 * (w_out + 2) <= MF_PPT * 256;
+    return (c_in >= MF_CI || c_in == 1) && w_out >= 1 && h_out >= 1 && MF_CI * 3 * (w_out + 2) <= MF_PPT * 256;
 }
 
 // y (+)= conv3x3(x, w) [+ bias, relu]; weights [9*c_in][w_ld] with columns [0, w_cols) readable, rows 16-B aligned
@@ -226,7 +235,8 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     a.h_out = h + 2 * pad - 2;
     a.w_out = w_in + 2 * pad - 2;
     a.w_ld = w_ld; a.w_cols = w_cols;
-    conv_mfma_plan(a.h_out, a.w_out, n, &a.img_t, &a.rows_t);
+    const int cit = c_in == 1 ? 1 : MF_CI;
+    conv_mfma_plan(a.h_out, a.w_out, n, &a.img_t, &a.rows_t, cit);
     a.bands = ceil_div(a.h_out, a.rows_t);
     a.relu = relu;
     const int co_tiles = ceil_div(c_out, 16);
@@ -234,10 +244,12 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     // and wide layers get twice the workgroups (conv5 of the reference CNN: 232 instead of 116)
     const int ct = co_tiles >= 4 ? 4 : (co_tiles >= 2 ? 2 : 1);
     a.co_b = ct * 16;
-    const size_t patch_n = (size_t)MF_CI * a.img_t * (a.rows_t + 2) * (a.w_out + 2);
-    const size_t lds = (((patch_n + 3) & ~(size_t)3) + (size_t)MF_CI * 9 * a.co_b) * sizeof(float);
+    const size_t patch_n = (size_t)cit * a.img_t * (a.rows_t + 2) * (a.w_out + 2);
+    const size_t lds = (((patch_n + 4) & ~(size_t)3) + (size_t)((cit * 9 + 3) / 4 * 4) * a.co_b) * sizeof(float);
     dim3 grid(ceil_div(n, a.img_t) * a.bands, ceil_div(c_out, a.co_b));
-#define TH_MF(CTV, ACC) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC>), grid, dim3(256), lds, ctx->stream, a);
+#define TH_MF(CTV, ACC)                                                                                          \
+    if (cit == 1) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, 1>), grid, dim3(256), lds, ctx->stream, a);         \
+    else hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, MF_CI>), grid, dim3(256), lds, ctx->stream, a);
 #define TH_MF_CT(ACC)                                  \
     switch (ct) {                                      \
         case 4: TH_MF(4, ACC) break;                   \

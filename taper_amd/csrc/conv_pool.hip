@@ -614,7 +614,7 @@ int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, floa
     TH_REQUIRE(ctx && d_x && d_gy && d_gw, "th_conv3x3_bwd_weight: null argument");
     TH_REQUIRE(pad == 0 || pad == 1, "th_conv3x3_bwd_weight: pad must be 0 or 1");
     const int h_out = h + 2 * pad - 2, w_out = w + 2 * pad - 2;
-    if (conv3x3_mfma_supported(c_in, h, w, pad) && (long)n * h_out * w_out >= 2048)   // enough pixels to contract over
+    if (c_in >= 8 && conv3x3_mfma_supported(c_in, h, w, pad) && (long)n * h_out * w_out >= 2048)   // enough channels and pixels to contract over
         return conv3x3_wgrad_mfma_launch(ctx, d_x, d_gy, d_gw, n, c_in, h, w, c_out, pad, weight_layout);
     int slabs = 1;
     if ((long)c_out * c_in < 512 && (long)n * h_out * w_out >= 8192) {   // few (co, ci) pairs, many pixels (conv1): split the images
