@@ -18,6 +18,8 @@
 // the zero-haloed input patch [8][IMG][R+2][W_out+2] and the weight slab [72][CO_B].  The global
 // loads of pass p+1 are issued before the MFMAs of pass p and parked in registers (one round trip per
 // pass, hidden behind 18 k-steps), then written to the single LDS buffer between two barriers.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace th {
@@ -25,11 +27,24 @@ namespace th {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int MF_CI = 8;              // input channels per pass  -> 72 k = 18 MFMA k-steps
-constexpr int MF_KS = MF_CI * 9 / 4;  // 18
 constexpr int MF_PX_MAX = 128;        // pixels per workgroup (8 tiles of 16)
-constexpr int MF_CO_MAX = 64;         // output channels per workgroup (4 tiles of 16)
 
 constexpr int MF_PPT = 12;            // patch elements per thread per pass (patch <= 3072 floats)
+
+// Exact quotient / remainder of small non-negative ints (e < 2^22, d >= 1) through one float multiply and one
+// correction step: the per-thread staging plans below need ~40 divisions by launch-time constants, and a
+// 32-bit integer division is ~35 VALU instructions on gfx950.
+struct FastDiv {
+    int d;
+    float inv;
+    __host__ __device__ explicit FastDiv(int dd) : d(dd), inv(1.0f / (float)dd) {}
+    __device__ __forceinline__ void divmod(int e, int &q, int &r) const {
+        q = (int)((float)e * inv);
+        r = e - q * d;
+        if (r < 0) { --q; r += d; }
+        else if (r >= d) { ++q; r -= d; }
+    }
+};
 
 struct ConvMfmaArgs {
     const float *x, *w, *bias;
@@ -43,6 +58,13 @@ struct ConvMfmaArgs {
     int relu;
 };
 
+#ifdef TH_PROFILE
+__device__ long long g_conv_prof[8];
+#define CONV_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 300 && blockIdx.y == 0) g_conv_prof[i] = wall_clock64(); } while (0)
+#else
+#define CONV_STAMP(i) do { } while (0)
+#endif
+
 template <int CT, bool ACCUM, int CIT>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -50,6 +72,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     constexpr int KS = (CIT * 9 + 3) / 4;                      // k-steps per pass: 18, or 3 (k = 9 padded to 12)
     constexpr int WQ = KS * 4 * CO_B / 4;                      // float4 quads in the weight slab (rows past 9*CIT are zero)
     constexpr int WPT = (WQ + 255) / 256;                      // quads per thread per pass
+    CONV_STAMP(0);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l16 = lane & 15, g4 = lane >> 4;
     const int wp = a.w_out + 2, rp = a.rows_t + 2;           // patch pitch / rows (input window of the band)
@@ -64,18 +87,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     const int px_per_img = a.rows_t * a.w_out;
     const int m_wg = a.img_t * px_per_img;                     // <= 128 (rows past rows_here are discarded)
 
+    const FastDiv d_pxi(px_per_img), d_wout(a.w_out), d_cis(ci_stride), d_ims(img_stride), d_wp(wp);
     // this lane's B column in its two pixel tiles: LDS offset of the window's top-left corner
     int pix_off[2];
-    bool pix_ok[2];
-    int pix_img[2], pix_r[2], pix_c[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int p = (wave + 4 * q) * 16 + l16;
-        const bool ok = p < m_wg;
-        const int il = ok ? p / px_per_img : 0, rem = ok ? p % px_per_img : 0;
-        const int r = rem / a.w_out, c = rem % a.w_out;
-        pix_img[q] = il; pix_r[q] = r; pix_c[q] = c;
-        pix_ok[q] = ok && r < rows_here && img0 + il < a.n;
+        int il, rem, r, c;
+        d_pxi.divmod(p < m_wg ? p : 0, il, rem);
+        d_wout.divmod(rem, r, c);
         pix_off[q] = il * img_stride + r * wp + c;
     }
     // LDS offset of tap k = 4s + g4 relative to the window corner, for the 18 k-steps of a pass
@@ -104,9 +124,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
         const int e = t + 256 * j;
         p_goff[j] = -1;
         if (e < patch_n) {
-            const int cl = e / ci_stride, r1 = e % ci_stride;
-            const int il = r1 / img_stride, r2 = r1 % img_stride;
-            const int rr = r2 / wp, cc = r2 % wp;
+            int cl, r1, il, r2, rr, cc;
+            d_cis.divmod(e, cl, r1);
+            d_ims.divmod(r1, il, r2);
+            d_wp.divmod(r2, rr, cc);
             const int img = img0 + il, ih = oh0 + rr - 1 + shift, iw = cc - 1 + shift;
             if (img < a.n && ih >= 0 && ih < a.h && iw >= 0 && iw < a.w_in)
                 p_goff[j] = (int)((((((long)il * a.c_in + cl) * a.h + ih) * a.w_in + iw) << 3) | cl);   // relative to image img0, channel cb
@@ -127,14 +148,17 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
 #define TH_MF_LOAD(CB)                                                                                           \
     {                                                                                                            \
         const float *xc = xbase + (long)(CB) * chan;                                                             \
-        _Pragma("unroll") for (int j = 0; j < MF_PPT; ++j)                                                       \
-            pv[j] = (p_goff[j] >= 0 && (CB) + (p_goff[j] & 7) < a.c_in) ? xc[p_goff[j] >> 3] : 0.f;               \
+        _Pragma("unroll") for (int j = 0; j < MF_PPT; ++j) {   /* always-valid address + select: no branch per load */   \
+            const bool ok = p_goff[j] >= 0 && (CB) + (p_goff[j] & 7) < a.c_in;                                    \
+            const float v = xc[ok ? (p_goff[j] >> 3) : 0];                                                        \
+            pv[j] = ok ? v : 0.f;                                                                                \
+        }                                                                                                        \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                        \
             const int u = t + 256 * j, kk = u / (CO_B / 4), cq = (u % (CO_B / 4)) * 4;                           \
             const int k = (CB) * 9 + kk, co = co0 + cq;                                                          \
-            wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
-            if (u < WQ && kk < CIT * 9 && k < a.c_in * 9 && co + 3 < a.w_cols)                                   \
-                wv[j] = *reinterpret_cast<const float4 *>(a.w + (long)k * a.w_ld + co);                          \
+            const bool ok = u < WQ && kk < CIT * 9 && k < a.c_in * 9 && co + 3 < a.w_cols;                       \
+            const float4 v = *reinterpret_cast<const float4 *>(a.w + (ok ? (long)k * a.w_ld + co : 0));          \
+            wv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
         }                                                                                                        \
     }
 #define TH_MF_STORE()                                                                                            \
@@ -148,9 +172,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
             if (u < WQ) *reinterpret_cast<float4 *>(wsl + 4 * u) = wv[j];                                        \
         }                                                                                                        \
     }
+    CONV_STAMP(1);
     TH_MF_LOAD(0)
     TH_MF_STORE()
     __syncthreads();
+    CONV_STAMP(2);
     for (int cb = 0; cb < a.c_in; cb += CIT) {
         const bool more = cb + CIT < a.c_in;
         if (more) TH_MF_LOAD(cb + CIT)
@@ -175,12 +201,22 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     }
 #undef TH_MF_LOAD
 #undef TH_MF_STORE
+    CONV_STAMP(3);
 
-    // ---- epilogue: bias + ReLU (tensor.rs:2005-2025, nn.rs:433-490), NCHW store ----
+    // ---- epilogue: bias + ReLU (tensor.rs:2005-2025, nn.rs:433-490), NCHW store straight from the D tiles: lane
+    //      (l16, g4) holds pixel px0 + l16 of channels co0 + 4*g4 + i.  (Staging the tiles through LDS for row-
+    //      contiguous stores was measured and is no faster: the tail of a workgroup is the MFMA queue draining.) ----
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        if (!pix_ok[q]) continue;
-        const int img = img0 + pix_img[q], oh = oh0 + pix_r[q], ow = pix_c[q];
+        const int p = (wave + 4 * q) * 16 + l16;
+        int il = 0, rem = 0, r = 0, c = 0;
+        if (p < m_wg) {
+            d_pxi.divmod(p, il, rem);
+            d_wout.divmod(rem, r, c);
+        }
+        if (!(p < m_wg && r < rows_here && img0 + il < a.n)) continue;
+        float *ypx = a.y + (((long)(img0 + il) * a.c_out) * a.h_out + (oh0 + r)) * a.w_out + c;
+        const long ochan = (long)a.h_out * a.w_out;
 #pragma unroll
         for (int j = 0; j < CT; ++j)
 #pragma unroll
@@ -189,11 +225,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
                 if (co >= a.c_out) continue;
                 float v = acc[q][j][i] + (a.bias ? a.bias[co] : 0.f);
                 if (a.relu) v = v > 0.f ? v : 0.f;
-                float *dst = a.y + (((long)img * a.c_out + co) * a.h_out + oh) * a.w_out + ow;
+                float *dst = ypx + (long)co * ochan;
                 if (ACCUM) *dst += v;
                 else *dst = v;
             }
     }
+    CONV_STAMP(4);
 }
 
 // images x rows per workgroup: the fullest tiling of <= 128 pixels by whole output rows of one or more images
@@ -242,7 +279,9 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     const int co_tiles = ceil_div(c_out, 16);
     // <= 64 output channels per workgroup: 32 accumulator + 18 prefetch VGPRs keep 3 workgroups per CU,
     // and wide layers get twice the workgroups (conv5 of the reference CNN: 232 instead of 116)
-    const int ct = co_tiles >= 4 ? 4 : (co_tiles >= 2 ? 2 : 1);
+    int ct = co_tiles >= 4 ? 4 : (co_tiles >= 2 ? 2 : 1);
+    static const int ct_env = getenv("TAPER_CONV_CT") ? atoi(getenv("TAPER_CONV_CT")) : 0;   // tuning probe
+    if (ct_env && ct > ct_env) ct = ct_env;
     a.co_b = ct * 16;
     const size_t patch_n = (size_t)cit * a.img_t * (a.rows_t + 2) * (a.w_out + 2);
     const size_t lds = (((patch_n + 4) & ~(size_t)3) + (size_t)((cit * 9 + 3) / 4 * 4) * a.co_b) * sizeof(float);
@@ -481,3 +520,11 @@ int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, floa
 }
 
 }  // namespace th
+
+#ifdef TH_PROFILE
+extern "C" int th_debug_conv_prof(th_ctx *ctx, long long *h_out8) {
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out8, HIP_SYMBOL(th::g_conv_prof), 8 * sizeof(long long)));
+    return 0;
+}
+#endif
