@@ -110,13 +110,13 @@ def run_steps(T, trainer, loader, steps):
     return samples
 
 
-class _AdamFuse(C.Structure):      # include/taper_hip.h: th_adam_fuse
-    _fields_ = [("d_p", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_t", C.c_void_p), ("d_lr", C.c_void_p),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
 
 
-class _AdamSlice(C.Structure):     # include/taper_hip.h: th_adam_slice
-    _fields_ = [("d_g", C.c_void_p), ("n", C.c_int64), ("f", _AdamFuse)]
+
+
+def hip_structs():
+    from taper_amd import hip   # imported lazily: bench.py must not load the native library before the rendezvous is up
+    return hip
 
 
 class StepKernels:
@@ -149,12 +149,12 @@ class StepKernels:
         self.loss, self.nc = ctx.empty(1), ctx.empty(1)
         self.metrics, self.state = ctx.zeros(2 * 4096), ctx.upload(np.zeros(2, np.int64))
         self.tick, self.lr = ctx.upload(np.array([0, 0], np.int32)), ctx.upload(np.array([1e-3], np.float32))
-        adam = lambda p, m, v, off: _AdamFuse(int(p) + 4 * off, int(m) + 4 * off, int(v) + 4 * off, int(self.tick), int(self.lr),
+        adam = lambda p, m, v, off: hip_structs().AdamFuse(int(p) + 4 * off, int(m) + 4 * off, int(v) + 4 * off, int(self.tick), int(self.lr),
                                                0.9, 0.999, 1e-8, 1e-4)
         self.w1f, self.b1f = adam(self.p1, self.m1, self.v1, 0), adam(self.p1, self.m1, self.v1, HID * IN)
-        self.carried = (_AdamSlice * 2)(
-            _AdamSlice(int(self.g2), OUT * HID, adam(self.p2, self.m2, self.v2, 0)),
-            _AdamSlice(int(self.g2) + 4 * OUT * HID, OUT, adam(self.p2, self.m2, self.v2, OUT * HID)))
+        self.carried = (hip_structs().AdamSlice * 2)(
+            hip_structs().AdamSlice(int(self.g2), OUT * HID, adam(self.p2, self.m2, self.v2, 0)),
+            hip_structs().AdamSlice(int(self.g2) + 4 * OUT * HID, OUT, adam(self.p2, self.m2, self.v2, OUT * HID)))
         b4 = 4 * B
         self.kernels = [
             ("sgemm_small16<true, true, 16>", "K1 layer-1 forward (+bias, ReLU)", 4 * (IN * B + HID * IN + HID + HID * B), 2 * B * IN * HID),

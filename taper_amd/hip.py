@@ -12,6 +12,17 @@ import numpy as np
 from ._lib import HIP_PROTOS, hip, th_check
 
 
+class AdamFuse(C.Structure):
+    """include/taper_hip.h: th_adam_fuse (device pointers as integers)"""
+    _fields_ = [("d_p", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_t", C.c_void_p), ("d_lr", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+class AdamSlice(C.Structure):
+    """include/taper_hip.h: th_adam_slice"""
+    _fields_ = [("d_g", C.c_void_p), ("n", C.c_int64), ("f", AdamFuse)]
+
+
 class DevBuf:
     """A device allocation from the ctx pool (freed on garbage collection)."""
 

@@ -8,14 +8,12 @@ import numpy as np
 import pytest
 
 from tests import backends
+from taper_amd.hip import AdamFuse, AdamSlice   # ctypes mirrors of th_adam_fuse / th_adam_slice
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-class AdamFuse(C.Structure):  # include/taper_hip.h: th_adam_fuse
-    _fields_ = [("d_p", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_t", C.c_void_p), ("d_lr", C.c_void_p),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
 
 
 @pytest.fixture(scope="module")
@@ -146,8 +144,6 @@ def test_fused_bwd_rejects_accumulating_into_fused_grad(ctx):
         ctx.call("th_linear_bwd_adam", z, z, z, None, None, z, None, 8, 8, 8, 2, C.byref(f), None)
 
 
-class AdamSlice(C.Structure):  # include/taper_hip.h: th_adam_slice
-    _fields_ = [("d_g", C.c_void_p), ("n", C.c_int64), ("f", AdamFuse)]
 
 
 @pytest.mark.parametrize("carrier", ["linear_bwd", "standalone"])

@@ -12,11 +12,9 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from taper_amd import hip  # noqa: E402
+from taper_amd.hip import AdamFuse  # noqa: E402
 
 
-class AdamFuse(C.Structure):
-    _fields_ = [("d_p", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_t", C.c_void_p), ("d_lr", C.c_void_p),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
 
 
 def chain_us(ctx, fn, n=100, reps=20):

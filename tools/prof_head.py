@@ -9,6 +9,7 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from taper_amd import hip  # noqa: E402
+from taper_amd.hip import AdamFuse  # noqa: E402
 from taper_amd._lib import hip as lib  # noqa: E402
 
 ctx = hip.Ctx(0)
@@ -19,9 +20,6 @@ rng = np.random.default_rng(0)
 h, w, b = ctx.upload(rng.random((B, K), np.float32)), ctx.upload(rng.random((Cc, K), np.float32)), ctx.upload(rng.random(Cc, np.float32))
 y = ctx.upload(rng.integers(0, Cc, B).astype(np.float32))
 loss, nc, dh, dw, db = ctx.empty(1), ctx.empty(1), ctx.empty(B * K), ctx.empty(Cc * K), ctx.empty(Cc)
-class AdamFuse(C.Structure):
-    _fields_ = [("d_p", C.c_void_p), ("d_m", C.c_void_p), ("d_v", C.c_void_p), ("d_t", C.c_void_p), ("d_lr", C.c_void_p),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
 
 
 FUSE = "--fuse" in sys.argv
