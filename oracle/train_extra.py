@@ -3,8 +3,10 @@ around the training step that SURVEY.md 8(f) ranks "next": LR schedulers and Ada
 cross_entropy_loss_onehot and Dropout (src/loss.rs, src/nn.rs), Metrics text and the text checkpoint
 (src/train.rs).  Each function cites the reference lines it follows.  Only tests/ may import this.
 
-Pinning: the schedulers against the reference's own unit-test expectations where it has them
-(src/optim.rs tests: none for schedulers -> closed forms checked in tests/test_train_extra.py);
+Pinning: the reference has no tests for the schedulers, bce_loss or the one-hot cross-entropy -> "parity unpinned by
+reference tests"; they are cross-checked against torch-CPU vectors (tests/golden/losses_extra.npz, generator committed:
+StepLR / ExponentialLR / CosineAnnealingLR sequences, F.binary_cross_entropy, the one-hot form of F.cross_entropy) and closed
+forms in tests/test_train_extra.py;
 the number format against Rust's documented `Display for f32` outputs (shortest round-trip digits,
 never an exponent: 1 -> "1", f32::MAX -> "340282350000000000000000000000000000000",
 f32::MIN_POSITIVE -> "0.000000000000000000000000000000000000011754944")."""

@@ -86,7 +86,46 @@ def misc_case(name):
                         colsum=f32(x.astype(np.float64).sum(0)), rowmax=x.max(1), rowargmax=f32(x.argmax(1)))
 
 
+def extra_cases():
+    """SURVEY.md 8(f) rows 2-4 (added later; own generator so the fixtures above keep their bytes):
+      bce_loss                  == F.binary_cross_entropy(reduction="mean") for p in (1e-6, 1 - 1e-6)   (loss.rs:6-73)
+      cross_entropy_loss_onehot == -(t * log_softmax(x)).sum() / B with one-hot rows                     (loss.rs:201-245)
+      StepLR / ExponentialLR / CosineAnnealingLR == torch.optim.lr_scheduler of the same names           (optim.rs:190-288)
+    """
+    r2 = np.random.default_rng(20250929)
+    n = 300
+    p = f32(r2.uniform(1e-4, 1 - 1e-4, n))
+    y = f32(r2.uniform(0, 1, n) > 0.5)
+    pt = torch.from_numpy(p).double().requires_grad_()
+    loss = F.binary_cross_entropy(pt, torch.from_numpy(y).double(), reduction="mean")
+    loss.backward()
+    b, c = 48, 10
+    logits = f32(r2.standard_normal((b, c)) * 2.5)
+    onehot = np.eye(c, dtype=np.float32)[r2.integers(0, c, b)]
+    lt = torch.from_numpy(logits).double().requires_grad_()
+    l2 = -(torch.from_numpy(onehot).double() * F.log_softmax(lt, 1)).sum() / b
+    l2.backward()
+    sched = {}
+    for name, mk in (("step", lambda o: torch.optim.lr_scheduler.StepLR(o, 3, 0.5)),
+                     ("exp", lambda o: torch.optim.lr_scheduler.ExponentialLR(o, 0.9)),
+                     ("cos", lambda o: torch.optim.lr_scheduler.CosineAnnealingLR(o, 10, 1e-4))):
+        opt = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=0.1)
+        sc, lrs = mk(opt), []
+        for _ in range(10):
+            opt.step()
+            sc.step()
+            lrs.append(sc.get_last_lr()[0])
+        sched[name] = np.array(lrs)
+    np.savez_compressed(OUT / "losses_extra.npz", p=p, y=y, bce=f32(loss.item()), dbce=f32(pt.grad.numpy()), logits=logits, onehot=onehot,
+                        ce=f32(l2.item()), dce=f32(lt.grad.numpy()), lr_step=sched["step"], lr_exp=sched["exp"], lr_cos=sched["cos"])
+
+
 if __name__ == "__main__":
+    import sys
+    if "--extra" in sys.argv:
+        extra_cases()
+        print("wrote losses_extra.npz")
+        sys.exit(0)
     conv_case(2, 1, 28, 28, 8, "conv_c1")
     conv_case(2, 16, 14, 14, 24, "conv_c16")
     conv_case(3, 5, 7, 7, 3, "conv_odd")
