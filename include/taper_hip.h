@@ -108,6 +108,14 @@ int th_sgemm(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, float a
  * activation.rs:10-12 / ops.rs:312-349 into the epilogue. */
 int th_linear_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_b, float *d_y,
                   int batch, int in_features, int out_features, int relu);
+/* same product, and the launch also (a) applies up to TH_MAX_ADAM_SLICES deferred
+ * Adam updates (extra nullable) of parameters this layer does not read, with the
+ * step counter AS IT STANDS (they belong to the step that just ended), then
+ * (b) advances the counter d_tick (nullable; th_adam_step's d_t) by one
+ * (optim.rs:84) -- the first launch of a fused training step (th_mlp_tail). */
+int th_linear_fwd_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_b, float *d_y,
+                     int batch, int in_features, int out_features, int relu,
+                     const th_adam_slice *extra, int n_extra, int32_t *d_tick);
 /* backward of the three reference nodes at once (ops.rs:238-294,
  * tensor.rs:574-587, 674-694); any of d_dx, d_dw, d_db may be NULL (input
  * without requires_grad: ops.rs:243).  d_relu_y (nullable): the layer's
@@ -150,6 +158,30 @@ int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d_w, const f
                         float *d_dh, float *d_dw, float *d_db, float *d_metrics, int64_t metrics_capacity,
                         int64_t *d_state, int64_t advance, int32_t *d_adam_tick, const th_adam_fuse *w_fuse,
                         const th_adam_fuse *b_fuse);
+
+/* ---- fused MLP tail: classifier head + the backward of the hidden layer ---- */
+/* For  ... -> H = relu(X . W1^T + b1) -> logits = H . W2^T + b2 -> cross-entropy
+ * ONE launch computes what th_linear_xent_head followed by
+ * th_linear_bwd_adam_ex(d_relu_y = H) compute (nn.rs:54-60, loss.rs:101-195,
+ * 271-290, backward closures ops.rs:238-294, 358-369, tensor.rs:574-587,
+ * 674-694) for an upstream gradient of exactly 1:
+ *   d_loss[1], d_ncorrect[1] (nullable), the step log (d_metrics / d_state as in
+ *   th_softmax_xent_fwd, nullable),
+ *   d_dw2[C,hid], d_db2[C]   (nullable; W2 / b2 are read by every workgroup, so their
+ *                             Adam update is the caller's: th_adam_slice in a later launch),
+ *   d_dw1[hid,in], d_db1[hid] (db1 nullable) -- overwritten (grad slots were None),
+ *   + the fused Adam update of W1 / b1 (w1_fuse / b1_fuse nullable; their d_t must
+ *   already be advanced for this step, e.g. by th_linear_fwd_ex).
+ * Every workgroup recomputes the 16-row logits / softmax it needs in registers;
+ * no dH buffer exists.  d_x[B,in] is the hidden layer's input, d_h[B,hid] its
+ * post-ReLU output (16-byte aligned, like d_w2).  th_mlp_tail_supported: batch <= 256,
+ * hidden <= 256 and a multiple of 4, classes <= 16. */
+int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes);
+int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
+                const float *d_targets, int batch, int in_features, int hidden, int classes,
+                float *d_loss, float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2,
+                float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse);
 
 /* ---- element-wise: src/ops.rs:8-120,377-496; src/tensor.rs:36-161 ----- */
 int th_add(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);

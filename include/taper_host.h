@@ -165,8 +165,10 @@ int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n);
 int tp_trainer_new(tp_module *model, tp_optim *adam, tp_trainer **out);
 int tp_trainer_set_sample_shape(tp_trainer *t, const size_t *shape, int ndim);  /* e.g. {1,28,28} for the CNN */
 int tp_trainer_set_comm(tp_trainer *t, tp_comm *c /* nullable */);
-/* graph-path knobs: steps per hipGraph replay; classifier head (last Linear + cross-entropy) as one
- * launch; Adam updates in the epilogues of the gradient kernels (ignored with a communicator) */
+/* graph-path knobs: steps per hipGraph replay; fuse_head 1 = classifier head (last Linear + cross-entropy)
+ * as one launch, 2 = additionally the backward of a Linear+ReLU layer in front of it in the same launch
+ * (th_mlp_tail; falls back to 1 where unsupported), 0 = off; Adam updates in the epilogues of the
+ * gradient kernels (ignored with a communicator) */
 int tp_trainer_set_options(tp_trainer *t, int graph_chunk, int fuse_head, int fuse_adam);
 int tp_trainer_free(tp_trainer *t);
 /* one reference-literal step (examples/train_mnist.rs:89-121); reads loss / accuracy back */

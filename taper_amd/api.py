@@ -568,10 +568,12 @@ class Trainer:
     EAGER, GRAPH, EVAL = 0, 1, 2
 
     def __init__(self, model: Module, optimizer: Adam, sample_shape=None, comm: Communicator | None = None,
-                 graph_chunk: int = 32, fuse_head: bool = True, fuse_adam: bool = True, scheduler=None):
+                 graph_chunk: int = 32, fuse_head: bool | int = True, fuse_adam: bool = True, scheduler=None):
         self.model, self.optimizer, self.comm, self.scheduler = model, optimizer, comm, scheduler
         self._h = _mk(host.tp_trainer_new, "Trainer::new", model._h, optimizer._h)
-        tp_check(host.tp_trainer_set_options(self._h, int(graph_chunk), 1 if fuse_head else 0, 1 if fuse_adam else 0), "set_options")
+        # fuse_head: False / 0 = off, 1 = classifier head only, True / 2 = head + hidden-layer backward in one launch
+        level = 2 if fuse_head is True else int(fuse_head)
+        tp_check(host.tp_trainer_set_options(self._h, int(graph_chunk), level, 1 if fuse_adam else 0), "set_options")
         if sample_shape:
             tp_check(host.tp_trainer_set_sample_shape(self._h, _shape_arr(sample_shape), len(sample_shape)), "set_sample_shape")
         if comm is not None:

@@ -83,16 +83,8 @@ static inline AdamSlices make_adam_slices(const th_adam_slice *s, int n) {
     return r;
 }
 
-// 256 threads; optim.rs:99-110 on elements [1024 b', 1024 b' + 1024) of the slice owning block b
-__device__ __forceinline__ void adam_slices_block(const AdamSlices &x, int b) {
-    int s = 0;
-#pragma unroll
-    for (int i = 1; i < TH_MAX_ADAM_SLICES; ++i)
-        if (i < x.count && b >= x.first_block[i]) s = i;
-    const AdamDev &a = x.a[s];
-    const float *__restrict__ g = x.g[s];
-    const int64_t n = x.n[s];
-    const int64_t i0 = (int64_t)(b - x.first_block[s]) * 1024 + threadIdx.x * 4;
+// optim.rs:99-110 on elements [i0, i0 + 4) of one slice (i0 a multiple of 4)
+__device__ __forceinline__ void adam_slice_quad(const AdamDev &a, const float *__restrict__ g, int64_t n, int64_t i0, float step) {
     if (i0 >= n) return;
     const bool vec = i0 + 4 <= n && ((((uintptr_t)a.p | (uintptr_t)a.m | (uintptr_t)a.v | (uintptr_t)g) & 15) == 0);
     float gv[4], pv[4], mv[4], vv[4];
@@ -111,7 +103,6 @@ __device__ __forceinline__ void adam_slices_block(const AdamSlices &x, int b) {
             gv[j] = g[i]; pv[j] = a.p[i]; mv[j] = a.m[i]; vv[j] = a.v[i];
         }
     }
-    const float step = adam_dev_step(a);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float gj = gv[j] + a.wd * pv[j];
@@ -128,6 +119,32 @@ __device__ __forceinline__ void adam_slices_block(const AdamSlices &x, int b) {
             a.p[i0 + j] = pv[j]; a.m[i0 + j] = mv[j]; a.v[i0 + j] = vv[j];
         }
     }
+}
+
+// 256 threads; elements [1024 b', 1024 b' + 1024) of the slice owning block b
+__device__ __forceinline__ void adam_slices_block(const AdamSlices &x, int b) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < TH_MAX_ADAM_SLICES; ++i)
+        if (i < x.count && b >= x.first_block[i]) s = i;
+    const AdamDev &a = x.a[s];
+    const int64_t i0 = (int64_t)(b - x.first_block[s]) * 1024 + threadIdx.x * 4;
+    if (i0 >= x.n[s]) return;
+    adam_slice_quad(a, x.g[s], x.n[s], i0, adam_dev_step(a));
+}
+
+// ALL slices in ONE workgroup, with the step counter as it stands at entry; afterwards `tick`
+// (nullable) is advanced by one (optim.rs:84).  For th_linear_fwd_ex: the slices belong to the
+// PREVIOUS step, the tick opens the next one; nothing else in that launch touches the counter.
+__device__ __forceinline__ void adam_slices_then_tick(const AdamSlices &x, int32_t *tick) {
+#pragma unroll
+    for (int s = 0; s < TH_MAX_ADAM_SLICES; ++s) {
+        if (s >= x.count) break;
+        const float step = adam_dev_step(x.a[s]);
+        for (int64_t i0 = (int64_t)threadIdx.x * 4; i0 < x.n[s]; i0 += (int64_t)blockDim.x * 4) adam_slice_quad(x.a[s], x.g[s], x.n[s], i0, step);
+    }
+    __syncthreads();
+    if (tick && threadIdx.x == 0) tick[0] += 1;
 }
 
 }  // namespace th

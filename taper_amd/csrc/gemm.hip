@@ -184,6 +184,18 @@ __global__ __launch_bounds__(64 * NW) void sgemm_small16(SmallArgs p) {
     small16_body<A_KC, B_KC, NW, false>(p, blockIdx.y, blockIdx.x, blockIdx.z, red);
 }
 
+// th_linear_fwd_ex: the same tiles on rows [0, gridDim.y - 1) of the grid; block (0, gridDim.y - 1) applies the
+// carried Adam slices with the step counter as it stands and then opens the next step (t += 1)
+template <bool A_KC, bool B_KC, int NW>
+__global__ __launch_bounds__(64 * NW) void sgemm_small16_tick(SmallArgs p, AdamSlices x, int32_t *tick) {
+    __shared__ float red[NW][64][4];
+    if (blockIdx.y + 1 < gridDim.y) {
+        small16_body<A_KC, B_KC, NW, false>(p, blockIdx.y, blockIdx.x, 0, red);
+        return;
+    }
+    if (blockIdx.x == 0) adam_slices_then_tick(x, tick);
+}
+
 // second pass of grid-level split-K: fixed slice order -> deterministic.  With ep.adam set, C is a
 // complete gradient and the parameter's Adam update (optim.rs:99-110) runs on the same element.
 __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ partial, float *__restrict__ C,
@@ -658,6 +670,33 @@ int th_linear_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *
     // Y = X . W^T: op(B) = W^T with W stored [out, in]  ->  trans_b
     Epilogue ep = make_ep(1.0f, 0.0f, d_b, relu);
     return gemm_dispatch(ctx, 0, 1, batch, out_features, in_features, d_x, d_w, d_y, ep);
+}
+
+int th_linear_fwd_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_b, float *d_y, int batch, int in_features,
+                     int out_features, int relu, const th_adam_slice *extra, int n_extra, int32_t *d_tick) {
+    TH_REQUIRE(ctx && d_x && d_w && d_y, "th_linear_fwd_ex: null argument");
+    TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_linear_fwd_ex: bad extra slices");
+    for (int i = 0; i < n_extra; ++i)
+        TH_REQUIRE(extra[i].f.d_p != d_w && extra[i].f.d_p != d_b, "th_linear_fwd_ex: a carried slice must not alias what this launch reads");
+    const int m = batch, n = out_features, k = in_features;
+    const long tiles = (long)ceil_div(m, 16) * ceil_div(n, 16);
+    // the latency-bound case this entry exists for: 16x16 tiles, no grid-level K split -> ONE launch
+    if (m > 0 && n > 0 && k > 0 && !gemm_is_big(m, n, k) && !(tiles < 64 && k >= 2048)) {
+        SmallArgs p{d_x, nullptr, d_w, d_y, nullptr, m, n, k, k, 1, 1, k, (k + 15) / 16 * 16, 0, 0, make_ep(1.0f, 0.0f, d_b, relu)};
+        p.a_vec = aligned16(d_x) && (k % 4 == 0);
+        p.b_vec = aligned16(d_w) && (k % 4 == 0);
+        const AdamSlices x = make_adam_slices(extra, n_extra);
+        const dim3 grid(ceil_div(n, 16), ceil_div(m, 16) + 1, 1);
+        if (tiles < 256 && k >= 256) hipLaunchKernelGGL((sgemm_small16_tick<true, true, 16>), grid, dim3(1024), 0, ctx->stream, p, x, d_tick);
+        else hipLaunchKernelGGL((sgemm_small16_tick<true, true, 4>), grid, dim3(256), 0, ctx->stream, p, x, d_tick);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
+    // other shapes: the slices (old counter), the tick, then the product
+    if (int rc = th_adam_slices(ctx, extra, n_extra)) return rc;
+    if (d_tick)
+        if (int rc = th_adam_tick(ctx, d_tick)) return rc;
+    return th_linear_fwd(ctx, d_x, d_w, d_b, d_y, batch, in_features, out_features, relu);
 }
 
 int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,

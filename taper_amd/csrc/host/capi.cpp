@@ -328,7 +328,7 @@ int tp_trainer_set_options(tp_trainer *t, int graph_chunk, int fuse_head, int fu
     TP_BEGIN
     TAPER_ASSERT(graph_chunk >= 1, "graph_chunk must be >= 1");
     t->t->graph_chunk = (size_t)graph_chunk;
-    t->t->fuse_head = fuse_head != 0;
+    t->t->fuse_head = fuse_head < 0 ? 0 : (fuse_head > 2 ? 2 : fuse_head);
     t->t->fuse_adam = fuse_adam != 0;
     TP_END
 }

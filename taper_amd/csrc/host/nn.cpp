@@ -142,6 +142,70 @@ Tensor linear_cross_entropy(const Tensor &h, const Tensor &w, const Tensor &bias
     return loss;
 }
 
+bool mlp_tail_supported(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2) {
+    if (x.shape().size() != 2 || w1.shape().size() != 2 || w2.shape().size() != 2) return false;
+    if (x.get_requires_grad() || x.shape()[1] != w1.shape()[1] || w2.shape()[1] != w1.shape()[0]) return false;
+    if (!w1.get_requires_grad() || !w2.get_requires_grad() || w1.has_grad() || w2.has_grad()) return false;
+    for (const Tensor *b : {&b1, &b2})
+        if (b->defined() && (!b->get_requires_grad() || b->has_grad())) return false;
+    return th_mlp_tail_supported((int)x.shape()[0], (int)x.shape()[1], (int)w1.shape()[0], (int)w2.shape()[0]) != 0;
+}
+
+Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
+                              const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log) {
+    TAPER_ASSERT(mlp_tail_supported(x, w1, b1, w2, b2), "mlp_tail_cross_entropy: unsupported shapes / gradient state");
+    TAPER_ASSERT(targets.shape()[0] == x.shape()[0], "Batch sizes must match");
+    const int b = (int)x.shape()[0], in_f = (int)x.shape()[1], hid = (int)w1.shape()[0], c = (int)w2.shape()[0];
+    th_ctx *ctx = Device::ctx();
+    Adam *fa = FusedAdamScope::active();
+    // launch 1 (nn.rs:54-60 + activation.rs:10-12): H = relu(x . W1^T + b1); the updates the PREVIOUS step
+    // deferred (its W2 / b2: read by every workgroup of its tail launch) ride here with that step's counter,
+    // then the counter opens this step (optim.rs:84)
+    th_adam_slice carried[TH_MAX_ADAM_SLICES];
+    const int n_carried = fa ? fa->take_deferred(w1.dptr(), carried) : 0;
+    if (fa && fa->has_deferred()) fa->flush_deferred();   // more than one launch can carry (never for a plain MLP): old counter too
+    Tensor h = Tensor::empty({(size_t)b, (size_t)hid});
+    TH(th_linear_fwd_ex(ctx, x.dptr(), w1.dptr(), b1.defined() ? b1.dptr() : nullptr, h.dptr(), b, in_f, hid, 1, carried, n_carried,
+                        fa ? fa->d_tick() : nullptr));
+    // launch 2: everything else
+    Tensor loss = Tensor::empty({1});
+    float *nc = nullptr;
+    if (n_correct_out) {
+        *n_correct_out = Tensor::empty({1});
+        nc = n_correct_out->dptr();
+    }
+    auto slot = [](const Tensor &p) -> float * {
+        if (!p.defined()) return nullptr;
+        if (!p.grad_->buf) p.grad_->buf = Buffer::alloc(p.len());
+        p.grad_->known_zero = false;
+        return p.grad_->buf->d;
+    };
+    float *dw1 = slot(w1), *db1 = slot(b1), *dw2 = slot(w2), *db2 = slot(b2);
+    th_adam_fuse wf{}, bf{};
+    const th_adam_fuse *pw = nullptr, *pb = nullptr;
+    if (fa) {
+        if (fa->fuse_for(w1, &wf)) pw = &wf;
+        if (b1.defined() && fa->fuse_for(b1, &bf)) pb = &bf;
+    }
+    TH(th_mlp_tail(ctx, x.dptr(), h.dptr(), w2.dptr(), b2.defined() ? b2.dptr() : nullptr, targets.dptr(), b, in_f, hid, c, loss.dptr(),
+                   nc, dw1, db1, dw2, db2, log ? log->d_metrics : nullptr, log ? log->capacity : 0, log ? log->d_state : nullptr,
+                   log ? log->advance : 0, pw, pb));
+    if (fa) {   // W2 / b2: complete gradients, updated by the next launch that does not read them
+        fa->defer_for(w2);
+        if (b2.defined()) fa->defer_for(b2);
+    }
+    loss.set_requires_grad(true);
+    Tensor p1 = w1, p2 = b1, p3 = w2, p4 = b2, out = loss, keep = h;
+    Tape::push(loss, true, [p1, p2, p3, p4, out, keep]() {
+        if (!out.has_grad()) return;
+        // the gradients were produced by the forward launches for an upstream grad of exactly 1
+        TAPER_ASSERT(out.grad_->shared_const, "mlp_tail_cross_entropy: only loss.backward() from the root is supported");
+        for (const Tensor *p : {&p1, &p2, &p3, &p4})
+            if (p->defined()) p->grad_->has = true;
+    });
+    return loss;
+}
+
 float accuracy(const Tensor &pred, const Tensor &targets) {  // loss.rs:271-290
     TAPER_ASSERT(pred.shape()[0] == targets.shape()[0], "Batch sizes must match");
     TAPER_ASSERT(pred.shape().size() == 2, "accuracy: predictions must be [B,C]");
@@ -390,7 +454,7 @@ void Adam::set_lr(float lr) {  // optim.rs:125-127
 }
 
 void Adam::step() {  // optim.rs:83-113
-    flush_deferred();  // complete gradients no backward launch carried
+    if (!carry_deferred_) flush_deferred();  // complete gradients no backward launch carried
     // parameters whose update already ran in a fused epilogue this step are masked out
     const size_t left = fp_.sync_mask(&fused_);
     std::fill(fused_.begin(), fused_.end(), 0);
@@ -657,22 +721,45 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
     auto *seq = dynamic_cast<Sequential *>(model.get());
     Linear *last = (fuse_head && seq && !seq->layers.empty()) ? dynamic_cast<Linear *>(seq->layers.back().get()) : nullptr;
     bool used_head = false;
+    Adam *adam = dynamic_cast<Adam *>(optimizer.get());
+    const size_t nl = seq ? seq->layers.size() : 0;
+    Linear *hidden = (last && fuse_head >= 2 && seq->fuse && nl >= 3 && dynamic_cast<ReLU *>(seq->layers[nl - 2].get()))
+                         ? dynamic_cast<Linear *>(seq->layers[nl - 3].get()) : nullptr;
     if (last) {
-        Tensor h = seq->forward_prefix(xin, seq->layers.size() - 1);
-        if (linear_cross_entropy_supported(h, last->weight) && !last->weight.has_grad() &&
-            !(last->bias.defined() && last->bias.has_grad())) {
-            loss = linear_cross_entropy(h, last->weight, last->bias, y, &ncorrect, &sink);
-            used_head = true;
+        Tensor h;
+        if (hidden) {   // Linear + ReLU + Linear + cross-entropy: two launches per step
+            Tensor xh = seq->forward_prefix(xin, nl - 3);
+            if (mlp_tail_supported(xh, hidden->weight, hidden->bias, last->weight, last->bias)) {
+                if (adam && FusedAdamScope::active()) adam->set_carry_deferred(true);   // flushed by enqueue_steps
+                loss = mlp_tail_cross_entropy(xh, hidden->weight, hidden->bias, last->weight, last->bias, y, &ncorrect, &sink);
+                used_head = true;
+            } else {
+                if (adam) adam->flush_deferred();
+                h = hidden->forward_fused_relu(xh);
+            }
         } else {
-            loss = cross_entropy_loss(last->forward(h), y, &ncorrect, &sink);
+            // updates a previous tail step left for its successor must run with ITS counter: before this step's tick
+            if (adam) adam->flush_deferred();
+            h = seq->forward_prefix(xin, nl - 1);
+        }
+        if (!used_head) {
+            if (linear_cross_entropy_supported(h, last->weight) && !last->weight.has_grad() &&
+                !(last->bias.defined() && last->bias.has_grad()))
+                loss = linear_cross_entropy(h, last->weight, last->bias, y, &ncorrect, &sink);
+            else
+                loss = cross_entropy_loss(last->forward(h), y, &ncorrect, &sink);
             used_head = true;
         }
     }
-    if (!used_head) loss = cross_entropy_loss(model->forward(xin), y, &ncorrect, &sink);
+    if (!used_head) {
+        if (adam) adam->flush_deferred();
+        loss = cross_entropy_loss(model->forward(xin), y, &ncorrect, &sink);
+    }
     loss.backward();
     reduce_grads(*this);
     optimizer->step();
     optimizer->zero_grad();
+    if (adam) adam->set_carry_deferred(false);
 }
 
 void Trainer::enqueue_steps(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
@@ -681,6 +768,8 @@ void Trainer::enqueue_steps(const float *d_images, const float *d_labels, const 
     TH(th_gather_batch(Device::ctx(), d_images, d_labels, d_indices, n_indices, state + 1, (int)(batch * steps), 784, xb_->d,
                        yb_->d));
     for (size_t s = 0; s < steps; ++s) enqueue_compute(xb_->d + s * batch * 784, yb_->d + s * batch, batch);
+    // a tail step leaves the head's W / b updates for its successor's first launch; the last one's run here
+    if (auto *adam = dynamic_cast<Adam *>(optimizer.get())) adam->flush_deferred();
 }
 
 void Trainer::drop_graphs() {

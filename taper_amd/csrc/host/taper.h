@@ -181,6 +181,12 @@ struct StepLogSink {
 bool linear_cross_entropy_supported(const Tensor &h, const Tensor &weight);
 Tensor linear_cross_entropy(const Tensor &h, const Tensor &weight, const Tensor &bias, const Tensor &targets,
                             Tensor *n_correct_out, const StepLogSink *log);
+// x -> relu(x . W1^T + b1) -> . W2^T + b2 -> cross-entropy as TWO launches: th_linear_fwd_ex (which also carries the
+// previous step's deferred Adam updates and opens this step) and th_mlp_tail (head + the hidden layer's whole
+// backward + its Adam update).  Same contract as linear_cross_entropy; x must not require a gradient.
+bool mlp_tail_supported(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2);
+Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
+                              const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log);
 // n_correct_out (optional): device scalar receiving accuracy()*B from the fused kernel
 Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out = nullptr,
                           const StepLogSink *log = nullptr);  // loss.rs:136-195
@@ -385,6 +391,10 @@ class Adam : public Optimizer {  // optim.rs:43-128
     bool defer_for(const Tensor &param);
     int take_deferred(const float *launch_reads, th_adam_slice *out);  // <= TH_MAX_ADAM_SLICES, skipping aliases
     void flush_deferred();
+    // keep the deferred updates across step(): the NEXT step's first launch carries them (th_linear_fwd_ex);
+    // whoever sets this flushes at the end of its run of steps
+    void set_carry_deferred(bool on) { carry_deferred_ = on; }
+    bool has_deferred() const { return !deferred_.empty(); }
     void set_external_tick(bool on) { external_tick_ = on; }
 
    private:
@@ -392,6 +402,7 @@ class Adam : public Optimizer {  // optim.rs:43-128
     std::shared_ptr<Buffer> m_, v_, state_;  // state_: int32 t, int32 arrival counter, float lr
     float lr_, beta1_, beta2_, eps_, wd_;
     bool external_tick_ = false;
+    bool carry_deferred_ = false;
     std::vector<char> fused_;                // per parameter: updated by a fused epilogue this step
     std::vector<th_adam_slice> deferred_;    // updates waiting for a carrier launch
 };
@@ -551,7 +562,8 @@ class Trainer {  // train.rs:74-172
     Shape sample_shape;                   // {} -> feed [B,784]; {1,28,28} -> reshape like train_mnist_cnn.rs:161-162
     std::string device = "hip:gfx950";    // train.rs:79 "For future GPU support"
     size_t graph_chunk = 32;              // steps captured per hipGraph replay (plus a 1-step graph for the tail)
-    bool fuse_head = true;                // last Linear + cross-entropy as one launch (graph path)
+    int fuse_head = 2;                    // graph path: 1 = last Linear + cross-entropy as one launch; 2 = additionally the
+                                          // backward (+ Adam) of a Linear+ReLU layer in front of it, same launch (th_mlp_tail)
     bool fuse_adam = true;                // Adam updates in the epilogue of the grad-producing kernels (graph path, no DP)
     Trainer(std::shared_ptr<Module> m, std::shared_ptr<Adam> o) : model(std::move(m)), optimizer(std::move(o)) {}
 

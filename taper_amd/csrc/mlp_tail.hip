@@ -1,0 +1,369 @@
+// mlp_tail.hip -- th_mlp_tail: the classifier head AND the whole backward of the Linear+ReLU layer
+// in front of it, in ONE launch (what th_linear_xent_head followed by th_linear_bwd_adam_ex
+// compute: nn.rs:54-60 + loss.rs:101-195,271-290 + the backward closures ops.rs:238-294,
+// tensor.rs:574-587,674-694 of both Linear layers and the ReLU node ops.rs:358-369).
+//
+// Why: at batch 64 the MNIST MLP step is three dependent launches (layer-1 forward, head, layer-1
+// backward) and the single-workgroup head alone costs 9 us of dependent round trips.  The head is
+// 164 kFLOP: cheap enough that EVERY workgroup of the layer-1 backward recomputes it in registers
+// and goes straight on to its dW1 tile -- no dH round trip through memory, no launch boundary.
+//
+// Each wave owns 16 batch rows (4 waves = one 64-row chunk; larger batches loop) and never
+// exchanges data with the other waves before the final tile reduction, because every product is
+// arranged so that the MFMA C/D layout of one step IS the operand layout of the next:
+//   logits^T[class][row] = W2 . H^T          A = W2[class=l&15][k], B = H[row=l&15][k]
+//                                            -> lane (r,g) holds logit[row r][class 4g+i], i = 0..3
+//   softmax / NLL / argmax / dlogits         over i in the lane and over g by xor-shuffles 16, 32
+//   dH[row][hid] = dl . W2                   A = dl[row r][class 4g+s] (= register s), B = W2[class 4g+s][hid r]
+//                                            -> lane (r,g) holds dH[row 4g+i][hid r]; ReLU mask H[row 4g+i][hid r]
+//   dW1[hid][in] += dH^T . X                 A = dH[row 4g+s][hid r] (= register s), B = X[row 4g+s][in r]
+// Workgroup roles by block index:
+//   [0, n_dw)        one 16-hidden x (16*TN)-input block of dW1 (+ fused Adam of W1), XCD-aware order
+//   next tiles_m     "head" workgroups, one per 16 hidden units hm: db1[16 hm ..] (+ fused Adam of b1),
+//                    dW2[:, 16 hm ..]; hm == 0 also db2, loss, hit count, the step log
+// W2 / b2 are READ by every workgroup, so their update cannot run here: the caller defers it
+// (th_adam_slice) to the next launch that does not read them (th_linear_fwd_ex of the next step).
+#include "adam_dev.h"
+
+namespace th {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct TailArgs {
+    const float *x, *h, *w2, *b2, *targets;
+    int batch, in_f, hid, c;
+    float *loss, *ncorrect, *dw1, *db1, *dw2, *db2;
+    float *metrics;
+    int64_t capacity;
+    int64_t *state;
+    int64_t advance;
+    AdamDev w1_adam, b1_adam;
+    int n_dw, tiles_m, groups;
+};
+
+__device__ __forceinline__ long tail_target_class(float tf) {  // Rust `as usize`: saturating, NaN -> 0
+    return (tf >= 0.f) ? (long)fminf(tf, 2147483520.f) : 0;
+}
+
+__device__ __forceinline__ float4 ldg4_or_zero(const float *p, bool ok) {
+    return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int KS, int TN>
+__global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
+    __shared__ float red[4][TN][64][4];   // cross-wave sums of the dW1 block (head role: slot 0 = dW2 tile)
+    __shared__ float tr[4][16][17];       // head role: per-wave transpose of dlogits
+    __shared__ float sc[4][36];           // head role: per-wave db1[16], db2[16], nll, hits
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const int bid = blockIdx.x;
+    const bool head_role = bid >= a.n_dw;
+    int tile_m, grp = 0;
+    if (!head_role) {   // block b runs on XCD b % 8: XCD x takes the x-th eighth of the blocks, hidden tile innermost
+        const int tt = (bid & 7) * (a.n_dw >> 3) + (bid >> 3);
+        if (tt >= a.tiles_m * a.groups) return;
+        tile_m = tt % a.tiles_m;
+        grp = tt / a.tiles_m;
+    } else {
+        tile_m = bid - a.n_dw;
+    }
+    const int hid = a.hid, C = a.c, in_f = a.in_f, B = a.batch;
+    const int hcol = tile_m * 16 + r16;          // this lane's hidden unit (B-operand / C-column position)
+    const bool hcol_ok = hcol < hid;
+    const int col0 = grp * 16 * TN;
+    const bool lead = head_role && tile_m == 0;
+
+    // ---- everything chunk-independent is requested first: one global round trip for the lot ----
+    float4 wv[KS];                                // W2[class r16][16 ks + 4 g4 ..]
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = ks * 16 + g4 * 4;
+        wv[ks] = ldg4_or_zero(a.w2 + (long)r16 * hid + k, r16 < C && k < hid);
+    }
+    float w2b[4], b2v[4];                         // W2[class 4 g4 + s][hcol], b2[class 4 g4 + i]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int cls = g4 * 4 + s;
+        w2b[s] = (cls < C && hcol_ok) ? a.w2[(long)cls * hid + hcol] : 0.f;
+        b2v[s] = (a.b2 && cls < C) ? a.b2[cls] : 0.f;
+    }
+    // epilogue operands: wave e finishes element e of every lane's C/D quad (row 4 g4 + e of the tile)
+    const int erow = tile_m * 16 + g4 * 4 + wave;
+    long e_ix[TN];
+    bool e_ok[TN];
+    float e_p[TN], e_m[TN], e_v[TN], w_step = 0.f;
+    const bool fuse_w = !head_role && a.w1_adam.p != nullptr;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int ecol = col0 + tn * 16 + r16;
+        e_ok[tn] = !head_role && erow < hid && ecol < in_f;
+        e_ix[tn] = e_ok[tn] ? (long)erow * in_f + ecol : 0;
+        e_p[tn] = e_m[tn] = e_v[tn] = 0.f;
+        if (fuse_w && e_ok[tn]) {
+            e_p[tn] = a.w1_adam.p[e_ix[tn]];
+            e_m[tn] = a.w1_adam.m[e_ix[tn]];
+            e_v[tn] = a.w1_adam.v[e_ix[tn]];
+        }
+    }
+    if (fuse_w) w_step = adam_dev_step(a.w1_adam);
+    const bool own_b1 = head_role && a.db1 && t < 16 && tile_m * 16 + t < hid;
+    const bool fuse_b = own_b1 && a.b1_adam.p != nullptr;
+    float bp_ = 0.f, bm_ = 0.f, bv_ = 0.f, b_step = 0.f;
+    if (fuse_b) {
+        bp_ = a.b1_adam.p[tile_m * 16 + t];
+        bm_ = a.b1_adam.m[tile_m * 16 + t];
+        bv_ = a.b1_adam.v[tile_m * 16 + t];
+        b_step = adam_dev_step(a.b1_adam);
+    }
+    const int64_t log_slot = (lead && t == 0 && a.metrics) ? a.state[0] % a.capacity : 0;
+
+    floatx4 accdw[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) accdw[tn] = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 acc_dw2 = {0.f, 0.f, 0.f, 0.f};
+    float db1_acc = 0.f, db2_acc[4] = {0.f, 0.f, 0.f, 0.f}, nll_acc = 0.f, hit_acc = 0.f;
+    const float inv_b = 1.0f / (float)B;
+
+    for (int c0 = 0; c0 < B; c0 += 64) {
+        const int r0 = c0 + wave * 16;            // this wave's 16 rows
+        const int row_a = r0 + r16;               // row in the lane's "r16" position
+        const bool row_a_ok = row_a < B;
+        // ---- this chunk's operands, all requested before the first MFMA ----
+        float4 hv[KS];                            // H[row_a][16 ks + 4 g4 ..]
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 16 + g4 * 4;
+            hv[ks] = ldg4_or_zero(a.h + (long)row_a * hid + k, row_a_ok && k < hid);
+        }
+        const float tf = row_a_ok ? a.targets[row_a] : 0.f;
+        float hm[4], xv[TN][4];                   // H[r0 + 4 g4 + s][hcol] (ReLU mask / dW2 operand), X[same row][col0 + 16 tn + r16]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = r0 + g4 * 4 + s;
+            hm[s] = (row < B && hcol_ok) ? a.h[(long)row * hid + hcol] : 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = col0 + tn * 16 + r16;
+                xv[tn][s] = (!head_role && row < B && col < in_f) ? a.x[(long)row * in_f + col] : 0.f;
+            }
+        }
+
+        // ---- logits^T (nn.rs:54-60): four independent accumulation chains, one per float4 component ----
+        floatx4 ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax, aw = ax;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ax = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].x, hv[ks].x, ax, 0, 0, 0);
+            ay = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].y, hv[ks].y, ay, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].z, hv[ks].z, az, 0, 0, 0);
+            aw = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].w, hv[ks].w, aw, 0, 0, 0);
+        }
+        // lane (r16, g4): logit[row_a][class 4 g4 + i]
+        float lg[4], dl[4];
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lg[i] = ((ax[i] + ay[i]) + (az[i] + aw[i])) + b2v[i];
+            const int cls = g4 * 4 + i;
+            if (cls < C && lg[i] > -INFINITY && lg[i] > best) {   // first max; NaN / -inf never win (tensor.rs:1062)
+                best = lg[i];
+                bi = cls;
+            }
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if (bi == 0x7fffffff) bi = 0;
+        float se = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) se += (g4 * 4 + i < C) ? expf(lg[i] - best) : 0.f;
+        se += __shfl_xor(se, 16, 64);
+        se += __shfl_xor(se, 32, 64);
+        const float log_sum = logf(se);
+        const long tcls = tail_target_class(tf);
+        float my_nll = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cls = g4 * 4 + i;
+            float dv = 0.f;
+            if (row_a_ok && cls < C) {
+                const float lp = (lg[i] - best) - log_sum;   // loss.rs:117-125
+                float gv = expf(lp);                          // loss.rs:178
+                if (cls == tcls) {
+                    my_nll = -lp;
+                    gv -= 1.0f;
+                }
+                dv = gv * inv_b;                              // loss.rs:185-188 with g0 = 1
+            }
+            dl[i] = dv;
+        }
+
+        // ---- dH tile (ops.rs:254-265) and the ReLU mask of the hidden layer (ops.rs:358-369, Q15) ----
+        floatx4 dh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dh = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[s], w2b[s], dh, 0, 0, 0);
+        float dhm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dhm[i] = hm[i] > 0.f ? dh[i] : 0.f;
+
+        if (!head_role) {
+            // ---- dW1 block (ops.rs:280-291 through the W^T node, tensor.rs:574-587) ----
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    accdw[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(dhm[s], xv[tn][s], accdw[tn], 0, 0, 0);
+        } else {
+            // ---- db1 (tensor.rs:686-691): rows 4 g4 + i in the lane, then over g4 ----
+            float cs = (dhm[0] + dhm[1]) + (dhm[2] + dhm[3]);
+            cs += __shfl_xor(cs, 16, 64);
+            cs += __shfl_xor(cs, 32, 64);
+            db1_acc += cs;
+            // ---- dW2 tile: A = dl[row 4 g4 + s][class r16] (wave-local transpose), B = H[row 4 g4 + s][hcol] ----
+            if (c0 > 0) __syncthreads();          // previous chunk's readers of tr are done
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tr[wave][r16][g4 * 4 + i] = dl[i];
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc_dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[wave][g4 * 4 + s][r16], hm[s], acc_dw2, 0, 0, 0);
+            if (lead) {
+                // db2 (column sums of dlogits), loss and hits: over the 16 rows (r16) by xor-shuffles
+                my_nll += __shfl_xor(my_nll, 16, 64);
+                my_nll += __shfl_xor(my_nll, 32, 64);
+                float nl = (row_a_ok && g4 == 0) ? ((tcls >= C) ? NAN : my_nll) : 0.f;   // the reference panics (loss.rs:161)
+                float ht = (row_a_ok && g4 == 0 && fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;   // loss.rs:283
+                float d4[4] = {dl[0], dl[1], dl[2], dl[3]};
+#pragma unroll
+                for (int off = 1; off <= 8; off <<= 1) {
+                    nl += __shfl_xor(nl, off, 64);
+                    ht += __shfl_xor(ht, off, 64);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d4[i] += __shfl_xor(d4[i], off, 64);
+                }
+                nll_acc += nl;
+                hit_acc += ht;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) db2_acc[i] += d4[i];
+            }
+        }
+    }
+
+    if (!head_role) {
+        // ---- deterministic cross-wave sum; wave e finishes element e (+ fused Adam, optim.rs:99-110) ----
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][tn][lane][i] = accdw[tn][i];
+        __syncthreads();
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            if (!e_ok[tn]) continue;
+            const float out = ((red[0][tn][lane][wave] + red[1][tn][lane][wave]) + red[2][tn][lane][wave]) + red[3][tn][lane][wave];
+            a.dw1[e_ix[tn]] = out;
+            if (fuse_w) {
+                const AdamDev &ad = a.w1_adam;
+                const float gv = out + ad.wd * e_p[tn];
+                const float mn = ad.beta1 * e_m[tn] + (1.0f - ad.beta1) * gv;
+                const float vn = ad.beta2 * e_v[tn] + (1.0f - ad.beta2) * gv * gv;
+                ad.m[e_ix[tn]] = mn;
+                ad.v[e_ix[tn]] = vn;
+                ad.p[e_ix[tn]] = e_p[tn] - w_step * mn / (sqrtf(vn) + ad.eps);
+            }
+        }
+        return;
+    }
+
+    // ---- head role: cross-wave sums in wave order ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][0][lane][i] = acc_dw2[i];
+    if (g4 == 0) sc[wave][r16] = db1_acc;
+    if (lead && r16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[wave][16 + g4 * 4 + i] = db2_acc[i];
+    }
+    if (lead && lane == 0) {
+        sc[wave][32] = nll_acc;
+        sc[wave][33] = hit_acc;
+    }
+    __syncthreads();
+    if (a.dw2) {   // wave e: class 4 g4 + e
+        const int cls = g4 * 4 + wave;
+        if (cls < C && hcol_ok)
+            a.dw2[(long)cls * hid + hcol] = ((red[0][0][lane][wave] + red[1][0][lane][wave]) + red[2][0][lane][wave]) + red[3][0][lane][wave];
+    }
+    if (own_b1) {
+        const float out = ((sc[0][t] + sc[1][t]) + sc[2][t]) + sc[3][t];
+        const int ix = tile_m * 16 + t;
+        a.db1[ix] = out;
+        if (fuse_b) {
+            const AdamDev &ad = a.b1_adam;
+            const float gv = out + ad.wd * bp_;
+            const float mn = ad.beta1 * bm_ + (1.0f - ad.beta1) * gv;
+            const float vn = ad.beta2 * bv_ + (1.0f - ad.beta2) * gv * gv;
+            ad.m[ix] = mn;
+            ad.v[ix] = vn;
+            ad.p[ix] = bp_ - b_step * mn / (sqrtf(vn) + ad.eps);
+        }
+    }
+    if (lead) {
+        if (a.db2 && t < C) a.db2[t] = ((sc[0][16 + t] + sc[1][16 + t]) + sc[2][16 + t]) + sc[3][16 + t];
+        if (t == 0) {
+            const float n = ((sc[0][32] + sc[1][32]) + sc[2][32]) + sc[3][32];
+            const float hsum = ((sc[0][33] + sc[1][33]) + sc[2][33]) + sc[3][33];
+            const float l = n / (float)B;   // loss.rs:164
+            a.loss[0] = l;
+            if (a.ncorrect) a.ncorrect[0] = hsum;
+            if (a.metrics) {                // the step log of th_log_step
+                a.metrics[2 * log_slot] = l;
+                a.metrics[2 * log_slot + 1] = hsum;
+                a.state[0] += 1;
+                a.state[1] += a.advance;
+            }
+        }
+    }
+}
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes) {
+    return batch > 0 && batch <= 256 && in_features > 0 && hidden > 0 && hidden <= 256 && (hidden % 4) == 0 && classes > 0 &&
+           classes <= 16;
+}
+
+extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
+                           const float *d_targets, int batch, int in_features, int hidden, int classes, float *d_loss,
+                           float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2, float *d_metrics,
+                           int64_t metrics_capacity, int64_t *d_state, int64_t advance, const th_adam_fuse *w1_fuse,
+                           const th_adam_fuse *b1_fuse) {
+    TH_REQUIRE(ctx && d_x && d_h && d_w2 && d_targets && d_loss && d_dw1, "th_mlp_tail: null argument");
+    TH_REQUIRE(th_mlp_tail_supported(batch, in_features, hidden, classes),
+               "th_mlp_tail: needs batch <= 256, hidden <= 256 and a multiple of 4, classes <= 16 (got %d, %d, %d)", batch, hidden, classes);
+    TH_REQUIRE((((uintptr_t)d_h | (uintptr_t)d_w2) & 15) == 0, "th_mlp_tail: d_h and d_w2 must be 16-byte aligned");
+    TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp_tail: metrics need d_state and a capacity");
+    TH_REQUIRE(!(b1_fuse && b1_fuse->d_p) || d_db1, "th_mlp_tail: fused b1 update needs d_db1");
+    constexpr int TN = 2;
+    TailArgs a{};
+    a.x = d_x; a.h = d_h; a.w2 = d_w2; a.b2 = d_b2; a.targets = d_targets;
+    a.batch = batch; a.in_f = in_features; a.hid = hidden; a.c = classes;
+    a.loss = d_loss; a.ncorrect = d_ncorrect; a.dw1 = d_dw1; a.db1 = d_db1; a.dw2 = d_dw2; a.db2 = d_db2;
+    a.metrics = d_metrics; a.capacity = metrics_capacity; a.state = d_state; a.advance = advance;
+    a.w1_adam = make_adam_dev(w1_fuse);
+    a.b1_adam = make_adam_dev(b1_fuse);
+    a.tiles_m = ceil_div(hidden, 16);
+    a.groups = ceil_div(in_features, 16 * TN);
+    a.n_dw = (a.tiles_m * a.groups + 7) & ~7;
+    const int grid = a.n_dw + a.tiles_m;
+    if (hidden <= 64) hipLaunchKernelGGL((mlp_tail_kernel<4, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    else if (hidden <= 128) hipLaunchKernelGGL((mlp_tail_kernel<8, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((mlp_tail_kernel<16, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    TH_LAUNCH_CHECK();
+    return 0;
+}

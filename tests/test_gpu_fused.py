@@ -189,7 +189,9 @@ def test_carried_slice_must_not_alias_the_weight_read_for_dx(ctx):
 
 
 CONFIGS = [dict(graph_chunk=1, fuse_head=False, fuse_adam=False), dict(graph_chunk=8, fuse_head=True, fuse_adam=False),
-           dict(graph_chunk=8, fuse_head=False, fuse_adam=True), dict(graph_chunk=32, fuse_head=True, fuse_adam=True)]
+           dict(graph_chunk=8, fuse_head=False, fuse_adam=True), dict(graph_chunk=32, fuse_head=True, fuse_adam=True),
+           dict(graph_chunk=32, fuse_head=1, fuse_adam=True),    # head-only fusion (the three-launch step)
+           dict(graph_chunk=3, fuse_head=2, fuse_adam=True)]     # tail fusion with short chunks: carried updates + flushes
 
 
 @pytest.mark.parametrize("model_name,batch", [("mlp_baseline", 64), ("mlp_example", 96)])
