@@ -120,19 +120,19 @@ def hip_structs():
 
 
 class StepKernels:
-    """The three launches of the fused MLP 784-128-10 step, issued through the C ABI on raw
-    buffers exactly as the Trainer's graph issues them, with HIP event-record nodes between them
-    inside ONE captured graph: each kernel is timed in situ (its operands were just written by
-    the previous launch, like in the real step), on the stream the kernels run on.
+    """The two launches of the fused MLP 784-128-10 step, issued through the C ABI on raw
+    buffers exactly as the Trainer's graph issues them, replayed as graph chains with / without
+    each launch: every kernel is timed in situ (its operands were just written by the previous
+    launch, like in the real step), on the stream the kernels run on.
 
     Algorithmic bytes per launch (every tensor touched once, fp32), B = batch:
-      K1 sgemm_small16<true,true,16>  H = relu(X.W1^T + b1):  4*(784B + 128*784 + 128 + 128B)
-      K2 linear_xent_head_kernel      logits/loss/dlogits/dH/dW2/db2 + step log:
-                                      4*(128B + 1280 + 10 + B) + 4*(128B + 1280 + 10) + 16
-      K3 linear_bwd_small<true>       dW1 = dZ1^T.X, db1, Adam(W1, b1) in the epilogue and the
-                                      carried Adam(W2, b2):  4*(784B + 128B + 128B)  [X, dH, relu mask]
-                                      + 4*100480 [dW1, db1 written] + 24*100480 [p, m, v read + written]
-                                      + 28*1290 [g, p, m, v read; p, m, v written]
+      K1 sgemm_small16_tick<true,true,16>  H = relu(X.W1^T + b1), the carried Adam(W2, b2) of the
+                                      previous step and the step counter:
+                                      4*(784B + 128*784 + 128 + 128B) + 28*1290 [g, p, m, v read; p, m, v written]
+      K2 mlp_tail_kernel<8,2>         logits / loss / dlogits / dH (registers only), dW2, db2, dW1 = dZ1^T.X, db1,
+                                      Adam(W1, b1) in the epilogue, step log:
+                                      4*(784B + 128B + B) [X, H, targets] + 4*1290 [W2, b2] + 4*1290 [dW2, db2]
+                                      + 4*100480 [dW1, db1 written] + 24*100480 [p, m, v read + written] + 16
     """
     IN, HID, OUT = 784, 128, 10
 
@@ -145,7 +145,7 @@ class StepKernels:
         n1, n2 = HID * IN + HID, OUT * HID + OUT
         self.p1, self.g1, self.m1, self.v1 = f(n1), ctx.zeros(n1), ctx.zeros(n1), ctx.zeros(n1)
         self.p2, self.g2, self.m2, self.v2 = f(n2), ctx.zeros(n2), ctx.zeros(n2), ctx.zeros(n2)
-        self.h, self.dh = ctx.empty(B * HID), ctx.empty(B * HID)
+        self.h = ctx.empty(B * HID)
         self.loss, self.nc = ctx.empty(1), ctx.empty(1)
         self.metrics, self.state = ctx.zeros(2 * 4096), ctx.upload(np.zeros(2, np.int64))
         self.tick, self.lr = ctx.upload(np.array([0, 0], np.int32)), ctx.upload(np.array([1e-3], np.float32))
@@ -155,28 +155,23 @@ class StepKernels:
         self.carried = (hip_structs().AdamSlice * 2)(
             hip_structs().AdamSlice(int(self.g2), OUT * HID, adam(self.p2, self.m2, self.v2, 0)),
             hip_structs().AdamSlice(int(self.g2) + 4 * OUT * HID, OUT, adam(self.p2, self.m2, self.v2, OUT * HID)))
-        b4 = 4 * B
         self.kernels = [
-            ("sgemm_small16<true, true, 16>", "K1 layer-1 forward (+bias, ReLU)", 4 * (IN * B + HID * IN + HID + HID * B), 2 * B * IN * HID),
-            ("linear_xent_head_kernel", "K2 head: Linear(128,10) + softmax-xent + dH/dW2/db2 + step log",
-             b4 * HID + 4 * (n2 + B) + b4 * HID + 4 * n2 + 16, 3 * 2 * B * HID * OUT),
-            ("linear_bwd_small<true>", "K3 layer-1 backward (dW1, db1) + Adam(W1,b1) epilogue + carried Adam(W2,b2)",
-             4 * (IN * B + 2 * HID * B) + 4 * n1 + 24 * n1 + 28 * n2, 2 * B * IN * HID + 14 * (n1 + n2)),
+            ("sgemm_small16_tick<true, true, 16>", "K1 layer-1 forward (+bias, ReLU) + carried Adam(W2,b2) of the previous step + step counter",
+             4 * (IN * B + HID * IN + HID + HID * B) + 28 * n2, 2 * B * IN * HID + 14 * n2),
+            ("mlp_tail_kernel<8, 2>", "K2 head (Linear(128,10) + softmax-xent + dW2/db2 + step log) + layer-1 backward (dW1, db1) + Adam(W1,b1) epilogue",
+             4 * (IN * B + HID * B + B) + 8 * n2 + 4 * n1 + 24 * n1 + 16, 3 * 2 * B * HID * OUT + 2 * B * IN * HID + 14 * n1),
         ]
 
     def _k1(self):
         c, B = self.ctx, self.B
-        c.call("th_linear_fwd", self.x, self.p1, int(self.p1) + 4 * self.HID * self.IN, self.h, B, self.IN, self.HID, 1)
+        c.call("th_linear_fwd_ex", self.x, self.p1, int(self.p1) + 4 * self.HID * self.IN, self.h, B, self.IN, self.HID, 1, self.carried, 2,
+               self.tick)
 
     def _k2(self):
-        c, B, n = self.ctx, self.B, self.OUT * self.HID
-        c.call("th_linear_xent_head", self.h, self.p2, int(self.p2) + 4 * n, self.y, B, self.HID, self.OUT, None, self.loss, self.nc,
-               self.dh, self.g2, int(self.g2) + 4 * n, self.metrics, 4096, self.state, 1, self.tick, None, None)
-
-    def _k3(self):
-        c, B, n = self.ctx, self.B, self.HID * self.IN
-        c.call("th_linear_bwd_adam_ex", self.x, None, self.dh, self.h, None, self.g1, int(self.g1) + 4 * n, B, self.IN, self.HID, 0,
-               C.byref(self.w1f), C.byref(self.b1f), self.carried, 2)
+        c, B, n1, n2 = self.ctx, self.B, self.HID * self.IN, self.OUT * self.HID
+        c.call("th_mlp_tail", self.x, self.h, self.p2, int(self.p2) + 4 * n2, self.y, B, self.IN, self.HID, self.OUT, self.loss, self.nc,
+               self.g1, int(self.g1) + 4 * n1, self.g2, int(self.g2) + 4 * n2, self.metrics, 4096, self.state, 1,
+               C.byref(self.w1f), C.byref(self.b1f))
 
     def _capture(self, launches, steps=16):
         """`steps` back-to-back steps as one hipGraph (<= 48 kernel nodes)"""
@@ -208,14 +203,14 @@ class StepKernels:
         return ms * 1e3 / (reps // inner * inner * steps)
 
     def measure(self):
-        """In-situ duration of each launch = (time of the 3-launch step) - (time of the step with that
+        """In-situ duration of each launch = (time of the 2-launch step) - (time of the step with that
         launch left out), both replayed as graph chains: the launch keeps its real neighbours, and the
         figure includes the dependent-launch boundary it adds -- which is also what rocprofv3's
         kernel-trace duration covers here (its per-kernel averages sum to the step time).
         All graphs stay alive until the end: under rocprofv3 --kernel-trace a replay issued after a
         hipGraphExecDestroy crashes in the profiler on this ROCm."""
-        ks = [self._k1, self._k2, self._k3]
-        graphs = [self._capture(ks)] + [self._capture([k for j, k in enumerate(ks) if j != i]) for i in range(3)]
+        ks = [self._k1, self._k2]
+        graphs = [self._capture(ks)] + [self._capture([k for j, k in enumerate(ks) if j != i]) for i in range(len(ks))]
         full = self._replay_us(graphs[0])
         out = []
         for i, (name, what, nbytes, flops) in enumerate(self.kernels):
@@ -261,7 +256,7 @@ def pmc_traffic(workload, kernel):
     if not files:
         return None, None
     for name, rec in json.loads(files[-1].read_text())["kernels"].items():
-        if kernel.split("<")[0] in name and ("<true>" in name) == ("<true>" in kernel):
+        if kernel.split("<")[0] + "<" in name:
             return rec["traffic_bytes_per_launch"], f"profiles/{files[-1].name}"
     return None, None
 
@@ -352,9 +347,9 @@ def main():
             # instantiated graph back to back; the Trainer's replays above are what the trace is for.
             roof = dict(skipped="per-kernel timers are not run under rocprofv3; see profiles/ for the trace of this command")
         elif key == "mlp_baseline" and not args.no_roofline:
-            # per-launch durations of the step's three kernels, measured live (HIP events on the ctx
+            # per-launch durations of the step's two kernels, measured live (HIP events on the ctx
             # stream, graph chains with / without each launch).  `roofline` is the kernel that carries
-            # the step's HBM traffic (81% of its algorithmic bytes); the full list is in `kernels`.
+            # the step's HBM traffic (83% of its algorithmic bytes); the full list is in `kernels`.
             from taper_amd import hip
             sk = StepKernels(hip.Ctx(handle=T.Device.ctx_handle()), batch).measure()
             k = max(sk["kernels"], key=lambda r: r["alg_bytes_per_launch"])
@@ -365,7 +360,7 @@ def main():
                         kernel=k["kernel"], role=k["role"], us_per_launch=k["us_per_launch"],
                         alg_bytes_per_launch=k["alg_bytes_per_launch"], mfma_tflops=k["mfma_tflops"],
                         dominant_by="algorithmic bytes; by time the leader is %s (%.1f us)" % (by_time["kernel"], by_time["us_per_launch"]),
-                        step_us_three_launch_chain=sk["step_us"], kernels=sk["kernels"])
+                        step_us_two_launch_chain=sk["step_us"], kernels=sk["kernels"])
         sweep = None
         # (not under rocprofv3: the trace of this command is for the headline workload's kernels only)
         if key == "mlp_baseline" and world == 1 and not args.batch and not args.no_sweep and not under_profiler:

@@ -18,9 +18,9 @@
 //                                            -> lane (r,g) holds dH[row 4g+i][hid r]; ReLU mask H[row 4g+i][hid r]
 //   dW1[hid][in] += dH^T . X                 A = dH[row 4g+s][hid r] (= register s), B = X[row 4g+s][in r]
 // Workgroup roles by block index:
-//   [0, n_dw)        one 16-hidden x (16*TN)-input block of dW1 (+ fused Adam of W1), XCD-aware order
-//   next tiles_m     "head" workgroups, one per 16 hidden units hm: db1[16 hm ..] (+ fused Adam of b1),
+//   [0, n_head)      "head" workgroups, one per 16 hidden units hm: db1[16 hm ..] (+ fused Adam of b1),
 //                    dW2[:, 16 hm ..]; hm == 0 also db2, loss, hit count, the step log
+//   next n_dw        one 16-hidden x (16*TN)-input block of dW1 (+ fused Adam of W1), XCD-aware order
 // W2 / b2 are READ by every workgroup, so their update cannot run here: the caller defers it
 // (th_adam_slice) to the next launch that does not read them (th_linear_fwd_ex of the next step).
 #include "adam_dev.h"
@@ -38,16 +38,26 @@ struct TailArgs {
     int64_t *state;
     int64_t advance;
     AdamDev w1_adam, b1_adam;
-    int n_dw, tiles_m, groups;
+    int n_dw, n_head, tiles_m, groups;   // n_head = tiles_m rounded up to 8 (keeps the XCD phase of the dW blocks)
 };
 
 __device__ __forceinline__ long tail_target_class(float tf) {  // Rust `as usize`: saturating, NaN -> 0
     return (tf >= 0.f) ? (long)fminf(tf, 2147483520.f) : 0;
 }
 
-__device__ __forceinline__ float4 ldg4_or_zero(const float *p, bool ok) {
-    return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
+#ifdef TH_PROFILE
+__device__ long long g_tail_prof[2][16];   // [0] lead head workgroup, [1] first dW1 workgroup
+#define TAIL_STAMP(i)                                                                         \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == a.n_head))                  \
+            g_tail_prof[blockIdx.x == 0 ? 0 : 1][i] = wall_clock64();                         \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+__global__ void tail_prof_mark_kernel(int i) { g_tail_prof[0][i] = g_tail_prof[1][i] = wall_clock64(); }
+#else
+#define TAIL_STAMP(i) do { } while (0)
+#endif
 
 template <int KS, int TN>
 __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
@@ -56,15 +66,18 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
     __shared__ float sc[4][36];           // head role: per-wave db1[16], db2[16], nll, hits
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
     const int bid = blockIdx.x;
-    const bool head_role = bid >= a.n_dw;
+    TAIL_STAMP(0);
+    const bool head_role = bid < a.n_head;   // dispatched first: they carry the most work per workgroup
     int tile_m, grp = 0;
     if (!head_role) {   // block b runs on XCD b % 8: XCD x takes the x-th eighth of the blocks, hidden tile innermost
-        const int tt = (bid & 7) * (a.n_dw >> 3) + (bid >> 3);
+        const int b2 = bid - a.n_head;
+        const int tt = (b2 & 7) * (a.n_dw >> 3) + (b2 >> 3);
         if (tt >= a.tiles_m * a.groups) return;
         tile_m = tt % a.tiles_m;
         grp = tt / a.tiles_m;
     } else {
-        tile_m = bid - a.n_dw;
+        tile_m = bid;
+        if (tile_m >= a.tiles_m) return;
     }
     const int hid = a.hid, C = a.c, in_f = a.in_f, B = a.batch;
     const int hcol = tile_m * 16 + r16;          // this lane's hidden unit (B-operand / C-column position)
@@ -72,19 +85,27 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
     const int col0 = grp * 16 * TN;
     const bool lead = head_role && tile_m == 0;
 
-    // ---- everything chunk-independent is requested first: one global round trip for the lot ----
+    // ---- everything is requested up front in ONE global round trip, branch-free: a guarded load reads a
+    //      clamped (always valid) address and the value is zeroed afterwards -- per-load exec-mask branches
+    //      cost ~1 us of scalar overhead here, and a wait between two groups of loads costs a second round trip ----
+    // the counters / learning rates of the fused updates: scalar loads, requested first (plain loads: nobody
+    // writes the counter in this launch); the step sizes are formed while the vector loads are in flight
+    const bool any_w = a.w1_adam.p != nullptr, any_b = a.db1 && a.b1_adam.p != nullptr;
+    const int32_t w_t = any_w ? a.w1_adam.t[0] : 1, b_t = any_b ? a.b1_adam.t[0] : 1;
+    const float w_lr = any_w ? a.w1_adam.lr[0] : 0.f, b_lr = any_b ? a.b1_adam.lr[0] : 0.f;
+    const int Cm1 = C - 1, hid4 = hid - 4, hcol_c = min(hcol, hid - 1);
     float4 wv[KS];                                // W2[class r16][16 ks + 4 g4 ..]
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int k = ks * 16 + g4 * 4;
-        wv[ks] = ldg4_or_zero(a.w2 + (long)r16 * hid + k, r16 < C && k < hid);
+        wv[ks] = *reinterpret_cast<const float4 *>(a.w2 + (long)min(r16, Cm1) * hid + min(k, hid4));
     }
     float w2b[4], b2v[4];                         // W2[class 4 g4 + s][hcol], b2[class 4 g4 + i]
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int cls = g4 * 4 + s;
-        w2b[s] = (cls < C && hcol_ok) ? a.w2[(long)cls * hid + hcol] : 0.f;
-        b2v[s] = (a.b2 && cls < C) ? a.b2[cls] : 0.f;
+        const int cls = min(g4 * 4 + s, Cm1);
+        w2b[s] = a.w2[(long)cls * hid + hcol_c];
+        b2v[s] = a.b2 ? a.b2[cls] : 0.f;
     }
     // epilogue operands: wave e finishes element e of every lane's C/D quad (row 4 g4 + e of the tile)
     const int erow = tile_m * 16 + g4 * 4 + wave;
@@ -98,23 +119,23 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
         e_ok[tn] = !head_role && erow < hid && ecol < in_f;
         e_ix[tn] = e_ok[tn] ? (long)erow * in_f + ecol : 0;
         e_p[tn] = e_m[tn] = e_v[tn] = 0.f;
-        if (fuse_w && e_ok[tn]) {
+        if (fuse_w) {
             e_p[tn] = a.w1_adam.p[e_ix[tn]];
             e_m[tn] = a.w1_adam.m[e_ix[tn]];
             e_v[tn] = a.w1_adam.v[e_ix[tn]];
         }
     }
-    if (fuse_w) w_step = adam_dev_step(a.w1_adam);
     const bool own_b1 = head_role && a.db1 && t < 16 && tile_m * 16 + t < hid;
-    const bool fuse_b = own_b1 && a.b1_adam.p != nullptr;
+    const bool fuse_b1 = head_role && a.db1 && a.b1_adam.p != nullptr;
+    const int b1_ix = own_b1 ? tile_m * 16 + t : 0;
     float bp_ = 0.f, bm_ = 0.f, bv_ = 0.f, b_step = 0.f;
-    if (fuse_b) {
-        bp_ = a.b1_adam.p[tile_m * 16 + t];
-        bm_ = a.b1_adam.m[tile_m * 16 + t];
-        bv_ = a.b1_adam.v[tile_m * 16 + t];
-        b_step = adam_dev_step(a.b1_adam);
+    if (fuse_b1) {
+        bp_ = a.b1_adam.p[b1_ix];
+        bm_ = a.b1_adam.m[b1_ix];
+        bv_ = a.b1_adam.v[b1_ix];
     }
-    const int64_t log_slot = (lead && t == 0 && a.metrics) ? a.state[0] % a.capacity : 0;
+    const bool fuse_b = own_b1 && fuse_b1;
+    const int64_t state0 = (lead && a.metrics) ? a.state[0] : 0, state1 = (lead && a.metrics) ? a.state[1] : 0;
 
     floatx4 accdw[TN];
 #pragma unroll
@@ -127,26 +148,52 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
         const int r0 = c0 + wave * 16;            // this wave's 16 rows
         const int row_a = r0 + r16;               // row in the lane's "r16" position
         const bool row_a_ok = row_a < B;
+        const int row_ac = min(row_a, B - 1);
         // ---- this chunk's operands, all requested before the first MFMA ----
         float4 hv[KS];                            // H[row_a][16 ks + 4 g4 ..]
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k = ks * 16 + g4 * 4;
-            hv[ks] = ldg4_or_zero(a.h + (long)row_a * hid + k, row_a_ok && k < hid);
+            hv[ks] = *reinterpret_cast<const float4 *>(a.h + (long)row_ac * hid + min(k, hid4));
         }
-        const float tf = row_a_ok ? a.targets[row_a] : 0.f;
+        const float tf_raw = a.targets[row_ac];
         float hm[4], xv[TN][4];                   // H[r0 + 4 g4 + s][hcol] (ReLU mask / dW2 operand), X[same row][col0 + 16 tn + r16]
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int row = r0 + g4 * 4 + s;
-            hm[s] = (row < B && hcol_ok) ? a.h[(long)row * hid + hcol] : 0.f;
+            const int row_c = min(r0 + g4 * 4 + s, B - 1);
+            hm[s] = a.h[(long)row_c * hid + hcol_c];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int col = col0 + tn * 16 + r16;
-                xv[tn][s] = (!head_role && row < B && col < in_f) ? a.x[(long)row * in_f + col] : 0.f;
+            for (int tn = 0; tn < TN; ++tn) xv[tn][s] = head_role ? 0.f : a.x[(long)row_c * in_f + min(col0 + tn * 16 + r16, in_f - 1)];
+        }
+        TAIL_STAMP(1);
+        if (c0 == 0) {
+            // step sizes of the fused updates (optim.rs:87-90): uniform ALU work that runs while the vector loads are in flight
+            if (fuse_w) w_step = adam_step_size(w_lr, a.w1_adam.beta1, a.w1_adam.beta2, w_t);
+            if (fuse_b1) b_step = adam_step_size(b_lr, a.b1_adam.beta1, a.b1_adam.beta2, b_t);
+        }
+        TAIL_STAMP(2);
+        // ---- zero what lies outside the problem ----
+        const float tf = row_a_ok ? tf_raw : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool k_ok = ks * 16 + g4 * 4 < hid;
+            if (c0 == 0 && !(r16 < C && k_ok)) wv[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(row_a_ok && k_ok)) hv[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool row_ok = r0 + g4 * 4 + s < B;
+            if (c0 == 0) {
+                if (!(g4 * 4 + s < C && hcol_ok)) w2b[s] = 0.f;
+                if (!(g4 * 4 + s < C)) b2v[s] = 0.f;
             }
+            if (!(row_ok && hcol_ok)) hm[s] = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                xv[tn][s] = (!head_role && row_ok && col0 + tn * 16 + r16 < in_f) ? xv[tn][s] : 0.f;
         }
 
+        TAIL_STAMP(3);
         // ---- logits^T (nn.rs:54-60): four independent accumulation chains, one per float4 component ----
         floatx4 ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax, aw = ax;
 #pragma unroll
@@ -203,6 +250,7 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
             dl[i] = dv;
         }
 
+        TAIL_STAMP(4);
         // ---- dH tile (ops.rs:254-265) and the ReLU mask of the hidden layer (ops.rs:358-369, Q15) ----
         floatx4 dh = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -254,6 +302,7 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
         }
     }
 
+    TAIL_STAMP(5);
     if (!head_role) {
         // ---- deterministic cross-wave sum; wave e finishes element e (+ fused Adam, optim.rs:99-110) ----
 #pragma unroll
@@ -261,6 +310,7 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[wave][tn][lane][i] = accdw[tn][i];
         __syncthreads();
+        TAIL_STAMP(6);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             if (!e_ok[tn]) continue;
@@ -276,6 +326,7 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
                 ad.p[e_ix[tn]] = e_p[tn] - w_step * mn / (sqrtf(vn) + ad.eps);
             }
         }
+        TAIL_STAMP(7);
         return;
     }
 
@@ -292,6 +343,7 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
         sc[wave][33] = hit_acc;
     }
     __syncthreads();
+    TAIL_STAMP(6);
     if (a.dw2) {   // wave e: class 4 g4 + e
         const int cls = g4 * 4 + wave;
         if (cls < C && hcol_ok)
@@ -320,13 +372,338 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
             a.loss[0] = l;
             if (a.ncorrect) a.ncorrect[0] = hsum;
             if (a.metrics) {                // the step log of th_log_step
+                const int64_t log_slot = state0 < a.capacity ? state0 : state0 % a.capacity;
                 a.metrics[2 * log_slot] = l;
                 a.metrics[2 * log_slot + 1] = hsum;
-                a.state[0] += 1;
-                a.state[1] += a.advance;
+                a.state[0] = state0 + 1;
+                a.state[1] = state1 + a.advance;
             }
         }
     }
+    TAIL_STAMP(7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same launch for whole tiles: hid == 16 KS, batch % 16 == 0, in_features % 16 == 0 (the MNIST MLP).
+// A lone wave per SIMD issues roughly one instruction every 5 cycles whatever its kind, so at this size
+// the kernel's duration IS its instruction count: no clamps or zero-fills (rows / hidden units / input
+// tiles are valid or skipped wave-uniformly; classes >= C are masked once, at the logits), 32-bit byte
+// offsets from uniform bases (one VALU op per address, immediates for the rest), cross-lane steps through
+// v_permlane{16,32}_swap instead of LDS round trips, branch-free softmax.
+__device__ __forceinline__ float ldg_b(const float *base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ float4 ldg4_b(const float *base, unsigned byte_off) {
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+// lane l and lane l ^ 16 (resp. l ^ 32) both receive (x of the lower lane, x of the upper lane)
+__device__ __forceinline__ void pair16(float x, float &lo, float &hi) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void pair32(float x, float &lo, float &hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_over_g4(float x) {
+    float lo, hi;
+    pair16(x, lo, hi);
+    x = lo + hi;
+    pair32(x, lo, hi);
+    return lo + hi;
+}
+__device__ __forceinline__ void argmax_step(float &best, int &bi, float v0, float v1, float i0, float i1) {
+    const int j0 = __float_as_int(i0), j1 = __float_as_int(i1);
+    const bool take1 = v1 > v0 || (v1 == v0 && j1 < j0);
+    best = take1 ? v1 : v0;
+    bi = take1 ? j1 : j0;
+}
+
+// Softmax cross-entropy of one row held as lg[i] = logit[class 4 g4 + i] over the four lanes (r16, 0..3)
+// (loss.rs:101-195, 271-290).  lg is -inf for classes >= C.  Every lane of the row gets nll and argmax.
+__device__ __forceinline__ void tail_row_softmax(const float (&lg)[4], int g4, int C, float tf, float inv_b, float (&dl)[4],
+                                                 float &nll, int &argmax) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // first max; NaN / -inf never win (tensor.rs:1062)
+        const bool w = lg[i] > best;
+        best = w ? lg[i] : best;
+        bi = w ? g4 * 4 + i : bi;
+    }
+    float v0, v1, i0, i1;
+    pair16(best, v0, v1);
+    pair16(__int_as_float(bi), i0, i1);
+    argmax_step(best, bi, v0, v1, i0, i1);
+    pair32(best, v0, v1);
+    pair32(__int_as_float(bi), i0, i1);
+    argmax_step(best, bi, v0, v1, i0, i1);
+    if (bi == 0x7fffffff) bi = 0;
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) se += (g4 * 4 + i < C) ? expf(lg[i] - best) : 0.f;
+    se = sum_over_g4(se);
+    const float log_sum = logf(se);
+    const int tc = (tf >= 0.f) ? (int)fminf(tf, 2147483520.f) : 0;   // Rust `as usize`: saturating, NaN -> 0
+    float my_nll = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cls = g4 * 4 + i;
+        const float lp = (lg[i] - best) - log_sum;   // loss.rs:117-125
+        const float gv = expf(lp);                    // loss.rs:178
+        const bool hit = cls == tc;
+        my_nll = hit ? -lp : my_nll;
+        dl[i] = (cls < C) ? (hit ? gv - 1.0f : gv) * inv_b : 0.f;   // loss.rs:185-188 with g0 = 1
+    }
+    my_nll = sum_over_g4(my_nll);
+    nll = (tc >= C) ? NAN : my_nll;                   // the reference panics (loss.rs:161)
+    argmax = bi;
+}
+
+template <int KS, int TN>
+__global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
+    constexpr unsigned HID = 16 * KS;
+    __shared__ float red[4][TN][64][4];
+    __shared__ float tr[4][16][17];
+    __shared__ float rowv[4][2][16];
+    __shared__ float sc[4][36];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const int bid = blockIdx.x;
+    TAIL_STAMP(0);
+    const bool head_role = bid < a.n_head;
+    int tile_m, grp = 0;
+    if (!head_role) {
+        const int b2 = bid - a.n_head;
+        const int tt = (b2 & 7) * (a.n_dw >> 3) + (b2 >> 3);
+        if (tt >= KS * a.groups) return;
+        tile_m = tt % KS;
+        grp = tt / KS;
+    } else {
+        tile_m = bid;
+        if (tile_m >= KS) return;
+    }
+    const int C = a.c, B = a.batch;
+    const unsigned in_f = (unsigned)a.in_f;
+    const unsigned hcol = tile_m * 16 + r16;
+    const unsigned col0 = grp * 16 * TN;
+    const bool lead = head_role && tile_m == 0;
+    const bool any_w = a.w1_adam.p != nullptr, any_b = a.db1 && a.b1_adam.p != nullptr;
+    const int32_t w_t = any_w ? a.w1_adam.t[0] : 1, b_t = any_b ? a.b1_adam.t[0] : 1;
+    const float w_lr = any_w ? a.w1_adam.lr[0] : 0.f, b_lr = any_b ? a.b1_adam.lr[0] : 0.f;
+
+    // ---- chunk-independent operands ----
+    float4 wv[KS];                                   // W2[class r16][16 ks + 4 g4 ..]; rows >= C: a copy of row C-1, masked at the logits
+    const unsigned w_off = ((unsigned)min(r16, C - 1) * HID + g4 * 4) * 4u;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wv[ks] = ldg4_b(a.w2, w_off + ks * 64);
+    float w2b[4], b2v[4];                            // W2[class 4 g4 + s][hcol] (classes >= C meet dl == 0), b2
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned cls = (unsigned)min(g4 * 4 + s, C - 1);
+        w2b[s] = ldg_b(a.w2, (cls * HID + hcol) * 4u);
+        b2v[s] = a.b2 ? ldg_b(a.b2, cls * 4u) : 0.f;
+    }
+    bool tn_ok[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) tn_ok[tn] = col0 + tn * 16 < in_f;   // workgroup-uniform
+    // epilogue operands: wave e finishes element e of every lane's C/D quad (row 4 g4 + e of the tile)
+    const unsigned e_off = ((tile_m * 16 + g4 * 4 + wave) * in_f + col0 + r16) * 4u;
+    const bool fuse_w = !head_role && any_w;
+    float e_p[TN], e_m[TN], e_v[TN], w_step = 0.f, b_step = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        e_p[tn] = e_m[tn] = e_v[tn] = 0.f;
+        if (fuse_w && tn_ok[tn]) {
+            e_p[tn] = ldg_b(a.w1_adam.p, e_off + tn * 64);
+            e_m[tn] = ldg_b(a.w1_adam.m, e_off + tn * 64);
+            e_v[tn] = ldg_b(a.w1_adam.v, e_off + tn * 64);
+        }
+    }
+    const bool fuse_b1 = head_role && any_b;
+    const unsigned b1_off = (tile_m * 16 + (t & 15)) * 4u;
+    float bp_ = 0.f, bm_ = 0.f, bv_ = 0.f;
+    if (fuse_b1) {
+        bp_ = ldg_b(a.b1_adam.p, b1_off);
+        bm_ = ldg_b(a.b1_adam.m, b1_off);
+        bv_ = ldg_b(a.b1_adam.v, b1_off);
+    }
+    const int64_t state0 = (lead && a.metrics) ? a.state[0] : 0, state1 = (lead && a.metrics) ? a.state[1] : 0;
+
+    floatx4 accdw[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) accdw[tn] = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 acc_dw2 = {0.f, 0.f, 0.f, 0.f};
+    float db1_acc = 0.f, db2_acc = 0.f, nll_acc = 0.f, hit_acc = 0.f;
+    const float inv_b = 1.0f / (float)B;
+
+    for (int c0 = 0; c0 < B; c0 += 64) {
+        const int r0 = c0 + wave * 16;               // this wave's 16 rows: all valid or (wave-uniformly) all absent
+        const bool rows_here = r0 < B;
+        float4 hv[KS];                               // H[r0 + r16][16 ks + 4 g4 ..]
+        float tf = 0.f, hm[4], xv[TN][4];            // H[r0 + 4 g4 + s][hcol], X[same row][col0 + 16 tn + r16]
+        if (rows_here) {
+            const unsigned h_off = ((unsigned)(r0 + r16) * HID + g4 * 4) * 4u;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) hv[ks] = ldg4_b(a.h, h_off + ks * 64);
+            tf = ldg_b(a.targets, (unsigned)(r0 + r16) * 4u);
+            const unsigned hm_off = ((unsigned)(r0 + g4 * 4) * HID + hcol) * 4u;
+            const unsigned x_off = ((unsigned)(r0 + g4 * 4) * in_f + col0 + r16) * 4u;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                hm[s] = ldg_b(a.h, hm_off + s * HID * 4);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    xv[tn][s] = (!head_role && tn_ok[tn]) ? ldg_b(a.x, x_off + s * in_f * 4u + tn * 64) : 0.f;
+            }
+        }
+        TAIL_STAMP(1);
+        if (c0 == 0) {   // step sizes of the fused updates (optim.rs:87-90): ALU work under the loads' latency (every wave: all finish elements)
+            if (fuse_w) w_step = adam_step_size(w_lr, a.w1_adam.beta1, a.w1_adam.beta2, w_t);
+            if (fuse_b1) b_step = adam_step_size(b_lr, a.b1_adam.beta1, a.b1_adam.beta2, b_t);
+        }
+        TAIL_STAMP(2);
+        if (rows_here) {
+            TAIL_STAMP(3);
+            // ---- logits^T (nn.rs:54-60): four independent accumulation chains, one per float4 component ----
+            floatx4 ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax, aw = ax;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                ax = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].x, hv[ks].x, ax, 0, 0, 0);
+                ay = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].y, hv[ks].y, ay, 0, 0, 0);
+                az = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].z, hv[ks].z, az, 0, 0, 0);
+                aw = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].w, hv[ks].w, aw, 0, 0, 0);
+            }
+            float lg[4], dl[4], nll_row;
+            int bi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[i] = (g4 * 4 + i < C) ? ((ax[i] + ay[i]) + (az[i] + aw[i])) + b2v[i] : -INFINITY;
+            tail_row_softmax(lg, g4, C, tf, inv_b, dl, nll_row, bi);
+            TAIL_STAMP(4);
+
+            // ---- dH tile (ops.rs:254-265) and the ReLU mask of the hidden layer (ops.rs:358-369, Q15) ----
+            floatx4 dh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dh = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[s], w2b[s], dh, 0, 0, 0);
+            float dhm[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dhm[i] = hm[i] > 0.f ? dh[i] : 0.f;
+
+            if (!head_role) {
+                // ---- dW1 block (ops.rs:280-291 through the W^T node, tensor.rs:574-587) ----
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        accdw[tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(dhm[s], xv[tn][s], accdw[tn], 0, 0, 0);
+            } else {
+                // ---- db1 (tensor.rs:686-691): rows 4 g4 + i in the lane, then over g4 ----
+                db1_acc += sum_over_g4((dhm[0] + dhm[1]) + (dhm[2] + dhm[3]));
+                // ---- dW2 tile: A = dl[row 4 g4 + s][class r16] (wave-private LDS transpose), B = H[row 4 g4 + s][hcol] ----
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tr[wave][r16][g4 * 4 + i] = dl[i];
+                if (lead && g4 == 0) {
+                    rowv[wave][0][r16] = nll_row;
+                    rowv[wave][1][r16] = (fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;   // loss.rs:283
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc_dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[wave][g4 * 4 + s][r16], hm[s], acc_dw2, 0, 0, 0);
+                if (lead) {   // db2 (column sums of dlogits), loss, hits over this wave's 16 rows, in row order
+                    float cs = 0.f, nl = 0.f, ht = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        cs += tr[wave][r][r16];
+                        nl += rowv[wave][0][r];
+                        ht += rowv[wave][1][r];
+                    }
+                    db2_acc += cs;
+                    nll_acc += nl;
+                    hit_acc += ht;
+                }
+            }
+        }
+    }
+
+    TAIL_STAMP(5);
+    if (!head_role) {
+        // ---- deterministic cross-wave sum; wave e finishes element e (+ fused Adam, optim.rs:99-110) ----
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][tn][lane][i] = accdw[tn][i];
+        __syncthreads();
+        TAIL_STAMP(6);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            if (!tn_ok[tn]) continue;
+            const float out = ((red[0][tn][lane][wave] + red[1][tn][lane][wave]) + red[2][tn][lane][wave]) + red[3][tn][lane][wave];
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dw1) + e_off + tn * 64) = out;
+            if (fuse_w) {
+                const AdamDev &ad = a.w1_adam;
+                const float gv = out + ad.wd * e_p[tn];
+                const float mn = ad.beta1 * e_m[tn] + (1.0f - ad.beta1) * gv;
+                const float vn = ad.beta2 * e_v[tn] + (1.0f - ad.beta2) * gv * gv;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(ad.m) + e_off + tn * 64) = mn;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(ad.v) + e_off + tn * 64) = vn;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(ad.p) + e_off + tn * 64) = e_p[tn] - w_step * mn / (sqrtf(vn) + ad.eps);
+            }
+        }
+        TAIL_STAMP(7);
+        return;
+    }
+
+    // ---- head role: cross-wave sums in wave order ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][0][lane][i] = acc_dw2[i];
+    if (g4 == 0) sc[wave][r16] = db1_acc;
+    if (lead && g4 == 0) sc[wave][16 + r16] = db2_acc;
+    if (lead && lane == 0) {
+        sc[wave][32] = nll_acc;
+        sc[wave][33] = hit_acc;
+    }
+    __syncthreads();
+    TAIL_STAMP(6);
+    if (a.dw2) {   // wave e: class 4 g4 + e
+        const int cls = g4 * 4 + wave;
+        if (cls < C)
+            a.dw2[cls * HID + hcol] = ((red[0][0][lane][wave] + red[1][0][lane][wave]) + red[2][0][lane][wave]) + red[3][0][lane][wave];
+    }
+    if (a.db1 && t < 16) {
+        const float out = ((sc[0][t] + sc[1][t]) + sc[2][t]) + sc[3][t];
+        const int ix = tile_m * 16 + t;
+        a.db1[ix] = out;
+        if (fuse_b1) {
+            const AdamDev &ad = a.b1_adam;
+            const float gv = out + ad.wd * bp_;
+            const float mn = ad.beta1 * bm_ + (1.0f - ad.beta1) * gv;
+            const float vn = ad.beta2 * bv_ + (1.0f - ad.beta2) * gv * gv;
+            ad.m[ix] = mn;
+            ad.v[ix] = vn;
+            ad.p[ix] = bp_ - b_step * mn / (sqrtf(vn) + ad.eps);
+        }
+    }
+    if (lead) {
+        if (a.db2 && t < C) a.db2[t] = ((sc[0][16 + t] + sc[1][16 + t]) + sc[2][16 + t]) + sc[3][16 + t];
+        if (t == 0) {
+            const float n = ((sc[0][32] + sc[1][32]) + sc[2][32]) + sc[3][32];
+            const float hsum = ((sc[0][33] + sc[1][33]) + sc[2][33]) + sc[3][33];
+            const float l = n / (float)B;   // loss.rs:164
+            a.loss[0] = l;
+            if (a.ncorrect) a.ncorrect[0] = hsum;
+            if (a.metrics) {                // the step log of th_log_step
+                const int64_t log_slot = state0 < a.capacity ? state0 : state0 % a.capacity;
+                a.metrics[2 * log_slot] = l;
+                a.metrics[2 * log_slot + 1] = hsum;
+                a.state[0] = state0 + 1;
+                a.state[1] = state1 + a.advance;
+            }
+        }
+    }
+    TAIL_STAMP(7);
 }
 
 }  // namespace th
@@ -349,7 +726,11 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
     TH_REQUIRE((((uintptr_t)d_h | (uintptr_t)d_w2) & 15) == 0, "th_mlp_tail: d_h and d_w2 must be 16-byte aligned");
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp_tail: metrics need d_state and a capacity");
     TH_REQUIRE(!(b1_fuse && b1_fuse->d_p) || d_db1, "th_mlp_tail: fused b1 update needs d_db1");
-    constexpr int TN = 2;
+    static const int tn = [] {   // measurement probe: TAPER_TAIL_TN = 1 | 2 | 4 input tiles per dW1 workgroup
+        const char *e = getenv("TAPER_TAIL_TN");
+        const int v = e ? atoi(e) : 2;
+        return (v == 1 || v == 4) ? v : 2;
+    }();
     TailArgs a{};
     a.x = d_x; a.h = d_h; a.w2 = d_w2; a.b2 = d_b2; a.targets = d_targets;
     a.batch = batch; a.in_f = in_features; a.hid = hidden; a.c = classes;
@@ -358,12 +739,41 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
     a.w1_adam = make_adam_dev(w1_fuse);
     a.b1_adam = make_adam_dev(b1_fuse);
     a.tiles_m = ceil_div(hidden, 16);
-    a.groups = ceil_div(in_features, 16 * TN);
+    a.groups = ceil_div(in_features, 16 * tn);
     a.n_dw = (a.tiles_m * a.groups + 7) & ~7;
-    const int grid = a.n_dw + a.tiles_m;
-    if (hidden <= 64) hipLaunchKernelGGL((mlp_tail_kernel<4, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    else if (hidden <= 128) hipLaunchKernelGGL((mlp_tail_kernel<8, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((mlp_tail_kernel<16, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    a.n_head = (a.tiles_m + 7) & ~7;
+    const int grid = a.n_dw + a.n_head;
+    // whole tiles everywhere (the MNIST MLP: 784-128-10, batches of 64 / 32): the short-instruction-stream kernel
+    const bool exact = (hidden == 64 || hidden == 128 || hidden == 256) && batch % 16 == 0 && in_features % 16 == 0 &&
+                       !(getenv("TAPER_TAIL_GENERAL") && getenv("TAPER_TAIL_GENERAL")[0] == '1');
+#define TH_TAIL_LAUNCH(KS, TN)                                                                                        \
+    do {                                                                                                              \
+        if (exact) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
+        else hipLaunchKernelGGL((mlp_tail_kernel<KS, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);                 \
+    } while (0)
+#define TH_TAIL_KS(TN)                          \
+    do {                                        \
+        if (hidden <= 64) TH_TAIL_LAUNCH(4, TN);       \
+        else if (hidden <= 128) TH_TAIL_LAUNCH(8, TN); \
+        else TH_TAIL_LAUNCH(16, TN);                   \
+    } while (0)
+    if (tn == 1) TH_TAIL_KS(1);
+    else if (tn == 4) TH_TAIL_KS(4);
+    else TH_TAIL_KS(2);
+#undef TH_TAIL_KS
+#undef TH_TAIL_LAUNCH
     TH_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef TH_PROFILE
+extern "C" int th_debug_tail_mark(th_ctx *ctx, int i) {
+    hipLaunchKernelGGL(tail_prof_mark_kernel, dim3(1), dim3(1), 0, ctx->stream, i);
+    return 0;
+}
+extern "C" int th_debug_tail_prof(th_ctx *ctx, long long *h_out32) {
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out32, HIP_SYMBOL(g_tail_prof), 32 * sizeof(long long)));
+    return 0;
+}
+#endif
