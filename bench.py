@@ -301,6 +301,7 @@ def main():
     ap.add_argument("--workload", default="mlp_784-128-10_b64", choices=sorted(WORKLOADS))
     ap.add_argument("--dataset-size", type=int, default=60000)
     ap.add_argument("--batch", type=int, default=0, help="override the workload's per-GPU batch (SURVEY 8d batch sweep)")
+    ap.add_argument("--graph-chunk", type=int, default=0, help="steps per hipGraph replay (0: the Trainer's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-backward", action="store_true",
                     help="CNN workloads: train the conv weights too (extension; the reference cuts the tape there, quirk Q2)")
@@ -322,7 +323,7 @@ def main():
     model = build_model(T, key)
     opt = T.Adam(model.parameters(), lr, None, None, 1e-4)          # examples/train_mnist.rs:50-51
     comm, comm_kind = make_comm(dist, T)
-    trainer = T.Trainer(model, opt, sample_shape=sample_shape, comm=comm)
+    trainer = T.Trainer(model, opt, sample_shape=sample_shape, comm=comm, **({"graph_chunk": args.graph_chunk} if args.graph_chunk else {}))
     # every rank owns its shard of the synthetic epoch (rows are independent: SURVEY.md 8e)
     ds = T.MNISTDataset.synthetic(args.dataset_size, seed=0x7461706572 + rank)
     loader = T.DataLoader(ds, batch, False)

@@ -568,7 +568,7 @@ class Trainer:
     EAGER, GRAPH, EVAL = 0, 1, 2
 
     def __init__(self, model: Module, optimizer: Adam, sample_shape=None, comm: Communicator | None = None,
-                 graph_chunk: int = 32, fuse_head: bool | int = True, fuse_adam: bool = True, scheduler=None):
+                 graph_chunk: int = 128, fuse_head: bool | int = True, fuse_adam: bool = True, scheduler=None):
         self.model, self.optimizer, self.comm, self.scheduler = model, optimizer, comm, scheduler
         self._h = _mk(host.tp_trainer_new, "Trainer::new", model._h, optimizer._h)
         # fuse_head: False / 0 = off, 1 = classifier head only, True / 2 = head + hidden-layer backward in one launch

@@ -785,7 +785,8 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     size_t nb = loader.num_batches();
     if (max_steps && max_steps < nb) nb = max_steps;
     const size_t n_full = std::min(nb, n / bs);
-    const size_t chunk = std::max<size_t>(graph_chunk, 1);
+    // steps per replay: graph_chunk, capped so that the gathered batches of one chunk stay within 256 MB
+    const size_t chunk = std::max<size_t>(std::min<size_t>(graph_chunk, ((size_t)1 << 26) / (bs * 784)), 1);
     if (!xb_ || xb_->n < chunk * bs * 784) {
         drop_graphs();
         xb_ = Buffer::alloc(chunk * bs * 784);
@@ -814,10 +815,14 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     // operator override: TAPER_DP_EAGER=1 keeps data-parallel steps out of hipGraphs (collectives launched eagerly)
     if (comm && !graph_capture_failed_ && std::getenv("TAPER_DP_EAGER") && std::getenv("TAPER_DP_EAGER")[0] == '1')
         graph_capture_failed_ = true;
+    // a ladder of sizes (chunk, chunk/4, chunk/16, ..., 1): the steps an epoch leaves over after its whole chunks
+    // replay as a few mid-sized graphs instead of dozens of single-step launches (~10 us of host time each)
     std::vector<size_t> want;
-    for (size_t steps : {chunk, (size_t)1}) {
-        if (steps == 0 || (steps > 1 && n_full < 2 * steps) || have(steps)) continue;
-        if (std::find(want.begin(), want.end(), steps) == want.end()) want.push_back(steps);
+    for (size_t steps = chunk;; steps /= 4) {
+        if (steps < 1) steps = 1;
+        if (!((steps > 1 && n_full < 2 * steps) || have(steps)) && std::find(want.begin(), want.end(), steps) == want.end())
+            want.push_back(steps);
+        if (steps == 1) break;
     }
     if (!want.empty() && n_full > 0 && !graph_capture_failed_) {
         // step 0 runs eagerly (pool warm-up, has_grad mask upload); then the SAME host code

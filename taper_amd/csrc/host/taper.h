@@ -561,7 +561,7 @@ class Trainer {  // train.rs:74-172
     std::shared_ptr<Communicator> comm;   // optional: data-parallel grad all-reduce before step()
     Shape sample_shape;                   // {} -> feed [B,784]; {1,28,28} -> reshape like train_mnist_cnn.rs:161-162
     std::string device = "hip:gfx950";    // train.rs:79 "For future GPU support"
-    size_t graph_chunk = 32;              // steps captured per hipGraph replay (plus a 1-step graph for the tail)
+    size_t graph_chunk = 128;             // steps captured per hipGraph replay (plus chunk/4, chunk/16, ..., 1-step graphs for the tail)
     int fuse_head = 2;                    // graph path: 1 = last Linear + cross-entropy as one launch; 2 = additionally the
                                           // backward (+ Adam) of a Linear+ReLU layer in front of it, same launch (th_mlp_tail)
     bool fuse_adam = true;                // Adam updates in the epilogue of the grad-producing kernels (graph path, no DP)
