@@ -49,7 +49,7 @@ def test_boundary_headers_are_plain_c11():
 
 @pytest.mark.gpu
 def test_plain_c_client_trains_through_the_abi():
-    """examples/cabi_step.c: the fused 3-launch MLP step driven from C through th_* alone"""
+    """examples/cabi_step.c: the fused 2-launch MLP step driven from C through th_* alone"""
     subprocess.check_call(["make", "-s", "-C", str(ROOT / "examples")])
     out = subprocess.run([str(BIN / "cabi_step")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
