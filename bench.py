@@ -170,7 +170,7 @@ class StepKernels:
     def _k2(self):
         c, B, n1, n2 = self.ctx, self.B, self.HID * self.IN, self.OUT * self.HID
         c.call("th_mlp_tail", self.x, self.h, self.p2, int(self.p2) + 4 * n2, self.y, B, self.IN, self.HID, self.OUT, self.loss, self.nc,
-               self.g1, int(self.g1) + 4 * n1, self.g2, int(self.g2) + 4 * n2, self.metrics, 4096, self.state, 1,
+               self.g1, int(self.g1) + 4 * n1, self.g2, int(self.g2) + 4 * n2, None, None, self.metrics, 4096, self.state, 1,
                C.byref(self.w1f), C.byref(self.b1f))
 
     def _capture(self, launches, steps=16):

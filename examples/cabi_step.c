@@ -61,8 +61,8 @@ int main(void) {
          * (every workgroup of its th_mlp_tail read them) and then opens this step: t += 1 (optim.rs:84) */
         CHECK(th_linear_fwd_ex(ctx, x, p1, p1 + HID * IN, h, B, IN, HID, 1, head, step ? 2 : 0, tick));
         /* head + loss (loss.rs:136-195) + every gradient + Adam(W1, b1) in the epilogue */
-        CHECK(th_mlp_tail(ctx, x, h, p2, p2 + OUT * HID, y, B, IN, HID, OUT, loss, NULL, g1, g1 + HID * IN, g2, g2 + OUT * HID, NULL, 0,
-                          NULL, 0, &w1f, &b1f));
+        CHECK(th_mlp_tail(ctx, x, h, p2, p2 + OUT * HID, y, B, IN, HID, OUT, loss, NULL, g1, g1 + HID * IN, g2, g2 + OUT * HID, NULL, NULL,
+                          NULL, 0, NULL, 0, &w1f, &b1f));
         if (step == 0 || step == 49) {
             float l;
             CHECK(th_memcpy_d2h(ctx, &l, loss, sizeof l));

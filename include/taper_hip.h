@@ -175,11 +175,16 @@ int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d_w, const f
  * Every workgroup recomputes the 16-row logits / softmax it needs in registers;
  * no dH buffer exists.  d_x[B,in] is the hidden layer's input, d_h[B,hid] its
  * post-ReLU output (16-byte aligned, like d_w2).  th_mlp_tail_supported: batch <= 256,
- * hidden <= 256 and a multiple of 4, classes <= 16. */
-int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes);
+ * hidden <= 256 and a multiple of 4, classes <= 16.
+ * d_dx[B,in] (nullable; needs d_w1[hid,in]): additionally dX = dZ1 . W1 for a hidden layer
+ * that is not the first (ops.rs:254-265), overwritten; whole tiles only (need_dx: hidden
+ * 64 / 128 / 256, batch and in_features multiples of 16) and, because the launch then
+ * reads W1, w1_fuse must be NULL: W1's update is the caller's (th_adam_slice), like W2's. */
+int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes, int need_dx);
 int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
                 const float *d_targets, int batch, int in_features, int hidden, int classes,
                 float *d_loss, float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2,
+                const float *d_w1, float *d_dx,
                 float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
                 const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse);
 

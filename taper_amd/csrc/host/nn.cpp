@@ -144,11 +144,13 @@ Tensor linear_cross_entropy(const Tensor &h, const Tensor &w, const Tensor &bias
 
 bool mlp_tail_supported(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2) {
     if (x.shape().size() != 2 || w1.shape().size() != 2 || w2.shape().size() != 2) return false;
-    if (x.get_requires_grad() || x.shape()[1] != w1.shape()[1] || w2.shape()[1] != w1.shape()[0]) return false;
+    if (x.shape()[1] != w1.shape()[1] || w2.shape()[1] != w1.shape()[0]) return false;
+    if (x.get_requires_grad() && (x.has_grad() || x.grad_->buf_is_arena)) return false;   // dX is written, never accumulated
     if (!w1.get_requires_grad() || !w2.get_requires_grad() || w1.has_grad() || w2.has_grad()) return false;
     for (const Tensor *b : {&b1, &b2})
         if (b->defined() && (!b->get_requires_grad() || b->has_grad())) return false;
-    return th_mlp_tail_supported((int)x.shape()[0], (int)x.shape()[1], (int)w1.shape()[0], (int)w2.shape()[0]) != 0;
+    return th_mlp_tail_supported((int)x.shape()[0], (int)x.shape()[1], (int)w1.shape()[0], (int)w2.shape()[0],
+                                 x.get_requires_grad() ? 1 : 0) != 0;
 }
 
 Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
@@ -181,25 +183,35 @@ Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b
         return p.grad_->buf->d;
     };
     float *dw1 = slot(w1), *db1 = slot(b1), *dw2 = slot(w2), *db2 = slot(b2);
+    // a hidden layer that is not the first also hands dX down: the launch then reads W1, whose update is deferred like W2's
+    const bool need_dx = x.get_requires_grad();
+    std::shared_ptr<Buffer> dx = need_dx ? Buffer::alloc(x.len()) : nullptr;
     th_adam_fuse wf{}, bf{};
     const th_adam_fuse *pw = nullptr, *pb = nullptr;
     if (fa) {
-        if (fa->fuse_for(w1, &wf)) pw = &wf;
+        if (!need_dx && fa->fuse_for(w1, &wf)) pw = &wf;
         if (b1.defined() && fa->fuse_for(b1, &bf)) pb = &bf;
     }
     TH(th_mlp_tail(ctx, x.dptr(), h.dptr(), w2.dptr(), b2.defined() ? b2.dptr() : nullptr, targets.dptr(), b, in_f, hid, c, loss.dptr(),
-                   nc, dw1, db1, dw2, db2, log ? log->d_metrics : nullptr, log ? log->capacity : 0, log ? log->d_state : nullptr,
-                   log ? log->advance : 0, pw, pb));
-    if (fa) {   // W2 / b2: complete gradients, updated by the next launch that does not read them
+                   nc, dw1, db1, dw2, db2, need_dx ? w1.dptr() : nullptr, dx ? dx->d : nullptr, log ? log->d_metrics : nullptr,
+                   log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0, pw, pb));
+    if (fa) {   // complete gradients of parameters this launch read: updated by the next launch that does not read them
+        if (need_dx) fa->defer_for(w1);
         fa->defer_for(w2);
         if (b2.defined()) fa->defer_for(b2);
     }
     loss.set_requires_grad(true);
-    Tensor p1 = w1, p2 = b1, p3 = w2, p4 = b2, out = loss, keep = h;
-    Tape::push(loss, true, [p1, p2, p3, p4, out, keep]() {
+    Tensor p1 = w1, p2 = b1, p3 = w2, p4 = b2, out = loss, keep = h, xin = x;
+    Tape::push(loss, true, [p1, p2, p3, p4, out, keep, xin, dx]() {
         if (!out.has_grad()) return;
         // the gradients were produced by the forward launches for an upstream grad of exactly 1
         TAPER_ASSERT(out.grad_->shared_const, "mlp_tail_cross_entropy: only loss.backward() from the root is supported");
+        if (dx) {
+            TAPER_ASSERT(!xin.has_grad() && !xin.grad_->buf_is_arena, "mlp_tail_cross_entropy: input already has a gradient");
+            xin.grad_->buf = dx;
+            xin.grad_->has = true;
+            xin.grad_->shared_const = false;
+        }
         for (const Tensor *p : {&p1, &p2, &p3, &p4})
             if (p->defined()) p->grad_->has = true;
     });

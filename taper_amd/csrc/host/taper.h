@@ -183,7 +183,8 @@ Tensor linear_cross_entropy(const Tensor &h, const Tensor &weight, const Tensor 
                             Tensor *n_correct_out, const StepLogSink *log);
 // x -> relu(x . W1^T + b1) -> . W2^T + b2 -> cross-entropy as TWO launches: th_linear_fwd_ex (which also carries the
 // previous step's deferred Adam updates and opens this step) and th_mlp_tail (head + the hidden layer's whole
-// backward + its Adam update).  Same contract as linear_cross_entropy; x must not require a gradient.
+// backward + its Adam update; with an input that requires a gradient also dX, whole tiles only).  Same contract as
+// linear_cross_entropy.
 bool mlp_tail_supported(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2);
 Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
                               const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log);

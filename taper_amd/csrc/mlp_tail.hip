@@ -39,6 +39,9 @@ struct TailArgs {
     int64_t advance;
     AdamDev w1_adam, b1_adam;
     int n_dw, n_head, tiles_m, groups;   // n_head = tiles_m rounded up to 8 (keeps the XCD phase of the dW blocks)
+    const float *w1;                     // dX role (whole-tile kernel only): dX[B,in] = dZ1 . W1
+    float *dx;
+    int xgroups;                         // 32-column groups of dX; its workgroups: xgroups x ceil(B / 64) behind the dW blocks
 };
 
 __device__ __forceinline__ long tail_target_class(float tf) {  // Rust `as usize`: saturating, NaN -> 0
@@ -462,6 +465,97 @@ __device__ __forceinline__ void tail_row_softmax(const float (&lg)[4], int g4, i
     argmax = bi;
 }
 
+// dX role of the whole-tile kernel (ops.rs:254-265 of the hidden layer, for MLPs with more layers in front):
+// workgroup (32-column group xg, 64-row chunk) -- each wave owns 16 rows and needs no other wave.  After the
+// same logits / softmax, per 16 hidden units th:
+//   dH^T[hid][row] = W2^T . dl^T      A = W2[class 4g+s][16 th + r], B = dl[row r][class 4g+s] (= register s)
+//                                     -> lane (r,g) holds dH[row r][hid 16 th + 4g + i]; its ReLU mask is the
+//                                        H value the lane loaded for the logits (hv[th], component i)
+//   dX[row][in] += dHm . W1           A = dHm[row r][hid 16 th + 4g + s] (= register s), B = W1[hid 16 th + 4g + s][in r]
+template <int KS>
+__device__ __forceinline__ void tail_dx_role(const TailArgs &a, int rb) {
+    constexpr unsigned HID = 16 * KS;
+    constexpr int TX = 2, TH_BLK = KS < 8 ? KS : 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const int C = a.c, B = a.batch;
+    const unsigned in_f = (unsigned)a.in_f;
+    const int chunk = rb / a.xgroups, xg = rb - chunk * a.xgroups;
+    const int r0 = chunk * 64 + wave * 16;
+    if (r0 >= B) return;                              // wave-uniform; this role has no barriers
+    const unsigned col0 = xg * 16 * TX;
+    bool tx_ok[TX];
+#pragma unroll
+    for (int tx = 0; tx < TX; ++tx) tx_ok[tx] = col0 + tx * 16 < in_f;
+    float4 wv[KS], hv[KS];
+    const unsigned w_off = ((unsigned)min(r16, C - 1) * HID + g4 * 4) * 4u;
+    const unsigned h_off = ((unsigned)(r0 + r16) * HID + g4 * 4) * 4u;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        wv[ks] = ldg4_b(a.w2, w_off + ks * 64);
+        hv[ks] = ldg4_b(a.h, h_off + ks * 64);
+    }
+    float b2v[4];
+    unsigned cls_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned cls = (unsigned)min(g4 * 4 + s, C - 1);
+        cls_off[s] = (cls * HID + r16) * 4u;          // W2[class][r16 (+ 16 th)]
+        b2v[s] = a.b2 ? ldg_b(a.b2, cls * 4u) : 0.f;
+    }
+    const float tf = ldg_b(a.targets, (unsigned)(r0 + r16) * 4u);
+    const unsigned w1_off = ((unsigned)(g4 * 4) * in_f + col0 + r16) * 4u;   // W1[4 g4 (+ 16 th + s)][col0 + r16 (+ 16 tx)]
+
+    floatx4 ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax, aw = ax;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        ax = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].x, hv[ks].x, ax, 0, 0, 0);
+        ay = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].y, hv[ks].y, ay, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].z, hv[ks].z, az, 0, 0, 0);
+        aw = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].w, hv[ks].w, aw, 0, 0, 0);
+    }
+    float lg[4], dl[4], nll_row;
+    int bi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lg[i] = (g4 * 4 + i < C) ? ((ax[i] + ay[i]) + (az[i] + aw[i])) + b2v[i] : -INFINITY;
+    tail_row_softmax(lg, g4, C, tf, 1.0f / (float)B, dl, nll_row, bi);
+
+    floatx4 accx[TX];
+#pragma unroll
+    for (int tx = 0; tx < TX; ++tx) accx[tx] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int th0 = 0; th0 < KS; th0 += TH_BLK) {
+        float w2t[TH_BLK][4], w1v[TH_BLK][TX][4];
+#pragma unroll
+        for (int t = 0; t < TH_BLK; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                w2t[t][s] = ldg_b(a.w2, cls_off[s] + (th0 + t) * 64);
+#pragma unroll
+                for (int tx = 0; tx < TX; ++tx)
+                    w1v[t][tx][s] = tx_ok[tx] ? ldg_b(a.w1, w1_off + ((th0 + t) * 16 + s) * in_f * 4u + tx * 64) : 0.f;
+            }
+#pragma unroll
+        for (int t = 0; t < TH_BLK; ++t) {
+            floatx4 dht = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dht = __builtin_amdgcn_mfma_f32_16x16x4f32(w2t[t][s], dl[s], dht, 0, 0, 0);
+            const float4 hq = hv[th0 + t];
+            const float m[4] = {hq.x > 0.f ? dht[0] : 0.f, hq.y > 0.f ? dht[1] : 0.f, hq.z > 0.f ? dht[2] : 0.f, hq.w > 0.f ? dht[3] : 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int tx = 0; tx < TX; ++tx) accx[tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[s], w1v[t][tx][s], accx[tx], 0, 0, 0);
+        }
+    }
+    const unsigned x_off = ((unsigned)(r0 + g4 * 4) * in_f + col0 + r16) * 4u;
+#pragma unroll
+    for (int tx = 0; tx < TX; ++tx) {
+        if (!tx_ok[tx]) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dx) + x_off + i * in_f * 4u + tx * 64) = accx[tx][i];
+    }
+}
+
 template <int KS, int TN>
 __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     constexpr unsigned HID = 16 * KS;
@@ -472,6 +566,10 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
     const int bid = blockIdx.x;
     TAIL_STAMP(0);
+    if (bid >= a.n_head + a.n_dw) {
+        tail_dx_role<KS>(a, bid - a.n_head - a.n_dw);
+        return;
+    }
     const bool head_role = bid < a.n_head;
     int tile_m, grp = 0;
     if (!head_role) {
@@ -710,19 +808,27 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
 
 using namespace th;
 
-extern "C" int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes) {
-    return batch > 0 && batch <= 256 && in_features > 0 && hidden > 0 && hidden <= 256 && (hidden % 4) == 0 && classes > 0 &&
-           classes <= 16;
+static bool tail_whole_tiles(int batch, int in_features, int hidden) {
+    return (hidden == 64 || hidden == 128 || hidden == 256) && batch % 16 == 0 && in_features % 16 == 0;
+}
+
+extern "C" int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes, int need_dx) {
+    const bool ok = batch > 0 && batch <= 256 && in_features > 0 && hidden > 0 && hidden <= 256 && (hidden % 4) == 0 && classes > 0 &&
+                    classes <= 16;
+    return ok && (!need_dx || tail_whole_tiles(batch, in_features, hidden));
 }
 
 extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
                            const float *d_targets, int batch, int in_features, int hidden, int classes, float *d_loss,
-                           float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2, float *d_metrics,
-                           int64_t metrics_capacity, int64_t *d_state, int64_t advance, const th_adam_fuse *w1_fuse,
-                           const th_adam_fuse *b1_fuse) {
+                           float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2, const float *d_w1, float *d_dx,
+                           float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                           const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse) {
     TH_REQUIRE(ctx && d_x && d_h && d_w2 && d_targets && d_loss && d_dw1, "th_mlp_tail: null argument");
-    TH_REQUIRE(th_mlp_tail_supported(batch, in_features, hidden, classes),
+    TH_REQUIRE(th_mlp_tail_supported(batch, in_features, hidden, classes, 0),
                "th_mlp_tail: needs batch <= 256, hidden <= 256 and a multiple of 4, classes <= 16 (got %d, %d, %d)", batch, hidden, classes);
+    TH_REQUIRE(!d_dx || (d_w1 && tail_whole_tiles(batch, in_features, hidden)),
+               "th_mlp_tail: d_dx needs d_w1 and whole tiles (hidden 64 / 128 / 256, batch and in_features multiples of 16)");
+    TH_REQUIRE(!d_dx || !(w1_fuse && w1_fuse->d_p), "th_mlp_tail: with d_dx the launch reads W1, its update must be deferred (th_adam_slice)");
     TH_REQUIRE((((uintptr_t)d_h | (uintptr_t)d_w2) & 15) == 0, "th_mlp_tail: d_h and d_w2 must be 16-byte aligned");
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp_tail: metrics need d_state and a capacity");
     TH_REQUIRE(!(b1_fuse && b1_fuse->d_p) || d_db1, "th_mlp_tail: fused b1 update needs d_db1");
@@ -742,10 +848,13 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
     a.groups = ceil_div(in_features, 16 * tn);
     a.n_dw = (a.tiles_m * a.groups + 7) & ~7;
     a.n_head = (a.tiles_m + 7) & ~7;
-    const int grid = a.n_dw + a.n_head;
+    a.w1 = d_w1;
+    a.dx = d_dx;
+    a.xgroups = ceil_div(in_features, 32);
+    const int grid = a.n_dw + a.n_head + (d_dx ? a.xgroups * ceil_div(batch, 64) : 0);
     // whole tiles everywhere (the MNIST MLP: 784-128-10, batches of 64 / 32): the short-instruction-stream kernel
-    const bool exact = (hidden == 64 || hidden == 128 || hidden == 256) && batch % 16 == 0 && in_features % 16 == 0 &&
-                       !(getenv("TAPER_TAIL_GENERAL") && getenv("TAPER_TAIL_GENERAL")[0] == '1');
+    const bool exact = tail_whole_tiles(batch, in_features, hidden) &&
+                       (d_dx || !(getenv("TAPER_TAIL_GENERAL") && getenv("TAPER_TAIL_GENERAL")[0] == '1'));
 #define TH_TAIL_LAUNCH(KS, TN)                                                                                        \
     do {                                                                                                              \
         if (exact) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);     \

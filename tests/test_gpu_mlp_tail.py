@@ -33,20 +33,22 @@ def oracle_tail(O, x, w1, b1, w2, b2, y):
     O.Tape.set_zero_sentinel(True)
     w1t, b1t = O.Tensor(w1).requires_grad(), O.Tensor(b1).requires_grad()
     w2t, b2t = O.Tensor(w2).requires_grad(), O.Tensor(b2).requires_grad()
-    h = O.Tensor(x).matmul(w1t.transpose()).add_broadcast(b1t).relu()
+    xt = O.Tensor(x).requires_grad()
+    h = xt.matmul(w1t.transpose()).add_broadcast(b1t).relu()
     logits = h.matmul(w2t.transpose()).add_broadcast(b2t)
     yt = O.Tensor(y)
     loss = O.cross_entropy_loss(logits, yt)
     acc = O.accuracy(logits, yt)
     loss.backward()
     out = dict(h=h.data(), loss=float(loss.data()[0]), ncorrect=round(acc * len(y)), dw1=w1t.grad(), db1=b1t.grad(),
-               dw2=w2t.grad(), db2=b2t.grad())
+               dw2=w2t.grad(), db2=b2t.grad(), dx=xt.grad())
     O.Tape.reset()
     return out
 
 
 SHAPES = [(64, 784, 128, 10), (32, 784, 128, 10), (128, 784, 128, 10), (1, 5, 4, 2), (70, 37, 20, 5), (256, 100, 256, 16),
-          (200, 50, 64, 10), (17, 784, 36, 3)]
+          (200, 50, 64, 10), (17, 784, 36, 3),
+          (256, 784, 128, 10), (192, 64, 64, 10), (48, 784, 128, 10), (16, 16, 256, 16), (240, 48, 256, 3)]   # whole tiles, several / partial chunks
 
 
 @pytest.mark.parametrize("batch,inf,hid,c", SHAPES)
@@ -72,7 +74,7 @@ def test_mlp_tail(ctx, O, batch, inf, hid, c, fuse):
     bf = AdamFuse(int(pb), int(mb), int(vb), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4)
     dw2_in = ctx.upload(w2)
     ctx.call("th_mlp_tail", ctx.upload(x), ctx.upload(h), dw2_in, ctx.upload(b2), ctx.upload(y), batch, inf, hid, c, loss, nc,
-             dw1, db1, dw2, db2, metrics, 16, state, batch, C.byref(wf) if fuse else None, C.byref(bf) if fuse else None)
+             dw1, db1, dw2, db2, None, None, metrics, 16, state, batch, C.byref(wf) if fuse else None, C.byref(bf) if fuse else None)
     assert ctx.download(loss, 1)[0] == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
     assert ctx.download(nc, 1)[0] == ref["ncorrect"]
     close(ctx.download(dw1, w1.shape), ref["dw1"], atol=1e-6)
@@ -94,6 +96,42 @@ def test_mlp_tail(ctx, O, batch, inf, hid, c, fuse):
         np.testing.assert_array_equal(ctx.download(pw, w1.shape), w1)
 
 
+@pytest.mark.parametrize("batch,inf,hid,c", [(64, 128, 64, 10), (256, 128, 64, 10), (48, 784, 128, 10), (32, 48, 256, 16), (16, 16, 64, 2)])
+def test_mlp_tail_dx(ctx, O, batch, inf, hid, c):
+    """a hidden layer that is not the first: the same launch also hands dX = dZ1 . W1 down (whole tiles only)"""
+    rng = np.random.default_rng(batch * 17 + inf + hid + c)
+    x = np.maximum(rng.standard_normal((batch, inf)), 0).astype(np.float32)     # a ReLU output
+    w1 = rng.uniform(-1, 1, (hid, inf)).astype(np.float32) * np.float32(np.sqrt(2.0 / inf))
+    b1 = rng.uniform(-0.1, 0.1, hid).astype(np.float32)
+    w2 = rng.uniform(-0.3, 0.3, (c, hid)).astype(np.float32)
+    b2 = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    ref = oracle_tail(O, x, w1, b1, w2, b2, y)
+    h = ref["h"].reshape(batch, hid).astype(np.float32)
+    dw1, db1, dw2, db2, dx = ctx.empty(w1.size), ctx.empty(hid), ctx.empty(w2.size), ctx.empty(c), ctx.empty(x.size)
+    loss, nc = ctx.empty(1), ctx.empty(1)
+    w1d = ctx.upload(w1)
+    ctx.call("th_mlp_tail", ctx.upload(x), ctx.upload(h), ctx.upload(w2), ctx.upload(b2), ctx.upload(y), batch, inf, hid, c, loss, nc,
+             dw1, db1, dw2, db2, w1d, dx, None, 0, None, 0, None, None)
+    assert ctx.download(loss, 1)[0] == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
+    close(ctx.download(dx, x.shape), ref["dx"], atol=1e-6)
+    close(ctx.download(dw1, w1.shape), ref["dw1"], atol=1e-6)
+    close(ctx.download(db1, hid), ref["db1"], atol=1e-6)
+    close(ctx.download(dw2, w2.shape), ref["dw2"], atol=1e-6)
+    np.testing.assert_array_equal(ctx.download(w1d, w1.shape), w1)
+
+
+def test_mlp_tail_dx_limits(ctx):
+    from taper_amd._lib import TaperError
+    from taper_amd.hip import AdamFuse
+    z = ctx.zeros(256 * 300)
+    with pytest.raises(TaperError, match="whole tiles"):
+        ctx.call("th_mlp_tail", z, z, z, None, z, 20, 48, 64, 3, z, None, z, None, None, None, z, z, None, 0, None, 0, None, None)
+    f = AdamFuse(int(z), int(z), int(z), int(z), int(z), 0.9, 0.999, 1e-8, 0.0)
+    with pytest.raises(TaperError, match="must be deferred"):
+        ctx.call("th_mlp_tail", z, z, z, None, z, 16, 48, 64, 3, z, None, z, None, None, None, z, z, None, 0, None, 0, C.byref(f), None)
+
+
 def test_mlp_tail_optional_outputs_and_limits(ctx):
     from taper_amd._lib import TaperError
     rng = np.random.default_rng(3)
@@ -101,13 +139,13 @@ def test_mlp_tail_optional_outputs_and_limits(ctx):
     w2, y = rng.uniform(-1, 1, (3, 16)).astype(np.float32), rng.integers(0, 3, 8).astype(np.float32)
     loss, dw1 = ctx.empty(1), ctx.empty(16 * 20)
     ctx.call("th_mlp_tail", ctx.upload(x), ctx.upload(h), ctx.upload(w2), None, ctx.upload(y), 8, 20, 16, 3, loss, None, dw1, None,
-             None, None, None, 0, None, 0, None, None)
+             None, None, None, None, None, 0, None, 0, None, None)
     assert np.isfinite(ctx.download(loss, 1)[0])
     z = ctx.zeros(1024 * 300)
     for shape, pat in [((300, 8, 16, 3), "batch <= 256"), ((8, 8, 300, 3), "hidden <= 256"), ((8, 8, 18, 3), "multiple of 4"),
                        ((8, 8, 16, 17), "classes <= 16")]:
         with pytest.raises(TaperError, match=pat):
-            ctx.call("th_mlp_tail", z, z, z, None, z, *shape, z, None, z, None, None, None, None, 0, None, 0, None, None)
+            ctx.call("th_mlp_tail", z, z, z, None, z, *shape, z, None, z, None, None, None, None, None, None, 0, None, 0, None, None)
 
 
 @pytest.mark.parametrize("batch,inf,outf", [(64, 784, 128), (32, 784, 128), (7, 20, 9), (64, 3136, 10), (512, 512, 512)])
