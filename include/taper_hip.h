@@ -279,6 +279,13 @@ int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float 
 /* add_bias_4d fwd/bwd: tensor.rs:1983-1992, 2017-2024 (gb[c] += sum_{n,h,w}) */
 int th_bias_add_nchw(th_ctx *ctx, const float *d_x, const float *d_bias, float *d_y, int n, int c, int hw, int relu);
 int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int c, int hw);
+/* same with the ReLU backward folded in (d_mask_y nullable: only elements whose d_mask_y value is > 0 count,
+ * ops.rs:358-369) and an overwrite form (accumulate == 0: the grad slot was None, no zero-fill needed).
+ * With d_gout = the gradient of a max-pool's OUTPUT and d_mask_y = that output, this is the bias gradient of a
+ * Conv2dReLU -> MaxPool2d pair whose conv output has no other consumer: every pooled gradient lands on exactly
+ * one conv output (tensor.rs:1496-1519), whose ReLU mask is "pooled value > 0" -- no scatter, no dZ buffer. */
+int th_bias_grad_nchw_masked(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw,
+                             int accumulate);
 /* full_backward extension (not in the reference: Q2 cuts these gradients) */
 int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx,
                          int n, int c_in, int h, int w, int c_out, int pad, int weight_layout); /* gx += */

@@ -336,8 +336,10 @@ __global__ __launch_bounds__(256) void bias_add_nchw_kernel(const float *__restr
 
 // grid = (c, slabs): block (ch, s) sums channel ch over its slab of images; with `part` set the slab sums land
 // in part[s][c] and th_colsum_accum adds them to gb in slab order (deterministic), else gb[ch] += the sum.
-__global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__restrict__ g, float *__restrict__ gb,
-                                                             float *__restrict__ part, int n, int c, int hw, int img_per_slab) {
+// mask (nullable): only elements with mask[same index] > 0 count -- the ReLU backward folded in; overwrite: gb = sum
+__global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__restrict__ g, const float *__restrict__ mask,
+                                                             float *__restrict__ gb, float *__restrict__ part, int n, int c, int hw,
+                                                             int img_per_slab, int overwrite) {
     __shared__ float sh[4];
     const int ch = blockIdx.x;
     const int b0 = blockIdx.y * img_per_slab, b1 = min(n, b0 + img_per_slab);
@@ -347,7 +349,9 @@ __global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__rest
     const int step_b = 256 / hw, step_sp = 256 % hw;
     int b = b0 + threadIdx.x / hw, sp = threadIdx.x % hw;
     for (long i = threadIdx.x; i < total; i += 256) {
-        s += g[((long)b * c + ch) * hw + sp];
+        const long ix = ((long)b * c + ch) * hw + sp;
+        const float v = g[ix];
+        s += (mask && !(mask[ix] > 0.f)) ? 0.f : v;
         sp += step_sp;
         b += step_b;
         if (sp >= hw) { sp -= hw; ++b; }
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__rest
     if (threadIdx.x == 0) {
         const float tot = ((sh[0] + sh[1]) + sh[2]) + sh[3];
         if (part) part[(long)blockIdx.y * c + ch] = tot;
-        else gb[ch] += tot;
+        else gb[ch] = overwrite ? tot : gb[ch] + tot;
     }
 }
 
@@ -682,6 +686,10 @@ int th_bias_add_nchw(th_ctx *ctx, const float *d_x, const float *d_bias, float *
 }
 
 int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int c, int hw) {
+    return th_bias_grad_nchw_masked(ctx, d_gout, nullptr, d_gb, n, c, hw, 1);
+}
+
+int th_bias_grad_nchw_masked(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw, int accumulate) {
     TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
     if (c == 0) return 0;
     int slabs = 1;
@@ -690,7 +698,8 @@ int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int 
         if (slabs > n) slabs = n;
     }
     if (slabs <= 1) {
-        hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_gb, (float *)nullptr, n, c, hw, n);
+        hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)nullptr, n, c, hw, n,
+                           accumulate ? 0 : 1);
         TH_LAUNCH_CHECK();
         return 0;
     }
@@ -698,9 +707,11 @@ int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int 
     slabs = ceil_div(n, ips);
     void *part = nullptr;
     if (th_malloc(ctx, (size_t)slabs * c * sizeof(float), &part)) return 1;
-    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c, slabs), dim3(256), 0, ctx->stream, d_gout, d_gb, (float *)part, n, c, hw, ips);
+    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c, slabs), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)part, n, c, hw,
+                       ips, 0);
     TH_LAUNCH_CHECK();
-    if (int rc = th_colsum_accum(ctx, (const float *)part, d_gb, slabs, c)) return rc;
+    if (int rc = accumulate ? th_colsum_accum(ctx, (const float *)part, d_gb, slabs, c) : th_colsum(ctx, (const float *)part, d_gb, slabs, c))
+        return rc;
     return th_free(ctx, part);
 }
 

@@ -460,6 +460,13 @@ FusedAdamScope::~FusedAdamScope() {
 }
 Adam *FusedAdamScope::active() { return t_fused_adam; }
 
+namespace {
+thread_local bool t_pool_bias = false;
+}
+PoolBiasScope::PoolBiasScope(bool on) : prev_(t_pool_bias) { t_pool_bias = on; }
+PoolBiasScope::~PoolBiasScope() { t_pool_bias = prev_; }
+bool PoolBiasScope::active() { return t_pool_bias; }
+
 void Adam::set_lr(float lr) {  // optim.rs:125-127
     lr_ = lr;
     TH(th_memcpy_h2d(Device::ctx(), state_->d + 2, &lr, sizeof(float)));
@@ -723,6 +730,7 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
     // Adam updates ride in the epilogues of the kernels that produce the gradients -- unless the
     // gradients still have to be all-reduced across ranks first
     FusedAdamScope scope((fuse_adam && !comm) ? optimizer.get() : nullptr);
+    PoolBiasScope pool_scope(fuse_head && dynamic_cast<Sequential *>(model.get()) != nullptr);
     Tape::reset();
     Tensor x = Tensor::from_device(d_xb, {batch, 784});
     Tensor y = Tensor::from_device(d_yb, {batch});

@@ -69,6 +69,12 @@ struct GradSlot {
     bool known_zero = false;      // arena slice currently all-zero (DP all-reduce of grad-less params)
     bool shared_const = false;    // buf is the ctx-wide read-only [1.0] (set by backward() on a scalar root)
     bool buf_is_arena = false;    // buf is a view into an optimizer's flat grad arena (never re-pointed)
+    // Trainer-internal peephole (PoolBiasScope): the slot belongs to the output of a Conv2dReLU whose only trainable
+    // input is its bias (Q2); a max-pool consuming it then leaves {gradient of the POOLED output, pooled output} here
+    // instead of scattering, and the conv's backward sums the bias gradient straight from them
+    bool wants_pooled = false;
+    std::shared_ptr<Buffer> pooled_dy, pooled_y;
+    int pooled_n = 0, pooled_c = 0, pooled_hw = 0;
 };
 
 class Tensor {
@@ -476,6 +482,18 @@ class ReduceLROnPlateau : public LRScheduler {  // optim.rs:290-352
 };
 
 // RAII: marks `adam` as the optimizer whose updates may be fused on this thread.
+// While active on this thread (Trainer graph steps over a Sequential model: every tensor has one consumer),
+// Conv2dReLU -> MaxPool2d pairs in bias-only mode skip the max-pool scatter and the ReLU-backward pass.
+class PoolBiasScope {
+   public:
+    explicit PoolBiasScope(bool on);
+    ~PoolBiasScope();
+    static bool active();
+
+   private:
+    bool prev_;
+};
+
 class FusedAdamScope {
    public:
     explicit FusedAdamScope(Adam *adam);

@@ -706,10 +706,22 @@ Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> s
     const bool x_grad = fb && requires_grad_ && is3 && pad == 1;
     if (bias_grad || w_grad || x_grad) {
         out.requires_grad_ = true;
+        out.grad_->wants_pooled = relu && bias_grad && !w_grad && !x_grad && PoolBiasScope::active();
         Tensor x = *this, wt = w, b = bias, r = out;
         Tape::push(out, true, [x, wt, b, r, n, c_in, h, wd, c_out, h_out, w_out, pad, relu, bias_grad, w_grad, x_grad, is3]() {
-            if (!r.has_grad()) return;
             th_ctx *c = Device::ctx();
+            if (r.grad_->pooled_dy && !r.grad_->has) {
+                // the max-pool behind this layer left its OUTPUT's gradient: db = sum of the pooled gradients whose
+                // pooled value is > 0 (the one conv output each lands on, and that output's ReLU mask)
+                GradSlot &g = *r.grad_;
+                bool none;
+                float *db = b.grad_for_write(&none);
+                TH(th_bias_grad_nchw_masked(c, g.pooled_dy->d, g.pooled_y->d, db, g.pooled_n, g.pooled_c, g.pooled_hw, none ? 0 : 1));
+                g.pooled_dy.reset();
+                g.pooled_y.reset();
+                return;
+            }
+            if (!r.has_grad()) return;
             const float *gy = r.grad_dptr();
             std::shared_ptr<Buffer> dz;
             if (relu) {
@@ -743,8 +755,18 @@ Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pai
     if (requires_grad_) {
         out.requires_grad_ = true;
         Tensor in = *this, r = out;
-        Tape::push(out, true, [in, r, arg, n, ch, h, w, k, s, p]() {
+        const int hw_out = h_out * w_out;
+        Tape::push(out, true, [in, r, arg, n, ch, h, w, k, s, p, hw_out]() {
             if (!r.has_grad()) return;
+            if (in.grad_->wants_pooled && !in.grad_->has && !r.grad_->shared_const) {   // PoolBiasScope: see GradSlot
+                GradSlot &g = *in.grad_;
+                g.pooled_dy = r.grad_->buf;
+                g.pooled_y = r.data_;
+                g.pooled_n = n;
+                g.pooled_c = ch;
+                g.pooled_hw = hw_out;
+                return;
+            }
             bool none;
             float *gin = in.grad_for_write(&none);  // zero_first (Q5) overwrites whatever was there
             TH(th_maxpool2d_bwd(Device::ctx(), r.grad_dptr(), reinterpret_cast<const int64_t *>(arg->d), gin, n, ch, h, w, k.first,

@@ -271,3 +271,32 @@ def test_data_parallel_step_with_single_rank_communicator_matches_plain_step():
     for a, b in zip(out[0][1], out[1][1]):
         np.testing.assert_array_equal(a, b)
     assert out[0][2] == out[1][2] == 41
+
+
+@pytest.mark.parametrize("model_name,batch", [("cnn_simple", 16), ("cnn_reference", 8)])
+def test_cnn_graph_epoch_matches_oracle(model_name, batch):
+    """the graph path of the CNNs (faithful mode, Q2: only the last conv's bias and the Linears train) against the
+    oracle: the Conv2dReLU -> MaxPool2d pair of the simple CNN takes the pooled bias-gradient shortcut
+    (th_bias_grad_nchw_masked on the pool's OUTPUT gradient, no scatter, no ReLU-backward pass)"""
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(17)
+    n = 3 * batch + batch // 2
+    spec = backends.nonzero_biases(getattr(backends, model_name)(rng), rng)
+    x, y = backends.mnist_like(rng, n)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    lr = 1e-2
+    hopt, oopt = T.Adam(hm.parameters(), lr, None, None, 1e-4), Orc.m.Adam(om.parameters(), lr, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt, sample_shape=(1, 28, 28))
+    loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False)
+    for epoch in range(2):
+        ep = tr.run_epoch(loader, T.Trainer.GRAPH)
+        ref_losses = []
+        for s in range(0, n, batch):
+            xb, yb = x[s:s + batch], y[s:s + batch]
+            ref_losses.append(om.train_step(oopt, xb, yb, (len(xb), 1, 28, 28))["loss"])
+        np.testing.assert_allclose(ep["losses"], ref_losses, rtol=1e-3, atol=1e-4, err_msg=f"epoch {epoch}")
+    for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+        np.testing.assert_allclose(hp.data(), op.data(), rtol=1e-3, atol=lr * 5e-2, err_msg=f"param {i}")
+    assert hopt.t() == oopt.t() == 8
