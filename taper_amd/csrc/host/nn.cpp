@@ -473,7 +473,20 @@ void Adam::set_lr(float lr) {  // optim.rs:125-127
 }
 
 void Adam::step() {  // optim.rs:83-113
-    if (!carry_deferred_) flush_deferred();  // complete gradients no backward launch carried
+    if (!carry_deferred_ && !deferred_.empty()) {
+        // complete gradients no backward launch carried.  When the arena-wide launch below runs anyway (some
+        // parameter was not fused), it takes them along: one launch instead of two, same arithmetic, same t.
+        bool general = false;
+        for (size_t i = 0; i < fp_.params.size(); ++i) general = general || (!fused_[i] && fp_.params[i].has_grad());
+        if (general) {
+            for (const th_adam_slice &d : deferred_)
+                for (size_t i = 0; i < fp_.params.size(); ++i)
+                    if (fp_.p_arena->d + fp_.offsets[i] == d.f.d_p) fused_[i] = 0;
+            deferred_.clear();
+        } else {
+            flush_deferred();
+        }
+    }
     // parameters whose update already ran in a fused epilogue this step are masked out
     const size_t left = fp_.sync_mask(&fused_);
     std::fill(fused_.begin(), fused_.end(), 0);

@@ -568,6 +568,14 @@ Tensor Tensor::reshape(const Shape &s) const {  // tensor.rs:803-840
         Tensor in = *this, r = out;
         Tape::push(out, true, [in, r]() {
             if (!r.has_grad()) return;
+            if (PoolBiasScope::active() && !in.has_grad() && !in.grad_->buf_is_arena && !r.grad_->shared_const && !r.grad_->buf_is_arena) {
+                // Trainer steps over a Sequential (one consumer per tensor): 0 + x is x -- adopt the view's gradient
+                in.grad_->buf = r.grad_->buf;
+                in.grad_->has = true;
+                in.grad_->known_zero = false;
+                in.grad_->shared_const = false;
+                return;
+            }
             accumulate_into(in, r.grad_dptr());
         });
     }
