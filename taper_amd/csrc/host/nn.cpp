@@ -798,9 +798,14 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
 void Trainer::enqueue_steps(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
                             size_t batch, size_t steps) {
     int64_t *state = reinterpret_cast<int64_t *>(state_->d);
-    TH(th_gather_batch(Device::ctx(), d_images, d_labels, d_indices, n_indices, state + 1, (int)(batch * steps), 784, xb_->d,
-                       yb_->d));
-    for (size_t s = 0; s < steps; ++s) enqueue_compute(xb_->d + s * batch * 784, yb_->d + s * batch, batch);
+    if (d_indices == nullptr) {
+        // one step over the whole dataset in index order: the "gathered" batch IS the dataset (no copy)
+        enqueue_compute(const_cast<float *>(d_images), const_cast<float *>(d_labels), batch);
+    } else {
+        TH(th_gather_batch(Device::ctx(), d_images, d_labels, d_indices, n_indices, state + 1, (int)(batch * steps), 784, xb_->d,
+                           yb_->d));
+        for (size_t s = 0; s < steps; ++s) enqueue_compute(xb_->d + s * batch * 784, yb_->d + s * batch, batch);
+    }
     // a tail step leaves the head's W / b updates for its successor's first launch; the last one's run here
     if (auto *adam = dynamic_cast<Adam *>(optimizer.get())) adam->flush_deferred();
 }
@@ -833,8 +838,9 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     }
     TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // step = 0, cursor = 0
     const float *d_img = ds.images.dptr(), *d_lab = ds.labels.dptr();
-    const int32_t *d_idx = loader.d_indices();
-    const void *key = d_img;
+    // full batch, index order (mnist.rs:355-363 without shuffle): the gather would be an identity copy of 188 MB
+    const int32_t *d_idx = (!loader.shuffled() && bs >= n && nb == 1) ? nullptr : loader.d_indices();
+    const void *key = d_idx ? (const void *)d_img : (const void *)(reinterpret_cast<const char *>(d_img) + 1);   // the zero-copy form is a different graph
     if (!graphs_.empty() && (graph_batch_ != bs || graph_key_ != key)) drop_graphs();
 
     size_t done = 0;

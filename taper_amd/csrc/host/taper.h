@@ -525,6 +525,7 @@ class DataLoader {  // mnist.rs:327-386
     bool next(Tensor *images, Tensor *labels);  // mnist.rs:373-385; false at end
     const MNISTDataset &dataset() const { return ds_; }
     size_t batch_size() const { return bs_; }
+    bool shuffled() const { return shuffle_; }
     const int32_t *d_indices() const { return reinterpret_cast<const int32_t *>(d_idx_->d); }
     size_t current() const { return cur_; }
     void advance(size_t n) { cur_ += n; }

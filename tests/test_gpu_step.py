@@ -161,6 +161,29 @@ def test_graph_epoch_equals_eager_epoch(n, batch):
         np.testing.assert_allclose(pb, pa, rtol=1e-4, atol=1e-3 * 5e-2)
 
 
+@pytest.mark.parametrize("n,batch", [(96, 96), (80, 128)])
+def test_full_batch_in_index_order_reads_the_dataset_in_place(n, batch):
+    """one step per epoch over the whole dataset without shuffling: the graph path skips the (identity) batch
+    gather and trains straight from the resident dataset -- same losses / weights as the eager loop"""
+    import taper_amd as T
+    H = backends.get("hip")
+    rng = np.random.default_rng(n)
+    spec = backends.mlp_baseline(rng)
+    x, y = backends.mnist_like(rng, n)
+    out = []
+    for mode in (T.Trainer.EAGER, T.Trainer.GRAPH):
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        tr = T.Trainer(model, opt)
+        loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False)
+        eps = [tr.run_epoch(loader, mode) for _ in range(3)]
+        out.append(([e["losses"][0] for e in eps], [p.data() for p in model.parameters()]))
+        assert opt.t() == 3
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=3e-4, atol=1e-5)
+    for pa, pb in zip(out[0][1], out[1][1]):
+        np.testing.assert_allclose(pb, pa, rtol=1e-4, atol=1e-3 * 5e-2)
+
+
 def test_epoch_against_oracle_with_loader_semantics():
     """DataLoader order (index order, last partial batch kept) + Trainer metrics formulas
     (train.rs:117,140-141, Q13) against the oracle driven with the same batches."""
