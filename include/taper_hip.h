@@ -158,6 +158,14 @@ int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d_w, const f
                         float *d_dh, float *d_dw, float *d_db, float *d_metrics, int64_t metrics_capacity,
                         int64_t *d_state, int64_t advance, int32_t *d_adam_tick, const th_adam_fuse *w_fuse,
                         const th_adam_fuse *b_fuse);
+/* same; mask_dh_by_h != 0: d_h is a ReLU output and d_dh receives dH * (H > 0), the gradient of the
+ * pre-activation (ops.rs:358-369, Q15) -- the previous layer's backward then needs no mask pass of its own
+ * (th_linear_bwd with d_relu_y = NULL; the mask is idempotent, so passing it anyway is harmless). */
+int th_linear_xent_head_masked(th_ctx *ctx, const float *d_h, const float *d_w, const float *d_bias, const float *d_targets,
+                               int batch, int in_features, int classes, float *d_logits, float *d_loss, float *d_ncorrect,
+                               float *d_dh, float *d_dw, float *d_db, float *d_metrics, int64_t metrics_capacity,
+                               int64_t *d_state, int64_t advance, int32_t *d_adam_tick, const th_adam_fuse *w_fuse,
+                               const th_adam_fuse *b_fuse, int mask_dh_by_h);
 
 /* ---- fused MLP tail: classifier head + the backward of the hidden layer ---- */
 /* For  ... -> H = relu(X . W1^T + b1) -> logits = H . W2^T + b2 -> cross-entropy

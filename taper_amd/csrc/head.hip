@@ -52,6 +52,7 @@ struct HeadArgs {
     // slots in order.  rows_per_wg == 0: one workgroup, final results written directly.
     int rows_per_wg;
     float *part_scalar;
+    int mask_dh;   // h is a ReLU output: write dH * (H > 0), i.e. the gradient of the PRE-activation (ops.rs:358-369, Q15)
 };
 
 __device__ __forceinline__ long head_target_class(float tf) {  // Rust `as usize`: saturating, NaN -> 0
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int rr = rt * 16 + g4 * 4 + i;
-                    if (rr < rows && col < K) a.dh[(long)(r0 + rr) * K + col] = acc[i];
+                    if (rr < rows && col < K) a.dh[(long)(r0 + rr) * K + col] = (a.mask_dh && !(Hs[rr * LD + col] > 0.f)) ? 0.f : acc[i];
                 }
             }
         }
@@ -483,6 +484,15 @@ extern "C" int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d
                                    float *d_dh, float *d_dw, float *d_db, float *d_metrics, int64_t metrics_capacity,
                                    int64_t *d_state, int64_t advance, int32_t *d_adam_tick, const th_adam_fuse *w_fuse,
                                    const th_adam_fuse *b_fuse) {
+    return th_linear_xent_head_masked(ctx, d_h, d_w, d_bias, d_targets, batch, in_features, classes, d_logits, d_loss, d_ncorrect, d_dh,
+                                      d_dw, d_db, d_metrics, metrics_capacity, d_state, advance, d_adam_tick, w_fuse, b_fuse, 0);
+}
+
+extern "C" int th_linear_xent_head_masked(th_ctx *ctx, const float *d_h, const float *d_w, const float *d_bias, const float *d_targets,
+                                          int batch, int in_features, int classes, float *d_logits, float *d_loss, float *d_ncorrect,
+                                          float *d_dh, float *d_dw, float *d_db, float *d_metrics, int64_t metrics_capacity,
+                                          int64_t *d_state, int64_t advance, int32_t *d_adam_tick, const th_adam_fuse *w_fuse,
+                                          const th_adam_fuse *b_fuse, int mask_dh_by_h) {
     TH_REQUIRE(ctx && d_h && d_w && d_targets && d_loss, "th_linear_xent_head: null argument");
     TH_REQUIRE(batch > 0 && batch <= (1 << 22) && classes > 0 && classes <= HEAD_CMAX && in_features > 0 && in_features <= HEAD_KMAX,
                "th_linear_xent_head: needs batch <= 4194304, classes <= 16, in_features <= 256 (got %d, %d, %d)", batch, classes,
@@ -491,7 +501,8 @@ extern "C" int th_linear_xent_head(th_ctx *ctx, const float *d_h, const float *d
     TH_REQUIRE(!(w_fuse && w_fuse->d_p) || d_dw, "th_linear_xent_head: fused W update needs d_dw");
     TH_REQUIRE(!(b_fuse && b_fuse->d_p) || d_db, "th_linear_xent_head: fused b update needs d_db");
     HeadArgs a{d_h, d_w, d_bias, d_targets, batch, in_features, classes, d_logits, d_loss, d_ncorrect, d_dh, d_dw, d_db,
-               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, make_adam_dev(w_fuse), make_adam_dev(b_fuse), 0, nullptr};
+               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, make_adam_dev(w_fuse), make_adam_dev(b_fuse), 0, nullptr,
+               mask_dh_by_h ? 1 : 0};
     const size_t lds = head_lds_bytes(in_features);
     static bool attr_set = false;
     if (!attr_set) {

@@ -119,13 +119,17 @@ Tensor linear_cross_entropy(const Tensor &h, const Tensor &w, const Tensor &bias
         if (w_grad) fa->defer_for(w);
         if (b_grad) fa->defer_for(bias);
     }
-    TH(th_linear_xent_head(ctx, h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, nullptr,
-                           loss.dptr(), nc, dh ? dh->d : nullptr, dw, db, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
-                           log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr, pw, pb));
+    // h straight out of a fused Linear+ReLU: dH leaves the kernel already masked (the large-batch backward of that
+    // layer would otherwise spend a pass over [B, hidden] on it)
+    const bool mask_dh = dh && h.grad_->relu_output;
+    TH(th_linear_xent_head_masked(ctx, h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, nullptr,
+                                  loss.dptr(), nc, dh ? dh->d : nullptr, dw, db, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                                  log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr, pw, pb,
+                                  mask_dh ? 1 : 0));
     if (h_grad || w_grad || b_grad) {
         loss.set_requires_grad(true);
         Tensor hh = h, ww = w, bb = bias, out = loss;
-        Tape::push(loss, true, [hh, ww, bb, out, dh, w_grad, b_grad]() {
+        Tape::push(loss, true, [hh, ww, bb, out, dh, w_grad, b_grad, mask_dh]() {
             if (!out.has_grad()) return;
             // the gradients were produced by the forward launch for an upstream grad of exactly 1
             TAPER_ASSERT(out.grad_->shared_const, "linear_cross_entropy: only loss.backward() from the root is supported");
@@ -134,6 +138,7 @@ Tensor linear_cross_entropy(const Tensor &h, const Tensor &w, const Tensor &bias
                 hh.grad_->buf = dh;
                 hh.grad_->has = true;
                 hh.grad_->shared_const = false;
+                hh.grad_->premasked = mask_dh;
             }
             if (w_grad) ww.grad_->has = true;
             if (b_grad) bb.grad_->has = true;

@@ -72,6 +72,8 @@ struct GradSlot {
     // Trainer-internal peephole (PoolBiasScope): the slot belongs to the output of a Conv2dReLU whose only trainable
     // input is its bias (Q2); a max-pool consuming it then leaves {gradient of the POOLED output, pooled output} here
     // instead of scattering, and the conv's backward sums the bias gradient straight from them
+    bool relu_output = false;     // the tensor is the output of a fused Linear+ReLU node
+    bool premasked = false;       // its gradient already carries that ReLU's mask (th_linear_xent_head_masked)
     bool wants_pooled = false;
     std::shared_ptr<Buffer> pooled_dy, pooled_y;
     int pooled_n = 0, pooled_c = 0, pooled_hw = 0;

@@ -460,6 +460,7 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
     const bool need = requires_grad_ || w.requires_grad_ || (bias.defined() && bias.requires_grad_);
     if (need) {
         out.requires_grad_ = true;
+        out.grad_->relu_output = relu;
         Tensor x = *this, wt = w, b = bias, r = out;
         Tape::push(out, true, [x, wt, b, r, batch, in_f, out_f, relu]() {
             if (!r.has_grad()) return;
@@ -467,7 +468,7 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
             const float *dy = r.grad_dptr();
             // relu backward through the post-activation mask (y > 0 <=> pre-activation > 0, Q15),
             // folded into the operand loads of the backward GEMMs
-            const float *relu_y = relu ? r.dptr() : nullptr;
+            const float *relu_y = (relu && !r.grad_->premasked) ? r.dptr() : nullptr;
             int mask = 0;
             bool none;
             float *dx = nullptr, *dw = nullptr, *db = nullptr;

@@ -81,6 +81,22 @@ def test_linear_xent_head(ctx, O, batch, k, c):
     assert np.isfinite(ctx.download(loss, 1)[0])
 
 
+@pytest.mark.parametrize("batch", [48, 300])
+def test_linear_xent_head_masked(ctx, O, batch):
+    """mask_dh_by_h: dH leaves the head already multiplied by (H > 0) -- the ReLU backward of the layer in front"""
+    k, c = 128, 10
+    rng = np.random.default_rng(batch)
+    h = np.maximum(rng.standard_normal((batch, k)), 0).astype(np.float32)
+    w = rng.uniform(-0.3, 0.3, (c, k)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    ref = oracle_head(O, h, w, b, y)
+    dh_, loss = ctx.empty(batch * k), ctx.empty(1)
+    ctx.call("th_linear_xent_head_masked", ctx.upload(h), ctx.upload(w), ctx.upload(b), ctx.upload(y), batch, k, c, None, loss, None,
+             dh_, None, None, None, 0, None, 0, None, None, None, 1)
+    close(ctx.download(dh_, (batch, k)), np.asarray(ref["dh"]).reshape(batch, k) * (h > 0))
+
+
 def test_head_limits_are_errors(ctx):
     from taper_amd._lib import TaperError
     x = ctx.zeros(64 * 300)
