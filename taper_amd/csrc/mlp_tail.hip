@@ -44,8 +44,77 @@ struct TailArgs {
     int xgroups;                         // 32-column groups of dX; its workgroups: xgroups x ceil(B / 64) behind the dW blocks
 };
 
-__device__ __forceinline__ long tail_target_class(float tf) {  // Rust `as usize`: saturating, NaN -> 0
-    return (tf >= 0.f) ? (long)fminf(tf, 2147483520.f) : 0;
+// ---- helpers shared by the general and the whole-tile kernel ----
+__device__ __forceinline__ float ldg_b(const float *base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ float4 ldg4_b(const float *base, unsigned byte_off) {
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+// lane l and lane l ^ 16 (resp. l ^ 32) both receive (x of the lower lane, x of the upper lane)
+__device__ __forceinline__ void pair16(float x, float &lo, float &hi) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void pair32(float x, float &lo, float &hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_over_g4(float x) {
+    float lo, hi;
+    pair16(x, lo, hi);
+    x = lo + hi;
+    pair32(x, lo, hi);
+    return lo + hi;
+}
+__device__ __forceinline__ void argmax_step(float &best, int &bi, float v0, float v1, float i0, float i1) {
+    const int j0 = __float_as_int(i0), j1 = __float_as_int(i1);
+    const bool take1 = v1 > v0 || (v1 == v0 && j1 < j0);
+    best = take1 ? v1 : v0;
+    bi = take1 ? j1 : j0;
+}
+
+// Softmax cross-entropy of one row held as lg[i] = logit[class 4 g4 + i] over the four lanes (r16, 0..3)
+// (loss.rs:101-195, 271-290).  lg is -inf for classes >= C.  Every lane of the row gets nll and argmax.
+__device__ __forceinline__ void tail_row_softmax(const float (&lg)[4], int g4, int C, float tf, float inv_b, float (&dl)[4],
+                                                 float &nll, int &argmax) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // first max; NaN / -inf never win (tensor.rs:1062)
+        const bool w = lg[i] > best;
+        best = w ? lg[i] : best;
+        bi = w ? g4 * 4 + i : bi;
+    }
+    float v0, v1, i0, i1;
+    pair16(best, v0, v1);
+    pair16(__int_as_float(bi), i0, i1);
+    argmax_step(best, bi, v0, v1, i0, i1);
+    pair32(best, v0, v1);
+    pair32(__int_as_float(bi), i0, i1);
+    argmax_step(best, bi, v0, v1, i0, i1);
+    if (bi == 0x7fffffff) bi = 0;
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) se += (g4 * 4 + i < C) ? expf(lg[i] - best) : 0.f;
+    se = sum_over_g4(se);
+    const float log_sum = logf(se);
+    const int tc = (tf >= 0.f) ? (int)fminf(tf, 2147483520.f) : 0;   // Rust `as usize`: saturating, NaN -> 0
+    float my_nll = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cls = g4 * 4 + i;
+        const float lp = (lg[i] - best) - log_sum;   // loss.rs:117-125
+        const float gv = expf(lp);                    // loss.rs:178
+        const bool hit = cls == tc;
+        my_nll = hit ? -lp : my_nll;
+        dl[i] = (cls < C) ? (hit ? gv - 1.0f : gv) * inv_b : 0.f;   // loss.rs:185-188 with g0 = 1
+    }
+    my_nll = sum_over_g4(my_nll);
+    nll = (tc >= C) ? NAN : my_nll;                   // the reference panics (loss.rs:161)
+    argmax = bi;
 }
 
 #ifdef TH_PROFILE
@@ -207,51 +276,13 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
             aw = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks].w, hv[ks].w, aw, 0, 0, 0);
         }
         // lane (r16, g4): logit[row_a][class 4 g4 + i]
-        float lg[4], dl[4];
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
+        float lg[4], dl[4], nll_row;
+        int bi;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lg[i] = ((ax[i] + ay[i]) + (az[i] + aw[i])) + b2v[i];
-            const int cls = g4 * 4 + i;
-            if (cls < C && lg[i] > -INFINITY && lg[i] > best) {   // first max; NaN / -inf never win (tensor.rs:1062)
-                best = lg[i];
-                bi = cls;
-            }
-        }
+        for (int i = 0; i < 4; ++i) lg[i] = (g4 * 4 + i < C) ? ((ax[i] + ay[i]) + (az[i] + aw[i])) + b2v[i] : -INFINITY;
+        tail_row_softmax(lg, g4, C, tf, inv_b, dl, nll_row, bi);
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float ov = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > best || (ov == best && oi < bi)) {
-                best = ov;
-                bi = oi;
-            }
-        }
-        if (bi == 0x7fffffff) bi = 0;
-        float se = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) se += (g4 * 4 + i < C) ? expf(lg[i] - best) : 0.f;
-        se += __shfl_xor(se, 16, 64);
-        se += __shfl_xor(se, 32, 64);
-        const float log_sum = logf(se);
-        const long tcls = tail_target_class(tf);
-        float my_nll = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int cls = g4 * 4 + i;
-            float dv = 0.f;
-            if (row_a_ok && cls < C) {
-                const float lp = (lg[i] - best) - log_sum;   // loss.rs:117-125
-                float gv = expf(lp);                          // loss.rs:178
-                if (cls == tcls) {
-                    my_nll = -lp;
-                    gv -= 1.0f;
-                }
-                dv = gv * inv_b;                              // loss.rs:185-188 with g0 = 1
-            }
-            dl[i] = dv;
-        }
+        for (int i = 0; i < 4; ++i) dl[i] = row_a_ok ? dl[i] : 0.f;
 
         TAIL_STAMP(4);
         // ---- dH tile (ops.rs:254-265) and the ReLU mask of the hidden layer (ops.rs:358-369, Q15) ----
@@ -285,9 +316,7 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
                 acc_dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tr[wave][g4 * 4 + s][r16], hm[s], acc_dw2, 0, 0, 0);
             if (lead) {
                 // db2 (column sums of dlogits), loss and hits: over the 16 rows (r16) by xor-shuffles
-                my_nll += __shfl_xor(my_nll, 16, 64);
-                my_nll += __shfl_xor(my_nll, 32, 64);
-                float nl = (row_a_ok && g4 == 0) ? ((tcls >= C) ? NAN : my_nll) : 0.f;   // the reference panics (loss.rs:161)
+                float nl = (row_a_ok && g4 == 0) ? nll_row : 0.f;
                 float ht = (row_a_ok && g4 == 0 && fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;   // loss.rs:283
                 float d4[4] = {dl[0], dl[1], dl[2], dl[3]};
 #pragma unroll
@@ -393,78 +422,6 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
 // tiles are valid or skipped wave-uniformly; classes >= C are masked once, at the logits), 32-bit byte
 // offsets from uniform bases (one VALU op per address, immediates for the rest), cross-lane steps through
 // v_permlane{16,32}_swap instead of LDS round trips, branch-free softmax.
-__device__ __forceinline__ float ldg_b(const float *base, unsigned byte_off) {
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-__device__ __forceinline__ float4 ldg4_b(const float *base, unsigned byte_off) {
-    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-// lane l and lane l ^ 16 (resp. l ^ 32) both receive (x of the lower lane, x of the upper lane)
-__device__ __forceinline__ void pair16(float x, float &lo, float &hi) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    lo = __uint_as_float(r[0]);
-    hi = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void pair32(float x, float &lo, float &hi) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    lo = __uint_as_float(r[0]);
-    hi = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float sum_over_g4(float x) {
-    float lo, hi;
-    pair16(x, lo, hi);
-    x = lo + hi;
-    pair32(x, lo, hi);
-    return lo + hi;
-}
-__device__ __forceinline__ void argmax_step(float &best, int &bi, float v0, float v1, float i0, float i1) {
-    const int j0 = __float_as_int(i0), j1 = __float_as_int(i1);
-    const bool take1 = v1 > v0 || (v1 == v0 && j1 < j0);
-    best = take1 ? v1 : v0;
-    bi = take1 ? j1 : j0;
-}
-
-// Softmax cross-entropy of one row held as lg[i] = logit[class 4 g4 + i] over the four lanes (r16, 0..3)
-// (loss.rs:101-195, 271-290).  lg is -inf for classes >= C.  Every lane of the row gets nll and argmax.
-__device__ __forceinline__ void tail_row_softmax(const float (&lg)[4], int g4, int C, float tf, float inv_b, float (&dl)[4],
-                                                 float &nll, int &argmax) {
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {          // first max; NaN / -inf never win (tensor.rs:1062)
-        const bool w = lg[i] > best;
-        best = w ? lg[i] : best;
-        bi = w ? g4 * 4 + i : bi;
-    }
-    float v0, v1, i0, i1;
-    pair16(best, v0, v1);
-    pair16(__int_as_float(bi), i0, i1);
-    argmax_step(best, bi, v0, v1, i0, i1);
-    pair32(best, v0, v1);
-    pair32(__int_as_float(bi), i0, i1);
-    argmax_step(best, bi, v0, v1, i0, i1);
-    if (bi == 0x7fffffff) bi = 0;
-    float se = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) se += (g4 * 4 + i < C) ? expf(lg[i] - best) : 0.f;
-    se = sum_over_g4(se);
-    const float log_sum = logf(se);
-    const int tc = (tf >= 0.f) ? (int)fminf(tf, 2147483520.f) : 0;   // Rust `as usize`: saturating, NaN -> 0
-    float my_nll = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int cls = g4 * 4 + i;
-        const float lp = (lg[i] - best) - log_sum;   // loss.rs:117-125
-        const float gv = expf(lp);                    // loss.rs:178
-        const bool hit = cls == tc;
-        my_nll = hit ? -lp : my_nll;
-        dl[i] = (cls < C) ? (hit ? gv - 1.0f : gv) * inv_b : 0.f;   // loss.rs:185-188 with g0 = 1
-    }
-    my_nll = sum_over_g4(my_nll);
-    nll = (tc >= C) ? NAN : my_nll;                   // the reference panics (loss.rs:161)
-    argmax = bi;
-}
-
 // dX role of the whole-tile kernel (ops.rs:254-265 of the hidden layer, for MLPs with more layers in front):
 // workgroup (32-column group xg, 64-row chunk) -- each wave owns 16 rows and needs no other wave.  After the
 // same logits / softmax, per 16 hidden units th:
