@@ -224,6 +224,9 @@ int th_pow_bwd(th_ctx *ctx, const float *d_x, float e, const float *d_gout, floa
 
 /* ---- broadcast / reduce / layout: src/tensor.rs ---------------------- */
 int th_transpose2d(th_ctx *ctx, const float *d_in, float *d_out, int rows, int cols);      /* tensor.rs:544-566 */
+/* dst[r*dst_ld + c] = src[r*src_ld + c] for r < rows, c < cols: the strided block copies behind slice_channels /
+ * slice_output_channels / cat of a grouped convolution (nn.rs:862-1014) */
+int th_copy2d(th_ctx *ctx, const float *d_src, float *d_dst, int64_t rows, int cols, int64_t src_ld, int64_t dst_ld);
 int th_transpose2d_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, int rows, int cols); /* tensor.rs:574-587: gin[i,j] += gout[j,i] */
 int th_bias_add_rows(th_ctx *ctx, const float *d_x, const float *d_bias, float *d_y, int rows, int cols, int relu); /* tensor.rs:658-663 */
 int th_colsum_accum(th_ctx *ctx, const float *d_g, float *d_gb, int rows, int cols);       /* tensor.rs:686-691: gb[f] += sum_b g[b,f] */

@@ -104,6 +104,13 @@ int tp_relu_new(tp_module **out);
 int tp_sigmoid_new(tp_module **out);
 int tp_conv2d_new(int in_ch, int out_ch, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, int with_bias,
                   int fuse_relu, uint64_t seed, tp_module **out);
+/* nn.rs:180-354 with groups > 1: weight [out, in/groups, k, k]; forward = slice_channels / slice_output_channels /
+ * slice_1d, one conv2d per group, cat(dim 1) (nn.rs:289-332, 859-1014).  Like the reference's, the slices carry no tape
+ * nodes: a grouped convolution is forward-only (nothing behind it, nor its own parameters, receives a gradient). */
+int tp_conv2d_grouped_new(int in_ch, int out_ch, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, int groups,
+                          int with_bias, int fuse_relu, uint64_t seed, tp_module **out);
+int tp_slice_channels(const tp_tensor *x, size_t start, size_t end, tp_tensor **out);   /* nn.rs:862-886 */
+int tp_cat(const tp_tensor *const *tensors, int n, size_t dim, tp_tensor **out);        /* nn.rs:928-1014: 2-D dim 0/1, 4-D dim 1 */
 int tp_maxpool2d_new(int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, tp_module **out);
 int tp_avgpool2d_new(int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, tp_module **out);
 int tp_adaptive_avgpool2d_new(int out_h, int out_w, tp_module **out);

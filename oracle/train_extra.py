@@ -129,6 +129,35 @@ def dropout_forward(x, mask=None, p=0.5, training=True):
     return (x * np.asarray(mask, f32)).astype(f32)
 
 
+# ---- src/nn.rs:289-332, 859-1014: grouped convolution = slices + per-group conv2d + cat --------------------
+def slice_channels(x, start, end):
+    """nn.rs:862-886 on a [N,C,H,W] array"""
+    return np.ascontiguousarray(np.asarray(x, f32)[:, start:end])
+
+
+def cat(arrays, dim):
+    """nn.rs:928-1014: 2-D along dim 0 / 1, 4-D along dim 1 (anything else is unimplemented!() in the reference)"""
+    nd = np.asarray(arrays[0]).ndim
+    if nd not in (2, 4) or (nd == 4 and dim != 1):
+        raise NotImplementedError("cat: the reference implements 2-D (dim 0/1) and 4-D (dim 1) only")
+    return np.concatenate([np.asarray(a, f32) for a in arrays], axis=dim)
+
+
+def grouped_conv2d(O, x, weight, bias, groups, stride=(1, 1), padding=(0, 0), relu=False):
+    """nn.rs:289-332 with the C oracle's conv2d (O = oracle.oracle) per group: weight [C_out, C_in/groups, k, k];
+    each group's weight slice is handed to conv2d as its own tensor, i.e. the reinterpretation quirk Q3 applies per group"""
+    x, weight = np.asarray(x, f32), np.asarray(weight, f32)
+    cin_g, cout_g = x.shape[1] // groups, weight.shape[0] // groups
+    outs = []
+    for g in range(groups):
+        xs = O.Tensor(slice_channels(x, g * cin_g, (g + 1) * cin_g))
+        ws = O.Tensor(np.ascontiguousarray(weight[g * cout_g:(g + 1) * cout_g]))          # slice_output_channels, nn.rs:889-914
+        bs = None if bias is None else O.Tensor(np.asarray(bias, f32)[g * cout_g:(g + 1) * cout_g].copy())   # slice_1d, nn.rs:917-925
+        y = (xs.conv2d_relu if relu else xs.conv2d)(ws, bs, stride, padding)
+        outs.append(np.asarray(y.data(), f32).reshape(y.shape()))
+    return cat(outs, 1)
+
+
 # ---- src/train.rs -----------------------------------------------------------------------------------
 def format_f32_display(v) -> str:
     """Rust `{}` for f32 (train.rs:283-285 `writeln!(file, "{}", value)`): shortest digits that

@@ -195,6 +195,14 @@ class Tensor:
     view = reshape
     def flatten(self, start_dim): return self._un(host.tp_flatten, "flatten", int(start_dim))
     def squeeze(self, dim=None): return self._un(host.tp_squeeze, "squeeze", -1 if dim is None else int(dim))
+    def slice_channels(self, start, end): return self._un(host.tp_slice_channels, "slice_channels", int(start), int(end))   # nn.rs:862-886
+
+    @staticmethod
+    def cat(tensors, dim):   # nn.rs:928-1014
+        arr = (C.c_void_p * len(tensors))(*[t._h for t in tensors])
+        out = _p()
+        tp_check(host.tp_cat(arr, len(tensors), int(dim), C.byref(out)), "cat")
+        return Tensor(_h=out.value)
     def unsqueeze(self, dim): return self._un(host.tp_unsqueeze, "unsqueeze", int(dim))
 
     def max(self, dim=None):
@@ -302,11 +310,12 @@ class Sigmoid(Module):
 class Conv2d(Module):
     def __init__(self, in_ch, out_ch, kernel_size, stride=None, padding=None, dilation=None, groups=None, bias=True,
                  seed=1, _relu=False):
-        if dilation not in (None, (1, 1)) or groups not in (None, 1):
-            raise TaperError("Conv2d: dilation/groups are out of scope (SURVEY.md section 2 row 8)")
+        if dilation not in (None, (1, 1)):
+            raise TaperError("Conv2d: dilation is out of scope (SURVEY.md section 2 row 8)")
         s, p = stride or (1, 1), padding or (0, 0)
-        super().__init__(_mk(host.tp_conv2d_new, "Conv2d::new", int(in_ch), int(out_ch), kernel_size[0], kernel_size[1],
-                             s[0], s[1], p[0], p[1], 1 if bias else 0, 1 if _relu else 0, int(seed)))
+        # groups > 1 (nn.rs:289-332): slice / conv per group / cat, forward only like the reference
+        super().__init__(_mk(host.tp_conv2d_grouped_new, "Conv2d::new", int(in_ch), int(out_ch), kernel_size[0], kernel_size[1],
+                             s[0], s[1], p[0], p[1], int(groups or 1), 1 if bias else 0, 1 if _relu else 0, int(seed)))
 
 
 class Conv2dReLU(Conv2d):

@@ -180,6 +180,26 @@ int tp_conv2d_new(int ic, int oc, int kh, int kw, int sh, int sw, int ph, int pw
     *out = new tp_module{c};
     TP_END
 }
+int tp_conv2d_grouped_new(int ic, int oc, int kh, int kw, int sh, int sw, int ph, int pw, int groups, int bias, int relu, uint64_t seed,
+                          tp_module **out) {
+    TP_BEGIN
+    TAPER_ASSERT(groups >= 1, "groups must be >= 1");
+    auto c = std::make_shared<Conv2d>((size_t)ic, (size_t)oc, std::make_pair(kh, kw), std::make_pair(sh, sw), std::make_pair(ph, pw),
+                                      bias != 0, seed, (size_t)groups);
+    c->fuse_relu = relu != 0;
+    *out = new tp_module{c};
+    TP_END
+}
+int tp_slice_channels(const tp_tensor *x, size_t start, size_t end, tp_tensor **out) {
+    TP_BEGIN *out = new tp_tensor{x->t.slice_channels(start, end)}; TP_END
+}
+int tp_cat(const tp_tensor *const *tensors, int n, size_t dim, tp_tensor **out) {
+    TP_BEGIN
+    std::vector<Tensor> ts;
+    for (int i = 0; i < n; ++i) ts.push_back(tensors[i]->t);
+    *out = new tp_tensor{Tensor::cat(ts, dim)};
+    TP_END
+}
 int tp_maxpool2d_new(int kh, int kw, int sh, int sw, int ph, int pw, tp_module **out) {
     TP_BEGIN *out = new tp_module{std::make_shared<MaxPool2d>(std::make_pair(kh, kw), std::make_pair(sh, sw), std::make_pair(ph, pw))}; TP_END
 }

@@ -275,16 +275,32 @@ std::vector<Tensor> Linear::parameters() const {  // nn.rs:71-77
 }
 
 Conv2d::Conv2d(size_t in_ch, size_t out_ch, std::pair<int, int> kernel, std::pair<int, int> s, std::pair<int, int> p,
-               bool with_bias, uint64_t seed)
-    : stride(s), padding(p) {  // nn.rs:190-244
-    const size_t fan_in = in_ch * kernel.first * kernel.second;
+               bool with_bias, uint64_t seed, size_t g)
+    : stride(s), padding(p), groups(g) {  // nn.rs:190-244
+    TAPER_ASSERT(groups >= 1 && in_ch % groups == 0, "in_channels must be divisible by groups");      // nn.rs:205-209
+    TAPER_ASSERT(out_ch % groups == 0, "out_channels must be divisible by groups");                    // nn.rs:210-214
+    const size_t fan_in = in_ch * kernel.first * kernel.second / groups;                               // nn.rs:219
     const float bound = std::sqrt(2.0f / (float)fan_in) * std::sqrt(3.0f);
-    weight = Tensor(uniform_init(out_ch * fan_in, bound, seed), {out_ch, in_ch, (size_t)kernel.first, (size_t)kernel.second})
+    weight = Tensor(uniform_init(out_ch * fan_in, bound, seed), {out_ch, in_ch / groups, (size_t)kernel.first, (size_t)kernel.second})
                  .requires_grad();
     if (with_bias) bias = Tensor(std::vector<float>(out_ch, 0.f), {out_ch}).requires_grad();
 }
 
-Tensor Conv2d::forward(const Tensor &x) const { return x.conv2d(weight, bias, stride, padding, dilation, fuse_relu); }
+Tensor Conv2d::forward(const Tensor &x) const {
+    if (groups == 1) return x.conv2d(weight, bias, stride, padding, dilation, fuse_relu);   // nn.rs:280-288
+    // nn.rs:289-332: slices are fresh tensors without tape nodes, so nothing upstream of a grouped
+    // convolution (and none of its own parameters) ever receives a gradient -- reproduced as is
+    TAPER_ASSERT(x.shape().size() == 4 && x.shape()[1] % groups == 0, "Input channels must be divisible by groups");
+    const size_t cin_g = x.shape()[1] / groups, cout_g = weight.shape()[0] / groups;
+    std::vector<Tensor> outs;
+    for (size_t g = 0; g < groups; ++g) {
+        Tensor xs = x.slice_channels(g * cin_g, (g + 1) * cin_g);
+        Tensor ws = weight.slice_output_channels(g * cout_g, (g + 1) * cout_g);
+        Tensor bs = bias.defined() ? bias.slice_1d(g * cout_g, (g + 1) * cout_g) : Tensor();
+        outs.push_back(xs.conv2d(ws, bs, stride, padding, dilation, fuse_relu));
+    }
+    return Tensor::cat(outs, 1);
+}
 
 std::vector<Tensor> Conv2d::parameters() const {
     std::vector<Tensor> p{weight};

@@ -131,6 +131,11 @@ class Tensor {
     Tensor log() const;                        // tensor.rs:1136-1169
     Tensor pow(float e) const;                 // tensor.rs:1172-1206
     Tensor sqrt() const { return pow(0.5f); }  // tensor.rs:1209-1211
+    // helpers of the grouped convolution (nn.rs:859-1014): plain data copies, no tape nodes (like the reference's Tensor::new)
+    Tensor slice_channels(size_t start, size_t end) const;         // nn.rs:862-886, 4-D [N,C,H,W] -> [N,end-start,H,W]
+    Tensor slice_output_channels(size_t start, size_t end) const;  // nn.rs:889-914, 4-D weight rows
+    Tensor slice_1d(size_t start, size_t end) const;               // nn.rs:917-925
+    static Tensor cat(const std::vector<Tensor> &tensors, size_t dim);  // nn.rs:928-1014 (2-D dim 0/1, 4-D dim 1)
     // conv / pool (tensor.rs:1221-1660).  bias may be undefined (None).
     Tensor conv2d(const Tensor &weight, const Tensor &bias, std::pair<int, int> stride, std::pair<int, int> padding,
                   std::pair<int, int> dilation, bool relu = false) const;
@@ -239,13 +244,14 @@ class Sigmoid : public Module {  // activation.rs:37-51
     const char *name() const override { return "Sigmoid"; }
 };
 
-class Conv2d : public Module {  // nn.rs:180-354 (groups == 1)
+class Conv2d : public Module {  // nn.rs:180-354
    public:
-    Tensor weight, bias;
+    Tensor weight, bias;   // [out, in / groups, k_h, k_w], [out]
     std::pair<int, int> stride{1, 1}, padding{0, 0}, dilation{1, 1};
+    size_t groups = 1;     // > 1: slice, convolve per group, cat (nn.rs:289-332) -- forward only, like the reference
     bool fuse_relu = false;
     Conv2d(size_t in_ch, size_t out_ch, std::pair<int, int> kernel, std::pair<int, int> stride, std::pair<int, int> padding,
-           bool with_bias, uint64_t seed);
+           bool with_bias, uint64_t seed, size_t groups = 1);
     Tensor forward(const Tensor &x) const override;
     std::vector<Tensor> parameters() const override;
     const char *name() const override { return fuse_relu ? "Conv2dReLU" : "Conv2d"; }

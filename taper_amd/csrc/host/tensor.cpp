@@ -583,6 +583,64 @@ Tensor Tensor::reshape(const Shape &s) const {  // tensor.rs:803-840
     return out;
 }
 
+// ---- grouped-convolution helpers (nn.rs:859-1014): strided block copies, no tape nodes ----
+Tensor Tensor::slice_channels(size_t start, size_t end) const {  // nn.rs:862-886
+    TAPER_ASSERT(shape_.size() == 4, "slice_channels only works on 4D tensors");
+    TAPER_ASSERT(start < end && end <= shape_[1], "Invalid channel range");
+    const size_t n = shape_[0], c = shape_[1], hw = shape_[2] * shape_[3], cs = end - start;
+    Tensor out = empty({n, cs, shape_[2], shape_[3]});
+    TH(th_copy2d(Device::ctx(), dptr() + start * hw, out.dptr(), (int64_t)n, (int)(cs * hw), (int64_t)(c * hw), (int64_t)(cs * hw)));
+    return out;
+}
+
+Tensor Tensor::slice_output_channels(size_t start, size_t end) const {  // nn.rs:889-914
+    TAPER_ASSERT(shape_.size() == 4, "slice_output_channels only works on 4D weight tensors");
+    TAPER_ASSERT(start < end && end <= shape_[0], "Invalid output channel range");
+    const size_t per = shape_[1] * shape_[2] * shape_[3], rows = end - start;
+    Tensor out = empty({rows, shape_[1], shape_[2], shape_[3]});
+    TH(th_copy2d(Device::ctx(), dptr() + start * per, out.dptr(), 1, (int)(rows * per), (int64_t)(rows * per), (int64_t)(rows * per)));
+    return out;
+}
+
+Tensor Tensor::slice_1d(size_t start, size_t end) const {  // nn.rs:917-925
+    TAPER_ASSERT(shape_.size() == 1, "slice_1d only works on 1D tensors");
+    TAPER_ASSERT(start < end && end <= shape_[0], "Invalid range");
+    Tensor out = empty({end - start});
+    TH(th_copy2d(Device::ctx(), dptr() + start, out.dptr(), 1, (int)(end - start), (int64_t)(end - start), (int64_t)(end - start)));
+    return out;
+}
+
+Tensor Tensor::cat(const std::vector<Tensor> &ts, size_t dim) {  // nn.rs:928-1014
+    TAPER_ASSERT(!ts.empty(), "Cannot concatenate empty tensor list");
+    const Shape &first = ts[0].shape();
+    const size_t nd = first.size();
+    TAPER_ASSERT(dim < nd, "Concatenation dimension out of bounds");
+    size_t total = 0;
+    for (const Tensor &t : ts) {
+        TAPER_ASSERT(t.shape().size() == nd, "All tensors must have same number of dimensions");
+        for (size_t i = 0; i < nd; ++i)
+            if (i != dim) TAPER_ASSERT(t.shape()[i] == first[i], "Tensor shapes must match except in concatenation dimension");
+        total += t.shape()[dim];
+    }
+    TAPER_ASSERT(nd == 2 || nd == 4, "Concatenation not implemented for " + std::to_string(nd) + "D tensors");
+    TAPER_ASSERT(nd == 2 || dim == 1, "General 4D concatenation not implemented for dim != 1");
+    Shape os = first;
+    os[dim] = total;
+    Tensor out = empty(os);
+    // view every operand as [outer][inner_i] rows laid side by side in [outer][sum inner_i]
+    size_t outer = 1, tail = 1;
+    for (size_t i = 0; i < dim; ++i) outer *= first[i];
+    for (size_t i = dim + 1; i < nd; ++i) tail *= first[i];
+    const size_t out_ld = total * tail;
+    size_t off = 0;
+    for (const Tensor &t : ts) {
+        const size_t inner = t.shape()[dim] * tail;
+        TH(th_copy2d(Device::ctx(), t.dptr(), out.dptr() + off, (int64_t)outer, (int)inner, (int64_t)inner, (int64_t)out_ld));
+        off += inner;
+    }
+    return out;
+}
+
 Tensor Tensor::flatten(size_t start_dim) const {  // tensor.rs:843-858
     TAPER_ASSERT(start_dim < shape_.size(), "start_dim out of bounds");
     Shape ns(shape_.begin(), shape_.begin() + start_dim);

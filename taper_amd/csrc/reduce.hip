@@ -404,6 +404,15 @@ __global__ __launch_bounds__(256) void accuracy_count_kernel(const float *__rest
     if (threadIdx.x == 0) out[0] = h;
 }
 
+// rows x cols block copy between two pitched fp32 matrices (slice_channels / cat, nn.rs:862-1014)
+__global__ __launch_bounds__(256) void copy2d_kernel(const float *__restrict__ src, float *__restrict__ dst, long total, int cols,
+                                                     long src_ld, long dst_ld) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cols, c = i - r * cols;
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+
 }  // namespace th
 
 using namespace th;
@@ -578,6 +587,17 @@ int th_log_softmax_fwd(th_ctx *ctx, const float *d_x, float *d_logp, int rows, i
 int th_accuracy_count(th_ctx *ctx, const float *d_argmax, const float *d_targets, int n, float *d_ncorrect) {
     TH_REQUIRE(ctx && d_argmax && d_targets && d_ncorrect && n >= 0, "th_accuracy_count: bad argument");
     hipLaunchKernelGGL(accuracy_count_kernel, dim3(1), dim3(256), 0, ctx->stream, d_argmax, d_targets, n, d_ncorrect);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_copy2d(th_ctx *ctx, const float *d_src, float *d_dst, int64_t rows, int cols, int64_t src_ld, int64_t dst_ld) {
+    TH_REQUIRE(ctx && rows >= 0 && cols >= 0 && src_ld >= cols && dst_ld >= cols, "th_copy2d: bad geometry");
+    const long total = (long)rows * cols;
+    if (total == 0) return 0;
+    TH_REQUIRE(d_src && d_dst, "th_copy2d: null argument");
+    hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid((size_t)total, 256)), dim3(256), 0, ctx->stream, d_src, d_dst, total, cols, (long)src_ld,
+                       (long)dst_ld);
     TH_LAUNCH_CHECK();
     return 0;
 }

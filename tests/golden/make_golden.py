@@ -120,8 +120,33 @@ def extra_cases():
                         ce=f32(l2.item()), dce=f32(lt.grad.numpy()), lr_step=sched["step"], lr_exp=sched["exp"], lr_cos=sched["cos"])
 
 
+def grouped_conv_case():
+    """Conv2d with groups (nn.rs:289-332) == per-group F.conv2d on the channel slices, each
+    group's weight slice reinterpreted per Q3 (the slice is a tensor of its own when it reaches conv2d), cat on dim 1.
+    torch's own groups= convolution (standard layout) is stored next to it to show the two differ."""
+    r3 = np.random.default_rng(20250930)
+    n, ci, h, w, co, g = 3, 8, 9, 7, 12, 4
+    x = f32(r3.uniform(-1, 1, (n, ci, h, w)))
+    wt = f32(r3.uniform(-0.5, 0.5, (co, ci // g, 3, 3)))
+    b = f32(r3.uniform(-0.5, 0.5, co))
+    cig, cog = ci // g, co // g
+    outs = []
+    for k in range(g):
+        wg = torch.from_numpy(wt[k * cog:(k + 1) * cog]).double()
+        w_eff = wg.flatten().reshape(9 * cig, cog).T.reshape(cog, cig, 3, 3)
+        outs.append(F.conv2d(torch.from_numpy(x[:, k * cig:(k + 1) * cig]).double(), w_eff, torch.from_numpy(b[k * cog:(k + 1) * cog]).double(),
+                             padding=1))
+    y_std = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), torch.from_numpy(b).double(), padding=1, groups=g)
+    np.savez_compressed(OUT / "conv_grouped.npz", x=x, w=wt, b=b, groups=np.array(g), y_taper=f32(torch.cat(outs, 1).numpy()),
+                        y_standard=f32(y_std.numpy()))
+
+
 if __name__ == "__main__":
     import sys
+    if "--grouped" in sys.argv:
+        grouped_conv_case()
+        print("wrote conv_grouped.npz")
+        sys.exit(0)
     if "--extra" in sys.argv:
         extra_cases()
         print("wrote losses_extra.npz")
