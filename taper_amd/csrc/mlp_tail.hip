@@ -45,6 +45,15 @@ struct TailArgs {
 };
 
 // ---- helpers shared by the general and the whole-tile kernel ----
+// A uniform value from global memory through the scalar unit (s_load): it travels on lgkmcnt, so waiting for it does
+// not drain the vector loads in flight.  (As a vector load + readfirstlane the compiler parks an s_waitcnt vmcnt(0)
+// right behind it: one full memory round trip per such value BEFORE the operand loads are even issued -- 2 us here.)
+// Safe for data written by an earlier launch only: the scalar cache is invalidated at kernel start.
+template <class T>
+__device__ __forceinline__ T sload(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
 __device__ __forceinline__ float ldg_b(const float *base, unsigned byte_off) {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
 }
@@ -163,8 +172,8 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
     // the counters / learning rates of the fused updates: scalar loads, requested first (plain loads: nobody
     // writes the counter in this launch); the step sizes are formed while the vector loads are in flight
     const bool any_w = a.w1_adam.p != nullptr, any_b = a.db1 && a.b1_adam.p != nullptr;
-    const int32_t w_t = any_w ? a.w1_adam.t[0] : 1, b_t = any_b ? a.b1_adam.t[0] : 1;
-    const float w_lr = any_w ? a.w1_adam.lr[0] : 0.f, b_lr = any_b ? a.b1_adam.lr[0] : 0.f;
+    const int32_t w_t = any_w ? sload(a.w1_adam.t) : 1, b_t = any_b ? sload(a.b1_adam.t) : 1;
+    const float w_lr = any_w ? sload(a.w1_adam.lr) : 0.f, b_lr = any_b ? sload(a.b1_adam.lr) : 0.f;
     const int Cm1 = C - 1, hid4 = hid - 4, hcol_c = min(hcol, hid - 1);
     float4 wv[KS];                                // W2[class r16][16 ks + 4 g4 ..]
 #pragma unroll
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
         bv_ = a.b1_adam.v[b1_ix];
     }
     const bool fuse_b = own_b1 && fuse_b1;
-    const int64_t state0 = (lead && a.metrics) ? a.state[0] : 0, state1 = (lead && a.metrics) ? a.state[1] : 0;
+    const int64_t state0 = (lead && a.metrics) ? sload(a.state) : 0, state1 = (lead && a.metrics) ? sload(a.state + 1) : 0;
 
     floatx4 accdw[TN];
 #pragma unroll
@@ -513,17 +522,23 @@ __device__ __forceinline__ void tail_dx_role(const TailArgs &a, int rb) {
     }
 }
 
-template <int KS, int TN>
+template <int KS, int TN, bool HAS_DX>
 __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     constexpr unsigned HID = 16 * KS;
     __shared__ float red[4][TN][64][4];
     __shared__ float tr[4][16][17];
     __shared__ float rowv[4][2][16];
     __shared__ float sc[4][36];
+    // ONE batch of scalar loads for the kernel arguments (left alone the compiler sinks each field's s_load into the block
+    // that first uses it, and every later batch has to wait out whatever scalar loads are in flight with it)
+    asm volatile("" ::"s"(a.x), "s"(a.h), "s"(a.w2), "s"(a.b2), "s"(a.targets), "s"(a.batch), "s"(a.in_f), "s"(a.c), "s"(a.dw1),
+                 "s"(a.db1), "s"(a.w1_adam.p), "s"(a.w1_adam.m), "s"(a.w1_adam.v), "s"(a.w1_adam.t), "s"(a.w1_adam.lr),
+                 "s"(a.b1_adam.p), "s"(a.b1_adam.t), "s"(a.b1_adam.lr), "s"(a.n_dw), "s"(a.n_head), "s"(a.groups), "s"(a.metrics),
+                 "s"(a.state));
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
     const int bid = blockIdx.x;
     TAIL_STAMP(0);
-    if (bid >= a.n_head + a.n_dw) {
+    if (HAS_DX && bid >= a.n_head + a.n_dw) {   // (its own instantiation: the code of a role nobody runs still costs instruction fetches)
         tail_dx_role<KS>(a, bid - a.n_head - a.n_dw);
         return;
     }
@@ -545,8 +560,8 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     const unsigned col0 = grp * 16 * TN;
     const bool lead = head_role && tile_m == 0;
     const bool any_w = a.w1_adam.p != nullptr, any_b = a.db1 && a.b1_adam.p != nullptr;
-    const int32_t w_t = any_w ? a.w1_adam.t[0] : 1, b_t = any_b ? a.b1_adam.t[0] : 1;
-    const float w_lr = any_w ? a.w1_adam.lr[0] : 0.f, b_lr = any_b ? a.b1_adam.lr[0] : 0.f;
+    const int32_t w_t = any_w ? sload(a.w1_adam.t) : 1, b_t = any_b ? sload(a.b1_adam.t) : 1;
+    const float w_lr = any_w ? sload(a.w1_adam.lr) : 0.f, b_lr = any_b ? sload(a.b1_adam.lr) : 0.f;
 
     // ---- chunk-independent operands ----
     float4 wv[KS];                                   // W2[class r16][16 ks + 4 g4 ..]; rows >= C: a copy of row C-1, masked at the logits
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
         bm_ = ldg_b(a.b1_adam.m, b1_off);
         bv_ = ldg_b(a.b1_adam.v, b1_off);
     }
-    const int64_t state0 = (lead && a.metrics) ? a.state[0] : 0, state1 = (lead && a.metrics) ? a.state[1] : 0;
+    const int64_t state0 = (lead && a.metrics) ? sload(a.state) : 0, state1 = (lead && a.metrics) ? sload(a.state + 1) : 0;
 
     floatx4 accdw[TN];
 #pragma unroll
@@ -593,32 +608,38 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     float db1_acc = 0.f, db2_acc = 0.f, nll_acc = 0.f, hit_acc = 0.f;
     const float inv_b = 1.0f / (float)B;
 
-    for (int c0 = 0; c0 < B; c0 += 64) {
+    // Chunk operands.  The first chunk's loads are issued HERE, in the same basic block as the chunk-independent ones
+    // above: behind a loop header the register allocator reuses VGPRs that still have loads in flight and parks
+    // s_waitcnt vmcnt(n) in front of the H loads -- a second, serialised memory round trip.
+    float4 hv[KS];                               // H[r0 + r16][16 ks + 4 g4 ..]
+    float tf = 0.f, hm[4], xv[TN][4];            // H[r0 + 4 g4 + s][hcol], X[same row][col0 + 16 tn + r16]
+    auto load_chunk = [&](int c0) {
+        const int r0 = c0 + wave * 16;
+        if (r0 >= B) return;                     // wave-uniform
+        const unsigned h_off = ((unsigned)(r0 + r16) * HID + g4 * 4) * 4u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) hv[ks] = ldg4_b(a.h, h_off + ks * 64);
+        tf = ldg_b(a.targets, (unsigned)(r0 + r16) * 4u);
+        const unsigned hm_off = ((unsigned)(r0 + g4 * 4) * HID + hcol) * 4u;
+        const unsigned x_off = ((unsigned)(r0 + g4 * 4) * in_f + col0 + r16) * 4u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            hm[s] = ldg_b(a.h, hm_off + s * HID * 4);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                xv[tn][s] = (!head_role && tn_ok[tn]) ? ldg_b(a.x, x_off + s * in_f * 4u + tn * 64) : 0.f;
+        }
+    };
+    load_chunk(0);
+    TAIL_STAMP(1);
+    // step sizes of the fused updates (optim.rs:87-90): ALU work under the loads' latency (every wave: all finish elements)
+    if (fuse_w) w_step = adam_step_size(w_lr, a.w1_adam.beta1, a.w1_adam.beta2, w_t);
+    if (fuse_b1) b_step = adam_step_size(b_lr, a.b1_adam.beta1, a.b1_adam.beta2, b_t);
+    TAIL_STAMP(2);
+
+    for (int c0 = 0;;) {
         const int r0 = c0 + wave * 16;               // this wave's 16 rows: all valid or (wave-uniformly) all absent
         const bool rows_here = r0 < B;
-        float4 hv[KS];                               // H[r0 + r16][16 ks + 4 g4 ..]
-        float tf = 0.f, hm[4], xv[TN][4];            // H[r0 + 4 g4 + s][hcol], X[same row][col0 + 16 tn + r16]
-        if (rows_here) {
-            const unsigned h_off = ((unsigned)(r0 + r16) * HID + g4 * 4) * 4u;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) hv[ks] = ldg4_b(a.h, h_off + ks * 64);
-            tf = ldg_b(a.targets, (unsigned)(r0 + r16) * 4u);
-            const unsigned hm_off = ((unsigned)(r0 + g4 * 4) * HID + hcol) * 4u;
-            const unsigned x_off = ((unsigned)(r0 + g4 * 4) * in_f + col0 + r16) * 4u;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                hm[s] = ldg_b(a.h, hm_off + s * HID * 4);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    xv[tn][s] = (!head_role && tn_ok[tn]) ? ldg_b(a.x, x_off + s * in_f * 4u + tn * 64) : 0.f;
-            }
-        }
-        TAIL_STAMP(1);
-        if (c0 == 0) {   // step sizes of the fused updates (optim.rs:87-90): ALU work under the loads' latency (every wave: all finish elements)
-            if (fuse_w) w_step = adam_step_size(w_lr, a.w1_adam.beta1, a.w1_adam.beta2, w_t);
-            if (fuse_b1) b_step = adam_step_size(b_lr, a.b1_adam.beta1, a.b1_adam.beta2, b_t);
-        }
-        TAIL_STAMP(2);
         if (rows_here) {
             TAIL_STAMP(3);
             // ---- logits^T (nn.rs:54-60): four independent accumulation chains, one per float4 component ----
@@ -681,6 +702,9 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
                 }
             }
         }
+        c0 += 64;
+        if (c0 >= B) break;
+        load_chunk(c0);
     }
 
     TAIL_STAMP(5);
@@ -814,7 +838,8 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
                        (d_dx || !(getenv("TAPER_TAIL_GENERAL") && getenv("TAPER_TAIL_GENERAL")[0] == '1'));
 #define TH_TAIL_LAUNCH(KS, TN)                                                                                        \
     do {                                                                                                              \
-        if (exact) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
+        if (exact && d_dx) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, true>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
+        else if (exact) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, false>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
         else hipLaunchKernelGGL((mlp_tail_kernel<KS, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);                 \
     } while (0)
 #define TH_TAIL_KS(TN)                          \
