@@ -48,9 +48,17 @@ struct AdamDev {
     float beta1, beta2, eps, wd;
 };
 
-__device__ __forceinline__ float adam_dev_step(const AdamDev &a) {
-    return adam_step_size(a.lr[0], a.beta1, a.beta2, __hip_atomic_load(a.t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+// A uniform value from global memory through the scalar unit (s_load): it travels on lgkmcnt, so waiting for it does
+// not drain the vector loads in flight.  (As a vector load + readfirstlane the compiler parks an s_waitcnt vmcnt(0)
+// right behind it: one full memory round trip per such value BEFORE the operand loads are even issued.)
+// Safe for data written by an EARLIER launch only: the scalar cache is invalidated at kernel start.
+template <class T>
+__device__ __forceinline__ T sload(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
 }
+
+// the counter was advanced by an earlier launch (th_adam_fuse: "ALREADY ticked"); nothing writes it while this one runs
+__device__ __forceinline__ float adam_dev_step(const AdamDev &a) { return adam_step_size(sload(a.lr), a.beta1, a.beta2, sload(a.t)); }
 
 static inline AdamDev make_adam_dev(const th_adam_fuse *f) {
     if (!f || !f->d_p) return AdamDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};

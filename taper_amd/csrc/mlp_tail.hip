@@ -45,15 +45,6 @@ struct TailArgs {
 };
 
 // ---- helpers shared by the general and the whole-tile kernel ----
-// A uniform value from global memory through the scalar unit (s_load): it travels on lgkmcnt, so waiting for it does
-// not drain the vector loads in flight.  (As a vector load + readfirstlane the compiler parks an s_waitcnt vmcnt(0)
-// right behind it: one full memory round trip per such value BEFORE the operand loads are even issued -- 2 us here.)
-// Safe for data written by an earlier launch only: the scalar cache is invalidated at kernel start.
-template <class T>
-__device__ __forceinline__ T sload(const T *p) {
-    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
-}
-
 __device__ __forceinline__ float ldg_b(const float *base, unsigned byte_off) {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
 }
