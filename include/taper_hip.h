@@ -186,7 +186,7 @@ int th_linear_xent_head_masked(th_ctx *ctx, const float *d_h, const float *d_w, 
  * hidden <= 256 and a multiple of 4, classes <= 16.
  * d_dx[B,in] (nullable; needs d_w1[hid,in]): additionally dX = dZ1 . W1 for a hidden layer
  * that is not the first (ops.rs:254-265), overwritten; whole tiles only (need_dx: hidden
- * 64 / 128 / 256, batch and in_features multiples of 16) and, because the launch then
+ * 32 / 64 / 128 / 256, batch and in_features multiples of 16) and, because the launch then
  * reads W1, w1_fuse must be NULL: W1's update is the caller's (th_adam_slice), like W2's. */
 int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes, int need_dx);
 int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
@@ -297,6 +297,11 @@ int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int 
  * one conv output (tensor.rs:1496-1519), whose ReLU mask is "pooled value > 0" -- no scatter, no dZ buffer. */
 int th_bias_grad_nchw_masked(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw,
                              int accumulate);
+/* the same shortcut behind a GLOBAL average pool (AdaptiveAvgPool2d((1,1)), nn.rs:670-686): d_gout_pooled is [n][c], the
+ * gradient of the pool's output; every element of plane (b, ch) receives d_gout_pooled[b][ch] / hw (tensor.rs:1626-1628)
+ * and counts where d_mask_y[b][ch][.] > 0.  db[ch] (+)= sum over the batch and the plane. */
+int th_bias_grad_avgpool_masked(th_ctx *ctx, const float *d_gout_pooled, const float *d_mask_y, float *d_gb, int n, int c, int hw,
+                                int accumulate);
 /* full_backward extension (not in the reference: Q2 cuts these gradients) */
 int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx,
                          int n, int c_in, int h, int w, int c_out, int pad, int weight_layout); /* gx += */

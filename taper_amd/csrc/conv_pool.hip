@@ -337,9 +337,11 @@ __global__ __launch_bounds__(256) void bias_add_nchw_kernel(const float *__restr
 // grid = (c, slabs): block (ch, s) sums channel ch over its slab of images; with `part` set the slab sums land
 // in part[s][c] and th_colsum_accum adds them to gb in slab order (deterministic), else gb[ch] += the sum.
 // mask (nullable): only elements with mask[same index] > 0 count -- the ReLU backward folded in; overwrite: gb = sum
+// pooled != 0: g is [n][c] -- the gradient of a GLOBAL average pool's output -- and every element of plane (b, ch)
+// receives g[b][ch] / hw (tensor.rs:1626-1628)
 __global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__restrict__ g, const float *__restrict__ mask,
                                                              float *__restrict__ gb, float *__restrict__ part, int n, int c, int hw,
-                                                             int img_per_slab, int overwrite) {
+                                                             int img_per_slab, int overwrite, int pooled) {
     __shared__ float sh[4];
     const int ch = blockIdx.x;
     const int b0 = blockIdx.y * img_per_slab, b1 = min(n, b0 + img_per_slab);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(256) void bias_grad_nchw_kernel(const float *__rest
     int b = b0 + threadIdx.x / hw, sp = threadIdx.x % hw;
     for (long i = threadIdx.x; i < total; i += 256) {
         const long ix = ((long)b * c + ch) * hw + sp;
-        const float v = g[ix];
+        const float v = pooled ? g[(long)b * c + ch] / (float)hw : g[ix];
         s += (mask && !(mask[ix] > 0.f)) ? 0.f : v;
         sp += step_sp;
         b += step_b;
@@ -568,6 +570,34 @@ int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c
 
 using namespace th;
 
+namespace th {
+int bias_grad_launch(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw, int accumulate, int pooled) {
+    TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
+    if (c == 0) return 0;
+    int slabs = 1;
+    if ((long)n * hw >= 4096 && c < 256) {   // one workgroup per channel cannot fill the chip: split the images
+        slabs = ceil_div(512, c);
+        if (slabs > n) slabs = n;
+    }
+    if (slabs <= 1) {
+        hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)nullptr, n, c, hw, n,
+                           accumulate ? 0 : 1, pooled);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
+    const int ips = ceil_div(n, slabs);
+    slabs = ceil_div(n, ips);
+    void *part = nullptr;
+    if (th_malloc(ctx, (size_t)slabs * c * sizeof(float), &part)) return 1;
+    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c, slabs), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)part, n, c, hw,
+                       ips, 0, pooled);
+    TH_LAUNCH_CHECK();
+    if (int rc = accumulate ? th_colsum_accum(ctx, (const float *)part, d_gb, slabs, c) : th_colsum(ctx, (const float *)part, d_gb, slabs, c))
+        return rc;
+    return th_free(ctx, part);
+}
+}  // namespace th
+
 extern "C" {
 
 int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y, int n, int c_in, int h,
@@ -690,30 +720,15 @@ int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int 
 }
 
 int th_bias_grad_nchw_masked(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw, int accumulate) {
-    TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
-    if (c == 0) return 0;
-    int slabs = 1;
-    if ((long)n * hw >= 4096 && c < 256) {   // one workgroup per channel cannot fill the chip: split the images
-        slabs = ceil_div(512, c);
-        if (slabs > n) slabs = n;
-    }
-    if (slabs <= 1) {
-        hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)nullptr, n, c, hw, n,
-                           accumulate ? 0 : 1);
-        TH_LAUNCH_CHECK();
-        return 0;
-    }
-    const int ips = ceil_div(n, slabs);
-    slabs = ceil_div(n, ips);
-    void *part = nullptr;
-    if (th_malloc(ctx, (size_t)slabs * c * sizeof(float), &part)) return 1;
-    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c, slabs), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)part, n, c, hw,
-                       ips, 0);
-    TH_LAUNCH_CHECK();
-    if (int rc = accumulate ? th_colsum_accum(ctx, (const float *)part, d_gb, slabs, c) : th_colsum(ctx, (const float *)part, d_gb, slabs, c))
-        return rc;
-    return th_free(ctx, part);
+    return th::bias_grad_launch(ctx, d_gout, d_mask_y, d_gb, n, c, hw, accumulate, 0);
 }
+
+int th_bias_grad_avgpool_masked(th_ctx *ctx, const float *d_gout_pooled, const float *d_mask_y, float *d_gb, int n, int c, int hw,
+                                int accumulate) {
+    TH_REQUIRE(d_mask_y, "th_bias_grad_avgpool_masked: null argument");
+    return th::bias_grad_launch(ctx, d_gout_pooled, d_mask_y, d_gb, n, c, hw, accumulate, 1);
+}
+
 
 int th_maxpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int64_t *d_argmax, int n, int c, int h, int w, int k_h, int k_w,
                      int s_h, int s_w, int pad_h, int pad_w) {

@@ -77,6 +77,7 @@ struct GradSlot {
     bool wants_pooled = false;
     std::shared_ptr<Buffer> pooled_dy, pooled_y;
     int pooled_n = 0, pooled_c = 0, pooled_hw = 0;
+    bool pooled_avg = false;      // the consumer was a global average pool: pooled_dy is [n][c], pooled_y the conv output itself
 };
 
 class Tensor {

@@ -783,7 +783,10 @@ Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> s
                 GradSlot &g = *r.grad_;
                 bool none;
                 float *db = b.grad_for_write(&none);
-                TH(th_bias_grad_nchw_masked(c, g.pooled_dy->d, g.pooled_y->d, db, g.pooled_n, g.pooled_c, g.pooled_hw, none ? 0 : 1));
+                if (g.pooled_avg)
+                    TH(th_bias_grad_avgpool_masked(c, g.pooled_dy->d, g.pooled_y->d, db, g.pooled_n, g.pooled_c, g.pooled_hw, none ? 0 : 1));
+                else
+                    TH(th_bias_grad_nchw_masked(c, g.pooled_dy->d, g.pooled_y->d, db, g.pooled_n, g.pooled_c, g.pooled_hw, none ? 0 : 1));
                 g.pooled_dy.reset();
                 g.pooled_y.reset();
                 return;
@@ -832,6 +835,7 @@ Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pai
                 g.pooled_n = n;
                 g.pooled_c = ch;
                 g.pooled_hw = hw_out;
+                g.pooled_avg = false;
                 return;
             }
             bool none;
@@ -856,6 +860,17 @@ Tensor Tensor::avg_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pai
         Tensor in = *this, r = out;
         Tape::push(out, true, [in, r, n, ch, h, w, k, s, p]() {
             if (!r.has_grad()) return;
+            if (in.grad_->wants_pooled && !in.grad_->has && !r.grad_->shared_const && k.first == h && k.second == w && p.first == 0 &&
+                p.second == 0) {   // PoolBiasScope, global pool: see GradSlot
+                GradSlot &g = *in.grad_;
+                g.pooled_dy = r.grad_->buf;
+                g.pooled_y = in.data_;
+                g.pooled_n = n;
+                g.pooled_c = ch;
+                g.pooled_hw = h * w;
+                g.pooled_avg = true;
+                return;
+            }
             TH(th_avgpool2d_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), n, ch, h, w, k.first, k.second, s.first, s.second,
                                 p.first, p.second));
         });

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
 using namespace th;
 
 static bool tail_whole_tiles(int batch, int in_features, int hidden) {
-    return (hidden == 64 || hidden == 128 || hidden == 256) && batch % 16 == 0 && in_features % 16 == 0;
+    return (hidden == 32 || hidden == 64 || hidden == 128 || hidden == 256) && batch % 16 == 0 && in_features % 16 == 0;
 }
 
 extern "C" int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes, int need_dx) {
@@ -799,7 +799,7 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
     TH_REQUIRE(th_mlp_tail_supported(batch, in_features, hidden, classes, 0),
                "th_mlp_tail: needs batch <= 256, hidden <= 256 and a multiple of 4, classes <= 16 (got %d, %d, %d)", batch, hidden, classes);
     TH_REQUIRE(!d_dx || (d_w1 && tail_whole_tiles(batch, in_features, hidden)),
-               "th_mlp_tail: d_dx needs d_w1 and whole tiles (hidden 64 / 128 / 256, batch and in_features multiples of 16)");
+               "th_mlp_tail: d_dx needs d_w1 and whole tiles (hidden 32 / 64 / 128 / 256, batch and in_features multiples of 16)");
     TH_REQUIRE(!d_dx || !(w1_fuse && w1_fuse->d_p), "th_mlp_tail: with d_dx the launch reads W1, its update must be deferred (th_adam_slice)");
     TH_REQUIRE((((uintptr_t)d_h | (uintptr_t)d_w2) & 15) == 0, "th_mlp_tail: d_h and d_w2 must be 16-byte aligned");
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp_tail: metrics need d_state and a capacity");
@@ -835,7 +835,8 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
     } while (0)
 #define TH_TAIL_KS(TN)                          \
     do {                                        \
-        if (hidden <= 64) TH_TAIL_LAUNCH(4, TN);       \
+        if (exact && hidden == 32) TH_TAIL_LAUNCH(2, TN); \
+        else if (hidden <= 64) TH_TAIL_LAUNCH(4, TN);  \
         else if (hidden <= 128) TH_TAIL_LAUNCH(8, TN); \
         else TH_TAIL_LAUNCH(16, TN);                   \
     } while (0)

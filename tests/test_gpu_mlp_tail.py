@@ -48,7 +48,7 @@ def oracle_tail(O, x, w1, b1, w2, b2, y):
 
 SHAPES = [(64, 784, 128, 10), (32, 784, 128, 10), (128, 784, 128, 10), (1, 5, 4, 2), (70, 37, 20, 5), (256, 100, 256, 16),
           (200, 50, 64, 10), (17, 784, 36, 3),
-          (256, 784, 128, 10), (192, 64, 64, 10), (48, 784, 128, 10), (16, 16, 256, 16), (240, 48, 256, 3)]   # whole tiles, several / partial chunks
+          (256, 784, 128, 10), (192, 64, 64, 10), (48, 784, 128, 10), (16, 16, 256, 16), (240, 48, 256, 3), (64, 64, 32, 10)]   # whole tiles, several / partial chunks
 
 
 @pytest.mark.parametrize("batch,inf,hid,c", SHAPES)
@@ -96,7 +96,8 @@ def test_mlp_tail(ctx, O, batch, inf, hid, c, fuse):
         np.testing.assert_array_equal(ctx.download(pw, w1.shape), w1)
 
 
-@pytest.mark.parametrize("batch,inf,hid,c", [(64, 128, 64, 10), (256, 128, 64, 10), (48, 784, 128, 10), (32, 48, 256, 16), (16, 16, 64, 2)])
+@pytest.mark.parametrize("batch,inf,hid,c", [(64, 128, 64, 10), (256, 128, 64, 10), (48, 784, 128, 10), (32, 48, 256, 16), (16, 16, 64, 2),
+                                             (256, 64, 32, 10), (16, 32, 32, 3)])   # hidden 32: the reference CNN's classifier
 def test_mlp_tail_dx(ctx, O, batch, inf, hid, c):
     """a hidden layer that is not the first: the same launch also hands dX = dZ1 . W1 down (whole tiles only)"""
     rng = np.random.default_rng(batch * 17 + inf + hid + c)
