@@ -280,6 +280,10 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     // <= 64 output channels per workgroup: 32 accumulator + 18 prefetch VGPRs keep 3 workgroups per CU,
     // and wide layers get twice the workgroups (conv5 of the reference CNN: 232 instead of 116)
     int ct = co_tiles >= 4 ? 4 : (co_tiles >= 2 ? 2 : 1);
+    // fewer than 1.5 workgroups per CU (conv5 of the reference CNN: 7x7 maps, 232 workgroups): nothing overlaps a
+    // workgroup's staging / barriers -- halve the channel block instead (measured 45.2 -> 40.5 us; it costs 7-9 us
+    // on the 14x14 layers, which have 430 workgroups)
+    if (ct == 4 && (long)ceil_div(n, a.img_t) * a.bands * ceil_div(c_out, 64) < 384) ct = 2;
     static const int ct_env = getenv("TAPER_CONV_CT") ? atoi(getenv("TAPER_CONV_CT")) : 0;   // tuning probe
     if (ct_env && ct > ct_env) ct = ct_env;
     a.co_b = ct * 16;
