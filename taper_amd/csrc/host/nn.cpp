@@ -732,25 +732,41 @@ EpochResult Trainer::train_epoch(DataLoader &loader) {  // train.rs:98-144
 }
 
 EpochResult Trainer::evaluate(DataLoader &loader) {  // train.rs:147-172
+    // Same formulas, no per-batch read-back: the loss kernel appends {loss, n_correct} of every batch to a device
+    // log (as in the graph-replayed training epoch) and the host reads the log once at the end.
     EpochResult r;
-    float total_loss = 0.f;
     loader.reset();
-    r.num_batches = loader.num_batches();
+    const size_t nb = loader.num_batches();
+    r.num_batches = nb;
+    if (nb == 0) return r;
+    th_ctx *ctx = Device::ctx();
+    auto log = Buffer::alloc(2 * nb), st = Buffer::alloc(4);
+    TH(th_fill_f32(ctx, st->d, 0.f, 4));
+    std::vector<size_t> sizes;
     Tensor images, labels;
     while (loader.next(&images, &labels)) {
         Tape::reset();
-        Tensor logits = model->forward(shape_input(images, sample_shape));
-        Tensor loss = cross_entropy_loss(logits, labels);
-        const float acc = accuracy(logits, labels);
         const size_t b = images.shape()[0];
-        r.total_correct += (size_t)(acc * (float)b);
-        r.total_samples += b;
-        const float l = loss.data()[0];
-        total_loss += l;
-        r.losses.push_back(l);
-        r.ncorrect.push_back(acc * (float)b);
+        StepLogSink sink{log->d, (int64_t)nb, reinterpret_cast<int64_t *>(st->d), (int64_t)b, nullptr};
+        Tensor logits = model->forward(shape_input(images, sample_shape));
+        Tensor ncorrect;
+        cross_entropy_loss(logits, labels, &ncorrect, &sink);   // loss.rs:136-195 + the count of loss.rs:271-290
+        sizes.push_back(b);
     }
-    r.avg_loss = total_loss / (float)r.num_batches;
+    Tape::reset();
+    std::vector<float> mt(2 * nb);
+    TH(th_memcpy_d2h(ctx, mt.data(), log->d, mt.size() * sizeof(float)));
+    float total_loss = 0.f;
+    for (size_t s = 0; s < nb && s < sizes.size(); ++s) {
+        const size_t b = sizes[s];
+        const float acc = mt[2 * s + 1] / (float)b;       // loss.rs:289
+        r.total_correct += (size_t)(acc * (float)b);      // train.rs:160 (truncating cast, Q13)
+        r.total_samples += b;
+        total_loss += mt[2 * s];
+        r.losses.push_back(mt[2 * s]);
+        r.ncorrect.push_back(mt[2 * s + 1]);
+    }
+    r.avg_loss = total_loss / (float)nb;
     r.accuracy = (float)r.total_correct / (float)r.total_samples;
     return r;
 }
