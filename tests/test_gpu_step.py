@@ -302,3 +302,32 @@ def test_full_batch_gradient_is_the_mean_of_shard_gradients():
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("name,batch", [("mlp_baseline", 64), ("cnn_simple", 16)])
+def test_evaluate_matches_oracle(name, batch):
+    """Trainer::evaluate (train.rs:147-172): per-batch loss / hit count from the device log (read once per pass)
+    against the oracle's forward + cross_entropy_loss + accuracy on the same batches, last partial batch included"""
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(31)
+    builder, sample = MODELS[name]
+    spec = backends.nonzero_biases(builder(rng), rng)
+    n = 3 * batch + batch // 2
+    x, y = backends.mnist_like(rng, n)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    tr = T.Trainer(hm, T.Adam(hm.parameters(), 1e-3, None, None, 1e-4), sample_shape=sample)
+    ev = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y, False), batch, False), T.Trainer.EVAL)
+    O = Orc.m
+    ref_loss, ref_nc = [], []
+    for s in range(0, n, batch):
+        xb, yb = x[s:s + batch], y[s:s + batch]
+        O.Tape.reset()
+        logits = om.forward(O.Tensor(xb.reshape((len(xb), 784) if sample is None else (len(xb),) + sample)))
+        ref_loss.append(float(O.cross_entropy_loss(logits, O.Tensor(yb)).data()[0]))
+        ref_nc.append(round(O.accuracy(logits, O.Tensor(yb)) * len(xb)))
+    np.testing.assert_allclose(ev["losses"], ref_loss, rtol=2e-4, atol=1e-5)
+    assert np.abs(np.asarray(ev["ncorrect"]) - np.asarray(ref_nc)).max() <= 1
+    assert ev["total_samples"] == n and ev["num_batches"] == 4
+    assert ev["avg_loss"] == pytest.approx(np.mean(ref_loss), rel=2e-4)
