@@ -494,7 +494,16 @@ void Adam::set_lr(float lr) {  // optim.rs:125-127
 }
 
 void Adam::step() {  // optim.rs:83-113
-    if (!carry_deferred_ && !deferred_.empty()) {
+    // In carry mode the next step's first launch applies what is left in ONE spare workgroup: fine for a classifier
+    // head's W / b, far too slow for a big slice (the reference CNN's Linear(128, 64) weight cost that launch 8 us) --
+    // only slices of <= 4096 elements wait, the rest is applied now.
+    std::vector<th_adam_slice> wait;
+    if (carry_deferred_) {
+        std::vector<th_adam_slice> now;
+        for (const th_adam_slice &d : deferred_) (d.n <= 4096 ? wait : now).push_back(d);
+        deferred_.swap(now);
+    }
+    if (!deferred_.empty()) {
         // complete gradients no backward launch carried.  When the arena-wide launch below runs anyway (some
         // parameter was not fused), it takes them along: one launch instead of two, same arithmetic, same t.
         bool general = false;
@@ -508,6 +517,7 @@ void Adam::step() {  // optim.rs:83-113
             flush_deferred();
         }
     }
+    deferred_.swap(wait);
     // parameters whose update already ran in a fused epilogue this step are masked out
     const size_t left = fp_.sync_mask(&fused_);
     std::fill(fused_.begin(), fused_.end(), 0);
