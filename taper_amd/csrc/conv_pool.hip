@@ -571,6 +571,31 @@ int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c
 using namespace th;
 
 namespace th {
+// Bias gradient behind a GLOBAL average pool with the ReLU mask folded in, planes of <= 64 elements (7x7 here): one wave
+// per plane -- lanes over the plane, the mask count by ballot -- adds (g[b][ch] / hw) * count; waves stride the slab's
+// images.  grid = (c, slabs); with `part` the slab sums land in part[s][c], else gb[ch] (+)= the sum.
+__global__ __launch_bounds__(256) void bias_grad_avgpool_small_kernel(const float *__restrict__ gp, const float *__restrict__ y,
+                                                                      float *__restrict__ gb, float *__restrict__ part, int n, int c,
+                                                                      int hw, int img_per_slab, int overwrite) {
+    __shared__ float sh[4];
+    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = blockIdx.y * img_per_slab, b1 = min(n, b0 + img_per_slab);
+    float s = 0.f;
+    for (int b = b0 + wave; b < b1; b += 4) {
+        const long plane = (long)b * c + ch;
+        const bool on = lane < hw && y[plane * hw + lane] > 0.f;
+        const int cnt = __popcll(__ballot(on));
+        s += (gp[plane] / (float)hw) * (float)cnt;      // wave-uniform
+    }
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        if (part) part[(long)blockIdx.y * c + ch] = tot;
+        else gb[ch] = overwrite ? tot : gb[ch] + tot;
+    }
+}
+
 int bias_grad_launch(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw, int accumulate, int pooled) {
     TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
     if (c == 0) return 0;
@@ -579,7 +604,12 @@ int bias_grad_launch(th_ctx *ctx, const float *d_gout, const float *d_mask_y, fl
         slabs = ceil_div(512, c);
         if (slabs > n) slabs = n;
     }
+    const bool small_planes = pooled && d_mask_y && hw <= 64;
     if (slabs <= 1) {
+        if (small_planes)
+            hipLaunchKernelGGL(bias_grad_avgpool_small_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)nullptr, n,
+                               c, hw, n, accumulate ? 0 : 1);
+        else
         hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)nullptr, n, c, hw, n,
                            accumulate ? 0 : 1, pooled);
         TH_LAUNCH_CHECK();
@@ -589,6 +619,10 @@ int bias_grad_launch(th_ctx *ctx, const float *d_gout, const float *d_mask_y, fl
     slabs = ceil_div(n, ips);
     void *part = nullptr;
     if (th_malloc(ctx, (size_t)slabs * c * sizeof(float), &part)) return 1;
+    if (small_planes)
+        hipLaunchKernelGGL(bias_grad_avgpool_small_kernel, dim3(c, slabs), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)part, n,
+                           c, hw, ips, 0);
+    else
     hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(c, slabs), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)part, n, c, hw,
                        ips, 0, pooled);
     TH_LAUNCH_CHECK();

@@ -620,3 +620,24 @@ def test_rccl_single_rank_allreduce(ctx):
     th_check(lib.th_allreduce_sum_scale(comm, ctx.h, int(d), x.size, 1.0), "th_allreduce_sum_scale")
     np.testing.assert_array_equal(ctx.download(d, x.size), x * np.float32(0.5))
     lib.th_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(256, 64, 7, 7), (6, 5, 3, 3), (40, 128, 7, 7), (9, 16, 10, 10), (300, 32, 14, 14)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_pooled_bias_gradients(ctx, n, c, h, w, accumulate):
+    """bias gradient of a Conv2dReLU straight from the gradient of the pool behind it:
+    max pool (th_bias_grad_nchw_masked on the pooled tensors) and global average pool (th_bias_grad_avgpool_masked)"""
+    rng = np.random.default_rng(n + c + h)
+    hw = h * w
+    dyp = rng.standard_normal((n, c, hw)).astype(np.float32)
+    yp = np.maximum(rng.standard_normal((n, c, hw)), 0).astype(np.float32)       # pooled ReLU outputs (zeros included)
+    db0 = rng.standard_normal(c).astype(np.float32)
+    out = ctx.upload(db0)
+    ctx.call("th_bias_grad_nchw_masked", ctx.upload(dyp), ctx.upload(yp), out, n, c, hw, accumulate)
+    ref = (dyp.astype(np.float64) * (yp > 0)).sum((0, 2)) + (db0 if accumulate else 0)
+    np.testing.assert_allclose(ctx.download(out, c), ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()) + 1e-6)
+    g = rng.standard_normal((n, c)).astype(np.float32)                            # gradient of the global average pool's output
+    out2 = ctx.upload(db0)
+    ctx.call("th_bias_grad_avgpool_masked", ctx.upload(g), ctx.upload(yp), out2, n, c, hw, accumulate)
+    ref2 = (g.astype(np.float64)[:, :, None] / hw * (yp > 0)).sum((0, 2)) + (db0 if accumulate else 0)
+    np.testing.assert_allclose(ctx.download(out2, c), ref2, rtol=1e-4, atol=1e-4 * float(np.abs(ref2).max()) + 1e-6)
