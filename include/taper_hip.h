@@ -283,6 +283,14 @@ int th_dropout_mask(th_ctx *ctx, float *d_mask, size_t n, float p, uint64_t seed
  * + add_bias_4d (1983-1992) (+ relu). */
 int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,
                    int n, int c_in, int h, int w, int c_out, int pad, int weight_layout, int relu);
+/* conv3x3 (taper weight layout, Q3) + bias [+ ReLU] + 2x2 / stride-2 max pool in one launch: only the pooled tensor
+ * [n][c_out][h_out/2][w_out/2] is written (values of tensor.rs:1391-1470; no index output) -- the Conv2dReLU -> MaxPool2d
+ * pair of the CNNs without the full-resolution round trip.  For a conv whose output nobody else reads and whose pool
+ * needs no scatter backward (faithful mode, Q2: see th_bias_grad_nchw_masked).  th_conv3x3_pool2_supported: the
+ * matrix-core path (c_in >= 8 or == 1), c_out % 4 == 0, even output height and width, output rows of <= 64 pixels. */
+int th_conv3x3_pool2_supported(int c_in, int h, int w, int c_out, int pad);
+int th_conv3x3_pool2_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y_pooled,
+                         int n, int c_in, int h, int w, int c_out, int pad, int relu);
 /* 1x1 stride-1 pad-0 convolution as GEMM.  layout 0 = taper (raw NCHW buffer
  * reinterpreted as [N*H*W, C], tensor.rs:1799-1801, Q4 + Q3); 1 = standard. */
 int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,

@@ -18,6 +18,7 @@
 // the zero-haloed input patch [8][IMG][R+2][W_out+2] and the weight slab [72][CO_B].  The global
 // loads of pass p+1 are issued before the MFMAs of pass p and parked in registers (one round trip per
 // pass, hidden behind 18 k-steps), then written to the single LDS buffer between two barriers.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -65,7 +66,10 @@ __device__ long long g_conv_prof[8];
 #define CONV_STAMP(i) do { } while (0)
 #endif
 
-template <int CT, bool ACCUM, int CIT>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
+// POOL: the epilogue additionally applies a 2x2 / stride-2 max pool (tensor.rs:1391-1470 values; no index output) and
+// stores ONLY the pooled tensor [n][c_out][h_out/2][w_out/2] -- the Conv2dReLU -> MaxPool2d pair of the CNNs without
+// the full-resolution round trip (needs even rows_t, h_out, w_out).
+template <int CT, bool ACCUM, int CIT, bool POOL = false>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CO_B = 16 * CT;
@@ -203,6 +207,46 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
 #undef TH_MF_STORE
     CONV_STAMP(3);
 
+    if (POOL) {
+        // ---- pooled epilogue: bias + ReLU into an LDS tile [CO_B][pixels], then 2x2 maxima straight to the pooled tensor ----
+        __syncthreads();                                   // every wave is done with the staged operands
+        const int ep_ld = m_wg | 1;                        // odd pitch
+        float *ep = lds;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = (wave + 4 * q) * 16 + l16;
+            if (p >= m_wg) continue;
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cl = 16 * j + 4 * g4 + i, co = co0 + cl;
+                    float v = acc[q][j][i] + ((a.bias && co < a.c_out) ? a.bias[co] : 0.f);
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    ep[cl * ep_ld + p] = v;
+                }
+        }
+        __syncthreads();
+        const int pw = a.w_out >> 1, np_img = (a.rows_t >> 1) * pw, np = a.img_t * np_img;
+        const FastDiv d_np(np), d_npi(np_img), d_pw(pw);
+        const long pchan = (long)(a.h_out >> 1) * pw;
+        for (int idx = t; idx < CO_B * np; idx += 256) {
+            int cl, rem, il, r2, pr, pc;
+            d_np.divmod(idx, cl, rem);
+            d_npi.divmod(rem, il, r2);
+            d_pw.divmod(r2, pr, pc);
+            if (co0 + cl >= a.c_out || img0 + il >= a.n || 2 * pr >= rows_here) continue;
+            const float *b = ep + cl * ep_ld + il * px_per_img + 2 * pr * a.w_out + 2 * pc;
+            float m = -INFINITY;                           // strict >: NaN never wins (tensor.rs:1449-1461)
+            m = b[0] > m ? b[0] : m;
+            m = b[1] > m ? b[1] : m;
+            m = b[a.w_out] > m ? b[a.w_out] : m;
+            m = b[a.w_out + 1] > m ? b[a.w_out + 1] : m;
+            a.y[((long)(img0 + il) * a.c_out + co0 + cl) * pchan + (long)((oh0 >> 1) + pr) * pw + pc] = m;
+        }
+        CONV_STAMP(4);
+        return;
+    }
     // ---- epilogue: bias + ReLU (tensor.rs:2005-2025, nn.rs:433-490), NCHW store straight from the D tiles: lane
     //      (l16, g4) holds pixel px0 + l16 of channels co0 + 4*g4 + i.  (Staging the tiles through LDS for row-
     //      contiguous stores was measured and is no faster: the tail of a workgroup is the MFMA queue draining.) ----
@@ -234,12 +278,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
 }
 
 // images x rows per workgroup: the fullest tiling of <= 128 pixels by whole output rows of one or more images
-static void conv_mfma_plan(int h_out, int w_out, int n, int *img_t, int *rows_t, int cit = MF_CI) {
+static void conv_mfma_plan(int h_out, int w_out, int n, int *img_t, int *rows_t, int cit = MF_CI, bool even_rows = false) {
     int best_fill = -1;
     *img_t = 1;
     *rows_t = 1;
     for (int r = 1; r <= h_out; ++r) {
         if (r * w_out > MF_PX_MAX) break;
+        if (even_rows && (r & 1)) continue;
         int im = MF_PX_MAX / (r * w_out);
         if (im > n) im = n;
         const int patch_cap = MF_PPT * 256 / (cit * (r + 2) * (w_out + 2));   // the staged patch is <= 12 floats per thread
@@ -263,8 +308,14 @@ bool conv3x3_mfma_supported(int c_in, int h, int w, int pad) {
 }
 
 // y (+)= conv3x3(x, w) [+ bias, relu]; weights [9*c_in][w_ld] with columns [0, w_cols) readable, rows 16-B aligned
+bool conv3x3_mfma_pool_supported(int c_in, int h, int w, int pad) {   // whole 2x2 windows, at least one even band of <= 128 pixels
+    const int w_out = w + 2 * pad - 2, h_out = h + 2 * pad - 2;
+    return conv3x3_mfma_supported(c_in, h, w, pad) && h_out % 2 == 0 && w_out % 2 == 0 && 2 * w_out <= MF_PX_MAX &&
+           MF_CI * 4 * (w_out + 2) <= MF_PPT * 256;
+}
+
 int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
-                        int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum) {
+                        int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool) {
     TH_REQUIRE(w_ld % 4 == 0 && ((uintptr_t)w & 15) == 0, "conv3x3_mfma: weight rows must be 16-byte aligned");
     ConvMfmaArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.y = y;
@@ -273,7 +324,7 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     a.w_out = w_in + 2 * pad - 2;
     a.w_ld = w_ld; a.w_cols = w_cols;
     const int cit = c_in == 1 ? 1 : MF_CI;
-    conv_mfma_plan(a.h_out, a.w_out, n, &a.img_t, &a.rows_t, cit);
+    conv_mfma_plan(a.h_out, a.w_out, n, &a.img_t, &a.rows_t, cit, pool);
     a.bands = ceil_div(a.h_out, a.rows_t);
     a.relu = relu;
     const int co_tiles = ceil_div(c_out, 16);
@@ -288,18 +339,19 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     if (ct_env && ct > ct_env) ct = ct_env;
     a.co_b = ct * 16;
     const size_t patch_n = (size_t)cit * a.img_t * (a.rows_t + 2) * (a.w_out + 2);
-    const size_t lds = (((patch_n + 4) & ~(size_t)3) + (size_t)((cit * 9 + 3) / 4 * 4) * a.co_b) * sizeof(float);
+    size_t lds = (((patch_n + 4) & ~(size_t)3) + (size_t)((cit * 9 + 3) / 4 * 4) * a.co_b) * sizeof(float);
+    if (pool) lds = std::max(lds, (size_t)a.co_b * ((size_t)(a.img_t * a.rows_t * a.w_out) | 1) * sizeof(float));   // the epilogue tile
     dim3 grid(ceil_div(n, a.img_t) * a.bands, ceil_div(c_out, a.co_b));
-#define TH_MF(CTV, ACC)                                                                                          \
-    if (cit == 1) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, 1>), grid, dim3(256), lds, ctx->stream, a);         \
-    else hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, MF_CI>), grid, dim3(256), lds, ctx->stream, a);
-#define TH_MF_CT(ACC)                                  \
+#define TH_MF(CTV, ACC, PL)                                                                                             \
+    if (cit == 1) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, 1, PL>), grid, dim3(256), lds, ctx->stream, a);     \
+    else hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, MF_CI, PL>), grid, dim3(256), lds, ctx->stream, a);
+#define TH_MF_CT(ACC, PL)                              \
     switch (ct) {                                      \
-        case 4: TH_MF(4, ACC) break;                   \
-        case 2: TH_MF(2, ACC) break;                   \
-        default: TH_MF(1, ACC) break;                  \
+        case 4: TH_MF(4, ACC, PL) break;               \
+        case 2: TH_MF(2, ACC, PL) break;               \
+        default: TH_MF(1, ACC, PL) break;              \
     }
-    if (accum) TH_MF_CT(true) else TH_MF_CT(false)
+    if (pool) TH_MF_CT(false, true) else if (accum) TH_MF_CT(true, false) else TH_MF_CT(false, false)
 #undef TH_MF_CT
 #undef TH_MF
     TH_LAUNCH_CHECK();

@@ -331,6 +331,19 @@ Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
                 continue;
             }
         }
+        if (fuse && i + 1 < n_layers && PoolBiasScope::active()) {
+            // Trainer steps: Conv2dReLU(3x3, stride 1) + MaxPool2d(2) as one launch that never writes the full-resolution map
+            auto *cv = dynamic_cast<Conv2d *>(layers[i].get());
+            auto *mp = dynamic_cast<MaxPool2d *>(layers[i + 1].get());
+            if (cv && mp && cv->fuse_relu && cv->groups == 1 && cv->stride == std::make_pair(1, 1) && cv->dilation == std::make_pair(1, 1) &&
+                mp->kernel == std::make_pair(2, 2) && (mp->stride == std::make_pair(0, 0) || mp->stride == std::make_pair(2, 2)) &&
+                mp->padding == std::make_pair(0, 0) &&   // (faithful mode never hands a gradient to the conv's input or weight, Q2)
+                x.conv2d_relu_maxpool2_supported(cv->weight, cv->bias, cv->padding)) {
+                x = x.conv2d_relu_maxpool2(cv->weight, cv->bias, cv->padding);
+                ++i;
+                continue;
+            }
+        }
         x = layers[i]->forward(x);
     }
     return x;

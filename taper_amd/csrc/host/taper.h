@@ -142,6 +142,11 @@ class Tensor {
                   std::pair<int, int> dilation, bool relu = false) const;
     Tensor conv2d_relu(const Tensor &weight, const Tensor &bias, std::pair<int, int> stride, std::pair<int, int> padding,
                        std::pair<int, int> dilation) const;
+    // Conv2dReLU (3x3, stride 1) + MaxPool2d(2, 2) as ONE launch that writes only the pooled tensor (th_conv3x3_pool2_fwd).
+    // Trainer-internal: valid in faithful mode (Q2: the conv's only gradient is its bias, taken from the pooled tensors)
+    // when nobody else reads the conv output.  conv2d_relu_maxpool2_supported tells whether the pair qualifies.
+    bool conv2d_relu_maxpool2_supported(const Tensor &weight, const Tensor &bias, std::pair<int, int> padding) const;
+    Tensor conv2d_relu_maxpool2(const Tensor &weight, const Tensor &bias, std::pair<int, int> padding) const;
     Tensor max_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride /* {0,0} = None */,
                       std::pair<int, int> padding) const;
     Tensor avg_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride, std::pair<int, int> padding) const;

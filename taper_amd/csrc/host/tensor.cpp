@@ -812,6 +812,36 @@ Tensor Tensor::conv2d_relu(const Tensor &w, const Tensor &bias, std::pair<int, i
     return conv2d(w, bias, stride, padding, dilation, true);
 }
 
+bool Tensor::conv2d_relu_maxpool2_supported(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
+    if (full_backward() || shape_.size() != 4 || w.shape_.size() != 4 || w.shape_[2] != 3 || w.shape_[3] != 3) return false;
+    if (w.shape_[1] != shape_[1] || padding.first != padding.second) return false;
+    if (bias.defined() && bias.shape_ != Shape{w.shape_[0]}) return false;
+    if (((uintptr_t)w.dptr() & 15) != 0) return false;
+    return th_conv3x3_pool2_supported((int)shape_[1], (int)shape_[2], (int)shape_[3], (int)w.shape_[0], padding.first) != 0;
+}
+
+Tensor Tensor::conv2d_relu_maxpool2(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
+    // tensor.rs:1221-1285 + nn.rs:433-490 + tensor.rs:1391-1470 (k = s = 2, p = 0), values only
+    TAPER_ASSERT(conv2d_relu_maxpool2_supported(w, bias, padding), "conv2d_relu_maxpool2: unsupported shapes / mode");
+    const int n = (int)shape_[0], c_in = (int)shape_[1], h = (int)shape_[2], wd = (int)shape_[3], c_out = (int)w.shape_[0];
+    const int pad = padding.first, hp = (h + 2 * pad - 2) / 2, wp = (wd + 2 * pad - 2) / 2;
+    Tensor out = empty({(size_t)n, (size_t)c_out, (size_t)hp, (size_t)wp});
+    TH(th_conv3x3_pool2_fwd(Device::ctx(), dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, out.dptr(), n, c_in, h, wd, c_out,
+                            pad, 1));
+    if (bias.defined() && bias.requires_grad_) {   // faithful mode (Q2): the bias is the pair's only trainable input
+        out.requires_grad_ = true;
+        Tensor b = bias, r = out;
+        Tape::push(out, true, [b, r, n, c_out, hp, wp]() {
+            if (!r.has_grad()) return;
+            // every pooled gradient lands on exactly one conv output (tensor.rs:1496-1519) whose ReLU mask is "pooled value > 0"
+            bool none;
+            float *db = b.grad_for_write(&none);
+            TH(th_bias_grad_nchw_masked(Device::ctx(), r.grad_dptr(), r.dptr(), db, n, c_out, hp * wp, none ? 0 : 1));
+        });
+    }
+    return out;
+}
+
 Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pair<int, int> p) const {  // tensor.rs:1391-1521
     TAPER_ASSERT(shape_.size() == 4, "Input must be 4D: [N, C, H, W]");
     if (s.first == 0) s = k;  // stride.unwrap_or(kernel_size)

@@ -641,3 +641,31 @@ def test_pooled_bias_gradients(ctx, n, c, h, w, accumulate):
     ctx.call("th_bias_grad_avgpool_masked", ctx.upload(g), ctx.upload(yp), out2, n, c, hw, accumulate)
     ref2 = (g.astype(np.float64)[:, :, None] / hw * (yp > 0)).sum((0, 2)) + (db0 if accumulate else 0)
     np.testing.assert_allclose(ctx.download(out2, c), ref2, rtol=1e-4, atol=1e-4 * float(np.abs(ref2).max()) + 1e-6)
+
+
+@pytest.mark.parametrize("n,ci,h,w,co,pad", [(4, 1, 28, 28, 32, 1), (5, 32, 28, 28, 32, 1), (3, 32, 14, 14, 64, 1), (7, 64, 14, 14, 64, 1),
+                                             (2, 16, 8, 6, 8, 1), (3, 8, 10, 12, 20, 0), (9, 8, 4, 4, 12, 1), (1, 24, 30, 62, 36, 1)])
+def test_conv3x3_pool2_fused(ctx, n, ci, h, w, co, pad):
+    """conv + bias + ReLU + 2x2 max pool in one launch == th_conv3x3_fwd followed by th_maxpool2d_fwd, bit for bit
+    (same k-ordered products per pixel, same maxima); only the pooled tensor is written"""
+    rng = np.random.default_rng(n * 31 + ci + h + w + co)
+    x = rng.standard_normal((n, ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    xd, wd, bd = ctx.upload(x), ctx.upload(wt), ctx.upload(b)
+    full, pooled_ref, arg = ctx.empty(n * co * ho * wo), ctx.empty(n * co * (ho // 2) * (wo // 2)), ctx.empty(n * co * (ho // 2) * (wo // 2), np.int64)
+    ctx.call("th_conv3x3_fwd", xd, wd, bd, full, n, ci, h, w, co, pad, 0, 1)
+    ctx.call("th_maxpool2d_fwd", full, pooled_ref, arg, n, co, ho, wo, 2, 2, 2, 2, 0, 0)
+    fused = ctx.empty(n * co * (ho // 2) * (wo // 2))
+    ctx.call("th_conv3x3_pool2_fwd", xd, wd, bd, fused, n, ci, h, w, co, pad, 1)
+    np.testing.assert_array_equal(ctx.download(fused, (n, co, ho // 2, wo // 2)), ctx.download(pooled_ref, (n, co, ho // 2, wo // 2)))
+
+
+def test_conv3x3_pool2_limits(ctx):
+    from taper_amd._lib import TaperError
+    z = ctx.zeros(4096)
+    with pytest.raises(TaperError, match="even output"):
+        ctx.call("th_conv3x3_pool2_fwd", z, z, None, z, 1, 8, 5, 6, 8, 1, 1)      # odd height
+    with pytest.raises(TaperError, match="even output"):
+        ctx.call("th_conv3x3_pool2_fwd", z, z, None, z, 1, 4, 6, 6, 8, 1, 1)      # c_in = 4: not the matrix-core path

@@ -8,6 +8,7 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from taper_amd import hip  # noqa: E402
+from taper_amd._lib import hip as lib  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 ctx = hip.Ctx(0)
@@ -28,4 +29,19 @@ for n, ci, h, w, co in LAYERS:
     ctx.record(e1)
     us = hip.Ctx.elapsed_ms(e0, e1) * 1e3 / reps
     gf = 2 * 9 * ci * co * h * w * n / 1e9
-    print(f"conv {ci:3d}->{co:3d} {h:2d}x{w:2d} batch {n}: {us:7.2f} us  {gf / (us * 1e-6) / 1e3:6.1f} TFLOP/s")
+    line = f"conv {ci:3d}->{co:3d} {h:2d}x{w:2d} batch {n}: {us:7.2f} us  {gf / (us * 1e-6) / 1e3:6.1f} TFLOP/s"
+    if h % 2 == 0 and lib.th_conv3x3_pool2_supported(ci, h, w, co, 1):
+        yp, arg = ctx.empty(n * co * h * w // 4), ctx.empty(n * co * h * w // 4, np.int64)
+        pool = lambda: ctx.call("th_maxpool2d_fwd", y, yp, arg, n, co, h, w, 2, 2, 2, 2, 0, 0)
+        fused = lambda: ctx.call("th_conv3x3_pool2_fwd", x, wt, b, yp, n, ci, h, w, co, 1, 1)
+        t = []
+        for f in (pool, fused):
+            for _ in range(5):
+                f()
+            ctx.record(e0)
+            for _ in range(reps):
+                f()
+            ctx.record(e1)
+            t.append(hip.Ctx.elapsed_ms(e0, e1) * 1e3 / reps)
+        line += f"   + 2x2 max pool {t[0]:6.2f} us; fused conv+pool {t[1]:6.2f} us"
+    print(line)
