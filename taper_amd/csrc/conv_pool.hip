@@ -633,6 +633,101 @@ int bias_grad_launch(th_ctx *ctx, const float *d_gout, const float *d_mask_y, fl
 }
 }  // namespace th
 
+namespace th {
+// Single-channel 3x3 convolution + bias + ReLU + 2x2 max pool (conv1 of both CNNs: 1 -> 32 channels on 28x28).
+// K = 9: nothing for the matrix cores to do, and a workgroup of the general kernel spends its life in set-up.  Here a
+// workgroup takes one image: the zero-haloed image sits in LDS, a thread owns one POOLED pixel -- its 4x4 input
+// window stays in registers -- and walks the output channels (weights through uniform loads); 36 FMAs per channel
+// in tap order (the k-ordered fmaf chain of the matrix-core kernel: same bits), only the pooled tensor is written.
+// grid = (n, channel blocks of CO_W); weights [9][c_out] (the taper layout as is, tensor.rs:1262).
+constexpr int C1_CO_W = 16;
+__global__ __launch_bounds__(256) void conv1_pool2_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ y, int h, int w_in,
+                                                          int c_out, int pad, int relu) {
+    extern __shared__ float img[];                       // [(h + 2)][(w_in + 2)], zero halo
+    __shared__ float wsm[C1_CO_W][12];                   // this block's filters (9 taps) + bias
+    const int wp = w_in + 2, hp = h + 2;
+    const float *xi = x + (long)blockIdx.x * h * w_in;
+    if (threadIdx.x < C1_CO_W * 10) {
+        const int cl = threadIdx.x / 10, k = threadIdx.x % 10, co = blockIdx.y * C1_CO_W + cl;
+        wsm[cl][k] = co < c_out ? (k < 9 ? w[k * c_out + co] : (bias ? bias[co] : 0.f)) : 0.f;
+    }
+    for (int e = threadIdx.x; e < hp * wp; e += 256) {
+        const int r = e / wp - 1, c = e % wp - 1;
+        img[e] = (r >= 0 && r < h && c >= 0 && c < w_in) ? xi[r * w_in + c] : 0.f;
+    }
+    __syncthreads();
+    const int h_out = h + 2 * pad - 2, w_out = w_in + 2 * pad - 2, ph = h_out >> 1, pw = w_out >> 1;
+    const int co0 = blockIdx.y * C1_CO_W, co1 = min(c_out, co0 + C1_CO_W);
+    const int shift = 1 - pad;                           // pad = 0: the window starts one pixel in
+    for (int p = threadIdx.x; p < ph * pw; p += 256) {
+        const int pr = p / pw, pc = p % pw;
+        float win[4][4];                                 // input rows 2 pr + shift .. + 3 (halo coordinates), cols 2 pc + shift ..
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) win[i][j] = img[(2 * pr + shift + i) * wp + 2 * pc + shift + j];
+        float *yo = y + ((long)blockIdx.x * c_out + co0) * ph * pw + p;
+#pragma unroll 4
+        for (int co = co0; co < co1; ++co, yo += ph * pw) {
+            float wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = wsm[co - co0][k];    // broadcast reads
+            const float b = wsm[co - co0][9];
+            float m = -INFINITY;                         // strict >: NaN never wins (tensor.rs:1449-1461)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], win[dy + k / 3][dx + k % 3], acc);
+                    float v = acc + b;
+                    if (relu) v = v > 0.f ? v : 0.f;
+                    m = v > m ? v : m;
+                }
+            *yo = m;
+        }
+    }
+}
+// the same without the pool (conv1 of the reference CNN feeds conv2 directly): a thread owns output pixels, 9 FMAs per channel
+__global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                    float *__restrict__ y, int h, int w_in, int c_out, int pad, int relu) {
+    extern __shared__ float img[];                       // [(h + 2)][(w_in + 2)], zero halo
+    __shared__ float wsm[C1_CO_W][12];
+    const int wp = w_in + 2, hp = h + 2;
+    const float *xi = x + (long)blockIdx.x * h * w_in;
+    if (threadIdx.x < C1_CO_W * 10) {
+        const int cl = threadIdx.x / 10, k = threadIdx.x % 10, co = blockIdx.y * C1_CO_W + cl;
+        wsm[cl][k] = co < c_out ? (k < 9 ? w[k * c_out + co] : (bias ? bias[co] : 0.f)) : 0.f;
+    }
+    for (int e = threadIdx.x; e < hp * wp; e += 256) {
+        const int r = e / wp - 1, c = e % wp - 1;
+        img[e] = (r >= 0 && r < h && c >= 0 && c < w_in) ? xi[r * w_in + c] : 0.f;
+    }
+    __syncthreads();
+    const int h_out = h + 2 * pad - 2, w_out = w_in + 2 * pad - 2;
+    const int co0 = blockIdx.y * C1_CO_W, co1 = min(c_out, co0 + C1_CO_W);
+    const int shift = 1 - pad;
+    for (int p = threadIdx.x; p < h_out * w_out; p += 256) {
+        const int r = p / w_out, c = p % w_out;
+        float win[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) win[k] = img[(r + shift + k / 3) * wp + c + shift + k % 3];
+        float *yo = y + ((long)blockIdx.x * c_out + co0) * h_out * w_out + p;
+#pragma unroll 4
+        for (int co = co0; co < co1; ++co, yo += h_out * w_out) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(wsm[co - co0][k], win[k], acc);
+            float v = acc + wsm[co - co0][9];
+            if (relu) v = v > 0.f ? v : 0.f;
+            *yo = v;
+        }
+    }
+}
+}  // namespace th
+
 extern "C" {
 
 int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y, int n, int c_in, int h,
@@ -641,6 +736,14 @@ int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float 
     TH_REQUIRE(n > 0 && c_in > 0 && c_out > 0 && h + 2 * pad >= 3 && w + 2 * pad >= 3, "th_conv3x3_fwd: bad geometry");
     TH_REQUIRE(pad == 0 || pad == 1, "th_conv3x3_fwd: pad must be 0 or 1 (got %d)", pad);
     TH_REQUIRE(weight_layout == 0 || weight_layout == 1, "th_conv3x3_fwd: weight_layout must be 0 (taper) or 1 (standard)");
+    if (c_in == 1 && weight_layout == 0 && (size_t)(h + 2) * (w + 2) * sizeof(float) <= (48u << 10)) {
+        // conv1: K = 9 -- one image per workgroup on the vector ALUs (17.3 -> 8 us at batch 256 against the matrix-core kernel)
+        const size_t lds = (size_t)(h + 2) * (w + 2) * sizeof(float);
+        hipLaunchKernelGGL(conv1_kernel, dim3(n, ceil_div(c_out, C1_CO_W)), dim3(256), lds, ctx->stream, d_x, d_w, d_bias, d_y, h, w, c_out,
+                           pad, relu);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
     const bool mfma = conv3x3_mfma_supported(c_in, h, w, pad);
     // the taper layout IS the [k][co] slab the matrix-core kernel stages (tensor.rs:1262): read it in place
     if (mfma && weight_layout == 0 && c_out % 4 == 0 && ((uintptr_t)d_w & 15) == 0)
@@ -670,6 +773,13 @@ int th_conv3x3_pool2_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const 
     TH_REQUIRE(th_conv3x3_pool2_supported(c_in, h, w, c_out, pad) && ((uintptr_t)d_w & 15) == 0,
                "th_conv3x3_pool2_fwd: needs the matrix-core path (c_in >= 8 or == 1), c_out %% 4 == 0, even output height / width, "
                "rows of <= 64 outputs and 16-byte aligned weights");
+    if (c_in == 1 && (size_t)(h + 2) * (w + 2) * sizeof(float) <= (48u << 10)) {   // conv1: one image per workgroup, VALU
+        const size_t lds = (size_t)(h + 2) * (w + 2) * sizeof(float);
+        hipLaunchKernelGGL(conv1_pool2_kernel, dim3(n, ceil_div(c_out, C1_CO_W)), dim3(256), lds, ctx->stream, d_x, d_w, d_bias, d_y_pooled,
+                           h, w, c_out, pad, relu);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
     // the taper layout IS the [k][co] slab the kernel stages (tensor.rs:1262)
     return conv3x3_mfma_launch(ctx, d_x, d_w, c_out, c_out, d_bias, d_y_pooled, n, c_in, h, w, c_out, pad, relu, false, true);
 }
