@@ -69,15 +69,19 @@ __device__ long long g_conv_prof[8];
 // POOL: the epilogue additionally applies a 2x2 / stride-2 max pool (tensor.rs:1391-1470 values; no index output) and
 // stores ONLY the pooled tensor [n][c_out][h_out/2][w_out/2] -- the Conv2dReLU -> MaxPool2d pair of the CNNs without
 // the full-resolution round trip (needs even rows_t, h_out, w_out).
-template <int CT, bool ACCUM, int CIT, bool POOL = false>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
+// WH = 2: 512 threads -- waves 4..7 take the upper half of the channel tiles on the SAME pixels and staged operands, so a
+// SIMD holds two of the workgroup's waves: twice the waves per SIMD with no extra staging per MFMA (the layers with 14x14
+// maps launch < 2 workgroups per CU and their matrix pipes idled 56 % of the time).
+template <int CT, bool ACCUM, int CIT, bool POOL = false, int WH = 1>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
+__global__ __launch_bounds__(256 * WH) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CO_B = 16 * CT;
     constexpr int KS = (CIT * 9 + 3) / 4;                      // k-steps per pass: 18, or 3 (k = 9 padded to 12)
     constexpr int WQ = KS * 4 * CO_B / 4;                      // float4 quads in the weight slab (rows past 9*CIT are zero)
-    constexpr int WPT = (WQ + 255) / 256;                      // quads per thread per pass
+    constexpr int NT = 256 * WH, PPT = MF_PPT / WH, CTW = CT / WH;   // threads, patch elements per thread per pass, channel tiles per wave
+    constexpr int WPT = (WQ + NT - 1) / NT;                    // quads per thread per pass
     CONV_STAMP(0);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = (t >> 6) & 3, chalf = t >> 8;   // pixel group, channel half
     const int l16 = lane & 15, g4 = lane >> 4;
     const int wp = a.w_out + 2, rp = a.rows_t + 2;           // patch pitch / rows (input window of the band)
     const int img_stride = rp * wp, ci_stride = a.img_t * img_stride;
@@ -122,10 +126,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     // its local channel; weight quad u = t + 256 j -> row kk and column quad.
     const int shift = 1 - a.pad;                               // pad = 0: the window starts one pixel in
     const long chan = (long)a.h * a.w_in;
-    int p_goff[MF_PPT];   // (offset << 3) | local channel, or -1
+    int p_goff[PPT];   // (offset << 3) | local channel, or -1
 #pragma unroll
-    for (int j = 0; j < MF_PPT; ++j) {
-        const int e = t + 256 * j;
+    for (int j = 0; j < PPT; ++j) {
+        const int e = t + NT * j;
         p_goff[j] = -1;
         if (e < patch_n) {
             int cl, r1, il, r2, rr, cc;
@@ -139,26 +143,26 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     }
     const float *xbase = a.x + (long)img0 * a.c_in * chan;
 
-    floatx4 acc[2][CT];
+    floatx4 acc[2][CTW];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < CT; ++j) acc[q][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < CTW; ++j) acc[q][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    float pv[MF_PPT];
+    float pv[PPT];
     float4 wv[WPT];
     // all global loads of a pass are issued back to back (one round trip), held in registers while the
     // previous pass computes, then written to LDS
 #define TH_MF_LOAD(CB)                                                                                           \
     {                                                                                                            \
         const float *xc = xbase + (long)(CB) * chan;                                                             \
-        _Pragma("unroll") for (int j = 0; j < MF_PPT; ++j) {   /* always-valid address + select: no branch per load */   \
+        _Pragma("unroll") for (int j = 0; j < PPT; ++j) {   /* always-valid address + select: no branch per load */   \
             const bool ok = p_goff[j] >= 0 && (CB) + (p_goff[j] & 7) < a.c_in;                                    \
             const float v = xc[ok ? (p_goff[j] >> 3) : 0];                                                        \
             pv[j] = ok ? v : 0.f;                                                                                \
         }                                                                                                        \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                        \
-            const int u = t + 256 * j, kk = u / (CO_B / 4), cq = (u % (CO_B / 4)) * 4;                           \
+            const int u = t + NT * j, kk = u / (CO_B / 4), cq = (u % (CO_B / 4)) * 4;                              \
             const int k = (CB) * 9 + kk, co = co0 + cq;                                                          \
             const bool ok = u < WQ && kk < CIT * 9 && k < a.c_in * 9 && co + 3 < a.w_cols;                       \
             const float4 v = *reinterpret_cast<const float4 *>(a.w + (ok ? (long)k * a.w_ld + co : 0));          \
@@ -167,12 +171,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     }
 #define TH_MF_STORE()                                                                                            \
     {                                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < MF_PPT; ++j) {                                                     \
-            const int e = t + 256 * j;                                                                           \
+        _Pragma("unroll") for (int j = 0; j < PPT; ++j) {                                                        \
+            const int e = t + NT * j;                                                                            \
             if (e < patch_n) patch[e] = pv[j];                                                                   \
         }                                                                                                        \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                                        \
-            const int u = t + 256 * j;                                                                           \
+            const int u = t + NT * j;                                                                            \
             if (u < WQ) *reinterpret_cast<float4 *>(wsl + 4 * u) = wv[j];                                        \
         }                                                                                                        \
     }
@@ -189,9 +193,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
         for (int s = 0; s < KS; ++s) {
             const float b0 = patch[(s == KS - 1 ? pix_off_pad[0] : pix_off[0]) + koff[s]];
             const float b1 = patch[(s == KS - 1 ? pix_off_pad[1] : pix_off[1]) + koff[s]];
-            const float *wk = wsl + (4 * s + g4) * CO_B + l16;
+            const float *wk = wsl + (4 * s + g4) * CO_B + l16 + 16 * CTW * chalf;
 #pragma unroll
-            for (int j = 0; j < CT; ++j) {
+            for (int j = 0; j < CTW; ++j) {
                 const float av = wk[16 * j];
                 acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0][j], 0, 0, 0);
                 acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1][j], 0, 0, 0);
@@ -217,10 +221,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
             const int p = (wave + 4 * q) * 16 + l16;
             if (p >= m_wg) continue;
 #pragma unroll
-            for (int j = 0; j < CT; ++j)
+            for (int j = 0; j < CTW; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int cl = 16 * j + 4 * g4 + i, co = co0 + cl;
+                    const int cl = 16 * (CTW * chalf + j) + 4 * g4 + i, co = co0 + cl;
                     float v = acc[q][j][i] + ((a.bias && co < a.c_out) ? a.bias[co] : 0.f);
                     if (a.relu) v = v > 0.f ? v : 0.f;
                     ep[cl * ep_ld + p] = v;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
         const int pw = a.w_out >> 1, np_img = (a.rows_t >> 1) * pw, np = a.img_t * np_img;
         const FastDiv d_np(np), d_npi(np_img), d_pw(pw);
         const long pchan = (long)(a.h_out >> 1) * pw;
-        for (int idx = t; idx < CO_B * np; idx += 256) {
+        for (int idx = t; idx < CO_B * np; idx += NT) {
             int cl, rem, il, r2, pr, pc;
             d_np.divmod(idx, cl, rem);
             d_npi.divmod(rem, il, r2);
@@ -262,10 +266,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
         float *ypx = a.y + (((long)(img0 + il) * a.c_out) * a.h_out + (oh0 + r)) * a.w_out + c;
         const long ochan = (long)a.h_out * a.w_out;
 #pragma unroll
-        for (int j = 0; j < CT; ++j)
+        for (int j = 0; j < CTW; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int co = co0 + 16 * j + 4 * g4 + i;
+                const int co = co0 + 16 * (CTW * chalf + j) + 4 * g4 + i;
                 if (co >= a.c_out) continue;
                 float v = acc[q][j][i] + (a.bias ? a.bias[co] : 0.f);
                 if (a.relu) v = v > 0.f ? v : 0.f;
@@ -342,15 +346,19 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     size_t lds = (((patch_n + 4) & ~(size_t)3) + (size_t)((cit * 9 + 3) / 4 * 4) * a.co_b) * sizeof(float);
     if (pool) lds = std::max(lds, (size_t)a.co_b * ((size_t)(a.img_t * a.rows_t * a.w_out) | 1) * sizeof(float));   // the epilogue tile
     dim3 grid(ceil_div(n, a.img_t) * a.bands, ceil_div(c_out, a.co_b));
-#define TH_MF(CTV, ACC, PL)                                                                                             \
-    if (cit == 1) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, 1, PL>), grid, dim3(256), lds, ctx->stream, a);     \
-    else hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, MF_CI, PL>), grid, dim3(256), lds, ctx->stream, a);
-#define TH_MF_CT(ACC, PL)                              \
-    switch (ct) {                                      \
-        case 4: TH_MF(4, ACC, PL) break;               \
-        case 2: TH_MF(2, ACC, PL) break;               \
-        default: TH_MF(1, ACC, PL) break;              \
+#define TH_MF(CTV, ACC, PL, WHV)                                                                                                   \
+    if (cit == 1) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, 1, PL, WHV>), grid, dim3(256 * WHV), lds, ctx->stream, a);     \
+    else hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, MF_CI, PL, WHV>), grid, dim3(256 * WHV), lds, ctx->stream, a);
+#define TH_MF_CT(ACC, PL)                                                       \
+    switch (ct) {                                                               \
+        case 4: if (wh2) { TH_MF(4, ACC, PL, 2) } else { TH_MF(4, ACC, PL, 1) } break;   \
+        case 2: if (wh2) { TH_MF(2, ACC, PL, 2) } else { TH_MF(2, ACC, PL, 1) } break;   \
+        default: TH_MF(1, ACC, PL, 1) break;                                    \
     }
+    // launches with < 3 workgroups per CU: 8 waves per workgroup (see WH; 14x14 layers 38.3 / 62.5 -> 34.4 / 56.5 us, 7x7: 40.0 -> 36.8 us;
+    // the 28x28 layer has 1792 workgroups and gains nothing)
+    static const int wh_env = getenv("TAPER_CONV_WH") ? atoi(getenv("TAPER_CONV_WH")) : 0;   // tuning probe: 1 forces 4 waves
+    const bool wh2 = ct >= 2 && wh_env != 1 && (wh_env == 2 || (long)grid.x * grid.y < 768);
     if (pool) TH_MF_CT(false, true) else if (accum) TH_MF_CT(true, false) else TH_MF_CT(false, false)
 #undef TH_MF_CT
 #undef TH_MF
