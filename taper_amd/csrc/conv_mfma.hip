@@ -72,8 +72,10 @@ __device__ long long g_conv_prof[8];
 // WH = 2: 512 threads -- waves 4..7 take the upper half of the channel tiles on the SAME pixels and staged operands, so a
 // SIMD holds two of the workgroup's waves: twice the waves per SIMD with no extra staging per MFMA (the layers with 14x14
 // maps launch < 2 workgroups per CU and their matrix pipes idled 56 % of the time).
+// (<= 32-channel blocks with 4 waves: capped at 128 VGPRs so that 4 workgroups share a CU -- 4 spilled registers buy 66.8 -> 62.9 us
+// on the 28x28 layer; a cap of 102 for 5 workgroups spills the plans and costs 50 %)
 template <int CT, bool ACCUM, int CIT, bool POOL = false, int WH = 1>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
-__global__ __launch_bounds__(256 * WH) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
+__global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CO_B = 16 * CT;
     constexpr int KS = (CIT * 9 + 3) / 4;                      // k-steps per pass: 18, or 3 (k = 9 padded to 12)
