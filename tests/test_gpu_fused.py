@@ -316,3 +316,40 @@ def test_cnn_graph_epoch_matches_oracle(model_name, batch):
     for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
         np.testing.assert_allclose(hp.data(), op.data(), rtol=1e-3, atol=lr * 5e-2, err_msg=f"param {i}")
     assert hopt.t() == oopt.t() == 8
+
+
+@pytest.mark.parametrize("case", ["no_bias", "ragged", "deep_ragged", "no_decay"])
+def test_tail_path_edge_models_match_oracle(case):
+    """graph path (two-launch tail where it applies) against the oracle for models off the MNIST shapes: Linears without
+    bias, sizes that take the general (non whole-tile) tail kernel, a deeper ragged MLP (no dX role -> head-only form),
+    and Adam without weight decay"""
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng({"no_bias": 1, "ragged": 2, "deep_ragged": 3, "no_decay": 4}[case])
+    lin = lambda i, o, b=True: dict(kind="linear", w=(rng.uniform(-1, 1, (o, i)) * np.sqrt(2.0 / i)).astype(np.float32),
+                                    b=(rng.uniform(-0.1, 0.1, o).astype(np.float32) if b else None))
+    batch = 48
+    if case == "no_bias":
+        spec = [lin(784, 128, False), dict(kind="relu"), lin(128, 10, False)]
+    elif case == "ragged":
+        spec, batch = [lin(784, 100), dict(kind="relu"), lin(100, 7)], 50
+    elif case == "deep_ragged":
+        spec, batch = [lin(784, 60), dict(kind="relu"), lin(60, 36), dict(kind="relu"), lin(36, 10)], 40
+    else:
+        spec = [lin(784, 128), dict(kind="relu"), lin(128, 10)]
+    n = 3 * batch + batch // 2
+    x, y = backends.mnist_like(rng, n)
+    if case == "ragged":
+        y = (y % 7).astype(np.float32)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    wd = None if case == "no_decay" else 1e-4
+    hopt, oopt = T.Adam(hm.parameters(), 1e-3, None, None, wd), Orc.m.Adam(om.parameters(), 1e-3, None, None, wd)
+    tr = T.Trainer(hm, hopt)
+    loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False)
+    for epoch in range(2):
+        ep = tr.run_epoch(loader, T.Trainer.GRAPH)
+        ref = [om.train_step(oopt, x[s:s + batch], y[s:s + batch], (len(x[s:s + batch]), 784))["loss"] for s in range(0, n, batch)]
+        np.testing.assert_allclose(ep["losses"], ref, rtol=3e-4, atol=1e-5, err_msg=f"epoch {epoch}")
+    for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+        np.testing.assert_allclose(hp.data(), op.data(), rtol=1e-4, atol=2e-5, err_msg=f"param {i}")
