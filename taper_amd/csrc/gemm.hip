@@ -2,7 +2,7 @@
 // th_linear_fwd / th_linear_bwd (src/nn.rs:54-60 and its three tape nodes).
 //
 // Two kernels:
-//  * sgemm_tile128: 128x128x32 macro-tile, 4 waves x (2x2) v_mfma_f32_32x32x2_f32,
+//  * sgemm_tile<128>: 128x128x32 macro-tile, 4 waves x (2x2) v_mfma_f32_32x32x2_f32 (sgemm_tile<64>: 64x64x32, one MFMA tile per wave),
 //    LDS double-buffered with register prefetch, XCD-aware tile order.  Bound:
 //    MFMA fp32 peak (157.3 TF).  Used when the output has >= 64 macro-tiles.
 //  * sgemm_small16: 16x16 output tile per workgroup, 4 waves split K between
@@ -322,23 +322,31 @@ __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
 // 128x128x32 MFMA kernel
 // ------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LD_KC = BK + 1;   // [mn][k] image, odd stride: conflict-free ds_read_b32 / ds_write_b32
-constexpr int LD_MC = BM;       // [k][mn] image
-constexpr int TILE_KC = BM * LD_KC;
-constexpr int TILE_MC = BK * LD_MC;
-constexpr int TILE_MAX = TILE_KC > TILE_MC ? TILE_KC : TILE_MC;
+// Tile geometry for a TS x TS x BK macro-tile (TS = 128: 4 waves x (2x2) 32x32 MFMA tiles; TS = 64: 4 waves x one 32x32
+// tile -- for outputs too small to give the chip enough 128-tiles: tall-skinny MLP products at batch 512..8192).
+template <int TS>
+struct TileGeo {
+    static constexpr int LD_KC = BK + 1;   // [mn][k] image, odd stride: conflict-free ds_read_b32 / ds_write_b32
+    static constexpr int LD_MC = TS;       // [k][mn] image
+    static constexpr int TILE_KC = TS * LD_KC, TILE_MC = BK * LD_MC;
+    static constexpr int TILE_MAX = TILE_KC > TILE_MC ? TILE_KC : TILE_MC;
+    static constexpr int R = TS / 32;      // float4 per thread per operand per tile
+    static constexpr int QPR = TS / 4;     // float4 quads per k row of an m/n-contiguous tile
+};
+constexpr int TILE_MAX = TileGeo<128>::TILE_MAX;
 
-// Each thread stages 16 floats per operand per tile, as 4 float4.
-// KC source: the tile is [128 rows][32 k]; float4 along k: 8 per row ->
+// Each thread stages 4 R floats per operand per tile, as R float4.
+// KC source: the tile is [TS rows][32 k]; float4 along k: 8 per row ->
 //   thread t handles rows (t / 8) + 32*j, k quad (t % 8).
-// MC source: the tile is [32 k][128 mn]; float4 along mn: 32 per k row ->
-//   thread t handles k rows (t / 32) + 8*j, mn quad (t % 32).
-template <bool KC, bool GUARD>
+// MC source: the tile is [32 k][TS mn]; float4 along mn: QPR per k row ->
+//   thread t handles k rows (t / QPR) + (256 / QPR)*j, mn quad (t % QPR).
+template <bool KC, bool GUARD, int TS>
 __device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_mn, long rs_k, int mn0, int k0,
-                                          int mn_lim, int k_lim, int t, float4 (&reg)[4], bool vec = false) {
+                                          int mn_lim, int k_lim, int t, float4 (&reg)[TileGeo<TS>::R], bool vec = false) {
+    constexpr int R = TileGeo<TS>::R, QPR = TileGeo<TS>::QPR;
     // element (mn, k) lives at P[mn * rs_mn + k * rs_k]; exactly one stride is 1
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < R; ++j) {
         if (KC) {
             const int mn = mn0 + (t >> 3) + 32 * j, kq = k0 + (t & 7) * 4;
             const float *p = P + (long)mn * rs_mn + kq;
@@ -357,7 +365,7 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_m
                 reg[j] = make_float4(v[0], v[1], v[2], v[3]);
             }
         } else {
-            const int kr = k0 + (t >> 5) + 8 * j, mq = mn0 + (t & 31) * 4;
+            const int kr = k0 + t / QPR + (256 / QPR) * j, mq = mn0 + (t % QPR) * 4;
             const float *p = P + (long)kr * rs_k + mq;
             if (!GUARD) {
                 reg[j] = *reinterpret_cast<const float4 *>(p);
@@ -375,35 +383,37 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_m
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float *__restrict__ S, int t, const float4 (&reg)[4]) {
+template <bool KC, int TS>
+__device__ __forceinline__ void store_tile(float *__restrict__ S, int t, const float4 (&reg)[TileGeo<TS>::R]) {
+    constexpr int R = TileGeo<TS>::R, QPR = TileGeo<TS>::QPR;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < R; ++j) {
         if (KC) {
-            float *s = S + ((t >> 3) + 32 * j) * LD_KC + (t & 7) * 4;
+            float *s = S + ((t >> 3) + 32 * j) * TileGeo<TS>::LD_KC + (t & 7) * 4;
             s[0] = reg[j].x; s[1] = reg[j].y; s[2] = reg[j].z; s[3] = reg[j].w;
         } else {
-            float *s = S + ((t >> 5) + 8 * j) * LD_MC + (t & 31) * 4;
+            float *s = S + (t / QPR + (256 / QPR) * j) * TileGeo<TS>::LD_MC + (t % QPR) * 4;
             *reinterpret_cast<float4 *>(s) = reg[j];
         }
     }
 }
 
-template <bool KC>
+template <bool KC, int TS>
 __device__ __forceinline__ float frag(const float *__restrict__ S, int mn, int kx) {
-    return KC ? S[mn * LD_KC + kx] : S[kx * LD_MC + mn];
+    return KC ? S[mn * TileGeo<TS>::LD_KC + kx] : S[kx * TileGeo<TS>::LD_MC + mn];
 }
 
-template <bool A_KC, bool B_KC, bool GUARD>
-__global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict__ A, const float *__restrict__ B,
-                                                        float *__restrict__ C, int m, int n, int k,
-                                                        long a_rs, long a_cs, long b_rs, long b_cs,
-                                                        int tiles_m, int tiles_n, Epilogue ep, int kslice,
-                                                        float *__restrict__ partial, int vec) {
+template <int TS, bool A_KC, bool B_KC, bool GUARD>
+__global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A, const float *__restrict__ B,
+                                                     float *__restrict__ C, int m, int n, int k,
+                                                     long a_rs, long a_cs, long b_rs, long b_cs,
+                                                     int tiles_m, int tiles_n, Epilogue ep, int kslice,
+                                                     float *__restrict__ partial, int vec) {
     // blockIdx.y = K slice [y*kslice, (y+1)*kslice): with `partial` set every slice writes its raw
     // accumulators to partial[y][m*n] and splitk_reduce applies the epilogue in fixed slice order
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // LDS: As[2] then Bs[2], TILE_MAX floats each
+    constexpr int TMAX = TileGeo<TS>::TILE_MAX, R = TileGeo<TS>::R, WS = TS / 2, NS = WS / 32;
+    // LDS: As[2] then Bs[2], TMAX floats each
 
     // XCD-aware order: block b runs on XCD b % 8, so give each XCD a
     // contiguous chunk of the tile list (neighbouring tiles share A/B panels
@@ -414,60 +424,62 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile128(const float *__restrict_
     const int tile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + bid / kNumXCD;
     // within the chunk walk column-major in groups of 8 rows for panel reuse
     const int tm = tile % tiles_m, tn = tile / tiles_m;
-    const int row0 = tm * BM, col0 = tn * BN;
+    const int row0 = tm * TS, col0 = tn * TS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;  // wave's 64x64 sub-tile
+    const int wm = (wave >> 1) * WS, wn = (wave & 1) * WS;  // wave's WS x WS sub-tile
     const int li = lane & 31, lk = lane >> 5;
 
-    floatx16 acc[2][2];
+    floatx16 acc[NS][NS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NS; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NS; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float4 ra[4], rb[4];
+    float4 ra[R], rb[R];
     const int kbeg = blockIdx.y * kslice, kend = min(k, kbeg + kslice);
     const int nt = (kend - kbeg + BK - 1) / BK;
     // element (i,k) of op(A) at A[i*a_rs + k*a_cs]; (k,j) of op(B) at B[k*b_rs + j*b_cs]
-    load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, kbeg, m, kend, t, ra, vec);
-    load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, kbeg, n, kend, t, rb, vec);
-    store_tile<A_KC>(smem, t, ra);
-    store_tile<B_KC>(smem + 2 * TILE_MAX, t, rb);
+    load_tile<A_KC, GUARD, TS>(A, a_rs, a_cs, row0, kbeg, m, kend, t, ra, vec);
+    load_tile<B_KC, GUARD, TS>(B, b_cs, b_rs, col0, kbeg, n, kend, t, rb, vec);
+    store_tile<A_KC, TS>(smem, t, ra);
+    store_tile<B_KC, TS>(smem + 2 * TMAX, t, rb);
     __syncthreads();
 
     for (int it = 0; it < nt; ++it) {
         const int cur = it & 1;
         if (it + 1 < nt) {
-            load_tile<A_KC, GUARD>(A, a_rs, a_cs, row0, kbeg + (it + 1) * BK, m, kend, t, ra, vec);
-            load_tile<B_KC, GUARD>(B, b_cs, b_rs, col0, kbeg + (it + 1) * BK, n, kend, t, rb, vec);
+            load_tile<A_KC, GUARD, TS>(A, a_rs, a_cs, row0, kbeg + (it + 1) * BK, m, kend, t, ra, vec);
+            load_tile<B_KC, GUARD, TS>(B, b_cs, b_rs, col0, kbeg + (it + 1) * BK, n, kend, t, rb, vec);
         }
-        const float *as = smem + cur * TILE_MAX, *bs = smem + (2 + cur) * TILE_MAX;
+        const float *as = smem + cur * TMAX, *bs = smem + (2 + cur) * TMAX;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = frag<A_KC>(as, wm + li, kk + lk);
-            const float a1 = frag<A_KC>(as, wm + 32 + li, kk + lk);
-            const float b0 = frag<B_KC>(bs, wn + li, kk + lk);
-            const float b1 = frag<B_KC>(bs, wn + 32 + li, kk + lk);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float af[NS], bf[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                af[i] = frag<A_KC, TS>(as, wm + 32 * i + li, kk + lk);
+                bf[i] = frag<B_KC, TS>(bs, wn + 32 * i + li, kk + lk);
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (it + 1 < nt) {
-            store_tile<A_KC>(smem + (cur ^ 1) * TILE_MAX, t, ra);
-            store_tile<B_KC>(smem + (2 + (cur ^ 1)) * TILE_MAX, t, rb);
+            store_tile<A_KC, TS>(smem + (cur ^ 1) * TMAX, t, ra);
+            store_tile<B_KC, TS>(smem + (2 + (cur ^ 1)) * TMAX, t, rb);
         }
         __syncthreads();
     }
 
     // epilogue.  C/D map of 32x32x2: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NS; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NS; ++j) {
             const int col = col0 + wn + 32 * j + li;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -544,20 +556,30 @@ static inline int tile128_kz(int m, int n, int k) {
     return kz < 1 ? 1 : kz;
 }
 
-template <bool A_KC, bool B_KC>
-static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C, int m, int n, int k, long a_rs,
-                          long a_cs, long b_rs, long b_cs, const Epilogue &ep) {
-    const int tiles_m = ceil_div(m, BM), tiles_n = ceil_div(n, BN);
-    const size_t lds = 4 * TILE_MAX * sizeof(float);
+// K slices for the 64x64 kernel: target 2 workgroups per CU, slices of >= 128 k
+static inline int tile64_kz(int m, int n, int k) {
+    const long tiles = (long)ceil_div(m, 64) * ceil_div(n, 64);
+    if (tiles >= 384 || k < 256) return 1;
+    int kz = (int)((512 + tiles - 1) / tiles);
+    const int kz_max = k / 128;
+    if (kz > kz_max) kz = kz_max;
+    return kz < 1 ? 1 : kz;
+}
+
+template <int TS, bool A_KC, bool B_KC>
+static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, int m, int n, int k, long a_rs,
+                       long a_cs, long b_rs, long b_cs, const Epilogue &ep) {
+    const int tiles_m = ceil_div(m, TS), tiles_n = ceil_div(n, TS);
+    const size_t lds = 4 * TileGeo<TS>::TILE_MAX * sizeof(float);
     const long lda = A_KC ? a_rs : a_cs, ldb = B_KC ? b_cs : b_rs;
-    int kz = tile128_kz(m, n, k);
+    int kz = TS == 128 ? tile128_kz(m, n, k) : tile64_kz(m, n, k);
     int kslice = ceil_div(ceil_div(k, kz), BK) * BK;
     kz = ceil_div(k, kslice);
     // dwordx4 operand loads: 16-B aligned rows, and whole quads in or out of range along the vector axis
     // (k for a k-contiguous operand, m / n for an m/n-contiguous one); slices start on multiples of 32
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((A_KC ? k : m) % 4 == 0) &&
                      ((B_KC ? k : n) % 4 == 0) && m >= 4 && n >= 4 && k >= 4;
-    const bool exact = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && vec;
+    const bool exact = (m % TS == 0) && (n % TS == 0) && (k % BK == 0) && vec;
     float *partial = nullptr;
     if (kz > 1) {
         void *ws = nullptr;
@@ -568,7 +590,7 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
     Epilogue kep = ep;
     kep.adam.p = nullptr;
     if (exact) {
-        auto kern = sgemm_tile128<A_KC, B_KC, false>;
+        auto kern = sgemm_tile<TS, A_KC, B_KC, false>;
         static bool attr_set = false;
         if (!attr_set) {
             TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -577,7 +599,7 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
                            b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, 1);
     } else {
-        auto kern = sgemm_tile128<A_KC, B_KC, true>;
+        auto kern = sgemm_tile<TS, A_KC, B_KC, true>;
         static bool attr_set = false;
         if (!attr_set) {
             TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -598,11 +620,26 @@ static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C,
     return 0;
 }
 
+template <bool A_KC, bool B_KC>
+static int launch_tile128(th_ctx *ctx, const float *A, const float *B, float *C, int m, int n, int k, long a_rs,
+                          long a_cs, long b_rs, long b_cs, const Epilogue &ep) {
+    return launch_tile<128, A_KC, B_KC>(ctx, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, ep);
+}
+
 
 static inline bool gemm_is_big(int m, int n, int k) {
     const long tiles128 = (long)ceil_div(m, BM) * ceil_div(n, BN);
     if (m < BM || n < BN || k < BK) return false;
     return tiles128 >= 64 || tiles128 * tile128_kz(m, n, k) >= 96;   // deep K: split-K slices fill the chip (below: 16x16 tiles with K slices)
+}
+
+// 64x64 tiles: outputs with too few 128-tiles for the big kernel but far too much work for 16x16 tiles straight from L2
+// (the MLP's tall-skinny products at batch 512..8192: [B,128] = X . W1^T and [128,784] = dZ^T . X)
+static inline bool gemm_is_mid(int m, int n, int k) {
+    static const long min_macs = getenv("TAPER_GEMM_MID_MACS") ? atol(getenv("TAPER_GEMM_MID_MACS")) : 300000000L;
+    if (m < 64 || n < 64 || k < 64) return false;
+    const long tiles64 = (long)ceil_div(m, 64) * ceil_div(n, 64);
+    return (long)m * n * k >= min_macs && tiles64 * tile64_kz(m, n, k) >= 32;
 }
 
 // op(A)[i,k] = A[i*a_rs + k*a_cs], op(B)[k,j] = B[k*b_rs + j*b_cs]
@@ -637,9 +674,14 @@ int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, co
         if (bt && th_free(ctx, bt)) return 1;
         return 0;
     }
+    // a "big" product whose 128-tiles (x K slices) cannot give every CU a workgroup runs on 64-tiles instead
+    static const long big_min_wg = getenv("TAPER_GEMM_BIG_WG") ? atol(getenv("TAPER_GEMM_BIG_WG")) : 460;
+    const long wg128 = (long)ceil_div(m, BM) * ceil_div(n, BN) * tile128_kz(m, n, k);
+    const bool mid = gemm_is_mid(m, n, k) && (!big || wg128 < big_min_wg);
 #define TH_GEMM_CASE(AK, BKC)                                                                         \
     if (a_kc == AK && b_kc == BKC)                                                                          \
-        return big ? launch_tile128<AK, BKC>(ctx, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, ep)             \
+        return mid ? launch_tile<64, AK, BKC>(ctx, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, ep)            \
+             : big ? launch_tile128<AK, BKC>(ctx, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, ep)             \
                    : launch_small<AK, BKC>(ctx, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, ep);
     TH_GEMM_CASE(true, true)
     TH_GEMM_CASE(true, false)
