@@ -537,17 +537,13 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     int tile_m, grp = 0;
     if (!head_role) {
         const int b2 = bid - a.n_head;
-        if (KS == 8) {   // 8 hidden tiles, 8 XCDs: XCD x owns hidden tile x -- all of its W1 rows and their Adam state -- for every
-                         // column group (5.95 -> 5.75 us; the next forward launch reads the same rows on the same XCD)
-            tile_m = b2 & 7;
-            grp = b2 >> 3;
-            if (grp >= a.groups) return;
-        } else {
-            const int tt = (b2 & 7) * (a.n_dw >> 3) + (b2 >> 3);
-            if (tt >= KS * a.groups) return;
-            tile_m = tt % KS;
-            grp = tt / KS;
-        }
+        // XCD x takes the x-th eighth of the blocks, hidden tile innermost: each L2 fetches only its own X columns.
+        // (XCD x = hidden tile x for every column group was 0.2 us faster -- the next forward launch reads the same W1 rows
+        // on the same XCD -- but every L2 then fetches all of X: 4.9 MB instead of 3.8 MB of fabric traffic per launch.)
+        const int tt = (b2 & 7) * (a.n_dw >> 3) + (b2 >> 3);
+        if (tt >= KS * a.groups) return;
+        tile_m = tt % KS;
+        grp = tt / KS;
     } else {
         tile_m = bid;
         if (tile_m >= KS) return;
