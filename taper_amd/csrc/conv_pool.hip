@@ -606,6 +606,9 @@ int bias_grad_launch(th_ctx *ctx, const float *d_gout, const float *d_mask_y, fl
         if (slabs > n) slabs = n;
     }
     const bool small_planes = pooled && d_mask_y && hw <= 64;
+    if (small_planes && slabs > 1) {   // one plane per wave and iteration: latency-bound, so more, shorter slabs (<= 16 images each)
+        slabs = std::min(ceil_div(n, 4), std::max(slabs, ceil_div(2048, c)));
+    }
     if (slabs <= 1) {
         if (small_planes)
             hipLaunchKernelGGL(bias_grad_avgpool_small_kernel, dim3(c), dim3(256), 0, ctx->stream, d_gout, d_mask_y, d_gb, (float *)nullptr, n,
