@@ -222,6 +222,17 @@ int th_log_bwd(th_ctx *ctx, const float *d_x, const float *d_gout, float *d_gin,
 int th_pow_fwd(th_ctx *ctx, const float *d_x, float e, float *d_y, size_t n);         /* tensor.rs:1172-1178 */
 int th_pow_bwd(th_ctx *ctx, const float *d_x, float e, const float *d_gout, float *d_gin, size_t n); /* tensor.rs:1188-1202 */
 
+/* ---- post-training-quantization storage codecs: src/tensor.rs:2110-2288 (bit-exact restatements) ---- */
+/* IEEE half <-> fp32 as the reference hand-rolls it (tensor.rs:2191-2287): round half UP on the 13 dropped bits with the
+ * mantissa carry OR-ed into the exponent field, truncating denormals, NaN -> 0x7E00-style quiet pattern. */
+int th_f32_to_f16(th_ctx *ctx, const float *d_x, uint16_t *d_y, size_t n);
+int th_f16_to_f32(th_ctx *ctx, const uint16_t *d_x, float *d_y, size_t n);
+/* int8 affine quantisation (tensor.rs:2110-2152): min / max over the FINITE elements (+-0.1 when equal),
+ * scale = (max - min) / 255, q = clamp(round((x - min) / scale) as i32 - 128, -128, 127).  d_params[2] receives
+ * {min_val, scale} on the device; zero_point is -128.  Dequantise (tensor.rs:353-360): (q - zero_point) * scale + min_val. */
+int th_quantize_int8(th_ctx *ctx, const float *d_x, int8_t *d_q, size_t n, float *d_params);
+int th_dequantize_int8(th_ctx *ctx, const int8_t *d_q, float *d_y, size_t n, float scale, int zero_point, float min_val);
+
 /* ---- broadcast / reduce / layout: src/tensor.rs ---------------------- */
 int th_transpose2d(th_ctx *ctx, const float *d_in, float *d_out, int rows, int cols);      /* tensor.rs:544-566 */
 /* dst[r*dst_ld + c] = src[r*src_ld + c] for r < rows, c < cols: the strided block copies behind slice_channels /

@@ -158,6 +158,72 @@ def grouped_conv2d(O, x, weight, bias, groups, stride=(1, 1), padding=(0, 0), re
     return cat(outs, 1)
 
 
+# ---- src/tensor.rs:2110-2288: the PTQ storage codecs that do real work (int8, f16) ------------------------------------
+def f32_to_f16_bits(x):
+    """tensor.rs:2191-2238, vectorised over a float32 array -> uint16: round half UP on the dropped 13 bits, the mantissa
+    carry OR-ed into the exponent field, truncating denormals, overflow -> inf, |x| < 2^-25 -> 0"""
+    bits = np.asarray(x, f32).reshape(-1).view(np.uint32).astype(np.uint64)
+    sign, exponent, mantissa = (bits >> 31) & 1, (bits >> 23) & 0xFF, bits & 0x7FFFFF
+    e16 = exponent.astype(np.int64) - 127 + 15
+    out = np.zeros(bits.shape, np.uint64)
+    special = exponent == 0xFF
+    zero = (exponent == 0) & (mantissa == 0)
+    over = ~special & ~zero & (e16 >= 0x1F)
+    under = ~special & ~zero & (e16 <= 0)
+    tiny = under & (e16 < -10)
+    den = under & ~tiny
+    normal = ~special & ~zero & ~over & ~under
+    out[special] = (sign[special] << 15) | (0x1F << 10) | np.where(mantissa[special] != 0, 0x200, 0).astype(np.uint64)
+    out[zero | tiny] = sign[zero | tiny] << 15
+    out[over] = (sign[over] << 15) | (0x1F << 10)
+    shift = (1 - e16[den] + 13).astype(np.uint64)
+    out[den] = (sign[den] << 15) | ((mantissa[den] | 0x800000) >> shift)
+    out[normal] = (sign[normal] << 15) | (e16[normal].astype(np.uint64) << 10) | ((mantissa[normal] + 0x1000) >> 13)
+    return (out & 0xFFFF).astype(np.uint16).reshape(np.asarray(x).shape)
+
+
+def f16_bits_to_f32(h):
+    """tensor.rs:2241-2287 on a uint16 array -> float32"""
+    bits = np.asarray(h, np.uint16).reshape(-1).astype(np.uint32)
+    sign, exponent, mantissa = (bits >> 15) & 1, (bits >> 10) & 0x1F, bits & 0x3FF
+    out = np.zeros(bits.shape, np.uint32)
+    special = exponent == 0x1F
+    out[special] = (sign[special] << 31) | (0xFF << 23) | np.where(mantissa[special] != 0, mantissa[special] << 13, 0)
+    zero = (exponent == 0) & (mantissa == 0)
+    out[zero] = sign[zero] << 31
+    den = (exponent == 0) & (mantissa != 0)
+    for i in np.nonzero(den)[0]:
+        exp, mant = -14, int(mantissa[i])
+        while (mant & 0x400) == 0:
+            mant <<= 1
+            exp -= 1
+        out[i] = (int(sign[i]) << 31) | (((exp + 127) & 0xFF) << 23) | ((mant & 0x3FF) << 13)
+    normal = ~special & (exponent != 0)
+    out[normal] = (sign[normal] << 31) | (((exponent[normal] + 127 - 15) & 0xFF) << 23) | (mantissa[normal] << 13)
+    return out.view(f32).reshape(np.asarray(h).shape)
+
+
+def quantize_int8(x):
+    """tensor.rs:2110-2152 -> (q int8, scale, zero_point, min_val)"""
+    x = np.asarray(x, f32).reshape(-1)
+    fin = x[np.isfinite(x)]
+    mn, mx = (f32(fin.min()), f32(fin.max())) if fin.size else (f32(np.inf), f32(-np.inf))
+    if mn == mx:
+        mn, mx = f32(mn - f32(0.1)), f32(mx + f32(0.1))
+    with np.errstate(all="ignore"):
+        scale = f32(f32(mx - mn) / f32(255.0))
+        t = ((x - mn).astype(f32) / scale).astype(f32)
+        r = np.where(np.isnan(t), f32(0), np.sign(t) * np.floor(np.abs(t) + f32(0.5)))          # f32::round: half away from zero
+        r = np.clip(np.nan_to_num(r, nan=0.0, posinf=2147483647.0, neginf=-2147483648.0), -2147483648.0, 2147483647.0).astype(np.int64)   # `as i32`
+    q = np.clip(r - 128, -128, 127).astype(np.int8)
+    return q, float(scale), -128, float(mn)
+
+
+def dequantize_int8(q, scale, zero_point, min_val):
+    """tensor.rs:353-360"""
+    return ((np.asarray(q, np.int8).astype(np.int32) - zero_point).astype(f32) * f32(scale)).astype(f32) + f32(min_val)
+
+
 # ---- src/train.rs -----------------------------------------------------------------------------------
 def format_f32_display(v) -> str:
     """Rust `{}` for f32 (train.rs:283-285 `writeln!(file, "{}", value)`): shortest digits that

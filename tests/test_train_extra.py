@@ -383,3 +383,81 @@ def test_xor_example_learns_xor():
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "iteration    0: Loss = " in out.stdout and "learned XOR" in out.stdout
+
+
+# ---- PTQ storage codecs (src/tensor.rs:2110-2288) ------------------------------------------------------------------
+def _codec_inputs():
+    rng = np.random.default_rng(77)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65520.0, 70000.0, -70000.0, 6.1e-5, 6.0e-5, 5.96e-8, 2.9e-8, 1e-10, np.inf, -np.inf,
+                        np.nan, 1.0009765625, 1.00048828125, 1.000732421875, 2047.5, 2047.75, 0.333333343, 3.14159274], np.float32)
+    # values just below a power of two: the half-up rounding carries out of the mantissa (the OR-ed carry quirk)
+    carry = np.array([1.9998779296875, 3.99993896484375, 0.99993896484375, 1023.99993896484375], np.float32)
+    return np.concatenate([special, carry, rng.standard_normal(5000).astype(np.float32) * 10, rng.uniform(-7e4, 7e4, 2000).astype(np.float32),
+                           (rng.standard_normal(2000) * 1e-5).astype(np.float32)])
+
+
+def test_f16_codec_oracle_against_numpy_half():
+    """the restatement agrees with IEEE round-to-nearest-even wherever the reference's half-up / truncating shortcuts do
+    (everything but exact ties, denormal results and mantissa carries), and round-trips every half exactly"""
+    x = _codec_inputs()
+    h = OX.f32_to_f16_bits(x)
+    fin = np.isfinite(x) & (np.abs(x) >= 6.2e-5) & (np.abs(x) < 65504)
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).view(np.uint16)
+    low13 = x.view(np.uint32) & 0x1FFF
+    carry = ((x.view(np.uint32) & 0x7FFFFF) + 0x1000) >> 23 != 0
+    plain = fin & (low13 != 0x1000) & ~carry
+    np.testing.assert_array_equal(h[plain], ref[plain])
+    allh = np.arange(65536, dtype=np.uint16)
+    back = OX.f16_bits_to_f32(allh)
+    ieee = allh.view(np.float16).astype(np.float32)
+    nan = np.isnan(ieee)
+    np.testing.assert_array_equal(back[~nan].view(np.uint32), ieee[~nan].view(np.uint32))     # every non-NaN half decodes exactly
+    assert np.isnan(back[nan]).all()
+    # the quirk: 1.99988 rounds up out of the mantissa; the carry (0x400) is OR-ed into exponent field 15 << 10, where that bit is
+    # already set -> the result is 0x3C00 = 1.0 instead of 2.0 (tensor.rs:2234-2237)
+    assert OX.f32_to_f16_bits(np.float32(1.9998779296875)) == 0x3C00
+    assert OX.f32_to_f16_bits(np.float32(3.99993896484375)) == 0x4400              # exponent 16: bit 10 clear, the OR happens to carry correctly
+    normals = allh[((allh >> 10) & 0x1F != 0) & ((allh >> 10) & 0x1F != 0x1F)]
+    np.testing.assert_array_equal(OX.f32_to_f16_bits(OX.f16_bits_to_f32(normals)), normals)  # exact halves survive the round trip
+
+
+def test_int8_codec_oracle_properties():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(4000).astype(np.float32) * 3
+    q, scale, zp, mn = OX.quantize_int8(x)
+    assert zp == -128 and q.min() == -128 and q.max() == 127 and mn == pytest.approx(float(x.min()))
+    assert scale == pytest.approx((float(x.max()) - float(x.min())) / 255, rel=1e-6)
+    assert np.abs(OX.dequantize_int8(q, scale, zp, mn) - x).max() <= scale * 0.5001
+    q2, s2, _, m2 = OX.quantize_int8(np.full(7, 2.5, np.float32))                       # constant tensor: range widened by 0.1 either way
+    assert m2 == pytest.approx(2.4) and s2 == pytest.approx(0.2 / 255, rel=1e-5) and (q2 == q2[0]).all()
+
+
+@gpu
+def test_ptq_codecs_match_oracle_bit_for_bit():
+    from taper_amd import hip
+    ctx = hip.Ctx(0)
+    x = _codec_inputs()
+    n = x.size
+    h = ctx.empty((n + 1) // 2)                                                          # n uint16 in float-sized storage
+    ctx.call("th_f32_to_f16", ctx.upload(x), h, n)
+    hb = ctx.download(h, ((n + 1) // 2,), np.float32).view(np.uint16)[:n]
+    np.testing.assert_array_equal(hb, OX.f32_to_f16_bits(x))
+    allh = np.arange(65536, dtype=np.uint16)
+    back = ctx.empty(65536)
+    ctx.call("th_f16_to_f32", ctx.upload(allh.view(np.float32)), back, 65536)
+    got, ref = ctx.download(back, (65536,)), OX.f16_bits_to_f32(allh)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    for data in (x[np.isfinite(x)], x, np.full(9, -1.25, np.float32), (np.random.default_rng(3).standard_normal(100000) * 4).astype(np.float32)):
+        m = data.size
+        q, params = ctx.empty((m + 3) // 4), ctx.empty(2)
+        ctx.call("th_quantize_int8", ctx.upload(data), q, m, params)
+        qb = ctx.download(q, ((m + 3) // 4,), np.float32).view(np.int8)[:m]
+        mn, scale = ctx.download(params, (2,))
+        rq, rs, rzp, rmn = OX.quantize_int8(data)
+        assert float(mn) == rmn and float(scale) == rs
+        np.testing.assert_array_equal(qb, rq)
+        y = ctx.empty(m)
+        ctx.call("th_dequantize_int8", q, y, m, float(scale), -128, float(mn))
+        np.testing.assert_array_equal(ctx.download(y, (m,)).view(np.uint32), OX.dequantize_int8(rq, rs, rzp, rmn).view(np.uint32))
+    ctx.close()
