@@ -353,3 +353,25 @@ def test_tail_path_edge_models_match_oracle(case):
         np.testing.assert_allclose(ep["losses"], ref, rtol=3e-4, atol=1e-5, err_msg=f"epoch {epoch}")
     for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
         np.testing.assert_allclose(hp.data(), op.data(), rtol=1e-4, atol=2e-5, err_msg=f"param {i}")
+
+
+@pytest.mark.parametrize("model_name,batch,shape", [("mlp_baseline", 64, None), ("mlp_example", 256, None), ("cnn_simple", 32, (1, 28, 28))])
+def test_graph_path_is_deterministic(model_name, batch, shape):
+    """no atomics anywhere on the path (fixed-order reductions, slot sums): two runs from the same weights and batches
+    give bit-identical per-step losses and weights"""
+    import taper_amd as T
+    H = backends.get("hip")
+    rng = np.random.default_rng(99)
+    spec = backends.nonzero_biases(getattr(backends, model_name)(rng), rng)
+    n = 5 * batch + 7
+    x, y = backends.mnist_like(rng, n)
+    runs = []
+    for _ in range(2):
+        model = H.sequential(spec)
+        tr = T.Trainer(model, T.Adam(model.parameters(), 1e-3, None, None, 1e-4), sample_shape=shape)
+        loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, True, seed=5)
+        losses = [np.asarray(tr.run_epoch(loader, T.Trainer.GRAPH)["losses"], np.float32) for _ in range(2)]
+        runs.append((np.concatenate(losses), [np.asarray(p.data(), np.float32) for p in model.parameters()]))
+    np.testing.assert_array_equal(runs[0][0].view(np.uint32), runs[1][0].view(np.uint32))
+    for a, b in zip(runs[0][1], runs[1][1]):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
