@@ -8,7 +8,7 @@ from taper_amd import hip
 variant = sys.argv[1]
 ctx = hip.Ctx(0)
 sk = StepKernels(ctx, 64)
-ks = [sk._k1, sk._k2, sk._k3]
+ks = [sk._k1, sk._k2]
 if variant == "k1only":
     ks = [sk._k1]
 if variant == "k2only":

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel share of the MLP step, measured IN SITU: the step's three launches
-(layer-1 forward, fused head, layer-1 backward + Adam) are replayed as hipGraph chains with and without
+"""Per-kernel share of the MLP step, measured IN SITU: the step's two launches
+(layer-1 forward + carried updates + tick, fused head + layer-1 backward + Adam) are replayed as hipGraph chains with and without
 each launch (bench.StepKernels.measure), so every kernel keeps the data flow of
 the real step (operands freshly written by the previous launch)."""
 import argparse
