@@ -167,6 +167,18 @@ int th_linear_xent_head_masked(th_ctx *ctx, const float *d_h, const float *d_w, 
                                int64_t *d_state, int64_t advance, int32_t *d_adam_tick, const th_adam_fuse *w_fuse,
                                const th_adam_fuse *b_fuse, int mask_dh_by_h);
 
+/* ---- classifier head on a WIDE input (in_features > 256: a CNN's Linear on the flattened feature map) ---- */
+/* logits = X[B,in] . W[C,in]^T + b, the loss / accuracy count / step log / Adam tick of th_softmax_xent_fwd and the
+ * backward products for an upstream gradient of exactly 1 -- d_dx[B,in] = dlogits . W (nullable), d_dw[C,in] =
+ * dlogits^T . X, d_db[C] = colsum(dlogits) (nullable), all overwritten -- in TWO launches (K slices of the logits;
+ * then one kernel whose workgroups each own 32 input columns and recompute the softmax of every 16-row block in
+ * registers) instead of forward + slice reduce + loss + backward.  No parameter is updated: W is read by every
+ * workgroup, so its Adam update is the caller's (th_adam_slice / th_adam_step).  batch <= 4096, classes <= 16. */
+int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets,
+                        int batch, int in_features, int classes, float *d_loss, float *d_ncorrect,
+                        float *d_dx, float *d_dw, float *d_db, float *d_metrics, int64_t metrics_capacity,
+                        int64_t *d_state, int64_t advance, int32_t *d_adam_tick);
+
 /* ---- fused MLP tail: classifier head + the backward of the hidden layer ---- */
 /* For  ... -> H = relu(X . W1^T + b1) -> logits = H . W2^T + b2 -> cross-entropy
  * ONE launch computes what th_linear_xent_head followed by

@@ -691,6 +691,30 @@ int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, co
     return 3;
 }
 
+// First half of th_linear_xent_wide: the K slices of logits = X . W^T (no bias, no reduce) into a pool workspace
+// partial[kz][m*n]; the caller's kernel adds the slices in order and frees the workspace.
+int linear_fwd_partials(th_ctx *ctx, const float *x, const float *w, int m, int n, int k, float **partial_out, int *kz_out) {
+    const int tiles_m = ceil_div(m, 16), tiles_n = ceil_div(n, 16);
+    const long tiles = (long)tiles_m * tiles_n;
+    SmallArgs p{x, nullptr, w, nullptr, nullptr, m, n, k, k, 1, 1, k, 0, 0, 0, make_ep(1.0f, 0.0f)};
+    p.a_vec = aligned16(x) && (k % 4 == 0);
+    p.b_vec = aligned16(w) && (k % 4 == 0);
+    int kz = (int)std::min<long>((256 + tiles - 1) / tiles, k / 512);
+    if (kz < 1) kz = 1;
+    const int kslice = (ceil_div(k, kz) + 15) / 16 * 16;
+    kz = ceil_div(k, kslice);
+    p.kslice = kslice;
+    void *ws = nullptr;
+    if (th_malloc(ctx, (size_t)kz * m * n * sizeof(float), &ws)) return 1;
+    p.partial = (float *)ws;
+    if (tiles < 256 && k >= 256) hipLaunchKernelGGL((sgemm_small16<true, true, 16>), dim3(tiles_n, tiles_m, kz), dim3(1024), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((sgemm_small16<true, true, 4>), dim3(tiles_n, tiles_m, kz), dim3(256), 0, ctx->stream, p);
+    TH_LAUNCH_CHECK();
+    *partial_out = p.partial;
+    *kz_out = kz;
+    return 0;
+}
+
 }  // namespace th
 
 using namespace th;

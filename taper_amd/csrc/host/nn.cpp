@@ -147,6 +147,57 @@ Tensor linear_cross_entropy(const Tensor &h, const Tensor &w, const Tensor &bias
     return loss;
 }
 
+bool linear_cross_entropy_wide_supported(const Tensor &h, const Tensor &w, const Tensor &bias) {
+    if (h.shape().size() != 2 || w.shape().size() != 2 || h.shape()[1] != w.shape()[1]) return false;
+    if (w.shape()[1] <= 256 || w.shape()[0] > 16 || h.shape()[0] < 1 || h.shape()[0] > 4096) return false;
+    if (!w.get_requires_grad() || w.has_grad()) return false;
+    if (bias.defined() && (!bias.get_requires_grad() || bias.has_grad())) return false;
+    return !(h.get_requires_grad() && (h.has_grad() || h.grad_->buf_is_arena));   // dX is written, never accumulated
+}
+
+Tensor linear_cross_entropy_wide(const Tensor &h, const Tensor &w, const Tensor &bias, const Tensor &targets, Tensor *n_correct_out,
+                                 const StepLogSink *log) {   // nn.rs:54-60 + loss.rs:136-195 + the Linear's backward closures
+    TAPER_ASSERT(linear_cross_entropy_wide_supported(h, w, bias), "linear_cross_entropy_wide: unsupported shapes / gradient state");
+    TAPER_ASSERT(targets.shape()[0] == h.shape()[0], "Batch sizes must match");
+    const int b = (int)h.shape()[0], k = (int)h.shape()[1], c = (int)w.shape()[0];
+    Tensor loss = Tensor::empty({1});
+    float *nc = nullptr;
+    if (n_correct_out) {
+        *n_correct_out = Tensor::empty({1});
+        nc = n_correct_out->dptr();
+    }
+    auto slot = [](const Tensor &p) -> float * {
+        if (!p.defined()) return nullptr;
+        if (!p.grad_->buf) p.grad_->buf = Buffer::alloc(p.len());
+        p.grad_->known_zero = false;
+        return p.grad_->buf->d;
+    };
+    float *dw = slot(w), *db = slot(bias);
+    std::shared_ptr<Buffer> dh = h.get_requires_grad() ? Buffer::alloc(h.len()) : nullptr;
+    TH(th_linear_xent_wide(Device::ctx(), h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, loss.dptr(),
+                           nc, dh ? dh->d : nullptr, dw, db, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                           log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr));
+    if (Adam *fa = FusedAdamScope::active()) {   // complete gradients; every workgroup of the launch read W
+        fa->defer_for(w);
+        if (bias.defined()) fa->defer_for(bias);
+    }
+    loss.set_requires_grad(true);
+    Tensor hh = h, ww = w, bb = bias, out = loss;
+    Tape::push(loss, true, [hh, ww, bb, out, dh]() {
+        if (!out.has_grad()) return;
+        TAPER_ASSERT(out.grad_->shared_const, "linear_cross_entropy_wide: only loss.backward() from the root is supported");
+        if (dh) {
+            TAPER_ASSERT(!hh.has_grad() && !hh.grad_->buf_is_arena, "linear_cross_entropy_wide: input already has a gradient");
+            hh.grad_->buf = dh;
+            hh.grad_->has = true;
+            hh.grad_->shared_const = false;
+        }
+        ww.grad_->has = true;
+        if (bb.defined()) bb.grad_->has = true;
+    });
+    return loss;
+}
+
 bool mlp_tail_supported(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2) {
     if (x.shape().size() != 2 || w1.shape().size() != 2 || w2.shape().size() != 2) return false;
     if (x.shape()[1] != w1.shape()[1] || w2.shape()[1] != w1.shape()[0]) return false;
@@ -839,6 +890,8 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
             if (linear_cross_entropy_supported(h, last->weight) && !last->weight.has_grad() &&
                 !(last->bias.defined() && last->bias.has_grad()))
                 loss = linear_cross_entropy(h, last->weight, last->bias, y, &ncorrect, &sink);
+            else if (fuse_head >= 2 && linear_cross_entropy_wide_supported(h, last->weight, last->bias))
+                loss = linear_cross_entropy_wide(h, last->weight, last->bias, y, &ncorrect, &sink);
             else
                 loss = cross_entropy_loss(last->forward(h), y, &ncorrect, &sink);
             used_head = true;

@@ -200,6 +200,11 @@ struct StepLogSink {
 bool linear_cross_entropy_supported(const Tensor &h, const Tensor &weight);
 Tensor linear_cross_entropy(const Tensor &h, const Tensor &weight, const Tensor &bias, const Tensor &targets,
                             Tensor *n_correct_out, const StepLogSink *log);
+// The same for a WIDE input (in_features > 256, classes <= 16, batch <= 4096): th_linear_xent_wide, two launches; W / b are
+// never updated in the launch (deferred like the head's).
+bool linear_cross_entropy_wide_supported(const Tensor &h, const Tensor &weight, const Tensor &bias);
+Tensor linear_cross_entropy_wide(const Tensor &h, const Tensor &weight, const Tensor &bias, const Tensor &targets,
+                                 Tensor *n_correct_out, const StepLogSink *log);
 // x -> relu(x . W1^T + b1) -> . W2^T + b2 -> cross-entropy as TWO launches: th_linear_fwd_ex (which also carries the
 // previous step's deferred Adam updates and opens this step) and th_mlp_tail (head + the hidden layer's whole
 // backward + its Adam update; with an input that requires a gradient also dX, whole tiles only).  Same contract as

@@ -1,0 +1,213 @@
+// wide_head.hip -- th_linear_xent_wide: the classifier head for a WIDE input (in_features > 256: the simple CNN's
+// Linear(3136, 10) on the flattened feature map) -- last Linear + softmax cross-entropy + every backward product of that
+// Linear (nn.rs:54-60, loss.rs:101-195, 271-290, ops.rs:238-294, tensor.rs:574-587, 674-694) in TWO launches instead of
+// five (forward, K-slice reduce, loss, backward, ...):
+//   launch 1  the K slices of logits = X . W^T                         (gemm.hip: linear_fwd_partials)
+//   launch 2  this kernel: a workgroup (16 waves) owns 32 input columns; each wave takes 16-row blocks of the batch:
+//             logits (slices added in order + bias) -> softmax / NLL / argmax / dlogits in registers (tail_row_softmax),
+//             dX[rows][its columns] = dl . W      A = dl[row r][class 4g+s] (= register s), B = W[class 4g+s][col r]
+//             dW[classes][its columns] += dl^T . X  A = dl^T through a wave-private LDS transpose, B = X[row 4g+s][col r]
+//             one extra "lead" workgroup: db, loss, hit count, the step log and Adam's t += 1.
+// No parameter is updated here (W is read by every workgroup's dX product): the caller defers W / b (th_adam_slice).
+#include "tail_dev.h"
+
+namespace th {
+
+int linear_fwd_partials(th_ctx *ctx, const float *x, const float *w, int m, int n, int k, float **partial_out, int *kz_out);   // gemm.hip
+
+struct WideArgs {
+    const float *x, *w, *bias, *targets, *partial;
+    int batch, k, c, kz;
+    float *loss, *ncorrect, *dx, *dw, *db;
+    float *metrics;
+    int64_t capacity;
+    int64_t *state;
+    int64_t advance;
+    int32_t *adam_tick;
+    int n_col;           // column blocks (32 columns each); block n_col is the lead
+};
+
+constexpr int WH_TX = 2;   // 16-column tiles per workgroup
+constexpr int WH_NW = 16;  // waves per workgroup: 256 rows per pass (the chunks of a batch are a serial chain per wave, so go wide)
+
+__global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
+    __shared__ float red[WH_NW][WH_TX][64][4];
+    __shared__ float tr[WH_NW][16][17];
+    __shared__ float rowv[WH_NW][2][16];
+    __shared__ float sc[WH_NW][20];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const bool lead = (int)blockIdx.x == a.n_col;
+    const int B = a.batch, K = a.k, C = a.c;
+    const int col0 = blockIdx.x * 16 * WH_TX;
+    const float inv_b = 1.0f / (float)B;
+    const long bc = (long)B * C;
+
+    // chunk-independent operands: W[class 4 g4 + s][col0 + 16 tx + r16], bias
+    float wv[WH_TX][4], b4[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int cls = min(g4 * 4 + s, C - 1);
+        b4[s] = a.bias ? a.bias[cls] : 0.f;
+#pragma unroll
+        for (int tx = 0; tx < WH_TX; ++tx) {
+            const int col = col0 + tx * 16 + r16;
+            wv[tx][s] = (!lead && g4 * 4 + s < C && col < K) ? a.w[(long)cls * K + col] : 0.f;
+        }
+    }
+    const int64_t state0 = (lead && a.metrics) ? a.state[0] : 0, state1 = (lead && a.metrics) ? a.state[1] : 0;
+    const int32_t tick_old = (lead && a.adam_tick) ? a.adam_tick[0] : 0;
+
+    floatx4 accw[WH_TX];
+#pragma unroll
+    for (int tx = 0; tx < WH_TX; ++tx) accw[tx] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float db_acc = 0.f, nll_acc = 0.f, hit_acc = 0.f;
+
+    for (int c0 = 0; c0 < B; c0 += 16 * WH_NW) {
+        const int r0 = c0 + wave * 16;
+        const bool rows_here = r0 < B;                 // wave-uniform
+        if (rows_here) {
+            const int row_a = r0 + r16, row_ac = min(row_a, B - 1);
+            const bool row_ok = row_a < B;
+            // logits of (row_a, classes 4 g4 ..): the K slices in slice order, then the bias (nn.rs:54-60)
+            float lg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cls = min(g4 * 4 + i, C - 1);
+                float sum = 0.f;
+                for (int z = 0; z < a.kz; ++z) sum += a.partial[(long)z * bc + (long)row_ac * C + cls];
+                lg[i] = (g4 * 4 + i < C) ? sum + b4[i] : -INFINITY;
+            }
+            const float tf = a.targets[row_ac];
+            float xv[WH_TX][4];                        // X[r0 + 4 g4 + s][col0 + 16 tx + r16]
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = r0 + g4 * 4 + s;
+#pragma unroll
+                for (int tx = 0; tx < WH_TX; ++tx) {
+                    const int col = col0 + tx * 16 + r16;
+                    xv[tx][s] = (!lead && row < B && col < K) ? a.x[(long)row * K + col] : 0.f;
+                }
+            }
+            float dl[4], nll_row;
+            int bi;
+            tail_row_softmax(lg, g4, C, tf, inv_b, dl, nll_row, bi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dl[i] = row_ok ? dl[i] : 0.f;
+
+            // wave-private transpose of dlogits: A operand of the dW product, column sums for db
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tr[wave][r16][g4 * 4 + i] = dl[i];
+            if (lead && g4 == 0) {
+                rowv[wave][0][r16] = row_ok ? nll_row : 0.f;
+                rowv[wave][1][r16] = (row_ok && fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;   // loss.rs:283
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!lead) {
+                // dX block (ops.rs:254-265): rows 4 g4 + i of this wave's block, columns r16 of each tile
+                if (a.dx) {
+#pragma unroll
+                    for (int tx = 0; tx < WH_TX; ++tx) {
+                        floatx4 ax = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) ax = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[s], wv[tx][s], ax, 0, 0, 0);
+                        const int col = col0 + tx * 16 + r16;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = r0 + g4 * 4 + i;
+                            if (row < B && col < K) a.dx[(long)row * K + col] = ax[i];
+                        }
+                    }
+                }
+                // dW tile (ops.rs:280-291 through the W^T node): A[class r16][row 4 g4 + s], B = X[row 4 g4 + s][col r16]
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float at = tr[wave][g4 * 4 + s][r16];
+#pragma unroll
+                    for (int tx = 0; tx < WH_TX; ++tx) accw[tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, xv[tx][s], accw[tx], 0, 0, 0);
+                }
+            } else {
+                float cs = 0.f, nl = 0.f, ht = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    cs += tr[wave][r][r16];
+                    nl += rowv[wave][0][r];
+                    ht += rowv[wave][1][r];
+                }
+                db_acc += cs;
+                nll_acc += nl;
+                hit_acc += ht;
+            }
+        }
+    }
+
+    if (!lead) {   // deterministic cross-wave sum; wave e finishes class 4 g4 + e
+#pragma unroll
+        for (int tx = 0; tx < WH_TX; ++tx)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][tx][lane][i] = accw[tx][i];
+        __syncthreads();
+        if (wave < 4) {
+            const int cls = g4 * 4 + wave;
+#pragma unroll
+            for (int tx = 0; tx < WH_TX; ++tx) {
+                const int col = col0 + tx * 16 + r16;
+                float sum = red[0][tx][lane][wave];
+#pragma unroll
+                for (int w = 1; w < WH_NW; ++w) sum += red[w][tx][lane][wave];
+                if (cls < C && col < K) a.dw[(long)cls * K + col] = sum;
+            }
+        }
+        return;
+    }
+    if (g4 == 0) sc[wave][r16] = db_acc;
+    if (lane == 0) {
+        sc[wave][16] = nll_acc;
+        sc[wave][17] = hit_acc;
+    }
+    __syncthreads();
+    if (a.db && t < C) {
+        float sum = sc[0][t];
+        for (int w = 1; w < WH_NW; ++w) sum += sc[w][t];
+        a.db[t] = sum;
+    }
+    if (t == 0) {
+        float n = sc[0][16], hsum = sc[0][17];
+        for (int w = 1; w < WH_NW; ++w) {
+            n += sc[w][16];
+            hsum += sc[w][17];
+        }
+        const float l = n / (float)B;   // loss.rs:164
+        a.loss[0] = l;
+        if (a.ncorrect) a.ncorrect[0] = hsum;
+        if (a.adam_tick) a.adam_tick[0] = tick_old + 1;   // optim.rs:84 (nobody else touches the counter in this launch)
+        if (a.metrics) {
+            const int64_t slot = state0 < a.capacity ? state0 : state0 % a.capacity;
+            a.metrics[2 * slot] = l;
+            a.metrics[2 * slot + 1] = hsum;
+            a.state[0] = state0 + 1;
+            a.state[1] = state1 + a.advance;
+        }
+    }
+}
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
+                                   int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db,
+                                   float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick) {
+    TH_REQUIRE(ctx && d_x && d_w && d_targets && d_loss && d_dw, "th_linear_xent_wide: null argument");
+    TH_REQUIRE(batch > 0 && batch <= 4096 && in_features > 0 && classes > 0 && classes <= 16,
+               "th_linear_xent_wide: needs batch <= 4096, classes <= 16 (got %d, %d)", batch, classes);
+    TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_linear_xent_wide: metrics need d_state and a capacity");
+    float *partial = nullptr;
+    int kz = 0;
+    if (int rc = linear_fwd_partials(ctx, d_x, d_w, batch, classes, in_features, &partial, &kz)) return rc;
+    WideArgs a{d_x, d_w, d_bias, d_targets, partial, batch, in_features, classes, kz, d_loss, d_ncorrect, d_dx, d_dw, d_db,
+               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, ceil_div(in_features, 16 * WH_TX)};
+    hipLaunchKernelGGL(wide_head_kernel, dim3(a.n_col + 1), dim3(64 * WH_NW), 0, ctx->stream, a);
+    TH_LAUNCH_CHECK();
+    return th_free(ctx, partial);
+}

@@ -97,6 +97,36 @@ def test_linear_xent_head_masked(ctx, O, batch):
     close(ctx.download(dh_, (batch, k)), np.asarray(ref["dh"]).reshape(batch, k) * (h > 0))
 
 
+@pytest.mark.parametrize("batch,k,c", [(256, 3136, 10), (64, 300, 10), (100, 513, 7), (16, 260, 16), (300, 1000, 3), (1, 33, 2)])
+def test_linear_xent_wide(ctx, O, batch, k, c):
+    """the classifier head on a wide input (two launches: K slices of the logits, then softmax + every backward product)
+    against the oracle's Linear + cross_entropy_loss chain"""
+    rng = np.random.default_rng(batch + k + c)
+    h = np.maximum(rng.standard_normal((batch, k)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (c, k)) * np.sqrt(2.0 / k)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    ref = oracle_head(O, h, w, b, y)
+    dx_, dw_, db_ = ctx.empty(batch * k), ctx.empty(c * k), ctx.empty(c)
+    loss, nc = ctx.empty(1), ctx.empty(1)
+    state, metrics = ctx.upload(np.array([3, 100], np.int64)), ctx.zeros(2 * 16)
+    tick = ctx.upload(np.array([7, 0], np.int32))
+    wd = ctx.upload(w)
+    ctx.call("th_linear_xent_wide", ctx.upload(h), wd, ctx.upload(b), ctx.upload(y), batch, k, c, loss, nc, dx_, dw_, db_, metrics, 16,
+             state, batch, tick)
+    assert ctx.download(loss, 1)[0] == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
+    assert ctx.download(nc, 1)[0] == ref["ncorrect"]
+    close(ctx.download(dx_, (batch, k)), ref["dh"])
+    close(ctx.download(dw_, (c, k)), ref["dw"])
+    close(ctx.download(db_, c), ref["db"])
+    np.testing.assert_array_equal(ctx.download(state, 2, np.int64), [4, 100 + batch])
+    assert ctx.download(metrics, (16, 2))[3, 0] == ctx.download(loss, 1)[0]
+    assert ctx.download(tick, 2, np.int32)[0] == 8
+    np.testing.assert_array_equal(ctx.download(wd, w.shape), w)
+    ctx.call("th_linear_xent_wide", ctx.upload(h), wd, None, ctx.upload(y), batch, k, c, loss, None, None, dw_, None, None, 0, None, 0, None)
+    assert np.isfinite(ctx.download(loss, 1)[0])
+
+
 def test_head_limits_are_errors(ctx):
     from taper_amd._lib import TaperError
     x = ctx.zeros(64 * 300)
