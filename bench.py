@@ -158,7 +158,7 @@ class StepKernels:
         self.kernels = [
             ("sgemm_small16_tick<true, true, 16>", "K1 layer-1 forward (+bias, ReLU) + carried Adam(W2,b2) of the previous step + step counter",
              4 * (IN * B + HID * IN + HID + HID * B) + 28 * n2, 2 * B * IN * HID + 14 * n2),
-            ("mlp_tail_exact_kernel<8, 2, false>", "K2 head (Linear(128,10) + softmax-xent + dW2/db2 + step log) + layer-1 backward (dW1, db1) + Adam(W1,b1) epilogue",
+            ("mlp_tail_exact_kernel<8, 2, false, 4>", "K2 head (Linear(128,10) + softmax-xent + dW2/db2 + step log) + layer-1 backward (dW1, db1) + Adam(W1,b1) epilogue",
              4 * (IN * B + HID * B + B) + 8 * n2 + 4 * n1 + 24 * n1 + 16, 3 * 2 * B * HID * OUT + 2 * B * IN * HID + 14 * n1),
         ]
 

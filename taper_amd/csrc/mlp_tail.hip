@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void mlp_tail_kernel(TailArgs a) {
 //                                     -> lane (r,g) holds dH[row r][hid 16 th + 4g + i]; its ReLU mask is the
 //                                        H value the lane loaded for the logits (hv[th], component i)
 //   dX[row][in] += dHm . W1           A = dHm[row r][hid 16 th + 4g + s] (= register s), B = W1[hid 16 th + 4g + s][in r]
-template <int KS>
+template <int KS, int NW>
 __device__ __forceinline__ void tail_dx_role(const TailArgs &a, int rb) {
     constexpr unsigned HID = 16 * KS;
     constexpr int TX = 2, TH_BLK = KS < 8 ? KS : 8;
@@ -362,7 +362,7 @@ __device__ __forceinline__ void tail_dx_role(const TailArgs &a, int rb) {
     const int C = a.c, B = a.batch;
     const unsigned in_f = (unsigned)a.in_f;
     const int chunk = rb / a.xgroups, xg = rb - chunk * a.xgroups;
-    const int r0 = chunk * 64 + wave * 16;
+    const int r0 = chunk * 16 * NW + wave * 16;
     if (r0 >= B) return;                              // wave-uniform; this role has no barriers
     const unsigned col0 = xg * 16 * TX;
     bool tx_ok[TX];
@@ -438,13 +438,15 @@ __device__ __forceinline__ void tail_dx_role(const TailArgs &a, int rb) {
     }
 }
 
-template <int KS, int TN, bool HAS_DX>
-__global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
+// NW waves per workgroup (4 / 8): the 64-row chunks of a batch are a serial chain per wave (2.7 us each), so batches
+// above 64 rows get more waves instead of more iterations; waves 0..3 finish the tile.
+template <int KS, int TN, bool HAS_DX, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_tail_exact_kernel(TailArgs a) {
     constexpr unsigned HID = 16 * KS;
-    __shared__ float red[4][TN][64][4];
-    __shared__ float tr[4][16][17];
-    __shared__ float rowv[4][2][16];
-    __shared__ float sc[4][36];
+    __shared__ float red[NW][TN][64][4];
+    __shared__ float tr[NW][16][17];
+    __shared__ float rowv[NW][2][16];
+    __shared__ float sc[NW][36];
     // ONE batch of scalar loads for the kernel arguments (left alone the compiler sinks each field's s_load into the block
     // that first uses it, and every later batch has to wait out whatever scalar loads are in flight with it)
     asm volatile("" ::"s"(a.x), "s"(a.h), "s"(a.w2), "s"(a.b2), "s"(a.targets), "s"(a.batch), "s"(a.in_f), "s"(a.c), "s"(a.dw1),
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     const int bid = blockIdx.x;
     TAIL_STAMP(0);
     if (HAS_DX && bid >= a.n_head + a.n_dw) {   // (its own instantiation: the code of a role nobody runs still costs instruction fetches)
-        tail_dx_role<KS>(a, bid - a.n_head - a.n_dw);
+        tail_dx_role<KS, NW>(a, bid - a.n_head - a.n_dw);
         return;
     }
     const bool head_role = bid < a.n_head;
@@ -500,11 +502,12 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     // epilogue operands: wave e finishes element e of every lane's C/D quad (row 4 g4 + e of the tile)
     const unsigned e_off = ((tile_m * 16 + g4 * 4 + wave) * in_f + col0 + r16) * 4u;
     const bool fuse_w = !head_role && any_w;
+    const bool finisher = NW == 4 || wave < 4;      // waves 0..3 finish element `wave` of every C/D quad
     float e_p[TN], e_m[TN], e_v[TN], w_step = 0.f, b_step = 0.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         e_p[tn] = e_m[tn] = e_v[tn] = 0.f;
-        if (fuse_w && tn_ok[tn]) {
+        if (fuse_w && tn_ok[tn] && finisher) {
             e_p[tn] = ldg_b(a.w1_adam.p, e_off + tn * 64);
             e_m[tn] = ldg_b(a.w1_adam.m, e_off + tn * 64);
             e_v[tn] = ldg_b(a.w1_adam.v, e_off + tn * 64);
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
                 }
             }
         }
-        c0 += 64;
+        c0 += 16 * NW;
         if (c0 >= B) break;
         load_chunk(c0);
     }
@@ -637,8 +640,10 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
         TAIL_STAMP(6);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            if (!tn_ok[tn]) continue;
-            const float out = ((red[0][tn][lane][wave] + red[1][tn][lane][wave]) + red[2][tn][lane][wave]) + red[3][tn][lane][wave];
+            if (!tn_ok[tn] || !finisher) continue;
+            float out = red[0][tn][lane][wave];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) out += red[w][tn][lane][wave];
             *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dw1) + e_off + tn * 64) = out;
             if (fuse_w) {
                 const AdamDev &ad = a.w1_adam;
@@ -665,13 +670,17 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
     }
     __syncthreads();
     TAIL_STAMP(6);
-    if (a.dw2) {   // wave e: class 4 g4 + e
+    if (a.dw2 && (NW == 4 || wave < 4)) {   // wave e: class 4 g4 + e
         const int cls = g4 * 4 + wave;
-        if (cls < C)
-            a.dw2[cls * HID + hcol] = ((red[0][0][lane][wave] + red[1][0][lane][wave]) + red[2][0][lane][wave]) + red[3][0][lane][wave];
+        float sum = red[0][0][lane][wave];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sum += red[w][0][lane][wave];
+        if (cls < C) a.dw2[cls * HID + hcol] = sum;
     }
     if (a.db1 && t < 16) {
-        const float out = ((sc[0][t] + sc[1][t]) + sc[2][t]) + sc[3][t];
+        float out = sc[0][t];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) out += sc[w][t];
         const int ix = tile_m * 16 + t;
         a.db1[ix] = out;
         if (fuse_b1) {
@@ -685,10 +694,19 @@ __global__ __launch_bounds__(256) void mlp_tail_exact_kernel(TailArgs a) {
         }
     }
     if (lead) {
-        if (a.db2 && t < C) a.db2[t] = ((sc[0][16 + t] + sc[1][16 + t]) + sc[2][16 + t]) + sc[3][16 + t];
+        if (a.db2 && t < C) {
+            float sum = sc[0][16 + t];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sum += sc[w][16 + t];
+            a.db2[t] = sum;
+        }
         if (t == 0) {
-            const float n = ((sc[0][32] + sc[1][32]) + sc[2][32]) + sc[3][32];
-            const float hsum = ((sc[0][33] + sc[1][33]) + sc[2][33]) + sc[3][33];
+            float n = sc[0][32], hsum = sc[0][33];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                n += sc[w][32];
+                hsum += sc[w][33];
+            }
             const float l = n / (float)B;   // loss.rs:164
             a.loss[0] = l;
             if (a.ncorrect) a.ncorrect[0] = hsum;
@@ -751,14 +769,21 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
     a.w1 = d_w1;
     a.dx = d_dx;
     a.xgroups = ceil_div(in_features, 32);
-    const int grid = a.n_dw + a.n_head + (d_dx ? a.xgroups * ceil_div(batch, 64) : 0);
+    // waves per workgroup of the whole-tile kernel: one 16-row block per wave and pass -- 4 up to 64 rows, 8 above (16 waves need
+    // <= 128 VGPRs: spills, and measured no better); TAPER_TAIL_NW = 4 | 8 forces a count (measurement probe)
+    static const int nw_env = getenv("TAPER_TAIL_NW") ? atoi(getenv("TAPER_TAIL_NW")) : 0;
+    const int nw_eff = (nw_env == 4 || nw_env == 8) ? nw_env : (batch <= 64 ? 4 : 8);
+    const int nw = nw_eff;
+    const int grid = a.n_dw + a.n_head + (d_dx ? a.xgroups * ceil_div(batch, 16 * nw_eff) : 0);
     // whole tiles everywhere (the MNIST MLP: 784-128-10, batches of 64 / 32): the short-instruction-stream kernel
     const bool exact = tail_whole_tiles(batch, in_features, hidden) &&
                        (d_dx || !(getenv("TAPER_TAIL_GENERAL") && getenv("TAPER_TAIL_GENERAL")[0] == '1'));
 #define TH_TAIL_LAUNCH(KS, TN)                                                                                        \
     do {                                                                                                              \
-        if (exact && d_dx) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, true>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
-        else if (exact) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, false>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
+        if (exact && d_dx && nw == 8) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, true, 8>), dim3(grid), dim3(512), 0, ctx->stream, a);     \
+        else if (exact && d_dx) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, true, 4>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
+        else if (exact && nw == 8) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, false, 8>), dim3(grid), dim3(512), 0, ctx->stream, a);     \
+        else if (exact) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, false, 4>), dim3(grid), dim3(256), 0, ctx->stream, a);     \
         else hipLaunchKernelGGL((mlp_tail_kernel<KS, TN>), dim3(grid), dim3(256), 0, ctx->stream, a);                 \
     } while (0)
 #define TH_TAIL_KS(TN)                          \
