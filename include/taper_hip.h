@@ -194,7 +194,8 @@ int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d_w, const f
  *   already be advanced for this step, e.g. by th_linear_fwd_ex).
  * Every workgroup recomputes the 16-row logits / softmax it needs in registers;
  * no dH buffer exists.  d_x[B,in] is the hidden layer's input, d_h[B,hid] its
- * post-ReLU output (16-byte aligned, like d_w2).  th_mlp_tail_supported: batch <= 256,
+ * post-ReLU output (16-byte aligned, like d_w2).  th_mlp_tail_supported: batch <= 512 (above, the chunks of a batch run
+ * as a serial chain per wave and the row-parallel kernels win),
  * hidden <= 256 and a multiple of 4, classes <= 16.
  * d_dx[B,in] (nullable; needs d_w1[hid,in]): additionally dX = dZ1 . W1 for a hidden layer
  * that is not the first (ops.rs:254-265), overwritten; whole tiles only (need_dx: hidden

@@ -77,7 +77,7 @@ Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n
 }
 
 bool linear_cross_entropy_supported(const Tensor &h, const Tensor &weight) {
-    // batch <= 256: one workgroup, one launch; above: up to 256 workgroups + a finish pass
+    // batch <= 64: one workgroup, one launch; above: up to 256 workgroups + a finish pass
     return h.shape().size() == 2 && weight.shape().size() == 2 && h.shape()[1] == weight.shape()[1] && weight.shape()[0] <= 16 &&
            weight.shape()[1] <= 256 && h.shape()[0] >= 1 && h.shape()[0] <= (1u << 22);
 }

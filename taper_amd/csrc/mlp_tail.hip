@@ -731,7 +731,7 @@ static bool tail_whole_tiles(int batch, int in_features, int hidden) {
 }
 
 extern "C" int th_mlp_tail_supported(int batch, int in_features, int hidden, int classes, int need_dx) {
-    const bool ok = batch > 0 && batch <= 256 && in_features > 0 && hidden > 0 && hidden <= 256 && (hidden % 4) == 0 && classes > 0 &&
+    const bool ok = batch > 0 && batch <= 512 && in_features > 0 && hidden > 0 && hidden <= 256 && (hidden % 4) == 0 && classes > 0 &&
                     classes <= 16;
     return ok && (!need_dx || tail_whole_tiles(batch, in_features, hidden));
 }
@@ -743,7 +743,7 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
                            const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse) {
     TH_REQUIRE(ctx && d_x && d_h && d_w2 && d_targets && d_loss && d_dw1, "th_mlp_tail: null argument");
     TH_REQUIRE(th_mlp_tail_supported(batch, in_features, hidden, classes, 0),
-               "th_mlp_tail: needs batch <= 256, hidden <= 256 and a multiple of 4, classes <= 16 (got %d, %d, %d)", batch, hidden, classes);
+               "th_mlp_tail: needs batch <= 512, hidden <= 256 and a multiple of 4, classes <= 16 (got %d, %d, %d)", batch, hidden, classes);
     TH_REQUIRE(!d_dx || (d_w1 && tail_whole_tiles(batch, in_features, hidden)),
                "th_mlp_tail: d_dx needs d_w1 and whole tiles (hidden 32 / 64 / 128 / 256, batch and in_features multiples of 16)");
     TH_REQUIRE(!d_dx || !(w1_fuse && w1_fuse->d_p), "th_mlp_tail: with d_dx the launch reads W1, its update must be deferred (th_adam_slice)");

@@ -48,7 +48,7 @@ def oracle_tail(O, x, w1, b1, w2, b2, y):
 
 SHAPES = [(64, 784, 128, 10), (32, 784, 128, 10), (128, 784, 128, 10), (1, 5, 4, 2), (70, 37, 20, 5), (256, 100, 256, 16),
           (200, 50, 64, 10), (17, 784, 36, 3),
-          (256, 784, 128, 10), (192, 64, 64, 10), (48, 784, 128, 10), (16, 16, 256, 16), (240, 48, 256, 3), (64, 64, 32, 10)]   # whole tiles, several / partial chunks
+          (256, 784, 128, 10), (192, 64, 64, 10), (48, 784, 128, 10), (16, 16, 256, 16), (240, 48, 256, 3), (64, 64, 32, 10), (512, 784, 128, 10), (400, 48, 64, 5), (300, 33, 20, 4)]   # whole tiles, several / partial chunks
 
 
 @pytest.mark.parametrize("batch,inf,hid,c", SHAPES)
@@ -142,8 +142,8 @@ def test_mlp_tail_optional_outputs_and_limits(ctx):
     ctx.call("th_mlp_tail", ctx.upload(x), ctx.upload(h), ctx.upload(w2), None, ctx.upload(y), 8, 20, 16, 3, loss, None, dw1, None,
              None, None, None, None, None, 0, None, 0, None, None)
     assert np.isfinite(ctx.download(loss, 1)[0])
-    z = ctx.zeros(1024 * 300)
-    for shape, pat in [((300, 8, 16, 3), "batch <= 256"), ((8, 8, 300, 3), "hidden <= 256"), ((8, 8, 18, 3), "multiple of 4"),
+    z = ctx.zeros(1024 * 600)
+    for shape, pat in [((600, 8, 16, 3), "batch <= 512"), ((8, 8, 300, 3), "hidden <= 256"), ((8, 8, 18, 3), "multiple of 4"),
                        ((8, 8, 16, 17), "classes <= 16")]:
         with pytest.raises(TaperError, match=pat):
             ctx.call("th_mlp_tail", z, z, z, None, z, *shape, z, None, z, None, None, None, None, None, None, 0, None, 0, None, None)
