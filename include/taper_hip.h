@@ -334,6 +334,11 @@ int th_bias_grad_nchw_masked(th_ctx *ctx, const float *d_gout, const float *d_ma
  * and counts where d_mask_y[b][ch][.] > 0.  db[ch] (+)= sum over the batch and the plane. */
 int th_bias_grad_avgpool_masked(th_ctx *ctx, const float *d_gout_pooled, const float *d_mask_y, float *d_gb, int n, int c, int hw,
                                 int accumulate);
+/* either form as the LAST backward launch of a fused step: one workgroup per channel, gradient overwritten (grad slot was None),
+ * the bias's Adam update in the epilogue (b_fuse nullable) and up to TH_MAX_ADAM_SLICES deferred updates of other parameters
+ * carried in spare workgroups (extra nullable) -- the step then needs no optimizer launch.  pooled_avg: d_gout is [n][c]. */
+int th_bias_grad_masked_adam(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw,
+                             int pooled_avg, const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra);
 /* full_backward extension (not in the reference: Q2 cuts these gradients) */
 int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx,
                          int n, int c_in, int h, int w, int c_out, int pad, int weight_layout); /* gx += */

@@ -13,7 +13,7 @@
 // is wave-uniform and is served by scalar loads (s_load_dwordx*), leaving the
 // LDS pipe to the input taps only.  The im2col buffer of the reference (up to
 // 231 MB at batch 256) is never materialised.
-#include "common.h"
+#include "adam_dev.h"
 
 namespace th {
 
@@ -597,6 +597,59 @@ __global__ __launch_bounds__(256) void bias_grad_avgpool_small_kernel(const floa
     }
 }
 
+// The bias gradient of a conv layer as the LAST backward launch of a fused training step: one 16-wave workgroup per channel
+// sums its (masked / pooled) plane gradients in a fixed order -- no slabs, no second launch -- and applies the bias's Adam
+// update (optim.rs:99-110) in place; the blocks behind the channels carry the deferred updates of other parameters
+// (th_adam_slice), so the step needs no optimizer launch at all.  mode 0: g is [n][c][hw]; 1: g is [n][c], the gradient of a
+// global average pool's output (every element of the plane receives g / hw, tensor.rs:1626-1628).
+__global__ __launch_bounds__(1024) void bias_grad_adam_kernel(const float *__restrict__ g, const float *__restrict__ mask,
+                                                              float *__restrict__ gb, int n, int c, int hw, int mode, AdamDev ad,
+                                                              AdamSlices extra) {
+    if ((int)blockIdx.x >= c) {
+        if (threadIdx.x < 256) adam_slices_block(extra, blockIdx.x - c);
+        return;
+    }
+    __shared__ float sh[16];
+    const int ch = blockIdx.x, t = threadIdx.x;
+    float pv = 0.f, mv = 0.f, vv = 0.f, step = 0.f;
+    if (t == 0 && ad.p) {   // requested before the sum, not after it
+        pv = ad.p[ch];
+        mv = ad.m[ch];
+        vv = ad.v[ch];
+        step = adam_dev_step(ad);
+    }
+    float s = 0.f;
+    const long total = (long)n * hw;
+    const int step_b = 1024 / hw, step_sp = 1024 % hw;   // (image, pixel) tracked incrementally: no division per element
+    int b = t / hw, sp = t % hw;
+    for (long i = t; i < total; i += 1024) {
+        const long ix = ((long)b * c + ch) * hw + sp;
+        const float v = mode ? g[(long)b * c + ch] / (float)hw : g[ix];
+        s += (mask && !(mask[ix] > 0.f)) ? 0.f : v;
+        sp += step_sp;
+        b += step_b;
+        if (sp >= hw) { sp -= hw; ++b; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((t & 63) == 0) sh[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) {
+        float tot = sh[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) tot += sh[w];
+        gb[ch] = tot;
+        if (ad.p) {
+            const float gv = tot + ad.wd * pv;
+            const float mn = ad.beta1 * mv + (1.0f - ad.beta1) * gv;
+            const float vn = ad.beta2 * vv + (1.0f - ad.beta2) * gv * gv;
+            ad.m[ch] = mn;
+            ad.v[ch] = vn;
+            ad.p[ch] = pv - step * mn / (sqrtf(vn) + ad.eps);
+        }
+    }
+}
+
 int bias_grad_launch(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw, int accumulate, int pooled) {
     TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
     if (c == 0) return 0;
@@ -884,6 +937,18 @@ int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int 
 
 int th_bias_grad_nchw_masked(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw, int accumulate) {
     return th::bias_grad_launch(ctx, d_gout, d_mask_y, d_gb, n, c, hw, accumulate, 0);
+}
+
+int th_bias_grad_masked_adam(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw, int pooled_avg,
+                             const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra) {
+    TH_REQUIRE(ctx && d_gout && d_gb && n > 0 && c > 0 && hw > 0, "th_bias_grad_masked_adam: null argument / empty tensor");
+    TH_REQUIRE(!pooled_avg || d_mask_y, "th_bias_grad_masked_adam: the average-pool form needs the conv output as mask");
+    TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_bias_grad_masked_adam: bad extra slices");
+    const AdamSlices x = make_adam_slices(extra, n_extra);
+    hipLaunchKernelGGL(bias_grad_adam_kernel, dim3(c + x.blocks()), dim3(1024), 0, ctx->stream, d_gout, d_mask_y, d_gb, n, c, hw,
+                       pooled_avg ? 1 : 0, make_adam_dev(b_fuse), x);
+    TH_LAUNCH_CHECK();
+    return 0;
 }
 
 int th_bias_grad_avgpool_masked(th_ctx *ctx, const float *d_gout_pooled, const float *d_mask_y, float *d_gb, int n, int c, int hw,

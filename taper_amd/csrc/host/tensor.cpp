@@ -740,6 +740,8 @@ std::pair<Tensor, Tensor> Tensor::max(int dim) const {  // tensor.rs:1021-1083 (
 Tensor Tensor::argmax(int dim) const { return max(dim).second; }
 
 // ---------------------------------------------------------------- conv / pool
+static void pooled_bias_grad(const Tensor &bias, const float *dy, const float *mask_y, int n, int c, int hw, bool avg);
+
 Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> stride, std::pair<int, int> padding,
                       std::pair<int, int> dilation, bool relu) const {  // tensor.rs:1221-1285 (+1379-1389)
     TAPER_ASSERT(shape_.size() == 4, "Input must be 4D: [N, C_in, H, W]");
@@ -781,12 +783,7 @@ Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> s
                 // the max-pool behind this layer left its OUTPUT's gradient: db = sum of the pooled gradients whose
                 // pooled value is > 0 (the one conv output each lands on, and that output's ReLU mask)
                 GradSlot &g = *r.grad_;
-                bool none;
-                float *db = b.grad_for_write(&none);
-                if (g.pooled_avg)
-                    TH(th_bias_grad_avgpool_masked(c, g.pooled_dy->d, g.pooled_y->d, db, g.pooled_n, g.pooled_c, g.pooled_hw, none ? 0 : 1));
-                else
-                    TH(th_bias_grad_nchw_masked(c, g.pooled_dy->d, g.pooled_y->d, db, g.pooled_n, g.pooled_c, g.pooled_hw, none ? 0 : 1));
+                pooled_bias_grad(b, g.pooled_dy->d, g.pooled_y->d, g.pooled_n, g.pooled_c, g.pooled_hw, g.pooled_avg);
                 g.pooled_dy.reset();
                 g.pooled_y.reset();
                 return;
@@ -812,6 +809,24 @@ Tensor Tensor::conv2d_relu(const Tensor &w, const Tensor &bias, std::pair<int, i
     return conv2d(w, bias, stride, padding, dilation, true);
 }
 
+// Bias gradient of a bias-only Conv2dReLU from pooled tensors (see GradSlot).  Inside a fused-update step it is the last backward
+// launch of the faithful CNNs: the bias's own Adam update and every deferred update still waiting ride in the same launch.
+static void pooled_bias_grad(const Tensor &bias, const float *dy, const float *mask_y, int n, int c, int hw, bool avg) {
+    th_ctx *ctx = Device::ctx();
+    bool none;
+    float *db = bias.grad_for_write(&none);
+    Adam *fa = FusedAdamScope::active();
+    th_adam_fuse bf{};
+    if (fa && none && fa->fuse_for(bias, &bf)) {
+        th_adam_slice carried[TH_MAX_ADAM_SLICES];
+        const int n_carried = fa->take_deferred(nullptr, carried);
+        TH(th_bias_grad_masked_adam(ctx, dy, mask_y, db, n, c, hw, avg ? 1 : 0, &bf, carried, n_carried));
+        return;
+    }
+    if (avg) TH(th_bias_grad_avgpool_masked(ctx, dy, mask_y, db, n, c, hw, none ? 0 : 1));
+    else TH(th_bias_grad_nchw_masked(ctx, dy, mask_y, db, n, c, hw, none ? 0 : 1));
+}
+
 bool Tensor::conv2d_relu_maxpool2_supported(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
     if (full_backward() || shape_.size() != 4 || w.shape_.size() != 4 || w.shape_[2] != 3 || w.shape_[3] != 3) return false;
     if (w.shape_[1] != shape_[1] || padding.first != padding.second) return false;
@@ -834,9 +849,7 @@ Tensor Tensor::conv2d_relu_maxpool2(const Tensor &w, const Tensor &bias, std::pa
         Tape::push(out, true, [b, r, n, c_out, hp, wp]() {
             if (!r.has_grad()) return;
             // every pooled gradient lands on exactly one conv output (tensor.rs:1496-1519) whose ReLU mask is "pooled value > 0"
-            bool none;
-            float *db = b.grad_for_write(&none);
-            TH(th_bias_grad_nchw_masked(Device::ctx(), r.grad_dptr(), r.dptr(), db, n, c_out, hp * wp, none ? 0 : 1));
+            pooled_bias_grad(b, r.grad_dptr(), r.dptr(), n, c_out, hp * wp, false);
         });
     }
     return out;

@@ -226,6 +226,49 @@ def test_deferred_adam_slices(ctx, O, carrier, sizes):
     assert ctx.download(tick, 2, np.int32)[0] == t
 
 
+@pytest.mark.parametrize("n,c,hw", [(256, 64, 49), (256, 32, 196), (6, 5, 9), (40, 128, 49), (300, 3, 1)])
+@pytest.mark.parametrize("pooled_avg", [0, 1])
+@pytest.mark.parametrize("carry", [(), (640, 10, 4099)])
+def test_bias_grad_masked_adam(ctx, O, n, c, hw, pooled_avg, carry):
+    """th_bias_grad_masked_adam: the bias gradient summed from the pool's tensors, Adam on the bias in the same workgroup,
+    other parameters' complete gradients updated by the launch's extra workgroups == numpy sums + oracle Adam"""
+    rng = np.random.default_rng(n + c + hw + pooled_avg + len(carry))
+    yp = np.maximum(rng.standard_normal((n, c, hw)), 0).astype(np.float32)
+    if pooled_avg:
+        g = (rng.standard_normal((n, c)) * 0.01).astype(np.float32)
+        gb = (g.astype(np.float64)[:, :, None] / hw * (yp > 0)).sum((0, 2))
+    else:
+        g = (rng.standard_normal((n, c, hw)) * 0.01).astype(np.float32)
+        gb = (g.astype(np.float64) * (yp > 0)).sum((0, 2))
+    lr, t = 1e-3, 4
+    b0 = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    b_ref, m_ref, _ = _adam_ref(O, b0, gb.astype(np.float32), lr, t)
+    tick, dlr = ctx.upload(np.array([t, 0], np.int32)), ctx.upload(np.array([lr], np.float32))
+    pb, mb, vb, out = ctx.upload(b0), ctx.zeros(c), ctx.zeros(c), ctx.empty(c)
+    bf = AdamFuse(int(pb), int(mb), int(vb), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4)
+    slices, refs, keep = (AdamSlice * max(len(carry), 1))(), [], []
+    for i, k in enumerate(carry):
+        p0 = rng.uniform(-0.1, 0.1, k).astype(np.float32)
+        gk = (rng.standard_normal(k) * 0.01).astype(np.float32)
+        refs.append(_adam_ref(O, p0, gk, lr, t))
+        bufs = [ctx.upload(p0), ctx.zeros(k), ctx.zeros(k), ctx.upload(gk)]
+        keep.append(bufs)
+        slices[i] = AdamSlice(int(bufs[3]), k, AdamFuse(int(bufs[0]), int(bufs[1]), int(bufs[2]), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4))
+    ctx.call("th_bias_grad_masked_adam", ctx.upload(g), ctx.upload(yp), out, n, c, hw, pooled_avg, C.byref(bf),
+             slices if carry else None, len(carry))
+    np.testing.assert_allclose(ctx.download(out, c), gb, rtol=1e-4, atol=1e-4 * float(np.abs(gb).max()) + 1e-7)
+    np.testing.assert_allclose(ctx.download(pb, c), b_ref, rtol=RTOL, atol=lr * 2e-2)
+    np.testing.assert_allclose(ctx.download(mb, c), m_ref.reshape(c), rtol=1e-3, atol=1e-8 + 1e-4 * float(np.abs(m_ref).max()))
+    for bufs, (p_ref, mk_ref, _), k in zip(keep, refs, carry):
+        np.testing.assert_allclose(ctx.download(bufs[0], (k,)), p_ref, rtol=RTOL, atol=lr * 2e-2)
+        np.testing.assert_allclose(ctx.download(bufs[1], (k,)), mk_ref.reshape(k), rtol=1e-3, atol=1e-8)
+    assert ctx.download(tick, 2, np.int32)[0] == t
+    # without a fuse descriptor the launch is the plain overwrite-form gradient
+    out2 = ctx.upload(np.full(c, 7.0, np.float32))
+    ctx.call("th_bias_grad_masked_adam", ctx.upload(g), ctx.upload(yp), out2, n, c, hw, pooled_avg, None, None, 0)
+    np.testing.assert_allclose(ctx.download(out2, c), gb, rtol=1e-4, atol=1e-4 * float(np.abs(gb).max()) + 1e-7)
+
+
 def test_carried_slice_must_not_alias_the_weight_read_for_dx(ctx):
     from taper_amd._lib import TaperError
     z = ctx.zeros(64 * 64)
