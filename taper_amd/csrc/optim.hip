@@ -26,13 +26,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
                                                    float *__restrict__ v, const int64_t *__restrict__ offsets,
                                                    const int32_t *__restrict__ has_grad, int n_tensors, int64_t total,
                                                    int32_t *t_state, const float *__restrict__ lr, float beta1, float beta2,
-                                                   float eps, float wd, int pre_ticked) {
+                                                   float eps, float wd, int pre_ticked, int vec_ok) {
     const int t = __hip_atomic_load(&t_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (pre_ticked ? 0 : 1);  // optim.rs:84
     const float step = adam_step_size(lr[0], beta1, beta2, t);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // four consecutive elements per thread (dwordx4 on all seven streams); a quad that straddles two tensors or the
+    // end of the arena goes element by element
+    const int64_t quads = (total + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
+        const int64_t i = q << 2;
         const int ti = find_tensor(offsets, n_tensors, i);
-        if (!has_grad[ti]) continue;  // grad None: skipped entirely (Q8)
-        adam_update(p, m, v, i, g[i], step, beta1, beta2, eps, wd);
+        if (vec_ok && i + 3 < total && (ti + 1 >= n_tensors || offsets[ti + 1] > i + 3)) {
+            if (!has_grad[ti]) continue;  // grad None: skipped entirely (Q8)
+            const float4 gv = *reinterpret_cast<const float4 *>(g + i);
+            const float4 pv = *reinterpret_cast<const float4 *>(p + i);
+            const float4 mv = *reinterpret_cast<const float4 *>(m + i);
+            const float4 vv = *reinterpret_cast<const float4 *>(v + i);
+            float4 po, mo, vo;
+#define TH_ADAM_LANE(c)                                                      \
+            {                                                                \
+                const float gg = gv.c + wd * pv.c;                           \
+                mo.c = beta1 * mv.c + (1.0f - beta1) * gg;                   \
+                vo.c = beta2 * vv.c + (1.0f - beta2) * gg * gg;              \
+                po.c = pv.c - step * mo.c / (sqrtf(vo.c) + eps);             \
+            }
+            TH_ADAM_LANE(x) TH_ADAM_LANE(y) TH_ADAM_LANE(z) TH_ADAM_LANE(w)
+#undef TH_ADAM_LANE
+            *reinterpret_cast<float4 *>(m + i) = mo;
+            *reinterpret_cast<float4 *>(v + i) = vo;
+            *reinterpret_cast<float4 *>(p + i) = po;
+            continue;
+        }
+        for (int64_t j = i; j < i + 4 && j < total; ++j) {
+            if (!has_grad[find_tensor(offsets, n_tensors, j)]) continue;
+            adam_update(p, m, v, j, g[j], step, beta1, beta2, eps, wd);
+        }
     }
     if (pre_ticked) return;
     __syncthreads();
@@ -124,9 +151,10 @@ int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m,
     TH_REQUIRE(ctx && d_params && d_grads && d_m && d_v && d_offsets && d_has_grad && d_t && d_lr, "th_adam_step: null argument");
     TH_REQUIRE(n_tensors > 0 && total >= 0, "th_adam_step: bad sizes");
     // the grid is never empty so that t always advances (optim.rs:84 increments even with no grads)
-    const int grid = ew_grid((size_t)(total > 0 ? total : 1), 256);
+    const int grid = ew_grid((size_t)(total > 0 ? (total + 3) / 4 : 1), 256);
+    const int vec_ok = (((uintptr_t)d_params | (uintptr_t)d_grads | (uintptr_t)d_m | (uintptr_t)d_v) & 15) == 0;   // dwordx4 streams
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_params, d_grads, d_m, d_v, d_offsets, d_has_grad,
-                       n_tensors, total, d_t, d_lr, beta1, beta2, eps, weight_decay, pre_ticked);
+                       n_tensors, total, d_t, d_lr, beta1, beta2, eps, weight_decay, pre_ticked, vec_ok);
     TH_LAUNCH_CHECK();
     return 0;
 }
