@@ -319,6 +319,14 @@ int th_conv3x3_pool2_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const 
  * reinterpreted as [N*H*W, C], tensor.rs:1799-1801, Q4 + Q3); 1 = standard. */
 int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,
                    int n, int c_in, int h, int w, int c_out, int weight_layout, int relu);
+/* General convolution (any kernel / stride / padding / dilation that is neither 3x3-stride-1 nor 1x1): the reference's
+ * im2col_general_simd (tensor.rs:1805-1906, copy_consecutive_elements 1910-1969) + matmul against the weight viewed
+ * [C_in*K_h*K_w, C_out] (1262, Q3) + NHWC -> NCHW (1275-1276) + add_bias_4d (1279-1282) [+ ReLU].  The gather keeps
+ * the reference's arithmetic: taps of one kernel row are copied from consecutive input columns starting at the first
+ * in-range tap (dilation is not applied inside the run) and the source plane is batch*ch + ch (Q9). */
+int th_conv2d_general_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,
+                          int n, int c_in, int h, int w, int c_out, int k_h, int k_w, int s_h, int s_w,
+                          int pad_h, int pad_w, int dil_h, int dil_w, int relu);
 /* add_bias_4d fwd/bwd: tensor.rs:1983-1992, 2017-2024 (gb[c] += sum_{n,h,w}) */
 int th_bias_add_nchw(th_ctx *ctx, const float *d_x, const float *d_bias, float *d_y, int n, int c, int hw, int relu);
 int th_bias_grad_nchw(th_ctx *ctx, const float *d_gout, float *d_gb, int n, int c, int hw);

@@ -158,6 +158,76 @@ def grouped_conv2d(O, x, weight, bias, groups, stride=(1, 1), padding=(0, 0), re
     return cat(outs, 1)
 
 
+# ---- src/tensor.rs:1663-1726, 1805-1970: conv2d through the GENERAL im2col (not 3x3-stride-1, not 1x1) ------------------
+def _copy_consecutive_elements(inp, out, batch, ch, h_in, w_in, in_h, in_w_start, out_start, count):
+    """tensor.rs:1910-1969.  Both branches (the >= 8 block copy and the scalar loop) index the plane as
+    batch*ch*h_in*w_in + ch*h_in*w_in (1931, 1964; quirk Q9: `ch`, not the channel count)."""
+    if count >= 8 and in_w_start + count <= w_in:                                       # 1928
+        in_base = batch * ch * h_in * w_in + ch * h_in * w_in + in_h * w_in + in_w_start   # 1931
+        out[out_start:out_start + count] = inp[in_base:in_base + count]                  # 1933-1957
+    else:
+        for i in range(count):                                                            # 1960
+            in_w = in_w_start + i
+            if in_w < w_in:                                                               # 1962
+                out[out_start + i] = inp[batch * ch * h_in * w_in + ch * h_in * w_in + in_h * w_in + in_w]   # 1964-1965
+
+
+def im2col_general(x, k_h, k_w, stride, padding, dilation):
+    """tensor.rs:1805-1906 loop for loop (pure Python: small cases only) -> col [n*h_out*w_out, c*k_h*k_w] float32"""
+    x = np.asarray(x, f32)
+    n, c, h_in, w_in = x.shape
+    (stride_h, stride_w), (pad_h, pad_w), (dil_h, dil_w) = stride, padding, dilation
+    h_out = (h_in + 2 * pad_h - dil_h * (k_h - 1) - 1) // stride_h + 1                   # 1676
+    w_out = (w_in + 2 * pad_w - dil_w * (k_w - 1) - 1) // stride_w + 1                   # 1677
+    col_size = c * k_h * k_w
+    inp, out = x.reshape(-1), np.zeros(n * h_out * w_out * col_size, f32)                # 1681
+    for batch in range(n):
+        for out_h in range(h_out):
+            for out_w in range(w_out):
+                col_base = (batch * h_out * w_out + out_h * w_out + out_w) * col_size    # 1829-1830
+                for ch in range(c):
+                    for k_row in range(k_h):
+                        in_h = out_h * stride_h + k_row * dil_h                          # 1834
+                        if not (pad_h <= in_h < h_in + pad_h):                           # 1836
+                            continue
+                        in_h_idx = in_h - pad_h
+                        consecutive_count, start_k_col = 0, 0
+                        for k_col in range(k_w):
+                            in_w = out_w * stride_w + k_col * dil_w                      # 1844
+                            if pad_w <= in_w < w_in + pad_w and consecutive_count == k_col - start_k_col:   # 1846-1849
+                                consecutive_count += 1
+                            else:
+                                if consecutive_count > 0:                                 # 1853
+                                    _copy_consecutive_elements(inp, out, batch, ch, h_in, w_in, in_h_idx,
+                                                               out_w * stride_w + start_k_col * dil_w - pad_w,
+                                                               col_base + ch * k_h * k_w + k_row * k_w + start_k_col, consecutive_count)
+                                col_idx = col_base + ch * k_h * k_w + k_row * k_w + k_col   # 1871-1872
+                                if pad_w <= in_w < w_in + pad_w:                          # 1874
+                                    out[col_idx] = inp[batch * c * h_in * w_in + ch * h_in * w_in + in_h_idx * w_in + (in_w - pad_w)]
+                                start_k_col, consecutive_count = k_col + 1, 0             # 1883-1884
+                        if consecutive_count > 0:                                         # 1889
+                            _copy_consecutive_elements(inp, out, batch, ch, h_in, w_in, in_h_idx,
+                                                       out_w * stride_w + start_k_col * dil_w - pad_w,
+                                                       col_base + ch * k_h * k_w + k_row * k_w + start_k_col, consecutive_count)
+    return out.reshape(n * h_out * w_out, col_size), h_out, w_out
+
+
+def conv2d_general(x, weight, bias, stride, padding, dilation, relu=False):
+    """tensor.rs:1221-1285 on the general im2col: col . weight viewed [K, C_out] (1262, Q3) -> [n, h_out, w_out, c_out]
+    -> NCHW (1275-1276) + bias (1279-1282) [+ ReLU, nn.rs:433-490]; fp32 accumulation in k order"""
+    x, weight = np.asarray(x, f32), np.asarray(weight, f32)
+    n, c_out, k_h, k_w = x.shape[0], weight.shape[0], weight.shape[2], weight.shape[3]
+    col, h_out, w_out = im2col_general(x, k_h, k_w, stride, padding, dilation)
+    w2 = weight.reshape(col.shape[1], c_out)
+    out2 = np.zeros((col.shape[0], c_out), f32)
+    for k in range(col.shape[1]):                     # k-ordered fp32 chain, like the reference's sgemm inner product
+        out2 += col[:, k:k + 1] * w2[k:k + 1, :]
+    out = np.ascontiguousarray(out2.reshape(n, h_out, w_out, c_out).transpose(0, 3, 1, 2))
+    if bias is not None:
+        out = out + np.asarray(bias, f32).reshape(1, c_out, 1, 1)
+    return np.maximum(out, 0).astype(f32) if relu else out.astype(f32)
+
+
 # ---- src/tensor.rs:2110-2288: the PTQ storage codecs that do real work (int8, f16) ------------------------------------
 def f32_to_f16_bits(x):
     """tensor.rs:2191-2238, vectorised over a float32 array -> uint16: round half UP on the dropped 13 bits, the mantissa

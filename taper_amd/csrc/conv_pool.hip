@@ -650,6 +650,34 @@ __global__ __launch_bounds__(1024) void bias_grad_adam_kernel(const float *__res
     }
 }
 
+// im2col of the reference's GENERAL path (tensor.rs:1805-1906 + copy_consecutive_elements 1910-1969), one thread per
+// element of col[window][ch][k_row][k_col].  Restated as a closed form of the loops: within one kernel row the taps that
+// fall inside the padded width form ONE run starting at k_col = first; the run is copied from CONSECUTIVE input columns
+// starting at the first tap's column (dilation is not applied inside a run, 1866/1891), and the plane it reads is
+// batch*ch + ch, not batch*c + ch (1931/1964, quirk Q9).  Elements outside the image stay 0 (col is zero-initialised, 1681).
+__global__ __launch_bounds__(256) void im2col_general_kernel(const float *__restrict__ x, float *__restrict__ col, long total, int c,
+                                                             int h_in, int w_in, int h_out, int w_out, int k_h, int k_w, int s_h,
+                                                             int s_w, int pad_h, int pad_w, int dil_h, int dil_w) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        long r = e;
+        const int k_col = (int)(r % k_w); r /= k_w;
+        const int k_row = (int)(r % k_h); r /= k_h;
+        const int ch = (int)(r % c); r /= c;
+        const int ow = (int)(r % w_out); r /= w_out;
+        const int oh = (int)(r % h_out);
+        const long batch = r / h_out;
+        float v = 0.f;
+        const int in_h = oh * s_h + k_row * dil_h, in_w_tap = ow * s_w + k_col * dil_w;
+        if (in_h >= pad_h && in_h < h_in + pad_h && in_w_tap >= pad_w && in_w_tap < w_in + pad_w) {
+            const int lack = pad_w - ow * s_w;                                    // first tap of the run: smallest k with ow*s_w + k*dil_w >= pad_w
+            const int first = lack > 0 ? (lack + dil_w - 1) / dil_w : 0;
+            const int in_w = ow * s_w + first * dil_w - pad_w + (k_col - first);  // consecutive columns from the run's start
+            if (in_w < w_in) v = x[((batch * ch + ch) * h_in + (in_h - pad_h)) * (long)w_in + in_w];
+        }
+        col[e] = v;
+    }
+}
+
 int bias_grad_launch(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw, int accumulate, int pooled) {
     TH_REQUIRE(ctx && d_gout && d_gb, "th_bias_grad_nchw: null argument");
     if (c == 0) return 0;
@@ -920,6 +948,30 @@ int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float 
         }
     }
     return 0;
+}
+
+int th_conv2d_general_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y, int n, int c_in, int h,
+                          int w, int c_out, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w, int dil_h, int dil_w, int relu) {
+    TH_REQUIRE(ctx && d_x && d_w && d_y, "th_conv2d_general_fwd: null argument");
+    TH_REQUIRE(n > 0 && c_in > 0 && c_out > 0 && k_h > 0 && k_w > 0 && s_h > 0 && s_w > 0 && dil_h > 0 && dil_w > 0 && pad_h >= 0 && pad_w >= 0,
+               "th_conv2d_general_fwd: bad geometry");
+    TH_REQUIRE(h + 2 * pad_h >= dil_h * (k_h - 1) + 1 && w + 2 * pad_w >= dil_w * (k_w - 1) + 1, "th_conv2d_general_fwd: kernel larger than the padded input");
+    const int h_out = (h + 2 * pad_h - dil_h * (k_h - 1) - 1) / s_h + 1, w_out = (w + 2 * pad_w - dil_w * (k_w - 1) - 1) / s_w + 1;
+    const long windows = (long)n * h_out * w_out, k = (long)c_in * k_h * k_w;
+    TH_REQUIRE(windows < (1L << 31) && k < (1L << 31), "th_conv2d_general_fwd: col matrix too large");
+    void *col = nullptr, *tmp = nullptr;
+    if (th_malloc(ctx, (size_t)(windows * k) * sizeof(float), &col)) return 1;
+    if (th_malloc(ctx, (size_t)windows * c_out * sizeof(float), &tmp)) return 1;
+    hipLaunchKernelGGL(im2col_general_kernel, dim3(ew_grid((size_t)(windows * k), 256)), dim3(256), 0, ctx->stream, d_x, (float *)col, windows * k,
+                       c_in, h, w, h_out, w_out, k_h, k_w, s_h, s_w, pad_h, pad_w, dil_h, dil_w);
+    TH_LAUNCH_CHECK();
+    // out2d[windows, c_out] = col . w viewed [k, c_out] (tensor.rs:1262, Q3) -> NHWC -> NCHW (+bias, tensor.rs:1272-1279)
+    if (int rc = th_sgemm(ctx, 0, 0, (int)windows, c_out, (int)k, 1.0f, (const float *)col, d_w, 0.0f, (float *)tmp)) return rc;
+    hipLaunchKernelGGL(nhwc_to_nchw_bias_kernel, dim3(ceil_div(c_out, 64), ceil_div(h_out * w_out, 64), n), dim3(256), 0, ctx->stream,
+                       (const float *)tmp, d_bias, d_y, h_out * w_out, c_out, relu);
+    TH_LAUNCH_CHECK();
+    if (int rc = th_free(ctx, col)) return rc;
+    return th_free(ctx, tmp);
 }
 
 int th_bias_add_nchw(th_ctx *ctx, const float *d_x, const float *d_bias, float *d_y, int n, int c, int hw, int relu) {

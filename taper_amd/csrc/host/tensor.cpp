@@ -764,8 +764,10 @@ Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> s
     } else if (is1) {
         TAPER_ASSERT(h == h_out && wd == w_out, "im2col_1x1 requires h_in == h_out (tensor.rs:1796-1797)");
         TH(th_conv1x1_fwd(c, dptr(), w.dptr(), bp, out.dptr(), n, c_in, h, wd, c_out, 0, relu ? 1 : 0));
-    } else {
-        throw Error("conv2d: only 3x3 stride-1 and 1x1 kernels are supported (the reference's general im2col is out of scope, Q9)");
+    } else {   // im2col_general_simd (tensor.rs:1703-1722, 1805-1906) with its arithmetic kept as is (Q9)
+        TAPER_ASSERT(stride.first > 0 && stride.second > 0 && dilation.first > 0 && dilation.second > 0, "conv2d: stride and dilation must be positive");
+        TH(th_conv2d_general_fwd(c, dptr(), w.dptr(), bp, out.dptr(), n, c_in, h, wd, c_out, k_h, k_w, stride.first, stride.second,
+                                 padding.first, padding.second, dilation.first, dilation.second, relu ? 1 : 0));
     }
     // Tape.  Faithful mode (Q2): the chain is cut at transpose_4d / im2col, so only
     // the bias (through add_bias_4d, tensor.rs:2003-2027) ever receives a gradient.

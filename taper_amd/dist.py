@@ -20,12 +20,21 @@ import time
 from pathlib import Path
 
 
+def _start_ticks(pid: int) -> str:
+    """start time of a process (clock ticks since boot, /proc/<pid>/stat field 22): with the PID it names one launcher
+    for good, so a directory left behind by a crashed run of a recycled PID is never mistaken for this run's"""
+    try:
+        return Path(f"/proc/{pid}/stat").read_text().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        return "0"
+
+
 class FileRendezvous:
     def __init__(self, rank: int, world: int, key: str | None = None, root: str | None = None, timeout_s: float = 600.0):
         self.rank, self.world, self.timeout_s = int(rank), int(world), timeout_s
         if key is None:
             # all workers of one torchrun share the agent as parent and the master port
-            key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+            key = f"{os.getppid()}_{_start_ticks(os.getppid())}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
         base = Path(root or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
         self.dir = base / f"taper_rdzv_{key}"
         self.dir.mkdir(parents=True, exist_ok=True)

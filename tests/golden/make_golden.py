@@ -141,8 +141,32 @@ def grouped_conv_case():
                         y_standard=f32(y_std.numpy()))
 
 
+def general_conv_cases():
+    """conv2d through the reference's general im2col (tensor.rs:1805-1970), dilation 1.
+    torch F.conv2d with the Q3 weight mapping; for n > 1 the reference reads plane batch*ch + ch instead of
+    batch*c + ch (Q9), so torch is fed the planes the reference actually reads (for n == 1 that is the input itself)."""
+    r4 = np.random.default_rng(20250931)
+    out = {}
+    cases = [(1, 3, 12, 12, 6, 5, 5, (1, 1), (2, 2)), (1, 4, 11, 9, 5, 3, 3, (2, 2), (1, 1)), (1, 2, 16, 16, 4, 7, 7, (2, 2), (3, 3)),
+             (1, 3, 8, 8, 4, 2, 2, (2, 2), (0, 0)), (3, 4, 9, 10, 5, 5, 5, (1, 1), (2, 2)), (2, 3, 10, 10, 4, 3, 5, (1, 2), (1, 2))]
+    for i, (n, c, h, w, co, kh, kw, st, pd) in enumerate(cases):
+        x = f32(r4.uniform(-1, 1, (n, c, h, w)))
+        wt = f32(r4.uniform(-0.5, 0.5, (co, c, kh, kw)))
+        b = f32(r4.uniform(-0.5, 0.5, co))
+        planes = x.reshape(n * c, h, w)
+        read = np.stack([np.stack([planes[bi * ch + ch] for ch in range(c)]) for bi in range(n)])
+        w_eff = torch.from_numpy(wt).double().flatten().reshape(c * kh * kw, co).T.reshape(co, c, kh, kw)
+        y = F.conv2d(torch.from_numpy(read).double(), w_eff, torch.from_numpy(b).double(), stride=st, padding=pd)
+        out.update({f"x{i}": x, f"w{i}": wt, f"b{i}": b, f"geo{i}": np.array([st[0], st[1], pd[0], pd[1]]), f"y{i}": f32(y.numpy())})
+    np.savez_compressed(OUT / "conv_general.npz", count=np.array(len(cases)), **out)
+
+
 if __name__ == "__main__":
     import sys
+    if "--general" in sys.argv:
+        general_conv_cases()
+        print("wrote conv_general.npz")
+        sys.exit(0)
     if "--grouped" in sys.argv:
         grouped_conv_case()
         print("wrote conv_grouped.npz")
