@@ -30,6 +30,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int MF_CI = 8;              // input channels per pass  -> 72 k = 18 MFMA k-steps
 constexpr int MF_PX_MAX = 128;        // pixels per workgroup (8 tiles of 16)
 
+constexpr int MF_OOB = 0x7ffffff0;     // byte offset beyond every buffer descriptor's range
 constexpr int MF_PPT = 12;            // patch elements per thread per pass (patch <= 3072 floats)
 
 // Exact quotient / remainder of small non-negative ints (e < 2^22, d >= 1) through one float multiply and one
@@ -61,9 +62,15 @@ struct ConvMfmaArgs {
 
 #ifdef TH_PROFILE
 __device__ long long g_conv_prof[8];
+__device__ long long g_conv_tl[4 * 4096];   // per workgroup: start, end of k loop, end (100 MHz wall clock), hardware id
+__device__ long long g_conv_clk[2 * 4096];  // shader clock (clock64) at start / end
+#define CONV_TL(slot) do { const int id_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && id_ < 4096) { g_conv_tl[4 * id_ + (slot)] = wall_clock64(); if ((slot) != 1) g_conv_clk[2 * id_ + ((slot) >> 1)] = clock64(); } } while (0)
+#define CONV_TL_HW() do { const int id_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && id_ < 4096) g_conv_tl[4 * id_ + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } while (0)
 #define CONV_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 300 && blockIdx.y == 0) g_conv_prof[i] = wall_clock64(); } while (0)
 #else
 #define CONV_STAMP(i) do { } while (0)
+#define CONV_TL(slot) do { } while (0)
+#define CONV_TL_HW() do { } while (0)
 #endif
 
 // POOL: the epilogue additionally applies a 2x2 / stride-2 max pool (tensor.rs:1391-1470 values; no index output) and
@@ -74,7 +81,11 @@ __device__ long long g_conv_prof[8];
 // maps launch < 2 workgroups per CU and their matrix pipes idled 56 % of the time).
 // (<= 32-channel blocks with 4 waves: capped at 128 VGPRs so that 4 workgroups share a CU -- 4 spilled registers buy 66.8 -> 62.9 us
 // on the 28x28 layer; a cap of 102 for 5 workgroups spills the plans and costs 50 %)
-template <int CT, bool ACCUM, int CIT, bool POOL = false, int WH = 1>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
+// DMA: the operands of a pass go global -> LDS directly (`buffer_load ... lds`: no staging registers, no ds_write pass, no
+// per-element address / select arithmetic -- halo and out-of-range elements are offsets past the buffer's end, which the
+// descriptor's range check turns into zeros), into the other of two LDS stages while the current one feeds the MFMAs: one
+// barrier per pass.  Needs whole 8-channel blocks (c_in % 8 == 0).
+template <int CT, bool ACCUM, int CIT, bool POOL = false, int WH = 1, bool DMA = false>   // CT = co_b / 16; CIT = input channels per pass: 8, or 1 for single-channel inputs (conv1)
 __global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x3_mfma_kernel(ConvMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CO_B = 16 * CT;
@@ -83,6 +94,8 @@ __global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x
     constexpr int NT = 256 * WH, PPT = MF_PPT / WH, CTW = CT / WH;   // threads, patch elements per thread per pass, channel tiles per wave
     constexpr int WPT = (WQ + NT - 1) / NT;                    // quads per thread per pass
     CONV_STAMP(0);
+    CONV_TL(0);
+    CONV_TL_HW();
     const int t = threadIdx.x, lane = t & 63, wave = (t >> 6) & 3, chalf = t >> 8;   // pixel group, channel half
     const int l16 = lane & 15, g4 = lane >> 4;
     const int wp = a.w_out + 2, rp = a.rows_t + 2;           // patch pitch / rows (input window of the band)
@@ -140,8 +153,10 @@ __global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x
             d_wp.divmod(r2, rr, cc);
             const int img = img0 + il, ih = oh0 + rr - 1 + shift, iw = cc - 1 + shift;
             if (img < a.n && ih >= 0 && ih < a.h && iw >= 0 && iw < a.w_in)
-                p_goff[j] = (int)((((((long)il * a.c_in + cl) * a.h + ih) * a.w_in + iw) << 3) | cl);   // relative to image img0, channel cb
+                p_goff[j] = DMA ? (int)(((((long)il * a.c_in + cl) * a.h + ih) * a.w_in + iw) << 2)        // byte offset
+                                : (int)((((((long)il * a.c_in + cl) * a.h + ih) * a.w_in + iw) << 3) | cl);   // relative to image img0, channel cb
         }
+        if (DMA && p_goff[j] < 0) p_goff[j] = MF_OOB;        // past the end of any buffer: reads as zero
     }
     const float *xbase = a.x + (long)img0 * a.c_in * chan;
 
@@ -151,6 +166,70 @@ __global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x
 #pragma unroll
         for (int j = 0; j < CTW; ++j) acc[q][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (DMA) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-descriptor builtins exist in the device pass only
+        typedef __attribute__((address_space(3))) void *lds_ptr_t;
+        const int stage_n = ((patch_n + 4) & ~3) + 4 * KS * CO_B;      // floats per stage: patch, then the weight slab
+        const int w0 = __builtin_amdgcn_readfirstlane(t >> 6) * 64;     // this wave's first thread (uniform)
+        int w_boff[WPT];                                               // weight quad u = t + NT j -> byte offset in channel block 0's slab
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int u = t + NT * j, kk = u / (CO_B / 4), cq = (u % (CO_B / 4)) * 4;
+            w_boff[j] = (u < WQ && co0 + cq + 3 < a.w_cols) ? (kk * a.w_ld + co0 + cq) << 2 : MF_OOB;
+        }
+        const int imgs_here = min(a.img_t, a.n - img0);
+        const int x_bytes = (int)((long)imgs_here * a.c_in * chan * 4), w_bytes = 9 * a.c_in * a.w_ld * 4;
+        auto issue = [&](int cb, int stage) {
+            // descriptors rebuilt per pass from uniform values: base at channel block cb, range = what is left behind it
+            const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(xbase + (long)cb * chan), 0, x_bytes - (int)(cb * chan * 4), 0x00020000);
+            const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)(a.w + (long)cb * 9 * a.w_ld), 0, w_bytes - cb * 9 * a.w_ld * 4, 0x00020000);
+            float *st = lds + stage * stage_n;
+            // whole rounds of NT elements go out unmasked (a uniform test); only the ragged last round is lane-masked
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                if (NT * (j + 1) <= patch_n)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + w0 + NT * j), 4, p_goff[j], 0, 0, 0);
+                else if (NT * j < patch_n && t + NT * j < patch_n)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + w0 + NT * j), 4, p_goff[j], 0, 0, 0);
+            }
+            float *ws = st + ((patch_n + 4) & ~3);
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) {
+                if (NT * (j + 1) <= WQ)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws + 4 * (w0 + NT * j)), 16, w_boff[j], 0, 0, 0);
+                else if (t + NT * j < WQ)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws + 4 * (w0 + NT * j)), 16, w_boff[j], 0, 0, 0);
+            }
+        };
+        CONV_STAMP(1);
+        issue(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        CONV_STAMP(2);
+        int stage = 0;
+        for (int cb = 0; cb < a.c_in; cb += CIT, stage ^= 1) {
+            const bool more = cb + CIT < a.c_in;
+            if (more) issue(cb + CIT, stage ^ 1);     // the other stage was last read before the barrier that ended the previous pass
+            const float *pp = lds + stage * stage_n, *ww = pp + ((patch_n + 4) & ~3);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float b0 = pp[pix_off[0] + koff[s]];
+                const float b1 = pp[pix_off[1] + koff[s]];
+                const float *wk = ww + (4 * s + g4) * CO_B + l16 + 16 * CTW * chalf;
+#pragma unroll
+                for (int j = 0; j < CTW; ++j) {
+                    const float av = wk[16 * j];
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1][j], 0, 0, 0);
+                }
+            }
+            if (more) {
+                __builtin_amdgcn_s_waitcnt(0);        // this wave's part of the next stage has landed
+                __syncthreads();                      // ... and everybody's; every wave is done reading this stage
+            }
+        }
+#endif
+    } else {
     float pv[PPT];
     float4 wv[WPT];
     // all global loads of a pass are issued back to back (one round trip), held in registers while the
@@ -211,7 +290,9 @@ __global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x
     }
 #undef TH_MF_LOAD
 #undef TH_MF_STORE
+    }
     CONV_STAMP(3);
+    CONV_TL(1);
 
     if (POOL) {
         // ---- pooled epilogue: bias + ReLU into an LDS tile [CO_B][pixels], then 2x2 maxima straight to the pooled tensor ----
@@ -251,6 +332,7 @@ __global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x
             a.y[((long)(img0 + il) * a.c_out + co0 + cl) * pchan + (long)((oh0 >> 1) + pr) * pw + pc] = m;
         }
         CONV_STAMP(4);
+        CONV_TL(2);
         return;
     }
     // ---- epilogue: bias + ReLU (tensor.rs:2005-2025, nn.rs:433-490), NCHW store straight from the D tiles: lane
@@ -281,6 +363,7 @@ __global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x
             }
     }
     CONV_STAMP(4);
+    CONV_TL(2);
 }
 
 // images x rows per workgroup: the fullest tiling of <= 128 pixels by whole output rows of one or more images
@@ -346,10 +429,16 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     a.co_b = ct * 16;
     const size_t patch_n = (size_t)cit * a.img_t * (a.rows_t + 2) * (a.w_out + 2);
     size_t lds = (((patch_n + 4) & ~(size_t)3) + (size_t)((cit * 9 + 3) / 4 * 4) * a.co_b) * sizeof(float);
+    // whole 8-channel blocks, plain (non-accumulating) output: operands go global -> LDS directly, two LDS stages
+    static const int dma_env = getenv("TAPER_CONV_DMA") ? atoi(getenv("TAPER_CONV_DMA")) : 1;   // tuning probe: 0 = register-staged passes
+    const bool dma = dma_env && cit == MF_CI && c_in % MF_CI == 0 && !accum && ct >= 2 &&
+                     (long)a.img_t * c_in * h * w_in < (1L << 28) && (long)9 * c_in * w_ld < (1L << 28);
+    if (dma) lds *= 2;
     if (pool) lds = std::max(lds, (size_t)a.co_b * ((size_t)(a.img_t * a.rows_t * a.w_out) | 1) * sizeof(float));   // the epilogue tile
     dim3 grid(ceil_div(n, a.img_t) * a.bands, ceil_div(c_out, a.co_b));
 #define TH_MF(CTV, ACC, PL, WHV)                                                                                                   \
     if (cit == 1) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, 1, PL, WHV>), grid, dim3(256 * WHV), lds, ctx->stream, a);     \
+    else if (dma && !ACC && CTV >= 2) hipLaunchKernelGGL((conv3x3_mfma_kernel<(CTV >= 2 ? CTV : 2), false, MF_CI, PL, WHV, true>), grid, dim3(256 * WHV), lds, ctx->stream, a); \
     else hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, MF_CI, PL, WHV>), grid, dim3(256 * WHV), lds, ctx->stream, a);
 #define TH_MF_CT(ACC, PL)                                                       \
     switch (ct) {                                                               \
@@ -591,6 +680,12 @@ int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, floa
 extern "C" int th_debug_conv_prof(th_ctx *ctx, long long *h_out8) {
     TH_HIP(hipStreamSynchronize(ctx->stream));
     TH_HIP(hipMemcpyFromSymbol(h_out8, HIP_SYMBOL(th::g_conv_prof), 8 * sizeof(long long)));
+    return 0;
+}
+extern "C" int th_debug_conv_timeline(th_ctx *ctx, long long *h_out, int n_wg) {   // tools/conv_timeline.py
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(th::g_conv_tl), (size_t)4 * n_wg * sizeof(long long)));
+    TH_HIP(hipMemcpyFromSymbol(h_out + 4 * n_wg, HIP_SYMBOL(th::g_conv_clk), (size_t)2 * n_wg * sizeof(long long)));
     return 0;
 }
 #endif
