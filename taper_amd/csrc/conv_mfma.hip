@@ -435,6 +435,8 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
                      (long)a.img_t * c_in * h * w_in < (1L << 28) && (long)9 * c_in * w_ld < (1L << 28);
     if (dma) lds *= 2;
     if (pool) lds = std::max(lds, (size_t)a.co_b * ((size_t)(a.img_t * a.rows_t * a.w_out) | 1) * sizeof(float));   // the epilogue tile
+    static const int lds_min_kb = getenv("TAPER_CONV_LDS_KB") ? atoi(getenv("TAPER_CONV_LDS_KB")) : 0;   // tuning probe: caps workgroups per CU
+    if (lds_min_kb) lds = std::max(lds, (size_t)lds_min_kb * 1024);
     dim3 grid(ceil_div(n, a.img_t) * a.bands, ceil_div(c_out, a.co_b));
 #define TH_MF(CTV, ACC, PL, WHV)                                                                                                   \
     if (cit == 1) hipLaunchKernelGGL((conv3x3_mfma_kernel<CTV, ACC, 1, PL, WHV>), grid, dim3(256 * WHV), lds, ctx->stream, a);     \
@@ -449,7 +451,8 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     // launches with < 3 workgroups per CU: 8 waves per workgroup (see WH; 14x14 layers 38.3 / 62.5 -> 34.4 / 56.5 us, 7x7: 40.0 -> 36.8 us;
     // the 28x28 layer has 1792 workgroups and gains nothing)
     static const int wh_env = getenv("TAPER_CONV_WH") ? atoi(getenv("TAPER_CONV_WH")) : 0;   // tuning probe: 1 forces 4 waves
-    const bool wh2 = ct >= 2 && wh_env != 1 && (wh_env == 2 || (long)grid.x * grid.y < 768);
+    // (with LDS-DMA staging there is no per-pass staging work left for extra waves to hide: 4 waves measure 2-6 % faster on those layers)
+    const bool wh2 = ct >= 2 && wh_env != 1 && (wh_env == 2 || (!dma && (long)grid.x * grid.y < 768));
     if (pool) TH_MF_CT(false, true) else if (accum) TH_MF_CT(true, false) else TH_MF_CT(false, false)
 #undef TH_MF_CT
 #undef TH_MF
