@@ -347,6 +347,14 @@ int th_bias_grad_avgpool_masked(th_ctx *ctx, const float *d_gout_pooled, const f
  * carried in spare workgroups (extra nullable) -- the step then needs no optimizer launch.  pooled_avg: d_gout is [n][c]. */
 int th_bias_grad_masked_adam(th_ctx *ctx, const float *d_gout, const float *d_mask_y, float *d_gb, int n, int c, int hw,
                              int pooled_avg, const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra);
+/* Global average pool of a post-ReLU map that also counts the elements > 0 of every plane (d_cnt [n][c], as floats), and the
+ * bias gradient of the Conv2dReLU in front of it from those counts: db[ch] = sum_n (g[n][ch] / hw) * cnt[n][ch] -- every
+ * element of a plane receives g / hw (tensor.rs:1626-1628) and passes the ReLU mask iff it is > 0 (ops.rs:358-369), so the
+ * sum over the plane (tensor.rs:2017-2024) is that product; 2 n c floats are read instead of the n c hw conv outputs.
+ * b_fuse / extra as in th_bias_grad_masked_adam. */
+int th_avgpool2d_global_fwd_counts(th_ctx *ctx, const float *d_x, float *d_y, float *d_cnt, int n, int c, int hw);
+int th_bias_grad_counts_adam(th_ctx *ctx, const float *d_gout_pooled, const float *d_cnt, float *d_gb, int n, int c, int hw,
+                             const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra);
 /* full_backward extension (not in the reference: Q2 cuts these gradients) */
 int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx,
                          int n, int c_in, int h, int w, int c_out, int pad, int weight_layout); /* gx += */

@@ -472,17 +472,58 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float *__restric
     }
 }
 
-// one wave per (b,c) plane when the window is the whole plane (global pool)
-__global__ __launch_bounds__(256) void avgpool_global_kernel(const float *__restrict__ x, float *__restrict__ y, long planes,
-                                                             int hw, float pool_size) {
+// one wave per (b,c) plane when the window is the whole plane (global pool); cnt (nullable): number of elements > 0 in
+// the plane -- for a post-ReLU input that is all its backward needs to know about the plane (th_bias_grad_counts_adam)
+__global__ __launch_bounds__(256) void avgpool_global_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ cnt,
+                                                             long planes, int hw, float pool_size) {
     const int lane = threadIdx.x & 63;
     const long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pl >= planes) return;
-    float s = 0.f;
-    for (int i = lane; i < hw; i += 64) s += x[pl * hw + i];
+    float s = 0.f, k = 0.f;
+    for (int i = lane; i < hw; i += 64) {
+        const float v = x[pl * hw + i];
+        s += v;
+        k += v > 0.f ? 1.f : 0.f;
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) y[pl] = s / pool_size;
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        k += __shfl_down(k, off, 64);
+    }
+    if (lane == 0) {
+        y[pl] = s / pool_size;
+        if (cnt) cnt[pl] = k;
+    }
+}
+
+// db[ch] = sum_n (g[n][ch] / hw) * cnt[n][ch] (+ the Adam update of that bias element, + carried deferred updates): the bias
+// gradient of Conv2dReLU -> global average pool from 2 n c floats instead of the n c hw conv outputs.
+__global__ __launch_bounds__(256) void bias_grad_counts_adam_kernel(const float *__restrict__ g, const float *__restrict__ cnt,
+                                                                    float *__restrict__ gb, int n, int c, int hw, AdamDev ad,
+                                                                    AdamSlices extra) {
+    const int groups = (c + 15) / 16;
+    if ((int)blockIdx.x >= groups) {
+        adam_slices_block(extra, blockIdx.x - groups);
+        return;
+    }
+    // 16 channels per workgroup: thread (r, q) sums images r, r + 16, ... of channel 16 blockIdx + q (64-byte segments)
+    __shared__ float sh[16][17];
+    const int q = threadIdx.x & 15, r = threadIdx.x >> 4, ch = blockIdx.x * 16 + q;
+    float s = 0.f;
+    if (ch < c)
+        for (int b = r; b < n; b += 16) s += g[(long)b * c + ch] / (float)hw * cnt[(long)b * c + ch];
+    sh[r][q] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && ch < c) {
+        float tot = sh[0][q];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tot += sh[i][q];
+        gb[ch] = tot;
+        if (ad.p) {
+            const float step = adam_dev_step(ad);
+            adam_update(ad.p, ad.m, ad.v, ch, tot, step, ad.beta1, ad.beta2, ad.eps, ad.wd);
+        }
+    }
 }
 
 // gather form of tensor.rs:1624-1653, (oh, ow) ascending like the reference
@@ -1047,12 +1088,32 @@ int th_avgpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int n, int c, in
     const long total = (long)n * c * h_out * w_out;
     if (total == 0) return 0;
     if (k_h == h && k_w == w && pad_h == 0 && pad_w == 0) {  // global pool: one wave per plane
-        hipLaunchKernelGGL(avgpool_global_kernel, dim3(ceil_div((long)n * c, 4)), dim3(256), 0, ctx->stream, d_x, d_y, (long)n * c,
-                           h * w, (float)(k_h * k_w));
+        hipLaunchKernelGGL(avgpool_global_kernel, dim3(ceil_div((long)n * c, 4)), dim3(256), 0, ctx->stream, d_x, d_y, (float *)nullptr,
+                           (long)n * c, h * w, (float)(k_h * k_w));
     } else {
         hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_y, total, h, w, h_out,
                            w_out, k_h, k_w, s_h, s_w, pad_h, pad_w);
     }
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_avgpool2d_global_fwd_counts(th_ctx *ctx, const float *d_x, float *d_y, float *d_cnt, int n, int c, int hw) {
+    TH_REQUIRE(ctx && d_x && d_y && d_cnt && hw > 0, "th_avgpool2d_global_fwd_counts: null argument");
+    if ((long)n * c == 0) return 0;
+    hipLaunchKernelGGL(avgpool_global_kernel, dim3(ceil_div((long)n * c, 4)), dim3(256), 0, ctx->stream, d_x, d_y, d_cnt, (long)n * c, hw,
+                       (float)hw);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_bias_grad_counts_adam(th_ctx *ctx, const float *d_gout_pooled, const float *d_cnt, float *d_gb, int n, int c, int hw,
+                             const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra) {
+    TH_REQUIRE(ctx && d_gout_pooled && d_cnt && d_gb && n > 0 && c > 0 && hw > 0, "th_bias_grad_counts_adam: null argument / empty tensor");
+    TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_bias_grad_counts_adam: bad extra slices");
+    const AdamSlices x = make_adam_slices(extra, n_extra);
+    hipLaunchKernelGGL(bias_grad_counts_adam_kernel, dim3(ceil_div(c, 16) + x.blocks()), dim3(256), 0, ctx->stream, d_gout_pooled, d_cnt,
+                       d_gb, n, c, hw, make_adam_dev(b_fuse), x);
     TH_LAUNCH_CHECK();
     return 0;
 }

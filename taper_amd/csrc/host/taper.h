@@ -76,6 +76,7 @@ struct GradSlot {
     bool premasked = false;       // its gradient already carries that ReLU's mask (th_linear_xent_head_masked)
     bool wants_pooled = false;
     std::shared_ptr<Buffer> pooled_dy, pooled_y;
+    std::shared_ptr<Buffer> pooled_cnt;   // [n][c] counts of elements > 0 per plane, left by a global average pool's forward
     int pooled_n = 0, pooled_c = 0, pooled_hw = 0;
     bool pooled_avg = false;      // the consumer was a global average pool: pooled_dy is [n][c], pooled_y the conv output itself
 };

@@ -740,7 +740,7 @@ std::pair<Tensor, Tensor> Tensor::max(int dim) const {  // tensor.rs:1021-1083 (
 Tensor Tensor::argmax(int dim) const { return max(dim).second; }
 
 // ---------------------------------------------------------------- conv / pool
-static void pooled_bias_grad(const Tensor &bias, const float *dy, const float *mask_y, int n, int c, int hw, bool avg);
+static void pooled_bias_grad(const Tensor &bias, const float *dy, const float *mask_y, int n, int c, int hw, bool avg, const float *cnt = nullptr);
 
 Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> stride, std::pair<int, int> padding,
                       std::pair<int, int> dilation, bool relu) const {  // tensor.rs:1221-1285 (+1379-1389)
@@ -785,9 +785,11 @@ Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> s
                 // the max-pool behind this layer left its OUTPUT's gradient: db = sum of the pooled gradients whose
                 // pooled value is > 0 (the one conv output each lands on, and that output's ReLU mask)
                 GradSlot &g = *r.grad_;
-                pooled_bias_grad(b, g.pooled_dy->d, g.pooled_y->d, g.pooled_n, g.pooled_c, g.pooled_hw, g.pooled_avg);
+                pooled_bias_grad(b, g.pooled_dy->d, g.pooled_y->d, g.pooled_n, g.pooled_c, g.pooled_hw, g.pooled_avg,
+                                 g.pooled_avg && g.pooled_cnt ? g.pooled_cnt->d : nullptr);
                 g.pooled_dy.reset();
                 g.pooled_y.reset();
+                g.pooled_cnt.reset();
                 return;
             }
             if (!r.has_grad()) return;
@@ -813,12 +815,20 @@ Tensor Tensor::conv2d_relu(const Tensor &w, const Tensor &bias, std::pair<int, i
 
 // Bias gradient of a bias-only Conv2dReLU from pooled tensors (see GradSlot).  Inside a fused-update step it is the last backward
 // launch of the faithful CNNs: the bias's own Adam update and every deferred update still waiting ride in the same launch.
-static void pooled_bias_grad(const Tensor &bias, const float *dy, const float *mask_y, int n, int c, int hw, bool avg) {
+static void pooled_bias_grad(const Tensor &bias, const float *dy, const float *mask_y, int n, int c, int hw, bool avg, const float *cnt) {
     th_ctx *ctx = Device::ctx();
     bool none;
     float *db = bias.grad_for_write(&none);
     Adam *fa = FusedAdamScope::active();
     th_adam_fuse bf{};
+    if (avg && cnt && none) {   // the pool's forward counted each plane's positive elements: 2 n c floats instead of n c hw
+        th_adam_slice carried[TH_MAX_ADAM_SLICES];
+        int n_carried = 0;
+        const bool fuse = fa && fa->fuse_for(bias, &bf);
+        if (fuse) n_carried = fa->take_deferred(nullptr, carried);
+        TH(th_bias_grad_counts_adam(ctx, dy, cnt, db, n, c, hw, fuse ? &bf : nullptr, carried, n_carried));
+        return;
+    }
     if (fa && none && fa->fuse_for(bias, &bf)) {
         th_adam_slice carried[TH_MAX_ADAM_SLICES];
         const int n_carried = fa->take_deferred(nullptr, carried);
@@ -899,6 +909,11 @@ Tensor Tensor::avg_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pai
     TAPER_ASSERT(k.first > 0 && k.second > 0 && h + 2 * p.first >= k.first && w + 2 * p.second >= k.second, "avg_pool2d: bad geometry");
     const int h_out = (h + 2 * p.first - k.first) / s.first + 1, w_out = (w + 2 * p.second - k.second) / s.second + 1;
     Tensor out = empty({(size_t)n, (size_t)ch, (size_t)h_out, (size_t)w_out});
+    if (grad_ && grad_->wants_pooled && k.first == h && k.second == w && p.first == 0 && p.second == 0) {
+        // PoolBiasScope: the producer is a bias-only Conv2dReLU -- count each plane's positive elements on the way (see GradSlot)
+        grad_->pooled_cnt = Buffer::alloc((size_t)n * ch);
+        TH(th_avgpool2d_global_fwd_counts(Device::ctx(), dptr(), out.dptr(), grad_->pooled_cnt->d, n, ch, h * w));
+    } else
     TH(th_avgpool2d_fwd(Device::ctx(), dptr(), out.dptr(), n, ch, h, w, k.first, k.second, s.first, s.second, p.first, p.second));
     if (requires_grad_) {
         out.requires_grad_ = true;

@@ -269,6 +269,40 @@ def test_bias_grad_masked_adam(ctx, O, n, c, hw, pooled_avg, carry):
     np.testing.assert_allclose(ctx.download(out2, c), gb, rtol=1e-4, atol=1e-4 * float(np.abs(gb).max()) + 1e-7)
 
 
+@pytest.mark.parametrize("n,c,hw", [(256, 128, 49), (6, 5, 9), (40, 33, 49), (300, 3, 1), (17, 64, 196)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_bias_grad_from_plane_counts(ctx, O, n, c, hw, fused):
+    """th_avgpool2d_global_fwd_counts (plane means + counts of elements > 0) and th_bias_grad_counts_adam: the bias gradient of a
+    Conv2dReLU in front of a global average pool from 2 n c floats == the sum over all n c hw masked elements (+ oracle Adam)"""
+    rng = np.random.default_rng(n + c + hw)
+    yp = np.maximum(rng.standard_normal((n, c, hw)), 0).astype(np.float32)
+    g = (rng.standard_normal((n, c)) * 0.01).astype(np.float32)
+    mean, cnt = ctx.empty(n * c), ctx.empty(n * c)
+    ctx.call("th_avgpool2d_global_fwd_counts", ctx.upload(yp), mean, cnt, n, c, hw)
+    np.testing.assert_allclose(ctx.download(mean, (n, c)), yp.astype(np.float64).mean(2), rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(ctx.download(cnt, (n, c)), (yp > 0).sum(2).astype(np.float32))
+    gb = (g.astype(np.float64)[:, :, None] / hw * (yp > 0)).sum((0, 2))
+    lr, t = 1e-3, 4
+    b0 = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    tick, dlr = ctx.upload(np.array([t, 0], np.int32)), ctx.upload(np.array([lr], np.float32))
+    pb, mb, vb, out = ctx.upload(b0), ctx.zeros(c), ctx.zeros(c), ctx.empty(c)
+    bf = AdamFuse(int(pb), int(mb), int(vb), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4)
+    k = 1500
+    p0, gk = rng.uniform(-0.1, 0.1, k).astype(np.float32), (rng.standard_normal(k) * 0.01).astype(np.float32)
+    bufs = [ctx.upload(p0), ctx.zeros(k), ctx.zeros(k), ctx.upload(gk)]
+    sl = (AdamSlice * 1)(AdamSlice(int(bufs[3]), k, AdamFuse(int(bufs[0]), int(bufs[1]), int(bufs[2]), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4)))
+    ctx.call("th_bias_grad_counts_adam", ctx.upload(g), cnt, out, n, c, hw, C.byref(bf) if fused else None, sl if fused else None, 1 if fused else 0)
+    np.testing.assert_allclose(ctx.download(out, c), gb, rtol=1e-4, atol=1e-4 * float(np.abs(gb).max()) + 1e-7)
+    if fused:
+        b_ref, m_ref, _ = _adam_ref(O, b0, gb.astype(np.float32), lr, t)
+        np.testing.assert_allclose(ctx.download(pb, c), b_ref, rtol=RTOL, atol=lr * 2e-2)
+        np.testing.assert_allclose(ctx.download(mb, c), m_ref.reshape(c), rtol=1e-3, atol=1e-8 + 1e-4 * float(np.abs(m_ref).max()))
+        p_ref, _, _ = _adam_ref(O, p0, gk, lr, t)
+        np.testing.assert_allclose(ctx.download(bufs[0], (k,)), p_ref, rtol=RTOL, atol=lr * 2e-2)
+    else:
+        np.testing.assert_array_equal(ctx.download(pb, c), b0)
+
+
 def test_carried_slice_must_not_alias_the_weight_read_for_dx(ctx):
     from taper_amd._lib import TaperError
     z = ctx.zeros(64 * 64)
