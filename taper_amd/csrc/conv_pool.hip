@@ -496,28 +496,69 @@ __global__ __launch_bounds__(256) void avgpool_global_kernel(const float *__rest
     }
 }
 
+// small planes (hw <= 256): a workgroup takes 16 consecutive planes = 16 hw contiguous floats, staged through LDS with every
+// thread's loads independent (one wave per 49-element plane is a single dependent load per lane: latency-bound at 1 TB/s);
+// 16 lanes then sum a plane in the same ascending-stride order and finish with a 16-lane shuffle tree
+__global__ __launch_bounds__(256) void avgpool_global16_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ cnt,
+                                                               long planes, int hw, float pool_size) {
+    extern __shared__ float pl_sh[];                      // [16][hw]
+    const long p0 = (long)blockIdx.x * 16;
+    const int n_here = (int)min((long)16, planes - p0), total = n_here * hw;
+    const float *src = x + p0 * hw;
+    for (int e = threadIdx.x; e < total; e += 256) pl_sh[e] = src[e];
+    __syncthreads();
+    const int pl = threadIdx.x >> 4, l = threadIdx.x & 15;
+    float s = 0.f, k = 0.f;
+    if (pl < n_here)
+        for (int i = l; i < hw; i += 16) {
+            const float v = pl_sh[pl * hw + i];
+            s += v;
+            k += v > 0.f ? 1.f : 0.f;
+        }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 16);
+        k += __shfl_down(k, off, 16);
+    }
+    if (l == 0 && pl < n_here) {
+        y[p0 + pl] = s / pool_size;
+        if (cnt) cnt[p0 + pl] = k;
+    }
+}
+
+static void avgpool_global_launch(th_ctx *ctx, const float *d_x, float *d_y, float *d_cnt, long planes, int hw) {
+    if (hw <= 256 && planes >= 64)
+        hipLaunchKernelGGL(avgpool_global16_kernel, dim3(ceil_div(planes, 16)), dim3(256), (size_t)16 * hw * sizeof(float), ctx->stream, d_x, d_y,
+                           d_cnt, planes, hw, (float)hw);
+    else
+        hipLaunchKernelGGL(avgpool_global_kernel, dim3(ceil_div(planes, 4)), dim3(256), 0, ctx->stream, d_x, d_y, d_cnt, planes, hw, (float)hw);
+}
+
 // db[ch] = sum_n (g[n][ch] / hw) * cnt[n][ch] (+ the Adam update of that bias element, + carried deferred updates): the bias
 // gradient of Conv2dReLU -> global average pool from 2 n c floats instead of the n c hw conv outputs.
-__global__ __launch_bounds__(256) void bias_grad_counts_adam_kernel(const float *__restrict__ g, const float *__restrict__ cnt,
-                                                                    float *__restrict__ gb, int n, int c, int hw, AdamDev ad,
-                                                                    AdamSlices extra) {
+__global__ __launch_bounds__(1024) void bias_grad_counts_adam_kernel(const float *__restrict__ g, const float *__restrict__ cnt,
+                                                                     float *__restrict__ gb, int n, int c, int hw, AdamDev ad,
+                                                                     AdamSlices extra) {
     const int groups = (c + 15) / 16;
     if ((int)blockIdx.x >= groups) {
-        adam_slices_block(extra, blockIdx.x - groups);
+        if (threadIdx.x < 256) adam_slices_block(extra, blockIdx.x - groups);
         return;
     }
-    // 16 channels per workgroup: thread (r, q) sums images r, r + 16, ... of channel 16 blockIdx + q (64-byte segments)
-    __shared__ float sh[16][17];
+    // 16 channels per workgroup: thread (r, q) sums images r, r + 64, ... of channel 16 blockIdx + q (64-byte segments,
+    // every load of a thread independent of the others: the launch is one or two round trips long)
+    __shared__ float sh[64][17];
     const int q = threadIdx.x & 15, r = threadIdx.x >> 4, ch = blockIdx.x * 16 + q;
     float s = 0.f;
-    if (ch < c)
-        for (int b = r; b < n; b += 16) s += g[(long)b * c + ch] / (float)hw * cnt[(long)b * c + ch];
+    if (ch < c) {
+#pragma unroll 4
+        for (int b = r; b < n; b += 64) s += g[(long)b * c + ch] / (float)hw * cnt[(long)b * c + ch];
+    }
     sh[r][q] = s;
     __syncthreads();
     if (threadIdx.x < 16 && ch < c) {
         float tot = sh[0][q];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) tot += sh[i][q];
+        for (int i = 1; i < 64; ++i) tot += sh[i][q];
         gb[ch] = tot;
         if (ad.p) {
             const float step = adam_dev_step(ad);
@@ -1088,8 +1129,7 @@ int th_avgpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int n, int c, in
     const long total = (long)n * c * h_out * w_out;
     if (total == 0) return 0;
     if (k_h == h && k_w == w && pad_h == 0 && pad_w == 0) {  // global pool: one wave per plane
-        hipLaunchKernelGGL(avgpool_global_kernel, dim3(ceil_div((long)n * c, 4)), dim3(256), 0, ctx->stream, d_x, d_y, (float *)nullptr,
-                           (long)n * c, h * w, (float)(k_h * k_w));
+        th::avgpool_global_launch(ctx, d_x, d_y, nullptr, (long)n * c, h * w);
     } else {
         hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_y, total, h, w, h_out,
                            w_out, k_h, k_w, s_h, s_w, pad_h, pad_w);
@@ -1101,8 +1141,7 @@ int th_avgpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int n, int c, in
 int th_avgpool2d_global_fwd_counts(th_ctx *ctx, const float *d_x, float *d_y, float *d_cnt, int n, int c, int hw) {
     TH_REQUIRE(ctx && d_x && d_y && d_cnt && hw > 0, "th_avgpool2d_global_fwd_counts: null argument");
     if ((long)n * c == 0) return 0;
-    hipLaunchKernelGGL(avgpool_global_kernel, dim3(ceil_div((long)n * c, 4)), dim3(256), 0, ctx->stream, d_x, d_y, d_cnt, (long)n * c, hw,
-                       (float)hw);
+    th::avgpool_global_launch(ctx, d_x, d_y, d_cnt, (long)n * c, hw);
     TH_LAUNCH_CHECK();
     return 0;
 }
@@ -1112,7 +1151,7 @@ int th_bias_grad_counts_adam(th_ctx *ctx, const float *d_gout_pooled, const floa
     TH_REQUIRE(ctx && d_gout_pooled && d_cnt && d_gb && n > 0 && c > 0 && hw > 0, "th_bias_grad_counts_adam: null argument / empty tensor");
     TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_bias_grad_counts_adam: bad extra slices");
     const AdamSlices x = make_adam_slices(extra, n_extra);
-    hipLaunchKernelGGL(bias_grad_counts_adam_kernel, dim3(ceil_div(c, 16) + x.blocks()), dim3(256), 0, ctx->stream, d_gout_pooled, d_cnt,
+    hipLaunchKernelGGL(bias_grad_counts_adam_kernel, dim3(ceil_div(c, 16) + x.blocks()), dim3(1024), 0, ctx->stream, d_gout_pooled, d_cnt,
                        d_gb, n, c, hw, make_adam_dev(b_fuse), x);
     TH_LAUNCH_CHECK();
     return 0;
