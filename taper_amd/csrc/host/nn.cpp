@@ -944,9 +944,11 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
         yb_ = Buffer::alloc(chunk * bs);
     }
     if (!state_) state_ = Buffer::alloc(4);
-    if (metrics_cap_ < nb + 1) {
+    // the step log is sized for the loader's whole epoch even when this call stops early (max_steps): the captured graphs
+    // hold its address, and a short first call followed by a full epoch would otherwise drop and re-record every graph
+    if (metrics_cap_ < loader.num_batches() + 1) {
         drop_graphs();
-        metrics_cap_ = nb + 1;
+        metrics_cap_ = loader.num_batches() + 1;
         metrics_ = Buffer::alloc(2 * metrics_cap_);
     }
     TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // step = 0, cursor = 0
