@@ -354,7 +354,8 @@ def main():
         samples = int(dist.all_reduce_sum(samples))  # whole-job aggregate
 
     sustained = None
-    if world == 1 and args.settle_seconds == 0 and not args.no_roofline:
+    under_profiler = "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
+    if world == 1 and args.settle_seconds == 0 and not args.no_roofline and not under_profiler:   # (the trace is of the W + K run only)
         # the same K steps again after 0.25 s of continuous stepping: under sustained load the part settles at lower clocks
         # than it holds through the first ~50 ms of a run; both states are reported, `value` is the contract's W + K run
         T.Device.sync()
@@ -371,7 +372,6 @@ def main():
     if rank == 0:
         flops, nbytes = algorithmic_step(key, batch)
         roof = None
-        under_profiler = "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
         if key == "mlp_baseline" and under_profiler:
             # rocprofv3 (ROCm 7.2) segfaults in hipGraphLaunch once a process replays more than one
             # instantiated graph back to back; the Trainer's replays above are what the trace is for.
