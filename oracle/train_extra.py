@@ -351,3 +351,36 @@ def fit_schedule(val_losses, scheduler, lr0):
         scheduler.step(vl)
         lr = scheduler.get_lr()
     return lrs
+
+
+# ---- src/data/mnist.rs:184-274 (IDX ingestion) ----------------------------------------------------
+def load_idx_images(buffer: bytes):
+    """mnist.rs:184-233 load_images: 16-byte big-endian header {0x00000803, count, 28, 28}, then count*784 bytes; each
+    pixel becomes `u8 as f32 / 255.0` (:226).  Errors are the reference's `Err(String)` texts, raised as ValueError."""
+    if len(buffer) < 16:
+        raise ValueError("is too small")                                              # :190-192
+    magic = int.from_bytes(buffer[0:4], "big")
+    if magic != 0x00000803:
+        raise ValueError(f"Invalid magic number for images: {magic:#x}")              # :195-198
+    n, rows, cols = (int.from_bytes(buffer[o:o + 4], "big") for o in (4, 8, 12))
+    if rows != 28 or cols != 28:
+        raise ValueError(f"Unexpected image size: {rows}x{cols}")                      # :205-207
+    expected = 16 + n * 784
+    if len(buffer) != expected:
+        raise ValueError(f"File size mismatch. Expected {expected}, got {len(buffer)}")  # :209-217
+    px = np.frombuffer(buffer, dtype=np.uint8, offset=16).astype(f32) / f32(255.0)     # :223-228
+    return px.reshape(n, 784)
+
+
+def load_idx_labels(buffer: bytes):
+    """mnist.rs:236-274 load_labels: 8-byte header {0x00000801, count}, then count bytes, each `u8 as f32` (:268)."""
+    if len(buffer) < 8:
+        raise ValueError("is too small")                                              # :242-244
+    magic = int.from_bytes(buffer[0:4], "big")
+    if magic != 0x00000801:
+        raise ValueError(f"Invalid magic number for labels: {magic:#x}")              # :247-250
+    n = int.from_bytes(buffer[4:8], "big")
+    expected = 8 + n
+    if len(buffer) != expected:
+        raise ValueError(f"File size mismatch. Expected {expected}, got {len(buffer)}")  # :254-262
+    return np.frombuffer(buffer, dtype=np.uint8, offset=8).astype(f32)

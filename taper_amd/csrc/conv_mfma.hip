@@ -403,6 +403,9 @@ bool conv3x3_mfma_pool_supported(int c_in, int h, int w, int pad) {   // whole 2
            MF_CI * 4 * (w_out + 2) <= MF_PPT * 256;
 }
 
+// launch configuration of this thread's most recent matrix-core convolution (th_debug_last_conv_config)
+thread_local int t_last_conv_cfg[6] = {0, 0, 0, 0, 0, 0};
+
 int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
                         int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool) {
     TH_REQUIRE(w_ld % 4 == 0 && ((uintptr_t)w & 15) == 0, "conv3x3_mfma: weight rows must be 16-byte aligned");
@@ -453,6 +456,8 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     static const int wh_env = getenv("TAPER_CONV_WH") ? atoi(getenv("TAPER_CONV_WH")) : 0;   // tuning probe: 1 forces 4 waves
     // (with LDS-DMA staging there is no per-pass staging work left for extra waves to hide: 4 waves measure 2-6 % faster on those layers)
     const bool wh2 = ct >= 2 && wh_env != 1 && (wh_env == 2 || (!dma && (long)grid.x * grid.y < 768));
+    t_last_conv_cfg[0] = ct; t_last_conv_cfg[1] = (dma && !accum && ct >= 2 && cit != 1) ? 1 : 0; t_last_conv_cfg[2] = wh2 ? 2 : 1;
+    t_last_conv_cfg[3] = (int)grid.x; t_last_conv_cfg[4] = (int)grid.y; t_last_conv_cfg[5] = pool ? 1 : 0;
     if (pool) TH_MF_CT(false, true) else if (accum) TH_MF_CT(true, false) else TH_MF_CT(false, false)
 #undef TH_MF_CT
 #undef TH_MF
@@ -692,3 +697,9 @@ extern "C" int th_debug_conv_timeline(th_ctx *ctx, long long *h_out, int n_wg) {
     return 0;
 }
 #endif
+
+extern "C" int th_debug_last_conv_config(th_ctx *ctx, int *out6) {
+    TH_REQUIRE(ctx && out6, "th_debug_last_conv_config: null argument");
+    for (int i = 0; i < 6; ++i) out6[i] = th::t_last_conv_cfg[i];
+    return 0;
+}

@@ -416,6 +416,29 @@ FlatParams::FlatParams(const std::vector<Tensor> &ps) : params(ps) {
         offsets[i + 1] = offsets[i] + (int64_t)((ps[i].len() + 3) / 4 * 4);
     }
     total = offsets.back();
+    // A parameter list that an earlier optimizer already homed (the reference allows several optimizers over the same
+    // tensors: Adam re-created with another lr, SGD then Adam): adopt that optimizer's arenas, so both keep updating the
+    // storage every handle points at.  A list that only partly overlaps an existing arena cannot be laid out flat without
+    // detaching the earlier optimizer (its captured graphs and fused-update pointers would go stale): refuse it.
+    size_t homed = 0;
+    for (size_t i = 0; i < ps.size(); ++i) homed += (!ps[i].data_->owned && ps[i].data_->parent && ps[i].grad_->buf_is_arena) ? 1 : 0;
+    if (homed) {
+        std::shared_ptr<Buffer> P = ps[0].data_->parent, G = ps[0].grad_->buf ? ps[0].grad_->buf->parent : nullptr;
+        bool same = homed == ps.size() && P && G && (int64_t)P->n == total && (int64_t)G->n == total;
+        for (size_t i = 0; same && i < ps.size(); ++i)
+            same = ps[i].data_->parent == P && ps[i].data_->d == P->d + offsets[i] && ps[i].grad_->buf->parent == G &&
+                   ps[i].grad_->buf->d == G->d + offsets[i];
+        TAPER_ASSERT(same, "optimizer: some of these parameters already live in another optimizer's flat arena; build the new "
+                           "optimizer over the same parameter list (same order) or over parameters no optimizer holds yet");
+        p_arena = P;
+        g_arena = G;
+        d_offsets_buf = Buffer::alloc((ps.size() + 1) * 2);
+        d_has_grad_buf = Buffer::alloc(ps.size());
+        TH(th_memcpy_h2d(ctx, d_offsets_buf->d, offsets.data(), offsets.size() * sizeof(int64_t)));
+        uploaded_mask.assign(ps.size(), -1);
+        sync_mask();
+        return;
+    }
     p_arena = Buffer::alloc((size_t)total);
     g_arena = Buffer::alloc((size_t)total);
     TH(th_fill_f32(ctx, p_arena->d, 0.f, (size_t)total));
@@ -938,7 +961,10 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     const size_t n_full = std::min(nb, n / bs);
     // steps per replay: graph_chunk, capped so that the gathered batches of one chunk stay within 256 MB
     const size_t chunk = std::max<size_t>(std::min<size_t>(graph_chunk, ((size_t)1 << 26) / (bs * 784)), 1);
-    if (!xb_ || xb_->n < chunk * bs * 784) {
+    const float *d_img = ds.images.dptr(), *d_lab = ds.labels.dptr();
+    // full batch, index order (mnist.rs:355-363 without shuffle): the gather would be an identity copy of 188 MB
+    const int32_t *d_idx = (!loader.shuffled() && bs >= n && nb == 1) ? nullptr : loader.d_indices();
+    if (d_idx && (!xb_ || xb_->n < chunk * bs * 784)) {   // (the zero-copy form reads the dataset in place: no staging buffers)
         drop_graphs();
         xb_ = Buffer::alloc(chunk * bs * 784);
         yb_ = Buffer::alloc(chunk * bs);
@@ -952,11 +978,23 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
         metrics_ = Buffer::alloc(2 * metrics_cap_);
     }
     TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // step = 0, cursor = 0
-    const float *d_img = ds.images.dptr(), *d_lab = ds.labels.dptr();
-    // full batch, index order (mnist.rs:355-363 without shuffle): the gather would be an identity copy of 188 MB
-    const int32_t *d_idx = (!loader.shuffled() && bs >= n && nb == 1) ? nullptr : loader.d_indices();
-    const void *key = d_idx ? (const void *)d_img : (const void *)(reinterpret_cast<const char *>(d_img) + 1);   // the zero-copy form is a different graph
-    if (!graphs_.empty() && (graph_batch_ != bs || graph_key_ != key)) drop_graphs();
+    // Everything a captured step bakes in as a kernel argument or as a choice of launch sequence: the dataset and index
+    // buffers (two loaders over one dataset share the images but own their index vectors), the epoch length the gather
+    // wraps at, the label buffer, the fusion switches, the input reshape, the communicator, the optimizer's arenas.
+    // (nullptr indices = the zero-copy full-batch form, a different graph.)  Any mismatch re-records.
+    std::vector<uintptr_t> key{(uintptr_t)d_img, (uintptr_t)d_lab, (uintptr_t)d_idx, (uintptr_t)n, (uintptr_t)bs, (uintptr_t)fuse_head,
+                               (uintptr_t)fuse_adam, (uintptr_t)comm.get(), (uintptr_t)model.get(), (uintptr_t)optimizer.get(),
+                               (uintptr_t)optimizer->flat().p_arena->d, (uintptr_t)optimizer->flat().g_arena->d, (uintptr_t)(xb_ ? xb_->d : nullptr),
+                               (uintptr_t)metrics_->d};
+    for (size_t d : sample_shape) key.push_back((uintptr_t)d);
+    // beta1 / beta2 / eps / weight decay are kernel arguments BY VALUE (only lr and t live in device memory)
+    for (float h : {optimizer->beta1(), optimizer->beta2(), optimizer->eps(), optimizer->weight_decay()}) {
+        uint32_t bits;
+        std::memcpy(&bits, &h, sizeof bits);
+        key.push_back(bits);
+    }
+    key.push_back((uintptr_t)full_backward());
+    if (!graphs_.empty() && graph_key_ != key) drop_graphs();
 
     size_t done = 0;
     // Graph sizes still missing for this epoch length (a short first call -- e.g. a 2-step warm-up -- only
@@ -1003,7 +1041,6 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             graphs_.emplace_back(steps, g);
         }
         std::sort(graphs_.begin(), graphs_.end(), [](const auto &x, const auto &y) { return x.first > y.first; });   // largest first
-        graph_batch_ = bs;
         graph_key_ = key;
     }
     while (done < n_full) {

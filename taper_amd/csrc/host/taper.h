@@ -635,9 +635,8 @@ class Trainer {  // train.rs:74-172
     void enqueue_compute(float *d_xb, float *d_yb, size_t batch);
     void drop_graphs();
     std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
-    size_t graph_batch_ = 0;
     bool graph_capture_failed_ = false;
-    const void *graph_key_ = nullptr;
+    std::vector<uintptr_t> graph_key_;   // what the captured steps bake in (train_epoch_graph); a mismatch drops the graphs
     std::shared_ptr<Buffer> xb_, yb_, state_, metrics_, step_loss_, step_ncorrect_;
     size_t metrics_cap_ = 0;
 };

@@ -300,8 +300,13 @@ void Trainer::load_optimizer_state(const std::string &path) {
         m.insert(m.end(), pm.begin(), pm.end());
         v.insert(v.end(), pv.begin(), pv.end());
     }
+    // beta1 / beta2 / eps are constructor arguments of the optimizer (optim.rs:54-70): a state file written by an optimizer
+    // with other values does not describe this one's moments
+    TAPER_ASSERT(parse_f32(b1) == optimizer->beta1() && parse_f32(b2) == optimizer->beta2() && parse_f32(eps) == optimizer->eps(),
+                 "load_optimizer_state: beta1/beta2/eps in " + path + " (" + b1 + ", " + b2 + ", " + eps + ") differ from the optimizer's");
     optimizer->set_lr(parse_f32(lr));
-    optimizer->set_weight_decay(parse_f32(wd));
+    optimizer->set_weight_decay(parse_f32(wd));   // a kernel argument by value: captured steps are re-recorded (graph key)
+    drop_graphs();
     optimizer->load_state(t, m, v);
 }
 

@@ -36,8 +36,19 @@ class FileRendezvous:
             # all workers of one torchrun share the agent as parent and the master port
             key = f"{os.getppid()}_{_start_ticks(os.getppid())}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
         base = Path(root or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
-        self.dir = base / f"taper_rdzv_{key}"
-        self.dir.mkdir(parents=True, exist_ok=True)
+        self.dir = base / f"taper_rdzv_{os.getuid()}_{key}"
+        # /dev/shm and /tmp are world-writable and the name is predictable: the directory is private (0700), must be a real
+        # directory (not a symlink someone planted) and must belong to this user -- otherwise another local user could feed
+        # the ranks a forged RCCL unique id or hold the barriers
+        try:
+            os.mkdir(self.dir, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(self.dir)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError(f"rendezvous directory {self.dir} is not a private directory of uid {os.getuid()} "
+                                  f"(mode {st.st_mode & 0o7777:o}, uid {st.st_uid}); refusing to use it")
         self._seq = 0
 
     # -- primitives ---------------------------------------------------------
@@ -102,8 +113,9 @@ class FileRendezvous:
                     except OSError:
                         pass
                 self.dir.rmdir()
-        except Exception:
-            pass
+        except (OSError, TimeoutError) as e:     # best effort: a peer that died leaves the directory behind; say so
+            import sys
+            print(f"taper rendezvous: could not clean up {self.dir}: {e}", file=sys.stderr)
 
 
 def env_rank_world():

@@ -1,0 +1,195 @@
+"""BASELINE configs[2] AT FULL SIZE (batch 256): the kernel instances `bench.py` and rocprofv3 show at that size are
+chosen by workgroup count (`conv3x3_mfma_launch`: 4 channel tiles per workgroup once a launch has >= 384 of them, the
+LDS-DMA staging, the fused 2x2 pool), so the small-batch parity cases never reach them.  Here every conv layer of both
+CNNs runs at batch 256 against the oracle (`ot_conv2d`: /root/reference/src/tensor.rs:1221-1285,1728-1780, max-pool
+1391-1470), with the launch configuration asserted through th_debug_last_conv_config, and both whole models run their
+forward / backward / Adam steps at batch 256 -- eagerly AND through the Trainer's captured (fused) step, the form the
+bench times -- against the oracle's tape (examples/train_mnist_cnn.rs:27,154-182)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import backends
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from taper_amd import hip
+    c = hip.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def last_conv_config(ctx):
+    out = (C.c_int * 6)()
+    ctx.call("th_debug_last_conv_config", C.cast(out, C.c_void_p))
+    return dict(ct=out[0], dma=out[1], waves=4 * out[2], grid=(out[3], out[4]), pool=out[5])
+
+
+# n, c_in, hw, c_out, expected channel tiles per workgroup (the instances rocprofv3 lists for the batch-256 CNN steps)
+FULL_LAYERS = [
+    (256, 32, 28, 32, 2),    # reference CNN conv2 (+ pool)
+    (256, 32, 14, 64, 4),    # reference CNN conv3; simple CNN conv2 (+ pool)
+    (256, 64, 14, 64, 4),    # reference CNN conv4 (+ pool)
+    (256, 64, 7, 128, 2),    # reference CNN conv5: < 384 workgroups of 64 channels -> 32-channel blocks
+]
+
+
+@pytest.mark.parametrize("n,c_in,hw,c_out,ct", FULL_LAYERS)
+def test_conv3x3_full_size_layers(ctx, O, n, c_in, hw, c_out, ct):
+    rng = np.random.default_rng(c_in * 1000 + hw * 10 + c_out)
+    x = rng.uniform(-1, 1, (n, c_in, hw, hw)).astype(np.float32)
+    bound = np.sqrt(6.0 / (c_in * 9))                                   # nn.rs:219-222
+    wt = rng.uniform(-bound, bound, (c_out, c_in, 3, 3)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, c_out).astype(np.float32)
+    xt, wtt, bt = O.Tensor(x), O.Tensor(wt), O.Tensor(b)
+    ref = xt.conv2d_relu(wtt, bt, (1, 1), (1, 1), (1, 1))
+    ref_d = ref.data()
+    dx, dw, db = ctx.upload(x), ctx.upload(wt), ctx.upload(b)
+    y = ctx.empty(n * c_out * hw * hw)
+    ctx.call("th_conv3x3_fwd", dx, dw, db, y, n, c_in, hw, hw, c_out, 1, 0, 1)
+    cfg = last_conv_config(ctx)
+    assert cfg["ct"] == ct and cfg["dma"] == 1 and cfg["pool"] == 0, cfg
+    assert cfg["grid"][0] * cfg["grid"][1] >= 256, cfg                 # a chip-filling launch, not the small-batch shape
+    got = ctx.download(y, ref_d.shape)
+    np.testing.assert_allclose(got, ref_d, rtol=RTOL, atol=1e-5)
+    # no ReLU, no bias (the pre-activation itself)
+    ctx.call("th_conv3x3_fwd", dx, dw, None, y, n, c_in, hw, hw, c_out, 1, 0, 0)
+    ref2 = xt.conv2d(wtt, None, (1, 1), (1, 1), (1, 1)).data()
+    np.testing.assert_allclose(ctx.download(y, ref2.shape), ref2, rtol=RTOL, atol=1e-5)
+    # fused 2x2 / stride-2 max-pool epilogue vs the oracle's conv2d_relu -> max_pool2d (values; the fused form keeps no indices)
+    if hw % 2 == 0:
+        assert ctx_supported(ctx, c_in, hw, c_out)
+        yp = ctx.empty(n * c_out * (hw // 2) ** 2)
+        ctx.call("th_conv3x3_pool2_fwd", dx, dw, db, yp, n, c_in, hw, hw, c_out, 1, 1)
+        cfg = last_conv_config(ctx)
+        assert cfg["ct"] == ct and cfg["pool"] == 1 and cfg["dma"] == 1, cfg
+        pooled = ref.max_pool2d((2, 2), (2, 2), (0, 0)).data()
+        np.testing.assert_allclose(ctx.download(yp, pooled.shape), pooled, rtol=RTOL, atol=1e-5)
+        # and bit-identical to the unfused HIP pair (same fmaf chain, max is exact)
+        ctx.call("th_conv3x3_fwd", dx, dw, db, y, n, c_in, hw, hw, c_out, 1, 0, 1)
+        np.testing.assert_array_equal(ctx.download(yp, pooled.shape), got.reshape(n, c_out, hw // 2, 2, hw // 2, 2).max(axis=(3, 5)))
+
+
+def ctx_supported(ctx, c_in, hw, c_out):
+    from taper_amd import hip
+    return hip.hip.th_conv3x3_pool2_supported(c_in, hw, hw, c_out, 1) == 1
+
+
+def test_conv1_full_size(ctx, O):
+    """conv1 of both CNNs at batch 256 (single input channel: the dedicated kernels, plain and pooled)"""
+    rng = np.random.default_rng(1)
+    n = 256
+    x = (rng.integers(0, 256, (n, 1, 28, 28)).astype(np.float32) / np.float32(255.0))
+    wt = rng.uniform(-0.8, 0.8, (32, 1, 3, 3)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, 32).astype(np.float32)
+    ref = O.Tensor(x).conv2d_relu(O.Tensor(wt), O.Tensor(b), (1, 1), (1, 1), (1, 1))
+    dx, dw, db = ctx.upload(x), ctx.upload(wt), ctx.upload(b)
+    y = ctx.empty(n * 32 * 28 * 28)
+    ctx.call("th_conv3x3_fwd", dx, dw, db, y, n, 1, 28, 28, 32, 1, 0, 1)
+    np.testing.assert_allclose(ctx.download(y, ref.shape()), ref.data(), rtol=RTOL, atol=1e-5)
+    yp = ctx.empty(n * 32 * 14 * 14)
+    ctx.call("th_conv3x3_pool2_fwd", dx, dw, db, yp, n, 1, 28, 28, 32, 1, 1)
+    pooled = ref.max_pool2d((2, 2), (2, 2), (0, 0)).data()
+    np.testing.assert_allclose(ctx.download(yp, pooled.shape), pooled, rtol=RTOL, atol=1e-5)
+
+
+def test_maxpool_full_size_bit_exact(ctx, O):
+    """[256,32,28,28] -> [256,32,14,14] (tensor.rs:1391-1470): values and absolute flat indices bit-exact, then the backward"""
+    rng = np.random.default_rng(2)
+    n, c, hw = 256, 32, 28
+    x = rng.integers(-6, 7, (n, c, hw, hw)).astype(np.float32)      # many ties: the first maximum must win
+    y_ref, idx_ref = O.Tensor(x).max_pool2d((2, 2), (2, 2), (0, 0), return_indices=True)
+    dx = ctx.upload(x)
+    y, idx = ctx.empty(n * c * 14 * 14), ctx.empty(n * c * 14 * 14, np.int64)
+    ctx.call("th_maxpool2d_fwd", dx, y, idx, n, c, hw, hw, 2, 2, 2, 2, 0, 0)
+    np.testing.assert_array_equal(ctx.download(y, y_ref.shape()), y_ref.data())
+    np.testing.assert_array_equal(ctx.download(idx, idx_ref.shape, np.int64), idx_ref)
+
+
+MODELS = {"cnn_simple": backends.cnn_simple, "cnn_reference": backends.cnn_reference}
+
+
+def _grads_close(h_grads, o_grads):
+    assert len(h_grads) == len(o_grads)
+    for i, (hg, og) in enumerate(zip(h_grads, o_grads)):
+        assert (hg is None) == (og is None), f"param {i}: grad None-ness differs"
+        if og is not None:
+            scale = float(np.abs(og).max())
+            np.testing.assert_allclose(hg, og, rtol=RTOL, atol=2e-4 * scale + 1e-8, err_msg=f"param {i}")
+
+
+@pytest.mark.parametrize("name", ["cnn_simple", "cnn_reference"])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_cnn_forward_backward_parity_batch_256(name, fuse):
+    """examples/train_mnist_cnn.rs:27 -- the whole model at its real batch: logits, loss, accuracy, every gradient
+    (and which ones are None, Q2) against the oracle's tape"""
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(256 + len(name))
+    batch = 256
+    spec = backends.nonzero_biases(MODELS[name](rng), rng)
+    x, y = backends.mnist_like(rng, batch)
+    shape = (batch, 1, 28, 28)
+    hm, om = H.sequential(spec, fuse=fuse), Orc.sequential(spec)
+    h_loss, h_acc, h_logits, h_grads = H.forward_backward(hm, x, y, shape)
+    o_loss, o_acc, o_logits, o_grads = Orc.forward_backward(om, x, y, shape)
+    np.testing.assert_allclose(h_logits, o_logits, rtol=RTOL, atol=RTOL * float(np.abs(o_logits).max()))
+    assert abs(h_loss - o_loss) <= RTOL * max(1.0, abs(o_loss))
+    assert abs(h_acc - o_acc) <= 1.0 / batch
+    _grads_close(h_grads, o_grads)
+    assert h_grads[0] is None and o_grads[0] is None     # Q2: conv weights never receive gradients
+
+
+@pytest.mark.parametrize("name", ["cnn_simple", "cnn_reference"])
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_cnn_training_steps_parity_batch_256(name, mode):
+    """3 Adam steps (lr 1e-2, wd 1e-4: train_mnist_cnn.rs:108-109) at batch 256 -- `graph` is the Trainer's captured,
+    fused step (conv + pool in one launch, pooled bias gradients, fused classifier tail, Adam in the epilogues): exactly
+    what bench.py times for the CNN workloads -- per-step loss / hit count and every weight against the oracle"""
+    import taper_amd as T
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(11 + len(name))
+    batch, steps, lr = 256, 3, 1e-2
+    spec = backends.nonzero_biases(MODELS[name](rng), rng)
+    hm, om = H.sequential(spec), Orc.sequential(spec)
+    hopt = T.Adam(hm.parameters(), lr, None, None, 1e-4)
+    oopt = Orc.m.Adam(om.parameters(), lr, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt, sample_shape=(1, 28, 28))
+    x, y = backends.mnist_like(rng, steps * batch)
+    ref = [om.train_step(oopt, x[s * batch:(s + 1) * batch], y[s * batch:(s + 1) * batch], (batch, 1, 28, 28)) for s in range(steps)]
+    if mode == "graph":
+        ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False), T.Trainer.GRAPH)
+        losses, ncorrect = ep["losses"], ep["ncorrect"]
+        cfg = last_conv_config_host()
+        assert cfg["ct"] in (2, 4) and cfg["dma"] == 1, cfg        # the matrix-core conv ran in this process's step
+    else:
+        losses, ncorrect = [], []
+        for s in range(steps):
+            l, a = tr.train_step(T.Tensor(x[s * batch:(s + 1) * batch]), T.Tensor(y[s * batch:(s + 1) * batch]))
+            losses.append(l)
+            ncorrect.append(a * batch)
+    np.testing.assert_allclose(losses, [r["loss"] for r in ref], rtol=3e-4, atol=1e-5)
+    assert np.abs(np.asarray(ncorrect) - np.asarray([r["acc"] * batch for r in ref])).max() <= 1.5
+    for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+        np.testing.assert_allclose(hp.data(), op.data(), rtol=RTOL, atol=lr * 2e-2, err_msg=f"param {i}")
+    assert hopt.t() == steps
+
+
+def last_conv_config_host():
+    """the host library enqueues on its own context but on the calling thread: same thread-local record"""
+    import taper_amd as T
+    from taper_amd import hip
+    c = hip.Ctx(handle=T.Device.ctx_handle())
+    return last_conv_config(c)
