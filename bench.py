@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of taper's training hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, or self-spawned)
 
 A "step" is one pass of the hot path over one batch of synthetic MNIST-shaped
 input already resident in HBM: gather batch -> forward -> softmax cross-entropy
 -> backward -> (N > 1: RCCL all-reduce of the flat grad arena) -> Adam -> log,
 replayed as one hipGraph (host: C++ tape in libtaper_host.so; device: the HIP
-kernels of libtaper_hip.so through the C ABI).  Default workload =
-BASELINE.json configs[1]: MLP 784-128-10, batch 64 per GPU, Adam(1e-3, wd 1e-4).
+kernels of libtaper_hip.so through the C ABI).  Headline workload at N = 1 =
+BASELINE.json configs[1]: MLP 784-128-10, batch 64, Adam(1e-3, wd 1e-4); at N > 1 = configs[3]: the same MLP at
+128 rows per GPU (global 1024 at N = 8), with the single-GPU figure of the same per-GPU batch printed beside it.
 
 Prints ONE JSON line (rank 0) with the BASELINE metric plus `roofline` (the
-dominant kernel timed live with HIP events) and `cpu_baseline` (the C
-restatement of the reference's CPU path, timed on this box's host cores).
+dominant kernel timed live with HIP events), `cpu_baseline` (the C restatement of the reference's CPU path, timed on
+this box's host cores) and, at N = 1, `workloads`: the other BASELINE configs (both CNNs at batch 256, the example
+MLP, the 4096-wide Linear stack and the 4096^3 sgemm variants), each with its step time, per-kernel roofline
+fractions and its own CPU baseline.
 """
 from __future__ import annotations
 
@@ -93,10 +96,31 @@ def barrier_sync(rdzv, T):
         rdzv.barrier()
 
 
-def make_comm(rdzv, T):
+def make_comm(rdzv, T, backend, optimizer):
+    """backend auto: the one-shot peer-to-peer all-reduce fused with Adam when every rank can map its peers and the
+    self-check passes, RCCL otherwise (the reason is reported)"""
     from taper_amd.dist import init_data_parallel
-    comm = init_data_parallel(T, rdzv)
-    return comm, ("rccl" if comm is not None else "none")
+    if rdzv is None:
+        return None, "none"
+    if backend in ("auto", "p2p"):
+        try:
+            return init_data_parallel(T, rdzv, backend="p2p", optimizer=optimizer), "p2p one-shot all-reduce + Adam (th_allreduce_adam) over xGMI"
+        except RuntimeError as e:
+            if backend == "p2p":
+                raise
+            why = f" (p2p unavailable: {e})"
+    else:
+        why = ""
+    return init_data_parallel(T, rdzv, backend="rccl"), "rccl ncclAllReduce(avg)" + why
+
+
+def replicas_identical(rdzv, model):
+    """crc32 of every rank's weights, compared on every rank (data-parallel replicas must stay bit-identical: SURVEY 8e)"""
+    import zlib
+    crc = 0
+    for prm in model.parameters():
+        crc = zlib.crc32(prm.data().tobytes(), crc)
+    return len(set(rdzv.all_gather_bytes(crc.to_bytes(4, "little")))) == 1
 
 
 # ---------------------------------------------------------------------------- the timed loop
@@ -223,17 +247,18 @@ class StepKernels:
         return dict(step_us=round(full, 3), kernels=out)
 
 
-def batch_sweep(T, build_model, key, lr, dataset_size, batches=(256, 1024, 4096, 16384, 60000)):
+def batch_sweep(T, build_model, key, lr, dataset, batches=(64, 256, 1024, 4096, 16384, 60000)):
     """SURVEY.md 8(d) batch sweep of the same model / optimizer / step on one GPU (fresh model per point; the
-    headline `value` stays BASELINE configs[1], batch 64): where the path stops being launch-bound."""
+    headline `value` stays BASELINE configs[1], batch 64, at the contract's K steps; these are long runs):
+    where the path stops being launch-bound."""
     out = []
     for b in batches:
-        if b > dataset_size:
+        if b > dataset.len():
             continue
         model = build_model(T, key)
         opt = T.Adam(model.parameters(), lr, None, None, 1e-4)
         trainer = T.Trainer(model, opt)
-        loader = T.DataLoader(T.MNISTDataset.synthetic(dataset_size, seed=0x7461706572), b, False)
+        loader = T.DataLoader(dataset, b, False)
         steps = min(80_000, max(200, 20_000_000 // b))   # >= 150 ms of work per point: short bursts run below the steady clocks
         run_steps(T, trainer, loader, max(steps // 8, 3))
         T.Device.sync()
@@ -261,36 +286,309 @@ def pmc_traffic(workload, kernel):
     return None, None
 
 
-def cpu_baseline(key, batch, sample_shape, lr, budget_s=12.0):
-    """The reference's CPU path (C restatement: oracle/, kind 'port'), 1 thread, timed on
-    this host on a bounded sample of the same workload (~budget_s seconds of CPU work)."""
-    from oracle import oracle as O
+# ---------------------------------------------------------------------------- CPU baseline (reported, never the target)
+_FAST_ORACLE = {}
+
+
+def _cpu_model():
     try:
-        so = O.build_native(tempfile.mkdtemp(prefix="taper_oracle_native_"))   # -march=native for THIS box
-        O.use_library(so)
-        flavour = "-O3 -march=native"
-    except Exception:
-        flavour = "-O3 -mavx -mfma (prebuilt)"
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(key, batch, sample_shape, lr, budget_s=8.0):
+    """The reference's CPU path on THIS box's host cores, on a bounded sample of the same workload (about budget_s
+    seconds of steps).  kind "port": the Rust crate cannot be built here (no cargo/rustc), so this is the C
+    restatement of the reference (oracle/) in its cpu_baseline build (`make -C oracle fast`, gcc -O3 -march=native =
+    .cargo/config.toml's target-cpu=native):
+      sgemm            packed, register-blocked FMA micro-kernel in matrixmultiply's style, ONE thread -- the reference's
+                       default feature set has no `threading` (Cargo.toml:16; src/gemm.rs:102-117)
+      im2col windows, max/avg-pool planes (fwd + bwd), batch gather
+                       thread-parallel like the reference's rayon loops (src/tensor.rs:1420,1491,1552,1614,1745;
+                       src/data/mnist.rs:291); thread count = the best of a short trial over {all logical CPUs, 16, 1}
+      everything else  the reference's scalar / auto-vectorised loops, one thread (Adam, softmax chain, transposes, bias)
+    plus, when a vendor CBLAS exists on the box (numpy's bundled OpenBLAS), the `--features blas` analogue with every
+    sgemm routed through cblas_sgemm (src/gemm.rs:32-47) at the vendor's default thread count."""
+    from oracle import oracle as O
     from tests import backends
-    rng = np.random.default_rng(1)
-    spec = getattr(backends, key)(rng)
-    ob = backends.get("oracle")
-    ob.set_zero_sentinel(True)
-    model = ob.sequential(spec)
-    opt = O.Adam(model.parameters(), lr, None, None, 1e-4)
-    x, y = backends.mnist_like(rng, batch)
+    if "so" not in _FAST_ORACLE:
+        _FAST_ORACLE["so"] = O.build_fast(tempfile.mkdtemp(prefix="taper_oracle_fast_"))   # -march=native for THIS box
+        O.use_library(_FAST_ORACLE["so"])
+        _FAST_ORACLE["cblas"] = O.find_cblas()
+    lib = O.lib
+    ncpu = os.cpu_count() or 1
     shape = (batch, 784) if sample_shape is None else (batch,) + tuple(sample_shape)
-    model.train_step(opt, x, y, shape)   # warm-up
-    t0, n = time.perf_counter(), 0
-    while True:
-        model.train_step(opt, x, y, shape)
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
+    rng = np.random.default_rng(1)
+    x, y = backends.mnist_like(rng, batch * 8)
+
+    def fresh():
+        ob = backends.get("oracle")
+        ob.set_zero_sentinel(True)
+        model = ob.sequential(getattr(backends, key)(np.random.default_rng(1)))
+        return model, O.Adam(model.parameters(), lr, None, None, 1e-4)
+
+    def timed(threads, seconds, cblas=None):
+        lib.ot_baseline_set_threads(int(threads))
+        lib.ot_baseline_set_cblas(cblas[0] if cblas else None, cblas[1] if cblas else 0)
+        model, opt = fresh()
+        model.run_steps(opt, x, y, shape, 1)      # warm-up (allocations, thread pool)
+        n, chunk, t0 = 0, 1, time.perf_counter()
+        while True:
+            model.run_steps(opt, x, y, shape, chunk)
+            n += chunk
+            dt = time.perf_counter() - t0
+            if dt > seconds:
+                break
+            chunk = max(1, min(int(n / dt * 0.25) or 1, 4096))   # ~0.25 s of steps per C call
+        lib.ot_baseline_set_cblas(None, 0)
+        return n, dt
+
+    trials = {}
+    for th in sorted({ncpu, min(16, ncpu), 1}, reverse=True):
+        n, dt = timed(th, min(1.0, budget_s / 8))
+        trials[th] = round(n * batch / dt, 1)
+    best = max(trials, key=trials.get)
+    n, dt = timed(best, budget_s * 0.55)
+    out = dict(value=n * batch / dt, unit="samples/s", cores=best, kind="port", cpu_model=_cpu_model(), nproc=ncpu,
+               threads={"sgemm": 1, "im2col/pool/gather loops": best, "adam/softmax/transpose/bias": 1},
+               threads_tried_samples_per_s={str(k): v for k, v in trials.items()},
+               sample=f"{n} steps of {key} batch {batch} (get_batch + fwd + xent + bwd + Adam) in {dt:.1f}s; C restatement of the reference "
+                      f"CPU path, gcc -O3 -march=native -fopenmp: packed FMA sgemm (matrixmultiply-style, 1 thread) + rayon-style "
+                      f"plane loops on {best} thread(s)")
+    if _FAST_ORACLE["cblas"] is not None:
+        addr, ilp64, what, _keep = _FAST_ORACLE["cblas"]
+        try:
+            n2, dt2 = timed(best, budget_s * 0.25, (addr, ilp64))
+            out["blas_feature"] = dict(value=n2 * batch / dt2, unit="samples/s", lib=what, sgemm_threads="vendor default",
+                                       sample=f"{n2} steps in {dt2:.1f}s with every sgemm through cblas_sgemm (src/gemm.rs:32-47)")
+        except Exception as e:   # reported, never required
+            out["blas_feature"] = dict(value=None, error=str(e))
+    return out
+
+
+# ---------------------------------------------------------------------------- the other BASELINE configs (N = 1)
+def _time_launches(ctx, call, reps, warm=5):
+    """us per launch: `reps` back-to-back launches on the ctx stream between two HIP events"""
+    from taper_amd import hip
+    for _ in range(warm):
+        call()
+    e0, e1 = hip.Event(), hip.Event()
+    ctx.record(e0)
+    for _ in range(reps):
+        call()
+    ctx.record(e1)
+    return hip.Ctx.elapsed_ms(e0, e1) * 1e3 / reps
+
+
+def conv_layer_kernels(ctx, layers, reps=60):
+    """The conv launches of a CNN step at batch 256, each timed on its own (back-to-back launches of the layer through the
+    C ABI, HIP events on the ctx stream).  Algorithmic work per launch (SURVEY.md 8d): 18*C_in*C_out*H*W flop per sample;
+    bytes = input + output (+ weights once), the pooled form writes a quarter of the output.  Bound: fp32 MFMA
+    (157.3 TF) for C_in >= 8; the single-channel conv1 (4.4 flop/B) is bound by HBM."""
+    rng = np.random.default_rng(0)
+    out = []
+    for (name, n, ci, hw, co, pool) in layers:
+        x = ctx.upload(rng.uniform(0, 1, (n, ci, hw, hw)).astype(np.float32))
+        w = ctx.upload(rng.uniform(-0.1, 0.1, (co, ci, 3, 3)).astype(np.float32))
+        b = ctx.upload(rng.uniform(-0.1, 0.1, co).astype(np.float32))
+        ho = hw // 2 if pool else hw
+        y = ctx.empty(n * co * ho * ho)
+        if pool:
+            call = lambda: ctx.call("th_conv3x3_pool2_fwd", x, w, b, y, n, ci, hw, hw, co, 1, 1)
+        else:
+            call = lambda: ctx.call("th_conv3x3_fwd", x, w, b, y, n, ci, hw, hw, co, 1, 0, 1)
+        us = _time_launches(ctx, call, reps)
+        cfg = (C.c_int * 6)()
+        ctx.call("th_debug_last_conv_config", C.cast(cfg, C.c_void_p))
+        flops = 18.0 * ci * co * hw * hw * n
+        nbytes = 4.0 * (n * ci * hw * hw + n * co * ho * ho + 9 * ci * co + co)
+        tf, gbs = flops / (us * 1e-6) / 1e12, nbytes / (us * 1e-6) / 1e9
+        kern = ("conv1_pool2_kernel" if pool else "conv1_kernel") if ci == 1 else \
+            f"conv3x3_mfma_kernel<{cfg[0]}, false, 8, {'true' if pool else 'false'}, {cfg[2]}, {'true' if cfg[1] else 'false'}>"
+        bound = "hbm" if ci == 1 else "mfma"
+        out.append(dict(kernel=kern, layer=name, us_per_launch=round(us, 2), alg_flops_per_launch=flops, alg_bytes_per_launch=nbytes,
+                        bound=bound, achieved=round(gbs if bound == "hbm" else tf, 2), peak=HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TF,
+                        unit="GB/s" if bound == "hbm" else "TFLOP/s",
+                        frac=round((gbs / HBM_PEAK_GBS) if bound == "hbm" else (tf / MFMA_F32_PEAK_TF), 4)))
+        del x, w, b, y
+    return out
+
+
+CNN_LAYERS = {
+    # (layer, batch, C_in, H = W, C_out, fused 2x2 max-pool epilogue) -- the launches the Trainer's captured step issues
+    "cnn_simple": [("conv1+pool 1->32 @28", 256, 1, 28, 32, True), ("conv2+pool 32->64 @14", 256, 32, 14, 64, True)],
+    "cnn_reference": [("conv1 1->32 @28", 256, 1, 28, 32, False), ("conv2+pool 32->32 @28", 256, 32, 28, 32, True),
+                      ("conv3 32->64 @14", 256, 32, 14, 64, False), ("conv4+pool 64->64 @14", 256, 64, 14, 64, True),
+                      ("conv5 64->128 @7", 256, 64, 7, 128, False)],
+}
+
+
+_KEEP_ALIVE = []
+
+
+def trainer_workload(T, name, dataset, steps=None):
+    """one of WORKLOADS through the Trainer's captured step (what the headline measures, another model / batch)"""
+    key, batch, sample_shape, lr = WORKLOADS[name]
+    model = build_model(T, key)
+    opt = T.Adam(model.parameters(), lr, None, None, 1e-4)
+    trainer = T.Trainer(model, opt, sample_shape=sample_shape)
+    loader = T.DataLoader(dataset, batch, False)
+    steps = steps or 2000
+    run_steps(T, trainer, loader, 260)              # untimed: records every graph size of the replay ladder
+    T.Device.sync()
+    t_w = time.perf_counter()                       # ... and >= 0.25 s of stepping: the CPU legs in between leave the part idle,
+    while time.perf_counter() - t_w < 0.25:         # and it takes tens of ms of load to come back to its running clocks
+        run_steps(T, trainer, loader, 200)
+        T.Device.sync()
+    t0 = time.perf_counter()
+    samples = run_steps(T, trainer, loader, steps)
+    T.Device.sync()
     dt = time.perf_counter() - t0
-    return dict(value=n * batch / dt, unit="samples/s", cores=1, kind="port",
-                sample=f"{n} steps of {key} batch {batch} in {dt:.1f}s; C restatement of the reference CPU tape "
-                       f"(gcc {flavour}, 1 thread = matrixmultiply without its threading feature); host has {os.cpu_count()} cpus")
+    flops, nbytes = algorithmic_step(key, batch)
+    rec = dict(workload=name, per_gpu_batch=batch, optimizer=f"Adam(lr={lr}, wd=1e-4)", steps=steps, ms_per_step=round(dt / steps * 1e3, 5),
+               samples_per_s=round(samples / dt, 1), step="hipGraph replay of gather+fwd+xent+bwd+adam+log")
+    if flops:
+        rec["step_roofline"] = {"alg_flops_per_step": flops, "alg_bytes_per_step": nbytes,
+                                "hbm_frac": round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 6),
+                                "mfma_frac": round(flops / (dt / steps) / 1e12 / MFMA_F32_PEAK_TF, 6)}
+    _KEEP_ALIVE.append((trainer, opt, model, loader))   # (rocprofv3 on ROCm 7.2 crashes in the next hipGraphLaunch after a hipGraphExecDestroy)
+    return rec, key, batch, sample_shape, lr
+
+
+def sgemm_kernels(ctx, size=4096, reps=120):
+    """BASELINE configs[4] / north_star "Linear-layer GEMM at >= 60 % MFMA peak on 4096^3 fp32": the three products of a
+    Linear layer's step -- forward X.W^T (NT), dX = dZ.W (NN), dW = dZ^T.X (TN, accumulating: beta = 1) -- through
+    th_sgemm (= src/gemm.rs:72-119 argument semantics), >= 100 back-to-back launches each (the part needs ~100 ms of
+    matrix load to settle its clocks).  2mnk flop, 4(mk + kn + mn) B (+ 4mn when beta != 0) per launch."""
+    rng = np.random.default_rng(0)
+    m = n = k = size
+    a = ctx.upload(rng.uniform(-1, 1, m * k).astype(np.float32))
+    b = ctx.upload(rng.uniform(-1, 1, k * n).astype(np.float32))
+    c = ctx.zeros(m * n)
+    out = []
+    for name, ta, tb, beta in (("NT (forward X.W^T)", 0, 1, 0.0), ("NN (dX = dZ.W)", 0, 0, 0.0), ("TN (dW += dZ^T.X)", 1, 0, 1.0)):
+        us = _time_launches(ctx, lambda: ctx.call("th_sgemm", ta, tb, m, n, k, 1.0, a, b, beta, c), reps, warm=10)
+        flops, nbytes = 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n * (2 if beta else 1))
+        tf = flops / (us * 1e-6) / 1e12
+        out.append(dict(kernel="sgemm_tile<128, ...>", variant=name, m=m, n=n, k=k, beta=beta, us_per_launch=round(us, 1), alg_flops_per_launch=flops,
+                        alg_bytes_per_launch=nbytes, bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                        frac=round(tf / MFMA_F32_PEAK_TF, 4)))
+    return out
+
+
+def linear_stack_workload(T, layers=4, width=4096, batch=4096, steps=12, warmup=4):
+    """BASELINE configs[4]: `layers` x (Linear(4096, 4096) + ReLU) + Linear(4096, 10), batch 4096, fp32: Tape::reset ->
+    forward -> cross_entropy_loss -> backward -> Adam::step through the op-by-op host API (every product is ~1 ms: no
+    step graph).  Algorithmic flops: (3L - 1) products of 2*B*W*W (the first layer has no dX) + the
+    classifier's three + 14 / parameter for Adam."""
+    L, W, B = layers, width, batch
+    mods = []
+    for i in range(L):
+        mods += [T.Linear(W, W, True, 1 + i), T.ReLU()]
+    mods.append(T.Linear(W, 10, True, 1 + L))
+    model = T.Sequential(mods)
+    opt = T.Adam(model.parameters(), 1e-4, None, None, 1e-4)
+    rng = np.random.default_rng(7)
+    x = T.Tensor(rng.uniform(0, 1, (B, W)).astype(np.float32))
+    y = T.Tensor(rng.integers(0, 10, B).astype(np.float32))
+
+    def step():
+        T.Tape.reset()
+        opt.zero_grad()
+        loss = T.cross_entropy_loss(model.forward(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    T.Device.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    T.Device.sync()
+    dt = (time.perf_counter() - t0) / steps
+    params = L * (W * W + W) + W * 10 + 10
+    flops = (3 * L - 1) * 2.0 * B * W * W + 3 * 2.0 * B * W * 10 + 14.0 * params
+    rec = dict(workload=f"linear_stack_{W}x{L}_b{B}", per_gpu_batch=B, steps=steps, ms_per_step=round(dt * 1e3, 4), samples_per_s=round(B / dt, 1),
+               step="eager op-by-op host API (Tape::reset, forward, cross_entropy_loss, backward, Adam::step)", alg_flops_per_step=flops,
+               tflops=round(flops / dt / 1e12, 2), frac_of_mfma_peak=round(flops / dt / 1e12 / MFMA_F32_PEAK_TF, 4),
+               loss_last=round(float(loss.data()[0]), 5))
+    del model, opt, x, y
+    T.Tape.reset()
+    return rec
+
+
+def extra_workloads(T, dataset, with_cpu, only=None):
+    """the BASELINE configs besides the headline, each on the same line (N = 1)"""
+    from taper_amd import hip
+    ctx = hip.Ctx(handle=T.Device.ctx_handle())
+    out = []
+    for name in ("cnn_simple_b256", "cnn_reference_b256", "mlp_784-128-64-10_b256"):
+        if only and name not in only:
+            continue
+        try:
+            rec, key, batch, sample_shape, lr = trainer_workload(T, name, dataset)
+            if key in CNN_LAYERS:
+                rec["kernels"] = conv_layer_kernels(ctx, CNN_LAYERS[key])
+                rec["conv_us_per_step"] = round(sum(k["us_per_launch"] for k in rec["kernels"]), 1)
+            if with_cpu and key != "mlp_example":
+                try:
+                    rec["cpu_baseline"] = cpu_baseline(key, batch, sample_shape, lr, budget_s=7.0)
+                except Exception as e:
+                    rec["cpu_baseline"] = dict(value=None, kind="port", sample=f"failed: {e}")
+        except Exception as e:   # one workload failing must not lose the line
+            rec = dict(workload=name, error=str(e))
+        out.append(rec)
+    if not only or "linear_stack_4096x4_b4096" in only:
+        try:
+            rec = linear_stack_workload(T)
+            rec["kernels"] = sgemm_kernels(ctx)
+        except Exception as e:
+            rec = dict(workload="linear_stack_4096x4_b4096", error=str(e))
+        out.append(rec)
+    return out
+
+
+# ---------------------------------------------------------------------------- launcher
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* exactly as torch.distributed.run would set them), one per GPU; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    from taper_amd import hip
+    have = hip.device_count()
+    if have < n and os.environ.get("TAPER_BENCH_SHARE_DEVICE") != "1":   # (test hook: every rank on GPU 0, p2p backend only)
+        sys.exit(f"bench.py: --gpus {n} but only {have} GPU(s) visible; refusing to run a smaller job under that name")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", TAPER_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def timed_run(T, dist, trainer, loader, steps):
+    """barrier + stream sync, exactly `steps` steps, barrier + stream sync; MAX over ranks, samples summed over ranks"""
+    barrier_sync(dist, T)
+    t0 = time.perf_counter()
+    samples = run_steps(T, trainer, loader, steps)
+    barrier_sync(dist, T)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dt = dist.all_reduce_max(dt)
+        samples = int(dist.all_reduce_sum(samples))
+    return samples, dt
 
 
 def main():
@@ -298,7 +596,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--workload", default="mlp_784-128-10_b64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: mlp_784-128-10_b64 (BASELINE configs[1]) at N = 1, mlp_784-128-10_b128 (configs[3]) at N > 1")
     ap.add_argument("--dataset-size", type=int, default=60000)
     ap.add_argument("--batch", type=int, default=0, help="override the workload's per-GPU batch (SURVEY 8d batch sweep)")
     ap.add_argument("--graph-chunk", type=int, default=0, help="steps per hipGraph replay (0: the Trainer's default)")
@@ -308,13 +607,22 @@ def main():
                     help="CNN workloads: train the conv weights too (extension; the reference cuts the tape there, quirk Q2)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel timing after the timed region")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch sweep (SURVEY 8d) reported beside the headline value")
+    ap.add_argument("--dp-backend", default="auto", choices=["auto", "p2p", "rccl"],
+                    help="N > 1 gradient exchange: p2p = one-shot peer-to-peer all-reduce fused with Adam, rccl = ncclAllReduce; auto = p2p "
+                         "when its self-check passes, else rccl")
+    ap.add_argument("--workloads", default="all", help="N = 1: the other BASELINE configs reported beside the headline: all | none | comma list")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args.gpus)          # never returns
     import taper_amd as T
     dist, rank, world = init_dist(args.gpus)
-    T.Device.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    share = os.environ.get("TAPER_BENCH_SHARE_DEVICE") == "1"
+    T.Device.set_device(0 if share else int(os.environ.get("LOCAL_RANK", "0")))
 
+    if args.workload is None:
+        args.workload = "mlp_784-128-10_b64" if world == 1 else "mlp_784-128-10_b128"
     key, batch, sample_shape, lr = WORKLOADS[args.workload]
     if args.full_backward:
         T.set_full_backward(True)
@@ -323,15 +631,15 @@ def main():
         args.workload = args.workload.rsplit("_b", 1)[0] + f"_b{batch}"
     model = build_model(T, key)
     opt = T.Adam(model.parameters(), lr, None, None, 1e-4)          # examples/train_mnist.rs:50-51
-    comm, comm_kind = make_comm(dist, T)
+    comm, comm_kind = make_comm(dist, T, args.dp_backend, opt)
     trainer = T.Trainer(model, opt, sample_shape=sample_shape, comm=comm, **({"graph_chunk": args.graph_chunk} if args.graph_chunk else {}))
     # every rank owns its shard of the synthetic epoch (rows are independent: SURVEY.md 8e)
     ds = T.MNISTDataset.synthetic(args.dataset_size, seed=0x7461706572 + rank)
     loader = T.DataLoader(ds, batch, False)
 
     run_steps(T, trainer, loader, max(args.warmup, 2))              # untimed; also captures the graph
-    # Every graph size of the replay ladder (128, 32, 8, 2, 1 steps) is recorded by the first call long enough to use it
-    # (2 x 128 steps): a warm-up shorter than that is topped up, untimed, so that no recording falls into the timed region.
+    # Every graph size of the replay ladder (128, 64, ..., 2, 1 steps) is recorded by the first call long enough to use it
+    # (128 + 1 steps): a warm-up shorter than that is topped up, untimed, so that no recording falls into the timed region.
     # Reported as config.graph_record_steps; the W steps above and the K timed steps below are exactly what was asked for.
     record_steps = max(0, 257 - max(args.warmup, 2))
     if record_steps:
@@ -343,15 +651,41 @@ def main():
         while time.perf_counter() - t_settle < args.settle_seconds:
             settle_steps += run_steps(T, trainer, loader, 256) // batch
             T.Device.sync()
-    barrier_sync(dist, T)
-    t0 = time.perf_counter()
-    samples = run_steps(T, trainer, loader, args.steps)
-    barrier_sync(dist, T)
-    dt = time.perf_counter() - t0
+    samples, dt = timed_run(T, dist, trainer, loader, args.steps)
 
-    if dist is not None:
-        dt = dist.all_reduce_max(dt)                 # MAX over ranks
-        samples = int(dist.all_reduce_sum(samples))  # whole-job aggregate
+    # N > 1: the single-GPU figure of the SAME per-GPU batch (no communicator), measured by rank 0 in the same run with the
+    # same W / K -- the denominator of SURVEY 8e's weak-scaling efficiency -- and the data-parallel figure at the N = 1
+    # headline's 64 rows per GPU (comparable with a separate N = 1 run of this script)
+    dp_extra = None
+    if world > 1 and not args.batch:
+        dp_extra = {}
+
+        dp_extra["replicas_bit_identical"] = replicas_identical(dist, model)
+
+        def side_run(b, backend):
+            m2 = build_model(T, key)
+            o2 = T.Adam(m2.parameters(), lr, None, None, 1e-4)
+            c2, kind2 = make_comm(dist, T, backend, o2) if backend else (None, "none")   # (a p2p communicator is bound to one optimizer's arena)
+            t2 = T.Trainer(m2, o2, sample_shape=sample_shape, comm=c2)
+            l2 = T.DataLoader(ds, b, False)
+            run_steps(T, t2, l2, max(args.warmup, 2) + record_steps)
+            s_, d_ = timed_run(T, dist if backend else None, t2, l2, args.steps)
+            same = replicas_identical(dist, m2) if backend else None
+            _KEEP_ALIVE.append((t2, o2, m2, l2, c2))
+            return s_, d_, kind2, same
+        if batch != 64 and key == "mlp_baseline":
+            s64, d64, k64, same64 = side_run(64, args.dp_backend)
+            dp_extra["dp_at_64_rows_per_gpu"] = dict(workload="mlp_784-128-10_b64", per_gpu_batch=64, global_batch=64 * world, value=round(s64 / d64, 1),
+                                                     unit="samples/s", ms_per_step=round(d64 / args.steps * 1e3, 5), comm=k64, replicas_bit_identical=same64)
+        if comm is not None and comm.is_p2p() and not share:      # the same job over RCCL, for comparison (RCCL needs a GPU per rank)
+            sr, dr, kr, samer = side_run(batch, "rccl")
+            dp_extra["same_job_over_rccl"] = dict(value=round(sr / dr, 1), unit="samples/s", ms_per_step=round(dr / args.steps * 1e3, 5), comm=kr,
+                                                  replicas_bit_identical=samer)
+        if rank == 0:
+            s1, d1, _, _ = side_run(batch, None)
+            dp_extra["single_gpu_same_per_gpu_batch"] = dict(workload=args.workload, per_gpu_batch=batch, n_gpus=1, value=round(s1 / d1, 1), unit="samples/s",
+                                                             ms_per_step=round(d1 / args.steps * 1e3, 5), steps=args.steps, warmup=args.warmup)
+        barrier_sync(dist, T)
 
     sustained = None
     under_profiler = "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
@@ -376,7 +710,7 @@ def main():
             # rocprofv3 (ROCm 7.2) segfaults in hipGraphLaunch once a process replays more than one
             # instantiated graph back to back; the Trainer's replays above are what the trace is for.
             roof = dict(skipped="per-kernel timers are not run under rocprofv3; see profiles/ for the trace of this command")
-        elif key == "mlp_baseline" and not args.no_roofline:
+        elif key == "mlp_baseline" and not args.no_roofline and batch <= 512:
             # per-launch durations of the step's two kernels, measured live (HIP events on the ctx
             # stream, graph chains with / without each launch).  `roofline` is the kernel that carries
             # the step's HBM traffic (83% of its algorithmic bytes); the full list is in `kernels`.
@@ -394,20 +728,25 @@ def main():
         sweep = None
         # (not under rocprofv3: the trace of this command is for the headline workload's kernels only)
         if key == "mlp_baseline" and world == 1 and not args.batch and not args.no_sweep and not under_profiler:
-            sweep = batch_sweep(T, build_model, key, lr, args.dataset_size)
+            sweep = batch_sweep(T, build_model, key, lr, ds)
         cpu = None
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
+        with_cpu = not args.no_cpu_baseline and world == 1          # the CPU leg is timed on rank 0 at N = 1 only
+        if with_cpu:
             try:
                 cpu = cpu_baseline(key, batch, sample_shape, lr)
             except Exception as e:  # the baseline is reported, never required
                 cpu = dict(value=None, unit="samples/s", cores=1, kind="port", sample=f"failed: {e}")
+        workloads = None
+        if world == 1 and not args.batch and args.workloads != "none" and args.workload == "mlp_784-128-10_b64":
+            only = None if args.workloads == "all" else set(args.workloads.split(","))
+            workloads = extra_workloads(T, ds, with_cpu, only)
         out = {
             "metric": "MNIST samples/sec fwd+bwd+step", "value": round(samples / dt, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "per_gpu_batch": batch, "global_batch": batch * world,
                        "optimizer": f"Adam(lr={lr}, wd=1e-4)", "parallelism": f"dp{world}" if world > 1 else "single",
-                       "comm": comm_kind, "step": "hipGraph replay of gather+fwd+xent+bwd+adam+log", "graph_record_steps": record_steps, "clock_settle_steps": settle_steps,
+                       "comm": comm_kind, **({"ranks_share_one_gpu": True} if share and world > 1 else {}), "step": "hipGraph replay of gather+fwd+xent+bwd+adam+log", "graph_record_steps": record_steps, "clock_settle_steps": settle_steps,
                        **({"conv_gradients": "full_backward (extension)"} if args.full_backward else {})},
             "epochs_per_s": round(samples / dt / 60000.0, 3),
             "step_roofline": None if flops is None else {
@@ -415,6 +754,8 @@ def main():
                 "hbm_frac": round(nbytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                 "mfma_frac": round(flops / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TF, 6)},
             "sustained": sustained, "batch_sweep": sweep, "roofline": roof, "cpu_baseline": cpu,
+            **({"data_parallel": dp_extra} if dp_extra is not None else {}),
+            **({"workloads": workloads} if workloads is not None else {}),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

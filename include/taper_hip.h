@@ -427,6 +427,26 @@ int th_comm_destroy(th_comm *comm);
 /* in-place sum over ranks of d_buf[n] then * scale (1/W): grads of the flat
  * arena between loss.backward() and optim.step() */
 int th_allreduce_sum_scale(th_comm *comm, th_ctx *ctx, float *d_buf, size_t n, float scale);
+/* Peer-to-peer communicator (one node, <= 8 ranks): a ONE-SHOT all-reduce for latency-bound buffers (the MLP's 407 KB
+ * gradient arena).  Every rank maps its peers' buffers through IPC handles and reads them directly over xGMI; sums are
+ * formed in rank order, so every rank gets the same bits.  Bootstrap: th_comm_init_p2p, then th_comm_p2p_export (registers
+ * the buffer this rank will reduce -- its flat gradient arena -- and fills a blob), ship the TH_P2P_BLOB_BYTES blobs of all
+ * ranks to all ranks out of band (rank order), th_comm_p2p_connect.  After that th_allreduce_sum_scale on the registered
+ * buffer takes the one-shot path (same signature, same in-place result), and th_allreduce_adam goes one further: the
+ * mean gradient is fed straight into Adam (optim.rs:83-113; arguments as th_adam_step) and never written back.
+ * Ranks may share a device (the test setup of a 1-GPU box) or own one each.  A peer that never arrives makes the
+ * launch give up after ~4 s and raises the flag th_comm_error reads (it synchronises the stream). */
+#define TH_P2P_BLOB_BYTES 192
+int th_comm_init_p2p(th_ctx *ctx, int n_ranks, int rank, th_comm **out);
+int th_comm_p2p_export(th_comm *comm, float *d_buf, size_t n, uint8_t out_blob[TH_P2P_BLOB_BYTES]);
+int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs /* n_ranks x TH_P2P_BLOB_BYTES, rank order */);
+int th_comm_is_p2p(const th_comm *comm);
+int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error);
+/* test hook: {in-place, fused-with-Adam} one-shot launches this communicator has enqueued or captured so far */
+int th_comm_stats(const th_comm *comm, int64_t out2[2]);
+int th_allreduce_adam(th_comm *comm, th_ctx *ctx, const float *d_grads, size_t n, float scale, float *d_params, float *d_m, float *d_v,
+                      const int64_t *d_offsets, const int32_t *d_has_grad, int n_tensors, int32_t *d_t, const float *d_lr,
+                      float beta1, float beta2, float eps, float weight_decay, int pre_ticked);
 
 #ifdef __cplusplus
 }

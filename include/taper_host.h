@@ -165,6 +165,15 @@ int tp_loader_free(tp_loader *l);
 /* ---- data parallel (new) ---- */
 int tp_comm_unique_id(uint8_t out_id[128]);
 int tp_comm_new(int n_ranks, int rank, const uint8_t id[128], tp_comm **out);
+/* peer-to-peer communicator (th_comm_init_p2p): new -> export_arena(optimizer) -> ship all 192-byte blobs to all ranks ->
+ * connect(blobs in rank order); the Trainer then runs all-reduce + Adam as one launch */
+int tp_comm_new_p2p(int n_ranks, int rank, tp_comm **out);
+int tp_comm_export_arena(tp_comm *c, tp_optim *optimizer, uint8_t out_blob[192]);
+int tp_comm_connect(tp_comm *c, const uint8_t *blobs, size_t n_bytes);
+/* collective self-test: a known pattern through the optimizer's gradient arena (every rank calls it, before training) */
+int tp_comm_self_check(tp_comm *c, tp_optim *optimizer, int *ok);
+int tp_comm_timed_out(tp_comm *c, int *out);
+int tp_comm_stats(tp_comm *c, int64_t out2[2]);   /* {in-place, fused} one-shot launches enqueued or captured */
 int tp_comm_free(tp_comm *c);
 int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n);
 

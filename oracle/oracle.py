@@ -32,6 +32,40 @@ def build_native(outdir: str) -> Path:
     return Path(outdir) / "libtaper_oracle_native.so"
 
 
+def build_fast(outdir: str) -> Path:
+    """bench.py's cpu_baseline build (`make fast`): -march=native, the matrixmultiply-style packed sgemm
+    (cpu_packed_sgemm.c) and the reference's rayon loops as OpenMP loops.  Not the parity oracle."""
+    subprocess.check_call(["make", "-C", str(_HERE), "-s", "fast", f"OUTDIR={outdir}"], stdout=subprocess.DEVNULL)
+    return Path(outdir) / "libtaper_oracle_fast.so"
+
+
+def find_cblas():
+    """A vendor cblas_sgemm on this box for the `--features blas` analogue (src/gemm.rs:32-47), or None.
+    Looks for the OpenBLAS that numpy's wheel bundles (ILP64, symbol prefix scipy_) and for system libraries.
+    -> (ctypes function address, ilp64 flag, description, CDLL kept alive)"""
+    import glob
+    cands = []
+    try:
+        import numpy
+        base = Path(numpy.__file__).resolve().parent
+        cands += sorted(glob.glob(str(base.parent / "numpy.libs" / "lib*openblas*.so*")))
+    except Exception:
+        pass
+    for pat in ("/usr/lib/x86_64-linux-gnu/libopenblas.so*", "/usr/lib/x86_64-linux-gnu/libblas.so*", "/usr/lib64/libopenblas.so*",
+                "/opt/intel/oneapi/mkl/latest/lib/intel64/libmkl_rt.so*"):
+        cands += sorted(glob.glob(pat))
+    for path in cands:
+        try:
+            dll = C.CDLL(path)
+        except OSError:
+            continue
+        for sym, ilp64 in (("cblas_sgemm", 0), ("scipy_cblas_sgemm64_", 1), ("cblas_sgemm64_", 1)):
+            fn = getattr(dll, sym, None)
+            if fn is not None:
+                return C.cast(fn, C.c_void_p).value, ilp64, f"{Path(path).name}:{sym}", dll
+    return None
+
+
 _p = C.c_void_p
 _f32p = C.POINTER(C.c_float)
 _szp = C.POINTER(C.c_size_t)
@@ -88,6 +122,12 @@ def _load(path: Path | None = None):
         "ot_train_step": (None, [C.POINTER(_ModelStruct), _p, _f32p, _f32p, _szp, C.c_int,
                                  _f32p, _f32p, _f32p, _f32p, C.POINTER(C.c_int)]),
     }
+    # only in the cpu_baseline build (`make fast`)
+    for name, proto in (("ot_baseline_flavour", (C.c_int, [])), ("ot_baseline_max_threads", (C.c_int, [])),
+                        ("ot_baseline_set_threads", (None, [C.c_int])), ("ot_baseline_set_cblas", (None, [_p, C.c_int])),
+                        ("ot_baseline_run_steps", (None, [C.POINTER(_ModelStruct), _p, _f32p, _f32p, C.c_size_t, _szp, C.c_int, C.c_size_t, _f32p]))):
+        if hasattr(lib, name):
+            sig[name] = proto
     for name in ("ot_add", "ot_mul", "ot_sub", "ot_div", "ot_matmul", "ot_add_broadcast", "ot_sub_broadcast_rows"):
         sig[name] = (_p, [_p, _p])
     for name in ("ot_relu", "ot_transpose", "ot_sigmoid", "ot_mean", "ot_exp", "ot_log", "ot_sqrt",
@@ -386,6 +426,15 @@ class Sequential:
                 if s.get("b") is not None:
                     out.append(s["b"])
         return out
+
+    def run_steps(self, opt, images, labels, x_shape, steps):
+        """cpu_baseline leg: `steps` x {get_batch -> training step} in ONE C call over a resident dataset; -> last loss"""
+        images = np.ascontiguousarray(images, dtype=np.float32).reshape(-1, 784)
+        labels = np.ascontiguousarray(labels, dtype=np.float32).reshape(-1)
+        loss = C.c_float()
+        lib.ot_baseline_run_steps(C.byref(self._m), opt._h, _fp(images.reshape(-1)), _fp(labels), labels.size, _shape_arr(x_shape),
+                                  len(x_shape), int(steps), C.cast(C.byref(loss), _f32p))
+        return loss.value
 
     def train_step(self, opt, images, labels, x_shape, want_logits=False, want_grads=False):
         """examples/train_mnist.rs:89-121 in one C call; returns dict."""

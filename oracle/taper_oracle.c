@@ -207,8 +207,43 @@ static void accumulate_grad_scaled(const ot_tensor *t, const float *src, float s
  * 0.3.10 (Cargo.lock); it computes the alpha*A*B panel and then combines it
  * with beta*C (beta == 0 overwrites).  Restated as: per output row an fp32
  * k-ordered accumulation, then c = beta*c + alpha*acc. */
+#ifdef OT_PACKED_SGEMM
+/* Baseline build only (`make fast`, bench.py's cpu_baseline leg): the GEMM goes to the matrixmultiply-style packed
+ * kernel (cpu_packed_sgemm.c) or, once ot_baseline_set_cblas() has been given a vendor cblas_sgemm, through the
+ * `--features blas` call of gemm.rs:32-47.  The parity oracle is built WITHOUT this macro. */
+void ot_packed_sgemm_rowmajor(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a, const float *b, float beta,
+                              float *c);
+typedef void (*ot_cblas32_fn)(int, int, int, int, int, int, float, const float *, int, const float *, int, float, float *, int);
+typedef void (*ot_cblas64_fn)(int, int, int, int64_t, int64_t, int64_t, float, const float *, int64_t, const float *, int64_t, float,
+                              float *, int64_t);
+static void *g_cblas_fn = NULL;
+static int g_cblas_ilp64 = 0;
+void ot_baseline_set_cblas(void *cblas_sgemm_fn, int ilp64) { g_cblas_fn = cblas_sgemm_fn; g_cblas_ilp64 = ilp64; }
+#endif
+int ot_baseline_flavour(void) { /* 0 = plain-loop parity oracle; 1 = packed sgemm; +2 = OpenMP plane loops */
+    int f = 0;
+#ifdef OT_PACKED_SGEMM
+    f |= 1;
+#endif
+#ifdef _OPENMP
+    f |= 2;
+#endif
+    return f;
+}
+
 void ot_sgemm_rowmajor(int trans_a, int trans_b, int m, int n, int k, float alpha,
                        const float *a, const float *b, float beta, float *c) {
+#ifdef OT_PACKED_SGEMM
+    if (g_cblas_fn) { /* gemm.rs:21-47: RowMajor = 101, NoTrans = 111, Trans = 112; lda = m|k, ldb = k|n, ldc = n */
+        const int ta = trans_a ? 112 : 111, tb = trans_b ? 112 : 111;
+        const int lda = trans_a ? m : k, ldb = trans_b ? k : n;
+        if (g_cblas_ilp64) ((ot_cblas64_fn)g_cblas_fn)(101, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, n);
+        else ((ot_cblas32_fn)g_cblas_fn)(101, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, n);
+    } else {
+        ot_packed_sgemm_rowmajor(trans_a, trans_b, m, n, k, alpha, a, b, beta, c);
+    }
+    return;
+#endif
     const long a_rs = trans_a ? 1 : k, a_cs = trans_a ? m : 1;
     const long b_rs = trans_b ? 1 : n, b_cs = trans_b ? k : 1;
     float *acc = xalloc_f((size_t)n);
@@ -334,8 +369,13 @@ ot_tensor *ot_transpose(const ot_tensor *x) { /* tensor.rs:544-591 */
     OT_CHECK(x->ndim == 2, "Can only transpose 2D tensors");
     size_t rows = x->shape[0], cols = x->shape[1];
     float *o = xalloc_f(rows * cols);
-    for (size_t i = 0; i < rows; ++i)
-        for (size_t j = 0; j < cols; ++j) o[j * rows + i] = x->core->data[i * cols + j];
+    const size_t block = 16; /* tensor.rs:551: "Optimal for most cache sizes" -- same values, the reference's loop order */
+    for (size_t i0 = 0; i0 < rows; i0 += block)
+        for (size_t j0 = 0; j0 < cols; j0 += block) {
+            size_t i_max = i0 + block < rows ? i0 + block : rows, j_max = j0 + block < cols ? j0 + block : cols;
+            for (size_t i = i0; i < i_max; ++i)
+                for (size_t j = j0; j < j_max; ++j) o[j * rows + i] = x->core->data[i * cols + j];
+        }
     size_t shp[2] = {cols, rows};
     ot_tensor *out = ot_wrap(o, shp, 2);
     if (x->requires_grad) {
@@ -640,6 +680,7 @@ static void im2col_3x3_s1(const float *in, float *col, size_t n, size_t c, size_
                           size_t h_out, size_t w_out, size_t pad_h, size_t pad_w) {
     size_t col_size = c * 9;
     size_t windows = n * h_out * w_out;
+    OT_PAR_FOR /* tensor.rs:1745 */
     for (size_t w_idx = 0; w_idx < windows; ++w_idx) {
         size_t batch = w_idx / (h_out * w_out), pos = w_idx % (h_out * w_out);
         size_t oh = pos / w_out, ow = pos % w_out;
@@ -815,7 +856,8 @@ ot_tensor *ot_max_pool2d(const ot_tensor *x, int k_h, int k_w, int s_h, int s_w,
     size_t w_out = (w_in + 2 * pad_w - k_w) / s_w + 1;
     size_t osp = h_out * w_out;
     float *o = xalloc_f(n * c * osp);
-    size_t *arg = (size_t *)calloc(n * c * osp ? n * c * osp : 1, sizeof(size_t));
+    size_t *arg = (size_t *)calloc(n * c * osp > 0 ? n * c * osp : 1, sizeof(size_t));
+    OT_PAR_FOR /* tensor.rs:1420 */
     for (size_t bc = 0; bc < n * c; ++bc) {
         size_t in_base = bc * h_in * w_in;
         for (size_t oh = 0; oh < h_out; ++oh)
@@ -863,6 +905,7 @@ ot_tensor *ot_avg_pool2d(const ot_tensor *x, int k_h, int k_w, int s_h, int s_w,
     size_t osp = h_out * w_out;
     float pool_size = (float)(k_h * k_w); /* padding counted in the divisor: Q6 */
     float *o = xalloc_f(n * c * osp);
+    OT_PAR_FOR /* tensor.rs:1552 */
     for (size_t bc = 0; bc < n * c; ++bc) {
         size_t in_base = bc * h_in * w_in;
         for (size_t oh = 0; oh < h_out; ++oh)
@@ -1159,6 +1202,7 @@ static void node_backward(size_t id) {
     case N_MAXPOOL: { /* tensor.rs:1479-1517 */
         size_t planes = nd.dims[0], isp = nd.dims[1], osp = nd.dims[2];
         float *gin = grad_slot(nd.a, planes * isp);
+        OT_PAR_FOR /* tensor.rs:1491 */
         for (size_t bc = 0; bc < planes; ++bc) {
             float *gp = gin + bc * isp;
             if (nd.iparam[0]) /* 1496-1500: zero the plane first (Q5) */
@@ -1171,6 +1215,7 @@ static void node_backward(size_t id) {
         size_t planes = nd.dims[0], h_in = nd.dims[1], w_in = nd.dims[2], h_out = nd.dims[3], w_out = nd.dims[4];
         size_t k_h = nd.dims[5], k_w = nd.dims[6], s_h = nd.dims[7], s_w = nd.dims[8], p_h = nd.dims[9], p_w = nd.dims[10];
         float *gin = grad_slot(nd.a, planes * h_in * w_in);
+        OT_PAR_FOR /* tensor.rs:1614 */
         for (size_t bc = 0; bc < planes; ++bc) {
             float *gp = gin + bc * h_in * w_in;
             const float *go = gout + bc * h_out * w_out;

@@ -24,6 +24,15 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The reference runs these loops through rayon (`par_chunks_mut`: tensor.rs:1420,1491,1552,1614,1745) on all cores.
+ * The parity oracle is built without OpenMP (the pragma vanishes: one thread, fixed order); the cpu_baseline build
+ * (`make fast`, -fopenmp) runs them thread-parallel like the reference.  Every iteration writes its own plane / row. */
+#ifdef _OPENMP
+#define OT_PAR_FOR _Pragma("omp parallel for schedule(static)")
+#else
+#define OT_PAR_FOR
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -64,6 +73,8 @@ void ot_backward(ot_tensor *t);           /* tensor.rs:520-529 */
 void ot_zero_grad(ot_tensor *t);          /* tensor.rs:531-533 */
 
 /* ---- gemm (src/gemm.rs:72-119 semantics) ------------------------------- */
+/* 0 = plain-loop parity oracle; bit 0 = packed sgemm (cpu_packed_sgemm.c), bit 1 = OpenMP plane loops: the cpu_baseline build */
+int ot_baseline_flavour(void);
 void ot_sgemm_rowmajor(int trans_a, int trans_b, int m, int n, int k,
                        float alpha, const float *a, const float *b,
                        float beta, float *c);
@@ -139,6 +150,9 @@ void ot_sgd_step(ot_tensor **params, int n, float lr);         /* optim.rs:21-33
 float ot_powi(float a, int b);
 
 /* ---- data (src/data/mnist.rs:277-310) ---------------------------------- */
+/* cpu_baseline leg only (see `make fast`) */
+int ot_baseline_max_threads(void);
+void ot_baseline_set_threads(int n);
 void ot_get_batch(const float *images, const float *labels, const size_t *indices, size_t batch,
                   float *out_images /* batch*784 */, float *out_labels);
 

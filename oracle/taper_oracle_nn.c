@@ -104,6 +104,7 @@ void ot_sgd_step(ot_tensor **params, int n, float lr) { /* optim.rs:21-33; momen
 
 void ot_get_batch(const float *images, const float *labels, const size_t *indices, size_t batch,
                   float *out_images, float *out_labels) { /* data/mnist.rs:277-310 */
+    OT_PAR_FOR /* data/mnist.rs:291 */
     for (size_t i = 0; i < batch; ++i) {
         memcpy(out_images + i * 784, images + indices[i] * 784, 784 * sizeof(float));
         out_labels[i] = labels[indices[i]];
@@ -198,3 +199,45 @@ void ot_train_step(const ot_model *m, ot_adam *opt, const float *images, const f
     ot_free(x); ot_free(y); ot_free(logits); ot_free(loss);
     ot_tape_reset(); /* drop captured clones so grads/activations are released */
 }
+
+/* ------------------------------------------------- cpu_baseline leg (bench.py) */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* threads of the rayon-style loops (rayon's default pool = one thread per logical CPU); 0 on a build without OpenMP */
+int ot_baseline_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 0;
+#endif
+}
+void ot_baseline_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* `steps` iterations of the examples' loop body over a resident dataset, batches in index order (wrapping):
+ * DataLoader::next -> MNISTDataset::get_batch (data/mnist.rs:373-385,277-310), then the training step of
+ * examples/train_mnist.rs:89-121.  One C call, so the timed region holds no interpreter time. */
+void ot_baseline_run_steps(const ot_model *m, ot_adam *opt, const float *images, const float *labels, size_t n_rows,
+                           const size_t *x_shape, int x_ndim, size_t steps, float *last_loss) {
+    const size_t batch = x_shape[0];
+    size_t *idx = (size_t *)malloc(batch * sizeof(size_t));
+    float *xb = (float *)malloc(batch * 784 * sizeof(float)), *yb = (float *)malloc(batch * sizeof(float));
+    size_t cur = 0;
+    float loss = 0.0f, acc = 0.0f;
+    for (size_t s = 0; s < steps; ++s) {
+        if (cur + batch > n_rows) cur = 0;
+        for (size_t i = 0; i < batch; ++i) idx[i] = cur + i;
+        cur += batch;
+        ot_get_batch(images, labels, idx, batch, xb, yb);
+        ot_train_step(m, opt, xb, yb, x_shape, x_ndim, &loss, &acc, NULL, NULL, NULL);
+    }
+    if (last_loss) *last_loss = loss;
+    free(idx); free(xb); free(yb);
+}
+

@@ -550,10 +550,49 @@ class DataLoader:
 class Communicator:
     """RCCL communicator, one process per GPU; the 128-byte id travels out of band."""
 
-    def __init__(self, n_ranks, rank, uid: bytes):
-        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+    BLOB_BYTES = 192
+
+    def __init__(self, n_ranks, rank, uid: bytes | None = None, _h=None):
         self.n_ranks, self.rank = n_ranks, rank
+        self._p2p = _h is not None
+        if _h is not None:
+            self._h = _h
+            return
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._h = _mk(host.tp_comm_new, "Communicator::new", int(n_ranks), int(rank), buf)
+
+    @staticmethod
+    def p2p(n_ranks, rank):
+        """peer-to-peer communicator (one node, <= 8 ranks): one-shot all-reduce of the gradient arena fused with Adam"""
+        return Communicator(n_ranks, rank, _h=_mk(host.tp_comm_new_p2p, "Communicator::p2p", int(n_ranks), int(rank)))
+
+    def export_arena(self, optimizer) -> bytes:
+        buf = (C.c_uint8 * self.BLOB_BYTES)()
+        tp_check(host.tp_comm_export_arena(self._h, optimizer._h, buf), "Communicator::export_arena")
+        return bytes(buf)
+
+    def connect(self, blobs: bytes):
+        buf = (C.c_uint8 * len(blobs)).from_buffer_copy(blobs)
+        tp_check(host.tp_comm_connect(self._h, buf, len(blobs)), "Communicator::connect")
+
+    def is_p2p(self) -> bool:
+        return self._p2p
+
+    def self_check(self, optimizer) -> bool:
+        """collective: all-reduce(mean) of a known pattern through the optimizer's gradient arena; True = every element exact"""
+        ok = C.c_int()
+        tp_check(host.tp_comm_self_check(self._h, optimizer._h, C.byref(ok)), "Communicator::self_check")
+        return bool(ok.value)
+
+    def stats(self):
+        out = (C.c_int64 * 2)()
+        tp_check(host.tp_comm_stats(self._h, out), "Communicator::stats")
+        return dict(inplace=int(out[0]), fused=int(out[1]))
+
+    def timed_out(self) -> bool:
+        out = C.c_int()
+        tp_check(host.tp_comm_timed_out(self._h, C.byref(out)), "Communicator::timed_out")
+        return bool(out.value)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

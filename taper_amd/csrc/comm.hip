@@ -9,9 +9,44 @@
 
 #include <cstring>
 
+#include <unistd.h>
+
+#include "adam_dev.h"
+
+constexpr int P2P_MAX_RANKS = 8;           // one node: 8 x MI355X, full xGMI mesh
+constexpr int P2P_FLAG_WORDS = 32;         // per rank: ready[8] | done[8] | pad (uint32 step values, monotonic)
+constexpr int P2P_READY = 0, P2P_DONE = 8;
+constexpr int P2P_MAX_BLOCKS = 256, P2P_QUADS = 8;   // in-place form: <= 8 float4 per thread held across the barrier
+constexpr long P2P_SPIN_TICKS = 400000000L;           // 4 s of the 100 MHz wall clock: a lost peer ends in an error, not a hang
+
+struct P2PBlob {                           // what a rank ships to its peers (TH_P2P_BLOB_BYTES)
+    hipIpcMemHandle_t buf, flags;          // allocation bases
+    uint64_t buf_offset, n;                // the reduced buffer inside its allocation; length in floats
+    int32_t pid, device, rank, pad;
+    uint8_t reserved[TH_P2P_BLOB_BYTES - 2 * sizeof(hipIpcMemHandle_t) - 2 * sizeof(uint64_t) - 4 * sizeof(int32_t)];
+};
+static_assert(sizeof(P2PBlob) == TH_P2P_BLOB_BYTES, "P2PBlob layout");
+
+struct P2PDev {                            // kernel argument
+    const float *buf[P2P_MAX_RANKS];       // buf[r]: rank r's gradient buffer as mapped here (own = local pointer)
+    uint32_t *flags[P2P_MAX_RANKS];        // flags[r]: rank r's flag block as mapped here (own = local pointer)
+    uint32_t *state;                       // local: [0] steps completed, [1] arrival counter, [2] error (timeout)
+    int n_ranks, rank;
+};
+
 struct th_comm {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+    // ---- peer-to-peer form (th_comm_init_p2p) ----
+    bool p2p = false, connected = false;
+    int device = 0;
+    float *reg_buf = nullptr;              // the registered buffer (this rank's flat gradient arena)
+    size_t reg_n = 0;
+    uint32_t *flags_local = nullptr, *state = nullptr;
+    void *peer_base[P2P_MAX_RANKS] = {};   // hipIpcOpenMemHandle results (to close)
+    void *peer_flag_base[P2P_MAX_RANKS] = {};
+    P2PDev dev{};
+    long launches_inplace = 0, launches_fused = 0;   // enqueued (or captured) one-shot launches, for tests
 };
 
 namespace th {
@@ -26,6 +61,159 @@ int scale_inplace(th_ctx *ctx, float *d_x, size_t n, float scale);
             return 1;                                                                                  \
         }                                                                                              \
     } while (0)
+
+namespace th {
+
+// ------------------------------------------------------------------------------------------------
+// One-shot peer-to-peer all-reduce for LATENCY-bound buffers (the MLP's 407 KB gradient arena: a ring spends
+// 2(W-1) dependent hops on it).  Every rank's buffer and flag block are mapped into every peer (IPC handles);
+// one launch per rank:
+//   1. workgroup 0 PUSHES "my gradients are complete" (the launch sits behind the backward kernels in the
+//      stream, whose writes reached memory at their kernel boundaries) into every peer's flag block;
+//   2. every workgroup polls its OWN flag block (local memory, system-scope acquire) until all W ranks are ready;
+//   3. each thread reads its elements from all W buffers over xGMI and adds them in RANK ORDER -- every rank
+//      computes the same sum bit for bit, so replicas stay identical -- then scales;
+//   4. FUSED: Adam (optim.rs:83-113) is applied to this rank's p / m / v straight from the registers: the
+//      reduced gradient is never written.  IN PLACE: the sums wait in registers;
+//   5. the last workgroup to finish pushes "done reading" to every peer and advances the local step count;
+//      nobody may overwrite its buffer before every peer is done: the in-place form waits for that before it
+//      stores, the fused form before workgroup 0 exits (the next backward launch is behind this one).
+// Flags are monotonic step numbers, so nothing is ever reset and a captured graph replays the launch as is.
+// Spins are bounded by the wall clock: a missing peer raises state[2] instead of hanging the GPU.
+__device__ __forceinline__ bool p2p_wait_all(const P2PDev &c, int word0, uint32_t step) {
+    // lanes 0..W-1 of the first wave each watch one rank's slot in the LOCAL flag block
+    bool ok = true;
+    if (threadIdx.x < (unsigned)c.n_ranks) {
+        const uint32_t *slot = c.flags[c.rank] + word0 + threadIdx.x;
+        const long t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
+            if (wall_clock64() - t0 > P2P_SPIN_TICKS) {
+                __hip_atomic_store(&c.state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // system scope: peers' data written before their flag is visible now
+    return ok;
+}
+
+__device__ __forceinline__ void p2p_push(const P2PDev &c, int word0, uint32_t step) {
+    // lane r writes this rank's slot in rank r's flag block (its own included)
+    if (threadIdx.x < (unsigned)c.n_ranks)
+        __hip_atomic_store(c.flags[threadIdx.x] + word0 + c.rank, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// arrival of this workgroup; the last one publishes the step and tells the peers this rank is done reading
+__device__ __forceinline__ void p2p_arrive(const P2PDev &c, uint32_t step) {
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t arrived = __hip_atomic_fetch_add(&c.state[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = arrived == gridDim.x - 1;
+        if (last) {
+            __hip_atomic_store(&c.state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c.state[0], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (last) p2p_push(c, P2P_DONE, step);
+}
+
+__device__ __forceinline__ float4 p2p_sum_quad(const P2PDev &c, long i, float scale) {
+    float4 s = *reinterpret_cast<const float4 *>(c.buf[0] + i);
+#pragma unroll
+    for (int r = 1; r < P2P_MAX_RANKS; ++r) {
+        if (r >= c.n_ranks) break;
+        const float4 x = *reinterpret_cast<const float4 *>(c.buf[r] + i);
+        s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+    }
+    s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+    return s;
+}
+
+// in place: buf[rank][0..n) = scale * sum_r buf[r][0..n); n % 4 == 0, 16-byte aligned
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PDev c, float *__restrict__ out, long n, float scale) {
+    const uint32_t step = __hip_atomic_load(&c.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (blockIdx.x == 0) p2p_push(c, P2P_READY, step);
+    const bool ok = p2p_wait_all(c, P2P_READY, step);
+    const long stride = (long)gridDim.x * 256 * 4;
+    float4 acc[P2P_QUADS];
+#pragma unroll
+    for (int q = 0; q < P2P_QUADS; ++q) {
+        const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4 + q * stride;
+        if (i < n) acc[q] = p2p_sum_quad(c, i, scale);
+    }
+    p2p_arrive(c, step);
+    p2p_wait_all(c, P2P_DONE, step);                  // every peer has read this rank's buffer: it may be overwritten
+    if (!ok) return;
+#pragma unroll
+    for (int q = 0; q < P2P_QUADS; ++q) {
+        const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4 + q * stride;
+        if (i < n) *reinterpret_cast<float4 *>(out + i) = acc[q];
+    }
+}
+
+__device__ __forceinline__ int p2p_find_tensor(const int64_t *__restrict__ offsets, int n_tensors, int64_t i) {
+    int lo = 0, hi = n_tensors;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// fused: the mean gradient goes straight from the W buffers into Adam (optim.rs:99-110) on this rank's p / m / v.
+// Arena slices are padded to multiples of 4 floats, so a quad never straddles two tensors; grad-less tensors are
+// skipped entirely (Q8; the mask is rank-invariant).  t: every workgroup forms t + 1 itself, workgroup 0 publishes it
+// on its way out (after every other reader is long past the load: they all arrive before the done flags go out).
+__global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long n, float scale, float *__restrict__ p, float *__restrict__ m,
+                                                                 float *__restrict__ v, const int64_t *__restrict__ offsets,
+                                                                 const int32_t *__restrict__ has_grad, int n_tensors, int32_t *t_state,
+                                                                 const float *__restrict__ lr, float beta1, float beta2, float eps, float wd,
+                                                                 int pre_ticked) {
+    const uint32_t step = __hip_atomic_load(&c.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (blockIdx.x == 0) p2p_push(c, P2P_READY, step);
+    const int t = __hip_atomic_load(&t_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (pre_ticked ? 0 : 1);   // optim.rs:84
+    const float step_size = adam_step_size(lr[0], beta1, beta2, t);
+    const bool ok = p2p_wait_all(c, P2P_READY, step);
+    if (ok) {
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 256 * 4) {
+            if (!has_grad[p2p_find_tensor(offsets, n_tensors, i)]) continue;
+            const float4 g = p2p_sum_quad(c, i, scale);
+            const float4 pv = *reinterpret_cast<const float4 *>(p + i), mv = *reinterpret_cast<const float4 *>(m + i),
+                         vv = *reinterpret_cast<const float4 *>(v + i);
+            float4 po, mo, vo;
+#define TH_ADAM_LANE(k)                                                  \
+            {                                                            \
+                const float gg = g.k + wd * pv.k;                        \
+                mo.k = beta1 * mv.k + (1.0f - beta1) * gg;               \
+                vo.k = beta2 * vv.k + (1.0f - beta2) * gg * gg;          \
+                po.k = pv.k - step_size * mo.k / (sqrtf(vo.k) + eps);    \
+            }
+            TH_ADAM_LANE(x) TH_ADAM_LANE(y) TH_ADAM_LANE(z) TH_ADAM_LANE(w)
+#undef TH_ADAM_LANE
+            *reinterpret_cast<float4 *>(m + i) = mo;
+            *reinterpret_cast<float4 *>(v + i) = vo;
+            *reinterpret_cast<float4 *>(p + i) = po;
+        }
+    }
+    p2p_arrive(c, step);
+    if (blockIdx.x == 0) {
+        p2p_wait_all(c, P2P_DONE, step);              // the next backward launch overwrites the buffer the peers were reading
+        if (!pre_ticked && threadIdx.x == 0) __hip_atomic_store(&t_state[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+static int p2p_grid(size_t n) {
+    long g = (long)((n / 4 + 255) / 256);
+    return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));   // one workgroup per CU at most: every one of them polls the flag block
+}
+
+}  // namespace th
 
 extern "C" {
 
@@ -60,13 +248,152 @@ int th_comm_init_rank(th_ctx *ctx, int n_ranks, int rank, const uint8_t id[128],
 int th_comm_destroy(th_comm *comm) {
     if (!comm) return 0;
     if (comm->comm) ncclCommDestroy(comm->comm);
+    if (comm->p2p) {
+        (void)hipSetDevice(comm->device);
+        for (int r = 0; r < comm->n_ranks; ++r) {
+            if (r == comm->rank) continue;
+            if (comm->peer_base[r]) (void)hipIpcCloseMemHandle(comm->peer_base[r]);
+            if (comm->peer_flag_base[r]) (void)hipIpcCloseMemHandle(comm->peer_flag_base[r]);
+        }
+        if (comm->flags_local) (void)hipFree(comm->flags_local);
+        if (comm->state) (void)hipFree(comm->state);
+    }
     delete comm;
+    return 0;
+}
+
+int th_comm_init_p2p(th_ctx *ctx, int n_ranks, int rank, th_comm **out) {
+    TH_REQUIRE(ctx && out, "th_comm_init_p2p: null argument");
+    TH_REQUIRE(n_ranks >= 1 && n_ranks <= P2P_MAX_RANKS && rank >= 0 && rank < n_ranks, "th_comm_init_p2p: bad rank %d of %d (at most %d ranks: one node)",
+               rank, n_ranks, P2P_MAX_RANKS);
+    TH_HIP(hipSetDevice(ctx->device));
+    th_comm *c = new th_comm();
+    c->p2p = true;
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    c->device = ctx->device;
+    // the flag block peers write into: fine-grained (uncached) device memory where the runtime offers it
+    void *f = nullptr;
+    if (hipExtMallocWithFlags(&f, P2P_MAX_RANKS * P2P_FLAG_WORDS * sizeof(uint32_t), hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&f, P2P_MAX_RANKS * P2P_FLAG_WORDS * sizeof(uint32_t)) != hipSuccess) {
+            delete c;
+            TH_REQUIRE(false, "th_comm_init_p2p: cannot allocate the flag block");
+        }
+    }
+    c->flags_local = (uint32_t *)f;
+    if (hipMalloc((void **)&c->state, 64) != hipSuccess || hipMemset(c->flags_local, 0, P2P_MAX_RANKS * P2P_FLAG_WORDS * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(c->state, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        th_comm_destroy(c);
+        TH_REQUIRE(false, "th_comm_init_p2p: cannot initialise the flag block");
+    }
+    *out = c;
+    return 0;
+}
+
+int th_comm_p2p_export(th_comm *comm, float *d_buf, size_t n, uint8_t out_blob[TH_P2P_BLOB_BYTES]) {
+    TH_REQUIRE(comm && comm->p2p && d_buf && out_blob, "th_comm_p2p_export: needs a peer-to-peer communicator and a buffer");
+    TH_REQUIRE(n > 0 && n % 4 == 0 && ((uintptr_t)d_buf & 15) == 0, "th_comm_p2p_export: the buffer must be 16-byte aligned with a length that is a multiple of 4 floats");
+    TH_REQUIRE(n <= (size_t)P2P_MAX_BLOCKS * 256 * 4 * P2P_QUADS, "th_comm_p2p_export: %zu floats is past the one-shot form (use the RCCL communicator)", n);
+    TH_HIP(hipSetDevice(comm->device));
+    P2PBlob b{};
+    hipDeviceptr_t base = nullptr;
+    size_t span = 0;
+    TH_HIP(hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)d_buf));     // the pool hands out slices of larger allocations
+    TH_HIP(hipIpcGetMemHandle(&b.buf, (void *)base));
+    TH_HIP(hipIpcGetMemHandle(&b.flags, comm->flags_local));
+    b.buf_offset = (uint64_t)((char *)d_buf - (char *)base);
+    b.n = n;
+    b.pid = (int32_t)getpid();
+    b.device = comm->device;
+    b.rank = comm->rank;
+    comm->reg_buf = d_buf;
+    comm->reg_n = n;
+    memcpy(out_blob, &b, sizeof(b));
+    return 0;
+}
+
+int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs) {
+    TH_REQUIRE(comm && comm->p2p && blobs && comm->reg_buf, "th_comm_p2p_connect: export this rank's buffer first");
+    TH_HIP(hipSetDevice(comm->device));
+    for (int r = 0; r < comm->n_ranks; ++r) {
+        P2PBlob b;
+        memcpy(&b, blobs + (size_t)r * TH_P2P_BLOB_BYTES, sizeof(b));
+        TH_REQUIRE(b.rank == r && b.n == comm->reg_n, "th_comm_p2p_connect: blob %d is from rank %d with %llu floats (expected rank %d, %zu floats)", r,
+                   b.rank, (unsigned long long)b.n, r, comm->reg_n);
+        if (r == comm->rank) {
+            comm->dev.buf[r] = comm->reg_buf;
+            comm->dev.flags[r] = comm->flags_local;
+            continue;
+        }
+        if (b.device != comm->device) {
+            int can = 0;
+            TH_HIP(hipDeviceCanAccessPeer(&can, comm->device, b.device));
+            TH_REQUIRE(can, "th_comm_p2p_connect: device %d cannot access device %d", comm->device, b.device);
+            hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) TH_HIP(e);
+            (void)hipGetLastError();
+        }
+        TH_HIP(hipIpcOpenMemHandle(&comm->peer_base[r], b.buf, hipIpcMemLazyEnablePeerAccess));
+        TH_HIP(hipIpcOpenMemHandle(&comm->peer_flag_base[r], b.flags, hipIpcMemLazyEnablePeerAccess));
+        comm->dev.buf[r] = (const float *)((char *)comm->peer_base[r] + b.buf_offset);
+        comm->dev.flags[r] = (uint32_t *)comm->peer_flag_base[r];
+    }
+    comm->dev.state = comm->state;
+    comm->dev.n_ranks = comm->n_ranks;
+    comm->dev.rank = comm->rank;
+    comm->connected = true;
+    return 0;
+}
+
+int th_comm_is_p2p(const th_comm *comm) { return comm && comm->p2p ? 1 : 0; }
+
+int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error) {
+    TH_REQUIRE(comm && ctx && out_error, "th_comm_error: null argument");
+    *out_error = 0;
+    if (!comm->p2p) return 0;
+    uint32_t st[3] = {0, 0, 0};
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpy(st, comm->state, sizeof(st), hipMemcpyDeviceToHost));
+    *out_error = (int)st[2];
+    return 0;
+}
+
+int th_allreduce_adam(th_comm *comm, th_ctx *ctx, const float *d_grads, size_t n, float scale, float *d_params, float *d_m, float *d_v,
+                      const int64_t *d_offsets, const int32_t *d_has_grad, int n_tensors, int32_t *d_t, const float *d_lr, float beta1,
+                      float beta2, float eps, float weight_decay, int pre_ticked) {
+    TH_REQUIRE(comm && ctx && d_grads && d_params && d_m && d_v && d_offsets && d_has_grad && d_t && d_lr && n_tensors > 0,
+               "th_allreduce_adam: null argument");
+    TH_REQUIRE(comm->p2p && comm->connected, "th_allreduce_adam: needs a connected peer-to-peer communicator (th_comm_init_p2p / _export / _connect)");
+    TH_REQUIRE(d_grads == comm->reg_buf && n == comm->reg_n, "th_allreduce_adam: not the buffer this communicator exported");
+    TH_REQUIRE(((uintptr_t)d_params & 15) == 0 && ((uintptr_t)d_m & 15) == 0 && ((uintptr_t)d_v & 15) == 0, "th_allreduce_adam: arenas must be 16-byte aligned");
+    hipLaunchKernelGGL(th::p2p_allreduce_adam_kernel, dim3(th::p2p_grid(n)), dim3(256), 0, ctx->stream, comm->dev, (long)n, scale, d_params, d_m, d_v,
+                       d_offsets, d_has_grad, n_tensors, d_t, d_lr, beta1, beta2, eps, weight_decay, pre_ticked);
+    TH_LAUNCH_CHECK();
+    ++comm->launches_fused;
+    return 0;
+}
+
+int th_comm_stats(const th_comm *comm, int64_t out2[2]) {
+    TH_REQUIRE(comm && out2, "th_comm_stats: null argument");
+    out2[0] = comm->launches_inplace;
+    out2[1] = comm->launches_fused;
     return 0;
 }
 
 int th_allreduce_sum_scale(th_comm *comm, th_ctx *ctx, float *d_buf, size_t n, float scale) {
     TH_REQUIRE(comm && ctx && (n == 0 || d_buf), "th_allreduce_sum_scale: null argument");
     if (n == 0) return 0;
+    if (comm->p2p) {   // one-shot over xGMI: every rank reads its peers' buffers directly and adds them in rank order
+        TH_REQUIRE(comm->connected, "th_allreduce_sum_scale: peer-to-peer communicator is not connected");
+        TH_REQUIRE(d_buf == comm->reg_buf && n == comm->reg_n, "th_allreduce_sum_scale: not the buffer this communicator exported");
+        int g = (int)((n / 4 + 255) / 256);             // one float4 per thread while that fits, up to P2P_QUADS beyond
+        if (g > P2P_MAX_BLOCKS) g = P2P_MAX_BLOCKS;     // (every workgroup stays resident until all peers are done reading)
+        hipLaunchKernelGGL(th::p2p_allreduce_kernel, dim3(g < 1 ? 1 : g), dim3(256), 0, ctx->stream, comm->dev, d_buf, (long)n, scale);
+        TH_LAUNCH_CHECK();
+        ++comm->launches_inplace;
+        return 0;
+    }
     // the data-parallel mean (scale == 1/n_ranks) is RCCL's own ncclAvg: no scale launch behind the collective
     const float mean = 1.0f / (float)comm->n_ranks;
     if (scale == mean) {

@@ -333,6 +333,17 @@ int tp_comm_unique_id(uint8_t out_id[128]) {
 int tp_comm_new(int n, int r, const uint8_t id[128], tp_comm **out) {
     TP_BEGIN *out = new tp_comm{std::make_shared<Communicator>(n, r, std::vector<uint8_t>(id, id + 128))}; TP_END
 }
+int tp_comm_new_p2p(int n, int r, tp_comm **out) { TP_BEGIN *out = new tp_comm{Communicator::p2p(n, r)}; TP_END }
+int tp_comm_export_arena(tp_comm *c, tp_optim *o, uint8_t out_blob[192]) {
+    TP_BEGIN
+    auto b = c->c->export_arena(*o->o);
+    std::memcpy(out_blob, b.data(), b.size());
+    TP_END
+}
+int tp_comm_connect(tp_comm *c, const uint8_t *blobs, size_t n_bytes) { TP_BEGIN c->c->connect(std::vector<uint8_t>(blobs, blobs + n_bytes)); TP_END }
+int tp_comm_stats(tp_comm *c, int64_t out2[2]) { TP_BEGIN th_check(th_comm_stats(c->c->handle(), out2), "th_comm_stats"); TP_END }
+int tp_comm_self_check(tp_comm *c, tp_optim *o, int *ok) { TP_BEGIN *ok = c->c->self_check(*o->o) ? 1 : 0; TP_END }
+int tp_comm_timed_out(tp_comm *c, int *out) { TP_BEGIN *out = c->c->timed_out() ? 1 : 0; TP_END }
 int tp_comm_free(tp_comm *c) { TP_BEGIN delete c; TP_END }
 int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n) { TP_BEGIN c->c->allreduce_mean((float *)d_buf, n); TP_END }
 

@@ -614,6 +614,16 @@ void Adam::step() {  // optim.rs:83-113
                     external_tick_ ? 1 : 0));
 }
 
+bool Adam::step_reduced(const Communicator &comm) {
+    if (!comm.is_p2p() || !comm.fuse_adam || external_tick_ || carry_deferred_ || !deferred_.empty()) return false;
+    for (char f : fused_)
+        if (f) return false;
+    fp_.sync_mask(&fused_);   // grad-less tensors are skipped entirely (Q8); the mask is the same on every rank
+    TH(th_allreduce_adam(comm.handle(), Device::ctx(), fp_.g_arena->d, (size_t)fp_.total, 1.0f / (float)comm.n_ranks, fp_.p_arena->d, m_->d,
+                         v_->d, fp_.d_offsets(), fp_.d_has_grad(), (int)fp_.params.size(), d_tick(), state_->d + 2, beta1_, beta2_, eps_, wd_, 0));
+    return true;
+}
+
 int Adam::t() const {
     int32_t t = 0;
     TH(th_memcpy_d2h(Device::ctx(), &t, state_->d, sizeof(t)));
@@ -775,6 +785,57 @@ Communicator::Communicator(int n, int r, const std::vector<uint8_t> &id) : n_ran
 
 Communicator::~Communicator() { th_comm_destroy(comm_); }
 
+std::shared_ptr<Communicator> Communicator::p2p(int n, int r) {
+    std::shared_ptr<Communicator> c(new Communicator());
+    c->n_ranks = n;
+    c->rank = r;
+    c->p2p_ = true;
+    TH(th_comm_init_p2p(Device::ctx(), n, r, &c->comm_));
+    if (const char *e = std::getenv("TAPER_P2P_FUSE")) c->fuse_adam = e[0] != '0';   // measurement / test probe
+    return c;
+}
+
+std::vector<uint8_t> Communicator::export_arena(Optimizer &opt) {
+    TAPER_ASSERT(p2p_, "Communicator::export_arena: not a peer-to-peer communicator");
+    FlatParams &fp = opt.flat();
+    std::vector<uint8_t> blob(TH_P2P_BLOB_BYTES);
+    TH(th_comm_p2p_export(comm_, fp.g_arena->d, (size_t)fp.total, blob.data()));
+    return blob;
+}
+
+void Communicator::connect(const std::vector<uint8_t> &blobs) {
+    TAPER_ASSERT(p2p_ && blobs.size() == (size_t)n_ranks * TH_P2P_BLOB_BYTES, "Communicator::connect: expected one blob per rank");
+    TH(th_comm_p2p_connect(comm_, blobs.data()));
+}
+
+bool Communicator::self_check(Optimizer &opt) {
+    // every rank fills its arena with (rank + 1); the mean over W ranks is (W + 1) / 2 in every element, exactly
+    // representable -- anything else (an unmapped peer, stale data, a peer that never arrived) fails the check
+    FlatParams &fp = opt.flat();
+    th_ctx *ctx = Device::ctx();
+    const size_t n = (size_t)fp.total;
+    TH(th_fill_f32(ctx, fp.g_arena->d, (float)(rank + 1), n));
+    allreduce_mean(fp.g_arena->d, n);
+    std::vector<float> got(n);
+    TH(th_memcpy_d2h(ctx, got.data(), fp.g_arena->d, n * sizeof(float)));
+    TH(th_fill_f32(ctx, fp.g_arena->d, 0.f, n));
+    for (auto &p : fp.params) {
+        p.grad_->has = false;
+        p.grad_->known_zero = true;
+    }
+    Device::sync();
+    const float want = (float)(n_ranks + 1) / 2.0f;
+    bool ok = !(p2p_ && timed_out());
+    for (size_t i = 0; ok && i < n; ++i) ok = got[i] == want;
+    return ok;
+}
+
+bool Communicator::timed_out() const {
+    int e = 0;
+    TH(th_comm_error(comm_, Device::ctx(), &e));
+    return e != 0;
+}
+
 void Communicator::allreduce_mean(float *d_buf, size_t n) const {
     TH(th_allreduce_sum_scale(comm_, Device::ctx(), d_buf, n, 1.0f / (float)n_ranks));
 }
@@ -800,8 +861,10 @@ void Trainer::train_step(const Tensor &images, const Tensor &labels, float *loss
     Tensor loss = cross_entropy_loss(logits, labels);           // :107
     const float acc = accuracy(logits, labels);                 // :110
     loss.backward();                                            // :115
-    reduce_grads(*this);
-    optimizer->step();                                          // :118
+    if (!(comm && optimizer->step_reduced(*comm))) {
+        reduce_grads(*this);
+        optimizer->step();                                      // :118
+    }
     optimizer->zero_grad();                                     // :119
     if (loss_out) *loss_out = loss.data()[0];                   // :121
     if (acc_out) *acc_out = acc;
@@ -925,8 +988,10 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
         loss = cross_entropy_loss(model->forward(xin), y, &ncorrect, &sink);
     }
     loss.backward();
-    reduce_grads(*this);
-    optimizer->step();
+    if (!(comm && optimizer->step_reduced(*comm))) {   // peer-to-peer communicator: all-reduce + Adam in one launch
+        reduce_grads(*this);
+        optimizer->step();
+    }
     optimizer->zero_grad();
     if (adam) adam->set_carry_deferred(false);
 }
@@ -1007,12 +1072,13 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     // operator override: TAPER_DP_EAGER=1 keeps data-parallel steps out of hipGraphs (collectives launched eagerly)
     if (comm && !graph_capture_failed_ && std::getenv("TAPER_DP_EAGER") && std::getenv("TAPER_DP_EAGER")[0] == '1')
         graph_capture_failed_ = true;
-    // a ladder of sizes (chunk, chunk/4, chunk/16, ..., 1): the steps an epoch leaves over after its whole chunks
-    // replay as a few mid-sized graphs instead of dozens of single-step launches (~10 us of host time each)
+    // a binary ladder of sizes (chunk, chunk/2, chunk/4, ..., 1): whatever an epoch (or a short run: 20 steps = 16 + 4)
+    // leaves over after its whole chunks replays as at most log2(chunk) graphs instead of dozens of single-step
+    // launches (~10 us of host time each).  A size is recorded by the first call long enough to use it.
     std::vector<size_t> want;
-    for (size_t steps = chunk;; steps /= 4) {
+    for (size_t steps = chunk;; steps /= 2) {
         if (steps < 1) steps = 1;
-        if (!((steps > 1 && n_full < 2 * steps) || have(steps)) && std::find(want.begin(), want.end(), steps) == want.end())
+        if (!((steps > 1 && n_full < steps + 1) || have(steps)) && std::find(want.begin(), want.end(), steps) == want.end())
             want.push_back(steps);
         if (steps == 1) break;
     }

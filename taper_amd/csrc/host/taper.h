@@ -391,6 +391,9 @@ class Adam : public Optimizer {  // optim.rs:43-128
     Adam(const std::vector<Tensor> &params, float lr, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f,
          float weight_decay = 0.0f);
     void step() override;                          // optim.rs:83-113
+    // data parallel over a peer-to-peer communicator: all-reduce(mean) of the gradient arena and this step's update in ONE
+    // launch (th_allreduce_adam); false = not applicable here (the caller all-reduces in place, then step())
+    bool step_reduced(const class Communicator &comm);
     void zero_grad() override { fp_.zero_grad(); } // optim.rs:115-119
     float get_lr() const { return lr_; }
     void set_lr(float lr);                         // optim.rs:125-127
@@ -565,13 +568,26 @@ class DataLoader {  // mnist.rs:327-386
 class Communicator {
    public:
     static std::vector<uint8_t> unique_id();
-    Communicator(int n_ranks, int rank, const std::vector<uint8_t> &id);
+    Communicator(int n_ranks, int rank, const std::vector<uint8_t> &id);   // RCCL
+    // Peer-to-peer form (one node, <= 8 ranks; th_comm_init_p2p): a one-shot all-reduce for latency-bound gradient arenas.
+    // p2p() -> export_arena(optimizer) -> [ship every rank's blob to every rank] -> connect(blobs in rank order).
+    static std::shared_ptr<Communicator> p2p(int n_ranks, int rank);
+    std::vector<uint8_t> export_arena(Optimizer &opt);
+    void connect(const std::vector<uint8_t> &blobs);
+    bool is_p2p() const { return p2p_; }
+    bool timed_out() const;                               // a peer never arrived (synchronises)
+    // collective: all-reduce a known pattern through the optimizer's gradient arena and compare (call on every rank, before training)
+    bool self_check(Optimizer &opt);
     ~Communicator();
     void allreduce_mean(float *d_buf, size_t n) const;  // sum over ranks * 1/W on the ctx stream
+    th_comm *handle() const { return comm_; }
     int n_ranks, rank;
+    bool fuse_adam = true;                                // p2p: feed the mean gradient straight into Adam::step (th_allreduce_adam)
 
    private:
+    Communicator() : n_ranks(1), rank(0) {}
     th_comm *comm_ = nullptr;
+    bool p2p_ = false;
 };
 
 // ---- train (src/train.rs, examples/train_mnist*.rs) ------------------------------------
@@ -601,7 +617,7 @@ class Trainer {  // train.rs:74-172
     std::shared_ptr<Communicator> comm;   // optional: data-parallel grad all-reduce before step()
     Shape sample_shape;                   // {} -> feed [B,784]; {1,28,28} -> reshape like train_mnist_cnn.rs:161-162
     std::string device = "hip:gfx950";    // train.rs:79 "For future GPU support"
-    size_t graph_chunk = 128;             // steps captured per hipGraph replay (plus chunk/4, chunk/16, ..., 1-step graphs for the tail)
+    size_t graph_chunk = 128;             // steps captured per hipGraph replay (plus chunk/2, chunk/4, ..., 1-step graphs for the tail)
     int fuse_head = 2;                    // graph path: 1 = last Linear + cross-entropy as one launch; 2 = additionally the
                                           // backward (+ Adam) of a Linear+ReLU layer in front of it, same launch (th_mlp_tail)
     bool fuse_adam = true;                // Adam updates in the epilogue of the grad-producing kernels (graph path, no DP)

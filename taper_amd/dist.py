@@ -122,9 +122,40 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_data_parallel(T, rdzv: FileRendezvous | None):
-    """-> taper_amd.Communicator over RCCL (or None for a single rank)."""
+def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", optimizer=None):
+    """-> taper_amd.Communicator (or None for a single rank).
+    backend "rccl": RCCL all-reduce (ring / tree over xGMI) -- rank 0's unique id is broadcast.
+    backend "p2p":  the one-shot peer-to-peer all-reduce fused with Adam (th_allreduce_adam): every rank registers the
+                    gradient arena of `optimizer`, the IPC blobs are all-gathered, every rank maps its peers."""
     if rdzv is None or rdzv.world == 1:
         return None
+    if backend == "p2p":
+        if optimizer is None:
+            raise ValueError("init_data_parallel(backend='p2p') needs the optimizer whose gradient arena is reduced")
+        # Every step below is collective: a rank that fails (no IPC, no peer access) still takes part in the exchanges, and
+        # every rank learns the verdict -- nobody is left waiting in a barrier for a peer that has given up.
+        comm, err = None, ""
+        try:
+            comm = T.Communicator.p2p(rdzv.world, rdzv.rank)
+            blob = comm.export_arena(optimizer)
+        except Exception as e:   # noqa: BLE001 -- reported to every rank below
+            blob, err = b"\0" * 192, f"export: {e}"
+        blobs = rdzv.all_gather_bytes(blob)
+        if not err and any(b == b"\0" * 192 for b in blobs):
+            err = "a peer could not export its arena"
+        if not err:
+            try:
+                comm.connect(b"".join(blobs))
+            except Exception as e:   # noqa: BLE001
+                err = f"connect: {e}"
+        if rdzv.all_reduce_sum(1.0 if err else 0.0) > 0:
+            raise RuntimeError(f"peer-to-peer communicator unavailable (rank {rdzv.rank}: {err or 'a peer failed'})")
+        # a known pattern through the real arena on the real links: a rank that sees stale or no peer data must not train
+        ok = comm.self_check(optimizer)
+        if rdzv.all_reduce_sum(0.0 if ok else 1.0) > 0:
+            raise RuntimeError(f"peer-to-peer all-reduce self-check failed (rank {rdzv.rank}: {'ok' if ok else 'mismatch or timeout'})")
+        return comm
+    if backend != "rccl":
+        raise ValueError(f"unknown data-parallel backend {backend!r}")
     uid = rdzv.broadcast_bytes(T.Communicator.unique_id() if rdzv.rank == 0 else None, src=0)
     return T.Communicator(rdzv.world, rdzv.rank, uid)

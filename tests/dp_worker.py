@@ -1,0 +1,56 @@
+"""One rank of a data-parallel run of the PRODUCT Trainer (tests/test_gpu_dp.py spawns W of these).
+env: RANK / LOCAL_RANK / WORLD_SIZE (torchrun's contract), TAPER_DP_OUT (directory), TAPER_DP_STEPS, TAPER_DP_GLOBAL_BATCH,
+TAPER_DP_MODE (graph | eager), TAPER_DP_DEVICE (optional: every rank on this device -- the peer-to-peer communicator can share
+one GPU, RCCL cannot), TAPER_DP_BACKEND (rccl | p2p)."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def make_problem(steps, global_batch, seed=11):
+    from tests import backends
+    rng = np.random.default_rng(seed)
+    spec = backends.nonzero_biases(backends.mlp_baseline(rng), rng)
+    x, y = backends.mnist_like(rng, steps * global_batch)
+    return spec, x, y
+
+
+def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    steps, gb = int(os.environ["TAPER_DP_STEPS"]), int(os.environ["TAPER_DP_GLOBAL_BATCH"])
+    out = Path(os.environ["TAPER_DP_OUT"])
+    import taper_amd as T
+    from taper_amd.dist import FileRendezvous, init_data_parallel
+    from tests import backends
+    dev = os.environ.get("TAPER_DP_DEVICE")
+    T.Device.set_device(int(dev) if dev is not None else int(os.environ.get("LOCAL_RANK", rank)))
+    rdzv = FileRendezvous(rank, world, key=os.environ["TAPER_DP_KEY"], root=str(out), timeout_s=120)
+    spec, x, y = make_problem(steps, gb)
+    per = gb // world
+    rows = np.concatenate([np.arange(s * gb + rank * per, s * gb + (rank + 1) * per) for s in range(steps)])   # SURVEY 8e partitioning
+    H = backends.get("hip")
+    model = H.sequential(spec)
+    opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+    comm = init_data_parallel(T, rdzv, backend=os.environ.get("TAPER_DP_BACKEND", "rccl"), optimizer=opt)
+    tr = T.Trainer(model, opt, comm=comm)
+    loader = T.DataLoader(T.MNISTDataset.from_host(x[rows], y[rows]), per, False)
+    mode = T.Trainer.GRAPH if os.environ.get("TAPER_DP_MODE", "graph") == "graph" else T.Trainer.EAGER
+    ep = tr.run_epoch(loader, mode)
+    ep2 = tr.run_epoch(loader, mode)          # a second epoch over the same rows: the captured graphs are replayed
+    if comm is not None and comm.is_p2p() and comm.timed_out():
+        raise SystemExit(f"rank {rank}: a peer never arrived at the all-reduce")
+    st = comm.stats() if comm is not None and comm.is_p2p() else dict(inplace=-1, fused=-1)
+    np.savez(out / f"rank{rank}.npz", launches_inplace=st["inplace"], launches_fused=st["fused"], losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
+             **{f"p{i}": p.data() for i, p in enumerate(model.parameters())})
+    rdzv.barrier()
+    rdzv.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,4 +126,99 @@ def test_file_rendezvous(world, tmp_path):
         assert mx == 1.5 + world - 1
         assert sm == 10.0 * world * (world + 1) / 2
         assert ga == [bytes([r]) for r in range(world)]
-    assert not (tmp_path / "taper_rdzv_t").exists()
+    assert not list(tmp_path.glob("taper_rdzv_*"))          # last one out removed the directory
+
+
+def test_rendezvous_directory_is_private_and_owned(tmp_path):
+    """/dev/shm is world-writable: the directory must be 0700, a real directory and ours"""
+    from taper_amd.dist import FileRendezvous
+    r = FileRendezvous(0, 1, key="own", root=str(tmp_path))
+    st = os.lstat(r.dir)
+    assert st.st_mode & 0o777 == 0o700 and st.st_uid == os.getuid()
+    r.close()
+    # a directory someone else could write into is refused
+    loose = tmp_path / f"taper_rdzv_{os.getuid()}_loose"
+    loose.mkdir(mode=0o777)
+    os.chmod(loose, 0o777)
+    with pytest.raises(PermissionError):
+        FileRendezvous(0, 1, key="loose", root=str(tmp_path))
+    # so is a symlink planted under the predictable name
+    target = tmp_path / "elsewhere"
+    target.mkdir(mode=0o700)
+    (tmp_path / f"taper_rdzv_{os.getuid()}_link").symlink_to(target)
+    with pytest.raises(PermissionError):
+        FileRendezvous(0, 1, key="link", root=str(tmp_path))
+
+
+class _FakeCommunicator:
+    """stands in for taper_amd.Communicator (RCCL needs GPUs): records what init_data_parallel hands it"""
+    made = []
+
+    def __init__(self, world, rank, uid):
+        self.world, self.rank, self.uid = world, rank, uid
+        _FakeCommunicator.made.append(self)
+
+    @staticmethod
+    def unique_id():
+        return bytes([os.getpid() % 251]) * 128          # differs per process: only rank 0's may be used
+
+
+class _FakeT:
+    Communicator = _FakeCommunicator
+
+
+def _init_dp_worker(rank, world, root, q):
+    sys.path.insert(0, str(ROOT))
+    # what torch.distributed.run / bench.py's self-spawn put in the environment
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29555")
+    from taper_amd.dist import FileRendezvous, env_rank_world, init_data_parallel
+    r, w, lr = env_rank_world()
+    rdzv = FileRendezvous(r, w, key="dp", root=root, timeout_s=60)
+    comm = init_data_parallel(_FakeT, rdzv)
+    # the shard of a 1024-row global batch this rank trains on (SURVEY 8e: rows [r*B/W, (r+1)*B/W))
+    per = 1024 // w
+    rows = (r * per, (r + 1) * per)
+    mx = rdzv.all_reduce_max(float(r))
+    rdzv.close()
+    q.put((rank, (r, w, lr), comm.world, comm.rank, comm.uid, _FakeCommunicator.unique_id(), rows, mx))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_init_data_parallel_control_flow(world, tmp_path):
+    """the product's launch-side logic on CPU: env -> (rank, world), rank 0's RCCL unique id reaches every rank, every rank builds
+    its communicator as (world, rank, that id), shards tile the global batch"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_init_dp_worker, args=(r, world, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    uid0 = res[0][5]                                     # what rank 0's unique_id() returns
+    covered = []
+    for rank, env, cw, cr, uid, _own, rows, mx in res:
+        assert env == (rank, world, rank)
+        assert (cw, cr) == (world, rank)
+        assert uid == uid0 and len(uid) == 128           # broadcast from rank 0, never a rank's own
+        assert mx == float(world - 1)
+        covered.append(rows)
+    assert covered == [(r * 1024 // world, (r + 1) * 1024 // world) for r in range(world)]
+    from taper_amd.dist import init_data_parallel
+    assert init_data_parallel(_FakeT, None) is None      # a single rank has no communicator
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher self-spawns N ranks -- and must not quietly run a smaller job when the box
+    has fewer GPUs (it used to fall back to 1 rank)"""
+    import subprocess
+    from taper_amd import hip
+    if hip.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and "visible" in r.stderr
+    assert r.stdout.strip() == ""

@@ -1,0 +1,124 @@
+"""W > 1 execution of the PRODUCT's data-parallel path: W processes, each running taper_amd's Trainer on its
+shard of every global batch with a Communicator between backward and Adam::step.  Checked: replicas bit-identical, and
+weights / losses equal to ONE process training on the full global batch (the mean of shard-mean gradients is the full-batch
+gradient).  The RCCL communicator needs one GPU per rank (skipped on a 1-GPU box); the peer-to-peer communicator
+(th_p2p_*: each rank reads its peers' gradient arenas through IPC handles) also runs with every rank on ONE GPU, which
+is how the 1-GPU CI box executes a real W = 2 / W = 4 step."""
+import os
+import subprocess
+import sys
+import uuid
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run_ranks(tmp_path, world, backend, mode, steps, global_batch, same_device, fuse=True):
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env0["TAPER_P2P_FUSE"] = "1" if fuse else "0"
+    key = uuid.uuid4().hex[:12]
+    procs = []
+    for r in range(world):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29561",
+                   TAPER_DP_OUT=str(tmp_path), TAPER_DP_STEPS=str(steps), TAPER_DP_GLOBAL_BATCH=str(global_batch), TAPER_DP_MODE=mode,
+                   TAPER_DP_BACKEND=backend, TAPER_DP_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if same_device:
+            env["TAPER_DP_DEVICE"] = "0"
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dp_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+
+
+def _single_process_reference(steps, global_batch):
+    """the same optimisation in ONE process on the full global batches (two epochs, like the workers)"""
+    import taper_amd as T
+    from tests import backends
+    from tests.dp_worker import make_problem
+    spec, x, y = make_problem(steps, global_batch)
+    H = backends.get("hip")
+    model = H.sequential(spec)
+    opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+    tr = T.Trainer(model, opt)
+    loader = T.DataLoader(T.MNISTDataset.from_host(x, y), global_batch, False)
+    losses = np.concatenate([tr.run_epoch(loader, T.Trainer.GRAPH)["losses"] for _ in range(2)])
+    return losses, [p.data() for p in model.parameters()], opt.t()
+
+
+def _check(ranks, world, steps, global_batch):
+    ref_losses, ref_params, ref_t = _single_process_reference(steps, global_batch)
+    n_params = len(ref_params)
+    for r in range(world):
+        assert int(ranks[r]["t"]) == ref_t == 2 * steps
+        for i in range(n_params):
+            np.testing.assert_array_equal(ranks[r][f"p{i}"], ranks[0][f"p{i}"], err_msg=f"rank {r} param {i}: replicas diverged")
+    # loss of the global batch = mean of the shard losses (each a mean over B/W rows)
+    mean_losses = np.mean([ranks[r]["losses"] for r in range(world)], axis=0)
+    np.testing.assert_allclose(mean_losses, ref_losses, rtol=3e-4, atol=1e-5)
+    for i in range(n_params):
+        np.testing.assert_allclose(ranks[0][f"p{i}"], ref_params[i], rtol=1e-4, atol=1e-3 * 5e-2, err_msg=f"param {i}")
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_rccl_two_ranks_equal_full_batch(tmp_path, mode):
+    from taper_amd import hip
+    if hip.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has %d" % hip.device_count())
+    ranks = _run_ranks(tmp_path, 2, "rccl", mode, steps=6, global_batch=256, same_device=False)
+    _check(ranks, 2, 6, 256)
+
+
+@pytest.mark.parametrize("world,mode,fuse", [(2, "graph", True), (2, "eager", True), (4, "graph", True), (2, "graph", False), (8, "graph", True),
+                                             (8, "eager", False)])
+def test_p2p_ranks_on_one_gpu_equal_full_batch(tmp_path, world, mode, fuse):
+    """the one-shot peer-to-peer all-reduce with every rank on GPU 0: a real multi-process step on the 1-GPU box.
+    fuse: all-reduce + Adam in one launch (th_allreduce_adam); otherwise th_allreduce_sum_scale in place, then Adam::step"""
+    ranks = _run_ranks(tmp_path, world, "p2p", mode, steps=6, global_batch=256, same_device=True, fuse=fuse)
+    _check(ranks, world, 6, 256)
+    for r in ranks:     # the path under test is the one that ran (eager: one launch per step; graph: one per captured step + the eager ones)
+        used, other = ("launches_fused", "launches_inplace") if fuse else ("launches_inplace", "launches_fused")
+        assert int(r[used]) >= 6 and int(r[other]) == 0, (int(r["launches_fused"]), int(r["launches_inplace"]))
+
+
+def test_p2p_ranks_on_separate_gpus(tmp_path):
+    from taper_amd import hip
+    if hip.device_count() < 2:
+        pytest.skip("needs 2 GPUs; this box has %d" % hip.device_count())
+    ranks = _run_ranks(tmp_path, 2, "p2p", "graph", steps=6, global_batch=256, same_device=False)
+    _check(ranks, 2, 6, 256)
+
+
+def test_bench_self_spawn_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher spawns the ranks itself; with the test hook that lets them share GPU 0 the whole
+    N > 1 bench flow (rendezvous, p2p bootstrap + self-check, timed region with barriers, replica check, single-GPU figure of the
+    same per-GPU batch) runs on the 1-GPU box"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(TAPER_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5", "--dp-backend", "p2p"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["config"]["workload"] == "mlp_784-128-10_b128"   # BASELINE configs[3]: 128 rows per GPU
+    assert d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp2" and "p2p" in d["config"]["comm"]
+    dp = d["data_parallel"]
+    assert dp["replicas_bit_identical"] is True
+    assert dp["single_gpu_same_per_gpu_batch"]["per_gpu_batch"] == 128 and dp["single_gpu_same_per_gpu_batch"]["value"] > 0
+    assert dp["dp_at_64_rows_per_gpu"]["replicas_bit_identical"] is True
+    assert d["value"] > 0 and d["value"] == pytest.approx(40 * 256 / (d["ms_per_step"] * 1e-3 * 40), rel=1e-3)
