@@ -710,7 +710,7 @@ def main():
             # rocprofv3 (ROCm 7.2) segfaults in hipGraphLaunch once a process replays more than one
             # instantiated graph back to back; the Trainer's replays above are what the trace is for.
             roof = dict(skipped="per-kernel timers are not run under rocprofv3; see profiles/ for the trace of this command")
-        elif key == "mlp_baseline" and not args.no_roofline and batch <= 512:
+        elif key == "mlp_baseline" and not args.no_roofline and batch <= 512 and world == 1:
             # per-launch durations of the step's two kernels, measured live (HIP events on the ctx
             # stream, graph chains with / without each launch).  `roofline` is the kernel that carries
             # the step's HBM traffic (83% of its algorithmic bytes); the full list is in `kernels`.

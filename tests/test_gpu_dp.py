@@ -90,8 +90,11 @@ def test_p2p_ranks_on_one_gpu_equal_full_batch(tmp_path, world, mode, fuse):
     ranks = _run_ranks(tmp_path, world, "p2p", mode, steps=6, global_batch=256, same_device=True, fuse=fuse)
     _check(ranks, world, 6, 256)
     for r in ranks:     # the path under test is the one that ran (eager: one launch per step; graph: one per captured step + the eager ones)
-        used, other = ("launches_fused", "launches_inplace") if fuse else ("launches_inplace", "launches_fused")
-        assert int(r[used]) >= 6 and int(r[other]) == 0, (int(r["launches_fused"]), int(r["launches_inplace"]))
+        fused, inplace = int(r["launches_fused"]), int(r["launches_inplace"])
+        if fuse:
+            assert fused >= 6 and inplace == 1, (fused, inplace)       # the bootstrap's self-check is the one in-place launch
+        else:
+            assert inplace >= 7 and fused == 0, (fused, inplace)
 
 
 def test_p2p_ranks_on_separate_gpus(tmp_path):
