@@ -407,8 +407,12 @@ def conv_layer_kernels(ctx, layers, reps=60):
         flops = 18.0 * ci * co * hw * hw * n
         nbytes = 4.0 * (n * ci * hw * hw + n * co * ho * ho + 9 * ci * co + co)
         tf, gbs = flops / (us * 1e-6) / 1e12, nbytes / (us * 1e-6) / 1e9
-        kern = ("conv1_pool2_kernel" if pool else "conv1_kernel") if ci == 1 else \
-            f"conv3x3_mfma_kernel<{cfg[0]}, false, 8, {'true' if pool else 'false'}, {cfg[2]}, {'true' if cfg[1] else 'false'}>"
+        if ci == 1:
+            kern = "conv1_pool2_kernel" if pool else "conv1_kernel"
+        elif cfg[1] == 2:    # image-resident: <channel tiles, pixel tiles per wave, pooled epilogue>, cfg[4] whole images per workgroup
+            kern = f"conv3x3_img_kernel<{cfg[0]}, {cfg[2]}, {'true' if pool else 'false'}>"
+        else:
+            kern = f"conv3x3_mfma_kernel<{cfg[0]}, false, 8, {'true' if pool else 'false'}, {cfg[2]}, {'true' if cfg[1] else 'false'}>"
         bound = "hbm" if ci == 1 else "mfma"
         out.append(dict(kernel=kern, layer=name, us_per_launch=round(us, 2), alg_flops_per_launch=flops, alg_bytes_per_launch=nbytes,
                         bound=bound, achieved=round(gbs if bound == "hbm" else tf, 2), peak=HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TF,

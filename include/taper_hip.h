@@ -317,8 +317,13 @@ int th_conv3x3_pool2_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const 
                          int n, int c_in, int h, int w, int c_out, int pad, int relu);
 /* Test hook: launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity
  * tests assert which kernel instance a shape takes): out6 = {16-channel tiles per workgroup (1/2/4), 1 if the
- * operands are staged by LDS-DMA, waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */
+ * operands are staged by LDS-DMA (2: the image-resident kernel), waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */
 int th_debug_last_conv_config(th_ctx *ctx, int *out6);
+/* Test hook: which matrix-core kernel takes a 3x3 launch.  -1 (default): the image-resident kernel (whole images per
+ * workgroup, every output tile in registers; out6[1] == 2 in th_debug_last_conv_config, out6[2] = pixel tiles per wave,
+ * out6[4] = images per unit) when the launch has at least one unit per two CUs, the 128-pixel kernel otherwise; 0: never;
+ * 1: whenever the shape fits it. */
+int th_debug_set_conv_img(th_ctx *ctx, int mode);
 /* 1x1 stride-1 pad-0 convolution as GEMM.  layout 0 = taper (raw NCHW buffer
  * reinterpreted as [N*H*W, C], tensor.rs:1799-1801, Q4 + Q3); 1 = standard. */
 int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <array>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -66,6 +67,8 @@ struct th_ctx {
     bool capturing = false;
     std::vector<void *> capture_blocks;               // allocated during the current capture
     std::multimap<size_t, void *> capture_free;       // freed again during the capture
+    // staging plans of the image-resident conv kernel, built on device once per geometry (conv_mfma.hip); plain hipMalloc, freed with the ctx
+    std::map<std::array<int, 8>, void *> conv_plans;
 };
 
 struct th_graph {

@@ -67,7 +67,9 @@ __device__ long long g_conv_clk[2 * 4096];  // shader clock (clock64) at start /
 #define CONV_TL(slot) do { const int id_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && id_ < 4096) { g_conv_tl[4 * id_ + (slot)] = wall_clock64(); if ((slot) != 1) g_conv_clk[2 * id_ + ((slot) >> 1)] = clock64(); } } while (0)
 #define CONV_TL_HW() do { const int id_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && id_ < 4096) g_conv_tl[4 * id_ + 3] = ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } while (0)
 #define CONV_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 300 && blockIdx.y == 0) g_conv_prof[i] = wall_clock64(); } while (0)
+#define IMG_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 100) { g_conv_prof[i] = wall_clock64(); if ((i) == 2 || (i) == 3) g_conv_prof[3 + (i)] = clock64(); } } while (0)
 #else
+#define IMG_STAMP(i) do { } while (0)
 #define CONV_STAMP(i) do { } while (0)
 #define CONV_TL(slot) do { } while (0)
 #define CONV_TL_HW() do { } while (0)
@@ -366,6 +368,275 @@ __global__ __launch_bounds__(256 * WH, (CT <= 2 && WH == 1) ? 4 : 1) void conv3x
     CONV_TL(2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3x3_img_kernel -- the same contraction with the loops turned inside out, for launches big enough to give every
+// CU a whole unit of work (the batch-256 layers of the CNNs): a workgroup owns IMG WHOLE IMAGES x CO_B output
+// channels and keeps EVERY output tile of the unit in registers -- wave w holds pixel tiles w, w + 4, ... (<= TPW of
+// them) x CT channel tiles -- while the input channels stream through LDS eight at a time.  Per kernel (not per 128
+// pixels): one set of staging plans, c_in / 8 barriers, one epilogue; the weight slab of a pass is staged once for
+// all of the unit's pixels.  The launch planner picks (IMG, CT) so that the units tile the 256 CUs evenly (one image
+// of a 28x28 layer, four of a 14x14 layer, eight of a 7x7 layer = 49 / 49 / 25 pixel tiles), which the
+// 128-pixel kernel above cannot do: its 430 workgroups on the 14x14 layers run as 2 + 1 per CU (r01: 0.34-0.44 of the
+// fp32 matrix peak, a workgroup's fixed prologue / epilogue ~9 us against 9-18 us of MFMA work).
+// Same operand layouts, same k order (exact fp32 fmaf chains in the same order: bit-identical to the kernel above),
+// same LDS-DMA staging with zero halos from the buffer descriptor's range check.
+constexpr int IM_PPT = 16;            // patch elements per thread per pass (patch <= 8192 floats, 512 threads)
+
+struct ConvImgArgs {
+    const float *x, *w, *bias;
+    float *y;
+    int n, c_in, h, w_in, c_out, pad, h_out, w_out, w_ld, w_cols;
+    int img_t;             // images per unit
+    int n_groups, n_co;    // image groups, channel blocks
+    int relu;
+    const int *goff_tab;   // [512 * IM_PPT] patch element -> byte offset within channel block 0 of the unit's first image (or past-the-end)
+    const int *pix_tab;    // [pixel tile slots * 16] pixel -> LDS offset of its window corner
+};
+
+// The per-thread staging plans are the same for every workgroup of a launch and for every launch of a geometry: patch element
+// e -> (channel, image, row, column) -> global byte offset or "halo", pixel p -> window corner.  Worked out in every workgroup they
+// cost ~40 float-reciprocal divisions per thread -- 5.2 us of a 52 us launch with two waves per SIMD; as tables (built on device once
+// per geometry, cached in the ctx) they are 16 + TPW coalesced loads.  Images past the batch's end need no entry of their own: their
+// offsets lie beyond the range of the unit's buffer descriptor and read as zero.
+__global__ void conv_img_tables_kernel(int *goff, int *pix, int n_goff, int n_pix, int c_in, int h, int w_in, int pad, int img_t) {
+    const int h_out = h + 2 * pad - 2, w_out = w_in + 2 * pad - 2, wp = w_out + 2, rp = h_out + 2;
+    const int img_stride = rp * wp, ci_stride = img_t * img_stride, patch_n = MF_CI * ci_stride, shift = 1 - pad;
+    const int px_img = h_out * w_out, m_full = img_t * px_img;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_goff + n_pix; e += gridDim.x * blockDim.x) {
+        if (e < n_goff) {
+            int v = MF_OOB;
+            if (e < patch_n) {
+                const int cl = e / ci_stride, r1 = e % ci_stride, il = r1 / img_stride, r2 = r1 % img_stride, rr = r2 / wp, cc = r2 % wp;
+                const int ih = rr - 1 + shift, iw = cc - 1 + shift;
+                if (ih >= 0 && ih < h && iw >= 0 && iw < w_in) v = (int)(((((long)il * c_in + cl) * h + ih) * w_in + iw) << 2);
+            }
+            goff[e] = v;
+        } else {
+            const int p0 = e - n_goff, p = p0 < m_full ? p0 : 0;
+            const int il = p / px_img, rem = p % px_img;
+            pix[p0] = il * img_stride + (rem / w_out) * wp + rem % w_out;
+        }
+    }
+}
+
+// 8 waves (two per SIMD: while one wave requests its next operands, computes addresses or stages, the other's MFMAs run -- a lone wave per
+// SIMD issues one instruction per 4 cycles and nothing of that overlapped its own matrix work: measured 34 % matrix-pipe busy).
+// Every wave owns ONE channel tile and TPW pixel tiles: CT = 2 -> waves 0-3 / 4-7 take channel tile 0 / 1 on pixel groups 0-3
+// (tile = group + 4 i); CT = 1 -> eight pixel groups (tile = wave + 8 i).
+template <int CT, int TPW, bool POOL>
+__global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CO_B = 16 * CT, KS = 18, NT = 512, WQ = KS * 4 * CO_B / 4, WPT = (WQ + NT - 1) / NT, PG = CT == 2 ? 4 : 8;
+    // units of one image group sit on one XCD (blocks go round-robin over the 8 XCDs): its channel blocks share the input in that L2
+    const int xcd = blockIdx.x & 7, q8 = blockIdx.x >> 3;
+    const int grp = xcd + 8 * (q8 / a.n_co), cob = q8 % a.n_co;
+    if (grp >= a.n_groups) return;
+    IMG_STAMP(0);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
+    const int pg = wave % PG, cj = wave / PG;                // pixel group, channel tile of this wave
+    const int wp = a.w_out + 2, rp = a.h_out + 2;
+    const int img_stride = rp * wp, ci_stride = a.img_t * img_stride, patch_n = MF_CI * ci_stride;
+    const int img0 = grp * a.img_t, co0 = cob * CO_B;
+    const int imgs_here = min(a.img_t, a.n - img0);
+    const int px_img = a.h_out * a.w_out, m_unit = imgs_here * px_img;
+    const FastDiv d_pxi(px_img);
+
+    int pix_off[TPW];                 // LDS offset of the window corner of this lane's pixel in each of its tiles
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) pix_off[i] = a.pix_tab[(pg + PG * i) * 16 + l16];
+    int p_goff[IM_PPT];               // byte offset within channel block 0 of image img0, or past-the-end (reads as zero)
+#pragma unroll
+    for (int j = 0; j < IM_PPT; ++j) p_goff[j] = a.goff_tab[t + NT * j];
+    int koff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int kk = 4 * s + g4, cl = kk / 9, tap = kk % 9;
+        koff[s] = cl * ci_stride + (tap / 3) * wp + (tap % 3);
+    }
+    const long chan = (long)a.h * a.w_in;
+    const float *xbase = a.x + (long)img0 * a.c_in * chan;
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const int stage_n = ((patch_n + 4) & ~3) + 4 * KS * CO_B;
+    const int w0 = wave * 64;
+    int w_boff[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int u = t + NT * j, kk = u / (CO_B / 4), cq = (u % (CO_B / 4)) * 4;
+        w_boff[j] = (u < WQ && co0 + cq + 3 < a.w_cols) ? (kk * a.w_ld + co0 + cq) << 2 : MF_OOB;
+    }
+    const int x_bytes = (int)((long)imgs_here * a.c_in * chan * 4), w_bytes = 9 * a.c_in * a.w_ld * 4;
+    auto issue = [&](int cb, int stage) {
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(xbase + (long)cb * chan), 0, x_bytes - (int)(cb * chan * 4), 0x00020000);
+        const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)(a.w + (long)cb * 9 * a.w_ld), 0, w_bytes - cb * 9 * a.w_ld * 4, 0x00020000);
+        float *st = lds + stage * stage_n;
+        float *ws = st + ((patch_n + 4) & ~3);
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            if (NT * (j + 1) <= WQ)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws + 4 * (w0 + NT * j)), 16, w_boff[j], 0, 0, 0);
+            else if (NT * j < WQ && t + NT * j < WQ)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws + 4 * (w0 + NT * j)), 16, w_boff[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < IM_PPT; ++j) {
+            if (NT * (j + 1) <= patch_n)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + w0 + NT * j), 4, p_goff[j], 0, 0, 0);
+            else if (NT * j < patch_n && t + NT * j < patch_n)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + w0 + NT * j), 4, p_goff[j], 0, 0, 0);
+        }
+    };
+    floatx4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    IMG_STAMP(1);
+    issue(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    IMG_STAMP(2);
+    int stage = 0;
+    for (int cb = 0; cb < a.c_in; cb += MF_CI, stage ^= 1) {
+        const bool more = cb + MF_CI < a.c_in;
+        if (more) issue(cb + MF_CI, stage ^ 1);
+        const float *pp = lds + stage * stage_n, *ww = pp + ((patch_n + 4) & ~3) + l16 + 16 * cj;
+        // The operands of k-step s + 1 are requested before the MFMAs of step s are issued, and pinned there: left alone, the scheduler
+        // sinks every read to its use -- one exposed LDS round trip per tile (68 us on the 28x28 layer with one wave per SIMD).
+        // Measured alternatives (28x28 layer, 32 -> 32, batch 256, this form 50.9 us): one request per MFMA, interleaved through
+        // sched_group_barrier: 62 us; the two waves of a SIMD in anti-phase (one requests while the other computes): 51.7 us; the
+        // LDS-DMA instructions of the next stage spread one per k-step instead of a burst at the top of the pass: 52.2 us.  With the LDS
+        // requests compiled out the k loop takes 35.4 us against 38.3 us with them (shader clock 2.13 GHz): the 13 back-to-back MFMAs
+        // per k-step and wave run at ~44 cycles each where 32 is the pipe's rate -- the matrix pipe itself, not its feeding, bounds this loop.
+        float b0[TPW], b1[TPW], a0, a1 = 0.f;
+#ifdef TH_IMG_NO_READS   /* timing probe: the k loop without its LDS requests (wrong results) */
+#define TH_IMG_REQ(B, A, S) { _Pragma("unroll") for (int i = 0; i < TPW; ++i) B[i] = __builtin_bit_cast(float, pix_off[i] + (S)); A = __builtin_bit_cast(float, koff[S]); }
+#else
+#define TH_IMG_REQ(B, A, S)                                                                  \
+        {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < TPW; ++i) B[i] = pp[pix_off[i] + koff[S]]; \
+            A = ww[(4 * (S) + g4) * CO_B];                                                   \
+        }
+#endif
+        TH_IMG_REQ(b0, a0, 0)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) TH_IMG_REQ(b1, a1, s + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            // (tile slots past the unit's last pixel tile compute on pixel 0 and are never stored: no per-tile branch in the stream)
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) b0[i] = b1[i];
+                a0 = a1;
+            }
+        }
+#undef TH_IMG_REQ
+        if (more) {
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+    }
+
+    IMG_STAMP(3);
+    // bias of this lane's four channels (co0 + 16 cj + 4 g4 + e)
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int co = co0 + 16 * cj + 4 * g4 + e;
+        bv[e] = (a.bias && co < a.c_out) ? a.bias[co] : 0.f;
+    }
+    if (POOL) {
+        // bias + ReLU into an LDS tile [CO_B][pixels of the unit], then the 2x2 / stride-2 maxima go to the pooled tensor
+        __syncthreads();
+        const int ep_ld = (a.img_t * px_img) | 1;
+        float *ep = lds;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int p = (pg + PG * i) * 16 + l16;
+            if (p >= m_unit) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[i][e] + bv[e];
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                ep[(16 * cj + 4 * g4 + e) * ep_ld + p] = v;
+            }
+        }
+        __syncthreads();
+        const int pw = a.w_out >> 1, np_img = (a.h_out >> 1) * pw, np = imgs_here * np_img;
+        const FastDiv d_np(np), d_npi(np_img), d_pw(pw);
+        for (int idx = t; idx < CO_B * np; idx += NT) {
+            int cl, rem, il, r2, pr, pc;
+            d_np.divmod(idx, cl, rem);
+            d_npi.divmod(rem, il, r2);
+            d_pw.divmod(r2, pr, pc);
+            if (co0 + cl >= a.c_out) continue;
+            const float *b = ep + cl * ep_ld + il * px_img + 2 * pr * a.w_out + 2 * pc;
+            float m = -INFINITY;                           // strict >: NaN never wins (tensor.rs:1449-1461)
+            m = b[0] > m ? b[0] : m;
+            m = b[1] > m ? b[1] : m;
+            m = b[a.w_out] > m ? b[a.w_out] : m;
+            m = b[a.w_out + 1] > m ? b[a.w_out + 1] : m;
+            a.y[((long)(img0 + il) * a.c_out + co0 + cl) * np_img + r2] = m;
+        }
+        IMG_STAMP(4);
+        return;
+    }
+    const long ochan = (long)px_img;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int p = (pg + PG * i) * 16 + l16;
+        if (p >= m_unit) continue;
+        int il, rem;
+        d_pxi.divmod(p, il, rem);
+        float *ypx = a.y + ((long)(img0 + il) * a.c_out) * ochan + rem;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = co0 + 16 * cj + 4 * g4 + e;
+            if (co >= a.c_out) continue;
+            float v = acc[i][e] + bv[e];
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            ypx[(long)co * ochan] = v;
+        }
+    }
+    IMG_STAMP(4);
+#endif
+}
+
+// (IMG, CT, TPW) of the image-resident kernel for a launch, or false: the 128-pixel kernel keeps it.  Cost of a candidate =
+// rounds of units over the 256 CUs x MFMAs per wave and pass (TPW slots x CT); the instance table below fixes TPW to 4 / 7 / 13.
+struct ConvImgPlan { int img_t, ct, tpw, n_groups, n_co; size_t lds; };
+static bool conv_img_plan(int n, int c_in, int h, int w_in, int c_out, int pad, bool pool, ConvImgPlan *out) {
+    const int h_out = h + 2 * pad - 2, w_out = w_in + 2 * pad - 2;
+    if (c_in % MF_CI != 0 || h_out < 1 || w_out < 1) return false;
+    if (pool && ((h_out | w_out) & 1)) return false;
+    long best = -1;
+    for (int ct = 1; ct <= 2; ++ct) {
+        if (ct == 2 && c_out <= 16) continue;
+        for (int img = 1; img <= 16; ++img) {
+            const long px = (long)img * h_out * w_out;
+            const int npt = (int)((px + 15) / 16), tpw_need = ct == 2 ? (npt + 3) / 4 : (npt + 7) / 8;   // 4 / 8 pixel groups of waves
+            const int tpw = tpw_need <= 4 ? 4 : (tpw_need <= 7 ? 7 : (tpw_need <= 13 ? 13 : 0));
+            if (!tpw) break;
+            const long patch_n = (long)MF_CI * img * (h_out + 2) * (w_out + 2);
+            if (patch_n > (long)IM_PPT * 512) break;
+            size_t lds = (size_t)2 * ((((size_t)patch_n + 4) & ~(size_t)3) + (size_t)72 * 16 * ct) * sizeof(float);
+            if (pool) lds = std::max(lds, (size_t)16 * ct * ((size_t)px | 1) * sizeof(float));
+            if (lds > (150u << 10)) continue;
+            if ((long)img * c_in * h * w_in >= (1L << 28) || (long)9 * c_in * c_out >= (1L << 28)) continue;
+            const int n_groups = ceil_div(n, img), n_co = ceil_div(c_out, 16 * ct);
+            const long units = (long)n_groups * n_co, rounds = (units + kNumCU - 1) / kNumCU;
+            const long cost = rounds * tpw * 1000 + (ct == 1 ? 1 : 0) + (units < kNumCU ? (kNumCU - units) * 4 : 0);   // MFMAs per wave and pass x rounds
+            if (best < 0 || cost < best) {
+                best = cost;
+                *out = ConvImgPlan{img, ct, tpw, n_groups, n_co, lds};
+            }
+        }
+    }
+    return best >= 0;
+}
+
 // images x rows per workgroup: the fullest tiling of <= 128 pixels by whole output rows of one or more images
 static void conv_mfma_plan(int h_out, int w_out, int n, int *img_t, int *rows_t, int cit = MF_CI, bool even_rows = false) {
     int best_fill = -1;
@@ -403,12 +674,60 @@ bool conv3x3_mfma_pool_supported(int c_in, int h, int w, int pad) {   // whole 2
            MF_CI * 4 * (w_out + 2) <= MF_PPT * 256;
 }
 
+// -1: the image-resident kernel takes launches with >= one unit per two CUs; 0: never; 1: whenever a plan exists
+// (TAPER_CONV_IMG at load, th_debug_set_conv_img at run time: the parity tests force both kernels onto the same shapes)
+int g_conv_img_mode = getenv("TAPER_CONV_IMG") ? atoi(getenv("TAPER_CONV_IMG")) : -1;
+
 // launch configuration of this thread's most recent matrix-core convolution (th_debug_last_conv_config)
 thread_local int t_last_conv_cfg[6] = {0, 0, 0, 0, 0, 0};
 
 int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
                         int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool) {
     TH_REQUIRE(w_ld % 4 == 0 && ((uintptr_t)w & 15) == 0, "conv3x3_mfma: weight rows must be 16-byte aligned");
+    {
+        // launches with at least a unit per two CUs take the image-resident kernel (TAPER_CONV_IMG = 0 / 1: never / whenever it fits)
+        const int img_env = g_conv_img_mode;
+        ConvImgPlan pl{};
+        if (img_env != 0 && !accum && c_in >= MF_CI && conv_img_plan(n, c_in, h, w_in, c_out, pad, pool, &pl) &&
+            (img_env == 1 || (long)pl.n_groups * pl.n_co >= kNumCU / 2)) {
+            ConvImgArgs g{};
+            g.x = x; g.w = w; g.bias = bias; g.y = y;
+            g.n = n; g.c_in = c_in; g.h = h; g.w_in = w_in; g.c_out = c_out; g.pad = pad;
+            g.h_out = h + 2 * pad - 2; g.w_out = w_in + 2 * pad - 2; g.w_ld = w_ld; g.w_cols = w_cols;
+            g.img_t = pl.img_t; g.n_groups = pl.n_groups; g.n_co = pl.n_co; g.relu = relu;
+            {   // staging plans of this geometry: built on device the first time, kept with the ctx
+                const int pgs = pl.ct == 2 ? 4 : 8, n_goff = 512 * IM_PPT, n_pix = pgs * pl.tpw * 16;
+                const std::array<int, 8> key{h, w_in, pad, c_in, pl.img_t, pgs, pl.tpw, 0};
+                auto it = ctx->conv_plans.find(key);
+                if (it == ctx->conv_plans.end()) {
+                    void *tab = nullptr;
+                    TH_HIP(hipMalloc(&tab, (size_t)(n_goff + n_pix) * sizeof(int)));
+                    hipLaunchKernelGGL(conv_img_tables_kernel, dim3(ceil_div(n_goff + n_pix, 256)), dim3(256), 0, ctx->stream, (int *)tab,
+                                       (int *)tab + n_goff, n_goff, n_pix, c_in, h, w_in, pad, pl.img_t);
+                    TH_LAUNCH_CHECK();
+                    it = ctx->conv_plans.emplace(key, tab).first;
+                }
+                g.goff_tab = (const int *)it->second;
+                g.pix_tab = g.goff_tab + n_goff;
+            }
+            const dim3 grid(8 * ceil_div(pl.n_groups, 8) * pl.n_co);
+#define TH_IMG(CTV, TPWV)                                                                                                   \
+            if (pool) { (void)hipFuncSetAttribute((const void *)conv3x3_img_kernel<CTV, TPWV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);   \
+                        hipLaunchKernelGGL((conv3x3_img_kernel<CTV, TPWV, true>), grid, dim3(512), pl.lds, ctx->stream, g); }  \
+            else { (void)hipFuncSetAttribute((const void *)conv3x3_img_kernel<CTV, TPWV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);       \
+                   hipLaunchKernelGGL((conv3x3_img_kernel<CTV, TPWV, false>), grid, dim3(512), pl.lds, ctx->stream, g); }
+            if (pl.ct == 2) {
+                if (pl.tpw == 4) { TH_IMG(2, 4) } else if (pl.tpw == 7) { TH_IMG(2, 7) } else { TH_IMG(2, 13) }
+            } else {
+                if (pl.tpw == 4) { TH_IMG(1, 4) } else if (pl.tpw == 7) { TH_IMG(1, 7) } else { TH_IMG(1, 13) }
+            }
+#undef TH_IMG
+            t_last_conv_cfg[0] = pl.ct; t_last_conv_cfg[1] = 2; t_last_conv_cfg[2] = pl.tpw;      // dma = 2: the image-resident kernel
+            t_last_conv_cfg[3] = (int)grid.x; t_last_conv_cfg[4] = pl.img_t; t_last_conv_cfg[5] = pool ? 1 : 0;
+            TH_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     ConvMfmaArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.n = n; a.c_in = c_in; a.h = h; a.w_in = w_in; a.c_out = c_out; a.pad = pad;
@@ -701,5 +1020,11 @@ extern "C" int th_debug_conv_timeline(th_ctx *ctx, long long *h_out, int n_wg) {
 extern "C" int th_debug_last_conv_config(th_ctx *ctx, int *out6) {
     TH_REQUIRE(ctx && out6, "th_debug_last_conv_config: null argument");
     for (int i = 0; i < 6; ++i) out6[i] = th::t_last_conv_cfg[i];
+    return 0;
+}
+
+extern "C" int th_debug_set_conv_img(th_ctx *ctx, int mode) {
+    TH_REQUIRE(ctx && mode >= -1 && mode <= 1, "th_debug_set_conv_img: mode must be -1 (auto), 0 (off) or 1 (whenever it fits)");
+    th::g_conv_img_mode = mode;
     return 0;
 }

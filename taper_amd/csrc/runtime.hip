@@ -71,6 +71,7 @@ int th_ctx_destroy(th_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->block_size) (void)hipFree(kv.first);
+    for (auto &kv : ctx->conv_plans) (void)hipFree(kv.second);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

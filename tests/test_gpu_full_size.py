@@ -36,17 +36,37 @@ def last_conv_config(ctx):
     return dict(ct=out[0], dma=out[1], waves=4 * out[2], grid=(out[3], out[4]), pool=out[5])
 
 
-# n, c_in, hw, c_out, expected channel tiles per workgroup (the instances rocprofv3 lists for the batch-256 CNN steps)
+# n, c_in, hw, c_out, then what the launch must pick at this size: the image-resident kernel's (images per unit, channel tiles,
+# pixel tiles per wave) -- the instances rocprofv3 lists for the batch-256 CNN steps -- and the 128-pixel kernel's channel tiles
 FULL_LAYERS = [
-    (256, 32, 28, 32, 2),    # reference CNN conv2 (+ pool)
-    (256, 32, 14, 64, 4),    # reference CNN conv3; simple CNN conv2 (+ pool)
-    (256, 64, 14, 64, 4),    # reference CNN conv4 (+ pool)
-    (256, 64, 7, 128, 2),    # reference CNN conv5: < 384 workgroups of 64 channels -> 32-channel blocks
+    (256, 32, 28, 32, (1, 2, 13), 2),    # reference CNN conv2 (+ pool): one 28x28 image x 32 channels per CU
+    (256, 32, 14, 64, (2, 2, 7), 4),     # reference CNN conv3; simple CNN conv2 (+ pool): two 14x14 images x 32 channels
+    (256, 64, 14, 64, (2, 2, 7), 4),     # reference CNN conv4 (+ pool)
+    (256, 64, 7, 128, (4, 2, 4), 2),     # reference CNN conv5: four 7x7 images x 32 channels
 ]
 
 
-@pytest.mark.parametrize("n,c_in,hw,c_out,ct", FULL_LAYERS)
-def test_conv3x3_full_size_layers(ctx, O, n, c_in, hw, c_out, ct):
+@pytest.mark.parametrize("kernel", ["image_resident", "pixel_block"])
+@pytest.mark.parametrize("n,c_in,hw,c_out,img_cfg,ct", FULL_LAYERS)
+def test_conv3x3_full_size_layers(ctx, O, n, c_in, hw, c_out, img_cfg, ct, kernel):
+    ctx.call("th_debug_set_conv_img", -1 if kernel == "image_resident" else 0)
+    try:
+        _full_size_layer(ctx, O, n, c_in, hw, c_out, img_cfg if kernel == "image_resident" else None, ct)
+    finally:
+        ctx.call("th_debug_set_conv_img", -1)
+
+
+def _expect_cfg(cfg, img_cfg, ct, pool):
+    if img_cfg is None:
+        assert cfg["ct"] == ct and cfg["dma"] == 1 and cfg["pool"] == pool, cfg
+        assert cfg["grid"][0] * cfg["grid"][1] >= 256, cfg                 # a chip-filling launch, not the small-batch shape
+    else:
+        img, ict, tpw = img_cfg
+        assert cfg["dma"] == 2 and cfg["ct"] == ict and cfg["waves"] == 4 * tpw and cfg["grid"][1] == img and cfg["pool"] == pool, cfg
+        assert cfg["grid"][0] == 256, cfg                                  # one unit per CU
+
+
+def _full_size_layer(ctx, O, n, c_in, hw, c_out, img_cfg, ct):
     rng = np.random.default_rng(c_in * 1000 + hw * 10 + c_out)
     x = rng.uniform(-1, 1, (n, c_in, hw, hw)).astype(np.float32)
     bound = np.sqrt(6.0 / (c_in * 9))                                   # nn.rs:219-222
@@ -58,9 +78,7 @@ def test_conv3x3_full_size_layers(ctx, O, n, c_in, hw, c_out, ct):
     dx, dw, db = ctx.upload(x), ctx.upload(wt), ctx.upload(b)
     y = ctx.empty(n * c_out * hw * hw)
     ctx.call("th_conv3x3_fwd", dx, dw, db, y, n, c_in, hw, hw, c_out, 1, 0, 1)
-    cfg = last_conv_config(ctx)
-    assert cfg["ct"] == ct and cfg["dma"] == 1 and cfg["pool"] == 0, cfg
-    assert cfg["grid"][0] * cfg["grid"][1] >= 256, cfg                 # a chip-filling launch, not the small-batch shape
+    _expect_cfg(last_conv_config(ctx), img_cfg, ct, 0)
     got = ctx.download(y, ref_d.shape)
     np.testing.assert_allclose(got, ref_d, rtol=RTOL, atol=1e-5)
     # no ReLU, no bias (the pre-activation itself)
@@ -72,8 +90,7 @@ def test_conv3x3_full_size_layers(ctx, O, n, c_in, hw, c_out, ct):
         assert ctx_supported(ctx, c_in, hw, c_out)
         yp = ctx.empty(n * c_out * (hw // 2) ** 2)
         ctx.call("th_conv3x3_pool2_fwd", dx, dw, db, yp, n, c_in, hw, hw, c_out, 1, 1)
-        cfg = last_conv_config(ctx)
-        assert cfg["ct"] == ct and cfg["pool"] == 1 and cfg["dma"] == 1, cfg
+        _expect_cfg(last_conv_config(ctx), img_cfg, ct, 1)
         pooled = ref.max_pool2d((2, 2), (2, 2), (0, 0)).data()
         np.testing.assert_allclose(ctx.download(yp, pooled.shape), pooled, rtol=RTOL, atol=1e-5)
         # and bit-identical to the unfused HIP pair (same fmaf chain, max is exact)
@@ -173,7 +190,7 @@ def test_cnn_training_steps_parity_batch_256(name, mode):
         ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False), T.Trainer.GRAPH)
         losses, ncorrect = ep["losses"], ep["ncorrect"]
         cfg = last_conv_config_host()
-        assert cfg["ct"] in (2, 4) and cfg["dma"] == 1, cfg        # the matrix-core conv ran in this process's step
+        assert cfg["ct"] in (1, 2) and cfg["dma"] == 2, cfg        # the image-resident matrix-core conv ran in this process's step
     else:
         losses, ncorrect = [], []
         for s in range(steps):
@@ -193,3 +210,51 @@ def last_conv_config_host():
     from taper_amd import hip
     c = hip.Ctx(handle=T.Device.ctx_handle())
     return last_conv_config(c)
+
+
+SMALL_IMG_CASES = [  # n, c_in, h, w, c_out, pad: the image-resident kernel FORCED onto small / ragged launches (it normally needs >= 128 units)
+    (3, 32, 28, 28, 32, 1), (5, 32, 14, 14, 64, 1), (9, 64, 7, 7, 128, 1), (2, 8, 10, 12, 16, 1), (3, 16, 9, 11, 33, 0), (7, 24, 5, 5, 150, 1),
+    (1, 64, 1, 1, 10, 1), (17, 8, 3, 3, 4, 0), (2, 40, 20, 20, 48, 1), (6, 8, 6, 8, 20, 1), (1, 8, 28, 28, 7, 1), (33, 16, 7, 7, 16, 1),
+]
+
+
+@pytest.mark.parametrize("n,c_in,h,w,c_out,pad", SMALL_IMG_CASES)
+@pytest.mark.parametrize("relu", [0, 1])
+def test_image_resident_kernel_on_small_and_ragged_shapes(ctx, O, n, c_in, h, w, c_out, pad, relu):
+    """ragged image groups (n not a multiple of the images per unit), channel counts that are not multiples of 16, pad 0, 1x1 planes,
+    partial pixel tiles: against the oracle, and bit-identical to the 128-pixel kernel (same fmaf chains in the same k order)"""
+    rng = np.random.default_rng(n * 131 + c_in * 17 + h * 5 + c_out)
+    x = rng.uniform(-1, 1, (n, c_in, h, w)).astype(np.float32)
+    wt = rng.uniform(-0.5, 0.5, (c_out, c_in, 3, 3)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, c_out).astype(np.float32)
+    xt, wtt, bt = O.Tensor(x), O.Tensor(wt), O.Tensor(b)
+    ref = (xt.conv2d_relu if relu else xt.conv2d)(wtt, bt, (1, 1), (pad, pad), (1, 1))
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    dx, dw, db = ctx.upload(x), ctx.upload(wt), ctx.upload(b)
+    out = {}
+    try:
+        for mode in (1, 0):
+            ctx.call("th_debug_set_conv_img", mode)
+            y = ctx.empty(n * c_out * ho * wo)
+            ctx.call("th_conv3x3_fwd", dx, dw, db, y, n, c_in, h, w, c_out, pad, 0, relu)
+            cfg = last_conv_config(ctx)
+            if mode == 1:
+                assert cfg["dma"] == 2, cfg
+            else:
+                assert cfg["dma"] != 2, cfg
+            out[mode] = ctx.download(y, (n, c_out, ho, wo))
+            pooled = None
+            if ho % 2 == 0 and wo % 2 == 0 and c_out % 4 == 0 and ctx_supported_pad(c_in, h, w, c_out, pad):
+                yp = ctx.empty(n * c_out * (ho // 2) * (wo // 2))
+                ctx.call("th_conv3x3_pool2_fwd", dx, dw, db, yp, n, c_in, h, w, c_out, pad, relu)
+                pooled = ctx.download(yp, (n, c_out, ho // 2, wo // 2))
+                np.testing.assert_array_equal(pooled, out[mode].reshape(n, c_out, ho // 2, 2, wo // 2, 2).max(axis=(3, 5)))
+    finally:
+        ctx.call("th_debug_set_conv_img", -1)
+    np.testing.assert_allclose(out[1], ref.data(), rtol=RTOL, atol=1e-5)
+    np.testing.assert_array_equal(out[1], out[0])
+
+
+def ctx_supported_pad(c_in, h, w, c_out, pad):
+    from taper_amd import hip
+    return hip.hip.th_conv3x3_pool2_supported(c_in, h, w, c_out, pad) == 1

@@ -33,6 +33,8 @@ for it in range(N + 3):
     lib.th_debug_conv_prof(ctx.h, out)
     if it >= 3:
         acc += np.diff([out[i] for i in range(5)]) * 0.01
+        if out[6] > out[5] > 0 and out[3] > out[2]:
+            ghz = (out[6] - out[5]) / ((out[3] - out[2]) * 10.0)
 for nm, v in zip(names, acc / N):
     print(f"{v:8.3f} us  {nm}")
-print(f"{acc.sum() / N:8.3f} us  workgroup 300 total;  kernel {ms * 1e3:.1f} us")
+print(f"{acc.sum() / N:8.3f} us  workgroup total;  kernel {ms * 1e3:.1f} us" + (f";  shader clock through the k loop {ghz:.2f} GHz" if "ghz" in dir() else ""))
