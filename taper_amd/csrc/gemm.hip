@@ -392,15 +392,19 @@ __device__ __forceinline__ void store_tile(float *__restrict__ S, int t, const f
             float *s = S + ((t >> 3) + 32 * j) * TileGeo<TS>::LD_KC + (t & 7) * 4;
             s[0] = reg[j].x; s[1] = reg[j].y; s[2] = reg[j].z; s[3] = reg[j].w;
         } else {
-            float *s = S + (t / QPR + (256 / QPR) * j) * TileGeo<TS>::LD_MC + (t % QPR) * 4;
-            *reinterpret_cast<float4 *>(s) = reg[j];
+            // an m/n-contiguous source is TRANSPOSED on its way into LDS: the quad (k row, 4 consecutive mn) lands in the same
+            // [mn][k] image the k-contiguous case builds, so the MFMA loop below is one code path for all four layouts and the
+            // separate transpose launch in front of deep NN / TN / TT products goes away (4-way bank conflict on these 4 writes
+            // per quad: ~2x on 16 ds_write_b32 per tile, against 4096 cycles of MFMA per tile and wave)
+            float *s = S + ((t % QPR) * 4) * TileGeo<TS>::LD_KC + t / QPR + (256 / QPR) * j;
+            s[0] = reg[j].x; s[TileGeo<TS>::LD_KC] = reg[j].y; s[2 * TileGeo<TS>::LD_KC] = reg[j].z; s[3 * TileGeo<TS>::LD_KC] = reg[j].w;
         }
     }
 }
 
 template <bool KC, int TS>
 __device__ __forceinline__ float frag(const float *__restrict__ S, int mn, int kx) {
-    return KC ? S[mn * TileGeo<TS>::LD_KC + kx] : S[kx * TileGeo<TS>::LD_MC + mn];
+    return S[mn * TileGeo<TS>::LD_KC + kx];   // every layout is staged as the [mn][k] image (store_tile)
 }
 
 template <int TS, bool A_KC, bool B_KC, bool GUARD>
@@ -650,13 +654,13 @@ int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, co
     const long b_rs = trans_b ? 1 : n, b_cs = trans_b ? k : 1;  // gemm.rs:93-97
     const bool a_kc = !trans_a, b_kc = trans_b != 0;
     const bool big = gemm_is_big(m, n, k);
-    // Layout normalisation for the MFMA kernel.  Measured on MI355X at 4096^3 (profiles/):
-    // both operands k-contiguous (NT) 116 TF, one m/n-contiguous operand 91-97 TF, both 84 TF
-    // (twice the L1->L2 read requests).  An O(n^2) LDS-tiled transpose of an m/n-contiguous
-    // operand costs ~35 us per 64 MB -- 3 % of the O(n^3) product -- so deep, large GEMMs are
-    // run as NT on transposed copies taken from the stream-ordered pool.
-    // (only when both m and n are wide: for a narrow output the copies cost as much as the product)
-    if (big && k >= 1024 && m >= 1024 && n >= 1024 && (!a_kc || !b_kc)) {
+    // Layouts.  r01 ran deep NN / TN / TT products as NT on transposed COPIES (a separate LDS-tiled transpose launch per
+    // m/n-contiguous operand, ~32 us per 64 MB: 2.7 % of the Linear-stack step) because the kernel's [k][mn] LDS image of such an
+    // operand ran at 84-97 TF against 116 for NT.  r02: the kernel transposes m/n-contiguous quads on their way into LDS (store_tile),
+    // so one MFMA loop serves all four layouts -- 4096^3 on MI355X: NN 128.0, NT 125.3, TN (beta = 1) 119.3, TT 119.5 TF against
+    // 122.3 / 125.4 / 113.5 / 121.4 with the copies (TAPER_GEMM_PRETRANSPOSE=1 restores them for comparison).
+    static const int pretranspose = getenv("TAPER_GEMM_PRETRANSPOSE") ? atoi(getenv("TAPER_GEMM_PRETRANSPOSE")) : 0;   // measurement probe
+    if (pretranspose && big && k >= 1024 && m >= 1024 && n >= 1024 && (!a_kc || !b_kc)) {
         void *at = nullptr, *bt = nullptr;
         const float *A2 = A, *B2 = B;
         if (!a_kc) {  // A stored [k][m] -> [m][k]
