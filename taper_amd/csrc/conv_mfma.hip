@@ -419,22 +419,36 @@ __global__ void conv_img_tables_kernel(int *goff, int *pix, int n_goff, int n_pi
     }
 }
 
-// 8 waves (two per SIMD: while one wave requests its next operands, computes addresses or stages, the other's MFMAs run -- a lone wave per
-// SIMD issues one instruction per 4 cycles and nothing of that overlapped its own matrix work: measured 34 % matrix-pipe busy).
-// Every wave owns ONE channel tile and TPW pixel tiles: CT = 2 -> waves 0-3 / 4-7 take channel tile 0 / 1 on pixel groups 0-3
-// (tile = group + 4 i); CT = 1 -> eight pixel groups (tile = wave + 8 i).
-template <int CT, int TPW, bool POOL>
-__global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
+// fp32 MFMA on gfx950 runs on the vector ALUs ("= the FP32 vector rate"): experiments/mfma_overlap.hip shows that NOTHING a wave -- or its
+// SIMD partner -- issues to the VALU or the LDS hides under an MFMA: 13 MFMAs + 27 v_add take 1092 cycles for two waves of a SIMD where
+// the MFMAs alone take 832, in phase or in anti-phase; a v_add costs ~4.8 cycles of the SIMD, a ds_read_b32 ~9.  The k loop is therefore
+// priced per k-step and wave as 32 P Q + 9 (P + Q) + 4.8 P cycles (P pixel tiles x Q channel tiles: P + Q operand reads, P address adds),
+// and what pays is operand REUSE: a wave that owns Q = 2 channel tiles feeds two MFMAs from every pixel operand.
+//   NW = 8: 8 waves, every wave ONE channel tile (CT = 2: waves 0-3 / 4-7 take tile 0 / 1 on pixel groups 0-3; CT = 1: 8 pixel groups)
+//   NW = 4: 4 waves, every wave ALL CT channel tiles on its pixel group (tile = wave + 4 i)
+// The launch planner prices both and picks per layer.
+// WP > 0: the patch geometry (pitch WP = w_out + 2, channel stride CIS = images x (h_out + 2) x WP) is a compile-time constant and
+// the 72 k of a pass are walked as (channel group of 4, tap): k-step s covers tap s % 9 of channels 4 (s / 9) + lane group.  A lane's
+// operand address is then (its window corner + its channel offset) + a per-step constant that fits the ds_read offset field -- the P
+// address adds per k-step go away (4.8 cycles each of the same ALUs that execute the MFMAs).  The weight slab is read through the same
+// permutation.  Sums
+// are formed in another order than in the generic instances (WP = 0, k = channel-major like the reference's im2col column): equal within
+// fp32 rounding, not bit for bit.
+template <int CT, int TPW, bool POOL, int NW, int WP = 0, int CIS = 0>
+__global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CO_B = 16 * CT, KS = 18, NT = 512, WQ = KS * 4 * CO_B / 4, WPT = (WQ + NT - 1) / NT, PG = CT == 2 ? 4 : 8;
+    constexpr int CO_B = 16 * CT, KS = 18, NT = 64 * NW, WQ = KS * 4 * CO_B / 4, WPT = (WQ + NT - 1) / NT;
+    constexpr int CTW = NW == 4 ? CT : 1;                    // channel tiles per wave
+    constexpr int PG = NW == 4 ? 4 : (CT == 2 ? 4 : 8);      // pixel groups of waves
+    constexpr int PPT = IM_PPT * 512 / NT;                   // patch elements per thread per pass
     // units of one image group sit on one XCD (blocks go round-robin over the 8 XCDs): its channel blocks share the input in that L2
     const int xcd = blockIdx.x & 7, q8 = blockIdx.x >> 3;
     const int grp = xcd + 8 * (q8 / a.n_co), cob = q8 % a.n_co;
     if (grp >= a.n_groups) return;
     IMG_STAMP(0);
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
-    const int pg = wave % PG, cj = wave / PG;                // pixel group, channel tile of this wave
+    const int pg = wave % PG, cj = NW == 4 ? 0 : wave / PG;  // pixel group, first channel tile of this wave
     const int wp = a.w_out + 2, rp = a.h_out + 2;
     const int img_stride = rp * wp, ci_stride = a.img_t * img_stride, patch_n = MF_CI * ci_stride;
     const int img0 = grp * a.img_t, co0 = cob * CO_B;
@@ -445,14 +459,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
     int pix_off[TPW];                 // LDS offset of the window corner of this lane's pixel in each of its tiles
 #pragma unroll
     for (int i = 0; i < TPW; ++i) pix_off[i] = a.pix_tab[(pg + PG * i) * 16 + l16];
-    int p_goff[IM_PPT];               // byte offset within channel block 0 of image img0, or past-the-end (reads as zero)
+    int p_goff[PPT];                  // byte offset within channel block 0 of image img0, or past-the-end (reads as zero)
 #pragma unroll
-    for (int j = 0; j < IM_PPT; ++j) p_goff[j] = a.goff_tab[t + NT * j];
+    for (int j = 0; j < PPT; ++j) p_goff[j] = a.goff_tab[t + NT * j];
     int koff[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const int kk = 4 * s + g4, cl = kk / 9, tap = kk % 9;
-        koff[s] = cl * ci_stride + (tap / 3) * wp + (tap % 3);
+        if (WP > 0) {   // compile-time part of the offset (channel group s / 9, tap s % 9); the lane part (g4 * CIS) is folded into pix_off below
+            koff[s] = (4 * (s / 9)) * CIS + ((s % 9) / 3) * WP + ((s % 9) % 3);
+        } else {
+            const int kk = 4 * s + g4, cl = kk / 9, tap = kk % 9;
+            koff[s] = cl * ci_stride + (tap / 3) * wp + (tap % 3);
+        }
+    }
+    if (WP > 0) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) pix_off[i] += g4 * CIS;
     }
     const long chan = (long)a.h * a.w_in;
     const float *xbase = a.x + (long)img0 * a.c_in * chan;
@@ -479,16 +501,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(ws + 4 * (w0 + NT * j)), 16, w_boff[j], 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < IM_PPT; ++j) {
+        for (int j = 0; j < PPT; ++j) {
             if (NT * (j + 1) <= patch_n)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + w0 + NT * j), 4, p_goff[j], 0, 0, 0);
             else if (NT * j < patch_n && t + NT * j < patch_n)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + w0 + NT * j), 4, p_goff[j], 0, 0, 0);
         }
     };
-    floatx4 acc[TPW];
+    floatx4 acc[TPW][CTW];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int j = 0; j < CTW; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     IMG_STAMP(1);
     issue(0, 0);
@@ -501,22 +525,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
         if (more) issue(cb + MF_CI, stage ^ 1);
         const float *pp = lds + stage * stage_n, *ww = pp + ((patch_n + 4) & ~3) + l16 + 16 * cj;
         // The operands of k-step s + 1 are requested before the MFMAs of step s are issued, and pinned there: left alone, the scheduler
-        // sinks every read to its use -- one exposed LDS round trip per tile (68 us on the 28x28 layer with one wave per SIMD).
-        // Measured alternatives (28x28 layer, 32 -> 32, batch 256, this form 50.9 us): one request per MFMA, interleaved through
-        // sched_group_barrier: 62 us; the two waves of a SIMD in anti-phase (one requests while the other computes): 51.7 us; the
-        // LDS-DMA instructions of the next stage spread one per k-step instead of a burst at the top of the pass: 52.2 us.  With the LDS
-        // requests compiled out the k loop takes 35.4 us against 38.3 us with them (shader clock 2.13 GHz): the 13 back-to-back MFMAs
-        // per k-step and wave run at ~44 cycles each where 32 is the pipe's rate -- the matrix pipe itself, not its feeding, bounds this loop.
-        float b0[TPW], b1[TPW], a0, a1 = 0.f;
+        // sinks every read to its use -- one exposed LDS round trip per tile.  (Tried on the 28x28 layer, 8 waves, 50.9 us in this form:
+        // one request per MFMA interleaved through sched_group_barrier 62 us; SIMD partners in anti-phase 51.7 us; the next stage's
+        // LDS-DMA instructions spread one per k-step 52.2 us -- none of it can win, see the note on fp32 MFMA above.)
+        float b0[TPW], b1[TPW], a0[CTW], a1[CTW];
+        // slab row of (k-step, lane group): channel-major k = 4 s + g4, or the tap-major permutation (channel 4 (s % 2) + g4, tap s / 2)
+        auto wrow = [&](int ks) { return WP > 0 ? (4 * (ks / 9) + g4) * 9 + ks % 9 : 4 * ks + g4; };
 #ifdef TH_IMG_NO_READS   /* timing probe: the k loop without its LDS requests (wrong results) */
-#define TH_IMG_REQ(B, A, S) { _Pragma("unroll") for (int i = 0; i < TPW; ++i) B[i] = __builtin_bit_cast(float, pix_off[i] + (S)); A = __builtin_bit_cast(float, koff[S]); }
+#define TH_IMG_REQ(B, A, S) { _Pragma("unroll") for (int i = 0; i < TPW; ++i) B[i] = __builtin_bit_cast(float, pix_off[i] + (S)); \
+                              _Pragma("unroll") for (int j = 0; j < CTW; ++j) A[j] = __builtin_bit_cast(float, koff[S] + j); }
 #else
 #define TH_IMG_REQ(B, A, S)                                                                  \
         {                                                                                    \
             _Pragma("unroll") for (int i = 0; i < TPW; ++i) B[i] = pp[pix_off[i] + koff[S]]; \
-            A = ww[(4 * (S) + g4) * CO_B];                                                   \
+            _Pragma("unroll") for (int j = 0; j < CTW; ++j) A[j] = ww[wrow(S) * CO_B + 16 * j];        \
         }
 #endif
+        // (two k-steps per round, so that the requests of consecutive taps pair up into ds_read2_b32 -- 167 instead of 371 non-MFMA
+        // instructions per pass in the 13-tile instance -- measured SLOWER: 46.9 vs 43.6 us on the pooled 28x28 layer)
         TH_IMG_REQ(b0, a0, 0)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -524,12 +550,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             // (tile slots past the unit's last pixel tile compute on pixel 0 and are never stored: no per-tile branch in the stream)
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[i], acc[i], 0, 0, 0);
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int j = 0; j < CTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < KS) {
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) b0[i] = b1[i];
-                a0 = a1;
+#pragma unroll
+                for (int j = 0; j < CTW; ++j) a0[j] = a1[j];
             }
         }
 #undef TH_IMG_REQ
@@ -540,13 +569,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
     }
 
     IMG_STAMP(3);
-    // bias of this lane's four channels (co0 + 16 cj + 4 g4 + e)
-    float bv[4];
+    // bias of this lane's channels (co0 + 16 (cj + j) + 4 g4 + e)
+    float bv[CTW][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int co = co0 + 16 * cj + 4 * g4 + e;
-        bv[e] = (a.bias && co < a.c_out) ? a.bias[co] : 0.f;
-    }
+    for (int j = 0; j < CTW; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = co0 + 16 * (cj + j) + 4 * g4 + e;
+            bv[j][e] = (a.bias && co < a.c_out) ? a.bias[co] : 0.f;
+        }
     if (POOL) {
         // bias + ReLU into an LDS tile [CO_B][pixels of the unit], then the 2x2 / stride-2 maxima go to the pooled tensor
         __syncthreads();
@@ -557,11 +588,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
             const int p = (pg + PG * i) * 16 + l16;
             if (p >= m_unit) continue;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = acc[i][e] + bv[e];
-                if (a.relu) v = v > 0.f ? v : 0.f;
-                ep[(16 * cj + 4 * g4 + e) * ep_ld + p] = v;
-            }
+            for (int j = 0; j < CTW; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][e] + bv[j][e];
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    ep[(16 * (cj + j) + 4 * g4 + e) * ep_ld + p] = v;
+                }
         }
         __syncthreads();
         const int pw = a.w_out >> 1, np_img = (a.h_out >> 1) * pw, np = imgs_here * np_img;
@@ -592,45 +625,56 @@ __global__ __launch_bounds__(512, 1) void conv3x3_img_kernel(ConvImgArgs a) {
         d_pxi.divmod(p, il, rem);
         float *ypx = a.y + ((long)(img0 + il) * a.c_out) * ochan + rem;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = co0 + 16 * cj + 4 * g4 + e;
-            if (co >= a.c_out) continue;
-            float v = acc[i][e] + bv[e];
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            ypx[(long)co * ochan] = v;
-        }
+        for (int j = 0; j < CTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + 16 * (cj + j) + 4 * g4 + e;
+                if (co >= a.c_out) continue;
+                float v = acc[i][j][e] + bv[j][e];
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                ypx[(long)co * ochan] = v;
+            }
     }
     IMG_STAMP(4);
 #endif
 }
 
-// (IMG, CT, TPW) of the image-resident kernel for a launch, or false: the 128-pixel kernel keeps it.  Cost of a candidate =
-// rounds of units over the 256 CUs x MFMAs per wave and pass (TPW slots x CT); the instance table below fixes TPW to 4 / 7 / 13.
-struct ConvImgPlan { int img_t, ct, tpw, n_groups, n_co; size_t lds; };
+// (IMG, CT, TPW, NW) of the image-resident kernel for a launch, or false: the 128-pixel kernel keeps it.  A candidate costs
+// rounds of units over the 256 CUs x waves per SIMD x (32 P Q + 9 (P + Q) + 4.8 P) cycles per k-step (see the kernel's header);
+// the instance table fixes P to 4 / 7 / 13.
+struct ConvImgPlan { int img_t, ct, tpw, nw, n_groups, n_co; size_t lds; };
 static bool conv_img_plan(int n, int c_in, int h, int w_in, int c_out, int pad, bool pool, ConvImgPlan *out) {
     const int h_out = h + 2 * pad - 2, w_out = w_in + 2 * pad - 2;
     if (c_in % MF_CI != 0 || h_out < 1 || w_out < 1) return false;
     if (pool && ((h_out | w_out) & 1)) return false;
-    long best = -1;
-    for (int ct = 1; ct <= 2; ++ct) {
-        if (ct == 2 && c_out <= 16) continue;
-        for (int img = 1; img <= 16; ++img) {
-            const long px = (long)img * h_out * w_out;
-            const int npt = (int)((px + 15) / 16), tpw_need = ct == 2 ? (npt + 3) / 4 : (npt + 7) / 8;   // 4 / 8 pixel groups of waves
-            const int tpw = tpw_need <= 4 ? 4 : (tpw_need <= 7 ? 7 : (tpw_need <= 13 ? 13 : 0));
-            if (!tpw) break;
-            const long patch_n = (long)MF_CI * img * (h_out + 2) * (w_out + 2);
-            if (patch_n > (long)IM_PPT * 512) break;
-            size_t lds = (size_t)2 * ((((size_t)patch_n + 4) & ~(size_t)3) + (size_t)72 * 16 * ct) * sizeof(float);
-            if (pool) lds = std::max(lds, (size_t)16 * ct * ((size_t)px | 1) * sizeof(float));
-            if (lds > (150u << 10)) continue;
-            if ((long)img * c_in * h * w_in >= (1L << 28) || (long)9 * c_in * c_out >= (1L << 28)) continue;
-            const int n_groups = ceil_div(n, img), n_co = ceil_div(c_out, 16 * ct);
-            const long units = (long)n_groups * n_co, rounds = (units + kNumCU - 1) / kNumCU;
-            const long cost = rounds * tpw * 1000 + (ct == 1 ? 1 : 0) + (units < kNumCU ? (kNumCU - units) * 4 : 0);   // MFMAs per wave and pass x rounds
-            if (best < 0 || cost < best) {
-                best = cost;
-                *out = ConvImgPlan{img, ct, tpw, n_groups, n_co, lds};
+    static const int nw_env = getenv("TAPER_CONV_IMG_NW") ? atoi(getenv("TAPER_CONV_IMG_NW")) : 0;   // tuning probe: force 4 / 8 waves
+    double best = -1;
+    for (int nw = 4; nw <= 8; nw += 4) {
+        // measured: the 4-wave form (every pixel operand feeds two MFMAs, but one wave per SIMD) is 10-17 % SLOWER on all four batch-256
+        // layers (28x28: 59.2 vs 50.4 us): it only runs when asked for
+        if (nw != (nw_env ? nw_env : 8)) continue;
+        for (int ct = 1; ct <= 2; ++ct) {
+            if (ct == 2 && c_out <= 16) continue;
+            const int pg = nw == 4 ? 4 : (ct == 2 ? 4 : 8), q = nw == 4 ? ct : 1;
+            for (int img = 1; img <= 16; ++img) {
+                const long px = (long)img * h_out * w_out;
+                const int npt = (int)((px + 15) / 16), tpw_need = (npt + pg - 1) / pg;
+                const int tpw = tpw_need <= 4 ? 4 : (tpw_need <= 7 ? 7 : (tpw_need <= 13 ? 13 : 0));
+                if (!tpw) break;
+                const long patch_n = (long)MF_CI * img * (h_out + 2) * (w_out + 2);
+                if (patch_n > (long)IM_PPT * 512) break;
+                size_t lds = (size_t)2 * ((((size_t)patch_n + 4) & ~(size_t)3) + (size_t)72 * 16 * ct) * sizeof(float);
+                if (pool) lds = std::max(lds, (size_t)16 * ct * ((size_t)px | 1) * sizeof(float));
+                if (lds > (150u << 10)) continue;
+                if ((long)img * c_in * h * w_in >= (1L << 28) || (long)9 * c_in * c_out >= (1L << 28)) continue;
+                const int n_groups = ceil_div(n, img), n_co = ceil_div(c_out, 16 * ct);
+                const long units = (long)n_groups * n_co, rounds = (units + kNumCU - 1) / kNumCU;
+                double cost = (double)rounds * (nw / 4) * (32.0 * tpw * q + 9.0 * (tpw + q) + 4.8 * tpw);
+                if (units < kNumCU) cost *= 1.0 + 0.5 * (double)(kNumCU - units) / kNumCU;   // idle CUs: prefer the split that fills the chip
+                if (best < 0 || cost < best) {
+                    best = cost;
+                    *out = ConvImgPlan{img, ct, tpw, nw, n_groups, n_co, lds};
+                }
             }
         }
     }
@@ -696,7 +740,7 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
             g.h_out = h + 2 * pad - 2; g.w_out = w_in + 2 * pad - 2; g.w_ld = w_ld; g.w_cols = w_cols;
             g.img_t = pl.img_t; g.n_groups = pl.n_groups; g.n_co = pl.n_co; g.relu = relu;
             {   // staging plans of this geometry: built on device the first time, kept with the ctx
-                const int pgs = pl.ct == 2 ? 4 : 8, n_goff = 512 * IM_PPT, n_pix = pgs * pl.tpw * 16;
+                const int pgs = pl.nw == 4 ? 4 : (pl.ct == 2 ? 4 : 8), n_goff = 512 * IM_PPT, n_pix = pgs * pl.tpw * 16;
                 const std::array<int, 8> key{h, w_in, pad, c_in, pl.img_t, pgs, pl.tpw, 0};
                 auto it = ctx->conv_plans.find(key);
                 if (it == ctx->conv_plans.end()) {
@@ -711,18 +755,38 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
                 g.pix_tab = g.goff_tab + n_goff;
             }
             const dim3 grid(8 * ceil_div(pl.n_groups, 8) * pl.n_co);
+#define TH_IMG2(CTV, TPWV, PL, NWV)                                                                                         \
+            { (void)hipFuncSetAttribute((const void *)conv3x3_img_kernel<CTV, TPWV, PL, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+              hipLaunchKernelGGL((conv3x3_img_kernel<CTV, TPWV, PL, NWV>), grid, dim3(64 * NWV), pl.lds, ctx->stream, g); }
 #define TH_IMG(CTV, TPWV)                                                                                                   \
-            if (pool) { (void)hipFuncSetAttribute((const void *)conv3x3_img_kernel<CTV, TPWV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);   \
-                        hipLaunchKernelGGL((conv3x3_img_kernel<CTV, TPWV, true>), grid, dim3(512), pl.lds, ctx->stream, g); }  \
-            else { (void)hipFuncSetAttribute((const void *)conv3x3_img_kernel<CTV, TPWV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);       \
-                   hipLaunchKernelGGL((conv3x3_img_kernel<CTV, TPWV, false>), grid, dim3(512), pl.lds, ctx->stream, g); }
-            if (pl.ct == 2) {
+            if (pool) { if (pl.nw == 4) TH_IMG2(CTV, TPWV, true, 4) else TH_IMG2(CTV, TPWV, true, 8) }                     \
+            else { if (pl.nw == 4) TH_IMG2(CTV, TPWV, false, 4) else TH_IMG2(CTV, TPWV, false, 8) }
+            // instances with the patch geometry compiled in (the batch-256 layers of the two CNNs); everything else takes the generic ones
+#define TH_IMG_GEO(CTV, TPWV, WPV, CISV)                                                                                    \
+            { if (pool) { (void)hipFuncSetAttribute((const void *)conv3x3_img_kernel<CTV, TPWV, true, 8, WPV, CISV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds); \
+                          hipLaunchKernelGGL((conv3x3_img_kernel<CTV, TPWV, true, 8, WPV, CISV>), grid, dim3(512), pl.lds, ctx->stream, g); }                                 \
+              else { (void)hipFuncSetAttribute((const void *)conv3x3_img_kernel<CTV, TPWV, false, 8, WPV, CISV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);    \
+                     hipLaunchKernelGGL((conv3x3_img_kernel<CTV, TPWV, false, 8, WPV, CISV>), grid, dim3(512), pl.lds, ctx->stream, g); } }
+            const int wp_ = g.w_out + 2, cis_ = pl.img_t * (g.h_out + 2) * wp_;
+            static const int geo_env = getenv("TAPER_CONV_IMG_GEO") ? atoi(getenv("TAPER_CONV_IMG_GEO")) : 1;   // tuning probe: 0 = generic instances only
+            bool special = false;
+            if (geo_env && pl.nw == 8) {
+                special = true;
+                if (pl.ct == 2 && pl.tpw == 13 && wp_ == 30 && cis_ == 900) TH_IMG_GEO(2, 13, 30, 900)          // 28x28, one image
+                else if (pl.ct == 1 && pl.tpw == 7 && wp_ == 16 && cis_ == 1024) TH_IMG_GEO(1, 7, 16, 1024)      // 14x14, four images
+                else if (pl.ct == 1 && pl.tpw == 4 && wp_ == 9 && cis_ == 648) TH_IMG_GEO(1, 4, 9, 648)          // 7x7, eight images
+                else special = false;
+            }
+            if (special) {
+            } else if (pl.ct == 2) {
                 if (pl.tpw == 4) { TH_IMG(2, 4) } else if (pl.tpw == 7) { TH_IMG(2, 7) } else { TH_IMG(2, 13) }
             } else {
                 if (pl.tpw == 4) { TH_IMG(1, 4) } else if (pl.tpw == 7) { TH_IMG(1, 7) } else { TH_IMG(1, 13) }
             }
+#undef TH_IMG_GEO
+#undef TH_IMG2
 #undef TH_IMG
-            t_last_conv_cfg[0] = pl.ct; t_last_conv_cfg[1] = 2; t_last_conv_cfg[2] = pl.tpw;      // dma = 2: the image-resident kernel
+            t_last_conv_cfg[0] = pl.ct; t_last_conv_cfg[1] = 2 + (pl.nw == 4 ? 1 : 0) + (special ? 2 : 0); t_last_conv_cfg[2] = pl.tpw;   // 2 / 3: the image-resident kernel with 8 / 4 waves
             t_last_conv_cfg[3] = (int)grid.x; t_last_conv_cfg[4] = pl.img_t; t_last_conv_cfg[5] = pool ? 1 : 0;
             TH_LAUNCH_CHECK();
             return 0;

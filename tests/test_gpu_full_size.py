@@ -40,9 +40,9 @@ def last_conv_config(ctx):
 # pixel tiles per wave) -- the instances rocprofv3 lists for the batch-256 CNN steps -- and the 128-pixel kernel's channel tiles
 FULL_LAYERS = [
     (256, 32, 28, 32, (1, 2, 13), 2),    # reference CNN conv2 (+ pool): one 28x28 image x 32 channels per CU
-    (256, 32, 14, 64, (2, 2, 7), 4),     # reference CNN conv3; simple CNN conv2 (+ pool): two 14x14 images x 32 channels
-    (256, 64, 14, 64, (2, 2, 7), 4),     # reference CNN conv4 (+ pool)
-    (256, 64, 7, 128, (4, 2, 4), 2),     # reference CNN conv5: four 7x7 images x 32 channels
+    (256, 32, 14, 64, (4, 1, 7), 4),     # reference CNN conv3; simple CNN conv2 (+ pool): four 14x14 images x 16 channels
+    (256, 64, 14, 64, (4, 1, 7), 4),     # reference CNN conv4 (+ pool)
+    (256, 64, 7, 128, (8, 1, 4), 2),     # reference CNN conv5: eight 7x7 images x 16 channels
 ]
 
 
@@ -62,7 +62,7 @@ def _expect_cfg(cfg, img_cfg, ct, pool):
         assert cfg["grid"][0] * cfg["grid"][1] >= 256, cfg                 # a chip-filling launch, not the small-batch shape
     else:
         img, ict, tpw = img_cfg
-        assert cfg["dma"] == 2 and cfg["ct"] == ict and cfg["waves"] == 4 * tpw and cfg["grid"][1] == img and cfg["pool"] == pool, cfg
+        assert cfg["dma"] in (2, 3, 4, 5) and cfg["ct"] == ict and cfg["waves"] == 4 * tpw and cfg["grid"][1] == img and cfg["pool"] == pool, cfg   # 2 / 3: 8 / 4 waves
         assert cfg["grid"][0] == 256, cfg                                  # one unit per CU
 
 
@@ -190,7 +190,7 @@ def test_cnn_training_steps_parity_batch_256(name, mode):
         ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False), T.Trainer.GRAPH)
         losses, ncorrect = ep["losses"], ep["ncorrect"]
         cfg = last_conv_config_host()
-        assert cfg["ct"] in (1, 2) and cfg["dma"] == 2, cfg        # the image-resident matrix-core conv ran in this process's step
+        assert cfg["ct"] in (1, 2) and cfg["dma"] in (2, 3, 4, 5), cfg   # the image-resident matrix-core conv ran in this process's step
     else:
         losses, ncorrect = [], []
         for s in range(steps):
@@ -239,9 +239,9 @@ def test_image_resident_kernel_on_small_and_ragged_shapes(ctx, O, n, c_in, h, w,
             ctx.call("th_conv3x3_fwd", dx, dw, db, y, n, c_in, h, w, c_out, pad, 0, relu)
             cfg = last_conv_config(ctx)
             if mode == 1:
-                assert cfg["dma"] == 2, cfg
+                assert cfg["dma"] in (2, 3, 4, 5), cfg
             else:
-                assert cfg["dma"] != 2, cfg
+                assert cfg["dma"] not in (2, 3, 4, 5), cfg
             out[mode] = ctx.download(y, (n, c_out, ho, wo))
             pooled = None
             if ho % 2 == 0 and wo % 2 == 0 and c_out % 4 == 0 and ctx_supported_pad(c_in, h, w, c_out, pad):
