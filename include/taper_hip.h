@@ -76,6 +76,11 @@ int th_ctx_device(th_ctx *ctx);
  * block to the pool; it is safe to reuse because all work is on one stream. */
 int th_malloc(th_ctx *ctx, size_t bytes, void **d_out);
 int th_free(th_ctx *ctx, void *d_ptr);
+/* Pinned host memory that kernels can write through the same pointer (hipHostMalloc, mapped + coherent): the per-step
+ * {loss, n_correct} log of a replayed epoch lives here, so the host reads it after one stream synchronisation instead of
+ * a staged device-to-host copy (examples/train_mnist.rs:110-121 reads both values every step).  Not pooled. */
+int th_host_malloc(th_ctx *ctx, size_t bytes, void **h_out);
+int th_host_free(th_ctx *ctx, void *h_ptr);
 int th_pool_stats(th_ctx *ctx, size_t *bytes_reserved, size_t *bytes_in_use);
 int th_memcpy_h2d(th_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int th_memcpy_d2h(th_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* waits */

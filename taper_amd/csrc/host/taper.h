@@ -53,11 +53,13 @@ struct Buffer {
     float *d = nullptr;
     size_t n = 0;
     bool owned = true;
+    bool host_pinned = false;        // th_host_malloc: pinned host memory the device writes through the same pointer
     std::shared_ptr<Buffer> parent;  // keeps an arena alive for views
     Buffer() = default;
     Buffer(const Buffer &) = delete;
     ~Buffer();
     static std::shared_ptr<Buffer> alloc(size_t n);
+    static std::shared_ptr<Buffer> alloc_host(size_t n);   // device-visible pinned host memory (read on the host after a stream sync)
     static std::shared_ptr<Buffer> view(const std::shared_ptr<Buffer> &parent, size_t offset, size_t n);
     static std::shared_ptr<Buffer> borrow(float *d, size_t n);
 };

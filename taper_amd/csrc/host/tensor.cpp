@@ -76,7 +76,20 @@ void Device::shutdown() {
 
 // ---------------------------------------------------------------- Buffer
 Buffer::~Buffer() {
-    if (owned && d && t_ctx) th_free(t_ctx, d);
+    if (owned && d && t_ctx) {
+        if (host_pinned) th_host_free(t_ctx, d);
+        else th_free(t_ctx, d);
+    }
+}
+
+std::shared_ptr<Buffer> Buffer::alloc_host(size_t n) {
+    auto b = std::make_shared<Buffer>();
+    void *p = nullptr;
+    TH(th_host_malloc(Device::ctx(), std::max<size_t>(n, 1) * sizeof(float), &p));
+    b->d = (float *)p;
+    b->n = n;
+    b->host_pinned = true;
+    return b;
 }
 
 std::shared_ptr<Buffer> Buffer::alloc(size_t n) {

@@ -155,6 +155,19 @@ int th_memcpy_h2d(th_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     return 0;
 }
 
+int th_host_malloc(th_ctx *ctx, size_t bytes, void **h_out) {
+    TH_REQUIRE(ctx && h_out, "th_host_malloc: null argument");
+    TH_HIP(hipSetDevice(ctx->device));
+    TH_HIP(hipHostMalloc(h_out, bytes ? bytes : 4, hipHostMallocMapped | hipHostMallocCoherent));
+    return 0;
+}
+
+int th_host_free(th_ctx *ctx, void *h_ptr) {
+    TH_REQUIRE(ctx, "th_host_free: null ctx");
+    if (h_ptr) TH_HIP(hipHostFree(h_ptr));
+    return 0;
+}
+
 int th_memcpy_d2h(th_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     TH_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "th_memcpy_d2h: null argument");
     if (bytes == 0) return 0;
