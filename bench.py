@@ -454,8 +454,10 @@ def trainer_workload(T, name, dataset, steps=None):
     T.Device.sync()
     dt = time.perf_counter() - t0
     flops, nbytes = algorithmic_step(key, batch)
+    eager = os.environ.get("TAPER_NO_GRAPH") == "1"
     rec = dict(workload=name, per_gpu_batch=batch, optimizer=f"Adam(lr={lr}, wd=1e-4)", steps=steps, ms_per_step=round(dt / steps * 1e3, 5),
-               samples_per_s=round(samples / dt, 1), step="hipGraph replay of gather+fwd+xent+bwd+adam+log")
+               samples_per_s=round(samples / dt, 1),
+               step="eager enqueue, one host launch per kernel (under rocprofv3: NOT the measurement)" if eager else "hipGraph replay of gather+fwd+xent+bwd+adam+log")
     if flops:
         rec["step_roofline"] = {"alg_flops_per_step": flops, "alg_bytes_per_step": nbytes,
                                 "hbm_frac": round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 6),
@@ -619,6 +621,7 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    under_profiler = "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args.gpus)          # never returns
     import taper_amd as T
@@ -693,7 +696,6 @@ def main():
         barrier_sync(dist, T)
 
     sustained = None
-    under_profiler = "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
     if world == 1 and args.settle_seconds == 0 and not args.no_roofline and not under_profiler:   # (the trace is of the W + K run only)
         # the same K steps again after 0.25 s of continuous stepping: under sustained load the part settles at lower clocks
         # than it holds through the first ~50 ms of a run; both states are reported, `value` is the contract's W + K run
@@ -742,6 +744,12 @@ def main():
             except Exception as e:  # the baseline is reported, never required
                 cpu = dict(value=None, unit="samples/s", cores=1, kind="port", sample=f"failed: {e}")
         workloads = None
+        if under_profiler:
+            # rocprofv3 (ROCm 7.2) crashes inside hipGraphLaunch once a process replays the graphs of a SECOND Trainer: the headline above ran as
+            # graph replays (its trace is the one compared with `roofline`); the other workloads enqueue every step's op list eagerly -- the
+            # same kernels with the same arguments, one host launch each -- so the trace holds their per-kernel durations, while their step
+            # times in THIS run are host-launch-bound and are not the measurement
+            os.environ["TAPER_NO_GRAPH"] = "1"
         if world == 1 and not args.batch and args.workloads != "none" and args.workload == "mlp_784-128-10_b64":
             only = None if args.workloads == "all" else set(args.workloads.split(","))
             workloads = extra_workloads(T, ds, with_cpu, only)
@@ -751,7 +759,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "per_gpu_batch": batch, "global_batch": batch * world,
                        "optimizer": f"Adam(lr={lr}, wd=1e-4)", "parallelism": f"dp{world}" if world > 1 else "single",
-                       "comm": comm_kind, **({"ranks_share_one_gpu": True} if share and world > 1 else {}), "step": "hipGraph replay of gather+fwd+xent+bwd+adam+log", "graph_record_steps": record_steps, "clock_settle_steps": settle_steps,
+                       "comm": comm_kind, **({"ranks_share_one_gpu": True} if share and world > 1 else {}),
+                       "step": "hipGraph replay of gather+fwd+xent+bwd+adam+log", "graph_record_steps": record_steps, "clock_settle_steps": settle_steps,
                        **({"conv_gradients": "full_backward (extension)"} if args.full_backward else {})},
             "epochs_per_s": round(samples / dt / 60000.0, 3),
             "step_roofline": None if flops is None else {

@@ -2,6 +2,7 @@
 // the host mirror (src/loss.rs, src/nn.rs, src/optim.rs, src/data/mnist.rs,
 // src/train.rs, examples/train_mnist*.rs).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1018,6 +1019,9 @@ void Trainer::drop_graphs() {
 
 EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     th_ctx *ctx = Device::ctx();
+    static const bool trace = std::getenv("TAPER_TRACE_EPOCH") != nullptr;   // host-side timeline of one call (stderr), a measurement probe
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto us_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
     loader.reset();
     const MNISTDataset &ds = loader.dataset();
     const size_t n = ds.len(), bs = loader.batch_size();
@@ -1071,14 +1075,19 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             if (g.first == steps) return true;
         return false;
     };
+    // operator override: TAPER_NO_GRAPH=1 enqueues every step's op list eagerly instead of replaying captured graphs -- same kernels, same
+    // results, one host launch per kernel (rocprofv3 on ROCm 7.2 crashes inside hipGraphLaunch once several instantiated graphs are replayed
+    // back to back: profiling runs use this)
+    if (!graph_capture_failed_ && std::getenv("TAPER_NO_GRAPH") && std::getenv("TAPER_NO_GRAPH")[0] == '1') graph_capture_failed_ = true;
     // operator override: TAPER_DP_EAGER=1 keeps data-parallel steps out of hipGraphs (collectives launched eagerly)
     if (comm && !graph_capture_failed_ && std::getenv("TAPER_DP_EAGER") && std::getenv("TAPER_DP_EAGER")[0] == '1')
         graph_capture_failed_ = true;
     // a binary ladder of sizes (chunk, chunk/2, chunk/4, ..., 1): whatever an epoch (or a short run: 20 steps = 16 + 4)
     // leaves over after its whole chunks replays as at most log2(chunk) graphs instead of dozens of single-step
     // launches (~10 us of host time each).  A size is recorded by the first call long enough to use it.
+    static const size_t ladder_div = std::getenv("TAPER_GRAPH_LADDER") ? (size_t)std::max(2, atoi(std::getenv("TAPER_GRAPH_LADDER"))) : 2;   // probe: 4 = r01's ladder
     std::vector<size_t> want;
-    for (size_t steps = chunk;; steps /= 2) {
+    for (size_t steps = chunk;; steps /= ladder_div) {
         if (steps < 1) steps = 1;
         if (!((steps > 1 && n_full < steps + 1) || have(steps)) && std::find(want.begin(), want.end(), steps) == want.end())
             want.push_back(steps);
@@ -1132,7 +1141,9 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     }
     loader.advance(std::min(n, nb * bs));
 
+    const double us_enqueued = us_since(t_enter);
     Device::sync();
+    if (trace) fprintf(stderr, "taper trace: train_epoch_graph %zu steps: enqueued after %.1f us, stream idle after %.1f us\n", nb, us_enqueued, us_since(t_enter));
     const float *mt = metrics_->d;   // host-visible (th_host_malloc); every step's entry has landed once the stream is idle
     EpochResult r;
     r.num_batches = nb;
