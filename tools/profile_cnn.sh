@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs on the GPU box: rocprofv3 kernel-trace stats of each CNN workload on its own (graph replay), outputs in gpurun_out/profile_cnn/.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/profile_cnn
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for w in cnn_simple_b256 cnn_reference_b256 mlp_784-128-64-10_b256; do
+    rm -rf /tmp/pc_$w
+    timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc_$w -- \
+        python $ROOT/bench.py --no-cpu-baseline --no-roofline --no-sweep --workloads none --steps 470 --warmup 260 --workload $w 2> /dev/null | tail -1 | cut -c1-260 > "$OUT/$w.json"
+    { echo "### $w (470 timed + 260 warm-up steps, graph replay; per-step time = sum over kernels of calls x avg / steps)"; cat "$OUT/$w.json"; echo; python $ROOT/tools/kstats.py /tmp/pc_$w/*/*kernel_stats.csv | head -24; } > "$OUT/$w.txt"
+    rm -rf /tmp/pc_$w
+done
+cat "$OUT"/*.txt
