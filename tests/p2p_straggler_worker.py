@@ -1,0 +1,35 @@
+"""Two ranks bootstrap a peer-to-peer communicator on GPU 0; rank 1 then never launches the collective.  Rank 0's launch must give
+up after its bounded spin (~4 s) and raise th_comm_error instead of hanging the GPU (tests/test_gpu_dp.py)."""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+rank, world = int(os.environ["RANK"]), 2
+out = Path(os.environ["TAPER_DP_OUT"])
+import taper_amd as T  # noqa: E402
+from taper_amd import hip  # noqa: E402
+from taper_amd.dist import FileRendezvous, init_data_parallel  # noqa: E402
+
+T.Device.set_device(0)
+rdzv = FileRendezvous(rank, world, key=os.environ["TAPER_DP_KEY"], root=str(out), timeout_s=60)
+model = T.Sequential([T.Linear(784, 128, True, seed=1), T.ReLU(), T.Linear(128, 10, True, seed=2)])
+opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+comm = init_data_parallel(T, rdzv, backend="p2p", optimizer=opt)      # includes the collective self-check: both ranks take part
+assert not comm.timed_out()
+t0 = time.time()
+if rank == 0:
+    tr = T.Trainer(model, opt, comm=comm)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0, 1, (64, 784)).astype(np.float32)
+    y = rng.integers(0, 10, 64).astype(np.float32)
+    tr.train_step(T.Tensor(x), T.Tensor(y))          # rank 1 never arrives at this all-reduce
+    timed_out = comm.timed_out()                      # synchronises: returns once the launch has given up
+    (out / "straggler_result.txt").write_text(f"{int(timed_out)} {time.time() - t0:.2f}")
+rdzv.barrier()
+rdzv.close()

@@ -125,3 +125,27 @@ def test_bench_self_spawn_two_ranks_on_one_gpu():
     assert dp["single_gpu_same_per_gpu_batch"]["per_gpu_batch"] == 128 and dp["single_gpu_same_per_gpu_batch"]["value"] > 0
     assert dp["dp_at_64_rows_per_gpu"]["replicas_bit_identical"] is True
     assert d["value"] > 0 and d["value"] == pytest.approx(40 * 256 / (d["ms_per_step"] * 1e-3 * 40), rel=1e-3)
+
+
+def test_p2p_missing_peer_times_out_instead_of_hanging(tmp_path):
+    """a peer that never launches its side of the all-reduce: the waiting rank's kernel gives up after its wall-clock-bounded spin and the
+    communicator reports it -- no GPU hang"""
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    key = uuid.uuid4().hex[:12]
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "p2p_straggler_worker.py")],
+                              env=dict(env0, RANK=str(r), WORLD_SIZE="2", TAPER_DP_OUT=str(tmp_path), TAPER_DP_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    flag, seconds = (tmp_path / "straggler_result.txt").read_text().split()
+    assert flag == "1"                       # th_comm_error raised
+    assert 2.0 < float(seconds) < 30.0       # after the ~4 s spin bound, not never
