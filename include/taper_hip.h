@@ -183,6 +183,16 @@ int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d_w, const f
                         int batch, int in_features, int classes, float *d_loss, float *d_ncorrect,
                         float *d_dx, float *d_dw, float *d_db, float *d_metrics, int64_t metrics_capacity,
                         int64_t *d_state, int64_t advance, int32_t *d_adam_tick);
+/* The same two launches with one more output: d_colsum_masked[col] = sum over the rows of dX[row][col] * [x[row][col] > 0]
+ * (written, not accumulated; d_dx may then be NULL: dX is not stored).  For an input that is the flattened output of a
+ * bias-only Conv2dReLU (+ max-pool) -- faithful mode, Q2 -- these column sums are all its backward needs:
+ * th_bias_from_colsum_adam finishes db[ch] = sum_j colsum[ch hw + j] (+ the bias's Adam update, + carried slices). */
+int th_linear_xent_wide_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
+                           int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db,
+                           float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick,
+                           float *d_colsum_masked);
+int th_bias_from_colsum_adam(th_ctx *ctx, const float *d_colsum, float *d_gb, int c, int hw, const th_adam_fuse *b_fuse,
+                             const th_adam_slice *extra, int n_extra);
 
 /* ---- fused MLP tail: classifier head + the backward of the hidden layer ---- */
 /* For  ... -> H = relu(X . W1^T + b1) -> logits = H . W2^T + b2 -> cross-entropy

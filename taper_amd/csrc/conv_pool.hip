@@ -732,6 +732,48 @@ __global__ __launch_bounds__(1024) void bias_grad_adam_kernel(const float *__res
     }
 }
 
+// The same bias gradient from per-COLUMN sums: when the consumer of a bias-only Conv2dReLU (+ pool) is flatten -> Linear, the
+// classifier head (th_linear_xent_wide_ex) has every dX[row][col] and x[row][col] in registers and hands over
+// colsum[col] = sum_rows dX * [x > 0]; channel ch owns columns [ch hw, (ch + 1) hw) of the flattened map, so db[ch] is hw additions
+// instead of a pass over two [n][c][hw] tensors, and dX is never written.  Block 0: one thread per channel (+ its Adam update);
+// the other blocks apply carried Adam slices.
+__global__ __launch_bounds__(1024) void bias_from_colsum_adam_kernel(const float *__restrict__ colsum, float *__restrict__ gb, int c, int hw, AdamDev ad,
+                                                                     AdamSlices extra) {
+    if (blockIdx.x > 0) {
+        if (threadIdx.x < 256) adam_slices_block(extra, blockIdx.x - 1);
+        return;
+    }
+    // 16 lanes per channel: lane j adds columns j, j + 16, ... (requested four at a time: a serial walk of hw dependent loads took 9 us),
+    // then the 16 partial sums meet in a fixed shuffle tree
+    const int sub = threadIdx.x & 15;
+    for (int ch0 = 0; ch0 < c; ch0 += 64) {
+        const int ch = ch0 + (threadIdx.x >> 4);
+        const float *row = colsum + (long)(ch < c ? ch : 0) * hw;
+        float part = 0.f;
+        for (int j = sub; j < hw; j += 64) {
+            const float v0 = row[j], v1 = j + 16 < hw ? row[j + 16] : 0.f, v2 = j + 32 < hw ? row[j + 32] : 0.f, v3 = j + 48 < hw ? row[j + 48] : 0.f;
+            part += (v0 + v1) + (v2 + v3);
+        }
+        part += __shfl_xor(part, 8, 64);
+        part += __shfl_xor(part, 4, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 1, 64);
+        if (sub == 0 && ch < c) {
+            const float tot = part;
+            gb[ch] = tot;
+            if (ad.p) {
+                const float step = adam_dev_step(ad), pv = ad.p[ch];
+                const float gv = tot + ad.wd * pv;
+                const float mn = ad.beta1 * ad.m[ch] + (1.0f - ad.beta1) * gv;
+                const float vn = ad.beta2 * ad.v[ch] + (1.0f - ad.beta2) * gv * gv;
+                ad.m[ch] = mn;
+                ad.v[ch] = vn;
+                ad.p[ch] = pv - step * mn / (sqrtf(vn) + ad.eps);
+            }
+        }
+    }
+}
+
 // im2col of the reference's GENERAL path (tensor.rs:1805-1906 + copy_consecutive_elements 1910-1969), one thread per
 // element of col[window][ch][k_row][k_col].  Restated as a closed form of the loops: within one kernel row the taps that
 // fall inside the padded width form ONE run starting at k_col = first; the run is copied from CONSECUTIVE input columns
@@ -1081,6 +1123,16 @@ int th_bias_grad_masked_adam(th_ctx *ctx, const float *d_gout, const float *d_ma
     const AdamSlices x = make_adam_slices(extra, n_extra);
     hipLaunchKernelGGL(bias_grad_adam_kernel, dim3(c + x.blocks()), dim3(1024), 0, ctx->stream, d_gout, d_mask_y, d_gb, n, c, hw,
                        pooled_avg ? 1 : 0, make_adam_dev(b_fuse), x);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_bias_from_colsum_adam(th_ctx *ctx, const float *d_colsum, float *d_gb, int c, int hw, const th_adam_fuse *b_fuse,
+                             const th_adam_slice *extra, int n_extra) {
+    TH_REQUIRE(ctx && d_colsum && d_gb && c > 0 && hw > 0, "th_bias_from_colsum_adam: null argument / empty tensor");
+    TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_bias_from_colsum_adam: bad extra slices");
+    const AdamSlices x = make_adam_slices(extra, n_extra);
+    hipLaunchKernelGGL(bias_from_colsum_adam_kernel, dim3(1 + x.blocks()), dim3(1024), 0, ctx->stream, d_colsum, d_gb, c, hw, make_adam_dev(b_fuse), x);
     TH_LAUNCH_CHECK();
     return 0;
 }

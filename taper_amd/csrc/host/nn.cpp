@@ -174,19 +174,23 @@ Tensor linear_cross_entropy_wide(const Tensor &h, const Tensor &w, const Tensor 
         return p.grad_->buf->d;
     };
     float *dw = slot(w), *db = slot(bias);
-    std::shared_ptr<Buffer> dh = h.get_requires_grad() ? Buffer::alloc(h.len()) : nullptr;
-    TH(th_linear_xent_wide(Device::ctx(), h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, loss.dptr(),
-                           nc, dh ? dh->d : nullptr, dw, db, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
-                           log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr));
+    // the input is the flattened output of a bias-only Conv2dReLU + pool (Trainer step): it asked for column sums of dX * [x > 0], not for dX
+    const bool colsum_mode = h.get_requires_grad() && h.grad_->wants_colsum && PoolBiasScope::active();
+    std::shared_ptr<Buffer> dh = (h.get_requires_grad() && !colsum_mode) ? Buffer::alloc(h.len()) : nullptr;
+    std::shared_ptr<Buffer> cs = colsum_mode ? Buffer::alloc((size_t)k) : nullptr;
+    TH(th_linear_xent_wide_ex(Device::ctx(), h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, loss.dptr(),
+                              nc, dh ? dh->d : nullptr, dw, db, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                              log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr, cs ? cs->d : nullptr));
     if (Adam *fa = FusedAdamScope::active()) {   // complete gradients; every workgroup of the launch read W
         fa->defer_for(w);
         if (bias.defined()) fa->defer_for(bias);
     }
     loss.set_requires_grad(true);
     Tensor hh = h, ww = w, bb = bias, out = loss;
-    Tape::push(loss, true, [hh, ww, bb, out, dh]() {
+    Tape::push(loss, true, [hh, ww, bb, out, dh, cs]() {
         if (!out.has_grad()) return;
         TAPER_ASSERT(out.grad_->shared_const, "linear_cross_entropy_wide: only loss.backward() from the root is supported");
+        if (cs) hh.grad_->colsum = cs;
         if (dh) {
             TAPER_ASSERT(!hh.has_grad() && !hh.grad_->buf_is_arena, "linear_cross_entropy_wide: input already has a gradient");
             hh.grad_->buf = dh;

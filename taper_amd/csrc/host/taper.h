@@ -81,6 +81,10 @@ struct GradSlot {
     std::shared_ptr<Buffer> pooled_cnt;   // [n][c] counts of elements > 0 per plane, left by a global average pool's forward
     int pooled_n = 0, pooled_c = 0, pooled_hw = 0;
     bool pooled_avg = false;      // the consumer was a global average pool: pooled_dy is [n][c], pooled_y the conv output itself
+    // Trainer-internal peephole (PoolBiasScope): the tensor is the (flattened) output of a bias-only Conv2dReLU + max-pool; all its backward
+    // needs of the gradient are the per-column sums of dX * [x > 0], which the wide classifier head leaves here instead of writing dX
+    bool wants_colsum = false;
+    std::shared_ptr<Buffer> colsum;   // [numel / batch]
 };
 
 class Tensor {

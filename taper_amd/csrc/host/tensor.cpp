@@ -579,8 +579,14 @@ Tensor Tensor::reshape(const Shape &s) const {  // tensor.rs:803-840
     Tensor out = make(data_, s);
     if (requires_grad_) {
         out.requires_grad_ = true;
+        // a view of [n, ...] as [n, rest] keeps the columns of a sample together: the column-sum wish (GradSlot) travels with it
+        if (PoolBiasScope::active() && grad_->wants_colsum && !s.empty() && !shape_.empty() && s[0] == shape_[0]) out.grad_->wants_colsum = true;
         Tensor in = *this, r = out;
         Tape::push(out, true, [in, r]() {
+            if (r.grad_->colsum) {   // the classifier head left column sums instead of a gradient: hand them on
+                in.grad_->colsum = std::move(r.grad_->colsum);
+                return;
+            }
             if (!r.has_grad()) return;
             if (PoolBiasScope::active() && !in.has_grad() && !in.grad_->buf_is_arena && !r.grad_->shared_const && !r.grad_->buf_is_arena) {
                 // Trainer steps over a Sequential (one consumer per tensor): 0 + x is x -- adopt the view's gradient
@@ -870,8 +876,25 @@ Tensor Tensor::conv2d_relu_maxpool2(const Tensor &w, const Tensor &bias, std::pa
                             pad, 1));
     if (bias.defined() && bias.requires_grad_) {   // faithful mode (Q2): the bias is the pair's only trainable input
         out.requires_grad_ = true;
+        // inside a Trainer step (one consumer per tensor) the sums of dX * [x > 0] per column are all this node needs of its gradient
+        out.grad_->wants_colsum = PoolBiasScope::active() && !bias.has_grad();
         Tensor b = bias, r = out;
         Tape::push(out, true, [b, r, n, c_out, hp, wp]() {
+            if (r.grad_->colsum) {
+                th_ctx *ctx = Device::ctx();
+                bool none;
+                float *db = b.grad_for_write(&none);
+                TAPER_ASSERT(none, "conv2d_relu_maxpool2: column sums arrived for a bias that already holds a gradient");
+                Adam *fa = FusedAdamScope::active();
+                th_adam_fuse bf{};
+                th_adam_slice carried[TH_MAX_ADAM_SLICES];
+                int n_carried = 0;
+                const bool fuse = fa && fa->fuse_for(b, &bf);
+                if (fuse) n_carried = fa->take_deferred(nullptr, carried);
+                TH(th_bias_from_colsum_adam(ctx, r.grad_->colsum->d, db, c_out, hp * wp, fuse ? &bf : nullptr, carried, n_carried));
+                r.grad_->colsum.reset();
+                return;
+            }
             if (!r.has_grad()) return;
             // every pooled gradient lands on exactly one conv output (tensor.rs:1496-1519) whose ReLU mask is "pooled value > 0"
             pooled_bias_grad(b, r.grad_dptr(), r.dptr(), n, c_out, hp * wp, false);

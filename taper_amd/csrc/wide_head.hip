@@ -25,6 +25,7 @@ struct WideArgs {
     int64_t advance;
     int32_t *adam_tick;
     int n_col;           // column blocks (32 columns each); block n_col is the lead
+    float *colsum;       // optional [k]: sum over the rows of dX[row][col] * [x[row][col] > 0] (see th_linear_xent_wide_ex)
 };
 
 constexpr int WH_TX = 2;   // 16-column tiles per workgroup
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
     __shared__ float tr[WH_NW][16][17];
     __shared__ float rowv[WH_NW][2][16];
     __shared__ float sc[WH_NW][20];
+    __shared__ float colred[WH_NW][WH_TX][16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
     const bool lead = (int)blockIdx.x == a.n_col;
     const int B = a.batch, K = a.k, C = a.c;
@@ -61,6 +63,9 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
 #pragma unroll
     for (int tx = 0; tx < WH_TX; ++tx) accw[tx] = floatx4{0.f, 0.f, 0.f, 0.f};
     float db_acc = 0.f, nll_acc = 0.f, hit_acc = 0.f;
+    float cs[WH_TX];     // this lane's share of the masked column sums (rows 4 g4 + i of every block the wave takes, column r16 of each tile)
+#pragma unroll
+    for (int tx = 0; tx < WH_TX; ++tx) cs[tx] = 0.f;
 
     for (int c0 = 0; c0 < B; c0 += 16 * WH_NW) {
         const int r0 = c0 + wave * 16;
@@ -105,17 +110,24 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
             __builtin_amdgcn_wave_barrier();
             if (!lead) {
                 // dX block (ops.rs:254-265): rows 4 g4 + i of this wave's block, columns r16 of each tile
-                if (a.dx) {
+                if (a.dx || a.colsum) {
 #pragma unroll
                     for (int tx = 0; tx < WH_TX; ++tx) {
                         floatx4 ax = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int s = 0; s < 4; ++s) ax = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[s], wv[tx][s], ax, 0, 0, 0);
                         const int col = col0 + tx * 16 + r16;
+                        if (a.dx) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = r0 + g4 * 4 + i;
-                            if (row < B && col < K) a.dx[(long)row * K + col] = ax[i];
+                            for (int i = 0; i < 4; ++i) {
+                                const int row = r0 + g4 * 4 + i;
+                                if (row < B && col < K) a.dx[(long)row * K + col] = ax[i];
+                            }
+                        }
+                        // x[row 4 g4 + i][col] sits in xv[tx][i] (the dW operand): the D tile and that operand share their (row, column) map
+                        if (a.colsum) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) cs[tx] += xv[tx][i] > 0.f ? ax[i] : 0.f;
                         }
                     }
                 }
@@ -141,6 +153,23 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
         }
     }
 
+    if (!lead && a.colsum) {   // the four row groups of a wave in a fixed tree, then the waves in order: deterministic
+#pragma unroll
+        for (int tx = 0; tx < WH_TX; ++tx) {
+            float v = cs[tx];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g4 == 0) colred[wave][tx][r16] = v;
+        }
+        __syncthreads();
+        if (t < 16 * WH_TX) {
+            const int tx = t >> 4, r = t & 15, col = col0 + tx * 16 + r;
+            float sum = colred[0][tx][r];
+#pragma unroll
+            for (int w = 1; w < WH_NW; ++w) sum += colred[w][tx][r];
+            if (col < K) a.colsum[col] = sum;
+        }
+    }
     if (!lead) {   // deterministic cross-wave sum; wave e finishes class 4 g4 + e
 #pragma unroll
         for (int tx = 0; tx < WH_TX; ++tx)
@@ -195,9 +224,10 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
 
 using namespace th;
 
-extern "C" int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
-                                   int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db,
-                                   float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick) {
+extern "C" int th_linear_xent_wide_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
+                                      int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db,
+                                      float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick,
+                                      float *d_colsum_masked) {
     TH_REQUIRE(ctx && d_x && d_w && d_targets && d_loss && d_dw, "th_linear_xent_wide: null argument");
     TH_REQUIRE(batch > 0 && batch <= 4096 && in_features > 0 && classes > 0 && classes <= 16,
                "th_linear_xent_wide: needs batch <= 4096, classes <= 16 (got %d, %d)", batch, classes);
@@ -206,8 +236,15 @@ extern "C" int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d
     int kz = 0;
     if (int rc = linear_fwd_partials(ctx, d_x, d_w, batch, classes, in_features, &partial, &kz)) return rc;
     WideArgs a{d_x, d_w, d_bias, d_targets, partial, batch, in_features, classes, kz, d_loss, d_ncorrect, d_dx, d_dw, d_db,
-               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, ceil_div(in_features, 16 * WH_TX)};
+               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, ceil_div(in_features, 16 * WH_TX), d_colsum_masked};
     hipLaunchKernelGGL(wide_head_kernel, dim3(a.n_col + 1), dim3(64 * WH_NW), 0, ctx->stream, a);
     TH_LAUNCH_CHECK();
     return th_free(ctx, partial);
+}
+
+extern "C" int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
+                                   int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db,
+                                   float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick) {
+    return th_linear_xent_wide_ex(ctx, d_x, d_w, d_bias, d_targets, batch, in_features, classes, d_loss, d_ncorrect, d_dx, d_dw, d_db, d_metrics,
+                                  metrics_capacity, d_state, advance, d_adam_tick, nullptr);
 }

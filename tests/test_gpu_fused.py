@@ -127,6 +127,50 @@ def test_linear_xent_wide(ctx, O, batch, k, c):
     assert np.isfinite(ctx.download(loss, 1)[0])
 
 
+@pytest.mark.parametrize("batch,c_conv,hw,c", [(256, 64, 49, 10), (96, 64, 49, 10), (37, 5, 9, 7), (300, 8, 36, 3)])
+def test_linear_xent_wide_column_sums_and_bias_finish(ctx, O, batch, c_conv, hw, c):
+    """th_linear_xent_wide_ex: the masked column sums of dX (what a bias-only Conv2dReLU + pool in front of flatten -> Linear needs,
+    Q2) without storing dX, then th_bias_from_colsum_adam: db[ch] = sum of its hw columns (+ Adam) -- against the oracle's dH and the
+    pooled-bias formula sum_n sum_sp dH * [x > 0]"""
+    k = c_conv * hw
+    rng = np.random.default_rng(batch + k + c)
+    h = np.maximum(rng.standard_normal((batch, k)), 0).astype(np.float32)      # a ReLU + max-pool output: zeros are masked positions
+    w = (rng.uniform(-1, 1, (c, k)) * np.sqrt(2.0 / k)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    ref = oracle_head(O, h, w, b, y)
+    dh = np.asarray(ref["dh"]).reshape(batch, k)
+    col_ref = (dh * (h > 0)).sum(axis=0, dtype=np.float64)
+    dw_, db_, cs_ = ctx.empty(c * k), ctx.empty(c), ctx.upload(np.full(k, 7.0, np.float32))     # overwritten, not accumulated
+    loss = ctx.empty(1)
+    ctx.call("th_linear_xent_wide_ex", ctx.upload(h), ctx.upload(w), ctx.upload(b), ctx.upload(y), batch, k, c, loss, None, None, dw_, db_, None, 0,
+             None, 0, None, cs_)
+    assert ctx.download(loss, 1)[0] == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
+    close(ctx.download(dw_, (c, k)), ref["dw"])
+    got = ctx.download(cs_, k)
+    np.testing.assert_allclose(got, col_ref, rtol=RTOL, atol=RTOL * float(np.abs(col_ref).max()) + 1e-9)
+    # with dX requested as well: the same sums, and dX as before
+    dx_, cs2 = ctx.empty(batch * k), ctx.empty(k)
+    ctx.call("th_linear_xent_wide_ex", ctx.upload(h), ctx.upload(w), ctx.upload(b), ctx.upload(y), batch, k, c, loss, None, dx_, dw_, db_, None, 0,
+             None, 0, None, cs2)
+    close(ctx.download(dx_, (batch, k)), dh)
+    np.testing.assert_array_equal(ctx.download(cs2, k), got)                       # deterministic
+    # the finishing launch: channel sums, then the same with the bias's Adam update fused
+    db_ref = col_ref.reshape(c_conv, hw).sum(axis=1)
+    gb = ctx.empty(c_conv)
+    ctx.call("th_bias_from_colsum_adam", cs_, gb, c_conv, hw, None, None, 0)
+    np.testing.assert_allclose(ctx.download(gb, c_conv), db_ref, rtol=RTOL, atol=RTOL * float(np.abs(db_ref).max()) + 1e-9)
+    from taper_amd import hip
+    p0 = rng.uniform(-0.5, 0.5, c_conv).astype(np.float32)
+    pd, md, vd = ctx.upload(p0), ctx.zeros(c_conv), ctx.zeros(c_conv)
+    tick, lr = ctx.upload(np.array([3, 0], np.int32)), ctx.upload(np.array([1e-2], np.float32))
+    fuse = hip.AdamFuse(int(pd), int(md), int(vd), int(tick), int(lr), 0.9, 0.999, 1e-8, 1e-4)
+    ctx.call("th_bias_from_colsum_adam", cs_, gb, c_conv, hw, C.byref(fuse), None, 0)
+    p_ref, m_ref, v_ref = _adam_ref(O, p0, ctx.download(gb, c_conv), 1e-2, 3)
+    np.testing.assert_allclose(ctx.download(pd, c_conv), p_ref, rtol=RTOL, atol=1e-2 * 2e-2)
+    np.testing.assert_allclose(ctx.download(md, c_conv), m_ref, rtol=1e-3, atol=1e-7)
+
+
 def test_head_limits_are_errors(ctx):
     from taper_amd._lib import TaperError
     x = ctx.zeros(64 * 300)
