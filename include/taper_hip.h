@@ -193,6 +193,21 @@ int th_linear_xent_wide_ex(th_ctx *ctx, const float *d_x, const float *d_w, cons
                            float *d_colsum_masked);
 int th_bias_from_colsum_adam(th_ctx *ctx, const float *d_colsum, float *d_gb, int c, int hw, const th_adam_fuse *b_fuse,
                              const th_adam_slice *extra, int n_extra);
+/* ... and the whole tail of such a step in those two launches: in the second one every workgroup also applies Adam (optim.rs:99-110)
+ * to the columns of W it owns (no other workgroup reads them: dX is not stored in this form), the lead workgroup to b, and the LAST
+ * workgroup to arrive sums the conv bias gradient from everybody's column sums (d_conv_gb[conv_c], conv_c * conv_hw == in_features),
+ * applies its Adam update and publishes the step counter.  The counter is ticked IN this launch (optim.rs:84): d_adam_tick points at
+ * {t, arrival counter (0 between launches)}; the d_t fields of the three th_adam_fuse are ignored, every update uses t + 1.
+ * Members with d_p == NULL are skipped; d_conv_gb == NULL: no conv bias in front. */
+typedef struct th_wide_fuse {
+    th_adam_fuse w, b, conv_b;
+    float *d_conv_gb;
+    int conv_c, conv_hw;
+} th_wide_fuse;
+int th_linear_xent_wide_fused(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
+                              int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dw, float *d_db,
+                              float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick,
+                              float *d_colsum_masked, const th_wide_fuse *fuse);
 
 /* ---- fused MLP tail: classifier head + the backward of the hidden layer ---- */
 /* For  ... -> H = relu(X . W1^T + b1) -> logits = H . W2^T + b2 -> cross-entropy

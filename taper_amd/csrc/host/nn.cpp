@@ -178,19 +178,45 @@ Tensor linear_cross_entropy_wide(const Tensor &h, const Tensor &w, const Tensor 
     const bool colsum_mode = h.get_requires_grad() && h.grad_->wants_colsum && PoolBiasScope::active();
     std::shared_ptr<Buffer> dh = (h.get_requires_grad() && !colsum_mode) ? Buffer::alloc(h.len()) : nullptr;
     std::shared_ptr<Buffer> cs = colsum_mode ? Buffer::alloc((size_t)k) : nullptr;
-    TH(th_linear_xent_wide_ex(Device::ctx(), h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, loss.dptr(),
-                              nc, dh ? dh->d : nullptr, dw, db, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
-                              log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr, cs ? cs->d : nullptr));
-    if (Adam *fa = FusedAdamScope::active()) {   // complete gradients; every workgroup of the launch read W
-        fa->defer_for(w);
-        if (bias.defined()) fa->defer_for(bias);
+    // With the Adam fusion on, the whole tail of the step fits these two launches: no dX is stored, so every workgroup owns its columns of W
+    // (Adam in its epilogue), the lead owns b, and the last workgroup to arrive finishes the conv bias from the column sums and ticks t.
+    Adam *fa = FusedAdamScope::active();
+    const std::shared_ptr<GradSlot> cbs = colsum_mode ? h.grad_->colsum_bias : nullptr;
+    // (measured on the simple CNN at batch 256: the head grows from 11.9 to 22.5 us -- Adam's p / m / v round trip behind the dW reduction in
+    // every workgroup, an agent-scope fence per workgroup, the last arriver's serial finish -- against the 5.0 us finishing launch it replaces:
+    // step 57.2 -> 64.1 us.  Off unless TAPER_WIDE_FUSED=1.)
+    static const bool wide_fused = std::getenv("TAPER_WIDE_FUSED") && std::getenv("TAPER_WIDE_FUSED")[0] == '1';
+    const bool full = wide_fused && colsum_mode && fa && log && log->d_adam_tick && cbs && cbs->buf && cbs->buf_is_arena && !cbs->has &&
+                      (long)h.grad_->colsum_c * h.grad_->colsum_hw == k;
+    bool fused_done = false;
+    if (full) {
+        th_wide_fuse f{};
+        const bool ok = fa->fuse_for(w, &f.w) && (!bias.defined() || fa->fuse_for(bias, &f.b)) && fa->fuse_for_slot(cbs, &f.conv_b);
+        TAPER_ASSERT(ok, "linear_cross_entropy_wide: a parameter of the fused tail is not held by the active optimizer");
+        f.d_conv_gb = cbs->buf->d;
+        f.conv_c = h.grad_->colsum_c;
+        f.conv_hw = h.grad_->colsum_hw;
+        TH(th_linear_xent_wide_fused(Device::ctx(), h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, loss.dptr(),
+                                     nc, dw, db, log->d_metrics, log->capacity, log->d_state, log->advance, log->d_adam_tick, cs->d, &f));
+        cbs->has = true;
+        cbs->known_zero = false;
+        fused_done = true;
+    } else {
+        TH(th_linear_xent_wide_ex(Device::ctx(), h.dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), b, k, c, loss.dptr(),
+                                  nc, dh ? dh->d : nullptr, dw, db, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                                  log ? log->d_state : nullptr, log ? log->advance : 0, log ? log->d_adam_tick : nullptr, cs ? cs->d : nullptr));
+        if (fa) {   // complete gradients; every workgroup of the launch read W
+            fa->defer_for(w);
+            if (bias.defined()) fa->defer_for(bias);
+        }
     }
     loss.set_requires_grad(true);
     Tensor hh = h, ww = w, bb = bias, out = loss;
-    Tape::push(loss, true, [hh, ww, bb, out, dh, cs]() {
+    Tape::push(loss, true, [hh, ww, bb, out, dh, cs, fused_done]() {
         if (!out.has_grad()) return;
         TAPER_ASSERT(out.grad_->shared_const, "linear_cross_entropy_wide: only loss.backward() from the root is supported");
-        if (cs) hh.grad_->colsum = cs;
+        if (fused_done) hh.grad_->colsum_done = true;
+        else if (cs) hh.grad_->colsum = cs;
         if (dh) {
             TAPER_ASSERT(!hh.has_grad() && !hh.grad_->buf_is_arena, "linear_cross_entropy_wide: input already has a gradient");
             hh.grad_->buf = dh;
@@ -526,9 +552,11 @@ Adam::Adam(const std::vector<Tensor> &params, float lr, float beta1, float beta2
     set_lr(lr);
 }
 
-bool Adam::fuse_for(const Tensor &param, th_adam_fuse *out) {
+bool Adam::fuse_for(const Tensor &param, th_adam_fuse *out) { return fuse_for_slot(param.grad_, out); }
+
+bool Adam::fuse_for_slot(const std::shared_ptr<GradSlot> &slot, th_adam_fuse *out) {
     for (size_t i = 0; i < fp_.params.size(); ++i) {
-        if (fp_.params[i].grad_ != param.grad_) continue;
+        if (fp_.params[i].grad_ != slot) continue;
         const int64_t off = fp_.offsets[i];
         *out = th_adam_fuse{fp_.p_arena->d + off, m_->d + off, v_->d + off, d_tick(), state_->d + 2, beta1_, beta2_, eps_, wd_};
         fused_[i] = 1;

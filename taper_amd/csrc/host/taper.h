@@ -85,6 +85,9 @@ struct GradSlot {
     // needs of the gradient are the per-column sums of dX * [x > 0], which the wide classifier head leaves here instead of writing dX
     bool wants_colsum = false;
     std::shared_ptr<Buffer> colsum;   // [numel / batch]
+    std::shared_ptr<GradSlot> colsum_bias;   // that conv's bias (grad slot) and geometry: the head can finish it in its own launch (th_linear_xent_wide_fused)
+    int colsum_c = 0, colsum_hw = 0;
+    bool colsum_done = false;                // ... and did
 };
 
 class Tensor {
@@ -421,6 +424,7 @@ class Adam : public Optimizer {  // optim.rs:43-128
     // step() then only covers the parameters nobody fused, with the counter already ticked.
     int32_t *d_tick() const { return reinterpret_cast<int32_t *>(state_->d); }
     bool fuse_for(const Tensor &param, th_adam_fuse *out);  // false: not ours / has a grad already
+    bool fuse_for_slot(const std::shared_ptr<GradSlot> &slot, th_adam_fuse *out);
     // The gradient of `param` is (or is being) completed by the launch just enqueued, which could not
     // update it in place (the head kernel; a backward whose dX workgroups still read W): a LATER
     // launch of this step carries the update in spare workgroups (th_adam_slice), step() the leftovers.

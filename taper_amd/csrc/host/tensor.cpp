@@ -580,9 +580,18 @@ Tensor Tensor::reshape(const Shape &s) const {  // tensor.rs:803-840
     if (requires_grad_) {
         out.requires_grad_ = true;
         // a view of [n, ...] as [n, rest] keeps the columns of a sample together: the column-sum wish (GradSlot) travels with it
-        if (PoolBiasScope::active() && grad_->wants_colsum && !s.empty() && !shape_.empty() && s[0] == shape_[0]) out.grad_->wants_colsum = true;
+        if (PoolBiasScope::active() && grad_->wants_colsum && !s.empty() && !shape_.empty() && s[0] == shape_[0]) {
+            out.grad_->wants_colsum = true;
+            out.grad_->colsum_bias = grad_->colsum_bias;
+            out.grad_->colsum_c = grad_->colsum_c;
+            out.grad_->colsum_hw = grad_->colsum_hw;
+        }
         Tensor in = *this, r = out;
         Tape::push(out, true, [in, r]() {
+            if (r.grad_->colsum_done) {   // the classifier head finished the conv bias in its own launch
+                in.grad_->colsum_done = true;
+                return;
+            }
             if (r.grad_->colsum) {   // the classifier head left column sums instead of a gradient: hand them on
                 in.grad_->colsum = std::move(r.grad_->colsum);
                 return;
@@ -878,8 +887,17 @@ Tensor Tensor::conv2d_relu_maxpool2(const Tensor &w, const Tensor &bias, std::pa
         out.requires_grad_ = true;
         // inside a Trainer step (one consumer per tensor) the sums of dX * [x > 0] per column are all this node needs of its gradient
         out.grad_->wants_colsum = PoolBiasScope::active() && !bias.has_grad();
+        if (out.grad_->wants_colsum) {
+            out.grad_->colsum_bias = bias.grad_;
+            out.grad_->colsum_c = c_out;
+            out.grad_->colsum_hw = hp * wp;
+        }
         Tensor b = bias, r = out;
         Tape::push(out, true, [b, r, n, c_out, hp, wp]() {
+            if (r.grad_->colsum_done) {   // gradient and Adam update of the bias already happened in the head's launch
+                r.grad_->colsum_done = false;
+                return;
+            }
             if (r.grad_->colsum) {
                 th_ctx *ctx = Device::ctx();
                 bool none;

@@ -10,6 +10,7 @@
 //             one extra "lead" workgroup: db, loss, hit count, the step log and Adam's t += 1.
 // No parameter is updated here (W is read by every workgroup's dX product): the caller defers W / b (th_adam_slice).
 #include "tail_dev.h"
+#include "adam_dev.h"
 
 namespace th {
 
@@ -26,6 +27,12 @@ struct WideArgs {
     int32_t *adam_tick;
     int n_col;           // column blocks (32 columns each); block n_col is the lead
     float *colsum;       // optional [k]: sum over the rows of dX[row][col] * [x[row][col] > 0] (see th_linear_xent_wide_ex)
+    // th_linear_xent_wide_fused: Adam (optim.rs:99-110) for W (every workgroup: the columns it owns -- nobody else reads them in this launch)
+    // and b (lead), and the finish of the conv bias in front (the LAST workgroup to arrive: db[ch] = sum of ch's hw column sums, + Adam).
+    // The step counter is ticked HERE: every workgroup forms t + 1 itself, the last arriver publishes it (adam_tick[1] = arrival counter).
+    AdamDev fw, fb, fcb;
+    float *conv_gb;
+    int conv_c, conv_hw, fused;
 };
 
 constexpr int WH_TX = 2;   // 16-column tiles per workgroup
@@ -57,7 +64,8 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
         }
     }
     const int64_t state0 = (lead && a.metrics) ? a.state[0] : 0, state1 = (lead && a.metrics) ? a.state[1] : 0;
-    const int32_t tick_old = (lead && a.adam_tick) ? a.adam_tick[0] : 0;
+    const int32_t tick_old = ((lead || a.fused) && a.adam_tick) ? __hip_atomic_load(&a.adam_tick[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __shared__ int last_flag;
 
     floatx4 accw[WH_TX];
 #pragma unroll
@@ -184,8 +192,87 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
                 float sum = red[0][tx][lane][wave];
 #pragma unroll
                 for (int w = 1; w < WH_NW; ++w) sum += red[w][tx][lane][wave];
-                if (cls < C && col < K) a.dw[(long)cls * K + col] = sum;
+                if (cls < C && col < K) {
+                    a.dw[(long)cls * K + col] = sum;
+                    if (a.fused && a.fw.p)
+                        adam_update(a.fw.p, a.fw.m, a.fw.v, (long)cls * K + col, sum, adam_step_size(a.fw.lr[0], a.fw.beta1, a.fw.beta2, tick_old + 1),
+                                    a.fw.beta1, a.fw.beta2, a.fw.eps, a.fw.wd);
+                }
             }
+        }
+        if (!a.fused) return;
+    }
+    if (a.fused) {
+        // arrival: the last workgroup finishes the conv bias from everybody's column sums and publishes the step counter
+        if (lead) {
+            if (g4 == 0) sc[wave][r16] = db_acc;
+            if (lane == 0) {
+                sc[wave][16] = nll_acc;
+                sc[wave][17] = hit_acc;
+            }
+            __syncthreads();
+            if (a.db && t < C) {
+                float sum = sc[0][t];
+                for (int w = 1; w < WH_NW; ++w) sum += sc[w][t];
+                a.db[t] = sum;
+                if (a.fb.p)
+                    adam_update(a.fb.p, a.fb.m, a.fb.v, t, sum, adam_step_size(a.fb.lr[0], a.fb.beta1, a.fb.beta2, tick_old + 1), a.fb.beta1,
+                                a.fb.beta2, a.fb.eps, a.fb.wd);
+            }
+            if (t == 0) {
+                float n = sc[0][16], hsum = sc[0][17];
+                for (int w = 1; w < WH_NW; ++w) {
+                    n += sc[w][16];
+                    hsum += sc[w][17];
+                }
+                const float l = n / (float)B;   // loss.rs:164
+                a.loss[0] = l;
+                if (a.ncorrect) a.ncorrect[0] = hsum;
+                if (a.metrics) {
+                    const int64_t slot = state0 < a.capacity ? state0 : state0 % a.capacity;
+                    a.metrics[2 * slot] = l;
+                    a.metrics[2 * slot + 1] = hsum;
+                    a.state[0] = state0 + 1;
+                    a.state[1] = state1 + a.advance;
+                }
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            __threadfence();                                   // this workgroup's column sums / updates are out before it is counted
+            const int arrived = __hip_atomic_fetch_add(&a.adam_tick[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = arrived == (int)gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        __threadfence();                                       // ... and everybody else's are visible here
+        if (a.colsum && a.conv_gb) {
+            // 16 lanes per channel of the conv in front: lane j adds column sums j, j + 16, ..., then a fixed shuffle tree (th_bias_from_colsum_adam)
+            const int sub = t & 15;
+            const float cstep = a.fcb.p ? adam_step_size(a.fcb.lr[0], a.fcb.beta1, a.fcb.beta2, tick_old + 1) : 0.f;
+            for (int ch0 = 0; ch0 < a.conv_c; ch0 += 64 * WH_NW / 16) {
+                const int ch = ch0 + (t >> 4);
+                const float *row = a.colsum + (long)(ch < a.conv_c ? ch : 0) * a.conv_hw;
+                float part = 0.f;
+                for (int j = sub; j < a.conv_hw; j += 64) {
+                    const float v0 = __builtin_nontemporal_load(row + j), v1 = j + 16 < a.conv_hw ? __builtin_nontemporal_load(row + j + 16) : 0.f,
+                                v2 = j + 32 < a.conv_hw ? __builtin_nontemporal_load(row + j + 32) : 0.f,
+                                v3 = j + 48 < a.conv_hw ? __builtin_nontemporal_load(row + j + 48) : 0.f;
+                    part += (v0 + v1) + (v2 + v3);
+                }
+                part += __shfl_xor(part, 8, 64);
+                part += __shfl_xor(part, 4, 64);
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 1, 64);
+                if (sub == 0 && ch < a.conv_c) {
+                    a.conv_gb[ch] = part;
+                    if (a.fcb.p) adam_update(a.fcb.p, a.fcb.m, a.fcb.v, ch, part, cstep, a.fcb.beta1, a.fcb.beta2, a.fcb.eps, a.fcb.wd);
+                }
+            }
+        }
+        if (t == 0) {
+            __hip_atomic_store(&a.adam_tick[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.adam_tick[0], tick_old + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // optim.rs:84
         }
         return;
     }
@@ -224,10 +311,10 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
 
 using namespace th;
 
-extern "C" int th_linear_xent_wide_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
-                                      int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db,
-                                      float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick,
-                                      float *d_colsum_masked) {
+static int wide_launch(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch, int in_features,
+                       int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db, float *d_metrics,
+                       int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick, float *d_colsum_masked,
+                       const th_wide_fuse *fuse) {
     TH_REQUIRE(ctx && d_x && d_w && d_targets && d_loss && d_dw, "th_linear_xent_wide: null argument");
     TH_REQUIRE(batch > 0 && batch <= 4096 && in_features > 0 && classes > 0 && classes <= 16,
                "th_linear_xent_wide: needs batch <= 4096, classes <= 16 (got %d, %d)", batch, classes);
@@ -236,15 +323,37 @@ extern "C" int th_linear_xent_wide_ex(th_ctx *ctx, const float *d_x, const float
     int kz = 0;
     if (int rc = linear_fwd_partials(ctx, d_x, d_w, batch, classes, in_features, &partial, &kz)) return rc;
     WideArgs a{d_x, d_w, d_bias, d_targets, partial, batch, in_features, classes, kz, d_loss, d_ncorrect, d_dx, d_dw, d_db,
-               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, ceil_div(in_features, 16 * WH_TX), d_colsum_masked};
+               d_metrics, metrics_capacity, d_state, advance, d_adam_tick, ceil_div(in_features, 16 * WH_TX), d_colsum_masked,
+               make_adam_dev(fuse ? &fuse->w : nullptr), make_adam_dev(fuse ? &fuse->b : nullptr), make_adam_dev(fuse ? &fuse->conv_b : nullptr),
+               fuse ? fuse->d_conv_gb : nullptr, fuse ? fuse->conv_c : 0, fuse ? fuse->conv_hw : 0, fuse ? 1 : 0};
     hipLaunchKernelGGL(wide_head_kernel, dim3(a.n_col + 1), dim3(64 * WH_NW), 0, ctx->stream, a);
     TH_LAUNCH_CHECK();
     return th_free(ctx, partial);
 }
 
+extern "C" int th_linear_xent_wide_fused(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
+                                         int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dw, float *d_db,
+                                         float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick,
+                                         float *d_colsum_masked, const th_wide_fuse *fuse) {
+    TH_REQUIRE(fuse && d_adam_tick, "th_linear_xent_wide_fused: needs the fuse descriptor and Adam's counter block");
+    TH_REQUIRE(!fuse->d_conv_gb || (d_colsum_masked && fuse->conv_c > 0 && fuse->conv_hw > 0 && (long)fuse->conv_c * fuse->conv_hw == in_features),
+               "th_linear_xent_wide_fused: the conv bias finish needs the column sums and conv_c * conv_hw == in_features");
+    TH_REQUIRE(!fuse->b.d_p || d_db, "th_linear_xent_wide_fused: a fused bias update needs d_db");
+    return wide_launch(ctx, d_x, d_w, d_bias, d_targets, batch, in_features, classes, d_loss, d_ncorrect, nullptr, d_dw, d_db, d_metrics,
+                       metrics_capacity, d_state, advance, d_adam_tick, d_colsum_masked, fuse);
+}
+
+extern "C" int th_linear_xent_wide_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
+                                      int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db,
+                                      float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick,
+                                      float *d_colsum_masked) {
+    return wide_launch(ctx, d_x, d_w, d_bias, d_targets, batch, in_features, classes, d_loss, d_ncorrect, d_dx, d_dw, d_db, d_metrics,
+                       metrics_capacity, d_state, advance, d_adam_tick, d_colsum_masked, nullptr);
+}
+
 extern "C" int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, const float *d_targets, int batch,
                                    int in_features, int classes, float *d_loss, float *d_ncorrect, float *d_dx, float *d_dw, float *d_db,
                                    float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_adam_tick) {
-    return th_linear_xent_wide_ex(ctx, d_x, d_w, d_bias, d_targets, batch, in_features, classes, d_loss, d_ncorrect, d_dx, d_dw, d_db, d_metrics,
-                                  metrics_capacity, d_state, advance, d_adam_tick, nullptr);
+    return wide_launch(ctx, d_x, d_w, d_bias, d_targets, batch, in_features, classes, d_loss, d_ncorrect, d_dx, d_dw, d_db, d_metrics,
+                       metrics_capacity, d_state, advance, d_adam_tick, nullptr, nullptr);
 }

@@ -23,6 +23,11 @@ class AdamSlice(C.Structure):
     _fields_ = [("d_g", C.c_void_p), ("n", C.c_int64), ("f", AdamFuse)]
 
 
+class WideFuse(C.Structure):
+    """include/taper_hip.h: th_wide_fuse"""
+    _fields_ = [("w", AdamFuse), ("b", AdamFuse), ("conv_b", AdamFuse), ("d_conv_gb", C.c_void_p), ("conv_c", C.c_int), ("conv_hw", C.c_int)]
+
+
 class DevBuf:
     """A device allocation from the ctx pool (freed on garbage collection)."""
 

@@ -171,6 +171,50 @@ def test_linear_xent_wide_column_sums_and_bias_finish(ctx, O, batch, c_conv, hw,
     np.testing.assert_allclose(ctx.download(md, c_conv), m_ref, rtol=1e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("batch,c_conv,hw,c", [(256, 64, 49, 10), (96, 64, 49, 10), (40, 6, 50, 7)])
+def test_linear_xent_wide_fused_tail(ctx, O, batch, c_conv, hw, c):
+    """th_linear_xent_wide_fused: the whole tail of a Conv2dReLU(+pool) -> flatten -> Linear -> cross-entropy step in the head's two
+    launches -- Adam on W (every workgroup its own columns), on b (lead), the conv bias finished by the last workgroup to arrive, the
+    step counter ticked in the launch -- against oracle gradients followed by oracle Adam at t = old + 1; two consecutive launches
+    (the arrival counter must come back to 0)"""
+    from taper_amd.hip import WideFuse
+    k = c_conv * hw
+    rng = np.random.default_rng(batch * 3 + k + c)
+    h = np.maximum(rng.standard_normal((batch, k)), 0).astype(np.float32)
+    w0 = (rng.uniform(-1, 1, (c, k)) * np.sqrt(2.0 / k)).astype(np.float32)
+    b0 = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    cb0 = rng.uniform(-0.3, 0.3, c_conv).astype(np.float32)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    lr = 1e-2
+    wd_, bd_, cbd_ = ctx.upload(w0), ctx.upload(b0), ctx.upload(cb0)
+    mom = {n: (ctx.zeros(sz), ctx.zeros(sz)) for n, sz in (("w", c * k), ("b", c), ("cb", c_conv))}
+    tick, lrd = ctx.upload(np.array([4, 0, 0, 0], np.int32)), ctx.upload(np.array([lr], np.float32))
+    fz = lambda p, n: AdamFuse(int(p), int(mom[n][0]), int(mom[n][1]), int(tick), int(lrd), 0.9, 0.999, 1e-8, 1e-4)
+    gcb = ctx.empty(c_conv)
+    f = WideFuse(fz(wd_, "w"), fz(bd_, "b"), fz(cbd_, "cb"), int(gcb), c_conv, hw)
+    dw_, db_, cs_, loss = ctx.empty(c * k), ctx.empty(c), ctx.empty(k), ctx.empty(1)
+    hd, yd = ctx.upload(h), ctx.upload(y)
+    w_ref, b_ref, cb_ref = w0, b0, cb0
+    state = {n: None for n in ("w", "b", "cb")}
+    for step in range(2):
+        ref = oracle_head(O, h, w_ref, b_ref, y)
+        dh = np.asarray(ref["dh"]).reshape(batch, k)
+        gcb_ref = (dh * (h > 0)).sum(axis=0, dtype=np.float64).reshape(c_conv, hw).sum(axis=1).astype(np.float32)
+        ctx.call("th_linear_xent_wide_fused", hd, wd_, bd_, yd, batch, k, c, loss, None, dw_, db_, None, 0, None, 0, tick, cs_, C.byref(f))
+        assert ctx.download(loss, 1)[0] == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
+        close(ctx.download(dw_, (c, k)), ref["dw"])
+        close(ctx.download(db_, c), ref["db"])
+        np.testing.assert_allclose(ctx.download(gcb, c_conv), gcb_ref, rtol=RTOL, atol=RTOL * float(np.abs(gcb_ref).max()) + 1e-9)
+        np.testing.assert_array_equal(ctx.download(tick, 4, np.int32)[:2], [5 + step, 0])      # ticked once, arrival counter back at 0
+        if step == 0:      # one Adam step from zero moments at t = 5 (the oracle helper starts from m = v = 0)
+            for name, p0, g, dev in (("w", w0, np.asarray(ref["dw"]).reshape(c, k), wd_), ("b", b0, np.asarray(ref["db"]), bd_), ("cb", cb0, gcb_ref, cbd_)):
+                p_ref, m_ref, _ = _adam_ref(O, p0.reshape(-1), g.reshape(-1).astype(np.float32), lr, 5)
+                np.testing.assert_allclose(ctx.download(dev, p0.size), p_ref, rtol=RTOL, atol=lr * 2e-2, err_msg=name)
+                np.testing.assert_allclose(ctx.download(mom[name][0], p0.size), m_ref, rtol=1e-3, atol=1e-7, err_msg=name)
+        # the second launch runs on the updated parameters
+        w_ref, b_ref = ctx.download(wd_, (c, k)), ctx.download(bd_, c)
+
+
 def test_head_limits_are_errors(ctx):
     from taper_amd._lib import TaperError
     x = ctx.zeros(64 * 300)
