@@ -345,6 +345,13 @@ int th_conv3x3_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float 
 int th_conv3x3_pool2_supported(int c_in, int h, int w, int c_out, int pad);
 int th_conv3x3_pool2_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y_pooled,
                          int n, int c_in, int h, int w, int c_out, int pad, int relu);
+/* Conv2dReLU(3x3, stride 1) -> GLOBAL average pool (tensor.rs:1221-1285 + 1524-1660 with kernel = the whole plane, nn.rs:670-686) as ONE
+ * launch of the image-resident kernel: d_y_mean[n][c_out] = plane means of relu(conv + bias), d_cnt[n][c_out] (nullable) = how many
+ * outputs of the plane are > 0 -- all a bias-only conv's backward needs of the map (th_bias_grad_counts_adam); the map itself is
+ * neither written nor re-read.  Same bits as th_conv3x3_fwd + th_avgpool2d_global_fwd_counts.  Taper weight layout. */
+int th_conv3x3_gap_supported(int n, int c_in, int h, int w, int c_out, int pad);
+int th_conv3x3_gap_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y_mean, float *d_cnt,
+                       int n, int c_in, int h, int w, int c_out, int pad, int relu);
 /* Test hook: launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity
  * tests assert which kernel instance a shape takes): out6 = {16-channel tiles per workgroup (1/2/4), 1 if the
  * operands are staged by LDS-DMA (2: the image-resident kernel), waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */

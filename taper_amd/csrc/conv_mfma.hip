@@ -389,6 +389,8 @@ struct ConvImgArgs {
     int img_t;             // images per unit
     int n_groups, n_co;    // image groups, channel blocks
     int relu;
+    float *gap_cnt;        // gap != 0: per (image, channel) count of outputs > 0, as floats (nullable)
+    int gap;               // POOL instances only: the epilogue is a GLOBAL AVERAGE pool (y = [n][c_out] plane means) instead of the 2x2 max-pool
     const int *goff_tab;   // [512 * IM_PPT] patch element -> byte offset within channel block 0 of the unit's first image (or past-the-end)
     const int *pix_tab;    // [pixel tile slots * 16] pixel -> LDS offset of its window corner
 };
@@ -447,6 +449,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
     const int grp = xcd + 8 * (q8 / a.n_co), cob = q8 % a.n_co;
     if (grp >= a.n_groups) return;
     IMG_STAMP(0);
+    CONV_TL(0);
+    CONV_TL_HW();
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
     const int pg = wave % PG, cj = NW == 4 ? 0 : wave / PG;  // pixel group, first channel tile of this wave
     const int wp = a.w_out + 2, rp = a.h_out + 2;
@@ -569,6 +573,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
     }
 
     IMG_STAMP(3);
+    CONV_TL(1);
     // bias of this lane's channels (co0 + 16 (cj + j) + 4 g4 + e)
     float bv[CTW][4];
 #pragma unroll
@@ -597,6 +602,36 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
                 }
         }
         __syncthreads();
+        if (a.gap) {
+            // Conv2dReLU -> global average pool (tensor.rs:1524-1660 with kernel = plane, nn.rs:670-686): the plane never leaves the CU.
+            // 16 lanes per (channel, image) plane, lane l adds elements l, l + 16, ... and a shuffle tree joins them -- the arithmetic of
+            // avgpool_global16_kernel on the stored map, so the fused form gives the same bits; the count of outputs > 0 per plane is what
+            // the conv's bias gradient needs of the map (th_bias_grad_counts_adam).
+            const int l = t & 15;
+            for (int pl = t >> 4; pl < CO_B * imgs_here; pl += NT / 16) {
+                const int cl = pl / imgs_here, il = pl - cl * imgs_here;
+                const float *row = ep + cl * ep_ld + il * px_img;
+                float sum = 0.f, k = 0.f;
+                for (int i = l; i < px_img; i += 16) {
+                    const float v = row[i];
+                    sum += v;
+                    k += v > 0.f ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    sum += __shfl_down(sum, off, 16);
+                    k += __shfl_down(k, off, 16);
+                }
+                if (l == 0 && co0 + cl < a.c_out) {
+                    const long o = (long)(img0 + il) * a.c_out + co0 + cl;
+                    a.y[o] = sum / (float)px_img;
+                    if (a.gap_cnt) a.gap_cnt[o] = k;
+                }
+            }
+            IMG_STAMP(4);
+            CONV_TL(2);
+            return;
+        }
         const int pw = a.w_out >> 1, np_img = (a.h_out >> 1) * pw, np = imgs_here * np_img;
         const FastDiv d_np(np), d_npi(np_img), d_pw(pw);
         for (int idx = t; idx < CO_B * np; idx += NT) {
@@ -614,6 +649,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
             a.y[((long)(img0 + il) * a.c_out + co0 + cl) * np_img + r2] = m;
         }
         IMG_STAMP(4);
+        CONV_TL(2);
         return;
     }
     const long ochan = (long)px_img;
@@ -636,6 +672,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
             }
     }
     IMG_STAMP(4);
+    CONV_TL(2);
 #endif
 }
 
@@ -643,10 +680,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
 // rounds of units over the 256 CUs x waves per SIMD x (32 P Q + 9 (P + Q) + 4.8 P) cycles per k-step (see the kernel's header);
 // the instance table fixes P to 4 / 7 / 13.
 struct ConvImgPlan { int img_t, ct, tpw, nw, n_groups, n_co; size_t lds; };
-static bool conv_img_plan(int n, int c_in, int h, int w_in, int c_out, int pad, bool pool, ConvImgPlan *out) {
+static bool conv_img_plan(int n, int c_in, int h, int w_in, int c_out, int pad, bool pool, ConvImgPlan *out, bool gap = false) {
     const int h_out = h + 2 * pad - 2, w_out = w_in + 2 * pad - 2;
     if (c_in % MF_CI != 0 || h_out < 1 || w_out < 1) return false;
-    if (pool && ((h_out | w_out) & 1)) return false;
+    if (pool && !gap && ((h_out | w_out) & 1)) return false;
     static const int nw_env = getenv("TAPER_CONV_IMG_NW") ? atoi(getenv("TAPER_CONV_IMG_NW")) : 0;   // tuning probe: force 4 / 8 waves
     double best = -1;
     for (int nw = 4; nw <= 8; nw += 4) {
@@ -725,20 +762,26 @@ int g_conv_img_mode = getenv("TAPER_CONV_IMG") ? atoi(getenv("TAPER_CONV_IMG")) 
 // launch configuration of this thread's most recent matrix-core convolution (th_debug_last_conv_config)
 thread_local int t_last_conv_cfg[6] = {0, 0, 0, 0, 0, 0};
 
+bool conv3x3_gap_supported(int n, int c_in, int h, int w_in, int c_out, int pad) {
+    ConvImgPlan pl{};
+    return c_in >= MF_CI && c_out % 4 == 0 && conv_img_plan(n, c_in, h, w_in, c_out, pad, true, &pl, true);
+}
+
 int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
-                        int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool) {
+                        int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool, float *gap_cnt, bool gap) {
     TH_REQUIRE(w_ld % 4 == 0 && ((uintptr_t)w & 15) == 0, "conv3x3_mfma: weight rows must be 16-byte aligned");
     {
         // launches with at least a unit per two CUs take the image-resident kernel (TAPER_CONV_IMG = 0 / 1: never / whenever it fits)
         const int img_env = g_conv_img_mode;
         ConvImgPlan pl{};
-        if (img_env != 0 && !accum && c_in >= MF_CI && conv_img_plan(n, c_in, h, w_in, c_out, pad, pool, &pl) &&
-            (img_env == 1 || (long)pl.n_groups * pl.n_co >= kNumCU / 2)) {
+        if ((img_env != 0 || gap) && !accum && c_in >= MF_CI && conv_img_plan(n, c_in, h, w_in, c_out, pad, pool, &pl, gap) &&
+            (gap || img_env == 1 || (long)pl.n_groups * pl.n_co >= kNumCU / 2)) {
             ConvImgArgs g{};
             g.x = x; g.w = w; g.bias = bias; g.y = y;
             g.n = n; g.c_in = c_in; g.h = h; g.w_in = w_in; g.c_out = c_out; g.pad = pad;
             g.h_out = h + 2 * pad - 2; g.w_out = w_in + 2 * pad - 2; g.w_ld = w_ld; g.w_cols = w_cols;
             g.img_t = pl.img_t; g.n_groups = pl.n_groups; g.n_co = pl.n_co; g.relu = relu;
+            g.gap = gap ? 1 : 0; g.gap_cnt = gap_cnt;
             {   // staging plans of this geometry: built on device the first time, kept with the ctx
                 const int pgs = pl.nw == 4 ? 4 : (pl.ct == 2 ? 4 : 8), n_goff = 512 * IM_PPT, n_pix = pgs * pl.tpw * 16;
                 const std::array<int, 8> key{h, w_in, pad, c_in, pl.img_t, pgs, pl.tpw, 0};
@@ -792,6 +835,7 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
             return 0;
         }
     }
+    TH_REQUIRE(!gap, "conv3x3 + global average pool: no image-resident plan for this shape (th_conv3x3_gap_supported)");
     ConvMfmaArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.n = n; a.c_in = c_in; a.h = h; a.w_in = w_in; a.c_out = c_out; a.pad = pad;

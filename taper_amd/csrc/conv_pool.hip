@@ -643,8 +643,10 @@ static int conv3x3_launch(th_ctx *ctx, const float *x, const float *w_t, const f
 // conv_mfma.hip: the matrix-core path for C_in >= 8
 bool conv3x3_mfma_supported(int c_in, int h, int w, int pad);
 bool conv3x3_mfma_pool_supported(int c_in, int h, int w, int pad);
+bool conv3x3_gap_supported(int n, int c_in, int h, int w_in, int c_out, int pad);
 int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
-                        int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool = false);
+                        int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool = false, float *gap_cnt = nullptr,
+                        bool gap = false);
 int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
                               int pad, int layout);
 int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout);
@@ -990,6 +992,19 @@ int th_conv3x3_pool2_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const 
     }
     // the taper layout IS the [k][co] slab the kernel stages (tensor.rs:1262)
     return conv3x3_mfma_launch(ctx, d_x, d_w, c_out, c_out, d_bias, d_y_pooled, n, c_in, h, w, c_out, pad, relu, false, true);
+}
+
+int th_conv3x3_gap_supported(int n, int c_in, int h, int w, int c_out, int pad) {
+    return (pad == 0 || pad == 1) && n > 0 && c_in > 0 && c_out > 0 && h + 2 * pad >= 3 && w + 2 * pad >= 3 &&
+           conv3x3_gap_supported(n, c_in, h, w, c_out, pad) ? 1 : 0;
+}
+
+int th_conv3x3_gap_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y_mean, float *d_cnt, int n, int c_in,
+                       int h, int w, int c_out, int pad, int relu) {
+    TH_REQUIRE(ctx && d_x && d_w && d_y_mean && n > 0, "th_conv3x3_gap_fwd: null argument");
+    TH_REQUIRE(th_conv3x3_gap_supported(n, c_in, h, w, c_out, pad) && ((uintptr_t)d_w & 15) == 0,
+               "th_conv3x3_gap_fwd: needs c_in %% 8 == 0, c_out %% 4 == 0, whole images that fit a workgroup's LDS and 16-byte aligned weights");
+    return conv3x3_mfma_launch(ctx, d_x, d_w, c_out, c_out, d_bias, d_y_mean, n, c_in, h, w, c_out, pad, relu, false, true, d_cnt, true);
 }
 
 int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx, int n, int c_in, int h, int w,

@@ -426,6 +426,17 @@ Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
                 continue;
             }
         }
+        if (fuse && i + 1 < n_layers && PoolBiasScope::active()) {
+            // Trainer steps: Conv2dReLU(3x3, stride 1) + global average pool as one launch that never writes the map
+            auto *cv = dynamic_cast<Conv2d *>(layers[i].get());
+            auto *gp = dynamic_cast<AdaptiveAvgPool2d *>(layers[i + 1].get());
+            if (cv && gp && gp->output_size == std::make_pair(1, 1) && cv->fuse_relu && cv->groups == 1 && cv->stride == std::make_pair(1, 1) &&
+                cv->dilation == std::make_pair(1, 1) && x.conv2d_relu_gap_supported(cv->weight, cv->bias, cv->padding)) {
+                x = x.conv2d_relu_gap(cv->weight, cv->bias, cv->padding);
+                ++i;
+                continue;
+            }
+        }
         x = layers[i]->forward(x);
     }
     return x;

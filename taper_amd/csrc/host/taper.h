@@ -157,6 +157,10 @@ class Tensor {
     // when nobody else reads the conv output.  conv2d_relu_maxpool2_supported tells whether the pair qualifies.
     bool conv2d_relu_maxpool2_supported(const Tensor &weight, const Tensor &bias, std::pair<int, int> padding) const;
     Tensor conv2d_relu_maxpool2(const Tensor &weight, const Tensor &bias, std::pair<int, int> padding) const;
+    // ... and Conv2dReLU(3x3, stride 1) -> global average pool (AdaptiveAvgPool2d((1, 1))): one launch writes the [n, c, 1, 1] plane means
+    // and each plane's count of outputs > 0 (the bias gradient's only need, th_bias_grad_counts_adam); the map is never stored
+    bool conv2d_relu_gap_supported(const Tensor &weight, const Tensor &bias, std::pair<int, int> padding) const;
+    Tensor conv2d_relu_gap(const Tensor &weight, const Tensor &bias, std::pair<int, int> padding) const;
     Tensor max_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride /* {0,0} = None */,
                       std::pair<int, int> padding) const;
     Tensor avg_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride, std::pair<int, int> padding) const;

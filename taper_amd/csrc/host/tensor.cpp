@@ -921,6 +921,35 @@ Tensor Tensor::conv2d_relu_maxpool2(const Tensor &w, const Tensor &bias, std::pa
     return out;
 }
 
+bool Tensor::conv2d_relu_gap_supported(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
+    if (full_backward() || shape_.size() != 4 || w.shape_.size() != 4 || w.shape_[2] != 3 || w.shape_[3] != 3) return false;
+    if (w.shape_[1] != shape_[1] || padding.first != padding.second) return false;
+    if (!bias.defined() || bias.shape_ != Shape{w.shape_[0]}) return false;
+    if (((uintptr_t)w.dptr() & 15) != 0) return false;
+    return th_conv3x3_gap_supported((int)shape_[0], (int)shape_[1], (int)shape_[2], (int)shape_[3], (int)w.shape_[0], padding.first) != 0;
+}
+
+Tensor Tensor::conv2d_relu_gap(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
+    // tensor.rs:1221-1285 + nn.rs:433-490 + tensor.rs:1524-1660 (kernel = the plane, nn.rs:670-686)
+    TAPER_ASSERT(conv2d_relu_gap_supported(w, bias, padding), "conv2d_relu_gap: unsupported shapes / mode");
+    const int n = (int)shape_[0], c_in = (int)shape_[1], h = (int)shape_[2], wd = (int)shape_[3], c_out = (int)w.shape_[0];
+    const int pad = padding.first, hw = (h + 2 * pad - 2) * (wd + 2 * pad - 2);
+    Tensor out = empty({(size_t)n, (size_t)c_out, 1, 1});
+    const bool bias_grad = bias.requires_grad_;
+    std::shared_ptr<Buffer> cnt = bias_grad ? Buffer::alloc((size_t)n * c_out) : nullptr;
+    TH(th_conv3x3_gap_fwd(Device::ctx(), dptr(), w.dptr(), bias.dptr(), out.dptr(), cnt ? cnt->d : nullptr, n, c_in, h, wd, c_out, pad, 1));
+    if (bias_grad) {   // faithful mode (Q2): the bias is the pair's only trainable input
+        out.requires_grad_ = true;
+        Tensor b = bias, r = out;
+        Tape::push(out, true, [b, r, cnt, n, c_out, hw]() {
+            if (!r.has_grad()) return;
+            // every element of a plane receives g / hw (tensor.rs:1626-1628) and passes the ReLU mask iff it is > 0: db = sum_n g / hw * count
+            pooled_bias_grad(b, r.grad_dptr(), nullptr, n, c_out, hw, true, cnt->d);
+        });
+    }
+    return out;
+}
+
 Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pair<int, int> p) const {  // tensor.rs:1391-1521
     TAPER_ASSERT(shape_.size() == 4, "Input must be 4D: [N, C, H, W]");
     if (s.first == 0) s = k;  // stride.unwrap_or(kernel_size)

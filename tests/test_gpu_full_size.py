@@ -258,3 +258,45 @@ def test_image_resident_kernel_on_small_and_ragged_shapes(ctx, O, n, c_in, h, w,
 def ctx_supported_pad(c_in, h, w, c_out, pad):
     from taper_amd import hip
     return hip.hip.th_conv3x3_pool2_supported(c_in, h, w, c_out, pad) == 1
+
+
+@pytest.mark.parametrize("n,c_in,h,w,c_out,pad", [(256, 64, 7, 7, 128, 1), (9, 64, 7, 7, 128, 1), (5, 8, 6, 8, 20, 1), (33, 16, 5, 5, 16, 0),
+                                                   (2, 32, 14, 14, 64, 1)])
+def test_conv3x3_relu_global_avgpool_fused(ctx, O, n, c_in, h, w, c_out, pad):
+    """th_conv3x3_gap_fwd (Conv2dReLU -> global average pool in one launch: the reference CNN's conv5 + AdaptiveAvgPool2d((1, 1)),
+    examples/train_mnist_cnn.rs:73-84): plane means and per-plane counts of positive outputs against the oracle's conv2d_relu -> avg_pool2d,
+    and bit-identical to the unfused HIP pair"""
+    from taper_amd import hip
+    assert hip.hip.th_conv3x3_gap_supported(n, c_in, h, w, c_out, pad) == 1
+    rng = np.random.default_rng(n + c_in + h * 3 + c_out)
+    x = rng.uniform(-1, 1, (n, c_in, h, w)).astype(np.float32)
+    bound = np.sqrt(6.0 / (c_in * 9))
+    wt = rng.uniform(-bound, bound, (c_out, c_in, 3, 3)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, c_out).astype(np.float32)
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    ref_map = O.Tensor(x).conv2d_relu(O.Tensor(wt), O.Tensor(b), (1, 1), (pad, pad), (1, 1))
+    ref_mean = ref_map.avg_pool2d((ho, wo), (ho, wo), (0, 0)).data().reshape(n, c_out)
+    ref_cnt = (ref_map.data() > 0).sum(axis=(2, 3)).astype(np.float32)
+    dx, dw, db = ctx.upload(x), ctx.upload(wt), ctx.upload(b)
+    ym, cnt = ctx.empty(n * c_out), ctx.empty(n * c_out)
+    ctx.call("th_conv3x3_gap_fwd", dx, dw, db, ym, cnt, n, c_in, h, w, c_out, pad, 1)
+    cfg = last_conv_config(ctx)
+    assert cfg["dma"] in (2, 3, 4, 5) and cfg["pool"] == 1, cfg
+    got_mean, got_cnt = ctx.download(ym, (n, c_out)), ctx.download(cnt, (n, c_out))
+    np.testing.assert_allclose(got_mean, ref_mean, rtol=RTOL, atol=1e-5)
+    # a count differs from the oracle's only where an output sits within rounding of 0
+    assert np.abs(got_cnt - ref_cnt).max() <= 1 and (got_cnt != ref_cnt).mean() < 0.01
+    # the unfused HIP pair, same kernel family: bit-identical means and counts
+    ctx.call("th_debug_set_conv_img", 1)
+    try:
+        y = ctx.empty(n * c_out * ho * wo)
+        ctx.call("th_conv3x3_fwd", dx, dw, db, y, n, c_in, h, w, c_out, pad, 0, 1)
+    finally:
+        ctx.call("th_debug_set_conv_img", -1)
+    ym2, cnt2 = ctx.empty(n * c_out), ctx.empty(n * c_out)
+    ctx.call("th_avgpool2d_global_fwd_counts", y, ym2, cnt2, n, c_out, ho * wo)
+    np.testing.assert_array_equal(got_cnt, ctx.download(cnt2, (n, c_out)))
+    np.testing.assert_array_equal(got_mean, ctx.download(ym2, (n, c_out)))
+    # without the counts
+    ctx.call("th_conv3x3_gap_fwd", dx, dw, db, ym2, None, n, c_in, h, w, c_out, pad, 1)
+    np.testing.assert_array_equal(got_mean, ctx.download(ym2, (n, c_out)))
