@@ -389,6 +389,7 @@ struct ConvImgArgs {
     int img_t;             // images per unit
     int n_groups, n_co;    // image groups, channel blocks
     int relu;
+    int tile_store;        // plain instances: go through an LDS tile [CO_B][pixels] and store whole planes as float4 (needs px per image % 4 == 0)
     float *gap_cnt;        // gap != 0: per (image, channel) count of outputs > 0, as floats (nullable)
     int gap;               // POOL instances only: the epilogue is a GLOBAL AVERAGE pool (y = [n][c_out] plane means) instead of the 2x2 max-pool
     const int *goff_tab;   // [512 * IM_PPT] patch element -> byte offset within channel block 0 of the unit's first image (or past-the-end)
@@ -632,27 +633,68 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
             CONV_TL(2);
             return;
         }
+        // a thread owns pooled positions q = t, t + NT, ... of the unit (decoded ONCE: image, row, column -> LDS and global offsets) and walks the
+        // CO_B channels over them: 4 LDS reads, 3 compares and a store per output.  (Decoding (channel, image, row, column) per output cost
+        // three float-reciprocal divisions each: 9.0 us of epilogue on the 28x28 layer.)
         const int pw = a.w_out >> 1, np_img = (a.h_out >> 1) * pw, np = imgs_here * np_img;
-        const FastDiv d_np(np), d_npi(np_img), d_pw(pw);
-        for (int idx = t; idx < CO_B * np; idx += NT) {
-            int cl, rem, il, r2, pr, pc;
-            d_np.divmod(idx, cl, rem);
-            d_npi.divmod(rem, il, r2);
+        const FastDiv d_npi(np_img), d_pw(pw);
+        for (int q = t; q < np; q += NT) {
+            int il, r2, pr, pc;
+            d_npi.divmod(q, il, r2);
             d_pw.divmod(r2, pr, pc);
-            if (co0 + cl >= a.c_out) continue;
-            const float *b = ep + cl * ep_ld + il * px_img + 2 * pr * a.w_out + 2 * pc;
-            float m = -INFINITY;                           // strict >: NaN never wins (tensor.rs:1449-1461)
-            m = b[0] > m ? b[0] : m;
-            m = b[1] > m ? b[1] : m;
-            m = b[a.w_out] > m ? b[a.w_out] : m;
-            m = b[a.w_out + 1] > m ? b[a.w_out + 1] : m;
-            a.y[((long)(img0 + il) * a.c_out + co0 + cl) * np_img + r2] = m;
+            const float *b = ep + il * px_img + 2 * pr * a.w_out + 2 * pc;
+            float *yo = a.y + ((long)(img0 + il) * a.c_out + co0) * np_img + r2;
+            const int c_here = min(CO_B, a.c_out - co0);
+#pragma unroll 4
+            for (int cl = 0; cl < c_here; ++cl, b += ep_ld, yo += np_img) {
+                float m = -INFINITY;                       // strict >: NaN never wins (tensor.rs:1449-1461)
+                m = b[0] > m ? b[0] : m;
+                m = b[1] > m ? b[1] : m;
+                m = b[a.w_out] > m ? b[a.w_out] : m;
+                m = b[a.w_out + 1] > m ? b[a.w_out + 1] : m;
+                *yo = m;
+            }
         }
         IMG_STAMP(4);
         CONV_TL(2);
         return;
     }
     const long ochan = (long)px_img;
+    if (a.tile_store) {
+        // bias + ReLU into an LDS tile [CO_B][pixels of the unit] (pitch a multiple of 4 floats + 4: the four row groups of a wave land 16
+        // banks apart), then every (channel, image) plane -- contiguous in the tile and in the NCHW tensor -- leaves as float4: 1 KB per wave
+        // store instead of 64-byte segments per channel (28x28 layer: 25.7 MB left in 10.5 us of epilogue)
+        __syncthreads();
+        const int tp = ((a.img_t * px_img + 3) & ~3) + 4;
+        float *ep = lds;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int p = (pg + PG * i) * 16 + l16;
+            if (p >= m_unit) continue;
+#pragma unroll
+            for (int j = 0; j < CTW; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][e] + bv[j][e];
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    ep[(16 * (cj + j) + 4 * g4 + e) * tp + p] = v;
+                }
+        }
+        __syncthreads();
+        const int q_img = px_img >> 2, q_unit = imgs_here * q_img, c_here = min(CO_B, a.c_out - co0);
+        const FastDiv d_q(q_img);
+        for (int q = t; q < q_unit; q += NT) {             // quad q of the unit's pixels: image il, quad r of its plane
+            int il, r;
+            d_q.divmod(q, il, r);
+            const float *src = ep + il * px_img + 4 * r;
+            float *dst = a.y + ((long)(img0 + il) * a.c_out + co0) * ochan + 4 * r;
+#pragma unroll 4
+            for (int cl = 0; cl < c_here; ++cl, src += tp, dst += ochan) *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+        }
+        IMG_STAMP(4);
+        CONV_TL(2);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int p = (pg + PG * i) * 16 + l16;
@@ -679,7 +721,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
 // (IMG, CT, TPW, NW) of the image-resident kernel for a launch, or false: the 128-pixel kernel keeps it.  A candidate costs
 // rounds of units over the 256 CUs x waves per SIMD x (32 P Q + 9 (P + Q) + 4.8 P) cycles per k-step (see the kernel's header);
 // the instance table fixes P to 4 / 7 / 13.
-struct ConvImgPlan { int img_t, ct, tpw, nw, n_groups, n_co; size_t lds; };
+struct ConvImgPlan { int img_t, ct, tpw, nw, n_groups, n_co; size_t lds; int tile_store; };
 static bool conv_img_plan(int n, int c_in, int h, int w_in, int c_out, int pad, bool pool, ConvImgPlan *out, bool gap = false) {
     const int h_out = h + 2 * pad - 2, w_out = w_in + 2 * pad - 2;
     if (c_in % MF_CI != 0 || h_out < 1 || w_out < 1) return false;
@@ -702,6 +744,12 @@ static bool conv_img_plan(int n, int c_in, int h, int w_in, int c_out, int pad, 
                 if (patch_n > (long)IM_PPT * 512) break;
                 size_t lds = (size_t)2 * ((((size_t)patch_n + 4) & ~(size_t)3) + (size_t)72 * 16 * ct) * sizeof(float);
                 if (pool) lds = std::max(lds, (size_t)16 * ct * ((size_t)px | 1) * sizeof(float));
+                // plain outputs of >= 2 MB with 16-byte aligned planes: through an LDS tile, whole planes as float4
+                static const int tile_env = getenv("TAPER_CONV_TILE_STORE") ? atoi(getenv("TAPER_CONV_TILE_STORE")) : 1;   // tuning probe
+                const size_t tile_lds = (size_t)16 * ct * ((((size_t)px + 3) & ~(size_t)3) + 4) * sizeof(float);
+                const int tile_store = tile_env && !pool && (h_out * w_out) % 4 == 0 && (long)n * c_out * h_out * w_out >= (1L << 19) &&
+                                       std::max(lds, tile_lds) <= (150u << 10);
+                if (tile_store) lds = std::max(lds, tile_lds);
                 if (lds > (150u << 10)) continue;
                 if ((long)img * c_in * h * w_in >= (1L << 28) || (long)9 * c_in * c_out >= (1L << 28)) continue;
                 const int n_groups = ceil_div(n, img), n_co = ceil_div(c_out, 16 * ct);
@@ -710,7 +758,7 @@ static bool conv_img_plan(int n, int c_in, int h, int w_in, int c_out, int pad, 
                 if (units < kNumCU) cost *= 1.0 + 0.5 * (double)(kNumCU - units) / kNumCU;   // idle CUs: prefer the split that fills the chip
                 if (best < 0 || cost < best) {
                     best = cost;
-                    *out = ConvImgPlan{img, ct, tpw, nw, n_groups, n_co, lds};
+                    *out = ConvImgPlan{img, ct, tpw, nw, n_groups, n_co, lds, tile_store};
                 }
             }
         }
@@ -781,7 +829,7 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
             g.n = n; g.c_in = c_in; g.h = h; g.w_in = w_in; g.c_out = c_out; g.pad = pad;
             g.h_out = h + 2 * pad - 2; g.w_out = w_in + 2 * pad - 2; g.w_ld = w_ld; g.w_cols = w_cols;
             g.img_t = pl.img_t; g.n_groups = pl.n_groups; g.n_co = pl.n_co; g.relu = relu;
-            g.gap = gap ? 1 : 0; g.gap_cnt = gap_cnt;
+            g.gap = gap ? 1 : 0; g.gap_cnt = gap_cnt; g.tile_store = pl.tile_store;
             {   // staging plans of this geometry: built on device the first time, kept with the ctx
                 const int pgs = pl.nw == 4 ? 4 : (pl.ct == 2 ? 4 : 8), n_goff = 512 * IM_PPT, n_pix = pgs * pl.tpw * 16;
                 const std::array<int, 8> key{h, w_in, pad, c_in, pl.img_t, pgs, pl.tpw, 0};

@@ -7,4 +7,4 @@ cd $GRAFT_REPO_ROOT/taper_amd/csrc
 OBJS=$(ls _build/*.o | grep -v conv_mfma.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libtaper_hip.so $OBJS /tmp/conv_mfma_prof.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 cd $GRAFT_REPO_ROOT
-for args in "256 32 28 28 32" "256 64 14 14 64"; do echo "== $args $*"; python tools/prof_conv.py $args; done
+for args in "256 32 28 28 32 plain" "256 32 28 28 32 pool" "256 64 14 14 64 pool" "256 32 14 14 64 plain" "256 64 7 7 128 gap"; do echo "== $args $*"; python tools/prof_conv.py $args; done
