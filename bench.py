@@ -280,9 +280,11 @@ def pmc_traffic(workload, kernel):
     files = sorted((ROOT / "profiles").glob("r*_mlp_b64_pmc_traffic.json"))
     if not files:
         return None, None
-    for name, rec in json.loads(files[-1].read_text())["kernels"].items():
-        if kernel.split("<")[0] + "<" in name:
-            return rec["traffic_bytes_per_launch"], f"profiles/{files[-1].name}"
+    kernels = json.loads(files[-1].read_text())["kernels"]
+    for exact in (True, False):      # the same template instance first (the trace of the default run holds other workloads' instances too)
+        for name, rec in kernels.items():
+            if (kernel in name) if exact else (kernel.split("<")[0] + "<" in name):
+                return rec["traffic_bytes_per_launch"], f"profiles/{files[-1].name}"
     return None, None
 
 
