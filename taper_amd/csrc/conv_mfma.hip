@@ -453,7 +453,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
     CONV_TL(0);
     CONV_TL_HW();
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
-    const int pg = wave % PG, cj = NW == 4 ? 0 : wave / PG;  // pixel group, first channel tile of this wave
+    // pixel group, first channel tile of this wave.  Waves w and w + 4 share a SIMD: with two channel tiles the two waves of a pixel group
+    // (the only group that owns a pixel tile more than the others when the tiles do not divide evenly) sit on DIFFERENT SIMDs
+    const int pg = NW == 8 && CT == 2 ? wave >> 1 : wave % PG, cj = NW == 4 ? 0 : (CT == 2 ? wave & 1 : wave / PG);
     const int wp = a.w_out + 2, rp = a.h_out + 2;
     const int img_stride = rp * wp, ci_stride = a.img_t * img_stride, patch_n = MF_CI * ci_stride;
     const int img0 = grp * a.img_t, co0 = cob * CO_B;
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(st + w0 + NT * j), 4, p_goff[j], 0, 0, 0);
         }
     };
+    const bool last_slot = (pg + PG * (TPW - 1)) * 16 < m_unit;     // wave-uniform
     floatx4 acc[TPW][CTW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
@@ -553,11 +556,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3x3_img_kernel(ConvImgArgs a) 
         for (int s = 0; s < KS; ++s) {
             if (s + 1 < KS) TH_IMG_REQ(b1, a1, s + 1)
             __builtin_amdgcn_sched_barrier(0);
-            // (tile slots past the unit's last pixel tile compute on pixel 0 and are never stored: no per-tile branch in the stream)
+            // The LAST tile slot of a wave is skipped (a scalar branch: `wave` is uniform) when it lies past the unit's pixel tiles: 49 tiles
+            // over 8 pixel groups are 7 + 6 x 7 -- one wave has 7, the others 6, so the busiest SIMD issues 13 MFMAs per k-step instead of 14.
+            // (Earlier slots past the end -- ragged last image group -- compute on pixel 0 and are never stored.)
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
+            for (int i = 0; i < TPW - 1; ++i)
 #pragma unroll
                 for (int j = 0; j < CTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[i], acc[i][j], 0, 0, 0);
+            if (last_slot) {
+#pragma unroll
+                for (int j = 0; j < CTW; ++j) acc[TPW - 1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[TPW - 1], acc[TPW - 1][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < KS) {
 #pragma unroll
