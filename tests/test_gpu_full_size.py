@@ -263,6 +263,15 @@ def ctx_supported_pad(c_in, h, w, c_out, pad):
 @pytest.mark.parametrize("n,c_in,h,w,c_out,pad", [(256, 64, 7, 7, 128, 1), (9, 64, 7, 7, 128, 1), (5, 8, 6, 8, 20, 1), (33, 16, 5, 5, 16, 0),
                                                    (2, 32, 14, 14, 64, 1)])
 def test_conv3x3_relu_global_avgpool_fused(ctx, O, n, c_in, h, w, c_out, pad):
+    gap_case(ctx, O, n, c_in, h, w, c_out, pad)
+
+
+def ctx_supported_gap(n, c_in, h, w, c_out, pad):
+    from taper_amd import hip
+    return hip.hip.th_conv3x3_gap_supported(n, c_in, h, w, c_out, pad) == 1
+
+
+def gap_case(ctx, O, n, c_in, h, w, c_out, pad):
     """th_conv3x3_gap_fwd (Conv2dReLU -> global average pool in one launch: the reference CNN's conv5 + AdaptiveAvgPool2d((1, 1)),
     examples/train_mnist_cnn.rs:73-84): plane means and per-plane counts of positive outputs against the oracle's conv2d_relu -> avg_pool2d,
     and bit-identical to the unfused HIP pair"""

@@ -53,3 +53,27 @@ def test_pools_random_geometry(ctx, O, n, c, h, w, kh, kw, sh, sw, ph, pw):
 @given(batch=st.integers(1, 400), classes=st.integers(1, 40))
 def test_softmax_xent_random_shapes(ctx, O, batch, classes):
     K.test_softmax_xent(ctx, O, batch, classes)
+
+
+@settings(**{**CFG, "max_examples": 40})
+@given(n=st.integers(1, 40), c8=st.integers(1, 8), h=st.integers(1, 30), w=st.integers(1, 30), c_out=st.integers(1, 70), pad=st.integers(0, 1),
+       relu=st.integers(0, 1))
+def test_image_resident_conv_random_shapes(ctx, O, n, c8, h, w, c_out, pad, relu):
+    """the image-resident matrix-core kernel FORCED (it normally takes only chip-filling launches) onto random geometries: ragged image
+    groups, partial pixel tiles, channel counts that are no multiple of 16, pad 0 -- against the oracle; and, where the shape allows, the
+    fused 2x2 max-pool and global-average-pool epilogues against the unfused results"""
+    from tests import test_gpu_full_size as F
+    if h + 2 * pad < 3 or w + 2 * pad < 3:
+        return
+    c_in = 8 * c8
+    ctx.call("th_debug_set_conv_img", 1)
+    try:
+        K.test_conv3x3_fwd(ctx, O, n, c_in, h, w, c_out, pad, 0, relu)
+        cfg = F.last_conv_config(ctx)
+    finally:
+        ctx.call("th_debug_set_conv_img", -1)
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    if 8 * (ho + 2) * (wo + 2) <= 8192:                       # one image's patch fits the staging plan: the image kernel must have run
+        assert cfg["dma"] in (2, 3, 4, 5), cfg
+    if c_out % 4 == 0 and F.ctx_supported_gap(n, c_in, h, w, c_out, pad):
+        F.gap_case(ctx, O, n, c_in, h, w, c_out, pad)
