@@ -461,3 +461,90 @@ def test_ptq_codecs_match_oracle_bit_for_bit():
         ctx.call("th_dequantize_int8", q, y, m, float(scale), -128, float(mn))
         np.testing.assert_array_equal(ctx.download(y, (m,)).view(np.uint32), OX.dequantize_int8(rq, rs, rzp, rmn).view(np.uint32))
     ctx.close()
+
+
+@gpu
+def test_two_loaders_over_one_dataset_do_not_share_captured_graphs():
+    """(r01 advisor) the captured steps bake in the loader's device index vector: a second DataLoader over the SAME dataset with the same
+    batch size has its own shuffle order and must not replay the first loader's graphs -- graph epochs through alternating loaders
+    equal the eager epochs through the same loaders"""
+    import taper_amd as T
+    rng = np.random.default_rng(12)
+    H = backends.get("hip")
+    spec = backends.nonzero_biases(backends.mlp_baseline(rng), rng)
+    (x, y), _ = _small_problem(rng, 640, 8)
+    out = []
+    for mode in (T.Trainer.EAGER, T.Trainer.GRAPH):
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        tr = T.Trainer(model, opt)
+        ds = T.MNISTDataset.from_host(x, y)
+        la, lb = T.DataLoader(ds, 64, True, seed=1), T.DataLoader(ds, 64, True, seed=2)       # different orders
+        losses = [tr.run_epoch(l, mode)["losses"] for l in (la, lb, la, lb)]
+        out.append((np.concatenate(losses), [p.data() for p in model.parameters()]))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=3e-4, atol=1e-5)
+    assert not np.allclose(out[0][0][:10], out[0][0][10:20])          # the two loaders really see different batches
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-3 * 5e-2)
+
+
+@gpu
+def test_optimizer_state_load_checks_hyperparameters_and_rerecords(tmp_path):
+    """(r01 advisor) beta1 / beta2 / eps of a state file must match the optimizer; weight decay is a kernel argument by value, so loading a
+    state with another decay re-records the captured steps -- the continuation equals an optimizer built with that decay"""
+    import taper_amd as T
+    rng = np.random.default_rng(13)
+    H = backends.get("hip")
+    spec = backends.nonzero_biases(backends.mlp_baseline(rng), rng)
+    (x, y), _ = _small_problem(rng, 256, 8)
+
+    def make(wd, beta1=None):
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, (beta1, 0.999) if beta1 else None, None, wd)
+        return model, opt, T.Trainer(model, opt), T.DataLoader(T.MNISTDataset.from_host(x, y), 64, False)
+
+    # a run with decay 1e-2 from the start, saved after one epoch
+    m1, o1, t1, l1 = make(1e-2)
+    t1.run_epoch(l1, T.Trainer.GRAPH)
+    ck, st = tmp_path / "m.ckpt", tmp_path / "o.ckpt"
+    t1.save_checkpoint(ck)
+    t1.save_optimizer_state(st)
+    ref = t1.run_epoch(l1, T.Trainer.GRAPH)["losses"]
+    # a trainer built with decay 1e-4 that has already captured its graphs, then loads that state: must continue with 1e-2
+    m2, o2, t2, l2 = make(1e-4)
+    t2.run_epoch(l2, T.Trainer.GRAPH)
+    t2.load_checkpoint(ck)
+    t2.load_optimizer_state(st)
+    got = t2.run_epoch(l2, T.Trainer.GRAPH)["losses"]
+    np.testing.assert_array_equal(got, ref)
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        np.testing.assert_array_equal(a.data(), b.data())
+    # other betas: refused
+    m3, o3, t3, l3 = make(1e-2, beta1=0.8)
+    with pytest.raises(T.TaperError, match="beta1/beta2/eps"):
+        t3.load_optimizer_state(st)
+
+
+@gpu
+def test_second_optimizer_over_the_same_parameters_shares_the_arenas():
+    """(r01 advisor) the reference lets several optimizers hold the same tensors (Adam re-created with another lr): the second one adopts
+    the first one's flat arenas -- both keep stepping the storage every handle points at; a partly overlapping list is refused"""
+    import taper_amd as T
+    rng = np.random.default_rng(14)
+    H = backends.get("hip")
+    spec = backends.nonzero_biases(backends.mlp_baseline(rng), rng)
+    x, y = backends.mnist_like(rng, 64)
+    model = H.sequential(spec)
+    a = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+    w0 = [p.data() for p in model.parameters()]
+    b = T.Adam(model.parameters(), 1e-2, None, None, 0.0)            # re-created optimizer: same list, same order
+    tr_a, tr_b = T.Trainer(model, a), T.Trainer(model, b)
+    tr_a.train_step(T.Tensor(x), T.Tensor(y))
+    w1 = [p.data() for p in model.parameters()]
+    assert all(not np.array_equal(u, v) for u, v in zip(w0, w1))     # the FIRST optimizer still moves the model's storage
+    tr_b.train_step(T.Tensor(x), T.Tensor(y))
+    w2 = [p.data() for p in model.parameters()]
+    assert all(not np.array_equal(u, v) for u, v in zip(w1, w2))     # ... and so does the second
+    assert a.t() == 1 and b.t() == 1                                 # each keeps its own step counter / moments
+    with pytest.raises(T.TaperError, match="another optimizer's flat arena"):
+        T.Adam(model.parameters()[:2] + [T.Tensor(np.zeros(4, np.float32)).requires_grad()], 1e-3)
