@@ -352,6 +352,24 @@ int th_conv3x3_pool2_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const 
 int th_conv3x3_gap_supported(int n, int c_in, int h, int w, int c_out, int pad);
 int th_conv3x3_gap_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y_mean, float *d_cnt,
                        int n, int c_in, int h, int w, int c_out, int pad, int relu);
+/* A run of Conv2dReLU(3x3, stride 1, pad 1) layers with their pools -- the convolutional front of a Sequential
+ * (examples/train_mnist_cnn.rs:35-100; nn.rs:433-490 Conv2dReLU, 622-655 MaxPool2d, 670-686 AdaptiveAvgPool2d) -- as ONE launch: a
+ * workgroup carries one image through every stage with the activations resident in LDS; only the last stage's output is written.
+ * Stage i: d_w taper layout [9 c_in_i][c_out] (tensor.rs:1262), d_bias [c_out], then `post`.  For a bias-only backward (faithful mode,
+ * Q2): intermediate maps are neither written nor available afterwards.  d_y: [n][c_out] plane means when the last stage ends in
+ * TH_CHAIN_GLOBAL_AVG (d_cnt [n][c_out], nullable: outputs > 0 per plane, see th_conv3x3_gap_fwd), else the last stage's (pooled) NCHW map.
+ * Same bits as the layer-by-layer launches at batch >= 128.  th_conv_chain_supported: 0 = no compiled chain for these stages (the
+ * caller launches the layers one by one), else the id of the compiled instance: 1 = 28x28, 1 -> 32, 32 -> 32 + pool, 32 -> 64,
+ * 64 -> 64 + pool, 64 -> 128 + global mean; 2 = 28x28, 1 -> 32 + pool, 32 -> 64 + pool. */
+enum { TH_CHAIN_NONE = 0, TH_CHAIN_MAXPOOL2 = 1, TH_CHAIN_GLOBAL_AVG = 2 };
+typedef struct th_conv_stage {
+    const float *d_w, *d_bias;
+    int c_out;
+    int post; /* TH_CHAIN_* */
+} th_conv_stage;
+int th_conv_chain_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages);
+int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, float *d_cnt, int n,
+                      int c_in, int h, int w);
 /* Test hook: launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity
  * tests assert which kernel instance a shape takes): out6 = {16-channel tiles per workgroup (1/2/4), 1 if the
  * operands are staged by LDS-DMA (2: the image-resident kernel), waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */

@@ -1,0 +1,385 @@
+// conv_chain.hip -- the convolutional front of the two MNIST CNNs (examples/train_mnist_cnn.rs:35-100: Conv2dReLU / MaxPool2d /
+// AdaptiveAvgPool2d rows of a Sequential, nn.rs:433-490, 622-686) as ONE launch: a workgroup owns ONE IMAGE and walks it through every
+// stage with the activations never leaving the CU's LDS.
+//
+// Why: at batch 256 every 3x3 layer is ~14-28 us of matrix-core issue time, and a launch per layer pays, on top of that, its own prologue
+// (staging plans, first stage), epilogue (bias / ReLU / pool, the store burst), launch + drain (~3 us) and the HBM round trip of the map:
+// 7-12 us per layer of a 171 us step, five times.  One image of every layer fits the 160 KB LDS in the padded [channel][rows + 2][cols + 2]
+// form the matrix-core k loop reads (28x28x32: 117 KB; 14x14x64: 70 KB; 7x7x64: 29 KB), 256 images fill the 256 CUs, and with the input
+// resident the k loop needs no staging, no barrier per pass and no LDS-DMA at all: the weight operand of a k-step is ONE dword per lane,
+// loaded from global memory (L2-resident, the same slab for every workgroup) a whole 8-channel pass ahead.
+//
+// Arithmetic = the layer-by-layer kernels (conv_mfma.hip's geometry instances, conv_pool.hip's conv1 kernels): the same k order
+// (pass of 8 channels; k-step s = tap s % 9 of channels 4 (s / 9) + lane group), bias after the sum, ReLU, strict-> pooling maxima,
+// 16-lane plane sums with the same shuffle tree -- the chain's outputs are bit-identical to the layered path's.
+#include "common.h"
+
+namespace th {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH_NT = 512;                                                      // threads per workgroup: 8 waves, two per SIMD
+__host__ __device__ constexpr int ch_cis(int wp) { return wp * wp + ((16 - (wp * wp) % 32) + 32) % 32; }   // channel stride = 16 mod 32: the
+                                                                                // two lane groups of a ds_read_b32 half land 16 banks apart
+__host__ __device__ constexpr int ch_tile_ld(int px) { return px + ((4 - px % 8) + 8) % 8; }               // tile pitch = 4 mod 8 (even: b64 reads)
+
+struct ConvChainArgs {
+    const float *x;            // [n][1][28][28]
+    const float *w[5], *b[5];  // taper layout [9 c_in][c_out] (tensor.rs:1262), bias [c_out]
+    float *y;                  // reference chain: [n][128] plane means; simple chain: [n][64][7][7] pooled map
+    float *cnt;                // reference chain: [n][128] outputs > 0 per plane (nullable)
+    int n;
+};
+
+// ---- one 3x3 / pad 1 layer on the matrix cores: IN [C_IN][CIS] padded planes in LDS -> TPW accumulator tiles per wave -------------------------
+// 8 waves = PG pixel groups x NCT channel tiles (one channel tile per wave): wave (pg, cj) owns pixel tiles pg, pg + PG, ...
+// Waves w and w + 4 share a SIMD: the mappings below give every SIMD one wave of each pixel-tile count.
+template <int S, int C_OUT> struct ChainGeo {
+    static constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, NPT = (PX + 15) / 16, NCT = C_OUT / 16, PG = 8 / NCT, TPW = (NPT + PG - 1) / PG;
+    static_assert(NCT == 2 || NCT == 4 || NCT == 8, "channel tiles per workgroup");
+    __device__ static int pg_of(int wave) { return NCT == 2 ? wave >> 1 : (NCT == 4 ? wave >> 2 : 0); }
+    __device__ static int cj_of(int wave) { return NCT == 2 ? wave & 1 : (NCT == 4 ? wave & 3 : wave); }
+};
+
+template <int S, int C_IN, int C_OUT>
+__device__ __forceinline__ void chain_mfma(const float *in, const float *__restrict__ w, floatx4 (&acc)[ChainGeo<S, C_OUT>::TPW], int wave, int lane) {
+    using G = ChainGeo<S, C_OUT>;
+    constexpr int WP = G::WP, CIS = G::CIS, TPW = G::TPW, PG = G::PG, KS = 18;
+    static_assert(C_IN % 8 == 0, "whole 8-channel passes");
+    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave), cj = G::cj_of(wave);
+    int pix_off[TPW];            // this lane's window corner in each of its tiles (+ its lane group's channel)
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        int p = (pg + PG * i) * 16 + l16;
+        if (p >= G::PX) p = 0;   // slots past the image compute on pixel 0 and are never stored
+        pix_off[i] = (p / S) * WP + p % S + g4 * CIS;
+    }
+    const bool last_slot = (pg + PG * (TPW - 1)) * 16 < G::PX;     // wave-uniform
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // weight operand of (pass cb, k-step s): row (cb + 4 (s / 9) + g4) * 9 + s % 9 of the [9 C_IN][C_OUT] slab, column 16 cj + l16
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * C_IN * C_OUT * 4, 0x00020000);
+    const int w_voff = (g4 * 9 * C_OUT + 16 * cj + l16) * 4;
+    float wc[KS], wn[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wc[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, w_voff, ((4 * (s / 9)) * 9 + s % 9) * C_OUT * 4, 0));
+#pragma unroll 1
+    for (int cb = 0; cb < C_IN; cb += 8) {
+        if (cb + 8 < C_IN) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                wn[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, w_voff, (((cb + 8) + 4 * (s / 9)) * 9 + s % 9) * C_OUT * 4, 0));
+        }
+        const float *pp = in + cb * CIS;
+        float b0[TPW], b1[TPW];
+#define CH_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < TPW; ++i) B[i] = pp[pix_off[i] + (4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
+        CH_REQ(b0, 0)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) CH_REQ(b1, s + 1)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TPW - 1; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s], b0[i], acc[i], 0, 0, 0);
+            if (last_slot) acc[TPW - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s], b0[TPW - 1], acc[TPW - 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) b0[i] = b1[i];
+            }
+        }
+#undef CH_REQ
+        if (cb + 8 < C_IN) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wc[s] = wn[s];
+        }
+    }
+}
+
+// bias of this lane's four channels (16 cj + 4 g4 + e)
+template <int S, int C_OUT>
+__device__ __forceinline__ void chain_bias(const float *__restrict__ bias, float (&bv)[4], int wave, int lane) {
+    const int c0 = 16 * ChainGeo<S, C_OUT>::cj_of(wave) + 4 * (lane >> 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = bias ? bias[c0 + e] : 0.f;
+}
+
+// accumulators (+ bias, ReLU) -> the next layer's padded planes OUT [C_OUT][CIS] (halo already zero)
+template <int S, int C_OUT>
+__device__ __forceinline__ void chain_to_planes(const floatx4 (&acc)[ChainGeo<S, C_OUT>::TPW], const float (&bv)[4], float *out, int wave, int lane) {
+    using G = ChainGeo<S, C_OUT>;
+    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave), cj = G::cj_of(wave);
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i) {
+        const int p = (pg + G::PG * i) * 16 + l16;
+        if (p >= G::PX) continue;
+        float *o = out + (16 * cj + 4 * g4) * G::CIS + (p / S + 1) * G::WP + p % S + 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[i][e] + bv[e];
+            v = v > 0.f ? v : 0.f;
+            o[e * G::CIS] = v;
+        }
+    }
+}
+
+// accumulators (+ bias, ReLU) -> a plain tile T [C_OUT][LD] of the layer's pixels (for the pooling passes)
+template <int S, int C_OUT>
+__device__ __forceinline__ void chain_to_tile(const floatx4 (&acc)[ChainGeo<S, C_OUT>::TPW], const float (&bv)[4], float *tile, int wave, int lane) {
+    using G = ChainGeo<S, C_OUT>;
+    constexpr int LD = ch_tile_ld(G::PX);
+    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave), cj = G::cj_of(wave);
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i) {
+        const int p = (pg + G::PG * i) * 16 + l16;
+        if (p >= G::PX) continue;
+        float *o = tile + (16 * cj + 4 * g4) * LD + p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[i][e] + bv[e];
+            v = v > 0.f ? v : 0.f;
+            o[e * LD] = v;
+        }
+    }
+}
+
+// 2x2 / stride-2 maxima of the tile (strict >: NaN never wins, tensor.rs:1449-1461) -> interior of the next layer's padded planes, or
+// (TO_GLOBAL) the pooled NCHW map of this image.  A thread owns one pooled position and a block of channels.
+template <int S, int C_OUT, bool TO_GLOBAL>
+__device__ __forceinline__ void chain_pool(const float *tile, float *out, int t) {
+    constexpr int LD = ch_tile_ld(S * S), HP = S / 2, NP = HP * HP, WPO = HP + 2, CISO = ch_cis(WPO);
+    constexpr int CHUNKS = (CH_NT / NP >= 8 ? 8 : (CH_NT / NP >= 4 ? 4 : (CH_NT / NP >= 2 ? 2 : 1))), CPC = C_OUT / CHUNKS;
+    static_assert(S % 2 == 0 && NP <= CH_NT && C_OUT % CHUNKS == 0, "pooled plane fits the workgroup");
+    const int q = t % NP, chunk = t / NP;
+    if (chunk >= CHUNKS) return;
+    const int pr = q / HP, pc = q % HP;
+    const float *b = tile + (chunk * CPC) * LD + 2 * pr * S + 2 * pc;
+    float *o = TO_GLOBAL ? out + (chunk * CPC) * NP + q : out + (chunk * CPC) * CISO + (pr + 1) * WPO + pc + 1;
+#pragma unroll 8
+    for (int cl = 0; cl < CPC; ++cl, b += LD, o += TO_GLOBAL ? NP : CISO) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(b), r1 = *reinterpret_cast<const float2 *>(b + S);
+        float m = -INFINITY;
+        m = r0.x > m ? r0.x : m;
+        m = r0.y > m ? r0.y : m;
+        m = r1.x > m ? r1.x : m;
+        m = r1.y > m ? r1.y : m;
+        *o = m;
+    }
+}
+
+__device__ __forceinline__ void chain_zero(float *p, int n4, int t) {   // n4 float4s
+    for (int i = t; i < n4; i += CH_NT) reinterpret_cast<float4 *>(p)[i] = float4{0.f, 0.f, 0.f, 0.f};
+}
+
+// the 28x28 image into its zero-haloed 30x30 LDS plane
+__device__ __forceinline__ void chain_load_image(const float *__restrict__ xi, float *img, int t) {
+    for (int e = t; e < 900; e += CH_NT) {
+        const int r = e / 30 - 1, c = e % 30 - 1;
+        img[e] = (r >= 0 && r < 28 && c >= 0 && c < 28) ? xi[r * 28 + c] : 0.f;
+    }
+}
+
+// conv1 (1 -> C1, K = 9: vector ALUs; conv_pool.hip conv1_kernel's arithmetic) over the padded positions of the 30x30 plane: interior
+// positions get relu(fma chain + bias), halo positions zero -- OUT [C1][CIS(30)] is conv2's resident input.  Weights are uniform: scalar loads.
+template <int C1>
+__device__ __forceinline__ void chain_conv1(const float *img, const float *__restrict__ w, const float *__restrict__ bias, float *out, int t) {
+    constexpr int CIS = ch_cis(30);
+    for (int e = t; e < 900; e += CH_NT) {
+        const int rr = e / 30, cc = e % 30;
+        const bool interior = rr >= 1 && rr <= 28 && cc >= 1 && cc <= 28;
+        float win[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) win[k] = interior ? img[(rr - 1 + k / 3) * 30 + cc - 1 + k % 3] : 0.f;
+        float *o = out + e;
+#pragma unroll 8
+        for (int co = 0; co < C1; ++co, o += CIS) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(w[k * C1 + co], win[k], acc);
+            float v = acc + (bias ? bias[co] : 0.f);
+            v = v > 0.f ? v : 0.f;
+            *o = interior ? v : 0.f;
+        }
+    }
+}
+
+// conv1 + 2x2 max-pool (conv_pool.hip conv1_pool2_kernel's arithmetic) over the padded positions of the pooled 16x16 plane; thread
+// (position, half of the channels)
+template <int C1>
+__device__ __forceinline__ void chain_conv1_pool(const float *img, const float *__restrict__ w, const float *__restrict__ bias, float *out, int t) {
+    constexpr int CIS = ch_cis(16), HALF = C1 / 2;
+    const int e = t & 255, c0 = (t >> 8) * HALF;
+    const int rr = e / 16, cc = e % 16;
+    const bool interior = rr >= 1 && rr <= 14 && cc >= 1 && cc <= 14;
+    float win[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) win[i][j] = interior ? img[(2 * (rr - 1) + i) * 30 + 2 * (cc - 1) + j] : 0.f;
+    float *o = out + c0 * CIS + e;
+#pragma unroll 4
+    for (int co = c0; co < c0 + HALF; ++co, o += CIS) {
+        const float b = bias ? bias[co] : 0.f;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc = fmaf(w[k * C1 + co], win[dy + k / 3][dx + k % 3], acc);
+                float v = acc + b;
+                v = v > 0.f ? v : 0.f;
+                m = v > m ? v : m;
+            }
+        *o = interior ? m : 0.f;
+    }
+}
+
+// ---- the reference CNN's front (examples/train_mnist_cnn.rs:35-62): 1 -> 32, 32 -> 32 + pool, 32 -> 64, 64 -> 64 + pool, 64 -> 128 + global mean ----
+// LDS map (floats); regions reuse each other's space once a barrier has retired their readers:
+//   A1 [32][912] @0        conv2's input           T2 [32][788] @0      conv2's outputs (over A1)    A2 [32][272] @25216  conv3's input
+//   A3 [64][272] @0        conv4's input           T4 [64][196] @17408  conv4's outputs (over A2)    A4 [64][112] @0      conv5's input
+//   T5 [128][52] @7168     conv5's outputs         IMG [900]    @33920
+constexpr int CR_A2 = 32 * ch_tile_ld(784), CR_IMG = CR_A2 + 32 * ch_cis(16), CR_LDS = CR_IMG + 900;
+constexpr int CR_T4 = 64 * ch_cis(16), CR_T5 = 64 * ch_cis(9);
+static_assert(32 * ch_cis(30) <= CR_IMG && CR_T4 + 64 * ch_tile_ld(196) <= CR_LDS && CR_T5 + 128 * ch_tile_ld(49) <= CR_LDS, "LDS map");
+
+__global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChainArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int img = blockIdx.x;
+    float *A1 = lds, *T2 = lds, *A2 = lds + CR_A2, *A3 = lds, *T4 = lds + CR_T4, *A4 = lds, *T5 = lds + CR_T5, *IMG = lds + CR_IMG;
+    float bv[4];
+
+    chain_load_image(a.x + (long)img * 784, IMG, t);
+    __syncthreads();
+    chain_conv1<32>(IMG, a.w[0], a.b[0], A1, t);
+    __syncthreads();
+    {   // conv2 32 -> 32 @28 + pool
+        floatx4 acc[ChainGeo<28, 32>::TPW];
+        chain_bias<28, 32>(a.b[1], bv, wave, lane);
+        chain_mfma<28, 32, 32>(A1, a.w[1], acc, wave, lane);
+        __syncthreads();                                    // every wave is done reading A1
+        chain_to_tile<28, 32>(acc, bv, T2, wave, lane);
+        chain_zero(A2, 32 * ch_cis(16) / 4, t);
+        __syncthreads();
+        chain_pool<28, 32, false>(T2, A2, t);
+        __syncthreads();
+    }
+    {   // conv3 32 -> 64 @14
+        floatx4 acc[ChainGeo<14, 64>::TPW];
+        chain_zero(A3, 64 * ch_cis(16) / 4, t);             // (T2 is dead; A3's interior is written after the k loop's barrier)
+        chain_bias<14, 64>(a.b[2], bv, wave, lane);
+        chain_mfma<14, 32, 64>(A2, a.w[2], acc, wave, lane);
+        __syncthreads();
+        chain_to_planes<14, 64>(acc, bv, A3, wave, lane);
+        __syncthreads();
+    }
+    {   // conv4 64 -> 64 @14 + pool
+        floatx4 acc[ChainGeo<14, 64>::TPW];
+        chain_bias<14, 64>(a.b[3], bv, wave, lane);
+        chain_mfma<14, 64, 64>(A3, a.w[3], acc, wave, lane);
+        __syncthreads();                                    // every wave is done reading A3
+        chain_to_tile<14, 64>(acc, bv, T4, wave, lane);
+        chain_zero(A4, 64 * ch_cis(9) / 4, t);
+        __syncthreads();
+        chain_pool<14, 64, false>(T4, A4, t);
+        __syncthreads();
+    }
+    {   // conv5 64 -> 128 @7 + global average pool
+        floatx4 acc[ChainGeo<7, 128>::TPW];
+        chain_bias<7, 128>(a.b[4], bv, wave, lane);
+        chain_mfma<7, 64, 128>(A4, a.w[4], acc, wave, lane);
+        chain_to_tile<7, 128>(acc, bv, T5, wave, lane);     // (T5 does not overlap A4)
+        __syncthreads();
+        // 16 lanes per channel plane, lane l adds elements l, l + 16, ... and a shuffle tree joins them: avgpool_global16_kernel's arithmetic
+        constexpr int LD = ch_tile_ld(49);
+        const int l = t & 15;
+        for (int c = t >> 4; c < 128; c += CH_NT / 16) {
+            const float *row = T5 + c * LD;
+            float sum = 0.f, k = 0.f;
+            for (int i = l; i < 49; i += 16) {
+                const float v = row[i];
+                sum += v;
+                k += v > 0.f ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                sum += __shfl_down(sum, off, 16);
+                k += __shfl_down(k, off, 16);
+            }
+            if (l == 0) {
+                a.y[(long)img * 128 + c] = sum / 49.0f;
+                if (a.cnt) a.cnt[(long)img * 128 + c] = k;
+            }
+        }
+    }
+#endif
+}
+
+// ---- the simple CNN's front (examples/train_mnist_cnn.rs:64-100): 1 -> 32 + pool, 32 -> 64 + pool -> [64][7][7] ----
+//   A [32][272] @0   conv2's input      T [64][196] @8704   conv2's outputs      IMG [900] @21248
+constexpr int CS_T = 32 * ch_cis(16), CS_IMG = CS_T + 64 * ch_tile_ld(196), CS_LDS = CS_IMG + 900;
+
+__global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int img = blockIdx.x;
+    float *A = lds, *T = lds + CS_T, *IMG = lds + CS_IMG;
+    float bv[4];
+    chain_load_image(a.x + (long)img * 784, IMG, t);
+    __syncthreads();
+    chain_conv1_pool<32>(IMG, a.w[0], a.b[0], A, t);
+    __syncthreads();
+    floatx4 acc[ChainGeo<14, 64>::TPW];
+    chain_bias<14, 64>(a.b[1], bv, wave, lane);
+    chain_mfma<14, 32, 64>(A, a.w[1], acc, wave, lane);
+    chain_to_tile<14, 64>(acc, bv, T, wave, lane);          // (T does not overlap A)
+    __syncthreads();
+    chain_pool<14, 64, true>(T, a.y + (long)img * 64 * 49, t);
+#endif
+}
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" {
+
+// 1: reference front (5 stages, ends in a global average pool), 2: simple front (2 stages, ends in a max-pool), 0: no compiled chain
+int th_conv_chain_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages) {
+    if (!stages || c_in != 1 || h != 28 || w != 28) return 0;
+    for (int i = 0; i < n_stages; ++i)
+        if (!stages[i].d_w || !stages[i].d_bias) return 0;
+    auto is = [&](int i, int c_out, int post) { return stages[i].c_out == c_out && stages[i].post == post; };
+    if (n_stages == 5 && is(0, 32, TH_CHAIN_NONE) && is(1, 32, TH_CHAIN_MAXPOOL2) && is(2, 64, TH_CHAIN_NONE) && is(3, 64, TH_CHAIN_MAXPOOL2) &&
+        is(4, 128, TH_CHAIN_GLOBAL_AVG))
+        return 1;
+    if (n_stages == 2 && is(0, 32, TH_CHAIN_MAXPOOL2) && is(1, 64, TH_CHAIN_MAXPOOL2)) return 2;
+    return 0;
+}
+
+int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, float *d_cnt, int n, int c_in,
+                      int h, int w) {
+    TH_REQUIRE(ctx && d_x && d_y && stages && n > 0, "th_conv_chain_fwd: null argument");
+    const int kind = th_conv_chain_supported(c_in, h, w, stages, n_stages);
+    TH_REQUIRE(kind != 0, "th_conv_chain_fwd: no compiled chain for these stages (th_conv_chain_supported)");
+    ConvChainArgs a{};
+    a.x = d_x; a.y = d_y; a.cnt = d_cnt; a.n = n;
+    for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
+    if (kind == 1) {
+        const int lds = CR_LDS * (int)sizeof(float);
+        (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(conv_chain_reference_kernel, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+    } else {
+        const int lds = CS_LDS * (int)sizeof(float);
+        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(conv_chain_simple_kernel, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+    }
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -55,6 +55,7 @@ struct SmallArgs {
     long a_rs, a_cs, b_rs, b_cs;
     int kslice, a_vec, b_vec;
     Epilogue ep;
+    int xcd_blocks = 0;   // sgemm_small16_tick only: 8 x 4 tiles handed out as one 2 x 2 block per XCD
 };
 
 template <bool A_KC, bool B_KC, int NW, bool MASKED>
@@ -190,7 +191,15 @@ template <bool A_KC, bool B_KC, int NW>
 __global__ __launch_bounds__(64 * NW) void sgemm_small16_tick(SmallArgs p, AdamSlices x, int32_t *tick) {
     __shared__ float red[NW][64][4];
     if (blockIdx.y + 1 < gridDim.y) {
-        small16_body<A_KC, B_KC, NW, false>(p, blockIdx.y, blockIdx.x, 0, red);
+        int tm = blockIdx.y, tn = blockIdx.x;
+        if (p.xcd_blocks) {
+            // 8 x 4 tiles (the MNIST MLP's layer 1 at batch 64): block b runs on XCD b % 8; give every XCD a 2 x 2 block of tiles instead of
+            // one column of 4, so its L2 fetches 2 row tiles of X and 2 of W (200 KB) instead of all of X and 1 of W (250 KB)
+            const int b = blockIdx.x + gridDim.x * blockIdx.y, q = b & 7, j = b >> 3;
+            tm = 2 * (q >> 2) + (j >> 1);
+            tn = 2 * (q & 3) + (j & 1);
+        }
+        small16_body<A_KC, B_KC, NW, false>(p, tm, tn, 0, red);
         return;
     }
     if (blockIdx.x == 0) adam_slices_then_tick(x, tick);
@@ -757,6 +766,8 @@ int th_linear_fwd_ex(th_ctx *ctx, const float *d_x, const float *d_w, const floa
         p.b_vec = aligned16(d_w) && (k % 4 == 0);
         const AdamSlices x = make_adam_slices(extra, n_extra);
         const dim3 grid(ceil_div(n, 16), ceil_div(m, 16) + 1, 1);
+        static const int xcd_map = [] { const char *e = std::getenv("TAPER_K1_XCD_MAP"); return e ? atoi(e) : 1; }();
+        p.xcd_blocks = xcd_map && grid.x == 8 && grid.y == 5;
         if (tiles < 256 && k >= 256) hipLaunchKernelGGL((sgemm_small16_tick<true, true, 16>), grid, dim3(1024), 0, ctx->stream, p, x, d_tick);
         else hipLaunchKernelGGL((sgemm_small16_tick<true, true, 4>), grid, dim3(256), 0, ctx->stream, p, x, d_tick);
         TH_LAUNCH_CHECK();

@@ -400,6 +400,12 @@ Tensor AdaptiveAvgPool2d::forward(const Tensor &x) const {  // nn.rs:670-686
     return x.avg_pool2d({kh, kw}, {kh, kw}, {0, 0});
 }
 
+// TAPER_CONV_CHAIN=0: Trainer steps launch the convolutional front layer by layer (measurement probe; default: one launch where compiled)
+static bool chain_fuse() {
+    static const bool on = [] { const char *e = std::getenv("TAPER_CONV_CHAIN"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 Tensor Sequential::forward(const Tensor &input) const { return forward_prefix(input, layers.size()); }  // nn.rs:149-151
 
 Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
@@ -410,6 +416,36 @@ Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
             if (lin && dynamic_cast<ReLU *>(layers[i + 1].get())) {
                 x = lin->forward_fused_relu(x);  // Linear + ReLU: one kernel, one tape node
                 ++i;
+                continue;
+            }
+        }
+        if (fuse && chain_fuse() && i + 1 < n_layers && PoolBiasScope::active() && x.shape().size() == 4 && x.shape()[1] == 1) {
+            // Trainer steps: the whole run of Conv2dReLU(3x3, stride 1, pad 1) [+ MaxPool2d(2) | + global average pool] rows in front of the
+            // classifier as ONE launch, when an instance is compiled for it (th_conv_chain_supported): the maps never leave the CU
+            std::vector<ConvStage> stages;
+            size_t j = i;
+            while (j < n_layers) {
+                auto *cv = dynamic_cast<Conv2d *>(layers[j].get());
+                if (!(cv && cv->fuse_relu && cv->groups == 1 && cv->stride == std::make_pair(1, 1) && cv->dilation == std::make_pair(1, 1) &&
+                      cv->padding == std::make_pair(1, 1) && cv->bias.defined()))
+                    break;
+                int post = TH_CHAIN_NONE;
+                if (j + 1 < n_layers) {
+                    auto *mp = dynamic_cast<MaxPool2d *>(layers[j + 1].get());
+                    auto *gp = dynamic_cast<AdaptiveAvgPool2d *>(layers[j + 1].get());
+                    if (mp && mp->kernel == std::make_pair(2, 2) && (mp->stride == std::make_pair(0, 0) || mp->stride == std::make_pair(2, 2)) &&
+                        mp->padding == std::make_pair(0, 0))
+                        post = TH_CHAIN_MAXPOOL2;
+                    else if (gp && gp->output_size == std::make_pair(1, 1))
+                        post = TH_CHAIN_GLOBAL_AVG;
+                }
+                stages.push_back({cv->weight, cv->bias, post});
+                j += post == TH_CHAIN_NONE ? 1 : 2;
+                if (post == TH_CHAIN_GLOBAL_AVG) break;
+            }
+            if (stages.size() >= 2 && stages.back().post != TH_CHAIN_NONE && x.conv_chain_supported(stages)) {
+                x = x.conv_chain(stages);
+                i = j - 1;
                 continue;
             }
         }

@@ -90,6 +90,7 @@ struct GradSlot {
     bool colsum_done = false;                // ... and did
 };
 
+struct ConvStage;   // one Conv2dReLU row of a conv chain (below)
 class Tensor {
    public:
     Tensor() = default;
@@ -161,6 +162,11 @@ class Tensor {
     // and each plane's count of outputs > 0 (the bias gradient's only need, th_bias_grad_counts_adam); the map is never stored
     bool conv2d_relu_gap_supported(const Tensor &weight, const Tensor &bias, std::pair<int, int> padding) const;
     Tensor conv2d_relu_gap(const Tensor &weight, const Tensor &bias, std::pair<int, int> padding) const;
+    // A whole run of Conv2dReLU(3x3, stride 1, pad 1) layers with their pools as ONE launch (th_conv_chain_fwd: one image per workgroup, the
+    // maps stay in LDS).  Trainer-internal like the pair fusions above (faithful mode, Q2: only the LAST conv's bias ever receives a
+    // gradient -- no conv hands one to its input -- and it is taken from the chain's output).  post: TH_CHAIN_* of include/taper_hip.h.
+    int conv_chain_supported(const std::vector<ConvStage> &stages) const;   // 0, or the compiled instance's id
+    Tensor conv_chain(const std::vector<ConvStage> &stages) const;
     Tensor max_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride /* {0,0} = None */,
                       std::pair<int, int> padding) const;
     Tensor avg_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride, std::pair<int, int> padding) const;
@@ -175,6 +181,11 @@ class Tensor {
     std::shared_ptr<GradSlot> grad_;
     bool requires_grad_ = false;
     std::shared_ptr<size_t> tape_node_;
+};
+
+struct ConvStage {   // Tensor::conv_chain: weight [c_out, c_in, 3, 3], bias [c_out], then TH_CHAIN_NONE / _MAXPOOL2 / _GLOBAL_AVG
+    Tensor weight, bias;
+    int post;
 };
 
 // ---- tape (src/tape.rs) ----------------------------------------------------

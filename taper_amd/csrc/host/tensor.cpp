@@ -867,23 +867,10 @@ static void pooled_bias_grad(const Tensor &bias, const float *dy, const float *m
     else TH(th_bias_grad_nchw_masked(ctx, dy, mask_y, db, n, c, hw, none ? 0 : 1));
 }
 
-bool Tensor::conv2d_relu_maxpool2_supported(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
-    if (full_backward() || shape_.size() != 4 || w.shape_.size() != 4 || w.shape_[2] != 3 || w.shape_[3] != 3) return false;
-    if (w.shape_[1] != shape_[1] || padding.first != padding.second) return false;
-    if (bias.defined() && bias.shape_ != Shape{w.shape_[0]}) return false;
-    if (((uintptr_t)w.dptr() & 15) != 0) return false;
-    return th_conv3x3_pool2_supported((int)shape_[1], (int)shape_[2], (int)shape_[3], (int)w.shape_[0], padding.first) != 0;
-}
-
-Tensor Tensor::conv2d_relu_maxpool2(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
-    // tensor.rs:1221-1285 + nn.rs:433-490 + tensor.rs:1391-1470 (k = s = 2, p = 0), values only
-    TAPER_ASSERT(conv2d_relu_maxpool2_supported(w, bias, padding), "conv2d_relu_maxpool2: unsupported shapes / mode");
-    const int n = (int)shape_[0], c_in = (int)shape_[1], h = (int)shape_[2], wd = (int)shape_[3], c_out = (int)w.shape_[0];
-    const int pad = padding.first, hp = (h + 2 * pad - 2) / 2, wp = (wd + 2 * pad - 2) / 2;
-    Tensor out = empty({(size_t)n, (size_t)c_out, (size_t)hp, (size_t)wp});
-    TH(th_conv3x3_pool2_fwd(Device::ctx(), dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, out.dptr(), n, c_in, h, wd, c_out,
-                            pad, 1));
-    if (bias.defined() && bias.requires_grad_) {   // faithful mode (Q2): the bias is the pair's only trainable input
+// tape node of a bias-only Conv2dReLU -> MaxPool2d(2) whose pooled output is `out` (faithful mode, Q2: the bias is the only trainable input)
+static void push_pooled_conv_bias_node(Tensor &out, const Tensor &bias, int n, int c_out, int hp, int wp) {
+    if (!(bias.defined() && bias.requires_grad_)) return;
+    {
         out.requires_grad_ = true;
         // inside a Trainer step (one consumer per tensor) the sums of dX * [x > 0] per column are all this node needs of its gradient
         out.grad_->wants_colsum = PoolBiasScope::active() && !bias.has_grad();
@@ -918,6 +905,38 @@ Tensor Tensor::conv2d_relu_maxpool2(const Tensor &w, const Tensor &bias, std::pa
             pooled_bias_grad(b, r.grad_dptr(), r.dptr(), n, c_out, hp * wp, false);
         });
     }
+}
+
+// tape node of a bias-only Conv2dReLU -> global average pool: `out` = plane means, cnt = outputs > 0 per plane
+static void push_gap_conv_bias_node(Tensor &out, const Tensor &bias, const std::shared_ptr<Buffer> &cnt, int n, int c_out, int hw) {
+    {   // faithful mode (Q2): the bias is the pair's only trainable input
+        out.requires_grad_ = true;
+        Tensor b = bias, r = out;
+        Tape::push(out, true, [b, r, cnt, n, c_out, hw]() {
+            if (!r.has_grad()) return;
+            // every element of a plane receives g / hw (tensor.rs:1626-1628) and passes the ReLU mask iff it is > 0: db = sum_n g / hw * count
+            pooled_bias_grad(b, r.grad_dptr(), nullptr, n, c_out, hw, true, cnt->d);
+        });
+    }
+}
+
+bool Tensor::conv2d_relu_maxpool2_supported(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
+    if (full_backward() || shape_.size() != 4 || w.shape_.size() != 4 || w.shape_[2] != 3 || w.shape_[3] != 3) return false;
+    if (w.shape_[1] != shape_[1] || padding.first != padding.second) return false;
+    if (bias.defined() && bias.shape_ != Shape{w.shape_[0]}) return false;
+    if (((uintptr_t)w.dptr() & 15) != 0) return false;
+    return th_conv3x3_pool2_supported((int)shape_[1], (int)shape_[2], (int)shape_[3], (int)w.shape_[0], padding.first) != 0;
+}
+
+Tensor Tensor::conv2d_relu_maxpool2(const Tensor &w, const Tensor &bias, std::pair<int, int> padding) const {
+    // tensor.rs:1221-1285 + nn.rs:433-490 + tensor.rs:1391-1470 (k = s = 2, p = 0), values only
+    TAPER_ASSERT(conv2d_relu_maxpool2_supported(w, bias, padding), "conv2d_relu_maxpool2: unsupported shapes / mode");
+    const int n = (int)shape_[0], c_in = (int)shape_[1], h = (int)shape_[2], wd = (int)shape_[3], c_out = (int)w.shape_[0];
+    const int pad = padding.first, hp = (h + 2 * pad - 2) / 2, wp = (wd + 2 * pad - 2) / 2;
+    Tensor out = empty({(size_t)n, (size_t)c_out, (size_t)hp, (size_t)wp});
+    TH(th_conv3x3_pool2_fwd(Device::ctx(), dptr(), w.dptr(), bias.defined() ? bias.dptr() : nullptr, out.dptr(), n, c_in, h, wd, c_out,
+                            pad, 1));
+    push_pooled_conv_bias_node(out, bias, n, c_out, hp, wp);
     return out;
 }
 
@@ -938,15 +957,55 @@ Tensor Tensor::conv2d_relu_gap(const Tensor &w, const Tensor &bias, std::pair<in
     const bool bias_grad = bias.requires_grad_;
     std::shared_ptr<Buffer> cnt = bias_grad ? Buffer::alloc((size_t)n * c_out) : nullptr;
     TH(th_conv3x3_gap_fwd(Device::ctx(), dptr(), w.dptr(), bias.dptr(), out.dptr(), cnt ? cnt->d : nullptr, n, c_in, h, wd, c_out, pad, 1));
-    if (bias_grad) {   // faithful mode (Q2): the bias is the pair's only trainable input
-        out.requires_grad_ = true;
-        Tensor b = bias, r = out;
-        Tape::push(out, true, [b, r, cnt, n, c_out, hw]() {
-            if (!r.has_grad()) return;
-            // every element of a plane receives g / hw (tensor.rs:1626-1628) and passes the ReLU mask iff it is > 0: db = sum_n g / hw * count
-            pooled_bias_grad(b, r.grad_dptr(), nullptr, n, c_out, hw, true, cnt->d);
-        });
+    if (bias_grad) push_gap_conv_bias_node(out, bias, cnt, n, c_out, hw);
+    return out;
+}
+
+static bool conv_chain_describe(const Tensor &x, const std::vector<ConvStage> &stages, std::vector<th_conv_stage> *out) {
+    if (full_backward() || x.shape().size() != 4 || stages.empty()) return false;
+    size_t c_in = x.shape()[1];
+    for (const auto &st : stages) {
+        const Shape &ws = st.weight.shape();
+        if (ws.size() != 4 || ws[1] != c_in || ws[2] != 3 || ws[3] != 3) return false;
+        if (!st.bias.defined() || st.bias.shape() != Shape{ws[0]}) return false;
+        out->push_back(th_conv_stage{st.weight.dptr(), st.bias.dptr(), (int)ws[0], st.post});
+        c_in = ws[0];
     }
+    return true;
+}
+
+int Tensor::conv_chain_supported(const std::vector<ConvStage> &stages) const {
+    std::vector<th_conv_stage> d;
+    if (!conv_chain_describe(*this, stages, &d)) return 0;
+    return th_conv_chain_supported((int)shape_[1], (int)shape_[2], (int)shape_[3], d.data(), (int)d.size());
+}
+
+Tensor Tensor::conv_chain(const std::vector<ConvStage> &stages) const {
+    // nn.rs:149-151 over Conv2dReLU (433-490) / MaxPool2d (508-549) / AdaptiveAvgPool2d (655-697) rows; tensor.rs:1221-1285, 1391-1470, 1524-1660
+    std::vector<th_conv_stage> d;
+    TAPER_ASSERT(conv_chain_describe(*this, stages, &d) &&
+                     th_conv_chain_supported((int)shape_[1], (int)shape_[2], (int)shape_[3], d.data(), (int)d.size()) != 0,
+                 "conv_chain: unsupported stages / mode");
+    const int n = (int)shape_[0];
+    int h = (int)shape_[2], w = (int)shape_[3];
+    for (const auto &st : stages) {
+        if (st.post == TH_CHAIN_MAXPOOL2) { h /= 2; w /= 2; }
+    }
+    const ConvStage &last = stages.back();
+    const int c_out = (int)last.weight.shape()[0];
+    if (last.post == TH_CHAIN_GLOBAL_AVG) {
+        Tensor out = empty({(size_t)n, (size_t)c_out, 1, 1});
+        const bool bias_grad = last.bias.requires_grad_;
+        std::shared_ptr<Buffer> cnt = bias_grad ? Buffer::alloc((size_t)n * c_out) : nullptr;
+        TH(th_conv_chain_fwd(Device::ctx(), dptr(), d.data(), (int)d.size(), out.dptr(), cnt ? cnt->d : nullptr, n, (int)shape_[1], (int)shape_[2],
+                             (int)shape_[3]));
+        if (bias_grad) push_gap_conv_bias_node(out, last.bias, cnt, n, c_out, h * w);
+        return out;
+    }
+    TAPER_ASSERT(last.post == TH_CHAIN_MAXPOOL2, "conv_chain: the last stage must end in a pool");
+    Tensor out = empty({(size_t)n, (size_t)c_out, (size_t)h, (size_t)w});
+    TH(th_conv_chain_fwd(Device::ctx(), dptr(), d.data(), (int)d.size(), out.dptr(), nullptr, n, (int)shape_[1], (int)shape_[2], (int)shape_[3]));
+    push_pooled_conv_bias_node(out, last.bias, n, c_out, h, w);
     return out;
 }
 

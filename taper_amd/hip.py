@@ -28,6 +28,22 @@ class WideFuse(C.Structure):
     _fields_ = [("w", AdamFuse), ("b", AdamFuse), ("conv_b", AdamFuse), ("d_conv_gb", C.c_void_p), ("conv_c", C.c_int), ("conv_hw", C.c_int)]
 
 
+class ConvStage(C.Structure):
+    """include/taper_hip.h: th_conv_stage"""
+    _fields_ = [("d_w", C.c_void_p), ("d_bias", C.c_void_p), ("c_out", C.c_int), ("post", C.c_int)]
+
+
+CHAIN_NONE, CHAIN_MAXPOOL2, CHAIN_GLOBAL_AVG = 0, 1, 2
+
+
+def conv_stages(stages):
+    """[(w DevBuf, bias DevBuf, c_out, post), ...] -> (ctypes array of th_conv_stage, count)"""
+    arr = (ConvStage * len(stages))()
+    for i, (w, b, c_out, post) in enumerate(stages):
+        arr[i] = ConvStage(int(w), int(b), int(c_out), int(post))
+    return arr, len(stages)
+
+
 class DevBuf:
     """A device allocation from the ctx pool (freed on garbage collection)."""
 

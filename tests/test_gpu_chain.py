@@ -1,0 +1,143 @@
+"""The convolutional fronts of the two CNNs as ONE launch (th_conv_chain_fwd: a workgroup carries an image through every stage in
+LDS) against the oracle's layer-by-layer tape ops (`conv2d_relu`, `max_pool2d`, global `avg_pool2d`: /root/reference/src/tensor.rs:1221-1285,
+1391-1470, 1524-1660; the model rows of examples/train_mnist_cnn.rs:35-100) and, at batch 256, bit for bit against the layer-by-layer
+HIP launches it replaces."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+REFERENCE = [(1, 32, 0), (32, 32, 1), (32, 64, 0), (64, 64, 1), (64, 128, 2)]      # (c_in, c_out, post): 0 none, 1 max-pool 2x2, 2 global mean
+SIMPLE = [(1, 32, 1), (32, 64, 1)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from taper_amd import hip
+    c = hip.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _params(spec, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for c_in, c_out, _ in spec:
+        bound = np.sqrt(6.0 / (c_in * 9))                                   # nn.rs:219-222
+        out.append((rng.uniform(-bound, bound, (c_out, c_in, 3, 3)).astype(np.float32), rng.uniform(-0.1, 0.1, c_out).astype(np.float32)))
+    return out
+
+
+def _oracle_chain(O, x, spec, params):
+    t = O.Tensor(x)
+    cnt = None
+    for (c_in, c_out, post), (w, b) in zip(spec, params):
+        t = t.conv2d_relu(O.Tensor(w), O.Tensor(b), (1, 1), (1, 1), (1, 1))
+        if post == 1:
+            t = t.max_pool2d((2, 2), (2, 2), (0, 0))
+        elif post == 2:
+            d = t.data()
+            cnt = (d > 0).sum(axis=(2, 3)).astype(np.float32)
+            t = t.avg_pool2d((d.shape[2], d.shape[3]), (d.shape[2], d.shape[3]), (0, 0))
+    return t.data(), cnt
+
+
+def _hip_layered(ctx, x, spec, params):
+    """the launches the chain replaces: th_conv3x3_fwd / th_conv3x3_pool2_fwd / th_conv3x3_gap_fwd, layer by layer"""
+    n, hw = x.shape[0], x.shape[2]
+    cur, cnt = ctx.upload(x), None
+    for (c_in, c_out, post), (w, b) in zip(spec, params):
+        dw, db = ctx.upload(w), ctx.upload(b)
+        if post == 0:
+            y = ctx.empty(n * c_out * hw * hw)
+            ctx.call("th_conv3x3_fwd", cur, dw, db, y, n, c_in, hw, hw, c_out, 1, 0, 1)
+        elif post == 1:
+            y = ctx.empty(n * c_out * (hw // 2) ** 2)
+            ctx.call("th_conv3x3_pool2_fwd", cur, dw, db, y, n, c_in, hw, hw, c_out, 1, 1)
+            hw //= 2
+        else:
+            y, cnt = ctx.empty(n * c_out), ctx.empty(n * c_out)
+            ctx.call("th_conv3x3_gap_fwd", cur, dw, db, y, cnt, n, c_in, hw, hw, c_out, 1, 1)
+            hw = 1
+        cur = y
+    return cur, cnt, hw
+
+
+def _hip_chain(ctx, x, spec, params, want_cnt=True):
+    from taper_amd import hip
+    n = x.shape[0]
+    bufs = [(ctx.upload(w), ctx.upload(b)) for w, b in params]
+    stages, ns = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in zip(bufs, spec)])
+    kind = hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(stages, C.c_void_p), ns)
+    assert kind == (1 if spec is REFERENCE else 2)
+    hw = 28
+    for _, _, post in spec:
+        hw = hw // 2 if post == 1 else (1 if post == 2 else hw)
+    c_last = spec[-1][1]
+    y = ctx.empty(n * c_last * hw * hw)
+    cnt = ctx.empty(n * c_last) if spec[-1][2] == 2 and want_cnt else None
+    ctx.call("th_conv_chain_fwd", ctx.upload(x), C.cast(stages, C.c_void_p), ns, y, cnt, n, 1, 28, 28)
+    ctx.sync()          # (the stage array and the uploads live until the launch has run)
+    return y, cnt, hw, c_last
+
+
+def _images(n, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)
+
+
+@pytest.mark.parametrize("n", [1, 3, 37, 256])
+@pytest.mark.parametrize("name", ["reference", "simple"])
+def test_chain_matches_the_oracle(ctx, O, name, n):
+    spec = REFERENCE if name == "reference" else SIMPLE
+    params = _params(spec, 11 + n)
+    x = _images(n, n)
+    ref, ref_cnt = _oracle_chain(O, x, spec, params)
+    y, cnt, hw, c_last = _hip_chain(ctx, x, spec, params)
+    got = ctx.download(y, (n, c_last, hw, hw))
+    np.testing.assert_allclose(got, ref.reshape(got.shape), rtol=RTOL, atol=1e-5)
+    if cnt is not None:
+        got_cnt = ctx.download(cnt, (n, c_last))
+        # a count can differ where a pre-activation sits within rounding of zero: allow a handful of planes to be off by a few elements
+        off = np.abs(got_cnt - ref_cnt)
+        assert off.max() <= 2 and (off > 0).mean() < 0.02, (off.max(), (off > 0).mean())
+
+
+@pytest.mark.parametrize("name", ["reference", "simple"])
+def test_chain_is_bit_identical_to_the_layered_launches_at_batch_256(ctx, name):
+    spec = REFERENCE if name == "reference" else SIMPLE
+    n = 256
+    params = _params(spec, 5)
+    x = _images(n, 99)
+    ly, lcnt, hw = _hip_layered(ctx, x, spec, params)
+    y, cnt, hw2, c_last = _hip_chain(ctx, x, spec, params)
+    assert hw == hw2
+    np.testing.assert_array_equal(ctx.download(y, (n, c_last, hw, hw)), ctx.download(ly, (n, c_last, hw, hw)))
+    if cnt is not None:
+        np.testing.assert_array_equal(ctx.download(cnt, (n, c_last)), ctx.download(lcnt, (n, c_last)))
+
+
+def test_chain_without_counts_and_unsupported_stages(ctx):
+    from taper_amd import hip
+    params = _params(REFERENCE, 1)
+    x = _images(2, 3)
+    y, cnt, hw, c_last = _hip_chain(ctx, x, REFERENCE, params, want_cnt=False)
+    y2, _, _, _ = _hip_chain(ctx, x, REFERENCE, params, want_cnt=True)
+    np.testing.assert_array_equal(ctx.download(y, (2, c_last)), ctx.download(y2, (2, c_last)))
+    # another channel count: no compiled chain -- the caller launches the layers one by one
+    bufs = [(ctx.upload(w), ctx.upload(b)) for w, b in params]
+    st, ns = hip.conv_stages([(bufs[0][0], bufs[0][1], 16, 1), (bufs[1][0], bufs[1][1], 64, 1)])
+    assert hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(st, C.c_void_p), ns) == 0
+    st, ns = hip.conv_stages([(bufs[0][0], bufs[0][1], 32, 1), (bufs[1][0], bufs[1][1], 64, 1)])
+    assert hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(st, C.c_void_p), ns) == 2
+    assert hip.hip.th_conv_chain_supported(1, 32, 32, C.cast(st, C.c_void_p), ns) == 0
+    assert hip.hip.th_conv_chain_supported(3, 28, 28, C.cast(st, C.c_void_p), ns) == 0
