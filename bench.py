@@ -425,6 +425,41 @@ def conv_layer_kernels(ctx, layers, reps=60):
     return out
 
 
+CNN_CHAINS = {   # (c_in, c_out, post) per stage -- include/taper_hip.h TH_CHAIN_*: 0 none, 1 max-pool 2x2, 2 global mean
+    "cnn_simple": ("conv_chain_simple_kernel", [(1, 32, 1), (32, 64, 1)]),
+    "cnn_reference": ("conv_chain_reference_kernel", [(1, 32, 0), (32, 32, 1), (32, 64, 0), (64, 64, 1), (64, 128, 2)]),
+}
+
+
+def conv_chain_kernel(ctx, key, n=256, reps=100):
+    """The ONE conv launch the Trainer's captured CNN step issues (th_conv_chain_fwd: every Conv2dReLU / pool row in front of the
+    classifier, one image per workgroup, maps resident in LDS), timed like the layers below.  Algorithmic work = the sum of the
+    layers' 18*C_in*C_out*H*W flop per sample; bytes = the images in, the last stage's output out, the weights once.
+    Bound: fp32 MFMA."""
+    from taper_amd import hip
+    name, spec = CNN_CHAINS[key]
+    rng = np.random.default_rng(0)
+    x = ctx.upload(rng.uniform(0, 1, (n, 1, 28, 28)).astype(np.float32))
+    bufs = [(ctx.upload(rng.uniform(-0.1, 0.1, (co, ci, 3, 3)).astype(np.float32)), ctx.upload(rng.uniform(-0.1, 0.1, co).astype(np.float32)))
+            for ci, co, _ in spec]
+    stages, ns = hip.conv_stages([(w, b, co, post) for (w, b), (_, co, post) in zip(bufs, spec)])
+    sp = C.cast(stages, C.c_void_p)
+    hw, flops, wbytes = 28, 0.0, 0.0
+    for ci, co, post in spec:
+        flops += 18.0 * ci * co * hw * hw * n
+        wbytes += 4.0 * (9 * ci * co + co)
+        hw = hw // 2 if post == 1 else (1 if post == 2 else hw)
+    co_last = spec[-1][1]
+    y, cnt = ctx.empty(n * co_last * hw * hw), ctx.empty(n * co_last)
+    us = _time_launches(ctx, lambda: ctx.call("th_conv_chain_fwd", x, sp, ns, y, cnt, n, 1, 28, 28), reps, warm=10)
+    ctx.sync()
+    nbytes = 4.0 * (n * 784 + n * co_last * hw * hw) + wbytes
+    tf = flops / (us * 1e-6) / 1e12
+    return dict(kernel=name, layer="conv chain: " + ", ".join("%d->%d%s" % (ci, co, ("", "+pool", "+mean")[post]) for ci, co, post in spec),
+                us_per_launch=round(us, 2), alg_flops_per_launch=flops, alg_bytes_per_launch=nbytes, bound="mfma", achieved=round(tf, 2),
+                peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4))
+
+
 CNN_LAYERS = {
     # (layer, batch, C_in, H = W, C_out, fused 2x2 max-pool epilogue) -- the launches the Trainer's captured step issues
     "cnn_simple": [("conv1+pool 1->32 @28", 256, 1, 28, 32, True), ("conv2+pool 32->64 @14", 256, 32, 14, 64, True)],
@@ -543,8 +578,14 @@ def extra_workloads(T, dataset, with_cpu, only=None):
         try:
             rec, key, batch, sample_shape, lr = trainer_workload(T, name, dataset)
             if key in CNN_LAYERS:
-                rec["kernels"] = conv_layer_kernels(ctx, CNN_LAYERS[key])
-                rec["conv_us_per_step"] = round(sum(k["us_per_launch"] for k in rec["kernels"]), 1)
+                # what the captured step launches (one chain kernel), then the layer-by-layer launches it replaced (still the path of
+                # forward() outside a Trainer step, of full_backward mode and of TAPER_CONV_CHAIN=0)
+                chain = os.environ.get("TAPER_CONV_CHAIN", "1") != "0"
+                layers = conv_layer_kernels(ctx, CNN_LAYERS[key])
+                for k in layers:
+                    k["in_step"] = not chain
+                rec["kernels"] = ([dict(conv_chain_kernel(ctx, key), in_step=True)] if chain else []) + layers
+                rec["conv_us_per_step"] = round(sum(k["us_per_launch"] for k in rec["kernels"] if k["in_step"]), 1)
             if with_cpu and key != "mlp_example":
                 try:
                     rec["cpu_baseline"] = cpu_baseline(key, batch, sample_shape, lr, budget_s=7.0)

@@ -23,6 +23,18 @@ __host__ __device__ constexpr int ch_cis(int wp) { return wp * wp + ((16 - (wp *
                                                                                 // two lane groups of a ds_read_b32 half land 16 banks apart
 __host__ __device__ constexpr int ch_tile_ld(int px) { return px + ((4 - px % 8) + 8) % 8; }               // tile pitch = 4 mod 8 (even: b64 reads)
 
+#ifdef TH_PROFILE
+__device__ long long g_chain_prof[32];    // wall clock (100 MHz) at phase boundaries of workgroup 100, then clock64 around conv2's k loop
+#define CH_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 100) g_chain_prof[i] = wall_clock64(); } while (0)
+#define CH_CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 100) g_chain_prof[i] = clock64(); } while (0)
+// per-pass stamps of the 14x14 layers' k loops (conv3: slots 13-16, conv4: 22-29)
+#define CH_PASS(S, C_IN, cb) do { if ((S) == 14) { __builtin_amdgcn_sched_barrier(0); CH_STAMP(((C_IN) == 32 ? 13 : 22) + (cb) / 8); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define CH_PASS(S, C_IN, cb) do { } while (0)
+#define CH_STAMP(i) do { } while (0)
+#define CH_CLK(i) do { } while (0)
+#endif
+
 struct ConvChainArgs {
     const float *x;            // [n][1][28][28]
     const float *w[5], *b[5];  // taper layout [9 c_in][c_out] (tensor.rs:1262), bias [c_out]
@@ -41,12 +53,33 @@ template <int S, int C_OUT> struct ChainGeo {
     __device__ static int cj_of(int wave) { return NCT == 2 ? wave & 1 : (NCT == 4 ? wave & 3 : wave); }
 };
 
+// Barrier for LDS hand-offs only: the weight loads in flight (global memory nobody writes) stay in flight across it -- __syncthreads() would
+// wait for them (its fence covers every address space), exposing a global round trip at each of the chain's 14 barriers.
+__device__ __forceinline__ void chain_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// weight operands of pass cb (8 input channels, 18 k-steps) of a layer's [9 C_IN][C_OUT] slab: k-step s wants row (cb + 4 (s / 9) + g4) * 9 + s % 9,
+// column 16 cj + l16 -- one dword per lane and k-step, requested a pass ahead (the first pass of a layer: before the previous layer's epilogue)
 template <int S, int C_IN, int C_OUT>
-__device__ __forceinline__ void chain_mfma(const float *in, const float *__restrict__ w, floatx4 (&acc)[ChainGeo<S, C_OUT>::TPW], int wave, int lane) {
+__device__ __forceinline__ void chain_weights(const float *__restrict__ w, int cb, float (&wr)[18], int wave, int lane) {
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * C_IN * C_OUT * 4, 0x00020000);
+    const int w_voff = ((lane >> 4) * 9 * C_OUT + 16 * ChainGeo<S, C_OUT>::cj_of(wave) + (lane & 15)) * 4;
+#pragma unroll
+    for (int s = 0; s < 18; ++s)
+        wr[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, w_voff, ((cb + 4 * (s / 9)) * 9 + s % 9) * C_OUT * 4, 0));
+}
+
+// wc: the operands of pass 0, already requested (chain_weights); holds the last pass's on return
+template <int S, int C_IN, int C_OUT>
+__device__ __forceinline__ void chain_mfma(const float *in, const float *__restrict__ w, float (&wc)[18], floatx4 (&acc)[ChainGeo<S, C_OUT>::TPW], int wave,
+                                           int lane) {
     using G = ChainGeo<S, C_OUT>;
     constexpr int WP = G::WP, CIS = G::CIS, TPW = G::TPW, PG = G::PG, KS = 18;
     static_assert(C_IN % 8 == 0, "whole 8-channel passes");
-    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave), cj = G::cj_of(wave);
+    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave);
     int pix_off[TPW];            // this lane's window corner in each of its tiles (+ its lane group's channel)
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
@@ -57,19 +90,11 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
     const bool last_slot = (pg + PG * (TPW - 1)) * 16 < G::PX;     // wave-uniform
 #pragma unroll
     for (int i = 0; i < TPW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    // weight operand of (pass cb, k-step s): row (cb + 4 (s / 9) + g4) * 9 + s % 9 of the [9 C_IN][C_OUT] slab, column 16 cj + l16
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * C_IN * C_OUT * 4, 0x00020000);
-    const int w_voff = (g4 * 9 * C_OUT + 16 * cj + l16) * 4;
-    float wc[KS], wn[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) wc[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, w_voff, ((4 * (s / 9)) * 9 + s % 9) * C_OUT * 4, 0));
+    float wn[KS];
 #pragma unroll 1
     for (int cb = 0; cb < C_IN; cb += 8) {
-        if (cb + 8 < C_IN) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                wn[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, w_voff, (((cb + 8) + 4 * (s / 9)) * 9 + s % 9) * C_OUT * 4, 0));
-        }
+        CH_PASS(S, C_IN, cb);
+        if (cb + 8 < C_IN) chain_weights<S, C_IN, C_OUT>(w, cb + 8, wn, wave, lane);
         const float *pp = in + cb * CIS;
         float b0[TPW], b1[TPW];
 #define CH_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < TPW; ++i) B[i] = pp[pix_off[i] + (4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
@@ -166,10 +191,6 @@ __device__ __forceinline__ void chain_pool(const float *tile, float *out, int t)
     }
 }
 
-__device__ __forceinline__ void chain_zero(float *p, int n4, int t) {   // n4 float4s
-    for (int i = t; i < n4; i += CH_NT) reinterpret_cast<float4 *>(p)[i] = float4{0.f, 0.f, 0.f, 0.f};
-}
-
 // the 28x28 image into its zero-haloed 30x30 LDS plane
 __device__ __forceinline__ void chain_load_image(const float *__restrict__ xi, float *img, int t) {
     for (int e = t; e < 900; e += CH_NT) {
@@ -178,60 +199,53 @@ __device__ __forceinline__ void chain_load_image(const float *__restrict__ xi, f
     }
 }
 
-// conv1 (1 -> C1, K = 9: vector ALUs; conv_pool.hip conv1_kernel's arithmetic) over the padded positions of the 30x30 plane: interior
-// positions get relu(fma chain + bias), halo positions zero -- OUT [C1][CIS(30)] is conv2's resident input.  Weights are uniform: scalar loads.
-template <int C1>
-__device__ __forceinline__ void chain_conv1(const float *img, const float *__restrict__ w, const float *__restrict__ bias, float *out, int t) {
-    constexpr int CIS = ch_cis(30);
-    for (int e = t; e < 900; e += CH_NT) {
-        const int rr = e / 30, cc = e % 30;
-        const bool interior = rr >= 1 && rr <= 28 && cc >= 1 && cc <= 28;
-        float win[9];
+// conv1 (1 -> 32 channels, K = 9) on the matrix cores as well: k = the tap, padded to three k-steps of 4 with zero weights (an fma with a
+// zero weight leaves the chain's value unchanged: the sum is conv_pool.hip conv1_kernel's fmaf chain over taps 0..8, bit for bit).  294 MFMAs
+// per image against 226 K FMAs on the vector ALUs (which would also wait on 320 scalar weight loads): 10.3 -> ~2 us of the chain.
+// IMG = the zero-haloed 30x30 plane; tile mapping = ChainGeo<28, 32> (the epilogues above apply).
+__device__ __forceinline__ void chain_conv1_weights(const float *__restrict__ w, float (&wa)[3], int wave, int lane) {
+    const int l16 = lane & 15, g4 = lane >> 4, cj = ChainGeo<28, 32>::cj_of(wave);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) win[k] = interior ? img[(rr - 1 + k / 3) * 30 + cc - 1 + k % 3] : 0.f;
-        float *o = out + e;
-#pragma unroll 8
-        for (int co = 0; co < C1; ++co, o += CIS) {
-            float acc = 0.f;
+    for (int s = 0; s < 3; ++s) wa[s] = 4 * s + g4 < 9 ? w[(4 * s + g4) * 32 + 16 * cj + l16] : 0.f;
+}
+
+__device__ __forceinline__ void chain_conv1_mfma(const float *img, const float (&wa)[3], floatx4 (&acc)[ChainGeo<28, 32>::TPW], int wave, int lane) {
+    using G = ChainGeo<28, 32>;
+    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave);
+    int toff[3];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc = fmaf(w[k * C1 + co], win[k], acc);
-            float v = acc + (bias ? bias[co] : 0.f);
-            v = v > 0.f ? v : 0.f;
-            *o = interior ? v : 0.f;
-        }
+    for (int s = 0; s < 3; ++s) {
+        const int tap = 4 * s + g4, tt = tap < 9 ? tap : 8;      // (a finite operand for the zero weights)
+        toff[s] = (tt / 3) * 30 + tt % 3;
+    }
+    const bool last_slot = (pg + G::PG * (G::TPW - 1)) * 16 < G::PX;
+#pragma unroll
+    for (int i = 0; i < G::TPW; ++i) {
+        acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (i == G::TPW - 1 && !last_slot) continue;
+        int p = (pg + G::PG * i) * 16 + l16;
+        if (p >= G::PX) p = 0;
+        const float *px = img + (p / 28) * 30 + p % 28;
+        float b[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) b[s] = px[toff[s]];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], b[s], acc[i], 0, 0, 0);
     }
 }
 
-// conv1 + 2x2 max-pool (conv_pool.hip conv1_pool2_kernel's arithmetic) over the padded positions of the pooled 16x16 plane; thread
-// (position, half of the channels)
-template <int C1>
-__device__ __forceinline__ void chain_conv1_pool(const float *img, const float *__restrict__ w, const float *__restrict__ bias, float *out, int t) {
-    constexpr int CIS = ch_cis(16), HALF = C1 / 2;
-    const int e = t & 255, c0 = (t >> 8) * HALF;
-    const int rr = e / 16, cc = e % 16;
-    const bool interior = rr >= 1 && rr <= 14 && cc >= 1 && cc <= 14;
-    float win[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) win[i][j] = interior ? img[(2 * (rr - 1) + i) * 30 + 2 * (cc - 1) + j] : 0.f;
-    float *o = out + c0 * CIS + e;
-#pragma unroll 4
-    for (int co = c0; co < c0 + HALF; ++co, o += CIS) {
-        const float b = bias ? bias[co] : 0.f;
-        float m = -INFINITY;
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) acc = fmaf(w[k * C1 + co], win[dy + k / 3][dx + k % 3], acc);
-                float v = acc + b;
-                v = v > 0.f ? v : 0.f;
-                m = v > m ? v : m;
-            }
-        *o = interior ? m : 0.f;
+// zeros on the halo ring of C padded planes [C][CIS] of an S x S map (the interior is written by chain_to_planes / chain_pool)
+template <int S, int C>
+__device__ __forceinline__ void chain_zero_halo(float *planes, int t) {
+    constexpr int WP = S + 2, CIS = ch_cis(WP), RING = 4 * S + 4;
+    for (int e = t; e < C * RING; e += CH_NT) {
+        const int c = e / RING, r = e % RING;
+        int pos;
+        if (r < WP) pos = r;                                         // top row
+        else if (r < 2 * WP) pos = (WP - 1) * WP + (r - WP);         // bottom row
+        else if (r < 2 * WP + S) pos = (r - 2 * WP + 1) * WP;        // left column
+        else pos = (r - 2 * WP - S + 1) * WP + WP - 1;               // right column
+        planes[c * CIS + pos] = 0.f;
     }
 }
 
@@ -250,49 +264,73 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int img = blockIdx.x;
     float *A1 = lds, *T2 = lds, *A2 = lds + CR_A2, *A3 = lds, *T4 = lds + CR_T4, *A4 = lds, *T5 = lds + CR_T5, *IMG = lds + CR_IMG;
-    float bv[4];
+    float bv[4], wc[18], wa[3];
 
+    CH_STAMP(0);
+    CH_CLK(20);
+    chain_conv1_weights(a.w[0], wa, wave, lane);
+    chain_bias<28, 32>(a.b[0], bv, wave, lane);
     chain_load_image(a.x + (long)img * 784, IMG, t);
-    __syncthreads();
-    chain_conv1<32>(IMG, a.w[0], a.b[0], A1, t);
-    __syncthreads();
+    chain_weights<28, 32, 32>(a.w[1], 0, wc, wave, lane);     // conv2's first pass: in flight under conv1
+    chain_sync();
+    CH_STAMP(1);
+    {   // conv1 1 -> 32 @28
+        floatx4 acc[ChainGeo<28, 32>::TPW];
+        chain_conv1_mfma(IMG, wa, acc, wave, lane);
+        chain_to_planes<28, 32>(acc, bv, A1, wave, lane);
+        chain_zero_halo<28, 32>(A1, t);
+    }
+    chain_sync();
+    CH_STAMP(2);
     {   // conv2 32 -> 32 @28 + pool
         floatx4 acc[ChainGeo<28, 32>::TPW];
         chain_bias<28, 32>(a.b[1], bv, wave, lane);
-        chain_mfma<28, 32, 32>(A1, a.w[1], acc, wave, lane);
-        __syncthreads();                                    // every wave is done reading A1
+        chain_mfma<28, 32, 32>(A1, a.w[1], wc, acc, wave, lane);
+        chain_weights<14, 32, 64>(a.w[2], 0, wc, wave, lane);  // conv3's first pass: under the pooling
+        chain_sync();
+        CH_STAMP(3);                                    // every wave is done reading A1
         chain_to_tile<28, 32>(acc, bv, T2, wave, lane);
-        chain_zero(A2, 32 * ch_cis(16) / 4, t);
-        __syncthreads();
+        chain_zero_halo<14, 32>(A2, t);
+        chain_sync();
+        CH_STAMP(4);
         chain_pool<28, 32, false>(T2, A2, t);
-        __syncthreads();
+        chain_sync();
+        CH_STAMP(5);
     }
     {   // conv3 32 -> 64 @14
         floatx4 acc[ChainGeo<14, 64>::TPW];
-        chain_zero(A3, 64 * ch_cis(16) / 4, t);             // (T2 is dead; A3's interior is written after the k loop's barrier)
+        chain_zero_halo<14, 64>(A3, t);                     // (T2 is dead; A3's interior is written after the k loop's barrier)
         chain_bias<14, 64>(a.b[2], bv, wave, lane);
-        chain_mfma<14, 32, 64>(A2, a.w[2], acc, wave, lane);
-        __syncthreads();
+        chain_mfma<14, 32, 64>(A2, a.w[2], wc, acc, wave, lane);
+        chain_weights<14, 64, 64>(a.w[3], 0, wc, wave, lane);
+        chain_sync();
+        CH_STAMP(6);
         chain_to_planes<14, 64>(acc, bv, A3, wave, lane);
-        __syncthreads();
+        chain_sync();
+        CH_STAMP(7);
     }
     {   // conv4 64 -> 64 @14 + pool
         floatx4 acc[ChainGeo<14, 64>::TPW];
         chain_bias<14, 64>(a.b[3], bv, wave, lane);
-        chain_mfma<14, 64, 64>(A3, a.w[3], acc, wave, lane);
-        __syncthreads();                                    // every wave is done reading A3
+        chain_mfma<14, 64, 64>(A3, a.w[3], wc, acc, wave, lane);
+        chain_weights<7, 64, 128>(a.w[4], 0, wc, wave, lane);
+        chain_sync();                                    // every wave is done reading A3
+        CH_STAMP(8);
         chain_to_tile<14, 64>(acc, bv, T4, wave, lane);
-        chain_zero(A4, 64 * ch_cis(9) / 4, t);
-        __syncthreads();
+        chain_zero_halo<7, 64>(A4, t);
+        chain_sync();
+        CH_STAMP(9);
         chain_pool<14, 64, false>(T4, A4, t);
-        __syncthreads();
+        chain_sync();
+        CH_STAMP(10);
     }
     {   // conv5 64 -> 128 @7 + global average pool
         floatx4 acc[ChainGeo<7, 128>::TPW];
         chain_bias<7, 128>(a.b[4], bv, wave, lane);
-        chain_mfma<7, 64, 128>(A4, a.w[4], acc, wave, lane);
+        chain_mfma<7, 64, 128>(A4, a.w[4], wc, acc, wave, lane);
         chain_to_tile<7, 128>(acc, bv, T5, wave, lane);     // (T5 does not overlap A4)
-        __syncthreads();
+        chain_sync();
+        CH_STAMP(11);
         // 16 lanes per channel plane, lane l adds elements l, l + 16, ... and a shuffle tree joins them: avgpool_global16_kernel's arithmetic
         constexpr int LD = ch_tile_ld(49);
         const int l = t & 15;
@@ -314,30 +352,44 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
                 if (a.cnt) a.cnt[(long)img * 128 + c] = k;
             }
         }
+        chain_sync();
+        CH_STAMP(12);
+        CH_CLK(21);
     }
 #endif
 }
 
 // ---- the simple CNN's front (examples/train_mnist_cnn.rs:64-100): 1 -> 32 + pool, 32 -> 64 + pool -> [64][7][7] ----
-//   A [32][272] @0   conv2's input      T [64][196] @8704   conv2's outputs      IMG [900] @21248
-constexpr int CS_T = 32 * ch_cis(16), CS_IMG = CS_T + 64 * ch_tile_ld(196), CS_LDS = CS_IMG + 900;
+//   T1 [32][788] @0  conv1's outputs    A [32][272] @25216  conv2's input    T [64][196] @0  conv2's outputs (over T1)    IMG [900] @33920
+constexpr int CS_A = 32 * ch_tile_ld(784), CS_IMG = CS_A + 32 * ch_cis(16), CS_LDS = CS_IMG + 900;
+static_assert(64 * ch_tile_ld(196) <= CS_A, "LDS map");
 
 __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int img = blockIdx.x;
-    float *A = lds, *T = lds + CS_T, *IMG = lds + CS_IMG;
-    float bv[4];
+    float *T1 = lds, *A = lds + CS_A, *T = lds, *IMG = lds + CS_IMG;
+    float bv[4], wc[18], wa[3];
+    chain_conv1_weights(a.w[0], wa, wave, lane);
+    chain_bias<28, 32>(a.b[0], bv, wave, lane);
     chain_load_image(a.x + (long)img * 784, IMG, t);
-    __syncthreads();
-    chain_conv1_pool<32>(IMG, a.w[0], a.b[0], A, t);
-    __syncthreads();
+    chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, lane);      // conv2's first pass: in flight under conv1 and its pool
+    chain_sync();
+    {   // conv1 1 -> 32 @28 + pool
+        floatx4 acc[ChainGeo<28, 32>::TPW];
+        chain_conv1_mfma(IMG, wa, acc, wave, lane);
+        chain_to_tile<28, 32>(acc, bv, T1, wave, lane);
+        chain_zero_halo<14, 32>(A, t);
+        chain_sync();
+        chain_pool<28, 32, false>(T1, A, t);
+        chain_sync();
+    }
     floatx4 acc[ChainGeo<14, 64>::TPW];
     chain_bias<14, 64>(a.b[1], bv, wave, lane);
-    chain_mfma<14, 32, 64>(A, a.w[1], acc, wave, lane);
-    chain_to_tile<14, 64>(acc, bv, T, wave, lane);          // (T does not overlap A)
-    __syncthreads();
+    chain_mfma<14, 32, 64>(A, a.w[1], wc, acc, wave, lane);
+    chain_to_tile<14, 64>(acc, bv, T, wave, lane);          // (T1 is dead; T does not overlap A)
+    chain_sync();
     chain_pool<14, 64, true>(T, a.y + (long)img * 64 * 49, t);
 #endif
 }
@@ -381,5 +433,13 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
     TH_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef TH_PROFILE
+int th_debug_chain_prof(th_ctx *ctx, long long *h_out32) {
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out32, HIP_SYMBOL(th::g_chain_prof), 32 * sizeof(long long)));
+    return 0;
+}
+#endif
 
 }  // extern "C"
