@@ -43,18 +43,32 @@ struct ConvChainArgs {
     int n;
 };
 
-// ---- one 3x3 / pad 1 layer on the matrix cores: IN [C_IN][CIS] padded planes in LDS -> TPW accumulator tiles per wave -------------------------
-// 8 waves = PG pixel groups x NCT channel tiles (one channel tile per wave): wave (pg, cj) owns pixel tiles pg, pg + PG, ...
-// Waves w and w + 4 share a SIMD: the mappings below give every SIMD one wave of each pixel-tile count.
+// ---- one 3x3 / pad 1 layer on the matrix cores: IN [C_IN][CIS] padded planes in LDS -> NSLOT accumulator tiles per wave ------------------------
+// fp32 MFMA shares the vector ALUs' issue slots with everything else a SIMD does (conv_mfma.hip): an LDS operand read costs ~5-6
+// cycles of the pipe that a 16x16x4 MFMA holds for 32, so what pays is operand REUSE.  A wave owns a PAIR of channel tiles (chA, chB: weight
+// operands in registers) and ND "double" pixel tiles -- every pixel operand read feeds two MFMAs -- and, where the (pixel tile, channel
+// tile) count does not divide into doubles evenly over the four SIMDs, one "single" tile (the last pixel tile x chA) on the first waves:
+//   28x28, 32 channels: 49 x 2 tiles = 6 doubles per wave (pixel tiles w, w + 8, ...) + singles (48, ch 0 / 1) on waves 0 / 1   -> 25 | 25 | 24 | 24 per SIMD
+//   14x14, 64 channels: 13 x 4 tiles = 3 doubles per wave (pair w & 1, pixel tiles w >> 1, + 4, + 8) + singles (12, ch 0..3) on waves 0..3 -> 13 per SIMD
+//   7x7, 128 channels:   4 x 8 tiles = 2 doubles per wave (pair w & 3, pixel tiles 2 (w >> 2), + 1)                              ->  8 per SIMD
+// (waves w and w + 4 share a SIMD).  Same per-output k order as one tile per wave: the sums do not depend on the mapping.
 template <int S, int C_OUT> struct ChainGeo {
-    static constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, NPT = (PX + 15) / 16, NCT = C_OUT / 16, PG = 8 / NCT, TPW = (NPT + PG - 1) / PG;
-    static_assert(NCT == 2 || NCT == 4 || NCT == 8, "channel tiles per workgroup");
-    __device__ static int pg_of(int wave) { return NCT == 2 ? wave >> 1 : (NCT == 4 ? wave >> 2 : 0); }
-    __device__ static int cj_of(int wave) { return NCT == 2 ? wave & 1 : (NCT == 4 ? wave & 3 : wave); }
+    static constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, NPT = (PX + 15) / 16, NCT = C_OUT / 16;
+    static_assert((NCT == 2 && NPT == 49) || (NCT == 4 && NPT == 13) || (NCT == 8 && NPT == 4), "the compiled tile mappings");
+    static constexpr int ND = NCT == 2 ? 6 : (NCT == 4 ? 3 : 2), NS = NCT == 2 ? 2 : (NCT == 4 ? 4 : 0);   // doubles per wave; waves with a single
+    static constexpr int NSLOT = 2 * ND + (NS ? 1 : 0), STILE = NPT - 1;
+    __device__ static int chA(int w) { return NCT == 2 ? (w & 1) : (NCT == 4 ? 2 * (w & 1) + ((w >> 1) & 1) : 2 * (w & 3)); }
+    __device__ static int chB(int w) { return NCT == 2 ? (w & 1) ^ 1 : (NCT == 4 ? 2 * (w & 1) + (((w >> 1) & 1) ^ 1) : 2 * (w & 3) + 1); }
+    __device__ static int dtile(int w, int i) { return NCT == 2 ? w + 8 * i : (NCT == 4 ? (w >> 1) + 4 * i : 2 * (w >> 2) + i); }
+    __device__ static bool has_single(int w) { return w < NS; }
+    // accumulator slot k of wave w -> (pixel tile, channel tile): slots 2 i, 2 i + 1 = double i x (chA, chB); slot 2 ND = the single
+    __device__ static int slot_px(int w, int k) { return k < 2 * ND ? dtile(w, k >> 1) : STILE; }
+    __device__ static int slot_ch(int w, int k) { return (k < 2 * ND && (k & 1)) ? chB(w) : chA(w); }
+    __device__ static bool slot_live(int w, int k) { return k < 2 * ND || has_single(w); }
 };
 
 // Barrier for LDS hand-offs only: the weight loads in flight (global memory nobody writes) stay in flight across it -- __syncthreads() would
-// wait for them (its fence covers every address space), exposing a global round trip at each of the chain's 14 barriers.
+// wait for them (its fence covers every address space), exposing a global round trip at each of the chain's barriers.
 __device__ __forceinline__ void chain_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
@@ -62,105 +76,117 @@ __device__ __forceinline__ void chain_sync() {
 }
 
 // weight operands of pass cb (8 input channels, 18 k-steps) of a layer's [9 C_IN][C_OUT] slab: k-step s wants row (cb + 4 (s / 9) + g4) * 9 + s % 9,
-// column 16 cj + l16 -- one dword per lane and k-step, requested a pass ahead (the first pass of a layer: before the previous layer's epilogue)
+// columns 16 chA + l16 and 16 chB + l16 -- two dwords per lane and k-step, requested a pass ahead (the first pass of a layer: before the
+// previous layer's epilogue)
+struct ChainW { float a[18], b[18]; };
 template <int S, int C_IN, int C_OUT>
-__device__ __forceinline__ void chain_weights(const float *__restrict__ w, int cb, float (&wr)[18], int wave, int lane) {
+__device__ __forceinline__ void chain_weights(const float *__restrict__ w, int cb, ChainW &wr, int wave, int lane) {
+    using G = ChainGeo<S, C_OUT>;
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * C_IN * C_OUT * 4, 0x00020000);
-    const int w_voff = ((lane >> 4) * 9 * C_OUT + 16 * ChainGeo<S, C_OUT>::cj_of(wave) + (lane & 15)) * 4;
+    const int row = ((lane >> 4) * 9 * C_OUT + (lane & 15)) * 4, va = row + 64 * G::chA(wave), vb = row + 64 * G::chB(wave);
 #pragma unroll
-    for (int s = 0; s < 18; ++s)
-        wr[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, w_voff, ((cb + 4 * (s / 9)) * 9 + s % 9) * C_OUT * 4, 0));
+    for (int s = 0; s < 18; ++s) {
+        const int so = ((cb + 4 * (s / 9)) * 9 + s % 9) * C_OUT * 4;
+        wr.a[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, va, so, 0));
+        wr.b[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vb, so, 0));
+    }
 }
 
-// wc: the operands of pass 0, already requested (chain_weights); holds the last pass's on return
+// wc: the operands of pass 0, already requested (chain_weights).  The k loop's only non-MFMA instructions are its LDS reads: a tile's
+// window-corner address lives in a register that moves on by eight channels per pass (the tap / channel-group part of an operand address is
+// the read's immediate offset -- kept below 64 KB by hiding the region's base from constant folding), the two weight sets alternate
+// between passes instead of being copied, and the single tile's READ is unconditional (only its MFMA is skipped by the waves without one).
 template <int S, int C_IN, int C_OUT>
-__device__ __forceinline__ void chain_mfma(const float *in, const float *__restrict__ w, float (&wc)[18], floatx4 (&acc)[ChainGeo<S, C_OUT>::TPW], int wave,
+__device__ __forceinline__ void chain_mfma(const float *in, const float *__restrict__ w, ChainW &wc, floatx4 (&acc)[ChainGeo<S, C_OUT>::NSLOT], int wave,
                                            int lane) {
     using G = ChainGeo<S, C_OUT>;
-    constexpr int WP = G::WP, CIS = G::CIS, TPW = G::TPW, PG = G::PG, KS = 18;
-    static_assert(C_IN % 8 == 0, "whole 8-channel passes");
-    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave);
-    int pix_off[TPW];            // this lane's window corner in each of its tiles (+ its lane group's channel)
+    constexpr int WP = G::WP, CIS = G::CIS, ND = G::ND, NP = ND + (G::NS ? 1 : 0), KS = 18;
+    static_assert(C_IN % 16 == 0, "whole pairs of 8-channel passes");
+    const int l16 = lane & 15, g4 = lane >> 4;
+#ifdef CH_PROBE_HS   /* timing probe: every wave (1) / no wave (0) runs the single tile, as a compile-time constant (wrong results) */
+    constexpr bool hs = CH_PROBE_HS != 0;
+#else
+    const bool hs = G::has_single(wave);     // wave-uniform
+#endif
+    typedef __attribute__((address_space(3))) const float lds_cf;
+    lds_cf *pt[NP];              // this lane's window corner in each of its pixel tiles (+ its lane group's channel), current pass
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        int p = (pg + PG * i) * 16 + l16;
-        if (p >= G::PX) p = 0;   // slots past the image compute on pixel 0 and are never stored
-        pix_off[i] = (p / S) * WP + p % S + g4 * CIS;
+    for (int i = 0; i < NP; ++i) {
+        int p = (i < ND ? G::dtile(wave, i) : G::STILE) * 16 + l16;
+        if (p >= G::PX) p = 0;   // lanes past the image compute on pixel 0 and are never stored
+        pt[i] = (lds_cf *)(in + (p / S) * WP + p % S + g4 * CIS);
+        asm volatile("" : "+v"(pt[i]));
     }
-    const bool last_slot = (pg + PG * (TPW - 1)) * 16 < G::PX;     // wave-uniform
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float wn[KS];
+    for (int k = 0; k < G::NSLOT; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+    ChainW wn;
+    // the operands of k-step s + 1 are requested before the MFMAs of step s are issued, and pinned there (conv_mfma.hip: left alone, the
+    // scheduler sinks every read to its use)
+#ifdef CH_NO_READS   /* timing probe: the k loop without its LDS reads (wrong results) */
+#define CH_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < NP; ++i) B[i] = __builtin_bit_cast(float, (int)(size_t)pt[i]); }
+#else
+#define CH_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < NP; ++i) B[i] = pt[i][(4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
+#endif
+#define CH_PASS_BODY(WCUR)                                                                                                                   \
+    {                                                                                                                                        \
+        float b0[NP], b1[NP];                                                                                                                \
+        CH_REQ(b0, 0)                                                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                                     \
+            if (s + 1 < KS) CH_REQ(b1, s + 1)                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                                                 \
+                acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[i], acc[2 * i], 0, 0, 0);                                    \
+                acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.b[s], b0[i], acc[2 * i + 1], 0, 0, 0);                            \
+            }                                                                                                                                \
+            if (G::NS && hs) acc[G::NSLOT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[NP - 1], acc[G::NSLOT - 1], 0, 0, 0);    \
+            __builtin_amdgcn_sched_barrier(0);                                                                                               \
+            if (s + 1 < KS) { _Pragma("unroll") for (int i = 0; i < NP; ++i) b0[i] = b1[i]; }                                                \
+        }                                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NP; ++i) pt[i] += 8 * CIS;                                                                     \
+    }
 #pragma unroll 1
-    for (int cb = 0; cb < C_IN; cb += 8) {
+    for (int cb = 0; cb < C_IN; cb += 16) {
         CH_PASS(S, C_IN, cb);
-        if (cb + 8 < C_IN) chain_weights<S, C_IN, C_OUT>(w, cb + 8, wn, wave, lane);
-        const float *pp = in + cb * CIS;
-        float b0[TPW], b1[TPW];
-#define CH_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < TPW; ++i) B[i] = pp[pix_off[i] + (4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
-        CH_REQ(b0, 0)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if (s + 1 < KS) CH_REQ(b1, s + 1)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TPW - 1; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s], b0[i], acc[i], 0, 0, 0);
-            if (last_slot) acc[TPW - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s], b0[TPW - 1], acc[TPW - 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < KS) {
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) b0[i] = b1[i];
-            }
-        }
+        chain_weights<S, C_IN, C_OUT>(w, cb + 8, wn, wave, lane);
+        CH_PASS_BODY(wc)
+        CH_PASS(S, C_IN, cb + 8);
+        if (cb + 16 < C_IN) chain_weights<S, C_IN, C_OUT>(w, cb + 16, wc, wave, lane);
+        CH_PASS_BODY(wn)
+    }
+#undef CH_PASS_BODY
 #undef CH_REQ
-        if (cb + 8 < C_IN) {
+}
+
+// bias of this lane's channels (16 chA + 4 g4 + e, 16 chB + 4 g4 + e)
+struct ChainBias { float a[4], b[4]; };
+template <int S, int C_OUT>
+__device__ __forceinline__ void chain_bias(const float *__restrict__ bias, ChainBias &bv, int wave, int lane) {
+    using G = ChainGeo<S, C_OUT>;
+    const int ca = 16 * G::chA(wave) + 4 * (lane >> 4), cb = 16 * G::chB(wave) + 4 * (lane >> 4);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) wc[s] = wn[s];
-        }
+    for (int e = 0; e < 4; ++e) {
+        bv.a[e] = bias ? bias[ca + e] : 0.f;
+        bv.b[e] = bias ? bias[cb + e] : 0.f;
     }
 }
 
-// bias of this lane's four channels (16 cj + 4 g4 + e)
-template <int S, int C_OUT>
-__device__ __forceinline__ void chain_bias(const float *__restrict__ bias, float (&bv)[4], int wave, int lane) {
-    const int c0 = 16 * ChainGeo<S, C_OUT>::cj_of(wave) + 4 * (lane >> 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bv[e] = bias ? bias[c0 + e] : 0.f;
-}
-
-// accumulators (+ bias, ReLU) -> the next layer's padded planes OUT [C_OUT][CIS] (halo already zero)
-template <int S, int C_OUT>
-__device__ __forceinline__ void chain_to_planes(const floatx4 (&acc)[ChainGeo<S, C_OUT>::TPW], const float (&bv)[4], float *out, int wave, int lane) {
+// accumulators (+ bias, ReLU) -> PLANES: the next layer's padded planes OUT [C_OUT][CIS] (halo already zero); else a plain tile
+// T [C_OUT][ch_tile_ld(pixels)] of the layer's pixels (for the pooling passes)
+template <int S, int C_OUT, bool PLANES>
+__device__ __forceinline__ void chain_store(const floatx4 (&acc)[ChainGeo<S, C_OUT>::NSLOT], const ChainBias &bv, float *out, int wave, int lane) {
     using G = ChainGeo<S, C_OUT>;
-    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave), cj = G::cj_of(wave);
+    constexpr int LD = PLANES ? G::CIS : ch_tile_ld(G::PX);
+    const int l16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < G::TPW; ++i) {
-        const int p = (pg + G::PG * i) * 16 + l16;
+    for (int k = 0; k < G::NSLOT; ++k) {
+        if (!G::slot_live(wave, k)) continue;
+        const int p = G::slot_px(wave, k) * 16 + l16;
         if (p >= G::PX) continue;
-        float *o = out + (16 * cj + 4 * g4) * G::CIS + (p / S + 1) * G::WP + p % S + 1;
+        const bool second = k < 2 * G::ND && (k & 1);
+        float *o = out + (16 * G::slot_ch(wave, k) + 4 * g4) * LD + (PLANES ? (p / S + 1) * G::WP + p % S + 1 : p);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float v = acc[i][e] + bv[e];
-            v = v > 0.f ? v : 0.f;
-            o[e * G::CIS] = v;
-        }
-    }
-}
-
-// accumulators (+ bias, ReLU) -> a plain tile T [C_OUT][LD] of the layer's pixels (for the pooling passes)
-template <int S, int C_OUT>
-__device__ __forceinline__ void chain_to_tile(const floatx4 (&acc)[ChainGeo<S, C_OUT>::TPW], const float (&bv)[4], float *tile, int wave, int lane) {
-    using G = ChainGeo<S, C_OUT>;
-    constexpr int LD = ch_tile_ld(G::PX);
-    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave), cj = G::cj_of(wave);
-#pragma unroll
-    for (int i = 0; i < G::TPW; ++i) {
-        const int p = (pg + G::PG * i) * 16 + l16;
-        if (p >= G::PX) continue;
-        float *o = tile + (16 * cj + 4 * g4) * LD + p;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = acc[i][e] + bv[e];
+            float v = acc[k][e] + (second ? bv.b[e] : bv.a[e]);
             v = v > 0.f ? v : 0.f;
             o[e * LD] = v;
         }
@@ -203,49 +229,68 @@ __device__ __forceinline__ void chain_load_image(const float *__restrict__ xi, f
 // zero weight leaves the chain's value unchanged: the sum is conv_pool.hip conv1_kernel's fmaf chain over taps 0..8, bit for bit).  294 MFMAs
 // per image against 226 K FMAs on the vector ALUs (which would also wait on 320 scalar weight loads): 10.3 -> ~2 us of the chain.
 // IMG = the zero-haloed 30x30 plane; tile mapping = ChainGeo<28, 32> (the epilogues above apply).
-__device__ __forceinline__ void chain_conv1_weights(const float *__restrict__ w, float (&wa)[3], int wave, int lane) {
-    const int l16 = lane & 15, g4 = lane >> 4, cj = ChainGeo<28, 32>::cj_of(wave);
+struct ChainW1 { float a[3], b[3]; };
+__device__ __forceinline__ void chain_conv1_weights(const float *__restrict__ w, ChainW1 &wa, int wave, int lane) {
+    using G = ChainGeo<28, 32>;
+    const int l16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) wa[s] = 4 * s + g4 < 9 ? w[(4 * s + g4) * 32 + 16 * cj + l16] : 0.f;
+    for (int s = 0; s < 3; ++s) {
+        wa.a[s] = 4 * s + g4 < 9 ? w[(4 * s + g4) * 32 + 16 * G::chA(wave) + l16] : 0.f;
+        wa.b[s] = 4 * s + g4 < 9 ? w[(4 * s + g4) * 32 + 16 * G::chB(wave) + l16] : 0.f;
+    }
 }
 
-__device__ __forceinline__ void chain_conv1_mfma(const float *img, const float (&wa)[3], floatx4 (&acc)[ChainGeo<28, 32>::TPW], int wave, int lane) {
+__device__ __forceinline__ void chain_conv1_mfma(const float *img, const ChainW1 &wa, floatx4 (&acc)[ChainGeo<28, 32>::NSLOT], int wave, int lane) {
     using G = ChainGeo<28, 32>;
-    const int l16 = lane & 15, g4 = lane >> 4, pg = G::pg_of(wave);
+    const int l16 = lane & 15, g4 = lane >> 4;
     int toff[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int tap = 4 * s + g4, tt = tap < 9 ? tap : 8;      // (a finite operand for the zero weights)
         toff[s] = (tt / 3) * 30 + tt % 3;
     }
-    const bool last_slot = (pg + G::PG * (G::TPW - 1)) * 16 < G::PX;
 #pragma unroll
-    for (int i = 0; i < G::TPW; ++i) {
-        acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (i == G::TPW - 1 && !last_slot) continue;
-        int p = (pg + G::PG * i) * 16 + l16;
+    for (int k = 0; k < G::NSLOT; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < G::ND + 1; ++i) {
+        if (i == G::ND && !G::has_single(wave)) continue;
+        int p = (i < G::ND ? G::dtile(wave, i) : G::STILE) * 16 + l16;
         if (p >= G::PX) p = 0;
         const float *px = img + (p / 28) * 30 + p % 28;
         float b[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) b[s] = px[toff[s]];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], b[s], acc[i], 0, 0, 0);
+        for (int s = 0; s < 3; ++s) {
+            if (i < G::ND) {
+                acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.a[s], b[s], acc[2 * i], 0, 0, 0);
+                acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.b[s], b[s], acc[2 * i + 1], 0, 0, 0);
+            } else {
+                acc[G::NSLOT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.a[s], b[s], acc[G::NSLOT - 1], 0, 0, 0);
+            }
+        }
     }
 }
 
-// zeros on the halo ring of C padded planes [C][CIS] of an S x S map (the interior is written by chain_to_planes / chain_pool)
+// zeros on the halo ring of C padded planes [C][CIS] of an S x S map (the interior is written by chain_store / chain_pool): a wave per
+// channel (no per-element division), lane l takes ring elements l, l + 64
 template <int S, int C>
-__device__ __forceinline__ void chain_zero_halo(float *planes, int t) {
+__device__ __forceinline__ void chain_zero_halo(float *planes, int wave, int lane) {
     constexpr int WP = S + 2, CIS = ch_cis(WP), RING = 4 * S + 4;
-    for (int e = t; e < C * RING; e += CH_NT) {
-        const int c = e / RING, r = e % RING;
-        int pos;
-        if (r < WP) pos = r;                                         // top row
-        else if (r < 2 * WP) pos = (WP - 1) * WP + (r - WP);         // bottom row
-        else if (r < 2 * WP + S) pos = (r - 2 * WP + 1) * WP;        // left column
-        else pos = (r - 2 * WP - S + 1) * WP + WP - 1;               // right column
-        planes[c * CIS + pos] = 0.f;
+    int pos[(RING + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (RING + 63) / 64; ++j) {
+        const int r = lane + 64 * j;
+        pos[j] = r < WP ? r                                          // top row
+               : r < 2 * WP ? (WP - 1) * WP + (r - WP)               // bottom row
+               : r < 2 * WP + S ? (r - 2 * WP + 1) * WP              // left column
+               : r < RING ? (r - 2 * WP - S + 1) * WP + WP - 1       // right column
+               : -1;
+    }
+    for (int c = wave; c < C; c += CH_NT / 64) {
+#pragma unroll
+        for (int j = 0; j < (RING + 63) / 64; ++j)
+            if (pos[j] >= 0) planes[c * CIS + pos[j]] = 0.f;
     }
 }
 
@@ -264,7 +309,9 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int img = blockIdx.x;
     float *A1 = lds, *T2 = lds, *A2 = lds + CR_A2, *A3 = lds, *T4 = lds + CR_T4, *A4 = lds, *T5 = lds + CR_T5, *IMG = lds + CR_IMG;
-    float bv[4], wc[18], wa[3];
+    ChainBias bv;
+    ChainW wc;
+    ChainW1 wa;
 
     CH_STAMP(0);
     CH_CLK(20);
@@ -275,22 +322,22 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
     chain_sync();
     CH_STAMP(1);
     {   // conv1 1 -> 32 @28
-        floatx4 acc[ChainGeo<28, 32>::TPW];
+        floatx4 acc[ChainGeo<28, 32>::NSLOT];
         chain_conv1_mfma(IMG, wa, acc, wave, lane);
-        chain_to_planes<28, 32>(acc, bv, A1, wave, lane);
-        chain_zero_halo<28, 32>(A1, t);
+        chain_store<28, 32, true>(acc, bv, A1, wave, lane);
+        chain_zero_halo<28, 32>(A1, wave, lane);
     }
     chain_sync();
     CH_STAMP(2);
     {   // conv2 32 -> 32 @28 + pool
-        floatx4 acc[ChainGeo<28, 32>::TPW];
+        floatx4 acc[ChainGeo<28, 32>::NSLOT];
         chain_bias<28, 32>(a.b[1], bv, wave, lane);
         chain_mfma<28, 32, 32>(A1, a.w[1], wc, acc, wave, lane);
         chain_weights<14, 32, 64>(a.w[2], 0, wc, wave, lane);  // conv3's first pass: under the pooling
         chain_sync();
         CH_STAMP(3);                                    // every wave is done reading A1
-        chain_to_tile<28, 32>(acc, bv, T2, wave, lane);
-        chain_zero_halo<14, 32>(A2, t);
+        chain_store<28, 32, false>(acc, bv, T2, wave, lane);
+        chain_zero_halo<14, 32>(A2, wave, lane);
         chain_sync();
         CH_STAMP(4);
         chain_pool<28, 32, false>(T2, A2, t);
@@ -298,26 +345,26 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
         CH_STAMP(5);
     }
     {   // conv3 32 -> 64 @14
-        floatx4 acc[ChainGeo<14, 64>::TPW];
-        chain_zero_halo<14, 64>(A3, t);                     // (T2 is dead; A3's interior is written after the k loop's barrier)
+        floatx4 acc[ChainGeo<14, 64>::NSLOT];
+        chain_zero_halo<14, 64>(A3, wave, lane);                     // (T2 is dead; A3's interior is written after the k loop's barrier)
         chain_bias<14, 64>(a.b[2], bv, wave, lane);
         chain_mfma<14, 32, 64>(A2, a.w[2], wc, acc, wave, lane);
         chain_weights<14, 64, 64>(a.w[3], 0, wc, wave, lane);
         chain_sync();
         CH_STAMP(6);
-        chain_to_planes<14, 64>(acc, bv, A3, wave, lane);
+        chain_store<14, 64, true>(acc, bv, A3, wave, lane);
         chain_sync();
         CH_STAMP(7);
     }
     {   // conv4 64 -> 64 @14 + pool
-        floatx4 acc[ChainGeo<14, 64>::TPW];
+        floatx4 acc[ChainGeo<14, 64>::NSLOT];
         chain_bias<14, 64>(a.b[3], bv, wave, lane);
         chain_mfma<14, 64, 64>(A3, a.w[3], wc, acc, wave, lane);
         chain_weights<7, 64, 128>(a.w[4], 0, wc, wave, lane);
         chain_sync();                                    // every wave is done reading A3
         CH_STAMP(8);
-        chain_to_tile<14, 64>(acc, bv, T4, wave, lane);
-        chain_zero_halo<7, 64>(A4, t);
+        chain_store<14, 64, false>(acc, bv, T4, wave, lane);
+        chain_zero_halo<7, 64>(A4, wave, lane);
         chain_sync();
         CH_STAMP(9);
         chain_pool<14, 64, false>(T4, A4, t);
@@ -325,10 +372,10 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
         CH_STAMP(10);
     }
     {   // conv5 64 -> 128 @7 + global average pool
-        floatx4 acc[ChainGeo<7, 128>::TPW];
+        floatx4 acc[ChainGeo<7, 128>::NSLOT];
         chain_bias<7, 128>(a.b[4], bv, wave, lane);
         chain_mfma<7, 64, 128>(A4, a.w[4], wc, acc, wave, lane);
-        chain_to_tile<7, 128>(acc, bv, T5, wave, lane);     // (T5 does not overlap A4)
+        chain_store<7, 128, false>(acc, bv, T5, wave, lane);     // (T5 does not overlap A4)
         chain_sync();
         CH_STAMP(11);
         // 16 lanes per channel plane, lane l adds elements l, l + 16, ... and a shuffle tree joins them: avgpool_global16_kernel's arithmetic
@@ -352,7 +399,9 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
                 if (a.cnt) a.cnt[(long)img * 128 + c] = k;
             }
         }
+#ifdef TH_PROFILE
         chain_sync();
+#endif
         CH_STAMP(12);
         CH_CLK(21);
     }
@@ -370,25 +419,27 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int img = blockIdx.x;
     float *T1 = lds, *A = lds + CS_A, *T = lds, *IMG = lds + CS_IMG;
-    float bv[4], wc[18], wa[3];
+    ChainBias bv;
+    ChainW wc;
+    ChainW1 wa;
     chain_conv1_weights(a.w[0], wa, wave, lane);
     chain_bias<28, 32>(a.b[0], bv, wave, lane);
     chain_load_image(a.x + (long)img * 784, IMG, t);
     chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, lane);      // conv2's first pass: in flight under conv1 and its pool
     chain_sync();
     {   // conv1 1 -> 32 @28 + pool
-        floatx4 acc[ChainGeo<28, 32>::TPW];
+        floatx4 acc[ChainGeo<28, 32>::NSLOT];
         chain_conv1_mfma(IMG, wa, acc, wave, lane);
-        chain_to_tile<28, 32>(acc, bv, T1, wave, lane);
-        chain_zero_halo<14, 32>(A, t);
+        chain_store<28, 32, false>(acc, bv, T1, wave, lane);
+        chain_zero_halo<14, 32>(A, wave, lane);
         chain_sync();
         chain_pool<28, 32, false>(T1, A, t);
         chain_sync();
     }
-    floatx4 acc[ChainGeo<14, 64>::TPW];
+    floatx4 acc[ChainGeo<14, 64>::NSLOT];
     chain_bias<14, 64>(a.b[1], bv, wave, lane);
     chain_mfma<14, 32, 64>(A, a.w[1], wc, acc, wave, lane);
-    chain_to_tile<14, 64>(acc, bv, T, wave, lane);          // (T1 is dead; T does not overlap A)
+    chain_store<14, 64, false>(acc, bv, T, wave, lane);          // (T1 is dead; T does not overlap A)
     chain_sync();
     chain_pool<14, 64, true>(T, a.y + (long)img * 64 * 49, t);
 #endif
