@@ -372,7 +372,7 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
                       int c_in, int h, int w);
 /* Test hook: launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity
  * tests assert which kernel instance a shape takes): out6 = {16-channel tiles per workgroup (1/2/4), 1 if the
- * operands are staged by LDS-DMA (2: the image-resident kernel), waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */
+ * operands are staged by LDS-DMA (2-5: the image-resident kernel; 6: a conv chain, out6[0] = its instance id), waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */
 int th_debug_last_conv_config(th_ctx *ctx, int *out6);
 /* Test hook: which matrix-core kernel takes a 3x3 launch.  -1 (default): the image-resident kernel (whole images per
  * workgroup, every output tile in registers; out6[1] == 2 in th_debug_last_conv_config, out6[2] = pixel tiles per wave,

@@ -40,6 +40,7 @@ int tp_tape_reset(void);                   /* tape.rs:43-49 */
 int tp_tape_len(size_t *out);
 int tp_tape_set_compat_zero_sentinel(int on);   /* quirk Q1 */
 int tp_set_full_backward(int on);               /* quirk Q2: 0 = faithful (default) */
+int tp_set_conv_chain(int on);                  /* Trainer steps: 1 (default) = the conv front of a Sequential as one launch where compiled (th_conv_chain_fwd), 0 = layer by layer */
 
 /* ---- Tensor (src/tensor.rs:470-541) ---- */
 int tp_tensor_new(const float *h_data, const size_t *shape, int ndim, tp_tensor **out);

@@ -63,6 +63,11 @@ def set_full_backward(on: bool):
     tp_check(host.tp_set_full_backward(1 if on else 0), "tp_set_full_backward")
 
 
+def set_conv_chain(on: bool):
+    """Trainer steps: the convolutional front of a Sequential as ONE launch where an instance is compiled (default), or layer by layer"""
+    tp_check(host.tp_set_conv_chain(1 if on else 0), "tp_set_conv_chain")
+
+
 class Tensor:
     """src/tensor.rs Tensor: a shared handle to device storage + grad slot + tape node."""
 

@@ -447,6 +447,9 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
 
 }  // namespace th
 
+namespace th {
+extern thread_local int t_last_conv_cfg[6];   // conv_mfma.hip: th_debug_last_conv_config
+}
 using namespace th;
 
 extern "C" {
@@ -481,6 +484,8 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
         (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(conv_chain_simple_kernel, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
     }
+    t_last_conv_cfg[0] = kind; t_last_conv_cfg[1] = 6; t_last_conv_cfg[2] = 0;   // 6: a conv chain (th_debug_last_conv_config)
+    t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;
     TH_LAUNCH_CHECK();
     return 0;
 }

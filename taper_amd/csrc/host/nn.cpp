@@ -401,10 +401,10 @@ Tensor AdaptiveAvgPool2d::forward(const Tensor &x) const {  // nn.rs:670-686
 }
 
 // TAPER_CONV_CHAIN=0: Trainer steps launch the convolutional front layer by layer (measurement probe; default: one launch where compiled)
-static bool chain_fuse() {
-    static const bool on = [] { const char *e = std::getenv("TAPER_CONV_CHAIN"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool g_conv_chain = [] { const char *e = std::getenv("TAPER_CONV_CHAIN"); return !(e && e[0] == '0'); }();
+void set_conv_chain(bool on) { g_conv_chain = on; }
+bool conv_chain_enabled() { return g_conv_chain; }
+static bool chain_fuse() { return g_conv_chain; }
 
 Tensor Sequential::forward(const Tensor &input) const { return forward_prefix(input, layers.size()); }  // nn.rs:149-151
 
@@ -1144,6 +1144,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
         key.push_back(bits);
     }
     key.push_back((uintptr_t)full_backward());
+    key.push_back((uintptr_t)conv_chain_enabled());
     if (!graphs_.empty() && graph_key_ != key) drop_graphs();
 
     size_t done = 0;

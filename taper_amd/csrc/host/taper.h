@@ -207,6 +207,10 @@ class Tape {
 // gradients); true = full_backward extension.
 void set_full_backward(bool on);
 bool full_backward();
+// Trainer steps launch the convolutional front of a Sequential as ONE kernel where an instance is compiled for it (Tensor::conv_chain);
+// false = layer by layer (the measurement probe TAPER_CONV_CHAIN=0 sets the initial value).
+void set_conv_chain(bool on);
+bool conv_chain_enabled();
 
 // ---- loss (src/loss.rs) ------------------------------------------------------
 Tensor log_softmax(const Tensor &x, int dim = -1);                         // loss.rs:101-126

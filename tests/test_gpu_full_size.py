@@ -169,12 +169,21 @@ def test_cnn_forward_backward_parity_batch_256(name, fuse):
 
 
 @pytest.mark.parametrize("name", ["cnn_simple", "cnn_reference"])
-@pytest.mark.parametrize("mode", ["eager", "graph"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "graph_layered"])
 def test_cnn_training_steps_parity_batch_256(name, mode):
     """3 Adam steps (lr 1e-2, wd 1e-4: train_mnist_cnn.rs:108-109) at batch 256 -- `graph` is the Trainer's captured,
     fused step (conv + pool in one launch, pooled bias gradients, fused classifier tail, Adam in the epilogues): exactly
-    what bench.py times for the CNN workloads -- per-step loss / hit count and every weight against the oracle"""
+    what bench.py times for the CNN workloads -- per-step loss / hit count and every weight against the oracle.  `graph` launches the
+    convolutional front as ONE kernel (th_conv_chain_fwd), `graph_layered` layer by layer (T.set_conv_chain(False))"""
     import taper_amd as T
+    T.set_conv_chain(mode != "graph_layered")
+    try:
+        _training_steps_parity(T, name, mode)
+    finally:
+        T.set_conv_chain(True)
+
+
+def _training_steps_parity(T, name, mode):
     H, Orc = backends.get("hip"), backends.get("oracle")
     Orc.set_zero_sentinel(True)
     rng = np.random.default_rng(11 + len(name))
@@ -186,11 +195,14 @@ def test_cnn_training_steps_parity_batch_256(name, mode):
     tr = T.Trainer(hm, hopt, sample_shape=(1, 28, 28))
     x, y = backends.mnist_like(rng, steps * batch)
     ref = [om.train_step(oopt, x[s * batch:(s + 1) * batch], y[s * batch:(s + 1) * batch], (batch, 1, 28, 28)) for s in range(steps)]
-    if mode == "graph":
+    if mode != "eager":
         ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False), T.Trainer.GRAPH)
         losses, ncorrect = ep["losses"], ep["ncorrect"]
         cfg = last_conv_config_host()
-        assert cfg["ct"] in (1, 2) and cfg["dma"] in (2, 3, 4, 5), cfg   # the image-resident matrix-core conv ran in this process's step
+        if mode == "graph":
+            assert cfg["dma"] == 6 and cfg["ct"] == (1 if name == "cnn_reference" else 2), cfg   # the conv chain ran in this process's step
+        else:
+            assert cfg["ct"] in (1, 2) and cfg["dma"] in (2, 3, 4, 5), cfg   # the image-resident matrix-core conv ran in this process's step
     else:
         losses, ncorrect = [], []
         for s in range(steps):
@@ -202,6 +214,33 @@ def test_cnn_training_steps_parity_batch_256(name, mode):
     for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
         np.testing.assert_allclose(hp.data(), op.data(), rtol=RTOL, atol=lr * 2e-2, err_msg=f"param {i}")
     assert hopt.t() == steps
+
+
+@pytest.mark.parametrize("name", ["cnn_simple", "cnn_reference"])
+def test_conv_chain_step_is_bit_identical_to_the_layered_step(name):
+    """the Trainer's captured step with the convolutional front as one launch against the same step launched layer by layer: same
+    per-output arithmetic, so every weight and every loss agrees bit for bit after 3 steps at batch 256"""
+    import taper_amd as T
+    H = backends.get("hip")
+    batch, steps = 256, 3
+    out = []
+    for chain in (True, False):
+        rng = np.random.default_rng(77)
+        spec = backends.nonzero_biases(MODELS[name](rng), rng)
+        x, y = backends.mnist_like(rng, steps * batch)
+        T.set_conv_chain(chain)
+        try:
+            hm = H.sequential(spec)
+            opt = T.Adam(hm.parameters(), 1e-2, None, None, 1e-4)
+            tr = T.Trainer(hm, opt, sample_shape=(1, 28, 28))
+            ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False), T.Trainer.GRAPH)
+            assert (last_conv_config_host()["dma"] == 6) == chain
+            out.append((ep["losses"], [p.data() for p in hm.parameters()]))
+        finally:
+            T.set_conv_chain(True)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(a, b)
 
 
 def last_conv_config_host():
