@@ -977,6 +977,9 @@ static bool conv_chain_describe(const Tensor &x, const std::vector<ConvStage> &s
 int Tensor::conv_chain_supported(const std::vector<ConvStage> &stages) const {
     std::vector<th_conv_stage> d;
     if (!conv_chain_describe(*this, stages, &d)) return 0;
+    // one image per workgroup: a launch takes the same ~100 us for 8 images as for 256 (measured, tools/chain_time.py: the reference front
+    // layer by layer 84 / 88 / 97 / 103 / 144 us at batch 8 / 32 / 64 / 96 / 192 against 100-104 us in one launch) -- small batches stay layered
+    if (shape_[0] < 96) return 0;
     return th_conv_chain_supported((int)shape_[1], (int)shape_[2], (int)shape_[3], d.data(), (int)d.size());
 }
 
