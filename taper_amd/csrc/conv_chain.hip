@@ -87,8 +87,13 @@ __device__ __forceinline__ void chain_weights(const float *__restrict__ w, int c
 #pragma unroll
     for (int s = 0; s < 18; ++s) {
         const int so = ((cb + 4 * (s / 9)) * 9 + s % 9) * C_OUT * 4;
+#ifdef CH_NO_WEIGHTS   /* timing probe: no weight loads (wrong results) */
+        wr.a[s] = __builtin_bit_cast(float, va + so);
+        wr.b[s] = __builtin_bit_cast(float, vb + so);
+#else
         wr.a[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, va, so, 0));
         wr.b[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vb, so, 0));
+#endif
     }
 }
 

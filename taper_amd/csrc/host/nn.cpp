@@ -1200,6 +1200,28 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
         std::sort(graphs_.begin(), graphs_.end(), [](const auto &x, const auto &y) { return x.first > y.first; });   // largest first
         graph_key_ = key;
     }
+    // What an epoch leaves over after its whole chunks (937 steps = 7 x 128 + 41), or a short run as a whole (20 steps), would replay as one
+    // ladder graph per set bit (41 = 32 + 8 + 1; 20 = 16 + 4), ~10 us of host time and a stream gap each: the first call that meets such a
+    // remainder records ONE graph of exactly that many steps (the ladder graphs are complete by then; at most four distinct remainders).
+    {
+        const size_t tail = n_full - done > 0 ? (n_full - done) % chunk : 0;
+        size_t exact = 0;
+        for (auto &g : graphs_) exact += (g.first & (g.first - 1)) != 0 ? 1 : 0;
+        if (tail > 2 && (tail & (tail - 1)) != 0 && ladder_div == 2 && !have(tail) && have(1) && exact < 4 && !graph_capture_failed_ &&
+            graph_key_ == key) {
+            TH(th_graph_begin(ctx));
+            th_graph *g = nullptr;
+            try {
+                enqueue_steps(d_img, d_lab, d_idx, (int64_t)n, bs, tail);
+                TH(th_graph_end(ctx, &g));
+                graphs_.emplace_back(tail, g);
+                std::sort(graphs_.begin(), graphs_.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+            } catch (const std::exception &) {   // (the ladder keeps serving the remainder)
+                if (!g) th_graph_end(ctx, &g);
+                if (g) th_graph_destroy(g);
+            }
+        }
+    }
     while (done < n_full) {
         bool launched = false;
         for (auto &g : graphs_) {

@@ -161,6 +161,34 @@ def test_graph_epoch_equals_eager_epoch(n, batch):
         np.testing.assert_allclose(pb, pa, rtol=1e-4, atol=1e-3 * 5e-2)
 
 
+def test_remainder_graph_equals_the_ladder_graphs():
+    """an epoch of 20 steps replays as ONE graph of exactly 20 steps (recorded by the first call that meets that remainder: 20 is no ladder
+    size); with 4 steps per replay the same epoch is five chunk graphs: same op list, so every loss and weight agrees bit for bit -- also
+    in the second epoch, which reuses the recorded graphs"""
+    import taper_amd as T
+    H = backends.get("hip")
+    rng = np.random.default_rng(2020)
+    spec = backends.mlp_baseline(rng)
+    batch = 32
+    x, y = backends.mnist_like(rng, 20 * batch)
+    out = []
+    for chunk in (128, 4):
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        tr = T.Trainer(model, opt, graph_chunk=chunk)
+        loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, True, seed=5)
+        losses = []
+        for _ in range(2):
+            ep = tr.run_epoch(loader, T.Trainer.GRAPH)
+            assert ep["num_batches"] == 20
+            losses += list(ep["losses"])
+        assert opt.t() == 40
+        out.append((np.asarray(losses), [p.data() for p in model.parameters()]))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("n,batch", [(96, 96), (80, 128)])
 def test_full_batch_in_index_order_reads_the_dataset_in_place(n, batch):
     """one step per epoch over the whole dataset without shuffling: the graph path skips the (identity) batch
