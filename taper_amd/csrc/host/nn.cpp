@@ -984,6 +984,9 @@ EpochResult Trainer::evaluate(DataLoader &loader) {  // train.rs:147-172
     TH(th_fill_f32(ctx, st->d, 0.f, 4));
     std::vector<size_t> sizes;
     Tensor images, labels;
+    // nothing is differentiated here: a Sequential's conv front may take the launches that never write the full-resolution maps
+    // (conv + pool pairs, the one-launch conv chain from batch 96 up) exactly as inside a training step
+    PoolBiasScope pool_scope(dynamic_cast<Sequential *>(model.get()) != nullptr);
     while (loader.next(&images, &labels)) {
         Tape::reset();
         const size_t b = images.shape()[0];

@@ -332,10 +332,11 @@ def test_smoke_entry():
     g.smoke()
 
 
-@pytest.mark.parametrize("name,batch", [("mlp_baseline", 64), ("cnn_simple", 16)])
+@pytest.mark.parametrize("name,batch", [("mlp_baseline", 64), ("cnn_simple", 16), ("cnn_simple", 128), ("cnn_reference", 96)])
 def test_evaluate_matches_oracle(name, batch):
     """Trainer::evaluate (train.rs:147-172): per-batch loss / hit count from the device log (read once per pass)
-    against the oracle's forward + cross_entropy_loss + accuracy on the same batches, last partial batch included"""
+    against the oracle's forward + cross_entropy_loss + accuracy on the same batches, last partial batch included (CNNs: the whole
+    batches of 96+ go through the one-launch conv chain, the partial one layer by layer)"""
     import taper_amd as T
     H, Orc = backends.get("hip"), backends.get("oracle")
     Orc.set_zero_sentinel(True)
