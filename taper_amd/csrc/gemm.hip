@@ -342,7 +342,6 @@ struct TileGeo {
     static constexpr int R = TS / 32;      // float4 per thread per operand per tile
     static constexpr int QPR = TS / 4;     // float4 quads per k row of an m/n-contiguous tile
 };
-constexpr int TILE_MAX = TileGeo<128>::TILE_MAX;
 
 // Each thread stages 4 R floats per operand per tile, as R float4.
 // KC source: the tile is [TS rows][32 k]; float4 along k: 8 per row ->

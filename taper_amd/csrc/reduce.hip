@@ -39,13 +39,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
     const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
 #pragma unroll
-    for (int r = ty; r < 64; r += 4) {
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = ty + 4 * rr;
         const int i = i0 + r, j = j0 + tx;
         tile[r][tx] = (i < rows && j < cols) ? in[(long)i * cols + j] : 0.f;
     }
     __syncthreads();
 #pragma unroll
-    for (int r = ty; r < 64; r += 4) {
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = ty + 4 * rr;
         const int j = j0 + r, i = i0 + tx;
         if (i < rows && j < cols) {
             const long o = (long)j * rows + i;
