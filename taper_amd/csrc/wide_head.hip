@@ -35,7 +35,10 @@ struct WideArgs {
     int conv_c, conv_hw, fused;
 };
 
-constexpr int WH_TX = 2;   // 16-column tiles per workgroup
+#ifndef TH_WH_TX
+#define TH_WH_TX 2
+#endif
+constexpr int WH_TX = TH_WH_TX;   // 16-column tiles per workgroup (tuning probe: -DTH_WH_TX=1: 196 workgroups of 16 columns)
 constexpr int WH_NW = 16;  // waves per workgroup: 256 rows per pass (the chunks of a batch are a serial chain per wave, so go wide)
 
 __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
