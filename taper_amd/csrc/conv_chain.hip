@@ -251,9 +251,10 @@ __device__ __forceinline__ void chain_conv1_mfma(const float *img, const ChainW1
     int toff[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const int tap = 4 * s + g4, tt = tap < 9 ? tap : 8;      // (a finite operand for the zero weights)
+        const int tap = 4 * s + g4, tt = tap < 9 ? tap : 0;
         toff[s] = (tt / 3) * 30 + tt % 3;
     }
+    const bool pad_lane = 8 + g4 >= 9;     // k-step 2, lane groups 1..3: taps 9..11 carry zero weights
 #pragma unroll
     for (int k = 0; k < G::NSLOT; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -264,7 +265,7 @@ __device__ __forceinline__ void chain_conv1_mfma(const float *img, const ChainW1
         const float *px = img + (p / 28) * 30 + p % 28;
         float b[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) b[s] = px[toff[s]];
+        for (int s = 0; s < 3; ++s) b[s] = (s == 2 && pad_lane ? img : px)[toff[s]];   // padded taps read the halo corner (0.0): 0 * 0, never 0 * Inf
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (i < G::ND) {

@@ -141,3 +141,25 @@ def test_chain_without_counts_and_unsupported_stages(ctx):
     assert hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(st, C.c_void_p), ns) == 2
     assert hip.hip.th_conv_chain_supported(1, 32, 32, C.cast(st, C.c_void_p), ns) == 0
     assert hip.hip.th_conv_chain_supported(3, 28, 28, C.cast(st, C.c_void_p), ns) == 0
+
+
+@pytest.mark.parametrize("name", ["reference", "simple"])
+def test_chain_propagates_non_finite_pixels_like_the_layered_launches(ctx, name):
+    """Inf / NaN pixels: ReLU of NaN is 0 (`_mm_max_ps`, ops.rs:312-330), the pool's strict > never picks NaN (tensor.rs:1449-1461), and
+    conv1's zero-weight tap padding on the matrix cores must not turn an Inf pixel into NaN (0 * Inf): the chain's outputs -- values AND
+    where they are non-finite -- are those of the layer-by-layer launches"""
+    spec = REFERENCE if name == "reference" else SIMPLE
+    n = 256          # (the batch at which the layered launches take the same k order: bit-identical finite values)
+    params = _params(spec, 21)
+    x = _images(n, 5)
+    rng = np.random.default_rng(8)
+    for img in range(0, n, 3):
+        r, c = rng.integers(0, 28, 2)
+        x[img, 0, r, c] = [np.inf, -np.inf, np.nan][img % 3]
+    x[1, 0, 27, 27] = np.inf          # the last pixel of an image: the single tile of waves 0 / 1
+    ly, lcnt, hw = _hip_layered(ctx, x, spec, params)
+    y, cnt, hw2, c_last = _hip_chain(ctx, x, spec, params)
+    a, b = ctx.download(y, (n, c_last, hw, hw)), ctx.download(ly, (n, c_last, hw, hw))
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    # (ReLU turns NaN into 0 at every layer, so the planted values need not survive to the last stage: the comparison above is the point)
