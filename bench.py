@@ -697,7 +697,7 @@ def main():
         run_steps(T, trainer, loader, record_steps)
     # ... and a run length that is no single ladder size (the contract's K = 20 = 16 + 4) gets ONE graph of exactly K steps, recorded by
     # the first call that asks for K steps: that call is made here, untimed, and counted in graph_record_steps as well
-    k_tail = args.steps % 128
+    k_tail = args.steps % (args.graph_chunk or 128)
     if k_tail > 2 and k_tail & (k_tail - 1):
         run_steps(T, trainer, loader, args.steps)
         record_steps += args.steps

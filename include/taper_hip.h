@@ -239,6 +239,28 @@ int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_
                 float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
                 const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse);
 
+/* A three-layer classifier -- Linear + ReLU, Linear + ReLU, Linear, softmax cross-entropy (the tail of examples/train_mnist_cnn.rs:53-61
+ * behind the global average pool; examples/train_mnist.rs:40-48 behind the images) -- forward AND backward in TWO launches: everything but
+ * the parameter gradients is row-parallel (nn.rs:54-60, loss.rs:101-195, ops.rs:254-265, 358-369), so launch 1 walks 16-row blocks through
+ * the three forward and three backward products with the activations in LDS (and opens the optimizer step: *d_tick += 1, optim.rs:84, when
+ * d_tick is given), launch 2 forms dW_l = dZ_l^T . A_l and db_l (ops.rs:266-294, tensor.rs:686-691) for all three layers with Adam
+ * (optim.rs:99-110) in the epilogues where w_fuse / b_fuse are given -- no workgroup of that launch reads a parameter -- plus the loss
+ * (loss.rs:164), the hit count (loss.rs:283) and the step log (th_log_step).  d_dx[B,in] (nullable): the gradient of the input, overwritten.
+ * layers[l]: d_w [out][in] (16-byte aligned), d_b [out] (nullable), d_dw / d_db overwritten (nullable: not computed).
+ * th_mlp3_supported: batch, in_features and both hidden sizes multiples of 16 (in <= 1024, hidden <= 256), classes <= 16. */
+typedef struct th_mlp3_layer {
+    const float *d_w, *d_b;
+    float *d_dw, *d_db;
+    const th_adam_fuse *w_fuse, *b_fuse;
+    int out_features;
+} th_mlp3_layer;
+int th_mlp3_supported(int batch, int in_features, int h1, int h2, int classes);
+int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batch, int in_features, const th_mlp3_layer *layers,
+                 float *d_dx, float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state,
+                 int64_t advance, int32_t *d_tick);
+/* Test hook: how many th_mlp3_xent calls this thread has enqueued (the parity tests assert which form a Trainer step took). */
+int th_debug_mlp3_calls(int64_t *out);
+
 /* ---- element-wise: src/ops.rs:8-120,377-496; src/tensor.rs:36-161 ----- */
 int th_add(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
 int th_sub(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);

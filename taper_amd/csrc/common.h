@@ -45,6 +45,14 @@ constexpr int kNumXCD = 8;
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Workgroup barrier for LDS hand-offs only: global loads and stores in flight stay in flight across it -- __syncthreads() waits for
+// them (its fence covers every address space), which exposes a global round trip at every barrier of a multi-stage kernel.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Memory-bound grid: cap at 8 blocks/CU and grid-stride the rest.
 static inline int ew_grid(size_t n_items, int block) {
     long g = (long)((n_items + block - 1) / block);

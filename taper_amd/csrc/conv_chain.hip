@@ -67,13 +67,8 @@ template <int S, int C_OUT> struct ChainGeo {
     __device__ static bool slot_live(int w, int k) { return k < 2 * ND || has_single(w); }
 };
 
-// Barrier for LDS hand-offs only: the weight loads in flight (global memory nobody writes) stay in flight across it -- __syncthreads() would
-// wait for them (its fence covers every address space), exposing a global round trip at each of the chain's barriers.
-__device__ __forceinline__ void chain_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
+// (barriers: lds_barrier() of common.h -- the weight loads in flight, global memory nobody writes, stay in flight across them)
+__device__ __forceinline__ void chain_sync() { lds_barrier(); }
 
 // weight operands of pass cb (8 input channels, 18 k-steps) of a layer's [9 C_IN][C_OUT] slab: k-step s wants row (cb + 4 (s / 9) + g4) * 9 + s % 9,
 // columns 16 chA + l16 and 16 chB + l16 -- two dwords per lane and k-step, requested a pass ahead (the first pass of a layer: before the

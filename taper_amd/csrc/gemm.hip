@@ -256,6 +256,63 @@ struct LinearBwdArgs {
     AdamSlices extra;
 };
 
+// bias gradient role of a Linear layer's backward: db[c] (+)= sum_b dZ[b][c] for 64 columns, Adam in the epilogue when asked for
+template <bool MASKED>
+__device__ __forceinline__ void linear_db_role(const LinearBwdArgs &q, int blk, float (*red)[64][4]) {
+    // bias gradient: 4 waves stride the batch rows, lanes are consecutive columns
+    float(*part)[64] = reinterpret_cast<float(*)[64]>(&red[0][0][0]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blk * 64 + lane;
+    // epilogue operands are requested before the column sum, not after it (one round trip, not two)
+    const bool own = wave == 0 && c < q.out_f, fuse = own && q.db_adam.p;
+    float pv = 0.f, mv = 0.f, vv = 0.f, step = 0.f, old = 0.f;
+    if (fuse) {
+        pv = q.db_adam.p[c];
+        mv = q.db_adam.m[c];
+        vv = q.db_adam.v[c];
+        step = adam_dev_step(q.db_adam);
+    }
+    if (own && q.db_accum) old = q.db[c];
+    float s = 0.f;
+    if (c < q.out_f) {
+        // 16 independent loads in flight per lane: at batch 1024 this role (256 rows per wave) was the
+        // kernel's long pole with 4
+        int r = wave;
+        for (; r + 60 < q.batch; r += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const long idx = (long)(r + 4 * u) * q.out_f + c;
+                v[u] = q.dy[idx];
+                if (MASKED) v[u] = q.ymask[idx] > 0.f ? v[u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; r < q.batch; r += 4) {
+            const long idx = (long)r * q.out_f + c;
+            float v = q.dy[idx];
+            if (MASKED) v = q.ymask[idx] > 0.f ? v : 0.f;
+            s += v;
+        }
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (own) {
+        const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        const float out = q.db_accum ? old + tot : tot;
+        q.db[c] = out;
+        if (fuse) {   // optim.rs:99-110
+            const float gv = out + q.db_adam.wd * pv;
+            const float mn = q.db_adam.beta1 * mv + (1.0f - q.db_adam.beta1) * gv;
+            const float vn = q.db_adam.beta2 * vv + (1.0f - q.db_adam.beta2) * gv * gv;
+            q.db_adam.m[c] = mn;
+            q.db_adam.v[c] = vn;
+            q.db_adam.p[c] = pv - step * mn / (sqrtf(vn) + q.db_adam.eps);
+        }
+    }
+}
+
 template <bool MASKED>
 __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
     __shared__ float red[4][64][4];
@@ -272,58 +329,57 @@ __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
     } else if (bid >= q.n_dw + q.n_dx + q.n_db) {
         adam_slices_block(q.extra, bid - q.n_dw - q.n_dx - q.n_db);
     } else {
-        // bias gradient: 4 waves stride the batch rows, lanes are consecutive columns
-        float(*part)[64] = reinterpret_cast<float(*)[64]>(&red[0][0][0]);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int c = (bid - q.n_dw - q.n_dx) * 64 + lane;
-        // epilogue operands are requested before the column sum, not after it (one round trip, not two)
-        const bool own = wave == 0 && c < q.out_f, fuse = own && q.db_adam.p;
-        float pv = 0.f, mv = 0.f, vv = 0.f, step = 0.f, old = 0.f;
-        if (fuse) {
-            pv = q.db_adam.p[c];
-            mv = q.db_adam.m[c];
-            vv = q.db_adam.v[c];
-            step = adam_dev_step(q.db_adam);
-        }
-        if (own && q.db_accum) old = q.db[c];
-        float s = 0.f;
-        if (c < q.out_f) {
-            // 16 independent loads in flight per lane: at batch 1024 this role (256 rows per wave) was the
-            // kernel's long pole with 4
-            int r = wave;
-            for (; r + 60 < q.batch; r += 64) {
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const long idx = (long)(r + 4 * u) * q.out_f + c;
-                    v[u] = q.dy[idx];
-                    if (MASKED) v[u] = q.ymask[idx] > 0.f ? v[u] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s += v[u];
+        linear_db_role<MASKED>(q, bid - q.n_dw - q.n_dx, red);
+    }
+}
+
+// ---- th_mlp3_xent, launch 2 (mlp3.hip): the parameter gradients of a three-layer classifier in ONE launch -- three dW + db jobs of
+// linear_bwd_small (the rows launch wrote the ReLU-masked dZ of every layer: no mask, no dX here) and a lead workgroup that adds the per-block
+// loss / hit partial sums in block order and writes the loss, the count and the step log (loss.rs:164, 283; train.rs:117).  Every dW / db
+// epilogue may carry its Adam update: nobody reads a parameter in this launch.
+struct Mlp3GradArgs {
+    LinearBwdArgs job[3];
+    int first[4];              // block ranges of the jobs; block first[3] is the lead
+    const float *part;         // [n_blk][2]: sum of the rows' NLL, hits
+    int n_blk, batch;
+    float *loss, *ncorrect, *metrics;
+    int64_t capacity;
+    int64_t *state;
+    int64_t advance;
+};
+
+__global__ __launch_bounds__(256) void mlp3_grads_kernel(Mlp3GradArgs a) {
+    __shared__ float red[4][64][4];
+    const int bid = blockIdx.x;
+    if (bid >= a.first[3]) {
+        if (threadIdx.x == 0) {
+            float n = 0.f, h = 0.f;
+            for (int b = 0; b < a.n_blk; ++b) {
+                n += a.part[2 * b];
+                h += a.part[2 * b + 1];
             }
-            for (; r < q.batch; r += 4) {
-                const long idx = (long)r * q.out_f + c;
-                float v = q.dy[idx];
-                if (MASKED) v = q.ymask[idx] > 0.f ? v : 0.f;
-                s += v;
-            }
-        }
-        part[wave][lane] = s;
-        __syncthreads();
-        if (own) {
-            const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-            const float out = q.db_accum ? old + tot : tot;
-            q.db[c] = out;
-            if (fuse) {   // optim.rs:99-110
-                const float gv = out + q.db_adam.wd * pv;
-                const float mn = q.db_adam.beta1 * mv + (1.0f - q.db_adam.beta1) * gv;
-                const float vn = q.db_adam.beta2 * vv + (1.0f - q.db_adam.beta2) * gv * gv;
-                q.db_adam.m[c] = mn;
-                q.db_adam.v[c] = vn;
-                q.db_adam.p[c] = pv - step * mn / (sqrtf(vn) + q.db_adam.eps);
+            const float l = n / (float)a.batch;   // loss.rs:164
+            a.loss[0] = l;
+            if (a.ncorrect) a.ncorrect[0] = h;
+            if (a.metrics) {                      // the step log of th_log_step
+                const int64_t s0 = a.state[0], s1 = a.state[1];
+                const int64_t slot = s0 < a.capacity ? s0 : s0 % a.capacity;
+                a.metrics[2 * slot] = l;
+                a.metrics[2 * slot + 1] = h;
+                a.state[0] = s0 + 1;
+                a.state[1] = s1 + a.advance;
             }
         }
+        return;
+    }
+    const int j = bid >= a.first[2] ? 2 : (bid >= a.first[1] ? 1 : 0);
+    const LinearBwdArgs &q = a.job[j];
+    const int b = bid - a.first[j];
+    if (b < q.n_dw) {
+        const int t = (b & 7) * (q.n_dw >> 3) + (b >> 3);
+        if (t < q.dw_tiles) small16_body<false, false, 4, false>(q.dw, t % q.dw_tiles_m, t / q.dw_tiles_m, 0, red);
+    } else {
+        linear_db_role<false>(q, b - q.n_dw, red);
     }
 }
 
@@ -701,6 +757,41 @@ int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, co
     TH_GEMM_CASE(false, false)
 #undef TH_GEMM_CASE
     return 3;
+}
+
+// th_mlp3_xent's second launch: layer l: dW_l[out][in] = dZ_l^T . A_l, db_l = column sums of dZ_l (dZ already masked), Adam fused where given
+int mlp3_grads_launch(th_ctx *ctx, const float *const dz[3], const float *const act[3], float *const dw[3], float *const db[3],
+                      const int out_f[3], const int in_f[3], const th_adam_fuse *const wf[3], const th_adam_fuse *const bf[3], int batch,
+                      const float *part, int n_blk, float *loss, float *ncorrect, float *metrics, int64_t capacity, int64_t *state,
+                      int64_t advance) {
+    Mlp3GradArgs a{};
+    int blocks = 0;
+    for (int l = 0; l < 3; ++l) {
+        LinearBwdArgs &q = a.job[l];
+        const int tm = ceil_div(out_f[l], 16), tn = ceil_div(in_f[l], 16);
+        q.dw_kz = 1;
+        q.dw_tiles = dw[l] ? tm * tn : 0;
+        q.n_dw = (q.dw_tiles + 7) & ~7;
+        q.dw_tiles_m = tm;
+        // dW = dZ^T . A : op(A)[i = o, k = b] = dZ[b * out + o] (rs 1, cs out); op(B)[k = b, j] = A[b * in + j]
+        q.dw = SmallArgs{dz[l], nullptr, act[l], dw[l], nullptr, out_f[l], in_f[l], batch, 1, out_f[l], in_f[l], 1, (batch + 15) / 16 * 16, 0, 0,
+                         make_ep(1.0f, 0.0f)};
+        q.dw.ep.adam = make_adam_dev(dw[l] ? wf[l] : nullptr);
+        q.db_adam = make_adam_dev(db[l] ? bf[l] : nullptr);
+        q.dy = dz[l];
+        q.db = db[l];
+        q.batch = batch;
+        q.out_f = out_f[l];
+        q.n_db = db[l] ? ceil_div(out_f[l], 64) : 0;
+        a.first[l] = blocks;
+        blocks += q.n_dw + q.n_db;
+    }
+    a.first[3] = blocks;
+    a.part = part; a.n_blk = n_blk; a.batch = batch;
+    a.loss = loss; a.ncorrect = ncorrect; a.metrics = metrics; a.capacity = capacity; a.state = state; a.advance = advance;
+    hipLaunchKernelGGL(mlp3_grads_kernel, dim3(blocks + 1), dim3(256), 0, ctx->stream, a);
+    TH_LAUNCH_CHECK();
+    return 0;
 }
 
 // First half of th_linear_xent_wide: the K slices of logits = X . W^T (no bias, no reduce) into a pool workspace

@@ -305,6 +305,75 @@ Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b
     return loss;
 }
 
+// Linear + ReLU, Linear + ReLU, Linear, softmax cross-entropy -- the classifier of examples/train_mnist_cnn.rs:53-61 and the whole model of
+// examples/train_mnist.rs:40-48 -- forward and backward in two launches (th_mlp3_xent): a row-parallel one (forward, loss terms, the
+// gradients of the activations down to dX) and one for every parameter gradient with Adam in the epilogues.  No launch reads a
+// parameter another one of the step updates, so nothing is deferred; the first launch opens the optimizer step.
+bool mlp3_supported(const Tensor &x, const Tensor (&w)[3], const Tensor (&b)[3]) {
+    if (x.shape().size() != 2) return false;
+    size_t in_f = x.shape()[1];
+    for (int l = 0; l < 3; ++l) {
+        if (w[l].shape().size() != 2 || w[l].shape()[1] != in_f) return false;
+        if (!w[l].get_requires_grad() || w[l].has_grad()) return false;
+        if (!b[l].defined() || b[l].shape() != Shape{w[l].shape()[0]} || !b[l].get_requires_grad() || b[l].has_grad()) return false;
+        if (((uintptr_t)w[l].dptr() & 15) != 0) return false;
+        in_f = w[l].shape()[0];
+    }
+    if (x.get_requires_grad() && (x.has_grad() || x.grad_->buf_is_arena)) return false;   // dX is written, never accumulated
+    if (((uintptr_t)x.dptr() & 15) != 0) return false;
+    return th_mlp3_supported((int)x.shape()[0], (int)x.shape()[1], (int)w[0].shape()[0], (int)w[1].shape()[0], (int)w[2].shape()[0]) != 0;
+}
+
+Tensor mlp3_cross_entropy(const Tensor &x, const Tensor (&w)[3], const Tensor (&b)[3], const Tensor &targets, Tensor *n_correct_out,
+                          const StepLogSink *log) {
+    TAPER_ASSERT(mlp3_supported(x, w, b), "mlp3_cross_entropy: unsupported shapes / gradient state");
+    TAPER_ASSERT(targets.shape()[0] == x.shape()[0], "Batch sizes must match");
+    th_ctx *ctx = Device::ctx();
+    Adam *fa = FusedAdamScope::active();
+    if (fa && fa->has_deferred()) fa->flush_deferred();   // updates an earlier (other) step form left behind: with their own counter
+    Tensor loss = Tensor::empty({1});
+    float *nc = nullptr;
+    if (n_correct_out) {
+        *n_correct_out = Tensor::empty({1});
+        nc = n_correct_out->dptr();
+    }
+    auto slot = [](const Tensor &p) -> float * {
+        if (!p.grad_->buf) p.grad_->buf = Buffer::alloc(p.len());
+        p.grad_->known_zero = false;
+        return p.grad_->buf->d;
+    };
+    th_mlp3_layer layers[3];
+    th_adam_fuse wf[3], bf[3];
+    for (int l = 0; l < 3; ++l) {
+        layers[l] = th_mlp3_layer{w[l].dptr(), b[l].dptr(), slot(w[l]), slot(b[l]), nullptr, nullptr, (int)w[l].shape()[0]};
+        if (fa) {
+            if (fa->fuse_for(w[l], &wf[l])) layers[l].w_fuse = &wf[l];
+            if (fa->fuse_for(b[l], &bf[l])) layers[l].b_fuse = &bf[l];
+        }
+    }
+    const bool need_dx = x.get_requires_grad();
+    std::shared_ptr<Buffer> dx = need_dx ? Buffer::alloc(x.len()) : nullptr;
+    TH(th_mlp3_xent(ctx, x.dptr(), targets.dptr(), (int)x.shape()[0], (int)x.shape()[1], layers, dx ? dx->d : nullptr, loss.dptr(), nc,
+                    log ? log->d_metrics : nullptr, log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0,
+                    fa ? fa->d_tick() : nullptr));
+    loss.set_requires_grad(true);
+    std::vector<Tensor> params{w[0], b[0], w[1], b[1], w[2], b[2]};
+    Tensor out = loss, xin = x;
+    Tape::push(loss, true, [params, out, xin, dx]() {
+        if (!out.has_grad()) return;
+        // the gradients were produced by the forward launches for an upstream grad of exactly 1
+        TAPER_ASSERT(out.grad_->shared_const, "mlp3_cross_entropy: only loss.backward() from the root is supported");
+        if (dx) {
+            TAPER_ASSERT(!xin.has_grad() && !xin.grad_->buf_is_arena, "mlp3_cross_entropy: input already has a gradient");
+            xin.grad_->buf = dx;
+            xin.grad_->has = true;
+            xin.grad_->shared_const = false;
+        }
+        for (const Tensor &p : params) p.grad_->has = true;
+    });
+    return loss;
+}
+
 float accuracy(const Tensor &pred, const Tensor &targets) {  // loss.rs:271-290
     TAPER_ASSERT(pred.shape()[0] == targets.shape()[0], "Batch sizes must match");
     TAPER_ASSERT(pred.shape().size() == 2, "accuracy: predictions must be [B,C]");
@@ -398,6 +467,12 @@ Tensor AvgPool2d::forward(const Tensor &x) const {  // nn.rs:593-608
 Tensor AdaptiveAvgPool2d::forward(const Tensor &x) const {  // nn.rs:670-686
     const int kh = (int)x.shape()[2] / output_size.first, kw = (int)x.shape()[3] / output_size.second;
     return x.avg_pool2d({kh, kw}, {kh, kw}, {0, 0});
+}
+
+// TAPER_MLP3=0: three-layer classifiers keep the launch-per-layer forms (measurement probe; default: th_mlp3_xent, two launches)
+static bool mlp3_fuse() {
+    static const bool on = [] { const char *e = std::getenv("TAPER_MLP3"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 // TAPER_CONV_CHAIN=0: Trainer steps launch the convolutional front layer by layer (measurement probe; default: one launch where compiled)
@@ -1038,7 +1113,29 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
     const size_t nl = seq ? seq->layers.size() : 0;
     Linear *hidden = (last && fuse_head >= 2 && seq->fuse && nl >= 3 && dynamic_cast<ReLU *>(seq->layers[nl - 2].get()))
                          ? dynamic_cast<Linear *>(seq->layers[nl - 3].get()) : nullptr;
-    if (last) {
+    // Linear + ReLU + Linear + ReLU + Linear + cross-entropy: two launches for the whole classifier (th_mlp3_xent)
+    Linear *hidden0 = (hidden && mlp3_fuse() && nl >= 5 && dynamic_cast<ReLU *>(seq->layers[nl - 4].get()))
+                          ? dynamic_cast<Linear *>(seq->layers[nl - 5].get()) : nullptr;
+    if (hidden0) {
+        const Tensor w3[3] = {hidden0->weight, hidden->weight, last->weight}, b3[3] = {hidden0->bias, hidden->bias, last->bias};
+        // (shapes first: the prefix is only run once the form of the step is known)
+        const size_t in_f = hidden0->weight.shape()[1];
+        if (th_mlp3_supported((int)batch, (int)in_f, (int)w3[0].shape()[0], (int)w3[1].shape()[0], (int)w3[2].shape()[0])) {
+            Tensor xh = seq->forward_prefix(xin, nl - 5);
+            if (mlp3_supported(xh, w3, b3)) {
+                loss = mlp3_cross_entropy(xh, w3, b3, y, &ncorrect, &sink);
+                used_head = true;
+            } else {
+                // (cannot happen for parameters homed in this Trainer's optimizer; keep the step correct anyway)
+                if (adam) adam->flush_deferred();
+                Tensor h = xh;
+                for (size_t i = nl - 5; i < nl; ++i) h = seq->layers[i]->forward(h);
+                loss = cross_entropy_loss(h, y, &ncorrect, &sink);
+                used_head = true;
+            }
+        }
+    }
+    if (last && !used_head) {
         Tensor h;
         if (hidden) {   // Linear + ReLU + Linear + cross-entropy: two launches per step
             Tensor xh = seq->forward_prefix(xin, nl - 3);

@@ -238,6 +238,10 @@ Tensor linear_cross_entropy_wide(const Tensor &h, const Tensor &weight, const Te
 // previous step's deferred Adam updates and opens this step) and th_mlp_tail (head + the hidden layer's whole
 // backward + its Adam update; with an input that requires a gradient also dX, whole tiles only).  Same contract as
 // linear_cross_entropy.
+// three-layer classifier (Linear + ReLU, Linear + ReLU, Linear) + cross-entropy, forward and backward in two launches (th_mlp3_xent)
+bool mlp3_supported(const Tensor &x, const Tensor (&w)[3], const Tensor (&b)[3]);
+Tensor mlp3_cross_entropy(const Tensor &x, const Tensor (&w)[3], const Tensor (&b)[3], const Tensor &targets, Tensor *n_correct_out,
+                          const StepLogSink *log);
 bool mlp_tail_supported(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2);
 Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
                               const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log);

@@ -28,6 +28,12 @@ class WideFuse(C.Structure):
     _fields_ = [("w", AdamFuse), ("b", AdamFuse), ("conv_b", AdamFuse), ("d_conv_gb", C.c_void_p), ("conv_c", C.c_int), ("conv_hw", C.c_int)]
 
 
+class Mlp3Layer(C.Structure):
+    """include/taper_hip.h: th_mlp3_layer"""
+    _fields_ = [("d_w", C.c_void_p), ("d_b", C.c_void_p), ("d_dw", C.c_void_p), ("d_db", C.c_void_p), ("w_fuse", C.c_void_p),
+                ("b_fuse", C.c_void_p), ("out_features", C.c_int)]
+
+
 class ConvStage(C.Structure):
     """include/taper_hip.h: th_conv_stage"""
     _fields_ = [("d_w", C.c_void_p), ("d_bias", C.c_void_p), ("c_out", C.c_int), ("post", C.c_int)]

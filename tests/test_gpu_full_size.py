@@ -195,6 +195,7 @@ def _training_steps_parity(T, name, mode):
     tr = T.Trainer(hm, hopt, sample_shape=(1, 28, 28))
     x, y = backends.mnist_like(rng, steps * batch)
     ref = [om.train_step(oopt, x[s * batch:(s + 1) * batch], y[s * batch:(s + 1) * batch], (batch, 1, 28, 28)) for s in range(steps)]
+    calls0 = mlp3_calls()
     if mode != "eager":
         ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False), T.Trainer.GRAPH)
         losses, ncorrect = ep["losses"], ep["ncorrect"]
@@ -203,6 +204,8 @@ def _training_steps_parity(T, name, mode):
             assert cfg["dma"] == 6 and cfg["ct"] == (1 if name == "cnn_reference" else 2), cfg   # the conv chain ran in this process's step
         else:
             assert cfg["ct"] in (1, 2) and cfg["dma"] in (2, 3, 4, 5), cfg   # the image-resident matrix-core conv ran in this process's step
+        if name == "cnn_reference":     # its three-layer classifier took th_mlp3_xent (two launches) in the captured step
+            assert mlp3_calls() > calls0
     else:
         losses, ncorrect = [], []
         for s in range(steps):
@@ -241,6 +244,13 @@ def test_conv_chain_step_is_bit_identical_to_the_layered_step(name):
     np.testing.assert_array_equal(out[0][0], out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         np.testing.assert_array_equal(a, b)
+
+
+def mlp3_calls():
+    from taper_amd import hip
+    n = C.c_int64(0)
+    hip.hip.th_debug_mlp3_calls(C.byref(n))
+    return n.value
 
 
 def last_conv_config_host():
