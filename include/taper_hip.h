@@ -254,10 +254,19 @@ typedef struct th_mlp3_layer {
     const th_adam_fuse *w_fuse, *b_fuse;
     int out_features;
 } th_mlp3_layer;
+/* gap (nullable): d_x[B,in] are the plane means of a bias-only Conv2dReLU -> global average pool (th_conv3x3_gap_fwd / th_conv_chain_fwd)
+ * with d_cnt[B,in] outputs > 0 per plane of hw elements: launch 2 then also forms that conv's bias gradient
+ * d_gb[ch] = sum_n (dX[n][ch] / hw) * cnt[n][ch] (th_bias_grad_counts_adam's formula; needs d_dx) with Adam where b_fuse is given. */
+typedef struct th_mlp3_gap {
+    const float *d_cnt;
+    float *d_gb;
+    int hw;
+    const th_adam_fuse *b_fuse;
+} th_mlp3_gap;
 int th_mlp3_supported(int batch, int in_features, int h1, int h2, int classes);
 int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batch, int in_features, const th_mlp3_layer *layers,
                  float *d_dx, float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state,
-                 int64_t advance, int32_t *d_tick);
+                 int64_t advance, int32_t *d_tick, const th_mlp3_gap *gap);
 /* Test hook: how many th_mlp3_xent calls this thread has enqueued (the parity tests assert which form a Trainer step took). */
 int th_debug_mlp3_calls(int64_t *out);
 

@@ -339,7 +339,13 @@ __global__ __launch_bounds__(256) void linear_bwd_small(LinearBwdArgs q) {
 // epilogue may carry its Adam update: nobody reads a parameter in this launch.
 struct Mlp3GradArgs {
     LinearBwdArgs job[3];
-    int first[4];              // block ranges of the jobs; block first[3] is the lead
+    int first[5];              // block ranges of the jobs, then of the gap role; block first[4] is the lead
+    // gap role (optional): the input rows are the plane means of a bias-only Conv2dReLU + global average pool; its bias gradient
+    // db[ch] = sum_n (dX[n][ch] / hw) * cnt[n][ch] (th_bias_grad_counts_adam's formula) and Adam, 16 channels per workgroup
+    const float *gap_dx, *gap_cnt;
+    float *gap_db;
+    int gap_c, gap_hw;
+    AdamDev gap_adam;
     const float *part;         // [n_blk][2]: sum of the rows' NLL, hits
     int n_blk, batch;
     float *loss, *ncorrect, *metrics;
@@ -351,7 +357,7 @@ struct Mlp3GradArgs {
 __global__ __launch_bounds__(256) void mlp3_grads_kernel(Mlp3GradArgs a) {
     __shared__ float red[4][64][4];
     const int bid = blockIdx.x;
-    if (bid >= a.first[3]) {
+    if (bid >= a.first[4]) {
         if (threadIdx.x == 0) {
             float n = 0.f, h = 0.f;
             for (int b = 0; b < a.n_blk; ++b) {
@@ -369,6 +375,26 @@ __global__ __launch_bounds__(256) void mlp3_grads_kernel(Mlp3GradArgs a) {
                 a.state[0] = s0 + 1;
                 a.state[1] = s1 + a.advance;
             }
+        }
+        return;
+    }
+    if (bid >= a.first[3]) {
+        float(*sh)[17] = reinterpret_cast<float(*)[17]>(&red[0][0][0]);
+        const int q = threadIdx.x & 15, r = threadIdx.x >> 4, ch = (bid - a.first[3]) * 16 + q;
+        float s = 0.f;
+        if (ch < a.gap_c) {
+#pragma unroll 4
+            for (int b = r; b < a.batch; b += 16) s += a.gap_dx[(long)b * a.gap_c + ch] / (float)a.gap_hw * a.gap_cnt[(long)b * a.gap_c + ch];
+        }
+        sh[r][q] = s;
+        __syncthreads();
+        if (threadIdx.x < 16 && ch < a.gap_c) {
+            float tot = sh[0][q];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) tot += sh[i][q];
+            a.gap_db[ch] = tot;
+            if (a.gap_adam.p) adam_update(a.gap_adam.p, a.gap_adam.m, a.gap_adam.v, ch, tot, adam_dev_step(a.gap_adam), a.gap_adam.beta1,
+                                          a.gap_adam.beta2, a.gap_adam.eps, a.gap_adam.wd);
         }
         return;
     }
@@ -763,7 +789,7 @@ int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, co
 int mlp3_grads_launch(th_ctx *ctx, const float *const dz[3], const float *const act[3], float *const dw[3], float *const db[3],
                       const int out_f[3], const int in_f[3], const th_adam_fuse *const wf[3], const th_adam_fuse *const bf[3], int batch,
                       const float *part, int n_blk, float *loss, float *ncorrect, float *metrics, int64_t capacity, int64_t *state,
-                      int64_t advance) {
+                      int64_t advance, const float *gap_dx, const th_mlp3_gap *gap) {
     Mlp3GradArgs a{};
     int blocks = 0;
     for (int l = 0; l < 3; ++l) {
@@ -787,6 +813,12 @@ int mlp3_grads_launch(th_ctx *ctx, const float *const dz[3], const float *const 
         blocks += q.n_dw + q.n_db;
     }
     a.first[3] = blocks;
+    if (gap && gap->d_cnt) {
+        a.gap_dx = gap_dx; a.gap_cnt = gap->d_cnt; a.gap_db = gap->d_gb; a.gap_c = in_f[0]; a.gap_hw = gap->hw;
+        a.gap_adam = make_adam_dev(gap->b_fuse);
+        blocks += ceil_div(a.gap_c, 16);
+    }
+    a.first[4] = blocks;
     a.part = part; a.n_blk = n_blk; a.batch = batch;
     a.loss = loss; a.ncorrect = ncorrect; a.metrics = metrics; a.capacity = capacity; a.state = state; a.advance = advance;
     hipLaunchKernelGGL(mlp3_grads_kernel, dim3(blocks + 1), dim3(256), 0, ctx->stream, a);

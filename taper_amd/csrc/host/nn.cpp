@@ -353,13 +353,28 @@ Tensor mlp3_cross_entropy(const Tensor &x, const Tensor (&w)[3], const Tensor (&
     }
     const bool need_dx = x.get_requires_grad();
     std::shared_ptr<Buffer> dx = need_dx ? Buffer::alloc(x.len()) : nullptr;
+    // x = the plane means of a bias-only Conv2dReLU + global average pool (GradSlot::gapfin_*): that conv's bias gradient and update
+    // ride in the gradient launch -- it needs dX and the counts, nothing else
+    th_mlp3_gap gap{};
+    th_adam_fuse gf{};
+    std::shared_ptr<GradSlot> gap_slot;
+    if (need_dx && PoolBiasScope::active() && x.grad_->gapfin_cnt && x.grad_->gapfin_bias && !x.grad_->gapfin_bias->has &&
+        x.grad_->gapfin_cnt->n == x.len()) {
+        gap_slot = x.grad_->gapfin_bias;
+        if (!gap_slot->buf) gap_slot->buf = Buffer::alloc(x.shape()[1]);
+        gap_slot->known_zero = false;
+        gap.d_cnt = x.grad_->gapfin_cnt->d;
+        gap.d_gb = gap_slot->buf->d;
+        gap.hw = x.grad_->gapfin_hw;
+        if (fa && fa->fuse_for_slot(gap_slot, &gf)) gap.b_fuse = &gf;
+    }
     TH(th_mlp3_xent(ctx, x.dptr(), targets.dptr(), (int)x.shape()[0], (int)x.shape()[1], layers, dx ? dx->d : nullptr, loss.dptr(), nc,
                     log ? log->d_metrics : nullptr, log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0,
-                    fa ? fa->d_tick() : nullptr));
+                    fa ? fa->d_tick() : nullptr, gap_slot ? &gap : nullptr));
     loss.set_requires_grad(true);
     std::vector<Tensor> params{w[0], b[0], w[1], b[1], w[2], b[2]};
     Tensor out = loss, xin = x;
-    Tape::push(loss, true, [params, out, xin, dx]() {
+    Tape::push(loss, true, [params, out, xin, dx, gap_slot]() {
         if (!out.has_grad()) return;
         // the gradients were produced by the forward launches for an upstream grad of exactly 1
         TAPER_ASSERT(out.grad_->shared_const, "mlp3_cross_entropy: only loss.backward() from the root is supported");
@@ -370,6 +385,10 @@ Tensor mlp3_cross_entropy(const Tensor &x, const Tensor (&w)[3], const Tensor (&
             xin.grad_->shared_const = false;
         }
         for (const Tensor &p : params) p.grad_->has = true;
+        if (gap_slot) {
+            gap_slot->has = true;
+            xin.grad_->gapfin_done = true;
+        }
     });
     return loss;
 }

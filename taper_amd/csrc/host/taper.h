@@ -88,6 +88,13 @@ struct GradSlot {
     std::shared_ptr<GradSlot> colsum_bias;   // that conv's bias (grad slot) and geometry: the head can finish it in its own launch (th_linear_xent_wide_fused)
     int colsum_c = 0, colsum_hw = 0;
     bool colsum_done = false;                // ... and did
+    // Trainer-internal peephole (PoolBiasScope): the tensor is the (flattened) [n, c] output of a bias-only Conv2dReLU + GLOBAL AVERAGE pool:
+    // {counts of outputs > 0 per plane, that conv's bias slot, plane size} -- a classifier launch that forms the tensor's gradient anyway
+    // (th_mlp3_xent) can finish the conv's bias there and say so
+    std::shared_ptr<Buffer> gapfin_cnt;
+    std::shared_ptr<GradSlot> gapfin_bias;
+    int gapfin_hw = 0;
+    bool gapfin_done = false;
 };
 
 struct ConvStage;   // one Conv2dReLU row of a conv chain (below)

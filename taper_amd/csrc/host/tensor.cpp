@@ -586,8 +586,17 @@ Tensor Tensor::reshape(const Shape &s) const {  // tensor.rs:803-840
             out.grad_->colsum_c = grad_->colsum_c;
             out.grad_->colsum_hw = grad_->colsum_hw;
         }
+        if (PoolBiasScope::active() && grad_->gapfin_cnt && !s.empty() && !shape_.empty() && s[0] == shape_[0]) {
+            out.grad_->gapfin_cnt = grad_->gapfin_cnt;
+            out.grad_->gapfin_bias = grad_->gapfin_bias;
+            out.grad_->gapfin_hw = grad_->gapfin_hw;
+        }
         Tensor in = *this, r = out;
         Tape::push(out, true, [in, r]() {
+            if (r.grad_->gapfin_done) {   // the classifier finished the conv bias in its own launch (the gradient itself travels on as usual)
+                r.grad_->gapfin_done = false;
+                in.grad_->gapfin_done = true;
+            }
             if (r.grad_->colsum_done) {   // the classifier head finished the conv bias in its own launch
                 in.grad_->colsum_done = true;
                 return;
@@ -909,10 +918,19 @@ static void push_pooled_conv_bias_node(Tensor &out, const Tensor &bias, int n, i
 
 // tape node of a bias-only Conv2dReLU -> global average pool: `out` = plane means, cnt = outputs > 0 per plane
 static void push_gap_conv_bias_node(Tensor &out, const Tensor &bias, const std::shared_ptr<Buffer> &cnt, int n, int c_out, int hw) {
-    {   // faithful mode (Q2): the bias is the pair's only trainable input
+    {
         out.requires_grad_ = true;
+        if (PoolBiasScope::active() && !bias.has_grad()) {   // (GradSlot: a classifier launch may finish this bias)
+            out.grad_->gapfin_cnt = cnt;
+            out.grad_->gapfin_bias = bias.grad_;
+            out.grad_->gapfin_hw = hw;
+        }
         Tensor b = bias, r = out;
         Tape::push(out, true, [b, r, cnt, n, c_out, hw]() {
+            if (r.grad_->gapfin_done) {   // gradient and Adam update of the bias already happened in the classifier's launch
+                r.grad_->gapfin_done = false;
+                return;
+            }
             if (!r.has_grad()) return;
             // every element of a plane receives g / hw (tensor.rs:1626-1628) and passes the ReLU mask iff it is > 0: db = sum_n g / hw * count
             pooled_bias_grad(b, r.grad_dptr(), nullptr, n, c_out, hw, true, cnt->d);

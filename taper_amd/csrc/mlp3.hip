@@ -22,7 +22,7 @@ namespace th {
 int mlp3_grads_launch(th_ctx *ctx, const float *const dz[3], const float *const act[3], float *const dw[3], float *const db[3],
                       const int out_f[3], const int in_f[3], const th_adam_fuse *const wf[3], const th_adam_fuse *const bf[3], int batch,
                       const float *part, int n_blk, float *loss, float *ncorrect, float *metrics, int64_t capacity, int64_t *state,
-                      int64_t advance);   // gemm.hip
+                      int64_t advance, const float *gap_dx, const th_mlp3_gap *gap);   // gemm.hip
 
 struct Mlp3RowsArgs {
     const float *x, *targets;
@@ -315,7 +315,7 @@ int th_mlp3_supported(int batch, int in_features, int h1, int h2, int classes) {
 
 int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batch, int in_features, const th_mlp3_layer *layers,
                  float *d_dx, float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state,
-                 int64_t advance, int32_t *d_tick) {
+                 int64_t advance, int32_t *d_tick, const th_mlp3_gap *gap) {
     TH_REQUIRE(ctx && d_x && d_targets && layers && d_loss, "th_mlp3_xent: null argument");
     const int h1 = layers[0].out_features, h2 = layers[1].out_features, c = layers[2].out_features;
     TH_REQUIRE(th_mlp3_supported(batch, in_features, h1, h2, c),
@@ -328,6 +328,7 @@ int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batc
     }
     TH_REQUIRE(((uintptr_t)d_x & 15) == 0, "th_mlp3_xent: d_x must be 16-byte aligned");
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp3_xent: metrics need d_state and a capacity");
+    TH_REQUIRE(!(gap && gap->d_cnt) || (d_dx && gap->d_gb && gap->hw > 0), "th_mlp3_xent: the gap bias finish needs d_dx, d_gb and hw > 0");
     // workspace: A1, A2, dZ1, dZ2, dZ3, the blocks' partial sums
     const int n_blk = batch / 16;
     const size_t n1 = (size_t)batch * h1, n2 = (size_t)batch * h2, n3 = (size_t)batch * c;
@@ -354,7 +355,7 @@ int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batc
     const int out_f[3] = {h1, h2, c}, in_f[3] = {in_features, h1, h2};
     const th_adam_fuse *wf[3] = {layers[0].w_fuse, layers[1].w_fuse, layers[2].w_fuse}, *bf[3] = {layers[0].b_fuse, layers[1].b_fuse, layers[2].b_fuse};
     if (int rc = mlp3_grads_launch(ctx, dz, act, dw, db, out_f, in_f, wf, bf, batch, part, n_blk, d_loss, d_ncorrect, d_metrics, metrics_capacity,
-                                   d_state, advance))
+                                   d_state, advance, d_dx, gap))
         return rc;
     ++t_mlp3_calls;
     return th_free(ctx, ws);

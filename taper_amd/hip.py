@@ -34,6 +34,11 @@ class Mlp3Layer(C.Structure):
                 ("b_fuse", C.c_void_p), ("out_features", C.c_int)]
 
 
+class Mlp3Gap(C.Structure):
+    """include/taper_hip.h: th_mlp3_gap"""
+    _fields_ = [("d_cnt", C.c_void_p), ("d_gb", C.c_void_p), ("hw", C.c_int), ("b_fuse", C.c_void_p)]
+
+
 class ConvStage(C.Structure):
     """include/taper_hip.h: th_conv_stage"""
     _fields_ = [("d_w", C.c_void_p), ("d_bias", C.c_void_p), ("c_out", C.c_int), ("post", C.c_int)]

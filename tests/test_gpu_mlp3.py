@@ -63,7 +63,7 @@ def _run(ctx, x, y, net, need_dx, fuse=None, tick=None, metrics=False):
     loss, nc = ctx.empty(1), ctx.empty(1)
     met = ctx.zeros(8) if metrics else None
     st = ctx.upload(np.zeros(2, np.int64)) if metrics else None
-    ctx.call("th_mlp3_xent", dx_, dy_, B, in_f, C.cast(layers, C.c_void_p), gx, loss, nc, met, 4 if metrics else 0, st, B if metrics else 0, tick)
+    ctx.call("th_mlp3_xent", dx_, dy_, B, in_f, C.cast(layers, C.c_void_p), gx, loss, nc, met, 4 if metrics else 0, st, B if metrics else 0, tick, None)
     ctx.sync()
     out = dict(loss=float(ctx.download(loss, (1,))[0]), nc=float(ctx.download(nc, (1,))[0]),
                grads=[(ctx.download(gw, w.shape), ctx.download(gb, b.shape)) for (w, b), (_, _, gw, gb) in zip(net, bufs)],
@@ -134,7 +134,7 @@ def test_mlp3_fused_adam_and_tick(ctx, O):
         (pw, _, _, gw, fw), (pb, _, _, gb, fb) = ent
         layers[l] = hip.Mlp3Layer(int(pw), int(pb), int(gw), int(gb), C.cast(C.pointer(fw), C.c_void_p), C.cast(C.pointer(fb), C.c_void_p), w.shape[0])
     loss, nc = ctx.empty(1), ctx.empty(1)
-    ctx.call("th_mlp3_xent", dxb, dyb, B, in_f, C.cast(layers, C.c_void_p), None, loss, nc, None, 0, None, 0, t)
+    ctx.call("th_mlp3_xent", dxb, dyb, B, in_f, C.cast(layers, C.c_void_p), None, loss, nc, None, 0, None, 0, t, None)
     ctx.sync()
     assert int(ctx.download(t, (1,), np.int32)[0]) == 1
     step = lr * np.sqrt(1 - b2) / (1 - b1)                      # optim.rs:87-90 at t = 1
@@ -156,3 +156,29 @@ def test_mlp3_unsupported_shapes():
     assert f(256, 128, 120, 64, 10) == 0
     assert f(256, 128, 128, 64, 17) == 0
     assert f(256, 2048, 128, 64, 10) == 0
+
+
+def test_mlp3_finishes_the_bias_of_the_conv_in_front(ctx):
+    """gap: the input rows are the plane means of a bias-only Conv2dReLU + global average pool; the gradient launch also forms that conv's
+    bias gradient db[ch] = sum_n (dX[n][ch] / hw) * cnt[n][ch] (tensor.rs:1626-1628 + ops.rs:358-369 through the counts, the formula of
+    th_bias_grad_counts_adam) from the dX the first launch wrote"""
+    from taper_amd import hip
+    B, in_f, h1, h2, c, hw = 256, 128, 128, 64, 10, 49
+    rng = np.random.default_rng(12)
+    net = _net(rng, in_f, h1, h2, c)
+    x = rng.uniform(0, 1, (B, in_f)).astype(np.float32)
+    y = rng.integers(0, c, B).astype(np.float32)
+    cnt = rng.integers(0, hw + 1, (B, in_f)).astype(np.float32)
+    dx_, dy_, dcnt = ctx.upload(x), ctx.upload(y), ctx.upload(cnt)
+    layers, keep = (hip.Mlp3Layer * 3)(), []
+    for l, (w, b) in enumerate(net):
+        bufs = (ctx.upload(w), ctx.upload(b), ctx.empty(w.size), ctx.empty(b.size))
+        keep.append(bufs)
+        layers[l] = hip.Mlp3Layer(int(bufs[0]), int(bufs[1]), int(bufs[2]), int(bufs[3]), None, None, w.shape[0])
+    gx, gb, loss, nc = ctx.empty(x.size), ctx.empty(in_f), ctx.empty(1), ctx.empty(1)
+    gap = hip.Mlp3Gap(int(dcnt), int(gb), hw, None)
+    ctx.call("th_mlp3_xent", dx_, dy_, B, in_f, C.cast(layers, C.c_void_p), gx, loss, nc, None, 0, None, 0, None, C.cast(C.pointer(gap), C.c_void_p))
+    ctx.sync()
+    dx = ctx.download(gx, x.shape).astype(np.float64)
+    want = (dx / hw * cnt).sum(axis=0)
+    np.testing.assert_allclose(ctx.download(gb, (in_f,)), want, rtol=1e-4, atol=1e-6 * float(np.abs(want).max()) + 1e-9)

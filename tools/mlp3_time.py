@@ -21,7 +21,7 @@ for B, in_f, h1, h2, c, need_dx in ((256, 128, 128, 64, 10, True), (256, 784, 12
     gx = ctx.empty(B * in_f) if need_dx else None
     loss, nc = ctx.empty(1), ctx.empty(1)
     lp = C.cast(layers, C.c_void_p)
-    call = lambda: ctx.call("th_mlp3_xent", x, y, B, in_f, lp, gx, loss, nc, None, 0, None, 0, None)
+    call = lambda: ctx.call("th_mlp3_xent", x, y, B, in_f, lp, gx, loss, nc, None, 0, None, 0, None, None)
     for _ in range(20):
         call()
     e0, e1 = hip.Event(), hip.Event()

@@ -22,7 +22,7 @@ gx=ctx.empty(B*in_f); loss,nc=ctx.empty(1),ctx.empty(1); lp=C.cast(layers,C.c_vo
 acc=np.zeros(9); N=30
 names=["X -> LDS (+ L1, L2 weights requested)","L1 forward","L2 forward","logits + softmax","dZ2","dZ1","(stamp 7)","","dX"]
 for it in range(N+5):
-    for _ in range(20): ctx.call("th_mlp3_xent",x,y,B,in_f,lp,gx,loss,nc,None,0,None,0,None)
+    for _ in range(20): ctx.call("th_mlp3_xent",x,y,B,in_f,lp,gx,loss,nc,None,0,None,0,None,None)
     out=(C.c_longlong*16)(); lib.th_debug_mlp3_prof(ctx.h,out)
     ts=[out[i] for i in (0,1,2,3,4,5,6,7,9)]
     if it>=5: acc[:8]+=np.diff(ts)*0.01
