@@ -33,6 +33,7 @@ struct Mlp3RowsArgs {
     float *dx;               // [B][in] (nullable)
     float *part;             // [blocks][2]
     int32_t *tick;           // nullable: t += 1
+    int a1_given;            // a1 already holds relu(X W1^T + b1) (th_linear_fwd: a wide first layer is a launch of its own, see th_mlp3_xent)
 };
 
 constexpr int M3_NW = 8;     // waves per workgroup
@@ -144,16 +145,24 @@ __global__ __launch_bounds__(64 * M3_NW) void mlp3_rows_kernel(Mlp3RowsArgs a) {
     M3W wa, wb;                                                                    // this stage's / the next stage's weight operands
     m3_fetch<true>(wa, a.w1, in_f, in_f, (wave % T1) * 16, lane, PRE);
     const float bias1 = a.b1 ? a.b1[(wave % T1) * 16 + l16] : 0.f, bias2 = a.b2 ? a.b2[(wave % T2) * 16 + l16] : 0.f;
-    // the block's rows of X -> LDS
-    for (int q = t; q < 16 * (in_f >> 2); q += 64 * M3_NW) {
-        const int r = q / (in_f >> 2), c4 = q % (in_f >> 2);
-        *reinterpret_cast<float4 *>(XS + r * ldx + 4 * c4) = *reinterpret_cast<const float4 *>(a.x + (long)(r0 + r) * in_f + 4 * c4);
+    if (!PRE && a.a1_given) {
+        // the first layer's output comes from its own launch: its rows -> LDS
+        for (int q = t; q < 16 * (H1 >> 2); q += 64 * M3_NW) {
+            const int r = q / (H1 >> 2), c4 = q % (H1 >> 2);
+            *reinterpret_cast<float4 *>(A1S + r * ld1 + 4 * c4) = *reinterpret_cast<const float4 *>(a.a1 + (long)(r0 + r) * H1 + 4 * c4);
+        }
+    } else {
+        // the block's rows of X -> LDS
+        for (int q = t; q < 16 * (in_f >> 2); q += 64 * M3_NW) {
+            const int r = q / (in_f >> 2), c4 = q % (in_f >> 2);
+            *reinterpret_cast<float4 *>(XS + r * ldx + 4 * c4) = *reinterpret_cast<const float4 *>(a.x + (long)(r0 + r) * in_f + 4 * c4);
+        }
     }
     m3_fetch<true>(wb, a.w2, H1, H1, (wave % T2) * 16, lane, PRE);
     lds_barrier();
     M3_STAMP(1);
     // ---- forward (nn.rs:54-60 + activation.rs:10-12): A1 = relu(X W1^T + b1), A2 = relu(A1 W2^T + b2) ----
-    for (int tile = wave; tile < T1; tile += M3_NW) {
+    for (int tile = wave; tile < ((!PRE && a.a1_given) ? 0 : T1); tile += M3_NW) {
         const floatx4 acc = m3_tile<true, PRE>(wa, XS, ldx, a.w1, in_f, in_f, tile * 16, lane);
         const int col = tile * 16 + l16;
         const float bv = tile == wave ? bias1 : (a.b1 ? a.b1[col] : 0.f);
@@ -341,6 +350,12 @@ int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batc
     r.w1 = layers[0].d_w; r.b1 = layers[0].d_b; r.w2 = layers[1].d_w; r.b2 = layers[1].d_b; r.w3 = layers[2].d_w; r.b3 = layers[2].d_b;
     r.batch = batch; r.in_f = in_features; r.h1 = h1; r.h2 = h2; r.c = c;
     r.a1 = a1; r.a2 = a2; r.dz3 = dz3; r.dz2 = dz2; r.dz1 = dz1; r.dx = d_dx; r.part = part; r.tick = d_tick;
+    // A first layer deeper than 128 is a latency chain of in / 128 weight round trips inside a 16-workgroup launch (18.7 us for 784-128-64);
+    // as a launch of its own (th_linear_fwd: 128 workgroups, K split over waves) it is 5 us, and the rows launch starts from its output
+    const bool split_l1 = in_features > 128;
+    if (split_l1)
+        if (int rc = th_linear_fwd(ctx, d_x, layers[0].d_w, layers[0].d_b, a1, batch, in_features, h1, 1)) return rc;
+    r.a1_given = split_l1 ? 1 : 0;
     const size_t lds = mlp3_lds_bytes(in_features, h1, h2);
     if (in_features == 128 && h1 == 128 && h2 == 64) {   // the reference CNN's classifier (examples/train_mnist_cnn.rs:53-61): sizes compiled in
         (void)hipFuncSetAttribute((const void *)mlp3_rows_kernel<true, 8, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
