@@ -836,6 +836,7 @@ int linear_fwd_partials(th_ctx *ctx, const float *x, const float *w, int m, int 
     p.b_vec = aligned16(w) && (k % 4 == 0);
     int kz = (int)std::min<long>((256 + tiles - 1) / tiles, k / 512);
     if (kz < 1) kz = 1;
+    if (kz > 8) kz = 8;   // wide_head.hip reads all slices of a logit at once (WH_KZ_MAX)
     const int kslice = (ceil_div(k, kz) + 15) / 16 * 16;
     kz = ceil_div(k, kslice);
     p.kslice = kslice;

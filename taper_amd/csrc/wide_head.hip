@@ -39,6 +39,14 @@ struct WideArgs {
 #define TH_WH_TX 2
 #endif
 constexpr int WH_TX = TH_WH_TX;   // 16-column tiles per workgroup (tuning probe: -DTH_WH_TX=1: 196 workgroups of 16 columns)
+#ifdef TH_PROFILE
+__device__ long long g_wh_prof[16];   // wall clock (100 MHz) at the phase boundaries of workgroup 5, wave 0
+#define WH_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x == 5) g_wh_prof[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WH_STAMP(i) do { } while (0)
+#endif
+
+constexpr int WH_KZ_MAX = 8;   // K slices of the logits (linear_fwd_partials: <= k / 512, capped here)
 constexpr int WH_NW = 16;  // waves per workgroup: 256 rows per pass (the chunks of a batch are a serial chain per wave, so go wide)
 
 __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
@@ -48,6 +56,7 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
     __shared__ float sc[WH_NW][20];
     __shared__ float colred[WH_NW][WH_TX][16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
+    WH_STAMP(0);
     const bool lead = (int)blockIdx.x == a.n_col;
     const int B = a.batch, K = a.k, C = a.c;
     const int col0 = blockIdx.x * 16 * WH_TX;
@@ -85,12 +94,21 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
             const int row_a = r0 + r16, row_ac = min(row_a, B - 1);
             const bool row_ok = row_a < B;
             // logits of (row_a, classes 4 g4 ..): the K slices in slice order, then the bias (nn.rs:54-60)
-            float lg[4];
+            // (every slice of every class is requested before the first add: as a loop of load + add the compiler waited for each load --
+            // 4 kz dependent L2 round trips, 24 at kz = 6: most of this kernel's 12 us)
+            float lg[4], pv[4][WH_KZ_MAX];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int cls = min(g4 * 4 + i, C - 1);
+                const float *pp = a.partial + (long)row_ac * C + cls;
+#pragma unroll
+                for (int z = 0; z < WH_KZ_MAX; ++z) pv[i][z] = pp[(long)min(z, a.kz - 1) * bc];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
                 float sum = 0.f;
-                for (int z = 0; z < a.kz; ++z) sum += a.partial[(long)z * bc + (long)row_ac * C + cls];
+#pragma unroll
+                for (int z = 0; z < WH_KZ_MAX; ++z) sum += z < a.kz ? pv[i][z] : 0.f;
                 lg[i] = (g4 * 4 + i < C) ? sum + b4[i] : -INFINITY;
             }
             const float tf = a.targets[row_ac];
@@ -104,9 +122,11 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
                     xv[tx][s] = (!lead && row < B && col < K) ? a.x[(long)row * K + col] : 0.f;
                 }
             }
+            WH_STAMP(1);
             float dl[4], nll_row;
             int bi;
             tail_row_softmax(lg, g4, C, tf, inv_b, dl, nll_row, bi);
+            WH_STAMP(2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dl[i] = row_ok ? dl[i] : 0.f;
 
@@ -164,6 +184,7 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
         }
     }
 
+    WH_STAMP(3);
     if (!lead && a.colsum) {   // the four row groups of a wave in a fixed tree, then the waves in order: deterministic
 #pragma unroll
         for (int tx = 0; tx < WH_TX; ++tx) {
@@ -181,6 +202,7 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
             if (col < K) a.colsum[col] = sum;
         }
     }
+    WH_STAMP(4);
     if (!lead) {   // deterministic cross-wave sum; wave e finishes class 4 g4 + e
 #pragma unroll
         for (int tx = 0; tx < WH_TX; ++tx)
@@ -203,6 +225,7 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
                 }
             }
         }
+        WH_STAMP(5);
         if (!a.fused) return;
     }
     if (a.fused) {
@@ -360,3 +383,11 @@ extern "C" int th_linear_xent_wide(th_ctx *ctx, const float *d_x, const float *d
     return wide_launch(ctx, d_x, d_w, d_bias, d_targets, batch, in_features, classes, d_loss, d_ncorrect, d_dx, d_dw, d_db, d_metrics,
                        metrics_capacity, d_state, advance, d_adam_tick, nullptr, nullptr);
 }
+
+#ifdef TH_PROFILE
+extern "C" int th_debug_wide_prof(th_ctx *ctx, long long *h_out16) {
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(th::g_wh_prof), 16 * sizeof(long long)));
+    return 0;
+}
+#endif
