@@ -1,7 +1,7 @@
 """One rank of a data-parallel run of the PRODUCT Trainer (tests/test_gpu_dp.py spawns W of these).
 env: RANK / LOCAL_RANK / WORLD_SIZE (torchrun's contract), TAPER_DP_OUT (directory), TAPER_DP_STEPS, TAPER_DP_GLOBAL_BATCH,
 TAPER_DP_MODE (graph | eager), TAPER_DP_DEVICE (optional: every rank on this device -- the peer-to-peer communicator can share
-one GPU, RCCL cannot), TAPER_DP_BACKEND (rccl | p2p)."""
+one GPU, RCCL cannot), TAPER_DP_BACKEND (rccl | p2p), TAPER_DP_MODEL (tests/backends.py builder: mlp_baseline | cnn_reference | ...)."""
 import os
 import sys
 from pathlib import Path
@@ -12,12 +12,16 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def make_problem(steps, global_batch, seed=11):
+def make_problem(steps, global_batch, seed=11, model="mlp_baseline"):
     from tests import backends
     rng = np.random.default_rng(seed)
-    spec = backends.nonzero_biases(backends.mlp_baseline(rng), rng)
+    spec = backends.nonzero_biases(getattr(backends, model)(rng), rng)
     x, y = backends.mnist_like(rng, steps * global_batch)
     return spec, x, y
+
+
+def sample_shape(model):
+    return (1, 28, 28) if model.startswith("cnn") else None
 
 
 def main():
@@ -31,14 +35,15 @@ def main():
     dev = os.environ.get("TAPER_DP_DEVICE")
     T.Device.set_device(int(dev) if dev is not None else int(os.environ.get("LOCAL_RANK", rank)))
     rdzv = FileRendezvous(rank, world, key=os.environ["TAPER_DP_KEY"], root=str(out), timeout_s=120)
-    spec, x, y = make_problem(steps, gb)
+    model_name = os.environ.get("TAPER_DP_MODEL", "mlp_baseline")
+    spec, x, y = make_problem(steps, gb, model=model_name)
     per = gb // world
     rows = np.concatenate([np.arange(s * gb + rank * per, s * gb + (rank + 1) * per) for s in range(steps)])   # SURVEY 8e partitioning
     H = backends.get("hip")
     model = H.sequential(spec)
     opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
     comm = init_data_parallel(T, rdzv, backend=os.environ.get("TAPER_DP_BACKEND", "rccl"), optimizer=opt)
-    tr = T.Trainer(model, opt, comm=comm)
+    tr = T.Trainer(model, opt, comm=comm, **({"sample_shape": sample_shape(model_name)} if sample_shape(model_name) else {}))
     loader = T.DataLoader(T.MNISTDataset.from_host(x[rows], y[rows]), per, False)
     mode = T.Trainer.GRAPH if os.environ.get("TAPER_DP_MODE", "graph") == "graph" else T.Trainer.EAGER
     ep = tr.run_epoch(loader, mode)

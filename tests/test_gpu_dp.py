@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _run_ranks(tmp_path, world, backend, mode, steps, global_batch, same_device, fuse=True):
+def _run_ranks(tmp_path, world, backend, mode, steps, global_batch, same_device, fuse=True, model="mlp_baseline"):
     env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env0["TAPER_DP_MODEL"] = model
     env0["TAPER_P2P_FUSE"] = "1" if fuse else "0"
     key = uuid.uuid4().hex[:12]
     procs = []
@@ -44,23 +45,23 @@ def _run_ranks(tmp_path, world, backend, mode, steps, global_batch, same_device,
     return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
 
 
-def _single_process_reference(steps, global_batch):
+def _single_process_reference(steps, global_batch, model_name="mlp_baseline"):
     """the same optimisation in ONE process on the full global batches (two epochs, like the workers)"""
     import taper_amd as T
     from tests import backends
-    from tests.dp_worker import make_problem
-    spec, x, y = make_problem(steps, global_batch)
+    from tests.dp_worker import make_problem, sample_shape
+    spec, x, y = make_problem(steps, global_batch, model=model_name)
     H = backends.get("hip")
     model = H.sequential(spec)
     opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
-    tr = T.Trainer(model, opt)
+    tr = T.Trainer(model, opt, **({"sample_shape": sample_shape(model_name)} if sample_shape(model_name) else {}))
     loader = T.DataLoader(T.MNISTDataset.from_host(x, y), global_batch, False)
     losses = np.concatenate([tr.run_epoch(loader, T.Trainer.GRAPH)["losses"] for _ in range(2)])
     return losses, [p.data() for p in model.parameters()], opt.t()
 
 
-def _check(ranks, world, steps, global_batch):
-    ref_losses, ref_params, ref_t = _single_process_reference(steps, global_batch)
+def _check(ranks, world, steps, global_batch, model="mlp_baseline"):
+    ref_losses, ref_params, ref_t = _single_process_reference(steps, global_batch, model)
     n_params = len(ref_params)
     for r in range(world):
         assert int(ranks[r]["t"]) == ref_t == 2 * steps
@@ -95,6 +96,14 @@ def test_p2p_ranks_on_one_gpu_equal_full_batch(tmp_path, world, mode, fuse):
             assert fused >= 6 and inplace == 1, (fused, inplace)       # the bootstrap's self-check is the one in-place launch
         else:
             assert inplace >= 7 and fused == 0, (fused, inplace)
+
+
+def test_p2p_reference_cnn_two_ranks_equal_full_batch(tmp_path):
+    """the reference CNN (examples/train_mnist_cnn.rs) data-parallel, 128 rows per rank: the conv chain and th_mlp3_xent write plain gradients
+    (no Adam in their epilogues: the all-reduce comes first), the one-shot all-reduce + Adam finishes the step; replicas bit-identical and
+    equal to the single-process step on the 256-row batches"""
+    ranks = _run_ranks(tmp_path, 2, "p2p", "graph", steps=3, global_batch=256, same_device=True, model="cnn_reference")
+    _check(ranks, 2, 3, 256, model="cnn_reference")
 
 
 def test_p2p_ranks_on_separate_gpus(tmp_path):
