@@ -77,3 +77,20 @@ def test_image_resident_conv_random_shapes(ctx, O, n, c8, h, w, c_out, pad, relu
         assert cfg["dma"] in (2, 3, 4, 5), cfg
     if c_out % 4 == 0 and F.ctx_supported_gap(n, c_in, h, w, c_out, pad):
         F.gap_case(ctx, O, n, c_in, h, w, c_out, pad)
+
+
+@settings(**{**CFG, "max_examples": 20})
+@given(b16=st.integers(1, 12), in16=st.integers(1, 20), h1_16=st.integers(1, 10), h2_16=st.integers(1, 10), c=st.integers(1, 16), need_dx=st.booleans())
+def test_mlp3_random_shapes(ctx, O, b16, in16, h1_16, h2_16, c, need_dx):
+    """th_mlp3_xent on random multiples of 16 (the runtime-size instance, with and without the first layer as its own launch, with and
+    without dX) against the oracle's tape"""
+    from tests import test_gpu_mlp3 as M
+    M.test_mlp3_matches_the_oracle_tape(ctx, O, 16 * b16, 16 * in16, 16 * h1_16, 16 * h2_16, c, need_dx)
+
+
+@settings(**{**CFG, "max_examples": 6})
+@given(n=st.integers(1, 70), name=st.sampled_from(["reference", "simple"]))
+def test_conv_chain_random_batches(ctx, O, n, name):
+    """th_conv_chain_fwd at random batch sizes (the grid is one workgroup per image: any n) against the oracle's layer-by-layer ops"""
+    from tests import test_gpu_chain as CH
+    CH.test_chain_matches_the_oracle(ctx, O, name, n)
