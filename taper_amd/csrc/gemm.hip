@@ -837,6 +837,8 @@ int linear_fwd_partials(th_ctx *ctx, const float *x, const float *w, int m, int 
     int kz = (int)std::min<long>((256 + tiles - 1) / tiles, k / 512);
     if (kz < 1) kz = 1;
     if (kz > 8) kz = 8;   // wide_head.hip reads all slices of a logit at once (WH_KZ_MAX)
+    static const int kz_env = getenv("TAPER_WIDE_KZ") ? atoi(getenv("TAPER_WIDE_KZ")) : 0;   // tuning probe: cap on the K slices
+    if (kz_env > 0 && kz > kz_env) kz = kz_env;
     const int kslice = (ceil_div(k, kz) + 15) / 16 * 16;
     kz = ceil_div(k, kslice);
     p.kslice = kslice;
