@@ -239,7 +239,8 @@ int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_
                 float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
                 const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse);
 
-/* MANY training steps of the two-layer MLP (Linear + ReLU, Linear, softmax cross-entropy, Adam: train.rs:98-144 over the model of
+/* EXPERIMENTAL -- measured, NOT on any Trainer path (14.2-15.8 us per step against 11.9 us for the two launches per step).
+ * MANY training steps of the two-layer MLP (Linear + ReLU, Linear, softmax cross-entropy, Adam: train.rs:98-144 over the model of
  * examples/train_mnist.rs with one hidden layer -- BASELINE configs[1]) in ONE persistent launch: (batch / 16) x (hidden / 16) <= 32
  * workgroups, all on one XCD (they share its L2: no fences), walk every step as forward tiles -> barrier -> head + dW1 tiles with Adam in
  * the epilogues -> barrier.  d_x [steps][batch][in], d_targets [steps][batch]: the gathered batches of the chunk.  fuse4: W1, b1, W2, b2

@@ -1,4 +1,5 @@
-// mlp_steps.hip -- th_mlp2_steps: MANY training steps of the two-layer MLP (Linear + ReLU, Linear, softmax cross-entropy, Adam:
+// mlp_steps.hip -- EXPERIMENTAL (tested against the oracle's step loop, measured, not used by the Trainer: see "Where it stands" below).
+// th_mlp2_steps: MANY training steps of the two-layer MLP (Linear + ReLU, Linear, softmax cross-entropy, Adam:
 // examples/train_mnist.rs / train.rs:98-144 with the 784-128-10 model of BASELINE configs[1]) in ONE persistent launch.
 //
 // Why: as two launches per step the batch-64 step is two kernel boundaries (1.6 us each) plus two chains of dependent round trips: 11.9 us,
@@ -18,11 +19,19 @@
 //            epilogue; column group 0 also db1 + Adam(b1); workgroup 0 also dW2, db2, the loss, the hit count, the step log   -- barrier --
 // Barrier = arrival counter in the L2 (relaxed agent-scope atomics), wall-clock bounded spin (never hangs the GPU: a time-out raises the
 // error word and every workgroup leaves), then the L1 invalidate.
+//
+// Where it stands (tools/prof_mlp_steps.sh, batch 64, 784-128-10): correct on the first run, no hangs; 86 us per step with the agent-scope acquire
+// fence after each barrier (buffer_inv sc1 also walks the L2: ~31 us per barrier), 29.8 us with buffer_inv sc0 (this CU's L1 only), 16.0 us with
+// the head's gradients spread over the column-group-0 workgroups instead of workgroup 0, 14.2 us with the per-lane addresses kept from
+// being hoisted out of the step loop (69 -> 22 spilled registers at 16 waves x 128 VGPRs), 15.8 us as 8 waves x 256 VGPRs with the dW1 tiles'
+// operands requested ahead (phases: H tile 5.2, barrier + skew 2.4, logits / dZ1 4.3, dW1 + Adam 2.4, barrier + skew 2.7).  The two launches per
+// step it would replace take 11.9 us: every phase here is still a chain of dependent L2 round trips on a quarter of the waves the launches
+// spread the same work over, and the barrier skew (2.5 us each) is larger than the kernel boundary (1.6 us) it was meant to beat.
 #include "tail_dev.h"
 
 namespace th {
 
-constexpr int MS_NW = 16;                   // waves per workgroup
+constexpr int MS_NW = 8;                    // waves per workgroup
 constexpr long long MS_SPIN_TICKS = 400000; // 4 ms at 100 MHz
 
 #ifdef TH_PROFILE
@@ -80,16 +89,17 @@ __device__ __forceinline__ bool ms_grid_barrier(unsigned *ctr, unsigned target, 
     return bad == 0;
 }
 
-template <int KS>   // hidden = 16 KS
-__global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a) {
-    constexpr int HID = 16 * KS;
+template <int KS, int NW>   // hidden = 16 KS; NW waves per workgroup (8: 256 VGPRs per wave -- at 16 waves the 128-register budget spills)
+__global__ __launch_bounds__(64 * NW) void mlp2_steps_kernel(Mlp2StepsArgs a) {
+    constexpr int HID = 16 * KS, NR = 64 / NW;     // k blocks of 16 per wave in phase A (in_features <= 1024)
+    constexpr int MAXT = 2;                       // dW1 tiles per wave whose operands are requested ahead
     if ((blockIdx.x & 7) != 0) return;
     const int me = blockIdx.x >> 3;
     const int RT = a.batch / 16, NWG = RT * KS;
     const int t = threadIdx.x, wave = t >> 6;
-    __shared__ float red[MS_NW][64][4];      // cross-wave sums of phase A / dW2
-    __shared__ float dzs[64][17];            // phase B: the dZ1 tile [row][hidden col] (batch <= 64 rows per pass)
-    __shared__ float dls[64][17];            // workgroup 0: dlogits [row][class]
+    __shared__ float red[NW][64][4];         // cross-wave sums of phase A; phase B: the high-half partial logits
+    __shared__ float dzs[64][17];            // phase B: the dZ1 tile [row][hidden col] (batch <= 64 rows)
+    __shared__ float dls[64][17];            // column group 0: dlogits [row][class]
     __shared__ float rowv[2][64];            // workgroup 0: the rows' NLL and hits
     __shared__ float dw2s[16][17], db2s[16]; // column group 0: this workgroup's dW2 tile [class][hidden col] (workgroup 0: db2), applied in the next phase A
     if (ms_xcc_id() != 0) {                  // not where the scheme needs it: nothing has been written yet; the others time out of barrier 1 at once
@@ -108,8 +118,8 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
     unsigned bar = 0;
 
     for (int s = 0; s < a.steps; ++s) {
-        // (per step, opaque to the optimizer: with the lane id loop-invariant every per-lane address of every phase is hoisted out of the
-        // step loop and lives through all of them -- 69 spilled registers at this kernel's 128-VGPR budget)
+        // (per step and phase, opaque to the optimizer: with the lane id loop-invariant every per-lane address of every phase is hoisted out
+        // of the step loop and lives through all of them)
         int lane = t & 63;
         asm volatile("" : "+v"(lane));
         int l16 = lane & 15, g4 = lane >> 4;
@@ -123,10 +133,10 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
             // H tile = relu(X[rows ra] . W1[cols ha]^T + b1): 16-deep k blocks round-robin over the waves, four accumulation chains
             const float *xp = xs + (long)(ra * 16 + l16) * in_f + 4 * g4, *wp = a.w1.p + (long)(ha * 16 + l16) * in_f + 4 * g4;
             floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
-            float4 av[4], bv[4];
+            float4 av[NR], bv[NR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kk = (wave + MS_NW * u) * 16;
+            for (int u = 0; u < NR; ++u) {
+                const int kk = (wave + NW * u) * 16;
                 if (kk < in_f) {
                     av[u] = *reinterpret_cast<const float4 *>(xp + kk);
                     bv[u] = *reinterpret_cast<const float4 *>(wp + kk);
@@ -144,8 +154,8 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kk = (wave + MS_NW * u) * 16;
+            for (int u = 0; u < NR; ++u) {
+                const int kk = (wave + NW * u) * 16;
                 if (kk < in_f) {
                     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u].x, c0, 0, 0, 0);
                     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u].y, c1, 0, 0, 0);
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
             if (wave < 4) {                  // wave e finishes element e of every lane's quad: row 4 g4 + e, column l16
                 float sum = red[0][lane][wave];
 #pragma unroll
-                for (int w = 1; w < MS_NW; ++w) sum += red[w][lane][wave];
+                for (int w = 1; w < NW; ++w) sum += red[w][lane][wave];
                 const int col = ha * 16 + l16, row = ra * 16 + 4 * g4 + wave;
                 float v = sum + a.b1.p[col];
                 v = v > 0.f ? v : 0.f;
@@ -172,29 +182,30 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
         // ---------------- phase B ----------------
         asm volatile("" : "+v"(lane));
         l16 = lane & 15, g4 = lane >> 4;
-        // operands that do not depend on this phase's results are requested first, under the logits: the first dW1 tile's Adam state and X columns
-        const int ct_first = ct0 + wave;
-        const bool tile_first = ct_first < ct1;
-        float pv[4], mv[4], vv[4], xv[4][4];
-        {
-            const long widx = (long)(hb * 16 + 4 * g4) * in_f + ct_first * 16 + l16;
+        // operands that do not depend on this phase's results are requested first, under the logits: the Adam state and the X columns of
+        // this wave's first dW1 tiles
+        float pv[MAXT][4], mv[MAXT][4], vv[MAXT][4], xv[MAXT][4][4];
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+            const int ct = ct0 + wave + NW * j;
+            const bool on = ct < ct1;
+            const long widx = (long)(hb * 16 + 4 * g4) * in_f + (on ? ct : ct0) * 16 + l16;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pv[e] = tile_first ? a.w1.p[widx + (long)e * in_f] : 0.f;
-                mv[e] = tile_first ? a.w1.m[widx + (long)e * in_f] : 0.f;
-                vv[e] = tile_first ? a.w1.v[widx + (long)e * in_f] : 0.f;
+                pv[j][e] = a.w1.p[widx + (long)e * in_f];
+                mv[j][e] = a.w1.m[widx + (long)e * in_f];
+                vv[j][e] = a.w1.v[widx + (long)e * in_f];
             }
 #pragma unroll
             for (int rb4 = 0; rb4 < 4; ++rb4)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    xv[rb4][i] = (tile_first && 16 * rb4 < B) ? xs[(long)(16 * rb4 + 4 * g4 + i) * in_f + ct_first * 16 + l16] : 0.f;
+                for (int i = 0; i < 4; ++i) xv[j][rb4][i] = xs[(long)(min(16 * rb4, B - 16) + 4 * g4 + i) * in_f + (on ? ct : ct0) * 16 + l16];
         }
         // (1) logits^T, softmax, dlogits, the dZ1 tile of hidden tile hb for every row block: waves 0 .. RT-1 take the low half of the hidden
-        //     dimension of row block `wave`, waves RT .. 2 RT - 1 the high half (half the operand registers per wave: at 1024 threads a wave
-        //     has 128 VGPRs, and a spilled register is a scratch reload through the L1 the barrier just emptied)
+        //     dimension of row block `wave`, waves RT .. 2 RT - 1 the high half
         const bool lo_half = wave < RT, hi_half = wave >= RT && wave < 2 * RT;
         floatx4 lgp = {0.f, 0.f, 0.f, 0.f};
+        float w2b[4], hm[4], b2v[4], tf = 0.f;
         if (lo_half || hi_half) {
             constexpr int KH = KS / 2;
             const int r0 = (wave % RT) * 16, kb = hi_half ? 16 * KH : 0;
@@ -205,6 +216,16 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
             for (int u = 0; u < KH; ++u) {
                 wv[u] = *reinterpret_cast<const float4 *>(wp + 16 * u);
                 hv[u] = *reinterpret_cast<const float4 *>(hp + 16 * u);
+            }
+            if (lo_half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cls = min(4 * g4 + i, C - 1);
+                    w2b[i] = a.w2.p[(long)cls * HID + hb * 16 + l16];
+                    b2v[i] = a.b2.p[cls];
+                    hm[i] = a.h[(long)(r0 + 4 * g4 + i) * HID + hb * 16 + l16];
+                }
+                tf = ts[r0 + l16];
             }
             floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
 #pragma unroll
@@ -220,18 +241,6 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) red[wave % RT][lane][i] = lgp[i];
             }
-        }
-        float w2b[4], hm[4], b2v[4], tf = 0.f;
-        if (lo_half) {
-            const int r0 = wave * 16;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int cls = min(4 * g4 + i, C - 1);
-                w2b[i] = a.w2.p[(long)cls * HID + hb * 16 + l16];
-                b2v[i] = a.b2.p[cls];
-                hm[i] = a.h[(long)(r0 + 4 * g4 + i) * HID + hb * 16 + l16];
-            }
-            tf = ts[r0 + l16];
         }
         __syncthreads();
         if (lo_half) {
@@ -258,14 +267,14 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
         }
         __syncthreads();
         MS_STAMP(4);
-        // (2) db1 + Adam(b1) (column group 0), the head's gradients and the step's numbers (workgroup 0)
-        if (cg == 0 && wave == 13) {          // db1 (tensor.rs:686-691): lane (column l16, row group g4), then the four groups
+        // (2) the last three waves (they own the fewest dW1 tiles): db1 + Adam(b1) and the dW2 tile (column group 0), the step's numbers (workgroup 0)
+        if (cg == 0 && wave == NW - 3) {      // db1 (tensor.rs:686-691): lane (column l16, row group g4), then the four groups
             float sum = 0.f;
             for (int r = g4; r < B; r += 4) sum += dzs[r][l16];
             sum = sum_over_g4(sum);
             if (g4 == 0) adam_update(a.b1.p, a.b1.m, a.b1.v, hb * 16 + l16, sum, step_sz, a.b1.beta1, a.b1.beta2, a.b1.eps, a.b1.wd);
         }
-        if (cg == 0 && wave == 14) {
+        if (cg == 0 && wave == NW - 2) {
             // dW2 tile [class l16 -> rows 4 g4 + e][hidden col l16] = sum_rows dl[row][class] H[row][col] (ops.rs:280-291): A = dl^T from LDS, B = H
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int rb = 0; rb < B; rb += 16) {
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) dw2s[4 * g4 + e][l16] = acc[e];
         }
-        if (me == 0 && wave == 15) {
+        if (me == 0 && wave == NW - 1) {
             if (lane < C) {
                 float sum = 0.f;
                 for (int r = 0; r < B; ++r) sum += dls[r][lane];
@@ -306,21 +315,32 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
             }
         }
         MS_STAMP(5);
-        // (3) dW1 tiles [hidden tile hb][column tiles ct0 .. ct1) with Adam in the epilogue: one tile per wave and round (the first round's
-        //     operands were requested at the top of the phase)
-        for (int ct = ct_first; ct < ct1; ct += MS_NW) {
+        // (3) dW1 tiles [hidden tile hb][column tiles ct0 .. ct1) with Adam in the epilogue; tile j of a wave: ct0 + wave + NW j
+        for (int j = 0, ct = ct0 + wave; ct < ct1; ++j, ct += NW) {
             const long widx = (long)(hb * 16 + 4 * g4) * in_f + ct * 16 + l16;      // D: rows = hidden 4 g4 + e, column l16
-            if (ct != ct_first) {
+            float p4[4], m4[4], v4[4], x4[4][4];
+            if (j < MAXT) {
+#pragma unroll
+                for (int jj = 0; jj < MAXT; ++jj)
+                    if (jj == j) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { p4[e] = pv[jj][e]; m4[e] = mv[jj][e]; v4[e] = vv[jj][e]; }
+#pragma unroll
+                        for (int rb4 = 0; rb4 < 4; ++rb4)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) x4[rb4][i] = xv[jj][rb4][i];
+                    }
+            } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pv[e] = a.w1.p[widx + (long)e * in_f];
-                    mv[e] = a.w1.m[widx + (long)e * in_f];
-                    vv[e] = a.w1.v[widx + (long)e * in_f];
+                    p4[e] = a.w1.p[widx + (long)e * in_f];
+                    m4[e] = a.w1.m[widx + (long)e * in_f];
+                    v4[e] = a.w1.v[widx + (long)e * in_f];
                 }
 #pragma unroll
                 for (int rb4 = 0; rb4 < 4; ++rb4)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) xv[rb4][i] = 16 * rb4 < B ? xs[(long)(16 * rb4 + 4 * g4 + i) * in_f + ct * 16 + l16] : 0.f;
+                    for (int i = 0; i < 4; ++i) x4[rb4][i] = xs[(long)(min(16 * rb4, B - 16) + 4 * g4 + i) * in_f + ct * 16 + l16];
             }
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -330,16 +350,16 @@ __global__ __launch_bounds__(64 * MS_NW) void mlp2_steps_kernel(Mlp2StepsArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dz[i] = dzs[16 * rb4 + 4 * g4 + i][l16];        // A: hidden l16, k = row 4 g4 + i; B: X[row][column l16]
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[i], xv[rb4][i], acc, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz[i], x4[rb4][i], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float gv = acc[e] + a.w1.wd * pv[e];
-                const float mn = a.w1.beta1 * mv[e] + (1.0f - a.w1.beta1) * gv;
-                const float vn = a.w1.beta2 * vv[e] + (1.0f - a.w1.beta2) * gv * gv;
+                const float gv = acc[e] + a.w1.wd * p4[e];
+                const float mn = a.w1.beta1 * m4[e] + (1.0f - a.w1.beta1) * gv;
+                const float vn = a.w1.beta2 * v4[e] + (1.0f - a.w1.beta2) * gv * gv;
                 a.w1.m[widx + (long)e * in_f] = mn;
                 a.w1.v[widx + (long)e * in_f] = vn;
-                a.w1.p[widx + (long)e * in_f] = pv[e] - step_sz * mn / (sqrtf(vn) + a.w1.eps);
+                a.w1.p[widx + (long)e * in_f] = p4[e] - step_sz * mn / (sqrtf(vn) + a.w1.eps);
             }
         }
         MS_STAMP(6);
@@ -392,9 +412,9 @@ int th_mlp2_steps(th_ctx *ctx, const float *d_x, const float *d_targets, int ste
     if (int rc = th_fill_f32(ctx, reinterpret_cast<float *>(a.sync), 0.f, 64)) return rc;
     const int nwg = (batch / 16) * (hidden / 16);
     const dim3 grid(8 * nwg), block(64 * MS_NW);
-    if (hidden == 128) hipLaunchKernelGGL(mlp2_steps_kernel<8>, grid, block, 0, ctx->stream, a);
-    else if (hidden == 64) hipLaunchKernelGGL(mlp2_steps_kernel<4>, grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL(mlp2_steps_kernel<2>, grid, block, 0, ctx->stream, a);
+    if (hidden == 128) hipLaunchKernelGGL((mlp2_steps_kernel<8, MS_NW>), grid, block, 0, ctx->stream, a);
+    else if (hidden == 64) hipLaunchKernelGGL((mlp2_steps_kernel<4, MS_NW>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((mlp2_steps_kernel<2, MS_NW>), grid, block, 0, ctx->stream, a);
     TH_LAUNCH_CHECK();
     return th_free(ctx, ws);
 }
