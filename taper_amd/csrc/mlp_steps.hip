@@ -1,4 +1,4 @@
-// mlp_steps.hip -- EXPERIMENTAL (tested against the oracle's step loop, measured, not used by the Trainer: see "Where it stands" below).
+// mlp_steps.hip -- EXPERIMENTAL (parity-tested in tests/test_gpu_mlp_steps.py, measured, not used by the Trainer: see "Where it stands" below).
 // th_mlp2_steps: MANY training steps of the two-layer MLP (Linear + ReLU, Linear, softmax cross-entropy, Adam:
 // examples/train_mnist.rs / train.rs:98-144 with the 784-128-10 model of BASELINE configs[1]) in ONE persistent launch.
 //
