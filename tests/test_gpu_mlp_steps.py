@@ -69,7 +69,9 @@ def test_mlp2_steps_match_the_oracle_loop(ctx, batch, in_f, hid, c, steps):
     y = rng.integers(0, c, steps * batch).astype(np.float32)
     ref, ref_params = _oracle(spec, x, y, steps, batch)
     got = _run(ctx, spec, x, y, steps, batch)
-    assert got["err"] == 0, "barrier time-out (1) or workgroups not on one XCD (2)"
+    if got["err"] == 2:
+        pytest.skip("this box does not place workgroup b on XCD b % 8 (another partition mode?): the launch refused to run, nothing was updated")
+    assert got["err"] == 0, "a barrier timed out"
     assert got["t"] == steps and list(got["state"]) == [steps, steps * batch]
     np.testing.assert_allclose(got["metrics"][:, 0], [r["loss"] for r in ref], rtol=3e-4, atol=1e-5)
     assert np.abs(got["metrics"][:, 1] - np.asarray([round(r["acc"] * batch) for r in ref])).max() <= 1
