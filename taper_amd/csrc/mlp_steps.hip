@@ -23,10 +23,11 @@
 // Where it stands (tools/prof_mlp_steps.sh, batch 64, 784-128-10): correct on the first run, no hangs; 86 us per step with the agent-scope acquire
 // fence after each barrier (buffer_inv sc1 also walks the L2: ~31 us per barrier), 29.8 us with buffer_inv sc0 (this CU's L1 only), 16.0 us with
 // the head's gradients spread over the column-group-0 workgroups instead of workgroup 0, 14.2 us with the per-lane addresses kept from
-// being hoisted out of the step loop (69 -> 22 spilled registers at 16 waves x 128 VGPRs), 15.8 us as 8 waves x 256 VGPRs with the dW1 tiles'
-// operands requested ahead (phases: H tile 5.2, barrier + skew 2.4, logits / dZ1 4.3, dW1 + Adam 2.4, barrier + skew 2.7).  The two launches per
+// being hoisted out of the step loop (69 -> 22 spilled registers at 16 waves x 128 VGPRs), 15.7 us as 8 waves x 256 VGPRs (no spills) with the
+// next step's X rows pulled into the L2 during phase B and one dW1 tile's operands requested ahead (per-workgroup stamps of a step: phase A 3.1 us,
+// 4.4 us where a W2 tile is updated; barrier 1.2; phase B 6.7; barrier 1.9).  The two launches per
 // step it would replace take 11.9 us: every phase here is still a chain of dependent L2 round trips on a quarter of the waves the launches
-// spread the same work over, and the barrier skew (2.5 us each) is larger than the kernel boundary (1.6 us) it was meant to beat.
+// spread the same work over, and a barrier with its skew (1.2 - 1.9 us) costs what the kernel boundary (1.6 us) it was meant to beat costs.
 #include "tail_dev.h"
 
 namespace th {
@@ -35,8 +36,9 @@ constexpr int MS_NW = 8;                    // waves per workgroup
 constexpr long long MS_SPIN_TICKS = 400000; // 4 ms at 100 MHz
 
 #ifdef TH_PROFILE
+__device__ long long g_ms_wg[32][4];     // every workgroup, last step: phase A start, arrival at barrier A, release from it, arrival at barrier B
 __device__ long long g_ms_prof[2][16];   // wall clock (100 MHz) at the phase boundaries of the LAST step: workgroup 0, workgroup 5
-#define MS_STAMP(i) do { if (threadIdx.x == 0 && s == a.steps - 1 && (me == 0 || me == 5)) g_ms_prof[me == 0 ? 0 : 1][i] = wall_clock64(); } while (0)
+#define MS_STAMP(i) do { if (threadIdx.x == 0 && s == a.steps - 1) { if (me == 0 || me == 5) g_ms_prof[me == 0 ? 0 : 1][i] = wall_clock64(); if ((i) == 1 || (i) == 2 || (i) == 3 || (i) == 6) g_ms_wg[me][(i) == 6 ? 3 : (i) - 1] = wall_clock64(); } } while (0)
 #else
 #define MS_STAMP(i) do { } while (0)
 #endif
@@ -92,7 +94,7 @@ __device__ __forceinline__ bool ms_grid_barrier(unsigned *ctr, unsigned target, 
 template <int KS, int NW>   // hidden = 16 KS; NW waves per workgroup (8: 256 VGPRs per wave -- at 16 waves the 128-register budget spills)
 __global__ __launch_bounds__(64 * NW) void mlp2_steps_kernel(Mlp2StepsArgs a) {
     constexpr int HID = 16 * KS, NR = 64 / NW;     // k blocks of 16 per wave in phase A (in_features <= 1024)
-    constexpr int MAXT = 2;                       // dW1 tiles per wave whose operands are requested ahead
+    constexpr int MAXT = 1;                       // dW1 tiles per wave whose operands are requested ahead
     if ((blockIdx.x & 7) != 0) return;
     const int me = blockIdx.x >> 3;
     const int RT = a.batch / 16, NWG = RT * KS;
@@ -142,16 +144,16 @@ __global__ __launch_bounds__(64 * NW) void mlp2_steps_kernel(Mlp2StepsArgs a) {
                     bv[u] = *reinterpret_cast<const float4 *>(wp + kk);
                 }
             }
-            // (under those loads) the PREVIOUS step's update of this workgroup's W2 tile [16 classes][16 hidden columns] and of b2: every
-            // workgroup read W2 / b2 in that step's phase B, so they could not be updated there; the gradients waited in LDS
-            if (cg == 0 && s > 0) {
-                const float st_prev = adam_step_size(lr, a.w2.beta1, a.w2.beta2, tcur - 1);
-                if (t < 256) {
-                    const int cls = t >> 4, col = hb * 16 + (t & 15);
-                    if (cls < C) adam_update(a.w2.p, a.w2.m, a.w2.v, (long)cls * HID + col, dw2s[cls][t & 15], st_prev, a.w2.beta1, a.w2.beta2, a.w2.eps, a.w2.wd);
-                } else if (me == 0 && t < 256 + C) {
-                    adam_update(a.b2.p, a.b2.m, a.b2.v, t - 256, db2s[t - 256], st_prev, a.b2.beta1, a.b2.beta2, a.b2.eps, a.b2.wd);
-                }
+            // the PREVIOUS step's update of this workgroup's W2 tile [16 classes][16 hidden columns] and of b2 (every workgroup read W2 / b2 in
+            // that step's phase B, so they could not be updated there; the gradients waited in LDS): state requested here, applied after the MFMAs
+            const bool upd_w2 = cg == 0 && s > 0 && t < 256 && (t >> 4) < C, upd_b2 = me == 0 && s > 0 && t >= 256 && t < 256 + C;
+            const long uix = upd_w2 ? (long)(t >> 4) * HID + hb * 16 + (t & 15) : (upd_b2 ? t - 256 : 0);
+            const AdamDev &ua = upd_b2 ? a.b2 : a.w2;
+            float up = 0.f, um = 0.f, uv = 0.f;
+            if (upd_w2 || upd_b2) {
+                up = ua.p[uix];
+                um = ua.m[uix];
+                uv = ua.v[uix];
             }
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
@@ -165,6 +167,14 @@ __global__ __launch_bounds__(64 * NW) void mlp2_steps_kernel(Mlp2StepsArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[wave][lane][e] = (c0[e] + c1[e]) + (c2[e] + c3[e]);
+            if (upd_w2 || upd_b2) {          // optim.rs:99-110 with the previous step's counter
+                const float st_prev = adam_step_size(lr, ua.beta1, ua.beta2, tcur - 1);
+                const float gv = (upd_b2 ? db2s[t - 256] : dw2s[t >> 4][t & 15]) + ua.wd * up;
+                const float mn = ua.beta1 * um + (1.0f - ua.beta1) * gv, vn = ua.beta2 * uv + (1.0f - ua.beta2) * gv * gv;
+                ua.m[uix] = mn;
+                ua.v[uix] = vn;
+                ua.p[uix] = up - st_prev * mn / (sqrtf(vn) + ua.eps);
+            }
             __syncthreads();
             if (wave < 4) {                  // wave e finishes element e of every lane's quad: row 4 g4 + e, column l16
                 float sum = red[0][lane][wave];
@@ -182,6 +192,45 @@ __global__ __launch_bounds__(64 * NW) void mlp2_steps_kernel(Mlp2StepsArgs a) {
         // ---------------- phase B ----------------
         asm volatile("" : "+v"(lane));
         l16 = lane & 15, g4 = lane >> 4;
+        // (1) logits^T, softmax, dlogits, the dZ1 tile of hidden tile hb for every row block: waves 0 .. RT-1 take the low half of the hidden
+        //     dimension of row block `wave`, waves RT .. 2 RT - 1 the high half
+        const bool lo_half = wave < RT, hi_half = wave >= RT && wave < 2 * RT;
+        floatx4 lgp = {0.f, 0.f, 0.f, 0.f};
+        float w2b[4], hm[4], b2v[4], tf = 0.f;
+        constexpr int KH = KS / 2;
+        float4 wv[KH], hv[KH];
+        if (lo_half || hi_half) {            // the critical chain's operands go out first
+            const int r0 = (wave % RT) * 16, kb = hi_half ? 16 * KH : 0;
+            const float *wp = a.w2.p + (long)min(l16, C - 1) * HID + kb + 4 * g4;     // A: class l16
+            const float *hp = a.h + (long)(r0 + l16) * HID + kb + 4 * g4;            // B: row l16
+#pragma unroll
+            for (int u = 0; u < KH; ++u) {
+                wv[u] = *reinterpret_cast<const float4 *>(wp + 16 * u);
+                hv[u] = *reinterpret_cast<const float4 *>(hp + 16 * u);
+            }
+            if (lo_half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cls = min(4 * g4 + i, C - 1);
+                    w2b[i] = a.w2.p[(long)cls * HID + hb * 16 + l16];
+                    b2v[i] = a.b2.p[cls];
+                    hm[i] = a.h[(long)(r0 + 4 * g4 + i) * HID + hb * 16 + l16];
+                }
+                tf = ts[r0 + l16];
+            }
+        }
+        // the NEXT step's X rows of this workgroup's phase-A tile, an eighth of them per workgroup of the row tile (they share the L2): pulled in
+        // now by the last wave, so that phase A does not start with a cold HBM / TLB round trip
+        float4 pf = {0.f, 0.f, 0.f, 0.f};
+        if (wave == NW - 1 && s + 1 < a.steps) {
+            const float *xn = xs + (long)B * in_f + (long)(ra * 16) * in_f;
+            const int c4n = in_f / 4, c4per = (c4n + KS - 1) / KS, c4a = ha * c4per, c4b = min(c4n, c4a + c4per);
+            for (int q = lane; q < 16 * (c4b - c4a); q += 64) {
+                const int r = q / (c4b - c4a), c4 = c4a + q % (c4b - c4a);
+                const float4 v = *reinterpret_cast<const float4 *>(xn + (long)r * in_f + 4 * c4);
+                pf.x += v.x; pf.y += v.y; pf.z += v.z; pf.w += v.w;
+            }
+        }
         // operands that do not depend on this phase's results are requested first, under the logits: the Adam state and the X columns of
         // this wave's first dW1 tiles
         float pv[MAXT][4], mv[MAXT][4], vv[MAXT][4], xv[MAXT][4][4];
@@ -201,32 +250,7 @@ __global__ __launch_bounds__(64 * NW) void mlp2_steps_kernel(Mlp2StepsArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xv[j][rb4][i] = xs[(long)(min(16 * rb4, B - 16) + 4 * g4 + i) * in_f + (on ? ct : ct0) * 16 + l16];
         }
-        // (1) logits^T, softmax, dlogits, the dZ1 tile of hidden tile hb for every row block: waves 0 .. RT-1 take the low half of the hidden
-        //     dimension of row block `wave`, waves RT .. 2 RT - 1 the high half
-        const bool lo_half = wave < RT, hi_half = wave >= RT && wave < 2 * RT;
-        floatx4 lgp = {0.f, 0.f, 0.f, 0.f};
-        float w2b[4], hm[4], b2v[4], tf = 0.f;
         if (lo_half || hi_half) {
-            constexpr int KH = KS / 2;
-            const int r0 = (wave % RT) * 16, kb = hi_half ? 16 * KH : 0;
-            const float *wp = a.w2.p + (long)min(l16, C - 1) * HID + kb + 4 * g4;     // A: class l16
-            const float *hp = a.h + (long)(r0 + l16) * HID + kb + 4 * g4;            // B: row l16
-            float4 wv[KH], hv[KH];
-#pragma unroll
-            for (int u = 0; u < KH; ++u) {
-                wv[u] = *reinterpret_cast<const float4 *>(wp + 16 * u);
-                hv[u] = *reinterpret_cast<const float4 *>(hp + 16 * u);
-            }
-            if (lo_half) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int cls = min(4 * g4 + i, C - 1);
-                    w2b[i] = a.w2.p[(long)cls * HID + hb * 16 + l16];
-                    b2v[i] = a.b2.p[cls];
-                    hm[i] = a.h[(long)(r0 + 4 * g4 + i) * HID + hb * 16 + l16];
-                }
-                tf = ts[r0 + l16];
-            }
             floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
 #pragma unroll
             for (int u = 0; u < KH; ++u) {
@@ -362,6 +386,7 @@ __global__ __launch_bounds__(64 * NW) void mlp2_steps_kernel(Mlp2StepsArgs a) {
                 a.w1.p[widx + (long)e * in_f] = p4[e] - step_sz * mn / (sqrtf(vn) + a.w1.eps);
             }
         }
+        if (pf.x + pf.y + pf.z + pf.w == 1.2345e38f) a.loss[0] = pf.x;   // (never: keeps the prefetch loads)
         MS_STAMP(6);
         if (!ms_grid_barrier(a.sync, (bar += NWG), a.err)) return;
         MS_STAMP(7);
@@ -423,6 +448,11 @@ int th_mlp2_steps(th_ctx *ctx, const float *d_x, const float *d_targets, int ste
 int th_debug_mlp_steps_prof(th_ctx *ctx, long long *h_out32) {
     TH_HIP(hipStreamSynchronize(ctx->stream));
     TH_HIP(hipMemcpyFromSymbol(h_out32, HIP_SYMBOL(th::g_ms_prof), 32 * sizeof(long long)));
+    return 0;
+}
+int th_debug_mlp_steps_wg(th_ctx *ctx, long long *h_out128) {
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out128, HIP_SYMBOL(th::g_ms_wg), 128 * sizeof(long long)));
     return 0;
 }
 #endif

@@ -26,6 +26,10 @@ for it in range(N+2):
     out=(C.c_longlong*32)(); lib.th_debug_mlp_steps_prof(ctx.h,out)
     if it>=2:
         for r in range(2): acc[r]+=np.diff([out[16*r+i] for i in range(8)])*0.01
+wg=(C.c_longlong*128)(); lib.th_debug_mlp_steps_wg.argtypes=[C.c_void_p,C.c_void_p]; lib.th_debug_mlp_steps_wg(ctx.h,wg)
+w=np.array(list(wg),dtype=np.int64).reshape(32,4); base=w[:,0].min()
+print('per workgroup (last step, us from the earliest phase-A start): start, arrives at barrier A, released, arrives at barrier B')
+for i in range(32): print(f'  wg {i:2d} (row tile {i//8}, hidden tile {i%8}): ' + ' '.join(f'{(v-base)*0.01:6.2f}' for v in w[i]))
 names=["W2 / b2 update (workgroup 0)","H tile","barrier A","logits, softmax, dZ1 tile","db1, head gradients, log","dW1 tiles + Adam","barrier B"]
 for r,role in enumerate(["workgroup 0","workgroup 5"]):
     print(role)
