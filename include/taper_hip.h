@@ -401,6 +401,30 @@ typedef struct th_conv_stage {
 int th_conv_chain_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages);
 int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, float *d_cnt, int n,
                       int c_in, int h, int w);
+/* The same launch with the classifier behind it -- Flatten + Linear(c_out h w, classes) + softmax cross-entropy (nn.rs:54-60, 730-756,
+ * loss.rs:101-195, 271-290) -- ROW by row in the chain's last epilogue: everything of that head but the sums over the batch.  The workgroup
+ * that holds image i's pooled map also writes d_dl[i][16] = dlogits of the row for an upstream gradient of exactly 1 (zeros past `classes`),
+ * d_rowstat[i][2] = {-log p[target], 1 if the first arg-max is the target}, and -- d_cbpart [n][c_out], nullable -- the per-channel sums of
+ * dX[i] * [x[i] > 0]: all a bias-only last Conv2dReLU + MaxPool2d needs of its gradient (tensor.rs:1496-1519).  d_tick (nullable): Adam's
+ * step counter, advanced by one (optim.rs:84).  th_wide_head_grads then forms dW, db, the loss, the hit count and the conv bias gradient
+ * (+ their Adam updates) in ONE more launch: the simple CNN's step is two launches.  d_y: the pooled NCHW map as in th_conv_chain_fwd. */
+typedef struct th_chain_head {
+    const float *d_w, *d_bias, *d_targets; /* [classes][c_out h w], [classes] (nullable), [n] */
+    int classes;
+    float *d_dl, *d_rowstat, *d_cbpart;
+    int32_t *d_tick;
+} th_chain_head;
+int th_conv_chain_head_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, int classes);
+int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, int n, int c_in, int h, int w,
+                           const th_chain_head *head);
+/* The batch sums behind th_conv_chain_head_fwd (ops.rs:280-291 through the W^T node, tensor.rs:686-691, loss.rs:164, 283):
+ * d_dw[classes][in] = dl^T . X, d_db[classes] = colsum(dl) (nullable), d_loss[1] = sum(nll) / batch, d_ncorrect[1] (nullable), the step log
+ * (th_log_step; d_metrics nullable), and d_conv_gb[conv_c] = sum_i d_cbpart[i][.] (both nullable).  No workgroup reads a parameter, so every
+ * Adam update (optim.rs:99-110; fuse descriptors nullable, d_t ALREADY ticked) rides in the epilogue of the workgroup that owns the gradient. */
+int th_wide_head_grads(th_ctx *ctx, const float *d_x, const float *d_dl, const float *d_rowstat, const float *d_cbpart, int batch,
+                       int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss, float *d_ncorrect,
+                       float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, const th_adam_fuse *w_fuse,
+                       const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse);
 /* Test hook: launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity
  * tests assert which kernel instance a shape takes): out6 = {16-channel tiles per workgroup (1/2/4), 1 if the
  * operands are staged by LDS-DMA (2-5: the image-resident kernel; 6: a conv chain, out6[0] = its instance id), waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */

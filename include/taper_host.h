@@ -41,6 +41,7 @@ int tp_tape_len(size_t *out);
 int tp_tape_set_compat_zero_sentinel(int on);   /* quirk Q1 */
 int tp_set_full_backward(int on);               /* quirk Q2: 0 = faithful (default) */
 int tp_set_conv_chain(int on);                  /* Trainer steps: 1 (default) = the conv front of a Sequential as one launch where compiled (th_conv_chain_fwd), 0 = layer by layer */
+int tp_set_conv_chain_head(int on);             /* ... and the classifier behind such a front row by row in the same launch where compiled (th_conv_chain_head_fwd + th_wide_head_grads: the simple CNN's step is two launches); default 1 */
 
 /* ---- Tensor (src/tensor.rs:470-541) ---- */
 int tp_tensor_new(const float *h_data, const size_t *shape, int ndim, tp_tensor **out);

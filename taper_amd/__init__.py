@@ -15,7 +15,7 @@ from .api import (  # noqa: F401
     SGD, Adam, AdamW, AdaptiveAvgPool2d, AvgPool2d, Communicator, Conv2d, Conv2dReLU, CosineAnnealingLR, DataLoader, Device,
     Dropout, ExponentialLR, Flatten, Linear, MaxPool2d, MNISTDataset, Module, ReduceLROnPlateau, ReLU, Sequential, Sigmoid,
     StepLR, Tape, Tensor, Trainer, accuracy, bce_loss, cross_entropy_loss, cross_entropy_loss_onehot, format_f32, log_softmax,
-    mse_loss, one_hot, set_conv_chain, set_full_backward, softmax,
+    mse_loss, one_hot, set_conv_chain, set_conv_chain_head, set_full_backward, softmax,
 )
 
 Layer = Module  # the north_star calls the trait nn::Layer

@@ -68,6 +68,11 @@ def set_conv_chain(on: bool):
     tp_check(host.tp_set_conv_chain(1 if on else 0), "tp_set_conv_chain")
 
 
+def set_conv_chain_head(on: bool):
+    """Trainer steps: the classifier behind such a front row by row inside the same launch where compiled (default), or as its own launches"""
+    tp_check(host.tp_set_conv_chain_head(1 if on else 0), "tp_set_conv_chain_head")
+
+
 class Tensor:
     """src/tensor.rs Tensor: a shared handle to device storage + grad slot + tape node."""
 

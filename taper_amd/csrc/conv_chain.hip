@@ -12,11 +12,9 @@
 // Arithmetic = the layer-by-layer kernels (conv_mfma.hip's geometry instances, conv_pool.hip's conv1 kernels): the same k order
 // (pass of 8 channels; k-step s = tap s % 9 of channels 4 (s / 9) + lane group), bias after the sum, ReLU, strict-> pooling maxima,
 // 16-lane plane sums with the same shuffle tree -- the chain's outputs are bit-identical to the layered path's.
-#include "common.h"
+#include "tail_dev.h"
 
 namespace th {
-
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int CH_NT = 512;                                                      // threads per workgroup: 8 waves, two per SIMD
 __host__ __device__ constexpr int ch_cis(int wp) { return wp * wp + ((16 - (wp * wp) % 32) + 32) % 32; }   // channel stride = 16 mod 32: the
@@ -35,12 +33,24 @@ __device__ long long g_chain_prof[32];    // wall clock (100 MHz) at phase bound
 #define CH_CLK(i) do { } while (0)
 #endif
 
+// The classifier behind a chain that ends in a pooled map (th_conv_chain_head_fwd): Linear(k, classes) on the flattened map + softmax
+// cross-entropy, one ROW per workgroup -- the image's logits, loss term, dlogits and (cbpart) the per-channel sums of dX * [x > 0], all
+// that a bias-only last conv needs of its gradient (nn.rs:54-60, loss.rs:101-195, 271-290, ops.rs:254-265, tensor.rs:1496-1519)
+struct ChainHeadArgs {
+    const float *w, *bias, *targets;   // [classes][k], [classes] (nullable), [n]
+    float *dl, *rowstat, *cbpart;      // [n][16] (zeros past `classes`), [n][2] = {nll, hit}, [n][c_last] (nullable)
+    int32_t *tick;                     // nullable: Adam's step counter, += 1 (optim.rs:84; nothing in this launch reads it)
+    int classes, k, c_last, hw;
+    float inv_b;
+};
+
 struct ConvChainArgs {
     const float *x;            // [n][1][28][28]
     const float *w[5], *b[5];  // taper layout [9 c_in][c_out] (tensor.rs:1262), bias [c_out]
     float *y;                  // reference chain: [n][128] plane means; simple chain: [n][64][7][7] pooled map
     float *cnt;                // reference chain: [n][128] outputs > 0 per plane (nullable)
     int n;
+    ChainHeadArgs head;        // conv_chain_simple_kernel<true, ..> only
 };
 
 // ---- one 3x3 / pad 1 layer on the matrix cores: IN [C_IN][CIS] padded planes in LDS -> NSLOT accumulator tiles per wave ------------------------
@@ -195,8 +205,8 @@ __device__ __forceinline__ void chain_store(const floatx4 (&acc)[ChainGeo<S, C_O
 
 // 2x2 / stride-2 maxima of the tile (strict >: NaN never wins, tensor.rs:1449-1461) -> interior of the next layer's padded planes, or
 // (TO_GLOBAL) the pooled NCHW map of this image.  A thread owns one pooled position and a block of channels.
-template <int S, int C_OUT, bool TO_GLOBAL>
-__device__ __forceinline__ void chain_pool(const float *tile, float *out, int t) {
+template <int S, int C_OUT, bool TO_GLOBAL, bool COPY = false>
+__device__ __forceinline__ void chain_pool(const float *tile, float *out, int t, float *flat = nullptr) {
     constexpr int LD = ch_tile_ld(S * S), HP = S / 2, NP = HP * HP, WPO = HP + 2, CISO = ch_cis(WPO);
     constexpr int CHUNKS = (CH_NT / NP >= 8 ? 8 : (CH_NT / NP >= 4 ? 4 : (CH_NT / NP >= 2 ? 2 : 1))), CPC = C_OUT / CHUNKS;
     static_assert(S % 2 == 0 && NP <= CH_NT && C_OUT % CHUNKS == 0, "pooled plane fits the workgroup");
@@ -214,6 +224,7 @@ __device__ __forceinline__ void chain_pool(const float *tile, float *out, int t)
         m = r1.x > m ? r1.x : m;
         m = r1.y > m ? r1.y : m;
         *o = m;
+        if (COPY) flat[(chunk * CPC + cl) * NP + q] = m;     // the image's flattened [C_OUT][NP] map, for the classifier rows below
     }
 }
 
@@ -409,11 +420,109 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
 #endif
 }
 
+// ---- classifier rows behind a chain that ends in a pooled map: one image = one row of the batch ------------------------------------------------
+// Forward, loss term, dlogits and dX of a row depend on that row only (nn.rs:54-60, loss.rs:101-195, ops.rs:254-265): the workgroup that
+// holds the image's flattened map XM [k] in LDS forms its `classes` logits (thread t owns elements t, t + 512, ...: the W reads are
+// perfectly coalesced, [classes][k] is 125 KB and L2-resident), the softmax / NLL / hit / dlogits of the row (tail_row_softmax: the
+// arithmetic of every fused head of this library), then dX[k] = sum_c dl[c] W[c][k] from the SAME weight registers, masked by x > 0, and
+// its per-channel sums -- what a bias-only Conv2dReLU + max-pool in front needs of its gradient (every pooled gradient lands on exactly one
+// conv output whose ReLU mask is "pooled value > 0", tensor.rs:1496-1519).  What is left for a second launch are the sums over the
+// batch: dW = dl^T X, db, the loss, the conv bias (wide_head.hip: wide_grads_kernel).
+// One buffer_load per value and nothing else: the lane's byte offset 4 t is the only vector operand, (c k + 512 j) 4 is a scalar; rows past
+// `classes` lie past the descriptor's range and read as zeros; the last round's elements past k are selected to zero (they would read the
+// next class's row).
+template <int NJ, int NC, int KC>
+__device__ __forceinline__ void chain_head_weights(const ChainHeadArgs &h, float (&wv)[NJ][NC], int t) {
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)h.w, 0, h.classes * KC * 4, 0x00020000);
+    const int vo = t * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vo, (c * KC + CH_NT * j) * 4, 0));
+            wv[j][c] = (CH_NT * (j + 1) <= KC || t + CH_NT * j < KC) ? v : 0.f;
+        }
+    }
+}
+
+// xm: LDS [k] (the map; overwritten by the masked dX), red: LDS [NC][CH_NT] + 64 floats.  Ends without a barrier (global stores only).
+template <int NJ, int NC>
+__device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const float (&wv)[NJ][NC], float *xm, float *red, int img, int t) {
+    static_assert(NC <= 16 && NC * 32 <= CH_NT, "one 32-lane half-wave per class in the reduction");
+    const int lane = t & 63, r16 = lane & 15, g4 = lane >> 4;
+    float *sc = red + NC * CH_NT;            // [0..15] logits, [16..31] dlogits
+    float xv[NJ], part[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) part[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int k = t + CH_NT * j;
+        xv[j] = k < h.k ? xm[k] : 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) part[c] = fmaf(xv[j], wv[j][c], part[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) red[c * CH_NT + t] = part[c];
+    chain_sync();
+    if (t < NC * 32) {                       // class t / 32: lane i adds threads i, i + 32, ... in order, then a fixed tree
+        const int c = t >> 5, i = t & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < CH_NT / 32; ++e) s += red[c * CH_NT + i + 32 * e];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 32);
+        if (i == 0) sc[c] = s + ((h.bias && c < h.classes) ? h.bias[c] : 0.f);   // nn.rs:54-60: bias after the product
+    }
+    chain_sync();
+    float lg[4], dl[4], nll;
+    int bi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lg[i] = (g4 * 4 + i < h.classes && g4 * 4 + i < NC) ? sc[g4 * 4 + i] : -INFINITY;
+    const float tf = h.targets[img];
+    tail_row_softmax(lg, g4, h.classes, tf, h.inv_b, dl, nll, bi);   // every wave, redundantly: no exchange, no extra barrier
+    if (t < 64 && r16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[16 + g4 * 4 + i] = dl[i];
+            h.dl[(long)img * 16 + g4 * 4 + i] = dl[i];
+        }
+        if (g4 == 0) {
+            h.rowstat[(long)img * 2] = nll;
+            h.rowstat[(long)img * 2 + 1] = fabsf((float)bi - tf) < 1e-6f ? 1.f : 0.f;   // loss.rs:283
+        }
+    }
+    if (!h.cbpart) return;                   // (uniform)
+    chain_sync();
+    float d16[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) d16[c] = sc[16 + c];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int k = t + CH_NT * j;
+        float dx = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dx = fmaf(d16[c], wv[j][c], dx);      // ops.rs:254-265, class order
+        if (k < h.k) xm[k] = xv[j] > 0.f ? dx : 0.f;
+    }
+    chain_sync();
+    for (int ch = t >> 4; ch < h.c_last; ch += CH_NT / 16) {                // 16 lanes per channel
+        const float *row = xm + ch * h.hw;
+        float p = 0.f;
+        for (int q = r16; q < h.hw; q += 16) p += row[q];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) p += __shfl_xor(p, off, 16);
+        if (r16 == 0) h.cbpart[(long)img * h.c_last + ch] = p;
+    }
+}
+
 // ---- the simple CNN's front (examples/train_mnist_cnn.rs:64-100): 1 -> 32 + pool, 32 -> 64 + pool -> [64][7][7] ----
 //   T1 [32][788] @0  conv1's outputs    A [32][272] @25216  conv2's input    T [64][196] @0  conv2's outputs (over T1)    IMG [900] @33920
+//   HEAD: XM [3136] @12544 (behind T: the flattened pooled map), RED [NC][512] + 64 @25216 (over A, dead after conv2's k loop)
 constexpr int CS_A = 32 * ch_tile_ld(784), CS_IMG = CS_A + 32 * ch_cis(16), CS_LDS = CS_IMG + 900;
-static_assert(64 * ch_tile_ld(196) <= CS_A, "LDS map");
+constexpr int CS_XM = 64 * ch_tile_ld(196), CS_K = 64 * 49, CS_NJ = (CS_K + CH_NT - 1) / CH_NT;
+static_assert(64 * ch_tile_ld(196) <= CS_A && CS_XM + CS_K <= CS_A && CS_A + 16 * CH_NT + 64 <= CS_LDS, "LDS map");
 
+template <bool HEAD, int NC>
 __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -427,6 +536,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     chain_bias<28, 32>(a.b[0], bv, wave, lane);
     chain_load_image(a.x + (long)img * 784, IMG, t);
     chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, lane);      // conv2's first pass: in flight under conv1 and its pool
+    if (HEAD && a.head.tick && img == 0 && t == 0) a.head.tick[0] += 1;
     chain_sync();
     {   // conv1 1 -> 32 @28 + pool
         floatx4 acc[ChainGeo<28, 32>::NSLOT];
@@ -439,10 +549,16 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     }
     floatx4 acc[ChainGeo<14, 64>::NSLOT];
     chain_bias<14, 64>(a.b[1], bv, wave, lane);
+    float hw_[CS_NJ][NC];
+    if constexpr (HEAD) chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t);   // the classifier's weights: in flight under conv2's k loop
     chain_mfma<14, 32, 64>(A, a.w[1], wc, acc, wave, lane);
     chain_store<14, 64, false>(acc, bv, T, wave, lane);          // (T1 is dead; T does not overlap A)
     chain_sync();
-    chain_pool<14, 64, true>(T, a.y + (long)img * 64 * 49, t);
+    chain_pool<14, 64, true, HEAD>(T, a.y + (long)img * 64 * 49, t, lds + CS_XM);
+    if constexpr (HEAD) {
+        chain_sync();                                            // XM complete; every wave is past conv2's k loop: A is free
+        chain_head_rows<CS_NJ, NC>(a.head, hw_, lds + CS_XM, A, img, t);
+    }
 #endif
 }
 
@@ -482,10 +598,41 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
         hipLaunchKernelGGL(conv_chain_reference_kernel, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
     } else {
         const int lds = CS_LDS * (int)sizeof(float);
-        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(conv_chain_simple_kernel, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
     }
     t_last_conv_cfg[0] = kind; t_last_conv_cfg[1] = 6; t_last_conv_cfg[2] = 0;   // 6: a conv chain (th_debug_last_conv_config)
+    t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+// the classifier rows ride in the chain's last epilogue where the flattened map fits a thread's registers (<= 7 elements per thread)
+int th_conv_chain_head_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, int classes) {
+    if (classes < 1 || classes > 16) return 0;
+    return th_conv_chain_supported(c_in, h, w, stages, n_stages) == 2 ? 2 : 0;
+}
+
+int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, int n, int c_in, int h, int w,
+                           const th_chain_head *head) {
+    TH_REQUIRE(ctx && d_x && d_y && stages && head && n > 0, "th_conv_chain_head_fwd: null argument");
+    TH_REQUIRE(head->d_w && head->d_targets && head->d_dl && head->d_rowstat, "th_conv_chain_head_fwd: the head needs d_w, d_targets, d_dl, d_rowstat");
+    const int kind = th_conv_chain_head_supported(c_in, h, w, stages, n_stages, head->classes);
+    TH_REQUIRE(kind != 0, "th_conv_chain_head_fwd: no compiled chain + head for these stages (th_conv_chain_head_supported)");
+    ConvChainArgs a{};
+    a.x = d_x; a.y = d_y; a.cnt = nullptr; a.n = n;
+    for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
+    a.head = ChainHeadArgs{head->d_w, head->d_bias, head->d_targets, head->d_dl, head->d_rowstat, head->d_cbpart, head->d_tick,
+                           head->classes, CS_K, 64, 49, 1.0f / (float)n};
+    const int lds = CS_LDS * (int)sizeof(float);
+    if (head->classes <= 10) {
+        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((conv_chain_simple_kernel<true, 10>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((conv_chain_simple_kernel<true, 16>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+    }
+    t_last_conv_cfg[0] = kind; t_last_conv_cfg[1] = 7; t_last_conv_cfg[2] = 0;   // 7: a conv chain with the classifier rows
     t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;
     TH_LAUNCH_CHECK();
     return 0;

@@ -53,6 +53,7 @@ int tp_tape_len(size_t *out) { TP_BEGIN *out = Tape::len(); TP_END }
 int tp_tape_set_compat_zero_sentinel(int on) { TP_BEGIN Tape::set_compat_zero_sentinel(on != 0); TP_END }
 int tp_set_full_backward(int on) { TP_BEGIN set_full_backward(on != 0); TP_END }
 int tp_set_conv_chain(int on) { TP_BEGIN set_conv_chain(on != 0); TP_END }
+int tp_set_conv_chain_head(int on) { TP_BEGIN set_conv_chain_head(on != 0); TP_END }
 
 int tp_tensor_new(const float *h, const size_t *shape, int nd, tp_tensor **out) {
     TP_BEGIN

@@ -229,6 +229,70 @@ Tensor linear_cross_entropy_wide(const Tensor &h, const Tensor &w, const Tensor 
     return loss;
 }
 
+bool conv_chain_head_supported(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor &w, const Tensor &bias) {
+    if (stages.empty() || stages.back().post != TH_CHAIN_MAXPOOL2 || x.shape().size() != 4 || w.shape().size() != 2) return false;
+    if (!w.get_requires_grad() || w.has_grad()) return false;
+    if (bias.defined() && (!bias.get_requires_grad() || bias.has_grad() || bias.shape() != Shape{w.shape()[0]})) return false;
+    const Tensor &cb = stages.back().bias;
+    if (cb.defined() && cb.get_requires_grad() && cb.has_grad()) return false;   // gradients are written, never accumulated
+    size_t h = x.shape()[2], wd = x.shape()[3];
+    for (const auto &st : stages)
+        if (st.post == TH_CHAIN_MAXPOOL2) { h /= 2; wd /= 2; }
+    if (w.shape()[1] != stages.back().weight.shape()[0] * h * wd) return false;
+    return x.conv_chain_head_supported(stages, (int)w.shape()[0]) != 0;
+}
+
+Tensor conv_chain_head_cross_entropy(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor &w, const Tensor &bias,
+                                     const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log) {
+    // nn.rs:149-151 (conv rows, Flatten, Linear) + loss.rs:136-195 + the backward closures of the Linear (ops.rs:238-294,
+    // tensor.rs:574-587, 674-694) and of the last Conv2dReLU's bias behind its pool (tensor.rs:1496-1519, 2017-2024, ops.rs:358-369)
+    TAPER_ASSERT(conv_chain_head_supported(x, stages, w, bias), "conv_chain_head_cross_entropy: unsupported stages / gradient state");
+    TAPER_ASSERT(targets.shape()[0] == x.shape()[0], "Batch sizes must match");
+    th_ctx *ctx = Device::ctx();
+    Adam *fa = FusedAdamScope::active();
+    if (fa && fa->has_deferred()) fa->flush_deferred();   // updates an earlier (other) step form left behind: with their own counter
+    const int n = (int)x.shape()[0], classes = (int)w.shape()[0], k = (int)w.shape()[1];
+    const Tensor &cbias = stages.back().bias;
+    const int c_last = (int)stages.back().weight.shape()[0];
+    const bool cb_grad = cbias.defined() && cbias.get_requires_grad();
+    auto dl = Buffer::alloc((size_t)n * 16), rowstat = Buffer::alloc((size_t)n * 2);
+    std::shared_ptr<Buffer> cbpart = cb_grad ? Buffer::alloc((size_t)n * c_last) : nullptr;
+    // launch 1: the conv rows with the classifier's row-parallel part in the last epilogue; opens the optimizer step (optim.rs:84)
+    th_chain_head head{w.dptr(), bias.defined() ? bias.dptr() : nullptr, targets.dptr(), classes, dl->d, rowstat->d,
+                       cbpart ? cbpart->d : nullptr, fa ? fa->d_tick() : nullptr};
+    Tensor map = x.conv_chain_head(stages, head);
+    // launch 2: the sums over the batch, Adam in the epilogues (nothing there reads a parameter)
+    Tensor loss = Tensor::empty({1});
+    float *nc = nullptr;
+    if (n_correct_out) {
+        *n_correct_out = Tensor::empty({1});
+        nc = n_correct_out->dptr();
+    }
+    auto slot = [](const Tensor &p) -> float * {
+        if (!p.defined()) return nullptr;
+        if (!p.grad_->buf) p.grad_->buf = Buffer::alloc(p.len());
+        p.grad_->known_zero = false;
+        return p.grad_->buf->d;
+    };
+    float *dw = slot(w), *db = slot(bias), *gcb = cb_grad ? slot(cbias) : nullptr;
+    th_adam_fuse wf{}, bf{}, cf{};
+    const bool fw = fa && fa->fuse_for(w, &wf), fb = fa && bias.defined() && fa->fuse_for(bias, &bf), fc = fa && cb_grad && fa->fuse_for(cbias, &cf);
+    TH(th_wide_head_grads(ctx, map.dptr(), dl->d, rowstat->d, cbpart ? cbpart->d : nullptr, n, k, classes, c_last, dw, db, gcb, loss.dptr(), nc,
+                          log ? log->d_metrics : nullptr, log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0,
+                          fw ? &wf : nullptr, fb ? &bf : nullptr, fc ? &cf : nullptr));
+    loss.set_requires_grad(true);
+    Tensor ww = w, bb = bias, cc = cb_grad ? cbias : Tensor(), out = loss;
+    Tape::push(loss, true, [ww, bb, cc, out]() {
+        if (!out.has_grad()) return;
+        // the gradients were produced by the forward launches for an upstream grad of exactly 1
+        TAPER_ASSERT(out.grad_->shared_const, "conv_chain_head_cross_entropy: only loss.backward() from the root is supported");
+        ww.grad_->has = true;
+        if (bb.defined()) bb.grad_->has = true;
+        if (cc.defined()) cc.grad_->has = true;
+    });
+    return loss;
+}
+
 bool mlp_tail_supported(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2) {
     if (x.shape().size() != 2 || w1.shape().size() != 2 || w2.shape().size() != 2) return false;
     if (x.shape()[1] != w1.shape()[1] || w2.shape()[1] != w1.shape()[0]) return false;
@@ -499,8 +563,36 @@ static bool g_conv_chain = [] { const char *e = std::getenv("TAPER_CONV_CHAIN");
 void set_conv_chain(bool on) { g_conv_chain = on; }
 bool conv_chain_enabled() { return g_conv_chain; }
 static bool chain_fuse() { return g_conv_chain; }
+// TAPER_CHAIN_HEAD=0: the classifier behind a chain keeps its own launches (th_linear_xent_wide + the bias finish)
+static bool g_conv_chain_head = [] { const char *e = std::getenv("TAPER_CHAIN_HEAD"); return !(e && e[0] == '0'); }();
+void set_conv_chain_head(bool on) { g_conv_chain_head = on; }
+bool conv_chain_head_enabled() { return g_conv_chain_head; }
 
 Tensor Sequential::forward(const Tensor &input) const { return forward_prefix(input, layers.size()); }  // nn.rs:149-151
+
+size_t Sequential::conv_stages_at(size_t i, size_t n_layers, std::vector<ConvStage> *stages) const {
+    size_t j = i;
+    while (j < n_layers) {
+        auto *cv = dynamic_cast<Conv2d *>(layers[j].get());
+        if (!(cv && cv->fuse_relu && cv->groups == 1 && cv->stride == std::make_pair(1, 1) && cv->dilation == std::make_pair(1, 1) &&
+              cv->padding == std::make_pair(1, 1) && cv->bias.defined()))
+            break;
+        int post = TH_CHAIN_NONE;
+        if (j + 1 < n_layers) {
+            auto *mp = dynamic_cast<MaxPool2d *>(layers[j + 1].get());
+            auto *gp = dynamic_cast<AdaptiveAvgPool2d *>(layers[j + 1].get());
+            if (mp && mp->kernel == std::make_pair(2, 2) && (mp->stride == std::make_pair(0, 0) || mp->stride == std::make_pair(2, 2)) &&
+                mp->padding == std::make_pair(0, 0))
+                post = TH_CHAIN_MAXPOOL2;
+            else if (gp && gp->output_size == std::make_pair(1, 1))
+                post = TH_CHAIN_GLOBAL_AVG;
+        }
+        stages->push_back({cv->weight, cv->bias, post});
+        j += post == TH_CHAIN_NONE ? 1 : 2;
+        if (post == TH_CHAIN_GLOBAL_AVG) break;
+    }
+    return j;
+}
 
 Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
     Tensor x = input;
@@ -517,26 +609,7 @@ Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
             // Trainer steps: the whole run of Conv2dReLU(3x3, stride 1, pad 1) [+ MaxPool2d(2) | + global average pool] rows in front of the
             // classifier as ONE launch, when an instance is compiled for it (th_conv_chain_supported): the maps never leave the CU
             std::vector<ConvStage> stages;
-            size_t j = i;
-            while (j < n_layers) {
-                auto *cv = dynamic_cast<Conv2d *>(layers[j].get());
-                if (!(cv && cv->fuse_relu && cv->groups == 1 && cv->stride == std::make_pair(1, 1) && cv->dilation == std::make_pair(1, 1) &&
-                      cv->padding == std::make_pair(1, 1) && cv->bias.defined()))
-                    break;
-                int post = TH_CHAIN_NONE;
-                if (j + 1 < n_layers) {
-                    auto *mp = dynamic_cast<MaxPool2d *>(layers[j + 1].get());
-                    auto *gp = dynamic_cast<AdaptiveAvgPool2d *>(layers[j + 1].get());
-                    if (mp && mp->kernel == std::make_pair(2, 2) && (mp->stride == std::make_pair(0, 0) || mp->stride == std::make_pair(2, 2)) &&
-                        mp->padding == std::make_pair(0, 0))
-                        post = TH_CHAIN_MAXPOOL2;
-                    else if (gp && gp->output_size == std::make_pair(1, 1))
-                        post = TH_CHAIN_GLOBAL_AVG;
-                }
-                stages.push_back({cv->weight, cv->bias, post});
-                j += post == TH_CHAIN_NONE ? 1 : 2;
-                if (post == TH_CHAIN_GLOBAL_AVG) break;
-            }
+            const size_t j = conv_stages_at(i, n_layers, &stages);
             if (stages.size() >= 2 && stages.back().post != TH_CHAIN_NONE && x.conv_chain_supported(stages)) {
                 x = x.conv_chain(stages);
                 i = j - 1;
@@ -1154,6 +1227,17 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
             }
         }
     }
+    if (last && !hidden && !used_head && fuse_head >= 2 && seq->fuse && conv_chain_enabled() && conv_chain_head_enabled() && nl >= 3 &&
+        PoolBiasScope::active() && xin.shape().size() == 4) {
+        // conv rows + Flatten + Linear + cross-entropy (the simple CNN): two launches per step
+        auto *fl = dynamic_cast<Flatten *>(seq->layers[nl - 2].get());
+        std::vector<ConvStage> stages;
+        if (fl && fl->start_dim == 1 && seq->conv_stages_at(0, nl - 2, &stages) == nl - 2 &&
+            conv_chain_head_supported(xin, stages, last->weight, last->bias)) {
+            loss = conv_chain_head_cross_entropy(xin, stages, last->weight, last->bias, y, &ncorrect, &sink);
+            used_head = true;
+        }
+    }
     if (last && !used_head) {
         Tensor h;
         if (hidden) {   // Linear + ReLU + Linear + cross-entropy: two launches per step
@@ -1264,6 +1348,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     }
     key.push_back((uintptr_t)full_backward());
     key.push_back((uintptr_t)conv_chain_enabled());
+    key.push_back((uintptr_t)conv_chain_head_enabled());
     if (!graphs_.empty() && graph_key_ != key) drop_graphs();
 
     size_t done = 0;

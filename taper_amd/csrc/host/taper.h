@@ -174,6 +174,10 @@ class Tensor {
     // gradient -- no conv hands one to its input -- and it is taken from the chain's output).  post: TH_CHAIN_* of include/taper_hip.h.
     int conv_chain_supported(const std::vector<ConvStage> &stages) const;   // 0, or the compiled instance's id
     Tensor conv_chain(const std::vector<ConvStage> &stages) const;
+    // ... with the classifier behind it (Flatten + Linear + cross-entropy) done row by row in the same launch (th_conv_chain_head_fwd):
+    // returns the pooled map, records NO tape node -- conv_chain_head_cross_entropy (below) owns the step's backward
+    int conv_chain_head_supported(const std::vector<ConvStage> &stages, int classes) const;
+    Tensor conv_chain_head(const std::vector<ConvStage> &stages, const th_chain_head &head) const;
     Tensor max_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride /* {0,0} = None */,
                       std::pair<int, int> padding) const;
     Tensor avg_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride, std::pair<int, int> padding) const;
@@ -218,6 +222,9 @@ bool full_backward();
 // false = layer by layer (the measurement probe TAPER_CONV_CHAIN=0 sets the initial value).
 void set_conv_chain(bool on);
 bool conv_chain_enabled();
+// ... and the classifier's rows inside that launch where compiled (conv_chain_head_cross_entropy; TAPER_CHAIN_HEAD=0 sets the initial value)
+void set_conv_chain_head(bool on);
+bool conv_chain_head_enabled();
 
 // ---- loss (src/loss.rs) ------------------------------------------------------
 Tensor log_softmax(const Tensor &x, int dim = -1);                         // loss.rs:101-126
@@ -241,6 +248,12 @@ Tensor linear_cross_entropy(const Tensor &h, const Tensor &weight, const Tensor 
 bool linear_cross_entropy_wide_supported(const Tensor &h, const Tensor &weight, const Tensor &bias);
 Tensor linear_cross_entropy_wide(const Tensor &h, const Tensor &weight, const Tensor &bias, const Tensor &targets,
                                  Tensor *n_correct_out, const StepLogSink *log);
+// A convolutional front that ends in a pooled map (Tensor::conv_chain), Flatten, Linear, cross-entropy -- the simple CNN of BASELINE
+// configs[2] -- as TWO launches: the chain with the classifier's rows in its last epilogue (th_conv_chain_head_fwd), then every sum over
+// the batch with the Adam updates in the epilogues (th_wide_head_grads).  Same contract as linear_cross_entropy.
+bool conv_chain_head_supported(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor &weight, const Tensor &bias);
+Tensor conv_chain_head_cross_entropy(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor &weight, const Tensor &bias,
+                                     const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log);
 // x -> relu(x . W1^T + b1) -> . W2^T + b2 -> cross-entropy as TWO launches: th_linear_fwd_ex (which also carries the
 // previous step's deferred Adam updates and opens this step) and th_mlp_tail (head + the hidden layer's whole
 // backward + its Adam update; with an input that requires a gradient also dX, whole tiles only).  Same contract as
@@ -378,6 +391,9 @@ class Sequential : public Module {  // nn.rs:130-162
     explicit Sequential(std::vector<std::shared_ptr<Module>> l) : layers(std::move(l)) {}
     Tensor forward(const Tensor &input) const override;
     Tensor forward_prefix(const Tensor &input, size_t n_layers) const;  // layers [0, n_layers)
+    // the run of Conv2dReLU(3x3, stride 1, pad 1) [+ MaxPool2d(2) | + global average pool] rows that starts at layer i (Tensor::conv_chain's
+    // stage list); returns the index of the first layer behind the run
+    size_t conv_stages_at(size_t i, size_t n_layers, std::vector<ConvStage> *stages) const;
     std::vector<Tensor> parameters() const override;
     const char *name() const override { return "Sequential"; }
 };

@@ -1030,6 +1030,26 @@ Tensor Tensor::conv_chain(const std::vector<ConvStage> &stages) const {
     return out;
 }
 
+int Tensor::conv_chain_head_supported(const std::vector<ConvStage> &stages, int classes) const {
+    std::vector<th_conv_stage> d;
+    if (!conv_chain_describe(*this, stages, &d)) return 0;
+    if (shape_[0] < 96) return 0;   // (as conv_chain_supported: one image per workgroup)
+    return th_conv_chain_head_supported((int)shape_[1], (int)shape_[2], (int)shape_[3], d.data(), (int)d.size(), classes);
+}
+
+Tensor Tensor::conv_chain_head(const std::vector<ConvStage> &stages, const th_chain_head &head) const {
+    // nn.rs:149-151 over the Conv2dReLU / MaxPool2d rows, Flatten (730-756) and the last Linear (54-60) + loss.rs:101-195 row by row
+    std::vector<th_conv_stage> d;
+    TAPER_ASSERT(conv_chain_describe(*this, stages, &d) && stages.back().post == TH_CHAIN_MAXPOOL2, "conv_chain_head: unsupported stages / mode");
+    const int n = (int)shape_[0];
+    int h = (int)shape_[2], w = (int)shape_[3];
+    for (const auto &st : stages)
+        if (st.post == TH_CHAIN_MAXPOOL2) { h /= 2; w /= 2; }
+    Tensor out = empty({(size_t)n, stages.back().weight.shape()[0], (size_t)h, (size_t)w});
+    TH(th_conv_chain_head_fwd(Device::ctx(), dptr(), d.data(), (int)d.size(), out.dptr(), n, (int)shape_[1], (int)shape_[2], (int)shape_[3], &head));
+    return out;
+}
+
 Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pair<int, int> p) const {  // tensor.rs:1391-1521
     TAPER_ASSERT(shape_.size() == 4, "Input must be 4D: [N, C, H, W]");
     if (s.first == 0) s = k;  // stride.unwrap_or(kernel_size)

@@ -333,6 +333,143 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
     }
 }
 
+// ---- th_wide_head_grads: the batch sums behind a chain launch that already did the classifier ROW by row (conv_chain.hip:
+// chain_head_rows) -- dW = dl^T X, db, the loss, the hit count, the conv bias in front -- with every Adam update in the epilogue of the
+// workgroup that owns the gradient: no workgroup of this launch reads a parameter, so nothing is deferred.
+//   blocks [0, n_col)      32 input columns each: 16 waves x 16-row blocks of dl^T X on v_mfma_f32_16x16x4_f32 (A = dl^T straight from the
+//                          [n][16] row records, B = X[row][col]), cross-wave sum in fixed order, Adam(W)
+//   block n_col            db (+ Adam), loss, hit count, step log
+//   blocks > n_col         16 conv channels each: sum over the images of the per-image channel sums (+ Adam)
+struct WideGradArgs {
+    const float *x, *dl, *rowstat, *cbpart;
+    int batch, k, c, conv_c, n_col;
+    float *dw, *db, *conv_gb, *loss, *ncorrect, *metrics;
+    int64_t capacity;
+    int64_t *state;
+    int64_t advance;
+    AdamDev fw, fb, fcb;
+};
+
+// column sums of a [rows][ld] slab, columns col0 .. col0 + 15 (ncols live): thread t < 16 returns the sum of column col0 + t, rows in
+// groups of 64 (thread (g, c) adds rows g, g + 64, ...), groups added in order.  1024 threads.
+__device__ __forceinline__ float slab_colsum16(const float *__restrict__ p, int ld, int rows, int col0, int ncols, float (*red)[16], int t) {
+    const int g = t >> 4, c = t & 15;
+    float s = 0.f;
+    if (c < ncols)
+        for (int r = g; r < rows; r += 64) s += p[(long)r * ld + col0 + c];
+    red[g][c] = s;
+    __syncthreads();
+    float tot = 0.f;
+    if (t < 16)
+        for (int g2 = 0; g2 < 64; ++g2) tot += red[g2][t];
+    __syncthreads();
+    return tot;
+}
+
+__global__ __launch_bounds__(64 * WH_NW) void wide_grads_kernel(WideGradArgs a) {
+    __shared__ float red[WH_NW][WH_TX][64][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const int B = a.batch, K = a.k, C = a.c;
+    if ((int)blockIdx.x < a.n_col) {
+        const int col0 = blockIdx.x * 16 * WH_TX;
+        // the finishing lanes (wave e < 4: class 4 g4 + e, column r16 of each tile) request their Adam state before anything else
+        const int fcls = g4 * 4 + wave;
+        float fp[WH_TX], fm[WH_TX], fv[WH_TX];
+        const bool fin = wave < 4 && fcls < C && a.fw.p;
+#pragma unroll
+        for (int tx = 0; tx < WH_TX; ++tx) {
+            const int col = col0 + tx * 16 + r16;
+            const bool ok = fin && col < K;
+            const long i = (long)fcls * K + col;
+            fp[tx] = ok ? a.fw.p[i] : 0.f;
+            fm[tx] = ok ? a.fw.m[i] : 0.f;
+            fv[tx] = ok ? a.fw.v[i] : 0.f;
+        }
+        floatx4 accw[WH_TX];
+#pragma unroll
+        for (int tx = 0; tx < WH_TX; ++tx) accw[tx] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < B; c0 += 16 * WH_NW) {
+            const int r0 = c0 + wave * 16;
+            if (r0 >= B) break;                        // wave-uniform
+            float at[4], xv[WH_TX][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {              // A[class r16][row 4 g4 + s] = dl[row][class]; B = X[row 4 g4 + s][col r16]
+                const int row = r0 + g4 * 4 + s;
+                at[s] = row < B ? a.dl[(long)row * 16 + r16] : 0.f;
+#pragma unroll
+                for (int tx = 0; tx < WH_TX; ++tx) {
+                    const int col = col0 + tx * 16 + r16;
+                    xv[tx][s] = (row < B && col < K) ? a.x[(long)row * K + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int tx = 0; tx < WH_TX; ++tx) accw[tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[s], xv[tx][s], accw[tx], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tx = 0; tx < WH_TX; ++tx)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][tx][lane][i] = accw[tx][i];
+        __syncthreads();
+        if (wave < 4) {                                // deterministic cross-wave sum; wave e finishes class 4 g4 + e
+            const float step = a.fw.p ? adam_dev_step(a.fw) : 0.f;
+#pragma unroll
+            for (int tx = 0; tx < WH_TX; ++tx) {
+                const int col = col0 + tx * 16 + r16;
+                float sum = red[0][tx][lane][wave];
+#pragma unroll
+                for (int w = 1; w < WH_NW; ++w) sum += red[w][tx][lane][wave];
+                if (fcls < C && col < K) {
+                    const long i = (long)fcls * K + col;
+                    a.dw[i] = sum;
+                    if (a.fw.p) {                      // optim.rs:99-110 on the state requested at entry
+                        const float gv = sum + a.fw.wd * fp[tx];
+                        const float mv = a.fw.beta1 * fm[tx] + (1.0f - a.fw.beta1) * gv;
+                        const float vv = a.fw.beta2 * fv[tx] + (1.0f - a.fw.beta2) * gv * gv;
+                        a.fw.m[i] = mv;
+                        a.fw.v[i] = vv;
+                        a.fw.p[i] = fp[tx] - step * mv / (sqrtf(vv) + a.fw.eps);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    float(*cred)[16] = reinterpret_cast<float(*)[16]>(&red[0][0][0][0]);   // [64][16]
+    if ((int)blockIdx.x == a.n_col) {
+        const int64_t state0 = a.metrics ? a.state[0] : 0, state1 = a.metrics ? a.state[1] : 0;
+        const float dbs = slab_colsum16(a.dl, 16, B, 0, C, cred, t);          // tensor.rs:686-691
+        if (t < C && a.db) {
+            a.db[t] = dbs;
+            if (a.fb.p) adam_update(a.fb.p, a.fb.m, a.fb.v, t, dbs, adam_dev_step(a.fb), a.fb.beta1, a.fb.beta2, a.fb.eps, a.fb.wd);
+        }
+        const float st = slab_colsum16(a.rowstat, 2, B, 0, 2, cred, t);       // {sum nll, hits}
+        __shared__ float st2[2];
+        if (t < 2) st2[t] = st;
+        __syncthreads();
+        if (t == 0) {
+            const float l = st2[0] / (float)B;   // loss.rs:164
+            a.loss[0] = l;
+            if (a.ncorrect) a.ncorrect[0] = st2[1];
+            if (a.metrics) {
+                const int64_t slot = state0 < a.capacity ? state0 : state0 % a.capacity;
+                a.metrics[2 * slot] = l;
+                a.metrics[2 * slot + 1] = st2[1];
+                a.state[0] = state0 + 1;
+                a.state[1] = state1 + a.advance;
+            }
+        }
+        return;
+    }
+    const int ch0 = ((int)blockIdx.x - a.n_col - 1) * 16;
+    const float cb = slab_colsum16(a.cbpart, a.conv_c, B, ch0, min(16, a.conv_c - ch0), cred, t);
+    if (t < 16 && ch0 + t < a.conv_c) {
+        a.conv_gb[ch0 + t] = cb;
+        if (a.fcb.p) adam_update(a.fcb.p, a.fcb.m, a.fcb.v, ch0 + t, cb, adam_dev_step(a.fcb), a.fcb.beta1, a.fcb.beta2, a.fcb.eps, a.fcb.wd);
+    }
+}
+
 }  // namespace th
 
 using namespace th;
@@ -391,3 +528,22 @@ extern "C" int th_debug_wide_prof(th_ctx *ctx, long long *h_out16) {
     return 0;
 }
 #endif
+
+extern "C" int th_wide_head_grads(th_ctx *ctx, const float *d_x, const float *d_dl, const float *d_rowstat, const float *d_cbpart, int batch,
+                                  int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss,
+                                  float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                                  const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse) {
+    TH_REQUIRE(ctx && d_x && d_dl && d_rowstat && d_dw && d_loss, "th_wide_head_grads: null argument");
+    TH_REQUIRE(batch > 0 && in_features > 0 && classes > 0 && classes <= 16, "th_wide_head_grads: needs classes <= 16 (got %d)", classes);
+    TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_wide_head_grads: metrics need d_state and a capacity");
+    TH_REQUIRE((d_cbpart != nullptr) == (d_conv_gb != nullptr) && (!d_cbpart || conv_c > 0),
+               "th_wide_head_grads: the conv bias needs d_cbpart, d_conv_gb and conv_c together");
+    TH_REQUIRE(!(b_fuse && b_fuse->d_p) || d_db, "th_wide_head_grads: a fused bias update needs d_db");
+    TH_REQUIRE(!(cb_fuse && cb_fuse->d_p) || d_conv_gb, "th_wide_head_grads: a fused conv bias update needs d_conv_gb");
+    WideGradArgs a{d_x, d_dl, d_rowstat, d_cbpart, batch, in_features, classes, d_cbpart ? conv_c : 0, ceil_div(in_features, 16 * WH_TX),
+                   d_dw, d_db, d_conv_gb, d_loss, d_ncorrect, d_metrics, metrics_capacity, d_state, advance,
+                   make_adam_dev(w_fuse), make_adam_dev(b_fuse), make_adam_dev(cb_fuse)};
+    hipLaunchKernelGGL(wide_grads_kernel, dim3(a.n_col + 1 + ceil_div(a.conv_c, 16)), dim3(64 * WH_NW), 0, ctx->stream, a);
+    TH_LAUNCH_CHECK();
+    return 0;
+}

@@ -201,7 +201,8 @@ def _training_steps_parity(T, name, mode):
         losses, ncorrect = ep["losses"], ep["ncorrect"]
         cfg = last_conv_config_host()
         if mode == "graph":
-            assert cfg["dma"] == 6 and cfg["ct"] == (1 if name == "cnn_reference" else 2), cfg   # the conv chain ran in this process's step
+            # the conv chain ran in this process's step (7: with the simple CNN's classifier rows in its last epilogue, th_conv_chain_head_fwd)
+            assert cfg["dma"] == (6 if name == "cnn_reference" else 7) and cfg["ct"] == (1 if name == "cnn_reference" else 2), cfg
         else:
             assert cfg["ct"] in (1, 2) and cfg["dma"] in (2, 3, 4, 5), cfg   # the image-resident matrix-core conv ran in this process's step
         if name == "cnn_reference":     # its three-layer classifier took th_mlp3_xent (two launches) in the captured step
@@ -222,7 +223,8 @@ def _training_steps_parity(T, name, mode):
 @pytest.mark.parametrize("name", ["cnn_simple", "cnn_reference"])
 def test_conv_chain_step_is_bit_identical_to_the_layered_step(name):
     """the Trainer's captured step with the convolutional front as one launch against the same step launched layer by layer: same
-    per-output arithmetic, so every weight and every loss agrees bit for bit after 3 steps at batch 256"""
+    per-output arithmetic, so every weight and every loss agrees bit for bit after 3 steps at batch 256 (the classifier as its own
+    launches in both: with its rows inside the chain launch the logits add in another order -- tests/test_gpu_chain_head.py)"""
     import taper_amd as T
     H = backends.get("hip")
     batch, steps = 256, 3
@@ -232,6 +234,7 @@ def test_conv_chain_step_is_bit_identical_to_the_layered_step(name):
         spec = backends.nonzero_biases(MODELS[name](rng), rng)
         x, y = backends.mnist_like(rng, steps * batch)
         T.set_conv_chain(chain)
+        T.set_conv_chain_head(False)
         try:
             hm = H.sequential(spec)
             opt = T.Adam(hm.parameters(), 1e-2, None, None, 1e-4)
@@ -241,6 +244,7 @@ def test_conv_chain_step_is_bit_identical_to_the_layered_step(name):
             out.append((ep["losses"], [p.data() for p in hm.parameters()]))
         finally:
             T.set_conv_chain(True)
+            T.set_conv_chain_head(True)
     np.testing.assert_array_equal(out[0][0], out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         np.testing.assert_array_equal(a, b)
