@@ -97,21 +97,18 @@ def barrier_sync(rdzv, T):
 
 
 def make_comm(rdzv, T, backend, optimizer):
-    """backend auto: the one-shot peer-to-peer all-reduce fused with Adam when every rank can map its peers and the
-    self-check passes, RCCL otherwise (the reason is reported)"""
+    """backend auto: the one-shot peer-to-peer all-reduce fused with Adam when every rank can map its peers and the multi-round
+    self-check passes (first on the pooled gradient arena, then on a fine-grained one), RCCL otherwise (the reason is reported)"""
     from taper_amd.dist import init_data_parallel
     if rdzv is None:
         return None, "none"
-    if backend in ("auto", "p2p"):
-        try:
-            return init_data_parallel(T, rdzv, backend="p2p", optimizer=optimizer), "p2p one-shot all-reduce + Adam (th_allreduce_adam) over xGMI"
-        except RuntimeError as e:
-            if backend == "p2p":
-                raise
-            why = f" (p2p unavailable: {e})"
-    else:
-        why = ""
-    return init_data_parallel(T, rdzv, backend="rccl"), "rccl ncclAllReduce(avg)" + why
+    info = {}
+    comm = init_data_parallel(T, rdzv, backend=backend, optimizer=optimizer, info=info)
+    kind = info.get("backend", backend)
+    why = f" ({info['why']})" if info.get("why") else ""
+    if kind.startswith("p2p"):
+        return comm, "p2p one-shot all-reduce + Adam (th_allreduce_adam) over xGMI" + (", fine-grained gradient arena" if kind.endswith("finegrained") else "") + why
+    return comm, "rccl ncclAllReduce(avg)" + why
 
 
 def replicas_identical(rdzv, model):
@@ -460,6 +457,58 @@ def conv_chain_kernel(ctx, key, n=256, reps=100):
                 peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4))
 
 
+class _ChainHead(C.Structure):
+    """include/taper_hip.h: th_chain_head"""
+    _fields_ = [("d_w", C.c_void_p), ("d_bias", C.c_void_p), ("d_targets", C.c_void_p), ("classes", C.c_int), ("d_dl", C.c_void_p),
+                ("d_rowstat", C.c_void_p), ("d_cbpart", C.c_void_p), ("d_tick", C.c_void_p)]
+
+
+def chain_head_kernels(ctx, n=256, classes=10, reps=100):
+    """The TWO launches of the simple CNN's captured step (BASELINE configs[2]): th_conv_chain_head_fwd -- the conv rows with the classifier's
+    row-parallel part in the last epilogue; bound fp32 MFMA, work = the conv layers' flops + 4*K*classes per image for logits and dX -- and
+    th_wide_head_grads -- dW = dl^T X, db, loss, the conv bias, Adam in the epilogues; bound HBM, bytes = X + the row records in, the
+    gradients out, 24 B/parameter of Adam state."""
+    from taper_amd import hip
+    from taper_amd.hip import AdamFuse
+    _, spec = CNN_CHAINS["cnn_simple"]
+    rng = np.random.default_rng(0)
+    k, c_last = 64 * 49, 64
+    x = ctx.upload(rng.uniform(0, 1, (n, 1, 28, 28)).astype(np.float32))
+    bufs = [(ctx.upload(rng.uniform(-0.1, 0.1, (co, ci, 3, 3)).astype(np.float32)), ctx.upload(rng.uniform(-0.1, 0.1, co).astype(np.float32)))
+            for ci, co, _ in spec]
+    stages, ns = hip.conv_stages([(w, b, co, post) for (w, b), (_, co, post) in zip(bufs, spec)])
+    sp = C.cast(stages, C.c_void_p)
+    w, b = ctx.upload(rng.uniform(-0.02, 0.02, (classes, k)).astype(np.float32)), ctx.upload(rng.uniform(-0.1, 0.1, classes).astype(np.float32))
+    yt = ctx.upload(rng.integers(0, classes, n).astype(np.float32))
+    ymap, dl, rs, cbp = ctx.empty(n * k), ctx.empty(n * 16), ctx.empty(n * 2), ctx.empty(n * c_last)
+    tick, lrd = ctx.upload(np.array([1, 0], np.int32)), ctx.upload(np.array([1e-2], np.float32))
+    head = _ChainHead(int(w), int(b), int(yt), classes, int(dl), int(rs), int(cbp), None)
+    us1 = _time_launches(ctx, lambda: ctx.call("th_conv_chain_head_fwd", x, sp, ns, ymap, n, 1, 28, 28, C.byref(head)), reps, warm=10)
+    mom = [(ctx.zeros(sz), ctx.zeros(sz)) for sz in (classes * k, classes, c_last)]
+    fz = lambda p, i: AdamFuse(int(p), int(mom[i][0]), int(mom[i][1]), int(tick), int(lrd), 0.9, 0.999, 1e-8, 1e-4)
+    f = [fz(w, 0), fz(b, 1), fz(bufs[1][1], 2)]
+    dw, db, gcb, loss = ctx.empty(classes * k), ctx.empty(classes), ctx.empty(c_last), ctx.empty(1)
+    us2 = _time_launches(ctx, lambda: ctx.call("th_wide_head_grads", ymap, dl, rs, cbp, n, k, classes, c_last, dw, db, gcb, loss, None, None, 0,
+                                                None, 0, C.byref(f[0]), C.byref(f[1]), C.byref(f[2])), reps, warm=10)
+    ctx.sync()
+    hw, flops, wbytes = 28, 4.0 * k * classes * n, 4.0 * classes * k
+    for ci, co, post in spec:
+        flops += 18.0 * ci * co * hw * hw * n
+        wbytes += 4.0 * (9 * ci * co + co)
+        hw = hw // 2 if post == 1 else hw
+    nb1 = 4.0 * (n * 784 + n * k + n * (16 + 2 + c_last)) + wbytes
+    tf = flops / (us1 * 1e-6) / 1e12
+    params = classes * k + classes + c_last
+    nb2 = 4.0 * (n * k + n * (16 + 2 + c_last)) + 28.0 * params
+    gbs = nb2 / (us2 * 1e-6) / 1e9
+    return [dict(kernel=f"conv_chain_simple_kernel<true, {10 if classes <= 10 else 16}>", layer="conv chain 1->32+pool, 32->64+pool + classifier rows",
+                 us_per_launch=round(us1, 2), alg_flops_per_launch=flops, alg_bytes_per_launch=nb1, bound="mfma", achieved=round(tf, 2),
+                 peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4), in_step=True),
+            dict(kernel="wide_grads_kernel", layer="dW, db, loss, conv bias + Adam", us_per_launch=round(us2, 2), alg_flops_per_launch=2.0 * n * k * classes,
+                 alg_bytes_per_launch=nb2, bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                 in_step=True)]
+
+
 CNN_LAYERS = {
     # (layer, batch, C_in, H = W, C_out, fused 2x2 max-pool epilogue) -- the launches the Trainer's captured step issues
     "cnn_simple": [("conv1+pool 1->32 @28", 256, 1, 28, 32, True), ("conv2+pool 32->64 @14", 256, 32, 14, 64, True)],
@@ -584,7 +633,8 @@ def extra_workloads(T, dataset, with_cpu, only=None):
                 layers = conv_layer_kernels(ctx, CNN_LAYERS[key])
                 for k in layers:
                     k["in_step"] = not chain
-                rec["kernels"] = ([dict(conv_chain_kernel(ctx, key), in_step=True)] if chain else []) + layers
+                head = chain and key == "cnn_simple" and os.environ.get("TAPER_CHAIN_HEAD", "1") != "0"
+                rec["kernels"] = (chain_head_kernels(ctx) if head else []) + ([dict(conv_chain_kernel(ctx, key), in_step=not head)] if chain else []) + layers
                 rec["conv_us_per_step"] = round(sum(k["us_per_launch"] for k in rec["kernels"] if k["in_step"]), 1)
             if with_cpu and key != "mlp_example":
                 try:

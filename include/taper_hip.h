@@ -80,6 +80,10 @@ int th_free(th_ctx *ctx, void *d_ptr);
  * {loss, n_correct} log of a replayed epoch lives here, so the host reads it after one stream synchronisation instead of
  * a staged device-to-host copy (examples/train_mnist.rs:110-121 reads both values every step).  Not pooled. */
 int th_host_malloc(th_ctx *ctx, size_t bytes, void **h_out);
+/* fine-grained (coherent across agents, uncached in remote L2s) device memory, outside the pool: hipExtMallocWithFlags; for buffers peers
+ * read while this device keeps writing them between kernel boundaries (th_comm_p2p_export) */
+int th_malloc_finegrained(th_ctx *ctx, size_t bytes, void **d_out);
+int th_free_finegrained(th_ctx *ctx, void *d_ptr);
 int th_host_free(th_ctx *ctx, void *h_ptr);
 int th_pool_stats(th_ctx *ctx, size_t *bytes_reserved, size_t *bytes_in_use);
 int th_memcpy_h2d(th_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
@@ -549,14 +553,21 @@ int th_allreduce_sum_scale(th_comm *comm, th_ctx *ctx, float *d_buf, size_t n, f
  * ranks to all ranks out of band (rank order), th_comm_p2p_connect.  After that th_allreduce_sum_scale on the registered
  * buffer takes the one-shot path (same signature, same in-place result), and th_allreduce_adam goes one further: the
  * mean gradient is fed straight into Adam (optim.rs:83-113; arguments as th_adam_step) and never written back.
- * Ranks may share a device (the test setup of a 1-GPU box) or own one each.  A peer that never arrives makes the
- * launch give up after ~4 s and raises the flag th_comm_error reads (it synchronises the stream). */
+ * Ranks may share a device (the test setup of a 1-GPU box) or own one each.  A peer that never arrives makes the launch give up
+ * after the communicator's bound (default 120 s; TAPER_P2P_TIMEOUT_MS at th_comm_init_p2p, th_comm_set_timeout_ms afterwards) and raises
+ * the error word.  The error is FINAL: the launch that timed out applies nothing (no reduced gradient is stored, no parameter moves, Adam's
+ * counter is not advanced), and every later launch of the communicator returns at once.  th_comm_error synchronises the stream and reads the
+ * word; th_comm_error_peek reads its host-visible copy without touching the stream (call it after any synchronisation the caller does
+ * anyway: the end of an epoch's graph replays).  The exported buffer may be fine-grained device memory (th_malloc_finegrained: uncached
+ * across agents) where coarse-grained memory cannot be trusted to show a peer's latest writes. */
 #define TH_P2P_BLOB_BYTES 192
 int th_comm_init_p2p(th_ctx *ctx, int n_ranks, int rank, th_comm **out);
 int th_comm_p2p_export(th_comm *comm, float *d_buf, size_t n, uint8_t out_blob[TH_P2P_BLOB_BYTES]);
 int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs /* n_ranks x TH_P2P_BLOB_BYTES, rank order */);
 int th_comm_is_p2p(const th_comm *comm);
 int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error);
+int th_comm_error_peek(const th_comm *comm, int *out_error);
+int th_comm_set_timeout_ms(th_comm *comm, int64_t ms);
 /* test hook: {in-place, fused-with-Adam} one-shot launches this communicator has enqueued or captured so far */
 int th_comm_stats(const th_comm *comm, int64_t out2[2]);
 int th_allreduce_adam(th_comm *comm, th_ctx *ctx, const float *d_grads, size_t n, float scale, float *d_params, float *d_m, float *d_v,

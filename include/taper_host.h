@@ -172,9 +172,19 @@ int tp_comm_new(int n_ranks, int rank, const uint8_t id[128], tp_comm **out);
 int tp_comm_new_p2p(int n_ranks, int rank, tp_comm **out);
 int tp_comm_export_arena(tp_comm *c, tp_optim *optimizer, uint8_t out_blob[192]);
 int tp_comm_connect(tp_comm *c, const uint8_t *blobs, size_t n_bytes);
-/* collective self-test: a known pattern through the optimizer's gradient arena (every rank calls it, before training) */
+/* fine_grained != 0: the optimizer's gradient arena is first moved into fine-grained device memory (coherent across agents, never cached
+ * in a peer's L2): the fallback when the self-check fails on the pooled, coarse-grained arena.  The communicator keeps the registered
+ * arenas alive; free it on every rank before the optimizer. */
+int tp_comm_export_arena_ex(tp_comm *c, tp_optim *optimizer, int fine_grained, uint8_t out_blob[192]);
+/* collective self-test (every rank calls it, before training): 3 (or `rounds`) all-reduces of patterns that differ per rank, round and
+ * element through the SAME addresses of the optimizer's gradient arena, through the in-place kernel and then through the fused
+ * all-reduce + Adam kernel (p / m / v against the closed form of optim.rs:83-113; state restored) */
 int tp_comm_self_check(tp_comm *c, tp_optim *optimizer, int *ok);
-int tp_comm_timed_out(tp_comm *c, int *out);
+int tp_comm_self_check_rounds(tp_comm *c, tp_optim *optimizer, int rounds, int *ok);
+int tp_comm_timed_out(tp_comm *c, int *out);   /* synchronises the stream */
+int tp_comm_failed(tp_comm *c, int *out);      /* the same verdict from the host-visible error word, no synchronisation; the Trainer throws on it after every epoch / eager step */
+int tp_comm_set_timeout_ms(tp_comm *c, int64_t ms);   /* bound of the in-kernel waits for a peer (default 120 s; TAPER_P2P_TIMEOUT_MS) */
+int tp_comm_set_fuse_adam(tp_comm *c, int on);        /* p2p: 1 (default) all-reduce + Adam in one launch, 0 all-reduce in place then Adam::step */
 int tp_comm_stats(tp_comm *c, int64_t out2[2]);   /* {in-place, fused} one-shot launches enqueued or captured */
 int tp_comm_free(tp_comm *c);
 int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n);

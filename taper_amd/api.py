@@ -576,9 +576,10 @@ class Communicator:
         """peer-to-peer communicator (one node, <= 8 ranks): one-shot all-reduce of the gradient arena fused with Adam"""
         return Communicator(n_ranks, rank, _h=_mk(host.tp_comm_new_p2p, "Communicator::p2p", int(n_ranks), int(rank)))
 
-    def export_arena(self, optimizer) -> bytes:
+    def export_arena(self, optimizer, fine_grained: bool = False) -> bytes:
+        """register the optimizer's gradient arena; fine_grained: move it into fine-grained (cross-agent coherent) device memory first"""
         buf = (C.c_uint8 * self.BLOB_BYTES)()
-        tp_check(host.tp_comm_export_arena(self._h, optimizer._h, buf), "Communicator::export_arena")
+        tp_check(host.tp_comm_export_arena_ex(self._h, optimizer._h, 1 if fine_grained else 0, buf), "Communicator::export_arena")
         return bytes(buf)
 
     def connect(self, blobs: bytes):
@@ -588,11 +589,24 @@ class Communicator:
     def is_p2p(self) -> bool:
         return self._p2p
 
-    def self_check(self, optimizer) -> bool:
-        """collective: all-reduce(mean) of a known pattern through the optimizer's gradient arena; True = every element exact"""
+    def self_check(self, optimizer, rounds: int = 3) -> bool:
+        """collective: `rounds` all-reduces of per-rank / per-round / per-element patterns through the SAME arena addresses, through the
+        in-place kernel and the fused all-reduce + Adam kernel (p / m / v against the closed form; state restored)"""
         ok = C.c_int()
-        tp_check(host.tp_comm_self_check(self._h, optimizer._h, C.byref(ok)), "Communicator::self_check")
+        tp_check(host.tp_comm_self_check_rounds(self._h, optimizer._h, int(rounds), C.byref(ok)), "Communicator::self_check")
         return bool(ok.value)
+
+    def failed(self) -> bool:
+        """a peer never arrived at some all-reduce (host-visible error word; no stream synchronisation)"""
+        out = C.c_int()
+        tp_check(host.tp_comm_failed(self._h, C.byref(out)), "Communicator::failed")
+        return bool(out.value)
+
+    def set_timeout_ms(self, ms: int):
+        tp_check(host.tp_comm_set_timeout_ms(self._h, int(ms)), "Communicator::set_timeout_ms")
+
+    def set_fuse_adam(self, on: bool):
+        tp_check(host.tp_comm_set_fuse_adam(self._h, 1 if on else 0), "Communicator::set_fuse_adam")
 
     def stats(self):
         out = (C.c_int64 * 2)()

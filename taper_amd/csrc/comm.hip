@@ -17,7 +17,8 @@ constexpr int P2P_MAX_RANKS = 8;           // one node: 8 x MI355X, full xGMI me
 constexpr int P2P_FLAG_WORDS = 32;         // per rank: ready[8] | done[8] | pad (uint32 step values, monotonic)
 constexpr int P2P_READY = 0, P2P_DONE = 8;
 constexpr int P2P_MAX_BLOCKS = 256, P2P_QUADS = 8;   // in-place form: <= 8 float4 per thread held across the barrier
-constexpr long P2P_SPIN_TICKS = 400000000L;           // 4 s of the 100 MHz wall clock: a lost peer ends in an error, not a hang
+constexpr long P2P_DEFAULT_TIMEOUT_MS = 120000;       // spins are bounded by the 100 MHz wall clock: a lost peer ends in an error, not a hang
+                                                      // (TAPER_P2P_TIMEOUT_MS / th_comm_set_timeout_ms; long enough for a peer that saves a checkpoint)
 
 struct P2PBlob {                           // what a rank ships to its peers (TH_P2P_BLOB_BYTES)
     hipIpcMemHandle_t buf, flags;          // allocation bases
@@ -30,7 +31,9 @@ static_assert(sizeof(P2PBlob) == TH_P2P_BLOB_BYTES, "P2PBlob layout");
 struct P2PDev {                            // kernel argument
     const float *buf[P2P_MAX_RANKS];       // buf[r]: rank r's gradient buffer as mapped here (own = local pointer)
     uint32_t *flags[P2P_MAX_RANKS];        // flags[r]: rank r's flag block as mapped here (own = local pointer)
-    uint32_t *state;                       // local: [0] steps completed, [1] arrival counter, [2] error (timeout)
+    uint32_t *state;                       // local: [0] steps completed, [1] arrival counter, [2] error (timeout; STICKY: later launches do nothing)
+    uint32_t *err_host;                    // the same error word in device-visible pinned host memory: the host reads it after any stream sync
+    long spin_ticks;
     int n_ranks, rank;
 };
 
@@ -42,7 +45,8 @@ struct th_comm {
     int device = 0;
     float *reg_buf = nullptr;              // the registered buffer (this rank's flat gradient arena)
     size_t reg_n = 0;
-    uint32_t *flags_local = nullptr, *state = nullptr;
+    uint32_t *flags_local = nullptr, *state = nullptr, *err_host = nullptr;
+    long timeout_ms = P2P_DEFAULT_TIMEOUT_MS;
     void *peer_base[P2P_MAX_RANKS] = {};   // hipIpcOpenMemHandle results (to close)
     void *peer_flag_base[P2P_MAX_RANKS] = {};
     P2PDev dev{};
@@ -87,17 +91,24 @@ __device__ __forceinline__ bool p2p_wait_all(const P2PDev &c, int word0, uint32_
         const uint32_t *slot = c.flags[c.rank] + word0 + threadIdx.x;
         const long t0 = wall_clock64();
         while ((int32_t)(__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
-            if (wall_clock64() - t0 > P2P_SPIN_TICKS) {
+            if (wall_clock64() - t0 > c.spin_ticks) {
                 __hip_atomic_store(&c.state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(c.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 ok = false;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
         }
     }
-    __syncthreads();
+    ok = __syncthreads_and(ok);                       // the verdict of the watching lanes, for the whole workgroup
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // system scope: peers' data written before their flag is visible now
     return ok;
+}
+
+// a time-out is final: once the error word is up every later launch of this communicator returns at once -- no flag is pushed, nothing is
+// reduced, no parameter moves, Adam's counter stays -- and the host raises at its next look (th_comm_error / th_comm_error_peek)
+__device__ __forceinline__ bool p2p_dead(const P2PDev &c) {
+    return __hip_atomic_load(&c.state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
 
 __device__ __forceinline__ void p2p_push(const P2PDev &c, int word0, uint32_t step) {
@@ -137,6 +148,7 @@ __device__ __forceinline__ float4 p2p_sum_quad(const P2PDev &c, long i, float sc
 
 // in place: buf[rank][0..n) = scale * sum_r buf[r][0..n); n % 4 == 0, 16-byte aligned
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PDev c, float *__restrict__ out, long n, float scale) {
+    if (p2p_dead(c)) return;
     const uint32_t step = __hip_atomic_load(&c.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (blockIdx.x == 0) p2p_push(c, P2P_READY, step);
     const bool ok = p2p_wait_all(c, P2P_READY, step);
@@ -148,8 +160,8 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PDev c, float *__r
         if (i < n) acc[q] = p2p_sum_quad(c, i, scale);
     }
     p2p_arrive(c, step);
-    p2p_wait_all(c, P2P_DONE, step);                  // every peer has read this rank's buffer: it may be overwritten
-    if (!ok) return;
+    const bool done = p2p_wait_all(c, P2P_DONE, step);   // every peer has read this rank's buffer: it may be overwritten
+    if (!ok || !done) return;
 #pragma unroll
     for (int q = 0; q < P2P_QUADS; ++q) {
         const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4 + q * stride;
@@ -175,6 +187,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long 
                                                                  const int32_t *__restrict__ has_grad, int n_tensors, int32_t *t_state,
                                                                  const float *__restrict__ lr, float beta1, float beta2, float eps, float wd,
                                                                  int pre_ticked) {
+    if (p2p_dead(c)) return;
     const uint32_t step = __hip_atomic_load(&c.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (blockIdx.x == 0) p2p_push(c, P2P_READY, step);
     const int t = __hip_atomic_load(&t_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (pre_ticked ? 0 : 1);   // optim.rs:84
@@ -203,8 +216,9 @@ __global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long 
     }
     p2p_arrive(c, step);
     if (blockIdx.x == 0) {
-        p2p_wait_all(c, P2P_DONE, step);              // the next backward launch overwrites the buffer the peers were reading
-        if (!pre_ticked && threadIdx.x == 0) __hip_atomic_store(&t_state[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool done = p2p_wait_all(c, P2P_DONE, step);   // the next backward launch overwrites the buffer the peers were reading
+        // (a step that timed out does not count: optim.rs:84 belongs to an update that happened)
+        if (!pre_ticked && ok && done && threadIdx.x == 0) __hip_atomic_store(&t_state[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -257,6 +271,7 @@ int th_comm_destroy(th_comm *comm) {
         }
         if (comm->flags_local) (void)hipFree(comm->flags_local);
         if (comm->state) (void)hipFree(comm->state);
+        if (comm->err_host) (void)hipHostFree(comm->err_host);
     }
     delete comm;
     return 0;
@@ -282,6 +297,16 @@ int th_comm_init_p2p(th_ctx *ctx, int n_ranks, int rank, th_comm **out) {
         }
     }
     c->flags_local = (uint32_t *)f;
+    if (const char *e = getenv("TAPER_P2P_TIMEOUT_MS")) {
+        const long ms = atol(e);
+        if (ms > 0) c->timeout_ms = ms;
+    }
+    if (hipHostMalloc((void **)&c->err_host, 64, hipHostMallocMapped) != hipSuccess) {
+        c->err_host = nullptr;
+        th_comm_destroy(c);
+        TH_REQUIRE(false, "th_comm_init_p2p: cannot allocate the host-visible error word");
+    }
+    c->err_host[0] = 0;
     if (hipMalloc((void **)&c->state, 64) != hipSuccess || hipMemset(c->flags_local, 0, P2P_MAX_RANKS * P2P_FLAG_WORDS * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(c->state, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         th_comm_destroy(c);
@@ -340,6 +365,8 @@ int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs) {
         comm->dev.flags[r] = (uint32_t *)comm->peer_flag_base[r];
     }
     comm->dev.state = comm->state;
+    comm->dev.err_host = comm->err_host;
+    comm->dev.spin_ticks = comm->timeout_ms * 100000L;   // 100 MHz wall clock
     comm->dev.n_ranks = comm->n_ranks;
     comm->dev.rank = comm->rank;
     comm->connected = true;
@@ -356,6 +383,19 @@ int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error) {
     TH_HIP(hipStreamSynchronize(ctx->stream));
     TH_HIP(hipMemcpy(st, comm->state, sizeof(st), hipMemcpyDeviceToHost));
     *out_error = (int)st[2];
+    return 0;
+}
+
+int th_comm_error_peek(const th_comm *comm, int *out_error) {
+    TH_REQUIRE(comm && out_error, "th_comm_error_peek: null argument");
+    *out_error = (comm->p2p && comm->err_host) ? (int)__atomic_load_n(comm->err_host, __ATOMIC_RELAXED) : 0;
+    return 0;
+}
+
+int th_comm_set_timeout_ms(th_comm *comm, int64_t ms) {
+    TH_REQUIRE(comm && comm->p2p && ms > 0, "th_comm_set_timeout_ms: needs a peer-to-peer communicator and a positive bound");
+    comm->timeout_ms = (long)ms;
+    comm->dev.spin_ticks = comm->timeout_ms * 100000L;   // launches enqueued (or captured) from here on
     return 0;
 }
 

@@ -474,6 +474,7 @@ __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const fl
         if (i == 0) sc[c] = s + ((h.bias && c < h.classes) ? h.bias[c] : 0.f);   // nn.rs:54-60: bias after the product
     }
     chain_sync();
+    CH_STAMP(7);
     float lg[4], dl[4], nll;
     int bi;
 #pragma unroll
@@ -493,6 +494,7 @@ __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const fl
     }
     if (!h.cbpart) return;                   // (uniform)
     chain_sync();
+    CH_STAMP(8);
     float d16[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) d16[c] = sc[16 + c];
@@ -505,6 +507,7 @@ __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const fl
         if (k < h.k) xm[k] = xv[j] > 0.f ? dx : 0.f;
     }
     chain_sync();
+    CH_STAMP(9);
     for (int ch = t >> 4; ch < h.c_last; ch += CH_NT / 16) {                // 16 lanes per channel
         const float *row = xm + ch * h.hw;
         float p = 0.f;
@@ -513,13 +516,15 @@ __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const fl
         for (int off = 8; off > 0; off >>= 1) p += __shfl_xor(p, off, 16);
         if (r16 == 0) h.cbpart[(long)img * h.c_last + ch] = p;
     }
+    CH_STAMP(10);
 }
 
 // ---- the simple CNN's front (examples/train_mnist_cnn.rs:64-100): 1 -> 32 + pool, 32 -> 64 + pool -> [64][7][7] ----
 //   T1 [32][788] @0  conv1's outputs    A [32][272] @25216  conv2's input    T [64][196] @0  conv2's outputs (over T1)    IMG [900] @33920
 //   HEAD: XM [3136] @12544 (behind T: the flattened pooled map), RED [NC][512] + 64 @25216 (over A, dead after conv2's k loop)
 constexpr int CS_A = 32 * ch_tile_ld(784), CS_IMG = CS_A + 32 * ch_cis(16), CS_LDS = CS_IMG + 900;
-constexpr int CS_XM = 64 * ch_tile_ld(196), CS_K = 64 * 49, CS_NJ = (CS_K + CH_NT - 1) / CH_NT;
+constexpr int CS_XM = 64 * ch_tile_ld(196), CS_K = 64 * 49;
+[[maybe_unused]] constexpr int CS_NJ = (CS_K + CH_NT - 1) / CH_NT;
 static_assert(64 * ch_tile_ld(196) <= CS_A && CS_XM + CS_K <= CS_A && CS_A + 16 * CH_NT + 64 <= CS_LDS, "LDS map");
 
 template <bool HEAD, int NC>
@@ -532,33 +537,46 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     ChainBias bv;
     ChainW wc;
     ChainW1 wa;
+    CH_STAMP(0);
+    CH_CLK(20);
     chain_conv1_weights(a.w[0], wa, wave, lane);
     chain_bias<28, 32>(a.b[0], bv, wave, lane);
     chain_load_image(a.x + (long)img * 784, IMG, t);
     chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, lane);      // conv2's first pass: in flight under conv1 and its pool
     if (HEAD && a.head.tick && img == 0 && t == 0) a.head.tick[0] += 1;
     chain_sync();
+    CH_STAMP(1);
     {   // conv1 1 -> 32 @28 + pool
         floatx4 acc[ChainGeo<28, 32>::NSLOT];
         chain_conv1_mfma(IMG, wa, acc, wave, lane);
         chain_store<28, 32, false>(acc, bv, T1, wave, lane);
         chain_zero_halo<14, 32>(A, wave, lane);
         chain_sync();
+        CH_STAMP(2);
         chain_pool<28, 32, false>(T1, A, t);
         chain_sync();
+        CH_STAMP(3);
     }
     floatx4 acc[ChainGeo<14, 64>::NSLOT];
     chain_bias<14, 64>(a.b[1], bv, wave, lane);
     float hw_[CS_NJ][NC];
     if constexpr (HEAD) chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t);   // the classifier's weights: in flight under conv2's k loop
     chain_mfma<14, 32, 64>(A, a.w[1], wc, acc, wave, lane);
+    CH_STAMP(4);
     chain_store<14, 64, false>(acc, bv, T, wave, lane);          // (T1 is dead; T does not overlap A)
     chain_sync();
+    CH_STAMP(5);
     chain_pool<14, 64, true, HEAD>(T, a.y + (long)img * 64 * 49, t, lds + CS_XM);
     if constexpr (HEAD) {
         chain_sync();                                            // XM complete; every wave is past conv2's k loop: A is free
+        CH_STAMP(6);
         chain_head_rows<CS_NJ, NC>(a.head, hw_, lds + CS_XM, A, img, t);
     }
+#ifdef TH_PROFILE
+    chain_sync();
+#endif
+    CH_STAMP(11);
+    CH_CLK(21);
 #endif
 }
 

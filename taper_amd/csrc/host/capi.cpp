@@ -344,8 +344,18 @@ int tp_comm_export_arena(tp_comm *c, tp_optim *o, uint8_t out_blob[192]) {
 }
 int tp_comm_connect(tp_comm *c, const uint8_t *blobs, size_t n_bytes) { TP_BEGIN c->c->connect(std::vector<uint8_t>(blobs, blobs + n_bytes)); TP_END }
 int tp_comm_stats(tp_comm *c, int64_t out2[2]) { TP_BEGIN th_check(th_comm_stats(c->c->handle(), out2), "th_comm_stats"); TP_END }
+int tp_comm_export_arena_ex(tp_comm *c, tp_optim *o, int fine_grained, uint8_t out_blob[192]) {
+    TP_BEGIN
+    auto b = c->c->export_arena(*o->o, fine_grained != 0);
+    std::memcpy(out_blob, b.data(), b.size());
+    TP_END
+}
 int tp_comm_self_check(tp_comm *c, tp_optim *o, int *ok) { TP_BEGIN *ok = c->c->self_check(*o->o) ? 1 : 0; TP_END }
+int tp_comm_self_check_rounds(tp_comm *c, tp_optim *o, int rounds, int *ok) { TP_BEGIN *ok = c->c->self_check(*o->o, rounds) ? 1 : 0; TP_END }
 int tp_comm_timed_out(tp_comm *c, int *out) { TP_BEGIN *out = c->c->timed_out() ? 1 : 0; TP_END }
+int tp_comm_failed(tp_comm *c, int *out) { TP_BEGIN *out = c->c->failed() ? 1 : 0; TP_END }
+int tp_comm_set_timeout_ms(tp_comm *c, int64_t ms) { TP_BEGIN c->c->set_timeout_ms(ms); TP_END }
+int tp_comm_set_fuse_adam(tp_comm *c, int on) { TP_BEGIN c->c->fuse_adam = on != 0; TP_END }
 int tp_comm_free(tp_comm *c) { TP_BEGIN delete c; TP_END }
 int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n) { TP_BEGIN c->c->allreduce_mean((float *)d_buf, n); TP_END }
 

@@ -713,6 +713,20 @@ FlatParams::FlatParams(const std::vector<Tensor> &ps) : params(ps) {
     sync_mask();
 }
 
+void FlatParams::rehome_grads(const std::shared_ptr<Buffer> &arena) {
+    TAPER_ASSERT(arena && arena->n >= (size_t)total, "FlatParams::rehome_grads: the new arena is too small");
+    th_ctx *ctx = Device::ctx();
+    TH(th_memcpy_d2d(ctx, arena->d, g_arena->d, (size_t)total * sizeof(float)));
+    for (size_t i = 0; i < params.size(); ++i) {
+        Buffer &v = *params[i].grad_->buf;
+        TAPER_ASSERT(params[i].grad_->buf_is_arena && v.parent == g_arena, "FlatParams::rehome_grads: a grad slot has left the arena");
+        v.d = arena->d + offsets[i];
+        v.parent = arena;
+    }
+    Device::sync();   // the copy has run before the old arena can go back to the pool
+    g_arena = arena;
+}
+
 size_t FlatParams::sync_mask(const std::vector<char> *excluded) {
     std::vector<int32_t> mask(params.size());
     size_t selected = 0;
@@ -817,7 +831,11 @@ Adam *FusedAdamScope::active() { return t_fused_adam; }
 
 namespace {
 thread_local bool t_pool_bias = false;
+thread_local bool t_no_grad = false;
 }
+NoGradScope::NoGradScope() : prev_(t_no_grad) { t_no_grad = true; }
+NoGradScope::~NoGradScope() { t_no_grad = prev_; }
+bool NoGradScope::active() { return t_no_grad; }
 PoolBiasScope::PoolBiasScope(bool on) : prev_(t_pool_bias) { t_pool_bias = on; }
 PoolBiasScope::~PoolBiasScope() { t_pool_bias = prev_; }
 bool PoolBiasScope::active() { return t_pool_bias; }
@@ -1042,11 +1060,14 @@ std::shared_ptr<Communicator> Communicator::p2p(int n, int r) {
     return c;
 }
 
-std::vector<uint8_t> Communicator::export_arena(Optimizer &opt) {
+std::vector<uint8_t> Communicator::export_arena(Optimizer &opt, bool fine_grained) {
     TAPER_ASSERT(p2p_, "Communicator::export_arena: not a peer-to-peer communicator");
     FlatParams &fp = opt.flat();
+    if (fine_grained && !fp.g_arena->fine_grained) fp.rehome_grads(Buffer::alloc_finegrained((size_t)fp.total));
     std::vector<uint8_t> blob(TH_P2P_BLOB_BYTES);
     TH(th_comm_p2p_export(comm_, fp.g_arena->d, (size_t)fp.total, blob.data()));
+    g_hold_ = fp.g_arena;   // peers map this allocation: it must outlive the communicator, whatever happens to the optimizer
+    p_hold_ = fp.p_arena;
     return blob;
 }
 
@@ -1055,25 +1076,101 @@ void Communicator::connect(const std::vector<uint8_t> &blobs) {
     TH(th_comm_p2p_connect(comm_, blobs.data()));
 }
 
-bool Communicator::self_check(Optimizer &opt) {
-    // every rank fills its arena with (rank + 1); the mean over W ranks is (W + 1) / 2 in every element, exactly
-    // representable -- anything else (an unmapped peer, stale data, a peer that never arrived) fails the check
+namespace {
+// the self-check's gradient of rank r, round k, element i: small integers, so every sum and mean below is exact in fp32
+inline float check_pattern(int r, int k, size_t i) { return (float)((r + 1) * (k + 1)) + (float)(i % 7); }
+inline float check_mean(int w, int k, size_t i) { return (float)(k + 1) * (float)(w + 1) / 2.0f + (float)(i % 7); }
+// llvm.powi.f32 as compiler-rt lowers it (csrc/adam_dev.h powi_f32; optim.rs:87-88)
+inline float host_powi(float a, int b) {
+    float r = 1.0f;
+    while (true) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return r;
+}
+}  // namespace
+
+bool Communicator::self_check(Optimizer &opt, int rounds) {
     FlatParams &fp = opt.flat();
     th_ctx *ctx = Device::ctx();
     const size_t n = (size_t)fp.total;
-    TH(th_fill_f32(ctx, fp.g_arena->d, (float)(rank + 1), n));
-    allreduce_mean(fp.g_arena->d, n);
-    std::vector<float> got(n);
-    TH(th_memcpy_d2h(ctx, got.data(), fp.g_arena->d, n * sizeof(float)));
-    TH(th_fill_f32(ctx, fp.g_arena->d, 0.f, n));
-    for (auto &p : fp.params) {
-        p.grad_->has = false;
-        p.grad_->known_zero = true;
+    std::vector<float> pat(n), got(n);
+    bool ok = true;
+    auto reset_grads = [&]() {
+        TH(th_fill_f32(ctx, fp.g_arena->d, 0.f, n));
+        for (auto &p : fp.params) {
+            p.grad_->has = false;
+            p.grad_->known_zero = true;
+        }
+    };
+    // (1) the in-place kernel, `rounds` times through the same addresses, a different pattern per rank / round / element.  Every rank runs
+    // every round whatever it has seen so far: nobody is left waiting for a peer that has given up.
+    for (int k = 0; k < rounds; ++k) {
+        for (size_t i = 0; i < n; ++i) pat[i] = check_pattern(rank, k, i);
+        TH(th_memcpy_h2d(ctx, fp.g_arena->d, pat.data(), n * sizeof(float)));
+        allreduce_mean(fp.g_arena->d, n);
+        TH(th_memcpy_d2h(ctx, got.data(), fp.g_arena->d, n * sizeof(float)));
+        // (patterns of different rounds / ranks differ by >= 0.5 per element; 1/W is not a power of two for every W)
+        for (size_t i = 0; ok && i < n; ++i) ok = std::fabs(got[i] - check_mean(n_ranks, k, i)) <= 1e-3f;
     }
+    if (p2p_ && timed_out()) ok = false;
+    // (2) the fused all-reduce + Adam kernel on the real p / m / v (saved and restored), against optim.rs:83-113 evaluated on the host
+    Adam *adam = dynamic_cast<Adam *>(&opt);
+    if (p2p_ && fuse_adam && adam) {
+        std::vector<float> p0(n), pm(n), pv(n), m0, v0;
+        TH(th_memcpy_d2h(ctx, p0.data(), fp.p_arena->d, n * sizeof(float)));
+        const int t0 = adam->t();
+        m0 = adam->m();
+        v0 = adam->v();
+        std::vector<char> had(fp.params.size());
+        for (size_t j = 0; j < fp.params.size(); ++j) {
+            had[j] = fp.params[j].grad_->has;
+            fp.params[j].grad_->has = true;          // the kernel skips grad-less tensors (Q8): check every slice
+        }
+        std::vector<float> ph = p0, mh(n, 0.f), vh(n, 0.f);
+        adam->load_state(t0, std::vector<float>(m0.size(), 0.f), std::vector<float>(v0.size(), 0.f));
+        const float b1 = adam->beta1(), b2 = adam->beta2(), eps = adam->eps(), wd = adam->weight_decay(), lr = adam->get_lr();
+        for (int k = 0; k < rounds; ++k) {
+            for (size_t i = 0; i < n; ++i) pat[i] = check_pattern(rank, k, i);
+            TH(th_memcpy_h2d(ctx, fp.g_arena->d, pat.data(), n * sizeof(float)));
+            const bool ran = adam->step_reduced(*this);
+            if (!ran) { ok = false; break; }
+            const int t = t0 + k + 1;
+            const float step = lr * (std::sqrt(1.0f - host_powi(b2, t)) / (1.0f - host_powi(b1, t)));
+            for (size_t j = 0; j < fp.params.size(); ++j)
+                for (size_t e = 0; e < fp.params[j].len(); ++e) {
+                    const size_t i = (size_t)fp.offsets[j] + e;
+                    const float g = check_mean(n_ranks, k, i) + wd * ph[i];
+                    mh[i] = b1 * mh[i] + (1.0f - b1) * g;
+                    vh[i] = b2 * vh[i] + (1.0f - b2) * g * g;
+                    ph[i] = ph[i] - step * mh[i] / (std::sqrt(vh[i]) + eps);
+                }
+        }
+        Device::sync();
+        if (ok) {
+            TH(th_memcpy_d2h(ctx, pm.data(), fp.p_arena->d, n * sizeof(float)));
+            const std::vector<float> mg = adam->m(), vg = adam->v();
+            size_t u = 0;
+            for (size_t j = 0; ok && j < fp.params.size(); ++j)
+                for (size_t e = 0; ok && e < fp.params[j].len(); ++e, ++u) {
+                    const size_t i = (size_t)fp.offsets[j] + e;
+                    auto near = [](float a, float b) { return std::fabs(a - b) <= 1e-5f * std::max(1.0f, std::fabs(b)); };
+                    ok = near(pm[i], ph[i]) && near(mg[u], mh[i]) && near(vg[u], vh[i]);
+                }
+            ok = ok && adam->t() == t0 + rounds;
+        }
+        // back to the state training starts from
+        TH(th_memcpy_h2d(ctx, fp.p_arena->d, p0.data(), n * sizeof(float)));
+        adam->load_state(t0, m0, v0);
+        for (size_t j = 0; j < fp.params.size(); ++j) fp.params[j].grad_->has = had[j];
+        if (timed_out()) ok = false;
+    }
+    reset_grads();
+    fp.sync_mask();
     Device::sync();
-    const float want = (float)(n_ranks + 1) / 2.0f;
-    bool ok = !(p2p_ && timed_out());
-    for (size_t i = 0; ok && i < n; ++i) ok = got[i] == want;
     return ok;
 }
 
@@ -1082,6 +1179,14 @@ bool Communicator::timed_out() const {
     TH(th_comm_error(comm_, Device::ctx(), &e));
     return e != 0;
 }
+
+bool Communicator::failed() const {
+    int e = 0;
+    TH(th_comm_error_peek(comm_, &e));
+    return e != 0;
+}
+
+void Communicator::set_timeout_ms(int64_t ms) { TH(th_comm_set_timeout_ms(comm_, ms)); }
 
 void Communicator::allreduce_mean(float *d_buf, size_t n) const {
     TH(th_allreduce_sum_scale(comm_, Device::ctx(), d_buf, n, 1.0f / (float)n_ranks));
@@ -1115,6 +1220,15 @@ void Trainer::train_step(const Tensor &images, const Tensor &labels, float *loss
     optimizer->zero_grad();                                     // :119
     if (loss_out) *loss_out = loss.data()[0];                   // :121
     if (acc_out) *acc_out = acc;
+    check_comm();                                               // (the read-back above synchronised the stream)
+}
+
+void Trainer::check_comm() const {
+    // a peer that never arrived at an all-reduce: the launch applied nothing and every later one is a no-op (th_comm_error_peek) -- the
+    // replicas are no longer in step, and the run must end here, loudly, not train on
+    if (comm && comm->is_p2p() && comm->failed())
+        throw Error("data-parallel all-reduce timed out waiting for a peer (rank " + std::to_string(comm->rank) + " of " +
+                    std::to_string(comm->n_ranks) + "): no update was applied from that step on; the replicas are out of step");
 }
 
 EpochResult Trainer::train_epoch(DataLoader &loader) {  // train.rs:98-144
@@ -1153,7 +1267,9 @@ EpochResult Trainer::evaluate(DataLoader &loader) {  // train.rs:147-172
     Tensor images, labels;
     // nothing is differentiated here: a Sequential's conv front may take the launches that never write the full-resolution maps
     // (conv + pool pairs, the one-launch conv chain from batch 96 up) exactly as inside a training step
-    PoolBiasScope pool_scope(dynamic_cast<Sequential *>(model.get()) != nullptr);
+    // (the same condition as a training step's; NoGradScope: no count buffers, no bias tape nodes for gradients nobody will ask for)
+    PoolBiasScope pool_scope(fuse_head && dynamic_cast<Sequential *>(model.get()) != nullptr);
+    NoGradScope no_grad;
     while (loader.next(&images, &labels)) {
         Tape::reset();
         const size_t b = images.shape()[0];
@@ -1420,9 +1536,19 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
                 TH(th_graph_end(ctx, &g));
                 graphs_.emplace_back(tail, g);
                 std::sort(graphs_.begin(), graphs_.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
-            } catch (const std::exception &) {   // (the ladder keeps serving the remainder)
+            } catch (const std::exception &e) {
+                // enqueue_steps had already changed host state when it failed (deferred / fused Adam bookkeeping, grad slot flags, the
+                // tape): put it back to "between steps" before anything replays.  The ladder keeps serving the remainder.
+                fprintf(stderr, "taper: capturing a %zu-step remainder graph failed (%s); the ladder graphs serve it\n", tail, e.what());
                 if (!g) th_graph_end(ctx, &g);
                 if (g) th_graph_destroy(g);
+                if (auto *adam = dynamic_cast<Adam *>(optimizer.get())) {
+                    adam->set_carry_deferred(false);
+                    adam->drop_step_bookkeeping();
+                }
+                optimizer->zero_grad();
+                Tape::reset();
+                if (!comm) throw;   // (as the ladder capture: without a communicator nothing here is expected to fail)
             }
         }
     }
@@ -1449,6 +1575,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
 
     const double us_enqueued = us_since(t_enter);
     Device::sync();
+    check_comm();
     if (trace) fprintf(stderr, "taper trace: train_epoch_graph %zu steps: enqueued after %.1f us, stream idle after %.1f us\n", nb, us_enqueued, us_since(t_enter));
     const float *mt = metrics_->d;   // host-visible (th_host_malloc); every step's entry has landed once the stream is idle
     EpochResult r;

@@ -11,6 +11,7 @@
 // The reference panics (assert!/panic!) on misuse; here that is taper::Error.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -54,12 +55,14 @@ struct Buffer {
     size_t n = 0;
     bool owned = true;
     bool host_pinned = false;        // th_host_malloc: pinned host memory the device writes through the same pointer
+    bool fine_grained = false;       // th_malloc_finegrained: device memory that is coherent across agents (peer-readable gradient arenas)
     std::shared_ptr<Buffer> parent;  // keeps an arena alive for views
     Buffer() = default;
     Buffer(const Buffer &) = delete;
     ~Buffer();
     static std::shared_ptr<Buffer> alloc(size_t n);
     static std::shared_ptr<Buffer> alloc_host(size_t n);   // device-visible pinned host memory (read on the host after a stream sync)
+    static std::shared_ptr<Buffer> alloc_finegrained(size_t n);
     static std::shared_ptr<Buffer> view(const std::shared_ptr<Buffer> &parent, size_t offset, size_t n);
     static std::shared_ptr<Buffer> borrow(float *d, size_t n);
 };
@@ -412,6 +415,10 @@ class FlatParams {
     std::vector<int32_t> uploaded_mask;
     int64_t total = 0;
     explicit FlatParams(const std::vector<Tensor> &ps);
+    // move the gradient arena into `arena` (>= total floats; contents and every slot's state preserved): the slots' views are re-pointed in
+    // place, so every handle follows.  For the peer-to-peer communicator's fine-grained arena; captured graphs that baked the old address
+    // must be dropped by their owner (Trainer keys its graphs on the arena pointer).
+    void rehome_grads(const std::shared_ptr<Buffer> &arena);
     const int64_t *d_offsets() const { return reinterpret_cast<const int64_t *>(d_offsets_buf->d); }
     const int32_t *d_has_grad() const { return reinterpret_cast<const int32_t *>(d_has_grad_buf->d); }
     // upload the (has_grad && !excluded) mask iff it changed (not allowed while capturing);
@@ -482,6 +489,8 @@ class Adam : public Optimizer {  // optim.rs:43-128
     void set_carry_deferred(bool on) { carry_deferred_ = on; }
     bool has_deferred() const { return !deferred_.empty(); }
     void set_external_tick(bool on) { external_tick_ = on; }
+    // a capture that failed midway: forget the updates queued / marked for the step that never ran
+    void drop_step_bookkeeping() { deferred_.clear(); std::fill(fused_.begin(), fused_.end(), 0); }
 
    private:
     FlatParams fp_;
@@ -572,6 +581,16 @@ class PoolBiasScope {
    private:
     bool prev_;
 };
+// Forward passes nobody differentiates (Trainer::evaluate): the Trainer-internal fused conv fronts skip their count buffers and bias tape nodes
+class NoGradScope {
+   public:
+    NoGradScope();
+    ~NoGradScope();
+    static bool active();
+
+   private:
+    bool prev_;
+};
 
 class FusedAdamScope {
    public:
@@ -628,12 +647,20 @@ class Communicator {
     // Peer-to-peer form (one node, <= 8 ranks; th_comm_init_p2p): a one-shot all-reduce for latency-bound gradient arenas.
     // p2p() -> export_arena(optimizer) -> [ship every rank's blob to every rank] -> connect(blobs in rank order).
     static std::shared_ptr<Communicator> p2p(int n_ranks, int rank);
-    std::vector<uint8_t> export_arena(Optimizer &opt);
+    // fine_grained: first move the optimizer's gradient arena into fine-grained device memory (coherent across agents, never cached in a
+    // peer's L2) -- the fallback when the multi-round self-check fails on the pooled, coarse-grained arena.  The communicator keeps the
+    // arenas it registered alive; destroy it on every rank before the optimizer goes away (peers hold IPC mappings of the arena).
+    std::vector<uint8_t> export_arena(Optimizer &opt, bool fine_grained = false);
     void connect(const std::vector<uint8_t> &blobs);
     bool is_p2p() const { return p2p_; }
-    bool timed_out() const;                               // a peer never arrived (synchronises)
-    // collective: all-reduce a known pattern through the optimizer's gradient arena and compare (call on every rank, before training)
-    bool self_check(Optimizer &opt);
+    bool timed_out() const;                               // a peer never arrived (synchronises the stream)
+    bool failed() const;                                  // the same verdict from the host-visible error word, without synchronising
+    void set_timeout_ms(int64_t ms);                      // bound of the in-kernel waits (default 120 s, TAPER_P2P_TIMEOUT_MS)
+    // Collective, before training, on every rank: `rounds` all-reduces of patterns that differ per rank, per round AND per element through
+    // the SAME addresses of the optimizer's real gradient arena -- a reader that keeps a stale line of a peer's arena from round k fails
+    // round k + 1 -- first through the in-place kernel (every element compared), then through the fused all-reduce + Adam kernel
+    // (p / m / v compared with the closed form of optim.rs:83-113 on the host; parameters, moments and the counter are restored).
+    bool self_check(Optimizer &opt, int rounds = 3);
     ~Communicator();
     void allreduce_mean(float *d_buf, size_t n) const;  // sum over ranks * 1/W on the ctx stream
     th_comm *handle() const { return comm_; }
@@ -644,6 +671,7 @@ class Communicator {
     Communicator() : n_ranks(1), rank(0) {}
     th_comm *comm_ = nullptr;
     bool p2p_ = false;
+    std::shared_ptr<Buffer> g_hold_, p_hold_;             // the arenas registered with (and mapped by) the peers
 };
 
 // ---- train (src/train.rs, examples/train_mnist*.rs) ------------------------------------
@@ -681,6 +709,7 @@ class Trainer {  // train.rs:74-172
 
     // one step exactly as examples/train_mnist.rs:89-121 (reads loss + accuracy back every step)
     void train_step(const Tensor &images, const Tensor &labels, float *loss_out, float *acc_out);
+    void check_comm() const;   // throws when the peer-to-peer communicator has timed out (after any stream synchronisation)
     EpochResult train_epoch(DataLoader &loader);              // train.rs:98-144 (eager, synchronising)
     EpochResult evaluate(DataLoader &loader);                 // train.rs:147-172
     // same arithmetic, but the step's op list is captured once into a hipGraph

@@ -78,6 +78,7 @@ void Device::shutdown() {
 Buffer::~Buffer() {
     if (owned && d && t_ctx) {
         if (host_pinned) th_host_free(t_ctx, d);
+        else if (fine_grained) th_free_finegrained(t_ctx, d);
         else th_free(t_ctx, d);
     }
 }
@@ -89,6 +90,16 @@ std::shared_ptr<Buffer> Buffer::alloc_host(size_t n) {
     b->d = (float *)p;
     b->n = n;
     b->host_pinned = true;
+    return b;
+}
+
+std::shared_ptr<Buffer> Buffer::alloc_finegrained(size_t n) {
+    auto b = std::make_shared<Buffer>();
+    void *p = nullptr;
+    TH(th_malloc_finegrained(Device::ctx(), std::max<size_t>(n, 1) * sizeof(float), &p));
+    b->d = (float *)p;
+    b->n = n;
+    b->fine_grained = true;
     return b;
 }
 
@@ -878,7 +889,7 @@ static void pooled_bias_grad(const Tensor &bias, const float *dy, const float *m
 
 // tape node of a bias-only Conv2dReLU -> MaxPool2d(2) whose pooled output is `out` (faithful mode, Q2: the bias is the only trainable input)
 static void push_pooled_conv_bias_node(Tensor &out, const Tensor &bias, int n, int c_out, int hp, int wp) {
-    if (!(bias.defined() && bias.requires_grad_)) return;
+    if (!(bias.defined() && bias.requires_grad_) || NoGradScope::active()) return;
     {
         out.requires_grad_ = true;
         // inside a Trainer step (one consumer per tensor) the sums of dX * [x > 0] per column are all this node needs of its gradient
@@ -972,7 +983,7 @@ Tensor Tensor::conv2d_relu_gap(const Tensor &w, const Tensor &bias, std::pair<in
     const int n = (int)shape_[0], c_in = (int)shape_[1], h = (int)shape_[2], wd = (int)shape_[3], c_out = (int)w.shape_[0];
     const int pad = padding.first, hw = (h + 2 * pad - 2) * (wd + 2 * pad - 2);
     Tensor out = empty({(size_t)n, (size_t)c_out, 1, 1});
-    const bool bias_grad = bias.requires_grad_;
+    const bool bias_grad = bias.requires_grad_ && !NoGradScope::active();
     std::shared_ptr<Buffer> cnt = bias_grad ? Buffer::alloc((size_t)n * c_out) : nullptr;
     TH(th_conv3x3_gap_fwd(Device::ctx(), dptr(), w.dptr(), bias.dptr(), out.dptr(), cnt ? cnt->d : nullptr, n, c_in, h, wd, c_out, pad, 1));
     if (bias_grad) push_gap_conv_bias_node(out, bias, cnt, n, c_out, hw);
@@ -1016,7 +1027,7 @@ Tensor Tensor::conv_chain(const std::vector<ConvStage> &stages) const {
     const int c_out = (int)last.weight.shape()[0];
     if (last.post == TH_CHAIN_GLOBAL_AVG) {
         Tensor out = empty({(size_t)n, (size_t)c_out, 1, 1});
-        const bool bias_grad = last.bias.requires_grad_;
+        const bool bias_grad = last.bias.requires_grad_ && !NoGradScope::active();
         std::shared_ptr<Buffer> cnt = bias_grad ? Buffer::alloc((size_t)n * c_out) : nullptr;
         TH(th_conv_chain_fwd(Device::ctx(), dptr(), d.data(), (int)d.size(), out.dptr(), cnt ? cnt->d : nullptr, n, (int)shape_[1], (int)shape_[2],
                              (int)shape_[3]));

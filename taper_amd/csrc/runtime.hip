@@ -155,6 +155,21 @@ int th_memcpy_h2d(th_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     return 0;
 }
 
+int th_malloc_finegrained(th_ctx *ctx, size_t bytes, void **d_out) {
+    TH_REQUIRE(ctx && d_out, "th_malloc_finegrained: null argument");
+    TH_HIP(hipSetDevice(ctx->device));
+    TH_HIP(hipExtMallocWithFlags(d_out, bytes ? bytes : 4, hipDeviceMallocFinegrained));
+    return 0;
+}
+
+int th_free_finegrained(th_ctx *ctx, void *d_ptr) {
+    TH_REQUIRE(ctx, "th_free_finegrained: null ctx");
+    if (!d_ptr) return 0;
+    TH_HIP(hipStreamSynchronize(ctx->stream));   // not stream-ordered: nothing in flight may still use it
+    TH_HIP(hipFree(d_ptr));
+    return 0;
+}
+
 int th_host_malloc(th_ctx *ctx, size_t bytes, void **h_out) {
     TH_REQUIRE(ctx && h_out, "th_host_malloc: null argument");
     TH_HIP(hipSetDevice(ctx->device));

@@ -40,6 +40,7 @@ class FileRendezvous:
         # /dev/shm and /tmp are world-writable and the name is predictable: the directory is private (0700), must be a real
         # directory (not a symlink someone planted) and must belong to this user -- otherwise another local user could feed
         # the ranks a forged RCCL unique id or hold the barriers
+        os.makedirs(base, exist_ok=True)          # a caller-supplied root that does not exist yet (the check below is on OUR directory)
         try:
             os.mkdir(self.dir, 0o700)
         except FileExistsError:
@@ -122,13 +123,29 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", optimizer=None):
+def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", optimizer=None, fine_grained: bool = False, info: dict | None = None):
     """-> taper_amd.Communicator (or None for a single rank).
     backend "rccl": RCCL all-reduce (ring / tree over xGMI) -- rank 0's unique id is broadcast.
     backend "p2p":  the one-shot peer-to-peer all-reduce fused with Adam (th_allreduce_adam): every rank registers the
-                    gradient arena of `optimizer`, the IPC blobs are all-gathered, every rank maps its peers."""
+                    gradient arena of `optimizer`, the IPC blobs are all-gathered, every rank maps its peers.  fine_grained: the arena is
+                    moved into fine-grained device memory first (never cached in a peer's L2).
+    backend "auto": p2p on the pooled arena; if its multi-round self-check fails, p2p on a fine-grained arena; then RCCL.  `info` (a
+                    dict) receives {"backend", "why"}."""
     if rdzv is None or rdzv.world == 1:
         return None
+    if backend == "auto":
+        why = []
+        for fine in (False, True):
+            try:
+                comm = init_data_parallel(T, rdzv, "p2p", optimizer, fine_grained=fine)
+                if info is not None:
+                    info.update(backend="p2p-finegrained" if fine else "p2p", why="; ".join(why))
+                return comm
+            except RuntimeError as e:
+                why.append(f"p2p{' (fine-grained arena)' if fine else ''}: {e}")
+        if info is not None:
+            info.update(backend="rccl", why="; ".join(why))
+        return init_data_parallel(T, rdzv, "rccl")
     if backend == "p2p":
         if optimizer is None:
             raise ValueError("init_data_parallel(backend='p2p') needs the optimizer whose gradient arena is reduced")
@@ -137,7 +154,7 @@ def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", op
         comm, err = None, ""
         try:
             comm = T.Communicator.p2p(rdzv.world, rdzv.rank)
-            blob = comm.export_arena(optimizer)
+            blob = comm.export_arena(optimizer, fine_grained)
         except Exception as e:   # noqa: BLE001 -- reported to every rank below
             blob, err = b"\0" * 192, f"export: {e}"
         blobs = rdzv.all_gather_bytes(blob)
@@ -149,11 +166,23 @@ def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", op
             except Exception as e:   # noqa: BLE001
                 err = f"connect: {e}"
         if rdzv.all_reduce_sum(1.0 if err else 0.0) > 0:
+            del comm
             raise RuntimeError(f"peer-to-peer communicator unavailable (rank {rdzv.rank}: {err or 'a peer failed'})")
-        # a known pattern through the real arena on the real links: a rank that sees stale or no peer data must not train
-        ok = comm.self_check(optimizer)
-        if rdzv.all_reduce_sum(0.0 if ok else 1.0) > 0:
-            raise RuntimeError(f"peer-to-peer all-reduce self-check failed (rank {rdzv.rank}: {'ok' if ok else 'mismatch or timeout'})")
+        # Known patterns through the real arena on the real links, several rounds through the SAME addresses and through BOTH kernels: a
+        # rank that sees stale or no peer data must not train.  The waits inside are short here (a bootstrap peer is either there or
+        # gone) and go back to the training bound afterwards.
+        comm.set_timeout_ms(int(os.environ.get("TAPER_P2P_BOOT_TIMEOUT_MS", "20000")))
+        try:
+            ok = comm.self_check(optimizer)
+        except Exception as e:   # noqa: BLE001
+            ok, err = False, f"self-check: {e}"
+        bad = rdzv.all_reduce_sum(0.0 if ok else 1.0)
+        if bad > 0:
+            del comm
+            rdzv.barrier()        # every rank has dropped its mappings before anybody frees or re-homes an arena
+            raise RuntimeError(f"peer-to-peer all-reduce self-check failed on {int(bad)} rank(s) (rank {rdzv.rank}: "
+                               f"{'ok' if ok else (err or 'mismatch or timeout')})")
+        comm.set_timeout_ms(int(os.environ.get("TAPER_P2P_TIMEOUT_MS", "120000")))
         return comm
     if backend != "rccl":
         raise ValueError(f"unknown data-parallel backend {backend!r}")

@@ -42,7 +42,8 @@ def main():
     H = backends.get("hip")
     model = H.sequential(spec)
     opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
-    comm = init_data_parallel(T, rdzv, backend=os.environ.get("TAPER_DP_BACKEND", "rccl"), optimizer=opt)
+    fine = os.environ.get("TAPER_DP_FINE", "0") == "1"
+    comm = init_data_parallel(T, rdzv, backend=os.environ.get("TAPER_DP_BACKEND", "rccl"), optimizer=opt, fine_grained=fine)
     tr = T.Trainer(model, opt, comm=comm, **({"sample_shape": sample_shape(model_name)} if sample_shape(model_name) else {}))
     loader = T.DataLoader(T.MNISTDataset.from_host(x[rows], y[rows]), per, False)
     mode = T.Trainer.GRAPH if os.environ.get("TAPER_DP_MODE", "graph") == "graph" else T.Trainer.EAGER
@@ -51,7 +52,7 @@ def main():
     if comm is not None and comm.is_p2p() and comm.timed_out():
         raise SystemExit(f"rank {rank}: a peer never arrived at the all-reduce")
     st = comm.stats() if comm is not None and comm.is_p2p() else dict(inplace=-1, fused=-1)
-    np.savez(out / f"rank{rank}.npz", launches_inplace=st["inplace"], launches_fused=st["fused"], losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
+    np.savez(out / f"rank{rank}.npz", fine=int(fine), launches_inplace=st["inplace"], launches_fused=st["fused"], losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
              **{f"p{i}": p.data() for i, p in enumerate(model.parameters())})
     rdzv.barrier()
     rdzv.close()

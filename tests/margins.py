@@ -1,0 +1,42 @@
+"""Observed parity margins: the step-level parity tests record, per tensor, how far the HIP path actually lands from
+the oracle -- max |got - ref| relative to the tensor's scale max |ref| (and, for weights after Adam steps, in units of the learning rate:
+Adam moves a weight by ~lr per step whatever the gradient's size, so lr is the natural scale of an error there) -- into
+gpurun_out/parity_margins.json on the box the tests run on; the builder copies that file to profiles/rNN_parity_margins.json and sets each
+test's tolerance to <= 2x the observed value.  Test infrastructure only."""
+import atexit
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+
+_ROOT = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent))
+_OUT = _ROOT / "gpurun_out" / "parity_margins.json"
+_seen = {}
+
+
+def record(test: str, tensor: str, got, ref, lr: float | None = None) -> dict:
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64).reshape(np.shape(got))
+    diff = float(np.abs(got - ref).max()) if got.size else 0.0
+    scale = float(np.abs(ref).max()) if ref.size else 0.0
+    nz = np.abs(ref) > 1e-3 * max(scale, 1e-30)
+    rec = dict(max_abs_err=diff, ref_scale=scale, err_over_scale=(diff / scale if scale > 0 else 0.0),
+               max_rel_err_on_elements_above_0p001_of_scale=float((np.abs(got - ref)[nz] / np.abs(ref)[nz]).max()) if nz.any() else 0.0)
+    if lr is not None:
+        rec["err_over_lr"] = diff / lr
+    _seen.setdefault(test, {})[tensor] = rec
+    return rec
+
+
+@atexit.register
+def _flush():
+    if not _seen:
+        return
+    try:
+        _OUT.parent.mkdir(parents=True, exist_ok=True)
+        old = json.loads(_OUT.read_text()) if _OUT.exists() else {}
+        for k, v in _seen.items():
+            old.setdefault(k, {}).update(v)
+        _OUT.write_text(json.dumps(old, indent=1, sort_keys=True))
+    except OSError:
+        pass

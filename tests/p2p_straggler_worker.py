@@ -1,5 +1,6 @@
 """Two ranks bootstrap a peer-to-peer communicator on GPU 0; rank 1 then never launches the collective.  Rank 0's launch must give
-up after its bounded spin (~4 s) and raise th_comm_error instead of hanging the GPU (tests/test_gpu_dp.py)."""
+up after its bounded spin (set to 3 s here) instead of hanging the GPU, apply NOTHING (no parameter moves, Adam's counter stays), and the
+Trainer must raise -- a second step after the error is a no-op that raises again (tests/test_gpu_dp.py)."""
 import os
 import sys
 import time
@@ -24,12 +25,23 @@ comm = init_data_parallel(T, rdzv, backend="p2p", optimizer=opt)      # includes
 assert not comm.timed_out()
 t0 = time.time()
 if rank == 0:
+    from taper_amd._lib import TaperError
+    comm.set_timeout_ms(3000)
     tr = T.Trainer(model, opt, comm=comm)
     rng = np.random.default_rng(0)
     x = rng.uniform(0, 1, (64, 784)).astype(np.float32)
     y = rng.integers(0, 10, 64).astype(np.float32)
-    tr.train_step(T.Tensor(x), T.Tensor(y))          # rank 1 never arrives at this all-reduce
-    timed_out = comm.timed_out()                      # synchronises: returns once the launch has given up
-    (out / "straggler_result.txt").write_text(f"{int(timed_out)} {time.time() - t0:.2f}")
+    before = [p.data() for p in model.parameters()]
+    raised = []
+    for _ in range(2):
+        try:
+            tr.train_step(T.Tensor(x), T.Tensor(y))          # rank 1 never arrives at this all-reduce
+            raised.append("")
+        except TaperError as e:
+            raised.append(str(e))
+    first = time.time() - t0
+    unchanged = all(np.array_equal(a, p.data()) for a, p in zip(before, model.parameters()))
+    ok = all("timed out waiting for a peer" in r for r in raised) and comm.failed() and comm.timed_out()
+    (out / "straggler_result.txt").write_text(f"{int(ok)} {first:.2f} {int(unchanged)} {opt.t()}")
 rdzv.barrier()
 rdzv.close()

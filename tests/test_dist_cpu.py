@@ -209,6 +209,71 @@ def test_init_data_parallel_control_flow(world, tmp_path):
     assert init_data_parallel(_FakeT, None) is None      # a single rank has no communicator
 
 
+class _FakeP2P:
+    """stands in for the peer-to-peer Communicator: the self-check's verdict is scripted per attempt (TAPER_FAKE_P2P = e.g. "fail,ok":
+    the pooled arena fails on rank 1 only, the fine-grained one passes)"""
+    attempts = 0
+
+    def __init__(self, world, rank, fine=None):
+        self.world, self.rank, self.fine, self.timeouts = world, rank, fine, []
+
+    def export_arena(self, optimizer, fine_grained=False):
+        self.fine = fine_grained
+        return bytes([self.rank + 1]) * 192
+
+    def connect(self, blobs):
+        assert len(blobs) == 192 * self.world and all(blobs[192 * r] == r + 1 for r in range(self.world))
+
+    def set_timeout_ms(self, ms):
+        self.timeouts.append(ms)
+
+    def self_check(self, optimizer, rounds=3):
+        plan = os.environ["TAPER_FAKE_P2P"].split(",")
+        verdict = plan[min(_FakeP2P.attempts, len(plan) - 1)]
+        _FakeP2P.attempts += 1
+        return verdict == "ok" or self.rank == 0          # a failure is seen by rank 1 only: rank 0 must still learn of it
+
+
+class _FakeTP2P:
+    class Communicator(_FakeCommunicator):
+        @staticmethod
+        def p2p(world, rank):
+            return _FakeP2P(world, rank)
+
+
+def _auto_worker(rank, world, root, plan, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["TAPER_FAKE_P2P"] = plan
+    from taper_amd.dist import FileRendezvous, init_data_parallel
+    rdzv = FileRendezvous(rank, world, key="auto" + plan.replace(",", ""), root=root, timeout_s=60)
+    info = {}
+    comm = init_data_parallel(_FakeTP2P, rdzv, backend="auto", optimizer=object(), info=info)
+    rdzv.close()
+    q.put((rank, type(comm).__name__, getattr(comm, "fine", None), getattr(comm, "timeouts", None), info))
+
+
+@pytest.mark.parametrize("plan,want", [("ok", ("_FakeP2P", False, "p2p")), ("fail,ok", ("_FakeP2P", True, "p2p-finegrained")),
+                                       ("fail,fail", ("Communicator", None, "rccl"))])
+def test_auto_backend_falls_back_p2p_then_finegrained_then_rccl(plan, want, tmp_path):
+    """world 2: a self-check that fails on ONE rank moves EVERY rank on -- first to the fine-grained gradient arena, then to RCCL -- and the
+    bootstrap's short wait bound is replaced by the training bound once the check has passed"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_auto_worker, args=(r, 2, str(tmp_path), plan, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, kind, fine, timeouts, info in res:
+        assert (kind, fine, info["backend"]) == want, (rank, kind, fine, info)
+        if kind == "_FakeP2P":
+            assert timeouts == [20000, 120000]
+        if want[2] != "p2p":
+            assert "self-check failed" in info["why"]
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """`python bench.py --gpus N` without a launcher self-spawns N ranks -- and must not quietly run a smaller job when the box
     has fewer GPUs (it used to fall back to 1 rank)"""

@@ -237,10 +237,14 @@ def test_simple_cnn_trainer_steps_take_the_two_launch_form_and_match_the_oracle(
     losses, nc, params, t, cfg = _trainer_run(T, H, spec, x, y, batch, True, mode)
     assert cfg["dma"] == 7 and cfg["ct"] == 2, cfg          # th_conv_chain_head_fwd ran in this process's step
     assert t == steps
+    from tests import margins
+    tag = f"cnn_simple_two_launch_step_b{batch}_3_adam_steps"
+    margins.record(tag, "losses", losses, [r["loss"] for r in ref])
     np.testing.assert_allclose(losses, [r["loss"] for r in ref], rtol=3e-4, atol=1e-5)
     assert np.abs(np.asarray(nc) - np.asarray([r["acc"] * batch for r in ref])).max() <= 1.5
     for i, (hp, op) in enumerate(zip(params, om.parameters())):
-        np.testing.assert_allclose(hp, op.data(), rtol=RTOL, atol=lr * 2e-2, err_msg=f"param {i}")
+        m = margins.record(tag, f"param{i}", hp, op.data(), lr=lr)
+        assert m["err_over_lr"] <= 2e-2, (i, m)
     # ... and the same step with the classifier as its own launches (th_linear_xent_wide + the bias finish): same results within rounding
     l2, nc2, p2, t2, cfg2 = _trainer_run(T, H, spec, x, y, batch, False, mode)
     assert cfg2["dma"] == 6 and t2 == steps

@@ -135,6 +135,9 @@ def test_maxpool_full_size_bit_exact(ctx, O):
 
 
 MODELS = {"cnn_simple": backends.cnn_simple, "cnn_reference": backends.cnn_reference}
+# observed on MI355X (profiles/r03_parity_margins.json) x 2: see _training_steps_parity
+LOSS_RTOL = 3e-4
+STEP_ERR_OVER_LR = 2e-2
 
 
 def _grads_close(h_grads, o_grads):
@@ -213,10 +216,16 @@ def _training_steps_parity(T, name, mode):
             l, a = tr.train_step(T.Tensor(x[s * batch:(s + 1) * batch]), T.Tensor(y[s * batch:(s + 1) * batch]))
             losses.append(l)
             ncorrect.append(a * batch)
-    np.testing.assert_allclose(losses, [r["loss"] for r in ref], rtol=3e-4, atol=1e-5)
+    from tests import margins
+    tag = f"{name}_b256_3_adam_steps[{mode}]"
+    margins.record(tag, "losses", losses, [r["loss"] for r in ref])
+    np.testing.assert_allclose(losses, [r["loss"] for r in ref], rtol=LOSS_RTOL, atol=1e-6)
     assert np.abs(np.asarray(ncorrect) - np.asarray([r["acc"] * batch for r in ref])).max() <= 1.5
     for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
-        np.testing.assert_allclose(hp.data(), op.data(), rtol=RTOL, atol=lr * 2e-2, err_msg=f"param {i}")
+        m = margins.record(tag, f"param{i}", hp.data(), op.data(), lr=lr)
+        # Adam's first steps move a weight by lr * m / (sqrt(v) + eps) ~ lr * sign(g): the natural scale of a weight error after 3 steps is
+        # lr, not the weight ("parity margins"); the bound is 2x the largest error observed on MI355X (profiles/r03_parity_margins.json)
+        assert m["err_over_lr"] <= STEP_ERR_OVER_LR, (i, m)
     assert hopt.t() == steps
 
 

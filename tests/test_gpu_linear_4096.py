@@ -1,0 +1,65 @@
+"""BASELINE configs[4] at FULL size as a training step against the oracle: Linear(4096, 4096) + ReLU + Linear(4096, 10) at batch 4096 --
+forward, loss, every gradient, one Adam step over 16.8 M parameters (/root/reference/src/ops.rs:200-298 at 4096^3, src/nn.rs:54-60,
+src/optim.rs:83-113) -- the eager op-by-op step bench.py's linear_stack workload times (big-tile th_linear_fwd / th_linear_bwd, the
+element-wise ReLU backward, adam_kernel over the flat arena).  The oracle runs in its packed-sgemm build (`make -C oracle fast`, held equal
+to the plain-loop oracle by tests/test_cpu_baseline.py): ~3 x 137 GFLOP of fp32 on the host."""
+import gc
+
+import numpy as np
+import pytest
+
+from tests import backends, margins
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def test_linear_4096_step_matches_the_oracle_at_full_size(tmp_path):
+    import taper_amd as T
+    from oracle import oracle as O
+    B, W, C = 4096, 4096, 10
+    rng = np.random.default_rng(4096)
+    spec = backends.nonzero_biases([backends._lin(rng, W, W), dict(kind="relu"), backends._lin(rng, W, C)], rng)
+    x = rng.uniform(0, 1, (B, W)).astype(np.float32)
+    y = rng.integers(0, C, B).astype(np.float32)
+    lr = 1e-3
+
+    default_so = O.build()
+    fast_so = O.build_fast(str(tmp_path))
+    O.use_library(fast_so)
+    try:
+        Orc = backends.get("oracle")
+        Orc.set_zero_sentinel(True)
+        om = Orc.sequential(spec)
+        oopt = Orc.m.Adam(om.parameters(), lr, None, None, 1e-4)
+        r = om.train_step(oopt, x, y, (B, W), want_logits=True, want_grads=True)
+        o_loss, o_acc, o_logits = r["loss"], r["acc"], r["logits"].copy()
+        sizes = [p.numel() for p in om.parameters()]
+        o_grads = np.split(r["grads"], np.cumsum(sizes)[:-1])
+        assert all(r["has_grad"])
+        o_params = [p.data().copy() for p in om.parameters()]
+        del om, oopt, r
+        gc.collect()
+    finally:
+        O.use_library(default_so)
+
+    H = backends.get("hip")
+    hm = H.sequential(spec)
+    h_loss, h_acc, h_logits, h_grads = H.forward_backward(hm, x, y, (B, W))
+    name = "linear_4096_step"
+    margins.record(name, "logits", h_logits, o_logits)
+    np.testing.assert_allclose(h_logits, o_logits, rtol=RTOL, atol=RTOL * float(np.abs(o_logits).max()))
+    assert abs(h_loss - o_loss) <= RTOL * max(1.0, abs(o_loss))
+    assert abs(h_acc - o_acc) <= 2.0 / B
+    for i, (hg, og) in enumerate(zip(h_grads, o_grads)):
+        og = og.reshape(hg.shape)
+        m = margins.record(name, f"grad{i}", hg, og)
+        assert m["err_over_scale"] <= 1e-4, (i, m)
+    hopt = T.Adam(hm.parameters(), lr, None, None, 1e-4)
+    tr = T.Trainer(hm, hopt)
+    loss, acc = tr.train_step(T.Tensor(x), T.Tensor(y))
+    assert abs(loss - o_loss) <= RTOL * max(1.0, abs(o_loss)) and hopt.t() == 1
+    for i, (hp, op) in enumerate(zip(hm.parameters(), o_params)):
+        m = margins.record(name, f"param{i}_after_adam", hp.data(), op.reshape(hp.data().shape), lr=lr)
+        # the first Adam step moves every weight by lr * g / (|g| + eps): an element whose gradient is ~eps-sized can land anywhere within lr
+        assert m["err_over_lr"] <= 2e-2, (i, m)

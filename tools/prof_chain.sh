@@ -7,4 +7,4 @@ cd $GRAFT_REPO_ROOT/taper_amd/csrc
 OBJS=$(ls _build/*.o | grep -v conv_chain.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libtaper_hip.so $OBJS /tmp/conv_chain_prof.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 cd $GRAFT_REPO_ROOT
-python tools/prof_chain.py 100
+python ${PROF_SCRIPT:-tools/prof_chain.py} 100
