@@ -240,11 +240,12 @@ def test_simple_cnn_trainer_steps_take_the_two_launch_form_and_match_the_oracle(
     from tests import margins
     tag = f"cnn_simple_two_launch_step_b{batch}_3_adam_steps"
     margins.record(tag, "losses", losses, [r["loss"] for r in ref])
-    np.testing.assert_allclose(losses, [r["loss"] for r in ref], rtol=3e-4, atol=1e-5)
+    # bounds = 2x the largest margin observed on MI355X (profiles/r03_parity_margins.json: losses 3.5e-6 of the largest, weights 4.0e-3 lr)
+    np.testing.assert_allclose(losses, [r["loss"] for r in ref], rtol=0, atol=7e-6 * max(abs(r["loss"]) for r in ref))
     assert np.abs(np.asarray(nc) - np.asarray([r["acc"] * batch for r in ref])).max() <= 1.5
     for i, (hp, op) in enumerate(zip(params, om.parameters())):
         m = margins.record(tag, f"param{i}", hp, op.data(), lr=lr)
-        assert m["err_over_lr"] <= 2e-2, (i, m)
+        assert m["err_over_lr"] <= 8e-3, (i, m)
     # ... and the same step with the classifier as its own launches (th_linear_xent_wide + the bias finish): same results within rounding
     l2, nc2, p2, t2, cfg2 = _trainer_run(T, H, spec, x, y, batch, False, mode)
     assert cfg2["dma"] == 6 and t2 == steps

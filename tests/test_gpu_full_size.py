@@ -136,8 +136,8 @@ def test_maxpool_full_size_bit_exact(ctx, O):
 
 MODELS = {"cnn_simple": backends.cnn_simple, "cnn_reference": backends.cnn_reference}
 # observed on MI355X (profiles/r03_parity_margins.json) x 2: see _training_steps_parity
-LOSS_RTOL = 3e-4
-STEP_ERR_OVER_LR = 2e-2
+LOSS_RTOL = 2e-6            # observed 7.4e-7 of the largest loss
+STEP_ERR_OVER_LR = 1.5e-2   # observed 7.4e-3 (simple CNN, the classifier's weight), 3.0e-3 (reference CNN)
 
 
 def _grads_close(h_grads, o_grads):
@@ -219,7 +219,7 @@ def _training_steps_parity(T, name, mode):
     from tests import margins
     tag = f"{name}_b256_3_adam_steps[{mode}]"
     margins.record(tag, "losses", losses, [r["loss"] for r in ref])
-    np.testing.assert_allclose(losses, [r["loss"] for r in ref], rtol=LOSS_RTOL, atol=1e-6)
+    np.testing.assert_allclose(losses, [r["loss"] for r in ref], rtol=0, atol=LOSS_RTOL * max(abs(r["loss"]) for r in ref))
     assert np.abs(np.asarray(ncorrect) - np.asarray([r["acc"] * batch for r in ref])).max() <= 1.5
     for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
         m = margins.record(tag, f"param{i}", hp.data(), op.data(), lr=lr)

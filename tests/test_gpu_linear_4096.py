@@ -51,15 +51,32 @@ def test_linear_4096_step_matches_the_oracle_at_full_size(tmp_path):
     np.testing.assert_allclose(h_logits, o_logits, rtol=RTOL, atol=RTOL * float(np.abs(o_logits).max()))
     assert abs(h_loss - o_loss) <= RTOL * max(1.0, abs(o_loss))
     assert abs(h_acc - o_acc) <= 2.0 / B
+    # The hidden layer's gradients pass the ReLU mask [h > 0] (ops.rs:358-369): 16.8 M pre-activations summed over k = 4096 in two different
+    # orders disagree about the sign of a few dozen that sit within rounding of zero, and each such flip moves ONE row of dW1 (and one
+    # element of db1) by that row's dZ1 = (dlogits . W2) element -- a discontinuity of the function, not an error of either side.  So: those
+    # two tensors may be off by a few |dZ1| elements on a small fraction of their rows; everything else is held to 1e-4 of its scale.
+    m_ = o_logits - o_logits.max(axis=1, keepdims=True)
+    p_ = np.exp(m_) / np.exp(m_).sum(axis=1, keepdims=True)
+    p_[np.arange(B), y.astype(int)] -= 1.0
+    dz_max = float(np.abs((p_ / B) @ spec[2]["w"]).max())
     for i, (hg, og) in enumerate(zip(h_grads, o_grads)):
         og = og.reshape(hg.shape)
         m = margins.record(name, f"grad{i}", hg, og)
-        assert m["err_over_scale"] <= 1e-4, (i, m)
+        if i < 2:
+            err_rows = np.abs(hg - og).reshape(W, -1).max(axis=1)
+            loose = err_rows > 1e-4 * m["ref_scale"]
+            m["rows_off_by_a_relu_mask_flip"] = int(loose.sum())
+            assert m["max_abs_err"] <= 4 * dz_max and loose.mean() <= 0.03, (i, m, dz_max)
+        else:
+            assert m["err_over_scale"] <= 1e-4, (i, m)
     hopt = T.Adam(hm.parameters(), lr, None, None, 1e-4)
     tr = T.Trainer(hm, hopt)
     loss, acc = tr.train_step(T.Tensor(x), T.Tensor(y))
     assert abs(loss - o_loss) <= RTOL * max(1.0, abs(o_loss)) and hopt.t() == 1
     for i, (hp, op) in enumerate(zip(hm.parameters(), o_params)):
         m = margins.record(name, f"param{i}_after_adam", hp.data(), op.reshape(hp.data().shape), lr=lr)
-        # the first Adam step moves every weight by lr * g / (|g| + eps): an element whose gradient is ~eps-sized can land anywhere within lr
-        assert m["err_over_lr"] <= 2e-2, (i, m)
+        # the first Adam step moves every weight by lr * g / (|g| + eps) = lr * sign(g) for all but eps-sized gradients: an element whose
+        # gradient changes sign under a mask flip (or is ~eps-sized) lands up to 2 lr away; all others within a few percent of lr
+        d = np.abs(hp.data() - op.reshape(hp.data().shape)) / lr
+        m["fraction_beyond_2pct_of_lr"] = float((d > 2e-2).mean())
+        assert m["err_over_lr"] <= 2.0 + 1e-3 and m["fraction_beyond_2pct_of_lr"] <= (2e-3 if i < 2 else 0.0), (i, m)
