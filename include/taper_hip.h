@@ -393,9 +393,12 @@ int th_conv3x3_gap_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const fl
  * Stage i: d_w taper layout [9 c_in_i][c_out] (tensor.rs:1262), d_bias [c_out], then `post`.  For a bias-only backward (faithful mode,
  * Q2): intermediate maps are neither written nor available afterwards.  d_y: [n][c_out] plane means when the last stage ends in
  * TH_CHAIN_GLOBAL_AVG (d_cnt [n][c_out], nullable: outputs > 0 per plane, see th_conv3x3_gap_fwd), else the last stage's (pooled) NCHW map.
- * Same bits as the layer-by-layer launches at batch >= 128.  th_conv_chain_supported: 0 = no compiled chain for these stages (the
- * caller launches the layers one by one), else the id of the compiled instance: 1 = 28x28, 1 -> 32, 32 -> 32 + pool, 32 -> 64,
- * 64 -> 64 + pool, 64 -> 128 + global mean; 2 = 28x28, 1 -> 32 + pool, 32 -> 64 + pool. */
+ * Same bits as the layer-by-layer launches at batch >= 128.  th_conv_chain_supported: 0 = these stages do not run as a chain (the caller
+ * launches the layers one by one); 1, 2 = an instance with its sizes compiled in (1: 28x28, 1 -> 32, 32 -> 32 + pool, 32 -> 64, 64 -> 64 + pool,
+ * 64 -> 128 + global mean; 2: 28x28, 1 -> 32 + pool, 32 -> 64 + pool); 3 = the kernel that takes its stages as ARGUMENTS: any run of up to
+ * 8 stages on a square 28 / 14 / 7 input with 1 or a multiple of 16 (<= 256) channels, c_out a multiple of 16 (<= 512), pools on even
+ * maps, ending in a pool or the global average, whose maps fit the 160 KB of LDS (the plan -- tile-to-wave mapping, LDS offsets -- is
+ * worked out on the host per launch); a launch walks min(n, 256) workgroups over the images. */
 enum { TH_CHAIN_NONE = 0, TH_CHAIN_MAXPOOL2 = 1, TH_CHAIN_GLOBAL_AVG = 2 };
 typedef struct th_conv_stage {
     const float *d_w, *d_bias;
@@ -429,6 +432,8 @@ int th_wide_head_grads(th_ctx *ctx, const float *d_x, const float *d_dl, const f
                        int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss, float *d_ncorrect,
                        float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, const th_adam_fuse *w_fuse,
                        const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse);
+/* Test hook: 1 = the compiled chain instances are not used on this thread (their nets take the run-time-described kernel, id 3); 0 = default */
+int th_debug_set_chain_generic(int on);
 /* Test hook: launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity
  * tests assert which kernel instance a shape takes): out6 = {16-channel tiles per workgroup (1/2/4), 1 if the
  * operands are staged by LDS-DMA (2-5: the image-resident kernel; 6: a conv chain, out6[0] = its instance id), waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */

@@ -445,6 +445,20 @@ __device__ __forceinline__ void chain_head_weights(const ChainHeadArgs &h, float
     }
 }
 
+template <int NJ, int NC>
+__device__ __forceinline__ void chain_head_weights_rt(const ChainHeadArgs &h, float (&wv)[NJ][NC], int t) {   // the same with a run-time k
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)h.w, 0, h.classes * h.k * 4, 0x00020000);
+    const int vo = t * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vo, (c * h.k + CH_NT * j) * 4, 0));
+            wv[j][c] = t + CH_NT * j < h.k ? v : 0.f;
+        }
+    }
+}
+
 // xm: LDS [k] (the map; overwritten by the masked dX), red: LDS [NC][CH_NT] + 64 floats.  Ends without a barrier (global stores only).
 template <int NJ, int NC>
 __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const float (&wv)[NJ][NC], float *xm, float *red, int img, int t) {
@@ -580,6 +594,308 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
 #endif
 }
 
+// ==== chains described at run time ==================================================================================================================
+// Any run of Conv2dReLU(3x3, stride 1, pad 1) [+ MaxPool2d(2) | + global average pool] stages whose maps fit the 160 KB of LDS, with the
+// same structure as the two compiled instances above -- a workgroup carries one image through every stage, the maps live in LDS in the
+// padded [channel][rows + 2][cols + 2] form, weights come from L2 a pass ahead -- but with the channel counts, the tile-to-wave mapping and
+// the LDS plan as kernel ARGUMENTS (RtStage, filled by rt_plan on the host).  Compiled in: the map sizes (S = 28, 14, 7: what a 28 x 28
+// input and its pools produce), so the tap part of an operand address stays an immediate, and the number of "double" pixel tiles a wave
+// carries per round (ND = 1, 2, 4, 7).  A wave owns ONE pair of channel tiles per round (chA = 2 q, chB = 2 q + 1: every pixel operand read
+// feeds two MFMAs) and ND pixel tiles (piece + m i): chunk (q, piece) = round * 8 + wave.  Same per-output arithmetic as the compiled
+// instances and the layer-by-layer kernels (k order, bias after the sum, ReLU, strict-> maxima, the 16-lane plane sums).
+constexpr int RT_MAX_STAGES = 8, RT_LDS_FLOATS = 40960;   // 160 KB
+
+struct RtStage {
+    const float *w, *b;            // taper layout [9 c_in][c_out], bias [c_out]
+    int c_in, c_out, s, post;      // s: the conv's map size (input = output); post: TH_CHAIN_*
+    int in_off, out_off, pool_off; // LDS offsets (floats): input planes; output planes (post none) or plain tile (pooled / averaged); pooled planes
+    int nd, m, rounds;             // doubles per chunk, chunks per channel pair, rounds of 8 chunks
+};
+
+struct RtChainArgs {
+    const float *x;                // [n][c0][s0][s0]
+    float *y, *cnt;
+    int n, n_stages, c0, s0;
+    int has_head, xm_off, red_off; // the classifier rows (chain_head_rows): LDS offsets of the flattened map and the reduction scratch
+    RtStage st[RT_MAX_STAGES];
+    ChainHeadArgs head;
+};
+
+template <int S>
+__device__ __forceinline__ void rt_load_planes(const float *__restrict__ xi, float *planes, int c0, int t) {
+    constexpr int WP = S + 2, CIS = ch_cis(WP);
+    for (int c = 0; c < c0; ++c)
+        for (int e = t; e < WP * WP; e += CH_NT) {
+            const int r = e / WP - 1, q = e % WP - 1;
+            planes[c * CIS + e] = (r >= 0 && r < S && q >= 0 && q < S) ? xi[(c * S + r) * S + q] : 0.f;
+        }
+}
+
+template <int S>
+__device__ __forceinline__ void rt_zero_halo(float *planes, int c, int wave, int lane) {
+    constexpr int WP = S + 2, CIS = ch_cis(WP), RING = 4 * S + 4;
+    int pos[(RING + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (RING + 63) / 64; ++j) {
+        const int r = lane + 64 * j;
+        pos[j] = r < WP ? r : r < 2 * WP ? (WP - 1) * WP + (r - WP) : r < 2 * WP + S ? (r - 2 * WP + 1) * WP : r < RING ? (r - 2 * WP - S + 1) * WP + WP - 1 : -1;
+    }
+    for (int ch = wave; ch < c; ch += CH_NT / 64) {
+#pragma unroll
+        for (int j = 0; j < (RING + 63) / 64; ++j)
+            if (pos[j] >= 0) planes[ch * CIS + pos[j]] = 0.f;
+    }
+}
+
+// weight operands of pass cb for the pair (chA, chB): one dword per lane and k-step each (chain_weights with run-time sizes)
+__device__ __forceinline__ void rt_weights(const float *__restrict__ w, int c_in, int c_out, int cb, int chA, int chB, ChainW &wr, int lane) {
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * c_in * c_out * 4, 0x00020000);
+    const int row = ((lane >> 4) * 9 * c_out + (lane & 15)) * 4, va = row + 64 * chA, vb = row + 64 * chB;
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+        const int so = ((cb + 4 * (s / 9)) * 9 + s % 9) * c_out * 4;
+        wr.a[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, va, so, 0));
+        wr.b[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vb, so, 0));
+    }
+}
+
+// the k loop of one chunk: in = padded planes [c_in][CIS]; acc[2 i], acc[2 i + 1] = pixel tile ptile[i] x (chA, chB)
+template <int S, int ND>
+__device__ __forceinline__ void rt_mfma(const float *in, const float *__restrict__ w, int c_in, int c_out, int chA, int chB, const int (&ptile)[ND],
+                                        floatx4 (&acc)[2 * ND], int lane) {
+    constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, KS = 18;
+    const int l16 = lane & 15, g4 = lane >> 4;
+    typedef __attribute__((address_space(3))) const float lds_cf;
+    lds_cf *pt[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        int p = ptile[i] * 16 + l16;
+        if (p >= PX) p = 0;        // lanes / tiles past the image compute on pixel 0 and are never stored
+        pt[i] = (lds_cf *)(in + (p / S) * WP + p % S + g4 * CIS);
+        asm volatile("" : "+v"(pt[i]));
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * ND; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+    ChainW wc, wn;
+    rt_weights(w, c_in, c_out, 0, chA, chB, wc, lane);
+#define RT_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < ND; ++i) B[i] = pt[i][(4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
+#define RT_PASS_BODY(WCUR)                                                                                                          \
+    {                                                                                                                               \
+        float b0[ND], b1[ND];                                                                                                       \
+        RT_REQ(b0, 0)                                                                                                               \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                            \
+            if (s + 1 < KS) RT_REQ(b1, s + 1)                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                                        \
+                acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[i], acc[2 * i], 0, 0, 0);                           \
+                acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.b[s], b0[i], acc[2 * i + 1], 0, 0, 0);                   \
+            }                                                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            if (s + 1 < KS) { _Pragma("unroll") for (int i = 0; i < ND; ++i) b0[i] = b1[i]; }                                       \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < ND; ++i) pt[i] += 8 * CIS;                                                            \
+    }
+#pragma unroll 1
+    for (int cb = 0; cb < c_in; cb += 16) {
+        rt_weights(w, c_in, c_out, cb + 8, chA, chB, wn, lane);
+        RT_PASS_BODY(wc)
+        if (cb + 16 < c_in) rt_weights(w, c_in, c_out, cb + 16, chA, chB, wc, lane);
+        RT_PASS_BODY(wn)
+    }
+#undef RT_PASS_BODY
+#undef RT_REQ
+}
+
+// a single input channel (the first stage of an image chain): k = the tap, padded to three k-steps of four with zero weights (chain_conv1_mfma)
+template <int S, int ND>
+__device__ __forceinline__ void rt_conv1(const float *img, const float *__restrict__ w, int c_out, int chA, int chB, const int (&ptile)[ND],
+                                         floatx4 (&acc)[2 * ND], int lane) {
+    constexpr int WP = S + 2, PX = S * S;
+    const int l16 = lane & 15, g4 = lane >> 4;
+    float wa[3], wb[3];
+    int toff[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int tap = 4 * s + g4, tt = tap < 9 ? tap : 0;
+        wa[s] = tap < 9 ? w[tap * c_out + 16 * chA + l16] : 0.f;
+        wb[s] = tap < 9 ? w[tap * c_out + 16 * chB + l16] : 0.f;
+        toff[s] = (tt / 3) * WP + tt % 3;
+    }
+    const bool pad_lane = 8 + g4 >= 9;
+#pragma unroll
+    for (int k = 0; k < 2 * ND; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        int p = ptile[i] * 16 + l16;
+        if (p >= PX) p = 0;
+        const float *px = img + (p / S) * WP + p % S;
+        float b[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) b[s] = (s == 2 && pad_lane ? img : px)[toff[s]];   // padded taps read the halo corner (0.0)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], b[s], acc[2 * i], 0, 0, 0);
+            acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s], b[s], acc[2 * i + 1], 0, 0, 0);
+        }
+    }
+}
+
+// 2x2 / stride-2 maxima of the tile [c][ld(S S)] -> interior of padded planes [c][CIS(S / 2)], or (TO_GLOBAL) the image's pooled NCHW map
+// (+ a flat LDS copy for the classifier rows); chain_pool with a run-time channel count
+template <int S>
+__device__ __forceinline__ void rt_pool(const float *tile, float *out, int c_out, bool to_global, float *flat, int t) {
+    constexpr int LD = ch_tile_ld(S * S), HP = S / 2, NP = HP * HP, WPO = HP + 2, CISO = ch_cis(WPO);
+    constexpr int CHUNKS = (CH_NT / NP >= 8 ? 8 : (CH_NT / NP >= 4 ? 4 : (CH_NT / NP >= 2 ? 2 : 1)));
+    static_assert(S % 2 == 0 && NP <= CH_NT, "pooled plane fits the workgroup");
+    const int q = t % NP, chunk = t / NP;
+    if (chunk >= CHUNKS) return;
+    const int cpc = (c_out + CHUNKS - 1) / CHUNKS, c0 = chunk * cpc, c1 = min(c_out, c0 + cpc);
+    const int pr = q / HP, pc = q % HP;
+    const float *b = tile + c0 * LD + 2 * pr * S + 2 * pc;
+    for (int c = c0; c < c1; ++c, b += LD) {
+        const float2 r0 = *reinterpret_cast<const float2 *>(b), r1 = *reinterpret_cast<const float2 *>(b + S);
+        float m = -INFINITY;
+        m = r0.x > m ? r0.x : m;
+        m = r0.y > m ? r0.y : m;
+        m = r1.x > m ? r1.x : m;
+        m = r1.y > m ? r1.y : m;
+        if (to_global) {
+            out[c * NP + q] = m;
+            if (flat) flat[c * NP + q] = m;
+        } else {
+            out[c * CISO + (pr + 1) * WPO + pc + 1] = m;
+        }
+    }
+}
+
+template <int S, int ND>
+__device__ __forceinline__ void rt_stage_nd(const RtChainArgs &a, const RtStage &st, float *lds, int img, int t, bool last) {
+    constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, NPT = (PX + 15) / 16, TLD = ch_tile_ld(PX);
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
+    const int nct = st.c_out / 16, np2 = (nct + 1) / 2;
+    const bool planes = st.post == TH_CHAIN_NONE;
+    const float *in = lds + st.in_off;
+    float *out = lds + st.out_off;
+    const int ld = planes ? CIS : TLD;
+    for (int r = 0; r < st.rounds; ++r) {
+        const int cid = r * (CH_NT / 64) + wave;
+        const bool active = cid < np2 * st.m;                    // wave-uniform
+        const int q = active ? cid / st.m : 0, piece = cid % st.m;
+        const int chA = 2 * q, chB = min(2 * q + 1, nct - 1);
+        const bool has_b = 2 * q + 1 < nct;
+        int ptile[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) ptile[i] = piece + st.m * i;
+        floatx4 acc[2 * ND];
+        float ba[4], bb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ba[e] = st.b[16 * chA + 4 * g4 + e];
+            bb[e] = st.b[16 * chB + 4 * g4 + e];
+        }
+        if (active) {
+            if (st.c_in == 1) rt_conv1<S, ND>(in, st.w, st.c_out, chA, chB, ptile, acc, lane);
+            else rt_mfma<S, ND>(in, st.w, st.c_in, st.c_out, chA, chB, ptile, acc, lane);
+        }
+        if (st.rounds == 1) {                                    // every wave is done reading the input: the output may overlay it
+            chain_sync();
+            if (planes) rt_zero_halo<S>(out, st.c_out, wave, lane);
+            else if (st.post == TH_CHAIN_MAXPOOL2 && !last) rt_zero_halo<S / 2>(lds + st.pool_off, st.c_out, wave, lane);
+        }
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 2 * ND; ++k) {
+                const int p = ptile[k >> 1] * 16 + l16;
+                const bool second = k & 1;
+                if (ptile[k >> 1] >= NPT || p >= PX || (second && !has_b)) continue;
+                float *o = out + (16 * (second ? chB : chA) + 4 * g4) * ld + (planes ? (p / S + 1) * WP + p % S + 1 : p);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[k][e] + (second ? bb[e] : ba[e]);
+                    v = v > 0.f ? v : 0.f;
+                    o[e * ld] = v;
+                }
+            }
+        }
+    }
+    if (st.rounds > 1) {                                         // (the output does not overlay the input: rt_plan)
+        if (planes) rt_zero_halo<S>(out, st.c_out, wave, lane);
+        else if (st.post == TH_CHAIN_MAXPOOL2 && !last) rt_zero_halo<S / 2>(lds + st.pool_off, st.c_out, wave, lane);
+    }
+    chain_sync();
+    if (st.post == TH_CHAIN_MAXPOOL2) {
+        if constexpr (S % 2 == 0) {
+            constexpr int NP = (S / 2) * (S / 2);
+            if (last) rt_pool<S>(out, a.y + (long)img * st.c_out * NP, st.c_out, true, a.has_head ? lds + a.xm_off : nullptr, t);
+            else rt_pool<S>(out, lds + st.pool_off, st.c_out, false, nullptr, t);
+        }
+        chain_sync();
+    } else if (st.post == TH_CHAIN_GLOBAL_AVG) {                 // 16 lanes per plane: avgpool_global16_kernel's arithmetic
+        for (int c = t >> 4; c < st.c_out; c += CH_NT / 16) {
+            const float *row = out + c * TLD;
+            float sum = 0.f, k = 0.f;
+            for (int i = l16; i < PX; i += 16) {
+                const float v = row[i];
+                sum += v;
+                k += v > 0.f ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                sum += __shfl_down(sum, off, 16);
+                k += __shfl_down(k, off, 16);
+            }
+            if (l16 == 0) {
+                a.y[(long)img * st.c_out + c] = sum / (float)PX;
+                if (a.cnt) a.cnt[(long)img * st.c_out + c] = k;
+            }
+        }
+        chain_sync();
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void rt_stage(const RtChainArgs &a, const RtStage &st, float *lds, int img, int t, bool last) {
+    switch (st.nd) {
+    case 1: rt_stage_nd<S, 1>(a, st, lds, img, t, last); break;
+    case 2: rt_stage_nd<S, 2>(a, st, lds, img, t, last); break;
+    case 4: rt_stage_nd<S, 4>(a, st, lds, img, t, last); break;
+    default: rt_stage_nd<S, 7>(a, st, lds, img, t, last); break;
+    }
+}
+
+__global__ __launch_bounds__(CH_NT, 1) void conv_chain_rt_kernel(RtChainArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x;
+    if (a.has_head && a.head.tick && blockIdx.x == 0 && t == 0) a.head.tick[0] += 1;
+    for (int img = blockIdx.x; img < a.n; img += gridDim.x) {
+        const float *xi = a.x + (long)img * a.c0 * a.s0 * a.s0;
+        float *in0 = lds + a.st[0].in_off;
+        switch (a.s0) {
+        case 28: rt_load_planes<28>(xi, in0, a.c0, t); break;
+        case 14: rt_load_planes<14>(xi, in0, a.c0, t); break;
+        default: rt_load_planes<7>(xi, in0, a.c0, t); break;
+        }
+        chain_sync();
+        for (int i = 0; i < a.n_stages; ++i) {
+            const RtStage &st = a.st[i];
+            const bool last = i == a.n_stages - 1;
+            switch (st.s) {
+            case 28: rt_stage<28>(a, st, lds, img, t, last); break;
+            case 14: rt_stage<14>(a, st, lds, img, t, last); break;
+            default: rt_stage<7>(a, st, lds, img, t, last); break;
+            }
+        }
+        if (a.has_head) {                                        // (the last stage's pool left the flattened map at xm_off, behind a barrier)
+            float hw_[CS_NJ][16];
+            chain_head_weights_rt<CS_NJ, 16>(a.head, hw_, t);
+            chain_head_rows<CS_NJ, 16>(a.head, hw_, lds + a.xm_off, lds + a.red_off, img, t);
+        }
+        chain_sync();                                            // the next image reuses the maps
+    }
+#endif
+}
+
 }  // namespace th
 
 namespace th {
@@ -587,18 +903,140 @@ extern thread_local int t_last_conv_cfg[6];   // conv_mfma.hip: th_debug_last_co
 }
 using namespace th;
 
+// ---- host side: the compiled instances as DATA, the run-time plan ------------------------------------------------------------------------------
+namespace {
+
+struct CompiledChain { int id, c_in, hw, n; int c_out[5], post[5]; };
+const CompiledChain kCompiled[] = {
+    {1, 1, 28, 5, {32, 32, 64, 64, 128}, {TH_CHAIN_NONE, TH_CHAIN_MAXPOOL2, TH_CHAIN_NONE, TH_CHAIN_MAXPOOL2, TH_CHAIN_GLOBAL_AVG}},   // examples/train_mnist_cnn.rs:35-62
+    {2, 1, 28, 2, {32, 64, 0, 0, 0}, {TH_CHAIN_MAXPOOL2, TH_CHAIN_MAXPOOL2, 0, 0, 0}},                                                  // BASELINE configs[2]
+};
+thread_local int t_chain_generic = [] { const char *e = getenv("TAPER_CHAIN_GENERIC"); return (e && e[0] == '1') ? 1 : 0; }();   // 1: never a compiled instance
+
+int compiled_chain(int c_in, int h, int w, const th_conv_stage *st, int n) {
+    if (t_chain_generic) return 0;
+    for (const CompiledChain &c : kCompiled) {
+        if (c.c_in != c_in || c.hw != h || c.hw != w || c.n != n) continue;
+        bool same = true;
+        for (int i = 0; i < n && same; ++i) same = st[i].c_out == c.c_out[i] && st[i].post == c.post[i];
+        if (same) return c.id;
+    }
+    return 0;
+}
+
+struct Span { int lo, hi; };
+// lowest 4-aligned offset for `sz` floats inside the LDS that avoids every live span; -1: none
+int rt_place(int sz, const Span *live, int n_live) {
+    int cand[8] = {0};
+    int nc = 1;
+    for (int i = 0; i < n_live; ++i) cand[nc++] = (live[i].hi + 3) & ~3;
+    int best = -1;
+    for (int c = 0; c < nc; ++c) {
+        const int lo = cand[c], hi = lo + sz;
+        if (hi > RT_LDS_FLOATS) continue;
+        bool clash = false;
+        for (int i = 0; i < n_live; ++i) clash = clash || (lo < live[i].hi && live[i].lo < hi);
+        if (!clash && (best < 0 || lo < best)) best = lo;
+    }
+    return best;
+}
+
+// Tile mapping and LDS plan of a run of stages (RtStage); false: not a chain this kernel runs.  head_classes > 0: with the classifier rows.
+bool rt_plan(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, int head_classes, RtChainArgs *out, int *lds_floats) {
+    if (!stages || h != w || (h != 28 && h != 14 && h != 7) || n_stages < 1 || n_stages > RT_MAX_STAGES) return false;
+    if (!(c_in == 1 || (c_in % 16 == 0 && c_in >= 16 && c_in <= 256))) return false;
+    RtChainArgs a{};
+    a.c0 = c_in; a.s0 = h; a.n_stages = n_stages;
+    int s = h, ci = c_in, end = 0;
+    Span in{0, c_in * ch_cis(h + 2)};
+    if (in.hi > RT_LDS_FLOATS) return false;
+    end = in.hi;
+    for (int i = 0; i < n_stages; ++i) {
+        const th_conv_stage &d = stages[i];
+        const bool last = i == n_stages - 1;
+        if (!d.d_w || !d.d_bias || d.c_out % 16 != 0 || d.c_out < 16 || d.c_out > 512) return false;
+        if (i > 0 && ci % 16 != 0) return false;
+        if (d.post != TH_CHAIN_NONE && d.post != TH_CHAIN_MAXPOOL2 && d.post != TH_CHAIN_GLOBAL_AVG) return false;
+        if (d.post == TH_CHAIN_MAXPOOL2 && s % 2 != 0) return false;
+        if ((d.post == TH_CHAIN_GLOBAL_AVG) != (last && d.post != TH_CHAIN_MAXPOOL2) || (last && d.post == TH_CHAIN_NONE)) return false;
+        RtStage &st = a.st[i];
+        st.w = d.d_w; st.b = d.d_bias; st.c_in = ci; st.c_out = d.c_out; st.s = s; st.post = d.post;
+        // tile mapping: np2 channel pairs x m chunks of nd pixel tiles, 8 chunks per round; cheapest rounds * nd, then fewest rounds
+        const int npt = (s * s + 15) / 16, np2 = (d.c_out / 16 + 1) / 2;
+        int best = 1 << 30;
+        for (int nd : {7, 4, 2, 1}) {
+            const int m = (npt + nd - 1) / nd, rounds = (np2 * m + 7) / 8, cost = rounds * nd * 16 + rounds;
+            if (cost < best) { best = cost; st.nd = nd; st.m = m; st.rounds = rounds; }
+        }
+        // LDS: the input is live through the k loops; with ONE round every accumulator is in registers when the input dies (a barrier), so
+        // the output may overlay it -- taken only when nothing else fits
+        st.in_off = in.lo;
+        const int out_sz = d.c_out * (d.post == TH_CHAIN_NONE ? ch_cis(s + 2) : ch_tile_ld(s * s));
+        int o = rt_place(out_sz, &in, 1);
+        if (o < 0 && st.rounds == 1) o = rt_place(out_sz, nullptr, 0);
+        if (o < 0) return false;
+        st.out_off = o;
+        Span outs{o, o + out_sz};
+        end = end > outs.hi ? end : outs.hi;
+        if (d.post == TH_CHAIN_NONE) {
+            in = outs;
+        } else if (d.post == TH_CHAIN_MAXPOOL2 && !last) {
+            const int p_sz = d.c_out * ch_cis(s / 2 + 2);
+            const Span live2[2] = {outs, in};
+            int po = rt_place(p_sz, live2, 2);
+            if (po < 0 && st.rounds == 1) po = rt_place(p_sz, &outs, 1);     // over the (dead) input
+            if (po < 0) return false;
+            st.pool_off = po;
+            in = Span{po, po + p_sz};
+            end = end > in.hi ? end : in.hi;
+            s /= 2;
+        } else if (d.post == TH_CHAIN_MAXPOOL2) {
+            s /= 2;
+        }
+        if (last && head_classes > 0) {
+            if (d.post != TH_CHAIN_MAXPOOL2 || head_classes > 16) return false;
+            const int k = d.c_out * s * s;
+            if (k > CS_NJ * CH_NT) return false;
+            const int xm = rt_place(k, &outs, 1);
+            if (xm < 0) return false;
+            const Span xs{xm, xm + k};
+            const int red = rt_place(16 * CH_NT + 64, &xs, 1);
+            if (red < 0) return false;
+            a.has_head = 1; a.xm_off = xm; a.red_off = red;
+            end = end > xs.hi ? end : xs.hi;
+            end = end > red + 16 * CH_NT + 64 ? end : red + 16 * CH_NT + 64;
+        }
+        ci = d.c_out;
+    }
+    if (out) *out = a;
+    if (lds_floats) *lds_floats = end;
+    return true;
+}
+
+}  // namespace
+
 extern "C" {
 
-// 1: reference front (5 stages, ends in a global average pool), 2: simple front (2 stages, ends in a max-pool), 0: no compiled chain
+// 0: no chain launch for these stages (the caller launches the layers one by one); 1, 2: a compiled instance (kCompiled); 3: the
+// run-time-described kernel
 int th_conv_chain_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages) {
-    if (!stages || c_in != 1 || h != 28 || w != 28) return 0;
+    if (!stages || n_stages < 1) return 0;
     for (int i = 0; i < n_stages; ++i)
         if (!stages[i].d_w || !stages[i].d_bias) return 0;
-    auto is = [&](int i, int c_out, int post) { return stages[i].c_out == c_out && stages[i].post == post; };
-    if (n_stages == 5 && is(0, 32, TH_CHAIN_NONE) && is(1, 32, TH_CHAIN_MAXPOOL2) && is(2, 64, TH_CHAIN_NONE) && is(3, 64, TH_CHAIN_MAXPOOL2) &&
-        is(4, 128, TH_CHAIN_GLOBAL_AVG))
-        return 1;
-    if (n_stages == 2 && is(0, 32, TH_CHAIN_MAXPOOL2) && is(1, 64, TH_CHAIN_MAXPOOL2)) return 2;
+    if (const int id = compiled_chain(c_in, h, w, stages, n_stages)) return id;
+    return rt_plan(c_in, h, w, stages, n_stages, 0, nullptr, nullptr) ? 3 : 0;
+}
+
+int th_debug_set_chain_generic(int on) {   // test hook: 1 = the compiled instances are not used (their nets take the run-time-described kernel)
+    t_chain_generic = on ? 1 : 0;
+    return 0;
+}
+
+static int rt_launch(th_ctx *ctx, RtChainArgs &a, int lds_floats, const float *d_x, float *d_y, float *d_cnt, int n) {
+    a.x = d_x; a.y = d_y; a.cnt = d_cnt; a.n = n;
+    const int lds = lds_floats * (int)sizeof(float);
+    (void)hipFuncSetAttribute((const void *)conv_chain_rt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(conv_chain_rt_kernel, dim3(n < kNumCU ? n : kNumCU), dim3(CH_NT), lds, ctx->stream, a);
     return 0;
 }
 
@@ -606,18 +1044,25 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
                       int h, int w) {
     TH_REQUIRE(ctx && d_x && d_y && stages && n > 0, "th_conv_chain_fwd: null argument");
     const int kind = th_conv_chain_supported(c_in, h, w, stages, n_stages);
-    TH_REQUIRE(kind != 0, "th_conv_chain_fwd: no compiled chain for these stages (th_conv_chain_supported)");
-    ConvChainArgs a{};
-    a.x = d_x; a.y = d_y; a.cnt = d_cnt; a.n = n;
-    for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
-    if (kind == 1) {
-        const int lds = CR_LDS * (int)sizeof(float);
-        (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(conv_chain_reference_kernel, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+    TH_REQUIRE(kind != 0, "th_conv_chain_fwd: these stages do not run as a chain (th_conv_chain_supported)");
+    if (kind == 3) {
+        RtChainArgs ra{};
+        int lds_floats = 0;
+        TH_REQUIRE(rt_plan(c_in, h, w, stages, n_stages, 0, &ra, &lds_floats), "th_conv_chain_fwd: no plan");
+        rt_launch(ctx, ra, lds_floats, d_x, d_y, stages[n_stages - 1].post == TH_CHAIN_GLOBAL_AVG ? d_cnt : nullptr, n);
     } else {
-        const int lds = CS_LDS * (int)sizeof(float);
-        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+        ConvChainArgs a{};
+        a.x = d_x; a.y = d_y; a.cnt = d_cnt; a.n = n;
+        for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
+        if (kind == 1) {
+            const int lds = CR_LDS * (int)sizeof(float);
+            (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL(conv_chain_reference_kernel, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+        } else {
+            const int lds = CS_LDS * (int)sizeof(float);
+            (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+        }
     }
     t_last_conv_cfg[0] = kind; t_last_conv_cfg[1] = 6; t_last_conv_cfg[2] = 0;   // 6: a conv chain (th_debug_last_conv_config)
     t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;
@@ -625,10 +1070,14 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
     return 0;
 }
 
-// the classifier rows ride in the chain's last epilogue where the flattened map fits a thread's registers (<= 7 elements per thread)
+// the classifier rows ride in the chain's last epilogue where the chain ends in a pooled map that fits a thread's registers (<= 7 elements
+// per thread): 2 = the compiled simple instance, 3 = the run-time-described kernel
 int th_conv_chain_head_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, int classes) {
-    if (classes < 1 || classes > 16) return 0;
-    return th_conv_chain_supported(c_in, h, w, stages, n_stages) == 2 ? 2 : 0;
+    if (classes < 1 || classes > 16 || !stages || n_stages < 1) return 0;
+    for (int i = 0; i < n_stages; ++i)
+        if (!stages[i].d_w || !stages[i].d_bias) return 0;
+    if (compiled_chain(c_in, h, w, stages, n_stages) == 2) return 2;
+    return rt_plan(c_in, h, w, stages, n_stages, classes, nullptr, nullptr) ? 3 : 0;
 }
 
 int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, int n, int c_in, int h, int w,
@@ -636,19 +1085,30 @@ int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *s
     TH_REQUIRE(ctx && d_x && d_y && stages && head && n > 0, "th_conv_chain_head_fwd: null argument");
     TH_REQUIRE(head->d_w && head->d_targets && head->d_dl && head->d_rowstat, "th_conv_chain_head_fwd: the head needs d_w, d_targets, d_dl, d_rowstat");
     const int kind = th_conv_chain_head_supported(c_in, h, w, stages, n_stages, head->classes);
-    TH_REQUIRE(kind != 0, "th_conv_chain_head_fwd: no compiled chain + head for these stages (th_conv_chain_head_supported)");
-    ConvChainArgs a{};
-    a.x = d_x; a.y = d_y; a.cnt = nullptr; a.n = n;
-    for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
-    a.head = ChainHeadArgs{head->d_w, head->d_bias, head->d_targets, head->d_dl, head->d_rowstat, head->d_cbpart, head->d_tick,
-                           head->classes, CS_K, 64, 49, 1.0f / (float)n};
-    const int lds = CS_LDS * (int)sizeof(float);
-    if (head->classes <= 10) {
-        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((conv_chain_simple_kernel<true, 10>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+    TH_REQUIRE(kind != 0, "th_conv_chain_head_fwd: these stages do not run as a chain + head (th_conv_chain_head_supported)");
+    if (kind == 3) {
+        RtChainArgs ra{};
+        int lds_floats = 0;
+        TH_REQUIRE(rt_plan(c_in, h, w, stages, n_stages, head->classes, &ra, &lds_floats), "th_conv_chain_head_fwd: no plan");
+        const RtStage &ls = ra.st[n_stages - 1];
+        const int hw = (ls.s / 2) * (ls.s / 2);
+        ra.head = ChainHeadArgs{head->d_w, head->d_bias, head->d_targets, head->d_dl, head->d_rowstat, head->d_cbpart, head->d_tick,
+                                head->classes, ls.c_out * hw, ls.c_out, hw, 1.0f / (float)n};
+        rt_launch(ctx, ra, lds_floats, d_x, d_y, nullptr, n);
     } else {
-        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((conv_chain_simple_kernel<true, 16>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+        ConvChainArgs a{};
+        a.x = d_x; a.y = d_y; a.cnt = nullptr; a.n = n;
+        for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
+        a.head = ChainHeadArgs{head->d_w, head->d_bias, head->d_targets, head->d_dl, head->d_rowstat, head->d_cbpart, head->d_tick,
+                               head->classes, CS_K, 64, 49, 1.0f / (float)n};
+        const int lds = CS_LDS * (int)sizeof(float);
+        if (head->classes <= 10) {
+            (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((conv_chain_simple_kernel<true, 10>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+        } else {
+            (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((conv_chain_simple_kernel<true, 16>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+        }
     }
     t_last_conv_cfg[0] = kind; t_last_conv_cfg[1] = 7; t_last_conv_cfg[2] = 0;   // 7: a conv chain with the classifier rows
     t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;

@@ -605,14 +605,18 @@ Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
                 continue;
             }
         }
-        if (fuse && chain_fuse() && i + 1 < n_layers && PoolBiasScope::active() && x.shape().size() == 4 && x.shape()[1] == 1) {
+        if (fuse && chain_fuse() && i + 1 < n_layers && PoolBiasScope::active() && x.shape().size() == 4) {
             // Trainer steps: the whole run of Conv2dReLU(3x3, stride 1, pad 1) [+ MaxPool2d(2) | + global average pool] rows in front of the
             // classifier as ONE launch, when an instance is compiled for it (th_conv_chain_supported): the maps never leave the CU
             std::vector<ConvStage> stages;
-            const size_t j = conv_stages_at(i, n_layers, &stages);
-            if (stages.size() >= 2 && stages.back().post != TH_CHAIN_NONE && x.conv_chain_supported(stages)) {
+            conv_stages_at(i, n_layers, &stages);
+            // (a run that ends in a conv without a pool stops at its last pooled stage)
+            while (!stages.empty() && stages.back().post == TH_CHAIN_NONE) stages.pop_back();
+            size_t j2 = i;
+            for (const auto &st : stages) j2 += st.post == TH_CHAIN_NONE ? 1 : 2;
+            if (stages.size() >= 2 && x.conv_chain_supported(stages)) {   // (a single conv + pool keeps its own launch, below)
                 x = x.conv_chain(stages);
-                i = j - 1;
+                i = j2 - 1;
                 continue;
             }
         }

@@ -72,20 +72,19 @@ def _hip_layered(ctx, x, spec, params):
     return cur, cnt, hw
 
 
-def _hip_chain(ctx, x, spec, params, want_cnt=True):
+def _hip_chain(ctx, x, spec, params, want_cnt=True, want_kind=None):
     from taper_amd import hip
-    n = x.shape[0]
+    n, c0, hw = x.shape[0], x.shape[1], x.shape[2]
     bufs = [(ctx.upload(w), ctx.upload(b)) for w, b in params]
     stages, ns = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in zip(bufs, spec)])
-    kind = hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(stages, C.c_void_p), ns)
-    assert kind == (1 if spec is REFERENCE else 2)
-    hw = 28
+    kind = hip.hip.th_conv_chain_supported(c0, hw, hw, C.cast(stages, C.c_void_p), ns)
+    assert kind == (want_kind if want_kind is not None else (1 if spec is REFERENCE else 2)), kind
     for _, _, post in spec:
         hw = hw // 2 if post == 1 else (1 if post == 2 else hw)
     c_last = spec[-1][1]
     y = ctx.empty(n * c_last * hw * hw)
     cnt = ctx.empty(n * c_last) if spec[-1][2] == 2 and want_cnt else None
-    ctx.call("th_conv_chain_fwd", ctx.upload(x), C.cast(stages, C.c_void_p), ns, y, cnt, n, 1, 28, 28)
+    ctx.call("th_conv_chain_fwd", ctx.upload(x), C.cast(stages, C.c_void_p), ns, y, cnt, n, c0, x.shape[2], x.shape[2])
     ctx.sync()          # (the stage array and the uploads live until the launch has run)
     return y, cnt, hw, c_last
 
@@ -133,10 +132,10 @@ def test_chain_without_counts_and_unsupported_stages(ctx):
     y, cnt, hw, c_last = _hip_chain(ctx, x, REFERENCE, params, want_cnt=False)
     y2, _, _, _ = _hip_chain(ctx, x, REFERENCE, params, want_cnt=True)
     np.testing.assert_array_equal(ctx.download(y, (2, c_last)), ctx.download(y2, (2, c_last)))
-    # another channel count: no compiled chain -- the caller launches the layers one by one
+    # another channel count: no compiled instance -- the kernel that takes its stages as arguments (3)
     bufs = [(ctx.upload(w), ctx.upload(b)) for w, b in params]
     st, ns = hip.conv_stages([(bufs[0][0], bufs[0][1], 16, 1), (bufs[1][0], bufs[1][1], 64, 1)])
-    assert hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(st, C.c_void_p), ns) == 0
+    assert hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(st, C.c_void_p), ns) == 3
     st, ns = hip.conv_stages([(bufs[0][0], bufs[0][1], 32, 1), (bufs[1][0], bufs[1][1], 64, 1)])
     assert hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(st, C.c_void_p), ns) == 2
     assert hip.hip.th_conv_chain_supported(1, 32, 32, C.cast(st, C.c_void_p), ns) == 0
@@ -163,3 +162,131 @@ def test_chain_propagates_non_finite_pixels_like_the_layered_launches(ctx, name)
     np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
     np.testing.assert_array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
     # (ReLU turns NaN into 0 at every layer, so the planted values need not survive to the last stage: the comparison above is the point)
+
+
+# ---- the kernel that takes its stages as arguments (th_conv_chain_supported == 3) ------------------------------------------------------------
+@pytest.fixture
+def generic(ctx):
+    """the compiled instances switched off: their nets take the run-time-described kernel"""
+    from taper_amd import hip
+    hip.hip.th_debug_set_chain_generic(1)
+    yield
+    hip.hip.th_debug_set_chain_generic(0)
+
+
+@pytest.mark.parametrize("name", ["reference", "simple"])
+@pytest.mark.parametrize("n", [256, 5, 300])
+def test_generic_chain_is_bit_identical_to_the_compiled_instances(ctx, name, n):
+    """same per-output arithmetic (k order, bias after the sum, ReLU, strict-> maxima, plane sums): the run-time-described kernel gives the
+    compiled instances' bits on their own nets; 300 images: workgroups walk more than one image"""
+    from taper_amd import hip
+    spec = REFERENCE if name == "reference" else SIMPLE
+    params = _params(spec, 21)
+    x = _images(n, 5 + n)
+    y0, cnt0, hw, c_last = _hip_chain(ctx, x, spec, params)
+    hip.hip.th_debug_set_chain_generic(1)
+    try:
+        y1, cnt1, hw1, _ = _hip_chain(ctx, x, spec, params, want_kind=3)
+    finally:
+        hip.hip.th_debug_set_chain_generic(0)
+    assert hw == hw1
+    np.testing.assert_array_equal(ctx.download(y1, (n, c_last, hw, hw)), ctx.download(y0, (n, c_last, hw, hw)))
+    if cnt0 is not None:
+        np.testing.assert_array_equal(ctx.download(cnt1, (n, c_last)), ctx.download(cnt0, (n, c_last)))
+
+
+def _random_stage_list(rng):
+    """a random run of Conv2dReLU / MaxPool2d(2) / global-average stages on a 28 x 28 single-channel image"""
+    spec, c_in, hw = [], 1, 28
+    for i in range(int(rng.integers(1, 6))):
+        c_out = int(rng.choice([16, 32, 48, 64, 96, 128]))
+        post = 1 if (hw % 2 == 0 and rng.random() < 0.5) else 0
+        spec.append((c_in, c_out, post))
+        c_in, hw = c_out, hw // 2 if post == 1 else hw
+    last = spec[-1]
+    end = 2 if (hw % 2 == 1 or rng.random() < 0.5) else 1
+    spec[-1] = (last[0], last[1], end)
+    return spec
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_generic_chain_random_stage_lists_match_the_oracle(ctx, O, seed):
+    """random stage lists and batch sizes against the oracle's layer-by-layer tape ops (/root/reference/src/tensor.rs:1221-1285, 1391-1470,
+    1524-1660); lists whose maps do not fit the LDS must be refused (th_conv_chain_supported == 0), everything else must run"""
+    from taper_amd import hip
+    rng = np.random.default_rng(900 + seed)
+    spec = _random_stage_list(rng)
+    n = int(rng.choice([1, 2, 7, 33, 96, 257]))
+    params = _params(spec, 40 + seed)
+    bufs = [(ctx.upload(w), ctx.upload(b)) for w, b in params]
+    stages, ns = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in zip(bufs, spec)])
+    kind = hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(stages, C.c_void_p), ns)
+    # what must fit: a stage's input planes beside its output (unless one round of tiles lets the output overlay the input)
+    words, hw = 0, 28
+    for c_in, c_out, post in spec:
+        pad = lambda s: (s + 2) ** 2 + ((16 - ((s + 2) ** 2) % 32) + 32) % 32
+        out = c_out * (pad(hw) if post == 0 else hw * hw + ((4 - (hw * hw) % 8) + 8) % 8)
+        words = max(words, out, c_in * pad(hw))
+        hw = hw // 2 if post == 1 else hw
+    if kind == 0:
+        assert words > 40960 // 2, (spec, words)        # only lists with a big map may be refused
+        return
+    assert kind in (2, 3)
+    x = _images(n, seed)
+    ref, ref_cnt = _oracle_chain(O, x, spec, params)
+    y, cnt, hw, c_last = _hip_chain(ctx, x, spec, params, want_kind=kind)
+    got = ctx.download(y, (n, c_last, hw, hw))
+    np.testing.assert_allclose(got, ref.reshape(got.shape), rtol=RTOL, atol=1e-5 + RTOL * float(np.abs(ref).max()), err_msg=str(spec))
+    if cnt is not None:
+        off = np.abs(ctx.download(cnt, (n, c_last)) - ref_cnt)
+        assert off.max() <= 2 and (off > 0).mean() < 0.02, (spec, off.max(), (off > 0).mean())
+
+
+@pytest.mark.parametrize("c0,hw,spec", [(16, 14, [(16, 32, 0), (32, 64, 1)]), (32, 14, [(32, 32, 1), (32, 128, 2)]), (64, 7, [(64, 256, 2)]),
+                                        (1, 14, [(1, 16, 1), (16, 16, 2)]), (1, 28, [(1, 16, 1), (16, 16, 1), (16, 512, 2)])])
+def test_generic_chain_other_inputs(ctx, O, c0, hw, spec):
+    """inputs that are not a 28 x 28 single-channel image: 16 / 32 / 64 input channels, 14 x 14 and 7 x 7 maps, 16 and 512 output channels
+    (one channel tile; two rounds of tiles)"""
+    rng = np.random.default_rng(c0 * 100 + hw)
+    n = 9
+    params = _params(spec, c0 + hw)
+    x = rng.uniform(0, 1, (n, c0, hw, hw)).astype(np.float32)
+    ref, ref_cnt = _oracle_chain(O, x, spec, params)
+    y, cnt, hw_o, c_last = _hip_chain_general(ctx, x, spec, params)
+    got = ctx.download(y, (n, c_last, hw_o, hw_o))
+    np.testing.assert_allclose(got, ref.reshape(got.shape), rtol=RTOL, atol=1e-5 + RTOL * float(np.abs(ref).max()))
+
+
+def _hip_chain_general(ctx, x, spec, params):
+    from taper_amd import hip
+    n, c0, s0 = x.shape[0], x.shape[1], x.shape[2]
+    bufs = [(ctx.upload(w), ctx.upload(b)) for w, b in params]
+    stages, ns = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in zip(bufs, spec)])
+    assert hip.hip.th_conv_chain_supported(c0, s0, s0, C.cast(stages, C.c_void_p), ns) == 3
+    hw = s0
+    for _, _, post in spec:
+        hw = hw // 2 if post == 1 else (1 if post == 2 else hw)
+    c_last = spec[-1][1]
+    y = ctx.empty(n * c_last * hw * hw)
+    cnt = ctx.empty(n * c_last) if spec[-1][2] == 2 else None
+    ctx.call("th_conv_chain_fwd", ctx.upload(x), C.cast(stages, C.c_void_p), ns, y, cnt, n, c0, s0, s0)
+    ctx.sync()
+    return y, cnt, hw, c_last
+
+
+def test_generic_chain_refusals(ctx):
+    from taper_amd import hip
+    params = _params([(1, 32, 1), (32, 64, 1)], 1)
+    bufs = [(ctx.upload(w), ctx.upload(b)) for w, b in params]
+    f = hip.hip.th_conv_chain_supported
+    st = lambda *rows: tuple(x if i == 0 else x for i, x in enumerate(hip.conv_stages([(bufs[0][0], bufs[0][1], c, p) for c, p in rows])))
+    for rows, c0, hw, want in [([(24, 1), (64, 1)], 1, 28, 0),        # 24 output channels: not whole 16-channel tiles
+                               ([(32, 1), (64, 0)], 1, 28, 0),        # ends in a conv without a pool: nothing to write
+                               ([(32, 2), (64, 1)], 1, 28, 0),        # the global average is not the last stage
+                               ([(32, 1), (64, 1), (64, 1)], 1, 28, 0),   # 7 x 7 cannot be pooled 2 x 2
+                               ([(64, 0), (64, 1)], 1, 28, 0),        # 64 planes of 30 x 30 do not fit beside anything
+                               ([(32, 1), (64, 1)], 3, 28, 0),        # 3 input channels
+                               ([(32, 1), (64, 1)], 1, 32, 0),        # 32 x 32 maps are not compiled in
+                               ([(16, 1), (32, 1)], 1, 28, 3)]:
+        arr, ns = st(*rows)
+        assert f(c0, hw, hw, C.cast(arr, C.c_void_p), ns) == want, rows

@@ -38,9 +38,17 @@ class ChainHead(C.Structure):
                 ("d_rowstat", C.c_void_p), ("d_cbpart", C.c_void_p), ("d_tick", C.c_void_p)]
 
 
-def _model(rng, classes):
+def _k_of(spec):
+    hw = 28
+    for _, _, post in spec:
+        hw = hw // 2 if post == 1 else hw
+    return spec[-1][1] * hw * hw, spec[-1][1], hw
+
+
+def _model(rng, classes, spec=SIMPLE):
+    K = _k_of(spec)[0]
     conv = []
-    for c_in, c_out, _ in SIMPLE:
+    for c_in, c_out, _ in spec:
         bound = np.sqrt(6.0 / (c_in * 9))
         conv.append((rng.uniform(-bound, bound, (c_out, c_in, 3, 3)).astype(np.float32), rng.uniform(-0.1, 0.1, c_out).astype(np.float32)))
     w = (rng.uniform(-1, 1, (classes, K)) * np.sqrt(2.0 / K)).astype(np.float32)
@@ -48,7 +56,7 @@ def _model(rng, classes):
     return conv, w, b
 
 
-def _oracle_step(O, conv, w, b, x, y):
+def _oracle_step(O, conv, w, b, x, y, spec=SIMPLE):
     """the oracle's tape over conv rows -> flatten -> linear -> cross-entropy; -> everything the two launches produce"""
     O.Tape.reset()
     cw = [O.Tensor(a).requires_grad() for a, _ in conv]
@@ -56,7 +64,9 @@ def _oracle_step(O, conv, w, b, x, y):
     wt, bt = O.Tensor(w).requires_grad(), O.Tensor(b).requires_grad()
     t = O.Tensor(x)
     for i in range(len(conv)):
-        t = t.conv2d_relu(cw[i], cb[i], (1, 1), (1, 1), (1, 1)).max_pool2d((2, 2), (2, 2), (0, 0))
+        t = t.conv2d_relu(cw[i], cb[i], (1, 1), (1, 1), (1, 1))
+        if spec[i][2] == 1:
+            t = t.max_pool2d((2, 2), (2, 2), (0, 0))
     pooled = t.data().copy()
     logits = t.flatten(1).matmul(wt.transpose()).add_broadcast(bt)
     lg = logits.data().copy()
@@ -68,29 +78,30 @@ def _oracle_step(O, conv, w, b, x, y):
     nll = -logp[np.arange(n), y.astype(int)]
     hit = (lg.argmax(axis=1) == y.astype(int)).astype(np.float32)
     dl = (np.exp(logp) - np.eye(lg.shape[1], dtype=np.float32)[y.astype(int)]) / n
-    assert cw[0].grad() is None and cw[1].grad() is None and cb[0].grad() is None      # Q2: the tape is cut at every conv
-    return dict(pooled=pooled, logits=lg, loss=float(loss.data()[0]), nll=nll, hit=hit, dl=dl, dw=wt.grad(), db=bt.grad(), gcb=cb[1].grad())
+    assert all(c.grad() is None for c in cw) and all(c.grad() is None for c in cb[:-1])      # Q2: the tape is cut at every conv
+    return dict(pooled=pooled, logits=lg, loss=float(loss.data()[0]), nll=nll, hit=hit, dl=dl, dw=wt.grad(), db=bt.grad(), gcb=cb[-1].grad())
 
 
-def _launch(ctx, conv, wd, bd, x, y, classes, want_cb=True, tick=None, fuses=(None, None, None)):
+def _launch(ctx, conv, wd, bd, x, y, classes, want_cb=True, tick=None, fuses=(None, None, None), spec=SIMPLE, kind=2):
     from taper_amd import hip
     n = x.shape[0]
+    K, c_last, hw = _k_of(spec)
     bufs = [(ctx.upload(cw), ctx.upload(cb)) for cw, cb in conv]
-    stages, ns = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in zip(bufs, SIMPLE)])
-    assert hip.hip.th_conv_chain_head_supported(1, 28, 28, C.cast(stages, C.c_void_p), ns, classes) == 2
+    stages, ns = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in zip(bufs, spec)])
+    assert hip.hip.th_conv_chain_head_supported(1, 28, 28, C.cast(stages, C.c_void_p), ns, classes) == kind
     ymap, dl, rs = ctx.empty(n * K), ctx.empty(n * 16), ctx.empty(n * 2)
-    cbp = ctx.empty(n * 64) if want_cb else None
+    cbp = ctx.empty(n * c_last) if want_cb else None
     yd = ctx.upload(y)
     head = ChainHead(int(wd), int(bd) if bd is not None else None, int(yd), classes, int(dl), int(rs), int(cbp) if cbp is not None else None,
                      int(tick) if tick is not None else None)
     ctx.call("th_conv_chain_head_fwd", ctx.upload(x), C.cast(stages, C.c_void_p), ns, ymap, n, 1, 28, 28, C.byref(head))
-    dw, db, gcb, loss, nc = ctx.empty(classes * K), ctx.empty(classes), (ctx.empty(64) if want_cb else None), ctx.empty(1), ctx.empty(1)
+    dw, db, gcb, loss, nc = ctx.empty(classes * K), ctx.empty(classes), (ctx.empty(c_last) if want_cb else None), ctx.empty(1), ctx.empty(1)
     f = [C.byref(v) if v is not None else None for v in fuses]
-    ctx.call("th_wide_head_grads", ymap, dl, rs, cbp, n, K, classes, 64, dw, db, gcb, loss, nc, None, 0, None, 0, f[0], f[1], f[2])
+    ctx.call("th_wide_head_grads", ymap, dl, rs, cbp, n, K, classes, c_last, dw, db, gcb, loss, nc, None, 0, None, 0, f[0], f[1], f[2])
     ctx.sync()
-    return dict(pooled=ctx.download(ymap, (n, 64, 7, 7)), dl=ctx.download(dl, (n, 16)), rs=ctx.download(rs, (n, 2)),
-                cbp=ctx.download(cbp, (n, 64)) if want_cb else None, dw=ctx.download(dw, (classes, K)), db=ctx.download(db, classes),
-                gcb=ctx.download(gcb, 64) if want_cb else None, loss=float(ctx.download(loss, 1)[0]), nc=float(ctx.download(nc, 1)[0]))
+    return dict(pooled=ctx.download(ymap, (n, c_last, hw, hw)), dl=ctx.download(dl, (n, 16)), rs=ctx.download(rs, (n, 2)),
+                cbp=ctx.download(cbp, (n, c_last)) if want_cb else None, dw=ctx.download(dw, (classes, K)), db=ctx.download(db, classes),
+                gcb=ctx.download(gcb, c_last) if want_cb else None, loss=float(ctx.download(loss, 1)[0]), nc=float(ctx.download(nc, 1)[0]))
 
 
 def _close_with_mask_flips(got, ref, dx_max, what):
@@ -128,6 +139,46 @@ def test_chain_head_launches_match_the_oracle_tape(ctx, O, n, classes):
     dx_max = float(np.abs(ref["dl"] @ w).max())
     _close_with_mask_flips(got["gcb"], ref["gcb"], dx_max, "conv bias gradient")
     _close_with_mask_flips(got["cbp"].sum(axis=0), ref["gcb"], dx_max, "per-image channel sums")
+
+
+GENERIC_NETS = [[(1, 32, 1), (32, 64, 1)],                  # the simple CNN's front on the run-time-described kernel (compiled instances off)
+                [(1, 16, 1), (16, 32, 1)],                  # k = 32 * 49
+                [(1, 16, 0), (16, 32, 1), (32, 48, 1)],     # three stages, k = 48 * 49
+                [(1, 32, 1), (32, 16, 0), (16, 16, 0)] ]    # ends in a conv without a pool: no chain + head (0)
+
+
+@pytest.mark.parametrize("net", range(4))
+@pytest.mark.parametrize("n,classes", [(256, 10), (37, 16), (300, 3)])
+def test_chain_head_on_the_run_time_described_kernel(ctx, O, net, n, classes):
+    """th_conv_chain_head_fwd where no instance is compiled: the kernel that takes its stages as arguments runs the same classifier rows"""
+    from taper_amd import hip
+    spec = GENERIC_NETS[net]
+    rng = np.random.default_rng(77 * net + n + classes)
+    hip.hip.th_debug_set_chain_generic(1)
+    try:
+        if net == 3:
+            conv, w, b = _model(rng, classes, spec[:1])
+            bufs = [(ctx.upload(np.zeros((co, ci, 3, 3), np.float32)), ctx.upload(np.zeros(co, np.float32))) for ci, co, _ in spec]
+            stages, ns = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in zip(bufs, spec)])
+            assert hip.hip.th_conv_chain_head_supported(1, 28, 28, C.cast(stages, C.c_void_p), ns, classes) == 0
+            return
+        conv, w, b = _model(rng, classes, spec)
+        x = rng.integers(0, 256, (n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)
+        y = rng.integers(0, classes, n).astype(np.float32)
+        ref = _oracle_step(O, conv, w, b, x, y, spec)
+        got = _launch(ctx, conv, ctx.upload(w), ctx.upload(b), x, y, classes, spec=spec, kind=3)
+    finally:
+        hip.hip.th_debug_set_chain_generic(0)
+    _close(got["pooled"], ref["pooled"], "pooled map")
+    _close(got["dl"][:, :classes], ref["dl"], "dlogits")
+    assert not got["dl"][:, classes:].any()
+    _close(got["rs"][:, 0], ref["nll"], "nll per row")
+    assert np.abs(got["rs"][:, 1] - ref["hit"]).sum() <= max(1, n // 256)
+    assert got["loss"] == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
+    _close(got["dw"], ref["dw"], "dW")
+    _close(got["db"], ref["db"], "db")
+    dx_max = float(np.abs(ref["dl"] @ w).max())
+    _close_with_mask_flips(got["gcb"], ref["gcb"], dx_max, "conv bias gradient")
 
 
 def test_chain_head_pooled_map_is_bit_identical_to_the_plain_chain(ctx):
@@ -252,3 +303,49 @@ def test_simple_cnn_trainer_steps_take_the_two_launch_form_and_match_the_oracle(
     np.testing.assert_allclose(losses, l2, rtol=1e-5, atol=1e-6)
     for i, (a, b) in enumerate(zip(params, p2)):
         np.testing.assert_allclose(a, b, rtol=RTOL, atol=lr * 2e-2, err_msg=f"param {i}")
+
+
+def _custom_cnn(rng, kind):
+    c, lin = backends._conv, backends._lin
+    pool = dict(kind="maxpool", kernel=(2, 2), stride=(2, 2))
+    if kind == "pool_head":          # conv rows end in a pooled map, Flatten, Linear: generic chain + classifier rows, two launches
+        return [c(rng, 1, 16), pool, c(rng, 16, 32), pool, dict(kind="flatten", start_dim=1), lin(rng, 32 * 49, 10)]
+    if kind == "pool_mlp":           # ... followed by Linear + ReLU + Linear: generic chain, then the two-launch MLP tail
+        return [c(rng, 1, 16), c(rng, 16, 16), pool, c(rng, 16, 48), pool, dict(kind="flatten", start_dim=1), lin(rng, 48 * 49, 64),
+                dict(kind="relu"), lin(rng, 64, 10)]
+    # global average + three-layer classifier, other widths than the reference CNN's
+    return [c(rng, 1, 16), pool, c(rng, 16, 32), c(rng, 32, 64), pool, c(rng, 64, 96), dict(kind="adaptive_avgpool", out=(1, 1)),
+            dict(kind="flatten", start_dim=1), lin(rng, 96, 64), dict(kind="relu"), lin(rng, 64, 32), dict(kind="relu"), lin(rng, 32, 10)]
+
+
+@pytest.mark.parametrize("kind,want_dma", [("pool_head", 7), ("pool_mlp", 6), ("gap_mlp3", 6)])
+@pytest.mark.parametrize("batch", [256, 100])
+def test_other_cnns_take_the_run_time_described_chain_and_match_the_oracle(kind, want_dma, batch):
+    """Sequentials that are neither of the two compiled nets: the Trainer's captured step launches their conv rows as ONE kernel all the same
+    (th_conv_chain_supported == 3) -- 3 Adam steps against the oracle's training loop"""
+    import taper_amd as T
+    from tests import margins
+    from tests.test_gpu_full_size import last_conv_config_host
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(batch + len(kind))
+    steps, lr = 3, 1e-2
+    spec = backends.nonzero_biases(_custom_cnn(rng, kind), rng)
+    x, y = backends.mnist_like(rng, steps * batch)
+    om = Orc.sequential(spec)
+    oopt = Orc.m.Adam(om.parameters(), lr, None, None, 1e-4)
+    ref = [om.train_step(oopt, x[s * batch:(s + 1) * batch], y[s * batch:(s + 1) * batch], (batch, 1, 28, 28)) for s in range(steps)]
+    hm = H.sequential(spec)
+    opt = T.Adam(hm.parameters(), lr, None, None, 1e-4)
+    tr = T.Trainer(hm, opt, sample_shape=(1, 28, 28))
+    ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False), T.Trainer.GRAPH)
+    cfg = last_conv_config_host()
+    assert cfg["dma"] == want_dma and cfg["ct"] == 3, cfg          # a conv chain, id 3: the kernel that takes its stages as arguments
+    assert opt.t() == steps
+    tag = f"custom_cnn_{kind}_b{batch}_3_adam_steps"
+    margins.record(tag, "losses", ep["losses"], [r["loss"] for r in ref])
+    np.testing.assert_allclose(ep["losses"], [r["loss"] for r in ref], rtol=0, atol=1e-5 * max(abs(r["loss"]) for r in ref))
+    assert np.abs(np.asarray(ep["ncorrect"]) - np.asarray([r["acc"] * batch for r in ref])).max() <= 1.5
+    for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+        m = margins.record(tag, f"param{i}", hp.data(), op.data(), lr=lr)
+        assert m["err_over_lr"] <= 2e-2, (i, m)
