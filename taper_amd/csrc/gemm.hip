@@ -417,12 +417,19 @@ constexpr int BM = 128, BN = 128, BK = 32;
 // tile -- for outputs too small to give the chip enough 128-tiles: tall-skinny MLP products at batch 512..8192).
 template <int TS>
 struct TileGeo {
-    static constexpr int LD_KC = BK + 1;   // [mn][k] image, odd stride: conflict-free ds_read_b32 / ds_write_b32
-    static constexpr int LD_MC = TS;       // [k][mn] image
-    static constexpr int TILE_KC = TS * LD_KC, TILE_MC = BK * LD_MC;
-    static constexpr int TILE_MAX = TILE_KC > TILE_MC ? TILE_KC : TILE_MC;
+    // LDS image of an operand tile: [mn][32 k], 128-byte rows, the eight 16-byte k quads of row r stored at quad ^ ((r >> 1) & 7).
+    //  * a lane reads the operands of FOUR k-steps with one ds_read_b128 (the 16 rows of a b128 lane group -- {0-3, 12-15, 20-27} and its
+    //    siblings -- map to 16 distinct 16-byte slots of the 256-byte bank row: conflict-free; MI355X_MICROARCH.md, LDS);
+    //  * a 128-byte pitch is what LDS-DMA (`buffer_load ... lds`: lane l of a wave lands at base + 16 l) can fill: a k-contiguous operand
+    //    goes global -> LDS without staging registers or ds_write -- the lane just FETCHES quad (l & 7) ^ swizzle of its row.
+    // An m/n-contiguous operand is staged AS IT LIES in memory -- image [32 k][TS mn], 4 TS-byte rows -- and read with ds_read_b32 (lanes on
+    // consecutive m / n: conflict-free; the k of a lane's four operands differ by whole rows: immediates): no transpose anywhere, and
+    // LDS-DMA fills this image too (a k row is a whole number of 16-byte lanes).
+    static constexpr int LD = BK;          // floats per row of the [mn][k] image
+    static constexpr int TILE_MAX = TS * LD;
     static constexpr int R = TS / 32;      // float4 per thread per operand per tile
     static constexpr int QPR = TS / 4;     // float4 quads per k row of an m/n-contiguous tile
+    __host__ __device__ static constexpr int swz(int row) { return (row >> 1) & 7; }
 };
 
 // Each thread stages 4 R floats per operand per tile, as R float4.
@@ -475,36 +482,67 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ P, long rs_m
 
 template <bool KC, int TS>
 __device__ __forceinline__ void store_tile(float *__restrict__ S, int t, const float4 (&reg)[TileGeo<TS>::R]) {
-    constexpr int R = TileGeo<TS>::R, QPR = TileGeo<TS>::QPR;
+    using G = TileGeo<TS>;
+    constexpr int R = G::R, QPR = G::QPR, LD = G::LD;
+    static_assert(R == 4 || R == 2, "a whole or a half k quad per thread");
+    if (KC) {
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        if (KC) {
-            float *s = S + ((t >> 3) + 32 * j) * TileGeo<TS>::LD_KC + (t & 7) * 4;
-            s[0] = reg[j].x; s[1] = reg[j].y; s[2] = reg[j].z; s[3] = reg[j].w;
-        } else {
-            // an m/n-contiguous source is TRANSPOSED on its way into LDS: the quad (k row, 4 consecutive mn) lands in the same
-            // [mn][k] image the k-contiguous case builds, so the MFMA loop below is one code path for all four layouts and the
-            // separate transpose launch in front of deep NN / TN / TT products goes away (4-way bank conflict on these 4 writes
-            // per quad: ~2x on 16 ds_write_b32 per tile, against 4096 cycles of MFMA per tile and wave)
-            float *s = S + ((t % QPR) * 4) * TileGeo<TS>::LD_KC + t / QPR + (256 / QPR) * j;
-            s[0] = reg[j].x; s[TileGeo<TS>::LD_KC] = reg[j].y; s[2 * TileGeo<TS>::LD_KC] = reg[j].z; s[3 * TileGeo<TS>::LD_KC] = reg[j].w;
+        for (int j = 0; j < R; ++j) {
+            const int row = (t >> 3) + 32 * j;
+            *reinterpret_cast<float4 *>(S + row * LD + (((t & 7) ^ G::swz(row)) << 2)) = reg[j];
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) *reinterpret_cast<float4 *>(S + (t / QPR + (256 / QPR) * j) * TS + (t % QPR) * 4) = reg[j];
     }
 }
 
-template <bool KC, int TS>
-__device__ __forceinline__ float frag(const float *__restrict__ S, int mn, int kx) {
-    return S[mn * TileGeo<TS>::LD_KC + kx];   // every layout is staged as the [mn][k] image (store_tile)
+// LDS-DMA fill of an operand tile (whole tiles only): wave w, instruction j writes the 1 KB at float offset 256 (4 j + w) of the image with
+// one `buffer_load_dwordx4 ... lds` (lane l lands at + 16 l bytes).  [mn][k] image: rows 8 (4 j + w) .. + 7, lane l fetches quad
+// (l & 7) ^ swizzle(row) of row + (l >> 3).  [k][mn] image: the image IS the memory order, 16-byte unit u = 64 (4 j + w) + l is k row
+// u / (TS / 4), m / n quad u % (TS / 4).
+template <int TS>
+struct DmaPlan { int voff[TileGeo<TS>::R]; };
+template <int TS, bool KC>
+__device__ __forceinline__ DmaPlan<TS> dma_plan(long ld_floats, int lane, int wave) {
+    DmaPlan<TS> p;
+#pragma unroll
+    for (int j = 0; j < TileGeo<TS>::R; ++j) {
+        if (KC) {
+            const int row = 8 * (4 * j + wave) + (lane >> 3);
+            p.voff[j] = (int)(((long)row * ld_floats + (((lane & 7) ^ TileGeo<TS>::swz(row)) << 2)) * 4);
+        } else {
+            const int u = 64 * (4 * j + wave) + lane;
+            p.voff[j] = (int)(((long)(u / (TS / 4)) * ld_floats + (u % (TS / 4)) * 4) * 4);
+        }
+    }
+    return p;
 }
+// KC: element (mn, k) at P[mn ld + k]; MC: at P[k ld + mn]
+template <int TS, bool KC>
+__device__ __forceinline__ void dma_tile(const float *__restrict__ P, long ld_floats, int mn0, int k0, float *S, const DmaPlan<TS> &p, int wave) {
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    // the descriptor starts at the tile (uniform values only): offsets stay far below 2^31 whatever the matrix size; whole tiles: no range to enforce
+    const float *base = KC ? P + (long)mn0 * ld_floats + k0 : P + (long)k0 * ld_floats + mn0;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TileGeo<TS>::R; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(S + 256 * (4 * j + wave)), 16, p.voff[j], 0, 0, 0);
+}
+
+#ifdef TH_PROFILE
+__device__ long long g_gemm_prof[4];   // workgroup 0: wall clock (100 MHz) and shader clock at entry and exit -- the clock the product ran at
+#endif
 
 template <int TS, bool A_KC, bool B_KC, bool GUARD>
 __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A, const float *__restrict__ B,
                                                      float *__restrict__ C, int m, int n, int k,
                                                      long a_rs, long a_cs, long b_rs, long b_cs,
                                                      int tiles_m, int tiles_n, Epilogue ep, int kslice,
-                                                     float *__restrict__ partial, int vec) {
+                                                     float *__restrict__ partial, int vec, int raster) {
     // blockIdx.y = K slice [y*kslice, (y+1)*kslice): with `partial` set every slice writes its raw
     // accumulators to partial[y][m*n] and splitk_reduce applies the epilogue in fixed slice order
+#if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TMAX = TileGeo<TS>::TILE_MAX, R = TileGeo<TS>::R, WS = TS / 2, NS = WS / 32;
     // LDS: As[2] then Bs[2], TMAX floats each
@@ -516,11 +554,24 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
     const int bid = blockIdx.x;
     const int xcd = bid % kNumXCD, q = nwg / kNumXCD, rmd = nwg % kNumXCD;
     const int tile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + bid / kNumXCD;
-    // within the chunk walk column-major in groups of 8 rows for panel reuse
-    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    // Within the list the tiles come in GROUPS of 8 tile rows, column-major inside a group: the 64 tiles an XCD has in flight (32 CUs x 2
+    // workgroups) then form an 8 x 8 block -- every A / B panel it fetches into its L2 serves 8 tiles -- instead of two whole columns of
+    // tiles_m rows, where each A panel served 2 (4096^3 NT: 2.2 GB through the fabric for 0.2 GB of operands).  raster < 0: the r02 order.
+    int tm, tn;
+    if (raster > 0) {
+        const int grp = tile / (raster * tiles_n), first = grp * raster, gh = min(raster, tiles_m - first), in = tile - grp * raster * tiles_n;
+        tm = first + in % gh;
+        tn = in / gh;
+    } else {
+        tm = tile % tiles_m;
+        tn = tile / tiles_m;
+    }
     const int row0 = tm * TS, col0 = tn * TS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef TH_PROFILE
+    if (bid == 0 && blockIdx.y == 0 && t == 0) { g_gemm_prof[0] = wall_clock64(); g_gemm_prof[1] = clock64(); }
+#endif
     const int wm = (wave >> 1) * WS, wn = (wave & 1) * WS;  // wave's WS x WS sub-tile
     const int li = lane & 31, lk = lane >> 5;
 
@@ -532,43 +583,98 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float4 ra[R], rb[R];
+    // operand staging: whole-tile launches bring both operands global -> LDS by LDS-DMA (no staging registers, no ds_write, no transpose);
+    // ragged shapes go through registers (clamped loads, zero fill) into the same images
+    constexpr bool A_DMA = !GUARD, B_DMA = !GUARD;
+    float4 ra[A_DMA ? 1 : R], rb[B_DMA ? 1 : R];
     const int kbeg = blockIdx.y * kslice, kend = min(k, kbeg + kslice);
     const int nt = (kend - kbeg + BK - 1) / BK;
+    DmaPlan<TS> pa{}, pb{};
+    if constexpr (A_DMA) pa = dma_plan<TS, A_KC>(A_KC ? a_rs : a_cs, lane, wave);
+    if constexpr (B_DMA) pb = dma_plan<TS, B_KC>(B_KC ? b_cs : b_rs, lane, wave);
     // element (i,k) of op(A) at A[i*a_rs + k*a_cs]; (k,j) of op(B) at B[k*b_rs + j*b_cs]
-    load_tile<A_KC, GUARD, TS>(A, a_rs, a_cs, row0, kbeg, m, kend, t, ra, vec);
-    load_tile<B_KC, GUARD, TS>(B, b_cs, b_rs, col0, kbeg, n, kend, t, rb, vec);
-    store_tile<A_KC, TS>(smem, t, ra);
-    store_tile<B_KC, TS>(smem + 2 * TMAX, t, rb);
+    auto fetch = [&](int k0, int stage) {
+        if constexpr (A_DMA) dma_tile<TS, A_KC>(A, A_KC ? a_rs : a_cs, row0, k0, smem + stage * TMAX, pa, wave);
+        else load_tile<A_KC, GUARD, TS>(A, a_rs, a_cs, row0, k0, m, kend, t, ra, vec);
+        if constexpr (B_DMA) dma_tile<TS, B_KC>(B, B_KC ? b_cs : b_rs, col0, k0, smem + (2 + stage) * TMAX, pb, wave);
+        else load_tile<B_KC, GUARD, TS>(B, b_cs, b_rs, col0, k0, n, kend, t, rb, vec);
+    };
+    auto stash = [&](int stage) {
+        if constexpr (!A_DMA) store_tile<A_KC, TS>(smem + stage * TMAX, t, ra);
+        if constexpr (!B_DMA) store_tile<B_KC, TS>(smem + (2 + stage) * TMAX, t, rb);
+        if constexpr (A_DMA || B_DMA) __builtin_amdgcn_s_waitcnt(0);   // the DMA writes of this wave have landed (the compiler does not track them)
+    };
+    fetch(kbeg, 0);
+    stash(0);
     __syncthreads();
+
+    // this lane's LDS addresses.  [mn][k] image: row (wave sub-tile + 32 i + li), k quad 2 r + lk of round r, swizzled -- the quads of rounds
+    // r = 0..3 differ from quad lk by an XOR of r << 1 on the quad index, r << 3 on the float offset.  [k][mn] image: k row 4 lk, column row;
+    // the four operands of round r lie (8 r + e) rows on.
+    int ao[NS], bo[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int ar = wm + 32 * i + li, br = wn + 32 * i + li;
+        ao[i] = A_KC ? ar * TileGeo<TS>::LD + ((lk ^ TileGeo<TS>::swz(ar)) << 2) : 4 * lk * TS + ar;
+        bo[i] = B_KC ? br * TileGeo<TS>::LD + ((lk ^ TileGeo<TS>::swz(br)) << 2) : 4 * lk * TS + br;
+    }
 
     for (int it = 0; it < nt; ++it) {
         const int cur = it & 1;
-        if (it + 1 < nt) {
-            load_tile<A_KC, GUARD, TS>(A, a_rs, a_cs, row0, kbeg + (it + 1) * BK, m, kend, t, ra, vec);
-            load_tile<B_KC, GUARD, TS>(B, b_cs, b_rs, col0, kbeg + (it + 1) * BK, n, kend, t, rb, vec);
-        }
+#ifndef GEMM_PROBE_NOLOAD   /* timing probes (wrong results): tools/prof_gemm_probes.sh */
+        if (it + 1 < nt) fetch(kbeg + (it + 1) * BK, cur ^ 1);
+#endif
         const float *as = smem + cur * TMAX, *bs = smem + (2 + cur) * TMAX;
+        // eight k per round: lane half lk holds k = 8 r + 4 lk + e, e = 0..3, of its row -- MFMA e of round r contracts k = {8 r + e,
+        // 8 r + 4 + e} (a permutation of the k order inside the tile; fp32 sums within tolerance).  The operands of round r + 1 are
+        // requested before the MFMAs of round r and pinned there.
+        float4 af[2][NS], bf[2][NS];
+#ifdef GEMM_PROBE_NOREAD
+#define TH_GEMM_REQ(SET, RR)                                                          \
+    _Pragma("unroll") for (int i = 0; i < NS; ++i) {                                  \
+        af[SET][i] = make_float4((float)(RR + it), 1.f, 2.f, 3.f);                    \
+        bf[SET][i] = make_float4(1.f, (float)(RR + i), 2.f, 3.f);                     \
+    }
+#else
+#define TH_GEMM_FRAG(KC, S, O, RR)                                                                                                 \
+    ((KC) ? *reinterpret_cast<const float4 *>((S) + ((O) ^ ((RR) << 3)))                                                           \
+          : make_float4((S)[(O) + (8 * (RR)) * TS], (S)[(O) + (8 * (RR) + 1) * TS], (S)[(O) + (8 * (RR) + 2) * TS], (S)[(O) + (8 * (RR) + 3) * TS]))
+#define TH_GEMM_REQ(SET, RR)                                                          \
+    _Pragma("unroll") for (int i = 0; i < NS; ++i) {                                  \
+        af[SET][i] = TH_GEMM_FRAG(A_KC, as, ao[i], RR);                               \
+        bf[SET][i] = TH_GEMM_FRAG(B_KC, bs, bo[i], RR);                               \
+    }
+#endif
+#define TH_GEMM_MFMA(CS, E)                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NS; ++i)                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NS; ++j)                                                                             \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CS][i].E, bf[CS][j].E, acc[i][j], 0, 0, 0);
+        TH_GEMM_REQ(0, 0)
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[NS], bf[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                af[i] = frag<A_KC, TS>(as, wm + 32 * i + li, kk + lk);
-                bf[i] = frag<B_KC, TS>(bs, wn + 32 * i + li, kk + lk);
-            }
-#pragma unroll
-            for (int i = 0; i < NS; ++i)
-#pragma unroll
-                for (int j = 0; j < NS; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int r = 0; r < BK / 8; ++r) {
+            const int cs = r & 1;
+            if (r + 1 < BK / 8) { TH_GEMM_REQ(cs ^ 1, r + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            TH_GEMM_MFMA(cs, x)
+            TH_GEMM_MFMA(cs, y)
+            TH_GEMM_MFMA(cs, z)
+            TH_GEMM_MFMA(cs, w)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (it + 1 < nt) {
-            store_tile<A_KC, TS>(smem + (cur ^ 1) * TMAX, t, ra);
-            store_tile<B_KC, TS>(smem + (2 + (cur ^ 1)) * TMAX, t, rb);
-        }
+#undef TH_GEMM_MFMA
+#undef TH_GEMM_REQ
+#undef TH_GEMM_FRAG
+#ifndef GEMM_PROBE_NOSTORE
+        if (it + 1 < nt) stash(cur ^ 1);
+#endif
+#ifndef GEMM_PROBE_NOSYNC
         __syncthreads();
+#endif
     }
 
+#ifdef TH_PROFILE
+    if (bid == 0 && blockIdx.y == 0 && t == 0) { g_gemm_prof[2] = wall_clock64(); g_gemm_prof[3] = clock64(); }
+#endif
     // epilogue.  C/D map of 32x32x2: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
 #pragma unroll
     for (int i = 0; i < NS; ++i)
@@ -589,6 +695,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
                 }
             }
         }
+#endif
 }
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -683,6 +790,8 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
     // a fused Adam update belongs to the pass that completes the gradient
     Epilogue kep = ep;
     kep.adam.p = nullptr;
+    // tile order: groups of 8 tile rows (TAPER_GEMM_RASTER = n: groups of n; 0: r02's whole columns)
+    static const int raster = [] { const char *e = getenv("TAPER_GEMM_RASTER"); return e ? atoi(e) : 8; }();
     if (exact) {
         auto kern = sgemm_tile<TS, A_KC, B_KC, false>;
         static bool attr_set = false;
@@ -691,7 +800,7 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
             attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
-                           b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, 1);
+                           b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, 1, raster);
     } else {
         auto kern = sgemm_tile<TS, A_KC, B_KC, true>;
         static bool attr_set = false;
@@ -700,7 +809,7 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
             attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
-                           b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, vec ? 1 : 0);
+                           b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, vec ? 1 : 0, raster);
     }
     TH_LAUNCH_CHECK();
     if (kz > 1) {
@@ -858,6 +967,14 @@ int linear_fwd_partials(th_ctx *ctx, const float *x, const float *w, int m, int 
 using namespace th;
 
 extern "C" {
+
+#ifdef TH_PROFILE
+int th_debug_gemm_prof(th_ctx *ctx, long long *h_out4) {
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out4, HIP_SYMBOL(th::g_gemm_prof), 4 * sizeof(long long)));
+    return 0;
+}
+#endif
 
 int th_sgemm(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, float alpha, const float *d_a,
              const float *d_b, float beta, float *d_c) {

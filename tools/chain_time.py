@@ -58,4 +58,8 @@ for name, spec in (("reference", REFERENCE), ("simple", SIMPLE)):
     for c_in, c_out, post in spec:
         flops += 2 * n * hw * hw * c_out * c_in * 9
         hw = hw // 2 if post == 1 else hw
-    print(f"{name}: chain {t_chain:.1f} us ({flops / t_chain * 1e-6:.1f} TF), layered {t_lay:.1f} us (eager launches back to back)")
+    hip.hip.th_debug_set_chain_generic(1)     # the same net through the kernel that takes its stages as arguments
+    t_rt = timed(lambda: ctx.call("th_conv_chain_fwd", x, sp, ns, y, cnt, n, 1, 28, 28))
+    hip.hip.th_debug_set_chain_generic(0)
+    print(f"{name} batch {n}: compiled chain {t_chain:.1f} us ({flops / t_chain * 1e-6:.1f} TF), run-time-described chain {t_rt:.1f} us "
+          f"({flops / t_rt * 1e-6:.1f} TF), layered {t_lay:.1f} us (eager launches back to back)")
