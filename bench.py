@@ -281,7 +281,7 @@ def pmc_traffic(workload, kernel):
     for exact in (True, False):      # the same template instance first (the trace of the default run holds other workloads' instances too)
         for name, rec in kernels.items():
             if (kernel in name) if exact else (kernel.split("<")[0] + "<" in name):
-                return rec["traffic_bytes_per_launch"], f"profiles/{files[-1].name}"
+                return rec["traffic_bytes_per_launch"], f"profiles/{files[-1].name} (a committed rocprofv3 --pmc pass of this command; NOT measured in this run)"
     return None, None
 
 

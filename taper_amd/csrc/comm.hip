@@ -90,7 +90,7 @@ __device__ __forceinline__ bool p2p_wait_all(const P2PDev &c, int word0, uint32_
     if (threadIdx.x < (unsigned)c.n_ranks) {
         const uint32_t *slot = c.flags[c.rank] + word0 + threadIdx.x;
         const long t0 = wall_clock64();
-        while ((int32_t)(__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
+        while ((int32_t)(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) {
             if (wall_clock64() - t0 > c.spin_ticks) {
                 __hip_atomic_store(&c.state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(c.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -101,7 +101,10 @@ __device__ __forceinline__ bool p2p_wait_all(const P2PDev &c, int word0, uint32_
         }
     }
     ok = __syncthreads_and(ok);                       // the verdict of the watching lanes, for the whole workgroup
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // system scope: peers' data written before their flag is visible now
+    // No acquire fence here (system scope = an invalidate walk of this XCD's L2 in every workgroup: 3.3 of the launch's 13.6 us with one
+    // rank): what must not be stale are the PEERS' arenas, and those are read with system-coherent loads (ld_sys: sc0 sc1, served by memory,
+    // never by a cache of this device) issued after this point -- the compiler may not move them up (asm volatile behind the barrier).
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     return ok;
 }
 
@@ -122,8 +125,9 @@ __device__ __forceinline__ void p2p_arrive(const P2PDev &c, uint32_t step) {
     __shared__ int last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const uint32_t arrived = __hip_atomic_fetch_add(&c.state[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // (nothing to release: "arrived" says this workgroup's READS of the peers' arenas have returned -- every thread consumed its
+        // values before the barrier above -- and no peer reads anything this launch writes)
+        const uint32_t arrived = __hip_atomic_fetch_add(&c.state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = arrived == gridDim.x - 1;
         if (last) {
             __hip_atomic_store(&c.state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -134,13 +138,33 @@ __device__ __forceinline__ void p2p_arrive(const P2PDev &c, uint32_t step) {
     if (last) p2p_push(c, P2P_DONE, step);
 }
 
+// a system-coherent 16-byte load: answered by memory (over xGMI for a peer's arena), not by this device's L1 / L2
+__device__ __forceinline__ float4 ld_sys(const float *p) {
+    float4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ float4 p2p_sum_quad(const P2PDev &c, long i, float scale) {
-    float4 s = *reinterpret_cast<const float4 *>(c.buf[0] + i);
+    // all W requests go out before the first value is used; this rank's own arena (written by the backward launches in front of this
+    // one in the stream) is an ordinary load.  Added in RANK ORDER: the same bits on every rank.
+    float4 v[P2P_MAX_RANKS];
+#pragma unroll
+    for (int r = 0; r < P2P_MAX_RANKS; ++r) {
+        if (r >= c.n_ranks) break;
+        if (r != c.rank) v[r] = ld_sys(c.buf[r] + i);
+    }
+#pragma unroll
+    for (int r = 0; r < P2P_MAX_RANKS; ++r) {
+        if (r >= c.n_ranks) break;
+        if (r != c.rank) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[r].x), "+v"(v[r].y), "+v"(v[r].z), "+v"(v[r].w) : : "memory");
+        else v[r] = *reinterpret_cast<const float4 *>(c.buf[r] + i);
+    }
+    float4 s = v[0];
 #pragma unroll
     for (int r = 1; r < P2P_MAX_RANKS; ++r) {
         if (r >= c.n_ranks) break;
-        const float4 x = *reinterpret_cast<const float4 *>(c.buf[r] + i);
-        s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        s.x += v[r].x; s.y += v[r].y; s.z += v[r].z; s.w += v[r].w;
     }
     s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
     return s;

@@ -12,7 +12,7 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INS
     rm -rf /tmp/chpmc_$i
     timeout -s KILL 200 rocprofv3 --pmc $set --output-format csv -d /tmp/chpmc_$i -- python $ROOT/tools/chain_time.py 256 > /dev/null 2>&1
     for c in $set; do
-        python $ROOT/tools/summarize_pmc.py /tmp/chpmc_$i $c | grep -E "conv_chain|Kernel_Name" > "$OUT/$c.csv"
+        python $ROOT/tools/summarize_pmc.py /tmp/chpmc_$i $c | grep -E "conv_chain|wide_grads|Kernel_Name" > "$OUT/$c.csv"
     done
 done
 python - "$OUT" <<'PY'

@@ -63,3 +63,26 @@ for name, spec in (("reference", REFERENCE), ("simple", SIMPLE)):
     hip.hip.th_debug_set_chain_generic(0)
     print(f"{name} batch {n}: compiled chain {t_chain:.1f} us ({flops / t_chain * 1e-6:.1f} TF), run-time-described chain {t_rt:.1f} us "
           f"({flops / t_rt * 1e-6:.1f} TF), layered {t_lay:.1f} us (eager launches back to back)")
+
+
+# the simple CNN's two-launch step: the chain with the classifier rows in its last epilogue + the batch sums (th_wide_head_grads)
+class _ChainHead(C.Structure):
+    _fields_ = [("d_w", C.c_void_p), ("d_bias", C.c_void_p), ("d_targets", C.c_void_p), ("classes", C.c_int), ("d_dl", C.c_void_p),
+                ("d_rowstat", C.c_void_p), ("d_cbpart", C.c_void_p), ("d_tick", C.c_void_p)]
+
+
+K = 64 * 49
+bufs = []
+for c_in, c_out, post in SIMPLE:
+    b = np.sqrt(6.0 / (c_in * 9))
+    bufs.append((ctx.upload(rng.uniform(-b, b, (c_out, c_in, 3, 3)).astype(np.float32)), ctx.upload(rng.uniform(-.1, .1, c_out).astype(np.float32))))
+stages, ns = hip.conv_stages([(w, b, c_out, post) for (w, b), (_, c_out, post) in zip(bufs, SIMPLE)])
+sp = C.cast(stages, C.c_void_p)
+w = ctx.upload((rng.uniform(-1, 1, (10, K)) * np.sqrt(2.0 / K)).astype(np.float32))
+bias, yt = ctx.upload(rng.uniform(-.1, .1, 10).astype(np.float32)), ctx.upload(rng.integers(0, 10, n).astype(np.float32))
+ymap, dl, rs, cbp = ctx.empty(n * K), ctx.empty(n * 16), ctx.empty(n * 2), ctx.empty(n * 64)
+head = _ChainHead(int(w), int(bias), int(yt), 10, int(dl), int(rs), int(cbp), None)
+dw, db, gcb, loss = ctx.empty(10 * K), ctx.empty(10), ctx.empty(64), ctx.empty(1)
+t_head = timed(lambda: ctx.call("th_conv_chain_head_fwd", x, sp, ns, ymap, n, 1, 28, 28, C.byref(head)))
+t_grads = timed(lambda: ctx.call("th_wide_head_grads", ymap, dl, rs, cbp, n, K, 10, 64, dw, db, gcb, loss, None, None, 0, None, 0, None, None, None))
+print(f"simple batch {n}: chain + classifier rows {t_head:.1f} us, batch sums (no Adam) {t_grads:.1f} us")
