@@ -663,7 +663,10 @@ __device__ __forceinline__ void rt_weights(const float *__restrict__ w, int c_in
 template <int S, int ND>
 __device__ __forceinline__ void rt_mfma(const float *in, const float *__restrict__ w, int c_in, int c_out, int chA, int chB, const int (&ptile)[ND],
                                         floatx4 (&acc)[2 * ND], int lane) {
-    constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, KS = 18;
+    constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, KS = 18, NPT = (PX + 15) / 16;
+    // a wave's tiles are piece, piece + m, ...: the waves of a channel pair carry ND or ND - 1 of them -- the last double's MFMAs are
+    // skipped (a wave-uniform branch per k-step; its operand read stays unconditional) where the tile does not exist
+    const bool last_live = ptile[ND - 1] < NPT;
     const int l16 = lane & 15, g4 = lane >> 4;
     typedef __attribute__((address_space(3))) const float lds_cf;
     lds_cf *pt[ND];
@@ -686,9 +689,13 @@ __device__ __forceinline__ void rt_mfma(const float *in, const float *__restrict
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                            \
             if (s + 1 < KS) RT_REQ(b1, s + 1)                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                                        \
+            _Pragma("unroll") for (int i = 0; i < ND - 1; ++i) {                                                                    \
                 acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[i], acc[2 * i], 0, 0, 0);                           \
                 acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.b[s], b0[i], acc[2 * i + 1], 0, 0, 0);                   \
+            }                                                                                                                       \
+            if (last_live) {                                                                                                        \
+                acc[2 * ND - 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[ND - 1], acc[2 * ND - 2], 0, 0, 0);            \
+                acc[2 * ND - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.b[s], b0[ND - 1], acc[2 * ND - 1], 0, 0, 0);            \
             }                                                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
             if (s + 1 < KS) { _Pragma("unroll") for (int i = 0; i < ND; ++i) b0[i] = b1[i]; }                                       \
@@ -780,7 +787,8 @@ __device__ __forceinline__ void rt_stage_nd(const RtChainArgs &a, const RtStage 
     for (int r = 0; r < st.rounds; ++r) {
         const int cid = r * (CH_NT / 64) + wave;
         const bool active = cid < np2 * st.m;                    // wave-uniform
-        const int q = active ? cid / st.m : 0, piece = cid % st.m;
+        const int q = active ? cid % np2 : 0, piece = cid / np2;  // neighbouring waves take different channel pairs: the waves that carry one
+                                                                  // tile more (piece < NPT % m) land on different SIMDs
         const int chA = 2 * q, chB = min(2 * q + 1, nct - 1);
         const bool has_b = 2 * q + 1 < nct;
         int ptile[ND];
@@ -963,7 +971,13 @@ bool rt_plan(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, 
         st.w = d.d_w; st.b = d.d_bias; st.c_in = ci; st.c_out = d.c_out; st.s = s; st.post = d.post;
         // tile mapping: np2 channel pairs x m chunks of nd pixel tiles, 8 chunks per round; cheapest rounds * nd, then fewest rounds
         const int npt = (s * s + 15) / 16, np2 = (d.c_out / 16 + 1) / 2;
+        // one round where it fits: the 8 / np2 waves of a channel pair interleave its pixel tiles (ND or ND - 1 each)
         int best = 1 << 30;
+        if (np2 <= 8) {
+            const int m = 8 / np2 < npt ? 8 / np2 : npt, need = (npt + m - 1) / m;
+            for (int nd : {1, 2, 4, 7})
+                if (nd >= need) { best = need * 16 + 1; st.nd = nd; st.m = m; st.rounds = 1; break; }
+        }
         for (int nd : {7, 4, 2, 1}) {
             const int m = (npt + nd - 1) / nd, rounds = (np2 * m + 7) / 8, cost = rounds * nd * 16 + rounds;
             if (cost < best) { best = cost; st.nd = nd; st.m = m; st.rounds = rounds; }
