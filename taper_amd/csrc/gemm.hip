@@ -780,7 +780,8 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
     // (k for a k-contiguous operand, m / n for an m/n-contiguous one); slices start on multiples of 32
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && ((A_KC ? k : m) % 4 == 0) &&
                      ((B_KC ? k : n) % 4 == 0) && m >= 4 && n >= 4 && k >= 4;
-    const bool exact = (m % TS == 0) && (n % TS == 0) && (k % BK == 0) && vec;
+    // whole tiles take the LDS-DMA kernel: its 32-bit lane offsets span a tile's rows (TS x leading dimension x 4 bytes < 2^31)
+    const bool exact = (m % TS == 0) && (n % TS == 0) && (k % BK == 0) && vec && lda < (1L << 22) && ldb < (1L << 22);
     float *partial = nullptr;
     if (kz > 1) {
         void *ws = nullptr;
@@ -853,11 +854,9 @@ int gemm_dispatch(th_ctx *ctx, int trans_a, int trans_b, int m, int n, int k, co
     const long b_rs = trans_b ? 1 : n, b_cs = trans_b ? k : 1;  // gemm.rs:93-97
     const bool a_kc = !trans_a, b_kc = trans_b != 0;
     const bool big = gemm_is_big(m, n, k);
-    // Layouts.  r01 ran deep NN / TN / TT products as NT on transposed COPIES (a separate LDS-tiled transpose launch per
-    // m/n-contiguous operand, ~32 us per 64 MB: 2.7 % of the Linear-stack step) because the kernel's [k][mn] LDS image of such an
-    // operand ran at 84-97 TF against 116 for NT.  r02: the kernel transposes m/n-contiguous quads on their way into LDS (store_tile),
-    // so one MFMA loop serves all four layouts -- 4096^3 on MI355X: NN 128.0, NT 125.3, TN (beta = 1) 119.3, TT 119.5 TF against
-    // 122.3 / 125.4 / 113.5 / 121.4 with the copies (TAPER_GEMM_PRETRANSPOSE=1 restores them for comparison).
+    // Layouts.  r01 ran deep NN / TN / TT products as NT on transposed COPIES (a transpose launch per m/n-contiguous operand); r02 transposed
+    // such operands on their way into LDS; r03 stages every operand in the layout it has in memory (sgemm_tile: two LDS images, one MFMA loop).
+    // TAPER_GEMM_PRETRANSPOSE=1 still runs the r01 form for comparison.
     static const int pretranspose = getenv("TAPER_GEMM_PRETRANSPOSE") ? atoi(getenv("TAPER_GEMM_PRETRANSPOSE")) : 0;   // measurement probe
     if (pretranspose && big && k >= 1024 && m >= 1024 && n >= 1024 && (!a_kc || !b_kc)) {
         void *at = nullptr, *bt = nullptr;
