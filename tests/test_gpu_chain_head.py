@@ -349,3 +349,26 @@ def test_other_cnns_take_the_run_time_described_chain_and_match_the_oracle(kind,
     for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
         m = margins.record(tag, f"param{i}", hp.data(), op.data(), lr=lr)
         assert m["err_over_lr"] <= 2e-2, (i, m)
+
+
+@pytest.mark.parametrize("n,k,classes,conv_c", [(1, 16, 1, 4), (37, 100, 7, 5), (256, 3136, 10, 64), (513, 1000, 16, 40), (700, 48, 3, 16),
+                                                 (4100, 130, 10, 13)])
+def test_wide_head_grads_ragged_shapes(ctx, n, k, classes, conv_c):
+    """th_wide_head_grads on its own: dW = dl^T X, db, loss, hit count, conv bias sums for batch / width / class / channel counts that are not
+    multiples of any tile, against float64 sums (ops.rs:280-291, tensor.rs:686-691, loss.rs:164, 283)"""
+    rng = np.random.default_rng(n + k + classes)
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    dl = np.zeros((n, 16), np.float32)
+    dl[:, :classes] = (rng.standard_normal((n, classes)) / n).astype(np.float32)
+    rs = np.stack([rng.uniform(0, 3, n), rng.integers(0, 2, n)], axis=1).astype(np.float32)
+    cbp = rng.standard_normal((n, conv_c)).astype(np.float32)
+    dw, db, gcb, loss, nc = ctx.empty(classes * k), ctx.empty(classes), ctx.empty(conv_c), ctx.empty(1), ctx.empty(1)
+    ctx.call("th_wide_head_grads", ctx.upload(x), ctx.upload(dl), ctx.upload(rs), ctx.upload(cbp), n, k, classes, conv_c, dw, db, gcb, loss, nc,
+             None, 0, None, 0, None, None, None)
+    ctx.sync()
+    ref_dw = dl[:, :classes].astype(np.float64).T @ x.astype(np.float64)
+    _close(ctx.download(dw, (classes, k)), ref_dw, "dW")
+    _close(ctx.download(db, classes), dl[:, :classes].astype(np.float64).sum(axis=0), "db")
+    _close(ctx.download(gcb, conv_c), cbp.astype(np.float64).sum(axis=0), "conv bias")
+    assert float(ctx.download(loss, 1)[0]) == pytest.approx(float(rs[:, 0].astype(np.float64).sum() / n), rel=1e-5)
+    assert float(ctx.download(nc, 1)[0]) == float(rs[:, 1].sum())
