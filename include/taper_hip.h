@@ -330,6 +330,10 @@ int th_sum_all(th_ctx *ctx, const float *d_x, float *d_out1, size_t n, float div
  * like the reference): tensor.rs:1021-1071, 1086-1088 */
 int th_rowmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols);
 int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols);
+/* global max over n elements, tensor.rs:1072-1083: `max_by(partial_cmp)` keeps the LAST of equal maxima; the index is stored as f32
+ * (`max_idx as f32`); n == 0 gives (0.0, 0).  d_nan_flag[0] (nullable) = 1 when a NaN is present: the reference's
+ * `partial_cmp(..).unwrap()` panics there, the host mirror raises. */
+int th_global_max(th_ctx *ctx, const float *d_x, size_t n, float *d_max, float *d_argmax_f32, int *d_nan_flag);
 
 /* ---- fused softmax cross-entropy: src/loss.rs:101-195, 271-290 -------- */
 /* logits [B,C], targets [B] fp32 class ids (cast `as usize`).  Writes

@@ -616,6 +616,8 @@ ot_tensor *ot_max(const ot_tensor *x, int dim, ot_tensor **indices_out) { /* ten
     float best = 0.0f;
     size_t best_i = 0;
     for (size_t i = 0; i < x->core->len; ++i) {
+        /* partial_cmp(..).unwrap() panics on the first comparison that involves a NaN (every element of a len >= 2 input is compared) */
+        OT_CHECK(!(x->core->len >= 2 && isnan(x->core->data[i])), "called `Option::unwrap()` on a `None` value");
         if (i == 0 || x->core->data[i] >= best) {
             best = x->core->data[i];
             best_i = i;

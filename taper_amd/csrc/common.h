@@ -53,6 +53,29 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// ---- device-raised errors (the reference panics inside an op -- e.g. loss.rs:161 "Target class {} out of bounds for {}" -- where a
+// kernel can only leave a note).  One 64-byte word block per device in host-visible, device-mapped memory; every translation unit that
+// raises holds its own copy of the block's address (g_err_word; no relocatable device code in this library) and registers a binder
+// that th_ctx_create runs once per device.  A raise is a few stores on a path no valid input takes; th_ctx_sync / th_memcpy_d2h look at
+// the block after their wait, turn a non-zero code into a non-zero return + th_last_error() and clear it (runtime.hip).
+enum : int32_t { TH_DEVERR_NONE = 0, TH_DEVERR_TARGET_OOB = 1 };
+static __device__ __attribute__((unused)) int32_t *g_err_word;
+__device__ __forceinline__ void raise_target_oob(long cls, int classes) {   // loss.rs:160-161
+    int32_t *w = g_err_word;
+    if (!w) return;
+    w[1] = (int32_t)(cls > 0x7fffffffL ? 0x7fffffffL : cls);
+    w[2] = classes;
+    __threadfence_system();
+    w[0] = TH_DEVERR_TARGET_OOB;
+}
+typedef int (*err_bind_fn)(int32_t *);
+struct ErrBindReg { explicit ErrBindReg(err_bind_fn f); };
+#define TH_USES_DEVICE_ERRORS()                                                                                        \
+    namespace {                                                                                                        \
+    int th_err_bind_here(int32_t *p) { return hipMemcpyToSymbol(HIP_SYMBOL(th::g_err_word), &p, sizeof(p)) == hipSuccess ? 0 : 1; } \
+    th::ErrBindReg th_err_reg_here(th_err_bind_here);                                                                  \
+    }
+
 // Memory-bound grid: cap at 8 blocks/CU and grid-stride the rest.
 static inline int ew_grid(size_t n_items, int block) {
     long g = (long)((n_items + block - 1) / block);
@@ -77,6 +100,7 @@ struct th_ctx {
     std::multimap<size_t, void *> capture_free;       // freed again during the capture
     // staging plans of the image-resident conv kernel, built on device once per geometry (conv_mfma.hip); plain hipMalloc, freed with the ctx
     std::map<std::array<int, 8>, void *> conv_plans;
+    int32_t *err_word = nullptr;                      // this device's error block (host-visible; shared by the contexts of a device)
 };
 
 struct th_graph {

@@ -14,6 +14,8 @@
 // 16-lane plane sums with the same shuffle tree -- the chain's outputs are bit-identical to the layered path's.
 #include "tail_dev.h"
 
+TH_USES_DEVICE_ERRORS()
+
 namespace th {
 
 constexpr int CH_NT = 512;                                                      // threads per workgroup: 8 waves, two per SIMD

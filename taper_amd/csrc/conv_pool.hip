@@ -426,10 +426,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restric
 // Gather form of the scatter-add of tensor.rs:1504-1514: every input pixel
 // walks the windows that can contain it in (oh, ow) ascending order -- the same
 // order the reference's sequential `for o in 0..out_spatial` adds them, so
-// the result is bit-identical, with no atomics.  (A pixel whose padded
-// coordinate lies outside a window can never be that window's argmax, except
-// the `best_idx = in_base` default of an all-NaN/-inf window, which points at
-// pixel (0,0): that window is the one covering (0,0) or contributes there.)
+// the result is bit-identical, with no atomics.  A pixel whose padded
+// coordinate lies outside a window can never be that window's argmax -- except
+// pixel (0,0) of a plane: a window with no element > -inf (all NaN / -inf, or
+// all padding) keeps the `best_idx = in_base` default (tensor.rs:1432) and its
+// gradient lands there (1504-1514), wherever the window is.  So the thread of
+// pixel (0,0) walks ALL windows of its plane, in the same ascending order.
 __global__ __launch_bounds__(256) void maxpool_bwd_geo_kernel(const float *__restrict__ gout, const int64_t *__restrict__ argmax,
                                                               float *__restrict__ gin, long total, int h, int w, int h_out,
                                                               int w_out, int k_h, int k_w, int s_h, int s_w, int pad_h,
@@ -442,11 +444,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_geo_kernel(const float *__res
         const int ihp = ih + pad_h, iwp = iw + pad_w;
         const int oh_lo = ihp >= k_h ? (ihp - k_h) / s_h + 1 : 0, oh_hi = min(h_out - 1, ihp / s_h);
         const int ow_lo = iwp >= k_w ? (iwp - k_w) / s_w + 1 : 0, ow_hi = min(w_out - 1, iwp / s_w);
-        for (int oh = oh_lo; oh <= oh_hi; ++oh)
-            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                const long o = obase + (long)oh * w_out + ow;
-                if (argmax[o] == i) v += gout[o];
-            }
+        if (ih == 0 && iw == 0) {
+            const int n_out = h_out * w_out;
+#pragma unroll 4
+            for (int o = 0; o < n_out; ++o)
+                if (argmax[obase + o] == i) v += gout[obase + o];
+        } else {
+            for (int oh = oh_lo; oh <= oh_hi; ++oh)
+                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                    const long o = obase + (long)oh * w_out + ow;
+                    if (argmax[o] == i) v += gout[o];
+                }
+        }
         gin[i] = v;
     }
 }

@@ -26,6 +26,8 @@
 // head_finish_kernel (+ th_colsum for many slots) adds them in slot order: deterministic, no atomics.
 #include "adam_dev.h"
 
+TH_USES_DEVICE_ERRORS()
+
 namespace th {
 
 int adam_slice(th_ctx *ctx, const AdamDev &a, const float *d_g, int64_t n);  // optim.hip
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(HEAD_T) void linear_xent_head_kernel(HeadArgs a) {
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) my_nll += __shfl_xor(my_nll, off, 64);
             if (active && sub == 0) {
-                nll_acc += (cls >= C) ? NAN : my_nll;         // the reference panics (loss.rs:161)
+                nll_acc += (cls >= C) ? NAN : my_nll;         // the reference panics (loss.rs:161): NaN + a note for the next wait
+                if (cls >= C) raise_target_oob(cls, C);
                 hit_acc += (fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;  // loss.rs:283
             }
             dl[row_l * HEAD_CMAX + sub] = dlv;                // rows >= `rows`, classes >= C hold 0

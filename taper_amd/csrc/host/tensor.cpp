@@ -768,10 +768,13 @@ Tensor Tensor::sum(int dim, bool keepdim) const {  // tensor.rs:890-1018
 std::pair<Tensor, Tensor> Tensor::max(int dim) const {  // tensor.rs:1021-1083 (no tape node)
     th_ctx *c = Device::ctx();
     if (dim < 0) {
-        // global max; NOTE the reference's max_by keeps the LAST of equal maxima,
-        // this kernel keeps the first (off the hot path; documented in DESIGN.md)
+        // global max (tensor.rs:1072-1083): max_by keeps the LAST of equal maxima; a NaN makes partial_cmp(..).unwrap() panic
         Tensor v = empty({1}), i = empty({1});
-        TH(th_rowmax(c, dptr(), v.dptr(), i.dptr(), 1, (int)len()));
+        auto flag = Buffer::alloc(1);
+        TH(th_global_max(c, dptr(), len(), v.dptr(), i.dptr(), reinterpret_cast<int *>(flag->d)));
+        int nan_seen = 0;
+        TH(th_memcpy_d2h(c, &nan_seen, flag->d, sizeof(int)));
+        TAPER_ASSERT(!(nan_seen && len() >= 2), "called `Option::unwrap()` on a `None` value (max: NaN in the input)");   // (one element: no comparison)
         return {v, i};
     }
     TAPER_ASSERT((size_t)dim < shape_.size(), "Dimension " + std::to_string(dim) + " out of bounds");

@@ -17,6 +17,8 @@
 // sgemm_small16): every k once, sums within fp32 rounding of the k-ordered reference chain (tolerance 1e-4, like every GEMM here).
 #include "tail_dev.h"
 
+TH_USES_DEVICE_ERRORS()
+
 namespace th {
 
 int mlp3_grads_launch(th_ctx *ctx, const float *const dz[3], const float *const act[3], float *const dw[3], float *const db[3],

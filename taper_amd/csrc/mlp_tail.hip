@@ -25,6 +25,8 @@
 // (th_adam_slice) to the next launch that does not read them (th_linear_fwd_ex of the next step).
 #include "tail_dev.h"
 
+TH_USES_DEVICE_ERRORS()
+
 namespace th {
 
 struct TailArgs {

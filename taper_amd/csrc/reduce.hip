@@ -4,6 +4,8 @@
 // combine (no atomics -> deterministic).
 #include "common.h"
 
+TH_USES_DEVICE_ERRORS()
+
 namespace th {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -232,6 +234,82 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x
     if (imax) imax[c] = (float)bi;
 }
 
+// ---- global max (tensor.rs:1072-1083): `max_by(partial_cmp)` keeps the LAST of equal maxima; a NaN anywhere makes the reference's
+// `partial_cmp(..).unwrap()` panic (flag[0] = 1 here, the host raises).  Two passes: per-block (value, index) pairs, then one block.
+__device__ __forceinline__ void lastmax_combine(float &v, long &i, float ov, long oi) {
+    if (oi >= 0 && (i < 0 || ov > v || (ov == v && oi > i))) {
+        v = ov;
+        i = oi;
+    }
+}
+
+__device__ __forceinline__ void lastmax_block(float &best, long &bi, int &nan_seen, float *shv, long *shi, int *shn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const long oi = __shfl_xor(bi, off, 64);
+        nan_seen |= __shfl_xor(nan_seen, off, 64);
+        lastmax_combine(best, bi, ov, oi);
+    }
+    if (lane == 0) {
+        shv[wave] = best;
+        shi[wave] = bi;
+        shn[wave] = nan_seen;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lastmax_combine(best, bi, shv[w], shi[w]);
+            nan_seen |= shn[w];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void global_max_partial_kernel(const float *__restrict__ x, long n, float *__restrict__ pv, long *__restrict__ pi,
+                                                                 int *__restrict__ pn) {
+    __shared__ float shv[4];
+    __shared__ long shi[4];
+    __shared__ int shn[4];
+    float best = 0.f;
+    long bi = -1;
+    int nan_seen = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        nan_seen |= (v != v) ? 1 : 0;
+        if (bi < 0 || v >= best) {   // ascending i inside a thread: >= keeps the later one
+            best = v;
+            bi = i;
+        }
+    }
+    lastmax_block(best, bi, nan_seen, shv, shi, shn);
+    if (threadIdx.x == 0) {
+        pv[blockIdx.x] = best;
+        pi[blockIdx.x] = bi;
+        pn[blockIdx.x] = nan_seen;
+    }
+}
+
+__global__ __launch_bounds__(256) void global_max_final_kernel(const float *__restrict__ pv, const long *__restrict__ pi, const int *__restrict__ pn,
+                                                               int nparts, float *__restrict__ vmax, float *__restrict__ imax, int *__restrict__ flag) {
+    __shared__ float shv[4];
+    __shared__ long shi[4];
+    __shared__ int shn[4];
+    float best = 0.f;
+    long bi = -1;
+    int nan_seen = 0;
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        lastmax_combine(best, bi, pv[p], pi[p]);
+        nan_seen |= pn[p];
+    }
+    lastmax_block(best, bi, nan_seen, shv, shi, shn);
+    if (threadIdx.x == 0) {
+        if (vmax) vmax[0] = bi < 0 ? 0.f : best;          // empty input: unwrap_or((0.0, 0))
+        if (imax) imax[0] = bi < 0 ? 0.f : (float)bi;      // `max_idx as f32`
+        if (flag) flag[0] = nan_seen;
+    }
+}
+
 // ---- fused log-softmax + NLL + argmax (loss.rs:101-195, 271-290) ---------
 // A row is owned by LPR lanes (16 when classes <= 16 -- four rows per wave for
 // the 10-class MNIST head -- else a whole wave); reductions are xor-shuffles
@@ -289,7 +367,8 @@ __device__ __forceinline__ void xent_row(const XentArgs &a, int row, int sub, fl
     }
 #pragma unroll
     for (int off = LPR / 2; off > 0; off >>= 1) my_nll += __shfl_xor(my_nll, off, 64);  // exactly one lane holds it
-    nll = (cls >= a.classes) ? NAN : my_nll;  // the reference panics (loss.rs:161)
+    nll = (cls >= a.classes) ? NAN : my_nll;  // the reference panics (loss.rs:161): NaN + a note the next wait turns into an error
+    if (cls >= a.classes && sub == 0) raise_target_oob(cls, a.classes);
     hit = (fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;  // loss.rs:283
     if (sub == 0 && a.argmax_out) a.argmax_out[row] = (float)bi;
 }
@@ -533,6 +612,23 @@ int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, 
     hipLaunchKernelGGL(colmax_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, ctx->stream, d_x, d_max, d_argmax_f32, rows, cols);
     TH_LAUNCH_CHECK();
     return 0;
+}
+
+int th_global_max(th_ctx *ctx, const float *d_x, size_t n, float *d_max, float *d_argmax_f32, int *d_nan_flag) {
+    TH_REQUIRE(ctx && (d_x || n == 0), "th_global_max: bad argument");
+    int nparts = (int)((n + 256 * 16 - 1) / (256 * 16));
+    nparts = nparts < 1 ? 1 : (nparts > 1024 ? 1024 : nparts);
+    void *ws = nullptr;
+    if (th_malloc(ctx, (size_t)nparts * 16, &ws)) return 1;
+    long *pi = (long *)ws;
+    float *pv = (float *)(pi + nparts);
+    int *pn = (int *)(pv + nparts);
+    hipLaunchKernelGGL(global_max_partial_kernel, dim3(nparts), dim3(256), 0, ctx->stream, d_x, (long)n, pv, pi, pn);
+    TH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(global_max_final_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float *)pv, (const long *)pi, (const int *)pn, nparts, d_max,
+                       d_argmax_f32, d_nan_flag);
+    TH_LAUNCH_CHECK();
+    return th_free(ctx, ws);
 }
 
 int th_softmax_xent_fwd(th_ctx *ctx, const float *d_logits, const float *d_targets, int batch, int classes, float *d_logp,

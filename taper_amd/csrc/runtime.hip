@@ -18,6 +18,42 @@ void set_error(const char *fmt, ...) {
     g_last_error = buf;
 }
 
+// device-raised errors (common.h): the binders of the translation units that raise, and one host-visible block per device
+static std::vector<err_bind_fn> &err_binders() {
+    static std::vector<err_bind_fn> v;
+    return v;
+}
+ErrBindReg::ErrBindReg(err_bind_fn f) { err_binders().push_back(f); }
+static std::map<int, int32_t *> g_err_blocks;
+
+static int err_block_for(int device, int32_t **out) {   // current device == device
+    auto it = g_err_blocks.find(device);
+    if (it == g_err_blocks.end()) {
+        int32_t *w = nullptr;
+        TH_HIP(hipHostMalloc((void **)&w, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(w, 0, 64);
+        for (err_bind_fn f : err_binders())
+            if (f(w)) {
+                set_error("th_ctx_create: binding the device error block failed");
+                return 1;
+            }
+        it = g_err_blocks.emplace(device, w).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// after a wait: did a kernel of this device leave a note?  (the reference would have panicked inside the op)
+static int err_block_check(th_ctx *ctx) {
+    volatile int32_t *w = ctx->err_word;
+    if (!w || w[0] == TH_DEVERR_NONE) return 0;
+    const int32_t code = w[0], a = w[1], b = w[2];
+    w[0] = TH_DEVERR_NONE;
+    if (code == TH_DEVERR_TARGET_OOB) set_error("Target class %d out of bounds for %d", a, b);   // loss.rs:161
+    else set_error("device error %d (%d, %d)", code, a, b);
+    return 3;
+}
+
 // Size classes: 256 B granularity below 64 KiB, then 1/8-octave steps, so a
 // training step's repeating allocation pattern hits the free lists exactly.
 static size_t round_size(size_t bytes) {
@@ -62,6 +98,7 @@ int th_ctx_create(int device_id, th_ctx **out) {
     th_ctx *c = new th_ctx();
     c->device = device_id;
     TH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (err_block_for(device_id, &c->err_word)) return 1;
     *out = c;
     return 0;
 }
@@ -80,7 +117,7 @@ int th_ctx_destroy(th_ctx *ctx) {
 int th_ctx_sync(th_ctx *ctx) {
     TH_REQUIRE(ctx, "th_ctx_sync: null ctx");
     TH_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return err_block_check(ctx);
 }
 
 void *th_ctx_stream(th_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -188,7 +225,7 @@ int th_memcpy_d2h(th_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (bytes == 0) return 0;
     TH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     TH_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return err_block_check(ctx);
 }
 
 int th_memcpy_d2d(th_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {

@@ -75,7 +75,8 @@ __device__ __forceinline__ void tail_row_softmax(const float (&lg)[4], int g4, i
         dl[i] = (cls < C) ? (hit ? gv - 1.0f : gv) * inv_b : 0.f;   // loss.rs:185-188 with g0 = 1
     }
     my_nll = sum_over_g4(my_nll);
-    nll = (tc >= C) ? NAN : my_nll;                   // the reference panics (loss.rs:161)
+    nll = (tc >= C) ? NAN : my_nll;                   // the reference panics (loss.rs:161): NaN loss + a note the next wait turns into an error
+    if (tc >= C) raise_target_oob(tc, C);
     argmax = bi;
 }
 

@@ -12,6 +12,8 @@
 #include "tail_dev.h"
 #include "adam_dev.h"
 
+TH_USES_DEVICE_ERRORS()
+
 namespace th {
 
 int linear_fwd_partials(th_ctx *ctx, const float *x, const float *w, int m, int n, int k, float **partial_out, int *kz_out);   // gemm.hip

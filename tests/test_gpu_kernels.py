@@ -290,6 +290,35 @@ def test_rowmax_colmax_bit_exact(ctx, O, rows, cols):
     np.testing.assert_array_equal(ctx.download(dv, cols), v.data().reshape(-1))
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 65, 4096, 4097, 300_000, 5_000_000])
+def test_global_max_last_of_equal_maxima(ctx, O, n):
+    """tensor.rs:1072-1083: `max_by(partial_cmp)` keeps the LAST of equal maxima; index as f32; bit-exact vs the oracle"""
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 3, n).astype(np.float32)       # three distinct values -> the maximum repeats ~n/3 times
+    v, i = O.Tensor(x).max(None)
+    dv, di, df = ctx.empty(1), ctx.empty(1), ctx.empty(1)
+    ctx.call("th_global_max", ctx.upload(x), n, dv, di, df)
+    assert ctx.download(dv, 1)[0] == v.data()[0]
+    assert ctx.download(di, 1)[0] == i.data()[0]
+    last = np.float32(np.flatnonzero(x == x.max())[-1])
+    assert ctx.download(di, 1)[0] == last
+    assert ctx.download(df, 1).view(np.int32)[0] == 0
+    # the host mirror (Tensor::max(None) / argmax(None)) takes the same kernel
+    import taper_amd as T
+    hv, hi = T.Tensor(x).max(None)
+    assert hv.data()[0] == v.data()[0] and hi.data()[0] == i.data()[0]
+    assert T.Tensor(x).argmax(None).data()[0] == i.data()[0]
+
+
+def test_global_max_nan_panics_like_partial_cmp_unwrap(ctx):
+    import taper_amd as T
+    x = np.array([1.0, np.nan, 3.0], np.float32)
+    with pytest.raises(Exception, match="unwrap"):
+        T.Tensor(x).max(None)
+    v, i = T.Tensor(np.array([np.nan], np.float32)).max(None)   # one element: no comparison, no panic
+    assert np.isnan(v.data()[0]) and i.data()[0] == 0.0
+
+
 # ------------------------------------------------------------------ softmax cross-entropy
 @pytest.mark.parametrize("batch,classes", [(64, 10), (128, 10), (256, 10), (1024, 10), (1, 2), (7, 3), (32, 100), (5, 1),
                                            (2048, 10), (1500, 37), (63, 16), (65, 17)])
@@ -460,6 +489,39 @@ def test_maxpool_bit_exact(ctx, O, n, c, h, w, k, s, pad):
     gin = ctx.upload(np.full(x.shape, 5.0, np.float32))
     ctx.call("th_maxpool2d_bwd", ctx.upload(gout), am, gin, n, c, h, w, k[0], k[1], sh, sw, pad[0], pad[1], 1)
     np.testing.assert_array_equal(ctx.download(gin, x.shape), xt.grad())                 # same add order: bit-exact
+    O.Tape.reset()
+
+
+@pytest.mark.parametrize("n,c,h,w,k,s,pad", [(2, 3, 8, 8, (2, 2), (2, 2), (0, 0)), (1, 2, 9, 7, (3, 3), (2, 2), (1, 1)),
+                                             (2, 2, 6, 6, (2, 2), (2, 2), (2, 2)), (1, 1, 5, 5, (1, 1), (1, 1), (1, 1))])
+def test_maxpool_windows_without_a_maximum(ctx, O, n, c, h, w, k, s, pad):
+    """A window whose entries are all NaN / -inf -- or all padding (pad >= kernel) -- keeps the reference's default index `in_base`
+    (tensor.rs:1432): value -inf, index = pixel (0,0) of ITS plane, and the backward adds that window's gradient there
+    (tensor.rs:1504-1514) wherever the window lies.  Bit-exact vs the oracle, forward indices and backward."""
+    rng = np.random.default_rng(h * 10 + w)
+    x = rng.integers(-3, 4, (n, c, h, w)).astype(np.float32)
+    x[0, 0, h - 4:, w - 4:] = np.nan          # all-NaN windows far from pixel (0,0)
+    x[n - 1, c - 1, 2:, :] = -np.inf          # -inf never beats the -inf start either
+    x[n - 1, c - 1, 0, 0] = np.nan
+    O.Tape.reset()
+    O.Tape.set_zero_sentinel(False)
+    xt = O.Tensor(x).requires_grad()
+    ref, ref_idx = xt.max_pool2d(k, s, pad, zero_first=True, return_indices=True)
+    _, _, ho, wo = ref.shape()
+    gout = rng.uniform(-1, 1, (n, c, ho, wo)).astype(np.float32)
+    (ref * O.Tensor(gout)).sum(None, False).backward()
+    O.Tape.set_zero_sentinel(True)
+    # the case is really exercised: some window away from the origin points at its plane's first pixel
+    plane_base = (np.arange(n * c) * h * w).reshape(n, c, 1, 1)
+    dflt = (ref_idx == plane_base) & np.isneginf(ref.data().reshape(n, c, ho, wo))
+    assert dflt[:, :, 1:, :].any() or dflt[:, :, :, 1:].any()
+    y, am = ctx.empty(n * c * ho * wo), ctx.empty(n * c * ho * wo, np.int64)
+    ctx.call("th_maxpool2d_fwd", ctx.upload(x), y, am, n, c, h, w, k[0], k[1], s[0], s[1], pad[0], pad[1])
+    np.testing.assert_array_equal(ctx.download(am, (n, c, ho, wo), np.int64), ref_idx)
+    np.testing.assert_array_equal(ctx.download(y, (n, c, ho, wo)), ref.data().reshape(n, c, ho, wo))
+    gin = ctx.upload(np.full(x.shape, 5.0, np.float32))
+    ctx.call("th_maxpool2d_bwd", ctx.upload(gout), am, gin, n, c, h, w, k[0], k[1], s[0], s[1], pad[0], pad[1], 1)
+    np.testing.assert_array_equal(ctx.download(gin, x.shape), xt.grad().reshape(x.shape))
     O.Tape.reset()
 
 
