@@ -28,6 +28,23 @@ def record(test: str, tensor: str, got, ref, lr: float | None = None) -> dict:
     return rec
 
 
+def check(tensor: str, got, ref, bound: float | None, lr: float | None = None, test: str | None = None) -> dict:
+    """Record the margin and hold it to `bound`: max |got - ref| <= bound * max |ref| -- or <= bound * lr when `lr` is given (weights
+    after Adam steps).  The record keeps the WORST case over a test's parametrisations (key = the test function's name), so a bound of
+    2x the recorded value covers all of them.  bound None: record only."""
+    if test is None:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "unknown").split(" ")[0].split("::")[-1].split("[")[0]
+    prev = _seen.get(test, {}).get(tensor)
+    rec = record(test, tensor, got, ref, lr)
+    key = "err_over_lr" if lr is not None else "err_over_scale"
+    val = rec[key]
+    if prev is not None and prev.get(key, 0.0) > val:
+        _seen[test][tensor] = prev
+    if bound is not None:
+        assert val <= bound, f"{test}/{tensor}: {key} = {val:.3e} > bound {bound:.3e} ({rec})"
+    return rec
+
+
 @atexit.register
 def _flush():
     if not _seen:
@@ -36,7 +53,7 @@ def _flush():
         _OUT.parent.mkdir(parents=True, exist_ok=True)
         old = json.loads(_OUT.read_text()) if _OUT.exists() else {}
         for k, v in _seen.items():
-            old.setdefault(k, {}).update(v)
+            old.setdefault(k, {}).update(v)   # (one pytest process per run: a re-run replaces its tests' records)
         _OUT.write_text(json.dumps(old, indent=1, sort_keys=True))
     except OSError:
         pass
