@@ -274,6 +274,36 @@ int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batc
 /* Test hook: how many th_mlp3_xent calls this thread has enqueued (the parity tests assert which form a Trainer step took). */
 int th_debug_mlp3_calls(int64_t *out);
 
+/* ---- th_mlp2_xent: the large-batch step of Linear + ReLU, Linear, softmax cross-entropy in THREE launches --------------------------
+ * (nn.rs:54-60, activation.rs:10-12, loss.rs:101-195, 271-290, the backward closures ops.rs:238-294, 358-369, tensor.rs:574-587, 674-694,
+ * and optim.rs:83-113 where fuses are given).  Bit-compatible in meaning with th_gather_batch + th_linear_fwd(relu) + th_linear_xent_head_masked
+ * + th_linear_bwd + th_adam_step on the same rows; fp32 sums reordered (1e-4 relative), argmax / hit count exact.
+ * The batch's rows are read where they lie: th_row_source names either a dense [batch][in_features] block (d_indices NULL; d_labels[r] is
+ * row r's target) or a resident dataset (d_rows [n_rows][in_features], d_labels [n_rows]) whose rows d_indices[(d_cursor[0] + r) % n_indices]
+ * form the batch -- DataLoader::next / MNISTDataset::get_batch (data/mnist.rs:277-310, 364-386) without the gathered copy.
+ *   launch 1: rows (forward, loss terms, masked dZ1, partial dW2 / db1 / db2 / NLL / hits per row block); d_tick (nullable): t += 1 (optim.rs:84)
+ *   launch 2: dW1 = dZ1^T X over K slices of the batch
+ *   launch 3: fixed-order sums -> d_dw1 [hidden][in], d_db1, d_dw2 [classes][hidden], d_db2, d_loss, d_ncorrect, the step log, and Adam for
+ *             every fuse given (complete gradients; no later launch of the step reads a parameter: nothing to defer).
+ * Needs hidden a multiple of 32 up to 128, classes <= 16, in_features a multiple of 4, batch >= 32, n_rows * in_features * 4 < 2^31.
+ * Nullable: d_b1, d_b2, d_db1, d_db2, d_ncorrect, metrics / state, d_tick, the fuses. */
+typedef struct th_row_source {
+    const float *d_rows;
+    const float *d_labels;
+    const int32_t *d_indices;   /* nullable */
+    const int64_t *d_cursor;    /* nullable: 0 */
+    int64_t n_indices;
+    int64_t n_rows;             /* rows held by d_rows (the extent reads are clamped to) */
+} th_row_source;
+int th_mlp2_xent_supported(int batch, int in_features, int hidden, int classes, int64_t n_rows);
+int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_features, int hidden, int classes, const float *d_w1,
+                 const float *d_b1, const float *d_w2, const float *d_b2, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2,
+                 float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                 int32_t *d_tick, const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse, const th_adam_fuse *w2_fuse,
+                 const th_adam_fuse *b2_fuse);
+/* Test hook: how many th_mlp2_xent calls this thread has enqueued. */
+int th_debug_mlp2_calls(int64_t *out);
+
 /* ---- element-wise: src/ops.rs:8-120,377-496; src/tensor.rs:36-161 ----- */
 int th_add(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
 int th_sub(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);

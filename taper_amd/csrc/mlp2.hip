@@ -1,0 +1,739 @@
+// mlp2.hip -- th_mlp2_xent: one training step of a two-layer classifier (Linear + ReLU, Linear, softmax cross-entropy: the MNIST MLP of
+// BASELINE configs[1] / [3], examples/train_mnist.rs with one hidden layer) at LARGE batch -- 1 024 .. 60 000 rows -- in THREE launches,
+// reading the batch's rows where they lie in the dataset (no gathered copy):
+//
+//   launch 1  mlp2_rows_kernel<RT>  a workgroup owns RT rows.  H = relu(X W1^T + b1) on v_mfma_f32_32x32x2_f32 with X (rows through the
+//             loader's index vector) and W1 streamed global -> LDS by LDS-DMA in 32-deep k chunks, double buffered (nn.rs:54-60,
+//             activation.rs:10-12); then, with H in LDS, everything that is ROW-parallel: logits, softmax / NLL / argmax / dlogits
+//             (loss.rs:101-195, 271-290), dH = dlogits W2 and the ReLU mask (ops.rs:254-265, 358-369).  Writes the masked dZ1 -- the
+//             only activation-sized tensor that leaves the CU -- and the workgroup's partial sums of everything that adds over rows but
+//             is small: dW2, db1, db2, NLL, hits.  H itself never reaches memory.  Its first thread opens the optimizer step (t += 1).
+//   launch 2  mlp2_dw1_kernel       dW1 = dZ1^T X (ops.rs:266-294): 128 x 128 tiles of the [hidden][in] output, the batch split into K
+//             slices over the workgroups; both operands by LDS-DMA as they lie in memory (X rows through the index vector again);
+//             every slice writes its raw accumulators.
+//   launch 3  mlp2_finish_kernel    adds the K slices of dW1 and the row-block partials of launch 1 in fixed order (deterministic),
+//             writes the four gradients, the loss, the hit count and the step log, and applies Adam (optim.rs:99-110) to all four
+//             parameters in the same threads -- no launch of the step reads a parameter after this one, so nothing is deferred.
+//
+// Bounds: launches 1 and 2 are 2 B in hid flop each -- MFMA fp32 peak (157.3 TF); launch 3 moves kz x 4 hid in bytes -- HBM.
+// fp32 sums are reordered with respect to the reference's k-ordered chains (k quads permuted inside a 32-chunk, K slices, row blocks):
+// within the 1e-4 relative bar, like every GEMM here; index work (argmax, hits) is exact.
+#include "tail_dev.h"
+
+TH_USES_DEVICE_ERRORS()
+
+namespace th {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+// where the rows of the batch live: a dense [batch][in] block, or rows idx[(cursor + r) % n_idx] of a resident dataset
+struct RowSource {
+    const float *x, *labels;
+    const int32_t *idx;       // nullable
+    const int64_t *cursor;    // nullable (0)
+    int64_t n_idx;
+    unsigned x_bytes;         // extent of x (buffer range of the LDS-DMA descriptor: reads past it return 0)
+};
+
+__device__ __forceinline__ int src_row(const RowSource &s, long cur, int r) {
+    if (!s.idx) return r;
+    long pos = cur + r;
+    if (pos >= s.n_idx) pos %= s.n_idx;
+    return s.idx[pos];
+}
+
+// LDS-DMA as inline assembly.  Through the builtin (raw_ptr_buffer_load_lds) the compiler knows the instruction writes LDS and -- without alias
+// information -- parks an `s_waitcnt vmcnt(0)` in front of the next ds_read: every request in flight is drained before the chunk that IS
+// there may be read, and a ring of stages degenerates to one.  As an opaque instruction the fetch stays in flight; its landing is waited for
+// explicitly (wait_vmcnt: vector-memory operations complete in order) before the workgroup barrier that publishes the stage.
+// (Operations the compiler does not count only make ITS vmcnt waits stricter, never weaker: the counter is in order.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc(const void *p, unsigned bytes) {
+    const uint64_t a = (uint64_t)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));   // stride 0: raw buffer
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);                              // range: offsets >= bytes read as 0
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+// lane l: 16 bytes from rs.base + voff + soff -> LDS byte address lds_dst + 16 l  (lds_dst, soff wave-uniform)
+__device__ __forceinline__ void lds_dma16(i32x4 rs, unsigned lds_dst, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory");   // (m0 is reserved: it cannot be declared as clobbered; nothing else in these kernels uses it)
+}
+
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = simm16[15:14, 3:0], expcnt [6:4], lgkmcnt [11:8]): "at most N vector-memory operations of
+// this wave still in flight" -- they complete in order, so the oldest fetches of a ring of LDS-DMA stages have landed
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
+#ifdef TH_PROFILE
+__device__ long long g_m2_prof[16];     // wall clock (100 MHz) at stage boundaries of the three launches (tools/prof_mlp2_stages.sh)
+#define M2_STAMP(i, cond) do { if (threadIdx.x == 0 && (cond)) g_m2_prof[i] = wall_clock64(); } while (0)
+#else
+#define M2_STAMP(i, cond) do { } while (0)
+#endif
+
+constexpr int M2_LDH __attribute__((unused)) = 132;   // row pitch of the H tile in LDS (hidden <= 128): 16-byte aligned rows, rows 4 apart 16 banks apart
+constexpr int M2_BK = 32;
+
+__host__ __device__ constexpr int m2_swz(int row) { return (row >> 1) & 7; }
+
+struct Mlp2RowsArgs {
+    RowSource src;
+    const float *w1, *b1, *w2, *b2;
+    int batch, in_f, hid, c;
+    float *dz1;          // [gridDim.x * RT][hid]: rows >= batch are written as zeros
+    float *part;         // [gridDim.x][part_stride]: dW2 [c][hid], db1 [hid], db2 [16], nll, hits
+    int part_stride;
+    int32_t *tick;       // nullable
+};
+
+// ---------------------------------------------------------------------------------------------------------------- launch 1
+// LDS images of the k chunk: [rows][32 k], 128-byte rows, the eight 16-byte k quads of row r stored at quad ^ swz(r) (gemm.hip's
+// k-contiguous image: one ds_read_b128 gives a lane the operands of four k-steps, conflict-free, and an LDS-DMA lane fills one quad).
+// The k chunks travel through a ring of NS stages: chunk it + NS - 1 is requested while chunk it is contracted, so a request has NS - 1
+// iterations (~0.5-1 us each) to cross the fabric -- with two stages the loop ran at the memory latency, not at the MFMA rate (r04: 52.7 us
+// for 3.3 GFLOP at batch 16 384).
+template <int RT, int NS>
+__global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2RowsArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NI = RT / 32;                 // 32-row MFMA tiles per wave (the wave owns 32 hidden columns of all RT rows)
+    constexpr int A_T = RT * M2_BK, B_T = 128 * M2_BK;
+    constexpr int NRB = RT / 16;                // 16-row blocks of the tile
+    constexpr int STG = A_T + B_T, L = NI + 4;  // floats per stage (X chunk, then W1 chunk); LDS-DMA instructions per wave and stage
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lk = lane >> 5, l16 = lane & 15, g4 = lane >> 4;
+    const int r0 = blockIdx.x * RT, B = a.batch, in_f = a.in_f, hid = a.hid, C = a.c;
+    M2_STAMP(0, blockIdx.x == 0);
+    if (a.tick && blockIdx.x == 0 && t == 0) a.tick[0] += 1;                  // optim.rs:84 (the launch that reads t comes later)
+    const long cur = (a.src.idx && a.src.cursor) ? a.src.cursor[0] : 0;
+
+    // ---- staging plans: lane -> (row, k quad) of the 1 KB an LDS-DMA instruction fills ----
+    int a_voff[NI], b_voff[4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int row = 8 * (4 * j + wave) + (lane >> 3);
+        const int srow = src_row(a.src, cur, min(r0 + row, B - 1));          // rows beyond the batch: a copy of its last row, zeroed below
+        a_voff[j] = (int)((unsigned)srow * (unsigned)in_f * 4u + (unsigned)(((lane & 7) ^ m2_swz(row)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (4 * j + wave) + (lane >> 3);
+        b_voff[j] = (int)((unsigned)min(row, hid - 1) * (unsigned)in_f * 4u + (unsigned)(((lane & 7) ^ m2_swz(row)) << 4));
+    }
+    const i32x4 rs_x = make_rsrc(a.src.x, a.src.x_bytes), rs_w = make_rsrc(a.w1, (unsigned)hid * (unsigned)in_f * 4u);
+    const unsigned lds0 = lds_addr(smem);
+    // what the epilogue needs from memory is requested now, under the whole k loop
+    const int hcol = 32 * wave + li;
+    const float bias1 = (a.b1 && hcol < hid) ? a.b1[hcol] : 0.f;
+    const int hrow = 16 * wave + l16;                                         // the row this lane owns in the classifier stage (wave < NRB)
+    const int grow = min(r0 + hrow, B - 1);
+    const float tf = (wave < NRB) ? a.src.labels[src_row(a.src, cur, grow)] : 0.f;
+    float4 w2a[8];                                                            // logits' A operand: W2[class l16][16 u + 4 g4 ..]
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = 16 * u + 4 * g4;
+        const float4 v = *reinterpret_cast<const float4 *>(a.w2 + (long)min(l16, C - 1) * hid + min(k, hid - 4));
+        w2a[u] = k < hid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float b2v[4], w2b[2][4];                                                  // b2[class 4 g4 + e]; dH's B operand: W2[class 4 g4 + s][col]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int cls = min(4 * g4 + e, C - 1);
+        b2v[e] = a.b2 ? a.b2[cls] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) w2b[tt][e] = a.w2[(long)cls * hid + min(32 * wave + 16 * tt + l16, hid - 1)];
+    }
+
+    const int nfull = in_f / M2_BK, ktail = in_f - nfull * M2_BK;
+    // the ragged last chunk goes through registers (zero fill beyond in_f), requested first: it is the oldest load in flight
+    float4 ta[NI], tb[4];
+    if (ktail) {
+        const int k0 = nfull * M2_BK;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int row = 8 * (4 * j + wave) + (lane >> 3), mq = (lane & 7) ^ m2_swz(row);
+            const bool in = mq * 4 < ktail;
+            const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src.x) + (unsigned)a_voff[j] - (unsigned)(mq << 4) +
+                                                               (unsigned)(k0 + (in ? mq * 4 : 0)) * 4u);
+            ta[j] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 8 * (4 * j + wave) + (lane >> 3), mq = (lane & 7) ^ m2_swz(row);
+            const bool in = mq * 4 < ktail;
+            const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.w1) + (unsigned)b_voff[j] - (unsigned)(mq << 4) +
+                                                               (unsigned)(k0 + (in ? mq * 4 : 0)) * 4u);
+            tb[j] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto fetch = [&](int it, int stage) {
+        const int k0 = it * M2_BK;
+        const unsigned st = lds0 + (unsigned)(stage * STG) * 4u;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) lds_dma16(rs_x, st + 1024u * (unsigned)(4 * j + wave_u), a_voff[j], k0 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16(rs_w, st + (unsigned)A_T * 4u + 1024u * (unsigned)(4 * j + wave_u), b_voff[j], k0 * 4);
+    };
+
+    floatx16 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    // this lane's LDS addresses: row (32 i + li) of X, row (32 wave + li) of W1; k quad 2 r + lk of round r, swizzled
+    int ao[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int ar = 32 * i + li;
+        ao[i] = ar * M2_BK + ((lk ^ m2_swz(ar)) << 2);
+    }
+    const int br = 32 * wave + li;
+    const int bo = br * M2_BK + ((lk ^ m2_swz(br)) << 2);
+
+    // eight k per round: lane half lk holds k = 8 r + 4 lk + e of its row; the operands of round r + 1 are requested before the MFMAs of round r
+    auto contract = [&](const float *as, const float *bs, int nr) {
+        float4 af[2][NI], bf[2];
+#define M2_REQ(SET, RR)                                                                       \
+    {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) af[SET][i] = *reinterpret_cast<const float4 *>(as + (ao[i] ^ ((RR) << 3))); \
+        bf[SET] = *reinterpret_cast<const float4 *>(bs + (bo ^ ((RR) << 3)));                 \
+    }
+#define M2_MFMA(CS, E) \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CS][i].E, bf[CS].E, acc[i], 0, 0, 0);
+        M2_REQ(0, 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cs = r & 1;
+            if (r < nr) {
+                if (r + 1 < 4) M2_REQ(cs ^ 1, r + 1)
+                __builtin_amdgcn_sched_barrier(0);
+                M2_MFMA(cs, x)
+                M2_MFMA(cs, y)
+                M2_MFMA(cs, z)
+                M2_MFMA(cs, w)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef M2_REQ
+#undef M2_MFMA
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nfull) fetch(s, s);
+    int stage = 0;
+    for (int it = 0; it < nfull; ++it) {
+        // chunk `it` has landed once only the NS - 2 fetches issued after it are still in flight (fewer were issued near the end: wait for all)
+        if (it + NS - 1 <= nfull) wait_vmcnt<(NS - 2) * L>();
+        else wait_vmcnt<0>();
+        lds_barrier();                                      // ... in every wave; and every wave is done with the stage refilled next
+        if (it == 0) M2_STAMP(1, blockIdx.x == 0);
+        const int nxt = it + NS - 1;
+        if (nxt < nfull) fetch(nxt, stage == 0 ? NS - 1 : stage - 1);
+        contract(smem + stage * STG, smem + stage * STG + A_T, 4);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    if (ktail) {
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) *reinterpret_cast<float4 *>(smem + 256 * (4 * j + wave) + 4 * lane) = ta[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(smem + A_T + 256 * (4 * j + wave) + 4 * lane) = tb[j];
+        lds_barrier();
+        contract(smem, smem + A_T, (ktail + 7) / 8);
+    }
+    lds_barrier();
+
+    M2_STAMP(2, blockIdx.x == 0);
+    // ---- epilogue: the staging buffers are dead; H, dlogits and two scalars per wave live in their place ----
+    float *Hs = smem;                           // [RT][M2_LDH]
+    float *D3S = Hs + RT * M2_LDH;              // [RT][20]: dlogits [row][class], zero for classes >= C and rows >= batch
+    float *sc = D3S + RT * 20;                  // [4][2]: the waves' NLL / hit sums
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;     // C/D map of 32x32x2
+            float v = acc[i][e] + bias1;
+            v = (v > 0.f && hcol < hid) ? v : 0.f;                         // activation.rs:10-12; columns beyond hid hold zeros
+            Hs[row * M2_LDH + hcol] = v;
+        }
+    lds_barrier();
+    // logits^T[class 4 g4 + e][row l16] = W2 . H^T + b2, the row's softmax cross-entropy (wave w: rows 16 w ..)
+    if (wave < NRB) {
+        const float *hp = Hs + hrow * M2_LDH + 4 * g4;
+        floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 h = *reinterpret_cast<const float4 *>(hp + 16 * u);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[u].x, h.x, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[u].y, h.y, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[u].z, h.z, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[u].w, h.w, c3, 0, 0, 0);
+        }
+        float lg[4], dl[4], nll_row;
+        int bi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lg[e] = 4 * g4 + e < C ? ((c0[e] + c1[e]) + (c2[e] + c3[e])) + b2v[e] : -INFINITY;
+        tail_row_softmax(lg, g4, C, tf, 1.0f / (float)B, dl, nll_row, bi);
+        const bool real = r0 + hrow < B;
+        *reinterpret_cast<float4 *>(D3S + hrow * 20 + 4 * g4) = real ? make_float4(dl[0], dl[1], dl[2], dl[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float ns = real ? nll_row : 0.f, hs = (real && fabsf((float)bi - tf) < 1e-6f) ? 1.f : 0.f;   // loss.rs:283
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {                               // a fixed tree over the 16 rows (lanes 0..15)
+            ns += __shfl_down(ns, off, 16);
+            hs += __shfl_down(hs, off, 16);
+        }
+        if (lane == 0) {
+            sc[2 * wave] = ns;
+            sc[2 * wave + 1] = hs;
+        }
+    }
+    lds_barrier();
+    M2_STAMP(3, blockIdx.x == 0);
+    float *part = a.part + (long)blockIdx.x * a.part_stride;
+    const int o_db1 = C * hid, o_db2 = o_db1 + hid, o_nll = o_db2 + 16;
+    // wave w owns hidden columns 32 w .. 32 w + 31 of ALL the tile's rows: dZ1 = (dlogits W2) * [H > 0] (ops.rs:254-265, 358-369), its
+    // column sums (db1, tensor.rs:686-691) and the tile's share of dW2 = dlogits^T H (ops.rs:266-294)
+    if (32 * wave < hid) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int col = 32 * wave + 16 * tt + l16;
+            float colsum = 0.f;
+            floatx4 dw2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float4 d = *reinterpret_cast<const float4 *>(D3S + (16 * rb + l16) * 20 + 4 * g4);   // A: dl[row l16][class 4 g4 + s]
+                floatx4 dh = {0.f, 0.f, 0.f, 0.f};
+                dh = __builtin_amdgcn_mfma_f32_16x16x4f32(d.x, w2b[tt][0], dh, 0, 0, 0);
+                dh = __builtin_amdgcn_mfma_f32_16x16x4f32(d.y, w2b[tt][1], dh, 0, 0, 0);
+                dh = __builtin_amdgcn_mfma_f32_16x16x4f32(d.z, w2b[tt][2], dh, 0, 0, 0);
+                dh = __builtin_amdgcn_mfma_f32_16x16x4f32(d.w, w2b[tt][3], dh, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * rb + 4 * g4 + e;                       // dh[e] = dH[row][col]
+                    const float hv = Hs[row * M2_LDH + col];
+                    const float dz = hv > 0.f ? dh[e] : 0.f;
+                    a.dz1[(long)(r0 + row) * hid + col] = dz;                   // (zeros for rows >= batch: launch 2 contracts whole 32-row chunks)
+                    colsum += dz;
+                    // dW2's operands of k-step e: A(class l16, row) and B(row, col) -- the row of this very element
+                    dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(D3S[row * 20 + l16], hv, dw2, 0, 0, 0);
+                }
+            }
+            colsum += __shfl_xor(colsum, 16, 64);
+            colsum += __shfl_xor(colsum, 32, 64);
+            if (lane < 16) part[o_db1 + col] = colsum;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g4 + e < C) part[(4 * g4 + e) * hid + col] = dw2[e];      // dw2[e] = dW2[class 4 g4 + e][col]
+        }
+    }
+    if (t < 16) {                                                             // db2 (tensor.rs:686-691): rows in order
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < RT; ++r) s += D3S[r * 20 + t];
+        part[o_db2 + t] = s;
+    }
+    if (t == 0) {
+        float ns = 0.f, hs = 0.f;
+#pragma unroll
+        for (int w = 0; w < NRB && w < 4; ++w) {
+            ns += sc[2 * w];
+            hs += sc[2 * w + 1];
+        }
+        part[o_nll] = ns;
+        part[o_nll + 1] = hs;
+    }
+    M2_STAMP(4, blockIdx.x == 0);
+    M2_STAMP(5, blockIdx.x == gridDim.x - 1);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------- launch 2
+struct Mlp2DwArgs {
+    RowSource src;
+    const float *dz1;     // [rows_pad][hid]
+    unsigned dz_bytes;
+    int rows_pad, batch, in_f, hid;
+    float *partial;       // [kz][hid][in_f]
+    int tiles_n, kz, kslice;   // kslice a multiple of 32
+};
+
+// dW1[m = hidden][n = in] over rows [z kslice, (z + 1) kslice): A(m, k) = dZ1[k][m], B(k, n) = X[row k][n] -- both m / n-contiguous, staged as
+// they lie in memory ([32 k][128] images, gemm.hip's m/n-contiguous form: ds_read_b32, lanes on consecutive m / n).  The last n tile reads
+// beyond a row's end (into the next row; beyond the buffer: zeros): those columns are never stored.
+template <int NS, int WGS, bool INDEXED>
+__global__ __launch_bounds__(256, WGS) void mlp2_dw1_kernel(Mlp2DwArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TS = 128, T_T = TS * M2_BK, STG = 2 * T_T, L = 8;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lk = lane >> 5;
+    // block b runs on XCD b % 8: every XCD takes a contiguous run of (K slice, n tile) pairs, n innermost -- the tiles of a slice share its dZ1 rows
+    const int nwg = a.tiles_n * a.kz, bid = blockIdx.x;
+    const int xcd = bid % kNumXCD, q = nwg / kNumXCD, rmd = nwg % kNumXCD;
+    const int w = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + bid / kNumXCD;
+    const int z = w / a.tiles_n, tn = w % a.tiles_n;
+    const int n0 = tn * TS, in_f = a.in_f, hid = a.hid;
+    const int kbeg = z * a.kslice, kend = min(a.rows_pad, kbeg + a.kslice), nt = (kend - kbeg) / M2_BK;
+    // The dataset rows of this K slice, resolved once into LDS (behind the ring): row r of the batch is idx[(cursor + r) % n].  The cursor was
+    // advanced by the PREVIOUS step's finish launch; positions are cursor % n + r < 2 n (batch <= n, host-checked).  In the loop a lane then
+    // picks its rows' entries with ds_read -- a scalar or vector load there would sit in the same in-order / unordered counters as the ring's
+    // LDS-DMA and the operand reads, and waiting for it would drain them.
+    int *rows_l = reinterpret_cast<int *>(smem + NS * STG);
+    {
+        const int n_idx = INDEXED ? (int)a.src.n_idx : 1;
+        const int cur = (INDEXED && a.src.cursor) ? (int)(sload(a.src.cursor) % a.src.n_idx) : 0;
+        for (int i = t; i < nt * M2_BK; i += 256) {
+            const int row = min(kbeg + i, a.batch - 1);
+            const int p = cur + row;
+            rows_l[i] = INDEXED ? a.src.idx[p >= n_idx ? p - n_idx : p] : row;
+        }
+    }
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    // staging: instruction j of wave w fills 16-byte units 64 (4 j + w) .. + 63 of the image = k rows 2 (4 j + w) and + 1, 32 quads each.
+    // The two rows' dataset indices are wave-uniform: scalar loads, a chunk ahead of the fetch that needs them.
+    int a_voff[4];
+    const int quad = lane & 31, upper = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_voff[j] = (int)((unsigned)(2 * (4 * j + wave) + upper) * (unsigned)hid * 4u + (unsigned)(quad << 4));
+    const i32x4 rs_a = make_rsrc(a.dz1, a.dz_bytes), rs_x = make_rsrc(a.src.x, a.src.x_bytes);
+    const unsigned lds0 = lds_addr(smem);
+    const unsigned xq = (unsigned)(n0 + quad * 4) * 4u;
+    auto fetch = [&](int it, int stage) {
+        const int k0 = kbeg + it * M2_BK;
+        const unsigned st = lds0 + (unsigned)(stage * STG) * 4u;
+        int srow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) srow[j] = rows_l[it * M2_BK + 2 * (4 * j + wave) + upper];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lds_dma16(rs_a, st + 1024u * (unsigned)(4 * j + wave), a_voff[j], (int)((unsigned)k0 * (unsigned)hid * 4u));
+            lds_dma16(rs_x, st + (unsigned)T_T * 4u + 1024u * (unsigned)(4 * j + wave), (int)((unsigned)srow[j] * (unsigned)in_f * 4u + xq), 0);
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int ao[2], bo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ao[i] = 4 * lk * TS + wm + 32 * i + li;
+        bo[i] = 4 * lk * TS + wn + 32 * i + li;
+    }
+    M2_STAMP(6, blockIdx.x == 0);
+    __syncthreads();                              // rows_l is complete
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nt) fetch(s, s);
+    int stage = 0;
+    for (int it = 0; it < nt; ++it) {
+        if (it + NS - 1 <= nt) wait_vmcnt<(NS - 2) * L>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+        const int nxt = it + NS - 1;
+        if (nxt < nt) fetch(nxt, stage == 0 ? NS - 1 : stage - 1);
+        const float *as = smem + stage * STG, *bs = as + T_T;
+        float4 af[2][2], bf[2][2];
+#define M2_FRAG(S, O, RR) make_float4((S)[(O) + (8 * (RR)) * TS], (S)[(O) + (8 * (RR) + 1) * TS], (S)[(O) + (8 * (RR) + 2) * TS], (S)[(O) + (8 * (RR) + 3) * TS])
+#define M2_REQ(SET, RR)                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {      \
+        af[SET][i] = M2_FRAG(as, ao[i], RR);             \
+        bf[SET][i] = M2_FRAG(bs, bo[i], RR);             \
+    }
+#define M2_MFMA(CS, E)                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CS][i].E, bf[CS][j].E, acc[i][j], 0, 0, 0);
+        M2_REQ(0, 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cs = r & 1;
+            if (r + 1 < 4) { M2_REQ(cs ^ 1, r + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            M2_MFMA(cs, x)
+            M2_MFMA(cs, y)
+            M2_MFMA(cs, z)
+            M2_MFMA(cs, w)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef M2_MFMA
+#undef M2_REQ
+#undef M2_FRAG
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    M2_STAMP(7, blockIdx.x == 0);
+    float *out = a.partial + (long)z * hid * in_f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (row < hid && col < in_f) out[(long)row * in_f + col] = acc[i][j][e];
+            }
+        }
+    M2_STAMP(8, blockIdx.x == 0);
+    M2_STAMP(9, blockIdx.x == gridDim.x - 1);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------- launch 3
+struct Mlp2FinishArgs {
+    const float *partial;   // [kz][hid * in_f]
+    const float *part;      // [n_blk][part_stride]
+    int kz, n_blk, part_stride, batch, in_f, hid, c;
+    float *dw1, *db1, *dw2, *db2, *loss, *ncorrect, *metrics;
+    int64_t capacity;
+    int64_t *state;
+    int64_t advance;
+    AdamDev w1a, b1a, w2a, b2a;
+    int w1_blocks;
+};
+
+__device__ __forceinline__ void m2_apply(const AdamDev &ad, long i, float g) {
+    if (ad.p) adam_update(ad.p, ad.m, ad.v, i, g, adam_dev_step(ad), ad.beta1, ad.beta2, ad.eps, ad.wd);
+}
+
+// Two roles.  dW1: a workgroup owns 64 float4 of the gradient; its four waves add the K slices z = wave, wave + 4, ... and the first
+// wave adds the four sums in wave order.  The row blocks' partial sums: a workgroup owns 16 of the elements, 16 threads per element add the
+// blocks b = sub, sub + 16, ..., the first adds the 16 sums in order.  (One thread per element adding 64 slices / 256 blocks one after
+// the other is a chain of dependent round trips: 62.6 us at batch 16 384 for 26 MB.)
+__global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
+    __shared__ float4 sh4[4][64];
+    const int bid = blockIdx.x, t = threadIdx.x;
+    M2_STAMP(10, blockIdx.x == 0);
+    M2_STAMP(11, blockIdx.x == gridDim.x - 1);
+    if (bid < a.w1_blocks) {
+        const long mn = (long)a.hid * a.in_f, i0 = ((long)bid * 64 + (t & 63)) * 4;
+        const int zg = t >> 6;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 < mn) {
+            int z = zg;
+            for (; z + 12 < a.kz; z += 16) {                 // four independent loads in flight per thread
+                const float4 v0 = *reinterpret_cast<const float4 *>(a.partial + (long)z * mn + i0);
+                const float4 v1 = *reinterpret_cast<const float4 *>(a.partial + (long)(z + 4) * mn + i0);
+                const float4 v2 = *reinterpret_cast<const float4 *>(a.partial + (long)(z + 8) * mn + i0);
+                const float4 v3 = *reinterpret_cast<const float4 *>(a.partial + (long)(z + 12) * mn + i0);
+                s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x;
+                s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+                s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z;
+                s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+            }
+            for (; z < a.kz; z += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(a.partial + (long)z * mn + i0);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        sh4[zg][t & 63] = s;
+        __syncthreads();
+        if (zg != 0 || i0 >= mn) return;
+        const float4 p1 = sh4[1][t], p2 = sh4[2][t], p3 = sh4[3][t];
+        s.x = ((s.x + p1.x) + p2.x) + p3.x;
+        s.y = ((s.y + p1.y) + p2.y) + p3.y;
+        s.z = ((s.z + p1.z) + p2.z) + p3.z;
+        s.w = ((s.w + p1.w) + p2.w) + p3.w;
+        *reinterpret_cast<float4 *>(a.dw1 + i0) = s;
+        if (a.w1a.p) {
+            const float step = adam_dev_step(a.w1a);
+            adam_update(a.w1a.p, a.w1a.m, a.w1a.v, i0, s.x, step, a.w1a.beta1, a.w1a.beta2, a.w1a.eps, a.w1a.wd);
+            adam_update(a.w1a.p, a.w1a.m, a.w1a.v, i0 + 1, s.y, step, a.w1a.beta1, a.w1a.beta2, a.w1a.eps, a.w1a.wd);
+            adam_update(a.w1a.p, a.w1a.m, a.w1a.v, i0 + 2, s.z, step, a.w1a.beta1, a.w1a.beta2, a.w1a.eps, a.w1a.wd);
+            adam_update(a.w1a.p, a.w1a.m, a.w1a.v, i0 + 3, s.w, step, a.w1a.beta1, a.w1a.beta2, a.w1a.eps, a.w1a.wd);
+        }
+        return;
+    }
+    // the row blocks' partial sums
+    float(*sh)[16][2] = reinterpret_cast<float(*)[16][2]>(&sh4[0][0]);       // [sub][element][value, second value]
+    const int el = t & 15, sub = t >> 4, e = (bid - a.w1_blocks) * 16 + el;
+    const int o_db1 = a.c * a.hid, o_db2 = o_db1 + a.hid, o_nll = o_db2 + 16;
+    float s = 0.f, s2 = 0.f;
+    if (e <= o_nll) {
+#pragma unroll 4
+        for (int b = sub; b < a.n_blk; b += 16) {
+            s += a.part[(long)b * a.part_stride + e];
+            if (e == o_nll) s2 += a.part[(long)b * a.part_stride + e + 1];
+        }
+    }
+    sh[sub][el][0] = s;
+    sh[sub][el][1] = s2;
+    __syncthreads();
+    if (sub != 0 || e > o_nll) return;
+#pragma unroll
+    for (int u = 1; u < 16; ++u) {
+        s += sh[u][el][0];
+        s2 += sh[u][el][1];
+    }
+    if (e < o_db1) {
+        a.dw2[e] = s;
+        m2_apply(a.w2a, e, s);
+    } else if (e < o_db2) {
+        if (a.db1) {
+            a.db1[e - o_db1] = s;
+            m2_apply(a.b1a, e - o_db1, s);
+        }
+    } else if (e < o_nll) {
+        if (a.db2 && e - o_db2 < a.c) {
+            a.db2[e - o_db2] = s;
+            m2_apply(a.b2a, e - o_db2, s);
+        }
+    } else {
+        const float l = s / (float)a.batch;       // loss.rs:164
+        a.loss[0] = l;
+        if (a.ncorrect) a.ncorrect[0] = s2;
+        if (a.metrics) {                          // th_log_step
+            const int64_t s0 = a.state[0], s1 = a.state[1];
+            const int64_t slot = s0 < a.capacity ? s0 : s0 % a.capacity;
+            a.metrics[2 * slot] = l;
+            a.metrics[2 * slot + 1] = s2;
+            a.state[0] = s0 + 1;
+            a.state[1] = s1 + a.advance;
+        }
+    }
+}
+
+thread_local long t_mlp2_calls = 0;
+
+static int m2_rows_per_block(int batch) {
+    static const int forced = [] { const char *e = getenv("TAPER_MLP2_RT"); return e ? atoi(e) : 0; }();
+    if (forced == 32 || forced == 64) return forced;
+    return batch >= 12288 ? 64 : 32;            // 64-row tiles once they fill the chip (>= 192 workgroups), 32-row tiles below
+}
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" {
+
+int th_mlp2_xent_supported(int batch, int in_features, int hidden, int classes, int64_t n_rows) {
+    return batch >= 32 && in_features >= 32 && in_features % 4 == 0 && hidden >= 32 && hidden <= 128 && hidden % 32 == 0 && classes >= 1 &&
+                   classes <= 16 && n_rows >= 1 && (double)n_rows * in_features * 4.0 < 2147483648.0 && (double)(batch + 64) * hidden * 4.0 < 2147483648.0
+               ? 1 : 0;
+}
+
+int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_features, int hidden, int classes, const float *d_w1,
+                 const float *d_b1, const float *d_w2, const float *d_b2, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2,
+                 float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                 int32_t *d_tick, const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse, const th_adam_fuse *w2_fuse,
+                 const th_adam_fuse *b2_fuse) {
+    TH_REQUIRE(ctx && src && src->d_rows && src->d_labels && d_w1 && d_w2 && d_dw1 && d_dw2 && d_loss, "th_mlp2_xent: null argument");
+    TH_REQUIRE(th_mlp2_xent_supported(batch, in_features, hidden, classes, src->n_rows),
+               "th_mlp2_xent: needs batch >= 32, in_features a multiple of 4 (>= 32), hidden a multiple of 32 up to 128, classes <= 16, "
+               "rows * in_features * 4 < 2^31 (got %d, %d, %d, %d, %ld rows)", batch, in_features, hidden, classes, (long)src->n_rows);
+    TH_REQUIRE(!src->d_indices || (src->n_indices >= batch && src->n_indices < (1LL << 30)), "th_mlp2_xent: the index vector must hold at least one batch (and fewer than 2^30 entries)");
+    TH_REQUIRE(src->d_indices || src->n_rows >= batch, "th_mlp2_xent: a dense row block must hold the batch");
+    TH_REQUIRE((((uintptr_t)src->d_rows | (uintptr_t)d_w1 | (uintptr_t)d_w2 | (uintptr_t)d_dw1) & 15) == 0, "th_mlp2_xent: rows, W1, W2 and dW1 must be 16-byte aligned");
+    TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp2_xent: metrics need d_state and a capacity");
+    TH_REQUIRE(!(b1_fuse && b1_fuse->d_p) || d_db1, "th_mlp2_xent: a fused bias update needs d_db1");
+    TH_REQUIRE(!(b2_fuse && b2_fuse->d_p) || d_db2, "th_mlp2_xent: a fused bias update needs d_db2");
+    const int RT = m2_rows_per_block(batch);
+    const int n_blk = ceil_div(batch, RT), rows_pad = n_blk * RT;
+    const int stride = (classes * hidden + hidden + 16 + 2 + 3) & ~3;
+    const int tiles_n = ceil_div(in_features, 128);
+    // K slices of launch 2: two workgroups per CU (two 64 KB double buffers), slices of at least 256 rows (TAPER_MLP2_KZ overrides the count)
+    static const int kz_forced = [] { const char *e = getenv("TAPER_MLP2_KZ"); return e ? atoi(e) : 0; }();
+    static const int dw_wgs = [] { const char *e = getenv("TAPER_MLP2_DW"); return e && atoi(e) % 10 == 1 ? 1 : 2; }();
+    int kz = kz_forced > 0 ? kz_forced : ceil_div(dw_wgs * kNumCU, tiles_n);
+    const int kz_max = rows_pad / 256 > 0 ? rows_pad / 256 : 1;
+    if (kz > kz_max) kz = kz_max;
+    int kslice = ceil_div(ceil_div(rows_pad, kz), M2_BK) * M2_BK;
+    kz = ceil_div(rows_pad, kslice);
+    const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_partial = (size_t)kz * hidden * in_features;
+    void *ws = nullptr;
+    if (th_malloc(ctx, (n_dz + n_part + n_partial) * sizeof(float), &ws)) return 1;
+    float *dz1 = (float *)ws, *part = dz1 + n_dz, *partial = part + n_part;
+
+    RowSource rs{src->d_rows, src->d_labels, src->d_indices, src->d_indices ? src->d_cursor : nullptr, src->n_indices,
+                 (unsigned)((size_t)src->n_rows * in_features * 4)};
+    Mlp2RowsArgs r{};
+    r.src = rs;
+    r.w1 = d_w1; r.b1 = d_b1; r.w2 = d_w2; r.b2 = d_b2;
+    r.batch = batch; r.in_f = in_features; r.hid = hidden; r.c = classes;
+    r.dz1 = dz1; r.part = part; r.part_stride = stride; r.tick = d_tick;
+    constexpr int NS_ROWS = 4;
+    if (RT == 64) {
+        const size_t lds = (size_t)NS_ROWS * (64 + 128) * M2_BK * sizeof(float);
+        static bool attr = false;
+        if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)mlp2_rows_kernel<64, NS_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL((mlp2_rows_kernel<64, NS_ROWS>), dim3(n_blk), dim3(256), lds, ctx->stream, r);
+    } else {
+        const size_t lds = (size_t)NS_ROWS * (32 + 128) * M2_BK * sizeof(float);
+        static bool attr = false;
+        if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)mlp2_rows_kernel<32, NS_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL((mlp2_rows_kernel<32, NS_ROWS>), dim3(n_blk), dim3(256), lds, ctx->stream, r);
+    }
+    TH_LAUNCH_CHECK();
+
+    Mlp2DwArgs d{};
+    d.src = rs;
+    d.dz1 = dz1; d.dz_bytes = (unsigned)(n_dz * 4);
+    d.rows_pad = rows_pad; d.batch = batch; d.in_f = in_features; d.hid = hidden;
+    d.partial = partial; d.tiles_n = tiles_n; d.kz = kz; d.kslice = kslice;
+    {
+        // ring depth x workgroups per CU of launch 2 (TAPER_MLP2_DW = 41 | 31 | 22 | 32: stages, workgroups per CU; a measurement knob)
+        static const int variant = [] { const char *e = getenv("TAPER_MLP2_DW"); return e ? atoi(e) : 22; }();
+        const int ns = variant / 10 >= 2 && variant / 10 <= 4 ? variant / 10 : 4;
+        const size_t lds = (size_t)ns * 2 * 128 * M2_BK * sizeof(float) + (size_t)kslice * sizeof(int);
+#define M2_DW_LAUNCH(NS_, WGS_)                                                                                                       \
+    do {                                                                                                                              \
+        static bool attr = false;                                                                                                     \
+        if (!attr) {                                                                                                                  \
+            TH_HIP(hipFuncSetAttribute((const void *)mlp2_dw1_kernel<NS_, WGS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));  \
+            TH_HIP(hipFuncSetAttribute((const void *)mlp2_dw1_kernel<NS_, WGS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10)); \
+            attr = true;                                                                                                              \
+        }                                                                                                                             \
+        if (rs.idx) hipLaunchKernelGGL((mlp2_dw1_kernel<NS_, WGS_, true>), dim3(tiles_n * kz), dim3(256), lds, ctx->stream, d);       \
+        else hipLaunchKernelGGL((mlp2_dw1_kernel<NS_, WGS_, false>), dim3(tiles_n * kz), dim3(256), lds, ctx->stream, d);             \
+    } while (0)
+        if (variant == 31) M2_DW_LAUNCH(3, 1);
+        else if (variant == 32) M2_DW_LAUNCH(3, 2);
+        else if (variant == 41) M2_DW_LAUNCH(4, 1);
+        else M2_DW_LAUNCH(2, 2);
+#undef M2_DW_LAUNCH
+    }
+    TH_LAUNCH_CHECK();
+
+    Mlp2FinishArgs f{};
+    f.partial = partial; f.part = part; f.kz = kz; f.n_blk = n_blk; f.part_stride = stride; f.batch = batch; f.in_f = in_features;
+    f.hid = hidden; f.c = classes;
+    f.dw1 = d_dw1; f.db1 = d_db1; f.dw2 = d_dw2; f.db2 = d_db2; f.loss = d_loss; f.ncorrect = d_ncorrect; f.metrics = d_metrics;
+    f.capacity = metrics_capacity; f.state = d_state; f.advance = advance;
+    f.w1a = make_adam_dev(w1_fuse); f.b1a = make_adam_dev(b1_fuse); f.w2a = make_adam_dev(w2_fuse); f.b2a = make_adam_dev(b2_fuse);
+    f.w1_blocks = ceil_div((long)hidden * in_features, 256);
+    const int tail_blocks = ceil_div(classes * hidden + hidden + 16 + 1, 16);
+    hipLaunchKernelGGL(mlp2_finish_kernel, dim3(f.w1_blocks + tail_blocks), dim3(256), 0, ctx->stream, f);
+    TH_LAUNCH_CHECK();
+    ++t_mlp2_calls;
+    return th_free(ctx, ws);
+}
+
+int th_debug_mlp2_calls(int64_t *out) {
+    if (out) *out = t_mlp2_calls;
+    return 0;
+}
+
+#ifdef TH_PROFILE
+int th_debug_mlp2_prof(th_ctx *ctx, long long *h_out16) {
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(th::g_m2_prof), 16 * sizeof(long long)));
+    return 0;
+}
+#endif
+
+}  // extern "C"

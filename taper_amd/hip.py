@@ -39,6 +39,12 @@ class Mlp3Gap(C.Structure):
     _fields_ = [("d_cnt", C.c_void_p), ("d_gb", C.c_void_p), ("hw", C.c_int), ("b_fuse", C.c_void_p)]
 
 
+class RowSource(C.Structure):
+    """include/taper_hip.h: th_row_source"""
+    _fields_ = [("d_rows", C.c_void_p), ("d_labels", C.c_void_p), ("d_indices", C.c_void_p), ("d_cursor", C.c_void_p),
+                ("n_indices", C.c_int64), ("n_rows", C.c_int64)]
+
+
 class ConvStage(C.Structure):
     """include/taper_hip.h: th_conv_stage"""
     _fields_ = [("d_w", C.c_void_p), ("d_bias", C.c_void_p), ("c_out", C.c_int), ("post", C.c_int)]

@@ -1,0 +1,153 @@
+"""th_mlp2_xent -- the large-batch step of Linear + ReLU, Linear, softmax cross-entropy in three launches (rows / dW1 K slices / fixed-order
+finish with Adam), reading the batch's rows through the loader's index vector -- against the oracle's unfused chain
+(/root/reference/src/nn.rs:54-60, src/loss.rs:101-195, 271-290, src/ops.rs:238-294, 358-369, src/tensor.rs:574-587, 674-694,
+src/optim.rs:83-113, src/data/mnist.rs:277-310)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import margins
+from tests.test_gpu_fused import _adam_ref, close, RTOL
+from tests.test_gpu_mlp_tail import oracle_tail
+from taper_amd.hip import AdamFuse, RowSource
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from taper_amd import hip
+    c = hip.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _params(rng, inf, hid, c):
+    w1 = rng.uniform(-1, 1, (hid, inf)).astype(np.float32) * np.float32(np.sqrt(2.0 / inf))
+    b1 = rng.uniform(-0.1, 0.1, hid).astype(np.float32)
+    w2 = rng.uniform(-0.3, 0.3, (c, hid)).astype(np.float32)
+    b2 = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+    return w1, b1, w2, b2
+
+
+def _call(ctx, src, batch, inf, hid, c, dev, fuses=(None, None, None, None), tick=None, log=None):
+    out = dict(dw1=ctx.empty(hid * inf), db1=ctx.empty(hid), dw2=ctx.empty(c * hid), db2=ctx.empty(c), loss=ctx.empty(1), nc=ctx.empty(1))
+    metrics, cap, state, adv = log if log else (None, 0, None, 0)
+    ctx.call("th_mlp2_xent", C.byref(src), batch, inf, hid, c, dev["w1"], dev["b1"], dev["w2"], dev["b2"], out["dw1"], out["db1"], out["dw2"],
+             out["db2"], out["loss"], out["nc"], metrics, cap, state, adv, tick, *[C.byref(f) if f is not None else None for f in fuses])
+    return out
+
+
+def _check_grads(ctx, out, ref, inf, hid, c, name):
+    loss = ctx.download(out["loss"], 1)[0]
+    assert loss == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
+    assert ctx.download(out["nc"], 1)[0] == ref["ncorrect"]                 # index work: exact
+    for k, shape in (("dw1", (hid, inf)), ("db1", (hid,)), ("dw2", (c, hid)), ("db2", (c,))):
+        got = ctx.download(out[k], shape)
+        close(got, np.asarray(ref[k]).reshape(shape), atol=1e-6)
+        margins.check(f"{k}", got, np.asarray(ref[k]).reshape(shape), 1e-4, test=name)
+
+
+DENSE = [(1024, 784, 128, 10), (4096, 784, 128, 10), (1000, 100, 64, 5), (33, 36, 32, 16), (5000, 784, 96, 10), (2048, 64, 128, 3),
+         (12288 + 5, 784, 128, 10), (16384, 784, 128, 10)]
+
+
+@pytest.mark.parametrize("batch,inf,hid,c", DENSE)
+def test_mlp2_dense_rows(ctx, O, batch, inf, hid, c):
+    rng = np.random.default_rng(batch + inf + hid + c)
+    x = (rng.integers(0, 256, (batch, inf)) * (rng.uniform(0, 1, (batch, inf)) < 0.3)).astype(np.float32) / np.float32(255.0)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    w1, b1, w2, b2 = _params(rng, inf, hid, c)
+    ref = oracle_tail(O, x, w1, b1, w2, b2, y)
+    dev = dict(w1=ctx.upload(w1), b1=ctx.upload(b1), w2=ctx.upload(w2), b2=ctx.upload(b2))
+    dx, dy = ctx.upload(x), ctx.upload(y)
+    src = RowSource(int(dx), int(dy), None, None, 0, batch)
+    calls = C.c_int64()
+    from taper_amd._lib import hip as lib
+    lib.th_debug_mlp2_calls(C.byref(calls))
+    out = _call(ctx, src, batch, inf, hid, c, dev)
+    _check_grads(ctx, out, ref, inf, hid, c, "test_mlp2_dense_rows")
+    after = C.c_int64()
+    lib.th_debug_mlp2_calls(C.byref(after))
+    assert after.value == calls.value + 1
+    # deterministic: fixed-order sums, no atomics
+    out2 = _call(ctx, src, batch, inf, hid, c, dev)
+    for k, n in (("dw1", hid * inf), ("dw2", c * hid), ("db1", hid), ("db2", c), ("loss", 1)):
+        np.testing.assert_array_equal(ctx.download(out[k], n), ctx.download(out2[k], n))
+    for k, a in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2)):          # parameters are only read without a fuse
+        np.testing.assert_array_equal(ctx.download(dev[k], a.shape), a)
+
+
+@pytest.mark.parametrize("n_rows,batch,cursor", [(3000, 256, 0), (3000, 256, 2900), (5000, 2048, 4000), (60000, 4096, 57000)])
+def test_mlp2_rows_through_the_index_vector(ctx, O, n_rows, batch, cursor):
+    """rows idx[(cursor + r) % n] of a resident dataset (data/mnist.rs:277-310 without the copy), wrapping at the epoch's end"""
+    inf, hid, c = 784, 128, 10
+    rng = np.random.default_rng(n_rows + batch + cursor)
+    data = (rng.integers(0, 256, (n_rows, inf)) * (rng.uniform(0, 1, (n_rows, inf)) < 0.25)).astype(np.float32) / np.float32(255.0)
+    labels = rng.integers(0, c, n_rows).astype(np.float32)
+    idx = rng.permutation(n_rows).astype(np.int32)
+    rows = idx[(cursor + np.arange(batch)) % n_rows]
+    w1, b1, w2, b2 = _params(rng, inf, hid, c)
+    ref = oracle_tail(O, data[rows], w1, b1, w2, b2, labels[rows])
+    dev = dict(w1=ctx.upload(w1), b1=ctx.upload(b1), w2=ctx.upload(w2), b2=ctx.upload(b2))
+    dd, dl, di = ctx.upload(data), ctx.upload(labels), ctx.upload(idx)
+    state = ctx.upload(np.array([3, cursor], np.int64))
+    src = RowSource(int(dd), int(dl), int(di), state.offset(8), n_rows, n_rows)
+    metrics = ctx.zeros(2 * 8)
+    out = _call(ctx, src, batch, inf, hid, c, dev, log=(metrics, 8, state, batch))
+    _check_grads(ctx, out, ref, inf, hid, c, "test_mlp2_rows_through_the_index_vector")
+    # the step log (train.rs:117-121): slot state[0], then step += 1, cursor += batch
+    np.testing.assert_array_equal(ctx.download(state, 2, np.int64), [4, cursor + batch])
+    m = ctx.download(metrics, 16)
+    assert m[6] == ctx.download(out["loss"], 1)[0] and m[7] == ref["ncorrect"]
+    # bit-identical to the same rows handed over as a dense block
+    dx, dy = ctx.upload(data[rows]), ctx.upload(labels[rows])
+    out_d = _call(ctx, RowSource(int(dx), int(dy), None, None, 0, batch), batch, inf, hid, c, dev)
+    for k, n in (("dw1", hid * inf), ("dw2", c * hid), ("db1", hid), ("db2", c), ("loss", 1), ("nc", 1)):
+        np.testing.assert_array_equal(ctx.download(out[k], n), ctx.download(out_d[k], n))
+
+
+@pytest.mark.parametrize("batch,inf,hid,c", [(1024, 784, 128, 10), (4096, 784, 128, 10), (1500, 100, 64, 7)])
+def test_mlp2_adam_in_the_finish_launch(ctx, O, batch, inf, hid, c):
+    """launch 1 opens the optimizer step (t += 1, optim.rs:84); launch 3 applies optim.rs:99-110 at that t to all four parameters"""
+    rng = np.random.default_rng(batch * 3 + hid)
+    x = rng.uniform(0, 1, (batch, inf)).astype(np.float32)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    w1, b1, w2, b2 = _params(rng, inf, hid, c)
+    ref = oracle_tail(O, x, w1, b1, w2, b2, y)
+    lr, t = 1e-3, 6
+    dev = dict(w1=ctx.upload(w1), b1=ctx.upload(b1), w2=ctx.upload(w2), b2=ctx.upload(b2))
+    mom = {k: (ctx.zeros(v.size), ctx.zeros(v.size)) for k, v in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2))}
+    tick, dlr = ctx.upload(np.array([t, 0], np.int32)), ctx.upload(np.array([lr], np.float32))
+    fuses = [AdamFuse(int(dev[k]), int(mom[k][0]), int(mom[k][1]), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4) for k in ("w1", "b1", "w2", "b2")]
+    dx, dy = ctx.upload(x), ctx.upload(y)
+    out = _call(ctx, RowSource(int(dx), int(dy), None, None, 0, batch), batch, inf, hid, c, dev, fuses=fuses, tick=tick)
+    assert ctx.download(tick, 2, np.int32)[0] == t + 1
+    _check_grads(ctx, out, ref, inf, hid, c, "test_mlp2_adam_in_the_finish_launch")
+    for k, p0, g in (("w1", w1, ref["dw1"]), ("b1", b1, ref["db1"]), ("w2", w2, ref["dw2"]), ("b2", b2, ref["db2"])):
+        p_ref, m_ref, v_ref = _adam_ref(O, p0.reshape(-1), np.asarray(g, np.float32).reshape(-1), lr, t + 1)
+        margins.check(f"{k}_after_adam", ctx.download(dev[k], p0.size), p_ref, 2e-2, lr=lr)      # (the smoke's error model: 2 % of lr)
+        margins.check(f"{k}_m", ctx.download(mom[k][0], p0.size), m_ref, 1e-4)
+        margins.check(f"{k}_v", ctx.download(mom[k][1], p0.size), v_ref, 2e-4)
+
+
+def test_mlp2_out_of_range_target_raises(ctx):
+    from taper_amd._lib import TaperError
+    rng = np.random.default_rng(5)
+    batch, inf, hid, c = 1024, 784, 128, 10
+    x = rng.uniform(0, 1, (batch, inf)).astype(np.float32)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    y[700] = 12.0
+    w1, b1, w2, b2 = _params(rng, inf, hid, c)
+    dev = dict(w1=ctx.upload(w1), b1=ctx.upload(b1), w2=ctx.upload(w2), b2=ctx.upload(b2))
+    dx, dy = ctx.upload(x), ctx.upload(y)
+    _call(ctx, RowSource(int(dx), int(dy), None, None, 0, batch), batch, inf, hid, c, dev)
+    with pytest.raises(TaperError, match="Target class 12 out of bounds for 10"):
+        ctx.sync()
