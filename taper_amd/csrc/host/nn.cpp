@@ -369,6 +369,68 @@ Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b
     return loss;
 }
 
+// TAPER_MLP2_MIN_BATCH: from this batch on a Linear + ReLU + Linear classifier steps through th_mlp2_xent (default 2048: below, the
+// launch-per-layer forms are as fast -- three dependent launches cost ~5 us each whatever they hold)
+static size_t mlp2_min_batch() {
+    static const size_t v = [] { const char *e = std::getenv("TAPER_MLP2_MIN_BATCH"); return e ? (size_t)std::max(32, atoi(e)) : (size_t)2048; }();
+    return v;
+}
+
+bool mlp2_supported(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2) {
+    if (w1.shape().size() != 2 || w2.shape().size() != 2 || w2.shape()[1] != w1.shape()[0]) return false;
+    if (!w1.get_requires_grad() || !w2.get_requires_grad() || w1.has_grad() || w2.has_grad()) return false;   // gradients are written, never accumulated
+    for (const Tensor *b : {&b1, &b2})
+        if (b->defined() && (!b->get_requires_grad() || b->has_grad())) return false;
+    if ((((uintptr_t)src.d_rows | (uintptr_t)w1.dptr() | (uintptr_t)w2.dptr()) & 15) != 0) return false;
+    if (src.d_indices && src.n_indices < (int64_t)batch) return false;
+    return th_mlp2_xent_supported((int)batch, (int)w1.shape()[1], (int)w1.shape()[0], (int)w2.shape()[0], src.n_rows) != 0;
+}
+
+Tensor mlp2_cross_entropy(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
+                          Tensor *n_correct_out, const StepLogSink *log) {
+    // nn.rs:54-60, activation.rs:10-12, loss.rs:136-195 and the backward closures of both Linear layers and the ReLU node
+    // (ops.rs:238-294, 358-369; tensor.rs:574-587, 674-694); data/mnist.rs:277-310 for the rows
+    TAPER_ASSERT(mlp2_supported(src, batch, w1, b1, w2, b2), "mlp2_cross_entropy: unsupported shapes / gradient state");
+    th_ctx *ctx = Device::ctx();
+    Adam *fa = FusedAdamScope::active();
+    if (fa && fa->has_deferred()) fa->flush_deferred();   // updates an earlier (other) step form left behind: with their own counter
+    Tensor loss = Tensor::empty({1});
+    float *nc = nullptr;
+    if (n_correct_out) {
+        *n_correct_out = Tensor::empty({1});
+        nc = n_correct_out->dptr();
+    }
+    auto slot = [](const Tensor &p) -> float * {
+        if (!p.defined()) return nullptr;
+        if (!p.grad_->buf) p.grad_->buf = Buffer::alloc(p.len());
+        p.grad_->known_zero = false;
+        return p.grad_->buf->d;
+    };
+    float *dw1 = slot(w1), *db1 = slot(b1), *dw2 = slot(w2), *db2 = slot(b2);
+    // the finish launch holds every complete gradient and no launch of the step reads a parameter after it: all four updates ride there
+    th_adam_fuse f[4];
+    const th_adam_fuse *pf[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (fa) {
+        const Tensor *ps[4] = {&w1, &b1, &w2, &b2};
+        for (int i = 0; i < 4; ++i)
+            if (ps[i]->defined() && fa->fuse_for(*ps[i], &f[i])) pf[i] = &f[i];
+    }
+    TH(th_mlp2_xent(ctx, &src, (int)batch, (int)w1.shape()[1], (int)w1.shape()[0], (int)w2.shape()[0], w1.dptr(), b1.defined() ? b1.dptr() : nullptr,
+                    w2.dptr(), b2.defined() ? b2.dptr() : nullptr, dw1, db1, dw2, db2, loss.dptr(), nc, log ? log->d_metrics : nullptr,
+                    log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0, fa ? fa->d_tick() : nullptr, pf[0], pf[1], pf[2],
+                    pf[3]));
+    loss.set_requires_grad(true);
+    Tensor p1 = w1, p2 = b1, p3 = w2, p4 = b2, out = loss;
+    Tape::push(loss, true, [p1, p2, p3, p4, out]() {
+        if (!out.has_grad()) return;
+        // the gradients were produced by the forward launches for an upstream grad of exactly 1
+        TAPER_ASSERT(out.grad_->shared_const, "mlp2_cross_entropy: only loss.backward() from the root is supported");
+        for (const Tensor *p : {&p1, &p2, &p3, &p4})
+            if (p->defined()) p->grad_->has = true;
+    });
+    return loss;
+}
+
 // Linear + ReLU, Linear + ReLU, Linear, softmax cross-entropy -- the classifier of examples/train_mnist_cnn.rs:53-61 and the whole model of
 // examples/train_mnist.rs:40-48 -- forward and backward in two launches (th_mlp3_xent): a row-parallel one (forward, loss terms, the
 // gradients of the activations down to dX) and one for every parameter gradient with Adam in the epilogues.  No launch reads a
@@ -1305,20 +1367,44 @@ EpochResult Trainer::evaluate(DataLoader &loader) {  // train.rs:147-172
 // come from the device-resident dataset through the device cursor (ONE gather launch for a
 // whole chunk of steps), and the loss kernel itself appends {loss, n_correct} to the device
 // log and advances the step / cursor state.
-void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
+bool Trainer::mlp2_step(size_t batch, int64_t n_rows) const {
+    auto *seq = dynamic_cast<Sequential *>(model.get());
+    if (!(fuse_head >= 2 && seq && seq->fuse && seq->layers.size() == 3 && sample_shape.empty()) || batch < mlp2_min_batch()) return false;
+    auto *l1 = dynamic_cast<Linear *>(seq->layers[0].get());
+    auto *l2 = dynamic_cast<Linear *>(seq->layers[2].get());
+    if (!(l1 && l2 && dynamic_cast<ReLU *>(seq->layers[1].get())) || l1->weight.shape()[1] != 784) return false;   // (the loader's rows are 784 wide)
+    return th_mlp2_xent_supported((int)batch, 784, (int)l1->weight.shape()[0], (int)l2->weight.shape()[0], n_rows) != 0;
+}
+
+void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_row_source *rows) {
     int64_t *state = reinterpret_cast<int64_t *>(state_->d);
     // Adam updates ride in the epilogues of the kernels that produce the gradients -- unless the
     // gradients still have to be all-reduced across ranks first
     FusedAdamScope scope((fuse_adam && !comm) ? optimizer.get() : nullptr);
     PoolBiasScope pool_scope(fuse_head && dynamic_cast<Sequential *>(model.get()) != nullptr);
     Tape::reset();
-    Tensor x = Tensor::from_device(d_xb, {batch, 784});
-    Tensor y = Tensor::from_device(d_yb, {batch});
-    Tensor xin = shape_input(x, sample_shape);
     StepLogSink sink{metrics_->d, (int64_t)metrics_cap_, state, (int64_t)batch,
                      FusedAdamScope::active() ? optimizer->d_tick() : nullptr};
     Tensor ncorrect, loss;
     auto *seq = dynamic_cast<Sequential *>(model.get());
+    if (rows) {
+        // Linear + ReLU + Linear at large batch: three launches for the whole step, the rows read in place (mlp2_step said so)
+        auto *l1 = dynamic_cast<Linear *>(seq->layers[0].get());
+        auto *l2 = dynamic_cast<Linear *>(seq->layers[2].get());
+        TAPER_ASSERT(l1 && l2 && mlp2_supported(*rows, batch, l1->weight, l1->bias, l2->weight, l2->bias),
+                     "Trainer: the large-batch MLP step met parameters it cannot take (gradients already present?)");
+        loss = mlp2_cross_entropy(*rows, batch, l1->weight, l1->bias, l2->weight, l2->bias, &ncorrect, &sink);
+        loss.backward();
+        if (!(comm && optimizer->step_reduced(*comm))) {
+            reduce_grads(*this);
+            optimizer->step();
+        }
+        optimizer->zero_grad();
+        return;
+    }
+    Tensor x = Tensor::from_device(d_xb, {batch, 784});
+    Tensor y = Tensor::from_device(d_yb, {batch});
+    Tensor xin = shape_input(x, sample_shape);
     Linear *last = (fuse_head && seq && !seq->layers.empty()) ? dynamic_cast<Linear *>(seq->layers.back().get()) : nullptr;
     bool used_head = false;
     Adam *adam = dynamic_cast<Adam *>(optimizer.get());
@@ -1402,7 +1488,13 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch) {
 void Trainer::enqueue_steps(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
                             size_t batch, size_t steps) {
     int64_t *state = reinterpret_cast<int64_t *>(state_->d);
-    if (d_indices == nullptr) {
+    if (mlp2_step(batch, d_indices ? n_indices : (int64_t)batch)) {
+        // the step reads its rows where they lie: through the index vector at the device cursor (every step's log advances it), or the
+        // dataset itself for the one-step epoch in index order -- no gather launch, no staging buffer
+        const th_row_source rows{d_images, d_labels, d_indices, d_indices ? state + 1 : nullptr, d_indices ? n_indices : 0,
+                                 d_indices ? n_indices : (int64_t)batch};
+        for (size_t s = 0; s < steps; ++s) enqueue_compute(nullptr, nullptr, batch, &rows);
+    } else if (d_indices == nullptr) {
         // one step over the whole dataset in index order: the "gathered" batch IS the dataset (no copy)
         enqueue_compute(const_cast<float *>(d_images), const_cast<float *>(d_labels), batch);
     } else {
@@ -1430,15 +1522,20 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     size_t nb = loader.num_batches();
     if (max_steps && max_steps < nb) nb = max_steps;
     const size_t n_full = std::min(nb, n / bs);
-    // steps per replay: graph_chunk, capped so that the gathered batches of one chunk stay within 256 MB
-    const size_t chunk = std::max<size_t>(std::min<size_t>(graph_chunk, ((size_t)1 << 26) / (bs * 784)), 1);
+    // steps per replay: graph_chunk, capped so that the gathered batches of one chunk stay within 256 MB (steps that read their rows in
+    // place -- mlp2_step -- gather nothing)
+    const bool full_in_place = mlp2_step(bs, (int64_t)n);
+    const size_t chunk = full_in_place ? std::max<size_t>(graph_chunk, 1) : std::max<size_t>(std::min<size_t>(graph_chunk, ((size_t)1 << 26) / (bs * 784)), 1);
     const float *d_img = ds.images.dptr(), *d_lab = ds.labels.dptr();
     // full batch, index order (mnist.rs:355-363 without shuffle): the gather would be an identity copy of 188 MB
     const int32_t *d_idx = (!loader.shuffled() && bs >= n && nb == 1) ? nullptr : loader.d_indices();
-    if (d_idx && (!xb_ || xb_->n < chunk * bs * 784)) {   // (the zero-copy form reads the dataset in place: no staging buffers)
+    // staging rows for the gathered forms: a chunk of full batches, and / or the last partial batch when it is too small for the in-place form
+    const size_t rem_rows = nb > n_full ? n - n_full * bs : 0;
+    const size_t stage_rows = std::max(full_in_place ? (size_t)0 : chunk * bs, (rem_rows && !mlp2_step(rem_rows, (int64_t)n)) ? rem_rows : (size_t)0);
+    if (d_idx && stage_rows && (!xb_ || xb_->n < stage_rows * 784)) {   // (the zero-copy forms read the dataset in place: no staging buffers)
         drop_graphs();
-        xb_ = Buffer::alloc(chunk * bs * 784);
-        yb_ = Buffer::alloc(chunk * bs);
+        xb_ = Buffer::alloc(stage_rows * 784);
+        yb_ = Buffer::alloc(stage_rows);
     }
     if (!state_) state_ = Buffer::alloc(4);
     // the step log is sized for the loader's whole epoch even when this call stops early (max_steps): the captured graphs

@@ -268,6 +268,11 @@ Tensor mlp3_cross_entropy(const Tensor &x, const Tensor (&w)[3], const Tensor (&
 bool mlp_tail_supported(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2);
 Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
                               const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log);
+// Linear + ReLU, Linear, cross-entropy at LARGE batch: three launches (th_mlp2_xent), the batch's rows read where they lie -- a dense block or
+// rows of the resident dataset through the loader's index vector (no gathered copy).  Trainer-internal, like the forms above.
+bool mlp2_supported(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2);
+Tensor mlp2_cross_entropy(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
+                          Tensor *n_correct_out, const StepLogSink *log);
 // n_correct_out (optional): device scalar receiving accuracy()*B from the fused kernel
 Tensor cross_entropy_loss(const Tensor &logits, const Tensor &targets, Tensor *n_correct_out = nullptr,
                           const StepLogSink *log = nullptr);  // loss.rs:136-195
@@ -733,7 +738,8 @@ class Trainer {  // train.rs:74-172
     // gathers `steps` batches with one launch, then enqueues the compute of each step
     void enqueue_steps(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
                        size_t batch, size_t steps);
-    void enqueue_compute(float *d_xb, float *d_yb, size_t batch);
+    void enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_row_source *rows = nullptr);
+    bool mlp2_step(size_t batch, int64_t n_rows) const;   // this model at this batch takes th_mlp2_xent (rows read in place)
     void drop_graphs();
     std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
     bool graph_capture_failed_ = false;

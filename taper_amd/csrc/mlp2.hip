@@ -493,6 +493,127 @@ __global__ __launch_bounds__(256, WGS) void mlp2_dw1_kernel(Mlp2DwArgs a) {
 #endif
 }
 
+// ---- launch 2, second form (default): ONE workgroup of eight waves per CU on a 128 x 112 tile -----------------------------------------
+// 784 = 7 x 112: no padded columns (the 128-wide tiles above compute 896).  The K slices hand out whole 32-row chunks, the first
+// n_chunks % kz slices one more than the rest, and 7 kz <= 256: every CU holds exactly one workgroup, all of (nearly) equal length -- the
+// 2 x 448 layout above leaves a quarter of the CUs with one workgroup and the rest with two.  Half as many slices: half the partial sums
+// written here and read by launch 3.  Eight waves keep two waves on every SIMD (one wave alone stalls its matrix pipe at every operand wait),
+// and one workgroup per CU leaves LDS for a four-stage ring (4 x 30 KB).
+//   wave w: rows m = 16 w .. 16 w + 15 of the tile, all 112 columns: seven v_mfma_f32_16x16x4_f32 accumulators.
+//   A image [32 k][128 m], m quad q of row k stored at q ^ ((k & 3) << 2): lane (r, g) of k-step s reads A[k = 4 s + g][m = m0 + r] -- the four
+//   g groups land on four different 16-bank groups.  B image [32 k][112 n] as it lies in memory: rows 4 apart are 448 floats = 0 mod 64
+//   banks + {0, 48, 32, 16} for g = 0..3: conflict-free too.
+struct Mlp2Dw8Args {
+    RowSource src;
+    const float *dz1;     // [rows_pad][hid]
+    unsigned dz_bytes;
+    int rows_pad, batch, in_f, hid;
+    float *partial;       // [kz][hid][in_f]
+    int tiles_n, kz;      // tiles of 112 columns
+};
+
+template <int NS, bool INDEXED>
+__global__ __launch_bounds__(512, 1) void mlp2_dw1_kernel8(Mlp2Dw8Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TN = 112, A_T = 128 * M2_BK, B_T = TN * M2_BK, STG = A_T + B_T;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
+    const int nwg = a.tiles_n * a.kz, bid = blockIdx.x;
+    const int xcd = bid % kNumXCD, q = nwg / kNumXCD, rmd = nwg % kNumXCD;
+    const int w = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + bid / kNumXCD;
+    const int z = w / a.tiles_n, tn = w % a.tiles_n;
+    const int n0 = tn * TN, in_f = a.in_f, hid = a.hid;
+    // whole chunks per slice: the first `extra` slices take one more
+    const int n_chunks = a.rows_pad / M2_BK, base = n_chunks / a.kz, extra = n_chunks % a.kz;
+    const int nt = base + (z < extra ? 1 : 0), kbeg = (z * base + min(z, extra)) * M2_BK;
+    int *rows_l = reinterpret_cast<int *>(smem + NS * STG);
+    {
+        const int n_idx = INDEXED ? (int)a.src.n_idx : 1;
+        const int cur = (INDEXED && a.src.cursor) ? (int)(sload(a.src.cursor) % a.src.n_idx) : 0;
+        for (int i = t; i < nt * M2_BK; i += 512) {
+            const int row = min(kbeg + i, a.batch - 1);
+            const int p = cur + row;
+            rows_l[i] = INDEXED ? a.src.idx[p >= n_idx ? p - n_idx : p] : row;
+        }
+    }
+    // staging plans.  A: 1024 16-byte units, unit u = 64 (2 wave + j) + lane: k row u >> 5, LDS quad u & 31 holds memory quad (u & 31) ^ ((krow & 3) << 2).
+    // B: 896 units, unit u = 64 i + lane (instruction i = wave, wave + 8 < 14): k row u / 28, quad u % 28.
+    int a_voff[2], b_krow[2];
+    unsigned b_q[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = 64 * (2 * wave + j) + lane, krow = u >> 5, mq = (u & 31) ^ ((krow & 3) << 2);
+        a_voff[j] = (int)((unsigned)krow * (unsigned)hid * 4u + (unsigned)(mq << 4));
+        const int ub = 64 * (wave + 8 * j) + lane;
+        b_krow[j] = ub / 28;
+        b_q[j] = (unsigned)(n0 + (ub % 28) * 4) * 4u;
+    }
+    const bool b_second = wave + 8 < 14;
+    const i32x4 rs_a = make_rsrc(a.dz1, a.dz_bytes), rs_x = make_rsrc(a.src.x, a.src.x_bytes);
+    const unsigned lds0 = lds_addr(smem);
+    auto fetch = [&](int it, int stage) {
+        const int k0 = kbeg + it * M2_BK;
+        const unsigned st = lds0 + (unsigned)(stage * STG) * 4u;
+        const int s0 = rows_l[it * M2_BK + b_krow[0]], s1 = b_second ? rows_l[it * M2_BK + b_krow[1]] : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) lds_dma16(rs_a, st + 1024u * (unsigned)(2 * wave + j), a_voff[j], (int)((unsigned)k0 * (unsigned)hid * 4u));
+        lds_dma16(rs_x, st + (unsigned)A_T * 4u + 1024u * (unsigned)wave, (int)((unsigned)s0 * (unsigned)in_f * 4u + b_q[0]), 0);
+        if (b_second) lds_dma16(rs_x, st + (unsigned)A_T * 4u + 1024u * (unsigned)(wave + 8), (int)((unsigned)s1 * (unsigned)in_f * 4u + b_q[1]), 0);
+    };
+    floatx4 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // operand addresses of k-step s: A[(4 s + g4) * 128 + ((16 wave + l16) ^ (g4 << 4))], B[(4 s + g4) * 112 + 16 i + l16]
+    const int ao = g4 * 128 + ((16 * wave + l16) ^ (g4 << 4)), bo = g4 * TN + l16;
+    __syncthreads();                              // rows_l is complete
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nt) fetch(s, s);
+    int stage = 0;
+    for (int it = 0; it < nt; ++it) {
+        // per wave and chunk: 4 LDS-DMA instructions (3 for waves 6, 7): "at most (NS - 2) x 4 in flight" covers both
+        if (it + NS - 1 <= nt) wait_vmcnt<(NS - 2) * 3>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+        const int nxt = it + NS - 1;
+        if (nxt < nt) fetch(nxt, stage == 0 ? NS - 1 : stage - 1);
+        const float *as = smem + stage * STG + ao, *bs = smem + stage * STG + A_T + bo;
+        float av[2], bv[2][7];
+#define M2_REQ8(SET, S)                                                       \
+    {                                                                         \
+        av[SET] = as[(S) * 4 * 128];                                          \
+        _Pragma("unroll") for (int i = 0; i < 7; ++i) bv[SET][i] = bs[(S) * 4 * TN + 16 * i]; \
+    }
+        M2_REQ8(0, 0)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int cs = s & 1;
+            if (s + 1 < 8) M2_REQ8(cs ^ 1, s + 1)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cs], bv[cs][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef M2_REQ8
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    M2_STAMP(7, blockIdx.x == 0);
+    // C/D map of 16x16x4: acc[i][e] = dW1[m = 16 wave + 4 g4 + e][n = n0 + 16 i + l16]
+    float *out = a.partial + (long)z * hid * in_f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int col = n0 + 16 * i + l16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 16 * wave + 4 * g4 + e;
+            if (row < hid && col < in_f) out[(long)row * in_f + col] = acc[i][e];
+        }
+    }
+    M2_STAMP(8, blockIdx.x == 0);
+    M2_STAMP(9, blockIdx.x == gridDim.x - 1);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------- launch 3
 struct Mlp2FinishArgs {
     const float *partial;   // [kz][hid * in_f]
@@ -645,15 +766,26 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     const int RT = m2_rows_per_block(batch);
     const int n_blk = ceil_div(batch, RT), rows_pad = n_blk * RT;
     const int stride = (classes * hidden + hidden + 16 + 2 + 3) & ~3;
-    const int tiles_n = ceil_div(in_features, 128);
-    // K slices of launch 2: two workgroups per CU (two 64 KB double buffers), slices of at least 256 rows (TAPER_MLP2_KZ overrides the count)
+    // launch 2's form: 8 (default) = one eight-wave workgroup per CU on 128 x 112 tiles; TAPER_MLP2_DW = 22 | 31 | 32 | 41 = the four-wave
+    // 128 x 128 form with that many ring stages x workgroups per CU (measurement knob)
+    static const int variant = [] { const char *e = getenv("TAPER_MLP2_DW"); return e ? atoi(e) : 8; }();
+    const bool dw8 = variant == 8;
+    const int tiles_n = ceil_div(in_features, dw8 ? 112 : 128);
     static const int kz_forced = [] { const char *e = getenv("TAPER_MLP2_KZ"); return e ? atoi(e) : 0; }();
-    static const int dw_wgs = [] { const char *e = getenv("TAPER_MLP2_DW"); return e && atoi(e) % 10 == 1 ? 1 : 2; }();
-    int kz = kz_forced > 0 ? kz_forced : ceil_div(dw_wgs * kNumCU, tiles_n);
-    const int kz_max = rows_pad / 256 > 0 ? rows_pad / 256 : 1;
-    if (kz > kz_max) kz = kz_max;
-    int kslice = ceil_div(ceil_div(rows_pad, kz), M2_BK) * M2_BK;
-    kz = ceil_div(rows_pad, kslice);
+    int kz, kslice = 0;
+    if (dw8) {
+        // as many slices as fit one workgroup per CU, at least one 32-row chunk each
+        kz = kz_forced > 0 ? kz_forced : kNumCU / tiles_n;
+        kz = std::max(1, std::min(kz, rows_pad / M2_BK));
+    } else {
+        // two workgroups per CU (two 64 KB double buffers), slices of at least 256 rows
+        const int dw_wgs = variant % 10 == 1 ? 1 : 2;
+        kz = kz_forced > 0 ? kz_forced : ceil_div(dw_wgs * kNumCU, tiles_n);
+        const int kz_max = rows_pad / 256 > 0 ? rows_pad / 256 : 1;
+        if (kz > kz_max) kz = kz_max;
+        kslice = ceil_div(ceil_div(rows_pad, kz), M2_BK) * M2_BK;
+        kz = ceil_div(rows_pad, kslice);
+    }
     const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_partial = (size_t)kz * hidden * in_features;
     void *ws = nullptr;
     if (th_malloc(ctx, (n_dz + n_part + n_partial) * sizeof(float), &ws)) return 1;
@@ -680,15 +812,31 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     }
     TH_LAUNCH_CHECK();
 
-    Mlp2DwArgs d{};
-    d.src = rs;
-    d.dz1 = dz1; d.dz_bytes = (unsigned)(n_dz * 4);
-    d.rows_pad = rows_pad; d.batch = batch; d.in_f = in_features; d.hid = hidden;
-    d.partial = partial; d.tiles_n = tiles_n; d.kz = kz; d.kslice = kslice;
-    {
-        // ring depth x workgroups per CU of launch 2 (TAPER_MLP2_DW = 41 | 31 | 22 | 32: stages, workgroups per CU; a measurement knob)
-        static const int variant = [] { const char *e = getenv("TAPER_MLP2_DW"); return e ? atoi(e) : 22; }();
-        const int ns = variant / 10 >= 2 && variant / 10 <= 4 ? variant / 10 : 4;
+    if (dw8) {
+        Mlp2Dw8Args d{};
+        d.src = rs;
+        d.dz1 = dz1; d.dz_bytes = (unsigned)(n_dz * 4);
+        d.rows_pad = rows_pad; d.batch = batch; d.in_f = in_features; d.hid = hidden;
+        d.partial = partial; d.tiles_n = tiles_n; d.kz = kz;
+        constexpr int NS8 = 4;
+        const int max_chunks = ceil_div(rows_pad / M2_BK, kz);
+        const size_t lds = (size_t)NS8 * (128 + 112) * M2_BK * sizeof(float) + (size_t)max_chunks * M2_BK * sizeof(int);
+        TH_REQUIRE(lds <= (160u << 10), "th_mlp2_xent: %d rows per K slice do not fit the index table in LDS", max_chunks * M2_BK);
+        static bool attr = false;
+        if (!attr) {
+            TH_HIP(hipFuncSetAttribute((const void *)mlp2_dw1_kernel8<NS8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+            TH_HIP(hipFuncSetAttribute((const void *)mlp2_dw1_kernel8<NS8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+            attr = true;
+        }
+        if (rs.idx) hipLaunchKernelGGL((mlp2_dw1_kernel8<NS8, true>), dim3(tiles_n * kz), dim3(512), lds, ctx->stream, d);
+        else hipLaunchKernelGGL((mlp2_dw1_kernel8<NS8, false>), dim3(tiles_n * kz), dim3(512), lds, ctx->stream, d);
+    } else {
+        Mlp2DwArgs d{};
+        d.src = rs;
+        d.dz1 = dz1; d.dz_bytes = (unsigned)(n_dz * 4);
+        d.rows_pad = rows_pad; d.batch = batch; d.in_f = in_features; d.hid = hidden;
+        d.partial = partial; d.tiles_n = tiles_n; d.kz = kz; d.kslice = kslice;
+        const int ns = variant / 10 >= 2 && variant / 10 <= 4 ? variant / 10 : 2;
         const size_t lds = (size_t)ns * 2 * 128 * M2_BK * sizeof(float) + (size_t)kslice * sizeof(int);
 #define M2_DW_LAUNCH(NS_, WGS_)                                                                                                       \
     do {                                                                                                                              \
