@@ -369,10 +369,10 @@ Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b
     return loss;
 }
 
-// TAPER_MLP2_MIN_BATCH: from this batch on a Linear + ReLU + Linear classifier steps through th_mlp2_xent (default 2048: below, the
+// TAPER_MLP2_MIN_BATCH: from this batch on a Linear + ReLU + Linear classifier steps through th_mlp2_xent (default 1024: below, the
 // launch-per-layer forms are as fast -- three dependent launches cost ~5 us each whatever they hold)
 static size_t mlp2_min_batch() {
-    static const size_t v = [] { const char *e = std::getenv("TAPER_MLP2_MIN_BATCH"); return e ? (size_t)std::max(32, atoi(e)) : (size_t)2048; }();
+    static const size_t v = [] { const char *e = std::getenv("TAPER_MLP2_MIN_BATCH"); return e ? (size_t)std::max(32, atoi(e)) : (size_t)1024; }();
     return v;
 }
 

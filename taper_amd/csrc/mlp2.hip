@@ -565,6 +565,7 @@ __global__ __launch_bounds__(512, 1) void mlp2_dw1_kernel8(Mlp2Dw8Args a) {
     for (int i = 0; i < 7; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     // operand addresses of k-step s: A[(4 s + g4) * 128 + ((16 wave + l16) ^ (g4 << 4))], B[(4 s + g4) * 112 + 16 i + l16]
     const int ao = g4 * 128 + ((16 * wave + l16) ^ (g4 << 4)), bo = g4 * TN + l16;
+    M2_STAMP(6, blockIdx.x == 0);
     __syncthreads();                              // rows_l is complete
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -631,44 +632,35 @@ __device__ __forceinline__ void m2_apply(const AdamDev &ad, long i, float g) {
     if (ad.p) adam_update(ad.p, ad.m, ad.v, i, g, adam_dev_step(ad), ad.beta1, ad.beta2, ad.eps, ad.wd);
 }
 
-// Two roles.  dW1: a workgroup owns 64 float4 of the gradient; its four waves add the K slices z = wave, wave + 4, ... and the first
-// wave adds the four sums in wave order.  The row blocks' partial sums: a workgroup owns 16 of the elements, 16 threads per element add the
+// Two roles.  dW1: a workgroup owns 16 float4 of the gradient, 16 threads per float4 add the K slices z = zg, zg + 16, ... and the first
+// adds the 16 sums in order.  The row blocks' partial sums: a workgroup owns 16 of the elements, 16 threads per element add the
 // blocks b = sub, sub + 16, ..., the first adds the 16 sums in order.  (One thread per element adding 64 slices / 256 blocks one after
 // the other is a chain of dependent round trips: 62.6 us at batch 16 384 for 26 MB.)
 __global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
-    __shared__ float4 sh4[4][64];
+    __shared__ float4 sh4[16][16];
     const int bid = blockIdx.x, t = threadIdx.x;
     M2_STAMP(10, blockIdx.x == 0);
     M2_STAMP(11, blockIdx.x == gridDim.x - 1);
     if (bid < a.w1_blocks) {
-        const long mn = (long)a.hid * a.in_f, i0 = ((long)bid * 64 + (t & 63)) * 4;
-        const int zg = t >> 6;
+        // 16 float4 of the gradient per workgroup, 16 threads per float4: thread zg adds slices zg, zg + 16, ...; thread 0 adds the 16 sums in order
+        const long mn = (long)a.hid * a.in_f, i0 = ((long)bid * 16 + (t & 15)) * 4;
+        const int zg = t >> 4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i0 < mn) {
-            int z = zg;
-            for (; z + 12 < a.kz; z += 16) {                 // four independent loads in flight per thread
-                const float4 v0 = *reinterpret_cast<const float4 *>(a.partial + (long)z * mn + i0);
-                const float4 v1 = *reinterpret_cast<const float4 *>(a.partial + (long)(z + 4) * mn + i0);
-                const float4 v2 = *reinterpret_cast<const float4 *>(a.partial + (long)(z + 8) * mn + i0);
-                const float4 v3 = *reinterpret_cast<const float4 *>(a.partial + (long)(z + 12) * mn + i0);
-                s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x;
-                s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
-                s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z;
-                s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
-            }
-            for (; z < a.kz; z += 4) {
+#pragma unroll 4
+            for (int z = zg; z < a.kz; z += 16) {
                 const float4 v = *reinterpret_cast<const float4 *>(a.partial + (long)z * mn + i0);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
         }
-        sh4[zg][t & 63] = s;
+        sh4[zg][t & 15] = s;
         __syncthreads();
         if (zg != 0 || i0 >= mn) return;
-        const float4 p1 = sh4[1][t], p2 = sh4[2][t], p3 = sh4[3][t];
-        s.x = ((s.x + p1.x) + p2.x) + p3.x;
-        s.y = ((s.y + p1.y) + p2.y) + p3.y;
-        s.z = ((s.z + p1.z) + p2.z) + p3.z;
-        s.w = ((s.w + p1.w) + p2.w) + p3.w;
+#pragma unroll
+        for (int u = 1; u < 16; ++u) {
+            const float4 p = sh4[u][t];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
         *reinterpret_cast<float4 *>(a.dw1 + i0) = s;
         if (a.w1a.p) {
             const float step = adam_dev_step(a.w1a);
@@ -798,18 +790,18 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     r.w1 = d_w1; r.b1 = d_b1; r.w2 = d_w2; r.b2 = d_b2;
     r.batch = batch; r.in_f = in_features; r.hid = hidden; r.c = classes;
     r.dz1 = dz1; r.part = part; r.part_stride = stride; r.tick = d_tick;
-    constexpr int NS_ROWS = 4;
-    if (RT == 64) {
-        const size_t lds = (size_t)NS_ROWS * (64 + 128) * M2_BK * sizeof(float);
-        static bool attr = false;
-        if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)mlp2_rows_kernel<64, NS_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-        hipLaunchKernelGGL((mlp2_rows_kernel<64, NS_ROWS>), dim3(n_blk), dim3(256), lds, ctx->stream, r);
-    } else {
-        const size_t lds = (size_t)NS_ROWS * (32 + 128) * M2_BK * sizeof(float);
-        static bool attr = false;
-        if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)mlp2_rows_kernel<32, NS_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-        hipLaunchKernelGGL((mlp2_rows_kernel<32, NS_ROWS>), dim3(n_blk), dim3(256), lds, ctx->stream, r);
-    }
+    // ring depth of launch 1: four stages (six for the 32-row tiles, one workgroup per CU, measured no faster: a lone wave per SIMD is bound by
+    // its own issue order, not by the requests in flight)
+#define M2_ROWS_LAUNCH(RT_, NS_)                                                                                                   \
+    do {                                                                                                                           \
+        const size_t lds = (size_t)NS_ * (RT_ + 128) * M2_BK * sizeof(float);                                                      \
+        static bool attr = false;                                                                                                  \
+        if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)mlp2_rows_kernel<RT_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
+        hipLaunchKernelGGL((mlp2_rows_kernel<RT_, NS_>), dim3(n_blk), dim3(256), lds, ctx->stream, r);                              \
+    } while (0)
+    if (RT == 64) M2_ROWS_LAUNCH(64, 4);
+    else M2_ROWS_LAUNCH(32, 4);
+#undef M2_ROWS_LAUNCH
     TH_LAUNCH_CHECK();
 
     if (dw8) {
@@ -863,7 +855,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     f.dw1 = d_dw1; f.db1 = d_db1; f.dw2 = d_dw2; f.db2 = d_db2; f.loss = d_loss; f.ncorrect = d_ncorrect; f.metrics = d_metrics;
     f.capacity = metrics_capacity; f.state = d_state; f.advance = advance;
     f.w1a = make_adam_dev(w1_fuse); f.b1a = make_adam_dev(b1_fuse); f.w2a = make_adam_dev(w2_fuse); f.b2a = make_adam_dev(b2_fuse);
-    f.w1_blocks = ceil_div((long)hidden * in_features, 256);
+    f.w1_blocks = ceil_div((long)hidden * in_features, 64);
     const int tail_blocks = ceil_div(classes * hidden + hidden + 16 + 1, 16);
     hipLaunchKernelGGL(mlp2_finish_kernel, dim3(f.w1_blocks + tail_blocks), dim3(256), 0, ctx->stream, f);
     TH_LAUNCH_CHECK();

@@ -194,8 +194,11 @@ def test_trainer_large_batch_epochs_match_oracle(n, batch, shuffle):
         assert np.abs(ep["ncorrect"] - np.array(ref_nc)).max() <= 1                   # an argmax between two logits within rounding may flip
     assert _mlp2_calls() - before >= 1 and n_big >= 2                                 # (captured steps replay without new enqueues)
     assert hopt.t() == oopt.t()
+    # Adam moves a weight by lr * m / (sqrt(v) + eps) per step: for the few W1 elements whose gradient is a sum of 16 384 terms cancelling to
+    # ~eps, a reordered sum changes the step by a few % of lr (the smoke's error model: 2 % of lr per step), and the steps' errors add:
+    # observed 7.1e-2 lr after 6 steps (b1 5.5e-3, W2 5.3e-4, b2 3.7e-5); the gradients themselves agree to 3e-6 of their scale (above)
     for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
-        margins.check(f"param{i}", hp.data(), op.data(), 2e-2, lr=lr)                # Adam's error model (the smoke's): 2 % of lr
+        margins.check(f"param{i}", hp.data(), op.data(), 2e-2 * hopt.t(), lr=lr)
     T.Tape.reset()
 
 
