@@ -111,6 +111,14 @@ def make_comm(rdzv, T, backend, optimizer):
     return comm, "rccl ncclAllReduce(avg)" + why
 
 
+def opt_total(T, opt):
+    """padded length of the optimizer's flat arenas = the all-reduce size in floats (include/taper_host.h: tp_optim_total)"""
+    from taper_amd._lib import host, tp_check
+    n = C.c_int64()
+    tp_check(host.tp_optim_total(opt._h, C.byref(n)), "tp_optim_total")
+    return int(n.value)
+
+
 def replicas_identical(rdzv, model):
     """crc32 of every rank's weights, compared on every rank (data-parallel replicas must stay bit-identical: SURVEY 8e)"""
     import zlib
@@ -263,8 +271,11 @@ def batch_sweep(T, build_model, key, lr, dataset, batches=(64, 256, 1024, 4096, 
         samples = run_steps(T, trainer, loader, steps)
         T.Device.sync()
         dt = time.perf_counter() - t0
+        flops, nbytes = algorithmic_step(key, b)
         out.append(dict(batch=b, steps=steps, ms_per_step=round(dt / steps * 1e3, 5), samples_per_s=round(samples / dt, 1),
-                        epochs_per_s=round(samples / dt / 60000.0, 2)))
+                        epochs_per_s=round(samples / dt / 60000.0, 2),
+                        mfma_frac=None if flops is None else round(flops / (dt / steps) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                        hbm_frac=None if nbytes is None else round(nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)))
         del trainer, opt, model, loader
     return out
 
@@ -654,6 +665,95 @@ def extra_workloads(T, dataset, with_cpu, only=None):
     return out
 
 
+
+# ---------------------------------------------------------------------------- what is printed
+def write_details(full):
+    """the full record (every workload's kernels[], the per-thread CPU trials, the data-parallel side runs ...) goes to a side file; the
+    printed line stays short enough for a 2 000-character tail to hold all of it"""
+    name = "bench_details.json" if full.get("n_gpus", 1) == 1 else f"bench_details_n{full['n_gpus']}.json"
+    for d in (ROOT / "gpurun_out", Path.cwd()):
+        try:
+            if d.is_dir():
+                (d / name).write_text(json.dumps(full, indent=1))
+                return str((d / name).relative_to(ROOT)) if str(d).startswith(str(ROOT)) else str(d / name)
+        except OSError:
+            continue
+    return None
+
+
+def _short(x, n):
+    x = str(x)
+    return x if len(x) <= n else x[: n - 3] + "..."
+
+
+def compact_line(full, details_path):
+    """ONE line: the contract's keys, `roofline`, `cpu_baseline`, and one short entry per other BASELINE config / sweep point"""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full[k] for k in keep}
+    cfg = full["config"]
+    out["config"] = {k: (_short(cfg[k], 60) if isinstance(cfg[k], str) else cfg[k])
+                     for k in ("workload", "per_gpu_batch", "global_batch", "parallelism", "comm", "graph_record_steps", "ranks_share_one_gpu") if k in cfg}
+    out["epochs_per_s"] = full["epochs_per_s"]
+    if full.get("sustained"):
+        out["sustained_ms_per_step"] = full["sustained"]["ms_per_step"]
+    sr = full.get("step_roofline")
+    if sr:
+        out["step_roofline"] = {"hbm_frac": round(sr["hbm_frac"], 4), "mfma_frac": round(sr["mfma_frac"], 4)}
+    if full.get("data_parallel"):
+        dp = full["data_parallel"]
+        d = {k: dp[k] for k in ("weak_scaling_efficiency", "replicas_bit_identical") if k in dp}
+        if "single_gpu_same_per_gpu_batch" in dp:
+            d["single_gpu_ms_per_step"] = dp["single_gpu_same_per_gpu_batch"]["ms_per_step"]
+        if "same_job_over_rccl" in dp:
+            r = dp["same_job_over_rccl"]
+            d["same_job_over_rccl"] = {k: r[k] for k in ("value", "ms_per_step", "rccl_ranks", "skipped") if k in r}
+        if "dp_at_64_rows_per_gpu" in dp:
+            d["b64_per_gpu_ms_per_step"] = dp["dp_at_64_rows_per_gpu"]["ms_per_step"]
+        out["data_parallel"] = d
+    if full.get("batch_sweep"):
+        out["batch_sweep"] = {str(e["batch"]): [round(e["ms_per_step"] * 1e3, 1), e["epochs_per_s"], e["mfma_frac"]] for e in full["batch_sweep"]}
+        out["batch_sweep_fields"] = "us/step, epochs/s, frac of fp32 MFMA peak"
+    if full.get("workloads"):
+        w = {}
+        for rec in full["workloads"]:
+            if "error" in rec:
+                w[rec["workload"]] = {"error": _short(rec["error"], 60)}
+                continue
+            e = {"ms_per_step": rec["ms_per_step"], "samples_per_s": rec["samples_per_s"]}
+            ks = [k for k in rec.get("kernels", []) if k.get("in_step", True)]
+            if ks:
+                k = max(ks, key=lambda r: r["us_per_launch"])
+                e["kernel"] = [_short(k["kernel"].split("<")[0].split("(")[0], 28), k["us_per_launch"], k["bound"], k["frac"]]
+            if "frac_of_mfma_peak" in rec:
+                e["mfma_frac"] = rec["frac_of_mfma_peak"]
+                e["sgemm_4096_frac"] = [k["frac"] for k in rec.get("kernels", [])]
+            cb = rec.get("cpu_baseline")
+            if cb and cb.get("value"):
+                e["cpu_samples_per_s"] = round(cb["value"], 1)
+            w[rec["workload"]] = e
+        out["workloads"] = w
+    rf = full.get("roofline")
+    if rf:
+        out["roofline"] = ({k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "us_per_launch", "peak_basis", "alg_bytes_per_launch") if k in rf}
+                           if "skipped" not in rf else rf)
+        if "kernel" in out["roofline"]:
+            out["roofline"]["kernel"] = _short(out["roofline"]["kernel"], 48)
+    else:
+        out["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: (round(cb[k], 1) if k == "value" and cb[k] else cb[k]) for k in ("value", "unit", "cores", "kind") if k in cb}
+        out["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 110)
+        if cb.get("blas_feature", {}).get("value"):
+            out["cpu_baseline"]["blas_feature_value"] = round(cb["blas_feature"]["value"], 1)
+        if "see" in cb:
+            out["cpu_baseline"]["see"] = cb["see"]
+    else:
+        out["cpu_baseline"] = None
+    out["details"] = details_path
+    return out
+
+
 # ---------------------------------------------------------------------------- launcher
 def self_spawn(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
@@ -786,15 +886,43 @@ def main():
             s64, d64, k64, same64 = side_run(64, args.dp_backend)
             dp_extra["dp_at_64_rows_per_gpu"] = dict(workload="mlp_784-128-10_b64", per_gpu_batch=64, global_batch=64 * world, value=round(s64 / d64, 1),
                                                      unit="samples/s", ms_per_step=round(d64 / args.steps * 1e3, 5), comm=k64, replicas_bit_identical=same64)
-        if comm is not None and comm.is_p2p() and not share:      # the same job over RCCL, for comparison (RCCL needs a GPU per rank)
-            sr, dr, kr, samer = side_run(batch, "rccl")
-            dp_extra["same_job_over_rccl"] = dict(value=round(sr / dr, 1), unit="samples/s", ms_per_step=round(dr / args.steps * 1e3, 5), comm=kr,
-                                                  replicas_bit_identical=samer)
+        # the same job over RCCL -- north_star's transport -- whenever every rank has a GPU of its own (RCCL cannot put two ranks on one
+        # device); rccl_ranks is what ncclCommCount reports for the communicator that ran it
+        from taper_amd import hip as _hip
+        if comm is not None and comm.is_p2p():
+            if not share and _hip.device_count() >= world:
+                sr, dr, kr, samer = side_run(batch, "rccl")
+                c_rccl = _KEEP_ALIVE[-1][4]
+                dp_extra["same_job_over_rccl"] = dict(value=round(sr / dr, 1), unit="samples/s", ms_per_step=round(dr / args.steps * 1e3, 5), comm=kr,
+                                                      rccl_ranks=c_rccl.count() if c_rccl is not None else None, replicas_bit_identical=samer)
+            else:
+                dp_extra["same_job_over_rccl"] = dict(skipped=f"{world} ranks share {_hip.device_count()} GPU(s): RCCL needs one device per rank")
+        elif comm is not None:
+            dp_extra["rccl_ranks"] = comm.count()
         if rank == 0:
             s1, d1, _, _ = side_run(batch, None)
             dp_extra["single_gpu_same_per_gpu_batch"] = dict(workload=args.workload, per_gpu_batch=batch, n_gpus=1, value=round(s1 / d1, 1), unit="samples/s",
                                                              ms_per_step=round(d1 / args.steps * 1e3, 5), steps=args.steps, warmup=args.warmup)
+            # eff(W) = T_step(1 GPU, B/W rows) / T_step(W GPUs, B/W rows each), same W / K, same run
+            dp_extra["weak_scaling_efficiency"] = round((d1 / args.steps) / (dt / args.steps), 4)
         barrier_sync(dist, T)
+        # the exchange launch on its own: `reps` gradient exchanges + Adam as the step issues them, back to back between two events on
+        # every rank's stream (collective).  Moves the optimizer state: the timed run and the replica check are behind us.
+        try:
+            ex_us = comm.time_exchange(opt, 200)
+            ex_us = dist.all_reduce_max(ex_us)
+        except Exception as e:   # reported, never required
+            ex_us, dp_extra["exchange_error"] = None, str(e)
+        if ex_us:
+            P = opt_total(T, opt)
+            ex_bytes = (world - 1) * 4.0 * P + 4.0 * P + 24.0 * P        # peers' gradients over the links + own + Adam's p / m / v read and written
+            links = 7 * 153.0
+            peak, basis = (HBM_PEAK_GBS, "HBM (the ranks share one GPU: peer reads are local)") if share else \
+                          (min(HBM_PEAK_GBS, links), "xGMI, 7 links x 153 GB/s per GPU (< HBM 8000 GB/s)")
+            dp_extra["exchange"] = dict(kernel="p2p_allreduce_adam_kernel" if comm.is_p2p() else "ncclAllReduce + adam_kernel", us_per_launch=round(ex_us, 2),
+                                        alg_bytes_per_launch=ex_bytes, bound="hbm", achieved=round(ex_bytes / (ex_us * 1e-6) / 1e9, 2), peak=round(peak, 1),
+                                        unit="GB/s", frac=round(ex_bytes / (ex_us * 1e-6) / 1e9 / peak, 5), peak_basis=basis, traffic=None,
+                                        note="latency-bound: 0.4 MB per rank; max over ranks of 200 back-to-back exchanges")
 
     sustained = None
     if world == 1 and args.settle_seconds == 0 and not args.no_roofline and not under_profiler:   # (the trace is of the W + K run only)
@@ -833,6 +961,8 @@ def main():
                         alg_bytes_per_launch=k["alg_bytes_per_launch"], mfma_tflops=k["mfma_tflops"],
                         dominant_by="algorithmic bytes; by time the leader is %s (%.1f us)" % (by_time["kernel"], by_time["us_per_launch"]),
                         step_us_two_launch_chain=sk["step_us"], kernels=sk["kernels"])
+        if world > 1 and dp_extra and dp_extra.get("exchange"):
+            roof = dict(dp_extra["exchange"])           # N > 1: the kernel the job adds to the N = 1 step is the gradient exchange
         sweep = None
         # (not under rocprofv3: the trace of this command is for the headline workload's kernels only)
         if key == "mlp_baseline" and world == 1 and not args.batch and not args.no_sweep and not under_profiler:
@@ -844,6 +974,9 @@ def main():
                 cpu = cpu_baseline(key, batch, sample_shape, lr)
             except Exception as e:  # the baseline is reported, never required
                 cpu = dict(value=None, unit="samples/s", cores=1, kind="port", sample=f"failed: {e}")
+        if world > 1:   # the CPU leg is timed at N = 1 only (rank 0's host cores are shared by the N ranks here)
+            cpu = dict(value=None, unit="samples/s", cores=None, kind="port", sample="not timed at N > 1",
+                       see="cpu_baseline of `python bench.py --gpus 1` (same box, same workload family)")
         workloads = None
         if under_profiler:
             # rocprofv3 (ROCm 7.2) crashes inside hipGraphLaunch once a process replays the graphs of a SECOND Trainer: the headline above ran as
@@ -872,7 +1005,7 @@ def main():
             **({"data_parallel": dp_extra} if dp_extra is not None else {}),
             **({"workloads": workloads} if workloads is not None else {}),
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact_line(out, write_details(out))), flush=True)
     if dist is not None:
         dist.close()
 

@@ -550,6 +550,13 @@ int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m,
                  const int64_t *d_offsets, const int32_t *d_has_grad, int n_tensors, int64_t total,
                  int32_t *d_t, const float *d_lr, float beta1, float beta2, float eps, float weight_decay,
                  int pre_ticked /* 1: d_t[0] was already advanced for this step; use it as is */);
+/* same; d_skip_if_nonzero (nullable): a device word written by an EARLIER launch -- the error word of the peer-to-peer communicator whose
+ * all-reduce produced d_grads (th_comm_error_word).  Non-zero: that all-reduce timed out, d_grads still holds this rank's own gradients,
+ * and the launch applies nothing (no update, no tick of t). */
+int th_adam_step_guarded(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v,
+                         const int64_t *d_offsets, const int32_t *d_has_grad, int n_tensors, int64_t total,
+                         int32_t *d_t, const float *d_lr, float beta1, float beta2, float eps, float weight_decay,
+                         int pre_ticked, const uint32_t *d_skip_if_nonzero);
 /* t += 1 alone (optim.rs:84), for steps whose updates all ran fused */
 int th_adam_tick(th_ctx *ctx, int32_t *d_t);
 /* the deferred updates nobody carried (one launch for all n <= TH_MAX_ADAM_SLICES slices) */
@@ -594,8 +601,15 @@ int th_allreduce_sum_scale(th_comm *comm, th_ctx *ctx, float *d_buf, size_t n, f
  * mean gradient is fed straight into Adam (optim.rs:83-113; arguments as th_adam_step) and never written back.
  * Ranks may share a device (the test setup of a 1-GPU box) or own one each.  A peer that never arrives makes the launch give up
  * after the communicator's bound (default 120 s; TAPER_P2P_TIMEOUT_MS at th_comm_init_p2p, th_comm_set_timeout_ms afterwards) and raises
- * the error word.  The error is FINAL: the launch that timed out applies nothing (no reduced gradient is stored, no parameter moves, Adam's
- * counter is not advanced), and every later launch of the communicator returns at once.  th_comm_error synchronises the stream and reads the
+ * the error word.  There is ONE verdict per launch and phase (workgroup 0 watches the flags against the clock and publishes it; every other
+ * workgroup follows it), so a launch applies its result in all workgroups or in none:
+ *   - peers not READY in time: nothing is read, no reduced gradient is stored, no parameter moves, Adam's counter is not advanced;
+ *   - peers not DONE reading in time, in-place form: the same (the reduced gradient is not stored; an Adam step behind it must be
+ *     th_adam_step_guarded with th_comm_error_word, which then applies nothing either);
+ *   - peers not DONE in time, fused form: the update WAS computed from all W gradients and stays applied, counter included (p / m / v / t
+ *     are one consistent step on); the error says a peer may not have finished reading.
+ * The error is FINAL: every later launch of the communicator returns at once (all of its workgroups: they consult the word as the previous
+ * launch left it), and the host must end the run -- the replicas may be one update apart.  th_comm_error synchronises the stream and reads the
  * word; th_comm_error_peek reads its host-visible copy without touching the stream (call it after any synchronisation the caller does
  * anyway: the end of an epoch's graph replays).  The exported buffer may be fine-grained device memory (th_malloc_finegrained: uncached
  * across agents) where coarse-grained memory cannot be trusted to show a peer's latest writes. */
@@ -604,9 +618,12 @@ int th_comm_init_p2p(th_ctx *ctx, int n_ranks, int rank, th_comm **out);
 int th_comm_p2p_export(th_comm *comm, float *d_buf, size_t n, uint8_t out_blob[TH_P2P_BLOB_BYTES]);
 int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs /* n_ranks x TH_P2P_BLOB_BYTES, rank order */);
 int th_comm_is_p2p(const th_comm *comm);
+int th_comm_count(const th_comm *comm, int *out_ranks);   /* ranks the communicator spans (RCCL: ncclCommCount) */
 int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error);
 int th_comm_error_peek(const th_comm *comm, int *out_error);
 int th_comm_set_timeout_ms(th_comm *comm, int64_t ms);
+/* the communicator's sticky error word in device memory (NULL for an RCCL communicator): th_adam_step_guarded's guard */
+int th_comm_error_word(const th_comm *comm, const uint32_t **d_out);
 /* test hook: {in-place, fused-with-Adam} one-shot launches this communicator has enqueued or captured so far */
 int th_comm_stats(const th_comm *comm, int64_t out2[2]);
 int th_allreduce_adam(th_comm *comm, th_ctx *ctx, const float *d_grads, size_t n, float scale, float *d_params, float *d_m, float *d_v,

@@ -188,6 +188,10 @@ int tp_comm_set_fuse_adam(tp_comm *c, int on);        /* p2p: 1 (default) all-re
 int tp_comm_stats(tp_comm *c, int64_t out2[2]);   /* {in-place, fused} one-shot launches enqueued or captured */
 int tp_comm_free(tp_comm *c);
 int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n);
+int tp_comm_count(tp_comm *c, int *out_ranks);                     /* th_comm_count: for RCCL, what ncclCommCount reports */
+/* `reps` gradient exchanges + Adam as a Trainer step issues them, timed with events on the stream; collective (every rank calls it);
+ * the optimizer state moves: for benchmarks, after the timed run */
+int tp_comm_time_exchange(tp_comm *c, tp_optim *adam, int reps, float *us_per_exchange);
 
 /* ---- train (src/train.rs, examples/train_mnist*.rs) ---- */
 int tp_trainer_new(tp_module *model, tp_optim *adam, tp_trainer **out);

@@ -632,6 +632,18 @@ class Communicator:
     def allreduce_mean(self, d_ptr: int, n: int):
         tp_check(host.tp_comm_allreduce_mean(self._h, d_ptr, int(n)), "allreduce_mean")
 
+    def count(self) -> int:
+        """ranks the communicator spans (RCCL: ncclCommCount)"""
+        out = C.c_int()
+        tp_check(host.tp_comm_count(self._h, C.byref(out)), "Communicator::count")
+        return int(out.value)
+
+    def time_exchange(self, optimizer, reps: int = 200) -> float:
+        """collective: us per gradient exchange + Adam as a Trainer step issues it (events on the stream); moves the optimizer state"""
+        out = C.c_float()
+        tp_check(host.tp_comm_time_exchange(self._h, optimizer._h, int(reps), C.byref(out)), "Communicator::time_exchange")
+        return float(out.value)
+
 
 # -- src/train.rs ---------------------------------------------------------------------
 class Trainer:

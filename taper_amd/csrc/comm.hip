@@ -31,7 +31,9 @@ static_assert(sizeof(P2PBlob) == TH_P2P_BLOB_BYTES, "P2PBlob layout");
 struct P2PDev {                            // kernel argument
     const float *buf[P2P_MAX_RANKS];       // buf[r]: rank r's gradient buffer as mapped here (own = local pointer)
     uint32_t *flags[P2P_MAX_RANKS];        // flags[r]: rank r's flag block as mapped here (own = local pointer)
-    uint32_t *state;                       // local: [0] steps completed, [1] arrival counter, [2] error (timeout; STICKY: later launches do nothing)
+    uint32_t *state;                       // local: [0] steps completed, [1] arrival counter, [2] error (timeout; STICKY), [3] READY verdict of the step
+                                           // in flight ((step << 1) | ok), [4] DONE verdict (in-place form), [5] "dead at entry": [2] as it stood when
+                                           // the previous launch ended -- what a launch's workgroups consult, so that they all see the same value
     uint32_t *err_host;                    // the same error word in device-visible pinned host memory: the host reads it after any stream sync
     long spin_ticks;
     int n_ranks, rank;
@@ -108,14 +110,45 @@ __device__ __forceinline__ bool p2p_wait_all(const P2PDev &c, int word0, uint32_
     return ok;
 }
 
+// ONE verdict per launch and phase.  Workgroup 0 alone watches the flag block against the clock and publishes (step << 1) | ok in
+// state[word]; every other workgroup waits for that word.  (Each workgroup polling -- and timing out -- on its own let a peer that arrived
+// at the bound be "in time" for some workgroups and "late" for others: a partly applied update.)  The word is local device memory read
+// with agent-scope atomics: it costs the followers one L2 round trip after workgroup 0's store.  All workgroups of these launches are
+// resident at once (<= 256), so workgroup 0 always runs.
+__device__ __forceinline__ bool p2p_verdict(const P2PDev &c, int flag_word0, int state_word, uint32_t step) {
+    if (blockIdx.x == 0) {
+        const bool ok = p2p_wait_all(c, flag_word0, step);
+        if (threadIdx.x == 0) __hip_atomic_store(&c.state[state_word], (step << 1) | (ok ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return ok;
+    }
+    __shared__ uint32_t verdict;
+    if (threadIdx.x == 0) {
+        uint32_t v;
+        while (((v = __hip_atomic_load(&c.state[state_word], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != (step & 0x7fffffffu)) __builtin_amdgcn_s_sleep(1);
+        verdict = v & 1u;
+    }
+    __syncthreads();
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    return verdict != 0u;
+}
+
 // a time-out is final: once the error word is up every later launch of this communicator returns at once -- no flag is pushed, nothing is
-// reduced, no parameter moves, Adam's counter stays -- and the host raises at its next look (th_comm_error / th_comm_error_peek)
+// reduced, no parameter moves, Adam's counter stays -- and the host raises at its next look (th_comm_error / th_comm_error_peek).
+// Consulted through state[5], the error word as the PREVIOUS launch left it: a raise in the middle of a launch cannot split that launch.
 __device__ __forceinline__ bool p2p_dead(const P2PDev &c) {
-    return __hip_atomic_load(&c.state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    return __hip_atomic_load(&c.state[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+// workgroup 0, thread 0, the last thing it does
+__device__ __forceinline__ void p2p_seal(const P2PDev &c) {
+    const uint32_t e = __hip_atomic_load(&c.state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e) __hip_atomic_store(&c.state[5], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void p2p_push(const P2PDev &c, int word0, uint32_t step) {
-    // lane r writes this rank's slot in rank r's flag block (its own included)
+    // lane r writes this rank's slot in rank r's flag block (its own included).  The store is a system-scope RELEASE: the compiler puts
+    // `buffer_wbl2 sc0 sc1` + `s_waitcnt vmcnt(0)` in front of it, i.e. everything this XCD's L2 still holds dirty goes to memory first; the
+    // gradient arena itself was written by EARLIER launches, whose end-of-kernel release wrote every XCD's L2 back (the XCD L2s of one device
+    // are not coherent with each other, so HIP's kernel boundary has to) -- a peer's system-coherent load then finds it in HBM / MALL.
     if (threadIdx.x < (unsigned)c.n_ranks)
         __hip_atomic_store(c.flags[threadIdx.x] + word0 + c.rank, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -175,17 +208,21 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PDev c, float *__r
     if (p2p_dead(c)) return;
     const uint32_t step = __hip_atomic_load(&c.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (blockIdx.x == 0) p2p_push(c, P2P_READY, step);
-    const bool ok = p2p_wait_all(c, P2P_READY, step);
+    const bool ok = p2p_verdict(c, P2P_READY, 3, step);
     const long stride = (long)gridDim.x * 256 * 4;
     float4 acc[P2P_QUADS];
+    if (ok) {
 #pragma unroll
-    for (int q = 0; q < P2P_QUADS; ++q) {
-        const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4 + q * stride;
-        if (i < n) acc[q] = p2p_sum_quad(c, i, scale);
+        for (int q = 0; q < P2P_QUADS; ++q) {
+            const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4 + q * stride;
+            if (i < n) acc[q] = p2p_sum_quad(c, i, scale);
+        }
+        p2p_arrive(c, step);
     }
-    p2p_arrive(c, step);
-    const bool done = p2p_wait_all(c, P2P_DONE, step);   // every peer has read this rank's buffer: it may be overwritten
-    if (!ok || !done) return;
+    // every peer has read this rank's buffer: it may be overwritten -- by ALL workgroups or by none (one verdict)
+    const bool done = ok && p2p_verdict(c, P2P_DONE, 4, step);
+    if (blockIdx.x == 0 && threadIdx.x == 0) p2p_seal(c);
+    if (!done) return;
 #pragma unroll
     for (int q = 0; q < P2P_QUADS; ++q) {
         const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4 + q * stride;
@@ -216,7 +253,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long 
     if (blockIdx.x == 0) p2p_push(c, P2P_READY, step);
     const int t = __hip_atomic_load(&t_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (pre_ticked ? 0 : 1);   // optim.rs:84
     const float step_size = adam_step_size(lr[0], beta1, beta2, t);
-    const bool ok = p2p_wait_all(c, P2P_READY, step);
+    const bool ok = p2p_verdict(c, P2P_READY, 3, step);   // all workgroups apply the update, or none does
     if (ok) {
         for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 256 * 4) {
             if (!has_grad[p2p_find_tensor(offsets, n_tensors, i)]) continue;
@@ -238,11 +275,20 @@ __global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long 
             *reinterpret_cast<float4 *>(p + i) = po;
         }
     }
+    if (!ok) {      // READY timed out: nothing was read, nothing moved, the counter stays; the error word is up
+        if (blockIdx.x == 0 && threadIdx.x == 0) p2p_seal(c);
+        return;
+    }
     p2p_arrive(c, step);
     if (blockIdx.x == 0) {
-        const bool done = p2p_wait_all(c, P2P_DONE, step);   // the next backward launch overwrites the buffer the peers were reading
-        // (a step that timed out does not count: optim.rs:84 belongs to an update that happened)
-        if (!pre_ticked && ok && done && threadIdx.x == 0) __hip_atomic_store(&t_state[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the next backward launch overwrites the buffer the peers are reading: wait for them.  A time-out HERE comes after a complete
+        // update (every gradient was summed over all W ranks): p / m / v moved, so the counter moves with them (optim.rs:84) -- the state
+        // stays consistent -- and the error word says that a peer may not have finished (the host raises: the replicas are out of step).
+        (void)p2p_wait_all(c, P2P_DONE, step);
+        if (threadIdx.x == 0) {
+            if (!pre_ticked) __hip_atomic_store(&t_state[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p2p_seal(c);
+        }
     }
 }
 
@@ -399,6 +445,13 @@ int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs) {
 
 int th_comm_is_p2p(const th_comm *comm) { return comm && comm->p2p ? 1 : 0; }
 
+int th_comm_count(const th_comm *comm, int *out_ranks) {
+    TH_REQUIRE(comm && out_ranks, "th_comm_count: null argument");
+    *out_ranks = comm->n_ranks;
+    if (!comm->p2p && comm->comm) TH_NCCL(ncclCommCount(comm->comm, out_ranks));   // what RCCL itself says the communicator spans
+    return 0;
+}
+
 int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error) {
     TH_REQUIRE(comm && ctx && out_error, "th_comm_error: null argument");
     *out_error = 0;
@@ -413,6 +466,12 @@ int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error) {
 int th_comm_error_peek(const th_comm *comm, int *out_error) {
     TH_REQUIRE(comm && out_error, "th_comm_error_peek: null argument");
     *out_error = (comm->p2p && comm->err_host) ? (int)__atomic_load_n(comm->err_host, __ATOMIC_RELAXED) : 0;
+    return 0;
+}
+
+int th_comm_error_word(const th_comm *comm, const uint32_t **d_out) {
+    TH_REQUIRE(comm && d_out, "th_comm_error_word: null argument");
+    *d_out = comm->p2p ? comm->state + 2 : nullptr;
     return 0;
 }
 

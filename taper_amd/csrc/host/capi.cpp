@@ -358,6 +358,14 @@ int tp_comm_set_timeout_ms(tp_comm *c, int64_t ms) { TP_BEGIN c->c->set_timeout_
 int tp_comm_set_fuse_adam(tp_comm *c, int on) { TP_BEGIN c->c->fuse_adam = on != 0; TP_END }
 int tp_comm_free(tp_comm *c) { TP_BEGIN delete c; TP_END }
 int tp_comm_allreduce_mean(tp_comm *c, void *d_buf, size_t n) { TP_BEGIN c->c->allreduce_mean((float *)d_buf, n); TP_END }
+int tp_comm_count(tp_comm *c, int *out_ranks) { TP_BEGIN th_check(th_comm_count(c->c->handle(), out_ranks), "th_comm_count"); TP_END }
+int tp_comm_time_exchange(tp_comm *c, tp_optim *o, int reps, float *us) {
+    TP_BEGIN
+    auto *adam = dynamic_cast<Adam *>(o->o.get());
+    TAPER_ASSERT(adam, "tp_comm_time_exchange: needs an Adam optimizer");
+    *us = c->c->time_exchange(*adam, reps);
+    TP_END
+}
 
 int tp_trainer_new(tp_module *m, tp_optim *o, tp_trainer **out) {
     TP_BEGIN

@@ -940,9 +940,9 @@ void Adam::step() {  // optim.rs:83-113
     const size_t left = fp_.sync_mask(&fused_);
     std::fill(fused_.begin(), fused_.end(), 0);
     if (external_tick_ && left == 0) return;  // t was ticked by the loss kernel and nothing is left to update
-    TH(th_adam_step(Device::ctx(), fp_.p_arena->d, fp_.g_arena->d, m_->d, v_->d, fp_.d_offsets(), fp_.d_has_grad(),
-                    (int)fp_.params.size(), fp_.total, d_tick(), state_->d + 2, beta1_, beta2_, eps_, wd_,
-                    external_tick_ ? 1 : 0));
+    TH(th_adam_step_guarded(Device::ctx(), fp_.p_arena->d, fp_.g_arena->d, m_->d, v_->d, fp_.d_offsets(), fp_.d_has_grad(),
+                            (int)fp_.params.size(), fp_.total, d_tick(), state_->d + 2, beta1_, beta2_, eps_, wd_,
+                            external_tick_ ? 1 : 0, step_guard_));
 }
 
 bool Adam::step_reduced(const Communicator &comm) {
@@ -1254,6 +1254,38 @@ bool Communicator::failed() const {
 
 void Communicator::set_timeout_ms(int64_t ms) { TH(th_comm_set_timeout_ms(comm_, ms)); }
 
+const uint32_t *Communicator::error_word() const {
+    const uint32_t *w = nullptr;
+    TH(th_comm_error_word(comm_, &w));
+    return w;
+}
+
+float Communicator::time_exchange(Adam &opt, int reps) {
+    th_ctx *ctx = Device::ctx();
+    th_event *e0 = nullptr, *e1 = nullptr;
+    TH(th_event_create(&e0));
+    TH(th_event_create(&e1));
+    FlatParams &fp = opt.flat();
+    opt.set_step_guard(is_p2p() ? error_word() : nullptr);
+    auto once = [&] {
+        if (!opt.step_reduced(*this)) {
+            fp.zero_missing();
+            allreduce_mean(fp.g_arena->d, (size_t)fp.total);
+            opt.step();
+        }
+    };
+    for (int i = 0; i < 3; ++i) once();
+    TH(th_event_record(ctx, e0));
+    for (int i = 0; i < reps; ++i) once();
+    TH(th_event_record(ctx, e1));
+    Device::sync();
+    float ms = 0.f;
+    TH(th_event_elapsed_ms(e0, e1, &ms));
+    th_event_destroy(e0);
+    th_event_destroy(e1);
+    return ms * 1e3f / (float)std::max(reps, 1);
+}
+
 void Communicator::allreduce_mean(float *d_buf, size_t n) const {
     TH(th_allreduce_sum_scale(comm_, Device::ctx(), d_buf, n, 1.0f / (float)n_ranks));
 }
@@ -1267,6 +1299,8 @@ static Tensor shape_input(const Tensor &images, const Shape &sample_shape) {
 }
 
 static void reduce_grads(Trainer &t) {
+    // (the Adam step behind a peer-to-peer all-reduce skips itself on the device when that all-reduce timed out)
+    t.optimizer->set_step_guard(t.comm && t.comm->is_p2p() ? t.comm->error_word() : nullptr);
     if (!t.comm) return;
     FlatParams &fp = t.optimizer->flat();
     fp.zero_missing();  // grad None contributes zeros; the has_grad mask is rank-invariant

@@ -461,6 +461,9 @@ class Adam : public Optimizer {  // optim.rs:43-128
     // data parallel over a peer-to-peer communicator: all-reduce(mean) of the gradient arena and this step's update in ONE
     // launch (th_allreduce_adam); false = not applicable here (the caller all-reduces in place, then step())
     bool step_reduced(const class Communicator &comm);
+    // step() behind an all-reduce of `comm` (peer-to-peer form): the update is skipped on the device when that all-reduce timed out
+    // (th_adam_step_guarded) -- the arena then still holds this rank's own gradients
+    void set_step_guard(const uint32_t *d_error_word) { step_guard_ = d_error_word; }
     void zero_grad() override { fp_.zero_grad(); } // optim.rs:115-119
     float get_lr() const { return lr_; }
     void set_lr(float lr);                         // optim.rs:125-127
@@ -503,6 +506,7 @@ class Adam : public Optimizer {  // optim.rs:43-128
     float lr_, beta1_, beta2_, eps_, wd_;
     bool external_tick_ = false;
     bool carry_deferred_ = false;
+    const uint32_t *step_guard_ = nullptr;
     std::vector<char> fused_;                // per parameter: updated by a fused epilogue this step
     std::vector<th_adam_slice> deferred_;    // updates waiting for a carrier launch
 };
@@ -669,6 +673,10 @@ class Communicator {
     ~Communicator();
     void allreduce_mean(float *d_buf, size_t n) const;  // sum over ranks * 1/W on the ctx stream
     th_comm *handle() const { return comm_; }
+    const uint32_t *error_word() const;                   // device word, non-zero once an all-reduce timed out (nullptr: RCCL)
+    // `reps` exchanges as a Trainer step issues them (all-reduce + Adam: one fused launch, or all-reduce then Adam::step), back to back
+    // between two events on the stream, on every rank at once; us per exchange.  The optimizer state moves (call it after the timed run).
+    float time_exchange(Adam &opt, int reps);
     int n_ranks, rank;
     bool fuse_adam = true;                                // p2p: feed the mean gradient straight into Adam::step (th_allreduce_adam)
 

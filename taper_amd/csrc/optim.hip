@@ -26,7 +26,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
                                                    float *__restrict__ v, const int64_t *__restrict__ offsets,
                                                    const int32_t *__restrict__ has_grad, int n_tensors, int64_t total,
                                                    int32_t *t_state, const float *__restrict__ lr, float beta1, float beta2,
-                                                   float eps, float wd, int pre_ticked, int vec_ok) {
+                                                   float eps, float wd, int pre_ticked, int vec_ok, const uint32_t *__restrict__ guard) {
+    // guard (nullable): the error word of the communicator whose all-reduce produced g.  Up = that all-reduce timed out and g still holds
+    // THIS rank's gradients: no update, no tick (written by an earlier launch only: every workgroup reads the same value)
+    if (guard && guard[0] != 0u) return;
     const int t = __hip_atomic_load(&t_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (pre_ticked ? 0 : 1);  // optim.rs:84
     const float step = adam_step_size(lr[0], beta1, beta2, t);
     // four consecutive elements per thread (dwordx4 on all seven streams); a quad that straddles two tensors or the
@@ -145,18 +148,25 @@ using namespace th;
 
 extern "C" {
 
-int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v, const int64_t *d_offsets,
-                 const int32_t *d_has_grad, int n_tensors, int64_t total, int32_t *d_t, const float *d_lr, float beta1,
-                 float beta2, float eps, float weight_decay, int pre_ticked) {
+int th_adam_step_guarded(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v, const int64_t *d_offsets,
+                         const int32_t *d_has_grad, int n_tensors, int64_t total, int32_t *d_t, const float *d_lr, float beta1,
+                         float beta2, float eps, float weight_decay, int pre_ticked, const uint32_t *d_skip_if_nonzero) {
     TH_REQUIRE(ctx && d_params && d_grads && d_m && d_v && d_offsets && d_has_grad && d_t && d_lr, "th_adam_step: null argument");
     TH_REQUIRE(n_tensors > 0 && total >= 0, "th_adam_step: bad sizes");
     // the grid is never empty so that t always advances (optim.rs:84 increments even with no grads)
     const int grid = ew_grid((size_t)(total > 0 ? (total + 3) / 4 : 1), 256);
     const int vec_ok = (((uintptr_t)d_params | (uintptr_t)d_grads | (uintptr_t)d_m | (uintptr_t)d_v) & 15) == 0;   // dwordx4 streams
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_params, d_grads, d_m, d_v, d_offsets, d_has_grad,
-                       n_tensors, total, d_t, d_lr, beta1, beta2, eps, weight_decay, pre_ticked, vec_ok);
+                       n_tensors, total, d_t, d_lr, beta1, beta2, eps, weight_decay, pre_ticked, vec_ok, d_skip_if_nonzero);
     TH_LAUNCH_CHECK();
     return 0;
+}
+
+int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m, float *d_v, const int64_t *d_offsets,
+                 const int32_t *d_has_grad, int n_tensors, int64_t total, int32_t *d_t, const float *d_lr, float beta1,
+                 float beta2, float eps, float weight_decay, int pre_ticked) {
+    return th_adam_step_guarded(ctx, d_params, d_grads, d_m, d_v, d_offsets, d_has_grad, n_tensors, total, d_t, d_lr, beta1, beta2, eps,
+                                weight_decay, pre_ticked, nullptr);
 }
 
 int th_adam_tick(th_ctx *ctx, int32_t *d_t) {

@@ -1,6 +1,7 @@
 """Two ranks bootstrap a peer-to-peer communicator on GPU 0; rank 1 then never launches the collective.  Rank 0's launch must give
 up after its bounded spin (set to 3 s here) instead of hanging the GPU, apply NOTHING (no parameter moves, Adam's counter stays), and the
-Trainer must raise -- a second step after the error is a no-op that raises again (tests/test_gpu_dp.py)."""
+Trainer must raise -- a second step after the error is a no-op that raises again (tests/test_gpu_dp.py).  TAPER_STRAGGLER_FORM=inplace:
+the same through the in-place all-reduce followed by Adam::step (th_adam_step_guarded skips on the communicator's error word)."""
 import os
 import sys
 import time
@@ -27,6 +28,8 @@ t0 = time.time()
 if rank == 0:
     from taper_amd._lib import TaperError
     comm.set_timeout_ms(3000)
+    if os.environ.get("TAPER_STRAGGLER_FORM") == "inplace":
+        comm.set_fuse_adam(False)       # in-place all-reduce, then Adam::step -- guarded by the communicator's error word
     tr = T.Trainer(model, opt, comm=comm)
     rng = np.random.default_rng(0)
     x = rng.uniform(0, 1, (64, 784)).astype(np.float32)

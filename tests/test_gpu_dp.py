@@ -186,11 +186,24 @@ def test_bench_self_spawn_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["config"]["workload"] == "mlp_784-128-10_b128"   # BASELINE configs[3]: 128 rows per GPU
     assert d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp2" and "p2p" in d["config"]["comm"]
+    assert len(lines[0]) < 2000                               # the whole line fits the driver's 2 000-character tail
     dp = d["data_parallel"]
     assert dp["replicas_bit_identical"] is True
-    assert dp["single_gpu_same_per_gpu_batch"]["per_gpu_batch"] == 128 and dp["single_gpu_same_per_gpu_batch"]["value"] > 0
-    assert dp["dp_at_64_rows_per_gpu"]["replicas_bit_identical"] is True
+    assert dp["single_gpu_ms_per_step"] > 0 and dp["b64_per_gpu_ms_per_step"] > 0
+    # eff = T(1 GPU, B/W rows) / T(W GPUs, B/W rows each), measured in the same run
+    assert dp["weak_scaling_efficiency"] == pytest.approx(dp["single_gpu_ms_per_step"] / d["ms_per_step"], rel=1e-3)
+    assert "skipped" in dp["same_job_over_rccl"]              # two ranks on one device: RCCL cannot run, and the line says so
+    rf = d["roofline"]                                        # N > 1: the exchange launch, timed live on every rank (max over ranks)
+    assert rf["kernel"].startswith("p2p_allreduce_adam") and rf["bound"] == "hbm" and rf["us_per_launch"] > 0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3) and "HBM" in rf["peak_basis"]
+    P = 101772                                                # 100 352 + 128 + 1 280 + 12 (slices padded to 4 floats)
+    assert rf["alg_bytes_per_launch"] == (2 - 1) * 4 * P + 4 * P + 24 * P
+    assert d["step_roofline"]["mfma_frac"] > 0
+    assert d["cpu_baseline"]["value"] is None and "--gpus 1" in d["cpu_baseline"]["see"]
     assert d["value"] > 0 and d["value"] == pytest.approx(40 * 256 / (d["ms_per_step"] * 1e-3 * 40), rel=1e-3)
+    full = json.loads((ROOT / d["details"]).read_text())      # the side file keeps everything the line left out
+    assert full["data_parallel"]["single_gpu_same_per_gpu_batch"]["per_gpu_batch"] == 128
+    assert full["data_parallel"]["dp_at_64_rows_per_gpu"]["replicas_bit_identical"] is True
 
 
 def test_bench_eight_ranks_is_global_batch_1024():
@@ -207,15 +220,20 @@ def test_bench_eight_ranks_is_global_batch_1024():
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 1024 and d["config"]["workload"] == "mlp_784-128-10_b128"
     assert d["config"]["parallelism"] == "dp8" and "p2p" in d["config"]["comm"]          # --dp-backend auto took the one-shot form
     assert d["data_parallel"]["replicas_bit_identical"] is True and d["scaling"] == "weak"
+    assert len(lines[0]) < 2000
+    assert d["data_parallel"]["weak_scaling_efficiency"] > 0 and d["roofline"]["alg_bytes_per_launch"] == (8 - 1 + 1 + 6) * 4 * 101772
 
 
-def test_p2p_missing_peer_times_out_instead_of_hanging(tmp_path):
+@pytest.mark.parametrize("form", ["fused", "inplace"])
+def test_p2p_missing_peer_times_out_instead_of_hanging(tmp_path, form):
     """a peer that never launches its side of the all-reduce: the waiting rank's kernel gives up after its wall-clock-bounded spin and the
-    communicator reports it -- no GPU hang"""
+    communicator reports it -- no GPU hang -- and NOTHING was applied, in both forms: the fused all-reduce + Adam launch skips its update,
+    and behind the in-place all-reduce (which stores nothing) Adam::step skips itself on the communicator's error word"""
     env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     key = uuid.uuid4().hex[:12]
     procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "p2p_straggler_worker.py")],
-                              env=dict(env0, RANK=str(r), WORLD_SIZE="2", TAPER_DP_OUT=str(tmp_path), TAPER_DP_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                              env=dict(env0, RANK=str(r), WORLD_SIZE="2", TAPER_DP_OUT=str(tmp_path), TAPER_DP_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                                       TAPER_STRAGGLER_FORM=form),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = []
     for p in procs:
