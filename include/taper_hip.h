@@ -271,8 +271,6 @@ int th_mlp3_supported(int batch, int in_features, int h1, int h2, int classes);
 int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batch, int in_features, const th_mlp3_layer *layers,
                  float *d_dx, float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state,
                  int64_t advance, int32_t *d_tick, const th_mlp3_gap *gap);
-/* Test hook: how many th_mlp3_xent calls this thread has enqueued (the parity tests assert which form a Trainer step took). */
-int th_debug_mlp3_calls(int64_t *out);
 
 /* ---- th_mlp2_xent: the large-batch step of Linear + ReLU, Linear, softmax cross-entropy in THREE launches --------------------------
  * (nn.rs:54-60, activation.rs:10-12, loss.rs:101-195, 271-290, the backward closures ops.rs:238-294, 358-369, tensor.rs:574-587, 674-694,
@@ -301,8 +299,6 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
                  float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
                  int32_t *d_tick, const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse, const th_adam_fuse *w2_fuse,
                  const th_adam_fuse *b2_fuse);
-/* Test hook: how many th_mlp2_xent calls this thread has enqueued. */
-int th_debug_mlp2_calls(int64_t *out);
 
 /* ---- element-wise: src/ops.rs:8-120,377-496; src/tensor.rs:36-161 ----- */
 int th_add(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
@@ -466,17 +462,6 @@ int th_wide_head_grads(th_ctx *ctx, const float *d_x, const float *d_dl, const f
                        int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss, float *d_ncorrect,
                        float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, const th_adam_fuse *w_fuse,
                        const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse);
-/* Test hook: 1 = the compiled chain instances are not used on this thread (their nets take the run-time-described kernel, id 3); 0 = default */
-int th_debug_set_chain_generic(int on);
-/* Test hook: launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity
- * tests assert which kernel instance a shape takes): out6 = {16-channel tiles per workgroup (1/2/4), 1 if the
- * operands are staged by LDS-DMA (2-5: the image-resident kernel; 6: a conv chain, out6[0] = its instance id), waves per workgroup / 4, grid.x, grid.y, 1 if the epilogue is the fused 2x2 pool}. */
-int th_debug_last_conv_config(th_ctx *ctx, int *out6);
-/* Test hook: which matrix-core kernel takes a 3x3 launch.  -1 (default): the image-resident kernel (whole images per
- * workgroup, every output tile in registers; out6[1] == 2 in th_debug_last_conv_config, out6[2] = pixel tiles per wave,
- * out6[4] = images per unit) when the launch has at least one unit per two CUs, the 128-pixel kernel otherwise; 0: never;
- * 1: whenever the shape fits it. */
-int th_debug_set_conv_img(th_ctx *ctx, int mode);
 /* 1x1 stride-1 pad-0 convolution as GEMM.  layout 0 = taper (raw NCHW buffer
  * reinterpreted as [N*H*W, C], tensor.rs:1799-1801, Q4 + Q3); 1 = standard. */
 int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,

@@ -1,5 +1,5 @@
 """Loads the two native libraries and declares their ctypes signatures by
-parsing the C-ABI headers (include/taper_hip.h, include/taper_host.h), so the
+parsing the C-ABI headers (include/taper_hip.h + taper_hip_debug.h, include/taper_host.h), so the
 Python binding can never drift from the boundary a Rust host would bind.
 
 There is NO CPU fallback: if the libraries are missing this module raises.
@@ -63,25 +63,28 @@ def build_native(verbose: bool = False) -> None:
     subprocess.check_call(["make", "-C", str(CSRC / "host")], stdout=out)
 
 
-def _load(name: str, header: str):
+def _load(name: str, *headers: str):
     so = LIBDIR / name
     if not so.exists():
         raise ImportError(
             f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "taper_amd has no CPU fallback.")
     lib = C.CDLL(str(so), mode=C.RTLD_GLOBAL)
-    protos = parse_header(INCLUDE / header)
+    protos = {}
+    for header in headers:
+        protos.update(parse_header(INCLUDE / header))
     for fn, (restype, argtypes) in protos.items():
         try:
             f = getattr(lib, fn)
         except AttributeError as e:
-            raise ImportError(f"{so} does not export {fn} declared in {header}") from e
+            raise ImportError(f"{so} does not export {fn} declared in {' / '.join(headers)}") from e
         f.restype = restype
         f.argtypes = argtypes
     return lib, protos
 
 
-hip, HIP_PROTOS = _load("libtaper_hip.so", "taper_hip.h")
+# (taper_hip_debug.h: the test hooks, declared apart from the boundary)
+hip, HIP_PROTOS = _load("libtaper_hip.so", "taper_hip.h", "taper_hip_debug.h")
 host, HOST_PROTOS = _load("libtaper_host.so", "taper_host.h")
 
 

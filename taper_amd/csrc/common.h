@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/taper_hip.h"
+#include "../../include/taper_hip_debug.h"   // test hooks: declared apart from the boundary, defined in the same library
 
 namespace th {
 

@@ -123,6 +123,16 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def _env_ms(name: str, default: int) -> int:
+    """a positive millisecond bound from the environment; anything else (unset, 0, negative, not a number) is the default -- what
+    th_comm_init_p2p does with the same variable, so that a rank with a malformed value does not raise after the collective self-check"""
+    try:
+        v = int(os.environ.get(name, ""))
+    except ValueError:
+        return default
+    return v if v > 0 else default
+
+
 def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", optimizer=None, fine_grained: bool = False, info: dict | None = None):
     """-> taper_amd.Communicator (or None for a single rank).
     backend "rccl": RCCL all-reduce (ring / tree over xGMI) -- rank 0's unique id is broadcast.
@@ -167,11 +177,12 @@ def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", op
                 err = f"connect: {e}"
         if rdzv.all_reduce_sum(1.0 if err else 0.0) > 0:
             del comm
+            rdzv.barrier()        # every rank has dropped its mappings before anybody frees or re-homes an arena (as below)
             raise RuntimeError(f"peer-to-peer communicator unavailable (rank {rdzv.rank}: {err or 'a peer failed'})")
         # Known patterns through the real arena on the real links, several rounds through the SAME addresses and through BOTH kernels: a
         # rank that sees stale or no peer data must not train.  The waits inside are short here (a bootstrap peer is either there or
         # gone) and go back to the training bound afterwards.
-        comm.set_timeout_ms(int(os.environ.get("TAPER_P2P_BOOT_TIMEOUT_MS", "20000")))
+        comm.set_timeout_ms(_env_ms("TAPER_P2P_BOOT_TIMEOUT_MS", 20000))
         try:
             ok = comm.self_check(optimizer)
         except Exception as e:   # noqa: BLE001
@@ -182,7 +193,7 @@ def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", op
             rdzv.barrier()        # every rank has dropped its mappings before anybody frees or re-homes an arena
             raise RuntimeError(f"peer-to-peer all-reduce self-check failed on {int(bad)} rank(s) (rank {rdzv.rank}: "
                                f"{'ok' if ok else (err or 'mismatch or timeout')})")
-        comm.set_timeout_ms(int(os.environ.get("TAPER_P2P_TIMEOUT_MS", "120000")))
+        comm.set_timeout_ms(_env_ms("TAPER_P2P_TIMEOUT_MS", 120000))
         return comm
     if backend != "rccl":
         raise ValueError(f"unknown data-parallel backend {backend!r}")

@@ -137,7 +137,7 @@ class Ctx:
     def call(self, name: str, *args):
         """name(ctx, *args) through the C ABI; DevBuf / None / ints are accepted for pointers."""
         if name not in HIP_PROTOS:
-            raise AttributeError(f"{name} is not declared in include/taper_hip.h")
+            raise AttributeError(f"{name} is not declared in include/taper_hip.h (or taper_hip_debug.h)")
         conv = [int(a) if isinstance(a, DevBuf) else a for a in args]
         th_check(getattr(hip, name)(self.h, *conv), name)
 

@@ -15,7 +15,8 @@ def _declared(header):
     return sorted(set(re.findall(r"\b((?:th|tp)_[a-z0-9_]+)\s*\(", text)))
 
 
-@pytest.mark.parametrize("so,header,min_syms", [("libtaper_hip.so", "taper_hip.h", 70), ("libtaper_host.so", "taper_host.h", 90)])
+@pytest.mark.parametrize("so,header,min_syms", [("libtaper_hip.so", "taper_hip.h", 70), ("libtaper_hip.so", "taper_hip_debug.h", 5),
+                                                ("libtaper_host.so", "taper_host.h", 90)])
 def test_library_exports_every_declared_symbol(so, header, min_syms):
     path = ROOT / "taper_amd" / "lib" / so
     assert path.exists(), f"{path} missing: run __graft_entry__.build()"
@@ -28,8 +29,10 @@ def test_library_exports_every_declared_symbol(so, header, min_syms):
 
 def test_header_parser_matches_declarations():
     from taper_amd import _lib
-    for header, protos in (("taper_hip.h", _lib.HIP_PROTOS), ("taper_host.h", _lib.HOST_PROTOS)):
-        assert sorted(protos) == _declared(header)
+    assert sorted(_lib.HIP_PROTOS) == sorted(_declared("taper_hip.h") + _declared("taper_hip_debug.h"))
+    assert sorted(_lib.HOST_PROTOS) == _declared("taper_host.h")
+    # the boundary itself holds no test hooks
+    assert not [n for n in _declared("taper_hip.h") if n.startswith("th_debug")]
     # spot-check a few parsed signatures against the header text
     r, a = _lib.HIP_PROTOS["th_sgemm"]
     assert r is ctypes.c_int and len(a) == 11 and a[1] is ctypes.c_int and a[6] is ctypes.c_float and a[7] is ctypes.c_void_p
