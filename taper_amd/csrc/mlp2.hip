@@ -102,40 +102,52 @@ struct Mlp2RowsArgs {
 // The k chunks travel through a ring of NS stages: chunk it + NS - 1 is requested while chunk it is contracted, so a request has NS - 1
 // iterations (~0.5-1 us each) to cross the fabric -- with two stages the loop ran at the memory latency, not at the MFMA rate (r04: 52.7 us
 // for 3.3 GFLOP at batch 16 384).
-template <int RT, int NS>
-__global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2RowsArgs a) {
+// NW = 4 (default) or 8 waves.  With eight, two waves share a SIMD: the waves are two groups of four column quarters -- on 64-row tiles the
+// groups are the two 32-row halves (one accumulator tile per wave); on 32-row tiles both groups hold the same 32 x 32 tile and split every
+// chunk's four k rounds between them, two accumulators that are added, group 0 + group 1, when H goes to LDS.  Built to test whether one
+// wave per SIMD was what held the k loop back; it was not (see the launcher), the form stays as a measurement knob.
+template <int RT, int NS, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_rows_kernel(Mlp2RowsArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NI = RT / 32;                 // 32-row MFMA tiles per wave (the wave owns 32 hidden columns of all RT rows)
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    constexpr int NI = NW == 4 ? RT / 32 : 1;   // 32-row MFMA tiles per wave
+    constexpr bool KSPLIT = NW == 8 && RT == 32;   // the two wave groups split a chunk's k rounds
     constexpr int A_T = RT * M2_BK, B_T = 128 * M2_BK;
     constexpr int NRB = RT / 16;                // 16-row blocks of the tile
-    constexpr int STG = A_T + B_T, L = NI + 4;  // floats per stage (X chunk, then W1 chunk); LDS-DMA instructions per wave and stage
+    constexpr int STG = A_T + B_T;              // floats per stage (X chunk, then W1 chunk)
+    constexpr int NA = (RT / 8 + NW - 1) / NW, NB = 16 / NW;   // LDS-DMA instructions per wave and stage (a wave may own fewer X instructions)
+    constexpr int LMIN = (RT / 8) / NW + NB;    // ... of the wave that issues the fewest: what the in-order counter may be allowed to hold
+    constexpr int NTT = 8 / NW;                 // 16-column tiles per wave in the dH stage
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lk = lane >> 5, l16 = lane & 15, g4 = lane >> 4;
+    const int cq = wave & 3, grp = wave >> 2;   // column quarter; wave group (NW == 8)
     const int r0 = blockIdx.x * RT, B = a.batch, in_f = a.in_f, hid = a.hid, C = a.c;
     M2_STAMP(0, blockIdx.x == 0);
     if (a.tick && blockIdx.x == 0 && t == 0) a.tick[0] += 1;                  // optim.rs:84 (the launch that reads t comes later)
     const long cur = (a.src.idx && a.src.cursor) ? a.src.cursor[0] : 0;
 
-    // ---- staging plans: lane -> (row, k quad) of the 1 KB an LDS-DMA instruction fills ----
-    int a_voff[NI], b_voff[4];
+    // ---- staging plans: lane -> (row, k quad) of the 1 KB an LDS-DMA instruction fills; instruction i = NW j + wave covers rows 8 i .. 8 i + 7 ----
+    int a_voff[NA], b_voff[NB];
+    bool a_on[NA];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int row = 8 * (4 * j + wave) + (lane >> 3);
-        const int srow = src_row(a.src, cur, min(r0 + row, B - 1));          // rows beyond the batch: a copy of its last row, zeroed below
+    for (int j = 0; j < NA; ++j) {
+        const int row = 8 * (NW * j + wave) + (lane >> 3);
+        a_on[j] = NW * j + wave < RT / 8;
+        const int srow = src_row(a.src, cur, min(r0 + min(row, RT - 1), B - 1));   // rows beyond the batch: a copy of its last row, zeroed below
         a_voff[j] = (int)((unsigned)srow * (unsigned)in_f * 4u + (unsigned)(((lane & 7) ^ m2_swz(row)) << 4));
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 8 * (4 * j + wave) + (lane >> 3);
+    for (int j = 0; j < NB; ++j) {
+        const int row = 8 * (NW * j + wave) + (lane >> 3);
         b_voff[j] = (int)((unsigned)min(row, hid - 1) * (unsigned)in_f * 4u + (unsigned)(((lane & 7) ^ m2_swz(row)) << 4));
     }
     const i32x4 rs_x = make_rsrc(a.src.x, a.src.x_bytes), rs_w = make_rsrc(a.w1, (unsigned)hid * (unsigned)in_f * 4u);
     const unsigned lds0 = lds_addr(smem);
     // what the epilogue needs from memory is requested now, under the whole k loop
-    const int hcol = 32 * wave + li;
+    const int hcol = 32 * cq + li;
     const float bias1 = (a.b1 && hcol < hid) ? a.b1[hcol] : 0.f;
     const int hrow = 16 * wave + l16;                                         // the row this lane owns in the classifier stage (wave < NRB)
-    const int grow = min(r0 + hrow, B - 1);
+    const int grow = min(r0 + min(hrow, RT - 1), B - 1);
     const float tf = (wave < NRB) ? a.src.labels[src_row(a.src, cur, grow)] : 0.f;
     float4 w2a[8];                                                            // logits' A operand: W2[class l16][16 u + 4 g4 ..]
 #pragma unroll
@@ -144,31 +156,31 @@ __global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2Ro
         const float4 v = *reinterpret_cast<const float4 *>(a.w2 + (long)min(l16, C - 1) * hid + min(k, hid - 4));
         w2a[u] = k < hid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float b2v[4], w2b[2][4];                                                  // b2[class 4 g4 + e]; dH's B operand: W2[class 4 g4 + s][col]
+    float b2v[4], w2b[NTT][4];                                                // b2[class 4 g4 + e]; dH's B operand: W2[class 4 g4 + s][col]
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int cls = min(4 * g4 + e, C - 1);
         b2v[e] = a.b2 ? a.b2[cls] : 0.f;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) w2b[tt][e] = a.w2[(long)cls * hid + min(32 * wave + 16 * tt + l16, hid - 1)];
+        for (int tt = 0; tt < NTT; ++tt) w2b[tt][e] = a.w2[(long)cls * hid + min(16 * NTT * wave + 16 * tt + l16, hid - 1)];
     }
 
     const int nfull = in_f / M2_BK, ktail = in_f - nfull * M2_BK;
     // the ragged last chunk goes through registers (zero fill beyond in_f), requested first: it is the oldest load in flight
-    float4 ta[NI], tb[4];
+    float4 ta[NA], tb[NB];
     if (ktail) {
         const int k0 = nfull * M2_BK;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int row = 8 * (4 * j + wave) + (lane >> 3), mq = (lane & 7) ^ m2_swz(row);
+        for (int j = 0; j < NA; ++j) {
+            const int row = 8 * (NW * j + wave) + (lane >> 3), mq = (lane & 7) ^ m2_swz(row);
             const bool in = mq * 4 < ktail;
             const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.src.x) + (unsigned)a_voff[j] - (unsigned)(mq << 4) +
                                                                (unsigned)(k0 + (in ? mq * 4 : 0)) * 4u);
             ta[j] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = 8 * (4 * j + wave) + (lane >> 3), mq = (lane & 7) ^ m2_swz(row);
+        for (int j = 0; j < NB; ++j) {
+            const int row = 8 * (NW * j + wave) + (lane >> 3), mq = (lane & 7) ^ m2_swz(row);
             const bool in = mq * 4 < ktail;
             const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.w1) + (unsigned)b_voff[j] - (unsigned)(mq << 4) +
                                                                (unsigned)(k0 + (in ? mq * 4 : 0)) * 4u);
@@ -180,9 +192,10 @@ __global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2Ro
         const int k0 = it * M2_BK;
         const unsigned st = lds0 + (unsigned)(stage * STG) * 4u;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) lds_dma16(rs_x, st + 1024u * (unsigned)(4 * j + wave_u), a_voff[j], k0 * 4);
+        for (int j = 0; j < NA; ++j)
+            if (NW * j + wave_u < RT / 8) lds_dma16(rs_x, st + 1024u * (unsigned)(NW * j + wave_u), a_voff[j], k0 * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16(rs_w, st + (unsigned)A_T * 4u + 1024u * (unsigned)(4 * j + wave_u), b_voff[j], k0 * 4);
+        for (int j = 0; j < NB; ++j) lds_dma16(rs_w, st + (unsigned)A_T * 4u + 1024u * (unsigned)(NW * j + wave_u), b_voff[j], k0 * 4);
     };
 
     floatx16 acc[NI];
@@ -190,15 +203,17 @@ __global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2Ro
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    // this lane's LDS addresses: row (32 i + li) of X, row (32 wave + li) of W1; k quad 2 r + lk of round r, swizzled
+    // this lane's LDS addresses: row (tile row + li) of X, row (32 cq + li) of W1; k quad 2 r + lk of round r, swizzled
+    const int row_tile0 = (NW == 8 && RT == 64) ? grp : 0;
     int ao[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int ar = 32 * i + li;
+        const int ar = 32 * (row_tile0 + i) + li;
         ao[i] = ar * M2_BK + ((lk ^ m2_swz(ar)) << 2);
     }
-    const int br = 32 * wave + li;
+    const int br = 32 * cq + li;
     const int bo = br * M2_BK + ((lk ^ m2_swz(br)) << 2);
+    const int r_lo = KSPLIT ? 2 * grp : 0, r_n = KSPLIT ? 2 : 4;              // this wave's k rounds of a chunk
 
     // eight k per round: lane half lk holds k = 8 r + 4 lk + e of its row; the operands of round r + 1 are requested before the MFMAs of round r
     auto contract = [&](const float *as, const float *bs, int nr) {
@@ -210,12 +225,12 @@ __global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2Ro
     }
 #define M2_MFMA(CS, E) \
     _Pragma("unroll") for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CS][i].E, bf[CS].E, acc[i], 0, 0, 0);
-        M2_REQ(0, 0)
+        M2_REQ(0, r_lo)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cs = r & 1;
+        for (int q = 0; q < r_n; ++q) {
+            const int cs = q & 1, r = r_lo + q;
             if (r < nr) {
-                if (r + 1 < 4) M2_REQ(cs ^ 1, r + 1)
+                if (q + 1 < r_n) M2_REQ(cs ^ 1, r + 1)
                 __builtin_amdgcn_sched_barrier(0);
                 M2_MFMA(cs, x)
                 M2_MFMA(cs, y)
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2Ro
     int stage = 0;
     for (int it = 0; it < nfull; ++it) {
         // chunk `it` has landed once only the NS - 2 fetches issued after it are still in flight (fewer were issued near the end: wait for all)
-        if (it + NS - 1 <= nfull) wait_vmcnt<(NS - 2) * L>();
+        if (it + NS - 1 <= nfull) wait_vmcnt<(NS - 2) * LMIN>();
         else wait_vmcnt<0>();
         lds_barrier();                                      // ... in every wave; and every wave is done with the stage refilled next
         if (it == 0) M2_STAMP(1, blockIdx.x == 0);
@@ -245,9 +260,10 @@ __global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2Ro
     if (ktail) {
         lds_barrier();
 #pragma unroll
-        for (int j = 0; j < NI; ++j) *reinterpret_cast<float4 *>(smem + 256 * (4 * j + wave) + 4 * lane) = ta[j];
+        for (int j = 0; j < NA; ++j)
+            if (NW * j + wave < RT / 8) *reinterpret_cast<float4 *>(smem + 256 * (NW * j + wave) + 4 * lane) = ta[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(smem + A_T + 256 * (4 * j + wave) + 4 * lane) = tb[j];
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<float4 *>(smem + A_T + 256 * (NW * j + wave) + 4 * lane) = tb[j];
         lds_barrier();
         contract(smem, smem + A_T, (ktail + 7) / 8);
     }
@@ -258,15 +274,26 @@ __global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2Ro
     float *Hs = smem;                           // [RT][M2_LDH]
     float *D3S = Hs + RT * M2_LDH;              // [RT][20]: dlogits [row][class], zero for classes >= C and rows >= batch
     float *sc = D3S + RT * 20;                  // [4][2]: the waves' NLL / hit sums
+    if (KSPLIT) {                               // the second group's half of the k sum goes through H's own cells: group 0 + group 1
+        if (grp == 1) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;     // C/D map of 32x32x2
-            float v = acc[i][e] + bias1;
-            v = (v > 0.f && hcol < hid) ? v : 0.f;                         // activation.rs:10-12; columns beyond hid hold zeros
-            Hs[row * M2_LDH + hcol] = v;
+            for (int e = 0; e < 16; ++e) Hs[((e & 3) + 8 * (e >> 2) + 4 * lk) * M2_LDH + hcol] = acc[0][e];
         }
+        lds_barrier();
+    }
+    if (!KSPLIT || grp == 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * (row_tile0 + i) + (e & 3) + 8 * (e >> 2) + 4 * lk;     // C/D map of 32x32x2
+                float v = acc[i][e];
+                if (KSPLIT) v = v + Hs[row * M2_LDH + hcol];
+                v += bias1;
+                v = (v > 0.f && hcol < hid) ? v : 0.f;                     // activation.rs:10-12; columns beyond hid hold zeros
+                Hs[row * M2_LDH + hcol] = v;
+            }
+    }
     lds_barrier();
     // logits^T[class 4 g4 + e][row l16] = W2 . H^T + b2, the row's softmax cross-entropy (wave w: rows 16 w ..)
     if (wave < NRB) {
@@ -302,12 +329,12 @@ __global__ __launch_bounds__(256, RT == 64 ? 1 : 2) void mlp2_rows_kernel(Mlp2Ro
     M2_STAMP(3, blockIdx.x == 0);
     float *part = a.part + (long)blockIdx.x * a.part_stride;
     const int o_db1 = C * hid, o_db2 = o_db1 + hid, o_nll = o_db2 + 16;
-    // wave w owns hidden columns 32 w .. 32 w + 31 of ALL the tile's rows: dZ1 = (dlogits W2) * [H > 0] (ops.rs:254-265, 358-369), its
+    // wave w owns 16 NTT hidden columns of ALL the tile's rows: dZ1 = (dlogits W2) * [H > 0] (ops.rs:254-265, 358-369), its
     // column sums (db1, tensor.rs:686-691) and the tile's share of dW2 = dlogits^T H (ops.rs:266-294)
-    if (32 * wave < hid) {
+    if (16 * NTT * wave < hid) {
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int col = 32 * wave + 16 * tt + l16;
+        for (int tt = 0; tt < NTT; ++tt) {
+            const int col = 16 * NTT * wave + 16 * tt + l16;
             float colsum = 0.f;
             floatx4 dw2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -792,15 +819,21 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     r.dz1 = dz1; r.part = part; r.part_stride = stride; r.tick = d_tick;
     // ring depth of launch 1: four stages (six for the 32-row tiles, one workgroup per CU, measured no faster: a lone wave per SIMD is bound by
     // its own issue order, not by the requests in flight)
-#define M2_ROWS_LAUNCH(RT_, NS_)                                                                                                   \
+#define M2_ROWS_LAUNCH(RT_, NS_, NW_)                                                                                              \
     do {                                                                                                                           \
         const size_t lds = (size_t)NS_ * (RT_ + 128) * M2_BK * sizeof(float);                                                      \
         static bool attr = false;                                                                                                  \
-        if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)mlp2_rows_kernel<RT_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
-        hipLaunchKernelGGL((mlp2_rows_kernel<RT_, NS_>), dim3(n_blk), dim3(256), lds, ctx->stream, r);                              \
+        if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)mlp2_rows_kernel<RT_, NS_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
+        hipLaunchKernelGGL((mlp2_rows_kernel<RT_, NS_, NW_>), dim3(n_blk), dim3(64 * NW_), lds, ctx->stream, r);                    \
     } while (0)
-    if (RT == 64) M2_ROWS_LAUNCH(64, 4);
-    else M2_ROWS_LAUNCH(32, 4);
+    // waves per workgroup of launch 1: four.  TAPER_MLP2_NW=8 (two waves per SIMD on the same ring; on 32-row tiles the two wave groups split
+    // every chunk's k rounds) measured the same to 2 %: 39.7 / 23.7 / 22.7 us against 39.2-40.5 / 23.5 / 22.5 us at 16 384 / 4 096 / 1 024 rows --
+    // the k loop already runs at the rate the matrix pipes sustain at the clocks the part holds under this load
+    static const int nw = [] { const char *e = getenv("TAPER_MLP2_NW"); return e && atoi(e) == 8 ? 8 : 4; }();
+    if (RT == 64 && nw == 8) M2_ROWS_LAUNCH(64, 4, 8);
+    else if (RT == 64) M2_ROWS_LAUNCH(64, 4, 4);
+    else if (nw == 8) M2_ROWS_LAUNCH(32, 4, 8);
+    else M2_ROWS_LAUNCH(32, 4, 4);
 #undef M2_ROWS_LAUNCH
     TH_LAUNCH_CHECK();
 
