@@ -426,9 +426,10 @@ int th_conv3x3_gap_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const fl
  * Same bits as the layer-by-layer launches at batch >= 128.  th_conv_chain_supported: 0 = these stages do not run as a chain (the caller
  * launches the layers one by one); 1, 2 = an instance with its sizes compiled in (1: 28x28, 1 -> 32, 32 -> 32 + pool, 32 -> 64, 64 -> 64 + pool,
  * 64 -> 128 + global mean; 2: 28x28, 1 -> 32 + pool, 32 -> 64 + pool); 3 = the kernel that takes its stages as ARGUMENTS: any run of up to
- * 8 stages on a square 28 / 14 / 7 input with 1 or a multiple of 16 (<= 256) channels, c_out a multiple of 16 (<= 512), pools on even
- * maps, ending in a pool or the global average, whose maps fit the 160 KB of LDS (the plan -- tile-to-wave mapping, LDS offsets -- is
- * worked out on the host per launch); a launch walks min(n, 256) workgroups over the images. */
+ * 8 stages on a square input of 4 .. 32 pixels a side with 1 or a multiple of 16 (<= 256) channels, c_out a multiple of 16 (<= 512),
+ * pools on even maps, ending in a pool, in the global average or in a conv row (d_y: that row's NCHW map), whose maps fit the 160 KB of
+ * LDS (the plan -- tile-to-wave mapping, LDS offsets -- is worked out on the host per launch; 28 / 14 / 7 maps run instances with the
+ * size compiled in, other sizes one that takes it as an argument); a launch walks min(n, 256) workgroups over the images. */
 enum { TH_CHAIN_NONE = 0, TH_CHAIN_MAXPOOL2 = 1, TH_CHAIN_GLOBAL_AVG = 2 };
 typedef struct th_conv_stage {
     const float *d_w, *d_bias;

@@ -600,8 +600,9 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
 // Any run of Conv2dReLU(3x3, stride 1, pad 1) [+ MaxPool2d(2) | + global average pool] stages whose maps fit the 160 KB of LDS, with the
 // same structure as the two compiled instances above -- a workgroup carries one image through every stage, the maps live in LDS in the
 // padded [channel][rows + 2][cols + 2] form, weights come from L2 a pass ahead -- but with the channel counts, the tile-to-wave mapping and
-// the LDS plan as kernel ARGUMENTS (RtStage, filled by rt_plan on the host).  Compiled in: the map sizes (S = 28, 14, 7: what a 28 x 28
-// input and its pools produce), so the tap part of an operand address stays an immediate, and the number of "double" pixel tiles a wave
+// the LDS plan as kernel ARGUMENTS (RtStage, filled by rt_plan on the host).  Compiled in: the map sizes a 28 x 28 input and its pools produce
+// (S = 28, 14, 7: the tap part of an operand address stays an immediate) -- any other square map up to 32 x 32 takes the instance with the
+// size as a run-time value (S = 0: one address add per operand read) --, and the number of "double" pixel tiles a wave
 // carries per round (ND = 1, 2, 4, 7).  A wave owns ONE pair of channel tiles per round (chA = 2 q, chB = 2 q + 1: every pixel operand read
 // feeds two MFMAs) and ND pixel tiles (piece + m i): chunk (q, piece) = round * 8 + wave.  Same per-output arithmetic as the compiled
 // instances and the layer-by-layer kernels (k order, bias after the sum, ReLU, strict-> maxima, the 16-lane plane sums).
@@ -623,28 +624,31 @@ struct RtChainArgs {
     ChainHeadArgs head;
 };
 
-template <int S>
-__device__ __forceinline__ void rt_load_planes(const float *__restrict__ xi, float *planes, int c0, int t) {
-    constexpr int WP = S + 2, CIS = ch_cis(WP);
+// the image's c0 planes [s][s] -> zero-haloed LDS planes [c0][CIS]: a wave per plane row, a lane per column (no per-element division; s + 2 <= 64)
+__device__ __forceinline__ void rt_load_planes(const float *__restrict__ xi, float *planes, int c0, int s, int t) {
+    const int wp = s + 2, cis = ch_cis(wp), q = (t & 63) - 1, r0 = t >> 6;
+    if (q + 1 >= wp) return;
     for (int c = 0; c < c0; ++c)
-        for (int e = t; e < WP * WP; e += CH_NT) {
-            const int r = e / WP - 1, q = e % WP - 1;
-            planes[c * CIS + e] = (r >= 0 && r < S && q >= 0 && q < S) ? xi[(c * S + r) * S + q] : 0.f;
+        for (int r = r0; r < wp; r += CH_NT / 64) {
+            const int ri = r - 1;
+            planes[c * cis + r * wp + q + 1] = (ri >= 0 && ri < s && q >= 0 && q < s) ? xi[(c * s + ri) * s + q] : 0.f;
         }
 }
 
+// S = 0 in the templates below: the map size is the run-time argument s_rt (any size up to 32 -- the tap part of an operand address is then a
+// register, one address add per operand read, instead of the read's immediate offset); S > 0: compiled in, s_rt ignored
 template <int S>
-__device__ __forceinline__ void rt_zero_halo(float *planes, int c, int wave, int lane) {
-    constexpr int WP = S + 2, CIS = ch_cis(WP), RING = 4 * S + 4;
-    int pos[(RING + 63) / 64];
+__device__ __forceinline__ void rt_zero_halo(float *planes, int c, int wave, int lane, int s_rt) {
+    const int SS = S ? S : s_rt, WP = SS + 2, CIS = ch_cis(WP), RING = 4 * SS + 4;
+    int pos[3];                                  // RING <= 132
 #pragma unroll
-    for (int j = 0; j < (RING + 63) / 64; ++j) {
+    for (int j = 0; j < 3; ++j) {
         const int r = lane + 64 * j;
-        pos[j] = r < WP ? r : r < 2 * WP ? (WP - 1) * WP + (r - WP) : r < 2 * WP + S ? (r - 2 * WP + 1) * WP : r < RING ? (r - 2 * WP - S + 1) * WP + WP - 1 : -1;
+        pos[j] = r < WP ? r : r < 2 * WP ? (WP - 1) * WP + (r - WP) : r < 2 * WP + SS ? (r - 2 * WP + 1) * WP : r < RING ? (r - 2 * WP - SS + 1) * WP + WP - 1 : -1;
     }
     for (int ch = wave; ch < c; ch += CH_NT / 64) {
 #pragma unroll
-        for (int j = 0; j < (RING + 63) / 64; ++j)
+        for (int j = 0; j < 3; ++j)
             if (pos[j] >= 0) planes[ch * CIS + pos[j]] = 0.f;
     }
 }
@@ -664,8 +668,9 @@ __device__ __forceinline__ void rt_weights(const float *__restrict__ w, int c_in
 // the k loop of one chunk: in = padded planes [c_in][CIS]; acc[2 i], acc[2 i + 1] = pixel tile ptile[i] x (chA, chB)
 template <int S, int ND>
 __device__ __forceinline__ void rt_mfma(const float *in, const float *__restrict__ w, int c_in, int c_out, int chA, int chB, const int (&ptile)[ND],
-                                        floatx4 (&acc)[2 * ND], int lane) {
-    constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, KS = 18, NPT = (PX + 15) / 16;
+                                        floatx4 (&acc)[2 * ND], int lane, int s_rt, const ChainW *w0) {
+    constexpr int KS = 18;
+    const int SS = S ? S : s_rt, WP = SS + 2, CIS = ch_cis(WP), PX = SS * SS, NPT = (PX + 15) / 16;
     // a wave's tiles are piece, piece + m, ...: the waves of a channel pair carry ND or ND - 1 of them -- the last double's MFMAs are
     // skipped (a wave-uniform branch per k-step; its operand read stays unconditional) where the tile does not exist
     const bool last_live = ptile[ND - 1] < NPT;
@@ -676,13 +681,14 @@ __device__ __forceinline__ void rt_mfma(const float *in, const float *__restrict
     for (int i = 0; i < ND; ++i) {
         int p = ptile[i] * 16 + l16;
         if (p >= PX) p = 0;        // lanes / tiles past the image compute on pixel 0 and are never stored
-        pt[i] = (lds_cf *)(in + (p / S) * WP + p % S + g4 * CIS);
+        pt[i] = (lds_cf *)(in + (p / SS) * WP + p % SS + g4 * CIS);
         asm volatile("" : "+v"(pt[i]));
     }
 #pragma unroll
     for (int k = 0; k < 2 * ND; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
     ChainW wc, wn;
-    rt_weights(w, c_in, c_out, 0, chA, chB, wc, lane);
+    if (w0) wc = *w0;                              // requested before the previous stage's epilogue (rt_stage_nd)
+    else rt_weights(w, c_in, c_out, 0, chA, chB, wc, lane);
 #define RT_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < ND; ++i) B[i] = pt[i][(4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
 #define RT_PASS_BODY(WCUR)                                                                                                          \
     {                                                                                                                               \
@@ -718,8 +724,8 @@ __device__ __forceinline__ void rt_mfma(const float *in, const float *__restrict
 // a single input channel (the first stage of an image chain): k = the tap, padded to three k-steps of four with zero weights (chain_conv1_mfma)
 template <int S, int ND>
 __device__ __forceinline__ void rt_conv1(const float *img, const float *__restrict__ w, int c_out, int chA, int chB, const int (&ptile)[ND],
-                                         floatx4 (&acc)[2 * ND], int lane) {
-    constexpr int WP = S + 2, PX = S * S;
+                                         floatx4 (&acc)[2 * ND], int lane, int s_rt) {
+    const int SS = S ? S : s_rt, WP = SS + 2, PX = SS * SS;
     const int l16 = lane & 15, g4 = lane >> 4;
     float wa[3], wb[3];
     int toff[3];
@@ -737,7 +743,7 @@ __device__ __forceinline__ void rt_conv1(const float *img, const float *__restri
     for (int i = 0; i < ND; ++i) {
         int p = ptile[i] * 16 + l16;
         if (p >= PX) p = 0;
-        const float *px = img + (p / S) * WP + p % S;
+        const float *px = img + (p / SS) * WP + p % SS;
         float b[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) b[s] = (s == 2 && pad_lane ? img : px)[toff[s]];   // padded taps read the halo corner (0.0)
@@ -752,17 +758,17 @@ __device__ __forceinline__ void rt_conv1(const float *img, const float *__restri
 // 2x2 / stride-2 maxima of the tile [c][ld(S S)] -> interior of padded planes [c][CIS(S / 2)], or (TO_GLOBAL) the image's pooled NCHW map
 // (+ a flat LDS copy for the classifier rows); chain_pool with a run-time channel count
 template <int S>
-__device__ __forceinline__ void rt_pool(const float *tile, float *out, int c_out, bool to_global, float *flat, int t) {
-    constexpr int LD = ch_tile_ld(S * S), HP = S / 2, NP = HP * HP, WPO = HP + 2, CISO = ch_cis(WPO);
-    constexpr int CHUNKS = (CH_NT / NP >= 8 ? 8 : (CH_NT / NP >= 4 ? 4 : (CH_NT / NP >= 2 ? 2 : 1)));
-    static_assert(S % 2 == 0 && NP <= CH_NT, "pooled plane fits the workgroup");
+__device__ __forceinline__ void rt_pool(const float *tile, float *out, int c_out, bool to_global, float *flat, int t, int s_rt) {
+    const int SS = S ? S : s_rt, LD = ch_tile_ld(SS * SS), HP = SS / 2, NP = HP * HP, WPO = HP + 2, CISO = ch_cis(WPO);
+    const int CHUNKS = (CH_NT / NP >= 8 ? 8 : (CH_NT / NP >= 4 ? 4 : (CH_NT / NP >= 2 ? 2 : 1)));
+    static_assert(S % 2 == 0 && (S / 2) * (S / 2) <= CH_NT, "pooled plane fits the workgroup");   // (run-time sizes: <= 32, even -- rt_plan)
     const int q = t % NP, chunk = t / NP;
     if (chunk >= CHUNKS) return;
     const int cpc = (c_out + CHUNKS - 1) / CHUNKS, c0 = chunk * cpc, c1 = min(c_out, c0 + cpc);
     const int pr = q / HP, pc = q % HP;
-    const float *b = tile + c0 * LD + 2 * pr * S + 2 * pc;
+    const float *b = tile + c0 * LD + 2 * pr * SS + 2 * pc;
     for (int c = c0; c < c1; ++c, b += LD) {
-        const float2 r0 = *reinterpret_cast<const float2 *>(b), r1 = *reinterpret_cast<const float2 *>(b + S);
+        const float2 r0 = *reinterpret_cast<const float2 *>(b), r1 = *reinterpret_cast<const float2 *>(b + SS);
         float m = -INFINITY;
         m = r0.x > m ? r0.x : m;
         m = r0.y > m ? r0.y : m;
@@ -779,12 +785,14 @@ __device__ __forceinline__ void rt_pool(const float *tile, float *out, int c_out
 
 template <int S, int ND>
 __device__ __forceinline__ void rt_stage_nd(const RtChainArgs &a, const RtStage &st, float *lds, int img, int t, bool last) {
-    constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, NPT = (PX + 15) / 16, TLD = ch_tile_ld(PX);
+    const int SS = S ? S : st.s, WP = SS + 2, CIS = ch_cis(WP), PX = SS * SS, NPT = (PX + 15) / 16, TLD = ch_tile_ld(PX);
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
     const int nct = st.c_out / 16, np2 = (nct + 1) / 2;
     const bool planes = st.post == TH_CHAIN_NONE;
+    const bool to_map = planes && last;          // a run that ends in a conv row: its NCHW map goes to memory, nothing is kept in LDS
     const float *in = lds + st.in_off;
-    float *out = lds + st.out_off;
+    float *out = lds + st.out_off;                // (an LDS pointer on every path: the map that goes to memory has its own store loop)
+    float *gmap = a.y + (long)img * st.c_out * PX;
     const int ld = planes ? CIS : TLD;
     for (int r = 0; r < st.rounds; ++r) {
         const int cid = r * (CH_NT / 64) + wave;
@@ -804,13 +812,16 @@ __device__ __forceinline__ void rt_stage_nd(const RtChainArgs &a, const RtStage 
             bb[e] = st.b[16 * chB + 4 * g4 + e];
         }
         if (active) {
-            if (st.c_in == 1) rt_conv1<S, ND>(in, st.w, st.c_out, chA, chB, ptile, acc, lane);
-            else rt_mfma<S, ND>(in, st.w, st.c_in, st.c_out, chA, chB, ptile, acc, lane);
+            if (st.c_in == 1) rt_conv1<S, ND>(in, st.w, st.c_out, chA, chB, ptile, acc, lane, st.s);
+            else rt_mfma<S, ND>(in, st.w, st.c_in, st.c_out, chA, chB, ptile, acc, lane, st.s, nullptr);
         }
-        if (st.rounds == 1) {                                    // every wave is done reading the input: the output may overlay it
+        // (Requesting the NEXT stage's first weight pass here, under this stage's epilogue -- as the compiled instances do -- was built and
+        // measured in r04: the 36 registers of that pass put the kernel past its 256 and the spills cost more than the round trips: reference
+        // front 116 -> 130 us.  Every stage opens with its own request.)
+        if (st.rounds == 1 && !to_map) {                         // every wave is done reading the input: the output may overlay it
             chain_sync();
-            if (planes) rt_zero_halo<S>(out, st.c_out, wave, lane);
-            else if (st.post == TH_CHAIN_MAXPOOL2 && !last) rt_zero_halo<S / 2>(lds + st.pool_off, st.c_out, wave, lane);
+            if (planes) rt_zero_halo<S>(out, st.c_out, wave, lane, st.s);
+            else if (st.post == TH_CHAIN_MAXPOOL2 && !last) rt_zero_halo<S / 2>(lds + st.pool_off, st.c_out, wave, lane, st.s / 2);
         }
         if (active) {
 #pragma unroll
@@ -818,7 +829,16 @@ __device__ __forceinline__ void rt_stage_nd(const RtChainArgs &a, const RtStage 
                 const int p = ptile[k >> 1] * 16 + l16;
                 const bool second = k & 1;
                 if (ptile[k >> 1] >= NPT || p >= PX || (second && !has_b)) continue;
-                float *o = out + (16 * (second ? chB : chA) + 4 * g4) * ld + (planes ? (p / S + 1) * WP + p % S + 1 : p);
+                const int ch0 = 16 * (second ? chB : chA) + 4 * g4;
+                if (to_map) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[k][e] + (second ? bb[e] : ba[e]);
+                        gmap[(long)(ch0 + e) * PX + p] = v > 0.f ? v : 0.f;
+                    }
+                    continue;
+                }
+                float *o = out + ch0 * ld + (planes ? (p / SS + 1) * WP + p % SS + 1 : p);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[k][e] + (second ? bb[e] : ba[e]);
@@ -828,16 +848,20 @@ __device__ __forceinline__ void rt_stage_nd(const RtChainArgs &a, const RtStage 
             }
         }
     }
+    if (to_map) {
+        chain_sync();                                            // (the next image's planes overwrite this stage's input)
+        return;
+    }
     if (st.rounds > 1) {                                         // (the output does not overlay the input: rt_plan)
-        if (planes) rt_zero_halo<S>(out, st.c_out, wave, lane);
-        else if (st.post == TH_CHAIN_MAXPOOL2 && !last) rt_zero_halo<S / 2>(lds + st.pool_off, st.c_out, wave, lane);
+        if (planes) rt_zero_halo<S>(out, st.c_out, wave, lane, st.s);
+        else if (st.post == TH_CHAIN_MAXPOOL2 && !last) rt_zero_halo<S / 2>(lds + st.pool_off, st.c_out, wave, lane, st.s / 2);
     }
     chain_sync();
     if (st.post == TH_CHAIN_MAXPOOL2) {
         if constexpr (S % 2 == 0) {
-            constexpr int NP = (S / 2) * (S / 2);
-            if (last) rt_pool<S>(out, a.y + (long)img * st.c_out * NP, st.c_out, true, a.has_head ? lds + a.xm_off : nullptr, t);
-            else rt_pool<S>(out, lds + st.pool_off, st.c_out, false, nullptr, t);
+            const int NP = (SS / 2) * (SS / 2);
+            if (last) rt_pool<S>(out, a.y + (long)img * st.c_out * NP, st.c_out, true, a.has_head ? lds + a.xm_off : nullptr, t, st.s);
+            else rt_pool<S>(out, lds + st.pool_off, st.c_out, false, nullptr, t, st.s);
         }
         chain_sync();
     } else if (st.post == TH_CHAIN_GLOBAL_AVG) {                 // 16 lanes per plane: avgpool_global16_kernel's arithmetic
@@ -873,6 +897,9 @@ __device__ __forceinline__ void rt_stage(const RtChainArgs &a, const RtStage &st
     }
 }
 
+// ANYSIZE: every stage takes the instance with the map size as a run-time value.  A chain's sizes are its input's and its halves: all of
+// them in {28, 14, 7} (ANYSIZE = false: the sizes compiled in) or none of them -- two kernels, so that neither pays the other's registers.
+template <bool ANYSIZE>
 __global__ __launch_bounds__(CH_NT, 1) void conv_chain_rt_kernel(RtChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -881,19 +908,19 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_rt_kernel(RtChainArgs a) 
     for (int img = blockIdx.x; img < a.n; img += gridDim.x) {
         const float *xi = a.x + (long)img * a.c0 * a.s0 * a.s0;
         float *in0 = lds + a.st[0].in_off;
-        switch (a.s0) {
-        case 28: rt_load_planes<28>(xi, in0, a.c0, t); break;
-        case 14: rt_load_planes<14>(xi, in0, a.c0, t); break;
-        default: rt_load_planes<7>(xi, in0, a.c0, t); break;
-        }
+        rt_load_planes(xi, in0, a.c0, a.s0, t);
         chain_sync();
         for (int i = 0; i < a.n_stages; ++i) {
             const RtStage &st = a.st[i];
             const bool last = i == a.n_stages - 1;
-            switch (st.s) {
-            case 28: rt_stage<28>(a, st, lds, img, t, last); break;
-            case 14: rt_stage<14>(a, st, lds, img, t, last); break;
-            default: rt_stage<7>(a, st, lds, img, t, last); break;
+            if constexpr (ANYSIZE) {
+                rt_stage<0>(a, st, lds, img, t, last);
+            } else {
+                switch (st.s) {
+                case 28: rt_stage<28>(a, st, lds, img, t, last); break;
+                case 14: rt_stage<14>(a, st, lds, img, t, last); break;
+                default: rt_stage<7>(a, st, lds, img, t, last); break;
+                }
             }
         }
         if (a.has_head) {                                        // (the last stage's pool left the flattened map at xm_off, behind a barrier)
@@ -953,7 +980,7 @@ int rt_place(int sz, const Span *live, int n_live) {
 
 // Tile mapping and LDS plan of a run of stages (RtStage); false: not a chain this kernel runs.  head_classes > 0: with the classifier rows.
 bool rt_plan(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, int head_classes, RtChainArgs *out, int *lds_floats) {
-    if (!stages || h != w || (h != 28 && h != 14 && h != 7) || n_stages < 1 || n_stages > RT_MAX_STAGES) return false;
+    if (!stages || h != w || h < 4 || h > 32 || n_stages < 1 || n_stages > RT_MAX_STAGES) return false;   // (square maps up to 32 x 32: s + 2 <= 64 lanes)
     if (!(c_in == 1 || (c_in % 16 == 0 && c_in >= 16 && c_in <= 256))) return false;
     RtChainArgs a{};
     a.c0 = c_in; a.s0 = h; a.n_stages = n_stages;
@@ -968,7 +995,7 @@ bool rt_plan(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, 
         if (i > 0 && ci % 16 != 0) return false;
         if (d.post != TH_CHAIN_NONE && d.post != TH_CHAIN_MAXPOOL2 && d.post != TH_CHAIN_GLOBAL_AVG) return false;
         if (d.post == TH_CHAIN_MAXPOOL2 && s % 2 != 0) return false;
-        if ((d.post == TH_CHAIN_GLOBAL_AVG) != (last && d.post != TH_CHAIN_MAXPOOL2) || (last && d.post == TH_CHAIN_NONE)) return false;
+        if (d.post == TH_CHAIN_GLOBAL_AVG && !last) return false;    // the plane means end a run; a run may also end in a pooled map or in a conv row
         RtStage &st = a.st[i];
         st.w = d.d_w; st.b = d.d_bias; st.c_in = ci; st.c_out = d.c_out; st.s = s; st.post = d.post;
         // tile mapping: np2 channel pairs x m chunks of nd pixel tiles, 8 chunks per round; cheapest rounds * nd, then fewest rounds
@@ -987,6 +1014,12 @@ bool rt_plan(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, 
         // LDS: the input is live through the k loops; with ONE round every accumulator is in registers when the input dies (a barrier), so
         // the output may overlay it -- taken only when nothing else fits
         st.in_off = in.lo;
+        if (last && d.post == TH_CHAIN_NONE) {    // the run's NCHW map goes straight to memory: no LDS region
+            if (head_classes > 0) return false;
+            st.out_off = 0;
+            ci = d.c_out;
+            continue;
+        }
         const int out_sz = d.c_out * (d.post == TH_CHAIN_NONE ? ch_cis(s + 2) : ch_tile_ld(s * s));
         int o = rt_place(out_sz, &in, 1);
         if (o < 0 && st.rounds == 1) o = rt_place(out_sz, nullptr, 0);
@@ -1051,8 +1084,13 @@ int th_debug_set_chain_generic(int on) {   // test hook: 1 = the compiled instan
 static int rt_launch(th_ctx *ctx, RtChainArgs &a, int lds_floats, const float *d_x, float *d_y, float *d_cnt, int n) {
     a.x = d_x; a.y = d_y; a.cnt = d_cnt; a.n = n;
     const int lds = lds_floats * (int)sizeof(float);
-    (void)hipFuncSetAttribute((const void *)conv_chain_rt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(conv_chain_rt_kernel, dim3(n < kNumCU ? n : kNumCU), dim3(CH_NT), lds, ctx->stream, a);
+    if (a.s0 == 28 || a.s0 == 14 || a.s0 == 7) {
+        (void)hipFuncSetAttribute((const void *)conv_chain_rt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(conv_chain_rt_kernel<false>, dim3(n < kNumCU ? n : kNumCU), dim3(CH_NT), lds, ctx->stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void *)conv_chain_rt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(conv_chain_rt_kernel<true>, dim3(n < kNumCU ? n : kNumCU), dim3(CH_NT), lds, ctx->stream, a);
+    }
     return 0;
 }
 

@@ -672,8 +672,9 @@ Tensor Sequential::forward_prefix(const Tensor &input, size_t n_layers) const {
             // classifier as ONE launch, when an instance is compiled for it (th_conv_chain_supported): the maps never leave the CU
             std::vector<ConvStage> stages;
             conv_stages_at(i, n_layers, &stages);
-            // (a run that ends in a conv without a pool stops at its last pooled stage)
-            while (!stages.empty() && stages.back().post == TH_CHAIN_NONE) stages.pop_back();
+            // (a run that ends in conv rows without a pool is taken whole where the chain kernel can write that map; else up to its last pooled stage)
+            if (!(stages.size() >= 2 && x.conv_chain_supported(stages)))
+                while (!stages.empty() && stages.back().post == TH_CHAIN_NONE) stages.pop_back();
             size_t j2 = i;
             for (const auto &st : stages) j2 += st.post == TH_CHAIN_NONE ? 1 : 2;
             if (stages.size() >= 2 && x.conv_chain_supported(stages)) {   // (a single conv + pool keeps its own launch, below)

@@ -1037,7 +1037,8 @@ Tensor Tensor::conv_chain(const std::vector<ConvStage> &stages) const {
         if (bias_grad) push_gap_conv_bias_node(out, last.bias, cnt, n, c_out, h * w);
         return out;
     }
-    TAPER_ASSERT(last.post == TH_CHAIN_MAXPOOL2, "conv_chain: the last stage must end in a pool");
+    // (a pooled map, or -- a run that ends in a conv row -- that row's map: either way dY * [y > 0] summed per channel is the last conv's
+    // bias gradient, tensor.rs:1496-1519, 2017-2024, ops.rs:358-369)
     Tensor out = empty({(size_t)n, (size_t)c_out, (size_t)h, (size_t)w});
     TH(th_conv_chain_fwd(Device::ctx(), dptr(), d.data(), (int)d.size(), out.dptr(), nullptr, n, (int)shape_[1], (int)shape_[2], (int)shape_[3]));
     push_pooled_conv_bias_node(out, last.bias, n, c_out, h, w);

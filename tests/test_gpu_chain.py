@@ -138,7 +138,9 @@ def test_chain_without_counts_and_unsupported_stages(ctx):
     assert hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(st, C.c_void_p), ns) == 3
     st, ns = hip.conv_stages([(bufs[0][0], bufs[0][1], 32, 1), (bufs[1][0], bufs[1][1], 64, 1)])
     assert hip.hip.th_conv_chain_supported(1, 28, 28, C.cast(st, C.c_void_p), ns) == 2
-    assert hip.hip.th_conv_chain_supported(1, 32, 32, C.cast(st, C.c_void_p), ns) == 0
+    assert hip.hip.th_conv_chain_supported(1, 32, 32, C.cast(st, C.c_void_p), ns) == 0      # 32 planes of 32 x 32 + their pooled planes: past the LDS
+    st16, ns16 = hip.conv_stages([(bufs[0][0], bufs[0][1], 16, 1), (bufs[1][0], bufs[1][1], 64, 1)])
+    assert hip.hip.th_conv_chain_supported(1, 32, 32, C.cast(st16, C.c_void_p), ns16) == 3  # (r04: any square map up to 32 x 32 that fits)
     assert hip.hip.th_conv_chain_supported(3, 28, 28, C.cast(st, C.c_void_p), ns) == 0
 
 
@@ -281,12 +283,84 @@ def test_generic_chain_refusals(ctx):
     f = hip.hip.th_conv_chain_supported
     st = lambda *rows: tuple(x if i == 0 else x for i, x in enumerate(hip.conv_stages([(bufs[0][0], bufs[0][1], c, p) for c, p in rows])))
     for rows, c0, hw, want in [([(24, 1), (64, 1)], 1, 28, 0),        # 24 output channels: not whole 16-channel tiles
-                               ([(32, 1), (64, 0)], 1, 28, 0),        # ends in a conv without a pool: nothing to write
+                               ([(32, 1), (64, 0)], 1, 28, 3),        # ends in a conv row: its map is written (r04)
                                ([(32, 2), (64, 1)], 1, 28, 0),        # the global average is not the last stage
                                ([(32, 1), (64, 1), (64, 1)], 1, 28, 0),   # 7 x 7 cannot be pooled 2 x 2
                                ([(64, 0), (64, 1)], 1, 28, 0),        # 64 planes of 30 x 30 do not fit beside anything
                                ([(32, 1), (64, 1)], 3, 28, 0),        # 3 input channels
-                               ([(32, 1), (64, 1)], 1, 32, 0),        # 32 x 32 maps are not compiled in
+                               ([(16, 1), (32, 1)], 1, 32, 3),        # 32 x 32: the instance that takes the map size as an argument (r04)
+                               ([(16, 1), (32, 1)], 1, 34, 0),        # 34 x 34: past the sizes the kernel takes
+                               ([(16, 1), (16, 1)], 1, 30, 0),        # 30 -> 15 -> cannot be pooled 2 x 2
                                ([(16, 1), (32, 1)], 1, 28, 3)]:
         arr, ns = st(*rows)
         assert f(c0, hw, hw, C.cast(arr, C.c_void_p), ns) == want, rows
+
+
+# ---- maps that are not MNIST-shaped (r04): any square input of 4 .. 32 pixels, runs that end in a conv row ----------------------------------
+def _random_stage_list_any_size(rng):
+    hw0 = int(rng.integers(8, 33))
+    c0 = int(rng.choice([1, 1, 16, 32]))
+    spec, c_in, hw = [], c0, hw0
+    for i in range(int(rng.integers(1, 5))):
+        c_out = int(rng.choice([16, 32, 48, 64]))
+        post = 1 if (hw % 2 == 0 and hw >= 8 and rng.random() < 0.6) else 0
+        spec.append((c_in, c_out, post))
+        c_in, hw = c_out, hw // 2 if post == 1 else hw
+    last = spec[-1]
+    r = rng.random()
+    end = 2 if r < 0.35 else (last[2] if r < 0.7 else 0)      # the global mean, whatever was drawn (a pool or a conv row), or a conv row
+    spec[-1] = (last[0], last[1], end)
+    return c0, hw0, spec
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_generic_chain_any_map_size_matches_the_oracle(ctx, O, seed):
+    """random square inputs of 8 .. 32 pixels a side (1 / 16 / 32 channels), random stage lists incl. runs that end in a conv row, random batches,
+    against the oracle's conv2d_relu / max_pool2d / avg_pool2d (/root/reference/src/tensor.rs:1221-1285, 1391-1470, 1524-1660); a list is only
+    refused when a map does not fit the LDS"""
+    from taper_amd import hip
+    rng = np.random.default_rng(7000 + seed)
+    c0, hw0, spec = _random_stage_list_any_size(rng)
+    n = int(rng.choice([1, 3, 20, 130, 257]))
+    params = _params(spec, 70 + seed)
+    bufs = [(ctx.upload(w), ctx.upload(b)) for w, b in params]
+    stages, ns = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in zip(bufs, spec)])
+    kind = hip.hip.th_conv_chain_supported(c0, hw0, hw0, C.cast(stages, C.c_void_p), ns)
+    pad = lambda s: (s + 2) ** 2 + ((16 - ((s + 2) ** 2) % 32) + 32) % 32
+    words, hw = c0 * pad(hw0), hw0
+    for c_in, c_out, post in spec:
+        words = max(words, c_in * pad(hw) + c_out * (pad(hw) if post == 0 else hw * hw + 8))
+        hw = hw // 2 if post == 1 else hw
+    if kind == 0:
+        assert words > 40960 // 2, (c0, hw0, spec, words)     # only lists with a big map may be refused
+        return
+    assert kind == 3, (kind, c0, hw0, spec)
+    x = rng.uniform(0, 1, (n, c0, hw0, hw0)).astype(np.float32)
+    ref, ref_cnt = _oracle_chain(O, x, spec, params)
+    hw = hw0
+    for _, _, post in spec:
+        hw = hw // 2 if post == 1 else (1 if post == 2 else hw)
+    c_last = spec[-1][1]
+    y = ctx.empty(n * c_last * hw * hw)
+    cnt = ctx.empty(n * c_last) if spec[-1][2] == 2 else None
+    ctx.call("th_conv_chain_fwd", ctx.upload(x), C.cast(stages, C.c_void_p), ns, y, cnt, n, c0, hw0, hw0)
+    ctx.sync()
+    got = ctx.download(y, (n, c_last, hw, hw))
+    np.testing.assert_allclose(got, ref.reshape(got.shape), rtol=RTOL, atol=1e-5 + RTOL * float(np.abs(ref).max()), err_msg=str((c0, hw0, spec)))
+    if cnt is not None:
+        off = np.abs(ctx.download(cnt, (n, c_last)) - ref_cnt)
+        assert off.max() <= 2 and (off > 0).mean() < 0.02, (spec, off.max(), (off > 0).mean())
+
+
+@pytest.mark.parametrize("hw0,spec", [(28, [(1, 32, 1), (32, 64, 0)]), (14, [(16, 32, 0)]), (7, [(64, 64, 0), (64, 128, 0)])])
+def test_compiled_size_instances_write_a_conv_row_map(ctx, O, hw0, spec):
+    """the 28 / 14 / 7 instances (map size compiled in) with a run that ends in a conv row"""
+    from taper_amd import hip
+    rng = np.random.default_rng(hw0)
+    n, c0 = 11, spec[0][0]
+    params = _params(spec, hw0)
+    x = rng.uniform(0, 1, (n, c0, hw0, hw0)).astype(np.float32)
+    ref, _ = _oracle_chain(O, x, spec, params)
+    y, cnt, hw, c_last = _hip_chain_general(ctx, x, spec, params)
+    got = ctx.download(y, (n, c_last, hw, hw))
+    np.testing.assert_allclose(got, ref.reshape(got.shape), rtol=RTOL, atol=1e-5 + RTOL * float(np.abs(ref).max()))

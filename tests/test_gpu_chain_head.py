@@ -315,12 +315,14 @@ def _custom_cnn(rng, kind):
     if kind == "pool_mlp":           # ... followed by Linear + ReLU + Linear: generic chain, then the two-launch MLP tail
         return [c(rng, 1, 16), c(rng, 16, 16), pool, c(rng, 16, 48), pool, dict(kind="flatten", start_dim=1), lin(rng, 48 * 49, 64),
                 dict(kind="relu"), lin(rng, 64, 10)]
+    if kind == "conv_row_end":       # the conv rows END in a conv (no pool behind it): the chain writes that row's map; Flatten, Linear
+        return [c(rng, 1, 16), pool, c(rng, 16, 32), pool, c(rng, 32, 16), dict(kind="flatten", start_dim=1), lin(rng, 16 * 49, 10)]
     # global average + three-layer classifier, other widths than the reference CNN's
     return [c(rng, 1, 16), pool, c(rng, 16, 32), c(rng, 32, 64), pool, c(rng, 64, 96), dict(kind="adaptive_avgpool", out=(1, 1)),
             dict(kind="flatten", start_dim=1), lin(rng, 96, 64), dict(kind="relu"), lin(rng, 64, 32), dict(kind="relu"), lin(rng, 32, 10)]
 
 
-@pytest.mark.parametrize("kind,want_dma", [("pool_head", 7), ("pool_mlp", 6), ("gap_mlp3", 6)])
+@pytest.mark.parametrize("kind,want_dma", [("pool_head", 7), ("pool_mlp", 6), ("gap_mlp3", 6), ("conv_row_end", 6)])
 @pytest.mark.parametrize("batch", [256, 100])
 def test_other_cnns_take_the_run_time_described_chain_and_match_the_oracle(kind, want_dma, batch):
     """Sequentials that are neither of the two compiled nets: the Trainer's captured step launches their conv rows as ONE kernel all the same
