@@ -419,6 +419,8 @@ def conv_layer_kernels(ctx, layers, reps=60):
         tf, gbs = flops / (us * 1e-6) / 1e12, nbytes / (us * 1e-6) / 1e9
         if ci == 1:
             kern = "conv1_pool2_kernel" if pool else "conv1_kernel"
+        elif cfg[1] == 8:               # one layer through the chain's compiled tile mapping (conv_chain.hip)
+            kern = "conv_layer_chain_kernel<%d, %d, %d, %d>" % (hw, ci, co, 1 if pool else 0)
         elif cfg[1] in (2, 3, 4, 5):    # image-resident: <channel tiles, pixel tiles per wave, pooled epilogue, waves>, cfg[4] whole images per workgroup
             kern = "conv3x3_img_kernel<%d, %d, %s, %d%s>" % (cfg[0], cfg[2], "true" if pool else "false", 4 if cfg[1] in (3, 5) else 8,
                                                                  ", patch geometry compiled in" if cfg[1] >= 4 else "")

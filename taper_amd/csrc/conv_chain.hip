@@ -596,6 +596,125 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
 #endif
 }
 
+// the image's c0 planes [s][s] -> zero-haloed LDS planes [c0][CIS]: a wave per plane row, a lane per column (no per-element division; s + 2 <= 64)
+__device__ __forceinline__ void rt_load_planes(const float *__restrict__ xi, float *planes, int c0, int s, int t) {
+    const int wp = s + 2, cis = ch_cis(wp), q = (t & 63) - 1, r0 = t >> 6;
+    if (q + 1 >= wp) return;
+    for (int c = 0; c < c0; ++c)
+        for (int r = r0; r < wp; r += CH_NT / 64) {
+            const int ri = r - 1;
+            planes[c * cis + r * wp + q + 1] = (ri >= 0 && ri < s && q >= 0 && q < s) ? xi[(c * s + ri) * s + q] : 0.f;
+        }
+}
+
+// ==== ONE Conv2dReLU layer with the chain's compiled tile mappings (r04) ==========================================================================
+// The four batch-256 layers of the reference CNN -- 32 -> 32 @28, 32 -> 64 @14, 64 -> 64 @14, 64 -> 128 @7 -- as launches of their own
+// (th_conv3x3_fwd / th_conv3x3_pool2_fwd / th_conv3x3_gap_fwd: forward() outside a Trainer step, TAPER_CONV_CHAIN=0, full_backward) ran
+// through conv3x3_img_kernel at 0.42-0.57 of the matrix peak while the same layers inside the chain ran at 0.67: same contraction, but there
+// a wave owns a PAIR of channel tiles per pixel tile (every pixel operand read feeds two MFMAs), tap offsets are immediates and the weight
+// operands come from L2 a pass ahead instead of an LDS slab.  This kernel is the chain's stage on its own: a workgroup loads ONE image's
+// planes into the padded LDS form, runs chain_mfma with the compiled mapping, and writes the map (POST 0), its 2x2 maxima (1) or its plane
+// means + positive counts (2).  Same k order, bias after the sum, ReLU, strict-> maxima, 16-lane plane sums: the bits of the layered path.
+struct LayerChainArgs {
+    const float *x, *w, *b;    // [n][C_IN][S][S]; taper layout [9 C_IN][C_OUT]; bias [C_OUT] (nullable)
+    float *y, *cnt;            // POST 0: [n][C_OUT][S][S]; 1: [n][C_OUT][S/2][S/2]; 2: [n][C_OUT] (+ cnt [n][C_OUT], nullable)
+    int n;
+};
+
+// one image's C_IN planes [S][S] -> the interior of the padded LDS planes: consecutive threads take consecutive elements (coalesced), all
+// of a thread's loads go out before its first LDS store (a load per loop iteration is a chain of ~1 us round trips: 32 planes of 28 x 28
+// took longer than their k loop that way), the (channel, row, column) of an element by compile-time divisions
+template <int S, int C_IN>
+__device__ __forceinline__ void layer_load_planes(const float *__restrict__ xi, float *planes, int t) {
+    constexpr int WP = S + 2, CIS = ch_cis(WP), N = C_IN * S * S, PER = (N + CH_NT - 1) / CH_NT, U = 7;
+    constexpr int UB = PER < U ? PER : U;       // (a last, partial batch is covered by the e < N guards)
+#pragma unroll 1
+    for (int j0 = 0; j0 < PER; j0 += UB) {
+        float v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int e = t + CH_NT * (j0 + u);
+            v[u] = e < N ? xi[e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int e = t + CH_NT * (j0 + u);
+            if (e < N) {
+                const int c = e / (S * S), rem = e - c * (S * S), r = rem / S, q = rem - r * S;
+                planes[c * CIS + (r + 1) * WP + q + 1] = v[u];
+            }
+        }
+    }
+}
+
+template <int S, int C_IN, int C_OUT, int POST>
+__global__ __launch_bounds__(CH_NT, 1) void conv_layer_chain_kernel(LayerChainArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using G = ChainGeo<S, C_OUT>;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
+    float *A = lds, *T = lds;                    // the output tile overlays the input planes once every wave is past the k loop
+    ChainBias bv;
+    chain_bias<S, C_OUT>(a.b, bv, wave, lane);
+    if (POST == 0) chain_zero_halo<S, C_IN>(A, wave, lane);             // (the map goes to memory: nothing ever overwrites the halo)
+    for (int img = blockIdx.x; img < a.n; img += gridDim.x) {
+        ChainW wc;
+        chain_weights<S, C_IN, C_OUT>(a.w, 0, wc, wave, lane);          // the first pass: in flight under the image load
+        if (POST != 0) chain_zero_halo<S, C_IN>(A, wave, lane);         // (the output tile overlaid the planes)
+        layer_load_planes<S, C_IN>(a.x + (long)img * C_IN * S * S, A, t);
+        chain_sync();
+        floatx4 acc[G::NSLOT];
+        chain_mfma<S, C_IN, C_OUT>(A, a.w, wc, acc, wave, lane);
+        if (POST == 0) {
+            // the NCHW map straight from the accumulators
+            float *ymap = a.y + (long)img * C_OUT * G::PX;
+#pragma unroll
+            for (int k = 0; k < G::NSLOT; ++k) {
+                if (!G::slot_live(wave, k)) continue;
+                const int p = G::slot_px(wave, k) * 16 + l16;
+                if (p >= G::PX) continue;
+                const bool second = k < 2 * G::ND && (k & 1);
+                float *o = ymap + (long)(16 * G::slot_ch(wave, k) + 4 * g4) * G::PX + p;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[k][e] + (second ? bv.b[e] : bv.a[e]);
+                    o[e * G::PX] = v > 0.f ? v : 0.f;
+                }
+            }
+            chain_sync();                                               // the next image's planes overwrite A
+            continue;
+        }
+        chain_sync();                                                   // every wave is done reading A
+        chain_store<S, C_OUT, false>(acc, bv, T, wave, lane);
+        chain_sync();
+        if constexpr (POST == 1 && S % 2 == 0) {
+            chain_pool<S, C_OUT, true>(T, a.y + (long)img * C_OUT * (S / 2) * (S / 2), t);
+        } else if constexpr (POST == 2) {
+            constexpr int LD = ch_tile_ld(S * S);
+            for (int c = t >> 4; c < C_OUT; c += CH_NT / 16) {             // avgpool_global16_kernel's arithmetic
+                const float *row = T + c * LD;
+                float sum = 0.f, k = 0.f;
+                for (int i = l16; i < S * S; i += 16) {
+                    const float v = row[i];
+                    sum += v;
+                    k += v > 0.f ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    sum += __shfl_down(sum, off, 16);
+                    k += __shfl_down(k, off, 16);
+                }
+                if (l16 == 0) {
+                    a.y[(long)img * C_OUT + c] = sum / (float)(S * S);
+                    if (a.cnt) a.cnt[(long)img * C_OUT + c] = k;
+                }
+            }
+        }
+        chain_sync();
+    }
+#endif
+}
+
 // ==== chains described at run time ==================================================================================================================
 // Any run of Conv2dReLU(3x3, stride 1, pad 1) [+ MaxPool2d(2) | + global average pool] stages whose maps fit the 160 KB of LDS, with the
 // same structure as the two compiled instances above -- a workgroup carries one image through every stage, the maps live in LDS in the
@@ -623,17 +742,6 @@ struct RtChainArgs {
     RtStage st[RT_MAX_STAGES];
     ChainHeadArgs head;
 };
-
-// the image's c0 planes [s][s] -> zero-haloed LDS planes [c0][CIS]: a wave per plane row, a lane per column (no per-element division; s + 2 <= 64)
-__device__ __forceinline__ void rt_load_planes(const float *__restrict__ xi, float *planes, int c0, int s, int t) {
-    const int wp = s + 2, cis = ch_cis(wp), q = (t & 63) - 1, r0 = t >> 6;
-    if (q + 1 >= wp) return;
-    for (int c = 0; c < c0; ++c)
-        for (int r = r0; r < wp; r += CH_NT / 64) {
-            const int ri = r - 1;
-            planes[c * cis + r * wp + q + 1] = (ri >= 0 && ri < s && q >= 0 && q < s) ? xi[(c * s + ri) * s + q] : 0.f;
-        }
-}
 
 // S = 0 in the templates below: the map size is the run-time argument s_rt (any size up to 32 -- the tap part of an operand address is then a
 // register, one address add per operand read, instead of the read's immediate offset); S > 0: compiled in, s_rt ignored
@@ -1063,6 +1171,31 @@ bool rt_plan(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, 
 }
 
 }  // namespace
+
+namespace th {
+// th_conv3x3_fwd / _pool2_fwd / _gap_fwd (conv_mfma.hip: conv3x3_mfma_launch) ask here first.  1: launched; 0: not one of the compiled geometries
+// (or fewer images than half the CUs: one image per workgroup); -1: error
+int conv_layer_chain_launch(th_ctx *ctx, const float *x, const float *w, const float *bias, float *y, float *cnt, int n, int c_in, int hw, int c_out,
+                            int post) {
+    if (n < kNumCU / 2) return 0;
+    LayerChainArgs a{x, w, bias, y, cnt, n};
+    const dim3 grid(n < kNumCU ? n : kNumCU);
+#define TH_LC(S_, CI_, CO_, P_)                                                                                                          \
+    do {                                                                                                                                 \
+        constexpr int fl = (CI_ * ch_cis(S_ + 2) > CO_ * ch_tile_ld(S_ * S_) ? CI_ * ch_cis(S_ + 2) : CO_ * ch_tile_ld(S_ * S_));         \
+        (void)hipFuncSetAttribute((const void *)conv_layer_chain_kernel<S_, CI_, CO_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, fl * 4); \
+        hipLaunchKernelGGL((conv_layer_chain_kernel<S_, CI_, CO_, P_>), grid, dim3(CH_NT), fl * 4, ctx->stream, a);                       \
+        if (hipGetLastError() != hipSuccess) return -1;                                                                                  \
+        return 1;                                                                                                                        \
+    } while (0)
+    if (hw == 28 && c_in == 32 && c_out == 32) { if (post == 0) TH_LC(28, 32, 32, 0); if (post == 1) TH_LC(28, 32, 32, 1); }
+    if (hw == 14 && c_in == 32 && c_out == 64) { if (post == 0) TH_LC(14, 32, 64, 0); if (post == 1) TH_LC(14, 32, 64, 1); }
+    if (hw == 14 && c_in == 64 && c_out == 64) { if (post == 0) TH_LC(14, 64, 64, 0); if (post == 1) TH_LC(14, 64, 64, 1); }
+    if (hw == 7 && c_in == 64 && c_out == 128) { if (post == 0) TH_LC(7, 64, 128, 0); if (post == 2) TH_LC(7, 64, 128, 2); }
+#undef TH_LC
+    return 0;
+}
+}  // namespace th
 
 extern "C" {
 

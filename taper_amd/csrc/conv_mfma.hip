@@ -815,6 +815,10 @@ bool conv3x3_mfma_pool_supported(int c_in, int h, int w, int pad) {   // whole 2
 // -1: the image-resident kernel takes launches with >= one unit per two CUs; 0: never; 1: whenever a plan exists
 // (TAPER_CONV_IMG at load, th_debug_set_conv_img at run time: the parity tests force both kernels onto the same shapes)
 int g_conv_img_mode = getenv("TAPER_CONV_IMG") ? atoi(getenv("TAPER_CONV_IMG")) : -1;
+// TAPER_CONV_LAYER_CHAIN=0: the four compiled layer geometries keep the image-resident kernel (measurement probe)
+static const bool g_conv_layer_chain = !(getenv("TAPER_CONV_LAYER_CHAIN") && getenv("TAPER_CONV_LAYER_CHAIN")[0] == '0');
+int conv_layer_chain_launch(th_ctx *ctx, const float *x, const float *w, const float *bias, float *y, float *cnt, int n, int c_in, int hw, int c_out,
+                            int post);   // conv_chain.hip
 
 // launch configuration of this thread's most recent matrix-core convolution (th_debug_last_conv_config)
 thread_local int t_last_conv_cfg[6] = {0, 0, 0, 0, 0, 0};
@@ -827,6 +831,17 @@ bool conv3x3_gap_supported(int n, int c_in, int h, int w_in, int c_out, int pad)
 int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, int w_cols, const float *bias, float *y, int n,
                         int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool, float *gap_cnt, bool gap) {
     TH_REQUIRE(w_ld % 4 == 0 && ((uintptr_t)w & 15) == 0, "conv3x3_mfma: weight rows must be 16-byte aligned");
+    // the batch-256 layers of the reference CNN as one-stage chains (conv_chain.hip: conv_layer_chain_kernel; same bits): the taper slab read in
+    // place, ReLU on, pad 1, default kernel choice only (th_debug_set_conv_img forces the kernels below)
+    if (g_conv_img_mode == -1 && g_conv_layer_chain && !accum && relu && pad == 1 && h == w_in && w_ld == c_out && w_cols == c_out) {
+        const int rc = conv_layer_chain_launch(ctx, x, w, bias, y, gap ? gap_cnt : nullptr, n, c_in, h, c_out, gap ? 2 : (pool ? 1 : 0));
+        if (rc < 0) { th::set_error("conv_layer_chain_kernel: launch failed"); return 1; }
+        if (rc == 1) {
+            t_last_conv_cfg[0] = c_out / 16; t_last_conv_cfg[1] = 8; t_last_conv_cfg[2] = 8;   // 8: one layer through the chain's compiled mapping
+            t_last_conv_cfg[3] = n < kNumCU ? n : kNumCU; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = pool ? 1 : 0;
+            return 0;
+        }
+    }
     {
         // launches with at least a unit per two CUs take the image-resident kernel (TAPER_CONV_IMG = 0 / 1: never / whenever it fits)
         const int img_env = g_conv_img_mode;

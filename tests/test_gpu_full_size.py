@@ -46,18 +46,22 @@ FULL_LAYERS = [
 ]
 
 
-@pytest.mark.parametrize("kernel", ["image_resident", "pixel_block"])
+@pytest.mark.parametrize("kernel", ["layer_chain", "image_resident", "pixel_block"])
 @pytest.mark.parametrize("n,c_in,hw,c_out,img_cfg,ct", FULL_LAYERS)
 def test_conv3x3_full_size_layers(ctx, O, n, c_in, hw, c_out, img_cfg, ct, kernel):
-    ctx.call("th_debug_set_conv_img", -1 if kernel == "image_resident" else 0)
+    """the default choice at batch 256 (r04): the layer as a one-stage chain with the chain's compiled tile mapping (conv_layer_chain_kernel,
+    config id 8); th_debug_set_conv_img forces the image-resident kernel (1) and the 128-pixel kernel (0) onto the same shapes"""
+    ctx.call("th_debug_set_conv_img", {"layer_chain": -1, "image_resident": 1, "pixel_block": 0}[kernel])
     try:
-        _full_size_layer(ctx, O, n, c_in, hw, c_out, img_cfg if kernel == "image_resident" else None, ct)
+        _full_size_layer(ctx, O, n, c_in, hw, c_out, {"layer_chain": ("chain", c_out // 16), "image_resident": img_cfg, "pixel_block": None}[kernel], ct)
     finally:
         ctx.call("th_debug_set_conv_img", -1)
 
 
 def _expect_cfg(cfg, img_cfg, ct, pool):
-    if img_cfg is None:
+    if img_cfg is not None and img_cfg[0] == "chain":
+        assert cfg["dma"] == 8 and cfg["ct"] == img_cfg[1] and cfg["grid"][0] == 256 and cfg["pool"] == pool, cfg
+    elif img_cfg is None:
         assert cfg["ct"] == ct and cfg["dma"] == 1 and cfg["pool"] == pool, cfg
         assert cfg["grid"][0] * cfg["grid"][1] >= 256, cfg                 # a chip-filling launch, not the small-batch shape
     else:
@@ -207,7 +211,7 @@ def _training_steps_parity(T, name, mode):
             # the conv chain ran in this process's step (7: with the simple CNN's classifier rows in its last epilogue, th_conv_chain_head_fwd)
             assert cfg["dma"] == (6 if name == "cnn_reference" else 7) and cfg["ct"] == (1 if name == "cnn_reference" else 2), cfg
         else:
-            assert cfg["ct"] in (1, 2) and cfg["dma"] in (2, 3, 4, 5), cfg   # the image-resident matrix-core conv ran in this process's step
+            assert cfg["dma"] in (2, 3, 4, 5, 8), cfg   # a layer-by-layer matrix-core conv ran in this process's step (8: as a one-stage chain)
         if name == "cnn_reference":     # its three-layer classifier took th_mlp3_xent (two launches) in the captured step
             assert mlp3_calls() > calls0
     else:
@@ -352,7 +356,7 @@ def gap_case(ctx, O, n, c_in, h, w, c_out, pad):
     ym, cnt = ctx.empty(n * c_out), ctx.empty(n * c_out)
     ctx.call("th_conv3x3_gap_fwd", dx, dw, db, ym, cnt, n, c_in, h, w, c_out, pad, 1)
     cfg = last_conv_config(ctx)
-    assert cfg["dma"] in (2, 3, 4, 5) and cfg["pool"] == 1, cfg
+    assert cfg["dma"] in (2, 3, 4, 5, 8) and cfg["pool"] == 1, cfg     # (8: the reference CNN's conv5 shape takes the one-stage chain kernel)
     got_mean, got_cnt = ctx.download(ym, (n, c_out)), ctx.download(cnt, (n, c_out))
     np.testing.assert_allclose(got_mean, ref_mean, rtol=RTOL, atol=1e-5)
     # a count differs from the oracle's only where an output sits within rounding of 0

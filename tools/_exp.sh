@@ -1,3 +1,11 @@
-cd /tmp
-R=$GRAFT_REPO_ROOT
-for ns in 4 6; do echo "== NS=$ns"; TAPER_MLP2_NS=$ns python $R/tools/mlp2_time.py 1024 2048 4096 8192; done
+cd $GRAFT_REPO_ROOT
+python bench.py --workloads cnn_reference_b256 --no-sweep --no-cpu-baseline --no-roofline --steps 100 --warmup 10 > /dev/null 2>&1; python -c "
+import json; d=json.load(open('gpurun_out/bench_details.json'))
+for w in d['workloads']:
+    for k in w.get('kernels',[]): print('   ', k.get('layer',''), k['us_per_launch'], k['frac'], k.get('in_step'))
+"
+TAPER_CONV_LAYER_CHAIN=0 python bench.py --workloads cnn_reference_b256 --no-sweep --no-cpu-baseline --no-roofline --steps 100 --warmup 10 > /dev/null 2>&1; python -c "
+import json; d=json.load(open('gpurun_out/bench_details.json'))
+for w in d['workloads']:
+    for k in w.get('kernels',[]): print('  old', k.get('layer',''), k['us_per_launch'], k['frac'], k.get('in_step'))
+"
