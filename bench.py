@@ -629,6 +629,58 @@ def linear_stack_workload(T, layers=4, width=4096, batch=4096, steps=12, warmup=
     return rec
 
 
+def mlp2_workload(ctx, batch=16384, reps=150):
+    """The large-batch MLP step (th_mlp2_xent, SURVEY 8d's sweep top) launch by launch: each of its three kernels alone between HIP events on
+    the ctx stream (th_debug_mlp2_only), the rows read through a shuffled index vector of a resident 60 000-row set like a Trainer step's.
+    Algorithmic work: rows and dW1 2 B 784 128 flop each (+ the classifier's 3 x 2 B 128 10 in the rows launch); finish: the K slices of dW1
+    (one workgroup per CU: 256 // 7 slices of 128 x 784 floats) + the row blocks' partials + 28 B per parameter of Adam traffic."""
+    from taper_amd import hip
+    from taper_amd.hip import AdamFuse, RowSource
+    rng = np.random.default_rng(3)
+    inf, hid, c, n_rows = 784, 128, 10, 60000
+    data = ctx.upload((rng.integers(0, 256, (n_rows, inf))).astype(np.float32) / np.float32(255.0))
+    labels = ctx.upload(rng.integers(0, c, n_rows).astype(np.float32))
+    idx = ctx.upload(rng.permutation(n_rows).astype(np.int32))
+    dev = dict(w1=ctx.upload((rng.uniform(-1, 1, (hid, inf)) * np.sqrt(2.0 / inf)).astype(np.float32)), b1=ctx.zeros(hid),
+               w2=ctx.upload(rng.uniform(-0.3, 0.3, (c, hid)).astype(np.float32)), b2=ctx.zeros(c))
+    mom = {k: (ctx.zeros(n), ctx.zeros(n)) for k, n in (("w1", hid * inf), ("b1", hid), ("w2", c * hid), ("b2", c))}
+    tick, dlr = ctx.upload(np.array([0, 0], np.int32)), ctx.upload(np.array([1e-3], np.float32))
+    fuses = [AdamFuse(int(dev[k]), int(mom[k][0]), int(mom[k][1]), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4) for k in ("w1", "b1", "w2", "b2")]
+    out = dict(dw1=ctx.empty(hid * inf), db1=ctx.empty(hid), dw2=ctx.empty(c * hid), db2=ctx.empty(c), loss=ctx.empty(1), nc=ctx.empty(1))
+    state = ctx.upload(np.array([0, 0], np.int64))
+    src = RowSource(int(data), int(labels), int(idx), state.offset(8), n_rows, n_rows)
+
+    def step():
+        ctx.call("th_mlp2_xent", C.byref(src), batch, inf, hid, c, dev["w1"], dev["b1"], dev["w2"], dev["b2"], out["dw1"], out["db1"], out["dw2"],
+                 out["db2"], out["loss"], out["nc"], None, 0, None, 0, tick, *[C.byref(f) for f in fuses])
+    P = hid * inf + hid + c * hid + c
+    rt = 64 if batch >= 12288 else 32
+    n_blk = -(-batch // rt)
+    kz = max(1, min(256 // 7, n_blk * rt // 32))
+    gemm = 2.0 * batch * inf * hid
+    specs = [("mlp2_rows_kernel<%d, 4, 4>" % rt, "rows: X W1^T + b1, ReLU, classifier, masked dZ1", 1, "mfma", gemm + 3 * 2.0 * batch * hid * c,
+              4.0 * (batch * inf + hid * inf + batch * hid)),
+             ("mlp2_dw1_kernel8<4, true>", "dW1 = dZ1^T X over %d K slices" % kz, 2, "mfma", gemm, 4.0 * (batch * inf + batch * hid + kz * hid * inf)),
+             ("mlp2_finish_kernel", "fixed-order sums + Adam", 3, "hbm", 14.0 * P, 4.0 * (kz * hid * inf + n_blk * (c * hid + hid + 18)) + 28.0 * P)]
+    us_step = _time_launches(ctx, step, reps, warm=20)
+    kernels = []
+    try:
+        for name, role, which, bound, flops, nbytes in specs:
+            hip.hip.th_debug_mlp2_only(which)
+            us = _time_launches(ctx, step, reps, warm=10)
+            tf, gbs = flops / (us * 1e-6) / 1e12, nbytes / (us * 1e-6) / 1e9
+            kernels.append(dict(kernel=name, role=role, in_step=True, us_per_launch=round(us, 2), alg_flops_per_launch=flops, alg_bytes_per_launch=nbytes,
+                                bound=bound, achieved=round(tf if bound == "mfma" else gbs, 2), peak=MFMA_F32_PEAK_TF if bound == "mfma" else HBM_PEAK_GBS,
+                                unit="TFLOP/s" if bound == "mfma" else "GB/s",
+                                frac=round(tf / MFMA_F32_PEAK_TF if bound == "mfma" else gbs / HBM_PEAK_GBS, 4)))
+    finally:
+        hip.hip.th_debug_mlp2_only(0)
+    flops = 409088.0 * batch + 14.0 * P
+    return dict(workload=f"mlp_784-128-10_b{batch}", per_gpu_batch=batch, ms_per_step=round(us_step * 1e-3, 5), samples_per_s=round(batch / (us_step * 1e-6), 1),
+                step="th_mlp2_xent through the C ABI, three eager launches back to back (the Trainer's replayed step: batch_sweep)",
+                alg_flops_per_step=flops, frac_of_mfma_peak_step=round(flops / (us_step * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4), kernels=kernels)
+
+
 def extra_workloads(T, dataset, with_cpu, only=None):
     """the BASELINE configs besides the headline, each on the same line (N = 1)"""
     from taper_amd import hip
@@ -657,6 +709,11 @@ def extra_workloads(T, dataset, with_cpu, only=None):
         except Exception as e:   # one workload failing must not lose the line
             rec = dict(workload=name, error=str(e))
         out.append(rec)
+    if not only or "mlp_784-128-10_b16384" in only:
+        try:
+            out.append(mlp2_workload(ctx))
+        except Exception as e:
+            out.append(dict(workload="mlp_784-128-10_b16384", error=str(e)))
     if not only or "linear_stack_4096x4_b4096" in only:
         try:
             rec = linear_stack_workload(T)
@@ -713,19 +770,21 @@ def compact_line(full, details_path):
             d["b64_per_gpu_ms_per_step"] = dp["dp_at_64_rows_per_gpu"]["ms_per_step"]
         out["data_parallel"] = d
     if full.get("batch_sweep"):
-        out["batch_sweep"] = {str(e["batch"]): [round(e["ms_per_step"] * 1e3, 1), e["epochs_per_s"], e["mfma_frac"]] for e in full["batch_sweep"]}
-        out["batch_sweep_fields"] = "us/step, epochs/s, frac of fp32 MFMA peak"
+        # {batch: [us/step, epochs/s, fraction of the fp32 MFMA peak]}
+        out["batch_sweep_us_epochs_frac"] = {str(e["batch"]): [round(e["ms_per_step"] * 1e3, 1), round(e["epochs_per_s"], 1), round(e["mfma_frac"], 3)] for e in full["batch_sweep"]}
     if full.get("workloads"):
         w = {}
         for rec in full["workloads"]:
             if "error" in rec:
                 w[rec["workload"]] = {"error": _short(rec["error"], 60)}
                 continue
-            e = {"ms_per_step": rec["ms_per_step"], "samples_per_s": rec["samples_per_s"]}
+            e = {"ms_per_step": rec["ms_per_step"]}      # (samples/s = per_gpu_batch / ms_per_step: in the details file)
             ks = [k for k in rec.get("kernels", []) if k.get("in_step", True)]
-            if ks:
+            if rec["workload"].startswith("mlp_784-128-10_b") and ks:      # th_mlp2_xent launch by launch: [us, fraction of its roofline]
+                e = {"ms_per_step": rec["ms_per_step"], "kernels": {k["kernel"].split("<")[0].replace("mlp2_", "").replace("_kernel8", "").replace("_kernel", ""): [k["us_per_launch"], k["frac"]] for k in ks}}
+            elif ks:
                 k = max(ks, key=lambda r: r["us_per_launch"])
-                e["kernel"] = [_short(k["kernel"].split("<")[0].split("(")[0], 28), k["us_per_launch"], k["bound"], k["frac"]]
+                e["kernel"] = [_short(k["kernel"].split("<")[0].split("(")[0], 24), k["us_per_launch"], k["bound"], k["frac"]]
             if "frac_of_mfma_peak" in rec:
                 e["mfma_frac"] = rec["frac_of_mfma_peak"]
                 e["sgemm_4096_frac"] = [k["frac"] for k in rec.get("kernels", [])]
@@ -745,7 +804,7 @@ def compact_line(full, details_path):
     cb = full.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: (round(cb[k], 1) if k == "value" and cb[k] else cb[k]) for k in ("value", "unit", "cores", "kind") if k in cb}
-        out["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 110)
+        out["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 64)
         if cb.get("blas_feature", {}).get("value"):
             out["cpu_baseline"]["blas_feature_value"] = round(cb["blas_feature"]["value"], 1)
         if "see" in cb:

@@ -748,6 +748,7 @@ __global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
 }
 
 thread_local long t_mlp2_calls = 0;
+thread_local int t_mlp2_only = 0;      // th_debug_mlp2_only: 0 = the step; 1 / 2 / 3 = that launch alone (per-launch timing; workspace kept from call to call)
 
 static int m2_rows_per_block(int batch) {
     static const int forced = [] { const char *e = getenv("TAPER_MLP2_RT"); return e ? atoi(e) : 0; }();
@@ -830,14 +831,18 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     // every chunk's k rounds) measured the same to 2 %: 39.7 / 23.7 / 22.7 us against 39.2-40.5 / 23.5 / 22.5 us at 16 384 / 4 096 / 1 024 rows --
     // the k loop already runs at the rate the matrix pipes sustain at the clocks the part holds under this load
     static const int nw = [] { const char *e = getenv("TAPER_MLP2_NW"); return e && atoi(e) == 8 ? 8 : 4; }();
-    if (RT == 64 && nw == 8) M2_ROWS_LAUNCH(64, 4, 8);
-    else if (RT == 64) M2_ROWS_LAUNCH(64, 4, 4);
-    else if (nw == 8) M2_ROWS_LAUNCH(32, 4, 8);
-    else M2_ROWS_LAUNCH(32, 4, 4);
+    const int only = t_mlp2_only;
+    if (only == 0 || only == 1) {
+        if (RT == 64 && nw == 8) M2_ROWS_LAUNCH(64, 4, 8);
+        else if (RT == 64) M2_ROWS_LAUNCH(64, 4, 4);
+        else if (nw == 8) M2_ROWS_LAUNCH(32, 4, 8);
+        else M2_ROWS_LAUNCH(32, 4, 4);
+    }
 #undef M2_ROWS_LAUNCH
     TH_LAUNCH_CHECK();
 
-    if (dw8) {
+    if (only != 0 && only != 2) {
+    } else if (dw8) {
         Mlp2Dw8Args d{};
         d.src = rs;
         d.dz1 = dz1; d.dz_bytes = (unsigned)(n_dz * 4);
@@ -890,7 +895,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     f.w1a = make_adam_dev(w1_fuse); f.b1a = make_adam_dev(b1_fuse); f.w2a = make_adam_dev(w2_fuse); f.b2a = make_adam_dev(b2_fuse);
     f.w1_blocks = ceil_div((long)hidden * in_features, 64);
     const int tail_blocks = ceil_div(classes * hidden + hidden + 16 + 1, 16);
-    hipLaunchKernelGGL(mlp2_finish_kernel, dim3(f.w1_blocks + tail_blocks), dim3(256), 0, ctx->stream, f);
+    if (only == 0 || only == 3) hipLaunchKernelGGL(mlp2_finish_kernel, dim3(f.w1_blocks + tail_blocks), dim3(256), 0, ctx->stream, f);
     TH_LAUNCH_CHECK();
     ++t_mlp2_calls;
     return th_free(ctx, ws);
@@ -898,6 +903,11 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
 
 int th_debug_mlp2_calls(int64_t *out) {
     if (out) *out = t_mlp2_calls;
+    return 0;
+}
+
+int th_debug_mlp2_only(int which) {
+    t_mlp2_only = (which >= 1 && which <= 3) ? which : 0;
     return 0;
 }
 
