@@ -672,6 +672,16 @@ __global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
         // 16 float4 of the gradient per workgroup, 16 threads per float4: thread zg adds slices zg, zg + 16, ...; thread 0 adds the 16 sums in order
         const long mn = (long)a.hid * a.in_f, i0 = ((long)bid * 16 + (t & 15)) * 4;
         const int zg = t >> 4;
+        // the owner's Adam operands are requested FIRST: behind the sums they would be a second dependent round trip
+        const bool owner = zg == 0 && i0 < mn, fuse = owner && a.w1a.p != nullptr;
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), mv = pv, vv = pv;
+        float step = 0.f;
+        if (fuse) {
+            pv = *reinterpret_cast<const float4 *>(a.w1a.p + i0);
+            mv = *reinterpret_cast<const float4 *>(a.w1a.m + i0);
+            vv = *reinterpret_cast<const float4 *>(a.w1a.v + i0);
+            step = adam_dev_step(a.w1a);
+        }
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i0 < mn) {
 #pragma unroll 4
@@ -689,12 +699,21 @@ __global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
             s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
         }
         *reinterpret_cast<float4 *>(a.dw1 + i0) = s;
-        if (a.w1a.p) {
-            const float step = adam_dev_step(a.w1a);
-            adam_update(a.w1a.p, a.w1a.m, a.w1a.v, i0, s.x, step, a.w1a.beta1, a.w1a.beta2, a.w1a.eps, a.w1a.wd);
-            adam_update(a.w1a.p, a.w1a.m, a.w1a.v, i0 + 1, s.y, step, a.w1a.beta1, a.w1a.beta2, a.w1a.eps, a.w1a.wd);
-            adam_update(a.w1a.p, a.w1a.m, a.w1a.v, i0 + 2, s.z, step, a.w1a.beta1, a.w1a.beta2, a.w1a.eps, a.w1a.wd);
-            adam_update(a.w1a.p, a.w1a.m, a.w1a.v, i0 + 3, s.w, step, a.w1a.beta1, a.w1a.beta2, a.w1a.eps, a.w1a.wd);
+        if (fuse) {      // optim.rs:99-110, element by element as adam_update does
+            const AdamDev &ad = a.w1a;
+            float4 po, mo, vo;
+#define M2_ADAM(k)                                                       \
+            {                                                            \
+                const float gg = s.k + ad.wd * pv.k;                     \
+                mo.k = ad.beta1 * mv.k + (1.0f - ad.beta1) * gg;         \
+                vo.k = ad.beta2 * vv.k + (1.0f - ad.beta2) * gg * gg;    \
+                po.k = pv.k - step * mo.k / (sqrtf(vo.k) + ad.eps);      \
+            }
+            M2_ADAM(x) M2_ADAM(y) M2_ADAM(z) M2_ADAM(w)
+#undef M2_ADAM
+            *reinterpret_cast<float4 *>(ad.m + i0) = mo;
+            *reinterpret_cast<float4 *>(ad.v + i0) = vo;
+            *reinterpret_cast<float4 *>(ad.p + i0) = po;
         }
         return;
     }
@@ -783,6 +802,8 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp2_xent: metrics need d_state and a capacity");
     TH_REQUIRE(!(b1_fuse && b1_fuse->d_p) || d_db1, "th_mlp2_xent: a fused bias update needs d_db1");
     TH_REQUIRE(!(b2_fuse && b2_fuse->d_p) || d_db2, "th_mlp2_xent: a fused bias update needs d_db2");
+    TH_REQUIRE(!(w1_fuse && w1_fuse->d_p) || ((((uintptr_t)w1_fuse->d_p | (uintptr_t)w1_fuse->d_m | (uintptr_t)w1_fuse->d_v) & 15) == 0),
+               "th_mlp2_xent: W1's p / m / v slices must be 16-byte aligned");
     const int RT = m2_rows_per_block(batch);
     const int n_blk = ceil_div(batch, RT), rows_pad = n_blk * RT;
     const int stride = (classes * hidden + hidden + 16 + 2 + 3) & ~3;
