@@ -654,11 +654,11 @@ def mlp2_workload(ctx, batch=16384, reps=150):
         ctx.call("th_mlp2_xent", C.byref(src), batch, inf, hid, c, dev["w1"], dev["b1"], dev["w2"], dev["b2"], out["dw1"], out["db1"], out["dw2"],
                  out["db2"], out["loss"], out["nc"], None, 0, None, 0, tick, *[C.byref(f) for f in fuses])
     P = hid * inf + hid + c * hid + c
-    rt = 64 if batch >= 12288 else 32
-    n_blk = -(-batch // rt)
+    rt = 64 if batch >= 12288 else (32 if batch > 4096 else 16)
+    n_blk = 2 * -(-batch // 32) if rt == 16 else -(-batch // rt)
     kz = max(1, min(256 // 7, n_blk * rt // 32))
     gemm = 2.0 * batch * inf * hid
-    specs = [("mlp2_rows_kernel<%d, 4, 4>" % rt, "rows: X W1^T + b1, ReLU, classifier, masked dZ1", 1, "mfma", gemm + 3 * 2.0 * batch * hid * c,
+    specs = [("mlp2_rows_kernel<%d, %d, 4>" % (rt, 8 if rt == 16 else 4), "rows: X W1^T + b1, ReLU, classifier, masked dZ1", 1, "mfma", gemm + 3 * 2.0 * batch * hid * c,
               4.0 * (batch * inf + hid * inf + batch * hid)),
              ("mlp2_dw1_kernel8<4, true>", "dW1 = dZ1^T X over %d K slices" % kz, 2, "mfma", gemm, 4.0 * (batch * inf + batch * hid + kz * hid * inf)),
              ("mlp2_finish_kernel", "fixed-order sums + Adam", 3, "hbm", 14.0 * P, 4.0 * (kz * hid * inf + n_blk * (c * hid + hid + 18)) + 28.0 * P)]

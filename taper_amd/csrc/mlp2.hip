@@ -111,7 +111,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(NW == 4 || NW == 8, "four or eight waves");
-    constexpr int NI = NW == 4 ? RT / 32 : 1;   // 32-row MFMA tiles per wave
+    constexpr bool R16 = RT == 16;              // 16-row tiles: v_mfma_f32_16x16x4_f32, two 16 x 16 accumulator tiles per wave (its 32 columns)
+    static_assert(!R16 || NW == 4, "the 16-row form has four waves");
+    constexpr int NI = (NW == 4 && RT >= 32) ? RT / 32 : 1;   // 32-row MFMA tiles per wave
     constexpr bool KSPLIT = NW == 8 && RT == 32;   // the two wave groups split a chunk's k rounds
     constexpr int A_T = RT * M2_BK, B_T = 128 * M2_BK;
     constexpr int NRB = RT / 16;                // 16-row blocks of the tile
@@ -146,6 +148,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
     // what the epilogue needs from memory is requested now, under the whole k loop
     const int hcol = 32 * cq + li;
     const float bias1 = (a.b1 && hcol < hid) ? a.b1[hcol] : 0.f;
+    float bias16[2];                                                          // 16-row form: the bias of this lane's two accumulator columns
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) bias16[tt] = (R16 && a.b1 && 32 * cq + 16 * tt + l16 < hid) ? a.b1[32 * cq + 16 * tt + l16] : 0.f;
     const int hrow = 16 * wave + l16;                                         // the row this lane owns in the classifier stage (wave < NRB)
     const int grow = min(r0 + min(hrow, RT - 1), B - 1);
     const float tf = (wave < NRB) ? a.src.labels[src_row(a.src, cur, grow)] : 0.f;
@@ -203,6 +208,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    // 16-row form: acc16[tt][e] = H[row 4 g4 + e][column 32 cq + 16 tt + l16].  A round contracts 16 k: lane group g4 reads k quad 4 rd + g4
+    // of its row (X row l16; W1 rows 32 cq + 16 tt + l16) with one ds_read_b128, and k-step e of the round uses component e of every group's
+    // quad -- k = 16 rd + 4 g4 + e, every k once, the same permutation on both operands; the swizzled image keeps the reads conflict-free.
+    floatx4 acc16[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+    int a16[2], b16[2][2];                      // [round]: float offsets of this lane's quads
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        a16[rd] = l16 * M2_BK + (((4 * rd + g4) ^ m2_swz(l16)) << 2);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int brow = 32 * cq + 16 * tt + l16;
+            b16[rd][tt] = brow * M2_BK + (((4 * rd + g4) ^ m2_swz(brow)) << 2);
+        }
+    }
     // this lane's LDS addresses: row (tile row + li) of X, row (32 cq + li) of W1; k quad 2 r + lk of round r, swizzled
     const int row_tile0 = (NW == 8 && RT == 64) ? grp : 0;
     int ao[NI];
@@ -217,6 +236,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
 
     // eight k per round: lane half lk holds k = 8 r + 4 lk + e of its row; the operands of round r + 1 are requested before the MFMAs of round r
     auto contract = [&](const float *as, const float *bs, int nr) {
+        if constexpr (R16) {
+            // nr counts 8-k rounds of the other forms: 16-k rounds here = (nr + 1) / 2
+            float4 xa[2], wb[2][2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                xa[rd] = *reinterpret_cast<const float4 *>(as + a16[rd]);
+                wb[rd][0] = *reinterpret_cast<const float4 *>(bs + b16[rd][0]);
+                wb[rd][1] = *reinterpret_cast<const float4 *>(bs + b16[rd][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                if (2 * rd < nr) {
+#define M2_MFMA16(E)                                                                                         \
+    acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[rd].E, wb[rd][0].E, acc16[0], 0, 0, 0);                \
+    acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[rd].E, wb[rd][1].E, acc16[1], 0, 0, 0);
+                    M2_MFMA16(x) M2_MFMA16(y) M2_MFMA16(z) M2_MFMA16(w)
+#undef M2_MFMA16
+                }
+            }
+            return;
+        }
         float4 af[2][NI], bf[2];
 #define M2_REQ(SET, RR)                                                                       \
     {                                                                                         \
@@ -281,7 +322,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
         }
         lds_barrier();
     }
-    if (!KSPLIT || grp == 0) {
+    if constexpr (R16) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {           // C/D map of 16x16x4: row 4 g4 + e, column l16
+                const int col = 32 * cq + 16 * tt + l16;
+                float v = acc16[tt][e] + bias16[tt];
+                v = (v > 0.f && col < hid) ? v : 0.f;
+                Hs[(4 * g4 + e) * M2_LDH + col] = v;
+            }
+    } else if (!KSPLIT || grp == 0) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -771,8 +822,10 @@ thread_local int t_mlp2_only = 0;      // th_debug_mlp2_only: 0 = the step; 1 / 
 
 static int m2_rows_per_block(int batch) {
     static const int forced = [] { const char *e = getenv("TAPER_MLP2_RT"); return e ? atoi(e) : 0; }();
-    if (forced == 32 || forced == 64) return forced;
-    return batch >= 12288 ? 64 : 32;            // 64-row tiles once they fill the chip (>= 192 workgroups), 32-row tiles below
+    if (forced == 16 || forced == 32 || forced == 64) return forced;
+    // 64-row tiles once they fill the chip (>= 192 workgroups); 32-row tiles down to 128 workgroups; 16-row tiles below (256 workgroups at 4 096
+    // rows: with 32-row tiles half the CUs sat idle while the others ran a 23 us k loop)
+    return batch >= 12288 ? 64 : (batch > 4096 ? 32 : 16);
 }
 
 }  // namespace th
@@ -805,7 +858,8 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     TH_REQUIRE(!(w1_fuse && w1_fuse->d_p) || ((((uintptr_t)w1_fuse->d_p | (uintptr_t)w1_fuse->d_m | (uintptr_t)w1_fuse->d_v) & 15) == 0),
                "th_mlp2_xent: W1's p / m / v slices must be 16-byte aligned");
     const int RT = m2_rows_per_block(batch);
-    const int n_blk = ceil_div(batch, RT), rows_pad = n_blk * RT;
+    // (16-row tiles: an even number of row blocks, so that launch 2 sees whole 32-row chunks; a block past the batch writes zeros)
+    const int n_blk = RT == 16 ? 2 * ceil_div(batch, 32) : ceil_div(batch, RT), rows_pad = n_blk * RT;
     const int stride = (classes * hidden + hidden + 16 + 2 + 3) & ~3;
     // launch 2's form: 8 (default) = one eight-wave workgroup per CU on 128 x 112 tiles; TAPER_MLP2_DW = 22 | 31 | 32 | 41 = the four-wave
     // 128 x 128 form with that many ring stages x workgroups per CU (measurement knob)
@@ -854,7 +908,8 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     static const int nw = [] { const char *e = getenv("TAPER_MLP2_NW"); return e && atoi(e) == 8 ? 8 : 4; }();
     const int only = t_mlp2_only;
     if (only == 0 || only == 1) {
-        if (RT == 64 && nw == 8) M2_ROWS_LAUNCH(64, 4, 8);
+        if (RT == 16) M2_ROWS_LAUNCH(16, 8, 4);          // (an eight-stage ring: a chunk is 0.25 us of MFMA work, a request ~2 us away)
+        else if (RT == 64 && nw == 8) M2_ROWS_LAUNCH(64, 4, 8);
         else if (RT == 64) M2_ROWS_LAUNCH(64, 4, 4);
         else if (nw == 8) M2_ROWS_LAUNCH(32, 4, 8);
         else M2_ROWS_LAUNCH(32, 4, 4);

@@ -203,8 +203,14 @@ def test_trainer_large_batch_epochs_match_oracle(n, batch, shuffle):
 
 
 def test_trainer_large_batch_graph_equals_eager_launches():
-    """the captured steps (hipGraph replay) and the same op list enqueued eagerly (TAPER_NO_GRAPH-style: Trainer.EAGER runs the reference-literal
-    loop on the launch-per-layer kernels) agree within fp32 reordering; the mlp2 form itself is deterministic run to run"""
+    """the captured steps (hipGraph replay of th_mlp2_xent) and Trainer.EAGER (the reference-literal loop on the launch-per-layer kernels)
+    agree within fp32 reordering; the mlp2 form itself is deterministic run to run.  Adam's eps is 1e-3 here, not the default 1e-8: with
+    the default, an element whose gradient is below the paths' ~1e-8 of absolute rounding error moves by +-lr per step on noise alone
+    (optim.rs:104-109: m_hat / (sqrt(v_hat) + eps)), and one hidden pre-activation within rounding of zero (a ReLU mask flip, ~0.5 expected
+    per 4096 x 128 step) shifts a whole W1 row's small gradients by ~1e-5 -- measured on this very case: W1 up to 1.9 lr apart at
+    eps = 1e-8, 0.14 lr (one row) at 1e-5, 6e-4 lr at 1e-3, while each path's one-step gradients sit within 1.3e-8 of the oracle's.  At
+    eps = 1e-3 the comparison is about the kernels: a wrong element would still show as >> 1e-3 lr.  (Default-eps weights are held to
+    the oracle in test_trainer_large_batch_epochs_match_oracle.)"""
     import taper_amd as T
     from tests import backends
     H = backends.get("hip")
@@ -215,7 +221,7 @@ def test_trainer_large_batch_graph_equals_eager_launches():
     outs = []
     for mode in (T.Trainer.GRAPH, T.Trainer.GRAPH, T.Trainer.EAGER):
         model = H.sequential(spec)
-        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        opt = T.Adam(model.parameters(), 1e-3, None, 1e-3, 1e-4)
         tr = T.Trainer(model, opt)
         loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, True, seed=5)
         ep = [tr.run_epoch(loader, mode) for _ in range(2)]
@@ -223,9 +229,9 @@ def test_trainer_large_batch_graph_equals_eager_launches():
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         np.testing.assert_array_equal(a, b)
-    margins.check("losses_graph_vs_eager", outs[0][0], outs[2][0], 4e-6)
+    margins.check("losses_graph_vs_eager", outs[0][0], outs[2][0], 1e-5)
     for i, (a, b) in enumerate(zip(outs[0][1], outs[2][1])):
-        margins.check(f"param{i}_graph_vs_eager", a, b, 2e-2, lr=1e-3)
+        margins.check(f"param{i}_graph_vs_eager", a, b, 1.5e-3, lr=1e-3)
     T.Tape.reset()
 
 
