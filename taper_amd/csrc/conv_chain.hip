@@ -104,16 +104,28 @@ __device__ __forceinline__ void chain_weights(const float *__restrict__ w, int c
     }
 }
 
-// wc: the operands of pass 0, already requested (chain_weights).  The k loop's only non-MFMA instructions are its LDS reads: a tile's
-// window-corner address lives in a register that moves on by eight channels per pass (the tap / channel-group part of an operand address is
-// the read's immediate offset -- kept below 64 KB by hiding the region's base from constant folding), the two weight sets alternate
-// between passes instead of being copied, and the single tile's READ is unconditional (only its MFMA is skipped by the waves without one).
-template <int S, int C_IN, int C_OUT>
+// wc: the operands of pass 0, already requested (chain_weights).  The k loop's only non-MFMA instructions are its LDS reads and the next
+// pass's weight requests: a tile's window-corner address lives in a register that moves on by eight channels per pass (the tap /
+// channel-group part of an operand address is the read's immediate offset -- kept below 64 KB by hiding the region's base from constant
+// folding), the two weight sets alternate between passes instead of being copied, and the single tile's READ is unconditional (only its
+// MFMA is skipped by the waves without one).
+// Where the non-MFMA instructions sit matters more than how many there are (experiments/mfma_rate.hip, this loop's shape on its own: the
+// next step's reads issued as a group in front of the step's MFMAs: 38.3 cycles per MFMA per SIMD with two waves, 44.6 with one; ONE read
+// behind each pair of MFMAs: 34.3 / 36.0; no reads at all: 33.2 -- an instruction's issue is hidden by the MFMA in flight only when it
+// follows one).  So: the read of the next k-step's operand i sits behind MFMA pair i, and the next pass's 36 weight requests sit two per
+// k-step behind the first two pairs instead of in a burst at the head of the pass (in-kernel stamps, simple chain: the burst cost every
+// wave ~290 cycles of issue per pass with the matrix pipe idle behind it).
+// NEXT_* / w_next: the layer that follows (0 / nullptr: none) -- ITS first pass is requested during this layer's last pass, into wc,
+// where the caller's next chain_mfma expects it.  (Without a next layer the last pass's requests go to a zero-sized buffer: they return
+// zeros without touching memory, and the loop body stays free of branches.)
+template <int S, int C_IN, int C_OUT, int NEXT_S = 0, int NEXT_CIN = 0, int NEXT_COUT = 0>
 __device__ __forceinline__ void chain_mfma(const float *in, const float *__restrict__ w, ChainW &wc, floatx4 (&acc)[ChainGeo<S, C_OUT>::NSLOT], int wave,
-                                           int lane) {
+                                           int lane, const float *__restrict__ w_next = nullptr) {
     using G = ChainGeo<S, C_OUT>;
-    constexpr int WP = G::WP, CIS = G::CIS, ND = G::ND, NP = ND + (G::NS ? 1 : 0), KS = 18;
-    static_assert(C_IN % 16 == 0, "whole pairs of 8-channel passes");
+    constexpr bool HAS_NEXT = NEXT_COUT != 0;
+    using G2 = ChainGeo<HAS_NEXT ? NEXT_S : S, HAS_NEXT ? NEXT_COUT : C_OUT>;
+    constexpr int WP = G::WP, CIS = G::CIS, ND = G::ND, NP = ND + (G::NS ? 1 : 0), KS = 18, CO2 = HAS_NEXT ? NEXT_COUT : C_OUT;
+    static_assert(C_IN % 16 == 0 && ND >= 2, "whole pairs of 8-channel passes; two pairs of MFMAs per k-step to put the weight requests behind");
     const int l16 = lane & 15, g4 = lane >> 4;
 #ifdef CH_PROBE_HS   /* timing probe: every wave (1) / no wave (0) runs the single tile, as a compile-time constant (wrong results) */
     constexpr bool hs = CH_PROBE_HS != 0;
@@ -132,26 +144,43 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
 #pragma unroll
     for (int k = 0; k < G::NSLOT; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
     ChainW wn;
-    // the operands of k-step s + 1 are requested before the MFMAs of step s are issued, and pinned there (conv_mfma.hip: left alone, the
-    // scheduler sinks every read to its use)
+    // weight addressing (chain_weights): this layer's, and the next layer's first pass
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * C_IN * C_OUT * 4, 0x00020000);
+    const int va = ((lane >> 4) * 9 * C_OUT + (lane & 15)) * 4 + 64 * G::chA(wave), vb = va + 64 * (G::chB(wave) - G::chA(wave));
+    const int va2 = ((lane >> 4) * 9 * CO2 + (lane & 15)) * 4 + 64 * G2::chA(wave), vb2 = va2 + 64 * (G2::chB(wave) - G2::chA(wave));
 #ifdef CH_NO_READS   /* timing probe: the k loop without its LDS reads (wrong results) */
-#define CH_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < NP; ++i) B[i] = __builtin_bit_cast(float, (int)(size_t)pt[i]); }
+#define CH_REQ1(B, SS, I) { B[I] = __builtin_bit_cast(float, (int)(size_t)pt[I]); }
 #else
-#define CH_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < NP; ++i) B[i] = pt[i][(4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
+#define CH_REQ1(B, SS, I) { B[I] = pt[I][(4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
 #endif
-#define CH_PASS_BODY(WCUR)                                                                                                                   \
+#ifdef CH_NO_WEIGHTS   /* timing probe: no weight loads (wrong results) */
+#define CH_WREQ(DST, RS, V, SO) { DST = __builtin_bit_cast(float, (V) + (SO)); }
+#else
+#define CH_WREQ(DST, RS, V, SO) { DST = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RS, V, SO, 0)); }
+#endif
+    // one pass: 18 k-steps on WCUR; behind pair 0 / pair 1 of step s, the requests for WNXT.a[s] / .b[s] (row (pass + 4 (s / 9)) * 9 + s % 9
+    // of the slab RS, ROWB bytes per row); behind pair i, the read of operand i of step s + 1
+#define CH_PASS_BODY(WCUR, WNXT, RS, VA, VB, SOBASE, ROWB)                                                                                   \
     {                                                                                                                                        \
         float b0[NP], b1[NP];                                                                                                                \
-        CH_REQ(b0, 0)                                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NP; ++i) CH_REQ1(b0, 0, i)                                                                     \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                                     \
-            if (s + 1 < KS) CH_REQ(b1, s + 1)                                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                                               \
             _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                                                 \
                 acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[i], acc[2 * i], 0, 0, 0);                                    \
                 acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.b[s], b0[i], acc[2 * i + 1], 0, 0, 0);                            \
+                __builtin_amdgcn_sched_barrier(0);                                                                                           \
+                if (s + 1 < KS) CH_REQ1(b1, s + 1, i)                                                                                        \
+                if (i == 0) CH_WREQ(WNXT.a[s], RS, VA, (SOBASE) + ((4 * (s / 9)) * 9 + s % 9) * (ROWB))                                      \
+                if (i == 1) CH_WREQ(WNXT.b[s], RS, VB, (SOBASE) + ((4 * (s / 9)) * 9 + s % 9) * (ROWB))                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                                           \
             }                                                                                                                                \
-            if (G::NS && hs) acc[G::NSLOT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[NP - 1], acc[G::NSLOT - 1], 0, 0, 0);    \
-            __builtin_amdgcn_sched_barrier(0);                                                                                               \
+            if (G::NS) {                                                                                                                     \
+                if (hs) acc[G::NSLOT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[NP - 1], acc[G::NSLOT - 1], 0, 0, 0);         \
+                __builtin_amdgcn_sched_barrier(0);                                                                                           \
+                if (s + 1 < KS) CH_REQ1(b1, s + 1, NP - 1)                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                                                           \
+            }                                                                                                                                \
             if (s + 1 < KS) { _Pragma("unroll") for (int i = 0; i < NP; ++i) b0[i] = b1[i]; }                                                \
         }                                                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < NP; ++i) pt[i] += 8 * CIS;                                                                     \
@@ -159,14 +188,17 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
 #pragma unroll 1
     for (int cb = 0; cb < C_IN; cb += 16) {
         CH_PASS(S, C_IN, cb);
-        chain_weights<S, C_IN, C_OUT>(w, cb + 8, wn, wave, lane);
-        CH_PASS_BODY(wc)
+        CH_PASS_BODY(wc, wn, rw, va, vb, (cb + 8) * 9 * C_OUT * 4, C_OUT * 4)
         CH_PASS(S, C_IN, cb + 8);
-        if (cb + 16 < C_IN) chain_weights<S, C_IN, C_OUT>(w, cb + 16, wc, wave, lane);
-        CH_PASS_BODY(wn)
+        const bool last = cb + 16 >= C_IN;   // (uniform: scalar selects)
+        const auto rn = __builtin_amdgcn_make_buffer_rsrc((void *)(last && HAS_NEXT ? w_next : w), 0,
+                                                          last ? (HAS_NEXT ? 9 * NEXT_CIN * NEXT_COUT * 4 : 0) : 9 * C_IN * C_OUT * 4, 0x00020000);
+        const int van = last ? va2 : va, vbn = last ? vb2 : vb, sob = last ? 0 : (cb + 16) * 9 * C_OUT * 4, rowb = last ? CO2 * 4 : C_OUT * 4;
+        CH_PASS_BODY(wn, wc, rn, van, vbn, sob, rowb)
     }
 #undef CH_PASS_BODY
-#undef CH_REQ
+#undef CH_REQ1
+#undef CH_WREQ
 }
 
 // bias of this lane's channels (16 chA + 4 g4 + e, 16 chB + 4 g4 + e)
@@ -346,8 +378,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
     {   // conv2 32 -> 32 @28 + pool
         floatx4 acc[ChainGeo<28, 32>::NSLOT];
         chain_bias<28, 32>(a.b[1], bv, wave, lane);
-        chain_mfma<28, 32, 32>(A1, a.w[1], wc, acc, wave, lane);
-        chain_weights<14, 32, 64>(a.w[2], 0, wc, wave, lane);  // conv3's first pass: under the pooling
+        chain_mfma<28, 32, 32, 14, 32, 64>(A1, a.w[1], wc, acc, wave, lane, a.w[2]);   // (+ conv3's first pass, requested during the last pass)
         chain_sync();
         CH_STAMP(3);                                    // every wave is done reading A1
         chain_store<28, 32, false>(acc, bv, T2, wave, lane);
@@ -362,8 +393,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
         floatx4 acc[ChainGeo<14, 64>::NSLOT];
         chain_zero_halo<14, 64>(A3, wave, lane);                     // (T2 is dead; A3's interior is written after the k loop's barrier)
         chain_bias<14, 64>(a.b[2], bv, wave, lane);
-        chain_mfma<14, 32, 64>(A2, a.w[2], wc, acc, wave, lane);
-        chain_weights<14, 64, 64>(a.w[3], 0, wc, wave, lane);
+        chain_mfma<14, 32, 64, 14, 64, 64>(A2, a.w[2], wc, acc, wave, lane, a.w[3]);
         chain_sync();
         CH_STAMP(6);
         chain_store<14, 64, true>(acc, bv, A3, wave, lane);
@@ -373,8 +403,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
     {   // conv4 64 -> 64 @14 + pool
         floatx4 acc[ChainGeo<14, 64>::NSLOT];
         chain_bias<14, 64>(a.b[3], bv, wave, lane);
-        chain_mfma<14, 64, 64>(A3, a.w[3], wc, acc, wave, lane);
-        chain_weights<7, 64, 128>(a.w[4], 0, wc, wave, lane);
+        chain_mfma<14, 64, 64, 7, 64, 128>(A3, a.w[3], wc, acc, wave, lane, a.w[4]);
         chain_sync();                                    // every wave is done reading A3
         CH_STAMP(8);
         chain_store<14, 64, false>(acc, bv, T4, wave, lane);
@@ -798,35 +827,51 @@ __device__ __forceinline__ void rt_mfma(const float *in, const float *__restrict
     if (w0) wc = *w0;                              // requested before the previous stage's epilogue (rt_stage_nd)
     else rt_weights(w, c_in, c_out, 0, chA, chB, wc, lane);
 #define RT_REQ(B, SS) { _Pragma("unroll") for (int i = 0; i < ND; ++i) B[i] = pt[i][(4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
-#define RT_PASS_BODY(WCUR)                                                                                                          \
+#define RT_REQ1(B, SS, I) { B[I] = pt[I][(4 * ((SS) / 9)) * CIS + (((SS) % 9) / 3) * WP + ((SS) % 9) % 3]; }
+#define RT_WREQ(DST, RS, V, SO) { DST = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RS, V, SO, 0)); }
+    /* as chain_mfma: one read of the next step behind each pair of MFMAs; the next pass's weight requests two per k-step behind the */
+    /* step's first pairs (the pass after the last one: a zero-sized buffer, no branch)                                              */
+#define RT_PASS_BODY(WCUR, WNXT, RS, SOBASE)                                                                                        \
     {                                                                                                                               \
         float b0[ND], b1[ND];                                                                                                       \
         RT_REQ(b0, 0)                                                                                                               \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                            \
-            if (s + 1 < KS) RT_REQ(b1, s + 1)                                                                                       \
+            const int so_ = (SOBASE) + ((4 * (s / 9)) * 9 + s % 9) * rowb;                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
             _Pragma("unroll") for (int i = 0; i < ND - 1; ++i) {                                                                    \
                 acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[i], acc[2 * i], 0, 0, 0);                           \
                 acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.b[s], b0[i], acc[2 * i + 1], 0, 0, 0);                   \
+                __builtin_amdgcn_sched_barrier(0);                                                                                  \
+                if (s + 1 < KS) RT_REQ1(b1, s + 1, i)                                                                               \
+                if (i == 0) RT_WREQ(WNXT.a[s], RS, va, so_)                                                                         \
+                if (i == 1) RT_WREQ(WNXT.b[s], RS, vb, so_)                                                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                                                  \
             }                                                                                                                       \
             if (last_live) {                                                                                                        \
                 acc[2 * ND - 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[ND - 1], acc[2 * ND - 2], 0, 0, 0);            \
                 acc[2 * ND - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.b[s], b0[ND - 1], acc[2 * ND - 1], 0, 0, 0);            \
             }                                                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                      \
+            if (s + 1 < KS) RT_REQ1(b1, s + 1, ND - 1)                                                                              \
+            if (ND - 1 == 0) RT_WREQ(WNXT.a[s], RS, va, so_)                                                                        \
+            if (ND - 1 <= 1) RT_WREQ(WNXT.b[s], RS, vb, so_)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                      \
             if (s + 1 < KS) { _Pragma("unroll") for (int i = 0; i < ND; ++i) b0[i] = b1[i]; }                                       \
         }                                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < ND; ++i) pt[i] += 8 * CIS;                                                            \
     }
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * c_in * c_out * 4, 0x00020000);
+    const int rowb = c_out * 4, va = ((lane >> 4) * 9 * c_out + (lane & 15)) * 4 + 64 * chA, vb = va + 64 * (chB - chA);
 #pragma unroll 1
     for (int cb = 0; cb < c_in; cb += 16) {
-        rt_weights(w, c_in, c_out, cb + 8, chA, chB, wn, lane);
-        RT_PASS_BODY(wc)
-        if (cb + 16 < c_in) rt_weights(w, c_in, c_out, cb + 16, chA, chB, wc, lane);
-        RT_PASS_BODY(wn)
+        RT_PASS_BODY(wc, wn, rw, (cb + 8) * 9 * rowb)
+        const auto rn = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, cb + 16 < c_in ? 9 * c_in * c_out * 4 : 0, 0x00020000);
+        RT_PASS_BODY(wn, wc, rn, (cb + 16) * 9 * rowb)
     }
+#undef RT_WREQ
 #undef RT_PASS_BODY
 #undef RT_REQ
+#undef RT_REQ1
 }
 
 // a single input channel (the first stage of an image chain): k = the tap, padded to three k-steps of four with zero weights (chain_conv1_mfma)

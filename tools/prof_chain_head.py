@@ -56,4 +56,5 @@ for it in range(N + 3):
         ghz = (out[21] - out[20]) / ((out[11] - out[0]) * 10.0)
 for nm, v in zip(names, acc / N):
     print(f"{v:8.3f} us  {nm}")
+print("conv2 passes as wave 0 sees them (us from kernel entry):", [round((out[i] - out[0]) * 0.01, 2) for i in range(13, 17)], "k loop ends", round((out[4] - out[0]) * 0.01, 2))
 print(f"{acc.sum() / N:8.3f} us  workgroup total;  kernel (events, eager) {tot / N * 1e3:.1f} us;  shader clock {ghz:.2f} GHz (burst of {BURST})")
