@@ -79,6 +79,23 @@ template <int S, int C_OUT> struct ChainGeo {
     __device__ static bool slot_live(int w, int k) { return k < 2 * ND || has_single(w); }
 };
 
+// Which pixel a lane's column of a pixel tile is.  Plain: 16 consecutive pixels (row-major, wrapping rows).  PM (a layer followed by a 2x2
+// max-pool, S even): tile t = pooled positions 4 t .. 4 t + 3 (row-major over the (S/2)^2 pooled map), lane l16 = window position l16 & 3
+// (dy = bit 1, dx = bit 0) of pooled position 4 t + (l16 >> 2) -- the four lanes of a quad hold one window, so the pooling is two DPP
+// quad-permute maxima on the accumulators and neither the full-resolution tile nor the pooling pass exists.  The tile count is the same
+// (28: 196 / 4 = 49; 14: 49 / 4 -> 13), and so is every output's k order: bit-identical results.  -1: no pixel (computed on pixel 0, never stored).
+template <int S, bool PM>
+__device__ __forceinline__ int chain_lane_pixel(int tile, int l16) {
+    if constexpr (PM) {
+        constexpr int HP = S / 2;
+        const int q = tile * 4 + (l16 >> 2);
+        return q < HP * HP ? (2 * (q / HP) + ((l16 >> 1) & 1)) * S + 2 * (q % HP) + (l16 & 1) : -1;
+    } else {
+        const int p = tile * 16 + l16;
+        return p < S * S ? p : -1;
+    }
+}
+
 // (barriers: lds_barrier() of common.h -- the weight loads in flight, global memory nobody writes, stay in flight across them)
 __device__ __forceinline__ void chain_sync() { lds_barrier(); }
 
@@ -107,8 +124,8 @@ __device__ __forceinline__ void chain_weights(const float *__restrict__ w, int c
 // wc: the operands of pass 0, already requested (chain_weights).  The k loop's only non-MFMA instructions are its LDS reads and the next
 // pass's weight requests: a tile's window-corner address lives in a register that moves on by eight channels per pass (the tap /
 // channel-group part of an operand address is the read's immediate offset -- kept below 64 KB by hiding the region's base from constant
-// folding), the two weight sets alternate between passes instead of being copied, and the single tile's READ is unconditional (only its
-// MFMA is skipped by the waves without one).
+// folding), the two weight sets alternate between passes instead of being copied, and the waves without a single tile run their own copy of
+// the pass (no branch inside it).
 // Where the non-MFMA instructions sit matters more than how many there are (experiments/mfma_rate.hip, this loop's shape on its own: the
 // next step's reads issued as a group in front of the step's MFMAs: 38.3 cycles per MFMA per SIMD with two waves, 44.6 with one; ONE read
 // behind each pair of MFMAs: 34.3 / 36.0; no reads at all: 33.2 -- an instruction's issue is hidden by the MFMA in flight only when it
@@ -118,7 +135,7 @@ __device__ __forceinline__ void chain_weights(const float *__restrict__ w, int c
 // NEXT_* / w_next: the layer that follows (0 / nullptr: none) -- ITS first pass is requested during this layer's last pass, into wc,
 // where the caller's next chain_mfma expects it.  (Without a next layer the last pass's requests go to a zero-sized buffer: they return
 // zeros without touching memory, and the loop body stays free of branches.)
-template <int S, int C_IN, int C_OUT, int NEXT_S = 0, int NEXT_CIN = 0, int NEXT_COUT = 0>
+template <int S, int C_IN, int C_OUT, int NEXT_S = 0, int NEXT_CIN = 0, int NEXT_COUT = 0, bool PM = false>
 __device__ __forceinline__ void chain_mfma(const float *in, const float *__restrict__ w, ChainW &wc, floatx4 (&acc)[ChainGeo<S, C_OUT>::NSLOT], int wave,
                                            int lane, const float *__restrict__ w_next = nullptr) {
     using G = ChainGeo<S, C_OUT>;
@@ -136,8 +153,8 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
     lds_cf *pt[NP];              // this lane's window corner in each of its pixel tiles (+ its lane group's channel), current pass
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        int p = (i < ND ? G::dtile(wave, i) : G::STILE) * 16 + l16;
-        if (p >= G::PX) p = 0;   // lanes past the image compute on pixel 0 and are never stored
+        int p = chain_lane_pixel<S, PM>(i < ND ? G::dtile(wave, i) : G::STILE, l16);
+        if (p < 0) p = 0;        // lanes past the image compute on pixel 0 and are never stored
         pt[i] = (lds_cf *)(in + (p / S) * WP + p % S + g4 * CIS);
         asm volatile("" : "+v"(pt[i]));
     }
@@ -160,10 +177,10 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
 #endif
     // one pass: 18 k-steps on WCUR; behind pair 0 / pair 1 of step s, the requests for WNXT.a[s] / .b[s] (row (pass + 4 (s / 9)) * 9 + s % 9
     // of the slab RS, ROWB bytes per row); behind pair i, the read of operand i of step s + 1
-#define CH_PASS_BODY(WCUR, WNXT, RS, VA, VB, SOBASE, ROWB)                                                                                   \
+#define CH_PASS_BODY_HS(HS, WCUR, WNXT, RS, VA, VB, SOBASE, ROWB)                                                                            \
     {                                                                                                                                        \
         float b0[NP], b1[NP];                                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < NP; ++i) CH_REQ1(b0, 0, i)                                                                     \
+        _Pragma("unroll") for (int i = 0; i < (HS ? NP : ND); ++i) CH_REQ1(b0, 0, i)                                                         \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                                               \
             _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                                                 \
@@ -175,16 +192,20 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
                 if (i == 1) CH_WREQ(WNXT.b[s], RS, VB, (SOBASE) + ((4 * (s / 9)) * 9 + s % 9) * (ROWB))                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                                           \
             }                                                                                                                                \
-            if (G::NS) {                                                                                                                     \
-                if (hs) acc[G::NSLOT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[NP - 1], acc[G::NSLOT - 1], 0, 0, 0);         \
+            if (G::NS && HS) {                                                                                                               \
+                acc[G::NSLOT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[NP - 1], acc[G::NSLOT - 1], 0, 0, 0);                 \
                 __builtin_amdgcn_sched_barrier(0);                                                                                           \
                 if (s + 1 < KS) CH_REQ1(b1, s + 1, NP - 1)                                                                                   \
                 __builtin_amdgcn_sched_barrier(0);                                                                                           \
             }                                                                                                                                \
-            if (s + 1 < KS) { _Pragma("unroll") for (int i = 0; i < NP; ++i) b0[i] = b1[i]; }                                                \
+            if (s + 1 < KS) { _Pragma("unroll") for (int i = 0; i < (HS ? NP : ND); ++i) b0[i] = b1[i]; }                                    \
         }                                                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < NP; ++i) pt[i] += 8 * CIS;                                                                     \
     }
+    // the waves without a single tile run their own copy of the pass: a wave-uniform branch per PASS -- per k-step, the taken branch cost
+    // those waves ~35 of a step's 192 cycles (in-kernel stamps: 0.83 of the MFMA rate for a wave alone against 0.93 for its partner)
+#define CH_PASS_BODY(WCUR, WNXT, RS, VA, VB, SOBASE, ROWB)                                                                                   \
+    if (G::NS == 0 || hs) CH_PASS_BODY_HS(true, WCUR, WNXT, RS, VA, VB, SOBASE, ROWB) else CH_PASS_BODY_HS(false, WCUR, WNXT, RS, VA, VB, SOBASE, ROWB)
 #pragma unroll 1
     for (int cb = 0; cb < C_IN; cb += 16) {
         CH_PASS(S, C_IN, cb);
@@ -197,6 +218,7 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
         CH_PASS_BODY(wn, wc, rn, van, vbn, sob, rowb)
     }
 #undef CH_PASS_BODY
+#undef CH_PASS_BODY_HS
 #undef CH_REQ1
 #undef CH_WREQ
 }
@@ -233,6 +255,45 @@ __device__ __forceinline__ void chain_store(const floatx4 (&acc)[ChainGeo<S, C_O
             float v = acc[k][e] + (second ? bv.b[e] : bv.a[e]);
             v = v > 0.f ? v : 0.f;
             o[e * LD] = v;
+        }
+    }
+}
+
+// accumulators of a PM-mapped layer (+ bias, ReLU) -> their 2x2 maxima, straight from the registers: the next layer's padded planes OUT
+// [C_OUT][CISO] (TO_GLOBAL false) or the image's pooled NCHW map [C_OUT][HP * HP] in global memory, and (flat) a copy [C_OUT][HP * HP] in
+// LDS for the classifier rows.  tensor.rs:1449-1461 scans the window with a strict > from -inf, so NaN never wins -- behind the ReLU
+// (v > 0 ? v : 0) no value is NaN or -0, and the maximum of four such values does not depend on the order: v_max over the quad.
+template <int S, int C_OUT, bool TO_GLOBAL>
+__device__ __forceinline__ void chain_store_pooled(const floatx4 (&acc)[ChainGeo<S, C_OUT>::NSLOT], const ChainBias &bv, float *out, int wave, int lane,
+                                                   float *flat = nullptr) {
+    using G = ChainGeo<S, C_OUT>;
+    constexpr int HP = S / 2, NPO = HP * HP, WPO = HP + 2, CISO = ch_cis(WPO), LD = TO_GLOBAL ? NPO : CISO;
+    static_assert(S % 2 == 0, "2x2 windows");
+    const int l16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < G::NSLOT; ++k) {
+        if (!G::slot_live(wave, k)) continue;
+        const bool second = k < 2 * G::ND && (k & 1);
+        float m[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[k][e] + (second ? bv.b[e] : bv.a[e]);
+            v = v > 0.f ? v : 0.f;
+            // (values >= +0, never NaN: their order is the order of their bit patterns as integers -- an integer max carries no NaN
+            // canonicalisation and takes the quad permute as its DPP operand)
+            int iv = __builtin_bit_cast(int, v);
+            iv = max(iv, __builtin_amdgcn_mov_dpp(iv, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+            iv = max(iv, __builtin_amdgcn_mov_dpp(iv, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+            m[e] = __builtin_bit_cast(float, iv);
+        }
+        const int q = G::slot_px(wave, k) * 4 + (l16 >> 2);
+        if ((l16 & 3) != 0 || q >= NPO) continue;
+        const int c0 = 16 * G::slot_ch(wave, k) + 4 * g4;
+        float *o = out + c0 * LD + (TO_GLOBAL ? q : (q / HP + 1) * WPO + q % HP + 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e * LD] = m[e];
+            if (flat) flat[(c0 + e) * NPO + q] = m[e];
         }
     }
 }
@@ -285,6 +346,7 @@ __device__ __forceinline__ void chain_conv1_weights(const float *__restrict__ w,
     }
 }
 
+template <bool PM = false>
 __device__ __forceinline__ void chain_conv1_mfma(const float *img, const ChainW1 &wa, floatx4 (&acc)[ChainGeo<28, 32>::NSLOT], int wave, int lane) {
     using G = ChainGeo<28, 32>;
     const int l16 = lane & 15, g4 = lane >> 4;
@@ -300,8 +362,8 @@ __device__ __forceinline__ void chain_conv1_mfma(const float *img, const ChainW1
 #pragma unroll
     for (int i = 0; i < G::ND + 1; ++i) {
         if (i == G::ND && !G::has_single(wave)) continue;
-        int p = (i < G::ND ? G::dtile(wave, i) : G::STILE) * 16 + l16;
-        if (p >= G::PX) p = 0;
+        int p = chain_lane_pixel<28, PM>(i < G::ND ? G::dtile(wave, i) : G::STILE, l16);
+        if (p < 0) p = 0;
         const float *px = img + (p / 28) * 30 + p % 28;
         float b[3];
 #pragma unroll
@@ -565,12 +627,14 @@ __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const fl
 }
 
 // ---- the simple CNN's front (examples/train_mnist_cnn.rs:64-100): 1 -> 32 + pool, 32 -> 64 + pool -> [64][7][7] ----
-//   T1 [32][788] @0  conv1's outputs    A [32][272] @25216  conv2's input    T [64][196] @0  conv2's outputs (over T1)    IMG [900] @33920
-//   HEAD: XM [3136] @12544 (behind T: the flattened pooled map), RED [NC][512] + 64 @25216 (over A, dead after conv2's k loop)
-constexpr int CS_A = 32 * ch_tile_ld(784), CS_IMG = CS_A + 32 * ch_cis(16), CS_LDS = CS_IMG + 900;
-constexpr int CS_XM = 64 * ch_tile_ld(196), CS_K = 64 * 49;
+// Both layers are pooled: their pixel tiles are 2x2 windows (chain_lane_pixel<S, true>) and the maxima leave the accumulators directly
+// (chain_store_pooled) -- no full-resolution tile in LDS, no pooling pass, two barriers fewer than r03's form (kept as CH_SIMPLE_TILES
+// for measurements: 26.4 -> us chain + classifier rows at batch 256).
+//   A [32][272] @0  conv2's input (conv1's pooled output)    IMG [900] @8704
+//   HEAD: XM [3136] @9604 (the flattened pooled map), RED [NC][512] + 64 @0 (over A, dead after conv2's k loop)
+constexpr int CS_IMG = 32 * ch_cis(16), CS_XM = CS_IMG + 900, CS_K = 64 * 49, CS_LDS = CS_XM + CS_K;
 [[maybe_unused]] constexpr int CS_NJ = (CS_K + CH_NT - 1) / CH_NT;
-static_assert(64 * ch_tile_ld(196) <= CS_A && CS_XM + CS_K <= CS_A && CS_A + 16 * CH_NT + 64 <= CS_LDS, "LDS map");
+static_assert(16 * CH_NT + 64 <= CS_IMG, "LDS map: the classifier's reduction fits over A");
 
 template <bool HEAD, int NC>
 __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainArgs a) {
@@ -578,7 +642,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int img = blockIdx.x;
-    float *T1 = lds, *A = lds + CS_A, *T = lds, *IMG = lds + CS_IMG;
+    float *A = lds, *IMG = lds + CS_IMG, *XM = lds + CS_XM;
     ChainBias bv;
     ChainW wc;
     ChainW1 wa;
@@ -587,18 +651,16 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     chain_conv1_weights(a.w[0], wa, wave, lane);
     chain_bias<28, 32>(a.b[0], bv, wave, lane);
     chain_load_image(a.x + (long)img * 784, IMG, t);
-    chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, lane);      // conv2's first pass: in flight under conv1 and its pool
+    chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, lane);      // conv2's first pass: in flight under conv1
     if (HEAD && a.head.tick && img == 0 && t == 0) a.head.tick[0] += 1;
+    chain_zero_halo<14, 32>(A, wave, lane);
     chain_sync();
     CH_STAMP(1);
-    {   // conv1 1 -> 32 @28 + pool
+    {   // conv1 1 -> 32 @28, pooled -> A's interior
         floatx4 acc[ChainGeo<28, 32>::NSLOT];
-        chain_conv1_mfma(IMG, wa, acc, wave, lane);
-        chain_store<28, 32, false>(acc, bv, T1, wave, lane);
-        chain_zero_halo<14, 32>(A, wave, lane);
-        chain_sync();
+        chain_conv1_mfma<true>(IMG, wa, acc, wave, lane);
         CH_STAMP(2);
-        chain_pool<28, 32, false>(T1, A, t);
+        chain_store_pooled<28, 32, false>(acc, bv, A, wave, lane);
         chain_sync();
         CH_STAMP(3);
     }
@@ -606,16 +668,14 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     chain_bias<14, 64>(a.b[1], bv, wave, lane);
     float hw_[CS_NJ][NC];
     if constexpr (HEAD) chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t);   // the classifier's weights: in flight under conv2's k loop
-    chain_mfma<14, 32, 64>(A, a.w[1], wc, acc, wave, lane);
+    chain_mfma<14, 32, 64, 0, 0, 0, true>(A, a.w[1], wc, acc, wave, lane);
     CH_STAMP(4);
-    chain_store<14, 64, false>(acc, bv, T, wave, lane);          // (T1 is dead; T does not overlap A)
-    chain_sync();
     CH_STAMP(5);
-    chain_pool<14, 64, true, HEAD>(T, a.y + (long)img * 64 * 49, t, lds + CS_XM);
+    chain_store_pooled<14, 64, true>(acc, bv, a.y + (long)img * 64 * 49, wave, lane, HEAD ? XM : nullptr);   // (XM does not overlap A)
     if constexpr (HEAD) {
         chain_sync();                                            // XM complete; every wave is past conv2's k loop: A is free
         CH_STAMP(6);
-        chain_head_rows<CS_NJ, NC>(a.head, hw_, lds + CS_XM, A, img, t);
+        chain_head_rows<CS_NJ, NC>(a.head, hw_, XM, A, img, t);
     }
 #ifdef TH_PROFILE
     chain_sync();
@@ -860,6 +920,7 @@ __device__ __forceinline__ void rt_mfma(const float *in, const float *__restrict
         }                                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < ND; ++i) pt[i] += 8 * CIS;                                                            \
     }
+    /* (a copy of the pass per value of last_live, as chain_mfma has for its single tile, was tried: spills -- 114.0 against 113.5 us) */
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * c_in * c_out * 4, 0x00020000);
     const int rowb = c_out * 4, va = ((lane >> 4) * 9 * c_out + (lane & 15)) * 4 + 64 * chA, vb = va + 64 * (chB - chA);
 #pragma unroll 1

@@ -34,7 +34,7 @@ w = ctx.upload((rng.uniform(-1, 1, (10, K)) * np.sqrt(2.0 / K)).astype(np.float3
 bias, yt = ctx.upload(rng.uniform(-.1, .1, 10).astype(np.float32)), ctx.upload(rng.integers(0, 10, n).astype(np.float32))
 y, dl, rs, cbp = ctx.empty(n * K), ctx.empty(n * 16), ctx.empty(n * 2), ctx.empty(n * 64)
 head = ChainHead(int(w), int(bias), int(yt), 10, int(dl), int(rs), int(cbp), None)
-names = ["image -> LDS, weights requested", "conv1 -> tile, zero A", "pool -> A", "conv2 k loop", "conv2 -> tile", "pool -> y, XM",
+names = ["image -> LDS, weights requested, zero A", "conv1 MFMAs", "conv1 pooled -> A", "conv2 k loop (first wave)", "-", "conv2 pooled -> y, XM (+ the other waves' k loops)",
          "logits (partials, reduce)", "softmax, dlogits", "masked dX -> XM", "channel sums", "drain"]
 acc = np.zeros(11)
 N, tot = 20, 0.0
