@@ -655,7 +655,6 @@ __global__ __launch_bounds__(512, 1) void mlp2_dw1_kernel8(Mlp2Dw8Args a) {
         else wait_vmcnt<0>();
         lds_barrier();
         const int nxt = it + NS - 1;
-        if (nxt < nt) fetch(nxt, stage == 0 ? NS - 1 : stage - 1);
         const float *as = smem + stage * STG + ao, *bs = smem + stage * STG + A_T + bo;
         float av[2], bv[2][7];
 #define M2_REQ8(SET, S)                                                       \
@@ -663,15 +662,25 @@ __global__ __launch_bounds__(512, 1) void mlp2_dw1_kernel8(Mlp2Dw8Args a) {
         av[SET] = as[(S) * 4 * 128];                                          \
         _Pragma("unroll") for (int i = 0; i < 7; ++i) bv[SET][i] = bs[(S) * 4 * TN + 16 * i]; \
     }
+        // Eight operand reads per k-step of seven MFMAs: each sits BEHIND an MFMA (its issue is then hidden by the MFMA in flight -- as a group
+        // in front of the step's MFMAs the reads cost the matrix pipe their issue time, experiments/mfma_rate.hip), and the next stage's
+        // LDS-DMA requests sit behind the first step's MFMAs.
         M2_REQ8(0, 0)
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int cs = s & 1;
-            if (s + 1 < 8) M2_REQ8(cs ^ 1, s + 1)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cs], bv[cs][i], acc[i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 7; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cs], bv[cs][i], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < 8) {
+                    if (i == 0) av[cs ^ 1] = as[(s + 1) * 4 * 128];
+                    bv[cs ^ 1][i] = bs[(s + 1) * 4 * TN + 16 * i];
+                }
+                if (s == 0 && i == 1 && nxt < nt) fetch(nxt, stage == 0 ? NS - 1 : stage - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #undef M2_REQ8
         stage = stage + 1 == NS ? 0 : stage + 1;

@@ -43,4 +43,17 @@ for batch in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384]:
     ctx.sync()
     us = ctx.elapsed_ms(e0, e1) * 1e3 / reps
     flops = 2.0 * batch * inf * hid * 2 + 2.0 * batch * hid * c * 3
+    per = []
+    for which in (1, 2, 3):                      # each launch alone (th_debug_mlp2_only)
+        hip.hip.th_debug_mlp2_only(which)
+        for _ in range(10):
+            step()
+        ctx.record(e0)
+        for _ in range(reps):
+            step()
+        ctx.record(e1)
+        ctx.sync()
+        per.append(ctx.elapsed_ms(e0, e1) * 1e3 / reps)
+    hip.hip.th_debug_mlp2_only(0)
+    print(f"    rows {per[0]:.1f} us ({2.0 * batch * inf * hid / per[0] / 1e6 / 157.3:.3f})  dw1 {per[1]:.1f} us ({2.0 * batch * inf * hid / per[1] / 1e6 / 157.3:.3f})  finish {per[2]:.1f} us")
     print(f"batch {batch}: {us:.1f} us/step  {batch / us:.2f} M samples/s  {60000 / batch * us and 1e6 / (60000 / batch * us):.0f} epochs/s  {flops / us / 1e6:.1f} TF ({flops / us / 1e6 / 157.3:.3f} of peak)  loss {ctx.download(out['loss'], 1)[0]:.4f}")
