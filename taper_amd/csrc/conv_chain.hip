@@ -1029,9 +1029,10 @@ __device__ __forceinline__ void rt_stage_nd(const RtChainArgs &a, const RtStage 
             if (st.c_in == 1) rt_conv1<S, ND>(in, st.w, st.c_out, chA, chB, ptile, acc, lane, st.s);
             else rt_mfma<S, ND>(in, st.w, st.c_in, st.c_out, chA, chB, ptile, acc, lane, st.s, nullptr);
         }
-        // (Requesting the NEXT stage's first weight pass here, under this stage's epilogue -- as the compiled instances do -- was built and
-        // measured in r04: the 36 registers of that pass put the kernel past its 256 and the spills cost more than the round trips: reference
-        // front 116 -> 130 us.  Every stage opens with its own request.)
+        // (Requesting the NEXT contraction's first weight pass ahead -- as the compiled instances do -- was built twice in r04: under this
+        // stage's epilogue (36 more registers: past 256, reference front 116 -> 130 us), and inside the k loop's last pass with the set
+        // carried from contraction to contraction through the stage loop (79 - 90 spilled registers: 113.5 -> 204 us).  A stage list
+        // walked at run time cannot keep a 36-register set live across its switch; every contraction opens with its own request.)
         if (st.rounds == 1 && !to_map) {                         // every wave is done reading the input: the output may overlay it
             chain_sync();
             if (planes) rt_zero_halo<S>(out, st.c_out, wave, lane, st.s);
