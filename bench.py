@@ -656,7 +656,7 @@ def mlp2_workload(ctx, batch=16384, reps=150):
     P = hid * inf + hid + c * hid + c
     rt = 64 if batch >= 12288 else (32 if batch > 4096 else 16)
     n_blk = 2 * -(-batch // 32) if rt == 16 else -(-batch // rt)
-    kz = max(1, min(256 // 7, n_blk * rt // 32))
+    kz = max(1, min(256 // 7, max(1, n_blk * rt // 64)))   # two 32-row chunks per slice at least (mlp2.hip)
     gemm = 2.0 * batch * inf * hid
     specs = [("mlp2_rows_kernel<%d, %d, 4>" % (rt, 8 if rt == 16 else 4), "rows: X W1^T + b1, ReLU, classifier, masked dZ1", 1, "mfma", gemm + 3 * 2.0 * batch * hid * c,
               4.0 * (batch * inf + hid * inf + batch * hid)),
