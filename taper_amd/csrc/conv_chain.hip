@@ -628,8 +628,9 @@ __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const fl
 
 // ---- the simple CNN's front (examples/train_mnist_cnn.rs:64-100): 1 -> 32 + pool, 32 -> 64 + pool -> [64][7][7] ----
 // Both layers are pooled: their pixel tiles are 2x2 windows (chain_lane_pixel<S, true>) and the maxima leave the accumulators directly
-// (chain_store_pooled) -- no full-resolution tile in LDS, no pooling pass, two barriers fewer than r03's form (kept as CH_SIMPLE_TILES
-// for measurements: 26.4 -> us chain + classifier rows at batch 256).
+// (chain_store_pooled) -- no full-resolution tile in LDS, no pooling pass, two barriers fewer and 53 KB of LDS instead of 140 than
+// r03's tile-and-pool form; time-neutral at batch 256 (workgroup 24.5 against 24.6 us: the ~300 VALU instructions per wave it adds
+// cost what the tile pass did).
 //   A [32][272] @0  conv2's input (conv1's pooled output)    IMG [900] @8704
 //   HEAD: XM [3136] @9604 (the flattened pooled map), RED [NC][512] + 64 @0 (over A, dead after conv2's k loop)
 constexpr int CS_IMG = 32 * ch_cis(16), CS_XM = CS_IMG + 900, CS_K = 64 * 49, CS_LDS = CS_XM + CS_K;
