@@ -369,11 +369,10 @@ Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b
     return loss;
 }
 
-// TAPER_MLP2_MIN_BATCH: from this batch on a Linear + ReLU + Linear classifier steps through th_mlp2_xent (default 576: its three
-// dependent launches cost 32 - 33 us whatever they hold up to ~1 500 rows; the launch-per-layer forms take 30.7 us at 512 rows and 36.8
-// at 608 -- bench.py --batch B, both settings)
+// TAPER_MLP2_MIN_BATCH: from this batch on a Linear + ReLU + Linear classifier steps through th_mlp2_xent (default 480: the crossover
+// measured with bench.py --batch B, both settings -- launch-per-layer forms 24.9 us at 448 rows, 30.8 at 512; th_mlp2_xent 25.5 / 28.3)
 static size_t mlp2_min_batch() {
-    static const size_t v = [] { const char *e = std::getenv("TAPER_MLP2_MIN_BATCH"); return e ? (size_t)std::max(32, atoi(e)) : (size_t)576; }();
+    static const size_t v = [] { const char *e = std::getenv("TAPER_MLP2_MIN_BATCH"); return e ? (size_t)std::max(32, atoi(e)) : (size_t)480; }();
     return v;
 }
 

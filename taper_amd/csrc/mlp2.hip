@@ -94,7 +94,12 @@ struct Mlp2RowsArgs {
     float *part;         // [gridDim.x][part_stride]: dW2 [c][hid], db1 [hid], db2 [16], nll, hits
     int part_stride;
     int32_t *tick;       // nullable
+    int ksplit;          // 16-row form only: workgroups per row block, each contracting a share of the k chunks (1: none)
+    float *kpart;        // [gridDim.x][2048]: a workgroup's accumulators, in register order
 };
+
+// arrival counters of the row blocks whose k range is split over several workgroups (zero between launches: the last arrival resets its own)
+__device__ unsigned g_m2_karrive[512];
 
 // ---------------------------------------------------------------------------------------------------------------- launch 1
 // LDS images of the k chunk: [rows][32 k], 128-byte rows, the eight 16-byte k quads of row r stored at quad ^ swz(r) (gemm.hip's
@@ -123,7 +128,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
     constexpr int NTT = 8 / NW;                 // 16-column tiles per wave in the dH stage
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lk = lane >> 5, l16 = lane & 15, g4 = lane >> 4;
     const int cq = wave & 3, grp = wave >> 2;   // column quarter; wave group (NW == 8)
-    const int r0 = blockIdx.x * RT, B = a.batch, in_f = a.in_f, hid = a.hid, C = a.c;
+    // Few row blocks (batch <= 2 048 on the 16-row tiles: <= 128 of them on 256 CUs): `ksplit` workgroups share a block's k chunks, each
+    // leaves its accumulators in memory, and the LAST to arrive (an arrival counter per block) adds them in split order -- a fixed order,
+    // whoever is last -- and runs the classifier epilogue; the others are done.  The k loop of a block is the longest dependent chain of
+    // the step at these sizes (25 chunks: 9.6 us of 17 at batch 1 024); split four ways it is 7 chunks.
+    const int ksplit = R16 ? a.ksplit : 1, blk = R16 ? (int)blockIdx.x / ksplit : (int)blockIdx.x, ks = R16 ? (int)blockIdx.x % ksplit : 0;
+    const int r0 = blk * RT, B = a.batch, in_f = a.in_f, hid = a.hid, C = a.c;
     M2_STAMP(0, blockIdx.x == 0);
     if (a.tick && blockIdx.x == 0 && t == 0) a.tick[0] += 1;                  // optim.rs:84 (the launch that reads t comes later)
     const long cur = (a.src.idx && a.src.cursor) ? a.src.cursor[0] : 0;
@@ -170,11 +180,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
         for (int tt = 0; tt < NTT; ++tt) w2b[tt][e] = a.w2[(long)cls * hid + min(16 * NTT * wave + 16 * tt + l16, hid - 1)];
     }
 
-    const int nfull = in_f / M2_BK, ktail = in_f - nfull * M2_BK;
+    // this workgroup's chunks: [c_lo, c_hi) of the in_f / 32 full chunks (+ the ragged last one for the last split)
+    const int nfull_all = in_f / M2_BK, ktail_all = in_f - nfull_all * M2_BK, n_all = nfull_all + (ktail_all ? 1 : 0);
+    const int c_lo = (int)((long)n_all * ks / ksplit), c_hi_all = (int)((long)n_all * (ks + 1) / ksplit);
+    const int ktail = (ktail_all && c_hi_all == n_all) ? ktail_all : 0, nfull = c_hi_all - c_lo - (ktail ? 1 : 0), kbase = c_lo * M2_BK;
     // the ragged last chunk goes through registers (zero fill beyond in_f), requested first: it is the oldest load in flight
     float4 ta[NA], tb[NB];
     if (ktail) {
-        const int k0 = nfull * M2_BK;
+        const int k0 = nfull_all * M2_BK;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int row = 8 * (NW * j + wave) + (lane >> 3), mq = (lane & 7) ^ m2_swz(row);
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto fetch = [&](int it, int stage) {
-        const int k0 = it * M2_BK;
+        const int k0 = kbase + it * M2_BK;
         const unsigned st = lds0 + (unsigned)(stage * STG) * 4u;
 #pragma unroll
         for (int j = 0; j < NA; ++j)
@@ -311,6 +324,44 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
     lds_barrier();
 
     M2_STAMP(2, blockIdx.x == 0);
+    if constexpr (R16) {
+        if (ksplit > 1) {
+            __shared__ int last_arrival;
+            // The partial sums travel through MEMORY, not through this XCD's L2 (the splits of a block sit on different XCDs): system-coherent
+            // stores, waited for, then one arrival; the last arrival reads them with system-coherent loads.  (A device-scope __threadfence()
+            // instead costs a write-back of the whole L2 per workgroup on this part: measured 57 us for this launch against 16 unsplit.)
+            float *mine = a.kpart + (long)blockIdx.x * 2048 + (wave * 128 + lane) * 4;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine + tt * 256), "v"(acc16[tt]) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores have been acknowledged by memory ...
+            __syncthreads();                                   // ... every thread's, before the one arrival below
+            if (t == 0) last_arrival = __hip_atomic_fetch_add(&g_m2_karrive[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ksplit - 1);
+            __syncthreads();
+            if (!last_arrival) return;                         // (the whole workgroup: uniform)
+            const float *all = a.kpart + (long)blk * ksplit * 2048 + (wave * 128 + lane) * 4;
+            floatx4 pv[8][2];                                  // all requests out before the first value is used; added in SPLIT ORDER
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    if (q < ksplit) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(pv[q][tt]) : "v"(all + q * 2048 + tt * 256) : "memory");
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    if (q < ksplit) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[q][tt]) : : "memory");
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                floatx4 v = pv[0][tt];
+#pragma unroll
+                for (int q = 1; q < 8; ++q)
+                    if (q < ksplit) v += pv[q][tt];
+                acc16[tt] = v;
+            }
+            if (t == 0) g_m2_karrive[blk] = 0;                 // for the next launch (which starts after this one has ended)
+        }
+    }
     // ---- epilogue: the staging buffers are dead; H, dlogits and two scalars per wave live in their place ----
     float *Hs = smem;                           // [RT][M2_LDH]
     float *D3S = Hs + RT * M2_LDH;              // [RT][20]: dlogits [row][class], zero for classes >= C and rows >= batch
@@ -378,7 +429,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
     }
     lds_barrier();
     M2_STAMP(3, blockIdx.x == 0);
-    float *part = a.part + (long)blockIdx.x * a.part_stride;
+    float *part = a.part + (long)blk * a.part_stride;
     const int o_db1 = C * hid, o_db2 = o_db1 + hid, o_nll = o_db2 + 16;
     // wave w owns 16 NTT hidden columns of ALL the tile's rows: dZ1 = (dlogits W2) * [H > 0] (ops.rs:254-265, 358-369), its
     // column sums (db1, tensor.rs:686-691) and the tile's share of dW2 = dlogits^T H (ops.rs:266-294)
@@ -892,10 +943,17 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
         kslice = ceil_div(ceil_div(rows_pad, kz), M2_BK) * M2_BK;
         kz = ceil_div(rows_pad, kslice);
     }
+    // launch 1 on the 16-row tiles with few row blocks: as many workgroups per block as fill the CUs (up to 8) share its k chunks
+    // (mlp2_rows_kernel): 4 at batch 1 024, 2 at 2 048, none from 4 096 on.  Measured through the C ABI: 31.1 -> 27.3 us per step at 1 024
+    // rows (launch 1: 15.6 -> 11.5 us), 35.5 -> 33.1 at 2 048.  TAPER_MLP2_KSPLIT=1 turns it off (measurement knob).
+    static const int ksplit_forced = [] { const char *e = getenv("TAPER_MLP2_KSPLIT"); return e ? atoi(e) : 0; }();
+    int ksplit = RT != 16 ? 1 : std::max(1, std::min(8, kNumCU / n_blk));
+    if (RT == 16 && ksplit_forced >= 1 && ksplit_forced <= 8 && n_blk <= 512) ksplit = ksplit_forced;   // (the kernel sums up to 8 splits)
     const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_partial = (size_t)kz * hidden * in_features;
+    const size_t n_kpart = ksplit > 1 ? (size_t)n_blk * ksplit * 2048 : 0;
     void *ws = nullptr;
-    if (th_malloc(ctx, (n_dz + n_part + n_partial) * sizeof(float), &ws)) return 1;
-    float *dz1 = (float *)ws, *part = dz1 + n_dz, *partial = part + n_part;
+    if (th_malloc(ctx, (n_dz + n_part + n_partial + n_kpart) * sizeof(float), &ws)) return 1;
+    float *dz1 = (float *)ws, *part = dz1 + n_dz, *partial = part + n_part, *kpart = partial + n_partial;
 
     RowSource rs{src->d_rows, src->d_labels, src->d_indices, src->d_indices ? src->d_cursor : nullptr, src->n_indices,
                  (unsigned)((size_t)src->n_rows * in_features * 4)};
@@ -904,6 +962,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     r.w1 = d_w1; r.b1 = d_b1; r.w2 = d_w2; r.b2 = d_b2;
     r.batch = batch; r.in_f = in_features; r.hid = hidden; r.c = classes;
     r.dz1 = dz1; r.part = part; r.part_stride = stride; r.tick = d_tick;
+    r.ksplit = ksplit; r.kpart = kpart;
     // ring depth of launch 1: four stages (six for the 32-row tiles, one workgroup per CU, measured no faster: a lone wave per SIMD is bound by
     // its own issue order, not by the requests in flight)
 #define M2_ROWS_LAUNCH(RT_, NS_, NW_)                                                                                              \
@@ -911,7 +970,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
         const size_t lds = (size_t)NS_ * (RT_ + 128) * M2_BK * sizeof(float);                                                      \
         static bool attr = false;                                                                                                  \
         if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)mlp2_rows_kernel<RT_, NS_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
-        hipLaunchKernelGGL((mlp2_rows_kernel<RT_, NS_, NW_>), dim3(n_blk), dim3(64 * NW_), lds, ctx->stream, r);                    \
+        hipLaunchKernelGGL((mlp2_rows_kernel<RT_, NS_, NW_>), dim3(n_blk * (RT_ == 16 ? ksplit : 1)), dim3(64 * NW_), lds, ctx->stream, r);                    \
     } while (0)
     // waves per workgroup of launch 1: four.  TAPER_MLP2_NW=8 (two waves per SIMD on the same ring; on 32-row tiles the two wave groups split
     // every chunk's k rounds) measured the same to 2 %: 39.7 / 23.7 / 22.7 us against 39.2-40.5 / 23.5 / 22.5 us at 16 384 / 4 096 / 1 024 rows --

@@ -237,15 +237,17 @@ def test_trainer_large_batch_graph_equals_eager_launches():
 
 def test_mlp2_measurement_forms_in_a_subprocess():
     """the knobs kept for measurements (launch 2 as four-wave 128 x 128 tiles, launch 1 as eight waves on 64-row tiles at every batch) give
-    the same results: the dense-row and index-vector cases again under TAPER_MLP2_DW=22 TAPER_MLP2_RT=64 TAPER_MLP2_NW=8, and the 32-row
-    eight-wave form (k rounds split over two wave groups) under TAPER_MLP2_RT=32 (the choice is read once per process)"""
+    the same results: the dense-row and index-vector cases again under TAPER_MLP2_DW=22 TAPER_MLP2_RT=64 TAPER_MLP2_NW=8, the 32-row
+    eight-wave form (k rounds split over two wave groups) under TAPER_MLP2_RT=32, and the 16-row tiles at every batch with a row block's
+    k chunks on one workgroup (TAPER_MLP2_KSPLIT=1) and on three (the default splits by the CU count) -- the choice is read once per process"""
     import os
     import subprocess
     import sys
     if os.environ.get("TAPER_MLP2_DW"):
         pytest.skip("already inside the knob run")
     env = dict(os.environ, TAPER_MLP2_DW="22", TAPER_MLP2_RT="64", TAPER_MLP2_NW="8")
-    for extra in ({}, {"TAPER_MLP2_RT": "32", "TAPER_MLP2_DW": "8"}):
+    for extra in ({}, {"TAPER_MLP2_RT": "32", "TAPER_MLP2_DW": "8"}, {"TAPER_MLP2_RT": "16", "TAPER_MLP2_DW": "8", "TAPER_MLP2_NW": "4", "TAPER_MLP2_KSPLIT": "1"},
+                  {"TAPER_MLP2_RT": "16", "TAPER_MLP2_DW": "8", "TAPER_MLP2_NW": "4", "TAPER_MLP2_KSPLIT": "3"}):
         r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-m", "gpu", "-k", "dense_rows or index_vector", "-p", "no:cacheprovider"],
                            env=dict(env, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
