@@ -538,6 +538,25 @@ __device__ __forceinline__ void chain_head_weights(const ChainHeadArgs &h, float
     }
 }
 
+// the same as 16-byte requests: thread t owns elements k = 4 t + 2048 j + v (v = 0..3) -- wv[4 j + v][c]; a quarter of the requests (a
+// workgroup's 560 dword requests kept the address unit busy for ~1.2 us in front of conv2's k loop).  Plain global loads: this
+// compiler's __builtin_amdgcn_raw_buffer_load_b128 loads ONE dword and splats it (checked in the listing), and an inline-assembly load
+// would leave 80 registers written behind the register allocator's back for the length of the k loop.
+template <int NJ4, int NC, int KC>
+__device__ __forceinline__ void chain_head_weights4(const ChainHeadArgs &h, float (&wv)[4 * NJ4][NC], int t) {
+    static_assert(KC % 4 == 0, "whole quads");
+#pragma unroll
+    for (int j = 0; j < NJ4; ++j) {
+        const bool in = 4 * CH_NT * (j + 1) <= KC || 4 * t + 4 * CH_NT * j < KC;
+        const float *row = h.w + 4 * t + 4 * CH_NT * j;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float4 q = (in && c < h.classes) ? *reinterpret_cast<const float4 *>(row + (long)c * KC) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[4 * j][c] = q.x; wv[4 * j + 1][c] = q.y; wv[4 * j + 2][c] = q.z; wv[4 * j + 3][c] = q.w;
+        }
+    }
+}
+
 template <int NJ, int NC>
 __device__ __forceinline__ void chain_head_weights_rt(const ChainHeadArgs &h, float (&wv)[NJ][NC], int t) {   // the same with a run-time k
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)h.w, 0, h.classes * h.k * 4, 0x00020000);
@@ -553,8 +572,11 @@ __device__ __forceinline__ void chain_head_weights_rt(const ChainHeadArgs &h, fl
 }
 
 // xm: LDS [k] (the map; overwritten by the masked dX), red: LDS [NC][CH_NT] + 64 floats.  Ends without a barrier (global stores only).
-template <int NJ, int NC>
+// V = 1: thread t owns elements t + 512 j (chain_head_weights); V = 4: elements 4 t + 2048 j' + v, wv[4 j' + v] (chain_head_weights4; NJ = 4 NJ4)
+template <int NJ, int NC, int V = 1>
 __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const float (&wv)[NJ][NC], float *xm, float *red, int img, int t) {
+    static_assert(V == 1 || (V == 4 && NJ % 4 == 0), "dword or quad ownership");
+    auto k_of = [&](int j) { return V == 1 ? t + CH_NT * j : 4 * t + 4 * CH_NT * (j >> 2) + (j & 3); };
     static_assert(NC <= 16 && NC * 32 <= CH_NT, "one 32-lane half-wave per class in the reduction");
     const int lane = t & 63, r16 = lane & 15, g4 = lane >> 4;
     float *sc = red + NC * CH_NT;            // [0..15] logits, [16..31] dlogits
@@ -563,8 +585,15 @@ __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const fl
     for (int c = 0; c < NC; ++c) part[c] = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int k = t + CH_NT * j;
-        xv[j] = k < h.k ? xm[k] : 0.f;
+        const int k = k_of(j);
+        if (V == 4) {
+            if ((j & 3) == 0) {
+                const float4 q = k < h.k ? *reinterpret_cast<const float4 *>(xm + k) : make_float4(0.f, 0.f, 0.f, 0.f);   // (h.k % 4 == 0)
+                xv[j] = q.x; xv[j + 1] = q.y; xv[j + 2] = q.z; xv[j + 3] = q.w;
+            }
+        } else {
+            xv[j] = k < h.k ? xm[k] : 0.f;
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) part[c] = fmaf(xv[j], wv[j][c], part[c]);
     }
@@ -607,7 +636,7 @@ __device__ __forceinline__ void chain_head_rows(const ChainHeadArgs &h, const fl
     for (int c = 0; c < NC; ++c) d16[c] = sc[16 + c];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int k = t + CH_NT * j;
+        const int k = k_of(j);
         float dx = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) dx = fmaf(d16[c], wv[j][c], dx);      // ops.rs:254-265, class order
@@ -667,8 +696,12 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     }
     floatx4 acc[ChainGeo<14, 64>::NSLOT];
     chain_bias<14, 64>(a.b[1], bv, wave, lane);
-    float hw_[CS_NJ][NC];
-    if constexpr (HEAD) chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t);   // the classifier's weights: in flight under conv2's k loop
+    constexpr int HV = NC <= 10 ? 4 : 1, HNJ = HV == 4 ? 4 * ((CS_K + 4 * CH_NT - 1) / (4 * CH_NT)) : CS_NJ;   // (16 classes: 128 registers as quads)
+    float hw_[HNJ][NC];
+    if constexpr (HEAD) {                                        // the classifier's weights: in flight under conv2's k loop
+        if constexpr (HV == 4) chain_head_weights4<HNJ / 4, NC, CS_K>(a.head, hw_, t);
+        else chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t);
+    }
     chain_mfma<14, 32, 64, 0, 0, 0, true>(A, a.w[1], wc, acc, wave, lane);
     CH_STAMP(4);
     CH_STAMP(5);
@@ -676,7 +709,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     if constexpr (HEAD) {
         chain_sync();                                            // XM complete; every wave is past conv2's k loop: A is free
         CH_STAMP(6);
-        chain_head_rows<CS_NJ, NC>(a.head, hw_, XM, A, img, t);
+        chain_head_rows<HNJ, NC, HV>(a.head, hw_, XM, A, img, t);
     }
 #ifdef TH_PROFILE
     chain_sync();
