@@ -149,6 +149,17 @@ def test_p2p_eight_ranks_of_128_rows_is_baseline_configs_3(tmp_path, fuse):
     _check_against_oracle(ranks, 8, 4, 1024)
 
 
+def test_p2p_two_ranks_of_512_rows_take_the_three_launch_step(tmp_path):
+    """shards large enough for th_mlp2_xent (>= 480 rows): its finish launch writes plain gradients into the optimizer's arena (no Adam in
+    its epilogue: the all-reduce comes first), the one-shot all-reduce + Adam finishes the step.  Replicas bit-identical; weights and losses
+    equal to one process on the 1024-row batches (itself on th_mlp2_xent) and to the oracle's loop"""
+    ranks = _run_ranks(tmp_path, 2, "p2p", "graph", steps=4, global_batch=1024, same_device=True)
+    assert all(len(r["losses"]) == 8 for r in ranks)
+    assert all(int(r["mlp2_calls"]) > 0 for r in ranks), "the shards did not take th_mlp2_xent"
+    _check(ranks, 2, 4, 1024)
+    _check_against_oracle(ranks, 2, 4, 1024)
+
+
 def test_p2p_two_ranks_against_the_oracle(tmp_path):
     ranks = _run_ranks(tmp_path, 2, "p2p", "graph", steps=6, global_batch=256, same_device=True)
     _check_against_oracle(ranks, 2, 6, 256)
