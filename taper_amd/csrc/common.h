@@ -102,6 +102,7 @@ struct th_ctx {
     // staging plans of the image-resident conv kernel, built on device once per geometry (conv_mfma.hip); plain hipMalloc, freed with the ctx
     std::map<std::array<int, 8>, void *> conv_plans;
     int32_t *err_word = nullptr;                      // this device's error block (host-visible; shared by the contexts of a device)
+    unsigned *m2_arrive = nullptr;                    // mlp2.hip: arrival counters of k-split row blocks (zero between launches); plain hipMalloc, freed with the ctx
 };
 
 struct th_graph {

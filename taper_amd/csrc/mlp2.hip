@@ -96,10 +96,8 @@ struct Mlp2RowsArgs {
     int32_t *tick;       // nullable
     int ksplit;          // 16-row form only: workgroups per row block, each contracting a share of the k chunks (1: none)
     float *kpart;        // [gridDim.x][2048]: a workgroup's accumulators, in register order
+    unsigned *karrive;   // [row blocks]: arrival counters (the context's: zero between launches -- the last arrival resets its own)
 };
-
-// arrival counters of the row blocks whose k range is split over several workgroups (zero between launches: the last arrival resets its own)
-__device__ unsigned g_m2_karrive[512];
 
 // ---------------------------------------------------------------------------------------------------------------- launch 1
 // LDS images of the k chunk: [rows][32 k], 128-byte rows, the eight 16-byte k quads of row r stored at quad ^ swz(r) (gemm.hip's
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine + tt * 256), "v"(acc16[tt]) : "memory");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores have been acknowledged by memory ...
             __syncthreads();                                   // ... every thread's, before the one arrival below
-            if (t == 0) last_arrival = __hip_atomic_fetch_add(&g_m2_karrive[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ksplit - 1);
+            if (t == 0) last_arrival = __hip_atomic_fetch_add(&a.karrive[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ksplit - 1);
             __syncthreads();
             if (!last_arrival) return;                         // (the whole workgroup: uniform)
             const float *all = a.kpart + (long)blk * ksplit * 2048 + (wave * 128 + lane) * 4;
@@ -359,7 +357,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_r
                     if (q < ksplit) v += pv[q][tt];
                 acc16[tt] = v;
             }
-            if (t == 0) g_m2_karrive[blk] = 0;                 // for the next launch (which starts after this one has ended)
+            if (t == 0) __hip_atomic_store(&a.karrive[blk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch (it starts after this one has ended)
         }
     }
     // ---- epilogue: the staging buffers are dead; H, dlogits and two scalars per wave live in their place ----
@@ -963,6 +961,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     r.batch = batch; r.in_f = in_features; r.hid = hidden; r.c = classes;
     r.dz1 = dz1; r.part = part; r.part_stride = stride; r.tick = d_tick;
     r.ksplit = ksplit; r.kpart = kpart;
+    r.karrive = ctx->m2_arrive;
     // ring depth of launch 1: four stages (six for the 32-row tiles, one workgroup per CU, measured no faster: a lone wave per SIMD is bound by
     // its own issue order, not by the requests in flight)
 #define M2_ROWS_LAUNCH(RT_, NS_, NW_)                                                                                              \

@@ -99,6 +99,9 @@ int th_ctx_create(int device_id, th_ctx **out) {
     c->device = device_id;
     TH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (err_block_for(device_id, &c->err_word)) return 1;
+    // arrival counters of th_mlp2_xent's k-split row blocks (2 KB, zero between launches): here, so that no launch has to allocate inside a capture
+    TH_HIP(hipMalloc((void **)&c->m2_arrive, 512 * sizeof(unsigned)));
+    TH_HIP(hipMemset(c->m2_arrive, 0, 512 * sizeof(unsigned)));
     *out = c;
     return 0;
 }
@@ -109,6 +112,7 @@ int th_ctx_destroy(th_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->block_size) (void)hipFree(kv.first);
     for (auto &kv : ctx->conv_plans) (void)hipFree(kv.second);
+    if (ctx->m2_arrive) (void)hipFree(ctx->m2_arrive);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
