@@ -27,10 +27,13 @@ __host__ __device__ constexpr int ch_tile_ld(int px) { return px + ((4 - px % 8)
 __device__ long long g_chain_prof[32];    // wall clock (100 MHz) at phase boundaries of workgroup 100, then clock64 around conv2's k loop
 #define CH_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 100) g_chain_prof[i] = wall_clock64(); } while (0)
 #define CH_CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 100) g_chain_prof[i] = clock64(); } while (0)
+__device__ long long g_chain_span[2 * 256];   // every workgroup's first and last wall clock of the layer kernel (tools/prof_conv_layer.py: how a launch's workgroups are spread in time)
+#define CH_SPAN(k) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_chain_span[2 * blockIdx.x + (k)] = wall_clock64(); } while (0)
 // per-pass stamps of the 14x14 layers' k loops (conv3: slots 13-16, conv4: 22-29)
 #define CH_PASS(S, C_IN, cb) do { if ((S) == 14) { __builtin_amdgcn_sched_barrier(0); CH_STAMP(((C_IN) == 32 ? 13 : 22) + (cb) / 8); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define CH_PASS(S, C_IN, cb) do { } while (0)
+#define CH_SPAN(k) do { } while (0)
 #define CH_STAMP(i) do { } while (0)
 #define CH_CLK(i) do { } while (0)
 #endif
@@ -783,14 +786,18 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_layer_chain_kernel(LayerChainAr
     ChainBias bv;
     chain_bias<S, C_OUT>(a.b, bv, wave, lane);
     if (POST == 0) chain_zero_halo<S, C_IN>(A, wave, lane);             // (the map goes to memory: nothing ever overwrites the halo)
+    CH_SPAN(0);
     for (int img = blockIdx.x; img < a.n; img += gridDim.x) {
         ChainW wc;
+        CH_STAMP(0);
         chain_weights<S, C_IN, C_OUT>(a.w, 0, wc, wave, lane);          // the first pass: in flight under the image load
         if (POST != 0) chain_zero_halo<S, C_IN>(A, wave, lane);         // (the output tile overlaid the planes)
         layer_load_planes<S, C_IN>(a.x + (long)img * C_IN * S * S, A, t);
         chain_sync();
+        CH_STAMP(1);
         floatx4 acc[G::NSLOT];
         chain_mfma<S, C_IN, C_OUT>(A, a.w, wc, acc, wave, lane);
+        CH_STAMP(2);
         if (POST == 0) {
             // the NCHW map straight from the accumulators
             float *ymap = a.y + (long)img * C_OUT * G::PX;
@@ -808,9 +815,13 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_layer_chain_kernel(LayerChainAr
                 }
             }
             chain_sync();                                               // the next image's planes overwrite A
+            CH_STAMP(3);
+            CH_STAMP(4);
+            CH_SPAN(1);
             continue;
         }
         chain_sync();                                                   // every wave is done reading A
+        CH_STAMP(3);
         chain_store<S, C_OUT, false>(acc, bv, T, wave, lane);
         chain_sync();
         if constexpr (POST == 1 && S % 2 == 0) {
@@ -837,7 +848,9 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_layer_chain_kernel(LayerChainAr
             }
         }
         chain_sync();
+        CH_STAMP(4);
     }
+    CH_SPAN(1);
 #endif
 }
 
@@ -1451,6 +1464,11 @@ int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *s
 int th_debug_chain_prof(th_ctx *ctx, long long *h_out32) {
     TH_HIP(hipStreamSynchronize(ctx->stream));
     TH_HIP(hipMemcpyFromSymbol(h_out32, HIP_SYMBOL(th::g_chain_prof), 32 * sizeof(long long)));
+    return 0;
+}
+int th_debug_chain_span(th_ctx *ctx, long long *h_out512) {
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpyFromSymbol(h_out512, HIP_SYMBOL(th::g_chain_span), 512 * sizeof(long long)));
     return 0;
 }
 #endif
