@@ -110,7 +110,7 @@ struct Mlp2RowsArgs {
 // chunk's four k rounds between them, two accumulators that are added, group 0 + group 1, when H goes to LDS.  Built to test whether one
 // wave per SIMD was what held the k loop back; it was not (see the launcher), the form stays as a measurement knob.
 template <int RT, int NS, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && RT == 32) ? 2 : 1) void mlp2_rows_kernel(Mlp2RowsArgs a) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <= 3))) ? 2 : 1) void mlp2_rows_kernel(Mlp2RowsArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(NW == 4 || NW == 8, "four or eight waves");
@@ -975,10 +975,15 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     // every chunk's k rounds) measured the same to 2 %: 39.7 / 23.7 / 22.7 us against 39.2-40.5 / 23.5 / 22.5 us at 16 384 / 4 096 / 1 024 rows --
     // the k loop already runs at the rate the matrix pipes sustain at the clocks the part holds under this load
     static const int nw = [] { const char *e = getenv("TAPER_MLP2_NW"); return e && atoi(e) == 8 ? 8 : 4; }();
+    // 64-row tiles: a THREE-stage ring (72 KB) so that two workgroups share a CU once there are more workgroups than CUs -- one's first-chunk
+    // latency and classifier epilogue (8.4 us of a workgroup's 38) run under the other's k loop: launch 1 at 32 768 rows 73.6 -> 60.8 us (0.69 of
+    // the matrix peak), at 60 000 rows 142.7 -> 116.4 us; unchanged up to 16 384 rows (<= 256 workgroups).  TAPER_MLP2_NS64=4: r04's first form.
+    static const int ns64 = [] { const char *e = getenv("TAPER_MLP2_NS64"); return e ? atoi(e) : 3; }();
     const int only = t_mlp2_only;
     if (only == 0 || only == 1) {
         if (RT == 16) M2_ROWS_LAUNCH(16, 8, 4);          // (an eight-stage ring: a chunk is 0.25 us of MFMA work, a request ~2 us away)
         else if (RT == 64 && nw == 8) M2_ROWS_LAUNCH(64, 4, 8);
+        else if (RT == 64 && ns64 == 3) M2_ROWS_LAUNCH(64, 3, 4);
         else if (RT == 64) M2_ROWS_LAUNCH(64, 4, 4);
         else if (nw == 8) M2_ROWS_LAUNCH(32, 4, 8);
         else M2_ROWS_LAUNCH(32, 4, 4);
