@@ -504,10 +504,11 @@ int th_avgpool2d_global_fwd_counts(th_ctx *ctx, const float *d_x, float *d_y, fl
 int th_bias_grad_counts_adam(th_ctx *ctx, const float *d_gout_pooled, const float *d_cnt, float *d_gb, int n, int c, int hw,
                              const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra);
 /* full_backward extension (not in the reference: Q2 cuts these gradients) */
+/* accumulate != 0: gx / gw += (a gradient slot that is already Some, ops.rs:124-151); 0: overwrite (the slot was None: no zero fill) */
 int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx,
-                         int n, int c_in, int h, int w, int c_out, int pad, int weight_layout); /* gx += */
+                         int n, int c_in, int h, int w, int c_out, int pad, int weight_layout, int accumulate);
 int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, float *d_gw,
-                          int n, int c_in, int h, int w, int c_out, int pad, int weight_layout); /* gw += */
+                          int n, int c_in, int h, int w, int c_out, int pad, int weight_layout, int accumulate);
 
 /* max-pool: tensor.rs:1391-1521.  s_h == 0 -> stride = kernel (1403).
  * d_argmax: int64 absolute flat input index per output (1449-1461). */
@@ -517,6 +518,14 @@ int th_maxpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int64_t *d_argma
 int th_maxpool2d_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, float *d_gin,
                      int n, int c, int h, int w, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w,
                      int zero_first);
+/* The same scatter (zero_first = 1) for a pool whose input is the output of a ReLU (a Conv2dReLU row, nn.rs:433-490), with that ReLU's
+ * backward (ops.rs:358-369: gradient kept where the output is > 0) folded in: d_gin = relu_bwd(max_pool2d_bwd(d_gout)), bit for bit,
+ * without a pass over the full-resolution map -- the pixel a window's maximum came from has the POOLED value as its output.
+ * 2x2 windows, stride 2, no padding, even h and w only (_supported).  d_y_pooled: the pool's output; d_y_full: its input (read for
+ * pixel (0,0) of planes with a default-index window only, tensor.rs:1432).  full_backward extension. */
+int th_maxpool2d_relu_bwd_supported(int n, int c, int h, int w, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w);
+int th_maxpool2d_relu_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, const float *d_y_pooled,
+                          const float *d_y_full, float *d_gin, int n, int c, int h, int w);
 /* avg-pool: tensor.rs:1524-1660 (divisor k_h*k_w incl. padding, Q6) */
 int th_avgpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int n, int c, int h, int w,
                      int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w);

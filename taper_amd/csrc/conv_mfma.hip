@@ -1119,29 +1119,30 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a
 // gw (+)= tmp[k][co] through the weight layout map (0: [k][c_out], 1: [co][9 c_in]); tmp is the ordered
 // sum of the G partial slabs (th_colsum over the [G, kt*co_ld] matrix: deterministic, no atomics)
 __global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float *__restrict__ tmp, float *__restrict__ gw, int kt, int c_out,
-                                                            int co_ld, int layout) {
+                                                            int co_ld, int layout, int accumulate) {
     const long total = (long)kt * c_out;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int k = (int)(i / c_out), co = (int)(i % c_out);
         const long idx = layout == 0 ? (long)k * c_out + co : (long)co * kt + k;
-        gw[idx] += tmp[(long)k * co_ld + co];
+        const float v = tmp[(long)k * co_ld + co];
+        gw[idx] = accumulate ? gw[idx] + v : v;
     }
 }
 
 // part: [G][kt][co_ld] partial slabs -> gw
-int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout) {
+int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout, int accumulate) {
     void *tmp = nullptr;
     const int cols = kt * co_ld;
     if (th_malloc(ctx, (size_t)cols * sizeof(float), &tmp)) return 1;
     if (int rc = th_colsum(ctx, part, (float *)tmp, G, cols)) return rc;
     hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(ew_grid((size_t)kt * c_out, 256)), dim3(256), 0, ctx->stream, (const float *)tmp, gw, kt,
-                       c_out, co_ld, layout);
+                       c_out, co_ld, layout, accumulate);
     TH_LAUNCH_CHECK();
     return th_free(ctx, tmp);
 }
 
 int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
-                              int pad, int layout) {
+                              int pad, int layout, int accumulate) {
     ConvWgradArgs a{};
     a.x = x; a.gy = gy;
     a.n = n; a.c_in = c_in; a.h = h; a.w_in = w_in; a.c_out = c_out; a.pad = pad;
@@ -1177,7 +1178,7 @@ int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, floa
         default: hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<1>, grid, dim3(256), lds, ctx->stream, a); break;
     }
     TH_LAUNCH_CHECK();
-    if (int rc = wgrad_reduce(ctx, a.part, gw, G, kt, c_out, a.co_ld, layout)) return rc;
+    if (int rc = wgrad_reduce(ctx, a.part, gw, G, kt, c_out, a.co_ld, layout, accumulate)) return rc;
     return th_free(ctx, ws);
 }
 

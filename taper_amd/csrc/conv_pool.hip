@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const float *__restri
 __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                  float *__restrict__ gw, float *__restrict__ part, int n, int c_in,
                                                                  int h, int w, int c_out, int pad, int h_out, int w_out, int layout,
-                                                                 int img_per_slab) {
+                                                                 int img_per_slab, int accumulate) {
     __shared__ float sh[9][4];
     const int co = blockIdx.x, ci = blockIdx.y;
     const int b0 = blockIdx.z * img_per_slab, b1 = min(n, b0 + img_per_slab);
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__
             part[((long)blockIdx.z * c_in * 9 + k) * c_out + co] = tot;
         } else {
             const long idx = layout == 0 ? (long)k * c_out + co : (long)co * c_in * 9 + k;
-            gw[idx] += tot;
+            gw[idx] = accumulate ? gw[idx] + tot : tot;
         }
     }
 }
@@ -458,6 +458,77 @@ __global__ __launch_bounds__(256) void maxpool_bwd_geo_kernel(const float *__res
         }
         gin[i] = v;
     }
+}
+
+// The same scatter for the geometry the CNNs use -- 2x2 windows, stride 2, no padding, even height and width: every input pixel lies in
+// exactly ONE window, so a window's lane writes its four pixels (two float2 stores) and nothing is gathered.  The general kernel's
+// thread of pixel (0,0) walks all of its plane's windows one dependent load after the other (196 for a 28 x 28 plane: 82 us per launch
+// at batch 256 for 45 MB of traffic); here a WAVE owns a plane, its lanes read the plane's indices / gradients coalesced, and the
+// windows that kept the default index (tensor.rs:1432: none of their elements is > -inf) are found by a ballot -- only then does lane 0
+// walk the plane, adding in ascending window order like tensor.rs:1504-1514.  Same bits as the general kernel.
+// MASKED: the pool's input is the output of a ReLU (a Conv2dReLU row): the gradient that reaches pixel p is kept only where that
+// output is > 0 (ops.rs:358-369) -- for the pixel a window's maximum came from that is `pooled value > 0`, so the ReLU's backward
+// costs no pass over the full-resolution map (y_full is read for pixel (0,0) of planes with a default-index window only).
+template <bool MASKED>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restrict__ gout, const int64_t *__restrict__ argmax,
+                                                           const float *__restrict__ y_pooled, const float *__restrict__ y_full,
+                                                           float *__restrict__ gin, int planes, int h, int w, int zero_first) {
+    const int lane = threadIdx.x & 63, w_out = w >> 1, hw_out = (h >> 1) * w_out;
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (int pl = wave0; pl < planes; pl += n_waves) {
+        const long obase = (long)pl * hw_out, in_base = (long)pl * h * w;
+        bool deg = false;
+        float first = 0.f;                                 // what lane 0 wrote to pixel (0,0)
+        for (int o0 = 0; o0 < hw_out; o0 += 256) {         // four windows per lane and round: the loads of a round go out together
+            int64_t am[4];
+            float g[4], m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int o = o0 + 64 * u + lane;
+                const bool in = o < hw_out;
+                am[u] = in ? argmax[obase + o] : -1;
+                g[u] = in ? gout[obase + o] : 0.f;
+                m[u] = MASKED && in ? y_pooled[obase + o] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int o = o0 + 64 * u + lane;
+                if (o >= hw_out) continue;
+                const int oh = o / w_out, ow = o - oh * w_out;
+                const long p00 = in_base + (long)(2 * oh) * w + 2 * ow;
+                const long rel = am[u] - p00;
+                const float gv = (!MASKED || m[u] > 0.f) ? g[u] : 0.f;
+                float2 top = make_float2(0.f, 0.f), bot = top;
+                if (!zero_first) {
+                    top = *reinterpret_cast<const float2 *>(gin + p00);
+                    bot = *reinterpret_cast<const float2 *>(gin + p00 + w);
+                }
+                if (rel == 0) top.x += gv;
+                else if (rel == 1) top.y += gv;
+                else if (rel == w) bot.x += gv;
+                else if (rel == w + 1) bot.y += gv;
+                deg |= o != 0 && am[u] == in_base;
+                if (o == 0) first = top.x;
+                *reinterpret_cast<float2 *>(gin + p00) = top;
+                *reinterpret_cast<float2 *>(gin + p00 + w) = bot;
+            }
+        }
+        if (__ballot(deg) != 0ull && lane == 0) {
+            // rare: some window away from the origin kept the default index.  Pixel (0,0) = what lane 0 left there (the old value + window
+            // 0's share) + every other window that points at it, in ascending order.  Under MASKED (zero_first only) the ReLU mask of THAT
+            // pixel applies to the whole sum, so it is formed again from the unmasked gradients.
+            float v = MASKED ? 0.f : first;
+            for (int o = MASKED ? 0 : 1; o < hw_out; ++o)
+                if (argmax[obase + o] == in_base) v += gout[obase + o];
+            if (MASKED && !(y_full[in_base] > 0.f)) v = 0.f;
+            gin[in_base] = v;
+        }
+    }
+}
+
+static bool maxpool2_fast(int n, int c, int h, int w, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w) {
+    return k_h == 2 && k_w == 2 && s_h == 2 && s_w == 2 && pad_h == 0 && pad_w == 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0 &&
+           (long)n * c < (1L << 31);
 }
 
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long total, int h,
@@ -657,8 +728,8 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
                         int c_in, int h, int w_in, int c_out, int pad, int relu, bool accum, bool pool = false, float *gap_cnt = nullptr,
                         bool gap = false);
 int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
-                              int pad, int layout);
-int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout);
+                              int pad, int layout, int accumulate);
+int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout, int accumulate);
 
 }  // namespace th
 
@@ -1017,10 +1088,10 @@ int th_conv3x3_gap_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const fl
 }
 
 int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float *d_gx, int n, int c_in, int h, int w,
-                         int c_out, int pad, int weight_layout) {
+                         int c_out, int pad, int weight_layout, int accumulate) {
     TH_REQUIRE(ctx && d_gy && d_w && d_gx, "th_conv3x3_bwd_input: null argument");
     TH_REQUIRE(pad == 1, "th_conv3x3_bwd_input: only pad=1 (same-size) convolutions are supported");
-    // gx = conv3x3(gy, mirrored filter with ci/co swapped), pad 1, accumulated
+    // gx (+)= conv3x3(gy, mirrored filter with ci/co swapped), pad 1
     const int ci_pad = (c_in + CO_R - 1) / CO_R * CO_R;
     void *wt = nullptr;
     if (th_malloc(ctx, (size_t)c_out * 9 * ci_pad * sizeof(float), &wt)) return 1;
@@ -1028,20 +1099,20 @@ int th_conv3x3_bwd_input(th_ctx *ctx, const float *d_gy, const float *d_w, float
                        (float *)wt, c_in, c_out, weight_layout, 1, c_in, ci_pad, c_out);
     TH_LAUNCH_CHECK();
     if (conv3x3_mfma_supported(c_out, h, w, 1)) {   // the mirrored filter [k = (co, kh, kw)][ci] feeds the matrix-core kernel as is
-        if (int rc = conv3x3_mfma_launch(ctx, d_gy, (const float *)wt, ci_pad, ci_pad, nullptr, d_gx, n, c_out, h, w, c_in, 1, 0, true)) return rc;
-    } else if (int rc = conv3x3_launch(ctx, d_gy, (const float *)wt, nullptr, d_gx, n, c_out, h, w, c_in, ci_pad, 1, 0, true)) {
+        if (int rc = conv3x3_mfma_launch(ctx, d_gy, (const float *)wt, ci_pad, ci_pad, nullptr, d_gx, n, c_out, h, w, c_in, 1, 0, accumulate != 0)) return rc;
+    } else if (int rc = conv3x3_launch(ctx, d_gy, (const float *)wt, nullptr, d_gx, n, c_out, h, w, c_in, ci_pad, 1, 0, accumulate != 0)) {
         return rc;
     }
     return th_free(ctx, wt);
 }
 
 int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, float *d_gw, int n, int c_in, int h, int w,
-                          int c_out, int pad, int weight_layout) {
+                          int c_out, int pad, int weight_layout, int accumulate) {
     TH_REQUIRE(ctx && d_x && d_gy && d_gw, "th_conv3x3_bwd_weight: null argument");
     TH_REQUIRE(pad == 0 || pad == 1, "th_conv3x3_bwd_weight: pad must be 0 or 1");
     const int h_out = h + 2 * pad - 2, w_out = w + 2 * pad - 2;
     if (c_in >= 8 && conv3x3_mfma_supported(c_in, h, w, pad) && (long)n * h_out * w_out >= 2048)   // enough channels and pixels to contract over
-        return conv3x3_wgrad_mfma_launch(ctx, d_x, d_gy, d_gw, n, c_in, h, w, c_out, pad, weight_layout);
+        return conv3x3_wgrad_mfma_launch(ctx, d_x, d_gy, d_gw, n, c_in, h, w, c_out, pad, weight_layout, accumulate);
     int slabs = 1;
     if ((long)c_out * c_in < 512 && (long)n * h_out * w_out >= 8192) {   // few (co, ci) pairs, many pixels (conv1): split the images
         slabs = ceil_div(1024, c_out * c_in);
@@ -1049,7 +1120,7 @@ int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, floa
     }
     if (slabs <= 1) {
         hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(c_out, c_in), dim3(256), 0, ctx->stream, d_x, d_gy, d_gw, (float *)nullptr, n,
-                           c_in, h, w, c_out, pad, h_out, w_out, weight_layout, n);
+                           c_in, h, w, c_out, pad, h_out, w_out, weight_layout, n, accumulate);
         TH_LAUNCH_CHECK();
         return 0;
     }
@@ -1058,9 +1129,9 @@ int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, floa
     void *part = nullptr;
     if (th_malloc(ctx, (size_t)slabs * c_in * 9 * c_out * sizeof(float), &part)) return 1;
     hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(c_out, c_in, slabs), dim3(256), 0, ctx->stream, d_x, d_gy, d_gw, (float *)part, n,
-                       c_in, h, w, c_out, pad, h_out, w_out, weight_layout, ips);
+                       c_in, h, w, c_out, pad, h_out, w_out, weight_layout, ips, 0);
     TH_LAUNCH_CHECK();
-    if (int rc = wgrad_reduce(ctx, (const float *)part, d_gw, slabs, c_in * 9, c_out, c_out, weight_layout)) return rc;
+    if (int rc = wgrad_reduce(ctx, (const float *)part, d_gw, slabs, c_in * 9, c_out, c_out, weight_layout, accumulate)) return rc;
     return th_free(ctx, part);
 }
 
@@ -1190,8 +1261,33 @@ int th_maxpool2d_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, 
     const int h_out = (h + 2 * pad_h - k_h) / s_h + 1, w_out = (w + 2 * pad_w - k_w) / s_w + 1;
     const long total = (long)n * c * h * w;
     if (total == 0) return 0;
+    static const bool fast_off = getenv("TAPER_POOL_BWD_GENERAL") && getenv("TAPER_POOL_BWD_GENERAL")[0] == '1';   // measurement / parity knob
+    if (!fast_off && maxpool2_fast(n, c, h, w, k_h, k_w, s_h, s_w, pad_h, pad_w) && (((uintptr_t)d_gin) & 7) == 0) {
+        const int planes = n * c;
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(std::min(ceil_div(planes, 4), 8 * kNumCU)), dim3(256), 0, ctx->stream, d_gout, d_argmax,
+                           (const float *)nullptr, (const float *)nullptr, d_gin, planes, h, w, zero_first);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(maxpool_bwd_geo_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_gout, d_argmax, d_gin,
                        total, h, w, h_out, w_out, k_h, k_w, s_h, s_w, pad_h, pad_w, zero_first);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_maxpool2d_relu_bwd_supported(int n, int c, int h, int w, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w) {
+    if (s_h == 0) { s_h = k_h; s_w = k_w; }
+    return maxpool2_fast(n, c, h, w, k_h, k_w, s_h, s_w, pad_h, pad_w) ? 1 : 0;
+}
+
+int th_maxpool2d_relu_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, const float *d_y_pooled, const float *d_y_full,
+                          float *d_gin, int n, int c, int h, int w) {
+    TH_REQUIRE(ctx && d_gout && d_argmax && d_y_pooled && d_y_full && d_gin, "th_maxpool2d_relu_bwd: null argument");
+    TH_REQUIRE(maxpool2_fast(n, c, h, w, 2, 2, 2, 2, 0, 0) && (((uintptr_t)d_gin) & 7) == 0,
+               "th_maxpool2d_relu_bwd: 2x2 windows, stride 2, no padding, even height and width, 8-byte aligned gradient (got %d x %d)", h, w);
+    const int planes = n * c;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(std::min(ceil_div(planes, 4), 8 * kNumCU)), dim3(256), 0, ctx->stream, d_gout, d_argmax,
+                       d_y_pooled, d_y_full, d_gin, planes, h, w, 1);
     TH_LAUNCH_CHECK();
     return 0;
 }

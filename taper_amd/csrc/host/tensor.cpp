@@ -251,6 +251,7 @@ float *Tensor::grad_for_write(bool *was_none) const {
     if (was_none) *was_none = !grad_->has;
     grad_->has = true;
     grad_->known_zero = false;
+    grad_->premasked = false;   // whoever writes next does not know the mask: the producer's node applies it (to 0/1-masked terms: idempotent)
     return grad_->buf->d;
 }
 
@@ -829,6 +830,7 @@ Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> s
     if (bias_grad || w_grad || x_grad) {
         out.requires_grad_ = true;
         out.grad_->wants_pooled = relu && bias_grad && !w_grad && !x_grad && PoolBiasScope::active();
+        out.grad_->relu_output = relu && (w_grad || x_grad);   // full backward: a max-pool behind this layer may fold the ReLU's mask into its scatter
         Tensor x = *this, wt = w, b = bias, r = out;
         Tape::push(out, true, [x, wt, b, r, n, c_in, h, wd, c_out, h_out, w_out, pad, relu, bias_grad, w_grad, x_grad, is3]() {
             th_ctx *c = Device::ctx();
@@ -846,14 +848,26 @@ Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> s
             if (!r.has_grad()) return;
             const float *gy = r.grad_dptr();
             std::shared_ptr<Buffer> dz;
-            if (relu) {
+            // (premasked: the max-pool behind this layer scattered its gradient with this ReLU's mask already applied -- th_maxpool2d_relu_bwd)
+            if (relu && !r.grad_->premasked) {
                 dz = Buffer::alloc(r.len());
                 TH(th_relu_bwd(c, r.dptr(), gy, dz->d, r.len(), 0));
                 gy = dz->d;
             }
-            if (bias_grad) TH(th_bias_grad_nchw(c, gy, b.grad_accum_ptr(), n, c_out, h_out * w_out));
-            if (w_grad && is3) TH(th_conv3x3_bwd_weight(c, x.dptr(), gy, wt.grad_accum_ptr(), n, c_in, h, wd, c_out, pad, 0));
-            if (x_grad) TH(th_conv3x3_bwd_input(c, gy, wt.dptr(), x.grad_accum_ptr(), n, c_in, h, wd, c_out, pad, 0));
+            // a slot that is None is overwritten (0 + x): no zero fill in front of the launch
+            bool none;
+            if (bias_grad) {
+                float *db = b.grad_for_write(&none);
+                TH(th_bias_grad_nchw_masked(c, gy, nullptr, db, n, c_out, h_out * w_out, none ? 0 : 1));
+            }
+            if (w_grad && is3) {
+                float *dw = wt.grad_for_write(&none);
+                TH(th_conv3x3_bwd_weight(c, x.dptr(), gy, dw, n, c_in, h, wd, c_out, pad, 0, none ? 0 : 1));
+            }
+            if (x_grad) {
+                float *dx = x.grad_for_write(&none);
+                TH(th_conv3x3_bwd_input(c, gy, wt.dptr(), dx, n, c_in, h, wd, c_out, pad, 0, none ? 0 : 1));
+            }
         });
     }
     return out;
@@ -1093,6 +1107,12 @@ Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pai
             }
             bool none;
             float *gin = in.grad_for_write(&none);  // zero_first (Q5) overwrites whatever was there
+            if (in.grad_->relu_output && th_maxpool2d_relu_bwd_supported(n, ch, h, w, k.first, k.second, s.first, s.second, p.first, p.second)) {
+                // the input is a Conv2dReLU's output (full backward): the ReLU's backward rides in the scatter, and the conv's node skips it
+                TH(th_maxpool2d_relu_bwd(Device::ctx(), r.grad_dptr(), reinterpret_cast<const int64_t *>(arg->d), r.dptr(), in.dptr(), gin, n, ch, h, w));
+                in.grad_->premasked = true;
+                return;
+            }
             TH(th_maxpool2d_bwd(Device::ctx(), r.grad_dptr(), reinterpret_cast<const int64_t *>(arg->d), gin, n, ch, h, w, k.first,
                                 k.second, s.first, s.second, p.first, p.second, /*zero_first*/ 1));
         });

@@ -450,14 +450,17 @@ def test_conv3x3_bwd_full_mode(ctx, O, n, c_in, h, w, c_out, layout):
     O.Tape.set_zero_sentinel(True)
     gx_ref = xt.grad()
     gw_ref = wtt.grad() if layout == 0 else np.ascontiguousarray(wtt.grad().reshape(k, c_out).T).reshape(c_out, c_in, 3, 3)
-    gx, gw = ctx.zeros(x.size), ctx.zeros(wt.size)
-    ctx.call("th_conv3x3_bwd_input", ctx.upload(gy), ctx.upload(wt), gx, n, c_in, h, w, c_out, 1, layout)
-    ctx.call("th_conv3x3_bwd_weight", ctx.upload(x), ctx.upload(gy), gw, n, c_in, h, w, c_out, 1, layout)
+    # accumulate = 0 (the slot was None): whatever the buffers held is overwritten, no zero fill needed
+    gx, gw = ctx.upload(np.full(x.size, 7.0, np.float32)), ctx.upload(np.full(wt.size, -3.0, np.float32))
+    ctx.call("th_conv3x3_bwd_input", ctx.upload(gy), ctx.upload(wt), gx, n, c_in, h, w, c_out, 1, layout, 0)
+    ctx.call("th_conv3x3_bwd_weight", ctx.upload(x), ctx.upload(gy), gw, n, c_in, h, w, c_out, 1, layout, 0)
     close(ctx.download(gx, x.shape), gx_ref, atol=1e-4)
     close(ctx.download(gw, wt.shape), gw_ref, atol=1e-4 + 2e-7 * n * h * w)   # a reordered sum of n*h*w terms of O(1)
-    # the weight gradient ACCUMULATES (ops.rs:126-129 semantics of the slot): a second call doubles it
-    ctx.call("th_conv3x3_bwd_weight", ctx.upload(x), ctx.upload(gy), gw, n, c_in, h, w, c_out, 1, layout)
+    # accumulate = 1 (ops.rs:126-129 semantics of a slot that is Some): a second call doubles both
+    ctx.call("th_conv3x3_bwd_weight", ctx.upload(x), ctx.upload(gy), gw, n, c_in, h, w, c_out, 1, layout, 1)
     close(ctx.download(gw, wt.shape), 2 * gw_ref, atol=2e-4 + 4e-7 * n * h * w)
+    ctx.call("th_conv3x3_bwd_input", ctx.upload(gy), ctx.upload(wt), gx, n, c_in, h, w, c_out, 1, layout, 1)
+    close(ctx.download(gx, x.shape), 2 * gx_ref, atol=2e-4)
     O.Tape.reset()
 
 
@@ -523,6 +526,58 @@ def test_maxpool_windows_without_a_maximum(ctx, O, n, c, h, w, k, s, pad):
     ctx.call("th_maxpool2d_bwd", ctx.upload(gout), am, gin, n, c, h, w, k[0], k[1], s[0], s[1], pad[0], pad[1], 1)
     np.testing.assert_array_equal(ctx.download(gin, x.shape), xt.grad().reshape(x.shape))
     O.Tape.reset()
+
+
+@pytest.mark.parametrize("n,c,h,w", [(4, 32, 28, 28), (3, 64, 14, 14), (2, 3, 8, 8), (1, 1, 2, 2), (2, 5, 30, 18), (1, 2, 40, 40)])
+@pytest.mark.parametrize("zero_first", [1, 0])
+def test_maxpool2_bwd_fast_path_equals_the_general_kernel(ctx, n, c, h, w, zero_first):
+    """th_maxpool2d_bwd on 2x2 / stride 2 / unpadded pools takes a wave-per-plane kernel; TAPER_POOL_BWD_GENERAL is not set here, so the
+    comparison is against the scatter itself: gin[argmax[o]] (+)= gout[o] in ascending o (tensor.rs:1496-1519), with windows that kept
+    the default index (all NaN) landing on their plane's pixel (0,0) -- bit-exact, both with zero_first (Q5) and accumulating."""
+    rng = np.random.default_rng(n * 100 + c * 10 + h)
+    x = rng.integers(-3, 4, (n, c, h, w)).astype(np.float32)
+    if h >= 8:
+        x[0, 0, h - 4:, w - 4:] = np.nan      # default-index windows far from the origin
+        x[n - 1, c - 1, :2, :2] = np.nan      # ... and at it
+    ho, wo = h // 2, w // 2
+    y, am = ctx.empty(n * c * ho * wo), ctx.empty(n * c * ho * wo, np.int64)
+    ctx.call("th_maxpool2d_fwd", ctx.upload(x), y, am, n, c, h, w, 2, 2, 2, 2, 0, 0)
+    idx = ctx.download(am, (n * c * ho * wo,), np.int64)
+    gout = rng.uniform(-1, 1, n * c * ho * wo).astype(np.float32)
+    old = rng.uniform(-1, 1, x.size).astype(np.float32)
+    ref = np.zeros(x.size, np.float32) if zero_first else old.copy()
+    for o in range(idx.size):                  # sequential, ascending: the reference's order
+        ref[idx[o]] = np.float32(ref[idx[o]] + gout[o])
+    gin = ctx.upload(old)
+    ctx.call("th_maxpool2d_bwd", ctx.upload(gout), am, gin, n, c, h, w, 2, 2, 2, 2, 0, 0, zero_first)
+    np.testing.assert_array_equal(ctx.download(gin, (x.size,)), ref)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(4, 32, 28, 28), (3, 64, 14, 14), (2, 3, 8, 8), (1, 1, 2, 2), (2, 5, 30, 18)])
+def test_maxpool2d_relu_bwd_equals_pool_bwd_then_relu_bwd(ctx, n, c, h, w):
+    """th_maxpool2d_relu_bwd == th_maxpool2d_bwd(zero_first) followed by th_relu_bwd on the pool's input, bit for bit -- including planes
+    whose default-index windows send their gradient to pixel (0,0), where THAT pixel's output decides the mask."""
+    from taper_amd import hip
+    assert hip.hip.th_maxpool2d_relu_bwd_supported(n, c, h, w, 2, 2, 2, 2, 0, 0) == 1
+    assert hip.hip.th_maxpool2d_relu_bwd_supported(n, c, h, w, 3, 3, 2, 2, 1, 1) == 0
+    rng = np.random.default_rng(n * 100 + c * 10 + h)
+    x = np.maximum(rng.integers(-3, 4, (n, c, h, w)).astype(np.float32), 0)     # a ReLU's output: many zeros, many ties
+    if h >= 8:
+        x[0, 0, h - 4:, w - 4:] = np.nan
+        x[0, 0, 0, 0] = 2.0                   # pixel (0,0) > 0: the default-index windows' gradients survive the mask
+        x[n - 1, c - 1, h - 2:, w - 2:] = np.nan
+        x[n - 1, c - 1, 0, 0] = 0.0           # ... and here they do not
+    ho, wo = h // 2, w // 2
+    dx = ctx.upload(x)
+    y, am = ctx.empty(n * c * ho * wo), ctx.empty(n * c * ho * wo, np.int64)
+    ctx.call("th_maxpool2d_fwd", dx, y, am, n, c, h, w, 2, 2, 2, 2, 0, 0)
+    gout = ctx.upload(rng.uniform(-1, 1, n * c * ho * wo).astype(np.float32))
+    ref, tmp = ctx.empty(x.size), ctx.upload(np.full(x.size, 9.0, np.float32))
+    ctx.call("th_maxpool2d_bwd", gout, am, tmp, n, c, h, w, 2, 2, 2, 2, 0, 0, 1)
+    ctx.call("th_relu_bwd", dx, tmp, ref, x.size, 0)
+    got = ctx.upload(np.full(x.size, -5.0, np.float32))
+    ctx.call("th_maxpool2d_relu_bwd", gout, am, y, dx, got, n, c, h, w)
+    np.testing.assert_array_equal(ctx.download(got, (x.size,)), ctx.download(ref, (x.size,)))
 
 
 @pytest.mark.parametrize("n,c,h,w,k,s,pad", POOL_CASES + [(5, 128, 7, 7, (7, 7), (7, 7), (0, 0)), (2, 4, 7, 7, (7, 7), (1, 1), (0, 0))])
