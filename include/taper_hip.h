@@ -525,7 +525,12 @@ int th_maxpool2d_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, 
  * pixel (0,0) of planes with a default-index window only, tensor.rs:1432).  full_backward extension. */
 int th_maxpool2d_relu_bwd_supported(int n, int c, int h, int w, int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w);
 int th_maxpool2d_relu_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, const float *d_y_pooled,
-                          const float *d_y_full, float *d_gin, int n, int c, int h, int w);
+                          const float *d_y_full, float *d_gin, float *d_plane_sums /* nullable: [n][c] */, int n, int c, int h, int w);
+/* d_gin = relu_bwd(d_y, d_gout) (ops.rs:358-369) on an NCHW map, and d_plane_sums[b][ch] = the sum of plane (b, ch) of d_gin: the rows of
+ * the bias sum of the Conv2dReLU whose output d_y is (tensor.rs:2017-2024).  th_bias_grad_plane_sums: gb[ch] (+)= sum_b plane_sums[b][ch]
+ * -- together th_relu_bwd + th_bias_grad_nchw in one pass over the map.  full_backward extension. */
+int th_relu_bwd_plane_sums(th_ctx *ctx, const float *d_y, const float *d_gout, float *d_gin, float *d_plane_sums, int n, int c, int hw);
+int th_bias_grad_plane_sums(th_ctx *ctx, const float *d_plane_sums, float *d_gb, int n, int c, int accumulate);
 /* avg-pool: tensor.rs:1524-1660 (divisor k_h*k_w incl. padding, Q6) */
 int th_avgpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int n, int c, int h, int w,
                      int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w);

@@ -1131,6 +1131,8 @@ __global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float *__restr
 
 // part: [G][kt][co_ld] partial slabs -> gw
 int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout, int accumulate) {
+    // taper layout and unpadded channel rows: the ordered sum of the slabs IS the gradient as it lies in memory -- no scatter launch
+    if (layout == 0 && co_ld == c_out) return accumulate ? th_colsum_accum(ctx, part, gw, G, kt * c_out) : th_colsum(ctx, part, gw, G, kt * c_out);
     void *tmp = nullptr;
     const int cols = kt * co_ld;
     if (th_malloc(ctx, (size_t)cols * sizeof(float), &tmp)) return 1;

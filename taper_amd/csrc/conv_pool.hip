@@ -324,6 +324,90 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float *__
     }
 }
 
+// The same gradient for a SINGLE input channel (conv1 of both CNNs: 1 -> 32 on 28 x 28), where the kernel above is one workgroup per
+// (co, slab) striding over 6 272 pixels with nine guarded loads each (50 us at batch 256 for 26 MB of traffic).  Here a workgroup owns one
+// IMAGE: its zero-haloed input plane and its [c_out_blk <= 32][h_out w_out] gradient planes are staged in LDS with coalesced loads (all of a
+// thread's loads ahead of its first LDS store), then thread (channel, pixel slice) walks its slice with the nine tap sums in registers --
+// one gradient read and nine window reads from LDS per nine FMAs -- and the slices are added in slice order.  One partial [9][c_out] slab
+// per image; wgrad_reduce adds the images in order (deterministic).  grid = (n, ceil(c_out / 32)), 512 threads.
+constexpr int C1W_CO = 32, C1W_NT = 512, C1W_NS = C1W_NT / C1W_CO;
+__global__ __launch_bounds__(C1W_NT) void conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part,
+                                                            int h, int w, int c_out, int pad, int h_out, int w_out) {
+    extern __shared__ float c1w_lds[];
+    const int wp = w + 2, hp = h + 2, osp = h_out * w_out, gp = osp + 1;      // (odd plane pitch: the 32 channels of a wave half spread over the banks)
+    float *img = c1w_lds, *g = img + ((hp * wp + 3) & ~3), *red = g + C1W_CO * gp;     // red: [C1W_NS][C1W_CO][9]
+    const int t = threadIdx.x, b = blockIdx.x, co0 = blockIdx.y * C1W_CO, nco = min(C1W_CO, c_out - co0);
+    const float *xi = x + (long)b * h * w, *gi = gy + ((long)b * c_out + co0) * osp;
+    for (int e = t; e < hp * wp; e += C1W_NT) {
+        const int r = e / wp - 1, c = e % wp - 1;
+        img[e] = (r >= 0 && r < h && c >= 0 && c < w) ? xi[r * w + c] : 0.f;
+    }
+    {
+        const int total = nco * osp;           // the block's gradient planes are contiguous in memory
+        constexpr int U = 8;
+        for (int e0 = t; e0 < total; e0 += C1W_NT * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * C1W_NT;
+                v[u] = e < total ? gi[e] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * C1W_NT;
+                if (e < total) {
+                    const int c = e / osp;
+                    g[c * gp + e - c * osp] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int cl = t % C1W_CO, sl = t / C1W_CO;
+    const int per = (osp + C1W_NS - 1) / C1W_NS, p0 = sl * per, p1 = min(osp, p0 + per);
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    if (cl < nco && p0 < p1) {
+        int oh = p0 / w_out, ow = p0 - oh * w_out;
+        const float *gc = g + cl * gp;
+        const int shift = 1 - pad;             // halo coordinates of the window's corner: (oh + shift, ow + shift)
+        float win[9];                          // the window slides along the row: three new values per pixel, nine at a row's start
+        bool fresh = true;
+        for (int p = p0; p < p1; ++p) {
+            const float gv = gc[p];
+            const float *wc = img + (oh + shift) * wp + ow + shift;
+            if (fresh) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) win[k] = wc[(k / 3) * wp + k % 3];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    win[3 * r] = win[3 * r + 1];
+                    win[3 * r + 1] = win[3 * r + 2];
+                    win[3 * r + 2] = wc[r * wp + 2];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] = fmaf(win[k], gv, acc[k]);
+            fresh = ++ow == w_out;
+            if (fresh) { ow = 0; ++oh; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[(sl * C1W_CO + cl) * 9 + k] = acc[k];
+    __syncthreads();
+    if (t < C1W_CO * 9) {
+        const int c = t % C1W_CO, k = t / C1W_CO;
+        if (c < nco) {
+            float v = red[c * 9 + k];
+#pragma unroll
+            for (int q = 1; q < C1W_NS; ++q) v += red[(q * C1W_CO + c) * 9 + k];
+            part[((long)b * 9 + k) * c_out + co0 + c] = v;
+        }
+    }
+}
+
 // ---- NCHW bias (tensor.rs:1983-1992, 2017-2024) ---------------------------
 __global__ __launch_bounds__(256) void bias_add_nchw_kernel(const float *__restrict__ x, const float *__restrict__ bias,
                                                             float *__restrict__ y, long total, int c, int hw, int relu) {
@@ -472,13 +556,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_geo_kernel(const float *__res
 template <bool MASKED>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restrict__ gout, const int64_t *__restrict__ argmax,
                                                            const float *__restrict__ y_pooled, const float *__restrict__ y_full,
-                                                           float *__restrict__ gin, int planes, int h, int w, int zero_first) {
+                                                           float *__restrict__ gin, float *__restrict__ plane_sums, int planes, int h, int w,
+                                                           int zero_first) {
     const int lane = threadIdx.x & 63, w_out = w >> 1, hw_out = (h >> 1) * w_out;
     const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     for (int pl = wave0; pl < planes; pl += n_waves) {
         const long obase = (long)pl * hw_out, in_base = (long)pl * h * w;
         bool deg = false;
         float first = 0.f;                                 // what lane 0 wrote to pixel (0,0)
+        float wsum = 0.f;                                  // plane_sums (zero_first forms): what this lane's windows scattered
         for (int o0 = 0; o0 < hw_out; o0 += 256) {         // four windows per lane and round: the loads of a round go out together
             int64_t am[4];
             float g[4], m[4];
@@ -507,6 +593,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restri
                 else if (rel == 1) top.y += gv;
                 else if (rel == w) bot.x += gv;
                 else if (rel == w + 1) bot.y += gv;
+                if (rel == 0 || rel == 1 || rel == w || rel == w + 1) wsum += gv;
                 deg |= o != 0 && am[u] == in_base;
                 if (o == 0) first = top.x;
                 *reinterpret_cast<float2 *>(gin + p00) = top;
@@ -522,7 +609,67 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *__restri
                 if (argmax[obase + o] == in_base) v += gout[obase + o];
             if (MASKED && !(y_full[in_base] > 0.f)) v = 0.f;
             gin[in_base] = v;
+            wsum += v - first;
         }
+        if (plane_sums) {      // the sum of the plane's scattered gradient: the bias gradient of the Conv2dReLU in front needs nothing else of it
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wsum += __shfl_down(wsum, off, 64);
+            if (lane == 0) plane_sums[pl] = wsum;
+        }
+    }
+}
+
+// ReLU backward on an NCHW map with the sum of every plane of the result on the way (ops.rs:358-369 + the rows of tensor.rs:2017-2024's
+// bias sum): a wave per plane, float4 where the plane allows.  The bias gradient of a Conv2dReLU is then a sum over [n][c] instead of a
+// second pass over [n][c][h][w] (bias_grad_nchw_kernel: 15 us per layer at batch 256).
+__global__ __launch_bounds__(256) void relu_bwd_planes_kernel(const float *__restrict__ y, const float *__restrict__ gout, float *__restrict__ gin,
+                                                              float *__restrict__ plane_sums, int planes, int hw) {
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const bool vec = (hw & 3) == 0;
+    for (int pl = wave0; pl < planes; pl += n_waves) {
+        const long base = (long)pl * hw;
+        float s = 0.f;
+        if (vec) {
+            const float4 *y4 = reinterpret_cast<const float4 *>(y + base), *g4 = reinterpret_cast<const float4 *>(gout + base);
+            float4 *o4 = reinterpret_cast<float4 *>(gin + base);
+            for (int i = lane; i < hw / 4; i += 64) {
+                const float4 yv = y4[i], gv = g4[i];
+                float4 o;
+                o.x = yv.x > 0.f ? gv.x : 0.f; o.y = yv.y > 0.f ? gv.y : 0.f; o.z = yv.z > 0.f ? gv.z : 0.f; o.w = yv.w > 0.f ? gv.w : 0.f;
+                o4[i] = o;
+                s += (o.x + o.y) + (o.z + o.w);
+            }
+        } else {
+            for (int i = lane; i < hw; i += 64) {
+                const float o = y[base + i] > 0.f ? gout[base + i] : 0.f;
+                gin[base + i] = o;
+                s += o;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) plane_sums[pl] = s;
+    }
+}
+
+// gb[ch] (+)= sum over images of plane_sums[b][ch], images in ascending order within each of 16 interleaved chains (deterministic);
+// one workgroup per 16 channels: thread (chain q, channel) adds images q, q + 16, ...; the 16 chains are added in order
+__global__ __launch_bounds__(256) void bias_from_plane_sums_kernel(const float *__restrict__ ps, float *__restrict__ gb, int n, int c, int accumulate) {
+    __shared__ float sh[16][16];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, ch = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (ch < c) {
+#pragma unroll 8
+        for (int b = q; b < n; b += 16) s += ps[(long)b * c + ch];
+    }
+    sh[q][cl] = s;
+    __syncthreads();
+    if (q == 0 && ch < c) {
+        float tot = sh[0][cl];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) tot += sh[u][cl];
+        gb[ch] = accumulate ? gb[ch] + tot : tot;
     }
 }
 
@@ -1113,6 +1260,22 @@ int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, floa
     const int h_out = h + 2 * pad - 2, w_out = w + 2 * pad - 2;
     if (c_in >= 8 && conv3x3_mfma_supported(c_in, h, w, pad) && (long)n * h_out * w_out >= 2048)   // enough channels and pixels to contract over
         return conv3x3_wgrad_mfma_launch(ctx, d_x, d_gy, d_gw, n, c_in, h, w, c_out, pad, weight_layout, accumulate);
+    {
+        // one input channel, planes that fit the LDS (conv1): one image per workgroup, partial slabs per image
+        const size_t lds = ((size_t)(((h + 2) * (w + 2) + 3) & ~3) + (size_t)C1W_CO * (h_out * w_out + 1) + (size_t)C1W_NS * C1W_CO * 9) * sizeof(float);
+        static const bool off = getenv("TAPER_CONV1_WGRAD") && getenv("TAPER_CONV1_WGRAD")[0] == '0';   // measurement / parity knob
+        if (!off && c_in == 1 && n >= 32 && h_out > 0 && w_out > 0 && lds <= (160u << 10)) {
+            void *part = nullptr;
+            if (th_malloc(ctx, (size_t)n * 9 * c_out * sizeof(float), &part)) return 1;
+            static bool attr = false;
+            if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)conv1_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10)); attr = true; }
+            hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(n, ceil_div(c_out, C1W_CO)), dim3(C1W_NT), lds, ctx->stream, d_x, d_gy, (float *)part, h, w,
+                               c_out, pad, h_out, w_out);
+            TH_LAUNCH_CHECK();
+            if (int rc = wgrad_reduce(ctx, (const float *)part, d_gw, n, 9, c_out, c_out, weight_layout, accumulate)) return rc;
+            return th_free(ctx, part);
+        }
+    }
     int slabs = 1;
     if ((long)c_out * c_in < 512 && (long)n * h_out * w_out >= 8192) {   // few (co, ci) pairs, many pixels (conv1): split the images
         slabs = ceil_div(1024, c_out * c_in);
@@ -1265,7 +1428,7 @@ int th_maxpool2d_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, 
     if (!fast_off && maxpool2_fast(n, c, h, w, k_h, k_w, s_h, s_w, pad_h, pad_w) && (((uintptr_t)d_gin) & 7) == 0) {
         const int planes = n * c;
         hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(std::min(ceil_div(planes, 4), 8 * kNumCU)), dim3(256), 0, ctx->stream, d_gout, d_argmax,
-                           (const float *)nullptr, (const float *)nullptr, d_gin, planes, h, w, zero_first);
+                           (const float *)nullptr, (const float *)nullptr, d_gin, (float *)nullptr, planes, h, w, zero_first);
         TH_LAUNCH_CHECK();
         return 0;
     }
@@ -1281,13 +1444,32 @@ int th_maxpool2d_relu_bwd_supported(int n, int c, int h, int w, int k_h, int k_w
 }
 
 int th_maxpool2d_relu_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_argmax, const float *d_y_pooled, const float *d_y_full,
-                          float *d_gin, int n, int c, int h, int w) {
+                          float *d_gin, float *d_plane_sums, int n, int c, int h, int w) {
     TH_REQUIRE(ctx && d_gout && d_argmax && d_y_pooled && d_y_full && d_gin, "th_maxpool2d_relu_bwd: null argument");
     TH_REQUIRE(maxpool2_fast(n, c, h, w, 2, 2, 2, 2, 0, 0) && (((uintptr_t)d_gin) & 7) == 0,
                "th_maxpool2d_relu_bwd: 2x2 windows, stride 2, no padding, even height and width, 8-byte aligned gradient (got %d x %d)", h, w);
     const int planes = n * c;
     hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(std::min(ceil_div(planes, 4), 8 * kNumCU)), dim3(256), 0, ctx->stream, d_gout, d_argmax,
-                       d_y_pooled, d_y_full, d_gin, planes, h, w, 1);
+                       d_y_pooled, d_y_full, d_gin, d_plane_sums, planes, h, w, 1);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_relu_bwd_plane_sums(th_ctx *ctx, const float *d_y, const float *d_gout, float *d_gin, float *d_plane_sums, int n, int c, int hw) {
+    TH_REQUIRE(ctx && d_y && d_gout && d_gin && d_plane_sums, "th_relu_bwd_plane_sums: null argument");
+    TH_REQUIRE(n >= 0 && c >= 0 && hw > 0 && (long)n * c < (1L << 31), "th_relu_bwd_plane_sums: bad geometry");
+    TH_REQUIRE((hw & 3) != 0 || ((((uintptr_t)d_y | (uintptr_t)d_gout | (uintptr_t)d_gin) & 15) == 0), "th_relu_bwd_plane_sums: maps must be 16-byte aligned");
+    const int planes = n * c;
+    if (planes == 0) return 0;
+    hipLaunchKernelGGL(relu_bwd_planes_kernel, dim3(std::min(ceil_div(planes, 4), 8 * kNumCU)), dim3(256), 0, ctx->stream, d_y, d_gout, d_gin,
+                       d_plane_sums, planes, hw);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_bias_grad_plane_sums(th_ctx *ctx, const float *d_plane_sums, float *d_gb, int n, int c, int accumulate) {
+    TH_REQUIRE(ctx && d_plane_sums && d_gb && n >= 0 && c > 0, "th_bias_grad_plane_sums: bad argument");
+    hipLaunchKernelGGL(bias_from_plane_sums_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, ctx->stream, d_plane_sums, d_gb, n, c, accumulate);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -78,7 +78,8 @@ struct GradSlot {
     // input is its bias (Q2); a max-pool consuming it then leaves {gradient of the POOLED output, pooled output} here
     // instead of scattering, and the conv's backward sums the bias gradient straight from them
     bool relu_output = false;     // the tensor is the output of a fused Linear+ReLU node
-    bool premasked = false;       // its gradient already carries that ReLU's mask (th_linear_xent_head_masked)
+    bool premasked = false;       // its gradient already carries that ReLU's mask (th_linear_xent_head_masked; th_maxpool2d_relu_bwd)
+    std::shared_ptr<Buffer> plane_sums;   // full backward, premasked conv output: [n][c] sums of the planes of that gradient (the bias gradient's rows)
     bool wants_pooled = false;
     std::shared_ptr<Buffer> pooled_dy, pooled_y;
     std::shared_ptr<Buffer> pooled_cnt;   // [n][c] counts of elements > 0 per plane, left by a global average pool's forward

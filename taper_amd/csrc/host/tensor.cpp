@@ -252,6 +252,7 @@ float *Tensor::grad_for_write(bool *was_none) const {
     grad_->has = true;
     grad_->known_zero = false;
     grad_->premasked = false;   // whoever writes next does not know the mask: the producer's node applies it (to 0/1-masked terms: idempotent)
+    grad_->plane_sums.reset();
     return grad_->buf->d;
 }
 
@@ -849,16 +850,25 @@ Tensor Tensor::conv2d(const Tensor &w, const Tensor &bias, std::pair<int, int> s
             const float *gy = r.grad_dptr();
             std::shared_ptr<Buffer> dz;
             // (premasked: the max-pool behind this layer scattered its gradient with this ReLU's mask already applied -- th_maxpool2d_relu_bwd)
+            // plane sums [n][c_out] of the masked gradient: all the bias needs of it -- left by the pool's scatter, or formed by the ReLU's backward
+            std::shared_ptr<Buffer> ps = r.grad_->premasked ? r.grad_->plane_sums : nullptr;
+            r.grad_->plane_sums.reset();
             if (relu && !r.grad_->premasked) {
                 dz = Buffer::alloc(r.len());
-                TH(th_relu_bwd(c, r.dptr(), gy, dz->d, r.len(), 0));
+                if (bias_grad) {
+                    ps = Buffer::alloc((size_t)n * c_out);
+                    TH(th_relu_bwd_plane_sums(c, r.dptr(), gy, dz->d, ps->d, n, c_out, h_out * w_out));
+                } else {
+                    TH(th_relu_bwd(c, r.dptr(), gy, dz->d, r.len(), 0));
+                }
                 gy = dz->d;
             }
             // a slot that is None is overwritten (0 + x): no zero fill in front of the launch
             bool none;
             if (bias_grad) {
                 float *db = b.grad_for_write(&none);
-                TH(th_bias_grad_nchw_masked(c, gy, nullptr, db, n, c_out, h_out * w_out, none ? 0 : 1));
+                if (ps) TH(th_bias_grad_plane_sums(c, ps->d, db, n, c_out, none ? 0 : 1));
+                else TH(th_bias_grad_nchw_masked(c, gy, nullptr, db, n, c_out, h_out * w_out, none ? 0 : 1));
             }
             if (w_grad && is3) {
                 float *dw = wt.grad_for_write(&none);
@@ -1109,7 +1119,9 @@ Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pai
             float *gin = in.grad_for_write(&none);  // zero_first (Q5) overwrites whatever was there
             if (in.grad_->relu_output && th_maxpool2d_relu_bwd_supported(n, ch, h, w, k.first, k.second, s.first, s.second, p.first, p.second)) {
                 // the input is a Conv2dReLU's output (full backward): the ReLU's backward rides in the scatter, and the conv's node skips it
-                TH(th_maxpool2d_relu_bwd(Device::ctx(), r.grad_dptr(), reinterpret_cast<const int64_t *>(arg->d), r.dptr(), in.dptr(), gin, n, ch, h, w));
+                in.grad_->plane_sums = Buffer::alloc((size_t)n * ch);
+                TH(th_maxpool2d_relu_bwd(Device::ctx(), r.grad_dptr(), reinterpret_cast<const int64_t *>(arg->d), r.dptr(), in.dptr(), gin,
+                                         in.grad_->plane_sums->d, n, ch, h, w));
                 in.grad_->premasked = true;
                 return;
             }

@@ -430,7 +430,8 @@ def test_conv1x1_taper_layout(ctx, O, n, c_in, h, w, c_out):
 @pytest.mark.parametrize("n,c_in,h,w,c_out", [(3, 4, 8, 8, 5), (2, 32, 14, 14, 32), (4, 1, 28, 28, 8), (2, 16, 7, 7, 24),
                                               # >= 2048 output pixels and C_in >= 8: the matrix-core weight-gradient kernel
                                               (12, 16, 14, 14, 24), (4, 40, 28, 28, 70), (50, 9, 7, 7, 16), (3, 32, 28, 28, 32),
-                                              (16, 1, 28, 28, 32), (11, 3, 30, 30, 5)])   # few channel pairs, many pixels: image slabs
+                                              (16, 1, 28, 28, 32), (11, 3, 30, 30, 5),    # few channel pairs, many pixels: image slabs
+                                              (40, 1, 28, 28, 32), (33, 1, 32, 32, 16), (32, 1, 9, 7, 40)])   # one input channel, >= 32 images: an image per workgroup (conv1_wgrad_kernel)
 @pytest.mark.parametrize("layout", [0, 1])
 def test_conv3x3_bwd_full_mode(ctx, O, n, c_in, h, w, c_out, layout):
     """full_backward extension (not in the reference, Q2): checked against the oracle's
@@ -575,9 +576,37 @@ def test_maxpool2d_relu_bwd_equals_pool_bwd_then_relu_bwd(ctx, n, c, h, w):
     ref, tmp = ctx.empty(x.size), ctx.upload(np.full(x.size, 9.0, np.float32))
     ctx.call("th_maxpool2d_bwd", gout, am, tmp, n, c, h, w, 2, 2, 2, 2, 0, 0, 1)
     ctx.call("th_relu_bwd", dx, tmp, ref, x.size, 0)
-    got = ctx.upload(np.full(x.size, -5.0, np.float32))
-    ctx.call("th_maxpool2d_relu_bwd", gout, am, y, dx, got, n, c, h, w)
-    np.testing.assert_array_equal(ctx.download(got, (x.size,)), ctx.download(ref, (x.size,)))
+    got, sums = ctx.upload(np.full(x.size, -5.0, np.float32)), ctx.upload(np.full(n * c, 3.0, np.float32))
+    ctx.call("th_maxpool2d_relu_bwd", gout, am, y, dx, got, sums, n, c, h, w)
+    want = ctx.download(ref, (x.size,))
+    np.testing.assert_array_equal(ctx.download(got, (x.size,)), want)
+    # the plane sums of the result (the rows of the producer's bias gradient), and the same call without them
+    close(ctx.download(sums, (n * c,)), want.reshape(n * c, h * w).astype(np.float64).sum(1), atol=1e-5 * np.sqrt(h * w))
+    got2 = ctx.empty(x.size)
+    ctx.call("th_maxpool2d_relu_bwd", gout, am, y, dx, got2, None, n, c, h, w)
+    np.testing.assert_array_equal(ctx.download(got2, (x.size,)), want)
+
+
+@pytest.mark.parametrize("n,c,hw", [(4, 32, 784), (3, 64, 196), (5, 128, 49), (2, 3, 30), (1, 1, 1), (7, 5, 4096)])
+def test_relu_bwd_plane_sums_and_bias_from_them(ctx, n, c, hw):
+    """th_relu_bwd_plane_sums == th_relu_bwd bit for bit, + the per-plane sums; th_bias_grad_plane_sums adds those over the images:
+    together th_relu_bwd + th_bias_grad_nchw (tensor.rs:2017-2024) in one pass over the map."""
+    rng = np.random.default_rng(n * 7 + c + hw)
+    y = np.maximum(rng.uniform(-1, 1, (n, c, hw)), 0).astype(np.float32)
+    g = rng.uniform(-1, 1, (n, c, hw)).astype(np.float32)
+    dy, dg = ctx.upload(y), ctx.upload(g)
+    ref, got, sums = ctx.empty(y.size), ctx.upload(np.full(y.size, 4.0, np.float32)), ctx.empty(n * c)
+    ctx.call("th_relu_bwd", dy, dg, ref, y.size, 0)
+    ctx.call("th_relu_bwd_plane_sums", dy, dg, got, sums, n, c, hw)
+    want = ctx.download(ref, (n, c, hw))
+    np.testing.assert_array_equal(ctx.download(got, (n, c, hw)), want)
+    np.testing.assert_array_equal(want, np.where(y > 0, g, 0).astype(np.float32))
+    close(ctx.download(sums, (n, c)), want.astype(np.float64).sum(2), atol=2e-6 * hw)
+    gb = ctx.upload(np.full(c, 2.0, np.float32))
+    ctx.call("th_bias_grad_plane_sums", sums, gb, n, c, 0)
+    close(ctx.download(gb, (c,)), want.astype(np.float64).sum((0, 2)), atol=2e-6 * hw * n)
+    ctx.call("th_bias_grad_plane_sums", sums, gb, n, c, 1)
+    close(ctx.download(gb, (c,)), 2 * want.astype(np.float64).sum((0, 2)), atol=4e-6 * hw * n)
 
 
 @pytest.mark.parametrize("n,c,h,w,k,s,pad", POOL_CASES + [(5, 128, 7, 7, (7, 7), (7, 7), (0, 0)), (2, 4, 7, 7, (7, 7), (1, 1), (0, 0))])
