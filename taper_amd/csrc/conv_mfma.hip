@@ -1044,6 +1044,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    const int n_steps = (m_wg + 3) / 4;
     for (int pb = blockIdx.x; pb < a.n_pb; pb += a.G) {
         const int grp = pb / a.bands, band = pb % a.bands;
         const int img0 = grp * a.img_t, oh0 = band * a.rows_t;
@@ -1086,9 +1087,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a
             }
         }
         __syncthreads();
-        // ---- 32 reduction steps of 4 pixels ----
+        // ---- reduction steps of 4 pixels (pixels past m_wg are zero columns: their steps would add nothing) ----
 #pragma unroll 4
-        for (int rs = 0; rs < MF_PX_MAX / 4; ++rs) {
+        for (int rs = 0; rs < n_steps; ++rs) {
             const int px = 4 * rs + g4;
             const int po = pixoff[px];
             const float b_lo = gyl[(ct_lo * 16 + l16) * WG_GP + px];
