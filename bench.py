@@ -701,6 +701,17 @@ def extra_workloads(T, dataset, with_cpu, only=None):
                 head = chain and key == "cnn_simple" and os.environ.get("TAPER_CHAIN_HEAD", "1") != "0"
                 rec["kernels"] = (chain_head_kernels(ctx) if head else []) + ([dict(conv_chain_kernel(ctx, key), in_step=not head)] if chain else []) + layers
                 rec["conv_us_per_step"] = round(sum(k["us_per_launch"] for k in rec["kernels"] if k["in_step"]), 1)
+                # the same model with every conv weight training (full_backward: an extension -- the reference cuts the tape at im2col /
+                # transpose_4d, quirk Q2 -- through the layer-by-layer forward and the conv backward kernels)
+                try:
+                    T.set_full_backward(True)
+                    fb = trainer_workload(T, name, dataset, steps=300)[0]
+                    rec["full_backward"] = dict(ms_per_step=fb["ms_per_step"], samples_per_s=fb["samples_per_s"], steps=300,
+                                                note="extension: conv weights train too (not the reference's behaviour, quirk Q2)")
+                except Exception as e:
+                    rec["full_backward"] = dict(error=str(e))
+                finally:
+                    T.set_full_backward(False)
             if with_cpu and key != "mlp_example":
                 try:
                     rec["cpu_baseline"] = cpu_baseline(key, batch, sample_shape, lr, budget_s=7.0)
@@ -788,9 +799,11 @@ def compact_line(full, details_path):
             if "frac_of_mfma_peak" in rec:
                 e["mfma_frac"] = rec["frac_of_mfma_peak"]
                 e["sgemm_4096_frac"] = [k["frac"] for k in rec.get("kernels", [])]
+            if rec.get("full_backward", {}).get("ms_per_step"):
+                e["full_bwd_ms"] = round(rec["full_backward"]["ms_per_step"], 4)      # (extension: conv weights train too)
             cb = rec.get("cpu_baseline")
             if cb and cb.get("value"):
-                e["cpu_samples_per_s"] = round(cb["value"], 1)
+                e["cpu_sps"] = round(cb["value"], 1)      # CPU baseline, samples/s
             w[rec["workload"]] = e
         out["workloads"] = w
     rf = full.get("roofline")
