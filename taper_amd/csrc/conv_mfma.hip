@@ -1144,6 +1144,27 @@ int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c
     return th_free(ctx, tmp);
 }
 
+// images x rows per pixel block of the weight-gradient kernel: the tiling of <= 128 pixels by whole output rows that takes the fewest
+// 4-pixel reduction steps per image (the kernel's steps stop at the block's pixels) -- 14 x 14: two bands of 7 rows = 2 x 25 steps, where
+// the forward's fullest-tile plan (9 + 5 rows) takes 2 x 32; taller bands on ties (less halo re-read)
+static void conv_wgrad_plan(int h_out, int w_out, int n, int *img_t, int *rows_t) {
+    long best = -1;
+    *img_t = 1;
+    *rows_t = 1;
+    for (int r = 1; r <= h_out; ++r) {
+        if (r * w_out > MF_PX_MAX) break;
+        int im = std::min(n, MF_PX_MAX / (r * w_out));
+        im = std::min(im, 512 / ((r + 2) * (w_out + 2)));      // a channel's staged chunk: <= 512 floats (two per thread)
+        if (im < 1) continue;
+        const long cost = (long)ceil_div(h_out, r) * ceil_div(im * r * w_out, 4) * 1000 / im;
+        if (best < 0 || cost <= best) {
+            best = cost;
+            *img_t = im;
+            *rows_t = r;
+        }
+    }
+}
+
 int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
                               int pad, int layout, int accumulate) {
     ConvWgradArgs a{};
@@ -1151,7 +1172,7 @@ int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, floa
     a.n = n; a.c_in = c_in; a.h = h; a.w_in = w_in; a.c_out = c_out; a.pad = pad;
     a.h_out = h + 2 * pad - 2;
     a.w_out = w_in + 2 * pad - 2;
-    conv_mfma_plan(a.h_out, a.w_out, n, &a.img_t, &a.rows_t);
+    conv_wgrad_plan(a.h_out, a.w_out, n, &a.img_t, &a.rows_t);
     a.bands = ceil_div(a.h_out, a.rows_t);
     a.n_pb = ceil_div(n, a.img_t) * a.bands;
     const int co_tiles = ceil_div(c_out, 16);
