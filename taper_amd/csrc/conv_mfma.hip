@@ -977,25 +977,35 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
 //   B operand (4 px x 16 co): lane l -> gyL[co0 + (l&15)][px0 + (l>>4)]
 constexpr int WG_CI = 16;                 // input channels per slab
 constexpr int WG_KT = WG_CI * 9 / 16;     // 9 k-tiles
-constexpr int WG_GP = MF_PX_MAX + 1;      // odd pitch of the gy tile: conflict-free column reads
+constexpr int WG_GP = MF_PX_MAX + 2;      // pitch of the gy tile, 2 (mod 32): a half wave (16 channels x 2 pixels) reads 32 distinct banks
+// A channel's LDS pitch: the smallest value >= its chunk that is 2 (mod 32).  The A operand of k-tile `tap` is one dword per lane at
+// channel (lane & 15) * pitch + pixel (lane >> 4) + the tap's offset: with the 16 rows of a k-tile being 16 CHANNELS of one tap, a half
+// wave's 32 lanes (16 channels x 2 consecutive pixels) land on banks 2 c + p -- all 32 distinct.  (r04, k = (channel, tap) in one index:
+// a k-tile's rows mixed taps of two channels, rows 0 and 2 of a 16-wide padded window share their banks: 4-6 cycles per read instead of
+// 2, and with 9 such reads per 9 MFMAs from each of 8 waves the LDS was as busy as the matrix pipes.)
+__host__ __device__ constexpr int wg_cpitch(int chunk) { return chunk + ((2 - chunk % 32) + 32) % 32; }
 
 struct ConvWgradArgs {
     const float *x, *gy;
     float *part;           // [G][9*c_in][co_ld]
     int n, c_in, h, w_in, c_out, pad, h_out, w_out;
     int img_t, rows_t, bands, n_pb, G, co_ld;
+    unsigned x_bytes, gy_bytes;   // extents of x / gy: the ranges of the kernel's buffer descriptors
 };
 
-template <int CT>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a) {
+// PQ: patch elements per thread and channel (1 when a channel's chunk is <= 256 floats -- every batch-256 layer of the CNNs --, else 2).
+// Two workgroups per CU (launch bounds: <= 256 registers): one's LDS stores and barriers run under the other's MFMAs.
+template <int CT, int PQ>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CO_B = 16 * CT, NPAIR = WG_KT * CT, SLOTS = (NPAIR + 3) / 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l16 = lane & 15, g4 = lane >> 4;
     const int wp = a.w_out + 2, rp = a.rows_t + 2;
-    const int img_stride = rp * wp, ci_stride = a.img_t * img_stride;       // <= 384
-    float *patch = lds;                                                        // [16][img_t][rp][wp]
-    float *gyl = lds + WG_CI * ci_stride;                                      // [CO_B][WG_GP]
+    const int img_stride = rp * wp, ci_stride = a.img_t * img_stride;       // <= 512
+    const int cpitch = wg_cpitch(ci_stride);                                   // channel pitch in LDS: == 2 (mod 32), see the A operand below
+    float *patch = lds;                                                        // [16][cpitch] >= [16][img_t][rp][wp]
+    float *gyl = lds + WG_CI * cpitch;                                         // [CO_B][WG_GP]
     int *pixoff = reinterpret_cast<int *>(gyl + CO_B * WG_GP);                 // [128]
     const int cb = blockIdx.y * WG_CI, co0 = blockIdx.z * CO_B;
     const int px_per_img = a.rows_t * a.w_out, m_wg = a.img_t * px_per_img;
@@ -1009,9 +1019,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a
         pixoff[t] = il * img_stride + (rem / a.w_out) * wp + rem % a.w_out;
     }
     // patch element q (within one channel's [img_t][rp][wp] chunk), two per thread
-    int pq_rel[2], pq_meta[2];            // meta = il | rr << 8 | col_ok << 16 | present << 17
+    int pq_rel[PQ], pq_meta[PQ];          // meta = il | rr << 8 | col_ok << 16 | present << 17
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < PQ; ++u) {
         const int q = t + 256 * u;
         pq_rel[u] = 0;
         pq_meta[u] = 0;
@@ -1037,56 +1047,57 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a
         slot_ok[j] = p < NPAIR;
         const int ct = slot_ok[j] ? p / WG_KT : ct_lo, kt = slot_ok[j] ? p % WG_KT : 0;
         slot_hi[j] = ct != ct_lo;
-        const int k = kt * 16 + l16, cl = k / 9, tap = k % 9;
-        koffk[j] = cl * ci_stride + (tap / 3) * wp + tap % 3;
+        koffk[j] = l16 * cpitch + (kt / 3) * wp + kt % 3;     // k-tile kt = tap kt of the slab's 16 channels (row l16 = channel)
     }
     floatx4 acc[SLOTS];
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int n_steps = (m_wg + 3) / 4;
-    for (int pb = blockIdx.x; pb < a.n_pb; pb += a.G) {
+    // The blocks are software-pipelined through registers: block pb + G's input patch and gradient tile are REQUESTED (one batch of buffer
+    // loads: an element outside the image, the batch or the channel range gets an offset past the buffer and reads as 0 -- no branch per
+    // load) before block pb's reduction steps and stored to LDS after them, so a block's global round trip runs under the previous block's
+    // matrix work instead of in front of its own.
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.gy, 0, a.gy_bytes, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    float vp[16][PQ], vg[CO_B / 2];
+    auto request = [&](int pb) {
         const int grp = pb / a.bands, band = pb % a.bands;
         const int img0 = grp * a.img_t, oh0 = band * a.rows_t;
         const int rows_here = min(a.rows_t, a.h_out - oh0);
+        const int xb = (img0 * a.c_in + cb) * (int)chan + oh0 * a.w_in;
+        int xo[PQ];
+#pragma unroll
+        for (int u = 0; u < PQ; ++u) {
+            const int meta = pq_meta[u];
+            const int il = meta & 255, rr = (meta >> 8) & 255, ih = oh0 + rr - 1 + shift;
+            const bool ok = (meta >> 16 & 1) && ih >= 0 && ih < a.h && img0 + il < a.n;
+            xo[u] = ok ? (xb + pq_rel[u]) * 4 : OOB;
+        }
+#pragma unroll
+        for (int cl = 0; cl < 16; ++cl)
+#pragma unroll
+            for (int u = 0; u < PQ; ++u)
+                vp[cl][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (cb + cl < a.c_in) ? xo[u] : OOB, cl * (int)chan * 4, 0));
+        const bool pok = gp < m_wg && g_r < rows_here && img0 + g_il < a.n;
+        const int go = pok ? (((img0 + g_il) * a.c_out + co0 + gpar) * (int)ochan + (oh0 + g_r) * a.w_out + g_c) * 4 : OOB;
+#pragma unroll
+        for (int i = 0; i < CO_B / 2; ++i)
+            vg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (co0 + 2 * i + gpar < a.c_out) ? go : OOB, 2 * i * (int)ochan * 4, 0));
+    };
+    const int n_steps = (m_wg + 3) / 4;
+    if ((int)blockIdx.x < a.n_pb) request(blockIdx.x);
+    for (int pb = blockIdx.x; pb < a.n_pb; pb += a.G) {
         __syncthreads();   // the previous block's MFMAs are done with patch / gyl (and pixoff is written)
-        // ---- stage the 16-channel input patch (zero halo / tails), 8 channels per batch of loads ----
-        const float *xb = a.x + ((long)img0 * a.c_in + cb) * chan + (long)oh0 * a.w_in;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float v[8][2];
+        for (int cl = 0; cl < 16; ++cl)
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8)
+            for (int u = 0; u < PQ; ++u)
+                if (pq_meta[u] >> 17 & 1) patch[cl * cpitch + t + 256 * u] = vp[cl][u];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int cl = half * 8 + c8, meta = pq_meta[u];
-                    const int il = meta & 255, rr = (meta >> 8) & 255, ih = oh0 + rr - 1 + shift;
-                    const bool ok = (meta >> 16 & 1) && ih >= 0 && ih < a.h && img0 + il < a.n && cb + cl < a.c_in;
-                    v[c8][u] = ok ? xb[(long)cl * chan + pq_rel[u]] : 0.f;
-                }
-#pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (pq_meta[u] >> 17 & 1) patch[(half * 8 + c8) * ci_stride + t + 256 * u] = v[c8][u];
-        }
-        // ---- stage gy[co_b][128 px] (zero for pixels outside this block / image range) ----
-        {
-            const bool pok = gp < m_wg && g_r < rows_here && img0 + g_il < a.n;
-            const float *gb = a.gy + ((long)(img0 + g_il) * a.c_out + co0) * ochan + (long)(oh0 + g_r) * a.w_out + g_c;
-#pragma unroll
-            for (int b0 = 0; b0 < CO_B / 2; b0 += 8) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int co = 2 * (b0 + i) + gpar;
-                    v[i] = (pok && co0 + co < a.c_out) ? gb[(long)co * ochan] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) gyl[(2 * (b0 + i) + gpar) * WG_GP + gp] = v[i];
-            }
-        }
+        for (int i = 0; i < CO_B / 2; ++i) gyl[(2 * i + gpar) * WG_GP + gp] = vg[i];
         __syncthreads();
+        if (pb + a.G < a.n_pb) request(pb + a.G);
         // ---- reduction steps of 4 pixels (pixels past m_wg are zero columns: their steps would add nothing) ----
 #pragma unroll 4
         for (int rs = 0; rs < n_steps; ++rs) {
@@ -1111,8 +1122,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_mfma_kernel(ConvWgradArgs a
         const int co = co0 + ct * 16 + l16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = cb * 9 + kt * 16 + 4 * g4 + i;
-            if (k < a.c_in * 9 && co < a.co_ld) pp[(long)k * a.co_ld + co] = acc[j][i];
+            const int ch = cb + 4 * g4 + i;                // D row = channel 4 g4 + i of the slab, tile = tap kt
+            if (ch < a.c_in && co < a.co_ld) pp[(long)(ch * 9 + kt) * a.co_ld + co] = acc[j][i];
         }
     }
 }
@@ -1180,7 +1191,9 @@ int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, floa
     const int co_b = ct * 16;
     const int slabs = ceil_div(c_in, WG_CI), co_blocks = ceil_div(c_out, co_b);
     a.co_ld = co_blocks * co_b;
-    int G = ceil_div(512, slabs * co_blocks);           // 2 workgroups per CU in total (LDS: 58 KB each)
+    // workgroups per CU in total (LDS: <= 58 KB each): two -- TAPER_WGRAD_WGS = 1 .. 4 (measurement knob)
+    static const int wgs = [] { const char *e = getenv("TAPER_WGRAD_WGS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 4 ? v : 2; }();
+    int G = ceil_div(wgs * kNumCU, slabs * co_blocks);
     if (G > a.n_pb) G = a.n_pb;
     if (G > 512) G = 512;
     a.G = G;
@@ -1190,17 +1203,25 @@ int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, floa
     a.part = (float *)ws;
     const size_t ci_stride = (size_t)a.img_t * (a.rows_t + 2) * (a.w_out + 2);
     TH_REQUIRE(ci_stride <= 512, "conv3x3_wgrad: patch chunk too large");
-    const size_t lds = (WG_CI * ci_stride + (size_t)co_b * WG_GP) * sizeof(float) + MF_PX_MAX * sizeof(int);
+    const size_t xb = (size_t)n * c_in * h * w_in * 4, gb = (size_t)n * c_out * a.h_out * a.w_out * 4;
+    TH_REQUIRE(xb < (1u << 31) && gb < (1u << 31), "conv3x3_wgrad: maps of 2 GiB and more are not supported");
+    a.x_bytes = (unsigned)xb;
+    a.gy_bytes = (unsigned)gb;
+    const size_t lds = (WG_CI * (size_t)wg_cpitch((int)ci_stride) + (size_t)co_b * WG_GP) * sizeof(float) + MF_PX_MAX * sizeof(int);
     dim3 grid(G, slabs, co_blocks);
+#define TH_WG(CT_, PQ_)                                                                                                                  \
+    do {                                                                                                                                \
+        auto kern = conv3x3_wgrad_mfma_kernel<CT_, PQ_>;                                                                                \
+        if (lds > (64u << 10)) TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);                                                                 \
+    } while (0)
+    const bool one = ci_stride <= 256;
     switch (ct) {
-        case 4: {
-            auto kern = conv3x3_wgrad_mfma_kernel<4>;
-            if (lds > (64u << 10)) TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);
-        } break;
-        case 2: hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<2>, grid, dim3(256), lds, ctx->stream, a); break;
-        default: hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<1>, grid, dim3(256), lds, ctx->stream, a); break;
+        case 4: if (one) TH_WG(4, 1); else TH_WG(4, 2); break;
+        case 2: if (one) TH_WG(2, 1); else TH_WG(2, 2); break;
+        default: if (one) TH_WG(1, 1); else TH_WG(1, 2); break;
     }
+#undef TH_WG
     TH_LAUNCH_CHECK();
     if (int rc = wgrad_reduce(ctx, a.part, gw, G, kt, c_out, a.co_ld, layout, accumulate)) return rc;
     return th_free(ctx, ws);
