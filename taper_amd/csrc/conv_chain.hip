@@ -69,8 +69,12 @@ struct ConvChainArgs {
 // (waves w and w + 4 share a SIMD).  Same per-output k order as one tile per wave: the sums do not depend on the mapping.
 template <int S, int C_OUT> struct ChainGeo {
     static constexpr int WP = S + 2, CIS = ch_cis(WP), PX = S * S, NPT = (PX + 15) / 16, NCT = C_OUT / 16;
-    static_assert((NCT == 2 && NPT == 49) || (NCT == 4 && NPT == 13) || (NCT == 8 && NPT == 4), "the compiled tile mappings");
-    static constexpr int ND = NCT == 2 ? 6 : (NCT == 4 ? 3 : 2), NS = NCT == 2 ? 2 : (NCT == 4 ? 4 : 0);   // doubles per wave; waves with a single
+    // (+ two mappings for input gradients, conv_layer_chain_kernel<.., LIN>: 14x14 with 32 channels = 13 x 2 tiles -> 2 doubles per wave
+    // (pixel tiles w, w + 8; tiles past 12 are dead: computed on pixel 0, never stored); 7x7 with 64 channels = 4 x 4 tiles -> 1 double per wave)
+    static_assert((NCT == 2 && NPT == 49) || (NCT == 4 && NPT == 13) || (NCT == 8 && NPT == 4) || (NCT == 2 && NPT == 13) || (NCT == 4 && NPT == 4),
+                  "the compiled tile mappings");
+    static constexpr int ND = NCT == 2 ? (NPT == 49 ? 6 : 2) : (NCT == 4 ? (NPT == 13 ? 3 : 1) : 2);                 // doubles per wave
+    static constexpr int NS = NCT == 2 ? (NPT == 49 ? 2 : 0) : (NCT == 4 ? (NPT == 13 ? 4 : 0) : 0);                 // waves with a single
     static constexpr int NSLOT = 2 * ND + (NS ? 1 : 0), STILE = NPT - 1;
     __device__ static int chA(int w) { return NCT == 2 ? (w & 1) : (NCT == 4 ? 2 * (w & 1) + ((w >> 1) & 1) : 2 * (w & 3)); }
     __device__ static int chB(int w) { return NCT == 2 ? (w & 1) ^ 1 : (NCT == 4 ? 2 * (w & 1) + (((w >> 1) & 1) ^ 1) : 2 * (w & 3) + 1); }
@@ -145,7 +149,7 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
     constexpr bool HAS_NEXT = NEXT_COUT != 0;
     using G2 = ChainGeo<HAS_NEXT ? NEXT_S : S, HAS_NEXT ? NEXT_COUT : C_OUT>;
     constexpr int WP = G::WP, CIS = G::CIS, ND = G::ND, NP = ND + (G::NS ? 1 : 0), KS = 18, CO2 = HAS_NEXT ? NEXT_COUT : C_OUT;
-    static_assert(C_IN % 16 == 0 && ND >= 2, "whole pairs of 8-channel passes; two pairs of MFMAs per k-step to put the weight requests behind");
+    static_assert(C_IN % 16 == 0 && ND >= 1, "whole pairs of 8-channel passes");   // (ND == 1: both weight requests of a k-step sit behind its one pair)
     const int l16 = lane & 15, g4 = lane >> 4;
 #ifdef CH_PROBE_HS   /* timing probe: every wave (1) / no wave (0) runs the single tile, as a compile-time constant (wrong results) */
     constexpr bool hs = CH_PROBE_HS != 0;
@@ -192,7 +196,7 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
                 __builtin_amdgcn_sched_barrier(0);                                                                                           \
                 if (s + 1 < KS) CH_REQ1(b1, s + 1, i)                                                                                        \
                 if (i == 0) CH_WREQ(WNXT.a[s], RS, VA, (SOBASE) + ((4 * (s / 9)) * 9 + s % 9) * (ROWB))                                      \
-                if (i == 1) CH_WREQ(WNXT.b[s], RS, VB, (SOBASE) + ((4 * (s / 9)) * 9 + s % 9) * (ROWB))                                      \
+                if (i == (ND > 1 ? 1 : 0)) CH_WREQ(WNXT.b[s], RS, VB, (SOBASE) + ((4 * (s / 9)) * 9 + s % 9) * (ROWB))                       \
                 __builtin_amdgcn_sched_barrier(0);                                                                                           \
             }                                                                                                                                \
             if (G::NS && HS) {                                                                                                               \
@@ -776,15 +780,18 @@ __device__ __forceinline__ void layer_load_planes(const float *__restrict__ xi, 
     }
 }
 
-template <int S, int C_IN, int C_OUT, int POST>
+// LIN (POST 0 only): the map is the plain sum -- no bias, no ReLU: the INPUT GRADIENT of a 3x3 layer, whose mirrored, channel-swapped filter
+// th_conv3x3_bwd_input has laid out as a taper slab (full_backward extension)
+template <int S, int C_IN, int C_OUT, int POST, bool LIN = false>
 __global__ __launch_bounds__(CH_NT, 1) void conv_layer_chain_kernel(LayerChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using G = ChainGeo<S, C_OUT>;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
     float *A = lds, *T = lds;                    // the output tile overlays the input planes once every wave is past the k loop
+    static_assert(!LIN || POST == 0, "the linear form writes the map");
     ChainBias bv;
-    chain_bias<S, C_OUT>(a.b, bv, wave, lane);
+    chain_bias<S, C_OUT>(LIN ? nullptr : a.b, bv, wave, lane);
     if (POST == 0) chain_zero_halo<S, C_IN>(A, wave, lane);             // (the map goes to memory: nothing ever overwrites the halo)
     CH_SPAN(0);
     for (int img = blockIdx.x; img < a.n; img += gridDim.x) {
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_layer_chain_kernel(LayerChainAr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = acc[k][e] + (second ? bv.b[e] : bv.a[e]);
-                    o[e * G::PX] = v > 0.f ? v : 0.f;
+                    o[e * G::PX] = LIN ? acc[k][e] : (v > 0.f ? v : 0.f);
                 }
             }
             chain_sync();                                               // the next image's planes overwrite A
@@ -1333,23 +1340,35 @@ namespace th {
 // th_conv3x3_fwd / _pool2_fwd / _gap_fwd (conv_mfma.hip: conv3x3_mfma_launch) ask here first.  1: launched; 0: not one of the compiled geometries
 // (or fewer images than half the CUs: one image per workgroup); -1: error
 int conv_layer_chain_launch(th_ctx *ctx, const float *x, const float *w, const float *bias, float *y, float *cnt, int n, int c_in, int hw, int c_out,
-                            int post) {
+                            int post, bool linear) {
     if (n < kNumCU / 2) return 0;
     LayerChainArgs a{x, w, bias, y, cnt, n};
     const dim3 grid(n < kNumCU ? n : kNumCU);
-#define TH_LC(S_, CI_, CO_, P_)                                                                                                          \
+#define TH_LC_(S_, CI_, CO_, P_, L_)                                                                                                     \
     do {                                                                                                                                 \
         constexpr int fl = (CI_ * ch_cis(S_ + 2) > CO_ * ch_tile_ld(S_ * S_) ? CI_ * ch_cis(S_ + 2) : CO_ * ch_tile_ld(S_ * S_));         \
-        (void)hipFuncSetAttribute((const void *)conv_layer_chain_kernel<S_, CI_, CO_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, fl * 4); \
-        hipLaunchKernelGGL((conv_layer_chain_kernel<S_, CI_, CO_, P_>), grid, dim3(CH_NT), fl * 4, ctx->stream, a);                       \
+        (void)hipFuncSetAttribute((const void *)conv_layer_chain_kernel<S_, CI_, CO_, P_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, fl * 4); \
+        hipLaunchKernelGGL((conv_layer_chain_kernel<S_, CI_, CO_, P_, L_>), grid, dim3(CH_NT), fl * 4, ctx->stream, a);                   \
         if (hipGetLastError() != hipSuccess) return -1;                                                                                  \
         return 1;                                                                                                                        \
     } while (0)
+#define TH_LC(S_, CI_, CO_, P_) TH_LC_(S_, CI_, CO_, P_, false)
+    if (linear) {
+        // input gradients (no bias, no ReLU, the map written) of the four batch-256 layers: 64 -> 32 @14 and 128 -> 64 @7 ran at half their
+        // forward rate in the image-resident kernel (36 us each: 23.0 / 21.5 here)
+        if (post != 0) return 0;
+        if (hw == 14 && c_in == 64 && c_out == 32) TH_LC_(14, 64, 32, 0, true);
+        if (hw == 7 && c_in == 128 && c_out == 64) TH_LC_(7, 128, 64, 0, true);
+        if (hw == 28 && c_in == 32 && c_out == 32) TH_LC_(28, 32, 32, 0, true);
+        if (hw == 14 && c_in == 64 && c_out == 64) TH_LC_(14, 64, 64, 0, true);
+        return 0;
+    }
     if (hw == 28 && c_in == 32 && c_out == 32) { if (post == 0) TH_LC(28, 32, 32, 0); if (post == 1) TH_LC(28, 32, 32, 1); }
     if (hw == 14 && c_in == 32 && c_out == 64) { if (post == 0) TH_LC(14, 32, 64, 0); if (post == 1) TH_LC(14, 32, 64, 1); }
     if (hw == 14 && c_in == 64 && c_out == 64) { if (post == 0) TH_LC(14, 64, 64, 0); if (post == 1) TH_LC(14, 64, 64, 1); }
     if (hw == 7 && c_in == 64 && c_out == 128) { if (post == 0) TH_LC(7, 64, 128, 0); if (post == 2) TH_LC(7, 64, 128, 2); }
 #undef TH_LC
+#undef TH_LC_
     return 0;
 }
 }  // namespace th

@@ -818,7 +818,7 @@ int g_conv_img_mode = getenv("TAPER_CONV_IMG") ? atoi(getenv("TAPER_CONV_IMG")) 
 // TAPER_CONV_LAYER_CHAIN=0: the four compiled layer geometries keep the image-resident kernel (measurement probe)
 static const bool g_conv_layer_chain = !(getenv("TAPER_CONV_LAYER_CHAIN") && getenv("TAPER_CONV_LAYER_CHAIN")[0] == '0');
 int conv_layer_chain_launch(th_ctx *ctx, const float *x, const float *w, const float *bias, float *y, float *cnt, int n, int c_in, int hw, int c_out,
-                            int post);   // conv_chain.hip
+                            int post, bool linear);   // conv_chain.hip
 
 // launch configuration of this thread's most recent matrix-core convolution (th_debug_last_conv_config)
 thread_local int t_last_conv_cfg[6] = {0, 0, 0, 0, 0, 0};
@@ -833,8 +833,10 @@ int conv3x3_mfma_launch(th_ctx *ctx, const float *x, const float *w, int w_ld, i
     TH_REQUIRE(w_ld % 4 == 0 && ((uintptr_t)w & 15) == 0, "conv3x3_mfma: weight rows must be 16-byte aligned");
     // the batch-256 layers of the reference CNN as one-stage chains (conv_chain.hip: conv_layer_chain_kernel; same bits): the taper slab read in
     // place, ReLU on, pad 1, default kernel choice only (th_debug_set_conv_img forces the kernels below)
-    if (g_conv_img_mode == -1 && g_conv_layer_chain && !accum && relu && pad == 1 && h == w_in && w_ld == c_out && w_cols == c_out) {
-        const int rc = conv_layer_chain_launch(ctx, x, w, bias, y, gap ? gap_cnt : nullptr, n, c_in, h, c_out, gap ? 2 : (pool ? 1 : 0));
+    // (+ the plain sum -- no bias, no ReLU: an input gradient -- for the shapes conv_layer_chain_launch lists)
+    const bool lin = !relu && !bias && !pool && !gap;
+    if (g_conv_img_mode == -1 && g_conv_layer_chain && !accum && (relu || lin) && pad == 1 && h == w_in && w_ld == c_out && w_cols == c_out) {
+        const int rc = conv_layer_chain_launch(ctx, x, w, bias, y, gap ? gap_cnt : nullptr, n, c_in, h, c_out, gap ? 2 : (pool ? 1 : 0), lin);
         if (rc < 0) { th::set_error("conv_layer_chain_kernel: launch failed"); return 1; }
         if (rc == 1) {
             t_last_conv_cfg[0] = c_out / 16; t_last_conv_cfg[1] = 8; t_last_conv_cfg[2] = 8;   // 8: one layer through the chain's compiled mapping

@@ -431,7 +431,8 @@ def test_conv1x1_taper_layout(ctx, O, n, c_in, h, w, c_out):
                                               # >= 2048 output pixels and C_in >= 8: the matrix-core weight-gradient kernel
                                               (12, 16, 14, 14, 24), (4, 40, 28, 28, 70), (50, 9, 7, 7, 16), (3, 32, 28, 28, 32),
                                               (16, 1, 28, 28, 32), (11, 3, 30, 30, 5),    # few channel pairs, many pixels: image slabs
-                                              (40, 1, 28, 28, 32), (33, 1, 32, 32, 16), (32, 1, 9, 7, 40)])   # one input channel, >= 32 images: an image per workgroup (conv1_wgrad_kernel)
+                                              (40, 1, 28, 28, 32), (33, 1, 32, 32, 16), (32, 1, 9, 7, 40),    # one input channel, >= 32 images: an image per workgroup (conv1_wgrad_kernel)
+                                              (130, 32, 14, 14, 64), (129, 64, 7, 7, 128), (128, 32, 28, 28, 32), (131, 64, 14, 14, 64)])   # >= 128 images: the input gradient as a one-stage chain (conv_layer_chain_kernel<.., LIN>)
 @pytest.mark.parametrize("layout", [0, 1])
 def test_conv3x3_bwd_full_mode(ctx, O, n, c_in, h, w, c_out, layout):
     """full_backward extension (not in the reference, Q2): checked against the oracle's
