@@ -19,7 +19,7 @@ rm -rf "$OUT/trace"          # the raw trace is large; the stats summary is what
 
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 150 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -- \
-        python $ROOT/bench.py --gpus 1 --steps 192 --warmup 32 --no-cpu-baseline > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err"
+        python $ROOT/bench.py --gpus 1 --steps 192 --warmup 32 --no-cpu-baseline --no-sweep --workloads none > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err"
     python $ROOT/tools/summarize_pmc.py "$OUT/pmc_$c" $c > "$OUT/pmc_$c.summary.csv"
     rm -rf "$OUT/pmc_$c"
 done
