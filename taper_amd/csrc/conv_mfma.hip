@@ -1157,6 +1157,151 @@ int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c
     return th_free(ctx, tmp);
 }
 
+// ---- weight gradient, image-resident form (batch >= 128 on the 14 x 14 / 7 x 7 layers) ----------------------------------------------------
+// The kernel above walks 128-pixel blocks of 16-channel slabs: every (block, slab) pair re-stages its gradient tile, a wave issues one
+// gathered LDS read per MFMA, and a 14 x 14 image is two blocks.  Here a workgroup of eight waves owns IMAGES: the image's C_IN padded input
+// planes and its C_OUT gradient planes sit in LDS whole (pitches 2 (mod 32): a half wave = 16 channels x 2 pixels reads 32 distinct banks),
+// and a wave owns the 9 taps x CTW channel tiles of one 16-channel group -- per 4-pixel step 9 + CTW operand reads feed 9 CTW MFMAs
+// (11 reads / 18 MFMAs at CTW = 2, 13 / 36 at CTW = 4; the slab kernel: 10 / 9).  Waves: (channel group) x (block of CTW channel tiles) x
+// (PS pixel-step classes, added through LDS at the end).  A workgroup adds IPW images in its registers and writes ONE slab
+// [9 C_IN][C_OUT] (taper layout); wgrad_reduce adds the slabs in order.  Same MFMA, same per-image pixel order within a step class.
+__host__ __device__ constexpr int wi_pitch2(int v) { return v + ((2 - v % 32) + 32) % 32; }
+struct WgradImgArgs {
+    const float *x, *gy;   // [n][C_IN][S][S], [n][C_OUT][S][S]
+    float *part;           // [gridDim.x][9 C_IN][C_OUT]
+    int n, ipw;            // images per workgroup
+};
+template <int S, int C_IN, int C_OUT, int CTW, int PS>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_img_kernel(WgradImgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int WP = S + 2, PX = S * S, NSTEP = (PX + 3) / 4, XPITCH = wi_pitch2(WP * WP), GPITCH = wi_pitch2(4 * NSTEP);
+    constexpr int NG = C_IN / 16, NCB = C_OUT / 16 / CTW;
+    static_assert(NG * NCB * PS == 8 && C_IN % 16 == 0 && C_OUT % (16 * CTW) == 0, "eight waves: channel groups x channel-tile blocks x step classes");
+    float *xp = lds, *gp = lds + C_IN * XPITCH;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
+    const int g = wave % NG, cb = (wave / NG) % NCB, ps = wave / (NG * NCB);
+    // halos and the pixel columns past the image are zero for the whole launch: the interiors are overwritten image by image
+    for (int e = t; e < C_IN * XPITCH + C_OUT * GPITCH; e += 512) lds[e] = 0.f;
+    floatx4 acc[9][CTW];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < CTW; ++j) acc[k][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const float *arow = xp + (g * 16 + l16) * XPITCH;
+    const float *brow = gp + (cb * CTW * 16 + l16) * GPITCH;
+    const int img0 = blockIdx.x * a.ipw, img1 = min(a.n, img0 + a.ipw);
+    for (int img = img0; img < img1; ++img) {
+        __syncthreads();                                 // the previous image's steps are done with the planes (and the zeros are in place)
+        {
+            constexpr int U = 7;
+            const float *xi = a.x + (long)img * C_IN * PX;
+            for (int e0 = t; e0 < C_IN * PX; e0 += 512 * U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int e = e0 + 512 * u; v[u] = e < C_IN * PX ? xi[e] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + 512 * u;
+                    if (e < C_IN * PX) { const int c = e / PX, rem = e - c * PX, r = rem / S, q = rem - r * S; xp[c * XPITCH + (r + 1) * WP + q + 1] = v[u]; }
+                }
+            }
+            const float *gi = a.gy + (long)img * C_OUT * PX;
+            for (int e0 = t; e0 < C_OUT * PX; e0 += 512 * U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int e = e0 + 512 * u; v[u] = e < C_OUT * PX ? gi[e] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + 512 * u;
+                    if (e < C_OUT * PX) { const int c = e / PX; gp[c * GPITCH + e - c * PX] = v[u]; }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int step = ps; step < NSTEP; step += PS) {
+            const int p = 4 * step + g4, pc = p < PX ? p : PX - 1;        // (a column past the image: its gradient is 0)
+            const int r = pc / S, ao = r * WP + (pc - r * S);
+            float av[9], bv[CTW];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) av[k] = arow[ao + (k / 3) * WP + k % 3];
+#pragma unroll
+            for (int j = 0; j < CTW; ++j) bv[j] = brow[j * 16 * GPITCH + p];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int j = 0; j < CTW; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[j], acc[k][j], 0, 0, 0);
+        }
+    }
+    if (PS > 1) {
+        // the step classes' sums through LDS (over the planes: every wave is past its last step), class 1 .. PS - 1 onto class 0 in order
+        __syncthreads();
+        float *red = lds + (wave % (NG * NCB)) * (9 * CTW * 256);
+        for (int q = 1; q < PS; ++q) {
+            if (ps == q) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int j = 0; j < CTW; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) red[((k * CTW + j) * 4 + e) * 64 + lane] = acc[k][j][e];
+            }
+            __syncthreads();
+            if (ps == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int j = 0; j < CTW; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[k][j][e] += red[((k * CTW + j) * 4 + e) * 64 + lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (ps != 0) return;
+    // D tile (tap k, channel tile j): row = channel 4 g4 + e of the group, column = output channel l16 of the tile
+    float *pp = a.part + (long)blockIdx.x * 9 * C_IN * C_OUT;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < CTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                pp[(long)((g * 16 + 4 * g4 + e) * 9 + k) * C_OUT + (cb * CTW + j) * 16 + l16] = acc[k][j][e];
+}
+
+// 1: launched (slabs in *part_out, *n_slabs of them); 0: not one of the compiled shapes / batch too small
+static int conv_wgrad_img_launch(th_ctx *ctx, const float *x, const float *gy, int n, int c_in, int hw, int c_out, float **part_out, int *n_slabs) {
+    static const bool off = getenv("TAPER_WGRAD_IMG") && getenv("TAPER_WGRAD_IMG")[0] == '0';   // measurement / parity knob
+    if (off || n < kNumCU / 2) return 0;
+    WgradImgArgs a{x, gy, nullptr, n, 1};
+#define TH_WI(S_, CI_, CO_, CTW_, PS_, IPW_)                                                                                              \
+    do {                                                                                                                                 \
+        a.ipw = IPW_;                                                                                                                    \
+        const int grid = ceil_div(n, IPW_);                                                                                              \
+        void *ws = nullptr;                                                                                                              \
+        if (th_malloc(ctx, (size_t)grid * 9 * CI_ * CO_ * sizeof(float), &ws)) return -1;                                                \
+        a.part = (float *)ws;                                                                                                            \
+        constexpr int wp_ = S_ + 2, nst_ = (S_ * S_ + 3) / 4;                                                                            \
+        constexpr int stage_ = CI_ * wi_pitch2(wp_ * wp_) + CO_ * wi_pitch2(4 * nst_), red_ = (PS_ > 1 ? (8 / PS_) * 9 * CTW_ * 256 : 0);  \
+        constexpr int fl_ = stage_ > red_ ? stage_ : red_;                                                                              \
+        static_assert(fl_ * 4 <= (160 << 10), "planes fit the LDS");                                                                    \
+        auto kern = conv_wgrad_img_kernel<S_, CI_, CO_, CTW_, PS_>;                                                                      \
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, fl_ * 4);                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), fl_ * 4, ctx->stream, a);                                                        \
+        if (hipGetLastError() != hipSuccess) return -1;                                                                                  \
+        *part_out = a.part;                                                                                                              \
+        *n_slabs = grid;                                                                                                                 \
+        return 1;                                                                                                                        \
+    } while (0)
+    if (hw == 14 && c_in == 32 && c_out == 64) TH_WI(14, 32, 64, 2, 2, 1);
+    if (hw == 14 && c_in == 64 && c_out == 64) TH_WI(14, 64, 64, 2, 1, 1);
+    // (7 x 7, 64 -> 128, two images per workgroup: built and measured equal to the slab kernel -- 38.1 vs 38.5 us -- with twice the slab
+    // bytes for wgrad_reduce: 49 pixels per image are too few steps for a [576][128] slab per workgroup.  Left to the slab kernel.)
+#undef TH_WI
+    return 0;
+}
+
 // images x rows per pixel block of the weight-gradient kernel: the tiling of <= 128 pixels by whole output rows that takes the fewest
 // 4-pixel reduction steps per image (the kernel's steps stop at the block's pixels) -- 14 x 14: two bands of 7 rows = 2 x 25 steps, where
 // the forward's fullest-tile plan (9 + 5 rows) takes 2 x 32; taller bands on ties (less halo re-read)
@@ -1180,6 +1325,16 @@ static void conv_wgrad_plan(int h_out, int w_out, int n, int *img_t, int *rows_t
 
 int conv3x3_wgrad_mfma_launch(th_ctx *ctx, const float *x, const float *gy, float *gw, int n, int c_in, int h, int w_in, int c_out,
                               int pad, int layout, int accumulate) {
+    if (pad == 1 && h == w_in) {
+        float *part = nullptr;
+        int n_slabs = 0;
+        const int rc = conv_wgrad_img_launch(ctx, x, gy, n, c_in, h, c_out, &part, &n_slabs);
+        if (rc < 0) { th::set_error("conv_wgrad_img_kernel: launch failed"); return 1; }
+        if (rc == 1) {
+            if (int r2 = wgrad_reduce(ctx, part, gw, n_slabs, 9 * c_in, c_out, c_out, layout, accumulate)) return r2;
+            return th_free(ctx, part);
+        }
+    }
     ConvWgradArgs a{};
     a.x = x; a.gy = gy;
     a.n = n; a.c_in = c_in; a.h = h; a.w_in = w_in; a.c_out = c_out; a.pad = pad;
