@@ -1166,61 +1166,110 @@ int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c
 // (PS pixel-step classes, added through LDS at the end).  A workgroup adds IPW images in its registers and writes ONE slab
 // [9 C_IN][C_OUT] (taper layout); wgrad_reduce adds the slabs in order.  Same MFMA, same per-image pixel order within a step class.
 __host__ __device__ constexpr int wi_pitch2(int v) { return v + ((2 - v % 32) + 32) % 32; }
+// BANDS > 1: the image goes through the LDS in BANDS bands of S / BANDS output rows (+ their two halo rows of the input), one after the
+// other, into the same accumulators -- through TWO LDS buffers: band b + 1 is requested (branch-free buffer loads into registers) before
+// band b's steps and stored behind them, so only the first band's round trip is exposed (28 x 28 with 32 + 32 channels: four bands of 7
+// rows, 2 x 66 KB).
 struct WgradImgArgs {
     const float *x, *gy;   // [n][C_IN][S][S], [n][C_OUT][S][S]
     float *part;           // [gridDim.x][9 C_IN][C_OUT]
     int n, ipw;            // images per workgroup
+    unsigned x_bytes, gy_bytes;
 };
-template <int S, int C_IN, int C_OUT, int CTW, int PS>
+template <int S, int C_IN, int C_OUT, int CTW, int PS, int BANDS = 1>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_img_kernel(WgradImgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int WP = S + 2, PX = S * S, NSTEP = (PX + 3) / 4, XPITCH = wi_pitch2(WP * WP), GPITCH = wi_pitch2(4 * NSTEP);
+    static_assert(S % BANDS == 0, "whole bands");
+    constexpr int WP = S + 2, RB = S / BANDS, PX = S * S, PXB = RB * S, NSTEP = (PXB + 3) / 4, XROWS = RB + 2;
+    constexpr int XPITCH = wi_pitch2(XROWS * WP), GPITCH = wi_pitch2(4 * NSTEP), BUF = C_IN * XPITCH + C_OUT * GPITCH, NBUF = BANDS > 1 ? 2 : 1;
     constexpr int NG = C_IN / 16, NCB = C_OUT / 16 / CTW;
     static_assert(NG * NCB * PS == 8 && C_IN % 16 == 0 && C_OUT % (16 * CTW) == 0, "eight waves: channel groups x channel-tile blocks x step classes");
-    float *xp = lds, *gp = lds + C_IN * XPITCH;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
     const int g = wave % NG, cb = (wave / NG) % NCB, ps = wave / (NG * NCB);
-    // halos and the pixel columns past the image are zero for the whole launch: the interiors are overwritten image by image
-    for (int e = t; e < C_IN * XPITCH + C_OUT * GPITCH; e += 512) lds[e] = 0.f;
+    // the halo columns and the pixel columns past a band are zero for the whole launch: everything else is overwritten band by band
+    for (int e = t; e < NBUF * BUF; e += 512) lds[e] = 0.f;
     floatx4 acc[9][CTW];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int j = 0; j < CTW; ++j) acc[k][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const float *arow = xp + (g * 16 + l16) * XPITCH;
-    const float *brow = gp + (cb * CTW * 16 + l16) * GPITCH;
-    const int img0 = blockIdx.x * a.ipw, img1 = min(a.n, img0 + a.ipw);
-    for (int img = img0; img < img1; ++img) {
-        __syncthreads();                                 // the previous image's steps are done with the planes (and the zeros are in place)
-        {
-            constexpr int U = 7;
-            const float *xi = a.x + (long)img * C_IN * PX;
-            for (int e0 = t; e0 < C_IN * PX; e0 += 512 * U) {
-                float v[U];
+    const int aoff = (g * 16 + l16) * XPITCH, boff = C_IN * XPITCH + (cb * CTW * 16 + l16) * GPITCH;
+    // a band's elements, thread by thread: input rows band RB - 1 .. band RB + RB of every channel (rows outside the image read as zeros: an
+    // offset past the descriptor) and the band's gradient rows
+    constexpr int NX = C_IN * XROWS * S, NGY = C_OUT * PXB, UX = (NX + 511) / 512, UG = (NGY + 511) / 512, OOB = 0x7ffffff0;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.gy, 0, a.gy_bytes, 0x00020000);
+    // (one buffer: the whole image at once would be ~50 registers of staging -- it goes through in chunks of seven loads instead)
+    float vx[NBUF == 2 ? UX : 1], vg[NBUF == 2 ? UG : 1];
+    auto stage_direct = [&](int ib) {                  // (NBUF == 1 means BANDS == 1: the band is the image, its halo rows stay zero)
+        const int img = ib;
+        constexpr int U = 7;
+        const float *xi = a.x + (long)img * C_IN * PX;
+        for (int e0 = t; e0 < C_IN * PX; e0 += 512 * U) {
+            float v[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) { const int e = e0 + 512 * u; v[u] = e < C_IN * PX ? xi[e] : 0.f; }
+            for (int u = 0; u < U; ++u) { const int e = e0 + 512 * u; v[u] = e < C_IN * PX ? xi[e] : 0.f; }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = e0 + 512 * u;
-                    if (e < C_IN * PX) { const int c = e / PX, rem = e - c * PX, r = rem / S, q = rem - r * S; xp[c * XPITCH + (r + 1) * WP + q + 1] = v[u]; }
-                }
-            }
-            const float *gi = a.gy + (long)img * C_OUT * PX;
-            for (int e0 = t; e0 < C_OUT * PX; e0 += 512 * U) {
-                float v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) { const int e = e0 + 512 * u; v[u] = e < C_OUT * PX ? gi[e] : 0.f; }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = e0 + 512 * u;
-                    if (e < C_OUT * PX) { const int c = e / PX; gp[c * GPITCH + e - c * PX] = v[u]; }
-                }
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 512 * u;
+                if (e < C_IN * PX) { const int c = e / PX, rem = e - c * PX, r = rem / S, q = rem - r * S; lds[c * XPITCH + (r + 1) * WP + q + 1] = v[u]; }
             }
         }
-        __syncthreads();
+        const float *gi = a.gy + (long)img * C_OUT * PX;
+        for (int e0 = t; e0 < C_OUT * PX; e0 += 512 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = e0 + 512 * u; v[u] = e < C_OUT * PX ? gi[e] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 512 * u;
+                if (e < C_OUT * PX) { const int c = e / PX; lds[C_IN * XPITCH + c * GPITCH + e - c * PX] = v[u]; }
+            }
+        }
+    };
+    auto request = [&](int ib) {
+        if (NBUF == 1) return;
+        const int img = ib / BANDS, band = ib - img * BANDS;
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            const int e = t + 512 * u, c = e / (XROWS * S), rem = e - c * (XROWS * S), rr = rem / S, q = rem - rr * S;
+            const int ir = band * RB + rr - 1;
+            const bool ok = e < NX && ir >= 0 && ir < S;
+            vx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (((img * C_IN + c) * S + ir) * S + q) * 4 : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int e = t + 512 * u, c = e / PXB;
+            vg[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, e < NGY ? ((img * C_OUT + c) * PX + band * PXB + e - c * PXB) * 4 : OOB, 0, 0));
+        }
+    };
+    auto deposit = [&](float *buf) {
+        if (NBUF == 1) return;
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            const int e = t + 512 * u, c = e / (XROWS * S), rem = e - c * (XROWS * S), rr = rem / S, q = rem - rr * S;
+            if (e < NX) buf[c * XPITCH + rr * WP + q + 1] = vx[u];
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int e = t + 512 * u, c = e / PXB;
+            if (e < NGY) buf[C_IN * XPITCH + c * GPITCH + e - c * PXB] = vg[u];
+        }
+    };
+    const int img0 = blockIdx.x * a.ipw, img1 = min(a.n, img0 + a.ipw);
+    const int ib0 = img0 * BANDS, ib1 = img1 * BANDS;
+    int cur = 0;
+    if (ib0 < ib1) request(ib0);
+    __syncthreads();                                     // the zeros are in place
+    if (ib0 < ib1) { if (NBUF == 1) stage_direct(ib0); else deposit(lds); }
+    __syncthreads();
+    for (int ib = ib0; ib < ib1; ++ib) {
+        const bool more = ib + 1 < ib1;
+        if (more) request(ib + 1);
+        const float *arow = lds + cur * BUF + aoff, *brow = lds + cur * BUF + boff;
 #pragma unroll 2
         for (int step = ps; step < NSTEP; step += PS) {
-            const int p = 4 * step + g4, pc = p < PX ? p : PX - 1;        // (a column past the image: its gradient is 0)
+            const int p = 4 * step + g4, pc = p < PXB ? p : PXB - 1;      // (a column past the band: its gradient is 0)
             const int r = pc / S, ao = r * WP + (pc - r * S);
             float av[9], bv[CTW];
 #pragma unroll
@@ -1232,6 +1281,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_img_kernel(WgradImgArgs a) 
 #pragma unroll
                 for (int j = 0; j < CTW; ++j) acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[j], acc[k][j], 0, 0, 0);
         }
+        if (NBUF == 1) __syncthreads();                  // one buffer: every wave is done reading before the next band lands in it
+        if (more) { if (NBUF == 1) stage_direct(ib + 1); else deposit(lds + (cur ^ 1) * BUF); }
+        __syncthreads();
+        if (NBUF == 2) cur ^= 1;
     }
     if (PS > 1) {
         // the step classes' sums through LDS (over the planes: every wave is past its last step), class 1 .. PS - 1 onto class 0 in order
@@ -1274,19 +1327,23 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_img_kernel(WgradImgArgs a) 
 static int conv_wgrad_img_launch(th_ctx *ctx, const float *x, const float *gy, int n, int c_in, int hw, int c_out, float **part_out, int *n_slabs) {
     static const bool off = getenv("TAPER_WGRAD_IMG") && getenv("TAPER_WGRAD_IMG")[0] == '0';   // measurement / parity knob
     if (off || n < kNumCU / 2) return 0;
-    WgradImgArgs a{x, gy, nullptr, n, 1};
-#define TH_WI(S_, CI_, CO_, CTW_, PS_, IPW_)                                                                                              \
+    const size_t xb = (size_t)n * c_in * hw * hw * 4, gb = (size_t)n * c_out * hw * hw * 4;
+    if (xb >= (1u << 31) || gb >= (1u << 31)) return 0;
+    WgradImgArgs a{x, gy, nullptr, n, 1, (unsigned)xb, (unsigned)gb};
+#define TH_WI(S_, CI_, CO_, CTW_, PS_, IPW_) TH_WIB(S_, CI_, CO_, CTW_, PS_, IPW_, 1)
+#define TH_WIB(S_, CI_, CO_, CTW_, PS_, IPW_, NB_)                                                                                        \
     do {                                                                                                                                 \
         a.ipw = IPW_;                                                                                                                    \
         const int grid = ceil_div(n, IPW_);                                                                                              \
         void *ws = nullptr;                                                                                                              \
         if (th_malloc(ctx, (size_t)grid * 9 * CI_ * CO_ * sizeof(float), &ws)) return -1;                                                \
         a.part = (float *)ws;                                                                                                            \
-        constexpr int wp_ = S_ + 2, nst_ = (S_ * S_ + 3) / 4;                                                                            \
-        constexpr int stage_ = CI_ * wi_pitch2(wp_ * wp_) + CO_ * wi_pitch2(4 * nst_), red_ = (PS_ > 1 ? (8 / PS_) * 9 * CTW_ * 256 : 0);  \
+        constexpr int wp_ = S_ + 2, nst_ = ((S_ / NB_) * S_ + 3) / 4;                                                                    \
+        constexpr int stage_ = (NB_ > 1 ? 2 : 1) * (CI_ * wi_pitch2((S_ / NB_ + 2) * wp_) + CO_ * wi_pitch2(4 * nst_)),                     \
+                      red_ = (PS_ > 1 ? (8 / PS_) * 9 * CTW_ * 256 : 0);                                                                \
         constexpr int fl_ = stage_ > red_ ? stage_ : red_;                                                                              \
         static_assert(fl_ * 4 <= (160 << 10), "planes fit the LDS");                                                                    \
-        auto kern = conv_wgrad_img_kernel<S_, CI_, CO_, CTW_, PS_>;                                                                      \
+        auto kern = conv_wgrad_img_kernel<S_, CI_, CO_, CTW_, PS_, NB_>;                                                                 \
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, fl_ * 4);                              \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), fl_ * 4, ctx->stream, a);                                                        \
         if (hipGetLastError() != hipSuccess) return -1;                                                                                  \
@@ -1294,11 +1351,13 @@ static int conv_wgrad_img_launch(th_ctx *ctx, const float *x, const float *gy, i
         *n_slabs = grid;                                                                                                                 \
         return 1;                                                                                                                        \
     } while (0)
-    if (hw == 14 && c_in == 32 && c_out == 64) TH_WI(14, 32, 64, 2, 2, 1);
-    if (hw == 14 && c_in == 64 && c_out == 64) TH_WI(14, 64, 64, 2, 1, 1);
+    if (hw == 14 && c_in == 32 && c_out == 64) TH_WI(14, 32, 64, 2, 2, 1);     // (two pipelined bands: 24.9 vs 24.0 us)
+    if (hw == 14 && c_in == 64 && c_out == 64) TH_WI(14, 64, 64, 2, 1, 1);     // (two pipelined bands: 42.5 vs 39.4 us)
+    if (hw == 28 && c_in == 32 && c_out == 32) TH_WIB(28, 32, 32, 2, 4, 1, 4);
     // (7 x 7, 64 -> 128, two images per workgroup: built and measured equal to the slab kernel -- 38.1 vs 38.5 us -- with twice the slab
     // bytes for wgrad_reduce: 49 pixels per image are too few steps for a [576][128] slab per workgroup.  Left to the slab kernel.)
 #undef TH_WI
+#undef TH_WIB
     return 0;
 }
 
