@@ -1143,10 +1143,51 @@ __global__ __launch_bounds__(256) void wgrad_scatter_kernel(const float *__restr
     }
 }
 
+// gw[c] (+)= sum over the G slabs of part[g][c], c < cols (a multiple of 4): a thread owns four consecutive columns and one of eight row
+// classes (slabs r, r + 8, ...: eight 16-byte loads in flight, added in ascending order), the eight classes are added in order through LDS.
+// Deterministic.  (th_colsum's one dword per lane and two loads in flight per wave: 15 us for the 38 MB of the 64 -> 64 layer's 256 slabs.)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ part, float *__restrict__ gw, int G, int cols, int accumulate) {
+    __shared__ float4 sh[8][32];
+    const int q = threadIdx.x & 31, rc = threadIdx.x >> 5;
+    const long c4 = ((long)blockIdx.x * 32 + q) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < cols) {
+        int g = rc;
+        for (; g + 56 < G; g += 64) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(part + (long)(g + 8 * u) * cols + c4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; g < G; g += 8) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + (long)g * cols + c4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[rc][q] = s;
+    __syncthreads();
+    if (rc == 0 && c4 < cols) {
+#pragma unroll
+        for (int u = 1; u < 8; ++u) { const float4 v = sh[u][q]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        float4 *o = reinterpret_cast<float4 *>(gw + c4);
+        if (accumulate) { const float4 p = *o; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+        *o = s;
+    }
+}
+
 // part: [G][kt][co_ld] partial slabs -> gw
 int wgrad_reduce(th_ctx *ctx, const float *part, float *gw, int G, int kt, int c_out, int co_ld, int layout, int accumulate) {
     // taper layout and unpadded channel rows: the ordered sum of the slabs IS the gradient as it lies in memory -- no scatter launch
-    if (layout == 0 && co_ld == c_out) return accumulate ? th_colsum_accum(ctx, part, gw, G, kt * c_out) : th_colsum(ctx, part, gw, G, kt * c_out);
+    if (layout == 0 && co_ld == c_out) {
+        const int cols = kt * c_out;
+        if (cols % 4 == 0 && G >= 16 && ((((uintptr_t)part | (uintptr_t)gw) & 15) == 0)) {
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(ceil_div(cols, 128)), dim3(256), 0, ctx->stream, part, gw, G, cols, accumulate);
+            TH_LAUNCH_CHECK();
+            return 0;
+        }
+        return accumulate ? th_colsum_accum(ctx, part, gw, G, cols) : th_colsum(ctx, part, gw, G, cols);
+    }
     void *tmp = nullptr;
     const int cols = kt * co_ld;
     if (th_malloc(ctx, (size_t)cols * sizeof(float), &tmp)) return 1;
