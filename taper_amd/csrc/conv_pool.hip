@@ -507,6 +507,26 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restric
     }
 }
 
+// 2x2 / stride 2 / unpadded windows on even maps: a thread owns a window and reads it as two float2 (consecutive lanes = consecutive
+// windows of a row: coalesced), same scan (kh outer, kw inner, strict >, -inf start, default index = the plane's first pixel)
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t *__restrict__ argmax,
+                                                           long total, int h, int w) {
+    const int w_out = w >> 1, h_out = h >> 1;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int ow = (int)(o % w_out), oh = (int)((o / w_out) % h_out);
+        const long in_base = (o / ((long)w_out * h_out)) * h * w, p00 = in_base + (long)(2 * oh) * w + 2 * ow;
+        const float2 a = *reinterpret_cast<const float2 *>(x + p00), b = *reinterpret_cast<const float2 *>(x + p00 + w);
+        float best = -INFINITY;
+        long idx = in_base;
+        if (a.x > best) { best = a.x; idx = p00; }
+        if (a.y > best) { best = a.y; idx = p00 + 1; }
+        if (b.x > best) { best = b.x; idx = p00 + w; }
+        if (b.y > best) { best = b.y; idx = p00 + w + 1; }
+        y[o] = best;
+        if (argmax) argmax[o] = idx;
+    }
+}
+
 // Gather form of the scatter-add of tensor.rs:1504-1514: every input pixel
 // walks the windows that can contain it in (oh, ow) ascending order -- the same
 // order the reference's sequential `for o in 0..out_spatial` adds them, so
@@ -1410,6 +1430,11 @@ int th_maxpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int64_t *d_argma
     const int h_out = (h + 2 * pad_h - k_h) / s_h + 1, w_out = (w + 2 * pad_w - k_w) / s_w + 1;
     const long total = (long)n * c * h_out * w_out;
     if (total == 0) return 0;
+    if (maxpool2_fast(n, c, h, w, k_h, k_w, s_h, s_w, pad_h, pad_w) && (((uintptr_t)d_x) & 7) == 0) {
+        hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_y, d_argmax, total, h, w);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ctx->stream, d_x, d_y, d_argmax, total, h, w,
                        h_out, w_out, k_h, k_w, s_h, s_w, pad_h, pad_w);
     TH_LAUNCH_CHECK();
