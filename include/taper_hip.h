@@ -531,6 +531,11 @@ int th_maxpool2d_relu_bwd(th_ctx *ctx, const float *d_gout, const int64_t *d_arg
  * -- together th_relu_bwd + th_bias_grad_nchw in one pass over the map.  full_backward extension. */
 int th_relu_bwd_plane_sums(th_ctx *ctx, const float *d_y, const float *d_gout, float *d_gin, float *d_plane_sums, int n, int c, int hw);
 int th_bias_grad_plane_sums(th_ctx *ctx, const float *d_plane_sums, float *d_gb, int n, int c, int accumulate);
+/* Backward of a GLOBAL average pool (tensor.rs:1626-1628) over the output d_y of a ReLU, into a gradient slot that is None, with that
+ * ReLU's backward folded in: d_gin = relu_bwd(d_y, avg_pool2d_bwd(d_gout [n][c])), and d_plane_sums [n][c] (nullable) as above.
+ * full_backward extension. */
+int th_avgpool2d_global_relu_bwd(th_ctx *ctx, const float *d_gout, const float *d_y, float *d_gin, float *d_plane_sums,
+                                 int n, int c, int hw);
 /* avg-pool: tensor.rs:1524-1660 (divisor k_h*k_w incl. padding, Q6) */
 int th_avgpool2d_fwd(th_ctx *ctx, const float *d_x, float *d_y, int n, int c, int h, int w,
                      int k_h, int k_w, int s_h, int s_w, int pad_h, int pad_w);

@@ -673,6 +673,27 @@ __global__ __launch_bounds__(256) void relu_bwd_planes_kernel(const float *__res
     }
 }
 
+// Backward of a GLOBAL average pool (tensor.rs:1626-1628: every element of plane (b, ch) receives g[b][ch] / hw) whose input is the output
+// of a ReLU, with that ReLU's backward and the plane sums in the same pass: gin = (y > 0) ? 0 + g / hw : 0.  A wave per plane.
+__global__ __launch_bounds__(256) void gap_relu_bwd_planes_kernel(const float *__restrict__ y, const float *__restrict__ g, float *__restrict__ gin,
+                                                                  float *__restrict__ plane_sums, int planes, int hw) {
+    const int lane = threadIdx.x & 63;
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (int pl = wave0; pl < planes; pl += n_waves) {
+        const long base = (long)pl * hw;
+        const float gv = 0.f + g[pl] / (float)hw;      // (the pool's backward adds it to a zeroed slot)
+        float s = 0.f;
+        for (int i = lane; i < hw; i += 64) {
+            const float o = y[base + i] > 0.f ? gv : 0.f;
+            gin[base + i] = o;
+            s += o;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0 && plane_sums) plane_sums[pl] = s;
+    }
+}
+
 // gb[ch] (+)= sum over images of plane_sums[b][ch], images in ascending order within each of 16 interleaved chains (deterministic);
 // one workgroup per 16 channels: thread (chain q, channel) adds images q, q + 16, ...; the 16 chains are added in order
 __global__ __launch_bounds__(256) void bias_from_plane_sums_kernel(const float *__restrict__ ps, float *__restrict__ gb, int n, int c, int accumulate) {
@@ -1487,6 +1508,16 @@ int th_relu_bwd_plane_sums(th_ctx *ctx, const float *d_y, const float *d_gout, f
     const int planes = n * c;
     if (planes == 0) return 0;
     hipLaunchKernelGGL(relu_bwd_planes_kernel, dim3(std::min(ceil_div(planes, 4), 8 * kNumCU)), dim3(256), 0, ctx->stream, d_y, d_gout, d_gin,
+                       d_plane_sums, planes, hw);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_avgpool2d_global_relu_bwd(th_ctx *ctx, const float *d_gout, const float *d_y, float *d_gin, float *d_plane_sums, int n, int c, int hw) {
+    TH_REQUIRE(ctx && d_gout && d_y && d_gin && n >= 0 && c >= 0 && hw > 0 && (long)n * c < (1L << 31), "th_avgpool2d_global_relu_bwd: bad argument");
+    const int planes = n * c;
+    if (planes == 0) return 0;
+    hipLaunchKernelGGL(gap_relu_bwd_planes_kernel, dim3(std::min(ceil_div(planes, 4), 8 * kNumCU)), dim3(256), 0, ctx->stream, d_y, d_gout, d_gin,
                        d_plane_sums, planes, hw);
     TH_LAUNCH_CHECK();
     return 0;

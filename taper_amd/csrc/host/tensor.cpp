@@ -1161,8 +1161,17 @@ Tensor Tensor::avg_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pai
                 g.pooled_avg = true;
                 return;
             }
-            TH(th_avgpool2d_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), n, ch, h, w, k.first, k.second, s.first, s.second,
-                                p.first, p.second));
+            bool none;
+            float *gin = in.grad_for_write(&none);
+            if (none && in.grad_->relu_output && k.first == h && k.second == w && p.first == 0 && p.second == 0) {
+                // full backward, a global pool behind a Conv2dReLU: that ReLU's backward and the bias's plane sums ride in this launch
+                in.grad_->plane_sums = Buffer::alloc((size_t)n * ch);
+                TH(th_avgpool2d_global_relu_bwd(Device::ctx(), r.grad_dptr(), in.dptr(), gin, in.grad_->plane_sums->d, n, ch, h * w));
+                in.grad_->premasked = true;
+                return;
+            }
+            if (none) TH(th_fill_f32(Device::ctx(), gin, 0.0f, in.len()));
+            TH(th_avgpool2d_bwd(Device::ctx(), r.grad_dptr(), gin, n, ch, h, w, k.first, k.second, s.first, s.second, p.first, p.second));
         });
     }
     return out;

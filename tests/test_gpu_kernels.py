@@ -610,6 +610,23 @@ def test_relu_bwd_plane_sums_and_bias_from_them(ctx, n, c, hw):
     close(ctx.download(gb, (c,)), 2 * want.astype(np.float64).sum((0, 2)), atol=4e-6 * hw * n)
 
 
+@pytest.mark.parametrize("n,c,hw", [(5, 128, 49), (3, 7, 196), (2, 2, 1), (1, 3, 100)])
+def test_avgpool_global_relu_bwd_equals_pool_bwd_then_relu_bwd(ctx, n, c, hw):
+    """th_avgpool2d_global_relu_bwd == th_avgpool2d_bwd into a zeroed slot followed by th_relu_bwd, + the plane sums."""
+    rng = np.random.default_rng(n + c + hw)
+    y = np.maximum(rng.uniform(-1, 1, (n, c, hw)), 0).astype(np.float32)
+    g = rng.uniform(-1, 1, (n, c)).astype(np.float32)
+    dy, dg = ctx.upload(y), ctx.upload(g)
+    tmp, ref = ctx.zeros(y.size), ctx.empty(y.size)
+    ctx.call("th_avgpool2d_bwd", dg, tmp, n, c, hw, 1, hw, 1, hw, 1, 0, 0)
+    ctx.call("th_relu_bwd", dy, tmp, ref, y.size, 0)
+    got, sums = ctx.upload(np.full(y.size, 3.0, np.float32)), ctx.empty(n * c)
+    ctx.call("th_avgpool2d_global_relu_bwd", dg, dy, got, sums, n, c, hw)
+    want = ctx.download(ref, (n, c, hw))
+    np.testing.assert_array_equal(ctx.download(got, (n, c, hw)), want)
+    close(ctx.download(sums, (n, c)), want.astype(np.float64).sum(2), atol=2e-6 * hw)
+
+
 @pytest.mark.parametrize("n,c,h,w,k,s,pad", POOL_CASES + [(5, 128, 7, 7, (7, 7), (7, 7), (0, 0)), (2, 4, 7, 7, (7, 7), (1, 1), (0, 0))])
 def test_avgpool(ctx, O, n, c, h, w, k, s, pad):
     rng = np.random.default_rng(n * c + h)
