@@ -184,7 +184,7 @@ def init_data_parallel(T, rdzv: FileRendezvous | None, backend: str = "rccl", op
         # gone) and go back to the training bound afterwards.
         comm.set_timeout_ms(_env_ms("TAPER_P2P_BOOT_TIMEOUT_MS", 20000))
         try:
-            ok = comm.self_check(optimizer)
+            ok = comm.self_check(optimizer, int(os.environ.get("TAPER_P2P_SELFCHECK_ROUNDS", "3")))   # (0: skipped -- a measurement knob)
         except Exception as e:   # noqa: BLE001
             ok, err = False, f"self-check: {e}"
         bad = rdzv.all_reduce_sum(0.0 if ok else 1.0)
