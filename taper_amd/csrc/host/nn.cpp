@@ -1437,7 +1437,6 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
     auto *seq = dynamic_cast<Sequential *>(model.get());
     if (rows) {
         // Linear + ReLU + Linear at large batch: three launches for the whole step, the rows read in place (mlp2_step said so)
-        TH(th_mlp2_set_max_ksplit(Device::ctx(), comm ? 1 : 8));   // (data-parallel steps: no k split between workgroups -- mlp2.hip)
         auto *l1 = dynamic_cast<Linear *>(seq->layers[0].get());
         auto *l2 = dynamic_cast<Linear *>(seq->layers[2].get());
         TAPER_ASSERT(l1 && l2 && mlp2_supported(*rows, batch, l1->weight, l1->bias, l2->weight, l2->bias),

@@ -947,14 +947,17 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     static const int ksplit_forced = [] { const char *e = getenv("TAPER_MLP2_KSPLIT"); return e ? atoi(e) : 0; }();
     int ksplit = RT != 16 ? 1 : std::max(1, std::min(8, kNumCU / n_blk));
     if (RT == 16 && ksplit_forced >= 1 && ksplit_forced <= 8 && n_blk <= 512) ksplit = ksplit_forced;   // (the kernel sums up to 8 splits)
-    // th_mlp2_set_max_ksplit: the Trainer asks for NO split when a communicator is attached.  The hand-off between a block's workgroups
-    // (system-coherent stores, one arrival, system-coherent loads by the last one) has never failed with one process on the GPU (80 captured
-    // and 80 eager runs compared bit for bit, tools/mlp2_repro_stress.py), but with TWO processes sharing a GPU -- the data-parallel tests'
-    // configuration -- 5 - 8 of 30 CAPTURED runs had a step whose results were off by ~1e-5 .. 1e-3 (tools/dp512_flake_probe.py: 0 of 40
-    // eager, 0 of 24 with the split off, 1 of 24 with two or four splits; fine-grained hand-off memory and a read-back of the stores in front
-    // of the arrival changed nothing).  The cause is not understood; until it is, data-parallel steps pay the unsplit launch (15.6 vs 11.5 us
-    // at 1 024 rows per rank).
-    ksplit = std::max(1, std::min(ksplit, ctx->m2_max_ksplit));
+    // The split is OFF by default (th_mlp2_set_max_ksplit / TAPER_MLP2_KSPLIT_MAX raise the cap).  Its hand-off between a block's workgroups
+    // (system-coherent stores, "acknowledged", one arrival, system-coherent loads by the last arrival) has never failed with ONE process on
+    // the GPU (180 captured + 180 eager runs compared bit for bit, tools/mlp2_repro_stress.py), but with a second or third process on the
+    // same GPU a captured step came out wrong -- 5 - 8 of 30 data-parallel runs with two ranks sharing a GPU (tools/dp512_flake_probe.py:
+    // 0 of 40 eager, 0 of 24 unsplit, 1 of 24 with two or four splits), 1 of 180 single-process runs beside two other processes.  The partial
+    // sums in fine-grained memory, and a read-back of the stores in front of the arrival, changed nothing; the form that cannot take a value
+    // early -- 8-byte {tag, value} granules, the reader asking again on a stale tag (built twice: a sequence word read at kernel start; tickets
+    // from a never-reset counter) -- is correct and takes 15.4 - 17.0 us for launch 1 at 1 024 rows against 15.6 unsplit and 11.9 for the
+    // racy form: what the split gained was the time it did not wait.  DESIGN 6c.
+    static const int cap_env = [] { const char *e = getenv("TAPER_MLP2_KSPLIT_MAX"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
+    if (!(RT == 16 && ksplit_forced >= 1 && ksplit_forced <= 8)) ksplit = std::max(1, std::min(ksplit, cap_env ? cap_env : ctx->m2_max_ksplit));   // (TAPER_MLP2_KSPLIT forces a split past the cap: the parity tests)
     const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_partial = (size_t)kz * hidden * in_features;
     const size_t n_kpart = ksplit > 1 ? (size_t)n_blk * ksplit * 2048 : 0;
     void *ws = nullptr;
