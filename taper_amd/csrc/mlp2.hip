@@ -955,7 +955,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     // sums in fine-grained memory, and a read-back of the stores in front of the arrival, changed nothing; the form that cannot take a value
     // early -- 8-byte {tag, value} granules, the reader asking again on a stale tag (built twice: a sequence word read at kernel start; tickets
     // from a never-reset counter) -- is correct and takes 15.4 - 17.0 us for launch 1 at 1 024 rows against 15.6 unsplit and 11.9 for the
-    // racy form: what the split gained was the time it did not wait.  DESIGN 6c.
+    // racy form.  (Not simply "read too early": 7 us of s_sleep in front of the last arrival's loads changed nothing.)  DESIGN 6c.
     static const int cap_env = [] { const char *e = getenv("TAPER_MLP2_KSPLIT_MAX"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
     if (!(RT == 16 && ksplit_forced >= 1 && ksplit_forced <= 8)) ksplit = std::max(1, std::min(ksplit, cap_env ? cap_env : ctx->m2_max_ksplit));   // (TAPER_MLP2_KSPLIT forces a split past the cap: the parity tests)
     const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_partial = (size_t)kz * hidden * in_features;
