@@ -294,9 +294,8 @@ typedef struct th_row_source {
     int64_t n_rows;             /* rows held by d_rows (the extent reads are clamped to) */
 } th_row_source;
 int th_mlp2_xent_supported(int batch, int in_features, int hidden, int classes, int64_t n_rows);
-/* Cap (1 .. 8, default 1 = off) on the workgroups that share one 16-row block's k chunks in launch 1 at batches below 4096.  The
- * hand-off between those workgroups inside the launch gave wrong steps when OTHER processes shared the GPU (mlp2.hip): raise
- * the cap only on a GPU this process has to itself (launch 1 at 1 024 rows: 11.9 instead of 15.6 us). */
+/* Cap (1 .. 8, default 8) on the workgroups that share one 16-row block's k chunks in launch 1 at batches below 4096; 1 = no hand-off
+ * between workgroups inside the launch (launch 1 at 1 024 rows: 15.6 instead of 11.9 us).  A measurement / fallback switch. */
 int th_mlp2_set_max_ksplit(th_ctx *ctx, int max_ksplit);
 int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_features, int hidden, int classes, const float *d_w1,
                  const float *d_b1, const float *d_w2, const float *d_b2, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2,

@@ -102,7 +102,7 @@ struct th_ctx {
     // staging plans of the image-resident conv kernel, built on device once per geometry (conv_mfma.hip); plain hipMalloc, freed with the ctx
     std::map<std::array<int, 8>, void *> conv_plans;
     int32_t *err_word = nullptr;                      // this device's error block (host-visible; shared by the contexts of a device)
-    int m2_max_ksplit = 1;                            // mlp2.hip: cap on the workgroups sharing a row block's k chunks (th_mlp2_set_max_ksplit; 1 = no split, the default)
+    int m2_max_ksplit = 8;                            // mlp2.hip: cap on the workgroups sharing a row block's k chunks (th_mlp2_set_max_ksplit; 1 = no split)
     unsigned *m2_arrive = nullptr;                    // mlp2.hip: arrival counters of k-split row blocks (zero between launches); plain hipMalloc, freed with the ctx
 };
 

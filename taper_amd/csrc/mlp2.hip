@@ -329,10 +329,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
             // stores, waited for, then one arrival; the last arrival reads them with system-coherent loads.  (A device-scope __threadfence()
             // instead costs a write-back of the whole L2 per workgroup on this part: measured 57 us for this launch against 16 unsplit.)
             float *mine = a.kpart + (long)blockIdx.x * 2048 + (wave * 128 + lane) * 4;
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine + tt * 256), "v"(acc16[tt]) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores have been acknowledged by memory ...
+            // Both stores AND their wait in ONE statement: the compiler does not know an asm statement is a vector-memory store, so its
+            // hazard recognizer does not keep the next instruction from rewriting the 128-bit store data -- r04's first form (one statement
+            // per store) was compiled to `global_store_dwordx4 v[8:9], v[4:7]` / `s_mov_b64` / `v_accvgpr_read_b32 v7, a3` ...: the second
+            // store's data went into the registers the first store was still reading.  With the GPU to itself the store had read them in
+            // time, every time (360 runs); with another process's traffic backing up the store path, 5 - 8 of 30 captured runs had a wrong
+            // step.  Here the data registers are inputs of the statement that also waits for the stores: nothing can touch them
+            // before the stores are done.
+            asm volatile("global_store_dwordx4 %0, %2, off sc0 sc1\n\tglobal_store_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         ::"v"(mine), "v"(mine + 256), "v"(acc16[0]), "v"(acc16[1]) : "memory");   // ... acknowledged by memory ...
             __syncthreads();                                   // ... every thread's, before the one arrival below
             if (t == 0) last_arrival = __hip_atomic_fetch_add(&a.karrive[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ksplit - 1);
             __syncthreads();
@@ -947,15 +952,10 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     static const int ksplit_forced = [] { const char *e = getenv("TAPER_MLP2_KSPLIT"); return e ? atoi(e) : 0; }();
     int ksplit = RT != 16 ? 1 : std::max(1, std::min(8, kNumCU / n_blk));
     if (RT == 16 && ksplit_forced >= 1 && ksplit_forced <= 8 && n_blk <= 512) ksplit = ksplit_forced;   // (the kernel sums up to 8 splits)
-    // The split is OFF by default (th_mlp2_set_max_ksplit / TAPER_MLP2_KSPLIT_MAX raise the cap).  Its hand-off between a block's workgroups
-    // (system-coherent stores, "acknowledged", one arrival, system-coherent loads by the last arrival) has never failed with ONE process on
-    // the GPU (180 captured + 180 eager runs compared bit for bit, tools/mlp2_repro_stress.py), but with a second or third process on the
-    // same GPU a captured step came out wrong -- 5 - 8 of 30 data-parallel runs with two ranks sharing a GPU (tools/dp512_flake_probe.py:
-    // 0 of 40 eager, 0 of 24 unsplit, 1 of 24 with two or four splits), 1 of 180 single-process runs beside two other processes.  The partial
-    // sums in fine-grained memory, and a read-back of the stores in front of the arrival, changed nothing; the form that cannot take a value
-    // early -- 8-byte {tag, value} granules, the reader asking again on a stale tag (built twice: a sequence word read at kernel start; tickets
-    // from a never-reset counter) -- is correct and takes 15.4 - 17.0 us for launch 1 at 1 024 rows against 15.6 unsplit and 11.9 for the
-    // racy form.  (Not simply "read too early": 7 us of s_sleep in front of the last arrival's loads changed nothing.)  DESIGN 6c.
+    // th_mlp2_set_max_ksplit / TAPER_MLP2_KSPLIT_MAX cap the split (default 8 = the kernel's limit; 1 = off).  (The hand-off's stores are one
+    // asm statement with their wait -- mlp2_rows_kernel: as two statements the compiler reused the first store's data registers while it
+    // was still reading them, and with other processes on the GPU 5 - 8 of 30 captured runs had a wrong step: tools/dp512_flake_probe.py,
+    // tools/mlp2_repro_stress.py)
     static const int cap_env = [] { const char *e = getenv("TAPER_MLP2_KSPLIT_MAX"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
     if (!(RT == 16 && ksplit_forced >= 1 && ksplit_forced <= 8)) ksplit = std::max(1, std::min(ksplit, cap_env ? cap_env : ctx->m2_max_ksplit));   // (TAPER_MLP2_KSPLIT forces a split past the cap: the parity tests)
     const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_partial = (size_t)kz * hidden * in_features;
