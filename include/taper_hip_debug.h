@@ -15,6 +15,9 @@ int th_debug_mlp2_calls(int64_t *out);
 /* measurement hook: 1 / 2 / 3 = th_mlp2_xent enqueues only that launch (rows / dW1 / finish) on this thread, so that each can be timed with
  * events on its own (the pool hands the same workspace back from call to call: launches 2 and 3 read what an earlier full call left); 0 = the step */
 int th_debug_mlp2_only(int which);
+/* 1 .. 8 = th_mlp2_xent splits a 16-row block's k chunks over that many workgroups on this thread whatever the cap says (the repro tests
+ * walk the hand-off's forms); 0 = the default choice */
+int th_debug_mlp2_ksplit(int ksplit);
 /* 1 = the compiled chain instances are not used on this thread (their nets take the run-time-described kernel, id 3); 0 = default */
 int th_debug_set_chain_generic(int on);
 /* launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity

@@ -172,38 +172,36 @@ __device__ __forceinline__ void p2p_arrive(const P2PDev &c, uint32_t step) {
 }
 
 // a system-coherent 16-byte load: answered by memory (over xGMI for a peer's arena), not by this device's L1 / L2
-__device__ __forceinline__ float4 ld_sys(const float *p) {
-    float4 v;
+typedef float p2p_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ p2p_f4 ld_sys(const float *p) {
+    p2p_f4 v;
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
 
+// NR = 1 / 2 / 4 / 8 >= n_ranks, compiled in: the NR requests and their wait are ONE basic block -- no branch between an inline-asm load and
+// the wait that covers it, so what may touch a destination register before its data has landed can be read off the listing line by line
+// (tools/asm_hazard_audit.py; r04's form looped to the run-time rank count with a `break`, and took this rank's own arena through an
+// ordinary load behind a rank test: correct, but neither the compiler's nor the audit's reasoning covers loads and waits in different
+// blocks).  All requests go out before the first value is used.  Slots r >= n_ranks re-read this rank's own arena and are dropped by a
+// select; this rank's own arena (written by the backward launches in front of this one in the stream, written back at their kernel
+// boundaries) takes the same system-coherent load as the peers'.  Added in RANK ORDER: the same bits on every rank.
+template <int NR>
 __device__ __forceinline__ float4 p2p_sum_quad(const P2PDev &c, long i, float scale) {
-    // all W requests go out before the first value is used; this rank's own arena (written by the backward launches in front of this
-    // one in the stream) is an ordinary load.  Added in RANK ORDER: the same bits on every rank.
-    float4 v[P2P_MAX_RANKS];
+    p2p_f4 v[NR];
 #pragma unroll
-    for (int r = 0; r < P2P_MAX_RANKS; ++r) {
-        if (r >= c.n_ranks) break;
-        if (r != c.rank) v[r] = ld_sys(c.buf[r] + i);
-    }
+    for (int r = 0; r < NR; ++r) v[r] = ld_sys((r < c.n_ranks ? c.buf[r] : c.buf[c.rank]) + i);
 #pragma unroll
-    for (int r = 0; r < P2P_MAX_RANKS; ++r) {
-        if (r >= c.n_ranks) break;
-        if (r != c.rank) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[r].x), "+v"(v[r].y), "+v"(v[r].z), "+v"(v[r].w) : : "memory");
-        else v[r] = *reinterpret_cast<const float4 *>(c.buf[r] + i);
-    }
-    float4 s = v[0];
+    for (int r = 0; r < NR; ++r) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[r]) : : "memory");
+    p2p_f4 s = v[0];
 #pragma unroll
-    for (int r = 1; r < P2P_MAX_RANKS; ++r) {
-        if (r >= c.n_ranks) break;
-        s.x += v[r].x; s.y += v[r].y; s.z += v[r].z; s.w += v[r].w;
-    }
-    s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
-    return s;
+    for (int r = 1; r < NR; ++r) s = r < c.n_ranks ? s + v[r] : s;
+    s *= scale;
+    return make_float4(s.x, s.y, s.z, s.w);
 }
 
 // in place: buf[rank][0..n) = scale * sum_r buf[r][0..n); n % 4 == 0, 16-byte aligned
+template <int NR>
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PDev c, float *__restrict__ out, long n, float scale) {
     if (p2p_dead(c)) return;
     const uint32_t step = __hip_atomic_load(&c.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PDev c, float *__r
 #pragma unroll
         for (int q = 0; q < P2P_QUADS; ++q) {
             const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4 + q * stride;
-            if (i < n) acc[q] = p2p_sum_quad(c, i, scale);
+            if (i < n) acc[q] = p2p_sum_quad<NR>(c, i, scale);
         }
         p2p_arrive(c, step);
     }
@@ -243,6 +241,7 @@ __device__ __forceinline__ int p2p_find_tensor(const int64_t *__restrict__ offse
 // Arena slices are padded to multiples of 4 floats, so a quad never straddles two tensors; grad-less tensors are
 // skipped entirely (Q8; the mask is rank-invariant).  t: every workgroup forms t + 1 itself, workgroup 0 publishes it
 // on its way out (after every other reader is long past the load: they all arrive before the done flags go out).
+template <int NR>
 __global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long n, float scale, float *__restrict__ p, float *__restrict__ m,
                                                                  float *__restrict__ v, const int64_t *__restrict__ offsets,
                                                                  const int32_t *__restrict__ has_grad, int n_tensors, int32_t *t_state,
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long 
     if (ok) {
         for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 256 * 4) {
             if (!has_grad[p2p_find_tensor(offsets, n_tensors, i)]) continue;
-            const float4 g = p2p_sum_quad(c, i, scale);
+            const float4 g = p2p_sum_quad<NR>(c, i, scale);
             const float4 pv = *reinterpret_cast<const float4 *>(p + i), mv = *reinterpret_cast<const float4 *>(m + i),
                          vv = *reinterpret_cast<const float4 *>(v + i);
             float4 po, mo, vo;
@@ -490,8 +489,15 @@ int th_allreduce_adam(th_comm *comm, th_ctx *ctx, const float *d_grads, size_t n
     TH_REQUIRE(comm->p2p && comm->connected, "th_allreduce_adam: needs a connected peer-to-peer communicator (th_comm_init_p2p / _export / _connect)");
     TH_REQUIRE(d_grads == comm->reg_buf && n == comm->reg_n, "th_allreduce_adam: not the buffer this communicator exported");
     TH_REQUIRE(((uintptr_t)d_params & 15) == 0 && ((uintptr_t)d_m & 15) == 0 && ((uintptr_t)d_v & 15) == 0, "th_allreduce_adam: arenas must be 16-byte aligned");
-    hipLaunchKernelGGL(th::p2p_allreduce_adam_kernel, dim3(th::p2p_grid(n)), dim3(256), 0, ctx->stream, comm->dev, (long)n, scale, d_params, d_m, d_v,
-                       d_offsets, d_has_grad, n_tensors, d_t, d_lr, beta1, beta2, eps, weight_decay, pre_ticked);
+#define TH_P2P_ADAM(NR_)                                                                                                                       \
+    hipLaunchKernelGGL(th::p2p_allreduce_adam_kernel<NR_>, dim3(th::p2p_grid(n)), dim3(256), 0, ctx->stream, comm->dev, (long)n, scale, d_params, \
+                       d_m, d_v, d_offsets, d_has_grad, n_tensors, d_t, d_lr, beta1, beta2, eps, weight_decay, pre_ticked)
+    // the instance with the smallest compiled-in slot count >= n_ranks (p2p_sum_quad)
+    if (comm->n_ranks <= 1) TH_P2P_ADAM(1);
+    else if (comm->n_ranks == 2) TH_P2P_ADAM(2);
+    else if (comm->n_ranks <= 4) TH_P2P_ADAM(4);
+    else TH_P2P_ADAM(8);
+#undef TH_P2P_ADAM
     TH_LAUNCH_CHECK();
     ++comm->launches_fused;
     return 0;
@@ -512,7 +518,12 @@ int th_allreduce_sum_scale(th_comm *comm, th_ctx *ctx, float *d_buf, size_t n, f
         TH_REQUIRE(d_buf == comm->reg_buf && n == comm->reg_n, "th_allreduce_sum_scale: not the buffer this communicator exported");
         int g = (int)((n / 4 + 255) / 256);             // one float4 per thread while that fits, up to P2P_QUADS beyond
         if (g > P2P_MAX_BLOCKS) g = P2P_MAX_BLOCKS;     // (every workgroup stays resident until all peers are done reading)
-        hipLaunchKernelGGL(th::p2p_allreduce_kernel, dim3(g < 1 ? 1 : g), dim3(256), 0, ctx->stream, comm->dev, d_buf, (long)n, scale);
+#define TH_P2P_INPLACE(NR_) hipLaunchKernelGGL(th::p2p_allreduce_kernel<NR_>, dim3(g < 1 ? 1 : g), dim3(256), 0, ctx->stream, comm->dev, d_buf, (long)n, scale)
+        if (comm->n_ranks <= 1) TH_P2P_INPLACE(1);
+        else if (comm->n_ranks == 2) TH_P2P_INPLACE(2);
+        else if (comm->n_ranks <= 4) TH_P2P_INPLACE(4);
+        else TH_P2P_INPLACE(8);
+#undef TH_P2P_INPLACE
         TH_LAUNCH_CHECK();
         ++comm->launches_inplace;
         return 0;

@@ -882,6 +882,7 @@ __global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
 
 thread_local long t_mlp2_calls = 0;
 thread_local int t_mlp2_only = 0;      // th_debug_mlp2_only: 0 = the step; 1 / 2 / 3 = that launch alone (per-launch timing; workspace kept from call to call)
+thread_local int t_mlp2_ksplit = 0;    // th_debug_mlp2_ksplit: 1 .. 8 = that k split on the 16-row tiles whatever the cap says (tests/test_gpu_repro.py); 0 = default
 
 static int m2_rows_per_block(int batch) {
     static const int forced = [] { const char *e = getenv("TAPER_MLP2_RT"); return e ? atoi(e) : 0; }();
@@ -949,7 +950,8 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     // launch 1 on the 16-row tiles with few row blocks: as many workgroups per block as fill the CUs (up to 8) share its k chunks
     // (mlp2_rows_kernel): 4 at batch 1 024, 2 at 2 048, none from 4 096 on.  Measured through the C ABI: 31.1 -> 27.3 us per step at 1 024
     // rows (launch 1: 15.6 -> 11.5 us), 35.5 -> 33.1 at 2 048.  TAPER_MLP2_KSPLIT=1 turns it off (measurement knob).
-    static const int ksplit_forced = [] { const char *e = getenv("TAPER_MLP2_KSPLIT"); return e ? atoi(e) : 0; }();
+    static const int ksplit_env = [] { const char *e = getenv("TAPER_MLP2_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int ksplit_forced = t_mlp2_ksplit ? t_mlp2_ksplit : ksplit_env;
     int ksplit = RT != 16 ? 1 : std::max(1, std::min(8, kNumCU / n_blk));
     if (RT == 16 && ksplit_forced >= 1 && ksplit_forced <= 8 && n_blk <= 512) ksplit = ksplit_forced;   // (the kernel sums up to 8 splits)
     // th_mlp2_set_max_ksplit / TAPER_MLP2_KSPLIT_MAX cap the split (default 8 = the kernel's limit; 1 = off).  (The hand-off's stores are one
@@ -1070,6 +1072,11 @@ int th_mlp2_set_max_ksplit(th_ctx *ctx, int max_ksplit) {
 
 int th_debug_mlp2_calls(int64_t *out) {
     if (out) *out = t_mlp2_calls;
+    return 0;
+}
+
+int th_debug_mlp2_ksplit(int ksplit) {
+    t_mlp2_ksplit = (ksplit >= 1 && ksplit <= 8) ? ksplit : 0;
     return 0;
 }
 

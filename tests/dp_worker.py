@@ -1,7 +1,9 @@
 """One rank of a data-parallel run of the PRODUCT Trainer (tests/test_gpu_dp.py spawns W of these).
 env: RANK / LOCAL_RANK / WORLD_SIZE (torchrun's contract), TAPER_DP_OUT (directory), TAPER_DP_STEPS, TAPER_DP_GLOBAL_BATCH,
 TAPER_DP_MODE (graph | eager), TAPER_DP_DEVICE (optional: every rank on this device -- the peer-to-peer communicator can share
-one GPU, RCCL cannot), TAPER_DP_BACKEND (rccl | p2p), TAPER_DP_MODEL (tests/backends.py builder: mlp_baseline | cnn_reference | ...)."""
+one GPU, RCCL cannot), TAPER_DP_BACKEND (rccl | p2p), TAPER_DP_MODEL (tests/backends.py builder: mlp_baseline | cnn_reference | ...), TAPER_DP_REPEAT (optional: the
+two-epoch optimisation R times over from the same start -- parameters, Adam's moments and t restored in place, the captured graphs and the
+communicator kept -- every run's losses and weights saved as run{i}_*: tests/test_gpu_repro.py compares them bit for bit)."""
 import os
 import sys
 from pathlib import Path
@@ -47,8 +49,22 @@ def main():
     tr = T.Trainer(model, opt, comm=comm, **({"sample_shape": sample_shape(model_name)} if sample_shape(model_name) else {}))
     loader = T.DataLoader(T.MNISTDataset.from_host(x[rows], y[rows]), per, False)
     mode = T.Trainer.GRAPH if os.environ.get("TAPER_DP_MODE", "graph") == "graph" else T.Trainer.EAGER
-    ep = tr.run_epoch(loader, mode)
-    ep2 = tr.run_epoch(loader, mode)          # a second epoch over the same rows: the captured graphs are replayed
+    repeat = int(os.environ.get("TAPER_DP_REPEAT", "1"))
+    start = [p.data() for p in model.parameters()]
+    runs = {}
+    for run in range(repeat):
+        if run:                                # the same optimisation again from the same start
+            for p, a in zip(model.parameters(), start):
+                p.set_data(a)
+            n_all = sum(a.size for a in start)
+            opt.load_state(0, np.zeros(n_all, np.float32), np.zeros(n_all, np.float32))
+            loader.reset()
+        ep = tr.run_epoch(loader, mode)
+        ep2 = tr.run_epoch(loader, mode)          # a second epoch over the same rows: the captured graphs are replayed
+        if repeat > 1:
+            runs[f"run{run}_losses"] = np.concatenate([ep["losses"], ep2["losses"]])
+            for i, p in enumerate(model.parameters()):
+                runs[f"run{run}_p{i}"] = p.data()
     if comm is not None and comm.is_p2p() and comm.timed_out():
         raise SystemExit(f"rank {rank}: a peer never arrived at the all-reduce")
     st = comm.stats() if comm is not None and comm.is_p2p() else dict(inplace=-1, fused=-1)
@@ -57,7 +73,7 @@ def main():
     mlp2_calls = C.c_int64()
     lib.th_debug_mlp2_calls(C.byref(mlp2_calls))   # host-side calls of th_mlp2_xent on this thread (eager steps + captures)
     np.savez(out / f"rank{rank}.npz", fine=int(fine), mlp2_calls=mlp2_calls.value, launches_inplace=st["inplace"], launches_fused=st["fused"], losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
-             **{f"p{i}": p.data() for i, p in enumerate(model.parameters())})
+             **{f"p{i}": p.data() for i, p in enumerate(model.parameters())}, **runs)
     rdzv.barrier()
     rdzv.close()
 

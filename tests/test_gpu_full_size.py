@@ -233,6 +233,49 @@ def _training_steps_parity(T, name, mode):
     assert hopt.t() == steps
 
 
+FULL_BWD_STEP_LOSS = 2e-5      # per-step losses of the full-backward steps, of the largest loss (bound = the faithful steps' LOSS_RTOL class; margins recorded)
+FULL_BWD_STEP_ERR_OVER_LR = 2e-2   # weights after the steps, in units of lr: the error model of __graft_entry__.smoke (|g| ~ eps elements move by a visible fraction of lr)
+
+
+@pytest.mark.parametrize("name,steps", [("cnn_simple", 3), ("cnn_reference", 2)])
+def test_cnn_full_backward_graph_steps_parity_batch_256(name, steps):
+    """`full_backward` (extension: every conv weight trains; the reference cuts the tape, Q2) through the TRAINER at batch 256, captured --
+    the configuration bench.py quotes `full_bwd_ms` on (step 0 runs eagerly, the others are replayed graphs): per-step loss / hit count and
+    every weight after the Adam steps against the oracle's differentiable im2col chain (oracle conv_mode 1) -- the kernel-level
+    comparisons stop at batch 136, eager (tests/test_gpu_step.py)"""
+    import taper_amd as T
+    from tests import margins
+    H, Orc = backends.get("hip"), backends.get("oracle")
+    Orc.set_zero_sentinel(True)
+    rng = np.random.default_rng(23 + len(name))
+    batch, lr = 256, 1e-2
+    spec = backends.nonzero_biases(MODELS[name](rng), rng)
+    x, y = backends.mnist_like(rng, steps * batch)
+    om = Orc.sequential(spec, full_backward=True)
+    oopt = Orc.m.Adam(om.parameters(), lr, None, None, 1e-4)
+    ref = [om.train_step(oopt, x[s * batch:(s + 1) * batch], y[s * batch:(s + 1) * batch], (batch, 1, 28, 28)) for s in range(steps)]
+    try:
+        hm = H.sequential(spec, full_backward=True)
+        hopt = T.Adam(hm.parameters(), lr, None, None, 1e-4)
+        tr = T.Trainer(hm, hopt, sample_shape=(1, 28, 28))
+        ep = tr.run_epoch(T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False), T.Trainer.GRAPH)
+    finally:
+        T.set_full_backward(False)
+    tag = "test_cnn_full_backward_graph_steps_parity_batch_256"
+    margins.check(f"{name}_losses", ep["losses"], [r["loss"] for r in ref], FULL_BWD_STEP_LOSS, test=tag)
+    assert np.abs(np.asarray(ep["ncorrect"]) - np.asarray([r["acc"] * batch for r in ref])).max() <= 1.5
+    assert hopt.t() == steps
+    for i, (hp, op) in enumerate(zip(hm.parameters(), om.parameters())):
+        assert float(np.abs(np.ravel(hp.data()) - np.ravel(spec_param(spec, i))).max()) > 0, f"param {i} did not train in full_backward mode"
+        margins.check(f"{name}_param{i}", hp.data(), op.data(), FULL_BWD_STEP_ERR_OVER_LR, lr=lr, test=tag)
+
+
+def spec_param(spec, i):
+    """the i-th parameter's initial value in a backends spec (w, b per layer that has them)"""
+    flat = [l[k] for l in spec if "w" in l for k in ("w", "b") if l.get(k) is not None]
+    return flat[i]
+
+
 @pytest.mark.parametrize("name", ["cnn_simple", "cnn_reference"])
 def test_conv_chain_step_is_bit_identical_to_the_layered_step(name):
     """the Trainer's captured step with the convolutional front as one launch against the same step launched layer by layer: same

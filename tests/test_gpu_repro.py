@@ -1,0 +1,299 @@
+"""Run-to-run reproducibility of every launch in which one workgroup reads what another wrote (a cross-workgroup hand-off on ISA-level
+semantics), under the condition that exposed r04's intermittent wrong step: captured replays, back to back, BESIDE two other
+processes that keep the GPU's memory system busy (tests/hbm_stream_worker.py).  Each case replays a captured run of several optimizer steps
+>= 60 step executions in all from the same restored state and demands bit-identical outputs every time -- these launches add in fixed orders
+and have no atomics on their data paths -- and the first run within margin of the oracle's chain:
+
+  * th_mlp2_xent's k split of a 16-row block over 2 / 4 / 8 workgroups (mlp2.hip: partial accumulators through memory, an arrival counter,
+    the last arrival adds in split order) at batch 512 / 1 024 / 2 048, and its default forms at 4 096 / 16 384 rows
+    (/root/reference/src/nn.rs:54-60, src/loss.rs:101-195, src/ops.rs:238-294, src/optim.rs:83-113);
+  * th_linear_xent_wide_fused: the LAST workgroup to arrive sums the conv bias gradient from everybody's column sums and publishes the step
+    counter (wide_head.hip; src/tensor.rs:2017-2024, src/optim.rs:84);
+  * th_adam_step over a multi-workgroup arena: the last workgroup to finish publishes t + 1 (optim.hip; src/optim.rs:83-113);
+  * the data-parallel step of two ranks x 512 rows on one GPU (the one-shot peer-to-peer all-reduce fused with Adam, comm.hip, in front of it
+    the large-batch step with its k split): the very configuration that failed one `-m gpu` run in four in r04.
+
+Reverting commit 596fe87 (the hand-off's two stores as two asm statements) makes the k-split cases fail on a shared GPU."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+import uuid
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests import margins
+from tests.test_gpu_fused import oracle_head
+from tests.test_gpu_mlp_tail import oracle_tail
+from taper_amd.hip import AdamFuse, RowSource, WideFuse
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+RTOL = 1e-4
+BOUND_LR = 2e-2          # weights after a few Adam steps, in units of lr: the error model of __graft_entry__.smoke (|g| ~ eps elements)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from taper_amd import hip
+    c = hip.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def traffic(tmp_path_factory):
+    """two background processes streaming HBM on GPU 0 for the lifetime of this module's tests"""
+    d = tmp_path_factory.mktemp("traffic")
+    stop = d / "stop"
+    procs = []
+    for i in range(2):
+        ready = d / f"ready{i}"
+        p = subprocess.Popen([sys.executable, str(ROOT / "tests" / "hbm_stream_worker.py"), str(ready), str(stop), "170"],
+                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        procs.append((p, ready))
+    t0 = time.time()
+    for p, ready in procs:
+        while not ready.exists():
+            assert p.poll() is None, f"traffic generator died: {p.stderr.read()[-2000:]}"
+            assert time.time() - t0 < 90, "traffic generator never came up"
+            time.sleep(0.05)
+    yield d
+    stop.write_text("stop")
+    for p, _ in procs:
+        try:
+            p.wait(timeout=60)
+        except subprocess.TimeoutExpired:
+            p.kill()
+
+
+def _replay_identical(ctx, graph, restore, collect, replays):
+    """`replays` launches of a captured run, each from the state `restore()` puts back; every `collect()` equal to the first, bit for bit"""
+    first = None
+    for r in range(replays):
+        restore()
+        ctx.graph_launch(graph)
+        got = collect()
+        if first is None:
+            first = got
+            continue
+        for k in first:
+            if not np.array_equal(first[k], got[k]):
+                d = np.abs(np.asarray(first[k], np.float64) - np.asarray(got[k], np.float64))
+                raise AssertionError(f"replay {r}: `{k}` differs from the first replay in {int((d > 0).sum())} of {d.size} elements (max {d.max():.3e})")
+    return first
+
+
+# ------------------------------------------------------------------------------------------------------------------ th_mlp2_xent
+MLP2_CASES = [(512, 2), (512, 4), (512, 8), (1024, 2), (1024, 4), (1024, 8), (2048, 2), (2048, 4), (2048, 8), (1024, 0), (4096, 0), (16384, 0)]
+
+
+@pytest.mark.parametrize("batch,ksplit", MLP2_CASES)
+def test_mlp2_steps_repeat_bit_identical_beside_hbm_traffic(ctx, O, traffic, batch, ksplit):
+    """ksplit 0: the launcher's own choice (4 at 1 024 rows; none from 4 096 on, where the hand-off under test is the dW1 launch's)"""
+    from taper_amd._lib import hip as lib
+    inf, hid, c, lr = 784, 128, 10, 1e-3
+    steps, replays = (4, 15) if batch <= 4096 else (3, 20)
+    rng = np.random.default_rng(batch * 11 + ksplit)
+    x = (rng.integers(0, 256, (steps, batch, inf)) * (rng.uniform(0, 1, (steps, batch, inf)) < 0.3)).astype(np.float32) / np.float32(255.0)
+    y = rng.integers(0, c, (steps, batch)).astype(np.float32)
+    p0 = dict(w1=rng.uniform(-1, 1, (hid, inf)).astype(np.float32) * np.float32(np.sqrt(2.0 / inf)), b1=rng.uniform(-0.1, 0.1, hid).astype(np.float32),
+              w2=rng.uniform(-0.3, 0.3, (c, hid)).astype(np.float32), b2=rng.uniform(-0.1, 0.1, c).astype(np.float32))
+    names = ("w1", "b1", "w2", "b2")
+    dev = {k: ctx.upload(v) for k, v in p0.items()}
+    mom = {k: (ctx.zeros(v.size), ctx.zeros(v.size)) for k, v in p0.items()}
+    tick, dlr = ctx.upload(np.zeros(2, np.int32)), ctx.upload(np.array([lr], np.float32))
+    fuses = [AdamFuse(int(dev[k]), int(mom[k][0]), int(mom[k][1]), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4) for k in names]
+    dx, dy = [ctx.upload(x[s]) for s in range(steps)], [ctx.upload(y[s]) for s in range(steps)]
+    outs = [dict(dw1=ctx.empty(hid * inf), db1=ctx.empty(hid), dw2=ctx.empty(c * hid), db2=ctx.empty(c), loss=ctx.empty(1), nc=ctx.empty(1)) for _ in range(steps)]
+    srcs = [RowSource(int(dx[s]), int(dy[s]), None, None, 0, batch) for s in range(steps)]
+    lib.th_debug_mlp2_ksplit(ksplit)
+    try:
+        ctx.graph_begin()
+        for s in range(steps):
+            o = outs[s]
+            ctx.call("th_mlp2_xent", C.byref(srcs[s]), batch, inf, hid, c, dev["w1"], dev["b1"], dev["w2"], dev["b2"], o["dw1"], o["db1"], o["dw2"], o["db2"],
+                     o["loss"], o["nc"], None, 0, None, 0, tick, *[C.byref(f) for f in fuses])
+        g = ctx.graph_end()
+    finally:
+        lib.th_debug_mlp2_ksplit(0)
+    zeros = {k: np.zeros(v.size, np.float32) for k, v in p0.items()}
+
+    def restore():
+        from taper_amd._lib import th_check
+        for k in names:
+            for buf, a in ((dev[k], p0[k]), (mom[k][0], zeros[k]), (mom[k][1], zeros[k])):
+                a = np.ascontiguousarray(a)
+                th_check(lib.th_memcpy_h2d(ctx.h, int(buf), a.ctypes.data, a.nbytes), "th_memcpy_h2d")
+        t0 = np.zeros(2, np.int32)
+        th_check(lib.th_memcpy_h2d(ctx.h, int(tick), t0.ctypes.data, t0.nbytes), "th_memcpy_h2d")
+
+    def collect():
+        got = {k: ctx.download(dev[k], p0[k].size) for k in names}
+        for k in names:
+            got[k + "_m"], got[k + "_v"] = ctx.download(mom[k][0], p0[k].size), ctx.download(mom[k][1], p0[k].size)
+        got["losses"] = np.array([ctx.download(o["loss"], 1)[0] for o in outs])
+        got["hits"] = np.array([ctx.download(o["nc"], 1)[0] for o in outs])
+        got["dw1_last"] = ctx.download(outs[-1]["dw1"], hid * inf)
+        got["t"] = ctx.download(tick, 2, np.int32)
+        return got
+
+    try:
+        first = _replay_identical(ctx, g, restore, collect, replays)
+    finally:
+        ctx.graph_destroy(g)
+    assert first["t"][0] == steps
+    # the first run against the oracle: the first step's loss and hit count (the weights are p0), then every step through the oracle's Adam
+    w = {k: O.Tensor(p0[k]).requires_grad() for k in names}
+    om = O.Sequential([dict(kind="linear", w=w["w1"], b=w["b1"]), dict(kind="relu"), dict(kind="linear", w=w["w2"], b=w["b2"])])
+    oopt = O.Adam(om.parameters(), lr, None, None, 1e-4)
+    O.Tape.set_zero_sentinel(True)
+    ref = [om.train_step(oopt, x[s], y[s], (batch, inf)) for s in range(steps)]
+    test = "test_mlp2_steps_repeat_bit_identical_beside_hbm_traffic"
+    margins.check("losses", first["losses"], [r["loss"] for r in ref], 2 * RTOL, test=test)
+    assert abs(first["hits"][0] - ref[0]["acc"] * batch) < 0.5                   # index work on identical weights: exact
+    for k in names:
+        margins.check(f"{k}_after_{steps}_steps", first[k], w[k].data(), BOUND_LR, lr=lr, test=test)
+
+
+# ------------------------------------------------------------------------------------------------------------------ th_linear_xent_wide_fused
+def test_wide_fused_last_arrival_repeats_bit_identical_beside_hbm_traffic(ctx, O, traffic):
+    batch, c_conv, hw, c, lr, steps, replays = 256, 64, 49, 10, 1e-2, 4, 15
+    k = c_conv * hw
+    rng = np.random.default_rng(5)
+    h = np.maximum(rng.standard_normal((batch, k)), 0).astype(np.float32)
+    p0 = dict(w=(rng.uniform(-1, 1, (c, k)) * np.sqrt(2.0 / k)).astype(np.float32), b=rng.uniform(-0.1, 0.1, c).astype(np.float32),
+              cb=rng.uniform(-0.3, 0.3, c_conv).astype(np.float32))
+    y = rng.integers(0, c, batch).astype(np.float32)
+    dev = {n: ctx.upload(v) for n, v in p0.items()}
+    mom = {n: (ctx.zeros(v.size), ctx.zeros(v.size)) for n, v in p0.items()}
+    tick, lrd = ctx.upload(np.array([4, 0, 0, 0], np.int32)), ctx.upload(np.array([lr], np.float32))
+    fz = lambda n: AdamFuse(int(dev[n]), int(mom[n][0]), int(mom[n][1]), int(tick), int(lrd), 0.9, 0.999, 1e-8, 1e-4)
+    gcb = [ctx.empty(c_conv) for _ in range(steps)]
+    dw = [ctx.empty(c * k) for _ in range(steps)]
+    db_, cs_, loss = ctx.empty(c), ctx.empty(k), [ctx.empty(1) for _ in range(steps)]
+    hd, yd = ctx.upload(h), ctx.upload(y)
+    fs = [WideFuse(fz("w"), fz("b"), fz("cb"), int(gcb[s]), c_conv, hw) for s in range(steps)]
+    ctx.graph_begin()
+    for s in range(steps):
+        ctx.call("th_linear_xent_wide_fused", hd, dev["w"], dev["b"], yd, batch, k, c, loss[s], None, dw[s], db_, None, 0, None, 0, tick, cs_, C.byref(fs[s]))
+    g = ctx.graph_end()
+    from taper_amd._lib import hip as lib, th_check
+
+    def put(buf, a):
+        a = np.ascontiguousarray(a)
+        th_check(lib.th_memcpy_h2d(ctx.h, int(buf), a.ctypes.data, a.nbytes), "th_memcpy_h2d")
+
+    def restore():
+        for n, v in p0.items():
+            put(dev[n], v)
+            put(mom[n][0], np.zeros(v.size, np.float32))
+            put(mom[n][1], np.zeros(v.size, np.float32))
+        put(tick, np.array([4, 0, 0, 0], np.int32))
+
+    def collect():
+        got = {n: ctx.download(dev[n], v.size) for n, v in p0.items()}
+        got["cb_m"] = ctx.download(mom["cb"][0], c_conv)
+        got["gcb"] = np.stack([ctx.download(b, c_conv) for b in gcb])
+        got["losses"] = np.array([ctx.download(l, 1)[0] for l in loss])
+        got["dw0"] = ctx.download(dw[0], (c, k))
+        got["t"] = ctx.download(tick, 4, np.int32)[:2]
+        return got
+
+    try:
+        first = _replay_identical(ctx, g, restore, collect, replays)
+    finally:
+        ctx.graph_destroy(g)
+    np.testing.assert_array_equal(first["t"], [4 + steps, 0])               # ticked once per launch, the arrival counter back at 0
+    ref = oracle_head(O, h, p0["w"], p0["b"], y)
+    assert first["losses"][0] == pytest.approx(ref["loss"], rel=RTOL, abs=1e-6)
+    dh = np.asarray(ref["dh"]).reshape(batch, k)
+    gcb_ref = (dh * (h > 0)).sum(axis=0, dtype=np.float64).reshape(c_conv, hw).sum(axis=1).astype(np.float32)
+    test = "test_wide_fused_last_arrival_repeats_bit_identical_beside_hbm_traffic"
+    margins.check("conv_bias_grad_step0", first["gcb"][0], gcb_ref, RTOL, test=test)
+    margins.check("dw_step0", first["dw0"], np.asarray(ref["dw"]).reshape(c, k), RTOL, test=test)
+
+
+# ------------------------------------------------------------------------------------------------------------------ th_adam_step
+def test_adam_step_tick_repeats_bit_identical_beside_hbm_traffic(ctx, O, traffic):
+    """a multi-workgroup arena (the MLP's four tensors + one without a gradient, Q8): every workgroup derives t + 1 itself, the last one to
+    finish publishes it; 8 captured steps x 8 replays"""
+    steps, replays, lr = 8, 8, 1e-3
+    rng = np.random.default_rng(21)
+    sizes, has = [128 * 784, 128, 1280, 10, 7], [1, 1, 1, 1, 0]
+    offs = np.zeros(len(sizes) + 1, np.int64)
+    for i, s in enumerate(sizes):
+        offs[i + 1] = offs[i] + (s + 3) // 4 * 4
+    total = int(offs[-1])
+    p0 = rng.uniform(-0.1, 0.1, total).astype(np.float32)
+    gs = [(rng.standard_normal(total) * 0.01).astype(np.float32) for _ in range(steps)]
+    dp, dm, dv = ctx.upload(p0), ctx.zeros(total), ctx.zeros(total)
+    dg = [ctx.upload(g) for g in gs]
+    doffs, dhas = ctx.upload(offs), ctx.upload(np.array(has, np.int32))
+    state, dlr = ctx.upload(np.zeros(2, np.int32)), ctx.upload(np.array([lr], np.float32))
+    ctx.graph_begin()
+    for s in range(steps):
+        ctx.call("th_adam_step", dp, dg[s], dm, dv, doffs, dhas, len(sizes), total, state, dlr, 0.9, 0.999, 1e-8, 1e-4, 0)
+    g = ctx.graph_end()
+    from taper_amd._lib import hip as lib, th_check
+
+    def put(buf, a):
+        a = np.ascontiguousarray(a)
+        th_check(lib.th_memcpy_h2d(ctx.h, int(buf), a.ctypes.data, a.nbytes), "th_memcpy_h2d")
+
+    def restore():
+        put(dp, p0)
+        put(dm, np.zeros(total, np.float32))
+        put(dv, np.zeros(total, np.float32))
+        put(state, np.zeros(2, np.int32))
+
+    def collect():
+        return dict(p=ctx.download(dp, total), m=ctx.download(dm, total), v=ctx.download(dv, total), t=ctx.download(state, 2, np.int32))
+
+    try:
+        first = _replay_identical(ctx, g, restore, collect, replays)
+    finally:
+        ctx.graph_destroy(g)
+    np.testing.assert_array_equal(first["t"], [steps, 0])
+    params = [O.Tensor(p0[offs[i]:offs[i] + s]).requires_grad() for i, s in enumerate(sizes)]
+    oopt = O.Adam(params, lr, None, None, 1e-4)
+    for gstep in gs:
+        for i, s in enumerate(sizes):
+            params[i].set_grad(gstep[offs[i]:offs[i] + s] if has[i] else None)
+        oopt.step()
+    for i, s in enumerate(sizes):
+        np.testing.assert_allclose(first["p"][offs[i]:offs[i] + s], params[i].data(), rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(first["m"][offs[i]:offs[i] + s], oopt.m(i), rtol=RTOL, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------------------------ two ranks x 512 rows
+def test_two_ranks_of_512_rows_repeat_bit_identical_beside_hbm_traffic(tmp_path, traffic):
+    """tests/test_gpu_dp.py::test_p2p_two_ranks_of_512_rows_take_the_three_launch_step's run, 12 times over inside one pair of processes
+    (captured graphs and communicator kept, parameters / moments / t restored): 12 x 8 steps per rank, every run's losses and weights equal
+    to the first run's bit for bit, replicas identical, and the run equal to one process on the global batches (the DP test's own check)"""
+    from tests.test_gpu_dp import _check, _run_ranks
+    runs, steps, gb = 12, 4, 1024
+    os.environ["TAPER_DP_REPEAT"] = str(runs)
+    try:
+        ranks = _run_ranks(tmp_path, 2, "p2p", "graph", steps=steps, global_batch=gb, same_device=True)
+    finally:
+        del os.environ["TAPER_DP_REPEAT"]
+    for r in range(2):
+        assert int(ranks[r]["mlp2_calls"]) > 0                                  # 512 rows per rank: the large-batch step ran
+        for run in range(1, runs):
+            np.testing.assert_array_equal(ranks[r][f"run{run}_losses"], ranks[r]["run0_losses"], err_msg=f"rank {r} run {run}: losses moved")
+            for i in range(4):
+                np.testing.assert_array_equal(ranks[r][f"run{run}_p{i}"], ranks[r][f"run0_p{i}"], err_msg=f"rank {r} run {run}: param {i} moved")
+    for run in range(runs):
+        for i in range(4):
+            np.testing.assert_array_equal(ranks[0][f"run{run}_p{i}"], ranks[1][f"run{run}_p{i}"], err_msg=f"run {run}: replicas diverged in param {i}")
+    _check(ranks, 2, steps, gb)
