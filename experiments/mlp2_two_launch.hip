@@ -97,6 +97,7 @@ struct Mlp2RowsArgs {
     int ksplit;          // 16-row form only: workgroups per row block, each contracting a share of the k chunks (1: none)
     float *kpart;        // [gridDim.x][2048]: a workgroup's accumulators, in register order
     unsigned *karrive;   // [row blocks]: arrival counters (the context's: zero between launches -- the last arrival resets its own)
+    unsigned *sync2;     // [16]: launch 2's arrival counters and job tickets, zeroed here (launch 2 starts when this launch has ended)
 };
 
 // ---------------------------------------------------------------------------------------------------------------- launch 1
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
     const int r0 = blk * RT, B = a.batch, in_f = a.in_f, hid = a.hid, C = a.c;
     M2_STAMP(0, blockIdx.x == 0);
     if (a.tick && blockIdx.x == 0 && t == 0) a.tick[0] += 1;                  // optim.rs:84 (the launch that reads t comes later)
+    if (blockIdx.x == 0 && t < 16) a.sync2[t] = 0u;
     const long cur = (a.src.idx && a.src.cursor) ? a.src.cursor[0] : 0;
 
     // ---- staging plans: lane -> (row, k quad) of the 1 KB an LDS-DMA instruction fills; instruction i = NW j + wave covers rows 8 i .. 8 i + 7 ----
@@ -491,140 +493,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
 }
 
 // ---------------------------------------------------------------------------------------------------------------- launch 2
-struct Mlp2DwArgs {
-    RowSource src;
-    const float *dz1;     // [rows_pad][hid]
-    unsigned dz_bytes;
-    int rows_pad, batch, in_f, hid;
-    float *partial;       // [kz][hid][in_f]
-    int tiles_n, kz, kslice;   // kslice a multiple of 32
-};
-
-// dW1[m = hidden][n = in] over rows [z kslice, (z + 1) kslice): A(m, k) = dZ1[k][m], B(k, n) = X[row k][n] -- both m / n-contiguous, staged as
-// they lie in memory ([32 k][128] images, gemm.hip's m/n-contiguous form: ds_read_b32, lanes on consecutive m / n).  The last n tile reads
-// beyond a row's end (into the next row; beyond the buffer: zeros): those columns are never stored.
-template <int NS, int WGS, bool INDEXED>
-__global__ __launch_bounds__(256, WGS) void mlp2_dw1_kernel(Mlp2DwArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = 128, T_T = TS * M2_BK, STG = 2 * T_T, L = 8;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lk = lane >> 5;
-    // block b runs on XCD b % 8: every XCD takes a contiguous run of (K slice, n tile) pairs, n innermost -- the tiles of a slice share its dZ1 rows
-    const int nwg = a.tiles_n * a.kz, bid = blockIdx.x;
-    const int xcd = bid % kNumXCD, q = nwg / kNumXCD, rmd = nwg % kNumXCD;
-    const int w = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + bid / kNumXCD;
-    const int z = w / a.tiles_n, tn = w % a.tiles_n;
-    const int n0 = tn * TS, in_f = a.in_f, hid = a.hid;
-    const int kbeg = z * a.kslice, kend = min(a.rows_pad, kbeg + a.kslice), nt = (kend - kbeg) / M2_BK;
-    // The dataset rows of this K slice, resolved once into LDS (behind the ring): row r of the batch is idx[(cursor + r) % n].  The cursor was
-    // advanced by the PREVIOUS step's finish launch; positions are cursor % n + r < 2 n (batch <= n, host-checked).  In the loop a lane then
-    // picks its rows' entries with ds_read -- a scalar or vector load there would sit in the same in-order / unordered counters as the ring's
-    // LDS-DMA and the operand reads, and waiting for it would drain them.
-    int *rows_l = reinterpret_cast<int *>(smem + NS * STG);
-    {
-        const int n_idx = INDEXED ? (int)a.src.n_idx : 1;
-        const int cur = (INDEXED && a.src.cursor) ? (int)(sload(a.src.cursor) % a.src.n_idx) : 0;
-        for (int i = t; i < nt * M2_BK; i += 256) {
-            const int row = min(kbeg + i, a.batch - 1);
-            const int p = cur + row;
-            rows_l[i] = INDEXED ? a.src.idx[p >= n_idx ? p - n_idx : p] : row;
-        }
-    }
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-    // staging: instruction j of wave w fills 16-byte units 64 (4 j + w) .. + 63 of the image = k rows 2 (4 j + w) and + 1, 32 quads each.
-    // The two rows' dataset indices are wave-uniform: scalar loads, a chunk ahead of the fetch that needs them.
-    int a_voff[4];
-    const int quad = lane & 31, upper = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a_voff[j] = (int)((unsigned)(2 * (4 * j + wave) + upper) * (unsigned)hid * 4u + (unsigned)(quad << 4));
-    const i32x4 rs_a = make_rsrc(a.dz1, a.dz_bytes), rs_x = make_rsrc(a.src.x, a.src.x_bytes);
-    const unsigned lds0 = lds_addr(smem);
-    const unsigned xq = (unsigned)(n0 + quad * 4) * 4u;
-    auto fetch = [&](int it, int stage) {
-        const int k0 = kbeg + it * M2_BK;
-        const unsigned st = lds0 + (unsigned)(stage * STG) * 4u;
-        int srow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) srow[j] = rows_l[it * M2_BK + 2 * (4 * j + wave) + upper];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            lds_dma16(rs_a, st + 1024u * (unsigned)(4 * j + wave), a_voff[j], (int)((unsigned)k0 * (unsigned)hid * 4u));
-            lds_dma16(rs_x, st + (unsigned)T_T * 4u + 1024u * (unsigned)(4 * j + wave), (int)((unsigned)srow[j] * (unsigned)in_f * 4u + xq), 0);
-        }
-    };
-
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    int ao[2], bo[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        ao[i] = 4 * lk * TS + wm + 32 * i + li;
-        bo[i] = 4 * lk * TS + wn + 32 * i + li;
-    }
-    M2_STAMP(6, blockIdx.x == 0);
-    __syncthreads();                              // rows_l is complete
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nt) fetch(s, s);
-    int stage = 0;
-    for (int it = 0; it < nt; ++it) {
-        if (it + NS - 1 <= nt) wait_vmcnt<(NS - 2) * L>();
-        else wait_vmcnt<0>();
-        lds_barrier();
-        const int nxt = it + NS - 1;
-        if (nxt < nt) fetch(nxt, stage == 0 ? NS - 1 : stage - 1);
-        const float *as = smem + stage * STG, *bs = as + T_T;
-        float4 af[2][2], bf[2][2];
-#define M2_FRAG(S, O, RR) make_float4((S)[(O) + (8 * (RR)) * TS], (S)[(O) + (8 * (RR) + 1) * TS], (S)[(O) + (8 * (RR) + 2) * TS], (S)[(O) + (8 * (RR) + 3) * TS])
-#define M2_REQ(SET, RR)                                  \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {      \
-        af[SET][i] = M2_FRAG(as, ao[i], RR);             \
-        bf[SET][i] = M2_FRAG(bs, bo[i], RR);             \
-    }
-#define M2_MFMA(CS, E)                                   \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)        \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CS][i].E, bf[CS][j].E, acc[i][j], 0, 0, 0);
-        M2_REQ(0, 0)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cs = r & 1;
-            if (r + 1 < 4) { M2_REQ(cs ^ 1, r + 1) }
-            __builtin_amdgcn_sched_barrier(0);
-            M2_MFMA(cs, x)
-            M2_MFMA(cs, y)
-            M2_MFMA(cs, z)
-            M2_MFMA(cs, w)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef M2_MFMA
-#undef M2_REQ
-#undef M2_FRAG
-        stage = stage + 1 == NS ? 0 : stage + 1;
-    }
-    M2_STAMP(7, blockIdx.x == 0);
-    float *out = a.partial + (long)z * hid * in_f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn + 32 * j + li;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (row < hid && col < in_f) out[(long)row * in_f + col] = acc[i][j][e];
-            }
-        }
-    M2_STAMP(8, blockIdx.x == 0);
-    M2_STAMP(9, blockIdx.x == gridDim.x - 1);
-#endif
-}
-
 // ---- launch 2, second form (default): ONE workgroup of eight waves per CU on a 128 x 112 tile -----------------------------------------
 // 784 = 7 x 112: no padded columns (the 128-wide tiles above compute 896).  The K slices hand out whole 32-row chunks, the first
 // n_chunks % kz slices one more than the rest, and 7 kz <= 256: every CU holds exactly one workgroup, all of (nearly) equal length -- the
@@ -640,9 +508,97 @@ struct Mlp2Dw8Args {
     const float *dz1;     // [rows_pad][hid]
     unsigned dz_bytes;
     int rows_pad, batch, in_f, hid;
-    float *partial;       // [kz][hid][in_f]
+    float *slabs;         // [kz][tiles_n][56 units][64 lanes] float4: a workgroup's accumulators in REGISTER order (unit = 7 wave + column tile)
     int tiles_n, kz;      // tiles of 112 columns
+    unsigned *sync;       // [tile]: arrivals; [8 + tile]: job tickets (both zeroed by launch 1 of the same step)
+    long help_ticks;      // how long (100 MHz ticks) a workgroup that is not the last to arrive waits for its tile to complete before it leaves
+    float *dw1;           // [hid][in_f]
+    AdamDev w1a;
+    // the row blocks' partial sums of launch 1 (m2_tail_job)
+    const float *part;    // [n_blk][part_stride]
+    int n_blk, part_stride, c;
+    float *db1, *dw2, *db2, *loss, *ncorrect, *metrics;
+    int64_t capacity;
+    int64_t *state;
+    int64_t advance;
+    AdamDev b1a, w2a, b2a;
 };
+
+__device__ __forceinline__ void m2_apply(const AdamDev &ad, long i, float g) {
+    if (ad.p) adam_update(ad.p, ad.m, ad.v, i, g, adam_dev_step(ad), ad.beta1, ad.beta2, ad.eps, ad.wd);
+}
+
+// The row blocks' partial sums of launch 1 (dW2 [c][hid], db1 [hid], db2 [16], {nll, hits}; complete at the kernel boundary), as JOBS of one
+// pass of a 512-thread workgroup: a float4 of four consecutive elements is summed by SUBS = 16 / 32 / 64 threads (more where there are more
+// row blocks: <= 16 loads per thread) -- thread `sub` adds the blocks sub, sub + SUBS, ... in order, all requests out before the first add,
+// and the SUBS sums meet in a fixed shuffle tree: the order depends on n_blk alone.  A job covers 512 / SUBS float4s.  The sums are the
+// gradients (written), the loss, the hit count and the step log; Adam (optim.rs:99-110) in the same threads: no launch of the step reads a
+// parameter after this one, and no workgroup of THIS launch reads W2 / b1 / b2.  The jobs are done by the FIRST workgroups to arrive on each
+// tile's counter (mlp2_dw1_kernel8: the ones with the most time before their tile completes) -- r05's first form gave them to four extra
+// workgroups, which needed 24 us for six dependent rounds of loads and became the launch's critical path below 16 384 rows.
+__host__ __device__ inline int m2_tail_subs(int n_blk) { return n_blk <= 256 ? 16 : (n_blk <= 512 ? 32 : 64); }
+__host__ __device__ inline int m2_tail_jobs(int c, int hid, int n_blk) {
+    const int n_quads = (c * hid + hid + 16 + 2 + 3) / 4, qpj = 512 / m2_tail_subs(n_blk);
+    return (n_quads + qpj - 1) / qpj;
+}
+
+template <int SUBS>
+__device__ __forceinline__ void m2_tail_job(const Mlp2Dw8Args &a, int job, int t) {
+    const int o_db1 = a.c * a.hid, o_db2 = o_db1 + a.hid, o_nll = o_db2 + 16, n_quads = (o_nll + 2 + 3) / 4;
+    const int qd = job * (512 / SUBS) + t / SUBS, sub = t % SUBS;
+    const bool live = qd < n_quads;                // (whole SUBS-lane groups share qd)
+    const float *src = a.part + 4 * (live ? qd : 0);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b0 = sub; b0 < a.n_blk; b0 += SUBS * 16) {
+        float4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const float4 *>(src + (long)min(b0 + SUBS * j, a.n_blk - 1) * a.part_stride);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (b0 + SUBS * j < a.n_blk) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+    }
+#pragma unroll
+    for (int off = SUBS / 2; off > 0; off >>= 1) {
+        s.x += __shfl_down(s.x, off, SUBS);
+        s.y += __shfl_down(s.y, off, SUBS);
+        s.z += __shfl_down(s.z, off, SUBS);
+        s.w += __shfl_down(s.w, off, SUBS);
+    }
+    if (sub != 0 || !live) return;
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+    if (4 * qd == o_nll) {
+        const float l = sv[0] / (float)a.batch;       // loss.rs:164
+        a.loss[0] = l;
+        if (a.ncorrect) a.ncorrect[0] = sv[1];
+        if (a.metrics) {                              // th_log_step
+            const int64_t s0 = a.state[0], s1 = a.state[1];
+            const int64_t slot = s0 < a.capacity ? s0 : s0 % a.capacity;
+            a.metrics[2 * slot] = l;
+            a.metrics[2 * slot + 1] = sv[1];
+            a.state[0] = s0 + 1;
+            a.state[1] = s1 + a.advance;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = 4 * qd + j;
+        if (e < o_db1) {
+            a.dw2[e] = sv[j];
+            m2_apply(a.w2a, e, sv[j]);
+        } else if (e < o_db2) {
+            if (a.db1) {
+                a.db1[e - o_db1] = sv[j];
+                m2_apply(a.b1a, e - o_db1, sv[j]);
+            }
+        } else if (e < o_nll) {
+            if (a.db2 && e - o_db2 < a.c) {
+                a.db2[e - o_db2] = sv[j];
+                m2_apply(a.b2a, e - o_db2, sv[j]);
+            }
+        }
+    }
+}
 
 template <int NS, bool INDEXED>
 __global__ __launch_bounds__(512, 1) void mlp2_dw1_kernel8(Mlp2Dw8Args a) {
@@ -740,148 +696,133 @@ __global__ __launch_bounds__(512, 1) void mlp2_dw1_kernel8(Mlp2Dw8Args a) {
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
     M2_STAMP(7, blockIdx.x == 0);
-    // C/D map of 16x16x4: acc[i][e] = dW1[m = 16 wave + 4 g4 + e][n = n0 + 16 i + l16]
-    float *out = a.partial + (long)z * hid * in_f;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int col = n0 + 16 * i + l16;
+    // ---- the K slices of a tile meet INSIDE the launch (r05: the third launch -- 36 x 401 KB of partial sums written here, read back there
+    // at 0.25 of HBM, a boundary -- is gone).  C/D map of 16x16x4: acc[i][e] = dW1[m = 16 wave + 4 g4 + e][n = n0 + 16 i + l16]; a slab holds
+    // a workgroup's accumulators in REGISTER order, unit u = 7 wave + i, 1 KB per unit: seven coalesced 16-byte stores per lane, and the
+    // reader's lane (u, l) finds the same element of every slice at the same offset.
+    //   1. the slab goes to MEMORY (system-coherent stores: not through this XCD's L2 -- the slices of a tile sit on all eight XCDs) and is
+    //      waited for in the statement that stores it (the store data stay inputs until the stores are done: DESIGN 6c, r04's hazard);
+    //   2. one arrival per workgroup on the tile's counter.  The LAST to arrive sees all kz slabs; a workgroup that is not the last waits
+    //      -- bounded by the wall clock -- for the tile to complete and then HELPS: the tile's 56 units are 28 jobs handed out by a ticket
+    //      counter, and whoever has seen the tile complete draws tickets until none is left.  The last arrival always does, so every job is
+    //      done whoever else is there: nobody depends on another workgroup being resident (no deadlock when the GPU is shared; a helper
+    //      whose wait runs out simply leaves), and with the GPU to itself the slices end within a chunk of each other, so ~36 workgroups
+    //      share a tile's 2 MB instead of one reading it all.
+    //   3. a job = two units: waves 0-3 / 4-7 take one each, wave q of a half adds the slices z = q, q + 4, ... IN ORDER (system-coherent
+    //      loads, all requests out before the first add), the four sums meet in LDS in the order q = 0..3, and that lane writes the
+    //      gradient and applies Adam (optim.rs:99-110) to its four elements -- p / m / v requested before the slab loads.  The order of
+    //      every sum is a function of kz alone: the same bits whoever does the job.
+    float *mine = a.slabs + ((long)(z * a.tiles_n + tn) * 56 + 7 * wave) * 256 + lane * 4;
+    asm volatile("global_store_dwordx4 %0, %2, off sc0 sc1\n\t"
+                 "global_store_dwordx4 %0, %3, off offset:1024 sc0 sc1\n\t"
+                 "global_store_dwordx4 %0, %4, off offset:2048 sc0 sc1\n\t"
+                 "global_store_dwordx4 %0, %5, off offset:3072 sc0 sc1\n\t"
+                 "global_store_dwordx4 %1, %6, off sc0 sc1\n\t"
+                 "global_store_dwordx4 %1, %7, off offset:1024 sc0 sc1\n\t"
+                 "global_store_dwordx4 %1, %8, off offset:2048 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 ::"v"(mine), "v"(mine + 1024), "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]) : "memory");
+    __syncthreads();                              // every wave's stores are acknowledged; the ring is dead
+    M2_STAMP(8, blockIdx.x == 0);
+    int *sh_i = reinterpret_cast<int *>(smem);    // [0]: has this workgroup seen its tile complete; [1]: the ticket drawn
+    floatx4 *comb = reinterpret_cast<floatx4 *>(smem + 64);   // [half][q = 1..3][lane]
+    if (t == 0) sh_i[2] = (int)__hip_atomic_fetch_add(&a.sync[tn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrival = sh_i[2];                   // 0 .. kz - 1: every value exactly once per tile
+    // the first workgroups of a tile to arrive take the sums over launch 1's row blocks (static: job = f(tile, arrival index), no ticket)
+    {
+        const int n_jobs = m2_tail_jobs(a.c, hid, a.n_blk), jpt = (n_jobs + a.tiles_n - 1) / a.tiles_n, subs = m2_tail_subs(a.n_blk);
+        for (int j = arrival; j < jpt; j += a.kz) {
+            const int job = tn * jpt + j;
+            if (job >= n_jobs) break;
+            if (subs == 16) m2_tail_job<16>(a, job, t);
+            else if (subs == 32) m2_tail_job<32>(a, job, t);
+            else m2_tail_job<64>(a, job, t);
+        }
+    }
+    if (t == 0) {
+        const unsigned kz = (unsigned)a.kz;
+        bool done = (unsigned)arrival + 1u == kz;
+        if (!done && a.help_ticks > 0) {
+            const long t0 = wall_clock64();
+            for (;;) {
+                done = __hip_atomic_load(&a.sync[tn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kz;
+                if (done || wall_clock64() - t0 >= a.help_ticks) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        sh_i[0] = done ? 1 : 0;
+    }
+    __syncthreads();
+    M2_STAMP(10, blockIdx.x == 0);
+    if (!sh_i[0]) return;                         // (the whole workgroup: uniform)
+    const int half = wave >> 2, qz = wave & 3;
+    const float step = a.w1a.p ? adam_dev_step(a.w1a) : 0.f;
+    for (;;) {
+        __syncthreads();                          // the previous round's ticket and sums have been read
+        if (t == 0) sh_i[1] = (int)__hip_atomic_fetch_add(&a.sync[8 + tn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int job = sh_i[1];
+        M2_STAMP(11, blockIdx.x == 0);
+        if (job >= 28) break;
+        const int u = 2 * job + half, uw = u / 7, ui = u - 7 * uw;     // the unit: wave uw's column tile ui
+        const int col = n0 + 16 * ui + l16, row0 = 16 * uw + 4 * g4;
+        const bool fin = qz == 0, col_ok = col < in_f;
+        float pv[4], mv[4], vv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int row = 16 * wave + 4 * g4 + e;
-            if (row < hid && col < in_f) out[(long)row * in_f + col] = acc[i][e];
+            const bool ok = fin && a.w1a.p && col_ok && row0 + e < hid;
+            const long i = (long)(row0 + e) * in_f + col;
+            pv[e] = ok ? a.w1a.p[i] : 0.f;
+            mv[e] = ok ? a.w1a.m[i] : 0.f;
+            vv[e] = ok ? a.w1a.v[i] : 0.f;
         }
-    }
-    M2_STAMP(8, blockIdx.x == 0);
-    M2_STAMP(9, blockIdx.x == gridDim.x - 1);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------- launch 3
-struct Mlp2FinishArgs {
-    const float *partial;   // [kz][hid * in_f]
-    const float *part;      // [n_blk][part_stride]
-    int kz, n_blk, part_stride, batch, in_f, hid, c;
-    float *dw1, *db1, *dw2, *db2, *loss, *ncorrect, *metrics;
-    int64_t capacity;
-    int64_t *state;
-    int64_t advance;
-    AdamDev w1a, b1a, w2a, b2a;
-    int w1_blocks;
-};
-
-__device__ __forceinline__ void m2_apply(const AdamDev &ad, long i, float g) {
-    if (ad.p) adam_update(ad.p, ad.m, ad.v, i, g, adam_dev_step(ad), ad.beta1, ad.beta2, ad.eps, ad.wd);
-}
-
-// Two roles.  dW1: a workgroup owns 16 float4 of the gradient, 16 threads per float4 add the K slices z = zg, zg + 16, ... and the first
-// adds the 16 sums in order.  The row blocks' partial sums: a workgroup owns 16 of the elements, 16 threads per element add the
-// blocks b = sub, sub + 16, ..., the first adds the 16 sums in order.  (One thread per element adding 64 slices / 256 blocks one after
-// the other is a chain of dependent round trips: 62.6 us at batch 16 384 for 26 MB.)
-__global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
-    __shared__ float4 sh4[16][16];
-    const int bid = blockIdx.x, t = threadIdx.x;
-    M2_STAMP(10, blockIdx.x == 0);
-    M2_STAMP(11, blockIdx.x == gridDim.x - 1);
-    if (bid < a.w1_blocks) {
-        // 16 float4 of the gradient per workgroup, 16 threads per float4: thread zg adds slices zg, zg + 16, ...; thread 0 adds the 16 sums in order
-        const long mn = (long)a.hid * a.in_f, i0 = ((long)bid * 16 + (t & 15)) * 4;
-        const int zg = t >> 4;
-        // the owner's Adam operands are requested FIRST: behind the sums they would be a second dependent round trip
-        const bool owner = zg == 0 && i0 < mn, fuse = owner && a.w1a.p != nullptr;
-        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), mv = pv, vv = pv;
-        float step = 0.f;
-        if (fuse) {
-            pv = *reinterpret_cast<const float4 *>(a.w1a.p + i0);
-            mv = *reinterpret_cast<const float4 *>(a.w1a.m + i0);
-            vv = *reinterpret_cast<const float4 *>(a.w1a.v + i0);
-            step = adam_dev_step(a.w1a);
-        }
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i0 < mn) {
-#pragma unroll 4
-            for (int z = zg; z < a.kz; z += 16) {
-                const float4 v = *reinterpret_cast<const float4 *>(a.partial + (long)z * mn + i0);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        const float *sl = a.slabs + ((long)tn * 56 + u) * 256 + lane * 4;
+        const long zs = (long)a.tiles_n * 56 * 256;                    // floats from one slice's slab of this tile to the next
+        floatx4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int z0 = qz; z0 < a.kz; z0 += 4 * 9) {
+            floatx4 v[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {                              // (slices past kz: the last one again, dropped below -- no branch between a load and its wait)
+                const float *pz = sl + (long)min(z0 + 4 * j, a.kz - 1) * zs;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[j]) : "v"(pz) : "memory");
             }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[j]) : : "memory");
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sum = z0 + 4 * j < a.kz ? sum + v[j] : sum;
         }
-        sh4[zg][t & 15] = s;
+        if (qz != 0) comb[(half * 3 + qz - 1) * 64 + lane] = sum;
         __syncthreads();
-        if (zg != 0 || i0 >= mn) return;
+        M2_STAMP(12, blockIdx.x == 0);
+        if (fin) {
 #pragma unroll
-        for (int u = 1; u < 16; ++u) {
-            const float4 p = sh4[u][t];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-        }
-        *reinterpret_cast<float4 *>(a.dw1 + i0) = s;
-        if (fuse) {      // optim.rs:99-110, element by element as adam_update does
-            const AdamDev &ad = a.w1a;
-            float4 po, mo, vo;
-#define M2_ADAM(k)                                                       \
-            {                                                            \
-                const float gg = s.k + ad.wd * pv.k;                     \
-                mo.k = ad.beta1 * mv.k + (1.0f - ad.beta1) * gg;         \
-                vo.k = ad.beta2 * vv.k + (1.0f - ad.beta2) * gg * gg;    \
-                po.k = pv.k - step * mo.k / (sqrtf(vo.k) + ad.eps);      \
+            for (int qq = 0; qq < 3; ++qq) sum += comb[(half * 3 + qq) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!(col_ok && row0 + e < hid)) continue;
+                const long i = (long)(row0 + e) * in_f + col;
+                const float g = sum[e];
+                a.dw1[i] = g;
+                if (a.w1a.p) {                                         // optim.rs:99-110, as adam_update does
+                    const AdamDev &ad = a.w1a;
+                    const float gg = g + ad.wd * pv[e];
+                    const float mo = ad.beta1 * mv[e] + (1.0f - ad.beta1) * gg;
+                    const float vo = ad.beta2 * vv[e] + (1.0f - ad.beta2) * gg * gg;
+                    ad.m[i] = mo;
+                    ad.v[i] = vo;
+                    ad.p[i] = pv[e] - step * mo / (sqrtf(vo) + ad.eps);
+                }
             }
-            M2_ADAM(x) M2_ADAM(y) M2_ADAM(z) M2_ADAM(w)
-#undef M2_ADAM
-            *reinterpret_cast<float4 *>(ad.m + i0) = mo;
-            *reinterpret_cast<float4 *>(ad.v + i0) = vo;
-            *reinterpret_cast<float4 *>(ad.p + i0) = po;
-        }
-        return;
-    }
-    // the row blocks' partial sums
-    float(*sh)[16][2] = reinterpret_cast<float(*)[16][2]>(&sh4[0][0]);       // [sub][element][value, second value]
-    const int el = t & 15, sub = t >> 4, e = (bid - a.w1_blocks) * 16 + el;
-    const int o_db1 = a.c * a.hid, o_db2 = o_db1 + a.hid, o_nll = o_db2 + 16;
-    float s = 0.f, s2 = 0.f;
-    if (e <= o_nll) {
-#pragma unroll 4
-        for (int b = sub; b < a.n_blk; b += 16) {
-            s += a.part[(long)b * a.part_stride + e];
-            if (e == o_nll) s2 += a.part[(long)b * a.part_stride + e + 1];
         }
     }
-    sh[sub][el][0] = s;
-    sh[sub][el][1] = s2;
-    __syncthreads();
-    if (sub != 0 || e > o_nll) return;
-#pragma unroll
-    for (int u = 1; u < 16; ++u) {
-        s += sh[u][el][0];
-        s2 += sh[u][el][1];
-    }
-    if (e < o_db1) {
-        a.dw2[e] = s;
-        m2_apply(a.w2a, e, s);
-    } else if (e < o_db2) {
-        if (a.db1) {
-            a.db1[e - o_db1] = s;
-            m2_apply(a.b1a, e - o_db1, s);
-        }
-    } else if (e < o_nll) {
-        if (a.db2 && e - o_db2 < a.c) {
-            a.db2[e - o_db2] = s;
-            m2_apply(a.b2a, e - o_db2, s);
-        }
-    } else {
-        const float l = s / (float)a.batch;       // loss.rs:164
-        a.loss[0] = l;
-        if (a.ncorrect) a.ncorrect[0] = s2;
-        if (a.metrics) {                          // th_log_step
-            const int64_t s0 = a.state[0], s1 = a.state[1];
-            const int64_t slot = s0 < a.capacity ? s0 : s0 % a.capacity;
-            a.metrics[2 * slot] = l;
-            a.metrics[2 * slot + 1] = s2;
-            a.state[0] = s0 + 1;
-            a.state[1] = s1 + a.advance;
-        }
-    }
+    M2_STAMP(9, blockIdx.x == 0);
+#endif
 }
 
 thread_local long t_mlp2_calls = 0;
 thread_local int t_mlp2_only = 0;      // th_debug_mlp2_only: 0 = the step; 1 / 2 / 3 = that launch alone (per-launch timing; workspace kept from call to call)
+thread_local int t_mlp2_help_us = -1;  // th_debug_mlp2_help_us: >= 0 = how long launch 2's workgroups wait for their tile to complete before they leave (0: the last arrival sums alone); -1 = default
 thread_local int t_mlp2_ksplit = 0;    // th_debug_mlp2_ksplit: 1 .. 8 = that k split on the 16-row tiles whatever the cap says (tests/test_gpu_repro.py); 0 = default
 
 static int m2_rows_per_block(int batch) {
@@ -925,28 +866,14 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     // (16-row tiles: an even number of row blocks, so that launch 2 sees whole 32-row chunks; a block past the batch writes zeros)
     const int n_blk = RT == 16 ? 2 * ceil_div(batch, 32) : ceil_div(batch, RT), rows_pad = n_blk * RT;
     const int stride = (classes * hidden + hidden + 16 + 2 + 3) & ~3;
-    // launch 2's form: 8 (default) = one eight-wave workgroup per CU on 128 x 112 tiles; TAPER_MLP2_DW = 22 | 31 | 32 | 41 = the four-wave
-    // 128 x 128 form with that many ring stages x workgroups per CU (measurement knob)
-    static const int variant = [] { const char *e = getenv("TAPER_MLP2_DW"); return e ? atoi(e) : 8; }();
-    const bool dw8 = variant == 8;
-    const int tiles_n = ceil_div(in_features, dw8 ? 112 : 128);
+    // launch 2: one eight-wave workgroup per CU on 128 x 112 tiles, the batch in kz K slices of whole 32-row chunks, + the tail workgroups
+    const int tiles_n = ceil_div(in_features, 112);
     static const int kz_forced = [] { const char *e = getenv("TAPER_MLP2_KZ"); return e ? atoi(e) : 0; }();
-    int kz, kslice = 0;
-    if (dw8) {
-        // as many slices as fit one workgroup per CU, at least one 32-row chunk each
-        kz = kz_forced > 0 ? kz_forced : kNumCU / tiles_n;
-        // at least two 32-row chunks per slice unless the knob says otherwise: one-chunk slices (batch 1 024: 32 of them) write twice the
-        // partial sums for launch 3 to read and gain nothing -- measured 33.3 -> 31.2 us per step at 1 024 rows, 36.0 -> 35.4 at 2 048
-        kz = std::max(1, std::min(kz, kz_forced > 0 ? rows_pad / M2_BK : std::max(1, rows_pad / (2 * M2_BK))));
-    } else {
-        // two workgroups per CU (two 64 KB double buffers), slices of at least 256 rows
-        const int dw_wgs = variant % 10 == 1 ? 1 : 2;
-        kz = kz_forced > 0 ? kz_forced : ceil_div(dw_wgs * kNumCU, tiles_n);
-        const int kz_max = rows_pad / 256 > 0 ? rows_pad / 256 : 1;
-        if (kz > kz_max) kz = kz_max;
-        kslice = ceil_div(ceil_div(rows_pad, kz), M2_BK) * M2_BK;
-        kz = ceil_div(rows_pad, kslice);
-    }
+    // as many slices as fit one workgroup per CU, at least two 32-row chunks
+    // each unless the knob says otherwise: one-chunk slices (batch 1 024: 32 of them) write twice the partial sums and gain nothing --
+    // measured 33.3 -> 31.2 us per step at 1 024 rows, 36.0 -> 35.4 at 2 048
+    int kz = kz_forced > 0 ? kz_forced : kNumCU / tiles_n;
+    kz = std::max(1, std::min(kz, kz_forced > 0 ? rows_pad / M2_BK : std::max(1, rows_pad / (2 * M2_BK))));
     // launch 1 on the 16-row tiles with few row blocks: as many workgroups per block as fill the CUs (up to 8) share its k chunks
     // (mlp2_rows_kernel): 4 at batch 1 024, 2 at 2 048, none from 4 096 on.  Measured through the C ABI: 31.1 -> 27.3 us per step at 1 024
     // rows (launch 1: 15.6 -> 11.5 us), 35.5 -> 33.1 at 2 048.  TAPER_MLP2_KSPLIT=1 turns it off (measurement knob).
@@ -960,11 +887,11 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     // tools/mlp2_repro_stress.py)
     static const int cap_env = [] { const char *e = getenv("TAPER_MLP2_KSPLIT_MAX"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
     if (!(RT == 16 && ksplit_forced >= 1 && ksplit_forced <= 8)) ksplit = std::max(1, std::min(ksplit, cap_env ? cap_env : ctx->m2_max_ksplit));   // (TAPER_MLP2_KSPLIT forces a split past the cap: the parity tests)
-    const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_partial = (size_t)kz * hidden * in_features;
+    const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_slabs = (size_t)kz * tiles_n * 56 * 256;
     const size_t n_kpart = ksplit > 1 ? (size_t)n_blk * ksplit * 2048 : 0;
     void *ws = nullptr;
-    if (th_malloc(ctx, (n_dz + n_part + n_partial + n_kpart) * sizeof(float), &ws)) return 1;
-    float *dz1 = (float *)ws, *part = dz1 + n_dz, *partial = part + n_part, *kpart = partial + n_partial;
+    if (th_malloc(ctx, (n_dz + n_part + n_slabs + n_kpart) * sizeof(float), &ws)) return 1;
+    float *dz1 = (float *)ws, *part = dz1 + n_dz, *slabs = part + n_part, *kpart = slabs + n_slabs;
 
     RowSource rs{src->d_rows, src->d_labels, src->d_indices, src->d_indices ? src->d_cursor : nullptr, src->n_indices,
                  (unsigned)((size_t)src->n_rows * in_features * 4)};
@@ -975,6 +902,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
     r.dz1 = dz1; r.part = part; r.part_stride = stride; r.tick = d_tick;
     r.ksplit = ksplit; r.kpart = kpart;
     r.karrive = ctx->m2_arrive;
+    r.sync2 = ctx->m2_arrive + 496;               // launch 2's arrival counters and job tickets: zeroed by launch 1
     // ring depth of launch 1: four stages (six for the 32-row tiles, one workgroup per CU, measured no faster: a lone wave per SIMD is bound by
     // its own issue order, not by the requests in flight)
 #define M2_ROWS_LAUNCH(RT_, NS_, NW_)                                                                                              \
@@ -1003,13 +931,26 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
 #undef M2_ROWS_LAUNCH
     TH_LAUNCH_CHECK();
 
-    if (only != 0 && only != 2) {
-    } else if (dw8) {
+    if (only == 0 || only == 2) {
+        if (only == 2) TH_HIP(hipMemsetAsync(r.sync2, 0, 16 * sizeof(unsigned), ctx->stream));   // (launch 2 alone, for timing: launch 1 did not run)
         Mlp2Dw8Args d{};
         d.src = rs;
         d.dz1 = dz1; d.dz_bytes = (unsigned)(n_dz * 4);
         d.rows_pad = rows_pad; d.batch = batch; d.in_f = in_features; d.hid = hidden;
-        d.partial = partial; d.tiles_n = tiles_n; d.kz = kz;
+        d.slabs = slabs; d.tiles_n = tiles_n; d.kz = kz;
+        d.sync = r.sync2;
+        // how long a workgroup that is not its tile's last arrival waits for the tile to complete (then it helps with the sums): the slices of a
+        // tile end within a chunk of each other when the GPU is ours (<= 1.5 us).  th_debug_mlp2_help_us / TAPER_MLP2_HELP_US; 0 = nobody waits
+        // (the last arrival of a tile does all of its sums: the fallback the protocol always has, measured as such)
+        static const int help_env = [] { const char *e = getenv("TAPER_MLP2_HELP_US"); return e ? atoi(e) : -1; }();
+        const int help_us = t_mlp2_help_us >= 0 ? t_mlp2_help_us : (help_env >= 0 ? help_env : 10);
+        d.help_ticks = (long)help_us * 100;
+        d.dw1 = d_dw1;
+        d.w1a = make_adam_dev(w1_fuse);
+        d.part = part; d.n_blk = n_blk; d.part_stride = stride; d.c = classes;
+        d.db1 = d_db1; d.dw2 = d_dw2; d.db2 = d_db2; d.loss = d_loss; d.ncorrect = d_ncorrect; d.metrics = d_metrics;
+        d.capacity = metrics_capacity; d.state = d_state; d.advance = advance;
+        d.b1a = make_adam_dev(b1_fuse); d.w2a = make_adam_dev(w2_fuse); d.b2a = make_adam_dev(b2_fuse);
         constexpr int NS8 = 4;
         const int max_chunks = ceil_div(rows_pad / M2_BK, kz);
         const size_t lds = (size_t)NS8 * (128 + 112) * M2_BK * sizeof(float) + (size_t)max_chunks * M2_BK * sizeof(int);
@@ -1018,38 +959,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
         TH_SET_MAX_LDS(ctx, (mlp2_dw1_kernel8<NS8, false>), 160 << 10);
         if (rs.idx) hipLaunchKernelGGL((mlp2_dw1_kernel8<NS8, true>), dim3(tiles_n * kz), dim3(512), lds, ctx->stream, d);
         else hipLaunchKernelGGL((mlp2_dw1_kernel8<NS8, false>), dim3(tiles_n * kz), dim3(512), lds, ctx->stream, d);
-    } else {
-        Mlp2DwArgs d{};
-        d.src = rs;
-        d.dz1 = dz1; d.dz_bytes = (unsigned)(n_dz * 4);
-        d.rows_pad = rows_pad; d.batch = batch; d.in_f = in_features; d.hid = hidden;
-        d.partial = partial; d.tiles_n = tiles_n; d.kz = kz; d.kslice = kslice;
-        const int ns = variant / 10 >= 2 && variant / 10 <= 4 ? variant / 10 : 2;
-        const size_t lds = (size_t)ns * 2 * 128 * M2_BK * sizeof(float) + (size_t)kslice * sizeof(int);
-#define M2_DW_LAUNCH(NS_, WGS_)                                                                                                       \
-    do {                                                                                                                              \
-        TH_SET_MAX_LDS(ctx, (mlp2_dw1_kernel<NS_, WGS_, true>), 160 << 10);                                                          \
-        TH_SET_MAX_LDS(ctx, (mlp2_dw1_kernel<NS_, WGS_, false>), 160 << 10);                                                         \
-        if (rs.idx) hipLaunchKernelGGL((mlp2_dw1_kernel<NS_, WGS_, true>), dim3(tiles_n * kz), dim3(256), lds, ctx->stream, d);       \
-        else hipLaunchKernelGGL((mlp2_dw1_kernel<NS_, WGS_, false>), dim3(tiles_n * kz), dim3(256), lds, ctx->stream, d);             \
-    } while (0)
-        if (variant == 31) M2_DW_LAUNCH(3, 1);
-        else if (variant == 32) M2_DW_LAUNCH(3, 2);
-        else if (variant == 41) M2_DW_LAUNCH(4, 1);
-        else M2_DW_LAUNCH(2, 2);
-#undef M2_DW_LAUNCH
     }
-    TH_LAUNCH_CHECK();
-
-    Mlp2FinishArgs f{};
-    f.partial = partial; f.part = part; f.kz = kz; f.n_blk = n_blk; f.part_stride = stride; f.batch = batch; f.in_f = in_features;
-    f.hid = hidden; f.c = classes;
-    f.dw1 = d_dw1; f.db1 = d_db1; f.dw2 = d_dw2; f.db2 = d_db2; f.loss = d_loss; f.ncorrect = d_ncorrect; f.metrics = d_metrics;
-    f.capacity = metrics_capacity; f.state = d_state; f.advance = advance;
-    f.w1a = make_adam_dev(w1_fuse); f.b1a = make_adam_dev(b1_fuse); f.w2a = make_adam_dev(w2_fuse); f.b2a = make_adam_dev(b2_fuse);
-    f.w1_blocks = ceil_div((long)hidden * in_features, 64);
-    const int tail_blocks = ceil_div(classes * hidden + hidden + 16 + 1, 16);
-    if (only == 0 || only == 3) hipLaunchKernelGGL(mlp2_finish_kernel, dim3(f.w1_blocks + tail_blocks), dim3(256), 0, ctx->stream, f);
     TH_LAUNCH_CHECK();
     ++t_mlp2_calls;
     return th_free(ctx, ws);
@@ -1071,8 +981,13 @@ int th_debug_mlp2_ksplit(int ksplit) {
     return 0;
 }
 
+int th_debug_mlp2_help_us(int us) {
+    t_mlp2_help_us = us >= 0 ? us : -1;
+    return 0;
+}
+
 int th_debug_mlp2_only(int which) {
-    t_mlp2_only = (which >= 1 && which <= 3) ? which : 0;
+    t_mlp2_only = (which >= 1 && which <= 2) ? which : 0;
     return 0;
 }
 

@@ -198,7 +198,7 @@ int th_linear_xent_wide_ex(th_ctx *ctx, const float *d_x, const float *d_w, cons
 int th_bias_from_colsum_adam(th_ctx *ctx, const float *d_colsum, float *d_gb, int c, int hw, const th_adam_fuse *b_fuse,
                              const th_adam_slice *extra, int n_extra);
 /* ... and the whole tail of such a step in those two launches: in the second one every workgroup also applies Adam (optim.rs:99-110)
- * to the columns of W it owns (no other workgroup reads them: dX is not stored in this form), the lead workgroup to b, and the LAST
+ * to the columns of W it owns (no other workgroup reads them: dX is not stored in this form), the LAST workgroup to arrive to b (every workgroup reads b when it starts) -- from the lead's db --, and that same LAST
  * workgroup to arrive sums the conv bias gradient from everybody's column sums (d_conv_gb[conv_c], conv_c * conv_hw == in_features),
  * applies its Adam update and publishes the step counter.  The counter is ticked IN this launch (optim.rs:84): d_adam_tick points at
  * {t, arrival counter (0 between launches)}; the d_t fields of the three th_adam_fuse are ignored, every update uses t + 1.

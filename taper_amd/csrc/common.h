@@ -37,6 +37,18 @@ void set_error(const char *fmt, ...);
         }                                  \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (function, DEVICE) pair: set once per pair -- the static is per expansion site, i.e.
+// per kernel instance -- so that a process with contexts on several devices can launch > 64 KB of LDS on each of them.
+#define TH_SET_MAX_LDS(ctx_, fn_, bytes_)                                                                                \
+    do {                                                                                                                 \
+        static unsigned long long th_lds_done_ = 0ull;                                                                   \
+        const unsigned long long th_lds_bit_ = 1ull << ((ctx_)->device & 63);                                            \
+        if (!(th_lds_done_ & th_lds_bit_)) {                                                                             \
+            TH_HIP(hipFuncSetAttribute((const void *)(fn_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes_))); \
+            th_lds_done_ |= th_lds_bit_;                                                                                 \
+        }                                                                                                                \
+    } while (0)
+
 // launch check: kernel launches are asynchronous; this catches bad configs.
 #define TH_LAUNCH_CHECK() TH_HIP(hipGetLastError())
 

@@ -1308,8 +1308,7 @@ int th_conv3x3_bwd_weight(th_ctx *ctx, const float *d_x, const float *d_gy, floa
         if (!off && c_in == 1 && n >= 32 && h_out > 0 && w_out > 0 && lds <= (160u << 10)) {
             void *part = nullptr;
             if (th_malloc(ctx, (size_t)n * 9 * c_out * sizeof(float), &part)) return 1;
-            static bool attr = false;
-            if (!attr) { TH_HIP(hipFuncSetAttribute((const void *)conv1_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10)); attr = true; }
+            TH_SET_MAX_LDS(ctx, conv1_wgrad_kernel, 160 << 10);
             hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(n, ceil_div(c_out, C1W_CO)), dim3(C1W_NT), lds, ctx->stream, d_x, d_gy, (float *)part, h, w,
                                c_out, pad, h_out, w_out);
             TH_LAUNCH_CHECK();

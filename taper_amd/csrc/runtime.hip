@@ -101,7 +101,8 @@ int th_ctx_create(int device_id, th_ctx **out) {
     if (err_block_for(device_id, &c->err_word)) return 1;
     // arrival counters of th_mlp2_xent's k-split row blocks (2 KB, zero between launches): here, so that no launch has to allocate inside a capture
     TH_HIP(hipMalloc((void **)&c->m2_arrive, 512 * sizeof(unsigned)));
-    TH_HIP(hipMemset(c->m2_arrive, 0, 512 * sizeof(unsigned)));
+    TH_HIP(hipMemsetAsync(c->m2_arrive, 0, 512 * sizeof(unsigned), c->stream));   // on the context's own stream (non-blocking: the null stream does not order with it)
+    TH_HIP(hipStreamSynchronize(c->stream));
     *out = c;
     return 0;
 }

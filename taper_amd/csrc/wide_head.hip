@@ -242,10 +242,7 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
             if (a.db && t < C) {
                 float sum = sc[0][t];
                 for (int w = 1; w < WH_NW; ++w) sum += sc[w][t];
-                a.db[t] = sum;
-                if (a.fb.p)
-                    adam_update(a.fb.p, a.fb.m, a.fb.v, t, sum, adam_step_size(a.fb.lr[0], a.fb.beta1, a.fb.beta2, tick_old + 1), a.fb.beta1,
-                                a.fb.beta2, a.fb.eps, a.fb.wd);
+                a.db[t] = sum;      // (b itself moves in the LAST workgroup to arrive, below: every workgroup of this launch reads b at its start)
             }
             if (t == 0) {
                 float n = sc[0][16], hsum = sc[0][17];
@@ -274,6 +271,15 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_head_kernel(WideArgs a) {
         __syncthreads();
         if (!last_flag) return;
         __threadfence();                                       // ... and everybody else's are visible here
+        // b's update (optim.rs:99-110) from the lead's db.  NOT in the lead workgroup itself: every workgroup reads b for its logits when it
+        // starts, and a workgroup that is dispatched late -- other processes on the GPU -- would read the moved bias (r05: found by
+        // tests/test_gpu_repro.py beside two HBM-streaming processes: W off by ~0.1 lr on a replay; alone on the GPU every workgroup is
+        // resident at once and none was ever late).  Here every workgroup has arrived, i.e. is past its reads.
+        if (a.db && a.fb.p && t < C) {
+            const float g = __hip_atomic_load(&a.db[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            adam_update(a.fb.p, a.fb.m, a.fb.v, t, g, adam_step_size(a.fb.lr[0], a.fb.beta1, a.fb.beta2, tick_old + 1), a.fb.beta1, a.fb.beta2,
+                        a.fb.eps, a.fb.wd);
+        }
         if (a.colsum && a.conv_gb) {
             // 16 lanes per channel of the conv in front: lane j adds column sums j, j + 16, ..., then a fixed shuffle tree (th_bias_from_colsum_adam)
             const int sub = t & 15;

@@ -3,7 +3,8 @@ env: RANK / LOCAL_RANK / WORLD_SIZE (torchrun's contract), TAPER_DP_OUT (directo
 TAPER_DP_MODE (graph | eager), TAPER_DP_DEVICE (optional: every rank on this device -- the peer-to-peer communicator can share
 one GPU, RCCL cannot), TAPER_DP_BACKEND (rccl | p2p), TAPER_DP_MODEL (tests/backends.py builder: mlp_baseline | cnn_reference | ...), TAPER_DP_REPEAT (optional: the
 two-epoch optimisation R times over from the same start -- parameters, Adam's moments and t restored in place, the captured graphs and the
-communicator kept -- every run's losses and weights saved as run{i}_*: tests/test_gpu_repro.py compares them bit for bit)."""
+communicator kept -- every run compared with the first bit for bit (runs_same / runs_maxdiff / a byte checksum per run for the replica comparison):
+tests/test_gpu_repro.py)."""
 import os
 import sys
 from pathlib import Path
@@ -62,9 +63,16 @@ def main():
         ep = tr.run_epoch(loader, mode)
         ep2 = tr.run_epoch(loader, mode)          # a second epoch over the same rows: the captured graphs are replayed
         if repeat > 1:
-            runs[f"run{run}_losses"] = np.concatenate([ep["losses"], ep2["losses"]])
-            for i, p in enumerate(model.parameters()):
-                runs[f"run{run}_p{i}"] = p.data()
+            cur = [np.concatenate([ep["losses"], ep2["losses"]])] + [p.data() for p in model.parameters()]
+            if run == 0:
+                first = cur
+                runs["run0_losses"] = cur[0]
+                for i, a in enumerate(cur[1:]):
+                    runs[f"run0_p{i}"] = a
+            # per run: does anything differ from the first run, bit for bit?  (losses, then each parameter) -- and by how much
+            runs.setdefault("runs_same", []).append([bool(np.array_equal(a, b)) for a, b in zip(cur, first)])
+            runs.setdefault("runs_maxdiff", []).append([float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) for a, b in zip(cur, first)])
+            runs.setdefault("runs_crc", []).append([int(np.frombuffer(np.ascontiguousarray(a).tobytes(), np.uint8).astype(np.uint64).sum()) for a in cur])
     if comm is not None and comm.is_p2p() and comm.timed_out():
         raise SystemExit(f"rank {rank}: a peer never arrived at the all-reduce")
     st = comm.stats() if comm is not None and comm.is_p2p() else dict(inplace=-1, fused=-1)
@@ -73,7 +81,7 @@ def main():
     mlp2_calls = C.c_int64()
     lib.th_debug_mlp2_calls(C.byref(mlp2_calls))   # host-side calls of th_mlp2_xent on this thread (eager steps + captures)
     np.savez(out / f"rank{rank}.npz", fine=int(fine), mlp2_calls=mlp2_calls.value, launches_inplace=st["inplace"], launches_fused=st["fused"], losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
-             **{f"p{i}": p.data() for i, p in enumerate(model.parameters())}, **runs)
+             **{f"p{i}": p.data() for i, p in enumerate(model.parameters())}, **{k: np.asarray(v) for k, v in runs.items()})
     rdzv.barrier()
     rdzv.close()
 

@@ -45,6 +45,18 @@ def check(tensor: str, got, ref, bound: float | None, lr: float | None = None, t
     return rec
 
 
+def check_adam_weights(tensor: str, got, ref, v_ref, lr: float, steps: int, bound: float, test: str | None = None, v_floor: float = 1e-5) -> None:
+    """Weights after `steps` Adam steps (optim.rs:99-110) against the oracle's.  A weight moves by lr m / (sqrt(v) + eps) per step: for
+    an element whose gradient is a cancellation down to ~eps that quotient is O(1) whatever another summation order does to the gradient's
+    last bits, so the elements whose gradients stand clear of eps (sqrt(v_ref) > v_floor) are held to `bound` x lr, and every element to
+    2 lr per step (a sign flip of such a gradient) -- both recorded."""
+    got, ref = np.asarray(got, np.float64).reshape(-1), np.asarray(ref, np.float64).reshape(-1)
+    clear = np.sqrt(np.abs(np.asarray(v_ref, np.float64).reshape(-1))) > v_floor
+    assert clear.any(), f"{tensor}: no element has a gradient clear of eps"
+    check(f"{tensor}_clear_of_eps", got[clear], ref[clear], bound, lr=lr, test=test)
+    check(tensor, got, ref, 2.0 * steps, lr=lr, test=test)
+
+
 @atexit.register
 def _flush():
     if not _seen:

@@ -102,7 +102,7 @@ def test_mlp2_steps_repeat_bit_identical_beside_hbm_traffic(ctx, O, traffic, bat
     """ksplit 0: the launcher's own choice (4 at 1 024 rows; none from 4 096 on, where the hand-off under test is the dW1 launch's)"""
     from taper_amd._lib import hip as lib
     inf, hid, c, lr = 784, 128, 10, 1e-3
-    steps, replays = (4, 15) if batch <= 4096 else (3, 20)
+    steps, replays = (4, 30) if batch <= 4096 else (3, 20)
     rng = np.random.default_rng(batch * 11 + ksplit)
     x = (rng.integers(0, 256, (steps, batch, inf)) * (rng.uniform(0, 1, (steps, batch, inf)) < 0.3)).astype(np.float32) / np.float32(255.0)
     y = rng.integers(0, c, (steps, batch)).astype(np.float32)
@@ -161,13 +161,36 @@ def test_mlp2_steps_repeat_bit_identical_beside_hbm_traffic(ctx, O, traffic, bat
     test = "test_mlp2_steps_repeat_bit_identical_beside_hbm_traffic"
     margins.check("losses", first["losses"], [r["loss"] for r in ref], 2 * RTOL, test=test)
     assert abs(first["hits"][0] - ref[0]["acc"] * batch) < 0.5                   # index work on identical weights: exact
-    for k in names:
-        margins.check(f"{k}_after_{steps}_steps", first[k], w[k].data(), BOUND_LR, lr=lr, test=test)
+    # Adam's first moment is linear in the gradients: well conditioned, held to the tensor's scale -- except where a ReLU MASK FLIPS: a hidden
+    # pre-activation within rounding of zero gets another sign under another summation order, and that (row, unit)'s dZ1 element appears in
+    # / disappears from unit's row of dW1 and db1 -- a discontinuity of the function, not an error of either side ("parity
+    # margins": 3 of 4096 rows seen in the 4096-wide step).  So: W2 / b2 tight; W1 / b1 tight outside at most 8 hidden units, and inside
+    # them by at most one row's contribution (5 % of the tensor's scale).  A WEIGHT moves by lr m / (sqrt(v) + eps) -- for an element whose
+    # gradient is a cancellation down to ~eps that quotient is O(1) whatever the summation order does to the last bits: the weights are
+    # held to BOUND_LR of lr on the elements whose gradients stand clear of eps (and outside the flipped units), to 2 lr per step everywhere.
+    flipped = set()
+    for i, k in enumerate(names):
+        got_m, ref_m = first[k + "_m"].astype(np.float64), np.asarray(oopt.m(i), np.float64)
+        scale = float(np.abs(ref_m).max())
+        err = np.abs(got_m - ref_m)
+        if k in ("w1", "b1"):
+            units = np.nonzero((err.reshape(hid, -1) > 2 * RTOL * scale).any(axis=1))[0]
+            flipped |= set(units.tolist())
+            assert len(flipped) <= 8 and err.max() <= 5e-2 * scale, f"{k}: m off in hidden units {sorted(flipped)} (max {err.max() / scale:.2e} of scale)"
+            keep = np.ones(hid, bool)
+            keep[sorted(flipped)] = False
+            margins.check(f"{k}_m_after_{steps}_steps", got_m.reshape(hid, -1)[keep], ref_m.reshape(hid, -1)[keep], 2 * RTOL, test=test)
+            margins.check_adam_weights(f"{k}_after_{steps}_steps", first[k].reshape(hid, -1)[keep], np.asarray(w[k].data()).reshape(hid, -1)[keep],
+                                       np.asarray(oopt.v(i)).reshape(hid, -1)[keep], lr, steps, BOUND_LR, test=test)
+        else:
+            margins.check(f"{k}_m_after_{steps}_steps", got_m, ref_m, 2 * RTOL, test=test)
+            margins.check_adam_weights(f"{k}_after_{steps}_steps", first[k], w[k].data(), oopt.v(i), lr, steps, BOUND_LR, test=test)
+    margins.record(test, "relu_mask_flips_units", [float(len(flipped))], [0.0])
 
 
 # ------------------------------------------------------------------------------------------------------------------ th_linear_xent_wide_fused
 def test_wide_fused_last_arrival_repeats_bit_identical_beside_hbm_traffic(ctx, O, traffic):
-    batch, c_conv, hw, c, lr, steps, replays = 256, 64, 49, 10, 1e-2, 4, 15
+    batch, c_conv, hw, c, lr, steps, replays = 256, 64, 49, 10, 1e-2, 4, 30
     k = c_conv * hw
     rng = np.random.default_rng(5)
     h = np.maximum(rng.standard_normal((batch, k)), 0).astype(np.float32)
@@ -277,23 +300,36 @@ def test_adam_step_tick_repeats_bit_identical_beside_hbm_traffic(ctx, O, traffic
 
 # ------------------------------------------------------------------------------------------------------------------ two ranks x 512 rows
 def test_two_ranks_of_512_rows_repeat_bit_identical_beside_hbm_traffic(tmp_path, traffic):
-    """tests/test_gpu_dp.py::test_p2p_two_ranks_of_512_rows_take_the_three_launch_step's run, 12 times over inside one pair of processes
-    (captured graphs and communicator kept, parameters / moments / t restored): 12 x 8 steps per rank, every run's losses and weights equal
-    to the first run's bit for bit, replicas identical, and the run equal to one process on the global batches (the DP test's own check)"""
+    """tests/test_gpu_dp.py::test_p2p_two_ranks_of_512_rows_take_the_three_launch_step's run -- the configuration that failed one `-m gpu` run
+    in four in r04 -- as 8 FRESH pairs of processes (r04's hazard showed in the first executions of a fresh pair, 5 - 8 times in 30, and
+    not in the replays that follow: with commit 596fe87 reverted, 60 in-process repeats of one pair passed three times out of three), each
+    pair running the two-epoch optimisation 3 times over (captured graphs and communicator kept, parameters / moments / t restored): every
+    run of every pair gives the same losses and weights bit for bit, the replicas are identical, and the run equals one process on the
+    global batches (the DP test's own check)."""
     from tests.test_gpu_dp import _check, _run_ranks
-    runs, steps, gb = 12, 4, 1024
+    pairs, runs, steps, gb = 8, 3, 4, 1024
     os.environ["TAPER_DP_REPEAT"] = str(runs)
     try:
-        ranks = _run_ranks(tmp_path, 2, "p2p", "graph", steps=steps, global_batch=gb, same_device=True)
+        first = None
+        for pair in range(pairs):
+            d = tmp_path / f"pair{pair}"
+            d.mkdir()
+            ranks = _run_ranks(d, 2, "p2p", "graph", steps=steps, global_batch=gb, same_device=True)
+            for r in range(2):
+                assert int(ranks[r]["mlp2_calls"]) > 0                                  # 512 rows per rank: the large-batch step ran
+                same, diff = np.asarray(ranks[r]["runs_same"]), np.asarray(ranks[r]["runs_maxdiff"])
+                assert same.shape == (runs, 5)
+                bad = np.nonzero(~same.all(axis=1))[0]
+                assert bad.size == 0, f"pair {pair} rank {r}: runs {bad.tolist()} differ from its first (max |diff| per run [losses, p0..p3]: {diff[bad].tolist()})"
+            for i in range(4):
+                np.testing.assert_array_equal(ranks[0][f"p{i}"], ranks[1][f"p{i}"], err_msg=f"pair {pair}: replicas diverged in param {i}")
+            if first is None:
+                first = ranks
+                _check(ranks, 2, steps, gb)
+                continue
+            for r in range(2):
+                np.testing.assert_array_equal(ranks[r]["losses"], first[r]["losses"], err_msg=f"pair {pair} rank {r}: losses differ from the first pair's")
+            for i in range(4):
+                np.testing.assert_array_equal(ranks[0][f"p{i}"], first[0][f"p{i}"], err_msg=f"pair {pair}: param {i} differs from the first pair's")
     finally:
         del os.environ["TAPER_DP_REPEAT"]
-    for r in range(2):
-        assert int(ranks[r]["mlp2_calls"]) > 0                                  # 512 rows per rank: the large-batch step ran
-        for run in range(1, runs):
-            np.testing.assert_array_equal(ranks[r][f"run{run}_losses"], ranks[r]["run0_losses"], err_msg=f"rank {r} run {run}: losses moved")
-            for i in range(4):
-                np.testing.assert_array_equal(ranks[r][f"run{run}_p{i}"], ranks[r][f"run0_p{i}"], err_msg=f"rank {r} run {run}: param {i} moved")
-    for run in range(runs):
-        for i in range(4):
-            np.testing.assert_array_equal(ranks[0][f"run{run}_p{i}"], ranks[1][f"run{run}_p{i}"], err_msg=f"run {run}: replicas diverged in param {i}")
-    _check(ranks, 2, steps, gb)
