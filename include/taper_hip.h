@@ -303,6 +303,16 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
                  int32_t *d_tick, const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse, const th_adam_fuse *w2_fuse,
                  const th_adam_fuse *b2_fuse);
 
+/* The same step for TWO hidden layers -- Linear + ReLU, Linear + ReLU, Linear, softmax cross-entropy: the model of examples/train_mnist.rs:40-48
+ * (784-128-64-10) at large batch, still three launches.  The second hidden layer is a contraction on the hidden tile a row block holds in
+ * LDS anyway, and everything behind it stays row-parallel inside launch 1 (A2, the classifier, dZ2, dA1, the masked dZ1, the block's share
+ * of dW2 = dZ2^T A1 beside the small sums); only dW1 needs the batch-wide launch; launch 3 adds the blocks' shares and applies Adam for
+ * every fuse given.  layers[0..2] as in th_mlp3_xent (d_w [out][in] 16-byte aligned; d_dw required, d_b / d_db nullable); the first
+ * hidden size a multiple of 32, the second of 16, both <= 128; classes <= 16.  Same row source, step log and tick as th_mlp2_xent. */
+int th_mlp2_xent_deep_supported(int batch, int in_features, int h1, int h2, int classes, int64_t n_rows);
+int th_mlp2_xent_deep(th_ctx *ctx, const th_row_source *src, int batch, int in_features, const th_mlp3_layer *layers, float *d_loss,
+                      float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_tick);
+
 /* ---- element-wise: src/ops.rs:8-120,377-496; src/tensor.rs:36-161 ----- */
 int th_add(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);
 int th_sub(th_ctx *ctx, const float *d_a, const float *d_b, float *d_out, size_t n);

@@ -88,11 +88,14 @@ __host__ __device__ constexpr int m2_swz(int row) { return (row >> 1) & 7; }
 
 struct Mlp2RowsArgs {
     RowSource src;
-    const float *w1, *b1, *w2, *b2;
-    int batch, in_f, hid, c;
+    const float *w1, *b1, *w2, *b2;   // DEEP: w2 / b2 are the SECOND HIDDEN layer's [h2][hid] / [h2], w3 / b3 the classifier's [c][h2] / [c]
+    const float *w3, *b3;
+    int batch, in_f, hid, c, h2;
     float *dz1;          // [gridDim.x * RT][hid]: rows >= batch are written as zeros
     float *part;         // [gridDim.x][part_stride]: dW2 [c][hid], db1 [hid], db2 [16], nll, hits
-    int part_stride;
+                         // DEEP: dW3 [c][h2], db2 [h2], db3 [16], nll, hits (the block the shallow form lays out, for the classifier on h2), then
+                         // at o_deep: dW2 [h2][hid], db1 [hid]
+    int part_stride, o_deep;
     int32_t *tick;       // nullable
     int ksplit;          // 16-row form only: workgroups per row block, each contracting a share of the k chunks (1: none)
     float *kpart;        // [gridDim.x][2048]: a workgroup's accumulators, in register order
@@ -109,8 +112,13 @@ struct Mlp2RowsArgs {
 // groups are the two 32-row halves (one accumulator tile per wave); on 32-row tiles both groups hold the same 32 x 32 tile and split every
 // chunk's four k rounds between them, two accumulators that are added, group 0 + group 1, when H goes to LDS.  Built to test whether one
 // wave per SIMD was what held the k loop back; it was not (see the launcher), the form stays as a measurement knob.
-template <int RT, int NS, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <= 3))) ? 2 : 1) void mlp2_rows_kernel(Mlp2RowsArgs a) {
+// DEEP: TWO hidden layers (examples/train_mnist.rs:40-48: 784-128-64-10).  The second hidden layer is a hid -> h2 contraction on the H tile
+// that is in LDS anyway, and everything behind it is still row-parallel: A2 = relu(A1 W2^T + b2) on v_mfma_f32_16x16x4_f32 (a wave owns a
+// 16-column tile of h2, W2's operand registers requested when the k loop ends), the classifier and its backward on A2 exactly as the shallow
+// form has them on A1 (dZ2 replaces A2 in place), dA1 = dZ2 W2 and the ReLU mask -> the masked dZ1 as before, and the row block's share of
+// dW2 = dZ2^T A1 ([h2][hid]: 32 KB per block at 64 x 128) beside the small sums.  Only dW1 needs the batch-wide launch.  hid, h2 multiples of 16.
+template <int RT, int NS, int NW, bool DEEP = false>
+__global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 64 && NS <= 3))) ? 2 : 1) void mlp2_rows_kernel(Mlp2RowsArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(NW == 4 || NW == 8, "four or eight waves");
@@ -132,6 +140,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
     // the step at these sizes (25 chunks: 9.6 us of 17 at batch 1 024); split four ways it is 7 chunks.
     const int ksplit = R16 ? a.ksplit : 1, blk = R16 ? (int)blockIdx.x / ksplit : (int)blockIdx.x, ks = R16 ? (int)blockIdx.x % ksplit : 0;
     const int r0 = blk * RT, B = a.batch, in_f = a.in_f, hid = a.hid, C = a.c;
+    static_assert(!DEEP || NW == 4, "the two-hidden-layer form has four waves");
+    // the classifier's weights and the width of its input: the last hidden layer's
+    const float *wl = DEEP ? a.w3 : a.w2, *bl = DEEP ? a.b3 : a.b2;
+    const int kl = DEEP ? a.h2 : hid;
     M2_STAMP(0, blockIdx.x == 0);
     if (a.tick && blockIdx.x == 0 && t == 0) a.tick[0] += 1;                  // optim.rs:84 (the launch that reads t comes later)
     const long cur = (a.src.idx && a.src.cursor) ? a.src.cursor[0] : 0;
@@ -166,16 +178,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = 16 * u + 4 * g4;
-        const float4 v = *reinterpret_cast<const float4 *>(a.w2 + (long)min(l16, C - 1) * hid + min(k, hid - 4));
-        w2a[u] = k < hid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = *reinterpret_cast<const float4 *>(wl + (long)min(l16, C - 1) * kl + min(k, kl - 4));
+        w2a[u] = k < kl ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float b2v[4], w2b[NTT][4];                                                // b2[class 4 g4 + e]; dH's B operand: W2[class 4 g4 + s][col]
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int cls = min(4 * g4 + e, C - 1);
-        b2v[e] = a.b2 ? a.b2[cls] : 0.f;
+        b2v[e] = bl ? bl[cls] : 0.f;
 #pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) w2b[tt][e] = a.w2[(long)cls * hid + min(16 * NTT * wave + 16 * tt + l16, hid - 1)];
+        for (int tt = 0; tt < NTT; ++tt) w2b[tt][e] = wl[(long)cls * kl + min(16 * NTT * wave + 16 * tt + l16, kl - 1)];
     }
 
     // this workgroup's chunks: [c_lo, c_hi) of the in_f / 32 full chunks (+ the ragged last one for the last split)
@@ -367,8 +379,30 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
     }
     // ---- epilogue: the staging buffers are dead; H, dlogits and two scalars per wave live in their place ----
     float *Hs = smem;                           // [RT][M2_LDH]
-    float *D3S = Hs + RT * M2_LDH;              // [RT][20]: dlogits [row][class], zero for classes >= C and rows >= batch
+    float *H2s = Hs + RT * M2_LDH;              // DEEP: [RT][M2_LDH]: the second hidden layer's activations, later dZ2 in their place
+    float *Hc = DEEP ? H2s : Hs;                // the classifier's input tile
+    float *D3S = Hc + RT * M2_LDH;              // [RT][20]: dlogits [row][class], zero for classes >= C and rows >= batch
     float *sc = D3S + RT * 20;                  // [4][2]: the waves' NLL / hit sums
+    static_assert(!DEEP || (RT * (2 * M2_LDH + 20) + 8) <= NS * STG, "the two-hidden-layer epilogue lives in the ring's space");
+    // DEEP: the second hidden layer's operand registers, requested now (they cross the fabric while H goes to LDS).  Wave w owns the
+    // 16-column tiles ct = w, w + 4 of h2: B(k, n = l16) = W2[16 ct + l16][k], k = 16 u + 4 g4 + e as component e of quad u (the k order
+    // the A operand's float4 reads of the H tile give: every k once, the same permutation on both operands)
+    float4 w2f[DEEP ? 2 : 1][8];
+    float b2c[2] = {0.f, 0.f};
+    if constexpr (DEEP) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ct = wave + 4 * j;
+            const bool tile = 16 * ct < a.h2;
+            b2c[j] = (tile && a.b2) ? a.b2[16 * ct + l16] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = 16 * u + 4 * g4;
+                const float4 v = *reinterpret_cast<const float4 *>(a.w2 + (long)min(16 * ct + l16, a.h2 - 1) * hid + min(k, hid - 4));
+                w2f[j][u] = (tile && k < hid) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
     if (KSPLIT) {                               // the second group's half of the k sum goes through H's own cells: group 0 + group 1
         if (grp == 1) {
 #pragma unroll
@@ -400,9 +434,50 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
             }
     }
     lds_barrier();
+    float w2g[DEEP ? 2 : 1][32];                // DEEP: dA1's B operand, W2[k][16 (2 w + tt) + l16], k = 16 u + 4 g4 + e at [4 u + e]
+    if constexpr (DEEP) {
+        // A2 = relu(A1 W2^T + b2) (nn.rs:54-60, activation.rs:10-12): D[row 4 g4 + e][column l16] of tile ct, four accumulation chains
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ct = wave + 4 * j;
+            const bool tile = 16 * ct < a.h2;          // (wave-uniform; tiles beyond h2 hold zeros: the classifier reads whole quads)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+                if (tile) {
+                    const float *ap = Hs + (16 * rb + l16) * M2_LDH + 4 * g4;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float4 h = *reinterpret_cast<const float4 *>(ap + 16 * u);
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(h.x, w2f[j][u].x, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(h.y, w2f[j][u].y, c1, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(h.z, w2f[j][u].z, c2, 0, 0, 0);
+                        c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(h.w, w2f[j][u].w, c3, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = ((c0[e] + c1[e]) + (c2[e] + c3[e])) + b2c[j];
+                    H2s[(16 * rb + 4 * g4 + e) * M2_LDH + 16 * ct + l16] = (tile && v > 0.f) ? v : 0.f;
+                }
+            }
+        }
+        // dA1's operand registers: requested here, used behind the classifier
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 16 * u + 4 * g4 + e;
+                    const float v = a.w2[(long)min(k, a.h2 - 1) * hid + min(16 * (2 * wave + tt) + l16, hid - 1)];
+                    w2g[tt][4 * u + e] = k < a.h2 ? v : 0.f;
+                }
+        lds_barrier();
+    }
     // logits^T[class 4 g4 + e][row l16] = W2 . H^T + b2, the row's softmax cross-entropy (wave w: rows 16 w ..)
     if (wave < NRB) {
-        const float *hp = Hs + hrow * M2_LDH + 4 * g4;
+        const float *hp = Hc + hrow * M2_LDH + 4 * g4;
         floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -433,13 +508,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
     lds_barrier();
     M2_STAMP(3, blockIdx.x == 0);
     float *part = a.part + (long)blk * a.part_stride;
-    const int o_db1 = C * hid, o_db2 = o_db1 + hid, o_nll = o_db2 + 16;
+    const int o_db1 = C * kl, o_db2 = o_db1 + kl, o_nll = o_db2 + 16;
     // wave w owns 16 NTT hidden columns of ALL the tile's rows: dZ1 = (dlogits W2) * [H > 0] (ops.rs:254-265, 358-369), its
-    // column sums (db1, tensor.rs:686-691) and the tile's share of dW2 = dlogits^T H (ops.rs:266-294)
-    if (16 * NTT * wave < hid) {
+    // column sums (db1, tensor.rs:686-691) and the tile's share of dW2 = dlogits^T H (ops.rs:266-294).  (DEEP: the same on the second
+    // hidden layer -- dZ2, db2, dW3 -- with dZ2 written over A2 in LDS instead of to memory: the element's own lane is its last reader.)
+    if (16 * NTT * wave < kl) {
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             const int col = 16 * NTT * wave + 16 * tt + l16;
+            if (DEEP && 16 * (NTT * wave + tt) >= kl) break;                  // (h2 is a multiple of 16, not of 32: a wave's second tile may lie beyond it)
             float colsum = 0.f;
             floatx4 dw2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -453,9 +530,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int row = 16 * rb + 4 * g4 + e;                       // dh[e] = dH[row][col]
-                    const float hv = Hs[row * M2_LDH + col];
+                    const float hv = Hc[row * M2_LDH + col];
                     const float dz = hv > 0.f ? dh[e] : 0.f;
-                    a.dz1[(long)(r0 + row) * hid + col] = dz;                   // (zeros for rows >= batch: launch 2 contracts whole 32-row chunks)
+                    if constexpr (DEEP) Hc[row * M2_LDH + col] = dz;
+                    else a.dz1[(long)(r0 + row) * hid + col] = dz;              // (zeros for rows >= batch: launch 2 contracts whole 32-row chunks)
                     colsum += dz;
                     // dW2's operands of k-step e: A(class l16, row) and B(row, col) -- the row of this very element
                     dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(D3S[row * 20 + l16], hv, dw2, 0, 0, 0);
@@ -466,7 +544,75 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && (RT == 32 || (RT == 64 && NS <
             if (lane < 16) part[o_db1 + col] = colsum;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (4 * g4 + e < C) part[(4 * g4 + e) * hid + col] = dw2[e];      // dw2[e] = dW2[class 4 g4 + e][col]
+                if (4 * g4 + e < C) part[(4 * g4 + e) * kl + col] = dw2[e];       // dw2[e] = dW2[class 4 g4 + e][col]
+        }
+    }
+    if constexpr (DEEP) {
+        lds_barrier();                                                        // dZ2 is complete (in A2's place)
+        const int h2 = a.h2;
+        float *pd = part + a.o_deep;                                          // dW2 [h2][hid], then db1 [hid]
+        // dA1 = dZ2 W2 (ops.rs:254-265), dZ1 = dA1 * [A1 > 0] (ops.rs:358-369) -> memory, its column sums (db1): wave w owns the
+        // 16-column tiles 2 w, 2 w + 1 of hid
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int col = 16 * (2 * wave + tt) + l16;
+            if (16 * (2 * wave + tt) >= hid) break;                           // (wave-uniform)
+            float colsum = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float *zp = H2s + (16 * rb + l16) * M2_LDH + 4 * g4;
+                floatx4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (16 * u >= h2) break;
+                    const float4 z = *reinterpret_cast<const float4 *>(zp + 16 * u);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(z.x, w2g[tt][4 * u], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(z.y, w2g[tt][4 * u + 1], c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(z.z, w2g[tt][4 * u + 2], c2, 0, 0, 0);
+                    c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(z.w, w2g[tt][4 * u + 3], c3, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * rb + 4 * g4 + e;
+                    const float dz = Hs[row * M2_LDH + col] > 0.f ? ((c0[e] + c1[e]) + (c2[e] + c3[e])) : 0.f;
+                    a.dz1[(long)(r0 + row) * hid + col] = dz;                   // (zeros for rows >= batch: their dlogits are zero)
+                    colsum += dz;
+                }
+            }
+            colsum += __shfl_xor(colsum, 16, 64);
+            colsum += __shfl_xor(colsum, 32, 64);
+            if (lane < 16) pd[h2 * hid + col] = colsum;
+        }
+        // the row block's share of dW2 = dZ2^T A1 (ops.rs:266-294 through the W^T node): D[j = 16 tj + 4 g4 + e][n = 16 tn + l16], the
+        // contraction over the tile's rows -- A(m = j, k = row) = dZ2[row][j], B(k = row, n) = A1[row][n]; wave w owns tn = 2 w, 2 w + 1
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tn = 2 * wave + tt;
+            if (16 * tn >= hid) break;
+#pragma unroll
+            for (int tj0 = 0; tj0 < 8; tj0 += 4) {                             // four h2 tiles at a time (16 accumulator registers)
+                if (16 * tj0 >= h2) break;
+                floatx4 dw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dw[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int s4 = 0; s4 < RT / 4; ++s4) {
+                    const int row = 4 * s4 + g4;
+                    const float bv = Hs[row * M2_LDH + 16 * tn + l16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float av = H2s[row * M2_LDH + 16 * (tj0 + q) + l16];      // (tiles beyond h2 hold zeros)
+                        dw[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, dw[q], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = 16 * (tj0 + q) + 4 * g4 + e;
+                        if (j < h2) pd[(long)j * hid + 16 * tn + l16] = dw[q][e];
+                    }
+            }
         }
     }
     if (t < 16) {                                                             // db2 (tensor.rs:686-691): rows in order
@@ -757,16 +903,25 @@ __global__ __launch_bounds__(512, 1) void mlp2_dw1_kernel8(Mlp2Dw8Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- launch 3
+struct Mlp2Seg {           // a run of a row block's partial sums that is one parameter's gradient
+    int start, len;        // elements [start, start + len) of the block's record (start a multiple of 4)
+    float *grad;           // nullable: not wanted
+    AdamDev ad;
+};
+constexpr int M2_MAX_SEGS = 5;
+
 struct Mlp2FinishArgs {
     const float *partial;   // [kz][hid * in_f]
     const float *part;      // [n_blk][part_stride]
-    int kz, n_blk, part_stride, batch, in_f, hid, c;
-    float *dw1, *db1, *dw2, *db2, *loss, *ncorrect, *metrics;
+    int kz, n_blk, part_stride, batch, in_f, hid;
+    float *dw1, *loss, *ncorrect, *metrics;
     int64_t capacity;
     int64_t *state;
     int64_t advance;
-    AdamDev w1a, b1a, w2a, b2a;
+    AdamDev w1a;
     int w1_blocks;
+    Mlp2Seg seg[M2_MAX_SEGS];   // shallow: dW2, db1, db2; two hidden layers: dW3, db2, db3, dW2, db1
+    int n_seg, o_nll, part_len; // {nll, hits} at o_nll; part_len: the record's live length
 };
 
 __device__ __forceinline__ void m2_apply(const AdamDev &ad, long i, float g) {
@@ -831,51 +986,50 @@ __global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
         }
         return;
     }
-    // the row blocks' partial sums
-    float(*sh)[16][2] = reinterpret_cast<float(*)[16][2]>(&sh4[0][0]);       // [sub][element][value, second value]
-    const int el = t & 15, sub = t >> 4, e = (bid - a.w1_blocks) * 16 + el;
-    const int o_db1 = a.c * a.hid, o_db2 = o_db1 + a.hid, o_nll = o_db2 + 16;
-    float s = 0.f, s2 = 0.f;
-    if (e <= o_nll) {
+    // the row blocks' partial sums: 16 float4 of the record per workgroup, 16 threads per float4 -- thread `sub` adds the blocks sub, sub + 16, ...
+    // in order, thread 0 of the float4 adds the 16 sums in order (the order r04's element-wise form had)
+    const int qd = (bid - a.w1_blocks) * 16 + (t & 15), sub = t >> 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * qd < a.part_len) {
+        const float *src = a.part + 4 * qd;
 #pragma unroll 4
         for (int b = sub; b < a.n_blk; b += 16) {
-            s += a.part[(long)b * a.part_stride + e];
-            if (e == o_nll) s2 += a.part[(long)b * a.part_stride + e + 1];
+            const float4 v = *reinterpret_cast<const float4 *>(src + (long)b * a.part_stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
-    sh[sub][el][0] = s;
-    sh[sub][el][1] = s2;
+    sh4[sub][t & 15] = s;
     __syncthreads();
-    if (sub != 0 || e > o_nll) return;
+    if (sub != 0 || 4 * qd >= a.part_len) return;
 #pragma unroll
     for (int u = 1; u < 16; ++u) {
-        s += sh[u][el][0];
-        s2 += sh[u][el][1];
+        const float4 p = sh4[u][t];
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
-    if (e < o_db1) {
-        a.dw2[e] = s;
-        m2_apply(a.w2a, e, s);
-    } else if (e < o_db2) {
-        if (a.db1) {
-            a.db1[e - o_db1] = s;
-            m2_apply(a.b1a, e - o_db1, s);
-        }
-    } else if (e < o_nll) {
-        if (a.db2 && e - o_db2 < a.c) {
-            a.db2[e - o_db2] = s;
-            m2_apply(a.b2a, e - o_db2, s);
-        }
-    } else {
-        const float l = s / (float)a.batch;       // loss.rs:164
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+    if (4 * qd == a.o_nll) {
+        const float l = sv[0] / (float)a.batch;       // loss.rs:164
         a.loss[0] = l;
-        if (a.ncorrect) a.ncorrect[0] = s2;
-        if (a.metrics) {                          // th_log_step
+        if (a.ncorrect) a.ncorrect[0] = sv[1];
+        if (a.metrics) {                              // th_log_step
             const int64_t s0 = a.state[0], s1 = a.state[1];
             const int64_t slot = s0 < a.capacity ? s0 : s0 % a.capacity;
             a.metrics[2 * slot] = l;
-            a.metrics[2 * slot + 1] = s2;
+            a.metrics[2 * slot + 1] = sv[1];
             a.state[0] = s0 + 1;
             a.state[1] = s1 + a.advance;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = 4 * qd + j;
+#pragma unroll
+        for (int g = 0; g < M2_MAX_SEGS; ++g) {
+            if (g < a.n_seg && e >= a.seg[g].start && e < a.seg[g].start + a.seg[g].len && a.seg[g].grad) {
+                a.seg[g].grad[e - a.seg[g].start] = sv[j];
+                m2_apply(a.seg[g].ad, e - a.seg[g].start, sv[j]);
+            }
         }
     }
 }
@@ -892,39 +1046,29 @@ static int m2_rows_per_block(int batch) {
     return batch >= 12288 ? 64 : (batch > 4096 ? 32 : 16);
 }
 
-}  // namespace th
+// One layer of the classifier as the runner sees it
+struct M2Layer {
+    const float *w, *b;
+    float *dw, *db;
+    const th_adam_fuse *wf, *bf;
+    int out;
+};
 
-using namespace th;
-
-extern "C" {
-
-int th_mlp2_xent_supported(int batch, int in_features, int hidden, int classes, int64_t n_rows) {
-    return batch >= 32 && in_features >= 32 && in_features % 4 == 0 && hidden >= 32 && hidden <= 128 && hidden % 32 == 0 && classes >= 1 &&
-                   classes <= 16 && n_rows >= 1 && (double)n_rows * in_features * 4.0 < 2147483648.0 && (double)(batch + 64) * hidden * 4.0 < 2147483648.0
-               ? 1 : 0;
-}
-
-int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_features, int hidden, int classes, const float *d_w1,
-                 const float *d_b1, const float *d_w2, const float *d_b2, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2,
-                 float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
-                 int32_t *d_tick, const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse, const th_adam_fuse *w2_fuse,
-                 const th_adam_fuse *b2_fuse) {
-    TH_REQUIRE(ctx && src && src->d_rows && src->d_labels && d_w1 && d_w2 && d_dw1 && d_dw2 && d_loss, "th_mlp2_xent: null argument");
-    TH_REQUIRE(th_mlp2_xent_supported(batch, in_features, hidden, classes, src->n_rows),
-               "th_mlp2_xent: needs batch >= 32, in_features a multiple of 4 (>= 32), hidden a multiple of 32 up to 128, classes <= 16, "
-               "rows * in_features * 4 < 2^31 (got %d, %d, %d, %d, %ld rows)", batch, in_features, hidden, classes, (long)src->n_rows);
-    TH_REQUIRE(!src->d_indices || (src->n_indices >= batch && src->n_indices < (1LL << 30)), "th_mlp2_xent: the index vector must hold at least one batch (and fewer than 2^30 entries)");
-    TH_REQUIRE(src->d_indices || src->n_rows >= batch, "th_mlp2_xent: a dense row block must hold the batch");
-    TH_REQUIRE((((uintptr_t)src->d_rows | (uintptr_t)d_w1 | (uintptr_t)d_w2 | (uintptr_t)d_dw1) & 15) == 0, "th_mlp2_xent: rows, W1, W2 and dW1 must be 16-byte aligned");
-    TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp2_xent: metrics need d_state and a capacity");
-    TH_REQUIRE(!(b1_fuse && b1_fuse->d_p) || d_db1, "th_mlp2_xent: a fused bias update needs d_db1");
-    TH_REQUIRE(!(b2_fuse && b2_fuse->d_p) || d_db2, "th_mlp2_xent: a fused bias update needs d_db2");
-    TH_REQUIRE(!(w1_fuse && w1_fuse->d_p) || ((((uintptr_t)w1_fuse->d_p | (uintptr_t)w1_fuse->d_m | (uintptr_t)w1_fuse->d_v) & 15) == 0),
-               "th_mlp2_xent: W1's p / m / v slices must be 16-byte aligned");
+// the step for n_hidden = 1 (Linear + ReLU, Linear) or 2 (Linear + ReLU, Linear + ReLU, Linear) hidden layers; arguments checked by the callers
+static int mlp2_run(th_ctx *ctx, const th_row_source *src, int batch, int in_features, int n_hidden, const M2Layer *L, float *d_loss,
+                    float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_tick) {
+    const bool deep = n_hidden == 2;
+    const int hidden = L[0].out, h2 = deep ? L[1].out : 0, classes = L[n_hidden].out, kl = deep ? h2 : hidden;
+    const float *d_w1 = L[0].w, *d_b1 = L[0].b;
+    float *d_dw1 = L[0].dw;
+    const th_adam_fuse *w1_fuse = L[0].wf;
     const int RT = m2_rows_per_block(batch);
     // (16-row tiles: an even number of row blocks, so that launch 2 sees whole 32-row chunks; a block past the batch writes zeros)
     const int n_blk = RT == 16 ? 2 * ceil_div(batch, 32) : ceil_div(batch, RT), rows_pad = n_blk * RT;
-    const int stride = (classes * hidden + hidden + 16 + 2 + 3) & ~3;
+    // a row block's record: the classifier's dW [classes][kl], the bias gradient of the layer in front of it [kl], the classifier's db [16],
+    // {nll, hits}; with two hidden layers then dW2 [h2][hidden], db1 [hidden] at o_deep
+    const int o_nll = classes * kl + kl + 16, o_deep = (o_nll + 2 + 3) & ~3;
+    const int part_len = deep ? o_deep + h2 * hidden + hidden : o_nll + 2, stride = (part_len + 3) & ~3;
     // launch 2's form: 8 (default) = one eight-wave workgroup per CU on 128 x 112 tiles; TAPER_MLP2_DW = 22 | 31 | 32 | 41 = the four-wave
     // 128 x 128 form with that many ring stages x workgroups per CU (measurement knob)
     static const int variant = [] { const char *e = getenv("TAPER_MLP2_DW"); return e ? atoi(e) : 8; }();
@@ -970,19 +1114,21 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
                  (unsigned)((size_t)src->n_rows * in_features * 4)};
     Mlp2RowsArgs r{};
     r.src = rs;
-    r.w1 = d_w1; r.b1 = d_b1; r.w2 = d_w2; r.b2 = d_b2;
-    r.batch = batch; r.in_f = in_features; r.hid = hidden; r.c = classes;
-    r.dz1 = dz1; r.part = part; r.part_stride = stride; r.tick = d_tick;
+    r.w1 = d_w1; r.b1 = d_b1; r.w2 = L[1].w; r.b2 = L[1].b;
+    r.w3 = deep ? L[2].w : nullptr; r.b3 = deep ? L[2].b : nullptr;
+    r.batch = batch; r.in_f = in_features; r.hid = hidden; r.c = classes; r.h2 = h2;
+    r.dz1 = dz1; r.part = part; r.part_stride = stride; r.o_deep = o_deep; r.tick = d_tick;
     r.ksplit = ksplit; r.kpart = kpart;
     r.karrive = ctx->m2_arrive;
     // ring depth of launch 1: four stages (six for the 32-row tiles, one workgroup per CU, measured no faster: a lone wave per SIMD is bound by
     // its own issue order, not by the requests in flight)
-#define M2_ROWS_LAUNCH(RT_, NS_, NW_)                                                                                              \
+#define M2_ROWS_LAUNCH_(RT_, NS_, NW_, DEEP_)                                                                                      \
     do {                                                                                                                           \
         const size_t lds = (size_t)NS_ * (RT_ + 128) * M2_BK * sizeof(float);                                                      \
-        TH_SET_MAX_LDS(ctx, (mlp2_rows_kernel<RT_, NS_, NW_>), lds);                                                               \
-        hipLaunchKernelGGL((mlp2_rows_kernel<RT_, NS_, NW_>), dim3(n_blk * (RT_ == 16 ? ksplit : 1)), dim3(64 * NW_), lds, ctx->stream, r);                    \
+        TH_SET_MAX_LDS(ctx, (mlp2_rows_kernel<RT_, NS_, NW_, DEEP_>), lds);                                                        \
+        hipLaunchKernelGGL((mlp2_rows_kernel<RT_, NS_, NW_, DEEP_>), dim3(n_blk * (RT_ == 16 ? ksplit : 1)), dim3(64 * NW_), lds, ctx->stream, r); \
     } while (0)
+#define M2_ROWS_LAUNCH(RT_, NS_, NW_) do { if (deep) M2_ROWS_LAUNCH_(RT_, NS_, 4, true); else M2_ROWS_LAUNCH_(RT_, NS_, NW_, false); } while (0)
     // waves per workgroup of launch 1: four.  TAPER_MLP2_NW=8 (two waves per SIMD on the same ring; on 32-row tiles the two wave groups split
     // every chunk's k rounds) measured the same to 2 %: 39.7 / 23.7 / 22.7 us against 39.2-40.5 / 23.5 / 22.5 us at 16 384 / 4 096 / 1 024 rows --
     // the k loop already runs at the rate the matrix pipes sustain at the clocks the part holds under this load
@@ -1001,6 +1147,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
         else M2_ROWS_LAUNCH(32, 4, 4);
     }
 #undef M2_ROWS_LAUNCH
+#undef M2_ROWS_LAUNCH_
     TH_LAUNCH_CHECK();
 
     if (only != 0 && only != 2) {
@@ -1043,17 +1190,92 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
 
     Mlp2FinishArgs f{};
     f.partial = partial; f.part = part; f.kz = kz; f.n_blk = n_blk; f.part_stride = stride; f.batch = batch; f.in_f = in_features;
-    f.hid = hidden; f.c = classes;
-    f.dw1 = d_dw1; f.db1 = d_db1; f.dw2 = d_dw2; f.db2 = d_db2; f.loss = d_loss; f.ncorrect = d_ncorrect; f.metrics = d_metrics;
+    f.hid = hidden;
+    f.dw1 = d_dw1; f.loss = d_loss; f.ncorrect = d_ncorrect; f.metrics = d_metrics;
     f.capacity = metrics_capacity; f.state = d_state; f.advance = advance;
-    f.w1a = make_adam_dev(w1_fuse); f.b1a = make_adam_dev(b1_fuse); f.w2a = make_adam_dev(w2_fuse); f.b2a = make_adam_dev(b2_fuse);
+    f.w1a = make_adam_dev(w1_fuse);
     f.w1_blocks = ceil_div((long)hidden * in_features, 64);
-    const int tail_blocks = ceil_div(classes * hidden + hidden + 16 + 1, 16);
+    f.o_nll = o_nll; f.part_len = part_len;
+    {
+        const M2Layer &last = L[n_hidden], &prev = L[n_hidden - 1];
+        int g = 0;
+        f.seg[g++] = Mlp2Seg{0, classes * kl, last.dw, make_adam_dev(last.wf)};                              // the classifier's dW
+        f.seg[g++] = Mlp2Seg{classes * kl, kl, prev.db, make_adam_dev(prev.bf)};                             // the bias in front of it
+        f.seg[g++] = Mlp2Seg{classes * kl + kl, classes, last.db, make_adam_dev(last.bf)};                   // the classifier's db
+        if (deep) {
+            f.seg[g++] = Mlp2Seg{o_deep, h2 * hidden, L[1].dw, make_adam_dev(L[1].wf)};                      // dW2
+            f.seg[g++] = Mlp2Seg{o_deep + h2 * hidden, hidden, L[0].db, make_adam_dev(L[0].bf)};             // db1
+        }
+        f.n_seg = g;
+    }
+    const int tail_blocks = ceil_div(ceil_div(part_len, 4), 16);
     if (only == 0 || only == 3) hipLaunchKernelGGL(mlp2_finish_kernel, dim3(f.w1_blocks + tail_blocks), dim3(256), 0, ctx->stream, f);
     TH_LAUNCH_CHECK();
     ++t_mlp2_calls;
     return th_free(ctx, ws);
 }
+
+}  // namespace th
+
+using namespace th;
+
+extern "C" {
+
+int th_mlp2_xent_supported(int batch, int in_features, int hidden, int classes, int64_t n_rows) {
+    return batch >= 32 && in_features >= 32 && in_features % 4 == 0 && hidden >= 32 && hidden <= 128 && hidden % 32 == 0 && classes >= 1 &&
+                   classes <= 16 && n_rows >= 1 && (double)n_rows * in_features * 4.0 < 2147483648.0 && (double)(batch + 64) * hidden * 4.0 < 2147483648.0
+               ? 1 : 0;
+}
+
+int th_mlp2_xent_deep_supported(int batch, int in_features, int h1, int h2, int classes, int64_t n_rows) {
+    return th_mlp2_xent_supported(batch, in_features, h1, classes, n_rows) && h2 >= 16 && h2 <= 128 && h2 % 16 == 0 ? 1 : 0;
+}
+
+#define M2_COMMON_CHECKS(NAME)                                                                                                                                  \
+    TH_REQUIRE(!src->d_indices || (src->n_indices >= batch && src->n_indices < (1LL << 30)), NAME ": the index vector must hold at least one batch (and fewer than 2^30 entries)"); \
+    TH_REQUIRE(src->d_indices || src->n_rows >= batch, NAME ": a dense row block must hold the batch");                                                        \
+    TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), NAME ": metrics need d_state and a capacity")
+
+int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_features, int hidden, int classes, const float *d_w1,
+                 const float *d_b1, const float *d_w2, const float *d_b2, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2,
+                 float *d_loss, float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                 int32_t *d_tick, const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse, const th_adam_fuse *w2_fuse,
+                 const th_adam_fuse *b2_fuse) {
+    TH_REQUIRE(ctx && src && src->d_rows && src->d_labels && d_w1 && d_w2 && d_dw1 && d_dw2 && d_loss, "th_mlp2_xent: null argument");
+    TH_REQUIRE(th_mlp2_xent_supported(batch, in_features, hidden, classes, src->n_rows),
+               "th_mlp2_xent: needs batch >= 32, in_features a multiple of 4 (>= 32), hidden a multiple of 32 up to 128, classes <= 16, "
+               "rows * in_features * 4 < 2^31 (got %d, %d, %d, %d, %ld rows)", batch, in_features, hidden, classes, (long)src->n_rows);
+    M2_COMMON_CHECKS("th_mlp2_xent");
+    TH_REQUIRE((((uintptr_t)src->d_rows | (uintptr_t)d_w1 | (uintptr_t)d_w2 | (uintptr_t)d_dw1) & 15) == 0, "th_mlp2_xent: rows, W1, W2 and dW1 must be 16-byte aligned");
+    TH_REQUIRE(!(b1_fuse && b1_fuse->d_p) || d_db1, "th_mlp2_xent: a fused bias update needs d_db1");
+    TH_REQUIRE(!(b2_fuse && b2_fuse->d_p) || d_db2, "th_mlp2_xent: a fused bias update needs d_db2");
+    TH_REQUIRE(!(w1_fuse && w1_fuse->d_p) || ((((uintptr_t)w1_fuse->d_p | (uintptr_t)w1_fuse->d_m | (uintptr_t)w1_fuse->d_v) & 15) == 0),
+               "th_mlp2_xent: W1's p / m / v slices must be 16-byte aligned");
+    const M2Layer L[2] = {{d_w1, d_b1, d_dw1, d_db1, w1_fuse, b1_fuse, hidden}, {d_w2, d_b2, d_dw2, d_db2, w2_fuse, b2_fuse, classes}};
+    return mlp2_run(ctx, src, batch, in_features, 1, L, d_loss, d_ncorrect, d_metrics, metrics_capacity, d_state, advance, d_tick);
+}
+
+int th_mlp2_xent_deep(th_ctx *ctx, const th_row_source *src, int batch, int in_features, const th_mlp3_layer *layers, float *d_loss,
+                      float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_tick) {
+    TH_REQUIRE(ctx && src && src->d_rows && src->d_labels && layers && d_loss, "th_mlp2_xent_deep: null argument");
+    M2Layer L[3];
+    for (int l = 0; l < 3; ++l) {
+        const th_mlp3_layer &y = layers[l];
+        TH_REQUIRE(y.d_w && y.d_dw && (((uintptr_t)y.d_w | (uintptr_t)y.d_dw) & 15) == 0, "th_mlp2_xent_deep: layer %d needs 16-byte aligned d_w and d_dw", l);
+        TH_REQUIRE(!(y.b_fuse && y.b_fuse->d_p) || y.d_db, "th_mlp2_xent_deep: a fused bias update needs d_db (layer %d)", l);
+        L[l] = M2Layer{y.d_w, y.d_b, y.d_dw, y.d_db, y.w_fuse, y.b_fuse, y.out_features};
+    }
+    TH_REQUIRE(th_mlp2_xent_deep_supported(batch, in_features, L[0].out, L[1].out, L[2].out, src->n_rows),
+               "th_mlp2_xent_deep: needs batch >= 32, in_features a multiple of 4 (>= 32), the first hidden size a multiple of 32 and the second of 16 "
+               "(both <= 128), classes <= 16, rows * in_features * 4 < 2^31 (got %d, %d, %d, %d, %d, %ld rows)", batch, in_features, L[0].out,
+               L[1].out, L[2].out, (long)src->n_rows);
+    M2_COMMON_CHECKS("th_mlp2_xent_deep");
+    TH_REQUIRE(((uintptr_t)src->d_rows & 15) == 0, "th_mlp2_xent_deep: the rows must be 16-byte aligned");
+    TH_REQUIRE(!(L[0].wf && L[0].wf->d_p) || ((((uintptr_t)L[0].wf->d_p | (uintptr_t)L[0].wf->d_m | (uintptr_t)L[0].wf->d_v) & 15) == 0),
+               "th_mlp2_xent_deep: W1's p / m / v slices must be 16-byte aligned");
+    return mlp2_run(ctx, src, batch, in_features, 2, L, d_loss, d_ncorrect, d_metrics, metrics_capacity, d_state, advance, d_tick);
+}
+#undef M2_COMMON_CHECKS
 
 int th_mlp2_set_max_ksplit(th_ctx *ctx, int max_ksplit) {
     TH_REQUIRE(ctx && max_ksplit >= 1 && max_ksplit <= 8, "th_mlp2_set_max_ksplit: 1 .. 8");

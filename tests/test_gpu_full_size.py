@@ -238,7 +238,7 @@ FULL_BWD_STEP_LOSS = 1.6e-4    # later steps' losses, of the largest: observed 7
                                # by then, and the elements whose gradient is a cancellation down to ~eps move differently under another summation order
 FULL_BWD_STEP_ERR_OVER_LR = 4e-2   # weights after the steps, in units of lr, on all but FULL_BWD_OUTLIERS of a tensor's elements
 FULL_BWD_OUTLIERS = 2e-2           # (elements whose gradient is small against one flipped pixel's contribution)
-FULL_BWD_M = 5e-3                  # Adam's first moment after the steps, of the tensor's scale
+FULL_BWD_M = 2.5e-2                 # Adam's first moment after the steps, of the tensor's scale: observed 1.23e-2 (reference CNN, fc1 after 2 steps at lr 1e-2: step 2 runs on conv weights that each moved by ~lr sign(g)); 2x
 
 
 @pytest.mark.parametrize("name,steps", [("cnn_simple", 3), ("cnn_reference", 2)])

@@ -251,3 +251,152 @@ def test_mlp2_measurement_forms_in_a_subprocess():
         r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-m", "gpu", "-k", "dense_rows or index_vector", "-p", "no:cacheprovider"],
                            env=dict(env, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------------------------ two hidden layers
+def _oracle3(O, x, y, net):
+    """reference chain of examples/train_mnist.rs:40-48: Linear + ReLU, Linear + ReLU, Linear, cross_entropy_loss; backward from the loss"""
+    O.Tape.reset()
+    O.Tape.set_zero_sentinel(True)
+    params = [(O.Tensor(w).requires_grad(), O.Tensor(b).requires_grad()) for w, b in net]
+    h = O.Tensor(x)
+    for i, (w, b) in enumerate(params):
+        h = h.matmul(w.transpose()).add_broadcast(b)
+        if i < 2:
+            h = h.relu()
+    yt = O.Tensor(y)
+    loss = O.cross_entropy_loss(h, yt)
+    acc = O.accuracy(h, yt)
+    loss.backward()
+    out = float(loss.data()[0]), round(acc * len(y)), [(w.grad(), b.grad()) for w, b in params]
+    O.Tape.reset()
+    return out
+
+
+def _net3(rng, inf, h1, h2, c):
+    dims = [(h1, inf), (h2, h1), (c, h2)]
+    return [(rng.uniform(-1, 1, d).astype(np.float32) * np.float32(np.sqrt(2.0 / d[1])), rng.uniform(-0.1, 0.1, d[0]).astype(np.float32)) for d in dims]
+
+
+def _clear_of_relu_kinks(x, net, margin=2e-6):
+    """Nudges the hidden layers' biases until no pre-activation of the batch lies within `margin` (relative to the layer's largest) of zero.
+    A pre-activation within rounding of zero takes another sign under another summation order, and the ReLU mask it feeds flips: a
+    discontinuity of the function, not an error of either side -- one flipped element of the second hidden layer moves EVERY row of dW1 by
+    ~|dZ2| |W2| / B, i.e. by 1e-3 of that tensor's scale at batch 4096 (seen under the measurement forms).  The parity cases therefore run
+    on data that stay clear of the kinks in float64; fp32 sums differ from those by ~1e-7 relative, far inside the margin."""
+    h = x.astype(np.float64)
+    out = []
+    for l, (w, b) in enumerate(net):
+        b = b.copy()
+        if l < len(net) - 1:
+            z = h @ w.astype(np.float64).T
+            scale = float(np.abs(z).max()) + 1.0
+            for j in range(w.shape[0]):
+                for k in range(200):
+                    if np.abs(z[:, j] + np.float64(b[j])).min() > margin * scale:
+                        break
+                    b[j] = np.float32(b[j] + (k + 1) * 3e-4 * (1 if k % 2 == 0 else -1))
+                else:
+                    raise AssertionError(f"layer {l + 1} unit {j}: no bias within reach keeps the batch clear of the ReLU kink")
+            h = np.maximum(z + b.astype(np.float64), 0.0)
+        out.append((w, b))
+    return out
+
+
+def _call_deep(ctx, src, batch, inf, net_dev, fuses=None, tick=None, log=None):
+    from taper_amd import hip
+    layers = (hip.Mlp3Layer * 3)()
+    grads = []
+    for l, (dw_, db_, w, b) in enumerate(net_dev):
+        gw, gb = ctx.empty(w.size), ctx.empty(b.size)
+        grads.append((gw, gb))
+        wf = C.cast(C.pointer(fuses[l][0]), C.c_void_p) if fuses else None
+        bf = C.cast(C.pointer(fuses[l][1]), C.c_void_p) if fuses else None
+        layers[l] = hip.Mlp3Layer(int(dw_), int(db_), int(gw), int(gb), wf, bf, w.shape[0])
+    loss, nc = ctx.empty(1), ctx.empty(1)
+    metrics, cap, state, adv = log if log else (None, 0, None, 0)
+    ctx.call("th_mlp2_xent_deep", C.byref(src), batch, inf, C.cast(layers, C.c_void_p), loss, nc, metrics, cap, state, adv, tick)
+    return dict(loss=loss, nc=nc, grads=grads)
+
+
+DEEP = [(1024, 784, 128, 64, 10), (4096, 784, 128, 64, 10), (16384, 784, 128, 64, 10), (256, 784, 128, 64, 10), (1000, 100, 64, 32, 5),
+        (40, 36, 32, 16, 16), (5000, 784, 96, 48, 10), (2048, 64, 128, 128, 3), (12288 + 5, 784, 128, 64, 10)]
+
+
+@pytest.mark.parametrize("batch,inf,h1,h2,c", DEEP)
+def test_mlp2_deep_dense_rows(ctx, O, batch, inf, h1, h2, c):
+    """th_mlp2_xent_deep against the oracle's unfused chain: loss, hit count (exact), all six gradients; two calls give the same bits"""
+    from taper_amd._lib import hip as lib
+    assert lib.th_mlp2_xent_deep_supported(batch, inf, h1, h2, c, batch) == 1
+    rng = np.random.default_rng(batch + inf + h1 + h2 + c)
+    x = (rng.integers(0, 256, (batch, inf)) * (rng.uniform(0, 1, (batch, inf)) < 0.3)).astype(np.float32) / np.float32(255.0)
+    y = rng.integers(0, c, batch).astype(np.float32)
+    net = _clear_of_relu_kinks(x, _net3(rng, inf, h1, h2, c))
+    ref_loss, ref_hits, ref_grads = _oracle3(O, x, y, net)
+    net_dev = [(ctx.upload(w), ctx.upload(b), w, b) for w, b in net]
+    dx, dy = ctx.upload(x), ctx.upload(y)
+    src = RowSource(int(dx), int(dy), None, None, 0, batch)
+    out = _call_deep(ctx, src, batch, inf, net_dev)
+    assert ctx.download(out["loss"], 1)[0] == pytest.approx(ref_loss, rel=RTOL, abs=1e-6)
+    assert ctx.download(out["nc"], 1)[0] == ref_hits                          # index work: exact
+    for l, ((gw, gb), (rw, rb), (w, b)) in enumerate(zip(out["grads"], ref_grads, net)):
+        got_w, got_b = ctx.download(gw, w.shape), ctx.download(gb, b.shape)
+        close(got_w, np.asarray(rw).reshape(w.shape), atol=1e-6)
+        close(got_b, np.asarray(rb).reshape(b.shape), atol=1e-6)
+        margins.check(f"dw{l + 1}", got_w, np.asarray(rw).reshape(w.shape), 1e-4, test="test_mlp2_deep_dense_rows")
+        margins.check(f"db{l + 1}", got_b, np.asarray(rb).reshape(b.shape), 1e-4, test="test_mlp2_deep_dense_rows")
+    out2 = _call_deep(ctx, src, batch, inf, net_dev)
+    for (gw, gb), (gw2, gb2), (w, b) in zip(out["grads"], out2["grads"], net):
+        np.testing.assert_array_equal(ctx.download(gw, w.size), ctx.download(gw2, w.size))
+        np.testing.assert_array_equal(ctx.download(gb, b.size), ctx.download(gb2, b.size))
+    np.testing.assert_array_equal(ctx.download(out["loss"], 1), ctx.download(out2["loss"], 1))
+    for (dw_, db_, w, b) in net_dev:                                            # parameters are only read without a fuse
+        np.testing.assert_array_equal(ctx.download(dw_, w.shape), w)
+
+
+def test_mlp2_deep_rows_through_the_index_vector_with_adam(ctx, O):
+    """the reference's model on rows idx[(cursor + r) % n] of a resident set, wrapping at the epoch's end, with Adam for all six parameters
+    in the finish launch at the t the rows launch opened, and the step log"""
+    n_rows, batch, cursor, inf, h1, h2, c = 5000, 2048, 4000, 784, 128, 64, 10
+    rng = np.random.default_rng(77)
+    data = (rng.integers(0, 256, (n_rows, inf)) * (rng.uniform(0, 1, (n_rows, inf)) < 0.25)).astype(np.float32) / np.float32(255.0)
+    labels = rng.integers(0, c, n_rows).astype(np.float32)
+    idx = rng.permutation(n_rows).astype(np.int32)
+    rows = idx[(cursor + np.arange(batch)) % n_rows]
+    net = _clear_of_relu_kinks(data[rows], _net3(rng, inf, h1, h2, c))
+    ref_loss, ref_hits, ref_grads = _oracle3(O, data[rows], labels[rows], net)
+    lr, t = 1e-3, 6
+    net_dev = [(ctx.upload(w), ctx.upload(b), w, b) for w, b in net]
+    tick, dlr = ctx.upload(np.array([t, 0], np.int32)), ctx.upload(np.array([lr], np.float32))
+    moms, fuses = [], []
+    for (dw_, db_, w, b) in net_dev:
+        ent = []
+        for p, a in ((dw_, w), (db_, b)):
+            m, v = ctx.zeros(a.size), ctx.zeros(a.size)
+            moms.append((p, m, v, a))
+            ent.append(AdamFuse(int(p), int(m), int(v), int(tick), int(dlr), 0.9, 0.999, 1e-8, 1e-4))
+        fuses.append(ent)
+    dd, dl, di = ctx.upload(data), ctx.upload(labels), ctx.upload(idx)
+    state = ctx.upload(np.array([3, cursor], np.int64))
+    src = RowSource(int(dd), int(dl), int(di), state.offset(8), n_rows, n_rows)
+    metrics = ctx.zeros(2 * 8)
+    out = _call_deep(ctx, src, batch, inf, net_dev, fuses=fuses, tick=tick, log=(metrics, 8, state, batch))
+    assert ctx.download(tick, 2, np.int32)[0] == t + 1
+    assert ctx.download(out["loss"], 1)[0] == pytest.approx(ref_loss, rel=RTOL, abs=1e-6)
+    assert ctx.download(out["nc"], 1)[0] == ref_hits
+    np.testing.assert_array_equal(ctx.download(state, 2, np.int64), [4, cursor + batch])
+    m = ctx.download(metrics, 16)
+    assert m[6] == ctx.download(out["loss"], 1)[0] and m[7] == ref_hits
+    flat_ref = [g for pair in ref_grads for g in pair]
+    for k, ((p, m_, v_, a), g) in enumerate(zip(moms, flat_ref)):
+        p_ref, m_ref, v_ref = _adam_ref(O, a.reshape(-1), np.asarray(g, np.float32).reshape(-1), lr, t + 1)
+        margins.check(f"param{k}_m", ctx.download(m_, a.size), m_ref, 1e-4, test="test_mlp2_deep_rows_through_the_index_vector_with_adam")
+        margins.check_adam_weights(f"param{k}_after_adam", ctx.download(p, a.size), p_ref, v_ref, lr, 1, 2e-2, test="test_mlp2_deep_rows_through_the_index_vector_with_adam")
+
+
+def test_mlp2_deep_limits_are_errors(ctx):
+    from taper_amd._lib import TaperError, hip as lib
+    assert lib.th_mlp2_xent_deep_supported(1024, 784, 128, 72, 10, 60000) == 0     # the second hidden size: a multiple of 16
+    assert lib.th_mlp2_xent_deep_supported(1024, 784, 100, 64, 10, 60000) == 0     # the first: a multiple of 32
+    assert lib.th_mlp2_xent_deep_supported(1024, 784, 128, 144, 10, 60000) == 0
+    assert lib.th_mlp2_xent_deep_supported(1024, 784, 128, 64, 10, 60000) == 1
