@@ -783,6 +783,9 @@ def compact_line(full, details_path):
     if full.get("batch_sweep"):
         # {batch: [us/step, epochs/s, fraction of the fp32 MFMA peak]}
         out["batch_sweep_us_epochs_frac"] = {str(e["batch"]): [round(e["ms_per_step"] * 1e3, 1), round(e["epochs_per_s"], 1), round(e["mfma_frac"], 3)] for e in full["batch_sweep"]}
+    if full.get("batch_sweep_mlp_784-128-64-10"):
+        # the reference's own model (examples/train_mnist.rs): {batch: [us/step, epochs/s]}
+        out["sweep_784-128-64-10"] = {str(e["batch"]): [round(e["ms_per_step"] * 1e3, 1), round(e["epochs_per_s"])] for e in full["batch_sweep_mlp_784-128-64-10"]}
     if full.get("workloads"):
         w = {}
         for rec in full["workloads"]:
@@ -1037,10 +1040,13 @@ def main():
                         step_us_two_launch_chain=sk["step_us"], kernels=sk["kernels"])
         if world > 1 and dp_extra and dp_extra.get("exchange"):
             roof = dict(dp_extra["exchange"])           # N > 1: the kernel the job adds to the N = 1 step is the gradient exchange
-        sweep = None
+        sweep = sweep_example = None
         # (not under rocprofv3: the trace of this command is for the headline workload's kernels only)
         if key == "mlp_baseline" and world == 1 and not args.batch and not args.no_sweep and not under_profiler:
             sweep = batch_sweep(T, build_model, key, lr, ds)
+            # the reference's OWN example model (examples/train_mnist.rs:40-48: two hidden layers) over the same batches: from 480 rows on its
+            # step is th_mlp2_xent_deep (three launches)
+            sweep_example = batch_sweep(T, build_model, "mlp_example", lr, ds, batches=(256, 1024, 4096, 16384, 60000))
         cpu = None
         with_cpu = not args.no_cpu_baseline and world == 1          # the CPU leg is timed on rank 0 at N = 1 only
         if with_cpu:
@@ -1075,7 +1081,7 @@ def main():
                 "alg_flops_per_step": flops, "alg_bytes_per_step": nbytes,
                 "hbm_frac": round(nbytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
                 "mfma_frac": round(flops / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TF, 6)},
-            "sustained": sustained, "batch_sweep": sweep, "roofline": roof, "cpu_baseline": cpu,
+            "sustained": sustained, "batch_sweep": sweep, "batch_sweep_mlp_784-128-64-10": sweep_example, "roofline": roof, "cpu_baseline": cpu,
             **({"data_parallel": dp_extra} if dp_extra is not None else {}),
             **({"workloads": workloads} if workloads is not None else {}),
         }

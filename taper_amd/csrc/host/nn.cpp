@@ -376,21 +376,40 @@ static size_t mlp2_min_batch() {
     return v;
 }
 
-bool mlp2_supported(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2) {
-    if (w1.shape().size() != 2 || w2.shape().size() != 2 || w2.shape()[1] != w1.shape()[0]) return false;
-    if (!w1.get_requires_grad() || !w2.get_requires_grad() || w1.has_grad() || w2.has_grad()) return false;   // gradients are written, never accumulated
-    for (const Tensor *b : {&b1, &b2})
-        if (b->defined() && (!b->get_requires_grad() || b->has_grad())) return false;
-    if ((((uintptr_t)src.d_rows | (uintptr_t)w1.dptr() | (uintptr_t)w2.dptr()) & 15) != 0) return false;
-    if (src.d_indices && src.n_indices < (int64_t)batch) return false;
-    return th_mlp2_xent_supported((int)batch, (int)w1.shape()[1], (int)w1.shape()[0], (int)w2.shape()[0], src.n_rows) != 0;
+// What th_mlp2_xent / th_mlp2_xent_deep need of the parameters themselves, whatever the rows: gradients are written, never accumulated
+// (every slot empty), every parameter trains, shapes chain, 16-byte aligned storage.  `w`, `b`: 2 or 3 Linear layers, first to last.
+bool mlp2_params_ok(const std::vector<Tensor> &w, const std::vector<Tensor> &b) {
+    if ((w.size() != 2 && w.size() != 3) || b.size() != w.size()) return false;
+    for (size_t l = 0; l < w.size(); ++l) {
+        if (w[l].shape().size() != 2 || (l > 0 && w[l].shape()[1] != w[l - 1].shape()[0])) return false;
+        if (!w[l].get_requires_grad() || w[l].has_grad() || ((uintptr_t)w[l].dptr() & 15) != 0) return false;
+        if (b[l].defined() && (!b[l].get_requires_grad() || b[l].has_grad() || b[l].shape() != Shape{w[l].shape()[0]})) return false;
+    }
+    return true;
 }
 
-Tensor mlp2_cross_entropy(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
+static bool mlp2_shapes_ok(size_t batch, const std::vector<Tensor> &w, int64_t n_rows) {
+    const int in_f = (int)w[0].shape()[1], h1 = (int)w[0].shape()[0];
+    if (w.size() == 2) return th_mlp2_xent_supported((int)batch, in_f, h1, (int)w[1].shape()[0], n_rows) != 0;
+    return th_mlp2_xent_deep_supported((int)batch, in_f, h1, (int)w[1].shape()[0], (int)w[2].shape()[0], n_rows) != 0;
+}
+
+bool mlp2_supported(const th_row_source &src, size_t batch, const std::vector<Tensor> &w, const std::vector<Tensor> &b) {
+    if (!mlp2_params_ok(w, b)) return false;
+    if (((uintptr_t)src.d_rows & 15) != 0) return false;
+    if (src.d_indices && src.n_indices < (int64_t)batch) return false;
+    return mlp2_shapes_ok(batch, w, src.n_rows);
+}
+
+bool mlp2_supported(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2) {
+    return mlp2_supported(src, batch, std::vector<Tensor>{w1, w2}, std::vector<Tensor>{b1, b2});
+}
+
+Tensor mlp2_cross_entropy(const th_row_source &src, size_t batch, const std::vector<Tensor> &w, const std::vector<Tensor> &b,
                           Tensor *n_correct_out, const StepLogSink *log) {
-    // nn.rs:54-60, activation.rs:10-12, loss.rs:136-195 and the backward closures of both Linear layers and the ReLU node
+    // nn.rs:54-60, activation.rs:10-12, loss.rs:136-195 and the backward closures of the Linear layers and the ReLU nodes
     // (ops.rs:238-294, 358-369; tensor.rs:574-587, 674-694); data/mnist.rs:277-310 for the rows
-    TAPER_ASSERT(mlp2_supported(src, batch, w1, b1, w2, b2), "mlp2_cross_entropy: unsupported shapes / gradient state");
+    TAPER_ASSERT(mlp2_supported(src, batch, w, b), "mlp2_cross_entropy: unsupported shapes / gradient state");
     th_ctx *ctx = Device::ctx();
     Adam *fa = FusedAdamScope::active();
     if (fa && fa->has_deferred()) fa->flush_deferred();   // updates an earlier (other) step form left behind: with their own counter
@@ -406,29 +425,46 @@ Tensor mlp2_cross_entropy(const th_row_source &src, size_t batch, const Tensor &
         p.grad_->known_zero = false;
         return p.grad_->buf->d;
     };
-    float *dw1 = slot(w1), *db1 = slot(b1), *dw2 = slot(w2), *db2 = slot(b2);
-    // the finish launch holds every complete gradient and no launch of the step reads a parameter after it: all four updates ride there
-    th_adam_fuse f[4];
-    const th_adam_fuse *pf[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (fa) {
-        const Tensor *ps[4] = {&w1, &b1, &w2, &b2};
-        for (int i = 0; i < 4; ++i)
-            if (ps[i]->defined() && fa->fuse_for(*ps[i], &f[i])) pf[i] = &f[i];
+    // the finish launch holds every complete gradient and no launch of the step reads a parameter after it: every update rides there
+    const size_t nl = w.size();
+    th_adam_fuse fw[3], fb[3];
+    th_mlp3_layer L[3];
+    for (size_t l = 0; l < nl; ++l) {
+        L[l].d_w = w[l].dptr();
+        L[l].d_b = b[l].defined() ? b[l].dptr() : nullptr;
+        L[l].d_dw = slot(w[l]);
+        L[l].d_db = slot(b[l]);
+        L[l].w_fuse = (fa && fa->fuse_for(w[l], &fw[l])) ? &fw[l] : nullptr;
+        L[l].b_fuse = (fa && b[l].defined() && fa->fuse_for(b[l], &fb[l])) ? &fb[l] : nullptr;
+        L[l].out_features = (int)w[l].shape()[0];
     }
-    TH(th_mlp2_xent(ctx, &src, (int)batch, (int)w1.shape()[1], (int)w1.shape()[0], (int)w2.shape()[0], w1.dptr(), b1.defined() ? b1.dptr() : nullptr,
-                    w2.dptr(), b2.defined() ? b2.dptr() : nullptr, dw1, db1, dw2, db2, loss.dptr(), nc, log ? log->d_metrics : nullptr,
-                    log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0, fa ? fa->d_tick() : nullptr, pf[0], pf[1], pf[2],
-                    pf[3]));
+    if (nl == 2)
+        TH(th_mlp2_xent(ctx, &src, (int)batch, (int)w[0].shape()[1], L[0].out_features, L[1].out_features, L[0].d_w, L[0].d_b, L[1].d_w, L[1].d_b,
+                        L[0].d_dw, L[0].d_db, L[1].d_dw, L[1].d_db, loss.dptr(), nc, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                        log ? log->d_state : nullptr, log ? log->advance : 0, fa ? fa->d_tick() : nullptr, L[0].w_fuse, L[0].b_fuse, L[1].w_fuse,
+                        L[1].b_fuse));
+    else
+        TH(th_mlp2_xent_deep(ctx, &src, (int)batch, (int)w[0].shape()[1], L, loss.dptr(), nc, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                             log ? log->d_state : nullptr, log ? log->advance : 0, fa ? fa->d_tick() : nullptr));
     loss.set_requires_grad(true);
-    Tensor p1 = w1, p2 = b1, p3 = w2, p4 = b2, out = loss;
-    Tape::push(loss, true, [p1, p2, p3, p4, out]() {
+    std::vector<Tensor> ps;
+    for (size_t l = 0; l < nl; ++l) {
+        ps.push_back(w[l]);
+        if (b[l].defined()) ps.push_back(b[l]);
+    }
+    Tensor out = loss;
+    Tape::push(loss, true, [ps, out]() {
         if (!out.has_grad()) return;
         // the gradients were produced by the forward launches for an upstream grad of exactly 1
         TAPER_ASSERT(out.grad_->shared_const, "mlp2_cross_entropy: only loss.backward() from the root is supported");
-        for (const Tensor *p : {&p1, &p2, &p3, &p4})
-            if (p->defined()) p->grad_->has = true;
+        for (const Tensor &p : ps) p.grad_->has = true;
     });
     return loss;
+}
+
+Tensor mlp2_cross_entropy(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
+                          Tensor *n_correct_out, const StepLogSink *log) {
+    return mlp2_cross_entropy(src, batch, std::vector<Tensor>{w1, w2}, std::vector<Tensor>{b1, b2}, n_correct_out, log);
 }
 
 // Linear + ReLU, Linear + ReLU, Linear, softmax cross-entropy -- the classifier of examples/train_mnist_cnn.rs:53-61 and the whole model of
@@ -1415,13 +1451,34 @@ EpochResult Trainer::evaluate(DataLoader &loader) {  // train.rs:147-172
 // come from the device-resident dataset through the device cursor (ONE gather launch for a
 // whole chunk of steps), and the loss kernel itself appends {loss, n_correct} to the device
 // log and advances the step / cursor state.
+// The Linear layers of a model that is Linear + ReLU (+ Linear + ReLU) + Linear on the loader's 784-wide rows (BASELINE's 784-128-10,
+// examples/train_mnist.rs:40-48's 784-128-64-10); empty otherwise.
+static bool mlp2_layers(const Module *model, std::vector<Tensor> *w, std::vector<Tensor> *b) {
+    auto *seq = dynamic_cast<const Sequential *>(model);
+    if (!seq || !seq->fuse || (seq->layers.size() != 3 && seq->layers.size() != 5)) return false;
+    w->clear();
+    b->clear();
+    for (size_t i = 0; i < seq->layers.size(); ++i) {
+        if (i % 2 == 1) {
+            if (!dynamic_cast<ReLU *>(seq->layers[i].get())) return false;
+            continue;
+        }
+        auto *l = dynamic_cast<Linear *>(seq->layers[i].get());
+        if (!l) return false;
+        w->push_back(l->weight);
+        b->push_back(l->bias);
+    }
+    return (*w)[0].shape().size() == 2 && (*w)[0].shape()[1] == 784;   // (the loader's rows: data/mnist.rs:16)
+}
+
+// this model at this batch takes th_mlp2_xent / th_mlp2_xent_deep, its rows read in place -- decided on EVERYTHING the step will ask for
+// (shapes, and the parameters' state: every one trains, no gradient already present, aligned storage), so that a model the large-batch
+// step cannot take (a frozen layer, gradients left by a manual backward) falls back to the gathered forms instead of failing inside the
+// step (r04 checked the shapes only)
 bool Trainer::mlp2_step(size_t batch, int64_t n_rows) const {
-    auto *seq = dynamic_cast<Sequential *>(model.get());
-    if (!(fuse_head >= 2 && seq && seq->fuse && seq->layers.size() == 3 && sample_shape.empty()) || batch < mlp2_min_batch()) return false;
-    auto *l1 = dynamic_cast<Linear *>(seq->layers[0].get());
-    auto *l2 = dynamic_cast<Linear *>(seq->layers[2].get());
-    if (!(l1 && l2 && dynamic_cast<ReLU *>(seq->layers[1].get())) || l1->weight.shape()[1] != 784) return false;   // (the loader's rows are 784 wide)
-    return th_mlp2_xent_supported((int)batch, 784, (int)l1->weight.shape()[0], (int)l2->weight.shape()[0], n_rows) != 0;
+    if (fuse_head < 2 || !sample_shape.empty() || batch < mlp2_min_batch()) return false;
+    std::vector<Tensor> w, b;
+    return mlp2_layers(model.get(), &w, &b) && mlp2_params_ok(w, b) && mlp2_shapes_ok(batch, w, n_rows);
 }
 
 void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_row_source *rows) {
@@ -1436,12 +1493,12 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
     Tensor ncorrect, loss;
     auto *seq = dynamic_cast<Sequential *>(model.get());
     if (rows) {
-        // Linear + ReLU + Linear at large batch: three launches for the whole step, the rows read in place (mlp2_step said so)
-        auto *l1 = dynamic_cast<Linear *>(seq->layers[0].get());
-        auto *l2 = dynamic_cast<Linear *>(seq->layers[2].get());
-        TAPER_ASSERT(l1 && l2 && mlp2_supported(*rows, batch, l1->weight, l1->bias, l2->weight, l2->bias),
+        // Linear + ReLU (+ Linear + ReLU) + Linear at large batch: three launches for the whole step, the rows read in place (mlp2_step said so,
+        // on the same predicate, at the start of this chunk of steps; every step ends with zero_grad)
+        std::vector<Tensor> w, b;
+        TAPER_ASSERT(mlp2_layers(model.get(), &w, &b) && mlp2_supported(*rows, batch, w, b),
                      "Trainer: the large-batch MLP step met parameters it cannot take (gradients already present?)");
-        loss = mlp2_cross_entropy(*rows, batch, l1->weight, l1->bias, l2->weight, l2->bias, &ncorrect, &sink);
+        loss = mlp2_cross_entropy(*rows, batch, w, b, &ncorrect, &sink);
         loss.backward();
         if (!(comm && optimizer->step_reduced(*comm))) {
             reduce_grads(*this);

@@ -272,6 +272,11 @@ Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b
 // Linear + ReLU, Linear, cross-entropy at LARGE batch: three launches (th_mlp2_xent), the batch's rows read where they lie -- a dense block or
 // rows of the resident dataset through the loader's index vector (no gathered copy).  Trainer-internal, like the forms above.
 bool mlp2_supported(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2);
+// ... and for 2 or 3 Linear layers (one or two hidden layers: th_mlp2_xent / th_mlp2_xent_deep), first to last
+bool mlp2_params_ok(const std::vector<Tensor> &w, const std::vector<Tensor> &b);
+bool mlp2_supported(const th_row_source &src, size_t batch, const std::vector<Tensor> &w, const std::vector<Tensor> &b);
+Tensor mlp2_cross_entropy(const th_row_source &src, size_t batch, const std::vector<Tensor> &w, const std::vector<Tensor> &b,
+                          Tensor *n_correct_out = nullptr, const StepLogSink *log = nullptr);
 Tensor mlp2_cross_entropy(const th_row_source &src, size_t batch, const Tensor &w1, const Tensor &b1, const Tensor &w2, const Tensor &b2,
                           Tensor *n_correct_out, const StepLogSink *log);
 // n_correct_out (optional): device scalar receiving accuracy()*B from the fused kernel

@@ -986,50 +986,54 @@ __global__ __launch_bounds__(256) void mlp2_finish_kernel(Mlp2FinishArgs a) {
         }
         return;
     }
-    // the row blocks' partial sums: 16 float4 of the record per workgroup, 16 threads per float4 -- thread `sub` adds the blocks sub, sub + 16, ...
-    // in order, thread 0 of the float4 adds the 16 sums in order (the order r04's element-wise form had)
-    const int qd = (bid - a.w1_blocks) * 16 + (t & 15), sub = t >> 4;
+    // the row blocks' partial sums: a WAVE per float4 of the record (four per workgroup) -- lane `sub` adds the blocks sub, sub + 64, ... in
+    // order (four loads at 256 blocks, all in flight), the 64 sums meet in a fixed shuffle tree: no LDS, no barrier.  (r04: 16 threads per
+    // element, 16 dependent scalar loads each and one thread's chain of Adam updates behind them -- this role, not the 14 MB of K slices,
+    // was the launch's critical path: 8.7 - 9.5 us then, 6.3 - 6.6 us with float4 loads and one element per thread, measured.)
+    const int qd = (bid - a.w1_blocks) * 4 + (t >> 6), sub = t & 63;
+    if (4 * qd >= a.part_len) return;                  // (the whole wave)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (4 * qd < a.part_len) {
+    {
         const float *src = a.part + 4 * qd;
 #pragma unroll 4
-        for (int b = sub; b < a.n_blk; b += 16) {
+        for (int b = sub; b < a.n_blk; b += 64) {
             const float4 v = *reinterpret_cast<const float4 *>(src + (long)b * a.part_stride);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
-    sh4[sub][t & 15] = s;
-    __syncthreads();
-    if (sub != 0 || 4 * qd >= a.part_len) return;
 #pragma unroll
-    for (int u = 1; u < 16; ++u) {
-        const float4 p = sh4[u][t];
-        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    for (int off = 32; off > 0; off >>= 1) {
+        s.x += __shfl_down(s.x, off, 64);
+        s.y += __shfl_down(s.y, off, 64);
+        s.z += __shfl_down(s.z, off, 64);
+        s.w += __shfl_down(s.w, off, 64);
     }
-    const float sv[4] = {s.x, s.y, s.z, s.w};
+    // one element per lane from here (lane j < 4 takes component j): the Adam updates of a float4's four elements are four chains of
+    // dependent loads, side by side instead of one after the other
+    const float q0 = __shfl(s.x, 0, 64), q1 = __shfl(s.y, 0, 64), q2 = __shfl(s.z, 0, 64), q3 = __shfl(s.w, 0, 64);
+    if (sub >= 4) return;
     if (4 * qd == a.o_nll) {
-        const float l = sv[0] / (float)a.batch;       // loss.rs:164
+        if (sub != 0) return;
+        const float l = q0 / (float)a.batch;          // loss.rs:164
         a.loss[0] = l;
-        if (a.ncorrect) a.ncorrect[0] = sv[1];
+        if (a.ncorrect) a.ncorrect[0] = q1;
         if (a.metrics) {                              // th_log_step
             const int64_t s0 = a.state[0], s1 = a.state[1];
             const int64_t slot = s0 < a.capacity ? s0 : s0 % a.capacity;
             a.metrics[2 * slot] = l;
-            a.metrics[2 * slot + 1] = sv[1];
+            a.metrics[2 * slot + 1] = q1;
             a.state[0] = s0 + 1;
             a.state[1] = s1 + a.advance;
         }
         return;
     }
+    const float v = sub == 0 ? q0 : (sub == 1 ? q1 : (sub == 2 ? q2 : q3));
+    const int e = 4 * qd + sub;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = 4 * qd + j;
-#pragma unroll
-        for (int g = 0; g < M2_MAX_SEGS; ++g) {
-            if (g < a.n_seg && e >= a.seg[g].start && e < a.seg[g].start + a.seg[g].len && a.seg[g].grad) {
-                a.seg[g].grad[e - a.seg[g].start] = sv[j];
-                m2_apply(a.seg[g].ad, e - a.seg[g].start, sv[j]);
-            }
+    for (int g = 0; g < M2_MAX_SEGS; ++g) {
+        if (g < a.n_seg && e >= a.seg[g].start && e < a.seg[g].start + a.seg[g].len && a.seg[g].grad) {
+            a.seg[g].grad[e - a.seg[g].start] = v;
+            m2_apply(a.seg[g].ad, e - a.seg[g].start, v);
         }
     }
 }
@@ -1208,7 +1212,7 @@ static int mlp2_run(th_ctx *ctx, const th_row_source *src, int batch, int in_fea
         }
         f.n_seg = g;
     }
-    const int tail_blocks = ceil_div(ceil_div(part_len, 4), 16);
+    const int tail_blocks = ceil_div(ceil_div(part_len, 4), 4);
     if (only == 0 || only == 3) hipLaunchKernelGGL(mlp2_finish_kernel, dim3(f.w1_blocks + tail_blocks), dim3(256), 0, ctx->stream, f);
     TH_LAUNCH_CHECK();
     ++t_mlp2_calls;

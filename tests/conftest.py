@@ -27,3 +27,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _leave_no_tape_behind(request):
+    """a GPU test that fails half-way must not leave its tape / mode switches to the tests behind it (one failure then read as dozens)"""
+    yield
+    if "gpu" in request.keywords and _has_gpu():
+        try:
+            import taper_amd as T
+            T.Tape.reset()
+            T.set_full_backward(False)
+        except Exception:
+            pass
