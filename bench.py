@@ -565,6 +565,33 @@ def trainer_workload(T, name, dataset, steps=None):
     return rec, key, batch, sample_shape, lr
 
 
+CNN_FWD_FLOPS = {"cnn_reference": 43.85e6, "cnn_simple": 7.74e6}   # SURVEY 8d, per sample
+
+
+def cnn_batch_sweep(T, key, sample_shape, lr, dataset, batches=(1024, 4096)):
+    """SURVEY 8d's sweep for the CNN steps (r04 review: a single point at batch 256): the same captured Trainer step at larger batches.
+    One image per workgroup in the chain launch, so a batch of 1 024 is four rounds of workgroups per CU: launch, drain and the image
+    load amortise, the per-image phases do not overlap (no persistent form yet).  `mfma_frac_fwd` prices the forward conv flops only
+    (faithful mode: the conv weights do not train, quirk Q2)."""
+    out = []
+    for b in batches:
+        model = build_model(T, key)
+        opt = T.Adam(model.parameters(), lr, None, None, 1e-4)
+        trainer = T.Trainer(model, opt, sample_shape=sample_shape)
+        loader = T.DataLoader(dataset, b, False)
+        steps = max(40, 200_000 // b)
+        run_steps(T, trainer, loader, max(steps // 4, 20))
+        T.Device.sync()
+        t0 = time.perf_counter()
+        samples = run_steps(T, trainer, loader, steps)
+        T.Device.sync()
+        dt = time.perf_counter() - t0
+        out.append(dict(batch=b, steps=steps, ms_per_step=round(dt / steps * 1e3, 5), samples_per_s=round(samples / dt, 1),
+                        mfma_frac_fwd=round(CNN_FWD_FLOPS[key] * samples / dt / 1e12 / MFMA_F32_PEAK_TF, 4)))
+        _KEEP_ALIVE.append((trainer, opt, model, loader))
+    return out
+
+
 def sgemm_kernels(ctx, size=4096, reps=120):
     """BASELINE configs[4] / north_star "Linear-layer GEMM at >= 60 % MFMA peak on 4096^3 fp32": the three products of a
     Linear layer's step -- forward X.W^T (NT), dX = dZ.W (NN), dW = dZ^T.X (TN, accumulating: beta = 1) -- through
@@ -701,6 +728,10 @@ def extra_workloads(T, dataset, with_cpu, only=None):
                 head = chain and key == "cnn_simple" and os.environ.get("TAPER_CHAIN_HEAD", "1") != "0"
                 rec["kernels"] = (chain_head_kernels(ctx) if head else []) + ([dict(conv_chain_kernel(ctx, key), in_step=not head)] if chain else []) + layers
                 rec["conv_us_per_step"] = round(sum(k["us_per_launch"] for k in rec["kernels"] if k["in_step"]), 1)
+                try:
+                    rec["batch_sweep"] = cnn_batch_sweep(T, key, sample_shape, lr, dataset)
+                except Exception as e:
+                    rec["batch_sweep"] = dict(error=str(e))
                 # the same model with every conv weight training (full_backward: an extension -- the reference cuts the tape at im2col /
                 # transpose_4d, quirk Q2 -- through the layer-by-layer forward and the conv backward kernels)
                 try:
@@ -799,6 +830,8 @@ def compact_line(full, details_path):
             elif ks:
                 k = max(ks, key=lambda r: r["us_per_launch"])
                 e["kernel"] = [_short(k["kernel"].split("<")[0].split("(")[0], 24), k["us_per_launch"], k["bound"], k["frac"]]
+            if isinstance(rec.get("batch_sweep"), list):      # CNN steps at larger batches: {batch: [ms/step, forward-conv fraction of the MFMA peak]}
+                e["sweep"] = {str(x["batch"]): [round(x["ms_per_step"], 4), round(x["mfma_frac_fwd"], 3)] for x in rec["batch_sweep"]}
             if "frac_of_mfma_peak" in rec:
                 e["mfma_frac"] = rec["frac_of_mfma_peak"]
                 e["sgemm_4096_frac"] = [k["frac"] for k in rec.get("kernels", [])]

@@ -149,6 +149,17 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
                           float *d_dx, float *d_dw, float *d_db, int batch, int in_features, int out_features,
                           int accumulate_mask, const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse,
                           const th_adam_slice *extra, int n_extra);
+/* ... and with the backward of the layer IN FRONT folded into this layer's dX product, when that layer is a fused Linear + ReLU whose output
+ * is d_x: mask_dx != 0: d_dx <- d_dx * [d_x > 0] (that ReLU's backward, ops.rs:358-369: no pass over [batch, in_features] for it);
+ * d_dx_colpart (nullable) [th_linear_bwd_dx_epilogue_rows(..)][in_features]: column sums of the (masked) d_dx by row block, which
+ * th_colsum over its rows turns into that layer's bias gradient (tensor.rs:686-691: no pass for that either).  Needs d_dx written (not
+ * accumulated) and a shape for which th_linear_bwd_dx_epilogue_rows is > 0: the unsplit 128 x 128 MFMA tiles (4096-wide layers), or a thin
+ * layer (out_features <= 16 on >= 2^20 outputs), whose dX then runs as a streaming launch (67 MB in ~25 us instead of 119). */
+int th_linear_bwd_dx_epilogue_rows(int batch, int in_features, int out_features);
+int th_linear_bwd_adam_ex2(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
+                           float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask,
+                           const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra, int mask_dx,
+                           float *d_dx_colpart);
 
 /* ---- fused classifier head: last Linear + softmax cross-entropy --------- */
 /* One workgroup computes logits = H[B,in] . W[C,in]^T + b (nn.rs:54-60), the

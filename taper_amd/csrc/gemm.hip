@@ -24,10 +24,15 @@ struct Epilogue {
     int relu;
     AdamDev adam;       // adam.p != nullptr: C is a complete gradient and the Adam update of the
                         // parameter at the same index runs right here (th_linear_bwd_adam)
+    // sgemm_tile, unsplit launches only (th_linear_bwd_adam_ex2): the backward of the fused Linear + ReLU IN FRONT of a layer, folded into that
+    // layer's dX product -- C <- C * [mask > 0] (mask: the layer's input, [m][n] like C; ops.rs:358-369) and colpart [tiles_m][n] (nullable):
+    // column sums of the stored tile rows, which th_colsum over the tile rows turns into the bias gradient of the layer in front (tensor.rs:686-691)
+    const float *mask;
+    float *colpart;
 };
 
 static inline Epilogue make_ep(float alpha, float beta, const float *bias = nullptr, int relu = 0) {
-    return Epilogue{alpha, beta, bias, relu, AdamDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f}};
+    return Epilogue{alpha, beta, bias, relu, AdamDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f}, nullptr, nullptr};
 }
 
 __device__ __forceinline__ float epilogue_apply(float acc, float c_old, const Epilogue &ep, int col) {
@@ -534,7 +539,7 @@ __device__ __forceinline__ void dma_tile(const float *__restrict__ P, long ld_fl
 __device__ long long g_gemm_prof[4];   // workgroup 0: wall clock (100 MHz) and shader clock at entry and exit -- the clock the product ran at
 #endif
 
-template <int TS, bool A_KC, bool B_KC, bool GUARD>
+template <int TS, bool A_KC, bool B_KC, bool GUARD, bool DXEP = false>   // DXEP: the epilogue with Epilogue::mask / colpart (its own instances: the plain products keep their registers)
 __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A, const float *__restrict__ B,
                                                      float *__restrict__ C, int m, int n, int k,
                                                      long a_rs, long a_cs, long b_rs, long b_cs,
@@ -676,11 +681,23 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
     if (bid == 0 && blockIdx.y == 0 && t == 0) { g_gemm_prof[2] = wall_clock64(); g_gemm_prof[3] = clock64(); }
 #endif
     // epilogue.  C/D map of 32x32x2: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
+    const bool masked = DXEP && ep.mask != nullptr && !partial;
+    float csum[NS];                             // this lane's share of the column sums of what it stores (columns wn + 32 j + li)
+#pragma unroll
+    for (int j = 0; j < NS; ++j) csum[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int col = col0 + wn + 32 * j + li;
+            float mk[16];
+            if (masked) {                       // the mask's 16 values of this sub-tile are requested together
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                    mk[e] = (!GUARD || (row < m && col < n)) ? ep.mask[(long)row * n + col] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
@@ -691,10 +708,29 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
                         continue;
                     }
                     const float c_old = ep.beta != 0.0f ? C[idx] : 0.0f;
-                    C[idx] = epilogue_apply(acc[i][j][e], c_old, ep, col);
+                    float v = epilogue_apply(acc[i][j][e], c_old, ep, col);
+                    if (masked) v = mk[e] > 0.f ? v : 0.f;
+                    C[idx] = v;
+                    csum[j] += v;
                 }
             }
         }
+    if (DXEP && ep.colpart && !partial) {
+        // rows in a fixed order: a lane's 16 NS values above, then the two lane halves, then the two waves of a column half through LDS
+        // (the staging buffers are dead: every wave is behind the loop's last barrier)
+        float *cs = smem;                       // [2 row halves][TS columns]
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            float v = csum[j];
+            v += __shfl_xor(v, 32, 64);
+            if (lk == 0) cs[(wave >> 1) * TS + wn + 32 * j + li] = v;
+        }
+        __syncthreads();
+        if (t < TS) {
+            const int col = col0 + t;
+            if (!GUARD || col < n) ep.colpart[(long)tm * n + col] = cs[t] + cs[TS + t];
+        }
+    }
 #endif
 }
 
@@ -793,7 +829,20 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
     kep.adam.p = nullptr;
     // tile order: groups of 8 tile rows (TAPER_GEMM_RASTER = n: groups of n; 0: r02's whole columns)
     static const int raster = [] { const char *e = getenv("TAPER_GEMM_RASTER"); return e ? atoi(e) : 8; }();
-    if (exact) {
+    if (ep.mask || ep.colpart) {     // the dX product with the backward of the layer in front in its epilogue (th_linear_bwd_adam_ex2: unsplit by its predicate)
+        if (kz != 1) { th::set_error("sgemm_tile: the masked epilogue needs an unsplit product"); return 2; }
+        if (exact) {
+            auto kern = sgemm_tile<TS, A_KC, B_KC, false, true>;
+            TH_SET_MAX_LDS(ctx, kern, lds);
+            hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, tiles_m, tiles_n, kep,
+                               kslice, (float *)nullptr, 1, raster);
+        } else {
+            auto kern = sgemm_tile<TS, A_KC, B_KC, true, true>;
+            TH_SET_MAX_LDS(ctx, kern, lds);
+            hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, tiles_m, tiles_n, kep,
+                               kslice, (float *)nullptr, vec ? 1 : 0, raster);
+        }
+    } else if (exact) {
         auto kern = sgemm_tile<TS, A_KC, B_KC, false>;
         static bool attr_set = false;
         if (!attr_set) {
@@ -1021,6 +1070,70 @@ int th_linear_fwd_ex(th_ctx *ctx, const float *d_x, const float *d_w, const floa
     return th_linear_fwd(ctx, d_x, d_w, d_b, d_y, batch, in_features, out_features, relu);
 }
 
+}  // extern "C" (reopened below)
+
+namespace th {
+
+// dX = dZ . W for a THIN layer (out_features <= 16: a classifier on a wide input -- BASELINE configs[4]'s Linear(4096, 10) at batch 4096):
+// 2 B in out flop for 4 B in bytes written, i.e. a streaming kernel, not a product (ops.rs:254-265).  A workgroup owns 32 rows x 1024 columns:
+// a thread keeps W[o][its 4 columns] in registers (<= 16 float4), dZ's 32 rows sit in LDS, and each row is one float4 store (+ one float4
+// load of the input where the layer in front is a fused Linear + ReLU: dX * [x > 0], ops.rs:358-369, and the column sums of the masked rows,
+// colpart [blockIdx.y][in]: tensor.rs:686-691 for that layer's bias).  r04 ran this product on the 16 x 16 tiles of linear_bwd_small:
+// 119 us for 67 MB (0.07 of HBM).
+constexpr int THIN_ROWS = 32;
+__global__ __launch_bounds__(256) void linear_dx_thin_kernel(const float *__restrict__ dz, const float *__restrict__ w, const float *__restrict__ xmask,
+                                                             float *__restrict__ dx, float *__restrict__ colpart, int batch, int in_f, int out_f,
+                                                             int accumulate) {
+    __shared__ float dzs[THIN_ROWS][16];
+    const int t = threadIdx.x, r0 = blockIdx.y * THIN_ROWS, col = (blockIdx.x * 256 + t) * 4;
+    for (int i = t; i < THIN_ROWS * 16; i += 256) {
+        const int r = i >> 4, o = i & 15;
+        dzs[r][o] = (r0 + r < batch && o < out_f) ? dz[(long)(r0 + r) * out_f + o] : 0.f;
+    }
+    float4 wv[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) wv[o] = (o < out_f && col < in_f) ? *reinterpret_cast<const float4 *>(w + (long)o * in_f + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (col >= in_f) return;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int r = 0; r < THIN_ROWS; ++r) {
+        if (r0 + r >= batch) break;
+        const long idx = (long)(r0 + r) * in_f + col;
+        float4 v = accumulate ? *reinterpret_cast<const float4 *>(dx + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {                 // k ascending, like the product it replaces
+            const float d = dzs[r][o];
+            v.x = fmaf(d, wv[o].x, v.x); v.y = fmaf(d, wv[o].y, v.y); v.z = fmaf(d, wv[o].z, v.z); v.w = fmaf(d, wv[o].w, v.w);
+        }
+        if (xmask) {
+            const float4 m = *reinterpret_cast<const float4 *>(xmask + idx);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(dx + idx) = v;
+        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+    }
+    if (colpart) *reinterpret_cast<float4 *>(colpart + (long)blockIdx.y * in_f + col) = cs;
+}
+
+// rows of the column-partial matrix th_linear_bwd_adam_ex2 writes for this shape (0: the dX epilogue is not available for it)
+static int dx_epilogue_rows(int batch, int in_f, int out_f) {
+    if (batch <= 0 || in_f <= 0 || out_f <= 0) return 0;
+    if (out_f <= 16 && in_f % 4 == 0 && (long)batch * in_f >= (1L << 20)) return ceil_div(batch, THIN_ROWS);          // the thin kernel
+    const bool big = gemm_is_big(batch, in_f, out_f);
+    const long wg128 = (long)ceil_div(batch, BM) * ceil_div(in_f, BN) * tile128_kz(batch, in_f, out_f);
+    static const long big_min_wg = getenv("TAPER_GEMM_BIG_WG") ? atol(getenv("TAPER_GEMM_BIG_WG")) : 460;
+    const bool mid = gemm_is_mid(batch, in_f, out_f) && (!big || wg128 < big_min_wg);
+    if (big && !mid && tile128_kz(batch, in_f, out_f) == 1) return ceil_div(batch, BM);                                // sgemm_tile<128>, unsplit
+    return 0;
+}
+
+}  // namespace th
+
+extern "C" {
+
+int th_linear_bwd_dx_epilogue_rows(int batch, int in_features, int out_features) { return th::dx_epilogue_rows(batch, in_features, out_features); }
+
 int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
                   float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask) {
     return th_linear_bwd_adam(ctx, d_x, d_w, d_dy, d_relu_y, d_dx, d_dw, d_db, batch, in_features, out_features, accumulate_mask,
@@ -1037,7 +1150,20 @@ int th_linear_bwd_adam(th_ctx *ctx, const float *d_x, const float *d_w, const fl
 int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
                           float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask,
                           const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra) {
+    return th_linear_bwd_adam_ex2(ctx, d_x, d_w, d_dy, d_relu_y, d_dx, d_dw, d_db, batch, in_features, out_features, accumulate_mask, w_fuse,
+                                  b_fuse, extra, n_extra, 0, nullptr);
+}
+
+int th_linear_bwd_adam_ex2(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
+                           float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask,
+                           const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra, int mask_dx,
+                           float *d_dx_colpart) {
     TH_REQUIRE(ctx && d_dy, "th_linear_bwd: null argument");
+    const int ep_rows = (mask_dx || d_dx_colpart) ? th::dx_epilogue_rows(batch, in_features, out_features) : 0;
+    TH_REQUIRE(!(mask_dx || d_dx_colpart) || (d_dx && d_x && ep_rows > 0 && !(accumulate_mask & 1)),
+               "th_linear_bwd_adam_ex2: the dX epilogue (mask / column partials) needs d_dx written (not accumulated), d_x, and a shape "
+               "th_linear_bwd_dx_epilogue_rows accepts (got %d x %d x %d)", batch, in_features, out_features);
+    const bool thin_dx = ep_rows > 0 && out_features <= 16;
     TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_linear_bwd_adam_ex: bad extra slices");
     for (int i = 0; i < n_extra; ++i)
         TH_REQUIRE(extra[i].f.d_p != d_w || !d_dx, "th_linear_bwd_adam_ex: a carried slice must not alias the weight this launch reads");
@@ -1047,6 +1173,22 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
     TH_REQUIRE(!d_dx || d_w, "th_linear_bwd: d_w required for d_dx");
     TH_REQUIRE(!d_dw || d_x, "th_linear_bwd: d_x required for d_dw");
     if (batch == 0 || out_features == 0 || in_features == 0) return th_adam_slices(ctx, extra, n_extra);
+    if (thin_dx) {
+        // the thin layer's dX (+ the ReLU mask and column partials of the layer in front) as a streaming launch; its dW / db below
+        const float *dzt = d_dy;
+        void *tmpz = nullptr;
+        if (d_relu_y) {
+            const size_t nz = (size_t)batch * out_features;
+            if (th_malloc(ctx, nz * sizeof(float), &tmpz)) return 1;
+            if (int rc = th_relu_bwd(ctx, d_relu_y, d_dy, (float *)tmpz, nz, 0)) return rc;
+            dzt = (const float *)tmpz;
+        }
+        hipLaunchKernelGGL(th::linear_dx_thin_kernel, dim3(ceil_div(in_features, 1024), ceil_div(batch, th::THIN_ROWS)), dim3(256), 0, ctx->stream, dzt,
+                           d_w, mask_dx ? d_x : nullptr, d_dx, d_dx_colpart, batch, in_features, out_features, 0);
+        TH_LAUNCH_CHECK();
+        if (tmpz && th_free(ctx, tmpz)) return 1;
+        d_dx = nullptr;
+    }
     const bool dw_big = d_dw && gemm_is_big(out_features, in_features, batch);
     const bool dx_big = d_dx && gemm_is_big(batch, in_features, out_features);
     // latency-bound shapes (the MNIST MLP / classifier heads): the whole layer backward is ONE launch
@@ -1119,6 +1261,8 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
     }
     if (d_dx) {  // dX[B,in] (+)= dZ[B,out] . W[out,in]      (ops.rs:254-265 through the W^T node)
         Epilogue ep = make_ep(1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f);
+        ep.mask = mask_dx ? d_x : nullptr;      // (ep_rows > 0: this product takes sgemm_tile<128> unsplit)
+        ep.colpart = d_dx_colpart;
         if (int rc = gemm_dispatch(ctx, 0, 0, batch, in_features, out_features, dz, d_w, d_dx, ep)) return rc;
     }
     if (d_dw) {  // dW[out,in] (+)= dZ^T[out,B] . X[B,in]     (ops.rs:280-291 + tensor.rs:574-587)

@@ -79,6 +79,8 @@ struct GradSlot {
     // instead of scattering, and the conv's backward sums the bias gradient straight from them
     bool relu_output = false;     // the tensor is the output of a fused Linear+ReLU node
     bool premasked = false;       // its gradient already carries that ReLU's mask (th_linear_xent_head_masked; th_maxpool2d_relu_bwd)
+    std::shared_ptr<Buffer> dz_colpart;   // premasked output of a fused Linear + ReLU: [dz_colpart_rows][features] column sums of that gradient by row block,
+    int dz_colpart_rows = 0;              // left by the consumer's dX product (th_linear_bwd_adam_ex2): th_colsum over the rows is this layer's bias gradient
     std::shared_ptr<Buffer> plane_sums;   // full backward, premasked conv output: [n][c] sums of the planes of that gradient (the bias gradient's rows)
     bool wants_pooled = false;
     std::shared_ptr<Buffer> pooled_dy, pooled_y;

@@ -253,6 +253,7 @@ float *Tensor::grad_for_write(bool *was_none) const {
     grad_->known_zero = false;
     grad_->premasked = false;   // whoever writes next does not know the mask: the producer's node applies it (to 0/1-masked terms: idempotent)
     grad_->plane_sums.reset();
+    grad_->dz_colpart.reset();
     return grad_->buf->d;
 }
 
@@ -512,13 +513,33 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
                 else if (fa && dx) defer_w = true;   // the dX workgroups read W: the next launch updates it
                 else if (fa && fa->fuse_for(wt, &wf)) pw = &wf;
             }
+            // the consumer of this layer's output left the column sums of the (masked) gradient by row block beside it: the bias gradient
+            // is their sum (tensor.rs:686-691), no pass over [batch, out] for it
+            const std::shared_ptr<Buffer> colpart_in = (relu_y == nullptr && relu) ? r.grad_->dz_colpart : nullptr;
+            const int colpart_in_rows = r.grad_->dz_colpart_rows;
+            bool db_from_colpart = false, db_none = true;
             if (b.defined() && b.get_requires_grad()) {
                 db = b.grad_for_write(&none);
+                db_none = none;
                 if (!none) mask |= 4;
                 else if (fa && fa->fuse_for(b, &bf)) pb = &bf;
+                db_from_colpart = colpart_in != nullptr && pb == nullptr;
             }
-            TH(th_linear_bwd_adam_ex(c, x.dptr(), wt.dptr(), dy, relu_y, dx, dw, db, batch, in_f, out_f, mask, pw, pb, carried,
-                                     n_carried));
+            // ... and this layer does the same for the fused Linear + ReLU in front of it, in its dX product's epilogue: dX * [x > 0]
+            // (ops.rs:358-369) and the row blocks' column sums of that
+            const int ep_rows = (dx && !(mask & 1) && x.grad_->relu_output) ? th_linear_bwd_dx_epilogue_rows(batch, in_f, out_f) : 0;
+            std::shared_ptr<Buffer> colpart_out = ep_rows > 0 ? Buffer::alloc((size_t)ep_rows * in_f) : nullptr;
+            TH(th_linear_bwd_adam_ex2(c, x.dptr(), wt.dptr(), dy, relu_y, dx, dw, db_from_colpart ? nullptr : db, batch, in_f, out_f, mask, pw, pb,
+                                      carried, n_carried, ep_rows > 0 ? 1 : 0, colpart_out ? colpart_out->d : nullptr));
+            if (db_from_colpart) {
+                if (db_none) TH(th_colsum(c, colpart_in->d, db, colpart_in_rows, out_f));
+                else TH(th_colsum_accum(c, colpart_in->d, db, colpart_in_rows, out_f));
+            }
+            if (ep_rows > 0) {
+                x.grad_->premasked = true;
+                x.grad_->dz_colpart = colpart_out;
+                x.grad_->dz_colpart_rows = ep_rows;
+            }
             if (defer_w) fa->defer_for(wt);
         });
     }

@@ -153,6 +153,45 @@ def test_linear_fwd_bwd(ctx, O, batch, inf, outf, relu):
     O.Tape.reset()
 
 
+@pytest.mark.parametrize("batch,inf,outf", [(2816, 2816, 256), (2800, 2900, 300), (512, 2048, 10), (700, 2048, 16), (4096, 4096, 10)])
+def test_linear_bwd_dx_epilogue(ctx, batch, inf, outf):
+    """th_linear_bwd_adam_ex2: the backward of the fused Linear + ReLU in front (ops.rs:358-369; tensor.rs:686-691) folded into this layer's
+    dX product -- d_dx * [d_x > 0] bit-identical to the plain call's d_dx masked afterwards, the row blocks' column sums of it adding up to
+    the column sums of that, dW / db untouched -- on the unsplit 128-tiles (whole and ragged) and on the thin layer's streaming kernel"""
+    from taper_amd._lib import hip as lib
+    rows = lib.th_linear_bwd_dx_epilogue_rows(batch, inf, outf)
+    assert rows > 0
+    assert lib.th_linear_bwd_dx_epilogue_rows(64, 784, 128) == 0            # the latency-bound shapes keep the one-launch backward
+    rng = np.random.default_rng(batch + inf + outf)
+    x = np.maximum(rng.standard_normal((batch, inf)), 0).astype(np.float32)  # a post-ReLU input: about half of it zeros
+    w = rng.uniform(-0.1, 0.1, (outf, inf)).astype(np.float32)
+    dy = rng.uniform(-1, 1, (batch, outf)).astype(np.float32)
+    dx_, dw_, dyd = ctx.upload(x), ctx.upload(w), ctx.upload(dy)
+    gx0, gw0, gb0 = ctx.empty(batch * inf), ctx.empty(outf * inf), ctx.empty(outf)
+    ctx.call("th_linear_bwd_adam_ex", dx_, dw_, dyd, None, gx0, gw0, gb0, batch, inf, outf, 0, None, None, None, 0)
+    gx1, gw1, gb1, part = ctx.empty(batch * inf), ctx.empty(outf * inf), ctx.empty(outf), ctx.empty(rows * inf)
+    ctx.call("th_linear_bwd_adam_ex2", dx_, dw_, dyd, None, gx1, gw1, gb1, batch, inf, outf, 0, None, None, None, 0, 1, part)
+    plain = ctx.download(gx0, (batch, inf))
+    want = np.where(x > 0, plain, np.float32(0))
+    if outf > 16:
+        np.testing.assert_array_equal(ctx.download(gx1, (batch, inf)), want)    # the same product, masked in its epilogue
+    else:                                                                       # (the thin kernel adds k in order with fmaf: another rounding than the tiles')
+        ref = np.where(x > 0, dy.astype(np.float64) @ w.astype(np.float64), 0.0)
+        np.testing.assert_allclose(ctx.download(gx1, (batch, inf)), ref, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(plain, dy.astype(np.float64) @ w.astype(np.float64), rtol=RTOL, atol=1e-6)
+    np.testing.assert_array_equal(ctx.download(gw1, (outf, inf)), ctx.download(gw0, (outf, inf)))
+    np.testing.assert_array_equal(ctx.download(gb1, outf), ctx.download(gb0, outf))
+    cs = ctx.empty(inf)
+    ctx.call("th_colsum", part, cs, rows, inf)
+    got_masked = ctx.download(gx1, (batch, inf)).astype(np.float64)
+    np.testing.assert_allclose(ctx.download(cs, inf), got_masked.sum(axis=0), rtol=RTOL, atol=1e-5 * float(np.abs(got_masked.sum(axis=0)).max()))
+    # without the mask: column partials of the plain product
+    ctx.call("th_linear_bwd_adam_ex2", dx_, dw_, dyd, None, gx1, None, None, batch, inf, outf, 0, None, None, None, 0, 0, part)
+    ctx.call("th_colsum", part, cs, rows, inf)
+    p64 = ctx.download(gx1, (batch, inf)).astype(np.float64)
+    np.testing.assert_allclose(ctx.download(cs, inf), p64.sum(axis=0), rtol=RTOL, atol=1e-5 * float(np.abs(p64.sum(axis=0)).max()))
+
+
 # ------------------------------------------------------------------ element-wise
 @pytest.mark.parametrize("n", [1, 3, 4, 1000, 100_003, 1 << 20])
 def test_elementwise(ctx, n):
