@@ -380,6 +380,14 @@ int th_sum_all(th_ctx *ctx, const float *d_x, float *d_out1, size_t n, float div
  * like the reference): tensor.rs:1021-1071, 1086-1088 */
 int th_rowmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols);
 int th_colmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols);
+/* sum(dim) / max(dim) over ANY dimension of a tensor of 1..4 dimensions (shape: host array), restating the reference's per-element index
+ * arithmetic -- tensor.rs:917-937 (sum: [outer, d, inner] -> [outer, inner], a row's terms in input order: bit-exact), 960-994 (its backward:
+ * d_gin[i] += d_gout[the reference's index], quirk included: a dimension whose position is not below the output's element count is skipped),
+ * 1042-1066 (max: values + indices along dim as f32; strict >, the first of equals; NaN / -inf never win; quirk Q14 included: on rank > 2
+ * the output index only steps for dimensions in front of dim, so several positions share an output element).  Off the training step. */
+int th_sum_dim(th_ctx *ctx, const float *d_x, float *d_y, const int64_t *shape, int ndim, int dim);
+int th_sum_dim_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, const int64_t *shape, int ndim, int dim, int keepdim);
+int th_max_dim(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, const int64_t *shape, int ndim, int dim);
 /* global max over n elements, tensor.rs:1072-1083: `max_by(partial_cmp)` keeps the LAST of equal maxima; the index is stored as f32
  * (`max_idx as f32`); n == 0 gives (0.0, 0).  d_nan_flag[0] (nullable) = 1 when a NaN is present: the reference's
  * `partial_cmp(..).unwrap()` panics there, the host mirror raises. */

@@ -9,6 +9,8 @@
 
 #include "taper.h"
 
+#include <array>
+
 namespace taper {
 
 void th_check(int rc, const char *what) {
@@ -763,8 +765,6 @@ Tensor Tensor::sum(int dim, bool keepdim) const {  // tensor.rs:890-1018
     for (int i = 0; i < dim; ++i) outer *= shape_[i];
     for (size_t i = dim + 1; i < shape_.size(); ++i) inner *= shape_[i];
     const size_t d = shape_[dim];
-    // the reference's index math is only exercised for 2-D inputs (Q14)
-    TAPER_ASSERT(inner == 1 || outer == 1, "sum(dim): only the first or last dimension can be reduced");
     Shape os;
     for (size_t i = 0; i < shape_.size(); ++i) {
         if ((int)i == dim) { if (keepdim) os.push_back(1); }
@@ -772,16 +772,27 @@ Tensor Tensor::sum(int dim, bool keepdim) const {  // tensor.rs:890-1018
     }
     if (os.empty()) os.push_back(1);
     Tensor out = empty(os);
+    // the hot path (loss.rs:108-121) reduces 2-D tensors over their last dimension: wave-shuffle kernels; a first / last dimension of any
+    // shape takes the same kernels on the flattened view; a MIDDLE dimension -- which the reference accepts too (tensor.rs:917-937) -- and
+    // every output of fewer elements than the tensor has dimensions (where the reference's backward skips a coordinate, tensor.rs:975)
+    // take the literal kernels
+    const bool literal = (inner != 1 && outer != 1) || out.len() < shape_.size();
+    int64_t shp[4] = {1, 1, 1, 1};
+    for (size_t i = 0; i < shape_.size(); ++i) shp[i] = (int64_t)shape_[i];
+    const int nd = (int)shape_.size();
     const bool by_row = inner == 1;  // [outer, d] -> [outer]
     const int rows = by_row ? (int)outer : (int)d, cols = by_row ? (int)d : (int)inner;
-    if (by_row) TH(th_rowsum(c, dptr(), out.dptr(), rows, cols));
+    if (literal) TH(th_sum_dim(c, dptr(), out.dptr(), shp, nd, dim));
+    else if (by_row) TH(th_rowsum(c, dptr(), out.dptr(), rows, cols));
     else TH(th_colsum(c, dptr(), out.dptr(), rows, cols));
     if (requires_grad_) {
         out.requires_grad_ = true;
         Tensor in = *this, r = out;
-        Tape::push(out, true, [in, r, by_row, rows, cols]() {
+        const std::array<int64_t, 4> sh{shp[0], shp[1], shp[2], shp[3]};
+        Tape::push(out, true, [in, r, by_row, rows, cols, literal, sh, nd, dim, keepdim]() {
             if (!r.has_grad()) return;
-            if (by_row) TH(th_rowsum_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), rows, cols));
+            if (literal) TH(th_sum_dim_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), sh.data(), nd, dim, keepdim ? 1 : 0));
+            else if (by_row) TH(th_rowsum_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), rows, cols));
             else TH(th_colsum_bwd(Device::ctx(), r.grad_dptr(), in.grad_accum_ptr(), rows, cols));
         });
     }
@@ -801,13 +812,19 @@ std::pair<Tensor, Tensor> Tensor::max(int dim) const {  // tensor.rs:1021-1083 (
         return {v, i};
     }
     TAPER_ASSERT((size_t)dim < shape_.size(), "Dimension " + std::to_string(dim) + " out of bounds");
-    TAPER_ASSERT(shape_.size() == 2, "max(dim): 2-D tensors only (Q14)");
-    const int rows = (int)shape_[0], cols = (int)shape_[1];
     Shape os = shape_;
     os[dim] = 1;
     Tensor v = empty(os), i = empty(os);
-    if (dim == 1) TH(th_rowmax(c, dptr(), v.dptr(), i.dptr(), rows, cols));
-    else TH(th_colmax(c, dptr(), v.dptr(), i.dptr(), rows, cols));
+    if (shape_.size() == 2) {   // the hot path's shape (loss.rs:108, 271-290)
+        const int rows = (int)shape_[0], cols = (int)shape_[1];
+        if (dim == 1) TH(th_rowmax(c, dptr(), v.dptr(), i.dptr(), rows, cols));
+        else TH(th_colmax(c, dptr(), v.dptr(), i.dptr(), rows, cols));
+        return {v, i};
+    }
+    // any other rank: the reference's index arithmetic as it stands (tensor.rs:1042-1066, quirk Q14 included)
+    int64_t shp[4] = {1, 1, 1, 1};
+    for (size_t k = 0; k < shape_.size(); ++k) shp[k] = (int64_t)shape_[k];
+    TH(th_max_dim(c, dptr(), v.dptr(), i.dptr(), shp, (int)shape_.size(), dim));
     return {v, i};
 }
 

@@ -598,6 +598,150 @@ int th_sum_all(th_ctx *ctx, const float *d_x, float *d_out1, size_t n, float div
     return th_free(ctx, part);
 }
 
+}  // extern "C" (reopened below)
+
+namespace th {
+
+// ---- sum(dim) / max(dim) for ANY rank (<= 4), restating the reference's per-element index arithmetic (tensor.rs:917-937, 960-994, 1042-1066):
+// off the training step (the loss reduces 2-D tensors over their first or last dimension: the wave-shuffle kernels above), here so that the
+// host mirror accepts what the reference accepts -- and gives what it gives, quirk Q14 included: max(dim)'s output index only steps its
+// multiplier for dimensions IN FRONT of dim, so on rank > 2 several (row, column) pairs share an output element; sum's backward skips a
+// dimension when its position is not below the output's ELEMENT count.
+struct DimShape {
+    int64_t shape[4];
+    int ndim, dim, keepdim;
+    int64_t n, out_n;
+};
+
+// forward: one thread per output element, its terms added in the order the reference meets them (ascending input index): bit-exact
+__global__ __launch_bounds__(256) void sum_dim_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t outer, int64_t d, int64_t inner) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= outer * inner) return;
+    const int64_t a = o / inner, c = o - a * inner;
+    const float *p = x + a * d * inner + c;
+    float s = 0.f;
+    for (int64_t k = 0; k < d; ++k) s += p[k * inner];
+    y[o] = s;
+}
+
+// backward: gin[i] += gout[min(out_idx(i), len - 1)], out_idx by tensor.rs:966-990 literally
+__global__ __launch_bounds__(256) void sum_dim_bwd_kernel(const float *__restrict__ gout, float *__restrict__ gin, DimShape q) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= q.n) return;
+    int64_t idx = i, out_idx = 0, mult = 1;
+    for (int j = q.ndim - 1; j >= 0; --j) {
+        const int64_t coord = idx % q.shape[j];
+        idx /= q.shape[j];
+        if (j != q.dim) {
+            const int out_j = (j > q.dim && !q.keepdim) ? j - 1 : j;
+            if ((int64_t)out_j < q.out_n) {                // (the reference compares with gout.len(): the element count)
+                out_idx += coord * mult;
+                mult *= q.shape[j];                         // (every branch of tensor.rs:976-988 with j != d is in_shape[j])
+            }
+        }
+    }
+    gin[i] += gout[out_idx < q.out_n - 1 ? out_idx : q.out_n - 1];
+}
+
+// max(dim): every input element offers {value, its index} to the output element the reference's arithmetic names; the winner of an output
+// element is the largest value, the FIRST of equals (strict > in ascending input order), NaN and -inf never win (nothing is > them first):
+// one 64-bit atomicMax on {order-preserving bits of the value, ~index} is exactly that, whatever order the threads run in.
+__device__ __forceinline__ unsigned long long max_key(float v, int64_t i) {
+    const unsigned b = __float_as_uint(v);
+    const unsigned ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+}
+__device__ __forceinline__ int64_t max_out_index(int64_t i, const DimShape &q, int64_t *dim_idx) {
+    int64_t idx = i, out_idx = 0, mult = 1;
+    for (int j = q.ndim - 1; j >= 0; --j) {
+        const int64_t coord = idx % q.shape[j];
+        idx /= q.shape[j];
+        if (j == q.dim) *dim_idx = coord;
+        else {
+            out_idx += coord * mult;
+            mult *= (j < q.dim) ? q.shape[j] : 1;           // tensor.rs:1056 (Q14)
+        }
+    }
+    return out_idx < q.out_n - 1 ? out_idx : q.out_n - 1;
+}
+__global__ __launch_bounds__(256) void max_dim_offer_kernel(const float *__restrict__ x, unsigned long long *__restrict__ keys, DimShape q) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= q.n) return;
+    const float v = x[i];
+    if (!(v > -INFINITY)) return;                           // NaN, -inf: `data[i] > max_values[..]` is false against the initial -inf
+    int64_t dim_idx = 0;
+    const int64_t o = max_out_index(i, q, &dim_idx);
+    atomicMax(&keys[o], max_key(v, i));
+}
+__global__ __launch_bounds__(256) void max_dim_decode_kernel(const float *__restrict__ x, const unsigned long long *__restrict__ keys, float *__restrict__ vals,
+                                                             float *__restrict__ idxs, DimShape q) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= q.out_n) return;
+    const unsigned long long k = keys[o];
+    if (k == 0ull) {                                        // nothing won: the initial {-inf, 0.0}
+        vals[o] = -INFINITY;
+        if (idxs) idxs[o] = 0.f;
+        return;
+    }
+    const int64_t i = (int64_t)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+    int64_t dim_idx = 0;
+    (void)max_out_index(i, q, &dim_idx);
+    vals[o] = x[i];
+    if (idxs) idxs[o] = (float)dim_idx;
+}
+
+static int dim_shape(const int64_t *shape, int ndim, int dim, int keepdim, DimShape *q, const char *who) {
+    TH_REQUIRE(shape && ndim >= 1 && ndim <= 4 && dim >= 0 && dim < ndim, "%s: 1..4 dimensions, 0 <= dim < ndim", who);
+    q->ndim = ndim; q->dim = dim; q->keepdim = keepdim; q->n = 1; q->out_n = 1;
+    for (int j = 0; j < ndim; ++j) {
+        TH_REQUIRE(shape[j] >= 1, "%s: empty dimension", who);
+        q->shape[j] = shape[j];
+        q->n *= shape[j];
+        if (j != dim) q->out_n *= shape[j];
+    }
+    TH_REQUIRE(q->n < (1LL << 32), "%s: fewer than 2^32 elements", who);
+    return 0;
+}
+
+}  // namespace th
+
+extern "C" {
+
+int th_sum_dim(th_ctx *ctx, const float *d_x, float *d_y, const int64_t *shape, int ndim, int dim) {
+    TH_REQUIRE(ctx && d_x && d_y, "th_sum_dim: null argument");
+    th::DimShape q;
+    if (int rc = th::dim_shape(shape, ndim, dim, 0, &q, "th_sum_dim")) return rc;
+    int64_t outer = 1, inner = 1;
+    for (int j = 0; j < dim; ++j) outer *= shape[j];
+    for (int j = dim + 1; j < ndim; ++j) inner *= shape[j];
+    hipLaunchKernelGGL(th::sum_dim_kernel, dim3(th::ceil_div(outer * inner, 256)), dim3(256), 0, ctx->stream, d_x, d_y, outer, shape[dim], inner);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_sum_dim_bwd(th_ctx *ctx, const float *d_gout, float *d_gin, const int64_t *shape, int ndim, int dim, int keepdim) {
+    TH_REQUIRE(ctx && d_gout && d_gin, "th_sum_dim_bwd: null argument");
+    th::DimShape q;
+    if (int rc = th::dim_shape(shape, ndim, dim, keepdim, &q, "th_sum_dim_bwd")) return rc;
+    hipLaunchKernelGGL(th::sum_dim_bwd_kernel, dim3(th::ceil_div(q.n, 256)), dim3(256), 0, ctx->stream, d_gout, d_gin, q);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_max_dim(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, const int64_t *shape, int ndim, int dim) {
+    TH_REQUIRE(ctx && d_x && d_max, "th_max_dim: null argument");
+    th::DimShape q;
+    if (int rc = th::dim_shape(shape, ndim, dim, 1, &q, "th_max_dim")) return rc;
+    void *keys = nullptr;
+    if (th_malloc(ctx, (size_t)q.out_n * sizeof(unsigned long long), &keys)) return 1;
+    TH_HIP(hipMemsetAsync(keys, 0, (size_t)q.out_n * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(th::max_dim_offer_kernel, dim3(th::ceil_div(q.n, 256)), dim3(256), 0, ctx->stream, d_x, (unsigned long long *)keys, q);
+    hipLaunchKernelGGL(th::max_dim_decode_kernel, dim3(th::ceil_div(q.out_n, 256)), dim3(256), 0, ctx->stream, d_x, (const unsigned long long *)keys, d_max,
+                       d_argmax_f32, q);
+    TH_LAUNCH_CHECK();
+    return th_free(ctx, keys);
+}
+
 int th_rowmax(th_ctx *ctx, const float *d_x, float *d_max, float *d_argmax_f32, int rows, int cols) {
     TH_REQUIRE(ctx && d_x && rows >= 0 && cols >= 0, "th_rowmax: bad argument");
     if (rows == 0) return 0;
