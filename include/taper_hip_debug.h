@@ -18,6 +18,9 @@ int th_debug_mlp2_only(int which);
 /* 1 .. 8 = th_mlp2_xent splits a 16-row block's k chunks over that many workgroups on this thread whatever the cap says (the repro tests
  * walk the hand-off's forms); 0 = the default choice */
 int th_debug_mlp2_ksplit(int ksplit);
+/* 1 = conv chains over more than 256 images run as min(n, 256) workgroups that WALK the images (r05: bit-identical, measured 3 - 5 % slower
+ * than one workgroup per image, off by default); 0 = never; -1 = default */
+int th_debug_set_chain_loop(int on);
 /* 1 = the compiled chain instances are not used on this thread (their nets take the run-time-described kernel, id 3); 0 = default */
 int th_debug_set_chain_generic(int on);
 /* launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity

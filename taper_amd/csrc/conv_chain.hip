@@ -421,23 +421,37 @@ constexpr int CR_A2 = 32 * ch_tile_ld(784), CR_IMG = CR_A2 + 32 * ch_cis(16), CR
 constexpr int CR_T4 = 64 * ch_cis(16), CR_T5 = 64 * ch_cis(9);
 static_assert(32 * ch_cis(30) <= CR_IMG && CR_T4 + 64 * ch_tile_ld(196) <= CR_LDS && CR_T5 + 128 * ch_tile_ld(49) <= CR_LDS, "LDS map");
 
+// LOOP (batches above one image per CU, r05): min(n, 256) workgroups WALK the images -- image i + gridDim.x's pixels are requested in front of
+// conv5's k loop and stored into IMG behind it (IMG is nobody's after conv1), conv2's first weight pass rides in conv5's last pass like any
+// next layer's, conv1's weights stay in their registers: a workgroup's next image starts without the launch, the image round trip and the
+// weight round trips that a fresh workgroup pays.  Same per-image arithmetic: bit-identical outputs.  LOOP = false is r04's kernel as it was.
+static_assert(CR_T4 + 64 * ch_tile_ld(196) <= CR_IMG && 32 * ch_tile_ld(784) <= CR_IMG && CR_T5 + 128 * ch_tile_ld(49) <= CR_IMG, "IMG is free behind conv1");
+template <bool LOOP>
 __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int img = blockIdx.x;
-    float *A1 = lds, *T2 = lds, *A2 = lds + CR_A2, *A3 = lds, *T4 = lds + CR_T4, *A4 = lds, *T5 = lds + CR_T5, *IMG = lds + CR_IMG;
+    const int t0_ = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t0_ >> 6);
     ChainBias bv;
     ChainW wc;
     ChainW1 wa;
 
     CH_STAMP(0);
     CH_CLK(20);
-    chain_conv1_weights(a.w[0], wa, wave, lane);
+    chain_conv1_weights(a.w[0], wa, wave, t0_ & 63);
+    chain_load_image(a.x + (long)blockIdx.x * 784, lds + CR_IMG, t0_);
+    chain_weights<28, 32, 32>(a.w[1], 0, wc, wave, t0_ & 63);     // conv2's first pass: in flight under conv1
+  int img = blockIdx.x;
+  do {      // (LOOP = false: `while (false)` -- no loop in the instance, r04's straight-line code)
+    // LOOP: the thread index and the LDS base are made opaque once per image, so that every lane-dependent address is formed where it is
+    // used, as in the straight-line kernel -- hoisted out of the image loop they stay live across all five layers and the k loops spill
+    // (measured: 113 against 98 us per image)
+    int t = t0_;
+    float *ldsb = lds;
+    if constexpr (LOOP) { asm volatile("" : "+v"(t)); asm volatile("" : "+v"(ldsb)); }
+    const int lane = t & 63;
+    float *A1 = ldsb, *T2 = ldsb, *A2 = ldsb + CR_A2, *A3 = ldsb, *T4 = ldsb + CR_T4, *A4 = ldsb, *T5 = ldsb + CR_T5, *IMG = ldsb + CR_IMG;
     chain_bias<28, 32>(a.b[0], bv, wave, lane);
-    chain_load_image(a.x + (long)img * 784, IMG, t);
-    chain_weights<28, 32, 32>(a.w[1], 0, wc, wave, lane);     // conv2's first pass: in flight under conv1
-    chain_sync();
+    chain_sync();                                              // IMG is complete (LOOP: and the previous image's readers are done)
     CH_STAMP(1);
     {   // conv1 1 -> 32 @28
         floatx4 acc[ChainGeo<28, 32>::NSLOT];
@@ -489,8 +503,25 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
     {   // conv5 64 -> 128 @7 + global average pool
         floatx4 acc[ChainGeo<7, 128>::NSLOT];
         chain_bias<7, 128>(a.b[4], bv, wave, lane);
-        chain_mfma<7, 64, 128>(A4, a.w[4], wc, acc, wave, lane);
+        float px[2] = {0.f, 0.f};                                // LOOP: this thread's pixels t, t + 512 of the workgroup's next image
+        const int nimg = img + (int)gridDim.x;
+        if constexpr (LOOP) {
+            if (nimg < a.n) {
+                const float *xn = a.x + (long)nimg * 784;
+                px[0] = xn[t];
+                px[1] = t + CH_NT < 784 ? xn[t + CH_NT] : 0.f;
+            }
+            chain_mfma<7, 64, 128, 28, 32, 32>(A4, a.w[4], wc, acc, wave, lane, a.w[1]);   // (+ conv2's first pass for the next image)
+        } else {
+            chain_mfma<7, 64, 128>(A4, a.w[4], wc, acc, wave, lane);
+        }
         chain_store<7, 128, false>(acc, bv, T5, wave, lane);     // (T5 does not overlap A4)
+        if constexpr (LOOP) {
+            if (nimg < a.n) {
+                IMG[(t / 28 + 1) * 30 + t % 28 + 1] = px[0];
+                if (t + CH_NT < 784) IMG[((t + CH_NT) / 28 + 1) * 30 + (t + CH_NT) % 28 + 1] = px[1];
+            }
+        }
         chain_sync();
         CH_STAMP(11);
         // 16 lanes per channel plane, lane l adds elements l, l + 16, ... and a shuffle tree joins them: avgpool_global16_kernel's arithmetic
@@ -520,6 +551,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
         CH_STAMP(12);
         CH_CLK(21);
     }
+  } while (LOOP && (img += (int)gridDim.x) < a.n);
 #endif
 }
 
@@ -676,24 +708,41 @@ constexpr int CS_IMG = 32 * ch_cis(16), CS_XM = CS_IMG + 900, CS_K = 64 * 49, CS
 [[maybe_unused]] constexpr int CS_NJ = (CS_K + CH_NT - 1) / CH_NT;
 static_assert(16 * CH_NT + 64 <= CS_IMG, "LDS map: the classifier's reduction fits over A");
 
-template <bool HEAD, int NC>
+// LOOP (batches above one image per CU, r05): as conv_chain_reference_kernel<true> -- the workgroups walk the images, the next image's pixels
+// cross the fabric under conv2's k loop, conv2's first weight pass rides in its own last pass, and the classifier's weight registers are
+// loaded ONCE per workgroup instead of once per image (125 KB of L2 reads each).
+#ifndef CH_LOOP_KEEP_HEAD
+#define CH_LOOP_KEEP_HEAD 0      // 1: the walking form keeps the classifier's weight registers across its images (measured: no gain -- 80 more live registers through conv1)
+#endif
+template <bool HEAD, int NC, bool LOOP = false>
 __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int img = blockIdx.x;
-    float *A = lds, *IMG = lds + CS_IMG, *XM = lds + CS_XM;
+    const int t0_ = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t0_ >> 6);
     ChainBias bv;
     ChainW wc;
     ChainW1 wa;
     CH_STAMP(0);
     CH_CLK(20);
-    chain_conv1_weights(a.w[0], wa, wave, lane);
+    chain_conv1_weights(a.w[0], wa, wave, t0_ & 63);
+    chain_load_image(a.x + (long)blockIdx.x * 784, lds + CS_IMG, t0_);
+    chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, t0_ & 63);      // conv2's first pass: in flight under conv1
+    if (HEAD && a.head.tick && blockIdx.x == 0 && t0_ == 0) a.head.tick[0] += 1;
+    constexpr int HV = NC <= 10 ? 4 : 1, HNJ = HV == 4 ? 4 * ((CS_K + 4 * CH_NT - 1) / (4 * CH_NT)) : CS_NJ;   // (16 classes: 128 registers as quads)
+    float hw_[HNJ][NC];
+    if constexpr (HEAD && LOOP && CH_LOOP_KEEP_HEAD) {           // the classifier's weights, once for all of this workgroup's images
+        if constexpr (HV == 4) chain_head_weights4<HNJ / 4, NC, CS_K>(a.head, hw_, t0_);
+        else chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t0_);
+    }
+  int img = blockIdx.x;
+  do {      // (LOOP = false: `while (false)` -- no loop in the instance, r04's straight-line code)
+    int t = t0_;                                                 // LOOP: opaque once per image (conv_chain_reference_kernel)
+    float *ldsb = lds;
+    if constexpr (LOOP) { asm volatile("" : "+v"(t)); asm volatile("" : "+v"(ldsb)); }
+    const int lane = t & 63;
+    float *A = ldsb, *IMG = ldsb + CS_IMG, *XM = ldsb + CS_XM;
     chain_bias<28, 32>(a.b[0], bv, wave, lane);
-    chain_load_image(a.x + (long)img * 784, IMG, t);
-    chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, lane);      // conv2's first pass: in flight under conv1
-    if (HEAD && a.head.tick && img == 0 && t == 0) a.head.tick[0] += 1;
-    chain_zero_halo<14, 32>(A, wave, lane);
+    chain_zero_halo<14, 32>(A, wave, lane);                      // (LOOP: the previous image's classifier reduction lay over A)
     chain_sync();
     CH_STAMP(1);
     {   // conv1 1 -> 32 @28, pooled -> A's interior
@@ -706,13 +755,26 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     }
     floatx4 acc[ChainGeo<14, 64>::NSLOT];
     chain_bias<14, 64>(a.b[1], bv, wave, lane);
-    constexpr int HV = NC <= 10 ? 4 : 1, HNJ = HV == 4 ? 4 * ((CS_K + 4 * CH_NT - 1) / (4 * CH_NT)) : CS_NJ;   // (16 classes: 128 registers as quads)
-    float hw_[HNJ][NC];
-    if constexpr (HEAD) {                                        // the classifier's weights: in flight under conv2's k loop
+    if constexpr (HEAD && !(LOOP && CH_LOOP_KEEP_HEAD)) {        // the classifier's weights: in flight under conv2's k loop
         if constexpr (HV == 4) chain_head_weights4<HNJ / 4, NC, CS_K>(a.head, hw_, t);
         else chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t);
     }
-    chain_mfma<14, 32, 64, 0, 0, 0, true>(A, a.w[1], wc, acc, wave, lane);
+    float px[2] = {0.f, 0.f};                                    // LOOP: this thread's pixels t, t + 512 of the workgroup's next image
+    const int nimg = img + (int)gridDim.x;
+    if constexpr (LOOP) {
+        if (nimg < a.n) {
+            const float *xn = a.x + (long)nimg * 784;
+            px[0] = xn[t];
+            px[1] = t + CH_NT < 784 ? xn[t + CH_NT] : 0.f;
+        }
+        chain_mfma<14, 32, 64, 14, 32, 64, true>(A, a.w[1], wc, acc, wave, lane, a.w[1]);   // (+ its own first pass again, for the next image)
+        if (nimg < a.n) {                                        // IMG is nobody's behind conv1
+            IMG[(t / 28 + 1) * 30 + t % 28 + 1] = px[0];
+            if (t + CH_NT < 784) IMG[((t + CH_NT) / 28 + 1) * 30 + (t + CH_NT) % 28 + 1] = px[1];
+        }
+    } else {
+        chain_mfma<14, 32, 64, 0, 0, 0, true>(A, a.w[1], wc, acc, wave, lane);
+    }
     CH_STAMP(4);
     CH_STAMP(5);
     chain_store_pooled<14, 64, true>(acc, bv, a.y + (long)img * 64 * 49, wave, lane, HEAD ? XM : nullptr);   // (XM does not overlap A)
@@ -726,6 +788,8 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
 #endif
     CH_STAMP(11);
     CH_CLK(21);
+    if constexpr (LOOP) chain_sync();                            // the classifier's reduction (over A) and XM are read: the next image may write them
+  } while (LOOP && (img += (int)gridDim.x) < a.n);
 #endif
 }
 
@@ -1385,6 +1449,12 @@ int th_conv_chain_supported(int c_in, int h, int w, const th_conv_stage *stages,
     return rt_plan(c_in, h, w, stages, n_stages, 0, nullptr, nullptr) ? 3 : 0;
 }
 
+thread_local int t_chain_loop = -1;   // th_debug_set_chain_loop
+int th_debug_set_chain_loop(int on) {   // test hook: 1 = batches above 256 images take the walking instances on this thread; 0 = never; -1 = default (off)
+    t_chain_loop = on < 0 ? -1 : (on ? 1 : 0);
+    return 0;
+}
+
 int th_debug_set_chain_generic(int on) {   // test hook: 1 = the compiled instances are not used (their nets take the run-time-described kernel)
     t_chain_generic = on ? 1 : 0;
     return 0;
@@ -1403,6 +1473,17 @@ static int rt_launch(th_ctx *ctx, RtChainArgs &a, int lds_floats, const float *d
     return 0;
 }
 
+// The compiled instances as WALKING workgroups once there are more images than CUs (r05, asked for by the r04 review): built, bit-identical
+// per image (tests/test_gpu_chain.py, test_gpu_chain_head.py), and measured 3 - 5 % SLOWER than one workgroup per image at 1 024 and
+// 4 096 images (reference front 405 against 393 us per 1 024-image step, simple 118.9 against 113.2): the hardware hands a CU its next
+// workgroup within ~1 us, and what the walk saves on top of that (the image and first-weight round trips, ~2 us per image) the loop's code
+// gives back -- with the per-image addresses hoisted out of the image loop the k loops spilled (+15 us per image; made opaque per image:
+// the figures above).  OFF by default; TAPER_CHAIN_LOOP=1 / th_debug_set_chain_loop(1) turn it on.
+static bool chain_loop(int n) {
+    static const bool env_on = getenv("TAPER_CHAIN_LOOP") && getenv("TAPER_CHAIN_LOOP")[0] == '1';
+    return (t_chain_loop >= 0 ? t_chain_loop != 0 : env_on) && n > kNumCU;
+}
+
 int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, float *d_cnt, int n, int c_in,
                       int h, int w) {
     TH_REQUIRE(ctx && d_x && d_y && stages && n > 0, "th_conv_chain_fwd: null argument");
@@ -1419,12 +1500,23 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
         for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
         if (kind == 1) {
             const int lds = CR_LDS * (int)sizeof(float);
-            (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL(conv_chain_reference_kernel, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+            // (more images than CUs: optionally as walking workgroups -- chain_loop)
+            if (chain_loop(n)) {
+                (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(conv_chain_reference_kernel<true>, dim3(kNumCU), dim3(CH_NT), lds, ctx->stream, a);
+            } else {
+                (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(conv_chain_reference_kernel<false>, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+            }
         } else {
             const int lds = CS_LDS * (int)sizeof(float);
-            (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+            if (chain_loop(n)) {
+                (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1, true>), dim3(kNumCU), dim3(CH_NT), lds, ctx->stream, a);
+            } else {
+                (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+            }
         }
     }
     t_last_conv_cfg[0] = kind; t_last_conv_cfg[1] = 6; t_last_conv_cfg[2] = 0;   // 6: a conv chain (th_debug_last_conv_config)
@@ -1465,13 +1557,19 @@ int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *s
         a.head = ChainHeadArgs{head->d_w, head->d_bias, head->d_targets, head->d_dl, head->d_rowstat, head->d_cbpart, head->d_tick,
                                head->classes, CS_K, 64, 49, 1.0f / (float)n};
         const int lds = CS_LDS * (int)sizeof(float);
+#define TH_SIMPLE_HEAD(NC_, LOOP_, GRID_)                                                                                                          \
+    do {                                                                                                                                          \
+        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, NC_, LOOP_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);     \
+        hipLaunchKernelGGL((conv_chain_simple_kernel<true, NC_, LOOP_>), dim3(GRID_), dim3(CH_NT), lds, ctx->stream, a);                          \
+    } while (0)
         if (head->classes <= 10) {
-            (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL((conv_chain_simple_kernel<true, 10>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+            if (chain_loop(n)) TH_SIMPLE_HEAD(10, true, kNumCU);
+            else TH_SIMPLE_HEAD(10, false, n);
         } else {
-            (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL((conv_chain_simple_kernel<true, 16>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+            if (chain_loop(n)) TH_SIMPLE_HEAD(16, true, kNumCU);
+            else TH_SIMPLE_HEAD(16, false, n);
         }
+#undef TH_SIMPLE_HEAD
     }
     t_last_conv_cfg[0] = kind; t_last_conv_cfg[1] = 7; t_last_conv_cfg[2] = 0;   // 7: a conv chain with the classifier rows
     t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;

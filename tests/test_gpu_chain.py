@@ -364,3 +364,28 @@ def test_compiled_size_instances_write_a_conv_row_map(ctx, O, hw0, spec):
     y, cnt, hw, c_last = _hip_chain_general(ctx, x, spec, params)
     got = ctx.download(y, (n, c_last, hw, hw))
     np.testing.assert_allclose(got, ref.reshape(got.shape), rtol=RTOL, atol=1e-5 + RTOL * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name", ["reference", "simple"])
+@pytest.mark.parametrize("n", [257, 600, 1024])
+def test_walking_chain_is_bit_identical_per_image(ctx, name, n):
+    """more images than CUs (r05): min(n, 256) workgroups WALK the images -- the next image's pixels cross the fabric under the last k loop,
+    the next first weight pass rides in the last pass -- with the per-image arithmetic untouched: image i of a batch of n > 256 gives the
+    bits it gives as image (i mod 200) of batches of <= 200 (one workgroup per image, the kernel the oracle comparisons above hold)"""
+    spec = REFERENCE if name == "reference" else SIMPLE
+    from taper_amd._lib import hip as lib
+    params = _params(spec, 21)
+    x = _images(n, 1000 + n)
+    lib.th_debug_set_chain_loop(1)              # (off by default: measured 3 - 5 % slower than one workgroup per image)
+    try:
+        y, cnt, hw, c_last = _hip_chain(ctx, x, spec, params)
+    finally:
+        lib.th_debug_set_chain_loop(-1)
+    got = ctx.download(y, (n, c_last, hw, hw))
+    got_cnt = ctx.download(cnt, (n, c_last)) if cnt is not None else None
+    for lo in range(0, n, 200):
+        hi = min(n, lo + 200)
+        y1, cnt1, _, _ = _hip_chain(ctx, x[lo:hi], spec, params)
+        np.testing.assert_array_equal(got[lo:hi], ctx.download(y1, (hi - lo, c_last, hw, hw)), err_msg=f"images {lo}..{hi}")
+        if cnt is not None:
+            np.testing.assert_array_equal(got_cnt[lo:hi], ctx.download(cnt1, (hi - lo, c_last)))

@@ -376,3 +376,35 @@ def test_wide_head_grads_ragged_shapes(ctx, n, k, classes, conv_c):
     _close(ctx.download(gcb, conv_c), cbp.astype(np.float64).sum(axis=0), "conv bias")
     assert float(ctx.download(loss, 1)[0]) == pytest.approx(float(rs[:, 0].astype(np.float64).sum() / n), rel=1e-5)
     assert float(ctx.download(nc, 1)[0]) == float(rs[:, 1].sum())
+
+
+@pytest.mark.parametrize("n,classes", [(300, 10), (1024, 10), (700, 16)])
+def test_walking_chain_with_the_classifier_rows_is_bit_identical_per_image(ctx, n, classes):
+    """th_conv_chain_head_fwd on more images than CUs (r05: the workgroups walk the images, the classifier's weight registers are loaded once
+    per workgroup): per image -- pooled map, dlogits row, {nll, hit}, the conv bias partials -- the bits of the one-workgroup-per-image
+    launch.  dl and the row statistics carry 1 / n: the batches of <= 200 images are compared after rescaling by an exact power-of-two-free
+    ratio only where n / m is exact in fp32, so the row records are compared through the same launch size instead: two walks of the same
+    batch in another image order (reversed) must agree image by image."""
+    rng = np.random.default_rng(n + classes)
+    conv, w, b = _model(rng, classes)
+    x = (rng.integers(0, 256, (n, 1, 28, 28))).astype(np.float32) / np.float32(255.0)
+    y = rng.integers(0, classes, n).astype(np.float32)
+    from taper_amd._lib import hip as lib
+    wd, bd = ctx.upload(w), ctx.upload(b)
+    lib.th_debug_set_chain_loop(1)              # (off by default: measured 3 - 5 % slower than one workgroup per image)
+    try:
+        a = _launch(ctx, conv, wd, bd, x, y, classes)
+        r = _launch(ctx, conv, wd, bd, x[::-1].copy(), y[::-1].copy(), classes)      # image i here is image n - 1 - i there: another workgroup, another turn
+    finally:
+        lib.th_debug_set_chain_loop(-1)
+    plain = _launch(ctx, conv, wd, bd, x, y, classes)                                # one workgroup per image, the same launch size: the same bits
+    for k in ("pooled", "dl", "rs", "cbp"):
+        np.testing.assert_array_equal(a[k], plain[k], err_msg=k)
+    for k in ("pooled", "dl", "rs", "cbp"):
+        np.testing.assert_array_equal(a[k], r[k][::-1], err_msg=k)
+    # ... and the pooled maps against the one-workgroup-per-image launch (no 1 / n in them)
+    for lo in range(0, n, 200):
+        hi = min(n, lo + 200)
+        s = _launch(ctx, conv, wd, bd, x[lo:hi], y[lo:hi], classes)
+        np.testing.assert_array_equal(a["pooled"][lo:hi], s["pooled"])
+    assert a["loss"] == pytest.approx(r["loss"], rel=1e-6)

@@ -11,7 +11,8 @@ from taper_amd import hip  # noqa: E402
 from taper_amd._lib import hip as lib  # noqa: E402
 
 REFERENCE = [(1, 32, 0), (32, 32, 1), (32, 64, 0), (64, 64, 1), (64, 128, 2)]
-n = 256
+import os
+n = int(os.environ.get("N_IMG", 256))
 ctx = hip.Ctx(0)
 lib.th_debug_chain_prof.argtypes = [C.c_void_p, C.c_void_p]
 lib.th_debug_chain_prof.restype = C.c_int
