@@ -823,13 +823,15 @@ def compact_line(full, details_path):
             if "error" in rec:
                 w[rec["workload"]] = {"error": _short(rec["error"], 60)}
                 continue
+            if rec["workload"] == "mlp_784-128-64-10_b256" and full.get("batch_sweep_mlp_784-128-64-10"):
+                continue      # (the same point is the first entry of sweep_784-128-64-10)
             e = {"ms_per_step": rec["ms_per_step"]}      # (samples/s = per_gpu_batch / ms_per_step: in the details file)
             ks = [k for k in rec.get("kernels", []) if k.get("in_step", True)]
             if rec["workload"].startswith("mlp_784-128-10_b") and ks:      # th_mlp2_xent launch by launch: [us, fraction of its roofline]
                 e = {"ms_per_step": rec["ms_per_step"], "kernels": {k["kernel"].split("<")[0].replace("mlp2_", "").replace("_kernel8", "").replace("_kernel", ""): [k["us_per_launch"], k["frac"]] for k in ks}}
             elif ks:
                 k = max(ks, key=lambda r: r["us_per_launch"])
-                e["kernel"] = [_short(k["kernel"].split("<")[0].split("(")[0], 24), k["us_per_launch"], k["bound"], k["frac"]]
+                e["kernel"] = [_short(k["kernel"].split("<")[0].split("(")[0].replace("_kernel", ""), 20), k["us_per_launch"], k["bound"], k["frac"]]
             if isinstance(rec.get("batch_sweep"), list):      # CNN steps at larger batches: {batch: [ms/step, forward-conv fraction of the MFMA peak]}
                 e["sweep"] = {str(x["batch"]): [round(x["ms_per_step"], 4), round(x["mfma_frac_fwd"], 3)] for x in rec["batch_sweep"]}
             if "frac_of_mfma_peak" in rec:
@@ -853,7 +855,7 @@ def compact_line(full, details_path):
     cb = full.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: (round(cb[k], 1) if k == "value" and cb[k] else cb[k]) for k in ("value", "unit", "cores", "kind") if k in cb}
-        out["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 64)
+        out["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 44)
         if cb.get("blas_feature", {}).get("value"):
             out["cpu_baseline"]["blas_feature_value"] = round(cb["blas_feature"]["value"], 1)
         if "see" in cb:
@@ -861,6 +863,17 @@ def compact_line(full, details_path):
     else:
         out["cpu_baseline"] = None
     out["details"] = details_path
+    # the driver keeps the last 2 000 characters of the output: shed the least essential extras until the line fits (everything is in `details`)
+    for path in (("workloads", "*", "cpu_sps"), ("workloads", "*", "full_bwd_ms"), ("sustained_ms_per_step",), ("workloads", "*", "sweep"),
+                 ("sweep_784-128-64-10",), ("step_roofline",)):
+        if len(json.dumps(out)) <= 1960:
+            break
+        if len(path) == 1:
+            out.pop(path[0], None)
+        else:
+            for e in (out.get(path[0]) or {}).values():
+                if isinstance(e, dict):
+                    e.pop(path[2], None)
     return out
 
 
