@@ -83,6 +83,9 @@ __device__ long long g_m2_prof[16];     // wall clock (100 MHz) at stage boundar
 
 constexpr int M2_LDH __attribute__((unused)) = 132;   // row pitch of the H tile in LDS (hidden <= 128): 16-byte aligned rows, rows 4 apart 16 banks apart
 constexpr int M2_BK = 32;
+#ifndef TH_M2_PAIRS
+#define TH_M2_PAIRS 1      // 0: the 16-row tiles take their chunks one by one (r04; measurement)
+#endif
 
 __host__ __device__ constexpr int m2_swz(int row) { return (row >> 1) & 7; }
 
@@ -306,18 +309,64 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
 #undef M2_REQ
 #undef M2_MFMA
     };
+    // The 16-row form takes its chunks in PAIRS (r05): one wait + one barrier + one burst of requests per two chunks, and the second chunk's six
+    // operand reads are in flight under the first chunk's sixteen MFMAs.  A chunk is only 0.23 us of matrix work for a lone wave per SIMD
+    // against ~0.16 us of wait / barrier / LDS-DMA issue / LDS read latency around it -- measured per chunk 0.39 us.  Chunk c lives in stage
+    // c % NS (NS = 8): the pair (it, it + 1) is waited for while chunks up to it + 5 are in flight, and the stages of the pair before are
+    // refilled with chunks it + 6, it + 7 behind the barrier that retires their readers.
+    int it0 = 0;
+    if constexpr (R16 && NS == 8 && TH_M2_PAIRS) {
+        const int npair = nfull / 2;                        // (an odd count's last chunk is requested in turn and taken alone below)
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nfull) fetch(s, s);
-    int stage = 0;
-    for (int it = 0; it < nfull; ++it) {
+        for (int s = 0; s < NS - 2; ++s)
+            if (s < nfull) fetch(s, s);
+        for (int pr = 0; pr < npair; ++pr) {
+            const int it = 2 * pr;
+            if (it + NS - 2 <= nfull) wait_vmcnt<(NS - 4) * LMIN>();         // (the four chunks behind the pair may still be in flight)
+            else wait_vmcnt<0>();
+            lds_barrier();
+            if (pr == 0) M2_STAMP(1, blockIdx.x == 0);
+            if (it + NS - 2 < nfull) fetch(it + NS - 2, (it + NS - 2) % NS);
+            if (it + NS - 1 < nfull) fetch(it + NS - 1, (it + NS - 1) % NS);
+            const float *as0 = smem + (it % NS) * STG, *as1 = smem + ((it + 1) % NS) * STG;
+            float4 xa[2][2], wb[2][2][2];
+#pragma unroll
+            for (int cch = 0; cch < 2; ++cch) {
+                const float *as = cch ? as1 : as0, *bs = as + A_T;
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    xa[cch][rd] = *reinterpret_cast<const float4 *>(as + a16[rd]);
+                    wb[cch][rd][0] = *reinterpret_cast<const float4 *>(bs + b16[rd][0]);
+                    wb[cch][rd][1] = *reinterpret_cast<const float4 *>(bs + b16[rd][1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cch = 0; cch < 2; ++cch)
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+#define M2_MFMA16(E)                                                                                                   \
+    acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cch][rd].E, wb[cch][rd][0].E, acc16[0], 0, 0, 0);                \
+    acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cch][rd].E, wb[cch][rd][1].E, acc16[1], 0, 0, 0);
+                    M2_MFMA16(x) M2_MFMA16(y) M2_MFMA16(z) M2_MFMA16(w)
+#undef M2_MFMA16
+                }
+        }
+        it0 = 2 * npair;
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nfull) fetch(s, s);
+    }
+    int stage = it0 % NS;
+    for (int it = it0; it < nfull; ++it) {
         // chunk `it` has landed once only the NS - 2 fetches issued after it are still in flight (fewer were issued near the end: wait for all)
-        if (it + NS - 1 <= nfull) wait_vmcnt<(NS - 2) * LMIN>();
+        if (it + NS - 1 <= nfull && !(R16 && NS == 8 && TH_M2_PAIRS)) wait_vmcnt<(NS - 2) * LMIN>();
         else wait_vmcnt<0>();
         lds_barrier();                                      // ... in every wave; and every wave is done with the stage refilled next
         if (it == 0) M2_STAMP(1, blockIdx.x == 0);
         const int nxt = it + NS - 1;
-        if (nxt < nfull) fetch(nxt, stage == 0 ? NS - 1 : stage - 1);
+        if (nxt < nfull && !(R16 && NS == 8 && TH_M2_PAIRS)) fetch(nxt, stage == 0 ? NS - 1 : stage - 1);
         contract(smem + stage * STG, smem + stage * STG + A_T, 4);
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
