@@ -95,6 +95,7 @@ struct Mlp2RowsArgs {
     const float *w3, *b3;
     int batch, in_f, hid, c, h2;
     float *dz1;          // [gridDim.x * RT][hid]: rows >= batch are written as zeros
+    int32_t *rows_res;   // [gridDim.x * RT]: the dataset row of every batch row (rows >= batch: the last row's), for launch 2 (nullable)
     float *part;         // [gridDim.x][part_stride]: dW2 [c][hid], db1 [hid], db2 [16], nll, hits
                          // DEEP: dW3 [c][h2], db2 [h2], db3 [16], nll, hits (the block the shallow form lays out, for the classifier on h2), then
                          // at o_deep: dW2 [h2][hid], db1 [hid]
@@ -176,7 +177,10 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
     for (int tt = 0; tt < 2; ++tt) bias16[tt] = (R16 && a.b1 && 32 * cq + 16 * tt + l16 < hid) ? a.b1[32 * cq + 16 * tt + l16] : 0.f;
     const int hrow = 16 * wave + l16;                                         // the row this lane owns in the classifier stage (wave < NRB)
     const int grow = min(r0 + min(hrow, RT - 1), B - 1);
-    const float tf = (wave < NRB) ? a.src.labels[src_row(a.src, cur, grow)] : 0.f;
+    const int grow_src = (wave < NRB) ? src_row(a.src, cur, grow) : 0;
+    const float tf = (wave < NRB) ? a.src.labels[grow_src] : 0.f;
+    // launch 2 gathers the same rows: it reads them here instead of walking cursor -> index again (one dependent memory access less on its way in)
+    if (a.rows_res && wave < NRB && g4 == 0 && ks == 0) a.rows_res[r0 + hrow] = grow_src;
     float4 w2a[8];                                                            // logits' A operand: W2[class l16][16 u + 4 g4 ..]
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -222,9 +226,15 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
     auto fetch = [&](int it, int stage) {
         const int k0 = kbase + it * M2_BK;
         const unsigned st = lds0 + (unsigned)(stage * STG) * 4u;
+#ifdef TH_M2_EXP_NOA      // (measurement only: what the k loop costs without its X / W1 traffic -- results are garbage)
+        if (it < NS)
+#endif
 #pragma unroll
         for (int j = 0; j < NA; ++j)
             if (NW * j + wave_u < RT / 8) lds_dma16(rs_x, st + 1024u * (unsigned)(NW * j + wave_u), a_voff[j], k0 * 4);
+#ifdef TH_M2_EXP_NOB
+        if (it < NS)
+#endif
 #pragma unroll
         for (int j = 0; j < NB; ++j) lds_dma16(rs_w, st + (unsigned)A_T * 4u + 1024u * (unsigned)(NW * j + wave_u), b_voff[j], k0 * 4);
     };
@@ -320,6 +330,21 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
 #pragma unroll
         for (int s = 0; s < NS - 2; ++s)
             if (s < nfull) fetch(s, s);
+        float4 xq[2] = {}, wq[2][2] = {};                   // two operand sets: X quad, the two W1 quads
+        auto rd16 = [&](float4 &x, float4 (&w)[2], const float *as, int rd) {
+            x = *reinterpret_cast<const float4 *>(as + a16[rd]);
+            w[0] = *reinterpret_cast<const float4 *>(as + A_T + b16[rd][0]);
+            w[1] = *reinterpret_cast<const float4 *>(as + A_T + b16[rd][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mm16 = [&](const float4 &x, const float4 (&w)[2]) {
+#define M2_MFMA16(E)                                                                         \
+    acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.E, w[0].E, acc16[0], 0, 0, 0);          \
+    acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.E, w[1].E, acc16[1], 0, 0, 0);
+            M2_MFMA16(x) M2_MFMA16(y) M2_MFMA16(z) M2_MFMA16(w)
+#undef M2_MFMA16
+            __builtin_amdgcn_sched_barrier(0);
+        };
         for (int pr = 0; pr < npair; ++pr) {
             const int it = 2 * pr;
             if (it + NS - 2 <= nfull) wait_vmcnt<(NS - 4) * LMIN>();         // (the four chunks behind the pair may still be in flight)
@@ -328,30 +353,21 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
             if (pr == 0) M2_STAMP(1, blockIdx.x == 0);
             if (it + NS - 2 < nfull) fetch(it + NS - 2, (it + NS - 2) % NS);
             if (it + NS - 1 < nfull) fetch(it + NS - 1, (it + NS - 1) % NS);
+            // Operand reads run ONE 16-k ROUND AHEAD of the MFMAs, across the barrier too: a round is three ds_read_b128 per lane (12 KB over the
+            // four waves: ~100 LDS clocks + latency) against eight MFMAs (256 clocks), and with one wave per SIMD nothing else covers a read
+            // that is waited for -- reads-then-MFMAs per pair measured 0.30 us per chunk with the memory traffic switched OFF (0.21 is the
+            // matrix pipe alone).  The last round of a pair sits in registers over the next barrier (lds_barrier waits for LDS reads).
             const float *as0 = smem + (it % NS) * STG, *as1 = smem + ((it + 1) % NS) * STG;
-            float4 xa[2][2], wb[2][2][2];
-#pragma unroll
-            for (int cch = 0; cch < 2; ++cch) {
-                const float *as = cch ? as1 : as0, *bs = as + A_T;
-#pragma unroll
-                for (int rd = 0; rd < 2; ++rd) {
-                    xa[cch][rd] = *reinterpret_cast<const float4 *>(as + a16[rd]);
-                    wb[cch][rd][0] = *reinterpret_cast<const float4 *>(bs + b16[rd][0]);
-                    wb[cch][rd][1] = *reinterpret_cast<const float4 *>(bs + b16[rd][1]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cch = 0; cch < 2; ++cch)
-#pragma unroll
-                for (int rd = 0; rd < 2; ++rd) {
-#define M2_MFMA16(E)                                                                                                   \
-    acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cch][rd].E, wb[cch][rd][0].E, acc16[0], 0, 0, 0);                \
-    acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cch][rd].E, wb[cch][rd][1].E, acc16[1], 0, 0, 0);
-                    M2_MFMA16(x) M2_MFMA16(y) M2_MFMA16(z) M2_MFMA16(w)
-#undef M2_MFMA16
-                }
+            rd16(xq[0], wq[0], as0, 0);
+            if (pr > 0) mm16(xq[1], wq[1]);
+            rd16(xq[1], wq[1], as0, 1);
+            mm16(xq[0], wq[0]);
+            rd16(xq[0], wq[0], as1, 0);
+            mm16(xq[1], wq[1]);
+            rd16(xq[1], wq[1], as1, 1);
+            mm16(xq[0], wq[0]);
         }
+        if (npair > 0) mm16(xq[1], wq[1]);
         it0 = 2 * npair;
     } else {
 #pragma unroll
@@ -837,6 +853,7 @@ struct Mlp2Dw8Args {
     int rows_pad, batch, in_f, hid;
     float *partial;       // [kz][hid][in_f]
     int tiles_n, kz;      // tiles of 112 columns
+    const int32_t *rows_res;   // [rows_pad]: launch 1's resolved rows (nullable: resolve through src)
 };
 
 template <int NS, bool INDEXED>
@@ -855,12 +872,16 @@ __global__ __launch_bounds__(512, 1) void mlp2_dw1_kernel8(Mlp2Dw8Args a) {
     const int nt = base + (z < extra ? 1 : 0), kbeg = (z * base + min(z, extra)) * M2_BK;
     int *rows_l = reinterpret_cast<int *>(smem + NS * STG);
     {
-        const int n_idx = INDEXED ? (int)a.src.n_idx : 1;
-        const int cur = (INDEXED && a.src.cursor) ? (int)(sload(a.src.cursor) % a.src.n_idx) : 0;
-        for (int i = t; i < nt * M2_BK; i += 512) {
-            const int row = min(kbeg + i, a.batch - 1);
-            const int p = cur + row;
-            rows_l[i] = INDEXED ? a.src.idx[p >= n_idx ? p - n_idx : p] : row;
+        if (INDEXED && a.rows_res) {
+            for (int i = t; i < nt * M2_BK; i += 512) rows_l[i] = a.rows_res[kbeg + i];
+        } else {
+            const int n_idx = INDEXED ? (int)a.src.n_idx : 1;
+            const int cur = (INDEXED && a.src.cursor) ? (int)(sload(a.src.cursor) % a.src.n_idx) : 0;
+            for (int i = t; i < nt * M2_BK; i += 512) {
+                const int row = min(kbeg + i, a.batch - 1);
+                const int p = cur + row;
+                rows_l[i] = INDEXED ? a.src.idx[p >= n_idx ? p - n_idx : p] : row;
+            }
         }
     }
     // staging plans.  A: 1024 16-byte units, unit u = 64 (2 wave + j) + lane: k row u >> 5, LDS quad u & 31 holds memory quad (u & 31) ^ ((krow & 3) << 2).
@@ -1160,8 +1181,10 @@ static int mlp2_run(th_ctx *ctx, const th_row_source *src, int batch, int in_fea
     const size_t n_dz = (size_t)rows_pad * hidden, n_part = (size_t)n_blk * stride, n_partial = (size_t)kz * hidden * in_features;
     const size_t n_kpart = ksplit > 1 ? (size_t)n_blk * ksplit * 2048 : 0;
     void *ws = nullptr;
-    if (th_malloc(ctx, (n_dz + n_part + n_partial + n_kpart) * sizeof(float), &ws)) return 1;
+    if (th_malloc(ctx, (n_dz + n_part + n_partial + n_kpart + (size_t)rows_pad) * sizeof(float), &ws)) return 1;
     float *dz1 = (float *)ws, *part = dz1 + n_dz, *partial = part + n_part, *kpart = partial + n_partial;
+    // (t_mlp2_only: a timing hook that runs one launch alone -- launch 2 then resolves its rows itself)
+    int32_t *rows_res = (dw8 && src->d_indices && t_mlp2_only == 0) ? reinterpret_cast<int32_t *>(kpart + n_kpart) : nullptr;
 
     RowSource rs{src->d_rows, src->d_labels, src->d_indices, src->d_indices ? src->d_cursor : nullptr, src->n_indices,
                  (unsigned)((size_t)src->n_rows * in_features * 4)};
@@ -1173,6 +1196,7 @@ static int mlp2_run(th_ctx *ctx, const th_row_source *src, int batch, int in_fea
     r.dz1 = dz1; r.part = part; r.part_stride = stride; r.o_deep = o_deep; r.tick = d_tick;
     r.ksplit = ksplit; r.kpart = kpart;
     r.karrive = ctx->m2_arrive;
+    r.rows_res = rows_res;
     // ring depth of launch 1: four stages (six for the 32-row tiles, one workgroup per CU, measured no faster: a lone wave per SIMD is bound by
     // its own issue order, not by the requests in flight)
 #define M2_ROWS_LAUNCH_(RT_, NS_, NW_, DEEP_)                                                                                      \
@@ -1209,7 +1233,7 @@ static int mlp2_run(th_ctx *ctx, const th_row_source *src, int batch, int in_fea
         d.src = rs;
         d.dz1 = dz1; d.dz_bytes = (unsigned)(n_dz * 4);
         d.rows_pad = rows_pad; d.batch = batch; d.in_f = in_features; d.hid = hidden;
-        d.partial = partial; d.tiles_n = tiles_n; d.kz = kz;
+        d.partial = partial; d.tiles_n = tiles_n; d.kz = kz; d.rows_res = rows_res;
         constexpr int NS8 = 4;
         const int max_chunks = ceil_div(rows_pad / M2_BK, kz);
         const size_t lds = (size_t)NS8 * (128 + 112) * M2_BK * sizeof(float) + (size_t)max_chunks * M2_BK * sizeof(int);
