@@ -96,7 +96,7 @@ def barrier_sync(rdzv, T):
         rdzv.barrier()
 
 
-def make_comm(rdzv, T, backend, optimizer):
+def make_comm(rdzv, T, backend, optimizer, shared_device=False):
     """backend auto: the one-shot peer-to-peer all-reduce fused with Adam when every rank can map its peers and the multi-round
     self-check passes (first on the pooled gradient arena, then on a fine-grained one), RCCL otherwise (the reason is reported)"""
     from taper_amd.dist import init_data_parallel
@@ -107,7 +107,9 @@ def make_comm(rdzv, T, backend, optimizer):
     kind = info.get("backend", backend)
     why = f" ({info['why']})" if info.get("why") else ""
     if kind.startswith("p2p"):
-        return comm, "p2p one-shot all-reduce + Adam (th_allreduce_adam) over xGMI" + (", fine-grained gradient arena" if kind.endswith("finegrained") else "") + why
+        # (ranks sharing ONE device -- TAPER_BENCH_SHARE_DEVICE, the one-GPU harness -- map each other's arenas through IPC: no link is crossed)
+        link = "between processes on ONE shared device (IPC mappings, no xGMI link crossed)" if shared_device else "over xGMI"
+        return comm, f"p2p one-shot all-reduce + Adam (th_allreduce_adam) {link}" + (", fine-grained gradient arena" if kind.endswith("finegrained") else "") + why
     return comm, "rccl ncclAllReduce(avg)" + why
 
 
@@ -955,7 +957,7 @@ def main():
         args.workload = args.workload.rsplit("_b", 1)[0] + f"_b{batch}"
     model = build_model(T, key)
     opt = T.Adam(model.parameters(), lr, None, None, 1e-4)          # examples/train_mnist.rs:50-51
-    comm, comm_kind = make_comm(dist, T, args.dp_backend, opt)
+    comm, comm_kind = make_comm(dist, T, args.dp_backend, opt, share and world > 1)
     trainer = T.Trainer(model, opt, sample_shape=sample_shape, comm=comm, **({"graph_chunk": args.graph_chunk} if args.graph_chunk else {}))
     # every rank owns its shard of the synthetic epoch (rows are independent: SURVEY.md 8e)
     ds = T.MNISTDataset.synthetic(args.dataset_size, seed=0x7461706572 + rank)
@@ -995,7 +997,7 @@ def main():
         def side_run(b, backend):
             m2 = build_model(T, key)
             o2 = T.Adam(m2.parameters(), lr, None, None, 1e-4)
-            c2, kind2 = make_comm(dist, T, backend, o2) if backend else (None, "none")   # (a p2p communicator is bound to one optimizer's arena)
+            c2, kind2 = make_comm(dist, T, backend, o2, share and world > 1) if backend else (None, "none")   # (a p2p communicator is bound to one optimizer's arena)
             t2 = T.Trainer(m2, o2, sample_shape=sample_shape, comm=c2)
             l2 = T.DataLoader(ds, b, False)
             run_steps(T, t2, l2, max(args.warmup, 2) + record_steps)
