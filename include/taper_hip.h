@@ -294,7 +294,8 @@ int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batc
  *   launch 2: dW1 = dZ1^T X over K slices of the batch
  *   launch 3: fixed-order sums -> d_dw1 [hidden][in], d_db1, d_dw2 [classes][hidden], d_db2, d_loss, d_ncorrect, the step log, and Adam for
  *             every fuse given (complete gradients; no later launch of the step reads a parameter: nothing to defer).
- * Needs hidden a multiple of 32 up to 128, classes <= 16, in_features a multiple of 4, batch >= 32, n_rows * in_features * 4 < 2^31.
+ * Needs hidden a multiple of 4 up to 128 (a width that ends inside a wave's 16-column tile is padded with zero columns in the kernels:
+ * 784-100-10 runs at the rate of 784-128-10), classes <= 16, in_features a multiple of 4, batch >= 32, n_rows * in_features * 4 < 2^31.
  * Nullable: d_b1, d_b2, d_db1, d_db2, d_ncorrect, metrics / state, d_tick, the fuses. */
 typedef struct th_row_source {
     const float *d_rows;
@@ -319,7 +320,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
  * LDS anyway, and everything behind it stays row-parallel inside launch 1 (A2, the classifier, dZ2, dA1, the masked dZ1, the block's share
  * of dW2 = dZ2^T A1 beside the small sums); only dW1 needs the batch-wide launch; launch 3 adds the blocks' shares and applies Adam for
  * every fuse given.  layers[0..2] as in th_mlp3_xent (d_w [out][in] 16-byte aligned; d_dw required, d_b / d_db nullable); the first
- * hidden size a multiple of 32, the second of 16, both <= 128; classes <= 16.  Same row source, step log and tick as th_mlp2_xent. */
+ * hidden size and the second multiples of 4, both <= 128; classes <= 16.  Same row source, step log and tick as th_mlp2_xent. */
 int th_mlp2_xent_deep_supported(int batch, int in_features, int h1, int h2, int classes, int64_t n_rows);
 int th_mlp2_xent_deep(th_ctx *ctx, const th_row_source *src, int batch, int in_features, const th_mlp3_layer *layers, float *d_loss,
                       float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_tick);

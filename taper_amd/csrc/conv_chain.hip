@@ -844,6 +844,20 @@ __device__ __forceinline__ void layer_load_planes(const float *__restrict__ xi, 
     }
 }
 
+#ifndef TH_LC_STAGE_ALL
+#define TH_LC_STAGE_ALL 0     // 1: every map-writing layer goes through the LDS tile (measurement)
+#endif
+#ifndef TH_LC_STAGE_NONE
+#define TH_LC_STAGE_NONE 0    // 1: no layer does (r04's direct stores)
+#endif
+#ifndef TH_LC_NT
+#define TH_LC_NT 0            // 1: the staged map is written with non-temporal stores (measurement)
+#endif
+#if TH_LC_NT
+#define LC_STORE4(p_, v_) __builtin_nontemporal_store((v_), (p_))
+#else
+#define LC_STORE4(p_, v_) (*(p_) = (v_))
+#endif
 // LIN (POST 0 only): the map is the plain sum -- no bias, no ReLU: the INPUT GRADIENT of a 3x3 layer, whose mirrored, channel-swapped filter
 // th_conv3x3_bwd_input has laid out as a taper slab (full_backward extension)
 template <int S, int C_IN, int C_OUT, int POST, bool LIN = false>
@@ -854,6 +868,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_layer_chain_kernel(LayerChainAr
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g4 = lane >> 4;
     float *A = lds, *T = lds;                    // the output tile overlays the input planes once every wave is past the k loop
     static_assert(!LIN || POST == 0, "the linear form writes the map");
+    constexpr bool LC_STAGED = !LIN && POST == 0 && (TH_LC_STAGE_ALL || (S == 7 && !TH_LC_STAGE_NONE));
     ChainBias bv;
     chain_bias<S, C_OUT>(LIN ? nullptr : a.b, bv, wave, lane);
     if (POST == 0) chain_zero_halo<S, C_IN>(A, wave, lane);             // (the map goes to memory: nothing ever overwrites the halo)
@@ -869,6 +884,35 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_layer_chain_kernel(LayerChainAr
         floatx4 acc[G::NSLOT];
         chain_mfma<S, C_IN, C_OUT>(A, a.w, wc, acc, wave, lane);
         CH_STAMP(2);
+        if (POST == 0 && LC_STAGED) {
+            // the NCHW map through the LDS tile: an image's map [C_OUT][PX] is ONE contiguous block, written here as whole float4 lines
+            // (16 dword stores per lane straight from the accumulators are 64-byte pieces at a 4 PX-byte pitch -- partial lines, and at
+            // 7 x 7 never aligned: that store phase measured 4.6 us of the 18 a workgroup lives, r05)
+            chain_sync();                                               // every wave is done reading A
+            chain_store<S, C_OUT, false>(acc, bv, T, wave, lane);
+            chain_sync();
+            constexpr int LD = ch_tile_ld(G::PX), NQ = C_OUT * G::PX / 4;
+            static_assert(C_OUT * G::PX % 4 == 0, "whole float4s");
+            float4 *yq = reinterpret_cast<float4 *>(a.y + (long)img * C_OUT * G::PX);
+#pragma unroll 2
+            for (int f = t; f < NQ; f += CH_NT) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int el = 4 * f + e, c = el / G::PX, i = el - c * G::PX;
+                    v[e] = T[c * LD + i];
+                }
+                LC_STORE4(yq + f, make_float4(v[0], v[1], v[2], v[3]));
+            }
+            if (img + (int)gridDim.x < a.n) {
+                chain_sync();                                           // the next image's planes overwrite T
+                chain_zero_halo<S, C_IN>(A, wave, lane);
+            }
+            CH_STAMP(3);
+            CH_STAMP(4);
+            CH_SPAN(1);
+            continue;
+        }
         if (POST == 0) {
             // the NCHW map straight from the accumulators
             float *ymap = a.y + (long)img * C_OUT * G::PX;

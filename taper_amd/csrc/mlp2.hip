@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
         for (int j = 0; j < 2; ++j) {
             const int ct = wave + 4 * j;
             const bool tile = 16 * ct < a.h2;
-            b2c[j] = (tile && a.b2) ? a.b2[16 * ct + l16] : 0.f;
+            b2c[j] = (tile && a.b2 && 16 * ct + l16 < a.h2) ? a.b2[16 * ct + l16] : 0.f;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = 16 * u + 4 * g4;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = ((c0[e] + c1[e]) + (c2[e] + c3[e])) + b2c[j];
-                    H2s[(16 * rb + 4 * g4 + e) * M2_LDH + 16 * ct + l16] = (tile && v > 0.f) ? v : 0.f;
+                    H2s[(16 * rb + 4 * g4 + e) * M2_LDH + 16 * ct + l16] = (tile && 16 * ct + l16 < a.h2 && v > 0.f) ? v : 0.f;   // (a ragged last tile: zeros beyond h2)
                 }
             }
         }
@@ -581,7 +581,8 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             const int col = 16 * NTT * wave + 16 * tt + l16;
-            if (DEEP && 16 * (NTT * wave + tt) >= kl) break;                  // (h2 is a multiple of 16, not of 32: a wave's second tile may lie beyond it)
+            if (16 * (NTT * wave + tt) >= kl) break;                          // (kl is a multiple of 4, not of 32: a wave's second tile may lie beyond it,
+            const bool live = col < kl;                                       //  or end inside it: columns >= kl hold H = 0, so dz = 0, and are not stored)
             float colsum = 0.f;
             floatx4 dw2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
                     const float hv = Hc[row * M2_LDH + col];
                     const float dz = hv > 0.f ? dh[e] : 0.f;
                     if constexpr (DEEP) Hc[row * M2_LDH + col] = dz;
-                    else a.dz1[(long)(r0 + row) * hid + col] = dz;              // (zeros for rows >= batch: launch 2 contracts whole 32-row chunks)
+                    else if (live) a.dz1[(long)(r0 + row) * hid + col] = dz;    // (zeros for rows >= batch: launch 2 contracts whole 32-row chunks)
                     colsum += dz;
                     // dW2's operands of k-step e: A(class l16, row) and B(row, col) -- the row of this very element
                     dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(D3S[row * 20 + l16], hv, dw2, 0, 0, 0);
@@ -606,10 +607,10 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
             }
             colsum += __shfl_xor(colsum, 16, 64);
             colsum += __shfl_xor(colsum, 32, 64);
-            if (lane < 16) part[o_db1 + col] = colsum;
+            if (lane < 16 && live) part[o_db1 + col] = colsum;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (4 * g4 + e < C) part[(4 * g4 + e) * kl + col] = dw2[e];       // dw2[e] = dW2[class 4 g4 + e][col]
+                if (4 * g4 + e < C && live) part[(4 * g4 + e) * kl + col] = dw2[e];   // dw2[e] = dW2[class 4 g4 + e][col]
         }
     }
     if constexpr (DEEP) {
@@ -640,13 +641,13 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
                 for (int e = 0; e < 4; ++e) {
                     const int row = 16 * rb + 4 * g4 + e;
                     const float dz = Hs[row * M2_LDH + col] > 0.f ? ((c0[e] + c1[e]) + (c2[e] + c3[e])) : 0.f;
-                    a.dz1[(long)(r0 + row) * hid + col] = dz;                   // (zeros for rows >= batch: their dlogits are zero)
+                    if (col < hid) a.dz1[(long)(r0 + row) * hid + col] = dz;    // (zeros for rows >= batch: their dlogits are zero; a ragged last tile: A1 = 0 beyond hid)
                     colsum += dz;
                 }
             }
             colsum += __shfl_xor(colsum, 16, 64);
             colsum += __shfl_xor(colsum, 32, 64);
-            if (lane < 16) pd[h2 * hid + col] = colsum;
+            if (lane < 16 && col < hid) pd[h2 * hid + col] = colsum;
         }
         // the row block's share of dW2 = dZ2^T A1 (ops.rs:266-294 through the W^T node): D[j = 16 tj + 4 g4 + e][n = 16 tn + l16], the
         // contraction over the tile's rows -- A(m = j, k = row) = dZ2[row][j], B(k = row, n) = A1[row][n]; wave w owns tn = 2 w, 2 w + 1
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(64 * NW, (!DEEP && NW == 4 && (RT == 32 || (RT == 6
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int j = 16 * (tj0 + q) + 4 * g4 + e;
-                        if (j < h2) pd[(long)j * hid + 16 * tn + l16] = dw[q][e];
+                        if (j < h2 && 16 * tn + l16 < hid) pd[(long)j * hid + 16 * tn + l16] = dw[q][e];
                     }
             }
         }
@@ -1299,13 +1300,13 @@ using namespace th;
 extern "C" {
 
 int th_mlp2_xent_supported(int batch, int in_features, int hidden, int classes, int64_t n_rows) {
-    return batch >= 32 && in_features >= 32 && in_features % 4 == 0 && hidden >= 32 && hidden <= 128 && hidden % 32 == 0 && classes >= 1 &&
+    return batch >= 32 && in_features >= 32 && in_features % 4 == 0 && hidden >= 4 && hidden <= 128 && hidden % 4 == 0 && classes >= 1 &&
                    classes <= 16 && n_rows >= 1 && (double)n_rows * in_features * 4.0 < 2147483648.0 && (double)(batch + 64) * hidden * 4.0 < 2147483648.0
                ? 1 : 0;
 }
 
 int th_mlp2_xent_deep_supported(int batch, int in_features, int h1, int h2, int classes, int64_t n_rows) {
-    return th_mlp2_xent_supported(batch, in_features, h1, classes, n_rows) && h2 >= 16 && h2 <= 128 && h2 % 16 == 0 ? 1 : 0;
+    return th_mlp2_xent_supported(batch, in_features, h1, classes, n_rows) && h2 >= 4 && h2 <= 128 && h2 % 4 == 0 ? 1 : 0;
 }
 
 #define M2_COMMON_CHECKS(NAME)                                                                                                                                  \
@@ -1320,7 +1321,7 @@ int th_mlp2_xent(th_ctx *ctx, const th_row_source *src, int batch, int in_featur
                  const th_adam_fuse *b2_fuse) {
     TH_REQUIRE(ctx && src && src->d_rows && src->d_labels && d_w1 && d_w2 && d_dw1 && d_dw2 && d_loss, "th_mlp2_xent: null argument");
     TH_REQUIRE(th_mlp2_xent_supported(batch, in_features, hidden, classes, src->n_rows),
-               "th_mlp2_xent: needs batch >= 32, in_features a multiple of 4 (>= 32), hidden a multiple of 32 up to 128, classes <= 16, "
+               "th_mlp2_xent: needs batch >= 32, in_features a multiple of 4 (>= 32), hidden a multiple of 4 up to 128, classes <= 16, "
                "rows * in_features * 4 < 2^31 (got %d, %d, %d, %d, %ld rows)", batch, in_features, hidden, classes, (long)src->n_rows);
     M2_COMMON_CHECKS("th_mlp2_xent");
     TH_REQUIRE((((uintptr_t)src->d_rows | (uintptr_t)d_w1 | (uintptr_t)d_w2 | (uintptr_t)d_dw1) & 15) == 0, "th_mlp2_xent: rows, W1, W2 and dW1 must be 16-byte aligned");
@@ -1343,8 +1344,8 @@ int th_mlp2_xent_deep(th_ctx *ctx, const th_row_source *src, int batch, int in_f
         L[l] = M2Layer{y.d_w, y.d_b, y.d_dw, y.d_db, y.w_fuse, y.b_fuse, y.out_features};
     }
     TH_REQUIRE(th_mlp2_xent_deep_supported(batch, in_features, L[0].out, L[1].out, L[2].out, src->n_rows),
-               "th_mlp2_xent_deep: needs batch >= 32, in_features a multiple of 4 (>= 32), the first hidden size a multiple of 32 and the second of 16 "
-               "(both <= 128), classes <= 16, rows * in_features * 4 < 2^31 (got %d, %d, %d, %d, %d, %ld rows)", batch, in_features, L[0].out,
+               "th_mlp2_xent_deep: needs batch >= 32, in_features a multiple of 4 (>= 32), both hidden sizes multiples of 4 "
+               "(<= 128), classes <= 16, rows * in_features * 4 < 2^31 (got %d, %d, %d, %d, %d, %ld rows)", batch, in_features, L[0].out,
                L[1].out, L[2].out, (long)src->n_rows);
     M2_COMMON_CHECKS("th_mlp2_xent_deep");
     TH_REQUIRE(((uintptr_t)src->d_rows & 15) == 0, "th_mlp2_xent_deep: the rows must be 16-byte aligned");

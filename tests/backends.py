@@ -134,6 +134,14 @@ def mlp_baseline(rng):  # BASELINE.json configs[0/1]: 784-128-10 (src/train.rs:3
     return [_lin(rng, 784, 128), dict(kind="relu"), _lin(rng, 128, 10)]
 
 
+def mlp_100(rng):  # a hidden width that is no multiple of 32 (the fused large-batch step pads its tiles: r05)
+    return [_lin(rng, 784, 100), dict(kind="relu"), _lin(rng, 100, 10)]
+
+
+def mlp_100_52(rng):  # two hidden layers, both ragged
+    return [_lin(rng, 784, 100), dict(kind="relu"), _lin(rng, 100, 52), dict(kind="relu"), _lin(rng, 52, 10)]
+
+
 def mlp_example(rng):  # examples/train_mnist.rs:34-40: 784-128-64-10
     return [_lin(rng, 784, 128), dict(kind="relu"), _lin(rng, 128, 64), dict(kind="relu"), _lin(rng, 64, 10)]
 

@@ -55,8 +55,10 @@ def _check_grads(ctx, out, ref, inf, hid, c, name):
         margins.check(f"{k}", got, np.asarray(ref[k]).reshape(shape), 1e-4, test=name)
 
 
+# (hidden widths that are not multiples of 32 -- 100, 20, 4, 116 -- end inside a wave's 16-column tile: r05)
 DENSE = [(1024, 784, 128, 10), (4096, 784, 128, 10), (1000, 100, 64, 5), (33, 36, 32, 16), (5000, 784, 96, 10), (2048, 64, 128, 3),
-         (12288 + 5, 784, 128, 10), (16384, 784, 128, 10)]
+         (12288 + 5, 784, 128, 10), (16384, 784, 128, 10), (2048, 784, 100, 10), (520, 64, 20, 4), (700, 100, 4, 3), (4100, 784, 116, 10),
+         (13000, 784, 100, 10)]
 
 
 @pytest.mark.parametrize("batch,inf,hid,c", DENSE)
@@ -163,7 +165,9 @@ def _mlp2_calls():
 @pytest.mark.parametrize("n,batch,shuffle,model", [(10000, 4096, True, "mlp_baseline"), (40000, 16384, True, "mlp_baseline"), (8192, 4096, False, "mlp_baseline"),
                                                    (20000, 20000, False, "mlp_baseline"),
                                                    # examples/train_mnist.rs:40-48's own model (two hidden layers) through th_mlp2_xent_deep
-                                                   (10000, 4096, True, "mlp_example"), (40000, 16384, True, "mlp_example"), (3000, 1024, True, "mlp_example")])
+                                                   (10000, 4096, True, "mlp_example"), (40000, 16384, True, "mlp_example"), (3000, 1024, True, "mlp_example"),
+                                                   # hidden widths that are no multiples of 32 / 16 take the same step (ragged tiles)
+                                                   (10000, 4096, True, "mlp_100"), (3000, 1024, True, "mlp_100_52")])
 def test_trainer_large_batch_epochs_match_oracle(n, batch, shuffle, model):
     """Trainer steps of the MNIST MLP at batch >= 2048 take th_mlp2_xent: the rows are read in place through the loader's index vector (a
     last partial batch below 2048 rows is gathered and takes the small-batch forms).  Two epochs (graph replay: the second reuses the
@@ -326,7 +330,8 @@ def _call_deep(ctx, src, batch, inf, net_dev, fuses=None, tick=None, log=None):
 
 
 DEEP = [(1024, 784, 128, 64, 10), (4096, 784, 128, 64, 10), (16384, 784, 128, 64, 10), (256, 784, 128, 64, 10), (1000, 100, 64, 32, 5),
-        (40, 36, 32, 16, 16), (5000, 784, 96, 48, 10), (2048, 64, 128, 128, 3), (12288 + 5, 784, 128, 64, 10)]
+        (40, 36, 32, 16, 16), (5000, 784, 96, 48, 10), (2048, 64, 128, 128, 3), (12288 + 5, 784, 128, 64, 10),
+        (1024, 784, 100, 52, 10), (600, 100, 36, 20, 5), (4100, 784, 116, 12, 10), (13000, 784, 100, 52, 10)]     # (ragged tiles in both hidden layers: r05)
 
 
 @pytest.mark.parametrize("batch,inf,h1,h2,c", DEEP)
@@ -402,8 +407,9 @@ def test_mlp2_deep_rows_through_the_index_vector_with_adam(ctx, O):
 
 def test_mlp2_deep_limits_are_errors(ctx):
     from taper_amd._lib import TaperError, hip as lib
-    assert lib.th_mlp2_xent_deep_supported(1024, 784, 128, 72, 10, 60000) == 0     # the second hidden size: a multiple of 16
-    assert lib.th_mlp2_xent_deep_supported(1024, 784, 100, 64, 10, 60000) == 0     # the first: a multiple of 32
+    assert lib.th_mlp2_xent_deep_supported(1024, 784, 128, 70, 10, 60000) == 0     # the hidden sizes: multiples of 4
+    assert lib.th_mlp2_xent_deep_supported(1024, 784, 102, 64, 10, 60000) == 0
+    assert lib.th_mlp2_xent_deep_supported(1024, 784, 100, 72, 10, 60000) == 1
     assert lib.th_mlp2_xent_deep_supported(1024, 784, 128, 144, 10, 60000) == 0
     assert lib.th_mlp2_xent_deep_supported(1024, 784, 128, 64, 10, 60000) == 1
 
