@@ -21,7 +21,7 @@ def test_linear_random_shapes(ctx, O, batch, inf, outf, relu):
 @given(ta=st.integers(0, 1), tb=st.integers(0, 1), m=st.integers(1, 200), n=st.integers(1, 200), k=st.integers(1, 700),
        ab=st.sampled_from([(1.0, 0.0), (1.0, 1.0), (0.5, -2.0)]))
 def test_sgemm_random_shapes(ctx, O, ta, tb, m, n, k, ab):
-    K.test_sgemm(ctx, O, ta, tb, m, n, k, ab[0], ab[1])
+    K.test_sgemm(ctx, O, (ta, tb, m, n, k), ab)
 
 
 @settings(**CFG)
