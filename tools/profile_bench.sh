@@ -12,6 +12,7 @@ BENCH="python $ROOT/bench.py --gpus 1 ${BENCH_ARGS:-}"
 
 timeout -s KILL 400 $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 400 "$OUT/bench.json"
+cp "$ROOT/gpurun_out/bench_details.json" "$OUT/bench_details.json" 2>/dev/null   # (the later passes overwrite it)
 
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
