@@ -631,26 +631,36 @@ def linear_stack_workload(T, layers=4, width=4096, batch=4096, steps=12, warmup=
     x = T.Tensor(rng.uniform(0, 1, (B, W)).astype(np.float32))
     y = T.Tensor(rng.integers(0, 10, B).astype(np.float32))
 
-    def step():
+    def step(fused):
         T.Tape.reset()
         opt.zero_grad()
-        loss = T.cross_entropy_loss(model.forward(x), y)
-        loss.backward()
-        opt.step()
+        if fused:       # Adam.fused_step(): the Trainer's mode for a hand-written loop -- each update in the epilogue of the product that completes its gradient
+            with opt.fused_step():
+                loss = T.cross_entropy_loss(model.forward(x), y)
+                loss.backward()
+                opt.step()
+        else:           # the reference-literal order: backward, then one arena-wide Adam launch
+            loss = T.cross_entropy_loss(model.forward(x), y)
+            loss.backward()
+            opt.step()
         return loss
 
-    for _ in range(warmup):
-        step()
-    T.Device.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    T.Device.sync()
-    dt = (time.perf_counter() - t0) / steps
+    times = {}
+    for fused in (False, True):
+        for _ in range(warmup):
+            step(fused)
+        T.Device.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step(fused)
+        T.Device.sync()
+        times[fused] = (time.perf_counter() - t0) / steps
+    dt = times[True]
     params = L * (W * W + W) + W * 10 + 10
     flops = (3 * L - 1) * 2.0 * B * W * W + 3 * 2.0 * B * W * 10 + 14.0 * params
     rec = dict(workload=f"linear_stack_{W}x{L}_b{B}", per_gpu_batch=B, steps=steps, ms_per_step=round(dt * 1e3, 4), samples_per_s=round(B / dt, 1),
-               step="eager op-by-op host API (Tape::reset, forward, cross_entropy_loss, backward, Adam::step)", alg_flops_per_step=flops,
+               step="eager op-by-op host API (Tape::reset, forward, cross_entropy_loss, backward, Adam::step) inside Adam.fused_step(): updates in the dW products' epilogues",
+               ms_per_step_plain_loop=round(times[False] * 1e3, 4), frac_plain_loop=round(flops / times[False] / 1e12 / MFMA_F32_PEAK_TF, 4), alg_flops_per_step=flops,
                tflops=round(flops / dt / 1e12, 2), frac_of_mfma_peak=round(flops / dt / 1e12 / MFMA_F32_PEAK_TF, 4),
                loss_last=round(float(loss.data()[0]), 5))
     del model, opt, x, y

@@ -156,6 +156,11 @@ int th_linear_bwd_adam_ex(th_ctx *ctx, const float *d_x, const float *d_w, const
  * accumulated) and a shape for which th_linear_bwd_dx_epilogue_rows is > 0: the unsplit 128 x 128 MFMA tiles (4096-wide layers), or a thin
  * layer (out_features <= 16 on >= 2^20 outputs), whose dX then runs as a streaming launch (67 MB in ~25 us instead of 119). */
 int th_linear_bwd_dx_epilogue_rows(int batch, int in_features, int out_features);
+/* 1: th_linear_bwd_adam_ex2 runs this shape's products as launches of their own (the MFMA tile kernels: dX first, then dW -- so a fused W
+ * update may ride in the dW product's epilogue even when d_dx is asked for, the dX product has consumed W by then); 0: the one-launch form
+ * of the latency-bound shapes (there a W update next to d_dx runs as a slice launch behind it: let a later launch carry it instead).
+ * with_dx / with_dw: whether d_dx / d_dw will be given; dx_epilogue: whether mask_dx / d_dx_colpart will. */
+int th_linear_bwd_separate_products(int batch, int in_features, int out_features, int with_dx, int with_dw, int dx_epilogue);
 int th_linear_bwd_adam_ex2(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
                            float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask,
                            const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra, int mask_dx,

@@ -135,6 +135,11 @@ int tp_adamw_new(tp_tensor *const *params, int n, float lr, float beta1, float b
 int tp_optim_free(tp_optim *o);
 int tp_optim_step(tp_optim *o);
 int tp_optim_zero_grad(tp_optim *o);
+/* The Trainer's fused-update mode for a hand-written loop: between begin and end, Tensor::backward applies a parameter's Adam update
+ * (optim.rs:99-110, same arithmetic, same t) in the epilogue of the kernel that completes its gradient; tp_optim_step, called inside
+ * the pair as the loop would anyway, covers the parameters nobody fused.  begin opens the step (t += 1, optim.rs:84). */
+int tp_adam_fused_begin(tp_optim *o);
+int tp_adam_fused_end(tp_optim *o);
 int tp_adam_set_lr(tp_optim *o, float lr);
 int tp_adam_get_lr(const tp_optim *o, float *out);
 int tp_adam_t(const tp_optim *o, int *out);

@@ -405,6 +405,22 @@ class Adam(_Optim):
         self._h = _mk(host.tp_adam_new, "Adam::new", arr, len(self.params), float(lr), float(betas[0]), float(betas[1]),
                       float(1e-8 if eps is None else eps), float(0.0 if weight_decay is None else weight_decay))
 
+    def fused_step(self):
+        """Context manager: the Trainer's fused-update mode for a hand-written loop.  Inside it `loss.backward()` applies each parameter's
+        Adam update in the epilogue of the kernel that completes its gradient and `step()` (call it inside) covers the rest:
+            with opt.fused_step():
+                loss = T.cross_entropy_loss(model.forward(x), y); loss.backward(); opt.step()"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            tp_check(host.tp_adam_fused_begin(self._h), "Adam::fused_begin")
+            try:
+                yield self
+            finally:
+                tp_check(host.tp_adam_fused_end(self._h), "Adam::fused_end")
+        return scope()
+
     def set_lr(self, lr): tp_check(host.tp_adam_set_lr(self._h, float(lr)), "Adam::set_lr")
 
     def get_lr(self):

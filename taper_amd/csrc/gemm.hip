@@ -539,7 +539,9 @@ __device__ __forceinline__ void dma_tile(const float *__restrict__ P, long ld_fl
 __device__ long long g_gemm_prof[4];   // workgroup 0: wall clock (100 MHz) and shader clock at entry and exit -- the clock the product ran at
 #endif
 
-template <int TS, bool A_KC, bool B_KC, bool GUARD, bool DXEP = false>   // DXEP: the epilogue with Epilogue::mask / colpart (its own instances: the plain products keep their registers)
+// DXEP: the epilogue with Epilogue::mask / colpart; ADAMEP: C is a complete gradient and the parameter's Adam update (optim.rs:99-110) runs on
+// the element in the epilogue, under the matrix work of the CU's other workgroup (their own instances: the plain products keep their registers)
+template <int TS, bool A_KC, bool B_KC, bool GUARD, bool DXEP = false, bool ADAMEP = false>
 __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A, const float *__restrict__ B,
                                                      float *__restrict__ C, int m, int n, int k,
                                                      long a_rs, long a_cs, long b_rs, long b_cs,
@@ -682,6 +684,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
 #endif
     // epilogue.  C/D map of 32x32x2: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
     const bool masked = DXEP && ep.mask != nullptr && !partial;
+    float adam_step = 0.f;
+    if constexpr (ADAMEP) adam_step = adam_dev_step(ep.adam);
     float csum[NS];                             // this lane's share of the column sums of what it stores (columns wn + 32 j + li)
 #pragma unroll
     for (int j = 0; j < NS; ++j) csum[j] = 0.f;
@@ -698,8 +702,22 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
                     mk[e] = (!GUARD || (row < m && col < n)) ? ep.mask[(long)row * n + col] : 0.f;
                 }
             }
+            // ADAMEP: the 24 operands of eight elements' updates are requested together (a round trip per eight elements, not per element)
+            float ap[ADAMEP ? 8 : 1], am[ADAMEP ? 8 : 1], av[ADAMEP ? 8 : 1];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if constexpr (ADAMEP) {
+                    if ((e & 7) == 0) {
+#pragma unroll
+                        for (int f = 0; f < 8; ++f) {
+                            const int rowf = row0 + wm + 32 * i + ((e + f) & 3) + 8 * ((e + f) >> 2) + 4 * lk;
+                            const long idf = (!GUARD || (rowf < m && col < n)) ? (long)rowf * n + col : 0;
+                            ap[f] = ep.adam.p[idf];
+                            am[f] = ep.adam.m[idf];
+                            av[f] = ep.adam.v[idf];
+                        }
+                    }
+                }
                 const int row = row0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 if (!GUARD || (row < m && col < n)) {
                     const long idx = (long)row * n + col;
@@ -712,6 +730,15 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
                     if (masked) v = mk[e] > 0.f ? v : 0.f;
                     C[idx] = v;
                     csum[j] += v;
+                    if constexpr (ADAMEP) {     // adam_update's arithmetic, element by element
+                        const AdamDev &ad = ep.adam;
+                        const float gv = v + ad.wd * ap[e & 7];
+                        const float mn = ad.beta1 * am[e & 7] + (1.0f - ad.beta1) * gv;
+                        const float vn = ad.beta2 * av[e & 7] + (1.0f - ad.beta2) * gv * gv;
+                        ad.m[idx] = mn;
+                        ad.v[idx] = vn;
+                        ad.p[idx] = ap[e & 7] - adam_step * mn / (sqrtf(vn) + ad.eps);
+                    }
                 }
             }
         }
@@ -824,9 +851,23 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
         if (th_malloc(ctx, (size_t)kz * m * n * sizeof(float), &ws)) return 1;
         partial = (float *)ws;
     }
-    // a fused Adam update belongs to the pass that completes the gradient
+    // a fused Adam update belongs to the pass that completes the gradient: the reduce pass of a split product; the product's own epilogue
+    // when it is unsplit and runs on whole 128-tiles in the weight gradient's layout (TN: dW = dZ^T X, th_linear_bwd_adam_ex2's big shapes --
+    // 16.7 M parameters of a 4096 x 4096 layer cost a pass of 75 us over p / m / v / g as a launch of their own)
     Epilogue kep = ep;
     kep.adam.p = nullptr;
+    static const bool adam_ep_on = [] { const char *e = getenv("TAPER_GEMM_ADAM_EP"); return !e || atoi(e) != 0; }();   // 0: a slice launch behind the product (measurement)
+    if constexpr (TS == 128 && !A_KC && !B_KC) {
+        if (ep.adam.p && kz == 1 && exact && adam_ep_on && !ep.mask && !ep.colpart) {
+            auto kern = sgemm_tile<TS, A_KC, B_KC, false, false, true>;
+            TH_SET_MAX_LDS(ctx, kern, lds);
+            static const int raster_a = [] { const char *e = getenv("TAPER_GEMM_RASTER"); return e ? atoi(e) : 8; }();
+            hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs, b_rs, b_cs, tiles_m, tiles_n, ep,
+                               kslice, (float *)nullptr, 1, raster_a);
+            TH_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     // tile order: groups of 8 tile rows (TAPER_GEMM_RASTER = n: groups of n; 0: r02's whole columns)
     static const int raster = [] { const char *e = getenv("TAPER_GEMM_RASTER"); return e ? atoi(e) : 8; }();
     if (ep.mask || ep.colpart) {     // the dX product with the backward of the layer in front in its epilogue (th_linear_bwd_adam_ex2: unsplit by its predicate)
@@ -1133,6 +1174,15 @@ static int dx_epilogue_rows(int batch, int in_f, int out_f) {
 extern "C" {
 
 int th_linear_bwd_dx_epilogue_rows(int batch, int in_features, int out_features) { return th::dx_epilogue_rows(batch, in_features, out_features); }
+
+int th_linear_bwd_separate_products(int batch, int in_features, int out_features, int with_dx, int with_dw, int dx_epilogue) {
+    // (th_linear_bwd_adam_ex2's own decision, below)
+    const int ep_rows = (dx_epilogue && with_dx) ? th::dx_epilogue_rows(batch, in_features, out_features) : 0;
+    const bool thin_dx = ep_rows > 0 && out_features <= 16;
+    const bool dw_big = with_dw && gemm_is_big(out_features, in_features, batch);
+    const bool dx_big = with_dx && !thin_dx && gemm_is_big(batch, in_features, out_features);
+    return (!dw_big && !dx_big && batch <= 4096 && out_features <= 4096) ? 0 : 1;
+}
 
 int th_linear_bwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_dy, const float *d_relu_y, float *d_dx,
                   float *d_dw, float *d_db, int batch, int in_features, int out_features, int accumulate_mask) {

@@ -277,6 +277,25 @@ int tp_sched_free(tp_sched *s) { TP_BEGIN delete s; TP_END }
 int tp_optim_free(tp_optim *o) { TP_BEGIN delete o; TP_END }
 int tp_optim_step(tp_optim *o) { TP_BEGIN o->o->step(); TP_END }
 int tp_optim_zero_grad(tp_optim *o) { TP_BEGIN o->o->zero_grad(); TP_END }
+// The Trainer's fused-update mode for a hand-written loop (taper.h: FusedAdamScope): between begin and end, backward() applies a parameter's
+// Adam update in the epilogue of the kernel that completes its gradient; Adam::step() -- called INSIDE the scope, as the loop would anyway --
+// covers what nobody fused.  begin opens the optimizer step (t += 1, optim.rs:84) itself: no loss kernel of the eager API does.
+namespace { thread_local taper::FusedAdamScope *t_eager_scope = nullptr; }
+int tp_adam_fused_begin(tp_optim *o) {
+    TP_BEGIN
+    TAPER_ASSERT(o->adam, "not an Adam optimizer");
+    TAPER_ASSERT(!t_eager_scope && !taper::FusedAdamScope::active(), "a fused Adam step is already open on this thread");
+    t_eager_scope = new taper::FusedAdamScope(o->adam.get());
+    th_check(th_adam_tick(taper::Device::ctx(), o->adam->d_tick()), "th_adam_tick");
+    TP_END
+}
+int tp_adam_fused_end(tp_optim *o) {
+    TP_BEGIN
+    (void)o;
+    delete t_eager_scope;
+    t_eager_scope = nullptr;
+    TP_END
+}
 int tp_adam_set_lr(tp_optim *o, float lr) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); o->adam->set_lr(lr); TP_END }
 int tp_adam_get_lr(const tp_optim *o, float *out) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); *out = o->adam->get_lr(); TP_END }
 int tp_adam_t(const tp_optim *o, int *out) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); *out = o->adam->t(); TP_END }

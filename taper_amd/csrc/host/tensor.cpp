@@ -512,18 +512,26 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
             if (wt.get_requires_grad()) {
                 dw = wt.grad_for_write(&none);
                 if (!none) mask |= 2;
-                else if (fa && dx) defer_w = true;   // the dX workgroups read W: the next launch updates it
+                else if (fa && dx) {
+                    // one-launch form: the dX workgroups read W, the next launch updates it.  Products as launches of their own (the big
+                    // shapes): the dX product is through with W when the dW product runs -- the update rides in ITS epilogue, under the
+                    // matrix work of the other tiles, instead of costing a pass over p / m / v / g of its own (4096 x 4096: 75 us each)
+                    const bool ep_wanted = !(mask & 1) && x.grad_->relu_output;
+                    if (th_linear_bwd_separate_products(batch, in_f, out_f, 1, 1, ep_wanted ? 1 : 0) && fa->fuse_for(wt, &wf)) pw = &wf;
+                    else defer_w = true;
+                }
                 else if (fa && fa->fuse_for(wt, &wf)) pw = &wf;
             }
             // the consumer of this layer's output left the column sums of the (masked) gradient by row block beside it: the bias gradient
             // is their sum (tensor.rs:686-691), no pass over [batch, out] for it
             const std::shared_ptr<Buffer> colpart_in = (relu_y == nullptr && relu) ? r.grad_->dz_colpart : nullptr;
             const int colpart_in_rows = r.grad_->dz_colpart_rows;
-            bool db_from_colpart = false, db_none = true;
+            bool db_from_colpart = false, db_none = true, defer_b = false;
             if (b.defined() && b.get_requires_grad()) {
                 db = b.grad_for_write(&none);
                 db_none = none;
                 if (!none) mask |= 4;
+                else if (fa && colpart_in) defer_b = true;   // the gradient is a sum over a few rows of partials below: its update is carried by a later launch
                 else if (fa && fa->fuse_for(b, &bf)) pb = &bf;
                 db_from_colpart = colpart_in != nullptr && pb == nullptr;
             }
@@ -537,6 +545,7 @@ Tensor Tensor::linear(const Tensor &w, const Tensor &bias, bool relu) const {  /
                 if (db_none) TH(th_colsum(c, colpart_in->d, db, colpart_in_rows, out_f));
                 else TH(th_colsum_accum(c, colpart_in->d, db, colpart_in_rows, out_f));
             }
+            if (defer_b) fa->defer_for(b);
             if (ep_rows > 0) {
                 x.grad_->premasked = true;
                 x.grad_->dz_colpart = colpart_out;
