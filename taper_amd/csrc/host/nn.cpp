@@ -1478,7 +1478,15 @@ static bool mlp2_layers(const Module *model, std::vector<Tensor> *w, std::vector
 bool Trainer::mlp2_step(size_t batch, int64_t n_rows) const {
     if (fuse_head < 2 || !sample_shape.empty() || batch < mlp2_min_batch()) return false;
     std::vector<Tensor> w, b;
-    return mlp2_layers(model.get(), &w, &b) && mlp2_params_ok(w, b) && mlp2_shapes_ok(batch, w, n_rows);
+    if (!(mlp2_layers(model.get(), &w, &b) && mlp2_params_ok(w, b) && mlp2_shapes_ok(batch, w, n_rows))) return false;
+    // Two hidden layers: below ~1 800 rows the two-launch classifier (th_mlp3_xent behind a gather) is the faster step where it applies --
+    // 26.7 / 30.3 / 32.8 / 39.2 us at 512 / 768 / 1 024 / 1 536 rows against 34.4 / 35.8 / 37.7 / 42.0 for th_mlp2_xent_deep, whose 16-row
+    // blocks each leave a whole [h2][h1] share of dW2 behind; 47.5 against 43.7 at 2 048 (tools/mlp_min_batch_probe.py, r05)
+    static const size_t deep_min = [] { const char *e = std::getenv("TAPER_MLP2_DEEP_MIN_BATCH"); return e ? (size_t)std::max(32, atoi(e)) : (size_t)1792; }();
+    if (w.size() == 3 && batch < deep_min && mlp3_fuse() &&
+        th_mlp3_supported((int)batch, (int)w[0].shape()[1], (int)w[0].shape()[0], (int)w[1].shape()[0], (int)w[2].shape()[0]))
+        return false;
+    return true;
 }
 
 void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_row_source *rows) {

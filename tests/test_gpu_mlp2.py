@@ -165,7 +165,7 @@ def _mlp2_calls():
 @pytest.mark.parametrize("n,batch,shuffle,model", [(10000, 4096, True, "mlp_baseline"), (40000, 16384, True, "mlp_baseline"), (8192, 4096, False, "mlp_baseline"),
                                                    (20000, 20000, False, "mlp_baseline"),
                                                    # examples/train_mnist.rs:40-48's own model (two hidden layers) through th_mlp2_xent_deep
-                                                   (10000, 4096, True, "mlp_example"), (40000, 16384, True, "mlp_example"), (3000, 1024, True, "mlp_example"),
+                                                   (10000, 4096, True, "mlp_example"), (40000, 16384, True, "mlp_example"), (5000, 2048, True, "mlp_example"),
                                                    # hidden widths that are no multiples of 32 / 16 take the same step (ragged tiles)
                                                    (10000, 4096, True, "mlp_100"), (3000, 1024, True, "mlp_100_52")])
 def test_trainer_large_batch_epochs_match_oracle(n, batch, shuffle, model):
