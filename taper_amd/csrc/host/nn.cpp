@@ -1329,6 +1329,7 @@ float Communicator::time_exchange(Adam &opt, int reps) {
     for (int i = 0; i < reps; ++i) once();
     TH(th_event_record(ctx, e1));
     Device::sync();
+    opt.set_step_guard(nullptr);   // the word lives in this communicator's state block: a later opt.step() must not read it once we are gone
     float ms = 0.f;
     TH(th_event_elapsed_ms(e0, e1, &ms));
     th_event_destroy(e0);
@@ -1511,6 +1512,7 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
         if (!(comm && optimizer->step_reduced(*comm))) {
             reduce_grads(*this);
             optimizer->step();
+            optimizer->set_step_guard(nullptr);   // (the guard is the communicator's word: it must not outlive this call in the optimizer -- ADVICE r04)
         }
         optimizer->zero_grad();
         return;
@@ -1593,6 +1595,7 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
     if (!(comm && optimizer->step_reduced(*comm))) {   // peer-to-peer communicator: all-reduce + Adam in one launch
         reduce_grads(*this);
         optimizer->step();
+        optimizer->set_step_guard(nullptr);
     }
     optimizer->zero_grad();
     if (adam) adam->set_carry_deferred(false);
