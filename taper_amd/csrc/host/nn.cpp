@@ -1625,6 +1625,8 @@ void Trainer::enqueue_steps(const float *d_images, const float *d_labels, const 
 void Trainer::drop_graphs() {
     for (auto &g : graphs_) th_graph_destroy(g.second);
     graphs_.clear();
+    for (auto &g : whole_graphs_) th_graph_destroy(g.second);
+    whole_graphs_.clear();
 }
 
 EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
@@ -1663,7 +1665,6 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
         // host reads it after ONE stream synchronisation -- a staged device-to-host copy costs a short run (the contract's 20 steps) ~20 us
         metrics_ = Buffer::alloc_host(2 * metrics_cap_);
     }
-    TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // step = 0, cursor = 0
     // Everything a captured step bakes in as a kernel argument or as a choice of launch sequence: the dataset and index
     // buffers (two loaders over one dataset share the images but own their index vectors), the epoch length the gather
     // wraps at, the label buffer, the fusion switches, the input reshape, the communicator, the optimizer's arenas.
@@ -1685,6 +1686,21 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     if (!graphs_.empty() && graph_key_ != key) drop_graphs();
 
     size_t done = 0;
+    // A call that is ONE graph of full batches (the contract's 20 steps; any short run repeated) replays a graph that also holds the state
+    // reset in front of its steps: one host launch instead of two and no stream gap between them (3.5 us of host time in front of the
+    // replay + the reset's own launch: ~5 of such a call's 250 us, r05).  Recorded below, by the first call of that length that finds its
+    // plain graph in place.
+    th_graph *whole = nullptr;
+    if (nb == n_full && !graph_capture_failed_ && !(std::getenv("TAPER_NO_GRAPH") && std::getenv("TAPER_NO_GRAPH")[0] == '1'))
+        for (auto &g : whole_graphs_)
+            if (g.first == n_full) whole = g.second;
+    const double us_prep = us_since(t_enter);
+    if (!whole) TH(th_fill_f32(ctx, state_->d, 0.f, 4));  // step = 0, cursor = 0
+    const double us_fill = us_since(t_enter);
+    if (whole) {
+        TH(th_graph_launch(ctx, whole));
+        done = n_full;
+    }
     // Graph sizes still missing for this epoch length (a short first call -- e.g. a 2-step warm-up -- only
     // records the 1-step graph; the chunk graph is added by the first call long enough to use it).
     auto have = [&](size_t steps) {
@@ -1710,7 +1726,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             want.push_back(steps);
         if (steps == 1) break;
     }
-    if (!want.empty() && n_full > 0 && !graph_capture_failed_) {
+    if (!whole && !want.empty() && n_full > 0 && !graph_capture_failed_) {
         // step 0 runs eagerly (pool warm-up, has_grad mask upload); then the SAME host code
         // is run under stream capture to record the op list of 1 step and of a chunk of
         // steps (one hipGraphLaunch per chunk amortises the ~10 us host cost of a replay)
@@ -1740,7 +1756,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     // What an epoch leaves over after its whole chunks (937 steps = 7 x 128 + 41), or a short run as a whole (20 steps), would replay as one
     // ladder graph per set bit (41 = 32 + 8 + 1; 20 = 16 + 4), ~10 us of host time and a stream gap each: the first call that meets such a
     // remainder records ONE graph of exactly that many steps (the ladder graphs are complete by then; at most four distinct remainders).
-    {
+    if (!whole) {
         const size_t tail = n_full - done > 0 ? (n_full - done) % chunk : 0;
         size_t exact = 0;
         for (auto &g : graphs_) exact += (g.first & (g.first - 1)) != 0 ? 1 : 0;
@@ -1769,6 +1785,31 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             }
         }
     }
+    if (!whole && done == 0 && nb == n_full && n_full >= 2 && have(n_full) && whole_graphs_.size() < 4 && !graph_capture_failed_ && graph_key_ == key) {
+        TH(th_graph_begin(ctx));
+        th_graph *g = nullptr;
+        try {
+            TH(th_fill_f32(ctx, state_->d, 0.f, 4));
+            enqueue_steps(d_img, d_lab, d_idx, (int64_t)n, bs, n_full);
+            TH(th_graph_end(ctx, &g));
+            whole_graphs_.emplace_back(n_full, g);
+            // ... and serves this very call (a second reset in front of the steps changes nothing): a graph's FIRST replay pays its
+            // upload, which must not fall into a later, timed call
+            TH(th_graph_launch(ctx, g));
+            done = n_full;
+        } catch (const std::exception &e) {
+            fprintf(stderr, "taper: capturing a whole-call graph of %zu steps failed (%s); reset + replay stay two launches\n", n_full, e.what());
+            if (!g) th_graph_end(ctx, &g);
+            if (g) th_graph_destroy(g);
+            if (auto *adam = dynamic_cast<Adam *>(optimizer.get())) {
+                adam->set_carry_deferred(false);
+                adam->drop_step_bookkeeping();
+            }
+            optimizer->zero_grad();
+            Tape::reset();
+            if (!comm) throw;
+        }
+    }
     while (done < n_full) {
         bool launched = false;
         for (auto &g : graphs_) {
@@ -1793,7 +1834,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     const double us_enqueued = us_since(t_enter);
     Device::sync();
     check_comm();
-    if (trace) fprintf(stderr, "taper trace: train_epoch_graph %zu steps: enqueued after %.1f us, stream idle after %.1f us\n", nb, us_enqueued, us_since(t_enter));
+    if (trace) fprintf(stderr, "taper trace: train_epoch_graph %zu steps: state reset enqueued at %.1f - %.1f us, all enqueued after %.1f us, stream idle after %.1f us\n", nb, us_prep, us_fill, us_enqueued, us_since(t_enter));
     const float *mt = metrics_->d;   // host-visible (th_host_malloc); every step's entry has landed once the stream is idle
     EpochResult r;
     r.num_batches = nb;

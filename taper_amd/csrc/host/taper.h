@@ -758,6 +758,7 @@ class Trainer {  // train.rs:74-172
     bool mlp2_step(size_t batch, int64_t n_rows) const;   // this model at this batch takes th_mlp2_xent (rows read in place)
     void drop_graphs();
     std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
+    std::vector<std::pair<size_t, th_graph *>> whole_graphs_;  // (steps, graph): state reset + that many full steps -- a whole call in one replay
     bool graph_capture_failed_ = false;
     std::vector<uintptr_t> graph_key_;   // what the captured steps bake in (train_epoch_graph); a mismatch drops the graphs
     std::shared_ptr<Buffer> xb_, yb_, state_, metrics_, step_loss_, step_ncorrect_;
