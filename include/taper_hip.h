@@ -501,6 +501,21 @@ int th_wide_head_grads(th_ctx *ctx, const float *d_x, const float *d_dl, const f
                        int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss, float *d_ncorrect,
                        float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, const th_adam_fuse *w_fuse,
                        const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse);
+
+/* th_conv_chain_fwd + th_mlp3_xent in TWO launches instead of three -- the front AND the classifier of examples/train_mnist_cnn.rs:35-100
+ * (five Conv2dReLU rows with their pools and the global average pool, then Linear(128,128) + ReLU, Linear(128,64) + ReLU, Linear(64,classes),
+ * softmax cross-entropy): the classifier is row-parallel except for its parameter gradients (th_mlp3_xent above), and the chain launch
+ * holds ONE image per workgroup -- so the image's row of the classifier (forward, loss term, dlogits, the activations' gradients down to the
+ * plane means') runs in the chain launch's last epilogue, on the means it has just formed; launch 2 is th_mlp3_xent's (dW / db of the three
+ * layers over the batch, Adam in the epilogues, the conv bias finish `gap`, loss, hit count, step log).  The classifier's row launch was
+ * 10.7 us of the 111 us step.  d_y [n][128] plane means and d_cnt [n][128] (nullable) as th_conv_chain_fwd; the rest as th_mlp3_xent with
+ * d_x = d_y.  _supported: 1 for the compiled reference front (th_conv_chain_supported == 1) ending in 128 plane means, a 128-128-64-classes
+ * classifier (classes <= 16), n a multiple of 16. */
+int th_conv_chain_mlp3_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, int n, int h1, int h2, int classes);
+int th_conv_chain_mlp3_xent(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, float *d_cnt, int n, int c_in,
+                            int h, int w, const float *d_targets, const th_mlp3_layer *layers, float *d_dx, float *d_loss, float *d_ncorrect,
+                            float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_tick, const th_mlp3_gap *gap);
+
 /* 1x1 stride-1 pad-0 convolution as GEMM.  layout 0 = taper (raw NCHW buffer
  * reinterpreted as [N*H*W, C], tensor.rs:1799-1801, Q4 + Q3); 1 = standard. */
 int th_conv1x1_fwd(th_ctx *ctx, const float *d_x, const float *d_w, const float *d_bias, float *d_y,

@@ -18,6 +18,11 @@ TH_USES_DEVICE_ERRORS()
 
 namespace th {
 
+int mlp3_grads_launch(th_ctx *ctx, const float *const dz[3], const float *const act[3], float *const dw[3], float *const db[3],
+                      const int out_f[3], const int in_f[3], const th_adam_fuse *const wf[3], const th_adam_fuse *const bf[3], int batch,
+                      const float *part, int n_blk, float *loss, float *ncorrect, float *metrics, int64_t capacity, int64_t *state,
+                      int64_t advance, const float *gap_dx, const th_mlp3_gap *gap);   // gemm.hip
+
 constexpr int CH_NT = 512;                                                      // threads per workgroup: 8 waves, two per SIMD
 __host__ __device__ constexpr int ch_cis(int wp) { return wp * wp + ((16 - (wp * wp) % 32) + 32) % 32; }   // channel stride = 16 mod 32: the
                                                                                 // two lane groups of a ds_read_b32 half land 16 banks apart
@@ -49,6 +54,20 @@ struct ChainHeadArgs {
     float inv_b;
 };
 
+// The three-layer classifier behind the reference chain's plane means (th_conv_chain_mlp3_xent): Linear(128, 128) + ReLU, Linear(128, 64) + ReLU,
+// Linear(64, classes), softmax cross-entropy -- examples/train_mnist_cnn.rs:53-61 -- ONE ROW per workgroup, in the chain launch's last
+// epilogue: forward, loss term, dlogits and the activations' gradients down to dX depend on the row only (nn.rs:54-60, loss.rs:101-195,
+// ops.rs:254-265, 358-369); what adds over the batch (dW, db, the conv bias) is th_mlp3_xent's second launch, unchanged.
+struct ChainMlp3Args {
+    const float *w1, *b1, *w2, *b2, *w3, *b3;   // [128][128], [128], [64][128], [64], [classes][64], [classes] (biases nullable)
+    const float *targets;                       // [n]
+    float *a1, *a2, *dz1, *dz2, *dz3, *dx;      // [n][128], [n][64], [n][128], [n][64], [n][classes], [n][128] (dx nullable)
+    float *part;                                // [n][2]: the row's NLL, hit
+    int32_t *tick;                              // nullable: t += 1 (optim.rs:84; nothing in this launch reads it)
+    int classes;
+    float inv_b;
+};
+
 struct ConvChainArgs {
     const float *x;            // [n][1][28][28]
     const float *w[5], *b[5];  // taper layout [9 c_in][c_out] (tensor.rs:1262), bias [c_out]
@@ -56,6 +75,7 @@ struct ConvChainArgs {
     float *cnt;                // reference chain: [n][128] outputs > 0 per plane (nullable)
     int n;
     ChainHeadArgs head;        // conv_chain_simple_kernel<true, ..> only
+    ChainMlp3Args head3;       // conv_chain_reference_kernel<false, true> only
 };
 
 // ---- one 3x3 / pad 1 layer on the matrix cores: IN [C_IN][CIS] padded planes in LDS -> NSLOT accumulator tiles per wave ------------------------
@@ -425,8 +445,138 @@ static_assert(32 * ch_cis(30) <= CR_IMG && CR_T4 + 64 * ch_tile_ld(196) <= CR_LD
 // conv5's k loop and stored into IMG behind it (IMG is nobody's after conv1), conv2's first weight pass rides in conv5's last pass like any
 // next layer's, conv1's weights stay in their registers: a workgroup's next image starts without the launch, the image round trip and the
 // weight round trips that a fresh workgroup pays.  Same per-image arithmetic: bit-identical outputs.  LOOP = false is r04's kernel as it was.
+// xs: LDS [128], the image's plane means.  sc: LDS scratch, >= 1 200 floats, disjoint from xs.  512 threads; ends without a barrier (global
+// stores only).  Every weight is requested up front, in the order of use, as the operand registers of the thread that will use it
+// (forward: a thread owns a k range of one output row -- float4 along k; backward: a thread owns a range of the contracted index for one
+// output column -- dwords, lanes on consecutive columns): the weights cross the fabric while the means are being formed and while the
+// earlier stages run; 197 KB per workgroup from L2.  Sums: a thread's range in ascending index order, then a fixed tree over the threads
+// of an output (forward: xor shuffles; backward: four partial sums through LDS, ((0 + 1) + (2 + 3))) -- deterministic, and within fp32
+// rounding of the k-ordered chain like every product here (tolerance 1e-4).
+struct ChainMlp3W {
+    float4 f1[8], f2[4], f3;       // W1[o = t >> 2][32 (t & 3) ..], W2[o = t >> 3][16 (t & 7) ..], W3[o = t >> 4][4 (t & 15) ..]
+    float b3c[16], b2c[16], b1c[32];   // W3[c][j = t] (t < 64), W2[16 (t >> 7) + q][i = t & 127], W1[32 (t >> 7) + q][k = t & 127]
+};
+__device__ __forceinline__ void chain_mlp3_weights(const ChainMlp3Args &h, ChainMlp3W &w, int t) {
+    const float4 *r1 = reinterpret_cast<const float4 *>(h.w1 + (t >> 2) * 128 + 32 * (t & 3));
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w.f1[q] = r1[q];
+    const float4 *r2 = reinterpret_cast<const float4 *>(h.w2 + (t >> 3) * 128 + 16 * (t & 7));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w.f2[q] = r2[q];
+    w.f3 = (t >> 4) < h.classes ? *reinterpret_cast<const float4 *>(h.w3 + (t >> 4) * 64 + 4 * (t & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) w.b3c[c] = (t < 64 && c < h.classes) ? h.w3[c * 64 + t] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w.b2c[q] = h.w2[(16 * (t >> 7) + q) * 128 + (t & 127)];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) w.b1c[q] = h.w1[(32 * (t >> 7) + q) * 128 + (t & 127)];
+}
+
+__device__ __forceinline__ void chain_mlp3_rows(const ChainMlp3Args &h, const ChainMlp3W &w, const float *xs, float *sc, int img, int t) {
+    float *A1 = sc, *A2 = sc + 128, *LG = sc + 192, *D3 = sc + 208, *D2 = sc + 224, *D1 = sc + 288, *RED = sc + 416;   // RED [4][128]
+    const int lane = t & 63, r16 = lane & 15, g4 = lane >> 4;
+    if (h.tick && img == 0 && t == 0) h.tick[0] += 1;
+    {   // A1 = relu(W1 x + b1) (nn.rs:54-60, activation.rs:10-12)
+        const int o = t >> 2, p = t & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 x4 = *reinterpret_cast<const float4 *>(xs + 32 * p + 4 * q);
+            s = fmaf(w.f1[q].x, x4.x, s); s = fmaf(w.f1[q].y, x4.y, s); s = fmaf(w.f1[q].z, x4.z, s); s = fmaf(w.f1[q].w, x4.w, s);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += h.b1 ? h.b1[o] : 0.f;
+        s = s > 0.f ? s : 0.f;
+        if (p == 0) { A1[o] = s; h.a1[(long)img * 128 + o] = s; }
+    }
+    chain_sync();
+    {   // A2 = relu(W2 A1 + b2)
+        const int o = t >> 3, p = t & 7;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 x4 = *reinterpret_cast<const float4 *>(A1 + 16 * p + 4 * q);
+            s = fmaf(w.f2[q].x, x4.x, s); s = fmaf(w.f2[q].y, x4.y, s); s = fmaf(w.f2[q].z, x4.z, s); s = fmaf(w.f2[q].w, x4.w, s);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += h.b2 ? h.b2[o] : 0.f;
+        s = s > 0.f ? s : 0.f;
+        if (p == 0) { A2[o] = s; h.a2[(long)img * 64 + o] = s; }
+    }
+    chain_sync();
+    {   // logits = W3 A2 + b3
+        const int o = t >> 4, p = t & 15;
+        const float4 x4 = *reinterpret_cast<const float4 *>(A2 + 4 * p);
+        float s = fmaf(w.f3.x, x4.x, 0.f);
+        s = fmaf(w.f3.y, x4.y, s); s = fmaf(w.f3.z, x4.z, s); s = fmaf(w.f3.w, x4.w, s);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        if (p == 0 && o < 16) LG[o] = o < h.classes ? s + (h.b3 ? h.b3[o] : 0.f) : 0.f;
+    }
+    chain_sync();
+    {   // softmax cross-entropy of the row (loss.rs:101-195, 271-290): every wave, redundantly -- no exchange
+        float lg[4], dl[4], nll;
+        int bi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg[i] = g4 * 4 + i < h.classes ? LG[g4 * 4 + i] : -INFINITY;
+        const float tf = h.targets[img];
+        tail_row_softmax(lg, g4, h.classes, tf, h.inv_b, dl, nll, bi);
+        if (t < 64 && r16 == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                D3[g4 * 4 + i] = dl[i];
+                if (g4 * 4 + i < h.classes) h.dz3[(long)img * h.classes + g4 * 4 + i] = dl[i];
+            }
+            if (g4 == 0) {
+                h.part[(long)img * 2] = nll;
+                h.part[(long)img * 2 + 1] = fabsf((float)bi - tf) < 1e-6f ? 1.f : 0.f;   // loss.rs:283
+            }
+        }
+    }
+    chain_sync();
+    if (t < 64) {   // dZ2 = (dlogits W3) * [A2 > 0] (ops.rs:254-265, 358-369): class order
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s = fmaf(D3[c], w.b3c[c], s);      // (classes beyond h.classes: dlogits and weights are zero)
+        s = A2[t] > 0.f ? s : 0.f;
+        D2[t] = s;
+        h.dz2[(long)img * 64 + t] = s;
+    }
+    chain_sync();
+    {   // dZ1 = (dZ2 W2) * [A1 > 0]
+        const int i = t & 127, jp = t >> 7;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s = fmaf(D2[16 * jp + q], w.b2c[q], s);
+        RED[jp * 128 + i] = s;
+    }
+    chain_sync();
+    if (t < 128) {
+        float s = (RED[t] + RED[128 + t]) + (RED[256 + t] + RED[384 + t]);
+        s = A1[t] > 0.f ? s : 0.f;
+        D1[t] = s;
+        h.dz1[(long)img * 128 + t] = s;
+    }
+    if (!h.dx) return;                          // (uniform)
+    chain_sync();
+    {   // dX = dZ1 W1 (the plane means' gradient: the last conv's bias takes it from there, th_mlp3_gap)
+        const int k = t & 127, ip = t >> 7;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) s = fmaf(D1[32 * ip + q], w.b1c[q], s);
+        RED[ip * 128 + k] = s;                  // (RED's readers of the stage before are behind the barrier above)
+    }
+    chain_sync();
+    if (t < 128) h.dx[(long)img * 128 + t] = (RED[t] + RED[128 + t]) + (RED[256 + t] + RED[384 + t]);
+}
+
 static_assert(CR_T4 + 64 * ch_tile_ld(196) <= CR_IMG && 32 * ch_tile_ld(784) <= CR_IMG && CR_T5 + 128 * ch_tile_ld(49) <= CR_IMG, "IMG is free behind conv1");
-template <bool LOOP>
+template <bool LOOP, bool HEAD3 = false>
 __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -516,6 +666,8 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
             chain_mfma<7, 64, 128>(A4, a.w[4], wc, acc, wave, lane);
         }
         chain_store<7, 128, false>(acc, bv, T5, wave, lane);     // (T5 does not overlap A4)
+        ChainMlp3W hw;
+        if constexpr (HEAD3) chain_mlp3_weights(a.head3, hw, t);  // the classifier's weights: in flight under the plane means
         if constexpr (LOOP) {
             if (nimg < a.n) {
                 IMG[(t / 28 + 1) * 30 + t % 28 + 1] = px[0];
@@ -543,7 +695,13 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
             if (l == 0) {
                 a.y[(long)img * 128 + c] = sum / 49.0f;
                 if (a.cnt) a.cnt[(long)img * 128 + c] = k;
+                if constexpr (HEAD3) A4[c] = sum / 49.0f;         // (A4 is dead: every wave is behind the barrier above)
             }
+        }
+        if constexpr (HEAD3) {
+            chain_sync();
+            CH_STAMP(13);
+            chain_mlp3_rows(a.head3, hw, A4, A4 + 128, img, t);
         }
 #ifdef TH_PROFILE
         chain_sync();
@@ -1567,6 +1725,58 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
     t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;
     TH_LAUNCH_CHECK();
     return 0;
+}
+
+// th_conv_chain_fwd + th_mlp3_xent in TWO launches instead of three: the reference CNN's front with its three-layer classifier's rows in the
+// last epilogue (chain_mlp3_rows), then th_mlp3_xent's own second launch (mlp3_grads_launch, gemm.hip).  The classifier's row launch was
+// 10.7 us of the 111 us step, 2.7 of them waiting for the plane means it starts from to come back from memory.
+int th_conv_chain_mlp3_supported(int c_in, int h, int w, const th_conv_stage *stages, int n_stages, int n, int h1, int h2, int classes) {
+    if (!stages || n_stages < 1 || n < 1 || n % 16 != 0 || chain_loop(n)) return 0;
+    if (stages[n_stages - 1].post != TH_CHAIN_GLOBAL_AVG || stages[n_stages - 1].c_out != 128) return 0;
+    if (h1 != 128 || h2 != 64 || classes < 1 || classes > 16) return 0;
+    return th_conv_chain_supported(c_in, h, w, stages, n_stages) == 1 ? 1 : 0;      // the compiled reference instance
+}
+
+int th_conv_chain_mlp3_xent(th_ctx *ctx, const float *d_x, const th_conv_stage *stages, int n_stages, float *d_y, float *d_cnt, int n, int c_in,
+                            int h, int w, const float *d_targets, const th_mlp3_layer *layers, float *d_dx, float *d_loss, float *d_ncorrect,
+                            float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, int32_t *d_tick, const th_mlp3_gap *gap) {
+    TH_REQUIRE(ctx && d_x && d_y && stages && d_targets && layers && d_loss, "th_conv_chain_mlp3_xent: null argument");
+    const int h1 = layers[0].out_features, h2 = layers[1].out_features, c = layers[2].out_features;
+    TH_REQUIRE(th_conv_chain_mlp3_supported(c_in, h, w, stages, n_stages, n, h1, h2, c),
+               "th_conv_chain_mlp3_xent: needs the compiled reference front ending in 128 plane means, a 128-128-64-classes classifier (classes <= 16) "
+               "and a batch that is a multiple of 16 (got %d images, %d-%d-%d)", n, h1, h2, c);
+    for (int l = 0; l < 3; ++l) {
+        TH_REQUIRE(layers[l].d_w && ((uintptr_t)layers[l].d_w & 15) == 0, "th_conv_chain_mlp3_xent: weights must be 16-byte aligned");
+        TH_REQUIRE(!(layers[l].w_fuse && layers[l].w_fuse->d_p) || layers[l].d_dw, "th_conv_chain_mlp3_xent: a fused weight update needs d_dw");
+        TH_REQUIRE(!(layers[l].b_fuse && layers[l].b_fuse->d_p) || layers[l].d_db, "th_conv_chain_mlp3_xent: a fused bias update needs d_db");
+    }
+    TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_conv_chain_mlp3_xent: metrics need d_state and a capacity");
+    TH_REQUIRE(!(gap && gap->d_cnt) || (d_dx && gap->d_gb && gap->hw > 0 && gap->d_cnt == d_cnt),
+               "th_conv_chain_mlp3_xent: the gap bias finish needs d_dx, d_gb, hw > 0 and the counts this launch writes");
+    // workspace: A1, A2, dZ1, dZ2, dZ3, the rows' {NLL, hit}
+    const size_t n1 = (size_t)n * 128, n2 = (size_t)n * 64, n3 = (size_t)n * c, n3p = (n3 + 3) & ~(size_t)3;
+    void *ws = nullptr;
+    if (th_malloc(ctx, (2 * n1 + 2 * n2 + n3p + 2 * (size_t)n) * sizeof(float), &ws)) return 1;
+    float *a1 = (float *)ws, *a2 = a1 + n1, *dz1 = a2 + n2, *dz2 = dz1 + n1, *dz3 = dz2 + n2, *part = dz3 + n3p;
+    ConvChainArgs a{};
+    a.x = d_x; a.y = d_y; a.cnt = d_cnt; a.n = n;
+    for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
+    a.head3 = ChainMlp3Args{layers[0].d_w, layers[0].d_b, layers[1].d_w, layers[1].d_b, layers[2].d_w, layers[2].d_b, d_targets,
+                            a1, a2, dz1, dz2, dz3, d_dx, part, d_tick, c, 1.0f / (float)n};
+    const int lds = CR_LDS * (int)sizeof(float);
+    (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((conv_chain_reference_kernel<false, true>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+    t_last_conv_cfg[0] = 1; t_last_conv_cfg[1] = 9; t_last_conv_cfg[2] = 0;   // 9: a conv chain with the three-layer classifier's rows
+    t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;
+    TH_LAUNCH_CHECK();
+    const float *dz[3] = {dz1, dz2, dz3}, *act[3] = {d_y, a1, a2};
+    float *dw[3] = {layers[0].d_dw, layers[1].d_dw, layers[2].d_dw}, *db[3] = {layers[0].d_db, layers[1].d_db, layers[2].d_db};
+    const int out_f[3] = {h1, h2, c}, in_f[3] = {128, h1, h2};
+    const th_adam_fuse *wf[3] = {layers[0].w_fuse, layers[1].w_fuse, layers[2].w_fuse}, *bf[3] = {layers[0].b_fuse, layers[1].b_fuse, layers[2].b_fuse};
+    if (int rc = th::mlp3_grads_launch(ctx, dz, act, dw, db, out_f, in_f, wf, bf, n, part, n, d_loss, d_ncorrect, d_metrics, metrics_capacity, d_state,
+                                       advance, d_dx, gap))
+        return rc;
+    return th_free(ctx, ws);
 }
 
 // the classifier rows ride in the chain's last epilogue where the chain ends in a pooled map that fits a thread's registers (<= 7 elements

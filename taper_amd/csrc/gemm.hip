@@ -363,12 +363,35 @@ __global__ __launch_bounds__(256) void mlp3_grads_kernel(Mlp3GradArgs a) {
     __shared__ float red[4][64][4];
     const int bid = blockIdx.x;
     if (bid >= a.first[4]) {
-        if (threadIdx.x == 0) {
-            float n = 0.f, h = 0.f;
+        float n = 0.f, h = 0.f;
+        if (a.n_blk > 32) {
+            // one entry per ROW (th_conv_chain_mlp3_xent): thread t adds entries t, t + 256, ... in order, then a fixed tree over the 256 threads
+            // (one thread walking hundreds of entries is a chain of dependent round trips)
+            for (int b = threadIdx.x; b < a.n_blk; b += 256) {
+                n += a.part[2 * b];
+                h += a.part[2 * b + 1];
+            }
+            float *sh = &red[0][0][0];
+            sh[threadIdx.x] = n;
+            sh[256 + threadIdx.x] = h;
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const int t = threadIdx.x;
+                n = (sh[t] + sh[t + 64]) + (sh[t + 128] + sh[t + 192]);
+                h = (sh[256 + t] + sh[320 + t]) + (sh[384 + t] + sh[448 + t]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    n += __shfl_xor(n, off, 64);
+                    h += __shfl_xor(h, off, 64);
+                }
+            }
+        } else if (threadIdx.x == 0) {
             for (int b = 0; b < a.n_blk; ++b) {
                 n += a.part[2 * b];
                 h += a.part[2 * b + 1];
             }
+        }
+        if (threadIdx.x == 0) {
             const float l = n / (float)a.batch;   // loss.rs:164
             a.loss[0] = l;
             if (a.ncorrect) a.ncorrect[0] = h;

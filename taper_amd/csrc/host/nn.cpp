@@ -555,6 +555,85 @@ Tensor mlp3_cross_entropy(const Tensor &x, const Tensor (&w)[3], const Tensor (&
     return loss;
 }
 
+bool conv_chain_mlp3_supported(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor (&w)[3], const Tensor (&b)[3]) {
+    if (stages.empty() || stages.back().post != TH_CHAIN_GLOBAL_AVG || x.shape().size() != 4) return false;
+    static const size_t max_batch = [] { const char *e = std::getenv("TAPER_CHAIN_MLP3_MAX_BATCH"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)384; }();
+    if (x.shape()[0] > max_batch) return false;   // (one image per workgroup: at 1 024 images the classifier's own row launch is the faster form, 393 against 403 us)
+    size_t in_f = stages.back().weight.shape()[0];
+    for (int l = 0; l < 3; ++l) {
+        if (w[l].shape().size() != 2 || w[l].shape()[1] != in_f) return false;
+        if (!w[l].get_requires_grad() || w[l].has_grad()) return false;
+        if (!b[l].defined() || b[l].shape() != Shape{w[l].shape()[0]} || !b[l].get_requires_grad() || b[l].has_grad()) return false;
+        if (((uintptr_t)w[l].dptr() & 15) != 0) return false;
+        in_f = w[l].shape()[0];
+    }
+    const Tensor &cb = stages.back().bias;
+    if (cb.defined() && cb.get_requires_grad() && cb.has_grad()) return false;   // gradients are written, never accumulated
+    return x.conv_chain_mlp3_supported(stages, (int)w[0].shape()[0], (int)w[1].shape()[0], (int)w[2].shape()[0]) != 0;
+}
+
+Tensor conv_chain_mlp3_cross_entropy(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor (&w)[3], const Tensor (&b)[3],
+                                     const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log) {
+    // nn.rs:149-151 (conv rows, pool rows, Flatten, the classifier) + loss.rs:136-195 + the backward closures of the three Linear layers and
+    // their ReLU nodes (ops.rs:238-294, 358-369; tensor.rs:574-587, 674-694) and of the last Conv2dReLU's bias behind the global average pool
+    // (tensor.rs:1626-1628, ops.rs:358-369 through the positive counts): mlp3_cross_entropy on the chain's plane means, one launch less
+    TAPER_ASSERT(conv_chain_mlp3_supported(x, stages, w, b), "conv_chain_mlp3_cross_entropy: unsupported stages / shapes / gradient state");
+    TAPER_ASSERT(targets.shape()[0] == x.shape()[0], "Batch sizes must match");
+    Adam *fa = FusedAdamScope::active();
+    if (fa && fa->has_deferred()) fa->flush_deferred();   // updates an earlier (other) step form left behind: with their own counter
+    const size_t n = x.shape()[0], c_last = stages.back().weight.shape()[0];
+    Tensor loss = Tensor::empty({1});
+    float *nc = nullptr;
+    if (n_correct_out) {
+        *n_correct_out = Tensor::empty({1});
+        nc = n_correct_out->dptr();
+    }
+    auto slot = [](const Tensor &p) -> float * {
+        if (!p.grad_->buf) p.grad_->buf = Buffer::alloc(p.len());
+        p.grad_->known_zero = false;
+        return p.grad_->buf->d;
+    };
+    th_mlp3_layer layers[3];
+    th_adam_fuse wf[3], bf[3];
+    for (int l = 0; l < 3; ++l) {
+        layers[l] = th_mlp3_layer{w[l].dptr(), b[l].dptr(), slot(w[l]), slot(b[l]), nullptr, nullptr, (int)w[l].shape()[0]};
+        if (fa) {
+            if (fa->fuse_for(w[l], &wf[l])) layers[l].w_fuse = &wf[l];
+            if (fa->fuse_for(b[l], &bf[l])) layers[l].b_fuse = &bf[l];
+        }
+    }
+    // the last conv's bias (the only conv parameter the reference's tape reaches, quirk Q2): its gradient is formed by the gradient launch
+    // from the plane means' gradient and the positive counts the chain launch leaves
+    const Tensor &cbias = stages.back().bias;
+    const bool cb_grad = cbias.defined() && cbias.get_requires_grad() && !NoGradScope::active();
+    std::shared_ptr<Buffer> cnt = cb_grad ? Buffer::alloc(n * c_last) : nullptr, dx = cb_grad ? Buffer::alloc(n * c_last) : nullptr;
+    th_mlp3_gap gap{};
+    th_adam_fuse gf{};
+    size_t hw = x.shape()[2] * x.shape()[3];
+    for (const auto &st : stages)
+        if (st.post == TH_CHAIN_MAXPOOL2) hw /= 4;
+    if (cb_grad) {
+        gap.d_cnt = cnt->d;
+        gap.d_gb = slot(cbias);
+        gap.hw = (int)hw;
+        if (fa && fa->fuse_for(cbias, &gf)) gap.b_fuse = &gf;
+    }
+    Tensor means = x.conv_chain_mlp3(stages, cnt ? cnt->d : nullptr, targets.dptr(), layers, dx ? dx->d : nullptr, loss.dptr(), nc,
+                                     log ? log->d_metrics : nullptr, log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0,
+                                     fa ? fa->d_tick() : nullptr, cb_grad ? &gap : nullptr);
+    loss.set_requires_grad(true);
+    std::vector<Tensor> params{w[0], b[0], w[1], b[1], w[2], b[2]};
+    if (cb_grad) params.push_back(cbias);
+    Tensor out = loss, keep = means;
+    Tape::push(loss, true, [params, out, keep]() {
+        if (!out.has_grad()) return;
+        // the gradients were produced by the forward launches for an upstream grad of exactly 1
+        TAPER_ASSERT(out.grad_->shared_const, "conv_chain_mlp3_cross_entropy: only loss.backward() from the root is supported");
+        for (const Tensor &p : params) p.grad_->has = true;
+    });
+    return loss;
+}
+
 float accuracy(const Tensor &pred, const Tensor &targets) {  // loss.rs:271-290
     TAPER_ASSERT(pred.shape()[0] == targets.shape()[0], "Batch sizes must match");
     TAPER_ASSERT(pred.shape().size() == 2, "accuracy: predictions must be [B,C]");
@@ -1533,7 +1612,17 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
         const Tensor w3[3] = {hidden0->weight, hidden->weight, last->weight}, b3[3] = {hidden0->bias, hidden->bias, last->bias};
         // (shapes first: the prefix is only run once the form of the step is known)
         const size_t in_f = hidden0->weight.shape()[1];
-        if (th_mlp3_supported((int)batch, (int)in_f, (int)w3[0].shape()[0], (int)w3[1].shape()[0], (int)w3[2].shape()[0])) {
+        // the reference CNN whole (conv rows + pools, global average pool, Flatten, this classifier): its rows in the chain launch
+        if (fuse_head >= 2 && seq->fuse && conv_chain_enabled() && conv_chain_head_enabled() && PoolBiasScope::active() && xin.shape().size() == 4 &&
+            nl >= 8) {
+            auto *fl = dynamic_cast<Flatten *>(seq->layers[nl - 6].get());
+            std::vector<ConvStage> stages;
+            if (fl && fl->start_dim == 1 && seq->conv_stages_at(0, nl - 6, &stages) == nl - 6 && conv_chain_mlp3_supported(xin, stages, w3, b3)) {
+                loss = conv_chain_mlp3_cross_entropy(xin, stages, w3, b3, y, &ncorrect, &sink);
+                used_head = true;
+            }
+        }
+        if (!used_head && th_mlp3_supported((int)batch, (int)in_f, (int)w3[0].shape()[0], (int)w3[1].shape()[0], (int)w3[2].shape()[0])) {
             Tensor xh = seq->forward_prefix(xin, nl - 5);
             if (mlp3_supported(xh, w3, b3)) {
                 loss = mlp3_cross_entropy(xh, w3, b3, y, &ncorrect, &sink);

@@ -184,6 +184,12 @@ class Tensor {
     // returns the pooled map, records NO tape node -- conv_chain_head_cross_entropy (below) owns the step's backward
     int conv_chain_head_supported(const std::vector<ConvStage> &stages, int classes) const;
     Tensor conv_chain_head(const std::vector<ConvStage> &stages, const th_chain_head &head) const;
+    // ... and the reference CNN's front with its three-layer classifier's rows in the chain launch (th_conv_chain_mlp3_xent): runs BOTH launches
+    // of the step, returns the plane means, records NO tape node -- conv_chain_mlp3_cross_entropy (below) owns the step's backward
+    int conv_chain_mlp3_supported(const std::vector<ConvStage> &stages, int h1, int h2, int classes) const;
+    Tensor conv_chain_mlp3(const std::vector<ConvStage> &stages, float *d_cnt, const float *d_targets, const th_mlp3_layer *layers, float *d_dx,
+                           float *d_loss, float *d_ncorrect, float *d_metrics, int64_t capacity, int64_t *d_state, int64_t advance, int32_t *d_tick,
+                           const th_mlp3_gap *gap) const;
     Tensor max_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride /* {0,0} = None */,
                       std::pair<int, int> padding) const;
     Tensor avg_pool2d(std::pair<int, int> kernel, std::pair<int, int> stride, std::pair<int, int> padding) const;
@@ -258,6 +264,12 @@ Tensor linear_cross_entropy_wide(const Tensor &h, const Tensor &weight, const Te
 // configs[2] -- as TWO launches: the chain with the classifier's rows in its last epilogue (th_conv_chain_head_fwd), then every sum over
 // the batch with the Adam updates in the epilogues (th_wide_head_grads).  Same contract as linear_cross_entropy.
 bool conv_chain_head_supported(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor &weight, const Tensor &bias);
+// examples/train_mnist_cnn.rs:35-100 whole -- conv rows, global average pool, Flatten, Linear + ReLU, Linear + ReLU, Linear, cross-entropy -- as
+// TWO launches: the chain with the classifier's rows in its last epilogue, then every parameter gradient with Adam in the epilogues
+// (th_conv_chain_mlp3_xent).  One image per workgroup: worth it while the batch is about one image per CU (TAPER_CHAIN_MLP3_MAX_BATCH, default 384).
+bool conv_chain_mlp3_supported(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor (&w)[3], const Tensor (&b)[3]);
+Tensor conv_chain_mlp3_cross_entropy(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor (&w)[3], const Tensor (&b)[3],
+                                     const Tensor &targets, Tensor *n_correct_out = nullptr, const StepLogSink *log = nullptr);
 Tensor conv_chain_head_cross_entropy(const Tensor &x, const std::vector<ConvStage> &stages, const Tensor &weight, const Tensor &bias,
                                      const Tensor &targets, Tensor *n_correct_out, const StepLogSink *log);
 // x -> relu(x . W1^T + b1) -> . W2^T + b2 -> cross-entropy as TWO launches: th_linear_fwd_ex (which also carries the

@@ -1136,6 +1136,27 @@ Tensor Tensor::conv_chain_head(const std::vector<ConvStage> &stages, const th_ch
     return out;
 }
 
+int Tensor::conv_chain_mlp3_supported(const std::vector<ConvStage> &stages, int h1, int h2, int classes) const {
+    std::vector<th_conv_stage> d;
+    if (!conv_chain_describe(*this, stages, &d)) return 0;
+    if (shape_[0] < 96) return 0;   // (as conv_chain_supported: one image per workgroup)
+    return th_conv_chain_mlp3_supported((int)shape_[1], (int)shape_[2], (int)shape_[3], d.data(), (int)d.size(), (int)shape_[0], h1, h2, classes);
+}
+
+Tensor Tensor::conv_chain_mlp3(const std::vector<ConvStage> &stages, float *d_cnt, const float *d_targets, const th_mlp3_layer *layers, float *d_dx,
+                               float *d_loss, float *d_ncorrect, float *d_metrics, int64_t capacity, int64_t *d_state, int64_t advance,
+                               int32_t *d_tick, const th_mlp3_gap *gap) const {
+    // nn.rs:149-151 over the Conv2dReLU / MaxPool2d / AdaptiveAvgPool2d rows, Flatten (730-756), the Linear + ReLU rows and the last Linear
+    // (54-60), loss.rs:101-195: the rows of the classifier in the chain launch, the sums over the batch in a second one
+    std::vector<th_conv_stage> d;
+    TAPER_ASSERT(conv_chain_describe(*this, stages, &d) && stages.back().post == TH_CHAIN_GLOBAL_AVG, "conv_chain_mlp3: unsupported stages / mode");
+    const int n = (int)shape_[0];
+    Tensor out = empty({(size_t)n, stages.back().weight.shape()[0], 1, 1});
+    TH(th_conv_chain_mlp3_xent(Device::ctx(), dptr(), d.data(), (int)d.size(), out.dptr(), d_cnt, n, (int)shape_[1], (int)shape_[2], (int)shape_[3],
+                               d_targets, layers, d_dx, d_loss, d_ncorrect, d_metrics, capacity, d_state, advance, d_tick, gap));
+    return out;
+}
+
 Tensor Tensor::max_pool2d(std::pair<int, int> k, std::pair<int, int> s, std::pair<int, int> p) const {  // tensor.rs:1391-1521
     TAPER_ASSERT(shape_.size() == 4, "Input must be 4D: [N, C, H, W]");
     if (s.first == 0) s = k;  // stride.unwrap_or(kernel_size)

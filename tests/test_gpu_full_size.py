@@ -209,11 +209,12 @@ def _training_steps_parity(T, name, mode):
         cfg = last_conv_config_host()
         if mode == "graph":
             # the conv chain ran in this process's step (7: with the simple CNN's classifier rows in its last epilogue, th_conv_chain_head_fwd)
-            assert cfg["dma"] == (6 if name == "cnn_reference" else 7) and cfg["ct"] == (1 if name == "cnn_reference" else 2), cfg
+            # (9: with the reference CNN's three-layer classifier's rows in the chain launch, th_conv_chain_mlp3_xent: r05)
+            assert cfg["dma"] == (9 if name == "cnn_reference" else 7) and cfg["ct"] == (1 if name == "cnn_reference" else 2), cfg
         else:
             assert cfg["dma"] in (2, 3, 4, 5, 8), cfg   # a layer-by-layer matrix-core conv ran in this process's step (8: as a one-stage chain)
-        if name == "cnn_reference":     # its three-layer classifier took th_mlp3_xent (two launches) in the captured step
-            assert mlp3_calls() > calls0
+            if name == "cnn_reference":     # its three-layer classifier took th_mlp3_xent (two launches) in the captured step
+                assert mlp3_calls() > calls0
     else:
         losses, ncorrect = [], []
         for s in range(steps):
