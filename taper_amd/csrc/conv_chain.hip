@@ -700,7 +700,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_reference_kernel(ConvChai
         }
         if constexpr (HEAD3) {
             chain_sync();
-            CH_STAMP(13);
+            CH_STAMP(30);                                    // (13 .. 16, 22 .. 29 are the k loops' pass stamps)
             chain_mlp3_rows(a.head3, hw, A4, A4 + 128, img, t);
         }
 #ifdef TH_PROFILE
