@@ -524,6 +524,59 @@ def chain_head_kernels(ctx, n=256, classes=10, reps=100):
                  in_step=True)]
 
 
+def chain_mlp3_kernels(ctx, n=256, classes=10, reps=100):
+    """The TWO launches of the reference CNN's captured step (examples/train_mnist_cnn.rs): th_conv_chain_mlp3_xent's first -- the five conv
+    rows with their pools and the three-layer classifier's row in the last epilogue; bound fp32 MFMA, work = the conv layers' flops + the row's
+    six matrix-vector products -- and its second (th_mlp3_xent's gradient launch: dW / db of the three layers over the batch, the conv bias,
+    loss, Adam in the epilogues; latency-bound: 0.1 MB of parameters)."""
+    from taper_amd import hip
+    _, spec = CNN_CHAINS["cnn_reference"]
+    rng = np.random.default_rng(0)
+    x = ctx.upload(rng.uniform(0, 1, (n, 1, 28, 28)).astype(np.float32))
+    yt = ctx.upload(rng.integers(0, classes, n).astype(np.float32))
+    bufs = [(ctx.upload(rng.uniform(-0.1, 0.1, (co, ci, 3, 3)).astype(np.float32)), ctx.upload(rng.uniform(-0.1, 0.1, co).astype(np.float32)))
+            for ci, co, _ in spec]
+    stages, ns = hip.conv_stages([(w, b, co, post) for (w, b), (_, co, post) in zip(bufs, spec)])
+    sp = C.cast(stages, C.c_void_p)
+    dims = ((128, 128), (64, 128), (classes, 64))
+    layers, keep = (hip.Mlp3Layer * 3)(), []
+    for l, (o, i) in enumerate(dims):
+        b = (ctx.upload(rng.uniform(-0.1, 0.1, (o, i)).astype(np.float32)), ctx.zeros(o), ctx.empty(o * i), ctx.empty(o))
+        keep.append(b)
+        layers[l] = hip.Mlp3Layer(int(b[0]), int(b[1]), int(b[2]), int(b[3]), None, None, o)
+    lp = C.cast(layers, C.c_void_p)
+    means, cnt, gx, gb, loss, nc = ctx.empty(n * 128), ctx.empty(n * 128), ctx.empty(n * 128), ctx.empty(128), ctx.empty(1), ctx.empty(1)
+    gap = hip.Mlp3Gap(int(cnt), int(gb), 49, None)
+    gp = C.cast(C.pointer(gap), C.c_void_p)
+    call = lambda: ctx.call("th_conv_chain_mlp3_xent", x, sp, ns, means, cnt, n, 1, 28, 28, yt, lp, gx, loss, nc, None, 0, None, 0, None, gp)
+    us_both = _time_launches(ctx, call, reps, warm=10)
+    try:
+        hip.hip.th_debug_chain_mlp3_only(1)
+        us1 = _time_launches(ctx, call, reps, warm=10)
+    finally:
+        hip.hip.th_debug_chain_mlp3_only(0)
+    ctx.sync()
+    hw, flops, wbytes = 28, 0.0, 0.0
+    for ci, co, post in spec:
+        flops += 18.0 * ci * co * hw * hw * n
+        wbytes += 4.0 * (9 * ci * co + co)
+        hw = hw // 2 if post == 1 else (1 if post == 2 else hw)
+    p_cls = sum(o * i + o for o, i in dims)
+    flops1 = flops + 6.0 * n * sum(o * i for o, i in dims)                       # forward + the two backward products of every layer, per row
+    nb1 = 4.0 * (n * 784 + n * (2 * 128 + 2 * 128 + 2 * 64 + classes + 2)) + wbytes + 4.0 * p_cls
+    tf = flops1 / (us1 * 1e-6) / 1e12
+    us2 = max(us_both - us1, 1e-3)
+    nb2 = 4.0 * n * (3 * 128 + 2 * 64 + classes + 128) + 28.0 * (p_cls + 128)
+    gbs = nb2 / (us2 * 1e-6) / 1e9
+    return [dict(kernel="conv_chain_reference_kernel<false, true>", layer="conv chain 1->32, 32->32+pool, 32->64, 64->64+pool, 64->128+mean + classifier rows",
+                 us_per_launch=round(us1, 2), alg_flops_per_launch=flops1, alg_bytes_per_launch=nb1, bound="mfma", achieved=round(tf, 2),
+                 peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TF, 4), in_step=True),
+            dict(kernel="mlp3_grads_kernel", layer="dW / db of the classifier, conv bias, loss (+ Adam in the step)", us_per_launch=round(us2, 2),
+                 alg_flops_per_launch=2.0 * n * sum(o * i for o, i in dims), alg_bytes_per_launch=nb2, bound="hbm", achieved=round(gbs, 2),
+                 peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), in_step=True,
+                 note="both launches back to back minus the first alone")]
+
+
 CNN_LAYERS = {
     # (layer, batch, C_in, H = W, C_out, fused 2x2 max-pool epilogue) -- the launches the Trainer's captured step issues
     "cnn_simple": [("conv1+pool 1->32 @28", 256, 1, 28, 32, True), ("conv2+pool 32->64 @14", 256, 32, 14, 64, True)],
@@ -737,8 +790,9 @@ def extra_workloads(T, dataset, with_cpu, only=None):
                 layers = conv_layer_kernels(ctx, CNN_LAYERS[key])
                 for k in layers:
                     k["in_step"] = not chain
-                head = chain and key == "cnn_simple" and os.environ.get("TAPER_CHAIN_HEAD", "1") != "0"
-                rec["kernels"] = (chain_head_kernels(ctx) if head else []) + ([dict(conv_chain_kernel(ctx, key), in_step=not head)] if chain else []) + layers
+                head = chain and os.environ.get("TAPER_CHAIN_HEAD", "1") != "0"     # the classifier's rows ride in the chain launch (both CNNs)
+                rec["kernels"] = ((chain_head_kernels(ctx) if key == "cnn_simple" else chain_mlp3_kernels(ctx)) if head else []) + \
+                                 ([dict(conv_chain_kernel(ctx, key), in_step=not head)] if chain else []) + layers
                 rec["conv_us_per_step"] = round(sum(k["us_per_launch"] for k in rec["kernels"] if k["in_step"]), 1)
                 try:
                     rec["batch_sweep"] = cnn_batch_sweep(T, key, sample_shape, lr, dataset)

@@ -21,6 +21,8 @@ int th_debug_mlp2_ksplit(int ksplit);
 /* 1 = conv chains over more than 256 images run as min(n, 256) workgroups that WALK the images (r05: bit-identical, measured 3 - 5 % slower
  * than one workgroup per image, off by default); 0 = never; -1 = default */
 int th_debug_set_chain_loop(int on);
+/* 1: th_conv_chain_mlp3_xent enqueues its first launch (the chain with the classifier's rows) alone -- per-launch timing; 0: both */
+int th_debug_chain_mlp3_only(int which);
 /* 1 = the compiled chain instances are not used on this thread (their nets take the run-time-described kernel, id 3); 0 = default */
 int th_debug_set_chain_generic(int on);
 /* launch configuration of the most recent matrix-core 3x3 convolution this thread enqueued (the parity

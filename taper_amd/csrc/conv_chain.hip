@@ -1652,6 +1652,11 @@ int th_conv_chain_supported(int c_in, int h, int w, const th_conv_stage *stages,
 }
 
 thread_local int t_chain_loop = -1;   // th_debug_set_chain_loop
+thread_local int t_chain_mlp3_only = 0;   // th_debug_chain_mlp3_only: 1 = th_conv_chain_mlp3_xent runs its first launch alone (per-launch timing)
+int th_debug_chain_mlp3_only(int which) {
+    t_chain_mlp3_only = which == 1 ? 1 : 0;
+    return 0;
+}
 int th_debug_set_chain_loop(int on) {   // test hook: 1 = batches above 256 images take the walking instances on this thread; 0 = never; -1 = default (off)
     t_chain_loop = on < 0 ? -1 : (on ? 1 : 0);
     return 0;
@@ -1769,6 +1774,7 @@ int th_conv_chain_mlp3_xent(th_ctx *ctx, const float *d_x, const th_conv_stage *
     t_last_conv_cfg[0] = 1; t_last_conv_cfg[1] = 9; t_last_conv_cfg[2] = 0;   // 9: a conv chain with the three-layer classifier's rows
     t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;
     TH_LAUNCH_CHECK();
+    if (t_chain_mlp3_only) return th_free(ctx, ws);
     const float *dz[3] = {dz1, dz2, dz3}, *act[3] = {d_y, a1, a2};
     float *dw[3] = {layers[0].d_dw, layers[1].d_dw, layers[2].d_dw}, *db[3] = {layers[0].d_db, layers[1].d_db, layers[2].d_db};
     const int out_f[3] = {h1, h2, c}, in_f[3] = {128, h1, h2};
