@@ -466,10 +466,17 @@ __device__ __forceinline__ void chain_mlp3_weights(const ChainMlp3Args &h, Chain
     w.f3 = (t >> 4) < h.classes ? *reinterpret_cast<const float4 *>(h.w3 + (t >> 4) * 64 + 4 * (t & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int c = 0; c < 16; ++c) w.b3c[c] = (t < 64 && c < h.classes) ? h.w3[c * 64 + t] : 0.f;
+#ifdef CH_EXP_NO_BWD_LOADS   /* timing probe: the backward operands are not loaded (wrong results) */
+#pragma unroll
+    for (int q = 0; q < 16; ++q) w.b2c[q] = (float)(t + q);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) w.b1c[q] = (float)(t - q);
+#else
 #pragma unroll
     for (int q = 0; q < 16; ++q) w.b2c[q] = h.w2[(16 * (t >> 7) + q) * 128 + (t & 127)];
 #pragma unroll
     for (int q = 0; q < 32; ++q) w.b1c[q] = h.w1[(32 * (t >> 7) + q) * 128 + (t & 127)];
+#endif
 }
 
 __device__ __forceinline__ void chain_mlp3_rows(const ChainMlp3Args &h, const ChainMlp3W &w, const float *xs, float *sc, int img, int t) {

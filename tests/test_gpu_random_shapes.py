@@ -94,3 +94,21 @@ def test_conv_chain_random_batches(ctx, O, n, name):
     """th_conv_chain_fwd at random batch sizes (the grid is one workgroup per image: any n) against the oracle's layer-by-layer ops"""
     from tests import test_gpu_chain as CH
     CH.test_chain_matches_the_oracle(ctx, O, name, n)
+
+
+# ---- the large-batch MLP step on drawn shapes: ragged hidden widths (any multiple of 4), ragged batches, few / many classes -------------------
+from tests import test_gpu_mlp2 as M2   # noqa: E402
+
+m2_ctx, m2_O = M2.ctx, M2.O
+
+
+@settings(**{**CFG, "max_examples": 24})
+@given(batch=st.integers(32, 900), inf4=st.integers(8, 60), hid4=st.integers(1, 32), c=st.integers(1, 16))
+def test_mlp2_random_shapes(m2_ctx, m2_O, batch, inf4, hid4, c):
+    M2.test_mlp2_dense_rows(m2_ctx, m2_O, batch, 4 * inf4, 4 * hid4, c)
+
+
+@settings(**{**CFG, "max_examples": 16})
+@given(batch=st.integers(32, 700), inf4=st.integers(8, 50), h1=st.integers(1, 32), h2=st.integers(1, 32), c=st.integers(1, 16))
+def test_mlp2_deep_random_shapes(m2_ctx, m2_O, batch, inf4, h1, h2, c):
+    M2.test_mlp2_deep_dense_rows(m2_ctx, m2_O, batch, 4 * inf4, 4 * h1, 4 * h2, c)
