@@ -908,20 +908,12 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
         }
     } else if (exact) {
         auto kern = sgemm_tile<TS, A_KC, B_KC, false>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        TH_SET_MAX_LDS(ctx, kern, lds);       // (per device: ADVICE r04)
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
                            b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, 1, raster);
     } else {
         auto kern = sgemm_tile<TS, A_KC, B_KC, true>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            TH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        TH_SET_MAX_LDS(ctx, kern, lds);       // (per device: ADVICE r04)
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
                            b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, vec ? 1 : 0, raster);
     }

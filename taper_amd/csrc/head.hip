@@ -507,12 +507,7 @@ extern "C" int th_linear_xent_head_masked(th_ctx *ctx, const float *d_h, const f
                d_metrics, metrics_capacity, d_state, advance, d_adam_tick, make_adam_dev(w_fuse), make_adam_dev(b_fuse), 0, nullptr,
                mask_dh_by_h ? 1 : 0};
     const size_t lds = head_lds_bytes(in_features);
-    static bool attr_set = false;
-    if (!attr_set) {
-        TH_HIP(hipFuncSetAttribute((const void *)linear_xent_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)head_lds_bytes(HEAD_KMAX)));
-        attr_set = true;
-    }
+    TH_SET_MAX_LDS(ctx, linear_xent_head_kernel, head_lds_bytes(HEAD_KMAX));   // (per device: ADVICE r04)
     if (batch <= 64) {   // latency-bound: one workgroup, one launch (a single 64-row chunk)
         hipLaunchKernelGGL(linear_xent_head_kernel, dim3(1), dim3(HEAD_T), lds, ctx->stream, a);
         TH_LAUNCH_CHECK();
