@@ -256,9 +256,11 @@ __global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long 
     if (ok) {
         for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 256 * 4) {
             if (!has_grad[p2p_find_tensor(offsets, n_tensors, i)]) continue;
-            const float4 g = p2p_sum_quad<NR>(c, i, scale);
+            // this rank's p / m / v are requested BEFORE the gradient loads and their wait (inline assembly the compiler moves nothing across):
+            // behind it they were a second dependent round trip per quad -- 11.2 us for the launch with one rank against 8.6 (r05)
             const float4 pv = *reinterpret_cast<const float4 *>(p + i), mv = *reinterpret_cast<const float4 *>(m + i),
                          vv = *reinterpret_cast<const float4 *>(v + i);
+            const float4 g = p2p_sum_quad<NR>(c, i, scale);
             float4 po, mo, vo;
 #define TH_ADAM_LANE(k)                                                  \
             {                                                            \
