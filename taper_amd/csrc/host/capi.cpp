@@ -286,7 +286,13 @@ int tp_adam_fused_begin(tp_optim *o) {
     TAPER_ASSERT(o->adam, "not an Adam optimizer");
     TAPER_ASSERT(!t_eager_scope && !taper::FusedAdamScope::active(), "a fused Adam step is already open on this thread");
     t_eager_scope = new taper::FusedAdamScope(o->adam.get());
-    th_check(th_adam_tick(taper::Device::ctx(), o->adam->d_tick()), "th_adam_tick");
+    try {
+        th_check(th_adam_tick(taper::Device::ctx(), o->adam->d_tick()), "th_adam_tick");
+    } catch (...) {     // (the scope must not stay open behind a failed begin: the caller's `end` never runs)
+        delete t_eager_scope;
+        t_eager_scope = nullptr;
+        throw;
+    }
     TP_END
 }
 int tp_adam_fused_end(tp_optim *o) {
