@@ -557,9 +557,13 @@ class DataLoader:
     def reset(self): tp_check(host.tp_loader_reset(self._h), "DataLoader::reset")
 
     def num_batches(self):
-        n = C.c_size_t()
-        tp_check(host.tp_loader_num_batches(self._h, C.byref(n)), "num_batches")
-        return n.value
+        # (dataset length and batch size are fixed at construction: asked once -- the Trainer wrappers ask on every call)
+        n = getattr(self, "_nb", None)
+        if n is None:
+            c = C.c_size_t()
+            tp_check(host.tp_loader_num_batches(self._h, C.byref(c)), "num_batches")
+            n = self._nb = c.value
+        return n
 
     def __iter__(self):
         return self
