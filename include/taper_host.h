@@ -139,7 +139,7 @@ int tp_optim_zero_grad(tp_optim *o);
  * (optim.rs:99-110, same arithmetic, same t) in the epilogue of the kernel that completes its gradient; tp_optim_step, called inside
  * the pair as the loop would anyway, covers the parameters nobody fused.  begin opens the step (t += 1, optim.rs:84). */
 int tp_adam_fused_begin(tp_optim *o);
-int tp_adam_fused_end(tp_optim *o);
+int tp_adam_fused_end(tp_optim *o, int *step_was_open);   /* step_was_open (nullable): 1 = tp_optim_step was NOT called inside the pair; end completed the step */
 int tp_adam_set_lr(tp_optim *o, float lr);
 int tp_adam_get_lr(const tp_optim *o, float *out);
 int tp_adam_t(const tp_optim *o, int *out);

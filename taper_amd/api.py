@@ -415,10 +415,17 @@ class Adam(_Optim):
         @contextlib.contextmanager
         def scope():
             tp_check(host.tp_adam_fused_begin(self._h), "Adam::fused_begin")
+            was_open = C.c_int(0)
             try:
                 yield self
-            finally:
-                tp_check(host.tp_adam_fused_end(self._h), "Adam::fused_end")
+            except BaseException:
+                tp_check(host.tp_adam_fused_end(self._h, C.byref(was_open)), "Adam::fused_end")
+                raise
+            tp_check(host.tp_adam_fused_end(self._h, C.byref(was_open)), "Adam::fused_end")
+            if was_open.value:
+                raise RuntimeError("Adam.fused_step(): backward() ran inside the scope but step() did not -- some parameters had their update in the "
+                                   "backward kernels' epilogues already; the scope completed the step.  Call opt.step() INSIDE the with-block "
+                                   "(and not again behind it)")
         return scope()
 
     def set_lr(self, lr): tp_check(host.tp_adam_set_lr(self._h, float(lr)), "Adam::set_lr")

@@ -295,9 +295,19 @@ int tp_adam_fused_begin(tp_optim *o) {
     }
     TP_END
 }
-int tp_adam_fused_end(tp_optim *o) {
+int tp_adam_fused_end(tp_optim *o, int *step_was_open) {
     TP_BEGIN
-    (void)o;
+    // backward() ran inside the pair but step() did not: some parameters have their update, the rest do not.  The step is COMPLETED here (the
+    // optimizer's state stays a whole number of steps) and reported, so that the caller can tell its user to move step() inside
+    const bool open = t_eager_scope && o->adam && o->adam->step_open();
+    if (step_was_open) *step_was_open = open ? 1 : 0;
+    try {
+        if (open) o->adam->step();
+    } catch (...) {
+        delete t_eager_scope;
+        t_eager_scope = nullptr;
+        throw;
+    }
     delete t_eager_scope;
     t_eager_scope = nullptr;
     TP_END

@@ -516,6 +516,8 @@ class Adam : public Optimizer {  // optim.rs:43-128
     // whoever sets this flushes at the end of its run of steps
     void set_carry_deferred(bool on) { carry_deferred_ = on; }
     bool has_deferred() const { return !deferred_.empty(); }
+    // a fused-update step that step() has not closed yet: updates already applied in epilogues and / or waiting for a carrier
+    bool step_open() const { for (char f : fused_) if (f) return true; return !deferred_.empty(); }
     void set_external_tick(bool on) { external_tick_ = on; }
     // a capture that failed midway: forget the updates queued / marked for the step that never ran
     void drop_step_bookkeeping() { deferred_.clear(); std::fill(fused_.begin(), fused_.end(), 0); }

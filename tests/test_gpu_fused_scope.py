@@ -106,3 +106,33 @@ def test_fused_scope_refuses_to_nest():
     T.cross_entropy_loss(model.forward(x), y).backward()
     opt.step()
     T.Tape.reset()
+
+
+def test_fused_scope_without_step_inside_completes_the_step_and_says_so():
+    """backward() inside the scope, step() forgotten: the parameters fused in the backward kernels are already updated -- the scope's end
+    completes the step (same weights as the correct loop) and raises, instead of leaving half a step behind"""
+    import taper_amd as T
+    H = backends.get("hip")
+    rng = np.random.default_rng(5)
+    spec = _spec(rng, (96, 48, 32, 10))
+    x, y = rng.uniform(0, 1, (64, 96)).astype(np.float32), rng.integers(0, 10, 64).astype(np.float32)
+
+    def run(forget):
+        model = H.sequential(spec)
+        opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+        T.Tape.reset()
+        opt.zero_grad()
+        if forget:
+            with pytest.raises(RuntimeError, match="step\\(\\) did not"):
+                with opt.fused_step():
+                    T.cross_entropy_loss(model.forward(T.Tensor(x)), T.Tensor(y)).backward()
+        else:
+            with opt.fused_step():
+                T.cross_entropy_loss(model.forward(T.Tensor(x)), T.Tensor(y)).backward()
+                opt.step()
+        T.Tape.reset()
+        assert opt.t() == 1
+        return [p.data().copy() for p in model.parameters()]
+
+    for a, b in zip(run(False), run(True)):
+        np.testing.assert_array_equal(a, b)
