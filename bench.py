@@ -113,6 +113,55 @@ def make_comm(rdzv, T, backend, optimizer, shared_device=False):
     return comm, "rccl ncclAllReduce(avg)" + why
 
 
+def dp_on_device(T, key, lr, ds, per_gpu_batch=128, steps=4000, rounds=3):
+    """N = 1: what the data-parallel step of BASELINE configs[3] (128 rows per GPU) costs ON the device, before a link is crossed.  Four
+    Trainers on the same rows, timed alternately (min of `rounds`):
+      single      no communicator: the two-launch step of one GPU
+      one_rank    a 1-rank peer-to-peer communicator: nothing to exchange, the same two launches
+      loopback    W = 2 with this process as its own peer: the exchange inside the gradient launch (th_mlp_tail_dp) runs every push, flag,
+                  poll and load of its protocol, through local memory; results are the single-GPU step's bit for bit
+      three_launch  the r05 form with one rank: gradient launch WITHOUT fused updates, then the one-shot all-reduce + Adam launch
+    on_device_efficiency_ceiling = single / loopback: the weak-scaling efficiency the step could reach if links cost nothing."""
+    def make(kind):
+        m = build_model(T, key)
+        o = T.Adam(m.parameters(), lr, None, None, 1e-4)
+        c = None
+        if kind == "loopback":
+            c = T.Communicator.loopback()
+        elif kind in ("one_rank", "three_launch"):
+            c = T.Communicator.p2p(1, 0)
+            c.connect(c.export_arena(o))
+            if kind == "three_launch":
+                c.set_inkernel(False)
+        t = T.Trainer(m, o, comm=c)
+        l = T.DataLoader(ds, per_gpu_batch, False)
+        run_steps(T, t, l, 300)
+        _KEEP_ALIVE.append((t, o, m, l, c))
+        return t, l, c
+    kinds = ("single", "one_rank", "loopback", "three_launch")
+    runs = {k: make(k) for k in kinds}
+    best = {k: None for k in kinds}
+    for _ in range(rounds):
+        for k in kinds:
+            t, l, _c = runs[k]
+            T.Device.sync()
+            t0 = time.perf_counter()
+            run_steps(T, t, l, steps)
+            T.Device.sync()
+            us = (time.perf_counter() - t0) / steps * 1e6
+            best[k] = us if best[k] is None else min(best[k], us)
+    lb = runs["loopback"][2]
+    out = dict(per_gpu_batch=per_gpu_batch, steps=steps, rounds=rounds,
+               single_gpu_step_us=round(best["single"], 3), one_rank_step_us=round(best["one_rank"], 3),
+               loopback_two_rank_step_us=round(best["loopback"], 3), three_launch_one_rank_step_us=round(best["three_launch"], 3),
+               on_device_efficiency_ceiling=round(best["single"] / best["loopback"], 4),
+               one_rank_ceiling=round(best["single"] / best["one_rank"], 4),
+               three_launch_ceiling=round(best["single"] / best["three_launch"], 4),
+               loopback_inkernel_launches=lb.inkernel_launches(), loopback_timed_out=lb.timed_out(),
+               note="one device: flags and slices go through local memory; a link adds its latency per exchange and 0.4 MB per peer of transfer")
+    return out
+
+
 def opt_total(T, opt):
     """padded length of the optimizer's flat arenas = the all-reduce size in floats (include/taper_host.h: tp_optim_total)"""
     from taper_amd._lib import host, tp_check
@@ -684,36 +733,27 @@ def linear_stack_workload(T, layers=4, width=4096, batch=4096, steps=12, warmup=
     x = T.Tensor(rng.uniform(0, 1, (B, W)).astype(np.float32))
     y = T.Tensor(rng.integers(0, 10, B).astype(np.float32))
 
-    def step(fused):
+    def step():          # the reference-literal order (examples/train_mnist.rs:91-119): backward, then one arena-wide Adam launch
         T.Tape.reset()
         opt.zero_grad()
-        if fused:       # Adam.fused_step(): the Trainer's mode for a hand-written loop -- each update in the epilogue of the product that completes its gradient
-            with opt.fused_step():
-                loss = T.cross_entropy_loss(model.forward(x), y)
-                loss.backward()
-                opt.step()
-        else:           # the reference-literal order: backward, then one arena-wide Adam launch
-            loss = T.cross_entropy_loss(model.forward(x), y)
-            loss.backward()
-            opt.step()
+        loss = T.cross_entropy_loss(model.forward(x), y)
+        loss.backward()
+        opt.step()
         return loss
 
-    times = {}
-    for fused in (False, True):
-        for _ in range(warmup):
-            step(fused)
-        T.Device.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step(fused)
-        T.Device.sync()
-        times[fused] = (time.perf_counter() - t0) / steps
-    dt = times[True]
+    for _ in range(warmup):
+        step()
+    T.Device.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    T.Device.sync()
+    dt = (time.perf_counter() - t0) / steps
     params = L * (W * W + W) + W * 10 + 10
     flops = (3 * L - 1) * 2.0 * B * W * W + 3 * 2.0 * B * W * 10 + 14.0 * params
     rec = dict(workload=f"linear_stack_{W}x{L}_b{B}", per_gpu_batch=B, steps=steps, ms_per_step=round(dt * 1e3, 4), samples_per_s=round(B / dt, 1),
-               step="eager op-by-op host API (Tape::reset, forward, cross_entropy_loss, backward, Adam::step) inside Adam.fused_step(): updates in the dW products' epilogues",
-               ms_per_step_plain_loop=round(times[False] * 1e3, 4), frac_plain_loop=round(flops / times[False] / 1e12 / MFMA_F32_PEAK_TF, 4), alg_flops_per_step=flops,
+               step="eager op-by-op host API, the reference's loop: Tape::reset, forward, cross_entropy_loss, backward, Adam::step",
+               alg_flops_per_step=flops,
                tflops=round(flops / dt / 1e12, 2), frac_of_mfma_peak=round(flops / dt / 1e12 / MFMA_F32_PEAK_TF, 4),
                loss_last=round(float(loss.data()[0]), 5))
     del model, opt, x, y
@@ -868,7 +908,8 @@ def compact_line(full, details_path):
         out["step_roofline"] = {"hbm_frac": round(sr["hbm_frac"], 4), "mfma_frac": round(sr["mfma_frac"], 4)}
     if full.get("data_parallel"):
         dp = full["data_parallel"]
-        d = {k: dp[k] for k in ("weak_scaling_efficiency", "replicas_bit_identical") if k in dp}
+        d = {k: dp[k] for k in ("weak_scaling_efficiency", "replicas_bit_identical", "per_gpu_batch", "single_gpu_step_us", "one_rank_step_us",
+                                "loopback_two_rank_step_us", "three_launch_one_rank_step_us", "on_device_efficiency_ceiling", "error") if k in dp}
         if "single_gpu_same_per_gpu_batch" in dp:
             d["single_gpu_ms_per_step"] = dp["single_gpu_same_per_gpu_batch"]["ms_per_step"]
         if "same_job_over_rccl" in dp:
@@ -1093,16 +1134,35 @@ def main():
             dp_extra["single_gpu_same_per_gpu_batch"] = dict(workload=args.workload, per_gpu_batch=batch, n_gpus=1, value=round(s1 / d1, 1), unit="samples/s",
                                                              ms_per_step=round(d1 / args.steps * 1e3, 5), steps=args.steps, warmup=args.warmup)
             # eff(W) = T_step(1 GPU, B/W rows) / T_step(W GPUs, B/W rows each), same W / K, same run
-            dp_extra["weak_scaling_efficiency"] = round((d1 / args.steps) / (dt / args.steps), 4)
+            # (ranks that SHARE one device time-share it: their ratio is an artefact of the harness, not an efficiency -- null)
+            dp_extra["weak_scaling_efficiency"] = None if share else round((d1 / args.steps) / (dt / args.steps), 4)
         barrier_sync(dist, T)
         # the exchange launch on its own: `reps` gradient exchanges + Adam as the step issues them, back to back between two events on
         # every rank's stream (collective).  Moves the optimizer state: the timed run and the replica check are behind us.
+        inkernel = comm.is_p2p() and comm.inkernel_launches() > 0
+        dp_extra["exchange_form"] = ("inside the gradient launch (th_mlp_tail_dp): two launches per step" if inkernel else
+                                     "its own launch behind the gradient launch: three launches per step")
         try:
             ex_us = comm.time_exchange(opt, 200)
             ex_us = dist.all_reduce_max(ex_us)
         except Exception as e:   # reported, never required
             ex_us, dp_extra["exchange_error"] = None, str(e)
-        if ex_us:
+        if inkernel:
+            # no exchange launch exists: the roofline line is the whole step against the bytes it moves -- the single-GPU step's algorithmic
+            # bytes + every peer's gradient slices pushed out and the same amount read back from the receive region
+            P = opt_total(T, opt)
+            _, step_bytes = algorithmic_step(key, batch)
+            ex_bytes = float(step_bytes) + 2.0 * (world - 1) * 4.0 * P
+            us = dt / args.steps * 1e6
+            links = 7 * 153.0
+            peak, basis = (HBM_PEAK_GBS, "HBM (the ranks share one GPU: pushes are local)") if share else \
+                          (HBM_PEAK_GBS, "HBM 8000 GB/s (the pushed slices cross xGMI: 7 links x 153 GB/s per GPU)")
+            dp_extra["exchange"] = dict(kernel="sgemm_small16_tick + mlp_tail_exact_kernel<DP> (th_mlp_tail_dp)", us_per_launch=round(us, 2),
+                                        alg_bytes_per_launch=ex_bytes, bound="hbm", achieved=round(ex_bytes / (us * 1e-6) / 1e9, 2), peak=round(peak, 1),
+                                        unit="GB/s", frac=round(ex_bytes / (us * 1e-6) / 1e9 / peak, 5), peak_basis=basis, traffic=None,
+                                        three_launch_exchange_us=None if not ex_us else round(ex_us, 2),
+                                        note="latency-bound: the whole two-launch step; the exchange is %d x 0.4 MB pushed per rank" % (world - 1))
+        elif ex_us:
             P = opt_total(T, opt)
             ex_bytes = (world - 1) * 4.0 * P + 4.0 * P + 24.0 * P        # peers' gradients over the links + own + Adam's p / m / v read and written
             links = 7 * 153.0
@@ -1169,6 +1229,12 @@ def main():
         if world > 1:   # the CPU leg is timed at N = 1 only (rank 0's host cores are shared by the N ranks here)
             cpu = dict(value=None, unit="samples/s", cores=None, kind="port", sample="not timed at N > 1",
                        see="cpu_baseline of `python bench.py --gpus 1` (same box, same workload family)")
+        dp_ceiling = None
+        if world == 1 and key == "mlp_baseline" and not args.batch and not under_profiler and args.workloads != "none":
+            try:
+                dp_ceiling = dp_on_device(T, key, lr, ds)
+            except Exception as e:   # reported, never required
+                dp_ceiling = dict(error=str(e))
         workloads = None
         if under_profiler:
             # rocprofv3 (ROCm 7.2) crashes inside hipGraphLaunch once a process replays the graphs of a SECOND Trainer: the headline above ran as
@@ -1195,6 +1261,7 @@ def main():
                 "mfma_frac": round(flops / (dt / args.steps) / 1e12 / MFMA_F32_PEAK_TF, 6)},
             "sustained": sustained, "batch_sweep": sweep, "batch_sweep_mlp_784-128-64-10": sweep_example, "roofline": roof, "cpu_baseline": cpu,
             **({"data_parallel": dp_extra} if dp_extra is not None else {}),
+            **({"data_parallel": dp_ceiling} if dp_ceiling is not None else {}),
             **({"workloads": workloads} if workloads is not None else {}),
         }
         print(json.dumps(compact_line(out, write_details(out))), flush=True)

@@ -688,6 +688,39 @@ int th_allreduce_adam(th_comm *comm, th_ctx *ctx, const float *d_grads, size_t n
                       const int64_t *d_offsets, const int32_t *d_has_grad, int n_tensors, int32_t *d_t, const float *d_lr,
                       float beta1, float beta2, float eps, float weight_decay, int pre_ticked);
 
+/* ---- the exchange INSIDE the launch that produces the gradients (csrc/dp_dev.h) -------------------------------------------------
+ * The same peer-to-peer communicator also carries a receive region per rank (mapped by every peer with its flag block).  A workgroup
+ * that has finished a slice of a gradient pushes it into every peer's region as 8-byte words and polls its own region for the same
+ * words of every peer -- an empty word is all ones (a NaN no arithmetic produces), so the value is its own flag: one dependent trip through
+ * memory, no extra bytes -- adds the W values in rank order (the same bits on every rank), scales by 1/W, puts the empty mark back and goes
+ * on to Adam from registers: no extra launch, no arena-wide hand-shake, nothing to do with one rank.  th_mlp_tail_dp is th_mlp_tail with that
+ * exchange in its epilogues: dW1 / db1 are reduced and applied in place (w1_fuse / b1_fuse as before; their counter is the one
+ * th_linear_fwd_ex ticked), the reduced dW2 / db2 are written for the deferred update exactly as the single-GPU step writes its own.
+ * A waiting workgroup holds its place on the device, so ranks that SHARE a device may only take this form while the workgroups of all
+ * of them but one leave a place free (th_mlp_tail_dp_supported says so; the three-launch form above is the fallback).
+ * A peer whose slice does not arrive within the communicator's bound: the workgroup applies nothing, raises the error word (FINAL, as
+ * above) and the lead workgroup takes the counter's tick back; a peer that is absent altogether therefore leaves p / m / v / t untouched.
+ * (A peer that dies in the middle of its launch can leave the slices it did push applied: the error is raised all the same, the state is
+ * then one PARTIAL step on and only a checkpoint restores it -- the three-launch form's all-or-nothing verdict costs 2.5 us per step.)
+ * th_ctx_set_update_guard: while set, the launches that apply deferred updates or tick a counter (th_linear_fwd_ex's spare workgroup,
+ * th_adam_slices, th_adam_tick) look at the word first and do nothing once it is non-zero -- the steps behind a failed exchange in a captured
+ * graph; and a tick that does happen also advances *d_step_word (nullable; th_comm_step_word): the exchange's step number, which every
+ * workgroup of the gradient launch behind it then reads at no cost (it picks the half of the double-buffered receive region). */
+int th_comm_init_loopback(th_ctx *ctx, th_comm **out);       /* W = 2 with this rank as its own peer: the whole protocol through local memory; results are the single-GPU step's, bit for bit */
+int th_comm_is_loopback(const th_comm *comm);
+int th_comm_sharing(const th_comm *comm, int *out_ranks_on_this_device);
+int th_comm_stats_inkernel(const th_comm *comm, int64_t *out_launches);
+/* collective check of the exchange alone: `rounds` launches of `slots` workgroups, every value compared on the device; *out_bad = mismatches + time-outs */
+int th_comm_exchange_selftest(th_comm *comm, th_ctx *ctx, int slots, int rounds, int *out_bad);
+int th_ctx_set_update_guard(th_ctx *ctx, const uint32_t *d_skip_if_nonzero /* nullable: clears it */, uint32_t *d_step_word /* nullable */);
+int th_comm_step_word(const th_comm *comm, uint32_t **d_out);   /* NULL for an RCCL communicator */
+int th_mlp_tail_dp_supported(const th_comm *comm, th_ctx *ctx, int batch, int in_features, int hidden, int classes);
+int th_mlp_tail_dp(th_comm *comm, th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
+                   const float *d_targets, int batch, int in_features, int hidden, int classes,
+                   float *d_loss, float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2,
+                   float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                   const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse, int32_t *d_tick);
+
 #ifdef __cplusplus
 }
 #endif

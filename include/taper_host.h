@@ -135,11 +135,6 @@ int tp_adamw_new(tp_tensor *const *params, int n, float lr, float beta1, float b
 int tp_optim_free(tp_optim *o);
 int tp_optim_step(tp_optim *o);
 int tp_optim_zero_grad(tp_optim *o);
-/* The Trainer's fused-update mode for a hand-written loop: between begin and end, Tensor::backward applies a parameter's Adam update
- * (optim.rs:99-110, same arithmetic, same t) in the epilogue of the kernel that completes its gradient; tp_optim_step, called inside
- * the pair as the loop would anyway, covers the parameters nobody fused.  begin opens the step (t += 1, optim.rs:84). */
-int tp_adam_fused_begin(tp_optim *o);
-int tp_adam_fused_end(tp_optim *o, int *step_was_open);   /* step_was_open (nullable): 1 = tp_optim_step was NOT called inside the pair; end completed the step */
 int tp_adam_set_lr(tp_optim *o, float lr);
 int tp_adam_get_lr(const tp_optim *o, float *out);
 int tp_adam_t(const tp_optim *o, int *out);
@@ -175,6 +170,16 @@ int tp_comm_new(int n_ranks, int rank, const uint8_t id[128], tp_comm **out);
 /* peer-to-peer communicator (th_comm_init_p2p): new -> export_arena(optimizer) -> ship all 192-byte blobs to all ranks ->
  * connect(blobs in rank order); the Trainer then runs all-reduce + Adam as one launch */
 int tp_comm_new_p2p(int n_ranks, int rank, tp_comm **out);
+/* The exchange inside the gradient launch (th_mlp_tail_dp; include/taper_hip.h): a Trainer over a peer-to-peer communicator takes it for
+ * the Linear + ReLU + Linear step whenever tp_comm_tail_exchange_ok says the shapes and the placement of the ranks allow it
+ * (tp_comm_set_inkernel(c, 0): never -- the three-launch form, for A/B runs).  tp_comm_new_loopback: W = 2 with this process as its own
+ * peer -- the whole protocol through local memory, results bit-identical to the single-GPU step; what a 1-GPU box can time of it. */
+int tp_comm_new_loopback(tp_comm **out);
+int tp_comm_set_inkernel(tp_comm *c, int on);
+int tp_comm_inkernel_launches(tp_comm *c, int64_t *out);
+int tp_comm_exchange_selftest(tp_comm *c, int slots, int rounds, int *out_bad);   /* collective */
+int tp_comm_ranks_on_this_device(tp_comm *c, int *out);
+int tp_comm_tail_exchange_ok(tp_comm *c, int batch, int in_features, int hidden, int classes, int *out);
 int tp_comm_export_arena(tp_comm *c, tp_optim *optimizer, uint8_t out_blob[192]);
 int tp_comm_connect(tp_comm *c, const uint8_t *blobs, size_t n_bytes);
 /* fine_grained != 0: the optimizer's gradient arena is first moved into fine-grained device memory (coherent across agents, never cached

@@ -405,29 +405,6 @@ class Adam(_Optim):
         self._h = _mk(host.tp_adam_new, "Adam::new", arr, len(self.params), float(lr), float(betas[0]), float(betas[1]),
                       float(1e-8 if eps is None else eps), float(0.0 if weight_decay is None else weight_decay))
 
-    def fused_step(self):
-        """Context manager: the Trainer's fused-update mode for a hand-written loop.  Inside it `loss.backward()` applies each parameter's
-        Adam update in the epilogue of the kernel that completes its gradient and `step()` (call it inside) covers the rest:
-            with opt.fused_step():
-                loss = T.cross_entropy_loss(model.forward(x), y); loss.backward(); opt.step()"""
-        import contextlib
-
-        @contextlib.contextmanager
-        def scope():
-            tp_check(host.tp_adam_fused_begin(self._h), "Adam::fused_begin")
-            was_open = C.c_int(0)
-            try:
-                yield self
-            except BaseException:
-                tp_check(host.tp_adam_fused_end(self._h, C.byref(was_open)), "Adam::fused_end")
-                raise
-            tp_check(host.tp_adam_fused_end(self._h, C.byref(was_open)), "Adam::fused_end")
-            if was_open.value:
-                raise RuntimeError("Adam.fused_step(): backward() ran inside the scope but step() did not -- some parameters had their update in the "
-                                   "backward kernels' epilogues already; the scope completed the step.  Call opt.step() INSIDE the with-block "
-                                   "(and not again behind it)")
-        return scope()
-
     def set_lr(self, lr): tp_check(host.tp_adam_set_lr(self._h, float(lr)), "Adam::set_lr")
 
     def get_lr(self):
@@ -602,6 +579,37 @@ class Communicator:
     def p2p(n_ranks, rank):
         """peer-to-peer communicator (one node, <= 8 ranks): one-shot all-reduce of the gradient arena fused with Adam"""
         return Communicator(n_ranks, rank, _h=_mk(host.tp_comm_new_p2p, "Communicator::p2p", int(n_ranks), int(rank)))
+
+    @staticmethod
+    def loopback():
+        """W = 2 with this process as its own peer: the exchange inside the gradient launch (th_mlp_tail_dp) runs every push, flag, poll
+        and load of its protocol through local memory; results are the single-GPU step's, bit for bit"""
+        return Communicator(2, 0, _h=_mk(host.tp_comm_new_loopback, "Communicator::loopback"))
+
+    def set_inkernel(self, on: bool):
+        """False: never the in-launch exchange (the three-launch form: gradient launch, then all-reduce + Adam) -- A/B runs"""
+        tp_check(host.tp_comm_set_inkernel(self._h, 1 if on else 0), "Communicator::set_inkernel")
+
+    def inkernel_launches(self) -> int:
+        out = C.c_int64()
+        tp_check(host.tp_comm_inkernel_launches(self._h, C.byref(out)), "Communicator::inkernel_launches")
+        return int(out.value)
+
+    def exchange_selftest(self, slots: int = 16, rounds: int = 3) -> int:
+        """collective: the in-launch exchange alone on known patterns; -> mismatches + time-outs seen by this rank"""
+        out = C.c_int()
+        tp_check(host.tp_comm_exchange_selftest(self._h, int(slots), int(rounds), C.byref(out)), "Communicator::exchange_selftest")
+        return int(out.value)
+
+    def ranks_on_this_device(self) -> int:
+        out = C.c_int()
+        tp_check(host.tp_comm_ranks_on_this_device(self._h, C.byref(out)), "Communicator::ranks_on_this_device")
+        return int(out.value)
+
+    def tail_exchange_ok(self, batch: int, in_features: int, hidden: int, classes: int) -> bool:
+        out = C.c_int()
+        tp_check(host.tp_comm_tail_exchange_ok(self._h, int(batch), int(in_features), int(hidden), int(classes), C.byref(out)), "Communicator::tail_exchange_ok")
+        return bool(out.value)
 
     def export_arena(self, optimizer, fine_grained: bool = False) -> bytes:
         """register the optimizer's gradient arena; fine_grained: move it into fine-grained (cross-agent coherent) device memory first"""

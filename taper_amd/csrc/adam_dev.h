@@ -73,12 +73,16 @@ struct AdamSlices {
     int64_t n[TH_MAX_ADAM_SLICES];
     int first_block[TH_MAX_ADAM_SLICES + 1];   // prefix of blocks per slice
     int count;
+    const uint32_t *guard;                     // nullable (th_ctx_set_update_guard): non-zero = a data-parallel exchange failed; apply nothing, tick nothing
+    uint32_t *step_word;                       // nullable: advanced with every tick (the in-launch exchange's step number, dp_dev.h)
     int blocks() const { return first_block[count]; }
 };
 
-static inline AdamSlices make_adam_slices(const th_adam_slice *s, int n) {
+static inline AdamSlices make_adam_slices(const th_adam_slice *s, int n, const th_ctx *ctx) {
     AdamSlices r{};
     r.count = 0;
+    r.guard = ctx ? ctx->update_guard : nullptr;
+    r.step_word = ctx ? ctx->update_step_word : nullptr;
     for (int i = 0; i < n; ++i) {
         if (!s[i].f.d_p || s[i].n <= 0) continue;
         r.a[r.count] = make_adam_dev(&s[i].f);
@@ -131,6 +135,7 @@ __device__ __forceinline__ void adam_slice_quad(const AdamDev &a, const float *_
 
 // 256 threads; elements [1024 b', 1024 b' + 1024) of the slice owning block b
 __device__ __forceinline__ void adam_slices_block(const AdamSlices &x, int b) {
+    if (x.guard && sload(x.guard) != 0u) return;   // (written by an earlier launch)
     int s = 0;
 #pragma unroll
     for (int i = 1; i < TH_MAX_ADAM_SLICES; ++i)
@@ -145,6 +150,7 @@ __device__ __forceinline__ void adam_slices_block(const AdamSlices &x, int b) {
 // (nullable) is advanced by one (optim.rs:84).  For th_linear_fwd_ex: the slices belong to the
 // PREVIOUS step, the tick opens the next one; nothing else in that launch touches the counter.
 __device__ __forceinline__ void adam_slices_then_tick(const AdamSlices &x, int32_t *tick) {
+    if (x.guard && sload(x.guard) != 0u) return;   // (uniform: the whole workgroup leaves before the barrier below)
 #pragma unroll
     for (int s = 0; s < TH_MAX_ADAM_SLICES; ++s) {
         if (s >= x.count) break;
@@ -152,7 +158,10 @@ __device__ __forceinline__ void adam_slices_then_tick(const AdamSlices &x, int32
         for (int64_t i0 = (int64_t)threadIdx.x * 4; i0 < x.n[s]; i0 += (int64_t)blockDim.x * 4) adam_slice_quad(x.a[s], x.g[s], x.n[s], i0, step);
     }
     __syncthreads();
-    if (tick && threadIdx.x == 0) tick[0] += 1;
+    if (tick && threadIdx.x == 0) {
+        tick[0] += 1;
+        if (x.step_word) x.step_word[0] += 1u;
+    }
 }
 
 }  // namespace th

@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include "adam_dev.h"
+#include "dp_dev.h"
 
 constexpr int P2P_MAX_RANKS = 8;           // one node: 8 x MI355X, full xGMI mesh
 constexpr int P2P_FLAG_WORDS = 32;         // per rank: ready[8] | done[8] | pad (uint32 step values, monotonic)
@@ -24,8 +25,10 @@ struct P2PBlob {                           // what a rank ships to its peers (TH
     hipIpcMemHandle_t buf, flags;          // allocation bases
     uint64_t buf_offset, n;                // the reduced buffer inside its allocation; length in floats
     int32_t pid, device, rank, pad;
-    uint8_t reserved[TH_P2P_BLOB_BYTES - 2 * sizeof(hipIpcMemHandle_t) - 2 * sizeof(uint64_t) - 4 * sizeof(int32_t)];
+    char bus_id[16];                       // PCI bus id of the rank's device ("0000:05:00.0"): two ranks with the same id share a GPU
+    uint8_t reserved[TH_P2P_BLOB_BYTES - 2 * sizeof(hipIpcMemHandle_t) - 2 * sizeof(uint64_t) - 4 * sizeof(int32_t) - 16];
 };
+static_assert(th::DP_DATA_OFFSET >= P2P_MAX_RANKS * P2P_FLAG_WORDS * sizeof(uint32_t), "the three-launch flag block sits in front of the exchange region");
 static_assert(sizeof(P2PBlob) == TH_P2P_BLOB_BYTES, "P2PBlob layout");
 
 struct P2PDev {                            // kernel argument
@@ -53,7 +56,19 @@ struct th_comm {
     void *peer_flag_base[P2P_MAX_RANKS] = {};
     P2PDev dev{};
     long launches_inplace = 0, launches_fused = 0;   // enqueued (or captured) one-shot launches, for tests
+    // ---- exchange inside the gradient launch (dp_dev.h): the region behind flags_local, mapped by every peer with the flag block ----
+    th::DpDev dp{};
+    bool loopback = false;                 // two "ranks", both this one: every push, flag, poll and load of the protocol through local memory
+    int sharing = 1;                       // ranks on this rank's device (itself included)
+    char bus_id[16] = {};
+    long launches_inkernel = 0;
 };
+
+namespace th {
+const DpDev *comm_dp_dev(const th_comm *c) { return (c && c->p2p && c->connected) ? &c->dp : nullptr; }
+int comm_dp_sharing(const th_comm *c) { return c ? c->sharing : 1; }
+void comm_dp_count_launch(th_comm *c) { if (c) ++c->launches_inkernel; }
+}
 
 namespace th {
 int scale_inplace(th_ctx *ctx, float *d_x, size_t n, float scale);
@@ -293,6 +308,32 @@ __global__ __launch_bounds__(256) void p2p_allreduce_adam_kernel(P2PDev c, long 
     }
 }
 
+// The in-launch exchange on its own: one workgroup per slot, thread t of slot s on rank r in round k holds the pattern below (small
+// integers: every sum and mean is exact); each thread checks the mean it gets back.  Collective: every rank launches it, same slots and
+// rounds.  The same flags / receive slots / step counter as a training step's launch (dp_dev.h); 2 values per thread like mlp_tail.hip.
+__device__ __forceinline__ float dp_pattern(int r, int k, int s, int t, int j) { return (float)((r + 1) * (k + 1)) + (float)((s * 3 + t * 2 + j) % 7); }
+__global__ void dp_bump_kernel(uint32_t *state) {
+    if (state[DP_ST_DEAD] == 0u) dp_advance_step(state + DP_ST_STEP);
+}
+template <int NR>
+__global__ __launch_bounds__(256) void dp_selftest_kernel(DpDev c, int round, int loopback, uint32_t *bad) {
+    const DpTicket tk = dp_begin(c);
+    const int s = blockIdx.x, t = threadIdx.x;
+    float v[2] = {dp_pattern(c.rank, round, s, t, 0), dp_pattern(c.rank, round, s, t, 1)};
+    const bool ok = dp_exchange<NR, 2>(c, tk, s, t, v);
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float want = 0.f;
+            for (int r = 0; r < c.n_ranks; ++r) want += dp_pattern(loopback ? c.rank : r, round, s, t, j);
+            want *= c.scale;
+            if (v[j] != want) atomicAdd(bad, 1u);
+        }
+    } else if (t == 0) {
+        atomicAdd(bad, 1u);
+    }
+}
+
 static int p2p_grid(size_t n) {
     long g = (long)((n / 4 + 255) / 256);
     return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));   // one workgroup per CU at most: every one of them polls the flag block
@@ -359,10 +400,11 @@ int th_comm_init_p2p(th_ctx *ctx, int n_ranks, int rank, th_comm **out) {
     c->rank = rank;
     c->device = ctx->device;
     // the flag block peers write into: fine-grained (uncached) device memory where the runtime offers it
+    // (one allocation = one IPC handle: the three-launch form's flag block, then the in-launch exchange's flags and receive slots, dp_dev.h)
     void *f = nullptr;
-    if (hipExtMallocWithFlags(&f, P2P_MAX_RANKS * P2P_FLAG_WORDS * sizeof(uint32_t), hipDeviceMallocFinegrained) != hipSuccess) {
+    if (hipExtMallocWithFlags(&f, th::DP_REGION_BYTES, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
-        if (hipMalloc(&f, P2P_MAX_RANKS * P2P_FLAG_WORDS * sizeof(uint32_t)) != hipSuccess) {
+        if (hipMalloc(&f, th::DP_REGION_BYTES) != hipSuccess) {
             delete c;
             TH_REQUIRE(false, "th_comm_init_p2p: cannot allocate the flag block");
         }
@@ -378,7 +420,13 @@ int th_comm_init_p2p(th_ctx *ctx, int n_ranks, int rank, th_comm **out) {
         TH_REQUIRE(false, "th_comm_init_p2p: cannot allocate the host-visible error word");
     }
     c->err_host[0] = 0;
-    if (hipMalloc((void **)&c->state, 64) != hipSuccess || hipMemset(c->flags_local, 0, P2P_MAX_RANKS * P2P_FLAG_WORDS * sizeof(uint32_t)) != hipSuccess ||
+    if (hipDeviceGetPCIBusId(c->bus_id, (int)sizeof(c->bus_id), ctx->device) != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(c->bus_id, sizeof(c->bus_id), "dev%d", ctx->device);
+    }
+    // (the three-launch form's flags start at zero; every word of the receive region starts EMPTY: all ones, dp_dev.h)
+    if (hipMalloc((void **)&c->state, 64) != hipSuccess || hipMemset(c->flags_local, 0, th::DP_DATA_OFFSET) != hipSuccess ||
+        hipMemset((char *)c->flags_local + th::DP_DATA_OFFSET, 0xFF, th::DP_REGION_BYTES - th::DP_DATA_OFFSET) != hipSuccess ||
         hipMemset(c->state, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         th_comm_destroy(c);
         TH_REQUIRE(false, "th_comm_init_p2p: cannot initialise the flag block");
@@ -403,6 +451,7 @@ int th_comm_p2p_export(th_comm *comm, float *d_buf, size_t n, uint8_t out_blob[T
     b.pid = (int32_t)getpid();
     b.device = comm->device;
     b.rank = comm->rank;
+    memcpy(b.bus_id, comm->bus_id, sizeof(b.bus_id));
     comm->reg_buf = d_buf;
     comm->reg_n = n;
     memcpy(out_blob, &b, sizeof(b));
@@ -411,10 +460,13 @@ int th_comm_p2p_export(th_comm *comm, float *d_buf, size_t n, uint8_t out_blob[T
 
 int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs) {
     TH_REQUIRE(comm && comm->p2p && blobs && comm->reg_buf, "th_comm_p2p_connect: export this rank's buffer first");
+    TH_REQUIRE(!comm->loopback, "th_comm_p2p_connect: a loopback communicator is connected from its start");
     TH_HIP(hipSetDevice(comm->device));
+    comm->sharing = 0;
     for (int r = 0; r < comm->n_ranks; ++r) {
         P2PBlob b;
         memcpy(&b, blobs + (size_t)r * TH_P2P_BLOB_BYTES, sizeof(b));
+        if (memcmp(b.bus_id, comm->bus_id, sizeof(b.bus_id)) == 0) ++comm->sharing;
         TH_REQUIRE(b.rank == r && b.n == comm->reg_n, "th_comm_p2p_connect: blob %d is from rank %d with %llu floats (expected rank %d, %zu floats)", r,
                    b.rank, (unsigned long long)b.n, r, comm->reg_n);
         if (r == comm->rank) {
@@ -440,7 +492,52 @@ int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs) {
     comm->dev.spin_ticks = comm->timeout_ms * 100000L;   // 100 MHz wall clock
     comm->dev.n_ranks = comm->n_ranks;
     comm->dev.rank = comm->rank;
+    // the in-launch exchange: this rank's source block in every peer's region, its own region to receive in
+    th::DpDev &d = comm->dp;
+    for (int r = 0; r < comm->n_ranks; ++r) {
+        char *base = (char *)comm->dev.flags[r];
+        d.push_data[r] = (float *)(base + th::DP_DATA_OFFSET) + (size_t)comm->rank * th::DP_SRC_STRIDE;
+    }
+    d.recv_data = (float *)((char *)comm->flags_local + th::DP_DATA_OFFSET);
+    d.state = comm->state;
+    d.err_host = comm->err_host;
+    d.spin_ticks = comm->dev.spin_ticks;
+    d.n_ranks = comm->n_ranks;
+    d.rank = comm->rank;
+    d.scale = 1.0f / (float)comm->n_ranks;
+    if (comm->sharing < 1) comm->sharing = 1;
     comm->connected = true;
+    return 0;
+}
+
+int th_comm_init_loopback(th_ctx *ctx, th_comm **out) {
+    TH_REQUIRE(ctx && out, "th_comm_init_loopback: null argument");
+    th_comm *c = nullptr;
+    if (int rc = th_comm_init_p2p(ctx, 2, 0, &c)) return rc;
+    c->loopback = true;
+    th::DpDev &d = c->dp;
+    char *base = (char *)c->flags_local;
+    for (int r = 0; r < 2; ++r) {   // "rank 1" is this rank again: what it would push arrives in source block 1 of the local region
+        d.push_data[r] = (float *)(base + th::DP_DATA_OFFSET) + (size_t)r * th::DP_SRC_STRIDE;
+    }
+    d.recv_data = (float *)(base + th::DP_DATA_OFFSET);
+    d.state = c->state;
+    d.err_host = c->err_host;
+    d.spin_ticks = c->timeout_ms * 100000L;
+    d.n_ranks = 2;
+    d.rank = 0;
+    d.scale = 0.5f;
+    c->sharing = 1;
+    c->connected = true;
+    *out = c;
+    return 0;
+}
+
+int th_comm_is_loopback(const th_comm *comm) { return comm && comm->loopback ? 1 : 0; }
+
+int th_comm_sharing(const th_comm *comm, int *out_ranks_on_this_device) {
+    TH_REQUIRE(comm && out_ranks_on_this_device, "th_comm_sharing: null argument");
+    *out_ranks_on_this_device = comm->sharing;
     return 0;
 }
 
@@ -476,10 +573,17 @@ int th_comm_error_word(const th_comm *comm, const uint32_t **d_out) {
     return 0;
 }
 
+int th_comm_step_word(const th_comm *comm, uint32_t **d_out) {
+    TH_REQUIRE(comm && d_out, "th_comm_step_word: null argument");
+    *d_out = comm->p2p ? comm->state + th::DP_ST_STEP : nullptr;
+    return 0;
+}
+
 int th_comm_set_timeout_ms(th_comm *comm, int64_t ms) {
     TH_REQUIRE(comm && comm->p2p && ms > 0, "th_comm_set_timeout_ms: needs a peer-to-peer communicator and a positive bound");
     comm->timeout_ms = (long)ms;
     comm->dev.spin_ticks = comm->timeout_ms * 100000L;   // launches enqueued (or captured) from here on
+    comm->dp.spin_ticks = comm->dev.spin_ticks;
     return 0;
 }
 
@@ -488,7 +592,7 @@ int th_allreduce_adam(th_comm *comm, th_ctx *ctx, const float *d_grads, size_t n
                       float beta2, float eps, float weight_decay, int pre_ticked) {
     TH_REQUIRE(comm && ctx && d_grads && d_params && d_m && d_v && d_offsets && d_has_grad && d_t && d_lr && n_tensors > 0,
                "th_allreduce_adam: null argument");
-    TH_REQUIRE(comm->p2p && comm->connected, "th_allreduce_adam: needs a connected peer-to-peer communicator (th_comm_init_p2p / _export / _connect)");
+    TH_REQUIRE(comm->p2p && comm->connected && !comm->loopback, "th_allreduce_adam: needs a connected peer-to-peer communicator (th_comm_init_p2p / _export / _connect)");
     TH_REQUIRE(d_grads == comm->reg_buf && n == comm->reg_n, "th_allreduce_adam: not the buffer this communicator exported");
     TH_REQUIRE(((uintptr_t)d_params & 15) == 0 && ((uintptr_t)d_m & 15) == 0 && ((uintptr_t)d_v & 15) == 0, "th_allreduce_adam: arenas must be 16-byte aligned");
 #define TH_P2P_ADAM(NR_)                                                                                                                       \
@@ -512,11 +616,45 @@ int th_comm_stats(const th_comm *comm, int64_t out2[2]) {
     return 0;
 }
 
+int th_comm_stats_inkernel(const th_comm *comm, int64_t *out_launches) {
+    TH_REQUIRE(comm && out_launches, "th_comm_stats_inkernel: null argument");
+    *out_launches = comm->launches_inkernel;
+    return 0;
+}
+
+int th_comm_exchange_selftest(th_comm *comm, th_ctx *ctx, int slots, int rounds, int *out_bad) {
+    TH_REQUIRE(comm && ctx && out_bad, "th_comm_exchange_selftest: null argument");
+    TH_REQUIRE(comm->p2p && comm->connected, "th_comm_exchange_selftest: needs a connected peer-to-peer communicator");
+    TH_REQUIRE(slots >= 1 && slots <= th::DP_MAX_SLOTS && rounds >= 1, "th_comm_exchange_selftest: 1 .. %d slots", th::DP_MAX_SLOTS);
+    // every rank's workgroups must be able to be resident together when ranks share a device: a waiting workgroup holds its slot
+    TH_REQUIRE(comm->sharing <= 1 || (long)comm->sharing * slots <= 2L * th::kNumCU,
+               "th_comm_exchange_selftest: %d ranks on one device x %d slots do not fit the device together", comm->sharing, slots);
+    uint32_t *bad = nullptr;
+    TH_HIP(hipMalloc((void **)&bad, sizeof(uint32_t)));
+    TH_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+    for (int k = 0; k < rounds; ++k) {
+        hipLaunchKernelGGL(th::dp_bump_kernel, dim3(1), dim3(1), 0, ctx->stream, comm->state);
+#define TH_DP_SELFTEST(NR_) hipLaunchKernelGGL(th::dp_selftest_kernel<NR_>, dim3(slots), dim3(256), 0, ctx->stream, comm->dp, k, comm->loopback ? 1 : 0, bad)
+        if (comm->n_ranks <= 2) TH_DP_SELFTEST(2);
+        else if (comm->n_ranks <= 4) TH_DP_SELFTEST(4);
+        else TH_DP_SELFTEST(8);
+#undef TH_DP_SELFTEST
+    }
+    uint32_t h = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(bad);
+    TH_HIP(e);
+    *out_bad = (int)h;
+    return 0;
+}
+
 int th_allreduce_sum_scale(th_comm *comm, th_ctx *ctx, float *d_buf, size_t n, float scale) {
     TH_REQUIRE(comm && ctx && (n == 0 || d_buf), "th_allreduce_sum_scale: null argument");
     if (n == 0) return 0;
     if (comm->p2p) {   // one-shot over xGMI: every rank reads its peers' buffers directly and adds them in rank order
-        TH_REQUIRE(comm->connected, "th_allreduce_sum_scale: peer-to-peer communicator is not connected");
+        TH_REQUIRE(comm->connected && !comm->loopback, "th_allreduce_sum_scale: peer-to-peer communicator is not connected");
         TH_REQUIRE(d_buf == comm->reg_buf && n == comm->reg_n, "th_allreduce_sum_scale: not the buffer this communicator exported");
         int g = (int)((n / 4 + 255) / 256);             // one float4 per thread while that fits, up to P2P_QUADS beyond
         if (g > P2P_MAX_BLOCKS) g = P2P_MAX_BLOCKS;     // (every workgroup stays resident until all peers are done reading)

@@ -115,6 +115,8 @@ struct th_ctx {
     std::map<std::array<int, 8>, void *> conv_plans;
     int32_t *err_word = nullptr;                      // this device's error block (host-visible; shared by the contexts of a device)
     int m2_max_ksplit = 8;                            // mlp2.hip: cap on the workgroups sharing a row block's k chunks (th_mlp2_set_max_ksplit; 1 = no split)
+    const uint32_t *update_guard = nullptr;           // th_ctx_set_update_guard: deferred updates / counter ticks do nothing once this device word is non-zero
+    uint32_t *update_step_word = nullptr;             // ... and a tick that happens advances this word too (the in-launch exchange's step number, dp_dev.h)
     unsigned *m2_arrive = nullptr;                    // mlp2.hip: arrival counters of k-split row blocks (zero between launches); plain hipMalloc, freed with the ctx
 };
 

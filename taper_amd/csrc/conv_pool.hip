@@ -1418,7 +1418,7 @@ int th_bias_grad_masked_adam(th_ctx *ctx, const float *d_gout, const float *d_ma
     TH_REQUIRE(ctx && d_gout && d_gb && n > 0 && c > 0 && hw > 0, "th_bias_grad_masked_adam: null argument / empty tensor");
     TH_REQUIRE(!pooled_avg || d_mask_y, "th_bias_grad_masked_adam: the average-pool form needs the conv output as mask");
     TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_bias_grad_masked_adam: bad extra slices");
-    const AdamSlices x = make_adam_slices(extra, n_extra);
+    const AdamSlices x = make_adam_slices(extra, n_extra, ctx);
     hipLaunchKernelGGL(bias_grad_adam_kernel, dim3(c + x.blocks()), dim3(1024), 0, ctx->stream, d_gout, d_mask_y, d_gb, n, c, hw,
                        pooled_avg ? 1 : 0, make_adam_dev(b_fuse), x);
     TH_LAUNCH_CHECK();
@@ -1429,7 +1429,7 @@ int th_bias_from_colsum_adam(th_ctx *ctx, const float *d_colsum, float *d_gb, in
                              const th_adam_slice *extra, int n_extra) {
     TH_REQUIRE(ctx && d_colsum && d_gb && c > 0 && hw > 0, "th_bias_from_colsum_adam: null argument / empty tensor");
     TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_bias_from_colsum_adam: bad extra slices");
-    const AdamSlices x = make_adam_slices(extra, n_extra);
+    const AdamSlices x = make_adam_slices(extra, n_extra, ctx);
     hipLaunchKernelGGL(bias_from_colsum_adam_kernel, dim3(1 + x.blocks()), dim3(1024), 0, ctx->stream, d_colsum, d_gb, c, hw, make_adam_dev(b_fuse), x);
     TH_LAUNCH_CHECK();
     return 0;
@@ -1559,7 +1559,7 @@ int th_bias_grad_counts_adam(th_ctx *ctx, const float *d_gout_pooled, const floa
                              const th_adam_fuse *b_fuse, const th_adam_slice *extra, int n_extra) {
     TH_REQUIRE(ctx && d_gout_pooled && d_cnt && d_gb && n > 0 && c > 0 && hw > 0, "th_bias_grad_counts_adam: null argument / empty tensor");
     TH_REQUIRE(n_extra >= 0 && n_extra <= TH_MAX_ADAM_SLICES && (n_extra == 0 || extra), "th_bias_grad_counts_adam: bad extra slices");
-    const AdamSlices x = make_adam_slices(extra, n_extra);
+    const AdamSlices x = make_adam_slices(extra, n_extra, ctx);
     hipLaunchKernelGGL(bias_grad_counts_adam_kernel, dim3(ceil_div(c, 16) + x.blocks()), dim3(1024), 0, ctx->stream, d_gout_pooled, d_cnt,
                        d_gb, n, c, hw, make_adam_dev(b_fuse), x);
     TH_LAUNCH_CHECK();

@@ -1110,7 +1110,7 @@ int th_linear_fwd_ex(th_ctx *ctx, const float *d_x, const float *d_w, const floa
         SmallArgs p{d_x, nullptr, d_w, d_y, nullptr, m, n, k, k, 1, 1, k, (k + 15) / 16 * 16, 0, 0, make_ep(1.0f, 0.0f, d_b, relu)};
         p.a_vec = aligned16(d_x) && (k % 4 == 0);
         p.b_vec = aligned16(d_w) && (k % 4 == 0);
-        const AdamSlices x = make_adam_slices(extra, n_extra);
+        const AdamSlices x = make_adam_slices(extra, n_extra, ctx);
         const dim3 grid(ceil_div(n, 16), ceil_div(m, 16) + 1, 1);
         static const int xcd_map = [] { const char *e = std::getenv("TAPER_K1_XCD_MAP"); return e ? atoi(e) : 1; }();
         p.xcd_blocks = xcd_map && grid.x == 8 && grid.y == 5;
@@ -1296,7 +1296,7 @@ int th_linear_bwd_adam_ex2(th_ctx *ctx, const float *d_x, const float *d_w, cons
         q.out_f = out_features;
         q.db_accum = (accumulate_mask & 4) ? 1 : 0;
         q.n_db = d_db ? ceil_div(out_features, 64) : 0;
-        q.extra = make_adam_slices(extra, n_extra);
+        q.extra = make_adam_slices(extra, n_extra, ctx);
         const int grid = q.n_dw + q.n_dx + q.n_db + q.extra.blocks();
         if (grid == 0) return 0;
         if (d_relu_y) hipLaunchKernelGGL(linear_bwd_small<true>, dim3(grid), dim3(256), 0, ctx->stream, q);

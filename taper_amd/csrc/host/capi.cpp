@@ -277,41 +277,6 @@ int tp_sched_free(tp_sched *s) { TP_BEGIN delete s; TP_END }
 int tp_optim_free(tp_optim *o) { TP_BEGIN delete o; TP_END }
 int tp_optim_step(tp_optim *o) { TP_BEGIN o->o->step(); TP_END }
 int tp_optim_zero_grad(tp_optim *o) { TP_BEGIN o->o->zero_grad(); TP_END }
-// The Trainer's fused-update mode for a hand-written loop (taper.h: FusedAdamScope): between begin and end, backward() applies a parameter's
-// Adam update in the epilogue of the kernel that completes its gradient; Adam::step() -- called INSIDE the scope, as the loop would anyway --
-// covers what nobody fused.  begin opens the optimizer step (t += 1, optim.rs:84) itself: no loss kernel of the eager API does.
-namespace { thread_local taper::FusedAdamScope *t_eager_scope = nullptr; }
-int tp_adam_fused_begin(tp_optim *o) {
-    TP_BEGIN
-    TAPER_ASSERT(o->adam, "not an Adam optimizer");
-    TAPER_ASSERT(!t_eager_scope && !taper::FusedAdamScope::active(), "a fused Adam step is already open on this thread");
-    t_eager_scope = new taper::FusedAdamScope(o->adam.get());
-    try {
-        th_check(th_adam_tick(taper::Device::ctx(), o->adam->d_tick()), "th_adam_tick");
-    } catch (...) {     // (the scope must not stay open behind a failed begin: the caller's `end` never runs)
-        delete t_eager_scope;
-        t_eager_scope = nullptr;
-        throw;
-    }
-    TP_END
-}
-int tp_adam_fused_end(tp_optim *o, int *step_was_open) {
-    TP_BEGIN
-    // backward() ran inside the pair but step() did not: some parameters have their update, the rest do not.  The step is COMPLETED here (the
-    // optimizer's state stays a whole number of steps) and reported, so that the caller can tell its user to move step() inside
-    const bool open = t_eager_scope && o->adam && o->adam->step_open();
-    if (step_was_open) *step_was_open = open ? 1 : 0;
-    try {
-        if (open) o->adam->step();
-    } catch (...) {
-        delete t_eager_scope;
-        t_eager_scope = nullptr;
-        throw;
-    }
-    delete t_eager_scope;
-    t_eager_scope = nullptr;
-    TP_END
-}
 int tp_adam_set_lr(tp_optim *o, float lr) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); o->adam->set_lr(lr); TP_END }
 int tp_adam_get_lr(const tp_optim *o, float *out) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); *out = o->adam->get_lr(); TP_END }
 int tp_adam_t(const tp_optim *o, int *out) { TP_BEGIN TAPER_ASSERT(o->adam, "not an Adam optimizer"); *out = o->adam->t(); TP_END }
@@ -371,6 +336,14 @@ int tp_comm_new(int n, int r, const uint8_t id[128], tp_comm **out) {
     TP_BEGIN *out = new tp_comm{std::make_shared<Communicator>(n, r, std::vector<uint8_t>(id, id + 128))}; TP_END
 }
 int tp_comm_new_p2p(int n, int r, tp_comm **out) { TP_BEGIN *out = new tp_comm{Communicator::p2p(n, r)}; TP_END }
+int tp_comm_new_loopback(tp_comm **out) { TP_BEGIN *out = new tp_comm{Communicator::loopback()}; TP_END }
+int tp_comm_set_inkernel(tp_comm *c, int on) { TP_BEGIN c->c->inkernel = on != 0; TP_END }
+int tp_comm_inkernel_launches(tp_comm *c, int64_t *out) { TP_BEGIN *out = c->c->inkernel_launches(); TP_END }
+int tp_comm_exchange_selftest(tp_comm *c, int slots, int rounds, int *out_bad) { TP_BEGIN *out_bad = c->c->exchange_selftest(slots, rounds); TP_END }
+int tp_comm_ranks_on_this_device(tp_comm *c, int *out) { TP_BEGIN *out = c->c->ranks_on_this_device(); TP_END }
+int tp_comm_tail_exchange_ok(tp_comm *c, int batch, int in_features, int hidden, int classes, int *out) {
+    TP_BEGIN *out = c->c->tail_exchange_ok(batch, in_features, hidden, classes) ? 1 : 0; TP_END
+}
 int tp_comm_export_arena(tp_comm *c, tp_optim *o, uint8_t out_blob[192]) {
     TP_BEGIN
     auto b = c->c->export_arena(*o->o);

@@ -343,6 +343,14 @@ Tensor mlp_tail_cross_entropy(const Tensor &x, const Tensor &w1, const Tensor &b
         if (!need_dx && fa->fuse_for(w1, &wf)) pw = &wf;
         if (b1.defined() && fa->fuse_for(b1, &bf)) pb = &bf;
     }
+    const Communicator *xc = TailExchangeScope::active();
+    if (xc && xc->n_ranks > 1) {
+        // data parallel: the launch exchanges every finished slice with the peers; its epilogues apply the mean
+        TAPER_ASSERT(fa && !need_dx && xc->tail_exchange_ok(b, in_f, hid, c), "mlp_tail_cross_entropy: the in-launch exchange does not cover this step");
+        TH(th_mlp_tail_dp(xc->handle(), ctx, x.dptr(), h.dptr(), w2.dptr(), b2.defined() ? b2.dptr() : nullptr, targets.dptr(), b, in_f, hid, c,
+                          loss.dptr(), nc, dw1, db1, dw2, db2, log ? log->d_metrics : nullptr, log ? log->capacity : 0,
+                          log ? log->d_state : nullptr, log ? log->advance : 0, pw, pb, fa->d_tick()));
+    } else
     TH(th_mlp_tail(ctx, x.dptr(), h.dptr(), w2.dptr(), b2.defined() ? b2.dptr() : nullptr, targets.dptr(), b, in_f, hid, c, loss.dptr(),
                    nc, dw1, db1, dw2, db2, need_dx ? w1.dptr() : nullptr, dx ? dx->d : nullptr, log ? log->d_metrics : nullptr,
                    log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0, pw, pb));
@@ -1016,6 +1024,13 @@ FusedAdamScope::~FusedAdamScope() {
 Adam *FusedAdamScope::active() { return t_fused_adam; }
 
 namespace {
+thread_local const Communicator *t_tail_exchange = nullptr;
+}
+TailExchangeScope::TailExchangeScope(const Communicator *comm) : prev_(t_tail_exchange) { t_tail_exchange = comm; }
+TailExchangeScope::~TailExchangeScope() { t_tail_exchange = prev_; }
+const Communicator *TailExchangeScope::active() { return t_tail_exchange; }
+
+namespace {
 thread_local bool t_pool_bias = false;
 thread_local bool t_no_grad = false;
 }
@@ -1243,7 +1258,43 @@ std::shared_ptr<Communicator> Communicator::p2p(int n, int r) {
     c->p2p_ = true;
     TH(th_comm_init_p2p(Device::ctx(), n, r, &c->comm_));
     if (const char *e = std::getenv("TAPER_P2P_FUSE")) c->fuse_adam = e[0] != '0';   // measurement / test probe
+    if (const char *e = std::getenv("TAPER_DP_INKERNEL")) c->inkernel = e[0] != '0';  // 0: always the three-launch form
     return c;
+}
+
+std::shared_ptr<Communicator> Communicator::loopback() {
+    std::shared_ptr<Communicator> c(new Communicator());
+    c->n_ranks = 2;
+    c->rank = 0;
+    c->p2p_ = true;
+    c->loopback_ = true;
+    TH(th_comm_init_loopback(Device::ctx(), &c->comm_));
+    return c;
+}
+
+bool Communicator::tail_exchange_ok(int batch, int in_features, int hidden, int classes) const {
+    if (!p2p_ || !inkernel) return false;
+    // one rank: the mean over the ranks IS this rank's gradient -- the step is the single-GPU step, nothing to exchange
+    if (n_ranks == 1) return th_mlp_tail_supported(batch, in_features, hidden, classes, 0) != 0;
+    return th_mlp_tail_dp_supported(comm_, Device::ctx(), batch, in_features, hidden, classes) != 0;
+}
+
+int64_t Communicator::inkernel_launches() const {
+    int64_t n = 0;
+    TH(th_comm_stats_inkernel(comm_, &n));
+    return n;
+}
+
+int Communicator::exchange_selftest(int slots, int rounds) const {
+    int bad = 0;
+    TH(th_comm_exchange_selftest(comm_, Device::ctx(), slots, rounds, &bad));
+    return bad;
+}
+
+int Communicator::ranks_on_this_device() const {
+    int n = 1;
+    TH(th_comm_sharing(comm_, &n));
+    return n;
 }
 
 std::vector<uint8_t> Communicator::export_arena(Optimizer &opt, bool fine_grained) {
@@ -1366,6 +1417,12 @@ bool Communicator::self_check(Optimizer &opt, int rounds) {
     reset_grads();
     fp.sync_mask();
     Device::sync();
+    // (3) the exchange inside the gradient launch (th_mlp_tail_dp), on its own: 16 slots of patterns per round through the same flags, receive
+    // slots and step counter a training step uses.  Collective like the rounds above: every rank runs it whatever it has seen so far.
+    if (p2p_ && inkernel && rounds > 0) {
+        if (exchange_selftest(16, rounds) != 0) ok = false;
+        if (timed_out()) ok = false;
+    }
     return ok;
 }
 
@@ -1382,6 +1439,12 @@ bool Communicator::failed() const {
 }
 
 void Communicator::set_timeout_ms(int64_t ms) { TH(th_comm_set_timeout_ms(comm_, ms)); }
+
+uint32_t *Communicator::step_word() const {
+    uint32_t *w = nullptr;
+    TH(th_comm_step_word(comm_, &w));
+    return w;
+}
 
 const uint32_t *Communicator::error_word() const {
     const uint32_t *w = nullptr;
@@ -1572,8 +1635,11 @@ bool Trainer::mlp2_step(size_t batch, int64_t n_rows) const {
 void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_row_source *rows) {
     int64_t *state = reinterpret_cast<int64_t *>(state_->d);
     // Adam updates ride in the epilogues of the kernels that produce the gradients -- unless the
-    // gradients still have to be all-reduced across ranks first
-    FusedAdamScope scope((fuse_adam && !comm) ? optimizer.get() : nullptr);
+    // gradients still have to be all-reduced across ranks first by a launch of their own.  The Linear + ReLU + Linear step over a
+    // peer-to-peer communicator reduces them INSIDE its gradient launch (th_mlp_tail_dp) and keeps the fused epilogues.
+    const bool dp_tail = comm && !rows && tail_exchange_step(batch);
+    FusedAdamScope scope((fuse_adam && (!comm || dp_tail)) ? optimizer.get() : nullptr);
+    TailExchangeScope xscope(dp_tail ? comm.get() : nullptr);
     PoolBiasScope pool_scope(fuse_head && dynamic_cast<Sequential *>(model.get()) != nullptr);
     Tape::reset();
     StepLogSink sink{metrics_->d, (int64_t)metrics_cap_, state, (int64_t)batch,
@@ -1681,7 +1747,9 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
         loss = cross_entropy_loss(model->forward(xin), y, &ncorrect, &sink);
     }
     loss.backward();
-    if (!(comm && optimizer->step_reduced(*comm))) {   // peer-to-peer communicator: all-reduce + Adam in one launch
+    if (dp_tail) {
+        optimizer->step();   // (nothing is left: every update ran in an epilogue, on the mean gradient, or waits for the next step's first launch)
+    } else if (!(comm && optimizer->step_reduced(*comm))) {   // peer-to-peer communicator: all-reduce + Adam in one launch
         reduce_grads(*this);
         optimizer->step();
         optimizer->set_step_guard(nullptr);
@@ -1690,9 +1758,32 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
     if (adam) adam->set_carry_deferred(false);
 }
 
+// this step is Linear + ReLU + Linear + cross-entropy straight on the loader's rows, every parameter trains and has no gradient yet, the
+// optimizer is Adam with fused updates on, and the communicator can exchange the slices inside the launch: the two-launch step of one GPU,
+// with the mean gradient in its epilogues
+bool Trainer::tail_exchange_step(size_t batch) const {
+    if (!comm || !comm->is_p2p() || !comm->fuse_adam || !fuse_adam || fuse_head < 2 || !sample_shape.empty()) return false;
+    auto *seq = dynamic_cast<Sequential *>(model.get());
+    if (!seq || !seq->fuse || seq->layers.size() != 3 || !dynamic_cast<Adam *>(optimizer.get())) return false;
+    auto *l1 = dynamic_cast<Linear *>(seq->layers[0].get());
+    auto *l2 = dynamic_cast<Linear *>(seq->layers[2].get());
+    if (!l1 || !l2 || !dynamic_cast<ReLU *>(seq->layers[1].get()) || l1->weight.shape()[1] != 784) return false;
+    for (const Tensor *p : {&l1->weight, &l1->bias, &l2->weight, &l2->bias})
+        if (p->defined() && (!p->get_requires_grad() || p->has_grad())) return false;
+    if (!l1->bias.defined() || !l2->bias.defined()) return false;
+    return comm->tail_exchange_ok((int)batch, 784, (int)l1->weight.shape()[0], (int)l2->weight.shape()[0]);
+}
+
 void Trainer::enqueue_steps(const float *d_images, const float *d_labels, const int32_t *d_indices, int64_t n_indices,
                             size_t batch, size_t steps) {
     int64_t *state = reinterpret_cast<int64_t *>(state_->d);
+    // behind a failed exchange of a peer-to-peer communicator nothing may move: the launches that apply deferred updates or tick Adam's
+    // counter (the next step's first launch, the flush below) look at its error word first
+    // (and every tick of Adam's counter advances the exchange's step number with it: th_ctx_set_update_guard)
+    struct Guard {
+        Guard(const uint32_t *w, uint32_t *step) { TH(th_ctx_set_update_guard(Device::ctx(), w, step)); }
+        ~Guard() { th_ctx_set_update_guard(Device::ctx(), nullptr, nullptr); }
+    } guard(comm && comm->is_p2p() ? comm->error_word() : nullptr, comm && comm->is_p2p() ? comm->step_word() : nullptr);
     if (mlp2_step(batch, d_indices ? n_indices : (int64_t)batch)) {
         // the step reads its rows where they lie: through the index vector at the device cursor (every step's log advances it), or the
         // dataset itself for the one-step epoch in index order -- no gather launch, no staging buffer

@@ -633,6 +633,18 @@ class FusedAdamScope {
     Adam *prev_;
 };
 
+// A data-parallel step whose gradient launch exchanges its slices itself (Trainer-internal): while active, mlp_tail_cross_entropy
+// launches th_mlp_tail_dp on this communicator -- what its fused epilogues apply is then the mean over the ranks.
+class TailExchangeScope {
+   public:
+    explicit TailExchangeScope(const class Communicator *comm);
+    ~TailExchangeScope();
+    static const class Communicator *active();
+
+   private:
+    const class Communicator *prev_;
+};
+
 // ---- data (src/data/mnist.rs) -----------------------------------------------------
 class MNISTDataset {
    public:
@@ -678,6 +690,17 @@ class Communicator {
     // Peer-to-peer form (one node, <= 8 ranks; th_comm_init_p2p): a one-shot all-reduce for latency-bound gradient arenas.
     // p2p() -> export_arena(optimizer) -> [ship every rank's blob to every rank] -> connect(blobs in rank order).
     static std::shared_ptr<Communicator> p2p(int n_ranks, int rank);
+    // W = 2 with this process as its own peer (th_comm_init_loopback): every push, flag, poll and load of the in-launch exchange runs, through
+    // local memory; results are the single-GPU step's bit for bit.  What a one-GPU box can measure of the protocol's cost.
+    static std::shared_ptr<Communicator> loopback();
+    bool is_loopback() const { return loopback_; }
+    // The exchange inside the gradient launch (th_mlp_tail_dp): may this communicator take it for a Linear + ReLU + Linear classifier of these
+    // shapes?  (peer-to-peer, connected, >= 2 ranks, whole tiles, and -- ranks sharing a device -- room for the waiting workgroups)
+    bool tail_exchange_ok(int batch, int in_features, int hidden, int classes) const;
+    bool inkernel = true;                                 // TAPER_DP_INKERNEL=0: always the three-launch form (A/B probe)
+    int64_t inkernel_launches() const;                    // th_mlp_tail_dp launches enqueued or captured
+    int exchange_selftest(int slots, int rounds) const;   // collective; mismatches + time-outs seen by this rank (th_comm_exchange_selftest)
+    int ranks_on_this_device() const;
     // fine_grained: first move the optimizer's gradient arena into fine-grained device memory (coherent across agents, never cached in a
     // peer's L2) -- the fallback when the multi-round self-check fails on the pooled, coarse-grained arena.  The communicator keeps the
     // arenas it registered alive; destroy it on every rank before the optimizer goes away (peers hold IPC mappings of the arena).
@@ -696,6 +719,7 @@ class Communicator {
     void allreduce_mean(float *d_buf, size_t n) const;  // sum over ranks * 1/W on the ctx stream
     th_comm *handle() const { return comm_; }
     const uint32_t *error_word() const;                   // device word, non-zero once an all-reduce timed out (nullptr: RCCL)
+    uint32_t *step_word() const;                          // device word: the in-launch exchange's step number (nullptr: RCCL)
     // `reps` exchanges as a Trainer step issues them (all-reduce + Adam: one fused launch, or all-reduce then Adam::step), back to back
     // between two events on the stream, on every rank at once; us per exchange.  The optimizer state moves (call it after the timed run).
     float time_exchange(Adam &opt, int reps);
@@ -705,7 +729,7 @@ class Communicator {
    private:
     Communicator() : n_ranks(1), rank(0) {}
     th_comm *comm_ = nullptr;
-    bool p2p_ = false;
+    bool p2p_ = false, loopback_ = false;
     std::shared_ptr<Buffer> g_hold_, p_hold_;             // the arenas registered with (and mapped by) the peers
 };
 
@@ -770,6 +794,7 @@ class Trainer {  // train.rs:74-172
                        size_t batch, size_t steps);
     void enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_row_source *rows = nullptr);
     bool mlp2_step(size_t batch, int64_t n_rows) const;   // this model at this batch takes th_mlp2_xent (rows read in place)
+    bool tail_exchange_step(size_t batch) const;          // data parallel: this step reduces its gradients inside its own launch (th_mlp_tail_dp)
     void drop_graphs();
     std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
     std::vector<std::pair<size_t, th_graph *>> whole_graphs_;  // (steps, graph): state reset + that many full steps -- a whole call in one replay

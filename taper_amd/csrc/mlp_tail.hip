@@ -24,6 +24,7 @@
 // W2 / b2 are READ by every workgroup, so their update cannot run here: the caller defers it
 // (th_adam_slice) to the next launch that does not read them (th_linear_fwd_ex of the next step).
 #include "tail_dev.h"
+#include "dp_dev.h"
 
 TH_USES_DEVICE_ERRORS()
 
@@ -42,6 +43,8 @@ struct TailArgs {
     const float *w1;                     // dX role (whole-tile kernel only): dX[B,in] = dZ1 . W1
     float *dx;
     int xgroups;                         // 32-column groups of dX; its workgroups: xgroups x ceil(B / 64) behind the dW blocks
+    DpDev dp;                            // th_mlp_tail_dp: the gradient exchange across ranks in the epilogues (dp_dev.h)
+    int32_t *dp_tick;                    // ... the step counter this step's first launch ticked (taken back when the exchange fails)
 };
 
 #ifdef TH_PROFILE
@@ -442,7 +445,10 @@ __device__ __forceinline__ void tail_dx_role(const TailArgs &a, int rb) {
 
 // NW waves per workgroup (4 / 8): the 64-row chunks of a batch are a serial chain per wave (2.7 us each), so batches
 // above 64 rows get more waves instead of more iterations; waves 0..3 finish the tile.
-template <int KS, int TN, bool HAS_DX, int NW>
+// DPNR > 0 (th_mlp_tail_dp): data parallel, DPNR >= the communicator's rank count -- every finished slice (a dW1 block; a head workgroup's
+// dW2 tile, db1 and, in the lead, db2) goes through dp_exchange() before it is stored or fed to Adam: what is applied is the MEAN over the
+// ranks, formed in rank order.  Loss and hit count stay this rank's own (the host averages the step logs).
+template <int KS, int TN, bool HAS_DX, int NW, int DPNR = 0>
 __global__ __launch_bounds__(64 * NW) void mlp_tail_exact_kernel(TailArgs a) {
     constexpr unsigned HID = 16 * KS;
     __shared__ float red[NW][TN][64][4];
@@ -458,18 +464,20 @@ __global__ __launch_bounds__(64 * NW) void mlp_tail_exact_kernel(TailArgs a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
     const int bid = blockIdx.x;
     TAIL_STAMP(0);
+    DpTicket dp_tk{0u, 0u};
+    if constexpr (DPNR > 0) dp_tk = dp_begin(a.dp);   // (two scalar loads, looked at when the slice is ready)
     if (HAS_DX && bid >= a.n_head + a.n_dw) {   // (its own instantiation: the code of a role nobody runs still costs instruction fetches)
         tail_dx_role<KS, NW>(a, bid - a.n_head - a.n_dw);
         return;
     }
     const bool head_role = bid < a.n_head;
-    int tile_m, grp = 0;
+    int tile_m, grp = 0, tt = 0;
     if (!head_role) {
         const int b2 = bid - a.n_head;
         // XCD x takes the x-th eighth of the blocks, hidden tile innermost: each L2 fetches only its own X columns.
         // (XCD x = hidden tile x for every column group was 0.2 us faster -- the next forward launch reads the same W1 rows
         // on the same XCD -- but every L2 then fetches all of X: 4.9 MB instead of 3.8 MB of fabric traffic per launch.)
-        const int tt = (b2 & 7) * (a.n_dw >> 3) + (b2 >> 3);
+        tt = (b2 & 7) * (a.n_dw >> 3) + (b2 >> 3);
         if (tt >= KS * a.groups) return;
         tile_m = tt % KS;
         grp = tt / KS;
@@ -640,13 +648,26 @@ __global__ __launch_bounds__(64 * NW) void mlp_tail_exact_kernel(TailArgs a) {
             for (int i = 0; i < 4; ++i) red[wave][tn][lane][i] = accdw[tn][i];
         __syncthreads();
         TAIL_STAMP(6);
+        float outv[TN];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
+            outv[tn] = 0.f;
             if (!tn_ok[tn] || !finisher) continue;
             float out = red[0][tn][lane][wave];
 #pragma unroll
             for (int w = 1; w < NW; ++w) out += red[w][tn][lane][wave];
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dw1) + e_off + tn * 64) = out;
+            outv[tn] = out;
+        }
+        if constexpr (DPNR > 0) {
+            // slice KS + tt of the launch: the same block of dW1 on every rank (finisher thread (wave, lane) holds the same elements everywhere)
+            if (!dp_exchange<DPNR, TN>(a.dp, dp_tk, KS + tt, finisher ? t : -1, outv)) return;   // nothing applied; the word is up
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            if (!tn_ok[tn] || !finisher) continue;
+            const float out = outv[tn];
+            // (data parallel with the update fused: the reduced gradient goes straight into Adam and is never written)
+            if (DPNR == 0 || !fuse_w) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dw1) + e_off + tn * 64) = out;
             if (fuse_w) {
                 const AdamDev &ad = a.w1_adam;
                 const float gv = out + ad.wd * e_p[tn];
@@ -672,14 +693,59 @@ __global__ __launch_bounds__(64 * NW) void mlp_tail_exact_kernel(TailArgs a) {
     }
     __syncthreads();
     TAIL_STAMP(6);
-    if (a.dw2 && (NW == 4 || wave < 4)) {   // wave e: class 4 g4 + e
+    if constexpr (DPNR > 0) {
+        // slice tile_m of the launch, two values per thread of waves 0..3: [0] this thread's dW2 element, [1] db1 (threads 0..15) or, in the
+        // lead workgroup, db2 (threads 16..16 + C - 1).  Reduced over the ranks, then exactly the single-GPU epilogue on the means.
+        float hv2[2] = {0.f, 0.f};
+        const int cls = g4 * 4 + wave;
+        if (a.dw2 && wave < 4 && cls < C) {
+            float sum = red[0][0][lane][wave];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sum += red[w][0][lane][wave];
+            hv2[0] = sum;
+        }
+        if (a.db1 && t < 16) {
+            float out = sc[0][t];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) out += sc[w][t];
+            hv2[1] = out;
+        } else if (lead && a.db2 && t >= 16 && t < 16 + C) {
+            float sum = sc[0][t];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sum += sc[w][t];
+            hv2[1] = sum;
+        }
+        const bool okx = dp_exchange<DPNR, 2>(a.dp, dp_tk, tile_m, wave < 4 ? t : -1, hv2);
+        if (!okx) {   // a peer's slice never came: nothing is applied, nothing is logged; the lead takes this step's tick back (optim.rs:84)
+            // (only when the exchange failed in THIS launch: behind a dead communicator the step's first launch has not ticked)
+            if (lead && t == 0 && a.dp_tick && dp_tk.dead == 0u) atomicSub(a.dp_tick, 1);
+            return;
+        }
+        if (a.dw2 && wave < 4 && cls < C) a.dw2[cls * HID + hcol] = hv2[0];
+        if (a.db1 && t < 16) {
+            const float out = hv2[1];
+            const int ix = tile_m * 16 + t;
+            a.db1[ix] = out;
+            if (fuse_b1) {
+                const AdamDev &ad = a.b1_adam;
+                const float gv = out + ad.wd * bp_;
+                const float mn = ad.beta1 * bm_ + (1.0f - ad.beta1) * gv;
+                const float vn = ad.beta2 * bv_ + (1.0f - ad.beta2) * gv * gv;
+                ad.m[ix] = mn;
+                ad.v[ix] = vn;
+                ad.p[ix] = bp_ - b_step * mn / (sqrtf(vn) + ad.eps);
+            }
+        }
+        if (lead && a.db2 && t >= 16 && t < 16 + C) a.db2[t - 16] = hv2[1];
+    }
+    if (DPNR == 0 && a.dw2 && (NW == 4 || wave < 4)) {   // wave e: class 4 g4 + e
         const int cls = g4 * 4 + wave;
         float sum = red[0][0][lane][wave];
 #pragma unroll
         for (int w = 1; w < NW; ++w) sum += red[w][0][lane][wave];
         if (cls < C) a.dw2[cls * HID + hcol] = sum;
     }
-    if (a.db1 && t < 16) {
+    if (DPNR == 0 && a.db1 && t < 16) {
         float out = sc[0][t];
 #pragma unroll
         for (int w = 1; w < NW; ++w) out += sc[w][t];
@@ -696,7 +762,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_tail_exact_kernel(TailArgs a) {
         }
     }
     if (lead) {
-        if (a.db2 && t < C) {
+        if (DPNR == 0 && a.db2 && t < C) {
             float sum = sc[0][16 + t];
 #pragma unroll
             for (int w = 1; w < NW; ++w) sum += sc[w][16 + t];
@@ -738,11 +804,52 @@ extern "C" int th_mlp_tail_supported(int batch, int in_features, int hidden, int
     return ok && (!need_dx || tail_whole_tiles(batch, in_features, hidden));
 }
 
-extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
+// the data-parallel instances: whole tiles, two input tiles per dW1 workgroup, hidden 64 / 128 (the MNIST MLPs), no dX role
+static bool tail_dp_shapes(int batch, int in_features, int hidden, int classes) {
+    return th_mlp_tail_supported(batch, in_features, hidden, classes, 0) && tail_whole_tiles(batch, in_features, hidden) &&
+           (hidden == 64 || hidden == 128);
+}
+static int tail_dp_grid(int in_features, int hidden) {
+    const int tiles_m = hidden / 16, groups = ceil_div(in_features, 32);
+    return ((tiles_m * groups + 7) & ~7) + ((tiles_m + 7) & ~7);
+}
+template <int KS, int NW>
+static const void *tail_dp_instance(int n_ranks) {
+    if (n_ranks <= 2) return (const void *)mlp_tail_exact_kernel<KS, 2, false, NW, 2>;
+    if (n_ranks <= 4) return (const void *)mlp_tail_exact_kernel<KS, 2, false, NW, 4>;
+    return (const void *)mlp_tail_exact_kernel<KS, 2, false, NW, 8>;
+}
+static const void *tail_dp_kernel(int batch, int hidden, int n_ranks) {
+    const bool nw8 = batch > 64;
+    if (hidden == 64) return nw8 ? tail_dp_instance<4, 8>(n_ranks) : tail_dp_instance<4, 4>(n_ranks);
+    return nw8 ? tail_dp_instance<8, 8>(n_ranks) : tail_dp_instance<8, 4>(n_ranks);
+}
+
+extern "C" int th_mlp_tail_dp_supported(const th_comm *comm, th_ctx *ctx, int batch, int in_features, int hidden, int classes) {
+    const DpDev *dp = comm_dp_dev(comm);
+    if (!dp || !ctx || dp->n_ranks < 2 || !tail_dp_shapes(batch, in_features, hidden, classes)) return 0;
+    const int grid = tail_dp_grid(in_features, hidden);
+    if (grid > DP_MAX_SLOTS) return 0;
+    const int sharing = comm_dp_sharing(comm);
+    if (sharing > 1) {
+        // Ranks on ONE device (a test box): a workgroup that waits for a peer's slice holds its place, so the workgroups of all the
+        // ranks but one must leave a place free -- the rank that is furthest behind then always gets its next workgroup dispatched, its
+        // workgroups never wait for anybody who is not already resident, and the wait graph has no cycle.
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tail_dp_kernel(batch, hidden, dp->n_ranks), batch > 64 ? 512 : 256, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        if ((long)(sharing - 1) * grid >= (long)per_cu * kNumCU) return 0;
+    }
+    return 1;
+}
+
+static int mlp_tail_launch(th_comm *comm, th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
                            const float *d_targets, int batch, int in_features, int hidden, int classes, float *d_loss,
                            float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2, const float *d_w1, float *d_dx,
                            float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
-                           const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse) {
+                           const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse, int32_t *d_tick) {
     TH_REQUIRE(ctx && d_x && d_h && d_w2 && d_targets && d_loss && d_dw1, "th_mlp_tail: null argument");
     TH_REQUIRE(th_mlp_tail_supported(batch, in_features, hidden, classes, 0),
                "th_mlp_tail: needs batch <= 512, hidden <= 256 and a multiple of 4, classes <= 16 (got %d, %d, %d)", batch, hidden, classes);
@@ -752,11 +859,12 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
     TH_REQUIRE((((uintptr_t)d_h | (uintptr_t)d_w2) & 15) == 0, "th_mlp_tail: d_h and d_w2 must be 16-byte aligned");
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_mlp_tail: metrics need d_state and a capacity");
     TH_REQUIRE(!(b1_fuse && b1_fuse->d_p) || d_db1, "th_mlp_tail: fused b1 update needs d_db1");
-    static const int tn = [] {   // measurement probe: TAPER_TAIL_TN = 1 | 2 | 4 input tiles per dW1 workgroup
+    static const int tn_env = [] {   // measurement probe: TAPER_TAIL_TN = 1 | 2 | 4 input tiles per dW1 workgroup
         const char *e = getenv("TAPER_TAIL_TN");
         const int v = e ? atoi(e) : 2;
         return (v == 1 || v == 4) ? v : 2;
     }();
+    const int tn = comm ? 2 : tn_env;
     TailArgs a{};
     a.x = d_x; a.h = d_h; a.w2 = d_w2; a.b2 = d_b2; a.targets = d_targets;
     a.batch = batch; a.in_f = in_features; a.hid = hidden; a.c = classes;
@@ -774,12 +882,25 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
     // waves per workgroup of the whole-tile kernel: one 16-row block per wave and pass -- 4 up to 64 rows, 8 above (16 waves need
     // <= 128 VGPRs: spills, and measured no better); TAPER_TAIL_NW = 4 | 8 forces a count (measurement probe)
     static const int nw_env = getenv("TAPER_TAIL_NW") ? atoi(getenv("TAPER_TAIL_NW")) : 0;
-    const int nw_eff = (nw_env == 4 || nw_env == 8) ? nw_env : (batch <= 64 ? 4 : 8);
+    const int nw_eff = (!comm && (nw_env == 4 || nw_env == 8)) ? nw_env : (batch <= 64 ? 4 : 8);
     const int nw = nw_eff;
     const int grid = a.n_dw + a.n_head + (d_dx ? a.xgroups * ceil_div(batch, 16 * nw_eff) : 0);
     // whole tiles everywhere (the MNIST MLP: 784-128-10, batches of 64 / 32): the short-instruction-stream kernel
     const bool exact = tail_whole_tiles(batch, in_features, hidden) &&
                        (d_dx || !(getenv("TAPER_TAIL_GENERAL") && getenv("TAPER_TAIL_GENERAL")[0] == '1'));
+    if (comm) {
+        const DpDev *dp = comm_dp_dev(comm);
+        TH_REQUIRE(dp && th_mlp_tail_dp_supported(comm, ctx, batch, in_features, hidden, classes),
+                   "th_mlp_tail_dp: this communicator / shape cannot take the in-launch exchange (th_mlp_tail_dp_supported)");
+        TH_REQUIRE(!d_dx && exact && grid == tail_dp_grid(in_features, hidden), "th_mlp_tail_dp: internal: launch shape");
+        a.dp = *dp;
+        a.dp_tick = d_tick;
+        const void *fn = tail_dp_kernel(batch, hidden, dp->n_ranks);
+        void *args[] = {&a};
+        TH_HIP(hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), args, 0, ctx->stream));
+        comm_dp_count_launch(comm);
+        return 0;
+    }
 #define TH_TAIL_LAUNCH(KS, TN)                                                                                        \
     do {                                                                                                              \
         if (exact && d_dx && nw == 8) hipLaunchKernelGGL((mlp_tail_exact_kernel<KS, TN, true, 8>), dim3(grid), dim3(512), 0, ctx->stream, a);     \
@@ -802,6 +923,25 @@ extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, cons
 #undef TH_TAIL_LAUNCH
     TH_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int th_mlp_tail(th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
+                           const float *d_targets, int batch, int in_features, int hidden, int classes, float *d_loss,
+                           float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2, const float *d_w1, float *d_dx,
+                           float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                           const th_adam_fuse *w1_fuse, const th_adam_fuse *b1_fuse) {
+    return mlp_tail_launch(nullptr, ctx, d_x, d_h, d_w2, d_b2, d_targets, batch, in_features, hidden, classes, d_loss, d_ncorrect, d_dw1, d_db1,
+                           d_dw2, d_db2, d_w1, d_dx, d_metrics, metrics_capacity, d_state, advance, w1_fuse, b1_fuse, nullptr);
+}
+
+extern "C" int th_mlp_tail_dp(th_comm *comm, th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
+                              const float *d_targets, int batch, int in_features, int hidden, int classes, float *d_loss,
+                              float *d_ncorrect, float *d_dw1, float *d_db1, float *d_dw2, float *d_db2, float *d_metrics,
+                              int64_t metrics_capacity, int64_t *d_state, int64_t advance, const th_adam_fuse *w1_fuse,
+                              const th_adam_fuse *b1_fuse, int32_t *d_tick) {
+    TH_REQUIRE(comm, "th_mlp_tail_dp: null communicator");
+    return mlp_tail_launch(comm, ctx, d_x, d_h, d_w2, d_b2, d_targets, batch, in_features, hidden, classes, d_loss, d_ncorrect, d_dw1, d_db1,
+                           d_dw2, d_db2, nullptr, nullptr, d_metrics, metrics_capacity, d_state, advance, w1_fuse, b1_fuse, d_tick);
 }
 
 #ifdef TH_PROFILE

@@ -75,8 +75,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
-__global__ void adam_tick_kernel(int32_t *t_state) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) t_state[0] += 1;
+__global__ void adam_tick_kernel(int32_t *t_state, const uint32_t *guard, uint32_t *step_word) {
+    if (guard && guard[0] != 0u) return;   // th_ctx_set_update_guard
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        t_state[0] += 1;
+        if (step_word) step_word[0] += 1u;
+    }
 }
 
 // Adam on one contiguous slice with an already-ticked t (fallback of the fused
@@ -171,14 +175,14 @@ int th_adam_step(th_ctx *ctx, float *d_params, const float *d_grads, float *d_m,
 
 int th_adam_tick(th_ctx *ctx, int32_t *d_t) {
     TH_REQUIRE(ctx && d_t, "th_adam_tick: null argument");
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, ctx->stream, d_t);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, ctx->stream, d_t, ctx->update_guard, ctx->update_step_word);
     TH_LAUNCH_CHECK();
     return 0;
 }
 
 int th_adam_slices(th_ctx *ctx, const th_adam_slice *slices, int n) {
     TH_REQUIRE(ctx && n >= 0 && n <= TH_MAX_ADAM_SLICES && (n == 0 || slices), "th_adam_slices: bad argument");
-    const AdamSlices x = make_adam_slices(slices, n);
+    const AdamSlices x = make_adam_slices(slices, n, ctx);
     if (x.blocks() == 0) return 0;
     hipLaunchKernelGGL(adam_slices_kernel, dim3(x.blocks()), dim3(256), 0, ctx->stream, x);
     TH_LAUNCH_CHECK();

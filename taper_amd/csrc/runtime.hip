@@ -119,6 +119,13 @@ int th_ctx_destroy(th_ctx *ctx) {
     return 0;
 }
 
+int th_ctx_set_update_guard(th_ctx *ctx, const uint32_t *d_skip_if_nonzero, uint32_t *d_step_word) {
+    TH_REQUIRE(ctx, "th_ctx_set_update_guard: null ctx");
+    ctx->update_guard = d_skip_if_nonzero;   // read when a launch is enqueued (or captured): launches already in a graph keep what they were given
+    ctx->update_step_word = d_step_word;
+    return 0;
+}
+
 int th_ctx_sync(th_ctx *ctx) {
     TH_REQUIRE(ctx, "th_ctx_sync: null ctx");
     TH_HIP(hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,90 @@
+"""The data-parallel exchange INSIDE the gradient launch (csrc/dp_dev.h, th_mlp_tail_dp) in ONE process: a loopback communicator is
+W = 2 with this process as its own peer -- every push, flag, poll and load of the protocol runs, through local memory, and because
+(g + g) * 0.5 == g the step must be the single-GPU step bit for bit.  The W > 1 runs across processes are in tests/test_gpu_dp.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mlp(T, hidden=128):
+    return T.Sequential([T.Linear(784, hidden, True, seed=1), T.ReLU(), T.Linear(hidden, 10, True, seed=2)])
+
+
+def _data(n, seed=5):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 256, (n, 784)).astype(np.float32) / 255.0
+    y = rng.integers(0, 10, n).astype(np.float32)
+    return x, y
+
+
+def _train(T, batch, steps, mode, hidden, comm_kind):
+    model = _mlp(T, hidden)
+    opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+    comm = None
+    if comm_kind == "loopback":
+        comm = T.Communicator.loopback()
+    elif comm_kind == "one_rank":
+        comm = T.Communicator.p2p(1, 0)
+        comm.connect(comm.export_arena(opt))
+    tr = T.Trainer(model, opt, comm=comm)
+    x, y = _data(batch * steps)
+    loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False)
+    losses = np.concatenate([tr.run_epoch(loader, mode)["losses"] for _ in range(2)])
+    return losses, [p.data() for p in model.parameters()], opt.t(), opt.moments()[0], opt.moments()[1], comm
+
+
+def test_loopback_exchange_selftest():
+    import taper_amd as T
+    comm = T.Communicator.loopback()
+    assert comm.is_p2p() and comm.ranks_on_this_device() == 1
+    assert comm.exchange_selftest(64, 5) == 0
+    assert comm.exchange_selftest(512, 3) == 0      # every slot of the region, both parities, the step counter carried on
+    assert not comm.timed_out()
+
+
+@pytest.mark.parametrize("batch,hidden", [(64, 128), (128, 128), (32, 128), (256, 128), (64, 64), (128, 64)])
+@pytest.mark.parametrize("mode", ["graph", "enqueued"])
+def test_loopback_step_is_the_single_gpu_step_bit_for_bit(batch, hidden, mode, monkeypatch):
+    import taper_amd as T
+    if mode == "enqueued":
+        monkeypatch.setenv("TAPER_NO_GRAPH", "1")      # the same op list, every launch enqueued by the host instead of replayed
+    m = T.Trainer.GRAPH
+    steps = 7
+    ref = _train(T, batch, steps, m, hidden, None)
+    got = _train(T, batch, steps, m, hidden, "loopback")
+    comm = got[5]
+    assert comm.tail_exchange_ok(batch, 784, hidden, 10)
+    assert comm.inkernel_launches() >= steps, comm.inkernel_launches()   # the path under test is the one that ran
+    assert not comm.timed_out()
+    np.testing.assert_array_equal(got[0], ref[0])
+    for a, b in zip(got[1], ref[1]):
+        np.testing.assert_array_equal(a, b)
+    assert got[2] == ref[2] == 2 * steps
+    np.testing.assert_array_equal(got[3], ref[3])
+    np.testing.assert_array_equal(got[4], ref[4])
+
+
+def test_one_rank_communicator_takes_the_single_gpu_step():
+    """W = 1: the mean over the ranks is this rank's gradient -- no exchange launch, no exchange code: the two-launch step of one GPU"""
+    import taper_amd as T
+    ref = _train(T, 128, 5, T.Trainer.GRAPH, 128, None)
+    got = _train(T, 128, 5, T.Trainer.GRAPH, 128, "one_rank")
+    comm = got[5]
+    assert comm.stats()["fused"] == 0 and comm.stats()["inplace"] == 0 and comm.inkernel_launches() == 0
+    np.testing.assert_array_equal(got[0], ref[0])
+    for a, b in zip(got[1], ref[1]):
+        np.testing.assert_array_equal(a, b)
+    assert got[2] == ref[2]
+
+
+def test_shapes_the_exchange_does_not_cover_take_the_three_launch_step():
+    import taper_amd as T
+    comm = T.Communicator.loopback()
+    assert comm.tail_exchange_ok(64, 784, 128, 10) and comm.tail_exchange_ok(512, 784, 64, 10)
+    assert not comm.tail_exchange_ok(72, 784, 128, 10)       # not whole 16-row tiles
+    assert not comm.tail_exchange_ok(64, 784, 100, 10)       # ragged hidden width
+    assert not comm.tail_exchange_ok(64, 784, 256, 10)       # no instance
+    assert not comm.tail_exchange_ok(1024, 784, 128, 10)     # th_mlp2_xent's territory
+    comm.set_inkernel(False)
+    assert not comm.tail_exchange_ok(64, 784, 128, 10)

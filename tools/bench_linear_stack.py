@@ -29,7 +29,6 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-adam", action="store_true", help="forward + backward only")
-    ap.add_argument("--plain-loop", action="store_true", help="the reference-literal loop (backward, then one arena-wide Adam launch) instead of Adam.fused_step()")
     args = ap.parse_args()
     import taper_amd as T
     T.Device.set_device(0)
@@ -47,16 +46,10 @@ def main():
     def step():
         T.Tape.reset()
         opt.zero_grad()
-        if args.no_adam or args.plain_loop:
-            loss = T.cross_entropy_loss(model.forward(x), y)
-            loss.backward()
-            if not args.no_adam:
-                opt.step()
-        else:
-            with opt.fused_step():      # the Trainer's fused-update mode: Adam in the dW products' epilogues (bench.py's linear stack line)
-                loss = T.cross_entropy_loss(model.forward(x), y)
-                loss.backward()
-                opt.step()
+        loss = T.cross_entropy_loss(model.forward(x), y)
+        loss.backward()
+        if not args.no_adam:
+            opt.step()
         return loss
 
     for _ in range(args.warmup):
@@ -76,7 +69,7 @@ def main():
         "workload": f"linear_stack_{W}x{L}_b{B}", "dtype": "f32", "steps": args.steps, "ms_per_step": round(dt * 1e3, 4),
         "samples_per_s": round(B / dt, 1), "tflops": round(flops / dt / 1e12, 2), "frac_of_mfma_peak": round(flops / dt / 1e12 / MFMA_F32_PEAK_TF, 4),
         "alg_flops_per_step": flops, "alg_bytes_per_step": alg_bytes, "alg_GBps": round(alg_bytes / dt / 1e9, 1),
-        "adam": not args.no_adam, "fused_step": not (args.no_adam or args.plain_loop), "loss_first": round(first, 5), "loss_last": round(last, 5)}))
+        "adam": not args.no_adam, "loss_first": round(first, 5), "loss_last": round(last, 5)}))
 
 
 if __name__ == "__main__":
