@@ -132,3 +132,36 @@ def test_chain_mlp3_limits(ctx):
     assert f(256, 128, 32, 10) == 0 and f(256, 64, 64, 10) == 0 and f(256, 128, 64, 17) == 0
     stages2, ns2 = hip.conv_stages([(dw, db, c_out, post) for (dw, db), (_, c_out, post) in list(zip(cbufs, REFERENCE))[:4]])
     assert hip.hip.th_conv_chain_mlp3_supported(1, 28, 28, C.cast(stages2, C.c_void_p), ns2, 256, 128, 64, 10) == 0   # no plane means at its end
+
+
+@pytest.mark.parametrize("n,classes", [(256, 10), (96, 10), (112, 3)])
+def test_chain_mlp3_matches_the_oracle_tape(ctx, O, n, classes):
+    """the ONE call against the ORACLE, not against other HIP calls: the oracle's conv chain on the images (tensor.rs:1221-1285, 1391-1470 and
+    the global mean) gives the plane means, the oracle's tape on them (nn.rs:54-60, loss.rs:101-195, 271-290, the backward closures
+    ops.rs:238-294, 358-369, tensor.rs:574-587, 674-694) gives loss, hit count, the six classifier gradients and d(loss)/d(means) --
+    which th_conv_chain_mlp3_xent returns as d_dx and, summed over the images through the positive-count of each plane, as the last
+    conv's bias gradient"""
+    from tests.test_gpu_chain import _oracle_chain
+    from tests.test_gpu_mlp3 import _oracle as oracle_classifier
+    rng = np.random.default_rng(1000 + n + classes)
+    conv, net = _params(REFERENCE, 31 + n), _classifier(rng, classes)
+    x, y = _images(n, 7 * n), rng.integers(0, classes, n).astype(np.float32)
+    got = _run(ctx, x, y, conv, net, fused=True)
+    name = "test_chain_mlp3_matches_the_oracle_tape"
+    # the front: plane means within the conv tolerance of the oracle chain
+    ref_means, ref_cnt = _oracle_chain(O, x, REFERENCE, conv)
+    ref_means = np.asarray(ref_means, np.float32).reshape(n, 128)
+    np.testing.assert_allclose(got["means"], ref_means, rtol=1e-4, atol=1e-5)
+    # the classifier on the ORACLE's means: everything the call returns about it
+    ref_loss, ref_acc, ref_grads, ref_dx = oracle_classifier(O, ref_means, y, net, True)
+    assert abs(got["loss"] - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)), (got["loss"], ref_loss)
+    assert abs(got["nc"] - round(ref_acc * n)) <= 1
+    for l, ((gw, gb), (rw, rb)) in enumerate(zip(got["grads"], ref_grads)):
+        margins.check(f"dw{l + 1}_vs_oracle", gw, np.asarray(rw).reshape(gw.shape), 2e-6, test=name)   # observed <= 8.5e-7 (profiles/r06_parity_margins.json)
+        margins.check(f"db{l + 1}_vs_oracle", gb, np.asarray(rb).reshape(gb.shape), 2e-6, test=name)
+    ref_dx = np.asarray(ref_dx, np.float32).reshape(n, 128)
+    margins.check("dx_vs_oracle", got["dx"], ref_dx, 2e-6, test=name)
+    # the last conv's bias gradient (tensor.rs:1276-1283 through the mean's backward: every positive element of a plane receives
+    # d(mean) / 49): sum over images of dx * count / 49, with the oracle's own counts
+    ref_gb = (ref_dx.astype(np.float64) * ref_cnt.astype(np.float64) / 49.0).sum(axis=0)
+    margins.check("conv_bias_grad_vs_oracle", got["gb"], ref_gb.astype(np.float32), 2e-6, test=name)
