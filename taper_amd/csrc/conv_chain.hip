@@ -250,6 +250,87 @@ __device__ __forceinline__ void chain_mfma(const float *in, const float *__restr
 #undef CH_WREQ
 }
 
+// ---- the same k loop in HALF passes (r06, conv_chain_simple_kernel<.., LEAN>): the weight operands of 9 k-steps -- one group of 4 input channels
+// -- per request set instead of 18, i.e. 36 registers of weights in flight instead of 72, for the instance that must fit 128 registers so that
+// two workgroups share a CU (the shorter prefetch distance is the other workgroup's to cover).  Same k order (k-step s of pass cb = tap s % 9 of
+// channel group cb + 4 (s / 9): the half passes are the groups in turn), same placement of reads and requests behind the MFMA pairs: the sums
+// are the full-pass loop's bit for bit.  No next-layer prefetch (the simple chain's conv2 is its last layer).
+struct ChainW9 { float a[9], b[9]; };
+template <int S, int C_IN, int C_OUT>
+__device__ __forceinline__ void chain_weights9(const float *__restrict__ w, int c4, ChainW9 &wr, int wave, int lane) {
+    using G = ChainGeo<S, C_OUT>;
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * C_IN * C_OUT * 4, 0x00020000);
+    const int row = ((lane >> 4) * 9 * C_OUT + (lane & 15)) * 4, va = row + 64 * G::chA(wave), vb = row + 64 * G::chB(wave);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int so = (c4 * 9 + s) * C_OUT * 4;
+        wr.a[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, va, so, 0));
+        wr.b[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vb, so, 0));
+    }
+}
+template <int S, int C_IN, int C_OUT, bool PM>
+__device__ __forceinline__ void chain_mfma9(const float *in, const float *__restrict__ w, ChainW9 &wc, floatx4 (&acc)[ChainGeo<S, C_OUT>::NSLOT], int wave,
+                                            int lane) {
+    using G = ChainGeo<S, C_OUT>;
+    constexpr int WP = G::WP, CIS = G::CIS, ND = G::ND, NP = ND + (G::NS ? 1 : 0), KS = 9;
+    static_assert(C_IN % 8 == 0 && ND >= 1, "whole pairs of 4-channel half passes");
+    const int l16 = lane & 15, g4 = lane >> 4;
+    const bool hs = G::has_single(wave);     // wave-uniform
+    typedef __attribute__((address_space(3))) const float lds_cf;
+    lds_cf *pt[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        int p = chain_lane_pixel<S, PM>(i < ND ? G::dtile(wave, i) : G::STILE, l16);
+        if (p < 0) p = 0;
+        pt[i] = (lds_cf *)(in + (p / S) * WP + p % S + g4 * CIS);
+        asm volatile("" : "+v"(pt[i]));
+    }
+#pragma unroll
+    for (int k = 0; k < G::NSLOT; ++k) acc[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+    ChainW9 wn;
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, 9 * C_IN * C_OUT * 4, 0x00020000);
+    const int va = ((lane >> 4) * 9 * C_OUT + (lane & 15)) * 4 + 64 * G::chA(wave), vb = va + 64 * (G::chB(wave) - G::chA(wave));
+#define CH9_REQ1(B, SS, I) { B[I] = pt[I][((SS) / 3) * WP + (SS) % 3]; }
+#define CH9_WREQ(DST, RS, V, SO) { DST = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RS, V, SO, 0)); }
+#define CH9_HALF_HS(HS, WCUR, WNXT, RS, SOBASE)                                                                                              \
+    {                                                                                                                                        \
+        float b0[NP], b1[NP];                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < (HS ? NP : ND); ++i) CH9_REQ1(b0, 0, i)                                                        \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                                                                 \
+                acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[i], acc[2 * i], 0, 0, 0);                                    \
+                acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.b[s], b0[i], acc[2 * i + 1], 0, 0, 0);                            \
+                __builtin_amdgcn_sched_barrier(0);                                                                                           \
+                if (s + 1 < KS) CH9_REQ1(b1, s + 1, i)                                                                                       \
+                if (i == 0) CH9_WREQ(WNXT.a[s], RS, va, (SOBASE) + s * C_OUT * 4)                                                            \
+                if (i == (ND > 1 ? 1 : 0)) CH9_WREQ(WNXT.b[s], RS, vb, (SOBASE) + s * C_OUT * 4)                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                                                           \
+            }                                                                                                                                \
+            if (G::NS && HS) {                                                                                                               \
+                acc[G::NSLOT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(WCUR.a[s], b0[NP - 1], acc[G::NSLOT - 1], 0, 0, 0);                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                                           \
+                if (s + 1 < KS) CH9_REQ1(b1, s + 1, NP - 1)                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                                           \
+            }                                                                                                                                \
+            if (s + 1 < KS) { _Pragma("unroll") for (int i = 0; i < (HS ? NP : ND); ++i) b0[i] = b1[i]; }                                    \
+        }                                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NP; ++i) pt[i] += 4 * CIS;                                                                     \
+    }
+#define CH9_HALF(WCUR, WNXT, RS, SOBASE) if (G::NS == 0 || hs) CH9_HALF_HS(true, WCUR, WNXT, RS, SOBASE) else CH9_HALF_HS(false, WCUR, WNXT, RS, SOBASE)
+#pragma unroll 1
+    for (int c4 = 0; c4 < C_IN; c4 += 8) {
+        CH9_HALF(wc, wn, rw, (c4 + 4) * 9 * C_OUT * 4)
+        const bool last = c4 + 8 >= C_IN;    // (uniform; the last half pass requests from a zero-sized buffer: zeros, no memory touched, no branch)
+        const auto rn = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, last ? 0 : 9 * C_IN * C_OUT * 4, 0x00020000);
+        CH9_HALF(wn, wc, rn, (c4 + 8) * 9 * C_OUT * 4)
+    }
+#undef CH9_HALF
+#undef CH9_HALF_HS
+#undef CH9_REQ1
+#undef CH9_WREQ
+}
+
 // bias of this lane's channels (16 chA + 4 g4 + e, 16 chB + 4 g4 + e)
 struct ChainBias { float a[4], b[4]; };
 template <int S, int C_OUT>
@@ -879,19 +960,26 @@ static_assert(16 * CH_NT + 64 <= CS_IMG, "LDS map: the classifier's reduction fi
 #ifndef CH_LOOP_KEEP_HEAD
 #define CH_LOOP_KEEP_HEAD 0      // 1: the walking form keeps the classifier's weight registers across its images (measured: no gain -- 80 more live registers through conv1)
 #endif
-template <bool HEAD, int NC, bool LOOP = false>
-__global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainArgs a) {
+// LEAN (r06; batches with at least two images per CU): the same arithmetic within 128 registers per lane, so that TWO workgroups share a CU
+// -- 51 KB of LDS each -- and one's image load, conv1, pooling and classifier row run under the other's k loop.  What pays for the
+// registers: the classifier's weights are requested AFTER conv2's k loop instead of under it (80 registers per lane through the loop; the
+// wait they now expose is the other workgroup's to fill).
+template <bool HEAD, int NC, bool LOOP = false, bool LEAN = false>
+__global__ __launch_bounds__(CH_NT, LEAN ? 4 : 1) void conv_chain_simple_kernel(ConvChainArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t0_ = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t0_ >> 6);
     ChainBias bv;
     ChainW wc;
+    ChainW9 wc9;
     ChainW1 wa;
+    static_assert(!(LEAN && LOOP), "the two-to-a-CU instance does not walk");
     CH_STAMP(0);
     CH_CLK(20);
     chain_conv1_weights(a.w[0], wa, wave, t0_ & 63);
     chain_load_image(a.x + (long)blockIdx.x * 784, lds + CS_IMG, t0_);
-    chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, t0_ & 63);      // conv2's first pass: in flight under conv1
+    if constexpr (LEAN) chain_weights9<14, 32, 64>(a.w[1], 0, wc9, wave, t0_ & 63);   // conv2's first half pass: in flight under conv1
+    else chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, t0_ & 63);      // conv2's first pass: in flight under conv1
     if (HEAD && a.head.tick && blockIdx.x == 0 && t0_ == 0) a.head.tick[0] += 1;
     constexpr int HV = NC <= 10 ? 4 : 1, HNJ = HV == 4 ? 4 * ((CS_K + 4 * CH_NT - 1) / (4 * CH_NT)) : CS_NJ;   // (16 classes: 128 registers as quads)
     float hw_[HNJ][NC];
@@ -920,7 +1008,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
     }
     floatx4 acc[ChainGeo<14, 64>::NSLOT];
     chain_bias<14, 64>(a.b[1], bv, wave, lane);
-    if constexpr (HEAD && !(LOOP && CH_LOOP_KEEP_HEAD)) {        // the classifier's weights: in flight under conv2's k loop
+    if constexpr (HEAD && !LEAN && !(LOOP && CH_LOOP_KEEP_HEAD)) {        // the classifier's weights: in flight under conv2's k loop
         if constexpr (HV == 4) chain_head_weights4<HNJ / 4, NC, CS_K>(a.head, hw_, t);
         else chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t);
     }
@@ -937,12 +1025,18 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_simple_kernel(ConvChainAr
             IMG[(t / 28 + 1) * 30 + t % 28 + 1] = px[0];
             if (t + CH_NT < 784) IMG[((t + CH_NT) / 28 + 1) * 30 + (t + CH_NT) % 28 + 1] = px[1];
         }
+    } else if constexpr (LEAN) {
+        chain_mfma9<14, 32, 64, true>(A, a.w[1], wc9, acc, wave, lane);
     } else {
         chain_mfma<14, 32, 64, 0, 0, 0, true>(A, a.w[1], wc, acc, wave, lane);
     }
     CH_STAMP(4);
     CH_STAMP(5);
     chain_store_pooled<14, 64, true>(acc, bv, a.y + (long)img * 64 * 49, wave, lane, HEAD ? XM : nullptr);   // (XM does not overlap A)
+    if constexpr (HEAD && LEAN) {                                // (requested here: the registers were the k loop's until now)
+        if constexpr (HV == 4) chain_head_weights4<HNJ / 4, NC, CS_K>(a.head, hw_, t);
+        else chain_head_weights<CS_NJ, NC, CS_K>(a.head, hw_, t);
+    }
     if constexpr (HEAD) {
         chain_sync();                                            // XM complete; every wave is past conv2's k loop: A is free
         CH_STAMP(6);
@@ -1829,7 +1923,13 @@ int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *s
         (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, NC_, LOOP_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);     \
         hipLaunchKernelGGL((conv_chain_simple_kernel<true, NC_, LOOP_>), dim3(GRID_), dim3(CH_NT), lds, ctx->stream, a);                          \
     } while (0)
-        if (head->classes <= 10) {
+        // two images per CU and more: the 128-register instance, two workgroups to a CU (TAPER_CHAIN_LEAN = 0 | 1 forces it off / on: A/B probe)
+        static const int lean_env = [] { const char *e = getenv("TAPER_CHAIN_LEAN"); return e ? atoi(e) : -1; }();
+        const bool lean = lean_env >= 0 ? lean_env != 0 : n >= 2 * kNumCU;
+        if (head->classes <= 10 && lean) {
+            (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((conv_chain_simple_kernel<true, 10, false, true>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
+        } else if (head->classes <= 10) {
             if (chain_loop(n)) TH_SIMPLE_HEAD(10, true, kNumCU);
             else TH_SIMPLE_HEAD(10, false, n);
         } else {

@@ -362,9 +362,27 @@ struct WideGradArgs {
 // groups of 64 (thread (g, c) adds rows g, g + 64, ...), groups added in order.  1024 threads.
 __device__ __forceinline__ float slab_colsum16(const float *__restrict__ p, int ld, int rows, int col0, int ncols, float (*red)[16], int t) {
     const int g = t >> 4, c = t & 15;
+    // (a thread's rows are added in order, but requested eight at a time: one row per trip was a chain of rows / 64 memory round trips --
+    // at 4 096 rows the ONE workgroup that sums the dlogits set the whole launch's 31 us, r06)
     float s = 0.f;
-    if (c < ncols)
-        for (int r = g; r < rows; r += 64) s += p[(long)r * ld + col0 + c];
+    if (c < ncols) {
+        int r = g;
+        for (; r + 15 * 64 < rows; r += 16 * 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(long)(r + 64 * u) * ld + col0 + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; r + 3 * 64 < rows; r += 4 * 64) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p[(long)(r + 64 * u) * ld + col0 + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; r < rows; r += 64) s += p[(long)r * ld + col0 + c];
+    }
     red[g][c] = s;
     __syncthreads();
     float tot = 0.f;
@@ -396,24 +414,36 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_grads_kernel(WideGradArgs a) 
         floatx4 accw[WH_TX];
 #pragma unroll
         for (int tx = 0; tx < WH_TX; ++tx) accw[tx] = floatx4{0.f, 0.f, 0.f, 0.f};
-        for (int c0 = 0; c0 < B; c0 += 16 * WH_NW) {
-            const int r0 = c0 + wave * 16;
-            if (r0 >= B) break;                        // wave-uniform
-            float at[4], xv[WH_TX][4];
+        // A wave's 16-row blocks (wave, wave + 16, ...) are a serial chain of accumulations -- and, one block per trip, a serial chain of
+        // memory round trips: ~2 us each under the launch's own load, 31 us for 4 096 rows whatever the workgroup count or the width of the
+        // loads (r06: 196 workgroups, 16-byte loads, a one-block prefetch all measured 30 - 44 us).  The operands of WG_U blocks are
+        // requested together, then their MFMAs run in the same block order: the same bits, a quarter of the round trips.
+        constexpr int WG_U = 4;
+        for (int c0 = 0; c0 < B; c0 += 16 * WH_NW * WG_U) {
+            if (c0 + wave * 16 >= B) break;            // wave-uniform
+            float at[WG_U][4], xv[WG_U][WH_TX][4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {              // A[class r16][row 4 g4 + s] = dl[row][class]; B = X[row 4 g4 + s][col r16]
-                const int row = r0 + g4 * 4 + s;
-                at[s] = row < B ? a.dl[(long)row * 16 + r16] : 0.f;
+            for (int u = 0; u < WG_U; ++u) {
+                const int r0 = c0 + (u * WH_NW + wave) * 16;
 #pragma unroll
-                for (int tx = 0; tx < WH_TX; ++tx) {
-                    const int col = col0 + tx * 16 + r16;
-                    xv[tx][s] = (row < B && col < K) ? a.x[(long)row * K + col] : 0.f;
+                for (int s = 0; s < 4; ++s) {          // A[class r16][row 4 g4 + s] = dl[row][class]; B = X[row 4 g4 + s][col r16]
+                    const int row = r0 + g4 * 4 + s;
+                    at[u][s] = row < B ? a.dl[(long)row * 16 + r16] : 0.f;
+#pragma unroll
+                    for (int tx = 0; tx < WH_TX; ++tx) {
+                        const int col = col0 + tx * 16 + r16;
+                        xv[u][tx][s] = (row < B && col < K) ? a.x[(long)row * K + col] : 0.f;
+                    }
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int u = 0; u < WG_U; ++u) {
+                if (c0 + (u * WH_NW + wave) * 16 >= B) break;   // wave-uniform: blocks past the batch add nothing (not even a signed zero)
 #pragma unroll
-                for (int tx = 0; tx < WH_TX; ++tx) accw[tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[s], xv[tx][s], accw[tx], 0, 0, 0);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tx = 0; tx < WH_TX; ++tx) accw[tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[u][s], xv[u][tx][s], accw[tx], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int tx = 0; tx < WH_TX; ++tx)
