@@ -564,7 +564,10 @@ __device__ long long g_gemm_prof[4];   // workgroup 0: wall clock (100 MHz) and 
 
 // DXEP: the epilogue with Epilogue::mask / colpart; ADAMEP: C is a complete gradient and the parameter's Adam update (optim.rs:99-110) runs on
 // the element in the epilogue, under the matrix work of the CU's other workgroup (their own instances: the plain products keep their registers)
-template <int TS, bool A_KC, bool B_KC, bool GUARD, bool DXEP = false, bool ADAMEP = false>
+// RAG (r06; both operands m/n-contiguous, i.e. the weight gradient dW = dZ^T X): a ragged m or n (784 = 6 x 128 + 16) no longer sends EVERY
+// tile through the clamped register loads -- the operands still arrive by LDS-DMA, a lane whose 16-byte quad lies past the matrix edge asks
+// for an offset past the descriptor's range and gets zeros, and only the stores are guarded.  m, n multiples of 4 (quads in or out).
+template <int TS, bool A_KC, bool B_KC, bool GUARD, bool DXEP = false, bool ADAMEP = false, bool RAG = false>
 __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A, const float *__restrict__ B,
                                                      float *__restrict__ C, int m, int n, int k,
                                                      long a_rs, long a_cs, long b_rs, long b_cs,
@@ -622,6 +625,15 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
     DmaPlan<TS> pa{}, pb{};
     if constexpr (A_DMA) pa = dma_plan<TS, A_KC>(A_KC ? a_rs : a_cs, lane, wave);
     if constexpr (B_DMA) pb = dma_plan<TS, B_KC>(B_KC ? b_cs : b_rs, lane, wave);
+    if constexpr (RAG) {
+        static_assert(!RAG || (!GUARD && !A_KC && !B_KC), "edge quads by range: m/n-contiguous operands through LDS-DMA");
+#pragma unroll
+        for (int j = 0; j < R; ++j) {          // unit u of the [k][mn] image: m / n quad u % (TS / 4) (dma_plan)
+            const int quad = (64 * (4 * j + wave) + lane) % (TS / 4);
+            if (row0 + 4 * quad >= m) pa.voff[j] = 0x7fffffff;      // past the descriptor's range: the lane's 16 bytes arrive as zeros
+            if (col0 + 4 * quad >= n) pb.voff[j] = 0x7fffffff;
+        }
+    }
     // element (i,k) of op(A) at A[i*a_rs + k*a_cs]; (k,j) of op(B) at B[k*b_rs + j*b_cs]
     auto fetch = [&](int k0, int stage) {
         if constexpr (A_DMA) dma_tile<TS, A_KC>(A, A_KC ? a_rs : a_cs, row0, k0, smem + stage * TMAX, pa, wave);
@@ -722,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = row0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                    mk[e] = (!GUARD || (row < m && col < n)) ? ep.mask[(long)row * n + col] : 0.f;
+                    mk[e] = (!(GUARD || RAG) || (row < m && col < n)) ? ep.mask[(long)row * n + col] : 0.f;
                 }
             }
             // ADAMEP: the 24 operands of eight elements' updates are requested together (a round trip per eight elements, not per element)
@@ -734,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
 #pragma unroll
                         for (int f = 0; f < 8; ++f) {
                             const int rowf = row0 + wm + 32 * i + ((e + f) & 3) + 8 * ((e + f) >> 2) + 4 * lk;
-                            const long idf = (!GUARD || (rowf < m && col < n)) ? (long)rowf * n + col : 0;
+                            const long idf = (!(GUARD || RAG) || (rowf < m && col < n)) ? (long)rowf * n + col : 0;
                             ap[f] = ep.adam.p[idf];
                             am[f] = ep.adam.m[idf];
                             av[f] = ep.adam.v[idf];
@@ -742,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
                     }
                 }
                 const int row = row0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (!GUARD || (row < m && col < n)) {
+                if (!(GUARD || RAG) || (row < m && col < n)) {
                     const long idx = (long)row * n + col;
                     if (partial) {
                         partial[(long)blockIdx.y * m * n + idx] = acc[i][j][e];
@@ -778,7 +790,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
         __syncthreads();
         if (t < TS) {
             const int col = col0 + t;
-            if (!GUARD || col < n) ep.colpart[(long)tm * n + col] = cs[t] + cs[TS + t];
+            if (!(GUARD || RAG) || col < n) ep.colpart[(long)tm * n + col] = cs[t] + cs[TS + t];
         }
     }
 #endif
@@ -837,7 +849,11 @@ int adam_slice(th_ctx *ctx, const AdamDev &a, const float *d_g, int64_t n);  // 
 static inline int tile128_kz(int m, int n, int k) {
     const long tiles = (long)ceil_div(m, BM) * ceil_div(n, BN);
     if (tiles >= 384 || k < 512) return 1;
-    int kz = (int)((512 + tiles - 1) / tiles);   // 2 workgroups per CU (__launch_bounds__(256, 2))
+    static const int kz_env = [] { const char *e = getenv("TAPER_GEMM_KZ"); return e ? atoi(e) : 0; }();   // measurement probe
+    if (kz_env > 0) return kz_env;
+    // 2 workgroups per CU (__launch_bounds__(256, 2)) = 512 places: as many slices as fit in ONE round of them (r05 rounded up: 14 tiles x 37
+    // slices = 518 workgroups, six of which ran a second round on their own)
+    int kz = (int)(512 / tiles);
     const int kz_max = k / 256;
     if (kz > kz_max) kz = kz_max;
     return kz < 1 ? 1 : kz;
@@ -851,6 +867,12 @@ static inline int tile64_kz(int m, int n, int k) {
     const int kz_max = k / 128;
     if (kz > kz_max) kz = kz_max;
     return kz < 1 ? 1 : kz;
+}
+
+template <int TS, bool A_KC, bool B_KC>
+static inline bool rag_dma(int m, int n, int k, bool vec, long lda, long ldb) {
+    static const bool on = [] { const char *e = getenv("TAPER_GEMM_RAG"); return !e || atoi(e) != 0; }();   // 0: the clamped register loads (A/B probe)
+    return on && TS == 128 && !A_KC && !B_KC && vec && m % 4 == 0 && n % 4 == 0 && k % BK == 0 && lda < (1L << 22) && ldb < (1L << 22);
 }
 
 template <int TS, bool A_KC, bool B_KC>
@@ -911,6 +933,13 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
         TH_SET_MAX_LDS(ctx, kern, lds);       // (per device: ADVICE r04)
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
                            b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, 1, raster);
+    } else if (rag_dma<TS, A_KC, B_KC>(m, n, k, vec, lda, ldb)) {
+        if constexpr (TS == 128 && !A_KC && !B_KC) {      // a ragged weight gradient: LDS-DMA with the edge quads zeroed by range, guarded stores
+            auto kern = sgemm_tile<TS, A_KC, B_KC, false, false, false, true>;
+            TH_SET_MAX_LDS(ctx, kern, lds);
+            hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
+                               b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, 1, raster);
+        }
     } else {
         auto kern = sgemm_tile<TS, A_KC, B_KC, true>;
         TH_SET_MAX_LDS(ctx, kern, lds);       // (per device: ADVICE r04)

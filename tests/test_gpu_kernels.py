@@ -43,7 +43,10 @@ ODD_SHAPES = [(0, 0, 1, 1, 1), (0, 0, 2, 3, 2), (1, 1, 17, 5, 33), (0, 1, 33, 65
 BIG_SHAPES = [(0, 0, 1024, 1024, 256), (0, 1, 1024, 1152, 96), (1, 0, 1280, 1024, 64), (1, 1, 1024, 1024, 40),
               (0, 0, 1100, 1030, 70),
               # deep K on a narrow output: split-K slices of the 128x128 kernel + the fixed-order reduce
-              (1, 0, 128, 784, 4096), (1, 0, 128, 784, 5000), (0, 1, 4096, 128, 784), (0, 0, 256, 256, 3000), (1, 1, 130, 200, 2050)]
+              (1, 0, 128, 784, 4096), (1, 0, 128, 784, 5000), (0, 1, 4096, 128, 784), (0, 0, 256, 256, 3000), (1, 1, 130, 200, 2050),
+              # ragged weight gradients (dW = dZ^T X with in = 784, out = 256 / 200 / 132): LDS-DMA with the edge quads zeroed by the descriptor's
+              # range and guarded stores (sgemm_tile<.., RAG>, r06); 1300: m % 4 != 0 keeps the clamped register loads
+              (1, 0, 784, 256, 4096), (1, 0, 256, 784, 2048), (1, 0, 784, 200, 1024), (1, 0, 132, 784, 8192), (1, 0, 1300, 1026, 512)]
 
 
 # (alpha, beta) = (0.5, -2.0) on every shape but the big ones (> 5e7 multiply-adds): two variants of those are enough
