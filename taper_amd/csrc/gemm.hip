@@ -564,9 +564,10 @@ __device__ long long g_gemm_prof[4];   // workgroup 0: wall clock (100 MHz) and 
 
 // DXEP: the epilogue with Epilogue::mask / colpart; ADAMEP: C is a complete gradient and the parameter's Adam update (optim.rs:99-110) runs on
 // the element in the epilogue, under the matrix work of the CU's other workgroup (their own instances: the plain products keep their registers)
-// RAG (r06; both operands m/n-contiguous, i.e. the weight gradient dW = dZ^T X): a ragged m or n (784 = 6 x 128 + 16) no longer sends EVERY
-// tile through the clamped register loads -- the operands still arrive by LDS-DMA, a lane whose 16-byte quad lies past the matrix edge asks
-// for an offset past the descriptor's range and gets zeros, and only the stores are guarded.  m, n multiples of 4 (quads in or out).
+// RAG (r06): a ragged m, n or k (784 = 6 x 128 + 16 = 24 x 32 + 16) no longer sends EVERY tile through the clamped register loads -- the
+// operands still arrive by LDS-DMA, a lane whose 16-byte quad lies past the matrix edge asks for an offset past the descriptor's range and
+// gets zeros, and only the stores are guarded.  m / n-contiguous operands: quads past m / n (fixed per tile); k-contiguous operands: rows
+// past m / n (fixed per tile) and, in the LAST k chunk only, quads past k.  m, n, k multiples of 4 along the contiguous axis (quads in or out).
 template <int TS, bool A_KC, bool B_KC, bool GUARD, bool DXEP = false, bool ADAMEP = false, bool RAG = false>
 __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A, const float *__restrict__ B,
                                                      float *__restrict__ C, int m, int n, int k,
@@ -625,20 +626,39 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
     DmaPlan<TS> pa{}, pb{};
     if constexpr (A_DMA) pa = dma_plan<TS, A_KC>(A_KC ? a_rs : a_cs, lane, wave);
     if constexpr (B_DMA) pb = dma_plan<TS, B_KC>(B_KC ? b_cs : b_rs, lane, wave);
+    DmaPlan<TS> pa_last = pa, pb_last = pb;      // RAG: the plan of the slice's last k chunk (k-contiguous operands: quads past k zeroed)
     if constexpr (RAG) {
-        static_assert(!RAG || (!GUARD && !A_KC && !B_KC), "edge quads by range: m/n-contiguous operands through LDS-DMA");
+        static_assert(!RAG || !GUARD, "edge quads by range: operands through LDS-DMA");
+        const int k_left = kend - (kbeg + (nt - 1) * BK);          // valid k of the last chunk (a multiple of 4)
 #pragma unroll
-        for (int j = 0; j < R; ++j) {          // unit u of the [k][mn] image: m / n quad u % (TS / 4) (dma_plan)
-            const int quad = (64 * (4 * j + wave) + lane) % (TS / 4);
-            if (row0 + 4 * quad >= m) pa.voff[j] = 0x7fffffff;      // past the descriptor's range: the lane's 16 bytes arrive as zeros
-            if (col0 + 4 * quad >= n) pb.voff[j] = 0x7fffffff;
+        for (int j = 0; j < R; ++j) {
+            constexpr int OOB = 0x7fffffff;    // past the descriptor's range: the lane's 16 bytes arrive as zeros
+            if constexpr (A_KC) {              // [mn][k] image: row 8 (4 j + wave) + (lane >> 3), k quad (lane & 7) ^ swizzle(row) (dma_plan)
+                const int row = 8 * (4 * j + wave) + (lane >> 3), kq = ((lane & 7) ^ TileGeo<TS>::swz(row)) << 2;
+                if (row0 + row >= m) pa.voff[j] = OOB;
+                pa_last.voff[j] = (row0 + row >= m || kq >= k_left) ? OOB : pa.voff[j];
+            } else {                           // [k][mn] image: unit u = 64 (4 j + wave) + lane: k row u / (TS / 4), m quad u % (TS / 4)
+                const int u = 64 * (4 * j + wave) + lane;
+                if (row0 + 4 * (u % (TS / 4)) >= m) pa.voff[j] = OOB;
+                pa_last.voff[j] = (u / (TS / 4) >= k_left) ? OOB : pa.voff[j];
+            }
+            if constexpr (B_KC) {
+                const int row = 8 * (4 * j + wave) + (lane >> 3), kq = ((lane & 7) ^ TileGeo<TS>::swz(row)) << 2;
+                if (col0 + row >= n) pb.voff[j] = OOB;
+                pb_last.voff[j] = (col0 + row >= n || kq >= k_left) ? OOB : pb.voff[j];
+            } else {
+                const int u = 64 * (4 * j + wave) + lane;
+                if (col0 + 4 * (u % (TS / 4)) >= n) pb.voff[j] = OOB;
+                pb_last.voff[j] = (u / (TS / 4) >= k_left) ? OOB : pb.voff[j];
+            }
         }
     }
     // element (i,k) of op(A) at A[i*a_rs + k*a_cs]; (k,j) of op(B) at B[k*b_rs + j*b_cs]
     auto fetch = [&](int k0, int stage) {
-        if constexpr (A_DMA) dma_tile<TS, A_KC>(A, A_KC ? a_rs : a_cs, row0, k0, smem + stage * TMAX, pa, wave);
+        const bool last = RAG && k0 + BK >= kend;      // (uniform)
+        if constexpr (A_DMA) dma_tile<TS, A_KC>(A, A_KC ? a_rs : a_cs, row0, k0, smem + stage * TMAX, last ? pa_last : pa, wave);
         else load_tile<A_KC, GUARD, TS>(A, a_rs, a_cs, row0, k0, m, kend, t, ra, vec);
-        if constexpr (B_DMA) dma_tile<TS, B_KC>(B, B_KC ? b_cs : b_rs, col0, k0, smem + (2 + stage) * TMAX, pb, wave);
+        if constexpr (B_DMA) dma_tile<TS, B_KC>(B, B_KC ? b_cs : b_rs, col0, k0, smem + (2 + stage) * TMAX, last ? pb_last : pb, wave);
         else load_tile<B_KC, GUARD, TS>(B, b_cs, b_rs, col0, k0, n, kend, t, rb, vec);
     };
     auto stash = [&](int stage) {
@@ -872,7 +892,8 @@ static inline int tile64_kz(int m, int n, int k) {
 template <int TS, bool A_KC, bool B_KC>
 static inline bool rag_dma(int m, int n, int k, bool vec, long lda, long ldb) {
     static const bool on = [] { const char *e = getenv("TAPER_GEMM_RAG"); return !e || atoi(e) != 0; }();   // 0: the clamped register loads (A/B probe)
-    return on && TS == 128 && !A_KC && !B_KC && vec && m % 4 == 0 && n % 4 == 0 && k % BK == 0 && lda < (1L << 22) && ldb < (1L << 22);
+    // (`vec`: 16-byte aligned rows and whole quads in or out of range along each operand's contiguous axis)
+    return on && TS == 128 && vec && ((A_KC || B_KC) ? k % 4 == 0 : k % BK == 0) && lda < (1L << 22) && ldb < (1L << 22);
 }
 
 template <int TS, bool A_KC, bool B_KC>
@@ -934,7 +955,7 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,
                            b_rs, b_cs, tiles_m, tiles_n, kep, kslice, partial, 1, raster);
     } else if (rag_dma<TS, A_KC, B_KC>(m, n, k, vec, lda, ldb)) {
-        if constexpr (TS == 128 && !A_KC && !B_KC) {      // a ragged weight gradient: LDS-DMA with the edge quads zeroed by range, guarded stores
+        if constexpr (TS == 128) {      // ragged edges: LDS-DMA with the edge quads zeroed by range, guarded stores
             auto kern = sgemm_tile<TS, A_KC, B_KC, false, false, false, true>;
             TH_SET_MAX_LDS(ctx, kern, lds);
             hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, kz), dim3(256), lds, ctx->stream, A, B, C, m, n, k, a_rs, a_cs,

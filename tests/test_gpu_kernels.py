@@ -46,7 +46,10 @@ BIG_SHAPES = [(0, 0, 1024, 1024, 256), (0, 1, 1024, 1152, 96), (1, 0, 1280, 1024
               (1, 0, 128, 784, 4096), (1, 0, 128, 784, 5000), (0, 1, 4096, 128, 784), (0, 0, 256, 256, 3000), (1, 1, 130, 200, 2050),
               # ragged weight gradients (dW = dZ^T X with in = 784, out = 256 / 200 / 132): LDS-DMA with the edge quads zeroed by the descriptor's
               # range and guarded stores (sgemm_tile<.., RAG>, r06); 1300: m % 4 != 0 keeps the clamped register loads
-              (1, 0, 784, 256, 4096), (1, 0, 256, 784, 2048), (1, 0, 784, 200, 1024), (1, 0, 132, 784, 8192), (1, 0, 1300, 1026, 512)]
+              (1, 0, 784, 256, 4096), (1, 0, 256, 784, 2048), (1, 0, 784, 200, 1024), (1, 0, 132, 784, 8192), (1, 0, 1300, 1026, 512),
+              # ... and k-contiguous operands: rows past m / n, and in the last k chunk the quads past k (forward X W^T and dX = dZ W at in = 784)
+              (0, 1, 2048, 256, 784), (0, 1, 1000, 260, 784), (0, 0, 2048, 784, 256), (0, 0, 1100, 784, 260), (1, 1, 1000, 1028, 200),
+              (0, 1, 16384, 256, 784)]
 
 
 # (alpha, beta) = (0.5, -2.0) on every shape but the big ones (> 5e7 multiply-adds): two variants of those are enough
