@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <array>
+#include <atomic>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -37,15 +38,24 @@ void set_error(const char *fmt, ...);
         }                                  \
     } while (0)
 
-// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (function, DEVICE) pair: set once per pair -- the static is per expansion site, i.e.
-// per kernel instance -- so that a process with contexts on several devices can launch > 64 KB of LDS on each of them.
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (function, DEVICE) pair: set once per pair and size -- the statics are per expansion
+// site, i.e. per kernel instance -- so that a process with contexts on several devices can launch > 64 KB of LDS on each of them.  Atomic
+// (two host threads may launch the same instance), and a site whose size GROWS sets the attribute again (the largest size seen is kept).
 #define TH_SET_MAX_LDS(ctx_, fn_, bytes_)                                                                                \
     do {                                                                                                                 \
-        static unsigned long long th_lds_done_ = 0ull;                                                                   \
+        static std::atomic<unsigned long long> th_lds_done_{0ull};                                                       \
+        static std::atomic<int> th_lds_max_{0};                                                                          \
         const unsigned long long th_lds_bit_ = 1ull << ((ctx_)->device & 63);                                            \
-        if (!(th_lds_done_ & th_lds_bit_)) {                                                                             \
-            TH_HIP(hipFuncSetAttribute((const void *)(fn_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes_))); \
-            th_lds_done_ |= th_lds_bit_;                                                                                 \
+        const int th_lds_want_ = (int)(bytes_);                                                                          \
+        if (!(th_lds_done_.load(std::memory_order_relaxed) & th_lds_bit_) || th_lds_want_ > th_lds_max_.load(std::memory_order_relaxed)) { \
+            TH_HIP(hipFuncSetAttribute((const void *)(fn_), hipFuncAttributeMaxDynamicSharedMemorySize, th_lds_want_));  \
+            int th_lds_prev_ = th_lds_max_.load(std::memory_order_relaxed);                                              \
+            if (th_lds_want_ > th_lds_prev_) {                                                                           \
+                th_lds_max_.store(th_lds_want_, std::memory_order_relaxed);                                              \
+                th_lds_done_.store(th_lds_bit_, std::memory_order_relaxed);   /* a larger size: the other devices set it again */ \
+            } else {                                                                                                     \
+                th_lds_done_.fetch_or(th_lds_bit_, std::memory_order_relaxed);                                           \
+            }                                                                                                            \
         }                                                                                                                \
     } while (0)
 

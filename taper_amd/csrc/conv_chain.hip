@@ -1714,7 +1714,7 @@ int conv_layer_chain_launch(th_ctx *ctx, const float *x, const float *w, const f
 #define TH_LC_(S_, CI_, CO_, P_, L_)                                                                                                     \
     do {                                                                                                                                 \
         constexpr int fl = (CI_ * ch_cis(S_ + 2) > CO_ * ch_tile_ld(S_ * S_) ? CI_ * ch_cis(S_ + 2) : CO_ * ch_tile_ld(S_ * S_));         \
-        (void)hipFuncSetAttribute((const void *)conv_layer_chain_kernel<S_, CI_, CO_, P_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, fl * 4); \
+        TH_SET_MAX_LDS(ctx, (conv_layer_chain_kernel<S_, CI_, CO_, P_, L_>), fl * 4); \
         hipLaunchKernelGGL((conv_layer_chain_kernel<S_, CI_, CO_, P_, L_>), grid, dim3(CH_NT), fl * 4, ctx->stream, a);                   \
         if (hipGetLastError() != hipSuccess) return -1;                                                                                  \
         return 1;                                                                                                                        \
@@ -1772,10 +1772,10 @@ static int rt_launch(th_ctx *ctx, RtChainArgs &a, int lds_floats, const float *d
     a.x = d_x; a.y = d_y; a.cnt = d_cnt; a.n = n;
     const int lds = lds_floats * (int)sizeof(float);
     if (a.s0 == 28 || a.s0 == 14 || a.s0 == 7) {
-        (void)hipFuncSetAttribute((const void *)conv_chain_rt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        TH_SET_MAX_LDS(ctx, (conv_chain_rt_kernel<false>), lds);
         hipLaunchKernelGGL(conv_chain_rt_kernel<false>, dim3(n < kNumCU ? n : kNumCU), dim3(CH_NT), lds, ctx->stream, a);
     } else {
-        (void)hipFuncSetAttribute((const void *)conv_chain_rt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        TH_SET_MAX_LDS(ctx, (conv_chain_rt_kernel<true>), lds);
         hipLaunchKernelGGL(conv_chain_rt_kernel<true>, dim3(n < kNumCU ? n : kNumCU), dim3(CH_NT), lds, ctx->stream, a);
     }
     return 0;
@@ -1810,19 +1810,19 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
             const int lds = CR_LDS * (int)sizeof(float);
             // (more images than CUs: optionally as walking workgroups -- chain_loop)
             if (chain_loop(n)) {
-                (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                TH_SET_MAX_LDS(ctx, (conv_chain_reference_kernel<true>), lds);
                 hipLaunchKernelGGL(conv_chain_reference_kernel<true>, dim3(kNumCU), dim3(CH_NT), lds, ctx->stream, a);
             } else {
-                (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                TH_SET_MAX_LDS(ctx, (conv_chain_reference_kernel<false>), lds);
                 hipLaunchKernelGGL(conv_chain_reference_kernel<false>, dim3(n), dim3(CH_NT), lds, ctx->stream, a);
             }
         } else {
             const int lds = CS_LDS * (int)sizeof(float);
             if (chain_loop(n)) {
-                (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<false, 1, true>), lds);
                 hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1, true>), dim3(kNumCU), dim3(CH_NT), lds, ctx->stream, a);
             } else {
-                (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<false, 1>), lds);
                 hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
             }
         }
@@ -1870,7 +1870,7 @@ int th_conv_chain_mlp3_xent(th_ctx *ctx, const float *d_x, const th_conv_stage *
     a.head3 = ChainMlp3Args{layers[0].d_w, layers[0].d_b, layers[1].d_w, layers[1].d_b, layers[2].d_w, layers[2].d_b, d_targets,
                             a1, a2, dz1, dz2, dz3, d_dx, part, d_tick, c, 1.0f / (float)n};
     const int lds = CR_LDS * (int)sizeof(float);
-    (void)hipFuncSetAttribute((const void *)conv_chain_reference_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    TH_SET_MAX_LDS(ctx, (conv_chain_reference_kernel<false, true>), lds);
     hipLaunchKernelGGL((conv_chain_reference_kernel<false, true>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
     t_last_conv_cfg[0] = 1; t_last_conv_cfg[1] = 9; t_last_conv_cfg[2] = 0;   // 9: a conv chain with the three-layer classifier's rows
     t_last_conv_cfg[3] = n; t_last_conv_cfg[4] = 1; t_last_conv_cfg[5] = 0;
@@ -1920,14 +1920,14 @@ int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *s
         const int lds = CS_LDS * (int)sizeof(float);
 #define TH_SIMPLE_HEAD(NC_, LOOP_, GRID_)                                                                                                          \
     do {                                                                                                                                          \
-        (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, NC_, LOOP_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);     \
+        TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<true, NC_, LOOP_>), lds);     \
         hipLaunchKernelGGL((conv_chain_simple_kernel<true, NC_, LOOP_>), dim3(GRID_), dim3(CH_NT), lds, ctx->stream, a);                          \
     } while (0)
         // two images per CU and more: the 128-register instance, two workgroups to a CU (TAPER_CHAIN_LEAN = 0 | 1 forces it off / on: A/B probe)
         static const int lean_env = [] { const char *e = getenv("TAPER_CHAIN_LEAN"); return e ? atoi(e) : -1; }();
         const bool lean = lean_env >= 0 ? lean_env != 0 : n >= 2 * kNumCU;
         if (head->classes <= 10 && lean) {
-            (void)hipFuncSetAttribute((const void *)conv_chain_simple_kernel<true, 10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<true, 10, false, true>), lds);
             hipLaunchKernelGGL((conv_chain_simple_kernel<true, 10, false, true>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
         } else if (head->classes <= 10) {
             if (chain_loop(n)) TH_SIMPLE_HEAD(10, true, kNumCU);

@@ -799,6 +799,7 @@ class Trainer {  // train.rs:74-172
     std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
     std::vector<std::pair<size_t, th_graph *>> whole_graphs_;  // (steps, graph): state reset + that many full steps -- a whole call in one replay
     bool graph_capture_failed_ = false;
+    std::vector<size_t> whole_capture_failed_;                 // call lengths whose whole-call capture failed once: not tried again
     std::vector<uintptr_t> graph_key_;   // what the captured steps bake in (train_epoch_graph); a mismatch drops the graphs
     std::shared_ptr<Buffer> xb_, yb_, state_, metrics_, step_loss_, step_ncorrect_;
     size_t metrics_cap_ = 0;

@@ -447,6 +447,7 @@ void Trainer::drop_graphs() {
     graphs_.clear();
     for (auto &g : whole_graphs_) th_graph_destroy(g.second);
     whole_graphs_.clear();
+    whole_capture_failed_.clear();   // (another key: another launch sequence may capture)
 }
 
 EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
@@ -503,6 +504,14 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
     key.push_back((uintptr_t)full_backward());
     key.push_back((uintptr_t)conv_chain_enabled());
     key.push_back((uintptr_t)conv_chain_head_enabled());
+    // what the choice of launch sequence reads of the parameters themselves (Trainer::mlp2_step, tail_exchange_step: every parameter trains and
+    // has no gradient yet): freezing a layer behind a capture must re-record, not replay the other sequence's graphs
+    key.push_back((uintptr_t)full_in_place);
+    {
+        uintptr_t h = 1469598103934665603ull;
+        for (const Tensor &p : optimizer->flat().params) h = (h ^ (uintptr_t)(p.get_requires_grad() ? 2 : 1)) * 1099511628211ull;
+        key.push_back(h);
+    }
     if (!graphs_.empty() && graph_key_ != key) drop_graphs();
 
     size_t done = 0;
@@ -605,7 +614,8 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             }
         }
     }
-    if (!whole && done == 0 && nb == n_full && n_full >= 2 && have(n_full) && whole_graphs_.size() < 4 && !graph_capture_failed_ && graph_key_ == key) {
+    if (!whole && done == 0 && nb == n_full && n_full >= 2 && have(n_full) && whole_graphs_.size() < 4 && !graph_capture_failed_ && graph_key_ == key &&
+        std::find(whole_capture_failed_.begin(), whole_capture_failed_.end(), n_full) == whole_capture_failed_.end()) {
         TH(th_graph_begin(ctx));
         th_graph *g = nullptr;
         try {
@@ -619,6 +629,7 @@ EpochResult Trainer::train_epoch_graph(DataLoader &loader, size_t max_steps) {
             done = n_full;
         } catch (const std::exception &e) {
             fprintf(stderr, "taper: capturing a whole-call graph of %zu steps failed (%s); reset + replay stay two launches\n", n_full, e.what());
+            whole_capture_failed_.push_back(n_full);   // (latched: a later call of this length does not try, print and fail again)
             if (!g) th_graph_end(ctx, &g);
             if (g) th_graph_destroy(g);
             if (auto *adam = dynamic_cast<Adam *>(optimizer.get())) {

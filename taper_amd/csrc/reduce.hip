@@ -647,7 +647,9 @@ __global__ __launch_bounds__(256) void sum_dim_bwd_kernel(const float *__restric
 // element is the largest value, the FIRST of equals (strict > in ascending input order), NaN and -inf never win (nothing is > them first):
 // one 64-bit atomicMax on {order-preserving bits of the value, ~index} is exactly that, whatever order the threads run in.
 __device__ __forceinline__ unsigned long long max_key(float v, int64_t i) {
-    const unsigned b = __float_as_uint(v);
+    // (-0.0 and +0.0 compare EQUAL under the reference's strict > (tensor.rs:1062): the first of them wins -- both take +0.0's key; the
+    // value itself is decoded from x[index], sign included)
+    const unsigned b = __float_as_uint(v + 0.0f);
     const unsigned ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
     return ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
 }
