@@ -109,7 +109,9 @@ def make_comm(rdzv, T, backend, optimizer, shared_device=False):
     if kind.startswith("p2p"):
         # (ranks sharing ONE device -- TAPER_BENCH_SHARE_DEVICE, the one-GPU harness -- map each other's arenas through IPC: no link is crossed)
         link = "between processes on ONE shared device (IPC mappings, no xGMI link crossed)" if shared_device else "over xGMI"
-        return comm, f"p2p one-shot all-reduce + Adam (th_allreduce_adam) {link}" + (", fine-grained gradient arena" if kind.endswith("finegrained") else "") + why
+        form = {1: "one-shot", 2: "two-shot"}.get(comm.exchange_form(), "none")
+        return comm, (f"p2p: {form} exchange inside the gradient launch (th_mlp_tail_dp) where the step allows, else th_allreduce_adam; {link}"
+                      + (", fine-grained gradient arena" if kind.endswith("finegrained") else "") + why)
     return comm, "rccl ncclAllReduce(avg)" + why
 
 

@@ -708,6 +708,10 @@ int th_allreduce_adam(th_comm *comm, th_ctx *ctx, const float *d_grads, size_t n
  * workgroup of the gradient launch behind it then reads at no cost (it picks the half of the double-buffered receive region). */
 int th_comm_init_loopback(th_ctx *ctx, th_comm **out);       /* W = 2 with this rank as its own peer: the whole protocol through local memory; results are the single-GPU step's, bit for bit */
 int th_comm_is_loopback(const th_comm *comm);
+/* 0: no in-launch exchange (RCCL / not connected); 1: ONE-shot -- every rank reduces every slice, one hop (2 or 3 ranks, loopback);
+ * 2: TWO-shot -- slice s is reduced by rank s % W and the mean pushed back, two hops and 2 / W of the bytes per link (4 ranks and more;
+ * TAPER_DP_TWO_SHOT = 0 | 1 at th_comm_p2p_connect forces the form on every rank).  Both forms give the same bits. */
+int th_comm_exchange_form(const th_comm *comm, int *out_form);
 int th_comm_sharing(const th_comm *comm, int *out_ranks_on_this_device);
 int th_comm_stats_inkernel(const th_comm *comm, int64_t *out_launches);
 /* collective check of the exchange alone: `rounds` launches of `slots` workgroups, every value compared on the device; *out_bad = mismatches + time-outs */

@@ -179,6 +179,7 @@ int tp_comm_set_inkernel(tp_comm *c, int on);
 int tp_comm_inkernel_launches(tp_comm *c, int64_t *out);
 int tp_comm_exchange_selftest(tp_comm *c, int slots, int rounds, int *out_bad);   /* collective */
 int tp_comm_ranks_on_this_device(tp_comm *c, int *out);
+int tp_comm_exchange_form(tp_comm *c, int *out);   /* th_comm_exchange_form: 0 none, 1 one-shot, 2 two-shot */
 int tp_comm_tail_exchange_ok(tp_comm *c, int batch, int in_features, int hidden, int classes, int *out);
 int tp_comm_export_arena(tp_comm *c, tp_optim *optimizer, uint8_t out_blob[192]);
 int tp_comm_connect(tp_comm *c, const uint8_t *blobs, size_t n_bytes);

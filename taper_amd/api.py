@@ -601,6 +601,12 @@ class Communicator:
         tp_check(host.tp_comm_exchange_selftest(self._h, int(slots), int(rounds), C.byref(out)), "Communicator::exchange_selftest")
         return int(out.value)
 
+    def exchange_form(self) -> int:
+        """0: no in-launch exchange; 1: one-shot (every rank reduces every slice); 2: two-shot (slice s reduced by rank s % W; 4 ranks and more)"""
+        out = C.c_int()
+        tp_check(host.tp_comm_exchange_form(self._h, C.byref(out)), "Communicator::exchange_form")
+        return int(out.value)
+
     def ranks_on_this_device(self) -> int:
         out = C.c_int()
         tp_check(host.tp_comm_ranks_on_this_device(self._h, C.byref(out)), "Communicator::ranks_on_this_device")

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void dp_selftest_kernel(DpDev c, int round, in
     const DpTicket tk = dp_begin(c);
     const int s = blockIdx.x, t = threadIdx.x;
     float v[2] = {dp_pattern(c.rank, round, s, t, 0), dp_pattern(c.rank, round, s, t, 1)};
-    const bool ok = dp_exchange<NR, 2>(c, tk, s, t, v);
+    const bool ok = dp_reduce<NR, 2>(c, tk, s, t, v);
     if (ok) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -496,9 +496,15 @@ int th_comm_p2p_connect(th_comm *comm, const uint8_t *blobs) {
     th::DpDev &d = comm->dp;
     for (int r = 0; r < comm->n_ranks; ++r) {
         char *base = (char *)comm->dev.flags[r];
-        d.push_data[r] = (float *)(base + th::DP_DATA_OFFSET) + (size_t)comm->rank * th::DP_SRC_STRIDE;
+        d.peer_data[r] = (float *)(base + th::DP_DATA_OFFSET);
     }
     d.recv_data = (float *)((char *)comm->flags_local + th::DP_DATA_OFFSET);
+    // four ranks and more: a slice is reduced by ONE rank (two hops, 2 / W of the bytes per link); below, by every rank (one hop).
+    // TAPER_DP_TWO_SHOT = 0 | 1 forces the form (every rank must agree: it is part of the protocol)
+    {
+        const char *e = getenv("TAPER_DP_TWO_SHOT");
+        d.two_shot = e ? (atoi(e) != 0 && comm->n_ranks >= 2 ? 1 : 0) : (comm->n_ranks >= 4 ? 1 : 0);
+    }
     d.state = comm->state;
     d.err_host = comm->err_host;
     d.spin_ticks = comm->dev.spin_ticks;
@@ -518,9 +524,10 @@ int th_comm_init_loopback(th_ctx *ctx, th_comm **out) {
     th::DpDev &d = c->dp;
     char *base = (char *)c->flags_local;
     for (int r = 0; r < 2; ++r) {   // "rank 1" is this rank again: what it would push arrives in source block 1 of the local region
-        d.push_data[r] = (float *)(base + th::DP_DATA_OFFSET) + (size_t)r * th::DP_SRC_STRIDE;
+        d.peer_data[r] = (float *)(base + th::DP_DATA_OFFSET) + (size_t)r * th::DP_SRC_STRIDE;   // (+ r blocks: this rank is 0, its push to "rank 1" lands in block 1)
     }
     d.recv_data = (float *)(base + th::DP_DATA_OFFSET);
+    d.two_shot = 0;                          // (the owner of a slice would be a rank that does not exist: the one-hop form only)
     d.state = c->state;
     d.err_host = c->err_host;
     d.spin_ticks = c->timeout_ms * 100000L;
@@ -534,6 +541,12 @@ int th_comm_init_loopback(th_ctx *ctx, th_comm **out) {
 }
 
 int th_comm_is_loopback(const th_comm *comm) { return comm && comm->loopback ? 1 : 0; }
+
+int th_comm_exchange_form(const th_comm *comm, int *out_form) {
+    TH_REQUIRE(comm && out_form, "th_comm_exchange_form: null argument");
+    *out_form = !(comm->p2p && comm->connected) ? 0 : (comm->dp.two_shot ? 2 : 1);
+    return 0;
+}
 
 int th_comm_sharing(const th_comm *comm, int *out_ranks_on_this_device) {
     TH_REQUIRE(comm && out_ranks_on_this_device, "th_comm_sharing: null argument");

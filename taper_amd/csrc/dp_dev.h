@@ -34,12 +34,14 @@ constexpr int DP_ST_ERROR = 2, DP_ST_DEAD = 5, DP_ST_STEP = 6, DP_ST_ABORTS = 8;
 constexpr size_t DP_DATA_OFFSET = 4096;
 constexpr uint64_t DP_EMPTY = ~0ull;
 constexpr size_t DP_SRC_STRIDE = (size_t)DP_MAX_SLOTS * DP_SLOT_FLOATS;            // floats between two source ranks
-constexpr size_t DP_PARITY_STRIDE = (size_t)DP_MAX_RANKS * DP_SRC_STRIDE;          // floats between the two parities
+constexpr int DP_RESULT_BLOCK = DP_MAX_RANKS;                                       // two-shot form: the block an owner's means arrive in
+constexpr size_t DP_PARITY_STRIDE = (size_t)(DP_MAX_RANKS + 1) * DP_SRC_STRIDE;    // floats between the two parities
 constexpr size_t DP_REGION_BYTES = DP_DATA_OFFSET + 2 * DP_PARITY_STRIDE * sizeof(float);
 
 struct DpDev {                               // kernel argument (n_ranks == 0: no exchange)
-    float *push_data[DP_MAX_RANKS];          // [r]: where THIS rank's slices go in rank r's region (= its data + this rank's source block)
+    float *peer_data[DP_MAX_RANKS];          // [r]: rank r's region data as mapped here (this rank's slices go to its source block `rank` in it)
     float *recv_data;                        // the local region's data
+    int two_shot;                            // 0: every rank reduces every slice (one hop); 1: slice s is reduced by rank s % n_ranks (two hops, 1 / n_ranks of the bytes per link)
     uint32_t *state;                         // th_comm::state (local)
     uint32_t *err_host;                      // the error word's host-visible copy
     long spin_ticks;                         // bound of a poll, 100 MHz wall-clock ticks
@@ -104,7 +106,7 @@ __device__ __forceinline__ bool dp_exchange(const DpDev &c, const DpTicket &tk, 
             const uint64_t mine = dp_pack(v[2 * h], v[2 * h + 1]);
 #pragma unroll
             for (int r = 0; r < NR; ++r)
-                if (r < W && r != me) dp_st64(c.push_data[r] + par + off + 2 * h, mine);
+                if (r < W && r != me) dp_st64(c.peer_data[r] + (size_t)me * DP_SRC_STRIDE + par + off + 2 * h, mine);
         }
         // 2. poll: every peer's words for this thread, all requests of a round in flight together
         float *mine_in = c.recv_data + par + off;
@@ -151,6 +153,109 @@ __device__ __forceinline__ bool dp_exchange(const DpDev &c, const DpTicket &tk, 
         v[j] = acc * c.scale;
     }
     return true;
+}
+
+// The TWO-SHOT form of the same exchange, for rings of four ranks and more: slice `slot` is reduced by ONE rank, its owner slot % W.  A
+// non-owner pushes its values to the owner only and waits for the mean in the result block of its own region; the owner polls the W - 1
+// contributions, adds in rank order (its own at its rank's place: the bits every rank would have formed), scales, and pushes the mean to
+// every peer.  Two dependent hops instead of one, but a link carries 2 / W of a rank's gradient instead of all of it: with the MLP's 407 KB
+// and eight ranks 102 KB per link and direction instead of 407 -- ~1.4 us of a 76.8 GB/s xGMI direction instead of ~5.3, which is what
+// decides the step there.  Same words, same empty mark, same parity halves; every rank applies Adam itself to the mean it
+// received: p / m / v stay replicated, bit-identical.
+template <int NR, int NV>
+__device__ __forceinline__ bool dp_exchange_two_shot(const DpDev &c, const DpTicket &tk, int slot, int tid, float (&v)[NV]) {
+    static_assert(NV == 2 || NV == 4, "dp_exchange: 2 or 4 values per thread");
+    constexpr int NQ = NV / 2;
+    if (tk.dead != 0u) return false;
+    const int W = c.n_ranks, me = c.rank, owner = slot % W;
+    const size_t par = (size_t)(tk.step & 1u) * DP_PARITY_STRIDE;
+    const size_t off = (size_t)slot * DP_SLOT_FLOATS + (size_t)(tid < 0 ? 0 : tid) * NV;
+    bool ok = true;
+    if (tid >= 0) {
+        const long t0 = wall_clock64();
+        if (me == owner) {                      // (workgroup-uniform)
+            uint64_t q[NR][NQ];
+            float *in = c.recv_data + par + off;
+            while (true) {
+                bool all = true;
+#pragma unroll
+                for (int s = 0; s < NR; ++s)
+#pragma unroll
+                    for (int h = 0; h < NQ; ++h) {
+                        q[s][h] = (s < W && s != me) ? dp_ld64(in + (size_t)s * DP_SRC_STRIDE + 2 * h) : 0ull;
+                        all = all && q[s][h] != DP_EMPTY;
+                    }
+                if (all) break;
+                if (wall_clock64() - t0 > c.spin_ticks) {
+                    dp_raise(c);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (ok) {
+#pragma unroll
+                for (int s = 0; s < NR; ++s)
+                    if (s < W && s != me) {
+#pragma unroll
+                        for (int h = 0; h < NQ; ++h) dp_st64(in + (size_t)s * DP_SRC_STRIDE + 2 * h, DP_EMPTY);
+                    }
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int s = 0; s < NR; ++s) {
+                        const float x = s == me ? v[j] : __uint_as_float((uint32_t)(q[s][j / 2] >> (32 * (j & 1))));
+                        acc = s == 0 ? x : (s < W ? acc + x : acc);
+                    }
+                    v[j] = acc * c.scale;
+                }
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) {
+                    const uint64_t mean = dp_pack(v[2 * h], v[2 * h + 1]);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        if (r < W && r != me) dp_st64(c.peer_data[r] + (size_t)DP_RESULT_BLOCK * DP_SRC_STRIDE + par + off + 2 * h, mean);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < NQ; ++h)
+                dp_st64(c.peer_data[owner] + (size_t)me * DP_SRC_STRIDE + par + off + 2 * h, dp_pack(v[2 * h], v[2 * h + 1]));
+            float *res = c.recv_data + (size_t)DP_RESULT_BLOCK * DP_SRC_STRIDE + par + off;
+            uint64_t m[NQ];
+            while (true) {
+                bool all = true;
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) {
+                    m[h] = dp_ld64(res + 2 * h);
+                    all = all && m[h] != DP_EMPTY;
+                }
+                if (all) break;
+                if (wall_clock64() - t0 > c.spin_ticks) {
+                    dp_raise(c);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (ok) {
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) {
+                    dp_st64(res + 2 * h, DP_EMPTY);
+                    v[2 * h] = __uint_as_float((uint32_t)m[h]);        // (the owner's bits: dp_pack only ever changes a pair of all-ones NaNs)
+                    v[2 * h + 1] = __uint_as_float((uint32_t)(m[h] >> 32));
+                }
+            }
+        }
+    }
+    return __syncthreads_and(ok);
+}
+
+// what the kernels call: the communicator's form
+template <int NR, int NV>
+__device__ __forceinline__ bool dp_reduce(const DpDev &c, const DpTicket &tk, int slot, int tid, float (&v)[NV]) {
+    return c.two_shot ? dp_exchange_two_shot<NR, NV>(c, tk, slot, tid, v) : dp_exchange<NR, NV>(c, tk, slot, tid, v);
 }
 
 // host side (comm.hip): the communicator's exchange descriptor (nullptr: not a connected peer-to-peer communicator), how many ranks run on

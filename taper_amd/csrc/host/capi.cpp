@@ -341,6 +341,7 @@ int tp_comm_set_inkernel(tp_comm *c, int on) { TP_BEGIN c->c->inkernel = on != 0
 int tp_comm_inkernel_launches(tp_comm *c, int64_t *out) { TP_BEGIN *out = c->c->inkernel_launches(); TP_END }
 int tp_comm_exchange_selftest(tp_comm *c, int slots, int rounds, int *out_bad) { TP_BEGIN *out_bad = c->c->exchange_selftest(slots, rounds); TP_END }
 int tp_comm_ranks_on_this_device(tp_comm *c, int *out) { TP_BEGIN *out = c->c->ranks_on_this_device(); TP_END }
+int tp_comm_exchange_form(tp_comm *c, int *out) { TP_BEGIN *out = c->c->exchange_form(); TP_END }
 int tp_comm_tail_exchange_ok(tp_comm *c, int batch, int in_features, int hidden, int classes, int *out) {
     TP_BEGIN *out = c->c->tail_exchange_ok(batch, in_features, hidden, classes) ? 1 : 0; TP_END
 }

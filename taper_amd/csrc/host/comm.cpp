@@ -64,6 +64,12 @@ int Communicator::exchange_selftest(int slots, int rounds) const {
     return bad;
 }
 
+int Communicator::exchange_form() const {
+    int f = 0;
+    TH(th_comm_exchange_form(comm_, &f));
+    return f;
+}
+
 int Communicator::ranks_on_this_device() const {
     int n = 1;
     TH(th_comm_sharing(comm_, &n));

@@ -701,6 +701,7 @@ class Communicator {
     int64_t inkernel_launches() const;                    // th_mlp_tail_dp launches enqueued or captured
     int exchange_selftest(int slots, int rounds) const;   // collective; mismatches + time-outs seen by this rank (th_comm_exchange_selftest)
     int ranks_on_this_device() const;
+    int exchange_form() const;                            // th_comm_exchange_form: 0 none, 1 one-shot, 2 two-shot (4 ranks and more)
     // fine_grained: first move the optimizer's gradient arena into fine-grained device memory (coherent across agents, never cached in a
     // peer's L2) -- the fallback when the multi-round self-check fails on the pooled, coarse-grained arena.  The communicator keeps the
     // arenas it registered alive; destroy it on every rank before the optimizer goes away (peers hold IPC mappings of the arena).

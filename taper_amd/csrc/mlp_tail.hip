@@ -660,7 +660,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_tail_exact_kernel(TailArgs a) {
         }
         if constexpr (DPNR > 0) {
             // slice KS + tt of the launch: the same block of dW1 on every rank (finisher thread (wave, lane) holds the same elements everywhere)
-            if (!dp_exchange<DPNR, TN>(a.dp, dp_tk, KS + tt, finisher ? t : -1, outv)) return;   // nothing applied; the word is up
+            if (!dp_reduce<DPNR, TN>(a.dp, dp_tk, KS + tt, finisher ? t : -1, outv)) return;   // nothing applied; the word is up
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_tail_exact_kernel(TailArgs a) {
             for (int w = 1; w < NW; ++w) sum += sc[w][t];
             hv2[1] = sum;
         }
-        const bool okx = dp_exchange<DPNR, 2>(a.dp, dp_tk, tile_m, wave < 4 ? t : -1, hv2);
+        const bool okx = dp_reduce<DPNR, 2>(a.dp, dp_tk, tile_m, wave < 4 ? t : -1, hv2);
         if (!okx) {   // a peer's slice never came: nothing is applied, nothing is logged; the lead takes this step's tick back (optim.rs:84)
             // (only when the exchange failed in THIS launch: behind a dead communicator the step's first launch has not ticked)
             if (lead && t == 0 && a.dp_tick && dp_tk.dead == 0u) atomicSub(a.dp_tick, 1);

@@ -77,11 +77,12 @@ def main():
         raise SystemExit(f"rank {rank}: a peer never arrived at the all-reduce")
     st = comm.stats() if comm is not None and comm.is_p2p() else dict(inplace=-1, fused=-1)
     st["inkernel"] = comm.inkernel_launches() if comm is not None and comm.is_p2p() else -1
+    st["form"] = comm.exchange_form() if comm is not None and comm.is_p2p() else 0
     import ctypes as C
     from taper_amd._lib import hip as lib
     mlp2_calls = C.c_int64()
     lib.th_debug_mlp2_calls(C.byref(mlp2_calls))   # host-side calls of th_mlp2_xent on this thread (eager steps + captures)
-    np.savez(out / f"rank{rank}.npz", fine=int(fine), mlp2_calls=mlp2_calls.value, launches_inplace=st["inplace"], launches_fused=st["fused"], launches_inkernel=st["inkernel"], losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
+    np.savez(out / f"rank{rank}.npz", fine=int(fine), mlp2_calls=mlp2_calls.value, launches_inplace=st["inplace"], launches_fused=st["fused"], launches_inkernel=st["inkernel"], exchange_form=st["form"], losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
              **{f"p{i}": p.data() for i, p in enumerate(model.parameters())}, **{k: np.asarray(v) for k, v in runs.items()})
     rdzv.barrier()
     rdzv.close()

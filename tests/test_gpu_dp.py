@@ -119,6 +119,23 @@ def test_p2p_two_ranks_exchange_inside_the_gradient_launch(tmp_path, mode, globa
         assert int(r["launches_fused"]) == 3 and int(r["launches_inplace"]) == 3, (int(r["launches_fused"]), int(r["launches_inplace"]))
 
 
+def test_p2p_two_ranks_two_shot_exchange(tmp_path, monkeypatch):
+    """the TWO-shot form of the in-launch exchange (csrc/dp_dev.h: slice s is reduced by rank s % W, the mean pushed back -- what rings of
+    four ranks and more take, 2 / W of the bytes per link), forced on two ranks so that whole training runs go through it on the 1-GPU box:
+    the same bits as the one-shot form gives (both add in rank order), replicas identical, equal to one process and to the oracle"""
+    monkeypatch.setenv("TAPER_DP_TWO_SHOT", "1")
+    two = _run_ranks(tmp_path / "two", 2, "p2p", "graph", steps=6, global_batch=256, same_device=True) if (tmp_path / "two").mkdir() is None else None
+    _check(two, 2, 6, 256)
+    _check_against_oracle(two, 2, 6, 256)
+    assert all(int(r["exchange_form"]) == 2 and int(r["launches_inkernel"]) >= 6 for r in two)
+    monkeypatch.setenv("TAPER_DP_TWO_SHOT", "0")
+    one = _run_ranks(tmp_path / "one", 2, "p2p", "graph", steps=6, global_batch=256, same_device=True) if (tmp_path / "one").mkdir() is None else None
+    assert all(int(r["exchange_form"]) == 1 for r in one)
+    for i in range(4):
+        np.testing.assert_array_equal(two[0][f"p{i}"], one[0][f"p{i}"], err_msg=f"param {i}: the two forms differ")
+    np.testing.assert_array_equal(two[0]["losses"], one[0]["losses"])
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_p2p_many_ranks_on_one_gpu_fall_back_to_the_three_launch_step(tmp_path, world):
     """a workgroup that waits for a peer's slice holds its place on the device: with four or eight ranks on ONE device the waiting
@@ -128,6 +145,8 @@ def test_p2p_many_ranks_on_one_gpu_fall_back_to_the_three_launch_step(tmp_path, 
     _check(ranks, world, 4, 64 * world)
     for r in ranks:
         assert int(r["launches_inkernel"]) == 0 and int(r["launches_fused"]) >= 4 + 3
+        # (the bootstrap's self-check still ran the exchange on its own, 16 workgroups per rank, in the form four ranks and more take)
+        assert int(r["exchange_form"]) == 2
 
 
 def test_p2p_reference_cnn_two_ranks_equal_full_batch(tmp_path):
