@@ -625,7 +625,8 @@ def chain_mlp3_kernels(ctx, n=256, classes=10, reps=100):
             dict(kernel="mlp3_grads_kernel", layer="dW / db of the classifier, conv bias, loss (+ Adam in the step)", us_per_launch=round(us2, 2),
                  alg_flops_per_launch=2.0 * n * sum(o * i for o, i in dims), alg_bytes_per_launch=nb2, bound="hbm", achieved=round(gbs, 2),
                  peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), in_step=True,
-                 note="both launches back to back minus the first alone")]
+                 note="MARGINAL cost in the step: both launches back to back minus the first alone -- the kernel's own duration (rocprofv3, "
+                      "profiles/r06_cnn_kernel_stats.txt: ~6 us) plus the launch boundary it adds")]
 
 
 CNN_LAYERS = {
