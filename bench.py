@@ -911,8 +911,9 @@ def compact_line(full, details_path):
         out["step_roofline"] = {"hbm_frac": round(sr["hbm_frac"], 4), "mfma_frac": round(sr["mfma_frac"], 4)}
     if full.get("data_parallel"):
         dp = full["data_parallel"]
-        d = {k: dp[k] for k in ("weak_scaling_efficiency", "replicas_bit_identical", "per_gpu_batch", "single_gpu_step_us", "one_rank_step_us",
-                                "loopback_two_rank_step_us", "three_launch_one_rank_step_us", "on_device_efficiency_ceiling", "error") if k in dp}
+        # (N = 1: one_rank_step_us and three_launch_one_rank_step_us are in the details file)
+        d = {k: dp[k] for k in ("weak_scaling_efficiency", "replicas_bit_identical", "per_gpu_batch", "single_gpu_step_us",
+                                "loopback_two_rank_step_us", "on_device_efficiency_ceiling", "error") if k in dp}
         if "single_gpu_same_per_gpu_batch" in dp:
             d["single_gpu_ms_per_step"] = dp["single_gpu_same_per_gpu_batch"]["ms_per_step"]
         if "same_job_over_rccl" in dp:
@@ -974,8 +975,8 @@ def compact_line(full, details_path):
         out["cpu_baseline"] = None
     out["details"] = details_path
     # the driver keeps the last 2 000 characters of the output: shed the least essential extras until the line fits (everything is in `details`)
-    for path in (("workloads", "*", "cpu_sps"), ("workloads", "*", "full_bwd_ms"), ("sustained_ms_per_step",), ("workloads", "*", "sweep"),
-                 ("sweep_784-128-64-10",), ("step_roofline",)):
+    for path in (("workloads", "*", "cpu_sps"), ("workloads", "*", "full_bwd_ms"), ("sustained_ms_per_step",), ("sweep_784-128-64-10",),
+                 ("step_roofline",), ("workloads", "*", "sweep")):
         if len(json.dumps(out)) <= 1960:
             break
         if len(path) == 1:

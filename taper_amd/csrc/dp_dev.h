@@ -10,7 +10,7 @@
 //   4. RESET  it puts the sentinel back into the words it has just read (they are written again two steps later at the earliest, see below).
 // The caller then applies Adam from registers.  ONE dependent trip through memory per exchange -- the value IS the flag (no acknowledgement to
 // wait for before a flag may follow, no flag, no second trip to fetch what the flag announced: that form measured + 5.0 us on a 14.5 us
-// step with both "ranks" on one device, this one + X) -- no extra bytes on a link, no launch boundary, no arena-wide hand-shake: a
+// step with both "ranks" on one device, this one + 1.6) -- no extra bytes on a link, no launch boundary, no arena-wide hand-shake: a
 // slice is exchanged while other workgroups still compute theirs, and with one rank the function is empty.
 //
 // Reuse of the receive region needs no "done reading" hand-off: it is double-buffered on the step's parity.  A rank writes parity p of
