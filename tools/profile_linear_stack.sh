@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/linear_stack
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/tools/bench_linear_stack.py"
-{ timeout -s KILL 300 $CMD --steps 30 --warmup 8; timeout -s KILL 300 $CMD --steps 30 --warmup 8 --plain-loop; timeout -s KILL 300 $CMD --steps 30 --warmup 8 --no-adam; } > "$OUT/bench.jsonl"
+{ timeout -s KILL 300 $CMD --steps 30 --warmup 8; timeout -s KILL 300 $CMD --steps 30 --warmup 8; timeout -s KILL 300 $CMD --steps 30 --warmup 8 --no-adam; } > "$OUT/bench.jsonl"
 cat "$OUT/bench.jsonl" | cut -c1-220
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ls_trace -- $CMD --steps 12 --warmup 4 > /dev/null 2>&1
 python $ROOT/tools/kstats.py /tmp/ls_trace/*/*kernel_stats.csv | head -16 > "$OUT/kernel_stats.txt"
