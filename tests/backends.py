@@ -134,6 +134,10 @@ def mlp_baseline(rng):  # BASELINE.json configs[0/1]: 784-128-10 (src/train.rs:3
     return [_lin(rng, 784, 128), dict(kind="relu"), _lin(rng, 128, 10)]
 
 
+def mlp_64(rng):  # 784-64-10: the tail launch is 108 workgroups -- four ranks' worth of them fit ONE device together (tests/test_gpu_dp.py)
+    return [_lin(rng, 784, 64), dict(kind="relu"), _lin(rng, 64, 10)]
+
+
 def mlp_100(rng):  # a hidden width that is no multiple of 32 (the fused large-batch step pads its tiles: r05)
     return [_lin(rng, 784, 100), dict(kind="relu"), _lin(rng, 100, 10)]
 

@@ -136,6 +136,19 @@ def test_p2p_two_ranks_two_shot_exchange(tmp_path, monkeypatch):
     np.testing.assert_array_equal(two[0]["losses"], one[0]["losses"])
 
 
+def test_p2p_four_ranks_two_shot_exchange_inside_the_gradient_launch(tmp_path):
+    """FOUR processes on GPU 0 training through the in-launch exchange in its two-shot form (what four ranks and more take by default): the
+    784-64-10 model's tail launch is 108 workgroups of four waves at 64 rows per rank, so three ranks' worth of waiting workgroups leave
+    places free on one device and th_mlp_tail_dp_supported allows it.  Replicas bit-identical; weights and losses equal to one process on
+    the 256-row batches and to the oracle's loop."""
+    ranks = _run_ranks(tmp_path, 4, "p2p", "graph", steps=6, global_batch=256, same_device=True, model="mlp_64")
+    _check(ranks, 4, 6, 256, model="mlp_64")
+    _check_against_oracle(ranks, 4, 6, 256, model="mlp_64")
+    for r in ranks:
+        assert int(r["exchange_form"]) == 2 and int(r["launches_inkernel"]) >= 6, (int(r["exchange_form"]), int(r["launches_inkernel"]))
+        assert int(r["launches_fused"]) == 3          # the bootstrap's self-check only
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_p2p_many_ranks_on_one_gpu_fall_back_to_the_three_launch_step(tmp_path, world):
     """a workgroup that waits for a peer's slice holds its place on the device: with four or eight ranks on ONE device the waiting
