@@ -47,6 +47,8 @@ def main():
     opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
     fine = os.environ.get("TAPER_DP_FINE", "0") == "1"
     comm = init_data_parallel(T, rdzv, backend=os.environ.get("TAPER_DP_BACKEND", "rccl"), optimizer=opt, fine_grained=fine)
+    extra_rounds = int(os.environ.get("TAPER_DP_SELFTEST_ROUNDS", "0"))
+    selftest_bad = comm.exchange_selftest(16, extra_rounds) if extra_rounds and comm is not None and comm.is_p2p() else 0   # collective
     tr = T.Trainer(model, opt, comm=comm, **({"sample_shape": sample_shape(model_name)} if sample_shape(model_name) else {}))
     loader = T.DataLoader(T.MNISTDataset.from_host(x[rows], y[rows]), per, False)
     mode = T.Trainer.GRAPH if os.environ.get("TAPER_DP_MODE", "graph") == "graph" else T.Trainer.EAGER
@@ -82,7 +84,7 @@ def main():
     from taper_amd._lib import hip as lib
     mlp2_calls = C.c_int64()
     lib.th_debug_mlp2_calls(C.byref(mlp2_calls))   # host-side calls of th_mlp2_xent on this thread (eager steps + captures)
-    np.savez(out / f"rank{rank}.npz", fine=int(fine), mlp2_calls=mlp2_calls.value, launches_inplace=st["inplace"], launches_fused=st["fused"], launches_inkernel=st["inkernel"], exchange_form=st["form"], losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
+    np.savez(out / f"rank{rank}.npz", fine=int(fine), mlp2_calls=mlp2_calls.value, launches_inplace=st["inplace"], launches_fused=st["fused"], launches_inkernel=st["inkernel"], exchange_form=st["form"], selftest_bad=selftest_bad, losses=np.concatenate([ep["losses"], ep2["losses"]]), t=opt.t(),
              **{f"p{i}": p.data() for i, p in enumerate(model.parameters())}, **{k: np.asarray(v) for k, v in runs.items()})
     rdzv.barrier()
     rdzv.close()

@@ -149,6 +149,16 @@ def test_p2p_four_ranks_two_shot_exchange_inside_the_gradient_launch(tmp_path):
         assert int(r["launches_fused"]) == 3          # the bootstrap's self-check only
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_p2p_exchange_alone_many_rounds(tmp_path, world, monkeypatch):
+    """the exchange on its own (th_comm_exchange_selftest: 16 workgroups per rank, known patterns checked on the device) for 1 500 rounds
+    through the same words, W processes on GPU 0 -- the one-shot form at W = 2 / 3, the two-shot form at W = 8 (owners 0 .. 7 all in play)"""
+    monkeypatch.setenv("TAPER_DP_SELFTEST_ROUNDS", "1500")
+    ranks = _run_ranks(tmp_path, world, "p2p", "graph", steps=2, global_batch=64 * world, same_device=True)
+    for r in ranks:
+        assert int(r["selftest_bad"]) == 0 and int(r["exchange_form"]) == (2 if world >= 4 else 1)
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_p2p_many_ranks_on_one_gpu_fall_back_to_the_three_launch_step(tmp_path, world):
     """a workgroup that waits for a peer's slice holds its place on the device: with four or eight ranks on ONE device the waiting

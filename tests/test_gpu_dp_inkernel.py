@@ -40,6 +40,7 @@ def test_loopback_exchange_selftest():
     assert comm.is_p2p() and comm.ranks_on_this_device() == 1
     assert comm.exchange_selftest(64, 5) == 0
     assert comm.exchange_selftest(512, 3) == 0      # every slot of the region, both parities, the step counter carried on
+    assert comm.exchange_selftest(208, 2000) == 0   # a training run's worth of steps through the same words: every value, every time
     assert not comm.timed_out()
 
 
