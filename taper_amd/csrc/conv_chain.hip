@@ -1818,9 +1818,13 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
             }
         } else {
             const int lds = CS_LDS * (int)sizeof(float);
+            static const int lean_env = [] { const char *e = getenv("TAPER_CHAIN_LEAN"); return e ? atoi(e) : -1; }();
             if (chain_loop(n)) {
                 TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<false, 1, true>), lds);
                 hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1, true>), dim3(kNumCU), dim3(CH_NT), lds, ctx->stream, a);
+            } else if (lean_env >= 0 ? lean_env != 0 : n >= 2 * kNumCU) {      // two images per CU and more: two workgroups to a CU (as th_conv_chain_head_fwd)
+                TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<false, 1, false, true>), lds);
+                hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1, false, true>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
             } else {
                 TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<false, 1>), lds);
                 hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);

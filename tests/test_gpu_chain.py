@@ -389,3 +389,18 @@ def test_walking_chain_is_bit_identical_per_image(ctx, name, n):
         np.testing.assert_array_equal(got[lo:hi], ctx.download(y1, (hi - lo, c_last, hw, hw)), err_msg=f"images {lo}..{hi}")
         if cnt is not None:
             np.testing.assert_array_equal(got_cnt[lo:hi], ctx.download(cnt1, (hi - lo, c_last)))
+
+
+@pytest.mark.parametrize("n", [512, 600, 1024])
+def test_two_workgroups_per_cu_instance_is_bit_identical_per_image(ctx, n):
+    """from 512 images the simple chain runs its 128-register instance, two workgroups to a CU (conv_chain_simple_kernel<.., LEAN>: half-pass k
+    loop, the same k order): image i of the batch gives the bits it gives in batches of <= 200 images (the one-per-CU instance, held to the
+    oracle above)"""
+    params = _params(SIMPLE, 33)
+    x = _images(n, 2000 + n)
+    y, cnt, hw, c_last = _hip_chain(ctx, x, SIMPLE, params)
+    got = ctx.download(y, (n, c_last, hw, hw))
+    for lo in range(0, n, 200):
+        hi = min(n, lo + 200)
+        y1, _, _, _ = _hip_chain(ctx, x[lo:hi], SIMPLE, params)
+        np.testing.assert_array_equal(got[lo:hi], ctx.download(y1, (hi - lo, c_last, hw, hw)), err_msg=f"images {lo}..{hi}")
