@@ -1125,10 +1125,13 @@ def main():
         from taper_amd import hip as _hip
         if comm is not None and comm.is_p2p():
             if not share and _hip.device_count() >= world:
-                sr, dr, kr, samer = side_run(batch, "rccl")
-                c_rccl = _KEEP_ALIVE[-1][4]
-                dp_extra["same_job_over_rccl"] = dict(value=round(sr / dr, 1), unit="samples/s", ms_per_step=round(dr / args.steps * 1e3, 5), comm=kr,
-                                                      rccl_ranks=c_rccl.count() if c_rccl is not None else None, replicas_bit_identical=samer)
+                try:      # reported, never required: a failure here must not cost the run its line
+                    sr, dr, kr, samer = side_run(batch, "rccl")
+                    c_rccl = _KEEP_ALIVE[-1][4]
+                    dp_extra["same_job_over_rccl"] = dict(value=round(sr / dr, 1), unit="samples/s", ms_per_step=round(dr / args.steps * 1e3, 5), comm=kr,
+                                                          rccl_ranks=c_rccl.count() if c_rccl is not None else None, replicas_bit_identical=samer)
+                except Exception as e:   # noqa: BLE001
+                    dp_extra["same_job_over_rccl"] = dict(error=str(e)[:200])
             else:
                 dp_extra["same_job_over_rccl"] = dict(skipped=f"{world} ranks share {_hip.device_count()} GPU(s): RCCL needs one device per rank")
         elif comm is not None:
