@@ -918,7 +918,7 @@ def compact_line(full, details_path):
             d["single_gpu_ms_per_step"] = dp["single_gpu_same_per_gpu_batch"]["ms_per_step"]
         if "same_job_over_rccl" in dp:
             r = dp["same_job_over_rccl"]
-            d["same_job_over_rccl"] = {k: r[k] for k in ("value", "ms_per_step", "rccl_ranks", "skipped") if k in r}
+            d["same_job_over_rccl"] = {k: r[k] for k in ("value", "ms_per_step", "rccl_ranks", "skipped", "error") if k in r}
         if "dp_at_64_rows_per_gpu" in dp:
             d["b64_per_gpu_ms_per_step"] = dp["dp_at_64_rows_per_gpu"]["ms_per_step"]
         out["data_parallel"] = d
