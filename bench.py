@@ -911,8 +911,8 @@ def compact_line(full, details_path):
         out["step_roofline"] = {"hbm_frac": round(sr["hbm_frac"], 4), "mfma_frac": round(sr["mfma_frac"], 4)}
     if full.get("data_parallel"):
         dp = full["data_parallel"]
-        # (N = 1: one_rank_step_us and three_launch_one_rank_step_us are in the details file)
-        d = {k: dp[k] for k in ("weak_scaling_efficiency", "replicas_bit_identical", "per_gpu_batch", "single_gpu_step_us",
+        # (N = 1: three_launch_one_rank_step_us and the ceilings of the other forms are in the details file)
+        d = {k: dp[k] for k in ("weak_scaling_efficiency", "replicas_bit_identical", "per_gpu_batch", "single_gpu_step_us", "one_rank_step_us",
                                 "loopback_two_rank_step_us", "on_device_efficiency_ceiling", "error") if k in dp}
         if "single_gpu_same_per_gpu_batch" in dp:
             d["single_gpu_ms_per_step"] = dp["single_gpu_same_per_gpu_batch"]["ms_per_step"]
@@ -976,11 +976,14 @@ def compact_line(full, details_path):
     out["details"] = details_path
     # the driver keeps the last 2 000 characters of the output: shed the least essential extras until the line fits (everything is in `details`)
     for path in (("workloads", "*", "cpu_sps"), ("workloads", "*", "full_bwd_ms"), ("sustained_ms_per_step",), ("sweep_784-128-64-10",),
-                 ("step_roofline",), ("workloads", "*", "sweep")):
+                 ("cpu_baseline", "blas_feature_value"), ("cpu_baseline", "sample"), ("step_roofline",), ("data_parallel", "one_rank_step_us"),
+                 ("workloads", "*", "sweep")):
         if len(json.dumps(out)) <= 1960:
             break
         if len(path) == 1:
             out.pop(path[0], None)
+        elif path[1] != "*":
+            (out.get(path[0]) or {}).pop(path[1], None)
         else:
             for e in (out.get(path[0]) or {}).values():
                 if isinstance(e, dict):
