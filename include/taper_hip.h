@@ -679,6 +679,10 @@ int th_comm_is_p2p(const th_comm *comm);
 int th_comm_count(const th_comm *comm, int *out_ranks);   /* ranks the communicator spans (RCCL: ncclCommCount) */
 int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error);
 int th_comm_error_peek(const th_comm *comm, int *out_error);
+/* where an IN-LAUNCH exchange (csrc/dp_dev.h) gave up, for the error message: out4 = {slot of the first workgroup whose wait ran out (-1: none
+ * did -- the time-out was a copy-engine round's), that launch's exchange step, bit s set = rank s's words had not arrived, this rank's
+ * exchange step now}.  Synchronises the stream. */
+int th_comm_timeout_detail(th_comm *comm, th_ctx *ctx, int out4[4]);
 int th_comm_set_timeout_ms(th_comm *comm, int64_t ms);
 /* the communicator's sticky error word in device memory (NULL for an RCCL communicator): th_adam_step_guarded's guard */
 int th_comm_error_word(const th_comm *comm, const uint32_t **d_out);
@@ -718,6 +722,15 @@ int th_comm_stats_inkernel(const th_comm *comm, int64_t *out_launches);
 int th_comm_exchange_selftest(th_comm *comm, th_ctx *ctx, int slots, int rounds, int *out_bad);
 int th_ctx_set_update_guard(th_ctx *ctx, const uint32_t *d_skip_if_nonzero /* nullable: clears it */, uint32_t *d_step_word /* nullable */);
 int th_comm_step_word(const th_comm *comm, uint32_t **d_out);   /* NULL for an RCCL communicator */
+/* ... and the simple CNN's step (th_conv_chain_head_fwd, th_wide_head_grads): th_wide_head_grads_dp is th_wide_head_grads with every finished
+ * sum -- a block of dW, db, a block of the last conv's bias gradient -- reduced over the ranks before its store and its Adam epilogue; loss
+ * and hit count stay this rank's.  d_tick: the counter th_conv_chain_head_fwd ticked (with the guard set it also advances the exchange's
+ * step number), taken back by the launch when the exchange fails. */
+int th_wide_head_grads_dp_supported(const th_comm *comm, th_ctx *ctx, int batch, int in_features, int classes, int conv_c);
+int th_wide_head_grads_dp(th_comm *comm, th_ctx *ctx, const float *d_x, const float *d_dl, const float *d_rowstat, const float *d_cbpart, int batch,
+                          int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss, float *d_ncorrect,
+                          float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance, const th_adam_fuse *w_fuse,
+                          const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse, int32_t *d_tick);
 int th_mlp_tail_dp_supported(const th_comm *comm, th_ctx *ctx, int batch, int in_features, int hidden, int classes);
 int th_mlp_tail_dp(th_comm *comm, th_ctx *ctx, const float *d_x, const float *d_h, const float *d_w2, const float *d_b2,
                    const float *d_targets, int batch, int in_features, int hidden, int classes,

@@ -35,6 +35,9 @@ int th_debug_last_conv_config(th_ctx *ctx, int *out6);
  * 1: whenever the shape fits it. */
 int th_debug_set_conv_img(th_ctx *ctx, int mode);
 
+/* post-mortem of the in-launch exchange (csrc/dp_dev.h) on stderr: the communicator's state words and, per parity and source block of the
+ * receive region, the slots that hold words.  Trainer::check_comm calls it under TAPER_DP_POSTMORTEM=1 when a time-out is reported. */
+int th_comm_debug_dump(th_comm *comm, th_ctx *ctx);
 #ifdef __cplusplus
 }
 #endif

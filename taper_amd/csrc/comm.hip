@@ -8,6 +8,8 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include <unistd.h>
 
@@ -67,6 +69,16 @@ struct th_comm {
 namespace th {
 const DpDev *comm_dp_dev(const th_comm *c) { return (c && c->p2p && c->connected) ? &c->dp : nullptr; }
 int comm_dp_sharing(const th_comm *c) { return c ? c->sharing : 1; }
+// Ranks that SHARE a device (a test box; a deployment runs one rank per GPU) wait in each other's way: a waiting workgroup holds its place,
+// and the late rank still has to get the launches IN FRONT of its exchange launch dispatched.  Two ranks per device never starved one another
+// (r06: hundreds of steps, either model); with three, the late rank's first launch had 6 of its 33 1024-thread workgroups not dispatched
+// until the other two ranks' 208 waiting workgroups gave up -- 10 of 20 runs (profiles/r06_dp_three_ranks_one_device.txt; four and five
+// ranks finished 40 of 40, which is not an explanation).  So: in-launch exchange for at most two ranks per device; more take the
+// three-launch form.  TAPER_DP_SHARED_RANKS raises the bound (the four-rank protocol tests do).
+int comm_dp_sharing_limit() {
+    static const int lim = [] { const char *e = std::getenv("TAPER_DP_SHARED_RANKS"); return e ? std::max(1, atoi(e)) : 2; }();
+    return lim;
+}
 void comm_dp_count_launch(th_comm *c) { if (c) ++c->launches_inkernel; }
 }
 
@@ -571,6 +583,49 @@ int th_comm_error(th_comm *comm, th_ctx *ctx, int *out_error) {
     TH_HIP(hipStreamSynchronize(ctx->stream));
     TH_HIP(hipMemcpy(st, comm->state, sizeof(st), hipMemcpyDeviceToHost));
     *out_error = (int)st[2];
+    return 0;
+}
+
+// post-mortem of the in-launch exchange's receive region (TAPER_DP_POSTMORTEM=1, Trainer::check_comm): per parity and source block, the
+// slots whose first word is not the empty mark
+int th_comm_debug_dump(th_comm *comm, th_ctx *ctx) {
+    TH_REQUIRE(comm && ctx && comm->p2p, "th_comm_debug_dump: needs a peer-to-peer communicator");
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t st[16];
+    TH_HIP(hipMemcpy(st, comm->state, sizeof(st), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[dp post-mortem rank %d] state:", comm->rank);
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", st[i]);
+    fprintf(stderr, "\n");
+    std::vector<uint64_t> w(th::DP_SRC_STRIDE / 2);
+    const char *base = (const char *)comm->flags_local + th::DP_DATA_OFFSET;
+    for (int par = 0; par < 2; ++par)
+        for (int s = 0; s <= th::DP_MAX_RANKS; ++s) {
+            TH_HIP(hipMemcpy(w.data(), base + ((size_t)par * th::DP_PARITY_STRIDE + (size_t)s * th::DP_SRC_STRIDE) * sizeof(float),
+                             th::DP_SRC_STRIDE * sizeof(float), hipMemcpyDeviceToHost));
+            std::string line;
+            int n_set = 0;
+            for (int slot = 0; slot < th::DP_MAX_SLOTS; ++slot) {
+                int cnt = 0;
+                for (int i = 0; i < th::DP_SLOT_FLOATS / 2; ++i) cnt += w[(size_t)slot * (th::DP_SLOT_FLOATS / 2) + i] != ~0ull;
+                if (cnt) {
+                    ++n_set;
+                    if (line.size() < 400) line += " " + std::to_string(slot) + ":" + std::to_string(cnt);
+                }
+            }
+            if (n_set) fprintf(stderr, "[dp post-mortem rank %d] parity %d block %d: %d slots hold words (slot:count)%s\n", comm->rank, par, s, n_set, line.c_str());
+        }
+    return 0;
+}
+
+int th_comm_timeout_detail(th_comm *comm, th_ctx *ctx, int out4[4]) {
+    TH_REQUIRE(comm && ctx && out4 && comm->p2p, "th_comm_timeout_detail: needs a peer-to-peer communicator");
+    uint32_t st[16];
+    TH_HIP(hipStreamSynchronize(ctx->stream));
+    TH_HIP(hipMemcpy(st, comm->state, sizeof(st), hipMemcpyDeviceToHost));
+    out4[0] = (int)st[9] - 1;
+    out4[1] = (int)st[10];
+    out4[2] = (int)st[11];
+    out4[3] = (int)st[th::DP_ST_STEP];
     return 0;
 }
 

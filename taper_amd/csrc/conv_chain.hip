@@ -52,7 +52,14 @@ struct ChainHeadArgs {
     int32_t *tick;                     // nullable: Adam's step counter, += 1 (optim.rs:84; nothing in this launch reads it)
     int classes, k, c_last, hw;
     float inv_b;
+    const uint32_t *guard;             // th_ctx_set_update_guard (nullable): non-zero = a data-parallel exchange failed -- no tick
+    uint32_t *step_word;               // ... and the exchange's step number, advanced with the tick (th_wide_head_grads_dp reads it; dp_dev.h)
 };
+__device__ __forceinline__ void chain_head_tick(const ChainHeadArgs &h) {
+    if (h.guard && h.guard[0] != 0u) return;
+    h.tick[0] += 1;
+    if (h.step_word) h.step_word[0] += 1u;
+}
 
 // The three-layer classifier behind the reference chain's plane means (th_conv_chain_mlp3_xent): Linear(128, 128) + ReLU, Linear(128, 64) + ReLU,
 // Linear(64, classes), softmax cross-entropy -- examples/train_mnist_cnn.rs:53-61 -- ONE ROW per workgroup, in the chain launch's last
@@ -980,7 +987,7 @@ __global__ __launch_bounds__(CH_NT, LEAN ? 4 : 1) void conv_chain_simple_kernel(
     chain_load_image(a.x + (long)blockIdx.x * 784, lds + CS_IMG, t0_);
     if constexpr (LEAN) chain_weights9<14, 32, 64>(a.w[1], 0, wc9, wave, t0_ & 63);   // conv2's first half pass: in flight under conv1
     else chain_weights<14, 32, 64>(a.w[1], 0, wc, wave, t0_ & 63);      // conv2's first pass: in flight under conv1
-    if (HEAD && a.head.tick && blockIdx.x == 0 && t0_ == 0) a.head.tick[0] += 1;
+    if (HEAD && a.head.tick && blockIdx.x == 0 && t0_ == 0) chain_head_tick(a.head);
     constexpr int HV = NC <= 10 ? 4 : 1, HNJ = HV == 4 ? 4 * ((CS_K + 4 * CH_NT - 1) / (4 * CH_NT)) : CS_NJ;   // (16 classes: 128 registers as quads)
     float hw_[HNJ][NC];
     if constexpr (HEAD && LOOP && CH_LOOP_KEEP_HEAD) {           // the classifier's weights, once for all of this workgroup's images
@@ -1543,7 +1550,7 @@ __global__ __launch_bounds__(CH_NT, 1) void conv_chain_rt_kernel(RtChainArgs a) 
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
-    if (a.has_head && a.head.tick && blockIdx.x == 0 && t == 0) a.head.tick[0] += 1;
+    if (a.has_head && a.head.tick && blockIdx.x == 0 && t == 0) chain_head_tick(a.head);
     for (int img = blockIdx.x; img < a.n; img += gridDim.x) {
         const float *xi = a.x + (long)img * a.c0 * a.s0 * a.s0;
         float *in0 = lds + a.st[0].in_off;
@@ -1913,14 +1920,14 @@ int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *s
         const RtStage &ls = ra.st[n_stages - 1];
         const int hw = (ls.s / 2) * (ls.s / 2);
         ra.head = ChainHeadArgs{head->d_w, head->d_bias, head->d_targets, head->d_dl, head->d_rowstat, head->d_cbpart, head->d_tick,
-                                head->classes, ls.c_out * hw, ls.c_out, hw, 1.0f / (float)n};
+                                head->classes, ls.c_out * hw, ls.c_out, hw, 1.0f / (float)n, ctx->update_guard, ctx->update_step_word};
         rt_launch(ctx, ra, lds_floats, d_x, d_y, nullptr, n);
     } else {
         ConvChainArgs a{};
         a.x = d_x; a.y = d_y; a.cnt = nullptr; a.n = n;
         for (int i = 0; i < n_stages; ++i) { a.w[i] = stages[i].d_w; a.b[i] = stages[i].d_bias; }
         a.head = ChainHeadArgs{head->d_w, head->d_bias, head->d_targets, head->d_dl, head->d_rowstat, head->d_cbpart, head->d_tick,
-                               head->classes, CS_K, 64, 49, 1.0f / (float)n};
+                               head->classes, CS_K, 64, 49, 1.0f / (float)n, ctx->update_guard, ctx->update_step_word};
         const int lds = CS_LDS * (int)sizeof(float);
 #define TH_SIMPLE_HEAD(NC_, LOOP_, GRID_)                                                                                                          \
     do {                                                                                                                                          \

@@ -63,6 +63,13 @@ __device__ __forceinline__ DpTicket dp_begin(const DpDev &c) {
 // one thread, in a launch in front of the exchanging one
 __device__ __forceinline__ void dp_advance_step(uint32_t *step_word) { step_word[0] += 1u; }
 
+// (what the first workgroup to give up was waiting for: state[9] = slot + 1, [10] = step, [11] = bit s set: rank s's words had not arrived -- th_comm_timeout_detail)
+__device__ __forceinline__ void dp_note(const DpDev &c, int slot, uint32_t step, uint32_t missing) {
+    if (__hip_atomic_exchange(&c.state[9], (uint32_t)slot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        c.state[10] = step;
+        c.state[11] = missing;
+    }
+}
 __device__ __forceinline__ void dp_raise(const DpDev &c) {
     __hip_atomic_store(&c.state[DP_ST_ERROR], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&c.state[DP_ST_DEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -123,6 +130,11 @@ __device__ __forceinline__ bool dp_exchange(const DpDev &c, const DpTicket &tk, 
                 }
             if (all) break;
             if (wall_clock64() - t0 > c.spin_ticks) {
+                uint32_t missing = 0u;
+#pragma unroll
+                for (int s = 0; s < NR; ++s)
+                    if (s < W && s != me && q[s][0] == DP_EMPTY) missing |= 1u << s;
+                dp_note(c, slot, step, missing);
                 dp_raise(c);
                 ok = false;
                 break;
@@ -187,6 +199,11 @@ __device__ __forceinline__ bool dp_exchange_two_shot(const DpDev &c, const DpTic
                     }
                 if (all) break;
                 if (wall_clock64() - t0 > c.spin_ticks) {
+                    uint32_t missing = 0u;
+#pragma unroll
+                    for (int s = 0; s < NR; ++s)
+                        if (s < W && s != me && q[s][0] == DP_EMPTY) missing |= 1u << s;
+                    dp_note(c, slot, tk.step, missing);
                     dp_raise(c);
                     ok = false;
                     break;
@@ -233,6 +250,7 @@ __device__ __forceinline__ bool dp_exchange_two_shot(const DpDev &c, const DpTic
                 }
                 if (all) break;
                 if (wall_clock64() - t0 > c.spin_ticks) {
+                    dp_note(c, slot, tk.step, 1u << owner);
                     dp_raise(c);
                     ok = false;
                     break;
@@ -262,6 +280,7 @@ __device__ __forceinline__ bool dp_reduce(const DpDev &c, const DpTicket &tk, in
 // this rank's device, and the launch counter the tests read
 const DpDev *comm_dp_dev(const th_comm *c);
 int comm_dp_sharing(const th_comm *c);
+int comm_dp_sharing_limit();          // how many ranks on one device the in-launch exchange is offered to (comm.hip: 2, measured)
 void comm_dp_count_launch(th_comm *c);
 
 }  // namespace th

@@ -52,6 +52,12 @@ bool Communicator::tail_exchange_ok(int batch, int in_features, int hidden, int 
     return th_mlp_tail_dp_supported(comm_, Device::ctx(), batch, in_features, hidden, classes) != 0;
 }
 
+bool Communicator::wide_exchange_ok(int batch, int in_features, int classes, int conv_c) const {
+    if (!p2p_ || !inkernel) return false;
+    if (n_ranks == 1) return true;     // (the mean over one rank: the single-GPU launch)
+    return th_wide_head_grads_dp_supported(comm_, Device::ctx(), batch, in_features, classes, conv_c) != 0;
+}
+
 int64_t Communicator::inkernel_launches() const {
     int64_t n = 0;
     TH(th_comm_stats_inkernel(comm_, &n));

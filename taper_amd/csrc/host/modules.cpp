@@ -272,6 +272,14 @@ Tensor conv_chain_head_cross_entropy(const Tensor &x, const std::vector<ConvStag
     float *dw = slot(w), *db = slot(bias), *gcb = cb_grad ? slot(cbias) : nullptr;
     th_adam_fuse wf{}, bf{}, cf{};
     const bool fw = fa && fa->fuse_for(w, &wf), fb = fa && bias.defined() && fa->fuse_for(bias, &bf), fc = fa && cb_grad && fa->fuse_for(cbias, &cf);
+    const Communicator *xc = TailExchangeScope::active();
+    if (xc && xc->n_ranks > 1) {
+        // data parallel: the launch exchanges every finished sum with the peers; its epilogues apply the mean
+        TAPER_ASSERT(fa && xc->wide_exchange_ok(n, k, classes, c_last), "conv_chain_head_cross_entropy: the in-launch exchange does not cover this step");
+        TH(th_wide_head_grads_dp(xc->handle(), ctx, map.dptr(), dl->d, rowstat->d, cbpart ? cbpart->d : nullptr, n, k, classes, c_last, dw, db, gcb,
+                                 loss.dptr(), nc, log ? log->d_metrics : nullptr, log ? log->capacity : 0, log ? log->d_state : nullptr,
+                                 log ? log->advance : 0, fw ? &wf : nullptr, fb ? &bf : nullptr, fc ? &cf : nullptr, fa->d_tick()));
+    } else
     TH(th_wide_head_grads(ctx, map.dptr(), dl->d, rowstat->d, cbpart ? cbpart->d : nullptr, n, k, classes, c_last, dw, db, gcb, loss.dptr(), nc,
                           log ? log->d_metrics : nullptr, log ? log->capacity : 0, log ? log->d_state : nullptr, log ? log->advance : 0,
                           fw ? &wf : nullptr, fb ? &bf : nullptr, fc ? &cf : nullptr));

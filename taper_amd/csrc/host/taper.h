@@ -697,6 +697,8 @@ class Communicator {
     // The exchange inside the gradient launch (th_mlp_tail_dp): may this communicator take it for a Linear + ReLU + Linear classifier of these
     // shapes?  (peer-to-peer, connected, >= 2 ranks, whole tiles, and -- ranks sharing a device -- room for the waiting workgroups)
     bool tail_exchange_ok(int batch, int in_features, int hidden, int classes) const;
+    // ... and for the simple CNN's batch sums (th_wide_head_grads_dp): `in_features` = the flattened pooled map, conv_c = the last conv's channels
+    bool wide_exchange_ok(int batch, int in_features, int classes, int conv_c) const;
     bool inkernel = true;                                 // TAPER_DP_INKERNEL=0: always the three-launch form (A/B probe)
     int64_t inkernel_launches() const;                    // th_mlp_tail_dp launches enqueued or captured
     int exchange_selftest(int slots, int rounds) const;   // collective; mismatches + time-outs seen by this rank (th_comm_exchange_selftest)
@@ -796,6 +798,7 @@ class Trainer {  // train.rs:74-172
     void enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_row_source *rows = nullptr);
     bool mlp2_step(size_t batch, int64_t n_rows) const;   // this model at this batch takes th_mlp2_xent (rows read in place)
     bool tail_exchange_step(size_t batch) const;          // data parallel: this step reduces its gradients inside its own launch (th_mlp_tail_dp)
+    bool chain_exchange_step(const Tensor &xin) const;    // ... the simple CNN's step does (th_wide_head_grads_dp)
     void drop_graphs();
     std::vector<std::pair<size_t, th_graph *>> graphs_;  // (steps per replay, graph), largest first
     std::vector<std::pair<size_t, th_graph *>> whole_graphs_;  // (steps, graph): state reset + that many full steps -- a whole call in one replay

@@ -8,6 +8,7 @@
 #include <fstream>
 
 #include "nn_internal.h"
+#include "../../../include/taper_hip_debug.h"   // (th_comm_debug_dump: the post-mortem under TAPER_DP_POSTMORTEM)
 
 namespace taper {
 // ---------------------------------------------------------------- data
@@ -159,9 +160,19 @@ void Trainer::train_step(const Tensor &images, const Tensor &labels, float *loss
 void Trainer::check_comm() const {
     // a peer that never arrived at an all-reduce: the launch applied nothing and every later one is a no-op (th_comm_error_peek) -- the
     // replicas are no longer in step, and the run must end here, loudly, not train on
-    if (comm && comm->is_p2p() && comm->failed())
+    if (comm && comm->is_p2p() && comm->failed()) {
+        if (const char *e = std::getenv("TAPER_DP_POSTMORTEM"); e && atoi(e)) th_comm_debug_dump(comm->handle(), Device::ctx());
+        int d[4] = {-1, 0, 0, 0};
+        th_comm_timeout_detail(comm->handle(), Device::ctx(), d);
+        std::string where;
+        if (d[0] >= 0) {
+            where = "; first wait to run out: slot " + std::to_string(d[0]) + " of exchange step " + std::to_string(d[1]) + ", nothing from rank(s)";
+            for (int s = 0; s < comm->n_ranks; ++s)
+                if (d[2] >> s & 1) where += " " + std::to_string(s);
+        }
         throw Error("data-parallel all-reduce timed out waiting for a peer (rank " + std::to_string(comm->rank) + " of " +
-                    std::to_string(comm->n_ranks) + "): no update was applied from that step on; the replicas are out of step");
+                    std::to_string(comm->n_ranks) + "): no update was applied from that step on; the replicas are out of step" + where);
+    }
 }
 
 EpochResult Trainer::train_epoch(DataLoader &loader) {  // train.rs:98-144
@@ -277,7 +288,7 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
     // Adam updates ride in the epilogues of the kernels that produce the gradients -- unless the
     // gradients still have to be all-reduced across ranks first by a launch of their own.  The Linear + ReLU + Linear step over a
     // peer-to-peer communicator reduces them INSIDE its gradient launch (th_mlp_tail_dp) and keeps the fused epilogues.
-    const bool dp_tail = comm && !rows && tail_exchange_step(batch);
+    const bool dp_tail = comm && !rows && (tail_exchange_step(batch) || chain_exchange_step(shape_input(Tensor::from_device(d_xb, {batch, 784}), sample_shape)));
     FusedAdamScope scope((fuse_adam && (!comm || dp_tail)) ? optimizer.get() : nullptr);
     TailExchangeScope xscope(dp_tail ? comm.get() : nullptr);
     PoolBiasScope pool_scope(fuse_head && dynamic_cast<Sequential *>(model.get()) != nullptr);
@@ -396,6 +407,24 @@ void Trainer::enqueue_compute(float *d_xb, float *d_yb, size_t batch, const th_r
     }
     optimizer->zero_grad();
     if (adam) adam->set_carry_deferred(false);
+}
+
+// this step is the simple CNN's (conv rows ending in a pooled map, Flatten, Linear, cross-entropy: two launches), the optimizer is Adam with
+// fused updates on, and the communicator can exchange the batch sums inside their launch: the single-GPU step with the mean gradient in the
+// second launch's epilogues.  The same conditions the step's own choice of form checks (enqueue_compute), decided before the scopes open.
+bool Trainer::chain_exchange_step(const Tensor &xin) const {
+    if (!comm || !comm->is_p2p() || !comm->fuse_adam || !fuse_adam || fuse_head < 2 || xin.shape().size() != 4) return false;
+    auto *seq = dynamic_cast<Sequential *>(model.get());
+    if (!seq || !seq->fuse || !conv_chain_enabled() || !conv_chain_head_enabled() || !dynamic_cast<Adam *>(optimizer.get())) return false;
+    const size_t nl = seq->layers.size();
+    if (nl < 3) return false;
+    auto *last = dynamic_cast<Linear *>(seq->layers.back().get());
+    auto *fl = dynamic_cast<Flatten *>(seq->layers[nl - 2].get());
+    if (!last || !fl || fl->start_dim != 1) return false;
+    std::vector<ConvStage> stages;
+    if (seq->conv_stages_at(0, nl - 2, &stages) != nl - 2 || !conv_chain_head_supported(xin, stages, last->weight, last->bias)) return false;
+    if (xin.conv_chain_head_supported(stages, (int)last->weight.shape()[0]) != 2) return false;      // the compiled simple chain: its tick carries the step number
+    return comm->wide_exchange_ok((int)xin.shape()[0], (int)last->weight.shape()[1], (int)last->weight.shape()[0], (int)stages.back().weight.shape()[0]);
 }
 
 // this step is Linear + ReLU + Linear + cross-entropy straight on the loader's rows, every parameter trains and has no gradient yet, the

@@ -831,6 +831,7 @@ extern "C" int th_mlp_tail_dp_supported(const th_comm *comm, th_ctx *ctx, int ba
     const int grid = tail_dp_grid(in_features, hidden);
     if (grid > DP_MAX_SLOTS) return 0;
     const int sharing = comm_dp_sharing(comm);
+    if (sharing > comm_dp_sharing_limit()) return 0;
     if (sharing > 1) {
         // Ranks on ONE device (a test box): a workgroup that waits for a peer's slice holds its place, so the workgroups of all the
         // ranks but one must leave a place free -- the rank that is furthest behind then always gets its next workgroup dispatched, its

@@ -10,6 +10,7 @@
 //             one extra "lead" workgroup: db, loss, hit count, the step log and Adam's t += 1.
 // No parameter is updated here (W is read by every workgroup's dX product): the caller defers W / b (th_adam_slice).
 #include "tail_dev.h"
+#include "dp_dev.h"
 #include "adam_dev.h"
 
 TH_USES_DEVICE_ERRORS()
@@ -356,6 +357,8 @@ struct WideGradArgs {
     int64_t *state;
     int64_t advance;
     AdamDev fw, fb, fcb;
+    DpDev dp;            // th_wide_head_grads_dp: the gradient exchange across ranks between a finished sum and its store / Adam (dp_dev.h)
+    int32_t *dp_tick;    // ... Adam's counter, ticked by the chain launch in front: taken back when the exchange fails
 };
 
 // column sums of a [rows][ld] slab, columns col0 .. col0 + 15 (ncols live): thread t < 16 returns the sum of column col0 + t, rows in
@@ -392,10 +395,17 @@ __device__ __forceinline__ float slab_colsum16(const float *__restrict__ p, int 
     return tot;
 }
 
+// DPNR > 0 (th_wide_head_grads_dp): data parallel -- every sum this launch finishes (a dW block: two columns per finishing lane; db; a block of
+// the conv bias) goes through dp_reduce() before it is stored and fed to Adam: the MEAN over the ranks, formed in rank order.  Loss and hit
+// count stay this rank's own.  One slot per workgroup (blockIdx.x).
+template <int DPNR>
 __global__ __launch_bounds__(64 * WH_NW) void wide_grads_kernel(WideGradArgs a) {
     __shared__ float red[WH_NW][WH_TX][64][4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g4 = lane >> 4;
     const int B = a.batch, K = a.k, C = a.c;
+    DpTicket dp_tk{0u, 0u};
+    if constexpr (DPNR > 0) dp_tk = dp_begin(a.dp);
+    static_assert(DPNR == 0 || WH_TX == 2, "the exchange carries two values per finishing lane");
     if ((int)blockIdx.x < a.n_col) {
         const int col0 = blockIdx.x * 16 * WH_TX;
         // the finishing lanes (wave e < 4: class 4 g4 + e, column r16 of each tile) request their Adam state before anything else
@@ -450,14 +460,26 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_grads_kernel(WideGradArgs a) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[wave][tx][lane][i] = accw[tx][i];
         __syncthreads();
-        if (wave < 4) {                                // deterministic cross-wave sum; wave e finishes class 4 g4 + e
+        float sums[WH_TX];
+#pragma unroll
+        for (int tx = 0; tx < WH_TX; ++tx) {
+            sums[tx] = 0.f;
+            if (wave < 4) {                            // deterministic cross-wave sum; wave e finishes class 4 g4 + e
+                float sum = red[0][tx][lane][wave];
+#pragma unroll
+                for (int w = 1; w < WH_NW; ++w) sum += red[w][tx][lane][wave];
+                sums[tx] = sum;
+            }
+        }
+        if constexpr (DPNR > 0) {
+            if (!dp_reduce<DPNR, WH_TX>(a.dp, dp_tk, (int)blockIdx.x, wave < 4 ? t : -1, sums)) return;   // nothing applied; the word is up
+        }
+        if (wave < 4) {
             const float step = a.fw.p ? adam_dev_step(a.fw) : 0.f;
 #pragma unroll
             for (int tx = 0; tx < WH_TX; ++tx) {
                 const int col = col0 + tx * 16 + r16;
-                float sum = red[0][tx][lane][wave];
-#pragma unroll
-                for (int w = 1; w < WH_NW; ++w) sum += red[w][tx][lane][wave];
+                const float sum = sums[tx];
                 if (fcls < C && col < K) {
                     const long i = (long)fcls * K + col;
                     a.dw[i] = sum;
@@ -477,7 +499,17 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_grads_kernel(WideGradArgs a) 
     float(*cred)[16] = reinterpret_cast<float(*)[16]>(&red[0][0][0][0]);   // [64][16]
     if ((int)blockIdx.x == a.n_col) {
         const int64_t state0 = a.metrics ? a.state[0] : 0, state1 = a.metrics ? a.state[1] : 0;
-        const float dbs = slab_colsum16(a.dl, 16, B, 0, C, cred, t);          // tensor.rs:686-691
+        float dbs = slab_colsum16(a.dl, 16, B, 0, C, cred, t);          // tensor.rs:686-691
+        if constexpr (DPNR > 0) {
+            float pair[2] = {t < C ? dbs : 0.f, 0.f};
+            if (!dp_reduce<DPNR, 2>(a.dp, dp_tk, (int)blockIdx.x, t < 256 ? t : -1, pair)) {
+                // a peer's sums never came: nothing is applied, nothing is logged; this workgroup takes the step's tick back (optim.rs:84) --
+                // only when the exchange failed in THIS launch: behind a dead communicator the chain launch has not ticked
+                if (t == 0 && a.dp_tick && dp_tk.dead == 0u) atomicSub(a.dp_tick, 1);
+                return;
+            }
+            dbs = pair[0];
+        }
         if (t < C && a.db) {
             a.db[t] = dbs;
             if (a.fb.p) adam_update(a.fb.p, a.fb.m, a.fb.v, t, dbs, adam_dev_step(a.fb), a.fb.beta1, a.fb.beta2, a.fb.eps, a.fb.wd);
@@ -501,7 +533,12 @@ __global__ __launch_bounds__(64 * WH_NW) void wide_grads_kernel(WideGradArgs a) 
         return;
     }
     const int ch0 = ((int)blockIdx.x - a.n_col - 1) * 16;
-    const float cb = slab_colsum16(a.cbpart, a.conv_c, B, ch0, min(16, a.conv_c - ch0), cred, t);
+    float cb = slab_colsum16(a.cbpart, a.conv_c, B, ch0, min(16, a.conv_c - ch0), cred, t);
+    if constexpr (DPNR > 0) {
+        float pair[2] = {(t < 16 && ch0 + t < a.conv_c) ? cb : 0.f, 0.f};
+        if (!dp_reduce<DPNR, 2>(a.dp, dp_tk, (int)blockIdx.x, t < 256 ? t : -1, pair)) return;
+        cb = pair[0];
+    }
     if (t < 16 && ch0 + t < a.conv_c) {
         a.conv_gb[ch0 + t] = cb;
         if (a.fcb.p) adam_update(a.fcb.p, a.fcb.m, a.fcb.v, ch0 + t, cb, adam_dev_step(a.fcb), a.fcb.beta1, a.fcb.beta2, a.fcb.eps, a.fcb.wd);
@@ -567,10 +604,10 @@ extern "C" int th_debug_wide_prof(th_ctx *ctx, long long *h_out16) {
 }
 #endif
 
-extern "C" int th_wide_head_grads(th_ctx *ctx, const float *d_x, const float *d_dl, const float *d_rowstat, const float *d_cbpart, int batch,
-                                  int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss,
-                                  float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
-                                  const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse) {
+static int wide_grads_launch(th_comm *comm, th_ctx *ctx, const float *d_x, const float *d_dl, const float *d_rowstat, const float *d_cbpart, int batch,
+                             int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss,
+                             float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                             const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse, int32_t *d_tick) {
     TH_REQUIRE(ctx && d_x && d_dl && d_rowstat && d_dw && d_loss, "th_wide_head_grads: null argument");
     TH_REQUIRE(batch > 0 && in_features > 0 && classes > 0 && classes <= 16, "th_wide_head_grads: needs classes <= 16 (got %d)", classes);
     TH_REQUIRE(!d_metrics || (d_state && metrics_capacity > 0), "th_wide_head_grads: metrics need d_state and a capacity");
@@ -580,8 +617,58 @@ extern "C" int th_wide_head_grads(th_ctx *ctx, const float *d_x, const float *d_
     TH_REQUIRE(!(cb_fuse && cb_fuse->d_p) || d_conv_gb, "th_wide_head_grads: a fused conv bias update needs d_conv_gb");
     WideGradArgs a{d_x, d_dl, d_rowstat, d_cbpart, batch, in_features, classes, d_cbpart ? conv_c : 0, ceil_div(in_features, 16 * WH_TX),
                    d_dw, d_db, d_conv_gb, d_loss, d_ncorrect, d_metrics, metrics_capacity, d_state, advance,
-                   make_adam_dev(w_fuse), make_adam_dev(b_fuse), make_adam_dev(cb_fuse)};
-    hipLaunchKernelGGL(wide_grads_kernel, dim3(a.n_col + 1 + ceil_div(a.conv_c, 16)), dim3(64 * WH_NW), 0, ctx->stream, a);
+                   make_adam_dev(w_fuse), make_adam_dev(b_fuse), make_adam_dev(cb_fuse), DpDev{}, nullptr};
+    const int grid = a.n_col + 1 + ceil_div(a.conv_c, 16);
+    if (comm) {
+        const DpDev *dp = comm_dp_dev(comm);
+        TH_REQUIRE(dp && th_wide_head_grads_dp_supported(comm, ctx, batch, in_features, classes, conv_c),
+                   "th_wide_head_grads_dp: this communicator / shape cannot take the in-launch exchange (th_wide_head_grads_dp_supported)");
+        a.dp = *dp;
+        a.dp_tick = d_tick;
+        if (dp->n_ranks <= 2) hipLaunchKernelGGL(wide_grads_kernel<2>, dim3(grid), dim3(64 * WH_NW), 0, ctx->stream, a);
+        else if (dp->n_ranks <= 4) hipLaunchKernelGGL(wide_grads_kernel<4>, dim3(grid), dim3(64 * WH_NW), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(wide_grads_kernel<8>, dim3(grid), dim3(64 * WH_NW), 0, ctx->stream, a);
+        comm_dp_count_launch(comm);
+    } else {
+        hipLaunchKernelGGL(wide_grads_kernel<0>, dim3(grid), dim3(64 * WH_NW), 0, ctx->stream, a);
+    }
     TH_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int th_wide_head_grads(th_ctx *ctx, const float *d_x, const float *d_dl, const float *d_rowstat, const float *d_cbpart, int batch,
+                                  int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss,
+                                  float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                                  const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse) {
+    return wide_grads_launch(nullptr, ctx, d_x, d_dl, d_rowstat, d_cbpart, batch, in_features, classes, conv_c, d_dw, d_db, d_conv_gb, d_loss, d_ncorrect,
+                             d_metrics, metrics_capacity, d_state, advance, w_fuse, b_fuse, cb_fuse, nullptr);
+}
+
+// data parallel: the same launch with every finished sum reduced over the ranks before its store / Adam (csrc/dp_dev.h)
+extern "C" int th_wide_head_grads_dp_supported(const th_comm *comm, th_ctx *ctx, int batch, int in_features, int classes, int conv_c) {
+    const DpDev *dp = comm_dp_dev(comm);
+    if (!dp || !ctx || dp->n_ranks < 2 || batch <= 0 || in_features <= 0 || classes <= 0 || classes > 16 || WH_TX != 2) return 0;
+    const int grid = ceil_div(in_features, 16 * WH_TX) + 1 + ceil_div(conv_c, 16);
+    if (grid > DP_MAX_SLOTS) return 0;
+    const int sharing = comm_dp_sharing(comm);
+    if (sharing > comm_dp_sharing_limit()) return 0;
+    if (sharing > 1) {     // ranks on ONE device: the waiting workgroups of all the ranks but one must leave a place free (th_mlp_tail_dp_supported)
+        int per_cu = 0;
+        const void *fn = dp->n_ranks <= 2 ? (const void *)wide_grads_kernel<2> : dp->n_ranks <= 4 ? (const void *)wide_grads_kernel<4> : (const void *)wide_grads_kernel<8>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WH_NW, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        if ((long)(sharing - 1) * grid >= (long)per_cu * kNumCU) return 0;
+    }
+    return 1;
+}
+
+extern "C" int th_wide_head_grads_dp(th_comm *comm, th_ctx *ctx, const float *d_x, const float *d_dl, const float *d_rowstat, const float *d_cbpart,
+                                     int batch, int in_features, int classes, int conv_c, float *d_dw, float *d_db, float *d_conv_gb, float *d_loss,
+                                     float *d_ncorrect, float *d_metrics, int64_t metrics_capacity, int64_t *d_state, int64_t advance,
+                                     const th_adam_fuse *w_fuse, const th_adam_fuse *b_fuse, const th_adam_fuse *cb_fuse, int32_t *d_tick) {
+    TH_REQUIRE(comm, "th_wide_head_grads_dp: null communicator");
+    return wide_grads_launch(comm, ctx, d_x, d_dl, d_rowstat, d_cbpart, batch, in_features, classes, conv_c, d_dw, d_db, d_conv_gb, d_loss, d_ncorrect,
+                             d_metrics, metrics_capacity, d_state, advance, w_fuse, b_fuse, cb_fuse, d_tick);
 }
