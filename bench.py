@@ -115,7 +115,7 @@ def make_comm(rdzv, T, backend, optimizer, shared_device=False):
     return comm, "rccl ncclAllReduce(avg)" + why
 
 
-def dp_on_device(T, key, lr, ds, per_gpu_batch=128, steps=4000, rounds=3):
+def dp_on_device(T, key, lr, ds, per_gpu_batch=128, steps=4000, rounds=3, sample_shape=None):
     """N = 1: what the data-parallel step of BASELINE configs[3] (128 rows per GPU) costs ON the device, before a link is crossed.  Four
     Trainers on the same rows, timed alternately (min of `rounds`):
       single      no communicator: the two-launch step of one GPU
@@ -135,7 +135,7 @@ def dp_on_device(T, key, lr, ds, per_gpu_batch=128, steps=4000, rounds=3):
             c.connect(c.export_arena(o))
             if kind == "three_launch":
                 c.set_inkernel(False)
-        t = T.Trainer(m, o, comm=c)
+        t = T.Trainer(m, o, comm=c, **({"sample_shape": sample_shape} if sample_shape else {}))
         l = T.DataLoader(ds, per_gpu_batch, False)
         run_steps(T, t, l, 300)
         _KEEP_ALIVE.append((t, o, m, l, c))
@@ -160,7 +160,8 @@ def dp_on_device(T, key, lr, ds, per_gpu_batch=128, steps=4000, rounds=3):
                one_rank_ceiling=round(best["single"] / best["one_rank"], 4),
                three_launch_ceiling=round(best["single"] / best["three_launch"], 4),
                loopback_inkernel_launches=lb.inkernel_launches(), loopback_timed_out=lb.timed_out(),
-               note="one device: flags and slices go through local memory; a link adds its latency per exchange and 0.4 MB per peer of transfer")
+               note="one device: every word of the exchange goes through local memory; a link adds its latency per exchange and the gradient arena "
+                    "(0.4 MB for the MLP, 0.2 MB for the simple CNN) per peer of transfer")
     return out
 
 
@@ -841,6 +842,13 @@ def extra_workloads(T, dataset, with_cpu, only=None):
                     rec["batch_sweep"] = cnn_batch_sweep(T, key, sample_shape, lr, dataset)
                 except Exception as e:
                     rec["batch_sweep"] = dict(error=str(e))
+                if key == "cnn_simple":
+                    # the data-parallel step of this model on the device (th_wide_head_grads_dp: the exchange inside the batch-sums launch), as
+                    # dp_on_device measures the MLP's: 128 images per GPU
+                    try:
+                        rec["data_parallel"] = dp_on_device(T, key, lr, dataset, steps=1500, sample_shape=sample_shape)
+                    except Exception as e:
+                        rec["data_parallel"] = dict(error=str(e))
                 # the same model with every conv weight training (full_backward: an extension -- the reference cuts the tape at im2col /
                 # transpose_4d, quirk Q2 -- through the layer-by-layer forward and the conv backward kernels)
                 try:
