@@ -212,6 +212,60 @@ __global__ __launch_bounds__(64 * NW) void sgemm_small16_tick(SmallArgs p, AdamS
 
 // second pass of grid-level split-K: fixed slice order -> deterministic.  With ep.adam set, C is a
 // complete gradient and the parameter's Adam update (optim.rs:99-110) runs on the same element.
+// (the slabs are summed in slice order whatever the instance: same bits)
+__global__ __launch_bounds__(256) void splitk_reduce4(const float *__restrict__ partial, float *__restrict__ C, long mn, int n, int kz, Epilogue ep) {
+    // four neighbouring elements per thread, 16-byte loads, eight slabs requested together: the scalar form below spent 11 us on the 28 MB of
+    // a 784 x 256 gradient's 36 slabs (2.6 TB/s)
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= mn) return;
+    const bool fuse = ep.adam.p != nullptr;
+    float4 pv = {0.f, 0.f, 0.f, 0.f}, mv = pv, vv = pv, c_old = pv;
+    float step = 0.f;
+    if (fuse) {
+        pv = *reinterpret_cast<const float4 *>(ep.adam.p + i);
+        mv = *reinterpret_cast<const float4 *>(ep.adam.m + i);
+        vv = *reinterpret_cast<const float4 *>(ep.adam.v + i);
+        step = adam_dev_step(ep.adam);
+    }
+    if (ep.beta != 0.0f) c_old = *reinterpret_cast<const float4 *>(C + i);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    int z = 0;
+    for (; z + U <= kz; z += U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4 *>(partial + (long)(z + u) * mn + i);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
+        }
+    }
+    for (; z < kz; ++z) {
+        const float4 v = *reinterpret_cast<const float4 *>(partial + (long)z * mn + i);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+    const float co[4] = {c_old.x, c_old.y, c_old.z, c_old.w};
+    float out[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = epilogue_apply(s[e], co[e], ep, (int)((i + e) % n));
+    *reinterpret_cast<float4 *>(C + i) = make_float4(out[0], out[1], out[2], out[3]);
+    if (fuse) {
+        const AdamDev &ad = ep.adam;
+        const float p4[4] = {pv.x, pv.y, pv.z, pv.w}, m4[4] = {mv.x, mv.y, mv.z, mv.w}, v4[4] = {vv.x, vv.y, vv.z, vv.w};
+        float pn[4], mo[4], vo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gv = out[e] + ad.wd * p4[e];
+            mo[e] = ad.beta1 * m4[e] + (1.0f - ad.beta1) * gv;
+            vo[e] = ad.beta2 * v4[e] + (1.0f - ad.beta2) * gv * gv;
+            pn[e] = p4[e] - step * mo[e] / (sqrtf(vo[e]) + ad.eps);
+        }
+        *reinterpret_cast<float4 *>(ad.m + i) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+        *reinterpret_cast<float4 *>(ad.v + i) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+        *reinterpret_cast<float4 *>(ad.p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ partial, float *__restrict__ C,
                                                      long mn, int n, int kz, Epilogue ep) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -238,6 +292,15 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float *__restrict__ p
         ad.v[i] = vn;
         ad.p[i] = pv - step * mn_ / (sqrtf(vn) + ad.eps);
     }
+}
+
+static inline bool aligned16p(const void *p) { return ((uintptr_t)p & 15) == 0; }
+// the reduce pass: four elements per thread where every pointer and the slab stride allow 16-byte accesses
+static inline void launch_splitk_reduce(hipStream_t stream, const float *partial, float *C, long mn, int n, int kz, const Epilogue &ep) {
+    const bool quad = mn % 4 == 0 && aligned16p(partial) && aligned16p(C) && !ep.mask && !ep.colpart &&
+                      (!ep.adam.p || (aligned16p(ep.adam.p) && aligned16p(ep.adam.m) && aligned16p(ep.adam.v)));
+    if (quad) hipLaunchKernelGGL(splitk_reduce4, dim3(ceil_div(mn / 4, 256)), dim3(256), 0, stream, partial, C, mn, n, kz, ep);
+    else hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, stream, partial, C, mn, n, kz, ep);
 }
 
 // Whole backward of one (small) Linear layer in ONE launch (the reference runs
@@ -586,8 +649,26 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
     // in that XCD's L2).  Bijective for any grid size.
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
-    const int xcd = bid % kNumXCD, q = nwg / kNumXCD, rmd = nwg % kNumXCD;
-    const int tile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + bid / kNumXCD;
+    int tile, zslice = 0;
+    const bool slice_xcd = raster >= 0x100;      // (the host's choice rides on the raster argument: sgemm_tile128)
+    raster = raster >= 0x100 ? raster - 0x100 : raster;
+    if (gridDim.y == 1 || !slice_xcd) {
+        const int xcd = bid % kNumXCD, q = nwg / kNumXCD, rmd = nwg % kNumXCD;
+        tile = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + bid / kNumXCD;
+        zslice = blockIdx.y;
+    } else {
+        // K slices (grid.y > 1): the launch's workgroups are handed to the XCDs in LINEAR order, x fastest -- the tiles of ONE slice would
+        // land on 8 different L2s and each would fetch the slice's rows of A and B for itself (TN 784 x 256 x 16 384, 14 tiles x 36 slices:
+        // 188 MB through the fabric for 68 MB of operands).  Give every XCD a contiguous run of (slice, tile) pairs instead: the tiles of a
+        // slice run on one XCD, at the same time, and its rows are fetched once: 77 MB, 82.1 -> 79.2 us.  (Slices of fewer than 14 chunks keep
+        // the order above -- the host's choice, sgemm_tile128: 14 workgroups asking one L2 for the same rows at once cost more than the second
+        // fetch saves -- 784 x 256 x 4 096: 32.9 -> 35.6 us, x 8 192: 57.8 -> 60.1.)
+        const int total = nwg * (int)gridDim.y, lin = bid + nwg * (int)blockIdx.y;
+        const int xcd = lin % kNumXCD, q = total / kNumXCD, rmd = total % kNumXCD;
+        const int s = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + lin / kNumXCD;
+        zslice = s / nwg;
+        tile = s - zslice * nwg;
+    }
     // Within the list the tiles come in GROUPS of 8 tile rows, column-major inside a group: the 64 tiles an XCD has in flight (32 CUs x 2
     // workgroups) then form an 8 x 8 block -- every A / B panel it fetches into its L2 serves 8 tiles -- instead of two whole columns of
     // tiles_m rows, where each A panel served 2 (4096^3 NT: 2.2 GB through the fabric for 0.2 GB of operands).  raster < 0: the r02 order.
@@ -604,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #ifdef TH_PROFILE
-    if (bid == 0 && blockIdx.y == 0 && t == 0) { g_gemm_prof[0] = wall_clock64(); g_gemm_prof[1] = clock64(); }
+    if (bid == 0 && zslice == 0 && t == 0) { g_gemm_prof[0] = wall_clock64(); g_gemm_prof[1] = clock64(); }
 #endif
     const int wm = (wave >> 1) * WS, wn = (wave & 1) * WS;  // wave's WS x WS sub-tile
     const int li = lane & 31, lk = lane >> 5;
@@ -621,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
     // ragged shapes go through registers (clamped loads, zero fill) into the same images
     constexpr bool A_DMA = !GUARD, B_DMA = !GUARD;
     float4 ra[A_DMA ? 1 : R], rb[B_DMA ? 1 : R];
-    const int kbeg = blockIdx.y * kslice, kend = min(k, kbeg + kslice);
+    const int kbeg = zslice * kslice, kend = min(k, kbeg + kslice);
     const int nt = (kend - kbeg + BK - 1) / BK;
     DmaPlan<TS> pa{}, pb{};
     if constexpr (A_DMA) pa = dma_plan<TS, A_KC>(A_KC ? a_rs : a_cs, lane, wave);
@@ -735,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
     }
 
 #ifdef TH_PROFILE
-    if (bid == 0 && blockIdx.y == 0 && t == 0) { g_gemm_prof[2] = wall_clock64(); g_gemm_prof[3] = clock64(); }
+    if (bid == 0 && zslice == 0 && t == 0) { g_gemm_prof[2] = wall_clock64(); g_gemm_prof[3] = clock64(); }
 #endif
     // epilogue.  C/D map of 32x32x2: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
     const bool masked = DXEP && ep.mask != nullptr && !partial;
@@ -777,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_tile(const float *__restrict__ A
                 if (!(GUARD || RAG) || (row < m && col < n)) {
                     const long idx = (long)row * n + col;
                     if (partial) {
-                        partial[(long)blockIdx.y * m * n + idx] = acc[i][j][e];
+                        partial[(long)zslice * m * n + idx] = acc[i][j][e];
                         continue;
                     }
                     const float c_old = ep.beta != 0.0f ? C[idx] : 0.0f;
@@ -854,8 +935,7 @@ static int launch_small(th_ctx *ctx, const float *A, const float *B, float *C, i
     TH_LAUNCH_CHECK();
     if (kz > 1) {
         const long mn = (long)m * n;
-        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, ctx->stream, (const float *)p.partial, C, mn, n,
-                           kz, ep);
+        launch_splitk_reduce(ctx->stream, (const float *)p.partial, C, mn, n, kz, ep);
         TH_LAUNCH_CHECK();
         if (th_free(ctx, p.partial)) return 1;
     }
@@ -935,7 +1015,10 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
         }
     }
     // tile order: groups of 8 tile rows (TAPER_GEMM_RASTER = n: groups of n; 0: r02's whole columns)
-    static const int raster = [] { const char *e = getenv("TAPER_GEMM_RASTER"); return e ? atoi(e) : 8; }();
+    static const int raster0 = [] { const char *e = getenv("TAPER_GEMM_RASTER"); return e ? atoi(e) : 8; }();
+    // K slices of at least this many chunks are handed to the XCDs slice by slice (sgemm_tile; TAPER_GEMM_SLICE_XCD_CHUNKS, 0 = always, large = never)
+    static const int slice_xcd_chunks = [] { const char *e = getenv("TAPER_GEMM_SLICE_XCD_CHUNKS"); return e ? atoi(e) : 14; }();
+    const int raster = raster0 + ((raster0 >= 0 && kz > 1 && kslice >= slice_xcd_chunks * BK) ? 0x100 : 0);
     if (ep.mask || ep.colpart) {     // the dX product with the backward of the layer in front in its epilogue (th_linear_bwd_adam_ex2: unsplit by its predicate)
         if (kz != 1) { th::set_error("sgemm_tile: the masked epilogue needs an unsplit product"); return 2; }
         if (exact) {
@@ -970,7 +1053,7 @@ static int launch_tile(th_ctx *ctx, const float *A, const float *B, float *C, in
     TH_LAUNCH_CHECK();
     if (kz > 1) {
         const long mn = (long)m * n;
-        hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, ctx->stream, (const float *)partial, C, mn, n, kz, ep);
+        launch_splitk_reduce(ctx->stream, (const float *)partial, C, mn, n, kz, ep);
         TH_LAUNCH_CHECK();
         if (th_free(ctx, partial)) return 1;
     } else if (ep.adam.p) {
@@ -1357,8 +1440,7 @@ int th_linear_bwd_adam_ex2(th_ctx *ctx, const float *d_x, const float *d_w, cons
             Epilogue ep = make_ep(1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f);
             ep.adam = w_adam;
             const long mn = (long)out_features * in_features;
-            hipLaunchKernelGGL(splitk_reduce, dim3(ceil_div(mn, 256)), dim3(256), 0, ctx->stream, (const float *)dw_part, d_dw, mn,
-                               in_features, dw_kz, ep);
+            launch_splitk_reduce(ctx->stream, (const float *)dw_part, d_dw, mn, in_features, dw_kz, ep);
             TH_LAUNCH_CHECK();
             return th_free(ctx, dw_part);
         }
