@@ -89,3 +89,41 @@ def test_shapes_the_exchange_does_not_cover_take_the_three_launch_step():
     assert not comm.tail_exchange_ok(1024, 784, 128, 10)     # th_mlp2_xent's territory
     comm.set_inkernel(False)
     assert not comm.tail_exchange_ok(64, 784, 128, 10)
+
+
+def _simple_cnn(T):
+    C = lambda i, o, s: T.Conv2dReLU(i, o, (3, 3), (1, 1), (1, 1), None, None, True, seed=s)
+    return T.Sequential([C(1, 32, 1), T.MaxPool2d((2, 2), (2, 2)), C(32, 64, 2), T.MaxPool2d((2, 2), (2, 2)), T.Flatten(1),
+                         T.Linear(3136, 10, True, 3)])
+
+
+def _train_cnn(T, batch, steps, comm_kind):
+    model = _simple_cnn(T)
+    opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
+    comm = T.Communicator.loopback() if comm_kind == "loopback" else None
+    tr = T.Trainer(model, opt, comm=comm, sample_shape=(1, 28, 28))
+    x, y = _data(batch * steps, seed=9)
+    loader = T.DataLoader(T.MNISTDataset.from_host(x, y), batch, False)
+    losses = np.concatenate([tr.run_epoch(loader, T.Trainer.GRAPH)["losses"] for _ in range(2)])
+    return losses, [p.data() for p in model.parameters()], opt.t(), opt.moments()[0], opt.moments()[1], comm
+
+
+@pytest.mark.parametrize("batch", [96, 128, 256, 1024])
+def test_loopback_simple_cnn_step_is_the_single_gpu_step_bit_for_bit(batch):
+    """the simple CNN (BASELINE configs[2]'s model): th_wide_head_grads_dp through a loopback communicator -- the batch-sums launch pushes,
+    polls, adds and resets every one of its 103 slices -- must give the single-GPU step's bits: losses, every parameter, Adam's moments
+    and counter (1 024 images: the chain launch is the two-to-a-CU instance)"""
+    import taper_amd as T
+    steps = 4
+    ref = _train_cnn(T, batch, steps, None)
+    got = _train_cnn(T, batch, steps, "loopback")
+    comm = got[5]
+    assert comm.inkernel_launches() >= steps, comm.inkernel_launches()
+    assert not comm.timed_out()
+    assert comm.stats()["fused"] == 0 and comm.stats()["inplace"] == 0      # no all-reduce launch ran
+    np.testing.assert_array_equal(got[0], ref[0])
+    for a, b in zip(got[1], ref[1]):
+        np.testing.assert_array_equal(a, b)
+    assert got[2] == ref[2] == 2 * steps
+    np.testing.assert_array_equal(got[3], ref[3])
+    np.testing.assert_array_equal(got[4], ref[4])

@@ -336,37 +336,38 @@ def test_two_ranks_of_512_rows_repeat_bit_identical_beside_hbm_traffic(tmp_path,
 
 
 # ------------------------------------------------------------------------------------------------------------------ two ranks x 128 rows, exchange in the gradient launch
-def test_two_ranks_exchanging_inside_the_gradient_launch_repeat_bit_identical_beside_hbm_traffic(tmp_path, traffic):
-    """th_mlp_tail_dp's hand-off (csrc/dp_dev.h): every value a workgroup pushes to its peer is its own arrival flag (an empty word is all
+@pytest.mark.parametrize("model,steps,n_params", [("mlp_baseline", 12, 4), ("cnn_simple", 5, 6)])
+def test_two_ranks_exchanging_inside_the_gradient_launch_repeat_bit_identical_beside_hbm_traffic(tmp_path, traffic, model, steps, n_params):
+    """th_mlp_tail_dp's (and, for the simple CNN, th_wide_head_grads_dp's) hand-off (csrc/dp_dev.h): every value a workgroup pushes to its peer is its own arrival flag (an empty word is all
     ones), the peer resets what it has read, and the halves of the receive region alternate with a step number the launch in front
     advances.  4 FRESH pairs of processes beside two HBM-streaming processes, each pair running the two-epoch optimisation (2 x 12 steps
     of 128 rows per rank: BASELINE configs[3]'s shard) 3 times over from the same start -- captured graphs, communicator and its step
     number kept, parameters / moments / t restored: every run of every pair gives the same losses and weights bit for bit, the replicas
     are identical, and the first run equals one process on the 256-row batches (the DP test's own check)."""
     from tests.test_gpu_dp import _check, _run_ranks
-    pairs, runs, steps, gb = 4, 3, 12, 256
+    pairs, runs, gb = 4, 3, 256
     os.environ["TAPER_DP_REPEAT"] = str(runs)
     try:
         first = None
         for pair in range(pairs):
             d = tmp_path / f"pair{pair}"
             d.mkdir()
-            ranks = _run_ranks(d, 2, "p2p", "graph", steps=steps, global_batch=gb, same_device=True)
+            ranks = _run_ranks(d, 2, "p2p", "graph", steps=steps, global_batch=gb, same_device=True, model=model)
             for r in range(2):
                 assert int(ranks[r]["launches_inkernel"]) >= steps                      # the exchange ran inside the gradient launch
                 same, diff = np.asarray(ranks[r]["runs_same"]), np.asarray(ranks[r]["runs_maxdiff"])
-                assert same.shape == (runs, 5)
+                assert same.shape == (runs, 1 + n_params)
                 bad = np.nonzero(~same.all(axis=1))[0]
                 assert bad.size == 0, f"pair {pair} rank {r}: runs {bad.tolist()} differ from its first (max |diff| per run [losses, p0..p3]: {diff[bad].tolist()})"
-            for i in range(4):
+            for i in range(n_params):
                 np.testing.assert_array_equal(ranks[0][f"p{i}"], ranks[1][f"p{i}"], err_msg=f"pair {pair}: replicas diverged in param {i}")
             if first is None:
                 first = ranks
-                _check(ranks, 2, steps, gb)
+                _check(ranks, 2, steps, gb, model=model)
                 continue
             for r in range(2):
                 np.testing.assert_array_equal(ranks[r]["losses"], first[r]["losses"], err_msg=f"pair {pair} rank {r}: losses differ from the first pair's")
-            for i in range(4):
+            for i in range(n_params):
                 np.testing.assert_array_equal(ranks[0][f"p{i}"], first[0][f"p{i}"], err_msg=f"pair {pair}: param {i} differs from the first pair's")
     finally:
         del os.environ["TAPER_DP_REPEAT"]
