@@ -842,7 +842,7 @@ def extra_workloads(T, dataset, with_cpu, only=None):
                     rec["batch_sweep"] = cnn_batch_sweep(T, key, sample_shape, lr, dataset)
                 except Exception as e:
                     rec["batch_sweep"] = dict(error=str(e))
-                if key == "cnn_simple":
+                if key == "cnn_simple" and os.environ.get("TAPER_NO_GRAPH") != "1":      # (not under rocprofv3: its trace is of the batch-256 step)
                     # the data-parallel step of this model on the device (th_wide_head_grads_dp: the exchange inside the batch-sums launch), as
                     # dp_on_device measures the MLP's: 128 images per GPU
                     try:
