@@ -1892,8 +1892,10 @@ int th_conv_chain_mlp3_xent(th_ctx *ctx, const float *d_x, const th_conv_stage *
     const int out_f[3] = {h1, h2, c}, in_f[3] = {128, h1, h2};
     const th_adam_fuse *wf[3] = {layers[0].w_fuse, layers[1].w_fuse, layers[2].w_fuse}, *bf[3] = {layers[0].b_fuse, layers[1].b_fuse, layers[2].b_fuse};
     if (int rc = th::mlp3_grads_launch(ctx, dz, act, dw, db, out_f, in_f, wf, bf, n, part, n, d_loss, d_ncorrect, d_metrics, metrics_capacity, d_state,
-                                       advance, d_dx, gap))
+                                       advance, d_dx, gap)) {
+        (void)th_free(ctx, ws);         // (error paths give their workspace back: ADVICE r05)
         return rc;
+    }
     return th_free(ctx, ws);
 }
 

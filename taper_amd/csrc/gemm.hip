@@ -1378,7 +1378,10 @@ int th_linear_bwd_adam_ex2(th_ctx *ctx, const float *d_x, const float *d_w, cons
         if (d_relu_y) {
             const size_t nz = (size_t)batch * out_features;
             if (th_malloc(ctx, nz * sizeof(float), &tmpz)) return 1;
-            if (int rc = th_relu_bwd(ctx, d_relu_y, d_dy, (float *)tmpz, nz, 0)) return rc;
+            if (int rc = th_relu_bwd(ctx, d_relu_y, d_dy, (float *)tmpz, nz, 0)) {
+                (void)th_free(ctx, tmpz);       // (error paths give their workspace back: ADVICE r05)
+                return rc;
+            }
             dzt = (const float *)tmpz;
         }
         hipLaunchKernelGGL(th::linear_dx_thin_kernel, dim3(ceil_div(in_features, 1024), ceil_div(batch, th::THIN_ROWS)), dim3(256), 0, ctx->stream, dzt,
@@ -1453,29 +1456,38 @@ int th_linear_bwd_adam_ex2(th_ctx *ctx, const float *d_x, const float *d_w, cons
     if (d_relu_y) {
         const size_t n = (size_t)batch * out_features;
         if (th_malloc(ctx, n * sizeof(float), &tmp)) return 1;
-        if (int rc = th_relu_bwd(ctx, d_relu_y, d_dy, (float *)tmp, n, 0)) return rc;
-        dz = (const float *)tmp;
     }
-    if (d_dx) {  // dX[B,in] (+)= dZ[B,out] . W[out,in]      (ops.rs:254-265 through the W^T node)
-        Epilogue ep = make_ep(1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f);
-        ep.mask = mask_dx ? d_x : nullptr;      // (ep_rows > 0: this product takes sgemm_tile<128> unsplit)
-        ep.colpart = d_dx_colpart;
-        if (int rc = gemm_dispatch(ctx, 0, 0, batch, in_features, out_features, dz, d_w, d_dx, ep)) return rc;
+    // (one exit: a failing launch gives the mask's workspace back -- ADVICE r05)
+    const int rc = [&]() -> int {
+        if (tmp) {
+            if (int rc = th_relu_bwd(ctx, d_relu_y, d_dy, (float *)tmp, (size_t)batch * out_features, 0)) return rc;
+            dz = (const float *)tmp;
+        }
+        if (d_dx) {  // dX[B,in] (+)= dZ[B,out] . W[out,in]      (ops.rs:254-265 through the W^T node)
+            Epilogue ep = make_ep(1.0f, (accumulate_mask & 1) ? 1.0f : 0.0f);
+            ep.mask = mask_dx ? d_x : nullptr;      // (ep_rows > 0: this product takes sgemm_tile<128> unsplit)
+            ep.colpart = d_dx_colpart;
+            if (int rc = gemm_dispatch(ctx, 0, 0, batch, in_features, out_features, dz, d_w, d_dx, ep)) return rc;
+        }
+        if (d_dw) {  // dW[out,in] (+)= dZ^T[out,B] . X[B,in]     (ops.rs:280-291 + tensor.rs:574-587)
+            Epilogue ep = make_ep(1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f);
+            ep.adam = w_adam;   // the dX product above has already consumed W (same stream): update it with the gradient
+            if (int rc = gemm_dispatch(ctx, 1, 0, out_features, in_features, batch, dz, d_x, d_dw, ep)) return rc;
+        }
+        if (d_db) {  // db[out] (+)= sum_b dZ[b,out]               (tensor.rs:686-691)
+            if (int rc = (accumulate_mask & 4) ? th_colsum_accum(ctx, dz, d_db, batch, out_features)
+                                               : th_colsum(ctx, dz, d_db, batch, out_features))
+                return rc;
+        }
+        // large shapes: W's update rode in the dW product; the bias update runs as a slice kernel
+        if (int rc = adam_slice(ctx, b_adam, d_db, out_features)) return rc;
+        return th_adam_slices(ctx, extra, n_extra);
+    }();
+    if (tmp) {
+        const int rf = th_free(ctx, tmp);
+        return rc ? rc : rf;
     }
-    if (d_dw) {  // dW[out,in] (+)= dZ^T[out,B] . X[B,in]     (ops.rs:280-291 + tensor.rs:574-587)
-        Epilogue ep = make_ep(1.0f, (accumulate_mask & 2) ? 1.0f : 0.0f);
-        ep.adam = w_adam;   // the dX product above has already consumed W (same stream): update it with the gradient
-        if (int rc = gemm_dispatch(ctx, 1, 0, out_features, in_features, batch, dz, d_x, d_dw, ep)) return rc;
-    }
-    if (d_db) {  // db[out] (+)= sum_b dZ[b,out]               (tensor.rs:686-691)
-        if (int rc = (accumulate_mask & 4) ? th_colsum_accum(ctx, dz, d_db, batch, out_features)
-                                           : th_colsum(ctx, dz, d_db, batch, out_features))
-            return rc;
-    }
-    // large shapes: W's update rode in the dW product; the bias update runs as a slice kernel
-    if (int rc = adam_slice(ctx, b_adam, d_db, out_features)) return rc;
-    if (int rc = th_adam_slices(ctx, extra, n_extra)) return rc;
-    return tmp ? th_free(ctx, tmp) : 0;
+    return rc;
 }
 
 }  // extern "C"

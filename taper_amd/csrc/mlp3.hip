@@ -372,8 +372,10 @@ int th_mlp3_xent(th_ctx *ctx, const float *d_x, const float *d_targets, int batc
     const int out_f[3] = {h1, h2, c}, in_f[3] = {in_features, h1, h2};
     const th_adam_fuse *wf[3] = {layers[0].w_fuse, layers[1].w_fuse, layers[2].w_fuse}, *bf[3] = {layers[0].b_fuse, layers[1].b_fuse, layers[2].b_fuse};
     if (int rc = mlp3_grads_launch(ctx, dz, act, dw, db, out_f, in_f, wf, bf, batch, part, n_blk, d_loss, d_ncorrect, d_metrics, metrics_capacity,
-                                   d_state, advance, d_dx, gap))
+                                   d_state, advance, d_dx, gap)) {
+        (void)th_free(ctx, ws);
         return rc;
+    }
     ++t_mlp3_calls;
     return th_free(ctx, ws);
 }
