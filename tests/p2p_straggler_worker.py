@@ -20,7 +20,13 @@ from taper_amd.dist import FileRendezvous, init_data_parallel  # noqa: E402
 
 T.Device.set_device(0)
 rdzv = FileRendezvous(rank, world, key=os.environ["TAPER_DP_KEY"], root=str(out), timeout_s=60)
-model = T.Sequential([T.Linear(784, 128, True, seed=1), T.ReLU(), T.Linear(128, 10, True, seed=2)])
+form = os.environ.get("TAPER_STRAGGLER_FORM", "fused")
+if form == "inkernel_cnn":     # the simple CNN: the exchange inside its batch-sums launch (th_wide_head_grads_dp)
+    Cv = lambda i, o, s: T.Conv2dReLU(i, o, (3, 3), (1, 1), (1, 1), None, None, True, seed=s)
+    model = T.Sequential([Cv(1, 32, 1), T.MaxPool2d((2, 2), (2, 2)), Cv(32, 64, 2), T.MaxPool2d((2, 2), (2, 2)), T.Flatten(1),
+                          T.Linear(3136, 10, True, 3)])
+else:
+    model = T.Sequential([T.Linear(784, 128, True, seed=1), T.ReLU(), T.Linear(128, 10, True, seed=2)])
 opt = T.Adam(model.parameters(), 1e-3, None, None, 1e-4)
 comm = init_data_parallel(T, rdzv, backend="p2p", optimizer=opt)      # includes the collective self-check: both ranks take part
 assert not comm.timed_out()
@@ -30,20 +36,22 @@ if rank == 0:
     comm.set_timeout_ms(3000)
     if os.environ.get("TAPER_STRAGGLER_FORM") == "inplace":
         comm.set_fuse_adam(False)       # in-place all-reduce, then Adam::step -- guarded by the communicator's error word
-    tr = T.Trainer(model, opt, comm=comm)
+    cnn = form == "inkernel_cnn"
+    rows = 128 if cnn else 64
+    tr = T.Trainer(model, opt, comm=comm, **({"sample_shape": (1, 28, 28)} if cnn else {}))
     rng = np.random.default_rng(0)
-    x = rng.uniform(0, 1, (64, 784)).astype(np.float32)
-    y = rng.integers(0, 10, 64).astype(np.float32)
+    x = rng.uniform(0, 1, (rows, 784)).astype(np.float32)
+    y = rng.integers(0, 10, rows).astype(np.float32)
     before = [p.data() for p in model.parameters()]
     raised = []
-    inkernel = os.environ.get("TAPER_STRAGGLER_FORM") == "inkernel"
+    inkernel = form in ("inkernel", "inkernel_cnn")
     if inkernel:
         # the exchange inside the gradient launch (th_mlp_tail_dp), as an epoch of captured steps runs it: the first step's workgroups all
         # give up after the bound and the lead takes the tick back; every later launch of the epoch -- the next steps' first launches with
         # their deferred updates and ticks, the gradient launches, the final flush -- finds the word up and does nothing
         x4, y4 = np.tile(x, (4, 1)), np.tile(y, 4)
-        loader = T.DataLoader(T.MNISTDataset.from_host(x4, y4), 64, False)
-        assert comm.tail_exchange_ok(64, 784, 128, 10)
+        loader = T.DataLoader(T.MNISTDataset.from_host(x4, y4), rows, False)
+        assert cnn or comm.tail_exchange_ok(64, 784, 128, 10)
     for _ in range(2):
         try:
             if inkernel:

@@ -327,7 +327,7 @@ def test_bench_eight_ranks_is_global_batch_1024():
     assert d["roofline"]["kernel"].startswith("p2p_allreduce_adam")
 
 
-@pytest.mark.parametrize("form", ["fused", "inplace", "inkernel"])
+@pytest.mark.parametrize("form", ["fused", "inplace", "inkernel", "inkernel_cnn"])
 def test_p2p_missing_peer_times_out_instead_of_hanging(tmp_path, form):
     """a peer that never launches its side of the all-reduce: the waiting rank's kernel gives up after its wall-clock-bounded spin and the
     communicator reports it -- no GPU hang -- and NOTHING was applied, in both forms: the fused all-reduce + Adam launch skips its update,
