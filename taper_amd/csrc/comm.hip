@@ -69,15 +69,27 @@ struct th_comm {
 namespace th {
 const DpDev *comm_dp_dev(const th_comm *c) { return (c && c->p2p && c->connected) ? &c->dp : nullptr; }
 int comm_dp_sharing(const th_comm *c) { return c ? c->sharing : 1; }
-// Ranks that SHARE a device (a test box; a deployment runs one rank per GPU) wait in each other's way: a waiting workgroup holds its place,
-// and the late rank still has to get the launches IN FRONT of its exchange launch dispatched.  Two ranks per device never starved one another
-// (r06: hundreds of steps, either model); with three, the late rank's first launch had 6 of its 33 1024-thread workgroups not dispatched
-// until the other two ranks' 208 waiting workgroups gave up -- 10 of 20 runs (profiles/r06_dp_three_ranks_one_device.txt; four and five
-// ranks finished 40 of 40, which is not an explanation).  So: in-launch exchange for at most two ranks per device; more take the
-// three-launch form.  TAPER_DP_SHARED_RANKS raises the bound (the four-rank protocol tests do).
-int comm_dp_sharing_limit() {
-    static const int lim = [] { const char *e = std::getenv("TAPER_DP_SHARED_RANKS"); return e ? std::max(1, atoi(e)) : 2; }();
-    return lim;
+// Ranks that SHARE a device (a test box; a deployment runs one rank per GPU) wait in each other's way: a workgroup that waits for a peer's
+// slice holds its place, and the rank that is behind still has to get the launches IN FRONT of its exchange launch dispatched.  Two conditions:
+//   places   (ranks on the device - 1) x grid < occupancy x CUs: the late rank's own exchange workgroups always find a place, so they
+//            never wait for anybody who is not already resident and the wait graph has no cycle (necessary);
+//   engines  (ranks on the device - 1) x ceil(grid / 32) <= 7: measured on gfx950 (r06, device-side placement trace,
+//            profiles/r06_dp_three_ranks_one_device.txt) -- a launch's workgroups are dealt to an XCD's four shader engines (8 CUs each) in
+//            strict rotation, one waiting workgroup per CU, and a launch whose next workgroup is a whole-CU one (the MLP's first launch: 1 024
+//            threads; the conv chain) STALLS, in order, when the engine whose turn it is has no free CU.  One waiting rank leaves every
+//            engine 1 - 2 free CUs (its own workgroups were dealt evenly); two ranks of 13 - 14 workgroups per XCD each fill an engine
+//            (4 + 4) in half the runs, and the late rank's first launch then never finishes: all three time out.  The bound keeps one CU
+//            free in every engine, counting every waiting workgroup as a whole CU.
+// TAPER_DP_SHARED_RULE=places drops the second condition (the four-rank protocol test: its waiting workgroups are small enough to share
+// CUs with the first launch's, 48 of 48 runs).
+bool comm_dp_shared_fits(const th_comm *c, int grid, int per_cu) {
+    const int sharing = c ? c->sharing : 1;
+    if (sharing <= 1) return true;
+    if ((long)(sharing - 1) * grid >= (long)per_cu * kNumCU) return false;
+    static const bool places_only = [] { const char *e = std::getenv("TAPER_DP_SHARED_RULE"); return e && std::strcmp(e, "places") == 0; }();
+    if (places_only) return true;
+    constexpr int kEngines = kNumXCD * 4, kCUsPerEngine = kNumCU / kEngines;
+    return (long)(sharing - 1) * ((grid + kEngines - 1) / kEngines) <= kCUsPerEngine - 1;
 }
 void comm_dp_count_launch(th_comm *c) { if (c) ++c->launches_inkernel; }
 }

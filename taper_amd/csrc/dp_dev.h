@@ -280,7 +280,7 @@ __device__ __forceinline__ bool dp_reduce(const DpDev &c, const DpTicket &tk, in
 // this rank's device, and the launch counter the tests read
 const DpDev *comm_dp_dev(const th_comm *c);
 int comm_dp_sharing(const th_comm *c);
-int comm_dp_sharing_limit();          // how many ranks on one device the in-launch exchange is offered to (comm.hip: 2, measured)
+bool comm_dp_shared_fits(const th_comm *c, int grid, int per_cu);     // ranks sharing a device: may `grid` waiting workgroups per rank (per_cu to a CU) be launched? (comm.hip)
 void comm_dp_count_launch(th_comm *c);
 
 }  // namespace th

@@ -830,18 +830,13 @@ extern "C" int th_mlp_tail_dp_supported(const th_comm *comm, th_ctx *ctx, int ba
     if (!dp || !ctx || dp->n_ranks < 2 || !tail_dp_shapes(batch, in_features, hidden, classes)) return 0;
     const int grid = tail_dp_grid(in_features, hidden);
     if (grid > DP_MAX_SLOTS) return 0;
-    const int sharing = comm_dp_sharing(comm);
-    if (sharing > comm_dp_sharing_limit()) return 0;
-    if (sharing > 1) {
-        // Ranks on ONE device (a test box): a workgroup that waits for a peer's slice holds its place, so the workgroups of all the
-        // ranks but one must leave a place free -- the rank that is furthest behind then always gets its next workgroup dispatched, its
-        // workgroups never wait for anybody who is not already resident, and the wait graph has no cycle.
+    if (comm_dp_sharing(comm) > 1) {       // ranks on ONE device (a test box): comm_dp_shared_fits (comm.hip) has the two conditions and why
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tail_dp_kernel(batch, hidden, dp->n_ranks), batch > 64 ? 512 : 256, 0) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
-        if ((long)(sharing - 1) * grid >= (long)per_cu * kNumCU) return 0;
+        if (!comm_dp_shared_fits(comm, grid, per_cu)) return 0;
     }
     return 1;
 }

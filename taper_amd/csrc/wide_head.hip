@@ -650,16 +650,14 @@ extern "C" int th_wide_head_grads_dp_supported(const th_comm *comm, th_ctx *ctx,
     if (!dp || !ctx || dp->n_ranks < 2 || batch <= 0 || in_features <= 0 || classes <= 0 || classes > 16 || WH_TX != 2) return 0;
     const int grid = ceil_div(in_features, 16 * WH_TX) + 1 + ceil_div(conv_c, 16);
     if (grid > DP_MAX_SLOTS) return 0;
-    const int sharing = comm_dp_sharing(comm);
-    if (sharing > comm_dp_sharing_limit()) return 0;
-    if (sharing > 1) {     // ranks on ONE device: the waiting workgroups of all the ranks but one must leave a place free (th_mlp_tail_dp_supported)
+    if (comm_dp_sharing(comm) > 1) {       // ranks on ONE device: comm_dp_shared_fits (comm.hip)
         int per_cu = 0;
         const void *fn = dp->n_ranks <= 2 ? (const void *)wide_grads_kernel<2> : dp->n_ranks <= 4 ? (const void *)wide_grads_kernel<4> : (const void *)wide_grads_kernel<8>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WH_NW, 0) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
-        if ((long)(sharing - 1) * grid >= (long)per_cu * kNumCU) return 0;
+        if (!comm_dp_shared_fits(comm, grid, per_cu)) return 0;
     }
     return 1;
 }

@@ -139,10 +139,13 @@ def test_p2p_two_ranks_two_shot_exchange(tmp_path, monkeypatch):
 def test_p2p_four_ranks_two_shot_exchange_inside_the_gradient_launch(tmp_path, monkeypatch):
     """FOUR processes on GPU 0 training through the in-launch exchange in its two-shot form (what four ranks and more take by default): the
     784-64-10 model's tail launch is 108 workgroups of four waves at 64 rows per rank, so three ranks' worth of waiting workgroups leave
-    places free on one device.  More than two ranks per device are not offered the in-launch form by default (three starved one another,
-    profiles/r06_dp_three_ranks_one_device.txt); this PROTOCOL test raises the bound -- four ranks finished 48 of 48 runs in r06.
-    Replicas bit-identical; weights and losses equal to one process on the 256-row batches and to the oracle's loop."""
-    monkeypatch.setenv("TAPER_DP_SHARED_RANKS", "4")
+    places free on one device.  The default rule for ranks that share a device also keeps a CU free in every shader engine, counting each
+    waiting workgroup as a whole CU (comm_dp_shared_fits, csrc/comm.hip: three ranks of 128 rows starved one another without it,
+    profiles/r06_dp_three_ranks_one_device.txt), which refuses this configuration; its four-wave waiting workgroups do share CUs with the
+    first launch's (placement trace: 8 - 13 of 16 tiles land beside a waiting workgroup), so this PROTOCOL test asks for the places rule
+    alone -- 48 of 48 runs in r06.  Replicas bit-identical; weights and losses equal to one process on the 256-row batches and to the
+    oracle's loop."""
+    monkeypatch.setenv("TAPER_DP_SHARED_RULE", "places")
     ranks = _run_ranks(tmp_path, 4, "p2p", "graph", steps=6, global_batch=256, same_device=True, model="mlp_64")
     _check(ranks, 4, 6, 256, model="mlp_64")
     _check_against_oracle(ranks, 4, 6, 256, model="mlp_64")
@@ -164,10 +167,11 @@ def test_p2p_exchange_alone_many_rounds(tmp_path, world, monkeypatch):
 @pytest.mark.parametrize("world,model", [(4, "mlp_baseline"), (8, "mlp_baseline"), (3, "mlp_64"), (3, "cnn_simple")])
 def test_p2p_many_ranks_on_one_gpu_fall_back_to_the_three_launch_step(tmp_path, world, model):
     """a workgroup that waits for a peer's slice holds its place on the device, and the late rank still has to get the launches in front
-    of its exchange launch dispatched: more than two ranks on ONE device are not offered the in-launch exchange (three ranks of the 784-64-10
-    model, whose waiting workgroups all fit, starved the late rank's first launch in 10 of 20 runs: profiles/r06_dp_three_ranks_one_device.txt),
-    so th_mlp_tail_dp_supported / th_wide_head_grads_dp_supported say no and the Trainer takes the three-launch step (on a node with a GPU
-    per rank they say yes: every grid is resident on its own device)"""
+    of its exchange launch dispatched -- whole-CU workgroups, dealt to the shader engines in rotation: the waiting workgroups of the other
+    ranks must fit the device's places AND leave a CU free in every engine (comm_dp_shared_fits, csrc/comm.hip).  Four or eight ranks of
+    the 784-128-10 model fail the first condition; three ranks of the 784-64-10 model or of the simple CNN the second (2 x ceil(108 / 32)
+    = 8 > 7: they starved the late rank's first launch in 10 of 20 runs, profiles/r06_dp_three_ranks_one_device.txt) -- the Trainer takes
+    the three-launch step (on a node with a GPU per rank every grid is resident on its own device and the answer is always yes)"""
     steps, gb = (4, 64 * world) if model == "mlp_baseline" else (3, 128 * world)
     ranks = _run_ranks(tmp_path, world, "p2p", "graph", steps=steps, global_batch=gb, same_device=True, model=model)
     _check(ranks, world, steps, gb, model=model)
