@@ -1,6 +1,7 @@
 # W processes on GPU 0 train MODEL data-parallel through the in-launch exchange, TRIALS times; prints how many ranks finished each trial and,
 # for one that timed out, where the first wait ran out (and, with TAPER_DP_POSTMORTEM=1, what the receive regions held).  DESIGN 6e /
-# profiles/r06_dp_three_ranks_one_device.txt: mlp_64 at W = 3 needs TAPER_DP_SHARED_RANKS=3 to take the in-launch form at all.
+# profiles/r06_dp_three_ranks_one_device.txt: mlp_64 at W = 3 needs TAPER_DP_SHARED_RULE=places to take the in-launch form at all; with the
+# event-ring build (experiments/dp_event_ring.patch) a time-out also prints the `[dp ring ...]` lines tools/dp_placement.py reads.
 # usage: gpurun -- bash tools/dp_shared_device_probe.sh MODEL W GLOBAL_BATCH TRIALS [ENV=VAL ...]     (TMO=ms: the wait bound, default 5000)
 cd $GRAFT_REPO_ROOT
 MODEL=$1; W=$2; GB=$3; TRIALS=$4; shift 4
