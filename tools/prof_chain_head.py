@@ -18,7 +18,8 @@ class ChainHead(C.Structure):
 
 
 SIMPLE = [(1, 32, 1), (32, 64, 1)]
-n, K = 256, 3136
+import os
+n, K = int(os.environ.get("CHAIN_N", "256")), 3136
 ctx = hip.Ctx(0)
 lib.th_debug_chain_prof.argtypes = [C.c_void_p, C.c_void_p]
 lib.th_debug_chain_prof.restype = C.c_int
