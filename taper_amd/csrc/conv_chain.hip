@@ -1829,7 +1829,7 @@ int th_conv_chain_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *stages
             if (chain_loop(n)) {
                 TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<false, 1, true>), lds);
                 hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1, true>), dim3(kNumCU), dim3(CH_NT), lds, ctx->stream, a);
-            } else if (lean_env >= 0 ? lean_env != 0 : n >= 2 * kNumCU) {      // two images per CU and more: two workgroups to a CU (as th_conv_chain_head_fwd)
+            } else if (lean_env >= 0 ? lean_env != 0 : n > kNumCU) {      // more than one image per CU: two workgroups to a CU (as th_conv_chain_head_fwd)
                 TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<false, 1, false, true>), lds);
                 hipLaunchKernelGGL((conv_chain_simple_kernel<false, 1, false, true>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);
             } else {
@@ -1936,9 +1936,10 @@ int th_conv_chain_head_fwd(th_ctx *ctx, const float *d_x, const th_conv_stage *s
         TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<true, NC_, LOOP_>), lds);     \
         hipLaunchKernelGGL((conv_chain_simple_kernel<true, NC_, LOOP_>), dim3(GRID_), dim3(CH_NT), lds, ctx->stream, a);                          \
     } while (0)
-        // two images per CU and more: the 128-register instance, two workgroups to a CU (TAPER_CHAIN_LEAN = 0 | 1 forces it off / on: A/B probe)
+        // more than one image per CU: the 128-register instance, two workgroups to a CU (TAPER_CHAIN_LEAN = 0 | 1 forces it off / on: A/B probe).
+        // From 257 images on, not 512: the one-to-a-CU instance runs a second round for the 257th image (264 images: 48.7 against 43.3 us)
         static const int lean_env = [] { const char *e = getenv("TAPER_CHAIN_LEAN"); return e ? atoi(e) : -1; }();
-        const bool lean = lean_env >= 0 ? lean_env != 0 : n >= 2 * kNumCU;
+        const bool lean = lean_env >= 0 ? lean_env != 0 : n > kNumCU;
         if (head->classes <= 10 && lean) {
             TH_SET_MAX_LDS(ctx, (conv_chain_simple_kernel<true, 10, false, true>), lds);
             hipLaunchKernelGGL((conv_chain_simple_kernel<true, 10, false, true>), dim3(n), dim3(CH_NT), lds, ctx->stream, a);

@@ -391,9 +391,9 @@ def test_walking_chain_is_bit_identical_per_image(ctx, name, n):
             np.testing.assert_array_equal(got_cnt[lo:hi], ctx.download(cnt1, (hi - lo, c_last)))
 
 
-@pytest.mark.parametrize("n", [512, 600, 1024])
+@pytest.mark.parametrize("n", [257, 320, 512, 600, 1024])
 def test_two_workgroups_per_cu_instance_is_bit_identical_per_image(ctx, n):
-    """from 512 images the simple chain runs its 128-register instance, two workgroups to a CU (conv_chain_simple_kernel<.., LEAN>: half-pass k
+    """from 257 images (more than one per CU) the simple chain runs its 128-register instance, two workgroups to a CU (conv_chain_simple_kernel<.., LEAN>: half-pass k
     loop, the same k order): image i of the batch gives the bits it gives in batches of <= 200 images (the one-per-CU instance, held to the
     oracle above)"""
     params = _params(SIMPLE, 33)
