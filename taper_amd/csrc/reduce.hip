@@ -111,8 +111,51 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g
     }
 }
 
+// Narrow matrices (cols <= 16: the [batch][classes] gradient of a classifier's logits -> its bias gradient): the kernel above would use
+// `cols` of every wave's 64 lanes.  Here a workgroup's 256 threads are 16 row groups x 16 column slots over a contiguous run of rows
+// (consecutive lanes = consecutive addresses within a row, consecutive row groups = consecutive rows), 8 loads in flight per thread, then
+// the 16 row groups of a column are added in order; grid.x row slabs, a second launch of colsum_kernel adds the slabs.
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float *__restrict__ g, float *__restrict__ part, int rows, int cols, int rows_per_slab) {
+    __shared__ float sh[16][17];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int r_beg = blockIdx.x * rows_per_slab, r_end = min(rows, r_beg + rows_per_slab);
+    constexpr int U = 8;
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = 0.f;
+    if (c < cols) {
+        int r = r_beg + rg;
+        for (; r + 16 * (U - 1) < r_end; r += 16 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = g[(long)(r + 16 * u) * cols + c];
+#pragma unroll
+            for (int u = 0; u < U; ++u) s[u] += v[u];
+        }
+        for (; r < r_end; r += 16) s[0] += g[(long)r * cols + c];
+    }
+    sh[rg][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        float tot = sh[0][c];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tot += sh[i][c];
+        part[(long)blockIdx.x * cols + c] = tot;
+    }
+}
+
 template <bool ACCUM, bool NEGATE>
 static int colsum_launch(th_ctx *ctx, const float *g, float *out, int rows, int cols) {
+    if (cols <= 16 && rows >= 2048) {
+        const int slabs = std::min(256, ceil_div(rows, 512)), rps = ceil_div(rows, slabs), ns = ceil_div(rows, rps);
+        void *part = nullptr;
+        if (th_malloc(ctx, (size_t)ns * cols * sizeof(float), &part)) return 1;
+        hipLaunchKernelGGL(colsum_narrow_kernel, dim3(ns), dim3(256), 0, ctx->stream, g, (float *)part, rows, cols, rps);
+        TH_LAUNCH_CHECK();
+        hipLaunchKernelGGL((colsum_kernel<ACCUM, NEGATE>), dim3(1), dim3(256), 0, ctx->stream, (const float *)part, out, ns, cols, ns);
+        TH_LAUNCH_CHECK();
+        return th_free(ctx, part);
+    }
     const int gx = ceil_div(cols, 64);
     int slabs = 1;
     if (rows >= 256 && gx < 128) {   // too few column blocks to fill the chip: split the rows (>= 32 per slab)
